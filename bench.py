@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric: fp64 CSR SpMV GFLOP/s + achieved HBM GB/s
+on the 3-D Poisson matrix (examples/benchmark.cpp:353-477), 512^3 grid.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one product y = A*x through vex::SpMat's path (libvexhip.so).
+The matrix is built directly in HBM; inputs are resident before
+the timed region.  N > 1: the SAME 512^3 problem row-partitioned over the ranks
+(strong scaling), ghost planes exchanged over RCCL (vexcl_amd/distributed.py).
+
+Algorithmic work per product (independent of the internal
+storage format):  bytes = nnz*12 + (N+1)*4 + N*8 + N*8,  flops = 2*nnz.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def algorithmic_bytes(n_rows, nnz):
+    return nnz * 12 + (n_rows + 1) * 4 + n_rows * 8 + n_rows * 8
+
+
+def cpu_baseline(grid, seconds):
+    """The reference's CPU-device path restated (oracle/vex_oracle.c,
+    vxo_spmv_csr_f64_i32_omp: 8 x threads contiguous row chunks), timed on the
+    host cores of this box on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    ptr, col, val = oracle.poisson3d(grid)
+    N, nnz = grid ** 3, len(col)
+    x = np.full(N, 1e-2)
+    y = np.zeros(N)
+    oracle.spmv_csr(ptr, col, val, x, y, omp=True)          # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.spmv_csr(ptr, col, val, x, y, omp=True)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or reps >= 1000:
+            break
+    per = dt / reps
+    return {"value": round(2.0 * nnz / per / 1e9, 3), "unit": "GFLOP/s", "cores": oracle.num_threads(),
+            "kind": "port", "hbm_equiv_gbps": round(algorithmic_bytes(N, nnz) / per / 1e9, 2),
+            "sample": "%d products of the %d^3 Poisson matrix (N=%d, nnz=%d), OpenMP chunked csr_spmv restatement"
+                      % (reps, grid, N, nnz)}
+
+
+def read_traffic():
+    """HBM bytes per launch from the committed PMC pass (profiles/*pmc*.json), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+        try:
+            d = json.load(open(f))
+            if "hbm_bytes_per_launch" in d:
+                best = d
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge (512 = BASELINE config)")
+    ap.add_argument("--format", default="auto", choices=["auto", "hell", "csr"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-grid", type=int, default=256)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vexcl_amd import lib, ops
+    from vexcl_amd.distributed import DistSpMat, partition
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    L = lib()
+    n = args.grid
+    N = n ** 3
+    nnz_total = L.poisson3d_nnz(n)
+    part = partition(N, world)
+    r0, r1 = part[rank], part[rank + 1]
+
+    # ---- inputs resident in HBM before the timed region
+    ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
+    x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev), 42 + rank)
+    y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
+    if world == 1:
+        A = ops.SpMat(ptr, col, val, fmt=args.format)
+        fmt = A.fmt
+        if fmt == "hell":
+            del ptr, col, val                    # the product only needs the ELL arrays
+            A.ptr = A.col = A.val = None
+        step = lambda: A.apply(x, y, 1.0, False)
+    else:
+        A = DistSpMat(ptr, col, val, N, N, local_fmt=args.format)
+        fmt = A.loc.fmt
+        step = lambda: A.apply(x, y, 1.0, False)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+
+    # HIP events on the stream the kernels are launched on (torch's current stream)
+    import ctypes
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    L.event_create(local_rank, 1, ctypes.byref(e0))
+    L.event_create(local_rank, 1, ctypes.byref(e1))
+
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    L.event_record(local_rank, e0, stream)
+    for _ in range(args.steps):
+        step()
+    L.event_record(local_rank, e1, stream)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    ms = ctypes.c_float()
+    L.event_elapsed_ms(local_rank, e0, e1, ctypes.byref(ms))
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    per_step = elapsed / args.steps
+    kern_s = ms.value / 1e3 / args.steps         # average launch duration of the product on this rank
+
+    if rank == 0:
+        nnz_rank = L.poisson3d_strip_nnz(n, r0, r1)
+        alg_total = algorithmic_bytes(N, nnz_total)
+        alg_rank = algorithmic_bytes(r1 - r0, nnz_rank)
+        gflops = 2.0 * nnz_total / per_step / 1e9
+        gbps = alg_total / per_step / 1e9
+        traffic = read_traffic() if (world == 1 and n == 512) else None
+        out = {
+            "metric": "fp64 CSR SpMV GFLOP/s, 3D Poisson %d^3 (y = A*x, vex::SpMat path)" % n,
+            "value": round(gflops, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(per_step * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "hbm_gbps": round(gbps, 1),
+            "hbm_frac_of_peak": round(gbps / (HBM_PEAK_GBPS * world), 4),
+            "config": {"workload": "configs[%d]: 7-point 3D Poisson %d^3, N=%d rows, nnz=%d, fp64 values, int32 indices"
+                                   % (2 if world == 1 else 3, n, N, nnz_total),
+                       "format": fmt, "rows_per_gpu": r1 - r0,
+                       "parallelism": "row-partitioned x%d" % world},
+            "roofline": {"bound": "hbm",
+                         "achieved": round(alg_rank / kern_s / 1e9, 1),
+                         "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s",
+                         "frac": round(alg_rank / kern_s / 1e9 / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                         "kernel": "hell_kernel" if fmt == "hell" else "csr_stream_kernel",
+                         "algorithmic_bytes_per_launch": alg_rank,
+                         "avg_launch_ms": round(kern_s * 1e3, 5)},
+        }
+        if world > 1:
+            out["config"]["exchange_bytes_per_rank"] = A.exchange_bytes()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

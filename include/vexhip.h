@@ -1,0 +1,194 @@
+/*
+ * vexhip.h -- C ABI of libvexhip.so: the MI355X (gfx950) launch layer under the
+ * vex:: header API (vexcl/ *.hpp) and the Python harness (vexcl_amd/).
+ *
+ * The reference (ddemidov/vexcl) has no FFI; its seam is the compile-time
+ * `vex::backend` concept (vexcl/backend.hpp:40-96).  Every entry point below
+ * names the reference interface it stands in for.  Conventions:
+ *   - every function returns 0 on success, non-zero on failure; the failure
+ *     text (file:line + HIP error string, like backend/cuda/error.hpp:119-145)
+ *     is available from vexhip_last_error() on the calling thread;
+ *   - plain pointers and sizes only; `stream` is a hipStream_t passed as
+ *     void* (NULL = the device's null stream); `dev` is a HIP device ordinal;
+ *   - all device pointers must belong to `dev`; calls are asynchronous on
+ *     `stream` unless stated otherwise (the reference's assignments are
+ *     enqueue-only too, operations.hpp:1886-1894).
+ */
+#ifndef VEXHIP_H
+#define VEXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VEXHIP_ABI_VERSION 1
+
+/* ---- errors (backend/cuda/error.hpp:119-156, util.hpp:67-77) ------------ */
+const char *vexhip_last_error(void);
+int vexhip_abi_version(void);
+
+/* ---- devices (backend/cuda/context.hpp:96-203,383-413; devlist.hpp) ----- */
+typedef struct vexhip_device_props {
+    char     name[256];
+    char     arch[64];            /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    int32_t  compute_units;       /* 256 on MI355X */
+    int32_t  wavefront_size;      /* 64 */
+    int32_t  max_threads_per_block;
+    int32_t  lds_bytes_per_block; /* max shared memory per block */
+    int32_t  clock_khz;
+    int32_t  l2_bytes;
+    uint64_t global_mem_bytes;
+    int32_t  pci_bus_id;
+    int32_t  reserved;
+} vexhip_device_props;
+
+int vexhip_device_count(int *count);
+int vexhip_device_get_props(int dev, vexhip_device_props *props);
+int vexhip_device_sync(int dev);
+int vexhip_mem_info(int dev, uint64_t *free_bytes, uint64_t *total_bytes);
+
+/* ---- command queues = streams (backend/cuda/context.hpp:205-260) -------- */
+int vexhip_stream_create(int dev, void **stream);
+int vexhip_stream_destroy(int dev, void *stream);
+int vexhip_stream_sync(int dev, void *stream);                 /* command_queue::finish() */
+
+/* ---- events (backend/cuda/event.hpp:51-124; enqueue_marker/barrier) ----- */
+int vexhip_event_create(int dev, int timing, void **event);
+int vexhip_event_destroy(int dev, void *event);
+int vexhip_event_record(int dev, void *event, void *stream);   /* enqueue_marker */
+int vexhip_event_sync(int dev, void *event);                   /* event::wait()  */
+int vexhip_stream_wait_event(int dev, void *stream, void *event); /* enqueue_barrier(q, wait_list) */
+int vexhip_event_elapsed_ms(int dev, void *start, void *stop, float *ms);
+
+/* ---- device_vector<T> storage (backend/cuda/device_vector.hpp:66-214) --- */
+int vexhip_malloc(int dev, size_t bytes, void **ptr);
+int vexhip_free(int dev, void *ptr);
+int vexhip_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes, void *stream, int blocking); /* device_vector::write */
+int vexhip_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes, void *stream, int blocking); /* device_vector::read  */
+int vexhip_memcpy_d2d(int dev, void *dst, const void *src, size_t bytes, void *stream);
+int vexhip_memcpy_peer(int dst_dev, void *dst, int src_dev, const void *src, size_t bytes, void *stream);
+int vexhip_memset(int dev, void *ptr, int byte, size_t bytes, void *stream);
+int vexhip_host_alloc(size_t bytes, void **ptr);               /* pinned staging (device_vector::map) */
+int vexhip_host_free(void *ptr);
+
+/* ---- JIT: build_sources + kernel (backend/cuda/compiler.hpp:53-116,
+ *      backend/cuda/kernel.hpp:45-244, cache dir backend/common.hpp:215-285) */
+int vexhip_module_compile(int dev, const char *source, const char *options, void **module);
+int vexhip_module_unload(int dev, void *module);
+int vexhip_module_get_function(int dev, void *module, const char *name, void **function);
+int vexhip_function_max_threads(int dev, void *function, int *max_threads_per_block, int *static_lds_bytes);
+int vexhip_launch(int dev, void *function,
+        unsigned grid_x, unsigned grid_y, unsigned grid_z,
+        unsigned block_x, unsigned block_y, unsigned block_z,
+        unsigned dynamic_lds_bytes, void *stream, void **args);
+/* number of JIT compilations that missed both the in-process and the on-disk
+ * cache since load (the reference's VEXCL_CACHE_KERNELS behaviour is testable
+ * through it) */
+int vexhip_jit_stats(uint64_t *compiled, uint64_t *disk_hits);
+
+/* ---- fixed primitive: CSR SpMV  (spmat/csr.inl:153-185 `csr_spmv`) ------
+ * y[i] (= | +=) alpha * sum_{j in [ptr[i],ptr[i+1])} val[j]*x[col[j]],
+ * summation in CSR order, scale applied after the sum.  append!=0 => "+=".
+ * Hand-written LDS-staged kernel: one workgroup streams the (col,val) range of
+ * 256 consecutive rows with 16-byte loads, products are staged in LDS and each
+ * lane folds its own row in CSR order.                                        */
+int vexhip_spmv_csr_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
+        const int32_t *ptr, const int32_t *col, const double *val, const double *x, double *y);
+int vexhip_spmv_csr_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
+        const int32_t *ptr, const int32_t *col, const float *val, const float *x, float *y);
+int vexhip_spmv_csr_f64_i64(int dev, void *stream, int64_t n, double alpha, int append,
+        const int64_t *ptr, const int64_t *col, const double *val, const double *x, double *y);
+/* tuning variant selector for the CSR kernel (bench / sweep tool only):
+ * 0 = default. */
+int vexhip_spmv_csr_set_variant(int variant);
+int vexhip_spmv_hell_set_variant(int variant);
+
+/* ---- fixed primitive: hybrid ELL SpMV (spmat/hybrid_ell.inl:238-300) ----
+ * ELL part column-major with pitch (multiple of 16), padding column -1; CSR
+ * tail may be absent (csr_ptr == NULL), as the reference passes 0 for an empty
+ * part (hybrid_ell.inl:283-296).  ell_width == 0 => CSR tail only.            */
+int vexhip_spmv_hell_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
+        int64_t ell_width, int64_t ell_pitch, const int32_t *ell_col, const double *ell_val,
+        const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y);
+int vexhip_spmv_hell_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
+        int64_t ell_width, int64_t ell_pitch, const int32_t *ell_col, const float *ell_val,
+        const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y);
+
+/* CSR -> hybrid ELL conversion on the device (sparse/ell.hpp:400-508,
+ * `convert_csr2ell` :348-397; width rule hybrid_ell.inl:66-114).
+ * Step 1 (blocking): row-width histogram -> ELL width by the reference's
+ * "3 x rows-wider-than-w < n" rule, and the nnz of the CSR tail.
+ * Step 2: fill caller-allocated ell_col/ell_val (pitch*width each, pitch =
+ * alignup(n,16)) and csr_ptr (n+1) / csr_col / csr_val (tail_nnz).            */
+int vexhip_hell_analyze_i32(int dev, void *stream, int64_t n, const int32_t *ptr,
+        int64_t *ell_width, int64_t *tail_nnz);
+int vexhip_hell_fill_f64_i32(int dev, void *stream, int64_t n,
+        const int32_t *ptr, const int32_t *col, const double *val,
+        int64_t ell_width, int64_t ell_pitch, int32_t *ell_col, double *ell_val,
+        int32_t *csr_ptr, int32_t *csr_col, double *csr_val);
+int vexhip_hell_fill_f32_i32(int dev, void *stream, int64_t n,
+        const int32_t *ptr, const int32_t *col, const float *val,
+        int64_t ell_width, int64_t ell_pitch, int32_t *ell_col, float *ell_val,
+        int32_t *csr_ptr, int32_t *csr_col, float *csr_val);
+
+/* ---- gather for the ghost exchange (spmat.hpp:129-133 `permutation(cols)(x)`,
+ *      sparse/distributed.hpp:352-398 `vexcl_sparse_gather`) --------------- */
+int vexhip_gather_f64_i32(int dev, void *stream, int64_t n, const int32_t *idx, const double *src, double *dst);
+int vexhip_gather_f32_i32(int dev, void *stream, int64_t n, const int32_t *idx, const float *src, float *dst);
+
+/* ---- Reductor (reductor.hpp:302-439) ------------------------------------
+ * Two-stage, both stages on the device; result lands in *out_dev (device
+ * memory, one element of the value type; MIN_MAX writes two).  `tmp` must hold
+ * vexhip_reduce_tmp_bytes() bytes.  ops: */
+enum { VEXHIP_SUM = 0, VEXHIP_SUM_KAHAN = 1, VEXHIP_MIN = 2, VEXHIP_MAX = 3, VEXHIP_MIN_MAX = 4 };
+/* dtypes shared by reduce / scan / sort / fill: */
+enum { VEXHIP_F64 = 0, VEXHIP_F32 = 1, VEXHIP_I32 = 2, VEXHIP_U32 = 3, VEXHIP_I64 = 4, VEXHIP_U64 = 5 };
+size_t vexhip_reduce_tmp_bytes(void);
+int vexhip_reduce(int dev, void *stream, int op, int dtype, const void *in, int64_t n, void *out_dev, void *tmp);
+/* sum(a*b), the reduce section of examples/benchmark.cpp:224-246 */
+int vexhip_reduce_dot(int dev, void *stream, int dtype, const void *a, const void *b, int64_t n, void *out_dev, void *tmp);
+/* stage 2 alone: fold `nparts` partials produced by a JIT-generated stage-1
+ * kernel (reductor.hpp:412-436 does this fold on the host).                   */
+int vexhip_reduce_finish(int dev, void *stream, int op, int dtype, const void *partials, int64_t nparts, void *out_dev);
+/* number of partials (= workgroups) a JIT stage-1 kernel should produce       */
+int vexhip_reduce_num_groups(int dev, int *groups, int *block);
+
+/* ---- scan (scan.hpp:66-414: inclusive_scan / exclusive_scan with vex::plus)
+ * exclusive != 0: out[i] = init + in[0] + ... + in[i-1].  In-place allowed.
+ * `init` points to ONE host element of the dtype (ignored for inclusive).     */
+size_t vexhip_scan_tmp_bytes(int dtype, int64_t n);
+int vexhip_scan(int dev, void *stream, int dtype, int exclusive, const void *init_host,
+        const void *in, void *out, int64_t n, void *tmp);
+
+/* ---- sort (sort.hpp:2158-2182: vex::sort / vex::sort_by_key, stable) -----
+ * Stable LSD radix sort, ascending (descending != 0: vex::greater<T>).
+ * keys are sorted in place; keys_tmp (n keys) and, for pairs, vals_tmp are
+ * ping-pong buffers; tmp holds vexhip_sort_tmp_bytes().  value_bytes in {0,4,8}. */
+size_t vexhip_sort_tmp_bytes(int key_dtype, int64_t n);
+int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
+        void *keys, void *keys_tmp, int value_bytes, void *vals, void *vals_tmp,
+        int64_t n, void *tmp);
+
+/* ---- benchmark input generators (examples/benchmark.cpp:364-415; SURVEY
+ *      section 8(d): 512^3 is built on the device, never uploaded) ---------- */
+int64_t vexhip_poisson3d_nnz(int64_t n);
+int vexhip_poisson3d_csr_f64_i32(int dev, void *stream, int64_t n, int32_t *ptr, int32_t *col, double *val);
+/* rows [row_begin,row_end) of the same matrix with GLOBAL column ids and a
+ * strip-local ptr (ptr[0] = 0): the per-rank strip of the 8-GPU run.          */
+int vexhip_poisson3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end,
+        int32_t *ptr, int32_t *col, double *val);
+int64_t vexhip_poisson3d_strip_nnz(int64_t n, int64_t row_begin, int64_t row_end);
+/* counter-hash pseudo-random fill (same hash on host: tests restate it):
+ * u32: full range; f64/f32: U[0,1).                                           */
+int vexhip_fill_hash(int dev, void *stream, int dtype, uint64_t seed, void *out, int64_t n);
+int vexhip_fill_value(int dev, void *stream, int dtype, const void *value_host, void *out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEXHIP_H */

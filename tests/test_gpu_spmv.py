@@ -1,0 +1,220 @@
+"""GPU parity tests for the SpMV path, through the C ABI (libvexhip.so),
+against the CPU oracle on the cases the reference tests (tests/spmv.cpp:10-146,
+tests/sparse_matrices.cpp:66-151) and on Poisson matrices
+(examples/benchmark.cpp:364-415).
+
+Tolerance: |y - y_ref| <= 1e-10 * sum_j |a_ij x_j| -- the reference's own
+BOOST_CHECK_CLOSE(.., 1e-8 percent).  The kernels fold each row in CSR order
+with unfused multiply-add, so most checks are in fact bit-exact and say so.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    from vexcl_amd import ops
+    assert torch.cuda.is_available()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.torch, ns.ops, ns.dev = torch, ops, torch.device("cuda:0")
+    ns.up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ns.dev)
+    return ns
+
+
+def _check(got, want, bound, exact=False):
+    if exact:
+        assert np.array_equal(got, want)
+    err = np.abs(got - want)
+    assert np.all(err <= TOL * np.maximum(bound, 1e-300)), float(np.max(err / np.maximum(bound, 1e-300)))
+
+
+CASES = {
+    "square": lambda o: o.random_matrix(101, 1024, 1024, 16) + (1024,),          # spmv.cpp:10-59
+    "nonsquare": lambda o: o.random_matrix(102, 1024, 2048, 16) + (2048,),       # spmv.cpp:61-87
+    "empty_rows": lambda o: o.random_matrix(103, 1024, 1024, 16, 768) + (1024,),  # spmv.cpp:116-146
+    "odd_size": lambda o: o.random_matrix(104, 1000 + 37, 911, 16) + (911,),
+    "wide_rows": lambda o: o.random_matrix(105, 700, 5000, 900) + (5000,),        # rows span several LDS tiles
+    "tiny": lambda o: o.random_matrix(106, 3, 5, 4) + (5,),
+    "poisson32": lambda o: o.poisson3d(32) + (32 ** 3,),                          # spmv.cpp:148-231 grid size
+}
+
+
+@pytest.mark.parametrize("fmt", ["csr", "hell"])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_spmv_set_append_scale(T, oracle, case, fmt):
+    ptr, col, val, m = CASES[case](oracle)
+    n = len(ptr) - 1
+    x = oracle.random_f64(7, m)
+    y0 = oracle.random_f64(8, n)
+    A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), n_cols=m, fmt=fmt)
+    assert (A.rows(), A.cols(), A.nonzeros()) == (n, m, len(col))
+    dx = T.up(x)
+    bound = oracle.spmv_abs_bound(ptr, col, val, x)
+
+    # Y = A * X
+    y = T.up(y0.copy()); A.apply(dx, y, 1.0, False)
+    _check(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x), bound, exact=True)
+    # Y += 42 * (A * X)
+    y = T.up(y0.copy()); A.apply(dx, y, 42.0, True)
+    want = y0.copy(); oracle.spmv_csr(ptr, col, val, x, want, 42.0, True)
+    _check(y.cpu().numpy(), want, 42 * bound + np.abs(y0), exact=True)
+    # Y = A*X; Y -= A * X  -> 0   (spmv.cpp:34-40: |y| < 1e-8)
+    y = A @ dx; A.apply(dx, y, -1.0, True)
+    assert float(y.abs().max()) < 1e-8
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_csr_kernel_variants_agree(T, oracle, built_lib, variant):
+    ptr, col, val = oracle.poisson3d(40)
+    x = oracle.random_f64(5, 40 ** 3)
+    want = oracle.spmv_csr(ptr, col, val, x)
+    built_lib.spmv_csr_set_variant(variant)
+    try:
+        y = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt="csr") @ T.up(x)
+    finally:
+        built_lib.spmv_csr_set_variant(-1)
+    assert np.array_equal(y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+def test_hell_kernel_variants_agree(T, oracle, built_lib, variant):
+    ptr, col, val = oracle.poisson3d(37)          # odd size: ragged last lanes
+    x = oracle.random_f64(5, 37 ** 3)
+    want = oracle.spmv_csr(ptr, col, val, x)
+    A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt="hell")
+    assert A.hell.width == 7 and A.hell.tail_nnz == 0
+    built_lib.spmv_hell_set_variant(variant)
+    try:
+        y = A @ T.up(x)
+    finally:
+        built_lib.spmv_hell_set_variant(-1)
+    assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_hell_conversion_matches_oracle_layout(T, oracle):
+    # sparse/ell.hpp:400-508 device conversion == hybrid_ell.inl:138-198 host fill
+    ptr, col, val = oracle.random_matrix(31, 1024, 1024, 16)
+    h = oracle.hell_build(ptr, col, val)
+    A = T.ops.HybridELL(T.up(ptr), T.up(col), T.up(val))
+    assert (A.width, A.pitch, A.tail_nnz) == (h["width"], h["pitch"], h["tail"])
+    assert np.array_equal(A.ell_col.cpu().numpy(), h["ell_col"])
+    assert np.array_equal(A.ell_val.cpu().numpy(), h["ell_val"])
+    assert np.array_equal(A.csr_ptr.cpu().numpy(), h["csr_ptr"])
+    assert np.array_equal(A.csr_col.cpu().numpy(), h["csr_col"])
+    assert np.array_equal(A.csr_val.cpu().numpy(), h["csr_val"])
+
+
+def test_index_and_value_types(T, oracle):
+    # spmv.cpp:89-114 non-default index types; float matrices
+    ptr, col, val = oracle.random_matrix(41, 1024, 1024, 16)
+    x = oracle.random_f64(42, 1024)
+    want = oracle.spmv_csr(ptr, col, val, x)
+    A = T.ops.SpMat(T.up(ptr.astype(np.int64)), T.up(col.astype(np.int64)), T.up(val))
+    assert A.fmt == "csr"
+    assert np.array_equal((A @ T.up(x)).cpu().numpy(), want)
+    v32, x32 = val.astype(np.float32), x.astype(np.float32)
+    want32 = oracle.spmv_csr(ptr, col, v32, x32)
+    for fmt in ("csr", "hell"):
+        y = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), fmt=fmt) @ T.up(x32)
+        assert np.array_equal(y.cpu().numpy(), want32)
+
+
+def test_unaligned_views_take_the_scalar_path(T, oracle):
+    ptr, col, val = oracle.random_matrix(51, 512, 512, 16)
+    x = oracle.random_f64(52, 512)
+    pad_c = T.up(np.concatenate([[0], col]).astype(np.int32))[1:]
+    pad_v = T.up(np.concatenate([[0.0], val]))[1:]
+    y = T.torch.empty(512, dtype=T.torch.float64, device=T.dev)
+    T.ops.spmv_csr(T.up(ptr), pad_c, pad_v, T.up(x), y)
+    assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
+
+
+@pytest.mark.parametrize("name", ["poisson5", "poisson12", "rect"])
+def test_golden_fixtures(T, oracle, name):
+    ptr, col, val, x, want = (G[name + s] for s in ("_ptr", "_col", "_val", "_x", "_y"))
+    bound = oracle.spmv_abs_bound(ptr, col, val, x)
+    for fmt in ("csr", "hell"):
+        y = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), n_cols=len(x), fmt=fmt) @ T.up(x)
+        _check(y.cpu().numpy(), want, bound)
+
+
+def test_device_poisson_generator_is_the_reference_matrix(T, oracle):
+    for n in (2, 3, 9, 32):
+        ptr, col, val = oracle.poisson3d(n)
+        dp, dc, dv = T.ops.poisson3d(n, T.dev)
+        assert np.array_equal(dp.cpu().numpy(), ptr)
+        assert np.array_equal(dc.cpu().numpy(), col)
+        assert np.array_equal(dv.cpu().numpy(), val)
+    # a strip: global columns, local ptr
+    ptr, col, val = oracle.poisson3d(16)
+    r0, r1 = 1024, 3072
+    dp, dc, dv = T.ops.poisson3d(16, T.dev, rows=(r0, r1))
+    assert np.array_equal(dp.cpu().numpy(), ptr[r0:r1 + 1] - ptr[r0])
+    assert np.array_equal(dc.cpu().numpy(), col[ptr[r0]:ptr[r1]])
+
+
+def test_poisson128_benchmark_size(T, oracle):
+    # examples/benchmark.cpp:358-360: n = 128, N = 2 097 152, nnz = 14 099 408
+    n = 128
+    ptr, col, val = oracle.poisson3d(n)
+    assert len(col) == 14099408
+    x = oracle.random_f64(9, n ** 3)
+    want = oracle.spmv_csr(ptr, col, val, x, omp=True)
+    dp, dc, dv = T.ops.poisson3d(n, T.dev)
+    for fmt in ("csr", "hell"):
+        y = T.ops.SpMat(dp, dc, dv, fmt=fmt) @ T.up(x)
+        assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_poisson512_properties(T):
+    """BASELINE.json's full size (134 217 728 rows, 930 123 728 nnz): no CPU
+    oracle in seconds at this size, so size-independent properties:
+    (1) CSR and HELL kernels agree bit for bit; (2) A*1 = indicator of the
+    boundary (interior rows cancel exactly: 6h - 6h); (3) against an independent
+    fp64 stencil evaluation written with torch slicing; (4) linearity."""
+    torch, ops = T.torch, T.ops
+    n = 512
+    N = n ** 3
+    dp, dc, dv = ops.poisson3d(n, T.dev)
+    assert dc.numel() == 930123728 and int(dp[-1]) == 930123728
+    A_csr = ops.SpMat(dp, dc, dv, fmt="csr")
+    A_ell = ops.SpMat(dp, dc, dv, fmt="hell")
+    assert A_ell.hell.width == 7 and A_ell.hell.tail_nnz == 0
+
+    x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=T.dev), 42)
+    y1 = A_csr @ x
+    y2 = A_ell @ x
+    assert torch.equal(y1, y2)
+
+    ones = torch.ones(N, dtype=torch.float64, device=T.dev)
+    y = A_ell @ ones
+    g = y.view(n, n, n)
+    assert float(g[1:-1, 1:-1, 1:-1].abs().max()) == 0.0
+    assert float(y.sum()) == float(N - (n - 2) ** 3)
+    del ones, y, g
+
+    # independent stencil evaluation
+    h2i = float((n - 1) ** 2)
+    X = x.view(n, n, n)
+    ref = X.clone()
+    c = X[1:-1, 1:-1, 1:-1]
+    nb = (X[:-2, 1:-1, 1:-1] + X[2:, 1:-1, 1:-1] + X[1:-1, :-2, 1:-1] + X[1:-1, 2:, 1:-1]
+          + X[1:-1, 1:-1, :-2] + X[1:-1, 1:-1, 2:])
+    ref[1:-1, 1:-1, 1:-1] = h2i * (6 * c - nb)
+    bound = 12 * h2i          # sum |a_ij x_j| <= 12 h2i for x in [0,1)
+    assert float((y1.view(n, n, n) - ref).abs().max()) <= TOL * bound
+    del ref, nb, c
+
+    # linearity: A(2x) == 2 A x exactly (power-of-two scale)
+    y3 = A_ell @ (x * 2)
+    assert torch.equal(y3, y1 * 2)

@@ -1,0 +1,123 @@
+"""CPU tests: the oracle against the committed golden fixtures and against its
+own alternative formulations (HELL vs CSR, split vs whole)."""
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+
+
+@pytest.mark.parametrize("n", [5, 12])
+def test_poisson_generator_matches_independent_assembly(oracle, n):
+    ptr, col, val = oracle.poisson3d(n)
+    assert np.array_equal(ptr, G["poisson%d_ptr" % n])
+    assert np.array_equal(col, G["poisson%d_col" % n])
+    assert np.array_equal(val, G["poisson%d_val" % n])
+    assert oracle.poisson3d_nnz(n) == len(col)
+    p64, c64, v64 = oracle.poisson3d(n, index_dtype=np.int64)
+    assert np.array_equal(p64, ptr) and np.array_equal(c64, col) and np.array_equal(v64, val)
+
+
+def test_poisson_nnz_formula(oracle):
+    # 512^3 -> 930 123 728; benchmark.cpp 128^3 -> 14 099 408
+    assert oracle.poisson3d_nnz(512) == 930123728
+    assert oracle.poisson3d_nnz(128) == 14099408
+
+
+@pytest.mark.parametrize("name", ["poisson5", "poisson12", "rect"])
+def test_spmv_against_scipy_golden(oracle, name):
+    ptr, col, val, x, want = (G[name + s] for s in ("_ptr", "_col", "_val", "_x", "_y"))
+    got = oracle.spmv_csr(ptr, col, val, x)
+    bound = oracle.spmv_abs_bound(ptr, col, val, x)
+    assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(bound, 1e-300))
+
+
+def test_spmv_alpha_append_semantics(oracle):
+    # spmat.hpp:120-121 / tests/spmv.cpp:34-58
+    ptr, col, val = oracle.random_matrix(1, 1024, 1024, 16)
+    x = oracle.random_f64(2, 1024)
+    y0 = oracle.random_f64(3, 1024)
+    ax = oracle.spmv_csr(ptr, col, val, x)
+    y = y0.copy(); oracle.spmv_csr(ptr, col, val, x, y, alpha=42.0, append=True)
+    assert np.allclose(y, y0 + 42 * ax, rtol=1e-13, atol=0)
+    y = ax.copy(); oracle.spmv_csr(ptr, col, val, x, y, alpha=-1.0, append=True)
+    assert np.all(np.abs(y) <= 1e-8)
+    assert np.array_equal(oracle.spmv_csr(ptr, col, val, x, omp=True), ax)
+
+
+def test_random_matrix_shape(oracle):
+    # tests/random_matrix.hpp: width in [0, nnz_per_row-1], distinct sorted columns
+    ptr, col, val = oracle.random_matrix(5, 1024, 2048, 16, empty_tail=768)
+    w = np.diff(ptr)
+    assert w.max() <= 15 and np.all(w[-768:] == 0) and w[:256].max() > 0
+    for i in range(256):
+        c = col[ptr[i]:ptr[i + 1]]
+        assert np.all(np.diff(c) > 0) and (len(c) == 0 or (c.min() >= 0 and c.max() < 2048))
+    assert val.min() >= 0 and val.max() < 1
+
+
+@pytest.mark.parametrize("seed,n,m,tail", [(11, 1024, 1024, 0), (12, 1024, 2048, 0), (13, 1024, 1024, 768)])
+def test_hell_equals_csr(oracle, seed, n, m, tail):
+    ptr, col, val = oracle.random_matrix(seed, n, m, 16, empty_tail=tail)
+    x = oracle.random_f64(seed + 100, m)
+    h = oracle.hell_build(ptr, col, val)
+    assert h["pitch"] % 16 == 0 and h["pitch"] >= n
+    wide = np.sum(np.diff(ptr) > h["width"])
+    assert 3 * wide < n                                   # hybrid_ell.inl:103-110
+    assert h["tail"] == np.sum(np.maximum(np.diff(ptr) - h["width"], 0))
+    # ELL entries first, CSR tail after => same order as plain CSR => same bits
+    assert np.array_equal(oracle.spmv_hell(h, x), oracle.spmv_csr(ptr, col, val, x))
+
+
+def test_hell_width_poisson(oracle):
+    ptr, col, val = oracle.poisson3d(12)
+    assert oracle.hell_width(ptr) == 7
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3, 8])
+def test_partition(oracle, ndev):
+    # vector.hpp:157-162: boundaries aligned up to 16, clamped to n
+    for n in (0, 5, 1024, 1000, 134217728):
+        p = oracle.partition(n, ndev)
+        assert p[0] == 0 and p[-1] == n and len(p) == ndev + 1
+        assert all(a <= b for a, b in zip(p, p[1:]))
+        assert all(b % 16 == 0 or b == n for b in p[1:-1])
+    assert oracle.partition(134217728, 8) == [16777216 * d for d in range(9)]
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 4])
+def test_split_apply_equals_whole(oracle, ndev):
+    # spmat.hpp:120-185 on the host: local + remote parts with ghost renumbering
+    for ptr, col, val, m in [oracle.random_matrix(21, 1024, 1024, 16) + (1024,),
+                             oracle.random_matrix(22, 1024, 2048, 16) + (2048,),
+                             oracle.poisson3d(10) + (1000,)]:
+        x = oracle.random_f64(23, m)
+        S = oracle.split_rows(ptr, col, val, m, ndev)
+        got = oracle.spmv_split(S, x, alpha=1.5)
+        want = oracle.spmv_csr(ptr, col, val, x, alpha=1.5)
+        bound = 1.5 * oracle.spmv_abs_bound(ptr, col, val, x)
+        assert np.all(np.abs(got - want) <= 1e-13 * np.maximum(bound, 1e-300))
+        for d, D in enumerate(S["devs"]):                 # ghosts are really non-local
+            c0, c1 = D["cols"]
+            assert np.all((D["ghosts"] < c0) | (D["ghosts"] >= c1))
+            assert np.array_equal(S["cols_to_send"][D["cols_to_recv"]], D["ghosts"])
+
+
+def test_reductions(oracle):
+    v = G["sum_x"]
+    assert abs(oracle.sum_kahan(v) - float(G["sum_exact"])) <= 1e-10 * np.abs(v).sum() * 1e-6
+    assert v.min() == G["min_exact"] and v.max() == G["max_exact"]
+
+
+def test_scan_sort_golden(oracle):
+    assert np.array_equal(oracle.inclusive_scan(G["scan_in"]), G["scan_inclusive"])
+    ex = oracle.exclusive_scan(G["scan_in"], 7)
+    assert ex[0] == 7 and np.array_equal(ex[1:], (G["scan_inclusive"][:-1] + np.uint32(7)))
+    k, v = oracle.stable_sort_by_key(G["sort_keys"], G["sort_vals"])
+    assert np.array_equal(k, G["sort_keys_sorted"]) and np.array_equal(v, G["sort_vals_sorted"])
+
+
+def test_elementwise(oracle):
+    b, c, d = (oracle.random_f64(s, 1000) for s in (1, 2, 3))
+    assert np.allclose(oracle.ew_mul_add_sin(b, c, d), b * c + np.sin(d), rtol=1e-15)

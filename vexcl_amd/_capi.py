@@ -1,0 +1,147 @@
+"""ctypes binding of libvexhip.so (include/vexhip.h).
+
+The product path has no fallback: if the HIP library is missing this module
+raises, and every call that returns non-zero raises ``vexcl_amd.Error`` with
+the library's ``file:line`` + HIP error text (the reference reports errors as
+``vex::backend::error``, backend/cuda/error.hpp:119-145).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvexhip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class Error(RuntimeError):
+    """vex::error equivalent."""
+
+
+def build(force=False, jobs=8):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(jobs)]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_vp = ctypes.c_void_p
+c_f64 = ctypes.c_double
+c_f32 = ctypes.c_float
+c_u64 = ctypes.c_uint64
+c_size = ctypes.c_size_t
+
+F64, F32, I32, U32, I64, U64 = range(6)
+SUM, SUM_KAHAN, MIN, MAX, MIN_MAX = range(5)
+
+
+class DeviceProps(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 256), ("arch", ctypes.c_char * 64),
+                ("compute_units", ctypes.c_int32), ("wavefront_size", ctypes.c_int32),
+                ("max_threads_per_block", ctypes.c_int32), ("lds_bytes_per_block", ctypes.c_int32),
+                ("clock_khz", ctypes.c_int32), ("l2_bytes", ctypes.c_int32),
+                ("global_mem_bytes", ctypes.c_uint64), ("pci_bus_id", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); restype None means "int status, checked"
+_PROTOS = {
+    "vexhip_last_error": (ctypes.c_char_p, []),
+    "vexhip_abi_version": (c_int, []),
+    "vexhip_device_count": (None, [ctypes.POINTER(c_int)]),
+    "vexhip_device_get_props": (None, [c_int, ctypes.POINTER(DeviceProps)]),
+    "vexhip_device_sync": (None, [c_int]),
+    "vexhip_mem_info": (None, [c_int, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
+    "vexhip_stream_create": (None, [c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_stream_destroy": (None, [c_int, c_vp]),
+    "vexhip_stream_sync": (None, [c_int, c_vp]),
+    "vexhip_event_create": (None, [c_int, c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_event_destroy": (None, [c_int, c_vp]),
+    "vexhip_event_record": (None, [c_int, c_vp, c_vp]),
+    "vexhip_event_sync": (None, [c_int, c_vp]),
+    "vexhip_stream_wait_event": (None, [c_int, c_vp, c_vp]),
+    "vexhip_event_elapsed_ms": (None, [c_int, c_vp, c_vp, ctypes.POINTER(c_f32)]),
+    "vexhip_malloc": (None, [c_int, c_size, ctypes.POINTER(c_vp)]),
+    "vexhip_free": (None, [c_int, c_vp]),
+    "vexhip_memcpy_h2d": (None, [c_int, c_vp, c_vp, c_size, c_vp, c_int]),
+    "vexhip_memcpy_d2h": (None, [c_int, c_vp, c_vp, c_size, c_vp, c_int]),
+    "vexhip_memcpy_d2d": (None, [c_int, c_vp, c_vp, c_size, c_vp]),
+    "vexhip_memcpy_peer": (None, [c_int, c_vp, c_int, c_vp, c_size, c_vp]),
+    "vexhip_memset": (None, [c_int, c_vp, c_int, c_size, c_vp]),
+    "vexhip_host_alloc": (None, [c_size, ctypes.POINTER(c_vp)]),
+    "vexhip_host_free": (None, [c_vp]),
+    "vexhip_module_compile": (None, [c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "vexhip_module_unload": (None, [c_int, c_vp]),
+    "vexhip_module_get_function": (None, [c_int, c_vp, ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "vexhip_function_max_threads": (None, [c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "vexhip_launch": (None, [c_int, c_vp] + [ctypes.c_uint] * 7 + [c_vp, ctypes.POINTER(c_vp)]),
+    "vexhip_jit_stats": (None, [ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
+    "vexhip_spmv_csr_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vexhip_spmv_csr_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vexhip_spmv_csr_f64_i64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vexhip_spmv_csr_set_variant": (None, [c_int]),
+    "vexhip_spmv_hell_set_variant": (None, [c_int]),
+    "vexhip_spmv_hell_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64, c_i64] + [c_vp] * 7),
+    "vexhip_spmv_hell_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64, c_i64] + [c_vp] * 7),
+    "vexhip_hell_analyze_i32": (None, [c_int, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "vexhip_hell_fill_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64] + [c_vp] * 5),
+    "vexhip_hell_fill_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64] + [c_vp] * 5),
+    "vexhip_gather_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vexhip_gather_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vexhip_reduce_tmp_bytes": (c_size, []),
+    "vexhip_reduce": (None, [c_int, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "vexhip_reduce_dot": (None, [c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "vexhip_reduce_finish": (None, [c_int, c_vp, c_int, c_int, c_vp, c_i64, c_vp]),
+    "vexhip_reduce_num_groups": (None, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "vexhip_scan_tmp_bytes": (c_size, [c_int, c_i64]),
+    "vexhip_scan": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "vexhip_sort_tmp_bytes": (c_size, [c_int, c_i64]),
+    "vexhip_sort": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp]),
+    "vexhip_poisson3d_nnz": (c_i64, [c_i64]),
+    "vexhip_poisson3d_strip_nnz": (c_i64, [c_i64, c_i64, c_i64]),
+    "vexhip_poisson3d_csr_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vexhip_poisson3d_strip_f64_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "vexhip_fill_hash": (None, [c_int, c_vp, c_int, c_u64, c_vp, c_i64]),
+    "vexhip_fill_value": (None, [c_int, c_vp, c_int, c_vp, c_vp, c_i64]),
+}
+
+EXPORTS = tuple(sorted(_PROTOS))
+
+
+class _Lib:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise Error(
+                "libvexhip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C vexcl_amd/csrc`.  There is no CPU fallback." % path)
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(self.cdll, name)        # AttributeError = missing export
+            fn.argtypes = args
+            fn.restype = c_int if res is None else res
+            setattr(self, name[len("vexhip_"):], self._checked(fn) if res is None else fn)
+
+    def _checked(self, fn):
+        last_error = self.cdll.vexhip_last_error
+
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise Error(last_error().decode(errors="replace"))
+        call.__name__ = fn.__name__
+        return call
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib(LIB_PATH)
+    return _lib

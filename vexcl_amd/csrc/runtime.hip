@@ -1,0 +1,419 @@
+// libvexhip.so runtime layer: devices, streams, events, memory, hiprtc JIT and
+// generic kernel launch.  Stands in for the reference's backend concept
+// (backend/cuda/context.hpp, device_vector.hpp, kernel.hpp, compiler.hpp,
+// event.hpp, error.hpp; kernel-binary cache backend/common.hpp:215-285).
+#include "common.hpp"
+
+#include <hip/hiprtc.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <vector>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace vexhip {
+
+std::string &last_error() {
+    static thread_local std::string s;
+    return s;
+}
+
+int fail(const char *file, int line, const std::string &what) {
+    std::ostringstream o;
+    o << file << ":" << line << "\n\t" << what;
+    last_error() = o.str();
+    return 1;
+}
+
+const device_info &info(int dev) {
+    static std::mutex mx;
+    static std::vector<device_info> cache;
+    std::lock_guard<std::mutex> lock(mx);
+    if (cache.size() <= (size_t)dev) cache.resize(dev + 1);
+    if (!cache[dev].ok) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
+            cache[dev].cus = p.multiProcessorCount;
+            cache[dev].ok = true;
+        } else {
+            cache[dev].cus = 256;
+        }
+    }
+    return cache[dev];
+}
+
+} // namespace vexhip
+
+using namespace vexhip;
+
+// ---------------------------------------------------------------- JIT
+namespace {
+
+std::atomic<uint64_t> g_compiled{0}, g_disk_hits{0};
+
+// 128-bit FNV-1a style digest, hex-printed: names the cache entry the way the
+// reference names it by SHA-1 (backend/common.hpp:235-285).
+std::string digest(const std::string &s) {
+    uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+    for (unsigned char c : s) {
+        h1 = (h1 ^ c) * 0x100000001b3ull;
+        h2 = (h2 ^ (c + 0x9e)) * 0x100000001b3ull;
+        h2 ^= h2 >> 29;
+    }
+    char buf[40];
+    std::snprintf(buf, sizeof(buf), "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    return buf;
+}
+
+std::string cache_root() {
+    if (const char *e = std::getenv("VEXCL_CACHE_DIR")) return e;
+    const char *home = std::getenv("HOME");
+    return std::string(home ? home : "/tmp") + "/.vexcl_amd";
+}
+
+bool cache_enabled() {
+    const char *e = std::getenv("VEXCL_CACHE_KERNELS");
+    return !(e && e[0] == '0');
+}
+
+bool mkdirs(const std::string &path) {
+    std::string cur;
+    for (size_t i = 0; i < path.size(); ++i) {
+        cur += path[i];
+        if (path[i] == '/' || i + 1 == path.size())
+            if (::mkdir(cur.c_str(), 0755) != 0 && errno != EEXIST) return false;
+    }
+    return true;
+}
+
+bool read_file(const std::string &p, std::vector<char> &out) {
+    std::ifstream f(p, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    std::streamsize n = f.tellg();
+    if (n <= 0) return false;
+    f.seekg(0);
+    out.resize((size_t)n);
+    return (bool)f.read(out.data(), n);
+}
+
+void write_file_atomic(const std::string &dir, const std::string &name, const std::vector<char> &data) {
+    if (!mkdirs(dir)) return;
+    std::string tmp = dir + "/." + name + "." + std::to_string((long)::getpid());
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) return;
+        f.write(data.data(), (std::streamsize)data.size());
+        if (!f) { ::unlink(tmp.c_str()); return; }
+    }
+    if (::rename(tmp.c_str(), (dir + "/" + name).c_str()) != 0) ::unlink(tmp.c_str());
+}
+
+int rtc_fail(const char *file, int line, hiprtcResult r, const std::string &log) {
+    return fail(file, line, std::string("hiprtc: ") + hiprtcGetErrorString(r) + (log.empty() ? "" : "\n" + log));
+}
+
+} // namespace
+
+extern "C" {
+
+const char *vexhip_last_error(void) { return last_error().c_str(); }
+int vexhip_abi_version(void) { return VEXHIP_ABI_VERSION; }
+
+// ---------------------------------------------------------------- devices
+int vexhip_device_count(int *count) {
+    VEXHIP_REQUIRE(count, "count is NULL");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e == hipErrorNoDevice) { *count = 0; (void)hipGetLastError(); return 0; }
+    VEXHIP_TRY(e);
+    return 0;
+}
+
+int vexhip_device_get_props(int dev, vexhip_device_props *out) {
+    VEXHIP_REQUIRE(out, "props is NULL");
+    hipDeviceProp_t p;
+    VEXHIP_TRY(hipGetDeviceProperties(&p, dev));
+    std::memset(out, 0, sizeof(*out));
+    std::strncpy(out->name, p.name, sizeof(out->name) - 1);
+    std::strncpy(out->arch, p.gcnArchName, sizeof(out->arch) - 1);
+    out->compute_units = p.multiProcessorCount;
+    out->wavefront_size = p.warpSize;
+    out->max_threads_per_block = p.maxThreadsPerBlock;
+    out->lds_bytes_per_block = (int32_t)p.sharedMemPerBlock;
+    out->clock_khz = p.clockRate;
+    out->l2_bytes = p.l2CacheSize;
+    out->global_mem_bytes = p.totalGlobalMem;
+    out->pci_bus_id = p.pciBusID;
+    return 0;
+}
+
+int vexhip_device_sync(int dev) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int vexhip_mem_info(int dev, uint64_t *free_bytes, uint64_t *total_bytes) {
+    VEXHIP_SET_DEVICE(dev);
+    size_t f = 0, t = 0;
+    VEXHIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
+// ---------------------------------------------------------------- streams
+int vexhip_stream_create(int dev, void **stream) {
+    VEXHIP_REQUIRE(stream, "stream is NULL");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s;
+    VEXHIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return 0;
+}
+
+int vexhip_stream_destroy(int dev, void *stream) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipStreamDestroy(as_stream(stream)));
+    return 0;
+}
+
+int vexhip_stream_sync(int dev, void *stream) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return 0;
+}
+
+// ---------------------------------------------------------------- events
+int vexhip_event_create(int dev, int timing, void **event) {
+    VEXHIP_REQUIRE(event, "event is NULL");
+    VEXHIP_SET_DEVICE(dev);
+    hipEvent_t e;
+    VEXHIP_TRY(hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming));
+    *event = e;
+    return 0;
+}
+
+int vexhip_event_destroy(int dev, void *event) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return 0;
+}
+
+int vexhip_event_record(int dev, void *event, void *stream) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+    return 0;
+}
+
+int vexhip_event_sync(int dev, void *event) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipEventSynchronize((hipEvent_t)event));
+    return 0;
+}
+
+int vexhip_stream_wait_event(int dev, void *stream, void *event) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+    return 0;
+}
+
+int vexhip_event_elapsed_ms(int dev, void *start, void *stop, float *ms) {
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+// ---------------------------------------------------------------- memory
+int vexhip_malloc(int dev, size_t bytes, void **ptr) {
+    VEXHIP_REQUIRE(ptr, "ptr is NULL");
+    VEXHIP_SET_DEVICE(dev);
+    *ptr = nullptr;
+    if (bytes == 0) return 0;
+    VEXHIP_TRY(hipMalloc(ptr, bytes));
+    return 0;
+}
+
+int vexhip_free(int dev, void *ptr) {
+    if (!ptr) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipFree(ptr));
+    return 0;
+}
+
+int vexhip_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes, void *stream, int blocking) {
+    if (!bytes) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    if (blocking) VEXHIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return 0;
+}
+
+int vexhip_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes, void *stream, int blocking) {
+    if (!bytes) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    if (blocking) VEXHIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return 0;
+}
+
+int vexhip_memcpy_d2d(int dev, void *dst, const void *src, size_t bytes, void *stream) {
+    if (!bytes) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 0;
+}
+
+int vexhip_memcpy_peer(int dst_dev, void *dst, int src_dev, const void *src, size_t bytes, void *stream) {
+    if (!bytes) return 0;
+    VEXHIP_SET_DEVICE(dst_dev);
+    if (dst_dev == src_dev)
+        VEXHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    else
+        VEXHIP_TRY(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, as_stream(stream)));
+    return 0;
+}
+
+int vexhip_memset(int dev, void *ptr, int byte, size_t bytes, void *stream) {
+    if (!bytes) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipMemsetAsync(ptr, byte, bytes, as_stream(stream)));
+    return 0;
+}
+
+int vexhip_host_alloc(size_t bytes, void **ptr) {
+    VEXHIP_REQUIRE(ptr, "ptr is NULL");
+    VEXHIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+
+int vexhip_host_free(void *ptr) {
+    if (!ptr) return 0;
+    VEXHIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
+// ---------------------------------------------------------------- JIT
+
+int vexhip_module_compile(int dev, const char *source, const char *options, void **module) {
+    VEXHIP_REQUIRE(source && module, "source/module is NULL");
+    VEXHIP_SET_DEVICE(dev);
+    hipDeviceProp_t prop;
+    VEXHIP_TRY(hipGetDeviceProperties(&prop, dev));
+    std::string arch = prop.gcnArchName;
+    std::string opts = options ? options : "";
+
+    if (const char *show = std::getenv("VEXCL_SHOW_KERNELS"))
+        if (show[0] != '0') std::printf("%s\n", source);
+
+    int rtc_major = 0, rtc_minor = 0;
+    hiprtcVersion(&rtc_major, &rtc_minor);
+    std::string key = digest(std::string(source) + "\x01" + opts + "\x01" + arch + "\x01" +
+                             std::to_string(rtc_major) + "." + std::to_string(rtc_minor));
+    std::string dir = cache_root() + "/" + key.substr(0, 2) + "/" + key.substr(2);
+
+    std::vector<char> code;
+    bool from_disk = cache_enabled() && read_file(dir + "/kernel.hsaco", code);
+
+    if (!from_disk) {
+        hiprtcProgram prog;
+        hiprtcResult r = hiprtcCreateProgram(&prog, source, "vexcl_kernel.hip", 0, nullptr, nullptr);
+        if (r != HIPRTC_SUCCESS) return rtc_fail(__FILE__, __LINE__, r, "");
+
+        std::vector<std::string> ostr;
+        ostr.push_back("--offload-arch=" + arch);
+        ostr.push_back("-O3");
+        ostr.push_back("-std=c++17");
+        {
+            std::istringstream is(opts);
+            std::string tok;
+            while (is >> tok) ostr.push_back(tok);
+        }
+        std::vector<const char *> oc;
+        for (auto &s : ostr) oc.push_back(s.c_str());
+
+        r = hiprtcCompileProgram(prog, (int)oc.size(), oc.data());
+        if (r != HIPRTC_SUCCESS) {
+            size_t ls = 0;
+            hiprtcGetProgramLogSize(prog, &ls);
+            std::string log(ls, '\0');
+            if (ls) hiprtcGetProgramLog(prog, &log[0]);
+            hiprtcDestroyProgram(&prog);
+            // the reference prints source + build log, then rethrows
+            // (backend/opencl/compiler.hpp:164-174)
+            std::fprintf(stderr, "%s\n%s\n", source, log.c_str());
+            return rtc_fail(__FILE__, __LINE__, r, log);
+        }
+        size_t cs = 0;
+        r = hiprtcGetCodeSize(prog, &cs);
+        if (r != HIPRTC_SUCCESS) { hiprtcDestroyProgram(&prog); return rtc_fail(__FILE__, __LINE__, r, ""); }
+        code.resize(cs);
+        r = hiprtcGetCode(prog, code.data());
+        hiprtcDestroyProgram(&prog);
+        if (r != HIPRTC_SUCCESS) return rtc_fail(__FILE__, __LINE__, r, "");
+        ++g_compiled;
+        if (cache_enabled()) write_file_atomic(dir, "kernel.hsaco", code);
+    } else {
+        ++g_disk_hits;
+    }
+
+    hipModule_t m;
+    VEXHIP_TRY(hipModuleLoadData(&m, code.data()));
+    *module = m;
+    return 0;
+}
+
+int vexhip_module_unload(int dev, void *module) {
+    if (!module) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipModuleUnload((hipModule_t)module));
+    return 0;
+}
+
+int vexhip_module_get_function(int dev, void *module, const char *name, void **function) {
+    VEXHIP_REQUIRE(module && name && function, "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    hipFunction_t f;
+    VEXHIP_TRY(hipModuleGetFunction(&f, (hipModule_t)module, name));
+    *function = f;
+    return 0;
+}
+
+int vexhip_function_max_threads(int dev, void *function, int *max_threads, int *static_lds) {
+    VEXHIP_SET_DEVICE(dev);
+    int v = 0;
+    if (max_threads) {
+        VEXHIP_TRY(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, (hipFunction_t)function));
+        *max_threads = v;
+    }
+    if (static_lds) {
+        VEXHIP_TRY(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, (hipFunction_t)function));
+        *static_lds = v;
+    }
+    return 0;
+}
+
+int vexhip_launch(int dev, void *function,
+        unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz,
+        unsigned lds, void *stream, void **args) {
+    VEXHIP_REQUIRE(function, "function is NULL");
+    VEXHIP_SET_DEVICE(dev);
+    if (gx == 0 || gy == 0 || gz == 0) return 0;
+    VEXHIP_TRY(hipModuleLaunchKernel((hipFunction_t)function, gx, gy, gz, bx, by, bz, lds,
+                                     as_stream(stream), args, nullptr));
+    return 0;
+}
+
+int vexhip_jit_stats(uint64_t *compiled, uint64_t *disk_hits) {
+    if (compiled) *compiled = g_compiled.load();
+    if (disk_hits) *disk_hits = g_disk_hits.load();
+    return 0;
+}
+
+} // extern "C"

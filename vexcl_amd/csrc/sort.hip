@@ -1,0 +1,244 @@
+// vex::sort / vex::sort_by_key on gfx950 (vexcl/sort.hpp:2158-2182).
+// The reference is a merge sort (sort.hpp:820-1696) and its contract -- pinned
+// by tests/sort.cpp:22-45 -- is std::stable_sort.  Here: stable LSD radix sort,
+// 8-bit digits.  Per pass:
+//   (1) digit histogram per 4096-key tile        -> table[digit][tile]
+//   (2) exclusive scan of the table (scan.hip)   -> global base per (digit,tile)
+//   (3) scatter: wave-64 ballot match ranks the keys of a wave stably, LDS
+//       per-wave digit counters order the 4 waves, the tile is re-ordered in
+//       LDS and written out as runs of equal digits (coalesced).
+// Signed and floating keys are mapped to order-preserving unsigned bits on the
+// fly; the stored keys stay untouched.
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace vexhip {
+
+int scan_exclusive_u32_tmp(hipStream_t s, const unsigned *in, unsigned *out, int64_t n, unsigned *tmp);
+size_t scan_tmp_elems_u32(int64_t n);
+
+namespace {
+
+constexpr int RB = 256;              // lanes per workgroup
+constexpr int RW = RB / kWave;       // waves
+constexpr int KPT = 16;              // keys per lane
+constexpr int RTILE = RB * KPT;      // 4096 keys per tile
+constexpr int RADIX = 256;
+
+enum { KEY_UNSIGNED = 0, KEY_SIGNED = 1, KEY_FLOAT = 2 };
+
+template <typename K> struct kbits { static constexpr K sign = (K)1 << (sizeof(K) * 8 - 1); };
+
+template <typename K, int MODE, bool DESC>
+__device__ __forceinline__ K to_ordered(K k) {
+    if constexpr (MODE == KEY_SIGNED) k ^= kbits<K>::sign;
+    if constexpr (MODE == KEY_FLOAT)  k = (k & kbits<K>::sign) ? (K)~k : (K)(k ^ kbits<K>::sign);
+    if constexpr (DESC) k = (K)~k;
+    return k;
+}
+
+template <typename K, int MODE, bool DESC>
+__global__ __launch_bounds__(RB)
+void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsigned nblocks, unsigned *__restrict__ table)
+{
+    __shared__ unsigned s_h[RADIX];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * RTILE;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        long long i = base + k * RB + threadIdx.x;
+        if (i < n) {
+            unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(keys[i]) >> shift) & (RADIX - 1);
+            atomicAdd(&s_h[d], 1u);
+        }
+    }
+    __syncthreads();
+    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
+}
+
+template <int VB> struct valtype;
+template <> struct valtype<0> { typedef char type; };
+template <> struct valtype<4> { typedef unsigned type; };
+template <> struct valtype<8> { typedef unsigned long long type; };
+
+template <typename K, int MODE, bool DESC, int VB>
+__global__ __launch_bounds__(RB)
+void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+        const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
+        long long n, int shift, unsigned nblocks, const unsigned *__restrict__ table)
+{
+    typedef typename valtype<VB>::type VT;
+    const VT *vals_in = reinterpret_cast<const VT *>(vals_in_);
+    VT *vals_out = reinterpret_cast<VT *>(vals_out_);
+
+    __shared__ K s_keys[RTILE];
+    __shared__ VT s_vals[VB ? RTILE : 1];
+    __shared__ unsigned s_hist[RW][RADIX];
+    __shared__ unsigned s_dstart[RADIX];
+    __shared__ unsigned s_gbase[RADIX];
+    __shared__ unsigned s_wtot[RW];
+
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+    const long long base = (long long)blockIdx.x * RTILE;
+    const long long wbase = base + (long long)wave * (kWave * KPT);
+    const int nvalid = (int)((n - base < RTILE) ? (n - base) : RTILE);
+
+#pragma unroll
+    for (int w = 0; w < RW; ++w) s_hist[w][t] = 0;
+
+    K key[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        long long i = wbase + k * kWave + lane;
+        // padding keys sort last inside the tile and are never written out
+        key[k] = (i < n) ? keys_in[i] : K(0);
+    }
+    __syncthreads();
+
+    unsigned short rank[KPT];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        long long i = wbase + k * kWave + lane;
+        const bool valid = i < n;
+        K ok = to_ordered<K, MODE, DESC>(key[k]);
+        unsigned d = (unsigned)(ok >> shift) & (RADIX - 1);
+        // m = the real (non-padding) lanes of this wave holding the same digit
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1;
+            unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        unsigned before = __popcll(m & lt_mask);
+        unsigned cnt = __popcll(m);
+        unsigned prev = s_hist[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        // padding lanes take no rank and no slot: tile positions 0..nvalid-1
+        // are exactly the real keys
+        if (valid) {
+            if (before == 0) s_hist[wave][d] = prev + cnt;
+            rank[k] = (unsigned short)(prev + before);
+        } else {
+            rank[k] = 0xffff;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // digit t: exclusive offsets across the waves, tile count, tile-local start
+    unsigned count = 0;
+#pragma unroll
+    for (int w = 0; w < RW; ++w) { unsigned c = s_hist[w][t]; s_hist[w][t] = count; count += c; }
+    {
+        unsigned inc = count;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            unsigned u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == kWave - 1) s_wtot[wave] = inc;
+        __syncthreads();
+        unsigned woff = 0;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) if (w < wave) woff += s_wtot[w];
+        unsigned dstart = woff + inc - count;
+        s_dstart[t] = dstart;
+        s_gbase[t] = table[(size_t)t * nblocks + blockIdx.x] - dstart;
+    }
+    __syncthreads();
+
+    // re-order the tile in LDS
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        if (rank[k] != 0xffff) {
+            K ok = to_ordered<K, MODE, DESC>(key[k]);
+            unsigned d = (unsigned)(ok >> shift) & (RADIX - 1);
+            unsigned pos = s_dstart[d] + s_hist[wave][d] + rank[k];
+            s_keys[pos] = key[k];
+            if constexpr (VB != 0) s_vals[pos] = vals_in[wbase + k * kWave + lane];
+        }
+    }
+    __syncthreads();
+
+    for (int i = t; i < nvalid; i += RB) {
+        K kk = s_keys[i];
+        unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(kk) >> shift) & (RADIX - 1);
+        unsigned g = s_gbase[d] + (unsigned)i;
+        keys_out[g] = kk;
+        if constexpr (VB != 0) vals_out[g] = s_vals[i];
+    }
+}
+
+template <typename K, int MODE, bool DESC, int VB>
+int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp) {
+    const unsigned nblocks = (unsigned)((n + RTILE - 1) / RTILE);
+    const int64_t tn = (int64_t)nblocks * RADIX;
+    unsigned *table = tmp;
+    unsigned *scan_tmp = tmp + (tn + 3) / 4 * 4;
+    K *src = keys, *dst = keys_tmp;
+    void *vsrc = vals, *vdst = vals_tmp;
+    constexpr int passes = (int)sizeof(K);
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        radix_hist_kernel<K, MODE, DESC><<<nblocks, RB, 0, s>>>(src, n, shift, nblocks, table);
+        VEXHIP_LAUNCH_CHECK();
+        if (int rc = scan_exclusive_u32_tmp(s, table, table, tn, scan_tmp)) return rc;
+        radix_scatter_kernel<K, MODE, DESC, VB><<<nblocks, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, table);
+        VEXHIP_LAUNCH_CHECK();
+        std::swap(src, dst);
+        std::swap(vsrc, vdst);
+    }
+    // sizeof(K) passes is even => the result is back in `keys` / `vals`
+    static_assert(sizeof(K) % 2 == 0, "ping-pong parity");
+    return 0;
+}
+
+template <typename K, int MODE>
+int sort_dispatch(hipStream_t s, int desc, int vb, void *keys, void *keys_tmp, void *vals, void *vals_tmp, int64_t n, void *tmp) {
+#define GO(DESC, VB) return sort_passes<K, MODE, DESC, VB>(s, (K *)keys, (K *)keys_tmp, vals, vals_tmp, n, (unsigned *)tmp)
+    if (desc) { if (vb == 0) GO(true, 0); if (vb == 4) GO(true, 4); if (vb == 8) GO(true, 8); }
+    else      { if (vb == 0) GO(false, 0); if (vb == 4) GO(false, 4); if (vb == 8) GO(false, 8); }
+#undef GO
+    return fail(__FILE__, __LINE__, "value_bytes must be 0, 4 or 8");
+}
+
+} // namespace
+} // namespace vexhip
+
+using namespace vexhip;
+
+extern "C" {
+
+size_t vexhip_sort_tmp_bytes(int key_dtype, int64_t n) {
+    (void)key_dtype;
+    int64_t nblocks = (n + RTILE - 1) / RTILE;
+    int64_t tn = nblocks * RADIX;
+    return sizeof(unsigned) * (size_t)((tn + 3) / 4 * 4 + (int64_t)scan_tmp_elems_u32(tn) + 4);
+}
+
+int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
+        void *keys, void *keys_tmp, int value_bytes, void *vals, void *vals_tmp, int64_t n, void *tmp)
+{
+    VEXHIP_REQUIRE(n >= 0, "negative size");
+    if (n <= 1) return 0;
+    VEXHIP_REQUIRE(n < (1ll << 31), "at most 2^31-1 keys per call (sort.hpp:1738 has the same limit)");
+    VEXHIP_REQUIRE(keys && keys_tmp && tmp, "NULL argument");
+    VEXHIP_REQUIRE(value_bytes == 0 || (vals && vals_tmp), "NULL value buffers");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    switch (key_dtype) {
+        case VEXHIP_U32: return sort_dispatch<unsigned, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
+        case VEXHIP_I32: return sort_dispatch<unsigned, KEY_SIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
+        case VEXHIP_F32: return sort_dispatch<unsigned, KEY_FLOAT>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
+        case VEXHIP_U64: return sort_dispatch<unsigned long long, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
+        case VEXHIP_I64: return sort_dispatch<unsigned long long, KEY_SIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
+        case VEXHIP_F64: return sort_dispatch<unsigned long long, KEY_FLOAT>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
+    }
+    return fail(__FILE__, __LINE__, "unknown key dtype");
+}
+
+} // extern "C"

@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's operator interface for the hot path,
+over torch device tensors (torch supplies HBM allocations and streams only;
+every computation goes through libvexhip.so, include/vexhip.h).
+
+Names follow the reference: ``SpMat`` (vexcl/spmat.hpp:56-185), ``Reductor``
+(vexcl/reductor.hpp:289-439), ``sort`` / ``sort_by_key`` (vexcl/sort.hpp:
+2158-2182), ``inclusive_scan`` / ``exclusive_scan`` (vexcl/scan.hpp:461-518).
+The C++ header API (``vexcl/*.hpp``) is the primary host side; this module is
+what the Python parity tests and ``bench.py`` drive.
+"""
+import ctypes
+
+import torch
+
+from . import _capi
+from ._capi import Error, lib
+
+_DT = {torch.float64: _capi.F64, torch.float32: _capi.F32, torch.int32: _capi.I32, torch.int64: _capi.I64}
+for _name, _code in (("uint32", _capi.U32), ("uint64", _capi.U64)):
+    if hasattr(torch, _name):
+        _DT[getattr(torch, _name)] = _code
+
+
+def _dtype_code(t, unsigned=False):
+    code = _DT.get(t.dtype)
+    if code is None:
+        raise Error("unsupported element type %s" % t.dtype)
+    if unsigned and code == _capi.I32:
+        code = _capi.U32
+    if unsigned and code == _capi.I64:
+        code = _capi.U64
+    return code
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise Error("vexcl_amd operates on HBM-resident tensors only (got a %s tensor); "
+                    "there is no CPU fallback" % t.device.type)
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name):
+    if not t.is_contiguous():
+        raise Error("%s must be contiguous" % name)
+    return t
+
+
+# --------------------------------------------------------------------------
+# raw kernels
+# --------------------------------------------------------------------------
+def spmv_csr(ptr, col, val, x, y, alpha=1.0, append=False):
+    """y (=|+=) alpha * A x  -- `csr_spmv`, vexcl/spmat/csr.inl:153-185."""
+    n = ptr.numel() - 1
+    for t, nm in ((ptr, "ptr"), (col, "col"), (val, "val"), (x, "x"), (y, "y")):
+        _chk(t, nm)
+    if y.numel() != n:
+        raise Error("y has %d elements, matrix has %d rows" % (y.numel(), n))
+    L = lib()
+    if val.dtype == torch.float64 and ptr.dtype == torch.int32 and col.dtype == torch.int32:
+        fn, a = L.spmv_csr_f64_i32, ctypes.c_double(alpha)
+    elif val.dtype == torch.float32 and ptr.dtype == torch.int32 and col.dtype == torch.int32:
+        fn, a = L.spmv_csr_f32_i32, ctypes.c_float(alpha)
+    elif val.dtype == torch.float64 and ptr.dtype == torch.int64 and col.dtype == torch.int64:
+        fn, a = L.spmv_csr_f64_i64, ctypes.c_double(alpha)
+    else:
+        raise Error("unsupported CSR type combination %s/%s/%s" % (val.dtype, ptr.dtype, col.dtype))
+    fn(_dev(y), _stream(y), n, a, int(bool(append)), _p(ptr), _p(col), _p(val), _p(x), _p(y))
+    return y
+
+
+def gather(idx, src, dst=None):
+    """dst[i] = src[idx[i]] -- spmat.hpp:129-133 `permutation(cols_to_send)(x)`."""
+    if dst is None:
+        dst = torch.empty(idx.numel(), dtype=src.dtype, device=src.device)
+    L = lib()
+    fn = {torch.float64: L.gather_f64_i32, torch.float32: L.gather_f32_i32}.get(src.dtype)
+    if fn is None or idx.dtype != torch.int32:
+        raise Error("gather: unsupported types")
+    fn(_dev(src), _stream(src), idx.numel(), _p(idx), _p(src), _p(dst))
+    return dst
+
+
+def poisson3d(n, device="cuda", rows=None):
+    """3-D Poisson matrix of examples/benchmark.cpp:364-415, built in HBM.
+    rows=(r0, r1): only that row strip (global column ids, strip-local ptr)."""
+    L = lib()
+    dev = torch.device(device)
+    N = n ** 3
+    r0, r1 = (0, N) if rows is None else rows
+    nnz = L.poisson3d_strip_nnz(n, r0, r1)
+    ptr = torch.empty(r1 - r0 + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    L.poisson3d_strip_f64_i32(_dev(ptr), _stream(ptr), n, r0, r1, _p(ptr), _p(col), _p(val))
+    return ptr, col, val
+
+
+def fill_hash(t, seed):
+    lib().fill_hash(_dev(t), _stream(t), _dtype_code(t), ctypes.c_uint64(seed), _p(t), t.numel())
+    return t
+
+
+# --------------------------------------------------------------------------
+# SpMat: the reference's GPU path is hybrid ELL (spmat.hpp:98-103)
+# --------------------------------------------------------------------------
+class HybridELL:
+    """Device-resident ELL(+CSR tail) built from device CSR
+    (spmat/hybrid_ell.inl:55-216; device-side conversion sparse/ell.hpp:400-508)."""
+
+    def __init__(self, ptr, col, val):
+        L = lib()
+        self.n = n = ptr.numel() - 1
+        self.dtype = val.dtype
+        dev, s = _dev(val), _stream(val)
+        w, tail = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.hell_analyze_i32(dev, s, n, _p(ptr), ctypes.byref(w), ctypes.byref(tail))
+        self.width, self.tail_nnz = int(w.value), int(tail.value)
+        self.pitch = (n + 15) // 16 * 16
+        d = val.device
+        self.ell_col = torch.empty(self.pitch * self.width, dtype=torch.int32, device=d)
+        self.ell_val = torch.empty(self.pitch * self.width, dtype=val.dtype, device=d)
+        if self.tail_nnz:
+            self.csr_ptr = torch.empty(n + 1, dtype=torch.int32, device=d)
+            self.csr_col = torch.empty(self.tail_nnz, dtype=torch.int32, device=d)
+            self.csr_val = torch.empty(self.tail_nnz, dtype=val.dtype, device=d)
+        else:
+            self.csr_ptr = self.csr_col = self.csr_val = None
+        fill = L.hell_fill_f64_i32 if val.dtype == torch.float64 else L.hell_fill_f32_i32
+        fill(dev, s, n, _p(ptr), _p(col), _p(val), self.width, self.pitch,
+             _p(self.ell_col), _p(self.ell_val), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val))
+
+    def mul(self, x, y, alpha=1.0, append=False):
+        L = lib()
+        if self.dtype == torch.float64:
+            fn, a = L.spmv_hell_f64_i32, ctypes.c_double(alpha)
+        else:
+            fn, a = L.spmv_hell_f32_i32, ctypes.c_float(alpha)
+        fn(_dev(y), _stream(y), self.n, a, int(bool(append)), self.width, self.pitch,
+           _p(self.ell_col), _p(self.ell_val), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val),
+           _p(x), _p(y))
+        return y
+
+
+class SpMat:
+    """vex::SpMat<val_t, col_t, idx_t> on one GPU (spmat.hpp:56-185).
+
+    Built from device CSR arrays.  ``fmt='hell'`` (the reference's choice for
+    GPU devices, spmat.hpp:98-103), ``'csr'`` (its CPU-device kernel, run here
+    by the LDS-staged CSR kernel) or ``'auto'``.  ``apply(x, y, alpha, append)``
+    has the semantics of ``SpMat::apply`` (spmat.hpp:120-121):
+    ``y = alpha*A*x`` or ``y += alpha*A*x``.
+    """
+
+    def __init__(self, ptr, col, val, n_cols=None, fmt="auto"):
+        self.ptr, self.col, self.val = ptr, col, val
+        self.n = ptr.numel() - 1
+        self.m = self.n if n_cols is None else n_cols
+        if fmt == "auto":
+            fmt = "hell" if (ptr.dtype == torch.int32 and col.dtype == torch.int32) else "csr"
+        if fmt not in ("hell", "csr"):
+            raise Error("unknown SpMat format %r" % fmt)
+        self.fmt = fmt
+        self.hell = HybridELL(ptr, col, val) if fmt == "hell" else None
+
+    def rows(self):
+        return self.n
+
+    def cols(self):
+        return self.m
+
+    def nonzeros(self):
+        return self.col.numel()
+
+    def apply(self, x, y, alpha=1.0, append=False):
+        if x.numel() != self.m:
+            raise Error("x has %d elements, matrix has %d columns" % (x.numel(), self.m))
+        if self.fmt == "hell":
+            return self.hell.mul(x, y, alpha, append)
+        return spmv_csr(self.ptr, self.col, self.val, x, y, alpha, append)
+
+    def __matmul__(self, x):                      # y = A * x
+        y = torch.empty(self.n, dtype=x.dtype, device=x.device)
+        return self.apply(x, y, 1.0, False)
+
+
+# --------------------------------------------------------------------------
+# Reductor
+# --------------------------------------------------------------------------
+class Reductor:
+    """vex::Reductor<T, RDC> for plain-vector operands (reductor.hpp:289-439).
+    Blocking, returns a host scalar like the reference (MIN_MAX: a pair)."""
+    _OPS = {"SUM": _capi.SUM, "SUM_Kahan": _capi.SUM_KAHAN, "MIN": _capi.MIN, "MAX": _capi.MAX,
+            "MIN_MAX": _capi.MIN_MAX}
+
+    def __init__(self, op="SUM", device="cuda"):
+        if op not in self._OPS:
+            raise Error("unknown reduction %r" % op)
+        self.op = op
+        self._tmp = None
+
+    def _buffers(self, t):
+        if self._tmp is None or self._tmp.device != t.device:
+            self._tmp = torch.empty(lib().reduce_tmp_bytes() // 8, dtype=torch.float64, device=t.device)
+            self._out = torch.empty(2, dtype=torch.float64, device=t.device)
+        return self._tmp, self._out
+
+    def device_result(self, x, unsigned=False):
+        """Runs both stages on the device; returns the 1- (or 2-) element device tensor."""
+        tmp, out = self._buffers(x)
+        lib().reduce(_dev(x), _stream(x), self._OPS[self.op], _dtype_code(x, unsigned), _p(_chk(x, "x")),
+                     x.numel(), _p(out), _p(tmp))
+        k = 2 if self.op == "MIN_MAX" else 1
+        return out.view(torch.uint8)[: k * x.element_size()].view(x.dtype)
+
+    def __call__(self, x, unsigned=False):
+        r = self.device_result(x, unsigned).cpu()
+        return (r[0].item(), r[1].item()) if self.op == "MIN_MAX" else r[0].item()
+
+    def dot(self, a, b):
+        """sum(a*b), examples/benchmark.cpp:224-246."""
+        if self.op != "SUM":
+            raise Error("dot is a SUM reduction")
+        tmp, out = self._buffers(a)
+        lib().reduce_dot(_dev(a), _stream(a), _dtype_code(a), _p(a), _p(b), a.numel(), _p(out), _p(tmp))
+        return out.view(torch.uint8)[: a.element_size()].view(a.dtype).cpu()[0].item()
+
+
+# --------------------------------------------------------------------------
+# scan / sort
+# --------------------------------------------------------------------------
+def _scan(inp, out, exclusive, init, unsigned):
+    if out is None:
+        out = torch.empty_like(inp)
+    _chk(inp, "input"); _chk(out, "output")
+    if out.numel() != inp.numel() or out.dtype != inp.dtype:
+        raise Error("scan: input and output must have the same size and type")
+    L = lib()
+    code = _dtype_code(inp, unsigned)
+    n = inp.numel()
+    tmp = torch.empty(max(1, L.scan_tmp_bytes(code, n)), dtype=torch.uint8, device=inp.device)
+    host_init = None
+    if exclusive:
+        ct = {_capi.F64: ctypes.c_double, _capi.F32: ctypes.c_float, _capi.I32: ctypes.c_int32,
+              _capi.U32: ctypes.c_uint32, _capi.I64: ctypes.c_int64, _capi.U64: ctypes.c_uint64}[code]
+        host_init = ctypes.byref(ct(init))
+    L.scan(_dev(inp), _stream(inp), code, int(exclusive), host_init, _p(inp), _p(out), n, _p(tmp))
+    return out
+
+
+def inclusive_scan(inp, out=None, unsigned=False):
+    """vex::inclusive_scan(in, out) with vex::plus (scan.hpp:461-469). In-place allowed."""
+    return _scan(inp, out, False, 0, unsigned)
+
+
+def exclusive_scan(inp, out=None, init=0, unsigned=False):
+    """vex::exclusive_scan(in, out, init) (scan.hpp:510-518)."""
+    return _scan(inp, out, True, init, unsigned)
+
+
+def _sort(keys, vals, descending, unsigned):
+    _chk(keys, "keys")
+    L = lib()
+    n = keys.numel()
+    code = _dtype_code(keys, unsigned)
+    ktmp = torch.empty_like(keys)
+    vb, vtmp = 0, None
+    if vals is not None:
+        _chk(vals, "vals")
+        if vals.numel() != n:
+            raise Error("sort_by_key: keys and values differ in size")
+        vb = vals.element_size()
+        if vb not in (4, 8):
+            raise Error("sort_by_key: values must be 4 or 8 bytes wide")
+        vtmp = torch.empty_like(vals)
+    tmp = torch.empty(max(1, L.sort_tmp_bytes(code, n)), dtype=torch.uint8, device=keys.device)
+    L.sort(_dev(keys), _stream(keys), code, int(bool(descending)), _p(keys), _p(ktmp), vb, _p(vals), _p(vtmp),
+           n, _p(tmp))
+    return keys if vals is None else (keys, vals)
+
+
+def sort(keys, descending=False, unsigned=False):
+    """vex::sort(keys[, vex::greater]) -- in place, stable (sort.hpp:2158-2167)."""
+    return _sort(keys, None, descending, unsigned)
+
+
+def sort_by_key(keys, vals, descending=False, unsigned=False):
+    """vex::sort_by_key(keys, vals) -- in place, stable (sort.hpp:2170-2182)."""
+    return _sort(keys, vals, descending, unsigned)
