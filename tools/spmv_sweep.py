@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=512)
-    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--out", default="gpurun_out/spmv_sweep.json")
     args = ap.parse_args()
     import torch

@@ -132,7 +132,7 @@ void tail_count_kernel(long long n, const int *__restrict__ ptr, int w, int *cnt
         local += (unsigned long long)t;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, local);
+    if (total && (threadIdx.x & 63) == 0 && local) atomicAdd(total, local);
 }
 
 template <typename V>

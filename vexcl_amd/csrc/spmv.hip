@@ -266,7 +266,7 @@ void gather_kernel(long long n, const I *__restrict__ idx, const V *__restrict__
 int g_csr_variant = -1;     // -1: built-in default
 int g_hell_variant = -1;
 constexpr int kCsrDefault  = 0;
-constexpr int kHellDefault = 4;   // RPT = 2
+constexpr int kHellDefault = 7;   // RPT = 2, nontemporal streams, XCD-contiguous rows (sweep: profiles/)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
