@@ -54,15 +54,17 @@ def cpu_baseline(grid, seconds):
                       % (reps, grid, N, nnz)}
 
 
-def read_traffic():
-    """HBM bytes per launch from the committed PMC pass (profiles/*pmc*.json), or None."""
+def read_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes
+    (profiles/*pmc_summary.json written by tools/profile.sh + tools/pmc_summary.py:
+    FETCH_SIZE calibrated x2 on a stream of known size, + WRITE_SIZE), or None."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json"))):
         try:
             d = json.load(open(f))
-            if "hbm_bytes_per_launch" in d:
-                best = d
+            if kernel in d and "hbm_bytes_per_launch" in d[kernel]:
+                best = int(d[kernel]["hbm_bytes_per_launch"])
         except Exception:
             pass
     return best
@@ -165,7 +167,8 @@ def main():
         alg_rank = algorithmic_bytes(r1 - r0, nnz_rank)
         gflops = 2.0 * nnz_total / per_step / 1e9
         gbps = alg_total / per_step / 1e9
-        traffic = read_traffic() if (world == 1 and n == 512) else None
+        kname = "hell_kernel" if fmt == "hell" else "csr_stream_kernel"
+        traffic = read_traffic(kname) if (world == 1 and n == 512) else None
         out = {
             "metric": "fp64 CSR SpMV GFLOP/s, 3D Poisson %d^3 (y = A*x, vex::SpMat path)" % n,
             "value": round(gflops, 2),
@@ -190,8 +193,8 @@ def main():
                          "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s",
                          "frac": round(alg_rank / kern_s / 1e9 / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-                         "kernel": "hell_kernel" if fmt == "hell" else "csr_stream_kernel",
+                         "traffic": traffic,
+                         "kernel": kname,
                          "algorithmic_bytes_per_launch": alg_rank,
                          "avg_launch_ms": round(kern_s * 1e3, 5)},
         }

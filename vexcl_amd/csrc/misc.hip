@@ -113,12 +113,20 @@ void width_max_kernel(long long n, const int *__restrict__ ptr, int *maxw) {
 // histogram of min(width, cap) -- cap bucket collects everything wider
 __global__ __launch_bounds__(256)
 void width_hist_kernel(long long n, const int *__restrict__ ptr, int cap, unsigned long long *hist) {
+    // widths below 256 (every practical matrix) are counted in LDS first: a
+    // regular matrix would otherwise serialise all rows on one global atomic
+    __shared__ unsigned s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         int w = ptr[i + 1] - ptr[i];
         if (w > cap) w = cap;
-        atomicAdd(&hist[w], 1ull);
+        if (w < 256) atomicAdd(&s_h[w], 1u);
+        else atomicAdd(&hist[w], 1ull);
     }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256)
