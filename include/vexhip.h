@@ -88,6 +88,9 @@ int vexhip_launch(int dev, void *function,
  * cache since load (the reference's VEXCL_CACHE_KERNELS behaviour is testable
  * through it) */
 int vexhip_jit_stats(uint64_t *compiled, uint64_t *disk_hits);
+/* compile-only check of a kernel source for `arch` (e.g. "gfx950"); needs no
+ * GPU, loads nothing, bypasses the caches */
+int vexhip_jit_check(const char *source, const char *options, const char *arch);
 
 /* ---- fixed primitive: CSR SpMV  (spmat/csr.inl:153-185 `csr_spmv`) ------
  * y[i] (= | +=) alpha * sum_{j in [ptr[i],ptr[i+1])} val[j]*x[col[j]],

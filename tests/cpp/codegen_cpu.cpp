@@ -1,0 +1,165 @@
+// CPU-only: the expression engine's generated kernels, checked for shape
+//  and compiled for gfx950 with hiprtc (no GPU needed).
+#define VEX_TEST_CPU_ONLY
+#include "vex_test.hpp"
+#undef ctx
+
+using namespace vex;
+using detail::assignment_source;
+using detail::as_expr;
+
+VEX_FUNCTION(double, sqr, (double, x), return x * x;);
+VEX_FUNCTION(double, times2, (double, x), return x * 2;);
+VEX_FUNCTION(double, times4, (double, x), return x * 4;);
+VEX_FUNCTION_D(double, sqr_plus, (double, x)(double, y), (sqr), return sqr(x) + y;);
+VEX_FUNCTION_V1(old_style, double(double, int), "return prm1 * prm2;");
+
+template <class OP, class L, class R> std::string src_of(const L &l, const R &r) {
+    backend::command_queue q;
+    return assignment_source<OP>(as_expr<L>::get(l), as_expr<R>::get(r), q);
+}
+static bool has(const std::string &s, const std::string &what) { return s.find(what) != std::string::npos; }
+static size_t count(const std::string &s, const std::string &what) {
+    size_t n = 0; for (size_t p = s.find(what); p != std::string::npos; p = s.find(what, p + 1)) ++n; return n;
+}
+
+TEST_CASE(fused_elementwise_shape) {
+    vector<double> a, b, c, d;
+    std::string s = src_of<assign::SET>(a, b * c + sin(d));
+    CHECK(has(s, "extern \"C\" __global__ void vexcl_vector_kernel"));
+    CHECK(has(s, "ulong n"));
+    CHECK(has(s, "double * prm_1") && has(s, "double * prm_4") && !has(s, "prm_5"));
+    CHECK(has(s, "prm_1[idx] = ( ( prm_2[idx] * prm_3[idx] ) + sin( prm_4[idx] ) );"));
+    backend::check_sources(s);
+}
+
+TEST_CASE(scalars_are_parameters_not_text) {
+    vector<double> a, b;
+    std::string s = src_of<assign::ADD>(a, 5 * sin(b) + 42.5);
+    CHECK(has(s, "int prm_2") && has(s, "double prm_4"));
+    CHECK(!has(s, "42.5"));
+    CHECK(has(s, "prm_1[idx] += ( ( prm_2 * sin( prm_3[idx] ) ) + prm_4 );"));
+    backend::check_sources(s);
+}
+
+TEST_CASE(all_assignment_operators_compile) {
+    vector<int> a, b;
+    backend::check_sources(src_of<assign::SET>(a, b));
+    backend::check_sources(src_of<assign::SUB>(a, b + 1));
+    backend::check_sources(src_of<assign::MUL>(a, b));
+    backend::check_sources(src_of<assign::DIV>(a, b + 1));
+    backend::check_sources(src_of<assign::MOD>(a, b + 7));
+    backend::check_sources(src_of<assign::AND>(a, b));
+    backend::check_sources(src_of<assign::OR>(a, b));
+    backend::check_sources(src_of<assign::XOR>(a, b));
+    backend::check_sources(src_of<assign::LSH>(a, b & 3));
+    backend::check_sources(src_of<assign::RSH>(a, b & 3));
+}
+
+TEST_CASE(user_functions_once_by_name) {
+    vector<double> a, b;
+    std::string s = src_of<assign::SET>(a, sqr(b) + sqr(a) + times2(b) * times4(b));
+    CHECK_EQUAL(count(s, "__device__ double sqr"), size_t(1));
+    CHECK(has(s, "__device__ double times2") && has(s, "__device__ double times4"));
+    backend::check_sources(s);
+    s = src_of<assign::SET>(a, sqr_plus(a, b) + old_style(b, 3));
+    CHECK(s.find("__device__ double sqr") < s.find("__device__ double sqr_plus"));
+    CHECK(has(s, "double prm1") && has(s, "int prm2"));
+    backend::check_sources(s);
+}
+
+TEST_CASE(ternary_comparison_builtins) {
+    vector<double> a, b; vector<int> k;
+    std::string s = src_of<assign::SET>(a, if_else(b < 0.5, pow(b, 2), fabs(b - 1) + max(a, b) + abs(a)));
+    CHECK(has(s, " ? ") && has(s, "pow( ") && has(s, "fabs( "));
+    backend::check_sources(s);
+    backend::check_sources(src_of<assign::SET>(k, abs(k) + (k > 3) + !k + -k));
+    backend::check_sources(src_of<assign::SET>(a, constants::pi() * a + sqrt(b) * exp(-a) / log(b + 2)));
+}
+
+TEST_CASE(tagged_terminals_share_a_parameter) {
+    vector<double> a, b;
+    auto ta = tag<1>(a);
+    std::string s = src_of<assign::SET>(ta, 2.0 * ta + b);
+    CHECK_EQUAL(count(s, "double * prm_tag_1_1"), size_t(1));
+    CHECK(has(s, "prm_tag_1_1[idx] = ( ( prm_1 * prm_tag_1_1[idx] ) + prm_2[idx] );") ||
+          has(s, "prm_tag_1_1[idx] = ( ( prm_2 * prm_tag_1_1[idx] ) + prm_3[idx] );"));
+    backend::check_sources(s);
+    // untagged: the same vector twice = two parameters
+    s = src_of<assign::SET>(a, a + a);
+    CHECK(has(s, "prm_2") && has(s, "prm_3"));
+}
+
+TEST_CASE(element_index_and_value_types) {
+    vector<double> a; vector<float> f; vector<int> k;
+    std::string s = src_of<assign::SET>(a, sin(0.5 * element_index()));
+    CHECK(has(s, "( prm_3 + idx )") && has(s, "ulong prm_3"));
+    backend::check_sources(s);
+    static_assert(std::is_same<decltype(f * k)::value_type, float>::value, "common type");
+    static_assert(std::is_same<decltype(a + f)::value_type, double>::value, "common type");
+    static_assert(std::is_same<decltype(a < f)::value_type, cl_long>::value, "comparison -> long");
+    static_assert(std::is_same<decltype(k << 2)::value_type, int>::value, "shift -> left type");
+    backend::check_sources(src_of<assign::SET>(f, f * k + 1));
+}
+
+TEST_CASE(sparse_products_are_inlinable_terminals) {
+    backend::command_queue q;
+    sparse::csr<double> A(q);
+    sparse::ell<double> E(q);
+    vector<double> x, y;
+    std::string s = src_of<assign::SET>(y, x + A * sin(x));
+    CHECK(has(s, "prm_3_sum") && has(s, "const int * prm_3_ptr") && has(s, "sin( prm_3_x_1[idx] )"));
+    backend::check_sources(s);
+    s = src_of<assign::ADD>(y, 2.0 * (E * x));
+    CHECK(has(s, "_ell_width") && has(s, "} else break;"));
+    backend::check_sources(s);
+}
+
+TEST_CASE(additive_transform_classification) {
+    typedef SpMat<double, int, int> M;
+    typedef detail::additive_operator<M, vector<double>> AX;
+    typedef detail::vector_ref<double> V;
+    typedef detail::scalar_terminal<int> S;
+    using namespace detail;
+    static_assert(expr_kind<V>::value == 0, "");
+    static_assert(expr_kind<AX>::value == 1, "");
+    static_assert(expr_kind<binary_expr<tag::multiplies, S, AX>>::value == 1, "42 * (A*x)");
+    static_assert(expr_kind<binary_expr<tag::plus, V, AX>>::value == 2, "x + A*x");
+    static_assert(expr_kind<unary_expr<tag::negate, AX>>::value == 1, "-(A*x)");
+    static_assert(expr_kind<binary_expr<tag::multiplies, V, AX>>::value == -1, "x * (A*x) is not assignable");
+    static_assert(expr_kind<binary_expr<tag::minus, binary_expr<tag::plus, V, AX>, binary_expr<tag::multiplies, S, AX>>>::value == 2, "");
+    CHECK(true);
+}
+
+TEST_CASE(partition_and_util) {
+    CHECK_EQUAL(alignup(17), size_t(32));
+    CHECK_EQUAL(nextpow2(1000), size_t(1024));
+    std::vector<size_t> part = {0, 16, 48, 100};
+    CHECK_EQUAL(column_owner(0, part), size_t(0));
+    CHECK_EQUAL(column_owner(16, part), size_t(1));
+    CHECK_EQUAL(column_owner(99, part), size_t(2));
+    std::vector<backend::command_queue> one(1), eight(8);
+    CHECK_EQUAL(partition(1000, one).back(), size_t(1000));
+    auto p = partition(134217728, eight);
+    for (size_t d = 0; d <= 8; ++d) CHECK_EQUAL(p[d], size_t(16777216) * d);
+    p = partition(1000, eight);
+    for (size_t d = 1; d < 8; ++d) CHECK(p[d] % 16 == 0 && p[d] >= p[d - 1]);
+    bool thrown = false;
+    try { precondition(false, "x"); } catch (const std::runtime_error &) { thrown = true; }
+    CHECK(thrown);
+}
+
+TEST_CASE(type_names) {
+    CHECK_EQUAL(type_name<double>(), std::string("double"));
+    CHECK_EQUAL(type_name<size_t>(), std::string("ulong"));
+    CHECK_EQUAL(type_name<cl_uint>(), std::string("uint"));
+    CHECK_EQUAL(type_name<int *>(), std::string("int *"));
+    CHECK_EQUAL(type_name<global_ptr<const double>>(), std::string("const double *"));
+}
+
+TEST_CASE(broken_source_raises_vex_error_with_log) {
+    bool thrown = false;
+    try { backend::check_sources("extern \"C\" __global__ void k(int *x) { x[0] = undeclared_symbol; }"); }
+    catch (const vex::error &e) { thrown = std::string(e.what()).find("undeclared_symbol") != std::string::npos; }
+    CHECK(thrown);
+}

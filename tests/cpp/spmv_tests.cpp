@@ -1,0 +1,191 @@
+// GPU: vex::SpMat and vex::sparse::* against a host recomputation, as the
+// reference's tests/spmv.cpp:10-260 and tests/sparse_matrices.cpp:66-237 do,
+// on the 2-"device" context (partitioning + ghost exchange are exercised).
+#include "vex_test.hpp"
+
+template <class R, class C>
+std::vector<double> host_spmv(const std::vector<R> &row, const std::vector<C> &col, const std::vector<double> &val,
+        const std::vector<double> &x) {
+    std::vector<double> y(row.size() - 1);
+    for (size_t i = 0; i + 1 < row.size(); ++i) {                  // tests/spmv.cpp:28-32
+        double s = 0;
+        for (size_t j = row[i]; j < row[i + 1]; ++j) s += val[j] * x[col[j]];
+        y[i] = s;
+    }
+    return y;
+}
+
+TEST_CASE(spmv_square_multi_device) {                                // spmv.cpp:10-59
+    const size_t n = 1024;
+    std::vector<size_t> row, col; std::vector<double> val;
+    random_matrix(n, n, 16, row, col, val);
+    std::vector<double> x = random_vector<double>(n);
+    auto want = host_spmv(row, col, val, x);
+    vex::SpMat<double> A(ctx, n, n, row.data(), col.data(), val.data());
+    CHECK(A.rows() == n && A.cols() == n && A.nonzeros() == val.size());
+    vex::vector<double> X(ctx, x), Y(ctx, n);
+    Y = A * X;
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, want[i], 1e-8); });
+    Y = A * X; Y -= A * X;
+    check_sample(Y, [&](size_t, double v) { CHECK_SMALL(v, 1e-8); });
+    Y = 1; Y += 42 * (A * X);
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, 1 + 42 * want[i], 1e-8); });
+    Y = X + A * X;
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, x[i] + want[i], 1e-8); });
+    Y = X - 2 * (A * X) + A * X;
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, x[i] - want[i], 1e-7); });
+    Y = -(A * X);
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, -want[i], 1e-8); });
+    // every row, not a sample
+    Y = A * X;
+    std::vector<double> got(n); vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], want[i], 1e-8);
+}
+
+TEST_CASE(spmv_nonsquare_and_index_types) {                          // spmv.cpp:61-114
+    const size_t n = 1024, m = 2 * n;
+    std::vector<size_t> row; std::vector<int> col; std::vector<double> val;
+    random_matrix(n, m, 16, row, col, val);
+    std::vector<double> x = random_vector<double>(m);
+    auto want = host_spmv(row, col, val, x);
+    vex::SpMat<double, int> A(ctx, n, m, row.data(), col.data(), val.data());
+    vex::vector<double> X(ctx, x), Y(ctx, n);
+    Y = A * X;
+    std::vector<double> got(n); vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], want[i], 1e-8);
+    std::vector<unsigned> row_u(row.begin(), row.end());
+    vex::SpMat<double, int, unsigned> B(ctx, n, m, row_u.data(), col.data(), val.data());
+    Y = B * X;
+    vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], want[i], 1e-8);
+}
+
+TEST_CASE(spmv_empty_rows) {                                         // spmv.cpp:116-146
+    const size_t n = 1024, non_empty = 256;
+    std::vector<size_t> row, col; std::vector<double> val;
+    random_matrix(non_empty, n, 16, row, col, val);
+    while (row.size() < n + 1) row.push_back(row.back());
+    std::vector<double> x = random_vector<double>(n);
+    auto want = host_spmv(row, col, val, x);
+    vex::SpMat<double> A(ctx, n, n, row.data(), col.data(), val.data());
+    vex::vector<double> X(ctx, x), Y(ctx, n);
+    Y = 77; Y = A * X;                                               // empty parts zero-fill on SET
+    std::vector<double> got(n); vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], want[i], 1e-8);
+}
+
+static void poisson(size_t n, std::vector<size_t> &row, std::vector<unsigned> &col, std::vector<double> &val) {
+    const double h2i = (n - 1) * (n - 1);                            // examples/benchmark.cpp:364-415
+    row.assign(1, 0); col.clear(); val.clear();
+    for (size_t k = 0, idx = 0; k < n; k++) for (size_t j = 0; j < n; j++) for (size_t i = 0; i < n; i++, idx++) {
+        if (i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1) {
+            col.push_back(idx); val.push_back(1); row.push_back(row.back() + 1);
+        } else {
+            const long off[] = {-(long)(n * n), -(long)n, -1, 0, 1, (long)n, (long)(n * n)};
+            for (int q = 0; q < 7; ++q) { col.push_back(idx + off[q]); val.push_back(q == 3 ? 6 * h2i : -h2i); }
+            row.push_back(row.back() + 7);
+        }
+    }
+}
+
+TEST_CASE(spmv_poisson_with_ghost_planes) {                          // spmv.cpp:148-231 grid, SpMat instead of CCSR
+    const size_t n = 32, N = n * n * n;
+    std::vector<size_t> row; std::vector<unsigned> col; std::vector<double> val;
+    poisson(n, row, col, val);
+    std::vector<double> x = random_vector<double>(N);
+    auto want = host_spmv(row, col, val, x);
+    vex::SpMat<double, unsigned> A(ctx, N, N, row.data(), col.data(), val.data());
+    vex::vector<double> X(ctx, x), Y(ctx, N);
+    Y = A * X;
+    std::vector<double> got(N); vex::copy(Y, got);
+    double h2i = (n - 1) * (n - 1);
+    for (size_t i = 0; i < N; ++i) CHECK_SMALL(got[i] - want[i], 1e-10 * 12 * h2i);
+    for (int rep = 0; rep < 5; ++rep) Y += A * X;                    // repeated products reuse the exchange buffers
+    vex::copy(Y, got);
+    for (size_t i = 0; i < N; i += 17) CHECK_SMALL(got[i] - 6 * want[i], 1e-9 * 12 * h2i);
+}
+
+TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp:233-260
+    const size_t n = 1024;
+    std::vector<vex::command_queue> queue(1, ctx.queue(0));
+    std::vector<size_t> row, col; std::vector<double> val;
+    random_matrix(n, n, 16, row, col, val);
+    std::vector<double> x = random_vector<double>(n);
+    auto want = host_spmv(row, col, val, x);
+    vex::SpMat<double> A(queue, n, n, row.data(), col.data(), val.data());
+    vex::vector<double> X(queue, x), Y(queue, n);
+    Y = sin(vex::make_inline(A * X));
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, std::sin(want[i]), 1e-8); });
+    Y = X + 2 * vex::make_inline(A * X);
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, x[i] + 2 * want[i], 1e-8); });
+}
+
+TEST_CASE(sparse_csr_ell_matrix_single_queue) {                      // sparse_matrices.cpp:66-151
+    const size_t n = 1024;
+    std::vector<vex::command_queue> queue(1, ctx.queue(0));
+    std::vector<int> row, col; std::vector<double> val;
+    random_matrix(n, n, 16, row, col, val);
+    std::vector<double> x = random_vector<double>(n);
+    auto want = host_spmv(row, col, val, x);
+    vex::vector<double> X(queue, x), Y(queue, n);
+    {
+        vex::sparse::csr<double> A(queue, n, n, row, col, val);
+        Y = A * X;
+        check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, want[i], 1e-8); });
+        Y = X + A * (X * 2);                                         // x operand is an expression
+        check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, x[i] + 2 * want[i], 1e-8); });
+    }
+    {
+        vex::sparse::ell<double> A(queue, n, n, row, col, val);
+        CHECK(A.width() > 0 && A.width() <= 15);
+        Y = A * X;
+        std::vector<double> got(n); vex::copy(Y, got);
+        for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], want[i], 1e-8);
+    }
+    {
+        vex::sparse::matrix<double> A(queue, n, n, row, col, val);
+        Y = 3 * (A * X) - X;
+        check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, 3 * want[i] - x[i], 1e-8); });
+        vex::Reductor<double, vex::SUM> sum(queue);
+        double s = 0; for (size_t i = 0; i < n; ++i) s += x[i] * want[i];
+        CHECK_CLOSE(sum(X * (A * X)), s, 1e-8);                      // product inside a reduction
+    }
+}
+
+TEST_CASE(sparse_distributed_tridiagonal_all_rows) {                 // sparse_matrices.cpp:153-193
+    const size_t n = 1024;
+    std::vector<int> row(1, 0), col; std::vector<double> val;
+    for (size_t i = 0; i < n; ++i) {
+        if (i > 0) { col.push_back(i - 1); val.push_back(-1); }
+        col.push_back(i); val.push_back(2);
+        if (i + 1 < n) { col.push_back(i + 1); val.push_back(-1); }
+        row.push_back(col.size());
+    }
+    std::vector<double> x = random_vector<double>(n);
+    auto want = host_spmv(row, col, val, x);
+    vex::sparse::distributed<vex::sparse::ell<double>> A(ctx, n, n, row, col, val);
+    vex::vector<double> X(ctx, x), Y(ctx, n);
+    Y = A * X;
+    std::vector<double> got(n); vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], want[i], 1e-8);
+    Y = X - A * X;
+    vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_SMALL(got[i] - (x[i] - want[i]), 1e-12);
+    vex::sparse::distributed<vex::sparse::matrix<double>> B(ctx, n, n, row, col, val);
+    Y = B * (2 * X);                                                 // expression operand on several devices
+    vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], 2 * want[i], 1e-8);
+}
+
+TEST_CASE(sparse_distributed_single_queue_random) {                  // sparse_matrices.cpp:195-237
+    const size_t n = 1024;
+    std::vector<vex::command_queue> queue(1, ctx.queue(0));
+    std::vector<int> row, col; std::vector<double> val;
+    random_matrix(n, n, 16, row, col, val);
+    std::vector<double> x = random_vector<double>(n);
+    auto want = host_spmv(row, col, val, x);
+    vex::sparse::distributed<vex::sparse::csr<double>> A(queue, n, n, row, col, val);
+    vex::vector<double> X(queue, x), Y(queue, n);
+    Y = A * X;
+    check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, want[i], 1e-8); });
+}

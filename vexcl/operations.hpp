@@ -1,0 +1,512 @@
+#ifndef VEXCL_OPERATIONS_HPP
+#define VEXCL_OPERATIONS_HPP
+// The expression engine (reference: vexcl/operations.hpp, 2 326 lines on
+// Boost.Proto).  Re-designed as plain C++17 expression templates: every node is
+// a small value type that knows how to
+//     preamble()    emit the device functions it needs          (operations.hpp:1010-1124)
+//     params()      declare its kernel parameters                (:146-165, kernel_param_declaration)
+//     local_init()  emit per-element statements before the expression (:166-190, local_terminal_init)
+//     emit()        print its part of the expression text        (:1209-1354, vector_expr_context)
+//     set_args()    push its kernel arguments for one device     (:1356-1409, kernel_arg_setter)
+//     get_props()   report queue list / partition / size         (:1411-1460, expression_properties)
+// Terminals are numbered in traversal order, lhs first, exactly as the
+// reference does (prm_1, prm_2, ...), so generated kernels have the shape of
+// SURVEY appendix A.1 and are cached per expression TYPE per context.
+#include <set>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <vector>
+
+#include "backend.hpp"
+#include "cache.hpp"
+
+namespace vex {
+
+/// Assignment operators (operations.hpp:63-96).
+namespace assign {
+#define VEXCL_ASSIGN_OP(name, op) struct name { static std::string string() { return #op; } }
+    VEXCL_ASSIGN_OP(SET, =);  VEXCL_ASSIGN_OP(ADD, +=); VEXCL_ASSIGN_OP(SUB, -=);
+    VEXCL_ASSIGN_OP(MUL, *=); VEXCL_ASSIGN_OP(DIV, /=); VEXCL_ASSIGN_OP(MOD, %=);
+    VEXCL_ASSIGN_OP(AND, &=); VEXCL_ASSIGN_OP(OR, |=);  VEXCL_ASSIGN_OP(XOR, ^=);
+    VEXCL_ASSIGN_OP(LSH, <<=); VEXCL_ASSIGN_OP(RSH, >>=);
+#undef VEXCL_ASSIGN_OP
+}
+
+namespace detail {
+
+// ---- traversal contexts -----------------------------------------------------
+struct gen_context {
+    backend::source_generator &src;
+    const backend::command_queue &queue;
+    std::string prefix;
+    int pos;
+    std::set<std::string> own_seen;
+    std::set<std::string> &seen;    // functions / tagged terminals already handled in this pass
+    gen_context(backend::source_generator &s, const backend::command_queue &q, const std::string &p = "prm")
+        : src(s), queue(q), prefix(p), pos(0), seen(own_seen) {}
+    /// Child context with its own numbering (tagged terminals, the x operand of a sparse product).
+    gen_context(gen_context &parent, const std::string &p)
+        : src(parent.src), queue(parent.queue), prefix(p), pos(0), seen(parent.seen) {}
+    gen_context(const gen_context &) = delete;
+    std::string next() { std::ostringstream n; n << prefix << "_" << ++pos; return n.str(); }
+};
+
+struct arg_context {
+    backend::kernel &krn;
+    unsigned device;
+    size_t offset;                  // start of this device's partition
+    std::set<std::string> own_seen;
+    std::set<std::string> &seen;
+    int pos;
+    arg_context(backend::kernel &k, unsigned d, size_t off) : krn(k), device(d), offset(off), seen(own_seen), pos(0) {}
+    arg_context(arg_context &parent) : krn(parent.krn), device(parent.device), offset(parent.offset), seen(parent.seen), pos(0) {}
+    std::string next(const std::string &prefix = "prm") { std::ostringstream n; n << prefix << "_" << ++pos; return n.str(); }
+};
+
+struct prop_context {
+    std::vector<backend::command_queue> queue;
+    std::vector<size_t> part;
+    size_t size;
+    prop_context() : size(0) {}
+    bool empty() const { return queue.empty(); }
+};
+
+// ---- node classification ------------------------------------------------------
+struct expression_base {};
+template <class T> struct is_expr : std::is_base_of<expression_base, typename std::decay<T>::type> {};
+template <class T> struct is_scalar : std::is_arithmetic<typename std::decay<T>::type> {};
+
+// kind: 0 = vector expression, 1 = additive transform only (A*x terms),
+//       2 = mix of both joined by + / -, -1 = not assignable
+template <class E, class Enable = void> struct expr_kind : std::integral_constant<int, 0> {};
+
+/// Scalar literal: a value parameter, never baked into the source
+/// (operations.hpp:167-175,228-236).
+template <class T>
+struct scalar_terminal : expression_base {
+    typedef T value_type;
+    T v;
+    explicit scalar_terminal(T v) : v(v) {}
+    void preamble(gen_context &c) const { c.next(); }
+    void params(gen_context &c) const { c.src.template parameter<T>(c.next()); }
+    void local_init(gen_context &c) const { c.next(); }
+    void emit(gen_context &c) const { c.src << c.next(); }
+    void set_args(arg_context &a) const { a.next(); a.krn.push_arg(v); }
+    void get_props(prop_context &) const {}
+};
+
+// how an operand is stored inside a node: scalars by value in a
+// scalar_terminal, light nodes by value, heavy objects (vex::vector) through
+// the reference type they nominate
+template <class T, class Enable = void> struct as_expr;
+template <class T> struct as_expr<T, typename std::enable_if<is_scalar<T>::value>::type> {
+    typedef scalar_terminal<typename std::decay<T>::type> type;
+    static type get(const T &t) { return type(t); }
+};
+template <class T, class = void> struct has_ref_type : std::false_type {};
+template <class T> struct has_ref_type<T, typename std::enable_if<!std::is_void<typename T::expr_ref_type>::value>::type> : std::true_type {};
+template <class T> struct as_expr<T, typename std::enable_if<is_expr<T>::value && has_ref_type<typename std::decay<T>::type>::value>::type> {
+    typedef typename std::decay<T>::type::expr_ref_type type;
+    static type get(const T &t) { return type(t); }
+};
+template <class T> struct as_expr<T, typename std::enable_if<is_expr<T>::value && !has_ref_type<typename std::decay<T>::type>::value>::type> {
+    typedef typename std::decay<T>::type type;
+    static const type &get(const T &t) { return t; }
+};
+template <class T> using as_expr_t = typename as_expr<T>::type;
+
+template <class T> struct is_operand : std::integral_constant<bool, is_expr<T>::value || is_scalar<T>::value> {};
+
+// ---- operator tags -----------------------------------------------------------
+namespace tag {
+#define VEXCL_TAG(name, op) struct name { static const char *str() { return #op; } }
+    VEXCL_TAG(plus, +); VEXCL_TAG(minus, -); VEXCL_TAG(multiplies, *); VEXCL_TAG(divides, /); VEXCL_TAG(modulus, %);
+    VEXCL_TAG(shift_left, <<); VEXCL_TAG(shift_right, >>);
+    VEXCL_TAG(less, <); VEXCL_TAG(greater, >); VEXCL_TAG(less_equal, <=); VEXCL_TAG(greater_equal, >=);
+    VEXCL_TAG(equal_to, ==); VEXCL_TAG(not_equal_to, !=);
+    VEXCL_TAG(logical_and, &&); VEXCL_TAG(logical_or, ||);
+    VEXCL_TAG(bitwise_and, &); VEXCL_TAG(bitwise_or, |); VEXCL_TAG(bitwise_xor, ^);
+    VEXCL_TAG(negate, -); VEXCL_TAG(unary_plus, +); VEXCL_TAG(logical_not, !); VEXCL_TAG(complement, ~);
+#undef VEXCL_TAG
+    template <class T> struct is_comparison : std::false_type {};
+    template <> struct is_comparison<less> : std::true_type {};
+    template <> struct is_comparison<greater> : std::true_type {};
+    template <> struct is_comparison<less_equal> : std::true_type {};
+    template <> struct is_comparison<greater_equal> : std::true_type {};
+    template <> struct is_comparison<equal_to> : std::true_type {};
+    template <> struct is_comparison<not_equal_to> : std::true_type {};
+    template <> struct is_comparison<logical_and> : std::true_type {};
+    template <> struct is_comparison<logical_or> : std::true_type {};
+}
+
+// result types (operations.hpp:1723-1812): common type for arithmetic,
+// cl_long for comparisons and logical operators, left type for shifts
+template <class Tag, class L, class R, class Enable = void>
+struct binary_result { typedef typename std::common_type<L, R>::type type; };
+template <class Tag, class L, class R>
+struct binary_result<Tag, L, R, typename std::enable_if<tag::is_comparison<Tag>::value>::type> { typedef cl_long type; };
+template <class L, class R> struct binary_result<tag::shift_left, L, R, void> { typedef L type; };
+template <class L, class R> struct binary_result<tag::shift_right, L, R, void> { typedef L type; };
+
+template <class Tag, class L, class R>
+struct binary_expr : expression_base {
+    typedef typename binary_result<Tag, typename L::value_type, typename R::value_type>::type value_type;
+    typedef Tag tag_type; typedef L left_type; typedef R right_type;
+    L l; R r;
+    binary_expr(const L &l, const R &r) : l(l), r(r) {}
+    void preamble(gen_context &c) const { l.preamble(c); r.preamble(c); }
+    void params(gen_context &c) const { l.params(c); r.params(c); }
+    void local_init(gen_context &c) const { l.local_init(c); r.local_init(c); }
+    void emit(gen_context &c) const { c.src << "( "; l.emit(c); c.src << " " << Tag::str() << " "; r.emit(c); c.src << " )"; }
+    void set_args(arg_context &a) const { l.set_args(a); r.set_args(a); }
+    void get_props(prop_context &p) const { l.get_props(p); r.get_props(p); }
+};
+
+template <class Tag, class A>
+struct unary_expr : expression_base {
+    typedef typename std::conditional<std::is_same<Tag, tag::logical_not>::value, cl_long, typename A::value_type>::type value_type;
+    typedef Tag tag_type; typedef A arg_type;
+    A a;
+    explicit unary_expr(const A &a) : a(a) {}
+    void preamble(gen_context &c) const { a.preamble(c); }
+    void params(gen_context &c) const { a.params(c); }
+    void local_init(gen_context &c) const { a.local_init(c); }
+    void emit(gen_context &c) const { c.src << "( " << Tag::str() << "( "; a.emit(c); c.src << " ) )"; }
+    void set_args(arg_context &s) const { a.set_args(s); }
+    void get_props(prop_context &p) const { a.get_props(p); }
+};
+
+// ---- tuple helpers for n-ary nodes -------------------------------------------
+template <class Tuple, class F, size_t... I>
+void tuple_for_each_impl(const Tuple &t, F &&f, std::index_sequence<I...>) {
+    int dummy[] = {0, (f(std::get<I>(t), I), 0)...};
+    (void)dummy;
+}
+template <class... T, class F>
+void tuple_for_each(const std::tuple<T...> &t, F &&f) {
+    tuple_for_each_impl(t, std::forward<F>(f), std::index_sequence_for<T...>());
+}
+
+/// Call of a device function: user functions (VEX_FUNCTION) and builtins.
+/// F provides name(), and for user functions define(source_generator&).
+template <class F, class R, class... Args>
+struct function_call : expression_base {
+    typedef R value_type;
+    std::tuple<Args...> args;
+    explicit function_call(const Args &...a) : args(a...) {}
+    void preamble(gen_context &c) const {
+        F::preamble(c);
+        tuple_for_each(args, [&c](const auto &a, size_t) { a.preamble(c); });
+    }
+    void params(gen_context &c) const { tuple_for_each(args, [&c](const auto &a, size_t) { a.params(c); }); }
+    void local_init(gen_context &c) const { tuple_for_each(args, [&c](const auto &a, size_t) { a.local_init(c); }); }
+    void emit(gen_context &c) const {
+        c.src << F::name() << "( ";
+        tuple_for_each(args, [&c](const auto &a, size_t i) { if (i) c.src << ", "; a.emit(c); });
+        c.src << " )";
+    }
+    void set_args(arg_context &s) const { tuple_for_each(args, [&s](const auto &a, size_t) { a.set_args(s); }); }
+    void get_props(prop_context &p) const { tuple_for_each(args, [&p](const auto &a, size_t) { a.get_props(p); }); }
+};
+
+/// ( c ? a : b ) -- vex::if_else (operations.hpp ternary, tests/vector_arithmetics.cpp:238-250).
+template <class C, class A, class B>
+struct ternary_expr : expression_base {
+    typedef typename std::common_type<typename A::value_type, typename B::value_type>::type value_type;
+    C c_; A a; B b;
+    ternary_expr(const C &c, const A &a, const B &b) : c_(c), a(a), b(b) {}
+    void preamble(gen_context &c) const { c_.preamble(c); a.preamble(c); b.preamble(c); }
+    void params(gen_context &c) const { c_.params(c); a.params(c); b.params(c); }
+    void local_init(gen_context &c) const { c_.local_init(c); a.local_init(c); b.local_init(c); }
+    void emit(gen_context &c) const { c.src << "( "; c_.emit(c); c.src << " ? "; a.emit(c); c.src << " : "; b.emit(c); c.src << " )"; }
+    void set_args(arg_context &s) const { c_.set_args(s); a.set_args(s); b.set_args(s); }
+    void get_props(prop_context &p) const { c_.get_props(p); a.get_props(p); b.get_props(p); }
+};
+
+// ---- additive transforms: A*x terms (operations.hpp:759-776) ------------------
+struct additive_transform_base : expression_base {};
+
+template <class M, class V>
+struct additive_operator : additive_transform_base {
+    typedef typename V::value_type value_type;
+    const M &A; const V &x;
+    additive_operator(const M &A, const V &x) : A(A), x(x) {}
+    template <class W> void apply(W &y, double scale, bool append) const {
+        A.apply(x, y, static_cast<typename M::scalar_type>(scale), append);
+    }
+    // never part of generated source
+    void preamble(gen_context &) const {} void params(gen_context &) const {} void local_init(gen_context &) const {}
+    void emit(gen_context &) const {} void set_args(arg_context &) const {} void get_props(prop_context &) const {}
+};
+
+template <class E> struct is_transform : std::is_base_of<additive_transform_base, E> {};
+template <class E> struct is_scalar_terminal : std::false_type {};
+template <class T> struct is_scalar_terminal<scalar_terminal<T>> : std::true_type {};
+
+template <class M, class V> struct expr_kind<additive_operator<M, V>> : std::integral_constant<int, 1> {};
+
+constexpr int join_additive(int l, int r) { return (l < 0 || r < 0) ? -1 : (l == r && l != 2) ? l : 2; }
+constexpr int join_product(int l, int r, bool lscalar, bool rscalar) {
+    return (l == 0 && r == 0) ? 0 : ((l == 1 && rscalar) || (r == 1 && lscalar)) ? 1 : -1;
+}
+constexpr int join_other(int l, int r) { return (l == 0 && r == 0) ? 0 : -1; }
+
+template <class L, class R> struct expr_kind<binary_expr<tag::plus, L, R>>
+    : std::integral_constant<int, join_additive(expr_kind<L>::value, expr_kind<R>::value)> {};
+template <class L, class R> struct expr_kind<binary_expr<tag::minus, L, R>>
+    : std::integral_constant<int, join_additive(expr_kind<L>::value, expr_kind<R>::value)> {};
+template <class L, class R> struct expr_kind<binary_expr<tag::multiplies, L, R>>
+    : std::integral_constant<int, join_product(expr_kind<L>::value, expr_kind<R>::value,
+            is_scalar_terminal<L>::value, is_scalar_terminal<R>::value)> {};
+template <class Tag, class L, class R> struct expr_kind<binary_expr<Tag, L, R>>
+    : std::integral_constant<int, join_other(expr_kind<L>::value, expr_kind<R>::value)> {};
+template <class A> struct expr_kind<unary_expr<tag::negate, A>> : std::integral_constant<int, expr_kind<A>::value> {};
+template <class Tag, class A> struct expr_kind<unary_expr<Tag, A>>
+    : std::integral_constant<int, expr_kind<A>::value == 0 ? 0 : -1> {};
+
+template <class... A> struct all_vector_kind : std::true_type {};
+template <class H, class... T> struct all_vector_kind<H, T...>
+    : std::integral_constant<bool, expr_kind<H>::value == 0 && all_vector_kind<T...>::value> {};
+template <class F, class R, class... A> struct expr_kind<function_call<F, R, A...>>
+    : std::integral_constant<int, all_vector_kind<A...>::value ? 0 : -1> {};
+template <class C, class A, class B> struct expr_kind<ternary_expr<C, A, B>>
+    : std::integral_constant<int, all_vector_kind<C, A, B>::value ? 0 : -1> {};
+
+/// Applies every A*x term of an additive expression to y
+/// (operations.hpp:1475-1576: negations pushed to the leaves, first term SET or ADD, rest ADD).
+template <class W, class E>
+void apply_transforms(W &y, const E &e, double scale, bool &append) {
+    if constexpr (expr_kind<E>::value == 0) {
+        (void)y; (void)e; (void)scale; (void)append;             // vector part: handled by the caller
+    } else if constexpr (is_transform<E>::value) {
+        e.apply(y, scale, append);
+        append = true;
+    } else if constexpr (std::is_same<typename E::tag_type, tag::negate>::value) {
+        apply_transforms(y, e.a, -scale, append);
+    } else if constexpr (std::is_same<typename E::tag_type, tag::plus>::value) {
+        apply_transforms(y, e.l, scale, append);
+        apply_transforms(y, e.r, scale, append);
+    } else if constexpr (std::is_same<typename E::tag_type, tag::minus>::value) {
+        apply_transforms(y, e.l, scale, append);
+        apply_transforms(y, e.r, -scale, append);
+    } else {                                                       // scalar * transform (is_scalable)
+        if constexpr (is_scalar_terminal<typename E::left_type>::value)
+            apply_transforms(y, e.r, scale * static_cast<double>(e.l.v), append);
+        else
+            apply_transforms(y, e.l, scale * static_cast<double>(e.r.v), append);
+    }
+}
+
+/// The expression with its A*x terms removed (operations.hpp:514-564 extractors).
+template <class E>
+auto vector_part(const E &e) {
+    static_assert(expr_kind<E>::value == 0 || expr_kind<E>::value == 2, "no vector part");
+    if constexpr (expr_kind<E>::value == 0) {
+        return e;
+    } else if constexpr (std::is_same<typename E::tag_type, tag::negate>::value) {
+        auto v = vector_part(e.a);
+        return unary_expr<tag::negate, decltype(v)>(v);
+    } else {
+        typedef typename E::left_type L; typedef typename E::right_type R;
+        constexpr bool is_minus = std::is_same<typename E::tag_type, tag::minus>::value;
+        if constexpr (expr_kind<L>::value == 1) {
+            auto v = vector_part(e.r);
+            if constexpr (is_minus) return unary_expr<tag::negate, decltype(v)>(v); else return v;
+        } else if constexpr (expr_kind<R>::value == 1) {
+            return vector_part(e.l);
+        } else {
+            auto a = vector_part(e.l); auto b = vector_part(e.r);
+            return binary_expr<typename E::tag_type, decltype(a), decltype(b)>(a, b);
+        }
+    }
+}
+
+// ---- the fused elementwise kernel (operations.hpp:1818-1897) -------------------
+template <class OP, class LHS, class RHS>
+void assign_expression(const LHS &lhs, const RHS &rhs,
+        const std::vector<backend::command_queue> &queue, const std::vector<size_t> &part)
+{
+    static_assert(expr_kind<RHS>::value == 0, "expression contains terms that cannot be fused into a kernel");
+    static kernel_cache cache;
+
+    for (unsigned d = 0; d < queue.size(); ++d) {
+        size_t psize = part[d + 1] - part[d];
+        if (!psize) continue;
+
+        auto kernel = cache.find(queue[d]);
+        if (kernel == cache.end()) {
+            backend::source_generator source(queue[d]);
+            { gen_context c(source, queue[d]); lhs.preamble(c); rhs.preamble(c); }
+            source.begin_kernel("vexcl_vector_kernel");
+            source.begin_kernel_parameters();
+            source.template parameter<size_t>("n");
+            { gen_context c(source, queue[d]); lhs.params(c); rhs.params(c); }
+            source.end_kernel_parameters();
+            source.grid_stride_loop().open("{");
+            { gen_context c(source, queue[d]); lhs.local_init(c); rhs.local_init(c); }
+            source.new_line();
+            {
+                gen_context c(source, queue[d]);
+                lhs.emit(c);
+                source << " " << OP::string() << " ";
+                rhs.emit(c);
+                source << ";";
+            }
+            source.close("}");
+            source.end_kernel();
+            kernel = cache.insert(queue[d], backend::kernel(queue[d], source.str(), "vexcl_vector_kernel"));
+        }
+
+        backend::kernel &krn = kernel->second;
+        krn.push_arg(psize);
+        arg_context a(krn, d, part[d]);
+        lhs.set_args(a);
+        rhs.set_args(a);
+        krn(queue[d]);
+    }
+}
+
+/// Source text of the kernel an assignment would generate (for tests and
+/// VEXCL_SHOW_KERNELS-style inspection).
+template <class OP, class LHS, class RHS>
+std::string assignment_source(const LHS &lhs, const RHS &rhs, const backend::command_queue &q) {
+    backend::source_generator source(q);
+    { gen_context c(source, q); lhs.preamble(c); rhs.preamble(c); }
+    source.begin_kernel("vexcl_vector_kernel");
+    source.begin_kernel_parameters();
+    source.template parameter<size_t>("n");
+    { gen_context c(source, q); lhs.params(c); rhs.params(c); }
+    source.end_kernel_parameters();
+    source.grid_stride_loop().open("{");
+    { gen_context c(source, q); lhs.local_init(c); rhs.local_init(c); }
+    source.new_line();
+    { gen_context c(source, q); lhs.emit(c); source << " " << OP::string() << " "; rhs.emit(c); source << ";"; }
+    source.close("}");
+    source.end_kernel();
+    return source.str();
+}
+
+/// Assignment of any assignable expression to an lvalue terminal:
+/// fused kernel for the vector part, SpMat::apply for every A*x term
+/// (vector.hpp:698-801).
+template <class OP, class LHS, class W, class Expr>
+void assign_any(const LHS &lhs, W &target, const Expr &expr,
+        const std::vector<backend::command_queue> &queue, const std::vector<size_t> &part)
+{
+    constexpr int kind = expr_kind<Expr>::value;
+    static_assert(kind >= 0, "this expression cannot be assigned: A*x terms may only be added, subtracted or scaled");
+    if constexpr (kind == 0) {
+        (void)target;
+        assign_expression<OP>(lhs, expr, queue, part);
+    } else {
+        constexpr bool set = std::is_same<OP, assign::SET>::value;
+        constexpr bool add = std::is_same<OP, assign::ADD>::value;
+        constexpr bool sub = std::is_same<OP, assign::SUB>::value;
+        static_assert(set || add || sub, "A*x terms support only =, += and -=");
+        bool append = !set;
+        if constexpr (kind == 2) {
+            assign_expression<OP>(lhs, vector_part(expr), queue, part);
+            append = true;
+        }
+        apply_transforms(target, expr, sub ? -1.0 : 1.0, append);
+    }
+}
+
+} // namespace detail
+
+// ---- operators ----------------------------------------------------------------
+// Defined in vex::detail, where the node types live (ADL), and re-exported to vex::
+// for operands that are vex::vector / tagged terminals.
+namespace detail {
+#define VEXCL_BINARY_OPERATOR(tagname, op)                                                                     \
+    template <class L, class R>                                                                                \
+    typename std::enable_if<                                                                                   \
+        (is_expr<L>::value || is_expr<R>::value) &&                                            \
+        is_operand<L>::value && is_operand<R>::value,                                          \
+        binary_expr<tag::tagname, as_expr_t<L>, as_expr_t<R>>>::type           \
+    operator op(const L &l, const R &r) {                                                                      \
+        return binary_expr<tag::tagname, as_expr_t<L>, as_expr_t<R>>(          \
+                as_expr<L>::get(l), as_expr<R>::get(r));                                       \
+    }
+
+VEXCL_BINARY_OPERATOR(plus, +)
+VEXCL_BINARY_OPERATOR(minus, -)
+VEXCL_BINARY_OPERATOR(multiplies, *)
+VEXCL_BINARY_OPERATOR(divides, /)
+VEXCL_BINARY_OPERATOR(modulus, %)
+VEXCL_BINARY_OPERATOR(shift_left, <<)
+VEXCL_BINARY_OPERATOR(shift_right, >>)
+VEXCL_BINARY_OPERATOR(less, <)
+VEXCL_BINARY_OPERATOR(greater, >)
+VEXCL_BINARY_OPERATOR(less_equal, <=)
+VEXCL_BINARY_OPERATOR(greater_equal, >=)
+VEXCL_BINARY_OPERATOR(equal_to, ==)
+VEXCL_BINARY_OPERATOR(not_equal_to, !=)
+VEXCL_BINARY_OPERATOR(logical_and, &&)
+VEXCL_BINARY_OPERATOR(logical_or, ||)
+VEXCL_BINARY_OPERATOR(bitwise_and, &)
+VEXCL_BINARY_OPERATOR(bitwise_or, |)
+VEXCL_BINARY_OPERATOR(bitwise_xor, ^)
+#undef VEXCL_BINARY_OPERATOR
+
+#define VEXCL_UNARY_OPERATOR(tagname, op)                                                                      \
+    template <class A>                                                                                         \
+    typename std::enable_if<is_expr<A>::value,                                                         \
+        unary_expr<tag::tagname, as_expr_t<A>>>::type                                  \
+    operator op(const A &a) {                                                                                  \
+        return unary_expr<tag::tagname, as_expr_t<A>>(as_expr<A>::get(a));     \
+    }
+VEXCL_UNARY_OPERATOR(negate, -)
+VEXCL_UNARY_OPERATOR(unary_plus, +)
+VEXCL_UNARY_OPERATOR(logical_not, !)
+VEXCL_UNARY_OPERATOR(complement, ~)
+#undef VEXCL_UNARY_OPERATOR
+
+/// Elementwise ternary: if_else(cond, a, b).
+template <class C, class A, class B>
+typename std::enable_if<is_operand<C>::value && is_operand<A>::value && is_operand<B>::value &&
+    (is_expr<C>::value || is_expr<A>::value || is_expr<B>::value),
+    ternary_expr<as_expr_t<C>, as_expr_t<A>, as_expr_t<B>>>::type
+if_else(const C &c, const A &a, const B &b) {
+    return ternary_expr<as_expr_t<C>, as_expr_t<A>, as_expr_t<B>>(
+            as_expr<C>::get(c), as_expr<A>::get(a), as_expr<B>::get(b));
+}
+
+} // namespace detail
+
+using detail::operator+;
+using detail::operator-;
+using detail::operator*;
+using detail::operator/;
+using detail::operator%;
+using detail::operator<<;
+using detail::operator>>;
+using detail::operator<;
+using detail::operator>;
+using detail::operator<=;
+using detail::operator>=;
+using detail::operator==;
+using detail::operator!=;
+using detail::operator&&;
+using detail::operator||;
+using detail::operator&;
+using detail::operator|;
+using detail::operator^;
+using detail::operator!;
+using detail::operator~;
+using detail::if_else;
+
+/// Queue list, partitioning and size of an expression (operations.hpp:1411-1460).
+template <class Expr>
+void get_expression_properties(const Expr &expr, std::vector<backend::command_queue> &queue,
+        std::vector<size_t> &part, size_t &size)
+{
+    detail::prop_context p;
+    detail::as_expr<Expr>::get(expr).get_props(p);
+    queue = p.queue; part = p.part; size = p.size;
+}
+
+} // namespace vex
+#endif

@@ -1,0 +1,259 @@
+#ifndef VEXCL_REDUCTOR_HPP
+#define VEXCL_REDUCTOR_HPP
+// vex::Reductor<T, RDC> (reference: vexcl/reductor.hpp:47-280 operations,
+// :302-439 two-stage reduction).  Stage 1 is generated per expression type:
+// per-lane grid-stride accumulation (reductor.hpp:511-564), then a wave-64
+// __shfl_down fold and ONE LDS hop across the workgroup's waves (the reference
+// tree-reduces 1024 -> 1 through LDS with a barrier per level, :371-379).
+// Stage 2 runs on the device too (libvexhip: vexhip_reduce_finish), so each GPU
+// hands back one scalar; the host only combines one value per GPU
+// (the reference folds 8 x CU partials per device on the host, :412-436).
+#include <limits>
+#include <map>
+#include <memory>
+#include "operations.hpp"
+#include "vector.hpp"
+
+namespace vex {
+
+template <class T> struct cl_vec2 { T s[2]; };
+
+/// Summation (reductor.hpp:47-72).
+struct SUM {
+    template <class T> struct impl {
+        typedef T result_type;
+        static const int op = VEXHIP_SUM;
+        static T initial() { return T(); }
+        static std::string device(const std::string &a, const std::string &b) { return a + " + " + b; }
+        T operator()(const T &a, const T &b) const { return a + b; }
+    };
+};
+/// Compensated summation (reductor.hpp:74-80, kernel body :537-564).
+struct SUM_Kahan : SUM {};
+/// Maximum (reductor.hpp:82-104).
+struct MAX {
+    template <class T> struct impl {
+        typedef T result_type;
+        static const int op = VEXHIP_MAX;
+        static T initial() { return std::numeric_limits<T>::lowest(); }
+        static std::string device(const std::string &a, const std::string &b) { return "(" + a + " > " + b + " ? " + a + " : " + b + ")"; }
+        T operator()(const T &a, const T &b) const { return a > b ? a : b; }
+    };
+};
+/// Minimum (reductor.hpp:106-128).
+struct MIN {
+    template <class T> struct impl {
+        typedef T result_type;
+        static const int op = VEXHIP_MIN;
+        static T initial() { return std::numeric_limits<T>::max(); }
+        static std::string device(const std::string &a, const std::string &b) { return "(" + a + " < " + b + " ? " + a + " : " + b + ")"; }
+        T operator()(const T &a, const T &b) const { return a < b ? a : b; }
+    };
+};
+/// Minimum and maximum in one pass (reductor.hpp CombineReductors<MIN, MAX>).
+struct MIN_MAX {};
+
+namespace detail {
+    template <class T> struct reduce_dtype;
+    template <> struct reduce_dtype<double> { static const int value = VEXHIP_F64; };
+    template <> struct reduce_dtype<float> { static const int value = VEXHIP_F32; };
+    template <> struct reduce_dtype<int> { static const int value = VEXHIP_I32; };
+    template <> struct reduce_dtype<unsigned> { static const int value = VEXHIP_U32; };
+    template <> struct reduce_dtype<long> { static const int value = VEXHIP_I64; };
+    template <> struct reduce_dtype<unsigned long> { static const int value = VEXHIP_U64; };
+    template <> struct reduce_dtype<long long> { static const int value = VEXHIP_I64; };
+    template <> struct reduce_dtype<unsigned long long> { static const int value = VEXHIP_U64; };
+
+    template <class T> std::string literal(T v) {
+        std::ostringstream s;
+        s.precision(std::numeric_limits<T>::max_digits10);
+        if (std::is_floating_point<T>::value) s << std::scientific;
+        s << v;
+        return "(" + type_name<T>() + ")(" + s.str() + ")";
+    }
+
+    struct reductor_buffers {
+        backend::device_vector<char> partials, result;
+    };
+}
+
+template <typename ScalarType, class RDC = SUM>
+class Reductor {
+    public:
+        typedef typename std::conditional<std::is_same<RDC, MIN_MAX>::value, cl_vec2<ScalarType>, ScalarType>::type result_type;
+
+        Reductor(const std::vector<backend::command_queue> &queue = current_context().queue()) : queue(queue) {
+            for (const auto &q : this->queue) {
+                int groups = 0, block = 0;
+                backend::check(vexhip_reduce_num_groups(q.device_ordinal(), &groups, &block));
+                auto b = std::make_shared<detail::reductor_buffers>();
+                b->partials = backend::device_vector<char>(q, (size_t)groups * 2 * sizeof(ScalarType));
+                b->result = backend::device_vector<char>(q, 2 * sizeof(ScalarType));
+                bufs.push_back(b);
+                ngroups.push_back(groups);
+            }
+        }
+
+        /// Reduces the expression; blocking, returns a host value (reductor.hpp:302-439).
+        template <class Expr>
+        result_type operator()(const Expr &expr_) const {
+            using namespace detail;
+            typedef as_expr_t<Expr> E;
+            const E &expr = as_expr<Expr>::get(expr_);
+            static_assert(expr_kind<E>::value == 0, "only vector expressions can be reduced");
+
+            prop_context prop;
+            expr.get_props(prop);
+            if (prop.queue.empty()) prop.queue = queue;
+            if (prop.part.empty()) prop.part = vex::partition(prop.size, prop.queue);
+            precondition(prop.queue.size() == queue.size(), "expression and Reductor live on different queue lists");
+            const std::vector<size_t> &part = prop.part;
+
+            static kernel_cache cache;
+            constexpr bool minmax = std::is_same<RDC, MIN_MAX>::value;
+            constexpr int nout = minmax ? 2 : 1;
+            const int op = op_code();
+
+            std::vector<char> active(queue.size(), 0);
+            std::vector<ScalarType> host(queue.size() * 2);
+            for (unsigned d = 0; d < queue.size(); ++d) {
+                size_t psize = part[d + 1] - part[d];
+                if (!psize) continue;
+                active[d] = 1;
+                auto kernel = cache.find(queue[d]);
+                if (kernel == cache.end())
+                    kernel = cache.insert(queue[d], backend::kernel(queue[d], source(expr, queue[d]), "vexcl_reductor_kernel"));
+                backend::kernel &krn = kernel->second;
+                krn.push_arg(psize);
+                arg_context a(krn, d, part[d]);
+                expr.set_args(a);
+                krn.push_arg(bufs[d]->partials.raw());
+                krn.config(ngroups[d], 256);
+                krn(queue[d]);
+                backend::check(vexhip_reduce_finish(queue[d].device_ordinal(), queue[d].raw(), op,
+                            reduce_dtype<ScalarType>::value, bufs[d]->partials.raw(), ngroups[d], bufs[d]->result.raw()));
+                bufs[d]->result.read(queue[d], 0, nout * sizeof(ScalarType), reinterpret_cast<char *>(&host[2 * d]), false);
+            }
+            for (unsigned d = 0; d < queue.size(); ++d) if (active[d]) queue[d].finish();
+            return combine(host, active, std::integral_constant<bool, minmax>());
+        }
+
+    private:
+        std::vector<backend::command_queue> queue;
+        std::vector<std::shared_ptr<detail::reductor_buffers>> bufs;
+        std::vector<int> ngroups;
+
+        static int op_code() {
+            if (std::is_same<RDC, SUM>::value) return VEXHIP_SUM;
+            if (std::is_same<RDC, SUM_Kahan>::value) return VEXHIP_SUM;   // lanes already compensated; fold plainly (reductor.hpp:537-564)
+            if (std::is_same<RDC, MAX>::value) return VEXHIP_MAX;
+            if (std::is_same<RDC, MIN>::value) return VEXHIP_MIN;
+            return VEXHIP_MIN_MAX;
+        }
+
+        ScalarType combine(const std::vector<ScalarType> &h, const std::vector<char> &active, std::false_type) const {
+            typedef typename std::conditional<std::is_same<RDC, SUM_Kahan>::value, SUM, RDC>::type R;
+            typename R::template impl<ScalarType> fn;
+            ScalarType r = R::template impl<ScalarType>::initial();
+            for (unsigned d = 0; d < active.size(); ++d) if (active[d]) r = fn(r, h[2 * d]);
+            return r;
+        }
+        cl_vec2<ScalarType> combine(const std::vector<ScalarType> &h, const std::vector<char> &active, std::true_type) const {
+            cl_vec2<ScalarType> r = {{std::numeric_limits<ScalarType>::max(), std::numeric_limits<ScalarType>::lowest()}};
+            for (unsigned d = 0; d < active.size(); ++d) if (active[d]) {
+                r.s[0] = std::min(r.s[0], h[2 * d]); r.s[1] = std::max(r.s[1], h[2 * d + 1]);
+            }
+            return r;
+        }
+
+        template <class E>
+        static std::string source(const E &expr, const backend::command_queue &q) {
+            using namespace detail;
+            const std::string T = type_name<ScalarType>();
+            constexpr bool minmax = std::is_same<RDC, MIN_MAX>::value;
+            constexpr bool kahan = std::is_same<RDC, SUM_Kahan>::value;
+            backend::source_generator src(q);
+            { gen_context c(src, q); expr.preamble(c); }
+            src.begin_kernel("vexcl_reductor_kernel");
+            src.begin_kernel_parameters();
+            src.template parameter<size_t>("n");
+            { gen_context c(src, q); expr.params(c); }
+            src.template parameter<global_ptr<ScalarType>>("g_odata");
+            src.end_kernel_parameters();
+
+            auto fold = [&](const std::string &a, const std::string &b) -> std::string {
+                if (std::is_same<RDC, MAX>::value) return MAX::impl<ScalarType>::device(a, b);
+                if (std::is_same<RDC, MIN>::value) return MIN::impl<ScalarType>::device(a, b);
+                return SUM::impl<ScalarType>::device(a, b);
+            };
+
+            if (minmax) {
+                src.new_line() << T << " myMin = " << literal(std::numeric_limits<ScalarType>::max())
+                               << ", myMax = " << literal(std::numeric_limits<ScalarType>::lowest()) << ";";
+            } else if (kahan) {
+                src.new_line() << T << " mySum = (" << T << ")0, c = (" << T << ")0;";
+            } else {
+                typedef typename std::conditional<minmax, SUM, RDC>::type R;
+                src.new_line() << T << " mySum = " << literal(R::template impl<ScalarType>::initial()) << ";";
+            }
+            src.grid_stride_loop().open("{");
+            { gen_context c(src, q); expr.local_init(c); }
+            src.new_line() << T << " v = ";
+            { gen_context c(src, q); expr.emit(c); }
+            src << ";";
+            if (minmax) {
+                src.new_line() << "myMin = v < myMin ? v : myMin;";
+                src.new_line() << "myMax = v > myMax ? v : myMax;";
+            } else if (kahan) {
+                src.new_line() << T << " y = v - c;";
+                src.new_line() << T << " t = mySum + y;";
+                src.new_line() << "c = (t - mySum) - y;";
+                src.new_line() << "mySum = t;";
+            } else {
+                src.new_line() << "mySum = " << fold("mySum", "v") << ";";
+            }
+            src.close("}");
+
+            // wave-64 shuffle fold, then one LDS hop across the waves of the workgroup
+            auto wave_fold = [&](const std::string &var, const std::string &kind) {
+                src.new_line() << "for (int o = 32; o > 0; o >>= 1)";
+                src.open("{");
+                src.new_line() << T << " other = __shfl_down(" << var << ", o, 64);";
+                if (kind == "min") src.new_line() << var << " = other < " << var << " ? other : " << var << ";";
+                else if (kind == "max") src.new_line() << var << " = other > " << var << " ? other : " << var << ";";
+                else src.new_line() << var << " = " << fold(var, "other") << ";";
+                src.close("}");
+            };
+            const int nout = minmax ? 2 : 1;
+            src.new_line() << "__shared__ " << T << " sdata[" << 16 * nout << "];";
+            src.new_line() << "const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;";
+            if (minmax) {
+                wave_fold("myMin", "min"); wave_fold("myMax", "max");
+                src.new_line() << "if (lane == 0) { sdata[2 * wave] = myMin; sdata[2 * wave + 1] = myMax; }";
+                src.new_line() << "__syncthreads();";
+                src.new_line() << "if (threadIdx.x == 0)";
+                src.open("{");
+                src.new_line() << "for (int w = 1; w < nwaves; ++w)";
+                src.open("{");
+                src.new_line() << "myMin = sdata[2 * w] < myMin ? sdata[2 * w] : myMin;";
+                src.new_line() << "myMax = sdata[2 * w + 1] > myMax ? sdata[2 * w + 1] : myMax;";
+                src.close("}");
+                src.new_line() << "g_odata[2 * blockIdx.x] = myMin; g_odata[2 * blockIdx.x + 1] = myMax;";
+                src.close("}");
+            } else {
+                wave_fold("mySum", "fold");
+                src.new_line() << "if (lane == 0) sdata[wave] = mySum;";
+                src.new_line() << "__syncthreads();";
+                src.new_line() << "if (threadIdx.x == 0)";
+                src.open("{");
+                src.new_line() << "for (int w = 1; w < nwaves; ++w) mySum = " << fold("mySum", "sdata[w]") << ";";
+                src.new_line() << "g_odata[blockIdx.x] = mySum;";
+                src.close("}");
+            }
+            src.end_kernel();
+            return src.str();
+        }
+};
+
+} // namespace vex
+#endif

@@ -1,0 +1,29 @@
+#ifndef VEXCL_VECTOR_POINTER_HPP
+#define VEXCL_VECTOR_POINTER_HPP
+// vex::raw_pointer(v): passes the device pointer of a single-partition vector
+// into a kernel as "T * prm_k" (reference: vexcl/vector_pointer.hpp:146-160).
+#include "vector.hpp"
+
+namespace vex {
+namespace detail {
+template <class T>
+struct vector_pointer : expression_base {
+    typedef T *value_type;
+    const vector<T> *v;
+    explicit vector_pointer(const vector<T> &vec) : v(&vec) {}
+    void preamble(gen_context &c) const { c.next(); }
+    void params(gen_context &c) const { c.src.template parameter<global_ptr<T>>(c.next()); }
+    void local_init(gen_context &c) const { c.next(); }
+    void emit(gen_context &c) const { c.src << c.next(); }
+    void set_args(arg_context &a) const { a.next(); a.krn.push_arg((*v)(a.device)); }
+    void get_props(prop_context &) const {}
+};
+} // namespace detail
+
+template <class T>
+detail::vector_pointer<T> raw_pointer(const vector<T> &v) {
+    precondition(v.nparts() == 1, "raw_pointer is not supported for multi-device contexts");
+    return detail::vector_pointer<T>(v);
+}
+} // namespace vex
+#endif

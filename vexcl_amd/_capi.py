@@ -80,6 +80,7 @@ _PROTOS = {
     "vexhip_function_max_threads": (None, [c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "vexhip_launch": (None, [c_int, c_vp] + [ctypes.c_uint] * 7 + [c_vp, ctypes.POINTER(c_vp)]),
     "vexhip_jit_stats": (None, [ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
+    "vexhip_jit_check": (None, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]),
     "vexhip_spmv_csr_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vexhip_spmv_csr_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vexhip_spmv_csr_f64_i64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),

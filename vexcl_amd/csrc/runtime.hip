@@ -369,6 +369,35 @@ int vexhip_module_compile(int dev, const char *source, const char *options, void
     return 0;
 }
 
+int vexhip_jit_check(const char *source, const char *options, const char *arch) {
+    VEXHIP_REQUIRE(source && arch, "NULL argument");
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, source, "vexcl_kernel.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return rtc_fail(__FILE__, __LINE__, r, "");
+    std::vector<std::string> ostr;
+    ostr.push_back(std::string("--offload-arch=") + arch);
+    ostr.push_back("-O3");
+    ostr.push_back("-std=c++17");
+    {
+        std::istringstream is(options ? options : "");
+        std::string tok;
+        while (is >> tok) ostr.push_back(tok);
+    }
+    std::vector<const char *> oc;
+    for (auto &s : ostr) oc.push_back(s.c_str());
+    r = hiprtcCompileProgram(prog, (int)oc.size(), oc.data());
+    std::string log;
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        log.resize(ls);
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    }
+    hiprtcDestroyProgram(&prog);
+    if (r != HIPRTC_SUCCESS) return rtc_fail(__FILE__, __LINE__, r, log);
+    return 0;
+}
+
 int vexhip_module_unload(int dev, void *module) {
     if (!module) return 0;
     VEXHIP_SET_DEVICE(dev);
