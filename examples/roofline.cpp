@@ -1,0 +1,91 @@
+// Secondary rows of BASELINE.md section 4 through the vex:: API, timed with
+// HIP events on the compute queue:  C2 elementwise a = b*c + sin(d) (n = 1e8),
+// reduce sum(a*b) (n = 2^24 and 1e8), inclusive scan and sort of 1e9 uint32
+// keys.  Prints one JSON object per row: algorithmic GB/s and fraction of 8 TB/s.
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vexcl/vexcl.hpp>
+
+struct timer {
+    const vex::backend::command_queue &q; void *e0 = nullptr, *e1 = nullptr;
+    explicit timer(const vex::backend::command_queue &q) : q(q) {
+        vex::backend::check(vexhip_event_create(q.device_ordinal(), 1, &e0));
+        vex::backend::check(vexhip_event_create(q.device_ordinal(), 1, &e1));
+    }
+    void start() { vex::backend::check(vexhip_event_record(q.device_ordinal(), e0, q.raw())); }
+    double stop_ms() {
+        vex::backend::check(vexhip_event_record(q.device_ordinal(), e1, q.raw()));
+        vex::backend::check(vexhip_event_sync(q.device_ordinal(), e1));
+        float ms = 0; vex::backend::check(vexhip_event_elapsed_ms(q.device_ordinal(), e0, e1, &ms));
+        return ms;
+    }
+};
+
+static void report(const char *row, double n, double bytes_per_elem, double ms, const char *extra = "") {
+    double gbps = n * bytes_per_elem / ms / 1e6;
+    std::printf("{\"row\": \"%s\", \"n\": %.0f, \"ms\": %.4f, \"alg_gbps\": %.1f, \"frac_of_8TBps\": %.4f, \"elems_per_s\": %.4g%s}\n",
+            row, n, ms, gbps, gbps / 8000.0, n / ms * 1e3, extra);
+    std::fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+    size_t big = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000000000ull;
+    vex::Context ctx(vex::Filter::Env && vex::Filter::Count(1));
+    if (!ctx) { std::cerr << "no device" << std::endl; return 1; }
+    std::cout << ctx << std::endl;
+    const vex::backend::command_queue &q = ctx.queue(0);
+    timer t(q);
+    const int reps = 20;
+    {   // C2
+        const size_t n = 100000000;
+        vex::vector<double> a(ctx, n), b(ctx, n), c(ctx, n), d(ctx, n);
+        b = 0.5 + 1e-9 * vex::element_index(); c = 1.5; d = 1e-8 * vex::element_index();
+        a = b * c + sin(d); q.finish();
+        t.start(); for (int i = 0; i < reps; ++i) a = b * c + sin(d); double ms = t.stop_ms() / reps;
+        report("elementwise a=b*c+sin(d) f64", n, 32, ms);
+        t.start(); for (int i = 0; i < reps; ++i) a = b * c + d; ms = t.stop_ms() / reps;
+        report("elementwise a=b*c+d f64", n, 32, ms);
+        auto ta = vex::tag<1>(a);
+        t.start(); for (int i = 0; i < reps; ++i) ta = 0.5 * ta + b; ms = t.stop_ms() / reps;
+        report("saxpy a=alpha*a+b f64", n, 24, ms);
+        vex::Reductor<double, vex::SUM> sum(ctx);
+        double s = sum(a * b);
+        t.start(); for (int i = 0; i < reps; ++i) s += sum(a * b); ms = t.stop_ms() / reps;
+        report("reduce sum(a*b) f64 n=1e8", n, 16, ms);
+        (void)s;
+    }
+    {
+        const size_t n = 1 << 24;
+        vex::vector<double> a(ctx, n), b(ctx, n); a = 1.0; b = 0.5;
+        vex::Reductor<double, vex::SUM> sum(ctx);
+        double s = sum(a * b);
+        t.start(); for (int i = 0; i < 64; ++i) s += sum(a * b); double ms = t.stop_ms() / 64;
+        report("reduce sum(a*b) f64 n=2^24 (incl. host readback)", n, 16, ms);
+        (void)s;
+    }
+    {   // C5 scan
+        const size_t n = big;
+        vex::vector<cl_uint> x(ctx, n), y(ctx, n);
+        vex::backend::check(vexhip_fill_hash(q.device_ordinal(), q.raw(), VEXHIP_U32, 42, x(0).raw(), (int64_t)n));
+        vex::inclusive_scan(x, y); q.finish();
+        t.start(); for (int i = 0; i < 5; ++i) vex::inclusive_scan(x, y); double ms = t.stop_ms() / 5;
+        report("inclusive_scan u32", n, 8, ms);
+        // C5 sort
+        vex::sort(y); q.finish();
+        double tot = 0;
+        for (int i = 0; i < 3; ++i) {
+            y = x; q.finish();
+            t.start(); vex::sort(y); tot += t.stop_ms();
+        }
+        report("sort u32 keys", n, 8, tot / 3, ", \"note\": \"8-bit LSD radix: 4 passes x (hist read + scatter read + write)\"");
+        vex::Reductor<size_t, vex::SUM> bad(ctx);
+        vex::vector<cl_uint> z(ctx, n);
+        z = y;
+        // sortedness check on the device: count inversions between neighbours
+        size_t inv = bad(vex::if_else(vex::permutation(vex::element_index(0, n - 1) + 1)(z) < vex::permutation(vex::element_index(0, n - 1))(z), 1, 0));
+        std::printf("{\"row\": \"sort check\", \"inversions\": %zu}\n", inv);
+    }
+    return 0;
+}
