@@ -76,10 +76,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge (512 = BASELINE config)")
-    ap.add_argument("--format", default="auto", choices=["auto", "hell", "csr"])
+    ap.add_argument("--format", default="auto", choices=["auto", "sell", "hell", "csr"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=256)
+    ap.add_argument("--dist", action="store_true", help="use the partitioned SpMat even on one GPU (debug)")
     args = ap.parse_args()
 
     import torch
@@ -111,10 +112,10 @@ def main():
     ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
     x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev), 42 + rank)
     y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
-    if world == 1:
+    if world == 1 and not args.dist:
         A = ops.SpMat(ptr, col, val, fmt=args.format)
         fmt = A.fmt
-        if fmt == "hell":
+        if fmt in ("hell", "sell"):
             del ptr, col, val                    # the product only needs the ELL arrays
             A.ptr = A.col = A.val = None
         step = lambda: A.apply(x, y, 1.0, False)
@@ -167,7 +168,7 @@ def main():
         alg_rank = algorithmic_bytes(r1 - r0, nnz_rank)
         gflops = 2.0 * nnz_total / per_step / 1e9
         gbps = alg_total / per_step / 1e9
-        kname = "hell_kernel" if fmt == "hell" else "csr_stream_kernel"
+        kname = {"hell": "hell_kernel", "sell": "sell_kernel"}.get(fmt, "csr_stream_kernel")
         traffic = read_traffic(kname) if (world == 1 and n == 512) else None
         out = {
             "metric": "fp64 CSR SpMV GFLOP/s, 3D Poisson %d^3 (y = A*x, vex::SpMat path)" % n,

@@ -122,6 +122,49 @@ int vexhip_spmv_hell_f32_i32(int dev, void *stream, int64_t n, float alpha, int 
         const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y);
 
+/* L2-tiled traversal order for banded / stencil matrices (setup, blocking).
+ * Detects constant column offsets (e.g. +-1, +-n, +-n^2) in the ELL part and, if
+ * the farthest one is too long for the x values of three "planes" to stay in one
+ * XCD's 4 MiB L2, writes a workgroup -> row-block permutation that walks the rows
+ * in 64 Ki-row tiles, plane after plane, per XCD.  *grid_blocks = 0 means "use
+ * the plain product".  order must hold vexhip_hell_order_capacity(n) ints.
+ * The ordered product computes exactly what vexhip_spmv_hell_* computes.        */
+int64_t vexhip_hell_order_capacity(int64_t n);
+int vexhip_hell_order_i32(int dev, void *stream, int64_t n, int64_t ell_width, int64_t ell_pitch,
+        const int32_t *ell_col, int mode /* 0 = default (each XCD owns a strip of every plane), 1 = per-XCD slabs,
+                    2 = round-robin tiles, 100+k = strips of k row-blocks */,
+        int32_t *order, int64_t capacity, int64_t *grid_blocks);
+int vexhip_sell_order_i32(int dev, void *stream, int64_t n, int64_t ell_width,
+        const int32_t *sell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks);
+int vexhip_spmv_hell_ordered_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
+        int64_t ell_width, int64_t ell_pitch, const int32_t *ell_col, const double *ell_val,
+        const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const int32_t *order, int64_t grid_blocks);
+int vexhip_spmv_hell_ordered_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
+        int64_t ell_width, int64_t ell_pitch, const int32_t *ell_col, const float *ell_val,
+        const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const int32_t *order, int64_t grid_blocks);
+
+/* Sliced ELL (SELL-512): the ELL part stored slice-major (one slice = the 512 rows
+ * of one workgroup; element (r, j) of slice s at s*w*512 + j*512 + r), so that a
+ * workgroup streams two contiguous regions.  Same width rule, same CSR tail,
+ * same arithmetic and summation order as hybrid ELL.  Arrays hold
+ * vexhip_sell_elems(n, w) elements; `order`/grid_blocks as for the ordered HELL
+ * product (NULL / 0 = plain order).                                               */
+int64_t vexhip_sell_elems(int64_t n, int64_t ell_width);
+int vexhip_sell_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int64_t ell_width, int32_t *sell_col, double *sell_val);
+int vexhip_sell_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int64_t ell_width, int32_t *sell_col, float *sell_val);
+int vexhip_spmv_sell_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width,
+        const int32_t *sell_col, const double *sell_val,
+        const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const int32_t *order, int64_t grid_blocks);
+int vexhip_spmv_sell_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width,
+        const int32_t *sell_col, const float *sell_val,
+        const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const int32_t *order, int64_t grid_blocks);
+
 /* CSR -> hybrid ELL conversion on the device (sparse/ell.hpp:400-508,
  * `convert_csr2ell` :348-397; width rule hybrid_ell.inl:66-114).
  * Step 1 (blocking): row-width histogram -> ELL width by the reference's

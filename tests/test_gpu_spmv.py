@@ -49,7 +49,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("fmt", ["csr", "hell"])
+@pytest.mark.parametrize("fmt", ["csr", "hell", "sell"])
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_spmv_set_append_scale(T, oracle, case, fmt):
     ptr, col, val, m = CASES[case](oracle)
@@ -101,6 +101,23 @@ def test_hell_kernel_variants_agree(T, oracle, built_lib, variant):
     assert np.array_equal(y.cpu().numpy(), want)
 
 
+def test_sell_layout_and_tail(T, oracle):
+    # slice-major storage: element (r, j) of slice s at s*w*512 + j*512 + r; same width rule / tail as HELL
+    ptr, col, val = oracle.random_matrix(33, 1500, 1500, 16)
+    h = oracle.hell_build(ptr, col, val)
+    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+    assert (S.width, S.tail_nnz) == (h["width"], h["tail"])
+    w, n = S.width, 1500
+    sc = S.sell_col.cpu().numpy().reshape(-1, w, 512)
+    sv = S.sell_val.cpu().numpy().reshape(-1, w, 512)
+    ec = h["ell_col"].reshape(w, h["pitch"])
+    ev = h["ell_val"].reshape(w, h["pitch"])
+    for i in (0, 1, 511, 512, 1023, 1499):
+        assert np.array_equal(sc[i // 512, :, i % 512], ec[:, i]) and np.array_equal(sv[i // 512, :, i % 512], ev[:, i])
+    assert np.all(sc[2, :, 1500 - 1024:] == -1)          # padding rows of the last slice
+    assert np.array_equal(S.csr_ptr.cpu().numpy(), h["csr_ptr"]) and np.array_equal(S.csr_val.cpu().numpy(), h["csr_val"])
+
+
 def test_hell_conversion_matches_oracle_layout(T, oracle):
     # sparse/ell.hpp:400-508 device conversion == hybrid_ell.inl:138-198 host fill
     ptr, col, val = oracle.random_matrix(31, 1024, 1024, 16)
@@ -124,7 +141,7 @@ def test_index_and_value_types(T, oracle):
     assert np.array_equal((A @ T.up(x)).cpu().numpy(), want)
     v32, x32 = val.astype(np.float32), x.astype(np.float32)
     want32 = oracle.spmv_csr(ptr, col, v32, x32)
-    for fmt in ("csr", "hell"):
+    for fmt in ("csr", "hell", "sell"):
         y = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), fmt=fmt) @ T.up(x32)
         assert np.array_equal(y.cpu().numpy(), want32)
 
@@ -143,7 +160,7 @@ def test_unaligned_views_take_the_scalar_path(T, oracle):
 def test_golden_fixtures(T, oracle, name):
     ptr, col, val, x, want = (G[name + s] for s in ("_ptr", "_col", "_val", "_x", "_y"))
     bound = oracle.spmv_abs_bound(ptr, col, val, x)
-    for fmt in ("csr", "hell"):
+    for fmt in ("csr", "hell", "sell"):
         y = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), n_cols=len(x), fmt=fmt) @ T.up(x)
         _check(y.cpu().numpy(), want, bound)
 
@@ -171,7 +188,7 @@ def test_poisson128_benchmark_size(T, oracle):
     x = oracle.random_f64(9, n ** 3)
     want = oracle.spmv_csr(ptr, col, val, x, omp=True)
     dp, dc, dv = T.ops.poisson3d(n, T.dev)
-    for fmt in ("csr", "hell"):
+    for fmt in ("csr", "hell", "sell"):
         y = T.ops.SpMat(dp, dc, dv, fmt=fmt) @ T.up(x)
         assert np.array_equal(y.cpu().numpy(), want)
 
@@ -188,13 +205,20 @@ def test_poisson512_properties(T):
     dp, dc, dv = ops.poisson3d(n, T.dev)
     assert dc.numel() == 930123728 and int(dp[-1]) == 930123728
     A_csr = ops.SpMat(dp, dc, dv, fmt="csr")
-    A_ell = ops.SpMat(dp, dc, dv, fmt="hell")
-    assert A_ell.hell.width == 7 and A_ell.hell.tail_nnz == 0
+    A_ell = ops.SpMat(dp, dc, dv)                       # default format: SELL-512
+    assert A_ell.fmt == "sell" and A_ell.hell.width == 7 and A_ell.hell.tail_nnz == 0
+    A_hell = ops.SpMat(dp, dc, dv, fmt="hell")          # reference layout + L2-tiled traversal order
+    assert A_hell.hell.order_grid >= N // 512
 
     x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=T.dev), 42)
     y1 = A_csr @ x
     y2 = A_ell @ x
     assert torch.equal(y1, y2)
+    assert torch.equal(y1, A_hell @ x)
+    y0 = torch.empty_like(y1)
+    A_hell.hell.mul(x, y0, tiled=False)
+    assert torch.equal(y1, y0)
+    del A_hell, y0
 
     ones = torch.ones(N, dtype=torch.float64, device=T.dev)
     y = A_ell @ ones

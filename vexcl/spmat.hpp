@@ -74,10 +74,13 @@ class SpMat {
         const std::vector<backend::command_queue> &queue_list() const { return queue; }
         const std::vector<size_t> &row_partition() const { return part; }
 
+        // ELL part in SELL-512 storage (include/vexhip.h): slice-major, one slice = the 512
+        // rows of one workgroup; element (r, j) of slice s at s*w*512 + j*512 + r.
         struct matrix_arrays {
             size_t n = 0, nnz = 0;
-            long ell_w = 0; size_t ell_pitch = 0;
+            long ell_w = 0;
             backend::device_vector<int> ell_col; backend::device_vector<val_t> ell_val;
+            backend::device_vector<int> order; int64_t order_grid = 0;      // traversal order (0 = plain)
             backend::device_vector<int> csr_ptr, csr_col; backend::device_vector<val_t> csr_val;
             size_t csr_nnz = 0;
             bool empty() const { return nnz == 0; }
@@ -138,13 +141,25 @@ class SpMat {
                 int dev = q.device_ordinal();
                 int64_t w = 0, tail = 0;
                 backend::check(vexhip_hell_analyze_i32(dev, q.raw(), (int64_t)n, dptr.raw(), &w, &tail));
-                A.ell_w = (long)w; A.ell_pitch = alignup(n, 16); A.csr_nnz = (size_t)tail;
-                if (w) { A.ell_col = backend::device_vector<int>(q, A.ell_pitch * w); A.ell_val = backend::device_vector<val_t>(q, A.ell_pitch * w); }
-                if (tail) { A.csr_ptr = backend::device_vector<int>(q, n + 1); A.csr_col = backend::device_vector<int>(q, tail); A.csr_val = backend::device_vector<val_t>(q, tail); }
-                backend::check(fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, (int64_t)A.ell_pitch,
-                            A.ell_col.raw(), A.ell_val.raw(), A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw()));
+                if (w == 0) { A.csr_ptr = dptr; A.csr_col = dcol; A.csr_val = dval; A.csr_nnz = A.nnz; return; }
+                A.ell_w = (long)w; A.csr_nnz = (size_t)tail;
+                size_t ne = (size_t)vexhip_sell_elems((int64_t)n, w);
+                A.ell_col = backend::device_vector<int>(q, ne); A.ell_val = backend::device_vector<val_t>(q, ne);
+                if (tail) {
+                    A.csr_ptr = backend::device_vector<int>(q, n + 1); A.csr_col = backend::device_vector<int>(q, tail); A.csr_val = backend::device_vector<val_t>(q, tail);
+                    backend::check(fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, (int64_t)alignup(n, 16),
+                                nullptr, nullptr, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw()));
+                }
+                backend::check(sell_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, A.ell_col.raw(), A.ell_val.raw()));
+                int64_t cap = vexhip_hell_order_capacity((int64_t)n), grid = 0;
+                backend::device_vector<int> order(q, (size_t)cap);
+                backend::check(vexhip_sell_order_i32(dev, q.raw(), (int64_t)n, w, A.ell_col.raw(), 0, order.raw(), cap, &grid));
+                if (grid) { A.order = order; A.order_grid = grid; }
                 q.finish();
             }
+
+            static int sell_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, int *sc, double *sv) { return vexhip_sell_fill_f64_i32(dev, s, n, p, c, v, w, sc, sv); }
+            static int sell_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, int *sc, float *sv) { return vexhip_sell_fill_f32_i32(dev, s, n, p, c, v, w, sc, sv); }
 
             static int fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, int64_t pitch,
                     int *ec, double *ev, int *cp, int *cc, double *cv) { return vexhip_hell_fill_f64_i32(dev, s, n, p, c, v, w, pitch, ec, ev, cp, cc, cv); }
@@ -154,14 +169,14 @@ class SpMat {
             static int spmv(int dev, void *s, int64_t n, double a, int app, const matrix_arrays &A, const double *x, double *y) {
                 if (A.ell_w == 0 && A.csr_nnz)      // plain CSR storage: LDS-staged CSR kernel
                     return vexhip_spmv_csr_f64_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
-                return vexhip_spmv_hell_f64_i32(dev, s, n, a, app, A.ell_w, (int64_t)A.ell_pitch, A.ell_col.raw(), A.ell_val.raw(),
-                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y);
+                return vexhip_spmv_sell_f64_i32(dev, s, n, a, app, A.ell_w, A.ell_col.raw(), A.ell_val.raw(),
+                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, A.order.raw(), A.order_grid);
             }
             static int spmv(int dev, void *s, int64_t n, float a, int app, const matrix_arrays &A, const float *x, float *y) {
                 if (A.ell_w == 0 && A.csr_nnz)
                     return vexhip_spmv_csr_f32_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
-                return vexhip_spmv_hell_f32_i32(dev, s, n, a, app, A.ell_w, (int64_t)A.ell_pitch, A.ell_col.raw(), A.ell_val.raw(),
-                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y);
+                return vexhip_spmv_sell_f32_i32(dev, s, n, a, app, A.ell_w, A.ell_col.raw(), A.ell_val.raw(),
+                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, A.order.raw(), A.order_grid);
             }
 
             /// csr.inl:186-200: an empty local part zero-fills y on SET.
@@ -291,17 +306,18 @@ struct inline_spmv : expression_base {
         const std::string V = type_name<T>();
         c.src.begin_function(V, name + "_hell_spmv");
         c.src.begin_function_parameters();
-        c.src.parameter("long", "ell_w"); c.src.parameter("ulong", "ell_pitch");
+        c.src.parameter("long", "ell_w");
         c.src.parameter("const int *", "ell_col"); c.src.parameter("const " + V + " *", "ell_val");
         c.src.parameter("const int *", "csr_row"); c.src.parameter("const int *", "csr_col");
         c.src.parameter("const " + V + " *", "csr_val"); c.src.parameter("const " + V + " *", "in");
         c.src.parameter("ulong", "i");
         c.src.end_function_parameters();
         c.src.new_line() << V << " sum = 0;";
+        c.src.new_line() << "const ulong slice = (i >> 9) * ell_w * 512 + (i & 511);   // SELL-512 storage";
         c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
         c.src.open("{");
-        c.src.new_line() << "int c = ell_col[i + j * ell_pitch];";
-        c.src.new_line() << "if (c != -1) sum += ell_val[i + j * ell_pitch] * in[c];";
+        c.src.new_line() << "int c = ell_col[slice + j * 512];";
+        c.src.new_line() << "if (c != -1) sum += ell_val[slice + j * 512] * in[c];";
         c.src.close("}");
         c.src.new_line() << "if (csr_row)";
         c.src.open("{");
@@ -313,7 +329,7 @@ struct inline_spmv : expression_base {
     void params(gen_context &c) const {
         std::string name = c.next();
         const std::string V = type_name<T>();
-        c.src.parameter("long", name + "_ell_w"); c.src.parameter("ulong", name + "_ell_pitch");
+        c.src.parameter("long", name + "_ell_w");
         c.src.parameter("const int *", name + "_ell_col"); c.src.parameter("const " + V + " *", name + "_ell_val");
         c.src.parameter("const int *", name + "_csr_row"); c.src.parameter("const int *", name + "_csr_col");
         c.src.parameter("const " + V + " *", name + "_csr_val"); c.src.parameter("const " + V + " *", name + "_vec");
@@ -321,13 +337,13 @@ struct inline_spmv : expression_base {
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
-        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_ell_pitch, " << n << "_ell_col, " << n << "_ell_val, "
+        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_ell_col, " << n << "_ell_val, "
               << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, idx)";
     }
     void set_args(arg_context &a) const {
         a.next();
         const auto &L = A.part_of(a.device).loc;
-        a.krn.push_arg((long)L.ell_w); a.krn.push_arg((size_t)L.ell_pitch);
+        a.krn.push_arg((long)L.ell_w);
         a.krn.push_arg(static_cast<const int *>(L.ell_col.raw())); a.krn.push_arg(static_cast<const T *>(L.ell_val.raw()));
         a.krn.push_arg(static_cast<const int *>(L.csr_nnz ? L.csr_ptr.raw() : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_col.raw())); a.krn.push_arg(static_cast<const T *>(L.csr_val.raw()));

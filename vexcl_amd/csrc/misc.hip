@@ -154,14 +154,16 @@ void hell_fill_kernel(long long n, long long pitch, int w,
          i += (long long)gridDim.x * blockDim.x) {
         int b = 0, e = 0;
         if (i < n) { b = ptr[i]; e = ptr[i + 1]; }
-        int j = 0;
-        for (; j < w && b + j < e; ++j) {
-            ell_col[i + j * pitch] = col[b + j];
-            ell_val[i + j * pitch] = val[b + j];
-        }
-        for (; j < w; ++j) {
-            ell_col[i + j * pitch] = -1;
-            ell_val[i + j * pitch] = V(0);
+        if (ell_col) {                       // NULL: only the CSR tail is wanted (SELL storage)
+            int j = 0;
+            for (; j < w && b + j < e; ++j) {
+                ell_col[i + j * pitch] = col[b + j];
+                ell_val[i + j * pitch] = val[b + j];
+            }
+            for (; j < w; ++j) {
+                ell_col[i + j * pitch] = -1;
+                ell_val[i + j * pitch] = V(0);
+            }
         }
         if (csr_ptr && i < n) {
             int o = csr_ptr[i];

@@ -14,6 +14,9 @@
 // within the stated 1e-10 tolerance.
 #include "common.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace vexhip {
 namespace {
 
@@ -195,10 +198,13 @@ void hell_kernel(long long n, long long nblocks, V alpha, int append,
         int ell_w, long long pitch,
         const int *__restrict__ ell_col, const V *__restrict__ ell_val,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y)
+        const V *__restrict__ x, V *__restrict__ y, const int *__restrict__ order)
 {
-    const long long lb = logical_block<SWZ>(nblocks);
-    if (lb >= nblocks) return;
+    // order != NULL: a precomputed workgroup -> row-block map (vexhip_hell_order_i32)
+    // that walks the rows in L2-sized tiles; any permutation is correct.
+    long long lb;
+    if (order) { lb = order[blockIdx.x]; if (lb < 0) return; }
+    else { lb = logical_block<SWZ>(nblocks); if (lb >= nblocks) return; }
     const long long i = (lb * 256 + threadIdx.x) * RPT;
     if (i >= n) return;
 
@@ -247,6 +253,88 @@ void hell_kernel(long long n, long long nblocks, V alpha, int append,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Sliced ELL (SELL-512): the ELL part stored slice-major, one slice = the 512
+// rows of one workgroup, element (r, j) of slice s at s*w*512 + j*512 + r.  A
+// workgroup then streams TWO contiguous regions (w*2 KiB of columns, w*4 KiB of
+// values) instead of 2*w segments that lie pitch*4 / pitch*8 bytes apart:
+// fewer DRAM pages and TLB entries per workgroup.  Same arithmetic, same order.
+// ---------------------------------------------------------------------------
+constexpr int SELL_ROWS = 512;
+
+template <typename V, int W, bool NT>
+__global__ __launch_bounds__(256)
+void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
+        const int *__restrict__ sell_col, const V *__restrict__ sell_val,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        const V *__restrict__ x, V *__restrict__ y, const int *__restrict__ order)
+{
+    long long s;
+    if (order) { s = order[blockIdx.x]; if (s < 0) return; }
+    else { s = blockIdx.x; if (s >= nslices) return; }
+    const int r = 2 * threadIdx.x;
+    const long long i = s * SELL_ROWS + r;
+    const int w = W > 0 ? W : ell_w;
+    const int *cp = sell_col + s * (long long)w * SELL_ROWS + r;
+    const V *vp = sell_val + s * (long long)w * SELL_ROWS + r;
+
+    V sum[2] = {V(0), V(0)};
+    if constexpr (W > 0) {
+        int c[W][2]; V v[W][2];
+#pragma unroll
+        for (int j = 0; j < W; ++j) ell_load<V, 2, NT>(cp + j * SELL_ROWS, vp + j * SELL_ROWS, c[j], v[j]);
+        V xv[W][2];
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xv[j][q] = (c[j][q] != -1) ? x[c[j][q]] : V(0);
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (c[j][q] != -1) sum[q] += v[j][q] * xv[j][q];
+    } else {
+        for (int j = 0; j < w; ++j) {
+            int c[2]; V v[2];
+            ell_load<V, 2, NT>(cp + j * SELL_ROWS, vp + j * SELL_ROWS, c, v);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (c[q] != -1) sum[q] += v[q] * x[c[q]];
+        }
+    }
+    if (csr_ptr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (i + q < n)
+                for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (i + q < n) {
+            V o = alpha * sum[q];
+            if (append) o = y[i + q] + o;
+            y[i + q] = o;
+        }
+    }
+}
+
+template <typename V>
+__global__ __launch_bounds__(256)
+void sell_fill_kernel(long long n, long long nslices, int w,
+        const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        int *__restrict__ sell_col, V *__restrict__ sell_val)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nslices * SELL_ROWS;
+         i += (long long)gridDim.x * blockDim.x) {
+        int b = 0, e = 0;
+        if (i < n) { b = ptr[i]; e = ptr[i + 1]; }
+        const long long base = (i / SELL_ROWS) * (long long)w * SELL_ROWS + (i % SELL_ROWS);
+        for (int j = 0; j < w; ++j) {
+            bool in = b + j < e;
+            sell_col[base + (long long)j * SELL_ROWS] = in ? col[b + j] : -1;
+            sell_val[base + (long long)j * SELL_ROWS] = in ? val[b + j] : V(0);
+        }
+    }
+}
+
 template <typename V>
 __global__ __launch_bounds__(256)
 void zero_kernel(long long n, V *y) {
@@ -266,6 +354,7 @@ void gather_kernel(long long n, const I *__restrict__ idx, const V *__restrict__
 int g_csr_variant = -1;     // -1: built-in default
 int g_hell_variant = -1;
 constexpr int kCsrDefault  = 0;
+constexpr int kHellOrderRows = 512; // rows per workgroup of the ordered product (RPT = 2)
 constexpr int kHellDefault = 7;   // RPT = 2, nontemporal streams, XCD-contiguous rows (sweep: profiles/)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -302,14 +391,14 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
 template <typename V, int RPT, bool NT, bool SWZ>
 int launch_hell_w(hipStream_t s, long long grid, long long nb, int64_t n, V alpha, int append,
         int w, int64_t pitch, const int *ec, const V *ev,
-        const int *cp, const int *cc, const V *cv, const V *x, V *y)
+        const int *cp, const int *cc, const V *cv, const V *x, V *y, const int *order)
 {
 #define CASE(W) case W: hell_kernel<V, RPT, W, NT, SWZ><<<(unsigned)grid, 256, 0, s>>>( \
-        n, nb, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y); break;
+        n, nb, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, order); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
         default: hell_kernel<V, RPT, 0, NT, SWZ><<<(unsigned)grid, 256, 0, s>>>(
-                n, nb, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y);
+                n, nb, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, order);
     }
 #undef CASE
     return 0;
@@ -318,7 +407,8 @@ int launch_hell_w(hipStream_t s, long long grid, long long nb, int64_t n, V alph
 template <typename V>
 int spmv_hell(int dev, void *stream, int64_t n, V alpha, int append,
         int64_t w, int64_t pitch, const int *ec, const V *ev,
-        const int *cp, const int *cc, const V *cv, const V *x, V *y)
+        const int *cp, const int *cc, const V *cv, const V *x, V *y,
+        const int *order = nullptr, int64_t order_grid = 0)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 0, "negative size");
     if (n == 0) return 0;
@@ -346,11 +436,18 @@ int spmv_hell(int dev, void *stream, int64_t n, V alpha, int append,
     if (rpt > 1 && w > 0 && ((pitch % 16) != 0 || !aligned16(ec) || !aligned16(ev))) rpt = 1;
     if (rpt == 3 || rpt > 4) rpt = 4;
 
+    if (order && order_grid > 0) {
+        // the order was built for kHellOrderRows rows per workgroup
+        VEXHIP_REQUIRE(w > 0 && (pitch % 16) == 0 && aligned16(ec) && aligned16(ev), "ordered HELL product needs aligned ELL arrays");
+        rpt = kHellOrderRows / 256;
+        nt = true;
+    } else order = nullptr;
+
     long long nb = (n + (long long)256 * rpt - 1) / ((long long)256 * rpt);
-    long long grid = swz ? ((nb + 7) / 8) * 8 : nb;
+    long long grid = order ? order_grid : (swz ? ((nb + 7) / 8) * 8 : nb);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
 
-#define GO(RPT, NT, SWZ) launch_hell_w<V, RPT, NT, SWZ>(s, grid, nb, n, alpha, append, (int)w, pitch, ec, ev, cp, cc, cv, x, y)
+#define GO(RPT, NT, SWZ) launch_hell_w<V, RPT, NT, SWZ>(s, grid, nb, n, alpha, append, (int)w, pitch, ec, ev, cp, cc, cv, x, y, order)
 #define GO_RPT(RPT) do { \
         if (nt) { if (swz) GO(RPT, true, true); else GO(RPT, true, false); } \
         else    { if (swz) GO(RPT, false, true); else GO(RPT, false, false); } } while (0)
@@ -361,12 +458,249 @@ int spmv_hell(int dev, void *stream, int64_t n, V alpha, int append,
     return 0;
 }
 
+template <typename V>
+int spmv_sell(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
+        const int *sc, const V *sv, const int *cp, const int *cc, const V *cv, const V *x, V *y,
+        const int *order, int64_t order_grid)
+{
+    VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL geometry");
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(sc && sv && x && y && aligned16(sc) && aligned16(sv), "SELL arrays must be 16-byte aligned");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    long long ns = (n + SELL_ROWS - 1) / SELL_ROWS;
+    long long grid = (order && order_grid > 0) ? order_grid : ns;
+    if (!(order && order_grid > 0)) order = nullptr;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+#define CASE(W) case W: sell_kernel<V, W, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, sv, cp, cc, cv, x, y, order); break;
+    switch (w) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        default: sell_kernel<V, 0, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, sv, cp, cc, cv, x, y, order);
+    }
+#undef CASE
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename V>
+int sell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w, int *sc, V *sv) {
+    VEXHIP_REQUIRE(n >= 0 && w >= 1, "bad SELL geometry");
+    if (n == 0) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    long long ns = (n + SELL_ROWS - 1) / SELL_ROWS;
+    int grid = (int)std::min<int64_t>((ns * SELL_ROWS + 255) / 256, (int64_t)info(dev).cus * 16);
+    sell_fill_kernel<V><<<grid, 256, 0, as_stream(stream)>>>(n, ns, (int)w, ptr, col, val, sc, sv);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Agreement of every ELL column j with a constant offset col - row == ref[j].
+__global__ __launch_bounds__(256)
+void ell_offset_agree_kernel(long long n, int w, long long pitch, const int *__restrict__ ell_col,
+        const long long *__restrict__ ref, unsigned long long *__restrict__ agree)
+{
+    for (int j = 0; j < w; ++j) {
+        unsigned long long local = 0;
+        const long long off = ref[j];
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+             i += (long long)gridDim.x * blockDim.x) {
+            // pitch == 0: SELL-512 storage
+            long long e = pitch ? i + j * pitch : (i / SELL_ROWS) * (long long)w * SELL_ROWS + (long long)j * SELL_ROWS + i % SELL_ROWS;
+            int c = ell_col[e];
+            local += (c != -1 && (long long)c - i == off) ? 1ull : 0ull;
+        }
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+        if ((threadIdx.x & 63) == 0 && local) atomicAdd(&agree[j], local);
+    }
+}
+
 } // namespace
 } // namespace vexhip
 
 using namespace vexhip;
 
 extern "C" {
+
+// Workgroup -> row-block order for the HELL product of a banded / stencil matrix.
+// If most rows reach the same far column offsets (+-S_big, e.g. +-n^2 for a 3-D
+// stencil) the x values of three "planes" are live at once; walking whole planes
+// needs 3*S_big*8 bytes of cache.  The order walks the rows in tiles of <= 64 Ki
+// rows, plane after plane, inside each XCD's contiguous eighth of the matrix, so
+// the live part of x (3 tiles) stays in that XCD's 4 MiB L2 and x is fetched from
+// HBM about once instead of three times.  grid_blocks = 0: no reordering pays.
+static int build_order(int dev, void *stream, int64_t n, int64_t w, int64_t pitch /* 0 = SELL-512 */,
+        const int32_t *ell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks)
+{
+    VEXHIP_REQUIRE(grid_blocks, "NULL output");
+    *grid_blocks = 0;
+    const int64_t rpb = kHellOrderRows;
+    const int64_t tile_rows_max = 65536;                 // 3 tiles x 8 B = 1.5 MiB of x
+    if (w < 1 || w > 32 || n < 8 * tile_rows_max || (pitch % 16) != 0) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+
+    // modal (col - row) offset of every ELL column over 64 scattered sample rows
+    std::vector<long long> ref(w, 1ll << 62);
+    {
+        const int ns = 64;
+        std::vector<int> sample((size_t)ns * w, -1);
+        std::vector<int64_t> rows(ns);
+        for (int k = 0; k < ns; ++k) {
+            rows[k] = (int64_t)(((unsigned long long)(k + 1) * 0x9E3779B97F4A7C15ull) % (unsigned long long)n);
+            for (int j = 0; j < w; ++j)
+                VEXHIP_TRY(hipMemcpyAsync(&sample[(size_t)k * w + j],
+                            ell_col + (pitch ? rows[k] + j * pitch
+                                             : (rows[k] / SELL_ROWS) * w * SELL_ROWS + (int64_t)j * SELL_ROWS + rows[k] % SELL_ROWS),
+                            sizeof(int), hipMemcpyDeviceToHost, s));
+        }
+        VEXHIP_TRY(hipStreamSynchronize(s));
+        for (int j = 0; j < w; ++j) {
+            std::vector<long long> offs;
+            for (int k = 0; k < ns; ++k) if (sample[(size_t)k * w + j] != -1) offs.push_back((long long)sample[(size_t)k * w + j] - rows[k]);
+            std::sort(offs.begin(), offs.end());
+            size_t best = 0;
+            for (size_t a = 0; a < offs.size();) {
+                size_t b = a; while (b < offs.size() && offs[b] == offs[a]) ++b;
+                if (b - a > best) { best = b - a; ref[j] = offs[a]; }
+                a = b;
+            }
+        }
+    }
+    long long *dref = nullptr;
+    VEXHIP_TRY(hipMalloc(&dref, sizeof(long long) * 2 * w));
+    unsigned long long *dagree = reinterpret_cast<unsigned long long *>(dref + w);
+    VEXHIP_TRY(hipMemcpyAsync(dref, ref.data(), sizeof(long long) * w, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipMemsetAsync(dagree, 0, sizeof(long long) * w, s));
+    int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16);
+    ell_offset_agree_kernel<<<grid, 256, 0, s>>>(n, (int)w, pitch, ell_col, dref, dagree);
+    std::vector<unsigned long long> agree(w);
+    VEXHIP_TRY(hipMemcpyAsync(agree.data(), dagree, sizeof(long long) * w, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    VEXHIP_TRY(hipFree(dref));
+
+    int64_t s_big = 0, s_mid = 0;
+    for (int j = 0; j < w; ++j) {
+        if (agree[j] * 2 < (unsigned long long)n) continue;          // not a constant band
+        int64_t a = ref[j] < 0 ? -ref[j] : ref[j];
+        if (a > s_big) { if (s_big > s_mid) s_mid = s_big; s_big = a; }
+        else if (a < s_big && a > s_mid) s_mid = a;
+    }
+    if (s_big < 2 * tile_rows_max || (s_big % rpb) != 0) return 0;   // planes already fit in L2, or misaligned
+    const int64_t unit = (s_mid >= rpb && s_mid <= tile_rows_max && (s_mid % rpb) == 0) ? s_mid : rpb;
+    const int64_t tile_blocks = (tile_rows_max / unit) * unit / rpb;
+    const int64_t plane_blocks = s_big / rpb;
+    const int64_t nb = (n + rpb - 1) / rpb;
+    std::vector<int> host;
+    int64_t g = 0;
+    if (mode == 1) {
+        // per-XCD slabs: XCD k walks its own contiguous eighth of the rows, tile by tile
+        const int64_t per = (nb + 7) / 8;
+        std::vector<std::vector<int>> slab(8);
+        for (int k = 0; k < 8; ++k) {
+            const int64_t b0 = k * per, b1 = std::min<int64_t>(nb, b0 + per);
+            if (b0 >= b1) continue;
+            const int64_t p0 = b0 / plane_blocks, p1 = (b1 - 1) / plane_blocks;
+            for (int64_t t0 = 0; t0 < plane_blocks; t0 += tile_blocks)
+                for (int64_t p = p0; p <= p1; ++p)
+                    for (int64_t l = t0; l < std::min(plane_blocks, t0 + tile_blocks); ++l) {
+                        int64_t b = p * plane_blocks + l;
+                        if (b >= b0 && b < b1) slab[k].push_back((int)b);
+                    }
+        }
+        size_t longest = 0;
+        for (auto &v : slab) longest = std::max(longest, v.size());
+        g = (int64_t)longest * 8;
+        host.assign((size_t)g, -1);
+        for (int k = 0; k < 8; ++k)
+            for (size_t i = 0; i < slab[k].size(); ++i) host[i * 8 + k] = slab[k][i];   // workgroup b runs on XCD b % 8
+    } else if (mode == 2) {
+        // global tiles, consecutive row-blocks round-robin over the XCDs
+        const int64_t tb = std::max<int64_t>(8, tile_blocks / 8 * 8);
+        const int64_t planes = (nb + plane_blocks - 1) / plane_blocks;
+        host.reserve((size_t)nb + 8);
+        for (int64_t t0 = 0; t0 < plane_blocks; t0 += tb)
+            for (int64_t p = 0; p < planes; ++p)
+                for (int64_t l = t0; l < t0 + tb; ++l) {
+                    int64_t b = p * plane_blocks + l;
+                    host.push_back((l < plane_blocks && b < nb) ? (int)b : -1);
+                }
+        g = (int64_t)host.size();
+    } else {
+        // chunked tiles (default).  Per-XCD L2s are private, so BOTH kinds of reuse must stay
+        // on one XCD: a tile of tb row-blocks is cut into 8 chunks of tb/8 consecutive
+        // row-blocks, XCD k owns chunk k of the tile in every plane (neighbouring rows,
+        // +-S_mid, share its L2) and sweeps plane after plane (+-S_big re-reads are tb/8
+        // workgroups apart: still resident).  All XCDs stay within one tile of each other
+        // in memory.  Workgroup b runs on XCD b % 8.
+        // Default chunk: an eighth of a plane, at most 64 row-blocks (each XCD then owns a
+        // strip of the plane through ALL planes); mode >= 100 forces chunk = mode - 100 (tuning).
+        (void)tile_blocks;
+        const int64_t chunk = mode >= 100 ? std::max<int64_t>(1, mode - 100)
+                                          : std::max<int64_t>(1, std::min<int64_t>(64, plane_blocks / 8));
+        const int64_t tb = 8 * chunk;
+        const int64_t planes = (nb + plane_blocks - 1) / plane_blocks;
+        host.reserve((size_t)nb + 8);
+        for (int64_t t0 = 0; t0 < plane_blocks; t0 += tb)
+            for (int64_t p = 0; p < planes; ++p)
+                for (int64_t i = 0; i < chunk; ++i)
+                    for (int64_t k = 0; k < 8; ++k) {
+                        int64_t l = t0 + k * chunk + i;
+                        int64_t b = p * plane_blocks + l;
+                        host.push_back((l < plane_blocks && b < nb) ? (int)b : -1);
+                    }
+        g = (int64_t)host.size();
+    }
+    VEXHIP_REQUIRE(order && g <= capacity, "order buffer too small");
+    VEXHIP_TRY(hipMemcpyAsync(order, host.data(), sizeof(int) * (size_t)g, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    *grid_blocks = g;
+    return 0;
+}
+
+int vexhip_hell_order_i32(int dev, void *stream, int64_t n, int64_t w, int64_t pitch,
+        const int32_t *ell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks)
+{
+    VEXHIP_REQUIRE(pitch > 0, "ELL pitch must be positive");
+    return build_order(dev, stream, n, w, pitch, ell_col, mode, order, capacity, grid_blocks);
+}
+
+int vexhip_sell_order_i32(int dev, void *stream, int64_t n, int64_t w,
+        const int32_t *sell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks)
+{ return build_order(dev, stream, n, w, 0, sell_col, mode, order, capacity, grid_blocks); }
+
+int64_t vexhip_hell_order_capacity(int64_t n) { return 2 * ((n + kHellOrderRows - 1) / kHellOrderRows) + 4096; }
+
+int vexhip_spmv_hell_ordered_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
+        int64_t w, int64_t pitch, const int32_t *ec, const double *ev,
+        const int32_t *cp, const int32_t *cc, const double *cv, const double *x, double *y,
+        const int32_t *order, int64_t grid_blocks)
+{ return spmv_hell<double>(dev, stream, n, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, order, grid_blocks); }
+
+int vexhip_spmv_hell_ordered_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
+        int64_t w, int64_t pitch, const int32_t *ec, const float *ev,
+        const int32_t *cp, const int32_t *cc, const float *cv, const float *x, float *y,
+        const int32_t *order, int64_t grid_blocks)
+{ return spmv_hell<float>(dev, stream, n, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, order, grid_blocks); }
+
+int64_t vexhip_sell_elems(int64_t n, int64_t w) { return (n + SELL_ROWS - 1) / SELL_ROWS * SELL_ROWS * w; }
+
+int vexhip_sell_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int64_t w, int32_t *sell_col, double *sell_val)
+{ return sell_fill<double>(dev, stream, n, ptr, col, val, w, sell_col, sell_val); }
+
+int vexhip_sell_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int64_t w, int32_t *sell_col, float *sell_val)
+{ return sell_fill<float>(dev, stream, n, ptr, col, val, w, sell_col, sell_val); }
+
+int vexhip_spmv_sell_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w,
+        const int32_t *sc, const double *sv, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *x, double *y, const int32_t *order, int64_t grid_blocks)
+{ return spmv_sell<double>(dev, stream, n, alpha, append, w, sc, sv, cp, cc, cv, x, y, order, grid_blocks); }
+
+int vexhip_spmv_sell_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w,
+        const int32_t *sc, const float *sv, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *x, float *y, const int32_t *order, int64_t grid_blocks)
+{ return spmv_sell<float>(dev, stream, n, alpha, append, w, sc, sv, cp, cc, cv, x, y, order, grid_blocks); }
 
 int vexhip_spmv_csr_set_variant(int variant) { g_csr_variant = variant; return 0; }
 int vexhip_spmv_hell_set_variant(int variant) { g_hell_variant = variant; return 0; }

@@ -117,6 +117,7 @@ class DistSpMat:
         self.ghost_buf = torch.empty(int(ghosts.numel()), dtype=val.dtype, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._p2p = self._plan_p2p()
+        self._ops = None
 
     # ---- collectives used only at setup (portable across nccl / gloo) -------
     def _all_to_all_single(self, out, inp):
@@ -161,18 +162,24 @@ class DistSpMat:
         """payload this rank sends + receives per product (xGMI traffic)."""
         return (self.send_buf.numel() + self.ghost_buf.numel()) * self.send_buf.element_size()
 
+    def _p2p_ops(self):
+        """The grouped send/recv list is fixed for the life of the matrix: built once."""
+        if self._ops is None:
+            self._ops = []
+            for kind, peer, off, cnt in self._p2p:
+                buf = (self.send_buf if kind == "send" else self.ghost_buf)[off:off + cnt]
+                self._ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf,
+                                            self._global_rank(peer), self.group))
+        return self._ops
+
     def apply(self, x, y, alpha=1.0, append=False):
         """y (=|+=) alpha * A * x on this rank's strip (spmat.hpp:120-185)."""
         if x.numel() != self.local_cols or y.numel() != self.rows:
             raise ValueError("segment sizes do not match the partition")
-        reqs = []
+        reqs = ()
         if self._p2p:
-            self.k.gather(self.send_idx, x, self.send_buf)                  # phase 1
-            ops = []
-            for kind, peer, off, cnt in self._p2p:
-                buf = (self.send_buf if kind == "send" else self.ghost_buf)[off:off + cnt]
-                ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf,
-                                      self._global_rank(peer), self.group))
+            self.k.gather(self.send_idx, x, self.send_buf)                  # phase 1: pack
+            ops = self._p2p_ops()
             if self.comm_stream is not None:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.dev))
                 with torch.cuda.stream(self.comm_stream):

@@ -115,7 +115,7 @@ class HybridELL:
     """Device-resident ELL(+CSR tail) built from device CSR
     (spmat/hybrid_ell.inl:55-216; device-side conversion sparse/ell.hpp:400-508)."""
 
-    def __init__(self, ptr, col, val):
+    def __init__(self, ptr, col, val, tiled=True, order_mode=2):
         L = lib()
         self.n = n = ptr.numel() - 1
         self.dtype = val.dtype
@@ -136,26 +136,91 @@ class HybridELL:
         fill = L.hell_fill_f64_i32 if val.dtype == torch.float64 else L.hell_fill_f32_i32
         fill(dev, s, n, _p(ptr), _p(col), _p(val), self.width, self.pitch,
              _p(self.ell_col), _p(self.ell_val), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val))
+        # L2-tiled traversal order for banded matrices (0 blocks = plain order)
+        self.order, self.order_grid = None, 0
+        if self.width and tiled:
+            cap = L.hell_order_capacity(n)
+            order = torch.empty(cap, dtype=torch.int32, device=d)
+            g = ctypes.c_int64(0)
+            L.hell_order_i32(dev, s, n, self.width, self.pitch, _p(self.ell_col), order_mode, _p(order), cap, ctypes.byref(g))
+            if g.value:
+                self.order, self.order_grid = order, int(g.value)
 
-    def mul(self, x, y, alpha=1.0, append=False):
+    def mul(self, x, y, alpha=1.0, append=False, tiled=True):
         L = lib()
-        if self.dtype == torch.float64:
-            fn, a = L.spmv_hell_f64_i32, ctypes.c_double(alpha)
+        f64 = self.dtype == torch.float64
+        a = ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha)
+        args = (_dev(y), _stream(y), self.n, a, int(bool(append)), self.width, self.pitch,
+                _p(self.ell_col), _p(self.ell_val), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val),
+                _p(x), _p(y))
+        if tiled and self.order_grid:
+            (L.spmv_hell_ordered_f64_i32 if f64 else L.spmv_hell_ordered_f32_i32)(*args, _p(self.order), self.order_grid)
         else:
-            fn, a = L.spmv_hell_f32_i32, ctypes.c_float(alpha)
-        fn(_dev(y), _stream(y), self.n, a, int(bool(append)), self.width, self.pitch,
-           _p(self.ell_col), _p(self.ell_val), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val),
-           _p(x), _p(y))
+            (L.spmv_hell_f64_i32 if f64 else L.spmv_hell_f32_i32)(*args)
+        return y
+
+
+class SlicedELL:
+    """SELL-512 storage of the ELL part (include/vexhip.h `vexhip_spmv_sell_*`):
+    slice-major, one slice = the 512 rows of one workgroup, so a workgroup streams
+    two contiguous regions.  Width rule and CSR tail are those of hybrid ELL
+    (spmat/hybrid_ell.inl:66-216); same arithmetic, same summation order."""
+
+    def __init__(self, ptr, col, val, tiled=True, order_mode=0):
+        L = lib()
+        self.n = n = ptr.numel() - 1
+        self.dtype = val.dtype
+        dev, s, d = _dev(val), _stream(val), val.device
+        w, tail = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.hell_analyze_i32(dev, s, n, _p(ptr), ctypes.byref(w), ctypes.byref(tail))
+        self.width, self.tail_nnz = int(w.value), int(tail.value)
+        if not self.width:
+            raise Error("SlicedELL needs a non-empty ELL part")
+        self.csr_ptr = self.csr_col = self.csr_val = None
+        f64 = val.dtype == torch.float64
+        if self.tail_nnz:
+            self.csr_ptr = torch.empty(n + 1, dtype=torch.int32, device=d)
+            self.csr_col = torch.empty(self.tail_nnz, dtype=torch.int32, device=d)
+            self.csr_val = torch.empty(self.tail_nnz, dtype=val.dtype, device=d)
+            (L.hell_fill_f64_i32 if f64 else L.hell_fill_f32_i32)(
+                dev, s, n, _p(ptr), _p(col), _p(val), self.width, (n + 15) // 16 * 16, None, None,
+                _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val))
+        ne = L.sell_elems(n, self.width)
+        self.sell_col = torch.empty(ne, dtype=torch.int32, device=d)
+        self.sell_val = torch.empty(ne, dtype=val.dtype, device=d)
+        (L.sell_fill_f64_i32 if f64 else L.sell_fill_f32_i32)(
+            dev, s, n, _p(ptr), _p(col), _p(val), self.width, _p(self.sell_col), _p(self.sell_val))
+        # traversal order for banded / stencil matrices (0 blocks = plain order)
+        self.order, self.order_grid = None, 0
+        if tiled:
+            cap = L.hell_order_capacity(n)
+            order = torch.empty(cap, dtype=torch.int32, device=d)
+            g = ctypes.c_int64(0)
+            L.sell_order_i32(dev, s, n, self.width, _p(self.sell_col), order_mode, _p(order), cap, ctypes.byref(g))
+            if g.value:
+                self.order, self.order_grid = order, int(g.value)
+
+    def mul(self, x, y, alpha=1.0, append=False, tiled=True):
+        L = lib()
+        f64 = self.dtype == torch.float64
+        a = ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha)
+        use = bool(tiled and self.order_grid)
+        (L.spmv_sell_f64_i32 if f64 else L.spmv_sell_f32_i32)(
+            _dev(y), _stream(y), self.n, a, int(bool(append)), self.width, _p(self.sell_col), _p(self.sell_val),
+            _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), _p(x), _p(y),
+            _p(self.order) if use else None, self.order_grid if use else 0)
         return y
 
 
 class SpMat:
     """vex::SpMat<val_t, col_t, idx_t> on one GPU (spmat.hpp:56-185).
 
-    Built from device CSR arrays.  ``fmt='hell'`` (the reference's choice for
-    GPU devices, spmat.hpp:98-103), ``'csr'`` (its CPU-device kernel, run here
-    by the LDS-staged CSR kernel) or ``'auto'``.  ``apply(x, y, alpha, append)``
-    has the semantics of ``SpMat::apply`` (spmat.hpp:120-121):
+    Built from device CSR arrays.  Formats: ``'sell'`` -- hybrid ELL with the ELL
+    part stored slice-major (default for int32 indices: the reference picks hybrid
+    ELL for GPU devices, spmat.hpp:98-103; SELL-512 is its MI355X layout),
+    ``'hell'`` -- the reference's column-major hybrid ELL, ``'csr'`` -- the CSR
+    arrays as given (LDS-staged CSR kernel).  ``apply(x, y, alpha, append)`` has
+    the semantics of ``SpMat::apply`` (spmat.hpp:120-121):
     ``y = alpha*A*x`` or ``y += alpha*A*x``.
     """
 
@@ -164,11 +229,18 @@ class SpMat:
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
         if fmt == "auto":
-            fmt = "hell" if (ptr.dtype == torch.int32 and col.dtype == torch.int32) else "csr"
-        if fmt not in ("hell", "csr"):
+            fmt = "sell" if (ptr.dtype == torch.int32 and col.dtype == torch.int32) else "csr"
+        if fmt not in ("sell", "hell", "csr"):
             raise Error("unknown SpMat format %r" % fmt)
+        self.hell = None
+        if fmt == "sell":
+            try:
+                self.hell = SlicedELL(ptr, col, val)
+            except Error:                        # ELL width 0 (mostly empty rows): CSR is the format
+                fmt = "csr"
+        elif fmt == "hell":
+            self.hell = HybridELL(ptr, col, val)
         self.fmt = fmt
-        self.hell = HybridELL(ptr, col, val) if fmt == "hell" else None
 
     def rows(self):
         return self.n
@@ -182,7 +254,7 @@ class SpMat:
     def apply(self, x, y, alpha=1.0, append=False):
         if x.numel() != self.m:
             raise Error("x has %d elements, matrix has %d columns" % (x.numel(), self.m))
-        if self.fmt == "hell":
+        if self.hell is not None:
             return self.hell.mul(x, y, alpha, append)
         return spmv_csr(self.ptr, self.col, self.val, x, y, alpha, append)
 
