@@ -86,7 +86,7 @@ def main():
     import torch
     import torch.distributed as dist
     from vexcl_amd import lib, ops
-    from vexcl_amd.distributed import DistSpMat, partition
+    from vexcl_amd.distributed import DistReductor, DistSpMat, partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +110,9 @@ def main():
 
     # ---- inputs resident in HBM before the timed region
     ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
-    x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev), 42 + rank)
+    # x is a function of the GLOBAL index, so the job computes the same product for every N
+    x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev),
+                      (42 + r0 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
     y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
     if world == 1 and not args.dist:
         A = ops.SpMat(ptr, col, val, fmt=args.format)
@@ -154,6 +156,7 @@ def main():
     ms = ctypes.c_float()
     L.event_elapsed_ms(local_rank, e0, e1, ctypes.byref(ms))
 
+    checksum = DistReductor("SUM_Kahan")(y)          # sum(y): the same for every N up to rounding
     elapsed = t1 - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -183,6 +186,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "checksum_sum_y": checksum,
             "hbm_gbps": round(gbps, 1),
             "hbm_frac_of_peak": round(gbps / (HBM_PEAK_GBPS * world), 4),
             "config": {"workload": "configs[%d]: 7-point 3D Poisson %d^3, N=%d rows, nnz=%d, fp64 values, int32 indices"

@@ -92,10 +92,20 @@ def _worker(rank, world, port, case, out):
             A.apply(xs, ys, 1.5, True)
         err = np.abs(ys.numpy() - want[r0:r1])
         ok = bool(np.all(err <= 1e-10 * np.maximum(bound[r0:r1], 1e-300)))
+        # Reductor final combine across ranks (all-reduce of one scalar per rank)
+        from vexcl_amd.distributed import DistReductor
+
+        class HostReductor:                             # test double for the device stage
+            def __init__(self, f): self.f = f
+            def device_result(self, t): return self.f(t).reshape(1)
+        tot = DistReductor("SUM", local=HostReductor(torch.sum))(ys)
+        ok_red = abs(tot - float(want.sum())) <= 1e-9 * float(np.abs(want).sum())
+        mx = DistReductor("MAX", local=HostReductor(torch.max))(ys)
+        ok_red = ok_red and abs(mx - float(want.max())) <= 1e-9 * float(np.abs(want).max())
         ys2 = torch.full_like(ys, 123.0)                # SET semantics overwrite
         A.apply(xs, ys2, 1.0, False)
         ok = ok and bool(np.allclose(ys2.numpy(), oracle.spmv_csr(ptr, col, val, x)[r0:r1], rtol=1e-12, atol=1e-12))
-        out[rank] = 1 if ok else 0
+        out[rank] = 1 if (ok and ok_red) else 0
     finally:
         dist.destroy_process_group()
 

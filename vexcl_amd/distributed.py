@@ -197,3 +197,26 @@ class DistSpMat:
         if self.rem is not None:                                            # phase 5
             self.rem.apply(self.ghost_buf, y, alpha, True)
         return y
+
+
+class DistReductor:
+    """vex::Reductor across the GPUs of a job: each rank reduces its segment to ONE
+    scalar on the device (both stages, vexcl_amd.ops.Reductor) and the final
+    combine is an all-reduce of that scalar over RCCL (the reference folds the
+    per-device partials on the host, reductor.hpp:412-436)."""
+    _OPS = {"SUM": dist.ReduceOp.SUM, "SUM_Kahan": dist.ReduceOp.SUM, "MIN": dist.ReduceOp.MIN, "MAX": dist.ReduceOp.MAX}
+
+    def __init__(self, op="SUM", group=None, local=None):
+        if op not in self._OPS:
+            raise ValueError("unsupported distributed reduction %r" % op)
+        self.op, self.group = op, group
+        if local is None:
+            from . import ops
+            local = ops.Reductor(op)
+        self.local = local
+
+    def __call__(self, x):
+        r = self.local.device_result(x).clone()
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(r, op=self._OPS[self.op], group=self.group)
+        return r.cpu()[0].item()
