@@ -208,6 +208,9 @@ int vexhip_reduce_num_groups(int dev, int *groups, int *block);
  * exclusive != 0: out[i] = init + in[0] + ... + in[i-1].  In-place allowed.
  * `init` points to ONE host element of the dtype (ignored for inclusive).     */
 size_t vexhip_scan_tmp_bytes(int dtype, int64_t n);
+/* integer scans use a single-pass decoupled look-back kernel (1 read + 1 write per
+ * element); 0 forces the deterministic reduce-then-scan path (A/B, tests)       */
+int vexhip_scan_set_lookback(int enable);
 int vexhip_scan(int dev, void *stream, int dtype, int exclusive, const void *init_host,
         const void *in, void *out, int64_t n, void *tmp);
 

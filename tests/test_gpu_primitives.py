@@ -161,3 +161,35 @@ def test_fill_hash_matches_host_restatement(T):
     assert np.array_equal(t.cpu().numpy(), (z >> np.uint64(11)).astype(np.float64) / 2.0 ** 53)
     t = T.ops.fill_hash(T.torch.empty(n, dtype=T.torch.int32, device=T.dev), seed)
     assert np.array_equal(t.cpu().numpy().view(np.uint32), (z >> np.uint64(32)).astype(np.uint32))
+
+
+def test_scan_lookback_equals_reduce_then_scan_and_is_repeatable(T, oracle, built_lib):
+    # single-pass decoupled look-back (integers) vs the deterministic 3-kernel path; repeated to shake out races
+    n = (1 << 24) + 4099
+    x = oracle.random_u32(77, n)
+    want = oracle.inclusive_scan(x)
+    d = _u32(T, x)
+    built_lib.scan_set_lookback(0)
+    try:
+        ref = T.ops.inclusive_scan(d, unsigned=True).cpu().numpy().view(np.uint32)
+    finally:
+        built_lib.scan_set_lookback(1)
+    assert np.array_equal(ref, want)
+    for rep in range(20):
+        out = T.ops.inclusive_scan(d, unsigned=True)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want), rep
+    l = (x.astype(np.int64) << 20) - 12345
+    dl = T.up(l)
+    for rep in range(5):                                  # 64-bit: two status words per tile
+        out = T.ops.exclusive_scan(dl, init=5)
+        assert np.array_equal(out.cpu().numpy(), oracle.exclusive_scan(l, 5)), rep
+    # in place, under load from another stream
+    s2 = T.torch.cuda.Stream()
+    junk = T.torch.empty(1 << 26, dtype=T.torch.float32, device=T.dev)
+    with T.torch.cuda.stream(s2):
+        for _ in range(10):
+            junk.normal_()
+    dd = _u32(T, x)
+    T.ops.inclusive_scan(dd, dd, unsigned=True)
+    T.torch.cuda.synchronize()
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32), want)

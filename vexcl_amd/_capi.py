@@ -108,6 +108,7 @@ _PROTOS = {
     "vexhip_reduce_dot": (None, [c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "vexhip_reduce_finish": (None, [c_int, c_vp, c_int, c_int, c_vp, c_i64, c_vp]),
     "vexhip_reduce_num_groups": (None, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "vexhip_scan_set_lookback": (None, [c_int]),
     "vexhip_scan_tmp_bytes": (c_size, [c_int, c_i64]),
     "vexhip_scan": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vexhip_sort_tmp_bytes": (c_size, [c_int, c_i64]),
