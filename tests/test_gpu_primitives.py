@@ -95,7 +95,7 @@ def test_scan_golden_and_types(T, oracle):
     assert np.allclose(got, np.cumsum(f.astype(np.float64)), rtol=1e-5)
 
 
-@pytest.mark.parametrize("n", [2, 100, 4096, 4097, 1 << 20, (1 << 22) + 5])
+@pytest.mark.parametrize("n", [2, 100, 4096, 4097, 12288, 12289, 3 * 12288 - 1, 1 << 20, (1 << 22) + 5])
 def test_sort_u32_exact(T, oracle, n):
     x = oracle.random_u32(n + 1, n)
     d = _u32(T, x)

@@ -2,10 +2,10 @@
 // The reference is a merge sort (sort.hpp:820-1696) and its contract -- pinned
 // by tests/sort.cpp:22-45 -- is std::stable_sort.  Here: stable LSD radix sort,
 // 8-bit digits.  Per pass:
-//   (1) digit histogram per 4096-key tile        -> table[digit][tile]
+//   (1) digit histogram per tile (12 288 u32 keys) -> table[digit][tile]
 //   (2) exclusive scan of the table (scan.hip)   -> global base per (digit,tile)
 //   (3) scatter: wave-64 ballot match ranks the keys of a wave stably, LDS
-//       per-wave digit counters order the 4 waves, the tile is re-ordered in
+//       per-wave digit counters order the 16 waves, the tile is re-ordered in
 //       LDS and written out as runs of equal digits (coalesced).
 // Signed and floating keys are mapped to order-preserving unsigned bits on the
 // fly; the stored keys stay untouched.
@@ -20,11 +20,15 @@ size_t scan_tmp_elems_u32(int64_t n);
 
 namespace {
 
-constexpr int RB = 256;              // lanes per workgroup
-constexpr int RW = RB / kWave;       // waves
-constexpr int KPT = 16;              // keys per lane
-constexpr int RTILE = RB * KPT;      // 4096 keys per tile
+constexpr int RB = 1024;             // lanes per scatter workgroup (16 waves)
+constexpr int RW = RB / kWave;
+constexpr int HB = 256;              // lanes per histogram workgroup
 constexpr int RADIX = 256;
+
+// Keys per lane.  A tile is re-ordered in LDS, so (key + value) bytes x tile must
+// stay near 48 KiB (two workgroups per CU); longer tiles = longer runs of equal
+// digits = better coalesced scatter writes (12 288 u32 keys: 48-key runs).
+constexpr int keys_per_lane(int key_bytes, int value_bytes) { return 48 / (key_bytes + value_bytes); }
 
 enum { KEY_UNSIGNED = 0, KEY_SIGNED = 1, KEY_FLOAT = 2 };
 
@@ -38,22 +42,32 @@ __device__ __forceinline__ K to_ordered(K k) {
     return k;
 }
 
-template <typename K, int MODE, bool DESC>
-__global__ __launch_bounds__(RB)
-void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsigned nblocks, unsigned *__restrict__ table)
+template <typename K, int MODE, bool DESC, int KPT>
+__global__ __launch_bounds__(HB)
+void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsigned nblocks, unsigned *__restrict__ table, int vec_ok)
 {
+    constexpr int TILE = RB * KPT;
+    constexpr int VN = 16 / (int)sizeof(K);
+    typedef K vtype __attribute__((ext_vector_type(16 / sizeof(K))));
     __shared__ unsigned s_h[RADIX];
     s_h[threadIdx.x] = 0;
     __syncthreads();
-    const long long base = (long long)blockIdx.x * RTILE;
+    const long long base = (long long)blockIdx.x * TILE;
+    const int count = (int)((n - base < TILE) ? (n - base) : TILE);
+    int done = 0;
+    if (vec_ok) {
+        const int nv = count / VN;
+        const vtype *kv = reinterpret_cast<const vtype *>(keys + base);
+        for (int v = threadIdx.x; v < nv; v += HB) {
+            vtype q = kv[v];
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        long long i = base + k * RB + threadIdx.x;
-        if (i < n) {
-            unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(keys[i]) >> shift) & (RADIX - 1);
-            atomicAdd(&s_h[d], 1u);
+            for (int j = 0; j < VN; ++j)
+                atomicAdd(&s_h[(unsigned)(to_ordered<K, MODE, DESC>(q[j]) >> shift) & (RADIX - 1)], 1u);
         }
+        done = nv * VN;
     }
+    for (int i = done + threadIdx.x; i < count; i += HB)
+        atomicAdd(&s_h[(unsigned)(to_ordered<K, MODE, DESC>(keys[base + i]) >> shift) & (RADIX - 1)], 1u);
     __syncthreads();
     table[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
 }
@@ -63,36 +77,35 @@ template <> struct valtype<0> { typedef char type; };
 template <> struct valtype<4> { typedef unsigned type; };
 template <> struct valtype<8> { typedef unsigned long long type; };
 
-template <typename K, int MODE, bool DESC, int VB>
+template <typename K, int MODE, bool DESC, int VB, int KPT>
 __global__ __launch_bounds__(RB)
 void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
         long long n, int shift, unsigned nblocks, const unsigned *__restrict__ table)
 {
     typedef typename valtype<VB>::type VT;
+    constexpr int TILE = RB * KPT;
     const VT *vals_in = reinterpret_cast<const VT *>(vals_in_);
     VT *vals_out = reinterpret_cast<VT *>(vals_out_);
 
-    __shared__ K s_keys[RTILE];
-    __shared__ VT s_vals[VB ? RTILE : 1];
+    __shared__ K s_keys[TILE];
+    __shared__ VT s_vals[VB ? TILE : 1];
     __shared__ unsigned s_hist[RW][RADIX];
     __shared__ unsigned s_dstart[RADIX];
     __shared__ unsigned s_gbase[RADIX];
-    __shared__ unsigned s_wtot[RW];
+    __shared__ unsigned s_wtot[RADIX / kWave];
 
     const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
-    const long long base = (long long)blockIdx.x * RTILE;
+    const long long base = (long long)blockIdx.x * TILE;
     const long long wbase = base + (long long)wave * (kWave * KPT);
-    const int nvalid = (int)((n - base < RTILE) ? (n - base) : RTILE);
+    const int nvalid = (int)((n - base < TILE) ? (n - base) : TILE);
 
-#pragma unroll
-    for (int w = 0; w < RW; ++w) s_hist[w][t] = 0;
+    for (int i = t; i < RW * RADIX; i += RB) (&s_hist[0][0])[i] = 0;
 
     K key[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         long long i = wbase + k * kWave + lane;
-        // padding keys sort last inside the tile and are never written out
         key[k] = (i < n) ? keys_in[i] : K(0);
     }
     __syncthreads();
@@ -129,22 +142,24 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
     }
     __syncthreads();
 
-    // digit t: exclusive offsets across the waves, tile count, tile-local start
-    unsigned count = 0;
+    // lanes 0..255: digit t -> exclusive offsets across the 16 waves, tile count, tile-local start
+    unsigned count = 0, inc = 0;
+    if (t < RADIX) {
 #pragma unroll
-    for (int w = 0; w < RW; ++w) { unsigned c = s_hist[w][t]; s_hist[w][t] = count; count += c; }
-    {
-        unsigned inc = count;
+        for (int w = 0; w < RW; ++w) { unsigned c = s_hist[w][t]; s_hist[w][t] = count; count += c; }
+        inc = count;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             unsigned u = __shfl_up(inc, off, 64);
             if (lane >= off) inc += u;
         }
         if (lane == kWave - 1) s_wtot[wave] = inc;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (t < RADIX) {
         unsigned woff = 0;
 #pragma unroll
-        for (int w = 0; w < RW; ++w) if (w < wave) woff += s_wtot[w];
+        for (int w = 0; w < RADIX / kWave; ++w) if (w < wave) woff += s_wtot[w];
         unsigned dstart = woff + inc - count;
         s_dstart[t] = dstart;
         s_gbase[t] = table[(size_t)t * nblocks + blockIdx.x] - dstart;
@@ -173,21 +188,26 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
     }
 }
 
+template <typename K, int VB> constexpr int kpt_for() { return keys_per_lane((int)sizeof(K), VB); }
+
 template <typename K, int MODE, bool DESC, int VB>
 int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp) {
-    const unsigned nblocks = (unsigned)((n + RTILE - 1) / RTILE);
+    constexpr int KPT = kpt_for<K, VB>();
+    constexpr int TILE = RB * KPT;
+    const unsigned nblocks = (unsigned)((n + TILE - 1) / TILE);
     const int64_t tn = (int64_t)nblocks * RADIX;
     unsigned *table = tmp;
     unsigned *scan_tmp = tmp + (tn + 3) / 4 * 4;
     K *src = keys, *dst = keys_tmp;
     void *vsrc = vals, *vdst = vals_tmp;
     constexpr int passes = (int)sizeof(K);
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(keys) & 15) == 0) && ((reinterpret_cast<uintptr_t>(keys_tmp) & 15) == 0);
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        radix_hist_kernel<K, MODE, DESC><<<nblocks, RB, 0, s>>>(src, n, shift, nblocks, table);
+        radix_hist_kernel<K, MODE, DESC, KPT><<<nblocks, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
         VEXHIP_LAUNCH_CHECK();
         if (int rc = scan_exclusive_u32_tmp(s, table, table, tn, scan_tmp)) return rc;
-        radix_scatter_kernel<K, MODE, DESC, VB><<<nblocks, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, table);
+        radix_scatter_kernel<K, MODE, DESC, VB, KPT><<<nblocks, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, table);
         VEXHIP_LAUNCH_CHECK();
         std::swap(src, dst);
         std::swap(vsrc, vdst);
@@ -215,7 +235,8 @@ extern "C" {
 
 size_t vexhip_sort_tmp_bytes(int key_dtype, int64_t n) {
     (void)key_dtype;
-    int64_t nblocks = (n + RTILE - 1) / RTILE;
+    const int64_t smallest_tile = RB * 3;                 // (8-byte key, 8-byte value)
+    int64_t nblocks = (n + smallest_tile - 1) / smallest_tile;
     int64_t tn = nblocks * RADIX;
     return sizeof(unsigned) * (size_t)((tn + 3) / 4 * 4 + (int64_t)scan_tmp_elems_u32(tn) + 4);
 }
