@@ -122,48 +122,55 @@ int vexhip_spmv_hell_f32_i32(int dev, void *stream, int64_t n, float alpha, int 
         const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y);
 
-/* L2-tiled traversal order for banded / stencil matrices (setup, blocking).
- * Detects constant column offsets (e.g. +-1, +-n, +-n^2) in the ELL part and, if
- * the farthest one is too long for the x values of three "planes" to stay in one
- * XCD's 4 MiB L2, writes a workgroup -> row-block permutation that walks the rows
- * in 64 Ki-row tiles, plane after plane, per XCD.  *grid_blocks = 0 means "use
- * the plain product".  order must hold vexhip_hell_order_capacity(n) ints.
- * The ordered product computes exactly what vexhip_spmv_hell_* computes.        */
-int64_t vexhip_hell_order_capacity(int64_t n);
+/* Traversal order for banded / stencil matrices (setup, blocking).
+ * Detects constant column offsets (e.g. +-1, +-n, +-n^2 of a 3-D stencil) in the
+ * ELL part.  If the farthest one (S_big, a "plane") is too long for the x values of
+ * three planes to stay in one XCD's 4 MiB L2, the traversal gives every XCD a strip
+ * of consecutive row-blocks of EVERY plane and sweeps plane after plane: both the
+ * +-n neighbours and the +-n^2 re-reads stay in ONE private L2 (workgroup b runs on
+ * XCD b % 8), so x is fetched from HBM about once instead of three times.
+ * grid_blocks == 0 means "use the plain order".  The ordered product computes
+ * exactly what the plain one computes (any permutation of row-blocks is correct). */
+typedef struct vexhip_traversal {
+    int64_t grid_blocks;      /* workgroups to launch; 0 = plain order                          */
+    int64_t chunk;            /* > 0: strip order, computed arithmetically inside the kernel:   */
+    int64_t planes;           /*   workgroup b -> row-block p*plane_blocks + t*8*chunk          */
+    int64_t plane_blocks;     /*   + (b%8)*chunk + (b/8)%chunk, p = (b/(8*chunk)) % planes      */
+    const int32_t *order;     /* != NULL: explicit workgroup -> row-block map in device memory  */
+} vexhip_traversal;
+int64_t vexhip_hell_order_capacity(int64_t n);     /* ints needed by an explicit map */
+/* mode 0 = default (arithmetic strips, `order` may be NULL), 1 = per-XCD slabs,
+ * 2 = round-robin tiles, 100+k = strips of k row-blocks (tuning; modes 1, 2 write `order`) */
 int vexhip_hell_order_i32(int dev, void *stream, int64_t n, int64_t ell_width, int64_t ell_pitch,
-        const int32_t *ell_col, int mode /* 0 = default (each XCD owns a strip of every plane), 1 = per-XCD slabs,
-                    2 = round-robin tiles, 100+k = strips of k row-blocks */,
-        int32_t *order, int64_t capacity, int64_t *grid_blocks);
-int vexhip_sell_order_i32(int dev, void *stream, int64_t n, int64_t ell_width,
-        const int32_t *sell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks);
+        const int32_t *ell_col, int mode, int32_t *order, int64_t capacity, vexhip_traversal *out);
+int vexhip_sell_order_i32(int dev, void *stream, int64_t n, int64_t ell_width, int value_bytes,
+        const void *sell, int mode, int32_t *order, int64_t capacity, vexhip_traversal *out);
 int vexhip_spmv_hell_ordered_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
         int64_t ell_width, int64_t ell_pitch, const int32_t *ell_col, const double *ell_val,
         const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
-        const double *x, double *y, const int32_t *order, int64_t grid_blocks);
+        const double *x, double *y, const vexhip_traversal *traversal);
 int vexhip_spmv_hell_ordered_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
         int64_t ell_width, int64_t ell_pitch, const int32_t *ell_col, const float *ell_val,
         const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
-        const float *x, float *y, const int32_t *order, int64_t grid_blocks);
+        const float *x, float *y, const vexhip_traversal *traversal);
 
-/* Sliced ELL (SELL-512): the ELL part stored slice-major (one slice = the 512 rows
- * of one workgroup; element (r, j) of slice s at s*w*512 + j*512 + r), so that a
- * workgroup streams two contiguous regions.  Same width rule, same CSR tail,
- * same arithmetic and summation order as hybrid ELL.  Arrays hold
- * vexhip_sell_elems(n, w) elements; `order`/grid_blocks as for the ordered HELL
- * product (NULL / 0 = plain order).                                               */
-int64_t vexhip_sell_elems(int64_t n, int64_t ell_width);
+/* Sliced ELL (SELL-512): the ELL part stored slice-major.  One slice = the 512 rows
+ * of one workgroup = ONE contiguous region of w*512*(4 + sizeof(value)) bytes:
+ * first its w*512 int32 columns (element (r, j) at j*512 + r), then its w*512
+ * values in the same order.  Same width rule, same CSR tail, same arithmetic and
+ * summation order as hybrid ELL.  The buffer holds vexhip_sell_bytes(n, w,
+ * value_bytes) bytes; `traversal` as for the ordered HELL product (NULL = plain).  */
+int64_t vexhip_sell_bytes(int64_t n, int64_t ell_width, int value_bytes);
 int vexhip_sell_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
-        int64_t ell_width, int32_t *sell_col, double *sell_val);
+        int64_t ell_width, void *sell);
 int vexhip_sell_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
-        int64_t ell_width, int32_t *sell_col, float *sell_val);
+        int64_t ell_width, void *sell);
 int vexhip_spmv_sell_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width,
-        const int32_t *sell_col, const double *sell_val,
-        const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
-        const double *x, double *y, const int32_t *order, int64_t grid_blocks);
+        const void *sell, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const vexhip_traversal *traversal);
 int vexhip_spmv_sell_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width,
-        const int32_t *sell_col, const float *sell_val,
-        const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
-        const float *x, float *y, const int32_t *order, int64_t grid_blocks);
+        const void *sell, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const vexhip_traversal *traversal);
 
 /* CSR -> hybrid ELL conversion on the device (sparse/ell.hpp:400-508,
  * `convert_csr2ell` :348-397; width rule hybrid_ell.inl:66-114).

@@ -102,14 +102,15 @@ def test_hell_kernel_variants_agree(T, oracle, built_lib, variant):
 
 
 def test_sell_layout_and_tail(T, oracle):
-    # slice-major storage: element (r, j) of slice s at s*w*512 + j*512 + r; same width rule / tail as HELL
+    # slice-major storage, one contiguous region per slice; same width rule / tail as HELL
     ptr, col, val = oracle.random_matrix(33, 1500, 1500, 16)
     h = oracle.hell_build(ptr, col, val)
     S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
     assert (S.width, S.tail_nnz) == (h["width"], h["tail"])
     w, n = S.width, 1500
-    sc = S.sell_col.cpu().numpy().reshape(-1, w, 512)
-    sv = S.sell_val.cpu().numpy().reshape(-1, w, 512)
+    raw = S.sell.cpu().numpy().reshape(-1, w * 512 * 12)               # one region per slice: columns, then values
+    sc = raw[:, :w * 512 * 4].copy().view(np.int32).reshape(-1, w, 512)
+    sv = raw[:, w * 512 * 4:].copy().view(np.float64).reshape(-1, w, 512)
     ec = h["ell_col"].reshape(w, h["pitch"])
     ev = h["ell_val"].reshape(w, h["pitch"])
     for i in (0, 1, 511, 512, 1023, 1499):
@@ -208,7 +209,7 @@ def test_poisson512_properties(T):
     A_ell = ops.SpMat(dp, dc, dv)                       # default format: SELL-512
     assert A_ell.fmt == "sell" and A_ell.hell.width == 7 and A_ell.hell.tail_nnz == 0
     A_hell = ops.SpMat(dp, dc, dv, fmt="hell")          # reference layout + L2-tiled traversal order
-    assert A_hell.hell.order_grid >= N // 512
+    assert A_hell.hell.order_grid >= N // 512 and A_ell.hell.order_grid >= N // 512
 
     x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=T.dev), 42)
     y1 = A_csr @ x

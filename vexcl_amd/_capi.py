@@ -48,6 +48,12 @@ class DeviceProps(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class Traversal(ctypes.Structure):
+    """vexhip_traversal (include/vexhip.h)."""
+    _fields_ = [("grid_blocks", ctypes.c_int64), ("chunk", ctypes.c_int64), ("planes", ctypes.c_int64),
+                ("plane_blocks", ctypes.c_int64), ("order", ctypes.c_void_p)]
+
+
 # name -> (restype, argtypes); restype None means "int status, checked"
 _PROTOS = {
     "vexhip_last_error": (ctypes.c_char_p, []),
@@ -89,15 +95,15 @@ _PROTOS = {
     "vexhip_spmv_hell_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64, c_i64] + [c_vp] * 7),
     "vexhip_spmv_hell_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64, c_i64] + [c_vp] * 7),
     "vexhip_hell_order_capacity": (c_i64, [c_i64]),
-    "vexhip_hell_order_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, ctypes.POINTER(c_i64)]),
-    "vexhip_sell_order_i32": (None, [c_int, c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, ctypes.POINTER(c_i64)]),
-    "vexhip_spmv_hell_ordered_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64, c_i64] + [c_vp] * 8 + [c_i64]),
-    "vexhip_spmv_hell_ordered_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64, c_i64] + [c_vp] * 8 + [c_i64]),
-    "vexhip_sell_elems": (c_i64, [c_i64, c_i64]),
-    "vexhip_sell_fill_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    "vexhip_sell_fill_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    "vexhip_spmv_sell_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 8 + [c_i64]),
-    "vexhip_spmv_sell_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 8 + [c_i64]),
+    "vexhip_hell_order_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, ctypes.POINTER(Traversal)]),
+    "vexhip_sell_order_i32": (None, [c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_int, c_vp, c_i64, ctypes.POINTER(Traversal)]),
+    "vexhip_spmv_hell_ordered_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmv_hell_ordered_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
+    "vexhip_sell_bytes": (c_i64, [c_i64, c_i64, c_int]),
+    "vexhip_sell_fill_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "vexhip_sell_fill_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "vexhip_spmv_sell_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmv_sell_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Traversal)]),
     "vexhip_hell_analyze_i32": (None, [c_int, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "vexhip_hell_fill_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64] + [c_vp] * 5),
     "vexhip_hell_fill_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64] + [c_vp] * 5),

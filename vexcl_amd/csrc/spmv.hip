@@ -15,6 +15,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 namespace vexhip {
@@ -66,6 +67,25 @@ __device__ __forceinline__ long long logical_block(long long nblocks) {
         return lb;     // may be >= nblocks for the ragged tail: caller checks
     }
     return b;
+}
+
+// Traversal: which row-block a workgroup processes (include/vexhip.h
+// vexhip_traversal).  Strip order is pure arithmetic -- no dependent load at
+// workgroup start; an explicit map is one scalar load.
+struct trav_dev { const int *order; int chunk, planes, plane_blocks; };
+
+__device__ __forceinline__ long long traversal_block(const trav_dev &t, long long nblocks) {
+    const long long b = blockIdx.x;
+    if (t.order) return t.order[b];
+    if (t.chunk > 0) {
+        const long long k = b & 7, q = b >> 3;
+        const long long i = q % t.chunk, r = q / t.chunk;
+        const long long p = r % t.planes, tile = r / t.planes;
+        const long long l = tile * 8 * t.chunk + k * t.chunk + i;
+        const long long lb = p * t.plane_blocks + l;
+        return (l < t.plane_blocks && lb < nblocks) ? lb : -1;
+    }
+    return b < nblocks ? b : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -198,12 +218,11 @@ void hell_kernel(long long n, long long nblocks, V alpha, int append,
         int ell_w, long long pitch,
         const int *__restrict__ ell_col, const V *__restrict__ ell_val,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, const int *__restrict__ order)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
 {
-    // order != NULL: a precomputed workgroup -> row-block map (vexhip_hell_order_i32)
-    // that walks the rows in L2-sized tiles; any permutation is correct.
+    // a traversal (vexhip_hell_order_i32) walks the rows in L2-sized strips; any permutation is correct
     long long lb;
-    if (order) { lb = order[blockIdx.x]; if (lb < 0) return; }
+    if (trav.order || trav.chunk > 0) { lb = traversal_block(trav, nblocks); if (lb < 0) return; }
     else { lb = logical_block<SWZ>(nblocks); if (lb >= nblocks) return; }
     const long long i = (lb * 256 + threadIdx.x) * RPT;
     if (i >= n) return;
@@ -255,28 +274,31 @@ void hell_kernel(long long n, long long nblocks, V alpha, int append,
 
 // ---------------------------------------------------------------------------
 // Sliced ELL (SELL-512): the ELL part stored slice-major, one slice = the 512
-// rows of one workgroup, element (r, j) of slice s at s*w*512 + j*512 + r.  A
-// workgroup then streams TWO contiguous regions (w*2 KiB of columns, w*4 KiB of
-// values) instead of 2*w segments that lie pitch*4 / pitch*8 bytes apart:
-// fewer DRAM pages and TLB entries per workgroup.  Same arithmetic, same order.
+// rows of one workgroup; a slice is ONE contiguous region of w*512*(4+sizeof(V))
+// bytes: its w*512 columns (element (r, j) at j*512 + r) followed by its w*512
+// values.  A workgroup then streams 42 KiB (w = 7, fp64) front to back instead of
+// 2*w segments that lie pitch*4 / pitch*8 bytes apart: fewer DRAM pages and TLB
+// entries per workgroup, and the column / value streams never collide on the same
+// memory channels.  Same arithmetic, same order.
 // ---------------------------------------------------------------------------
 constexpr int SELL_ROWS = 512;
 
 template <typename V, int W, bool NT>
 __global__ __launch_bounds__(256)
 void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
-        const int *__restrict__ sell_col, const V *__restrict__ sell_val,
+        const char *__restrict__ sell,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, const int *__restrict__ order)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
 {
-    long long s;
-    if (order) { s = order[blockIdx.x]; if (s < 0) return; }
-    else { s = blockIdx.x; if (s >= nslices) return; }
+    const long long s = traversal_block(trav, nslices);
+    if (s < 0) return;
     const int r = 2 * threadIdx.x;
     const long long i = s * SELL_ROWS + r;
     const int w = W > 0 ? W : ell_w;
-    const int *cp = sell_col + s * (long long)w * SELL_ROWS + r;
-    const V *vp = sell_val + s * (long long)w * SELL_ROWS + r;
+    // one contiguous region per slice: w*512 columns, then w*512 values
+    const char *slice = sell + s * ((long long)w * SELL_ROWS * (4 + (long long)sizeof(V)));
+    const int *cp = reinterpret_cast<const int *>(slice) + r;
+    const V *vp = reinterpret_cast<const V *>(slice + (long long)w * SELL_ROWS * 4) + r;
 
     V sum[2] = {V(0), V(0)};
     if constexpr (W > 0) {
@@ -320,17 +342,19 @@ template <typename V>
 __global__ __launch_bounds__(256)
 void sell_fill_kernel(long long n, long long nslices, int w,
         const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
-        int *__restrict__ sell_col, V *__restrict__ sell_val)
+        char *__restrict__ sell)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nslices * SELL_ROWS;
          i += (long long)gridDim.x * blockDim.x) {
         int b = 0, e = 0;
         if (i < n) { b = ptr[i]; e = ptr[i + 1]; }
-        const long long base = (i / SELL_ROWS) * (long long)w * SELL_ROWS + (i % SELL_ROWS);
+        char *slice = sell + (i / SELL_ROWS) * ((long long)w * SELL_ROWS * (4 + (long long)sizeof(V)));
+        int *sc = reinterpret_cast<int *>(slice) + (i % SELL_ROWS);
+        V *sv = reinterpret_cast<V *>(slice + (long long)w * SELL_ROWS * 4) + (i % SELL_ROWS);
         for (int j = 0; j < w; ++j) {
             bool in = b + j < e;
-            sell_col[base + (long long)j * SELL_ROWS] = in ? col[b + j] : -1;
-            sell_val[base + (long long)j * SELL_ROWS] = in ? val[b + j] : V(0);
+            sc[j * SELL_ROWS] = in ? col[b + j] : -1;
+            sv[j * SELL_ROWS] = in ? val[b + j] : V(0);
         }
     }
 }
@@ -391,7 +415,7 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
 template <typename V, int RPT, bool NT, bool SWZ>
 int launch_hell_w(hipStream_t s, long long grid, long long nb, int64_t n, V alpha, int append,
         int w, int64_t pitch, const int *ec, const V *ev,
-        const int *cp, const int *cc, const V *cv, const V *x, V *y, const int *order)
+        const int *cp, const int *cc, const V *cv, const V *x, V *y, trav_dev order)
 {
 #define CASE(W) case W: hell_kernel<V, RPT, W, NT, SWZ><<<(unsigned)grid, 256, 0, s>>>( \
         n, nb, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, order); break;
@@ -408,7 +432,7 @@ template <typename V>
 int spmv_hell(int dev, void *stream, int64_t n, V alpha, int append,
         int64_t w, int64_t pitch, const int *ec, const V *ev,
         const int *cp, const int *cc, const V *cv, const V *x, V *y,
-        const int *order = nullptr, int64_t order_grid = 0)
+        const vexhip_traversal *tr = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 0, "negative size");
     if (n == 0) return 0;
@@ -436,15 +460,18 @@ int spmv_hell(int dev, void *stream, int64_t n, V alpha, int append,
     if (rpt > 1 && w > 0 && ((pitch % 16) != 0 || !aligned16(ec) || !aligned16(ev))) rpt = 1;
     if (rpt == 3 || rpt > 4) rpt = 4;
 
-    if (order && order_grid > 0) {
-        // the order was built for kHellOrderRows rows per workgroup
+    trav_dev order = {nullptr, 0, 0, 0};
+    const bool ordered = tr && tr->grid_blocks > 0;
+    if (ordered) {
+        // the traversal was built for kHellOrderRows rows per workgroup
         VEXHIP_REQUIRE(w > 0 && (pitch % 16) == 0 && aligned16(ec) && aligned16(ev), "ordered HELL product needs aligned ELL arrays");
         rpt = kHellOrderRows / 256;
         nt = true;
-    } else order = nullptr;
+        order = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
+    }
 
     long long nb = (n + (long long)256 * rpt - 1) / ((long long)256 * rpt);
-    long long grid = order ? order_grid : (swz ? ((nb + 7) / 8) * 8 : nb);
+    long long grid = ordered ? tr->grid_blocks : (swz ? ((nb + 7) / 8) * 8 : nb);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
 
 #define GO(RPT, NT, SWZ) launch_hell_w<V, RPT, NT, SWZ>(s, grid, nb, n, alpha, append, (int)w, pitch, ec, ev, cp, cc, cv, x, y, order)
@@ -460,22 +487,25 @@ int spmv_hell(int dev, void *stream, int64_t n, V alpha, int append,
 
 template <typename V>
 int spmv_sell(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
-        const int *sc, const V *sv, const int *cp, const int *cc, const V *cv, const V *x, V *y,
-        const int *order, int64_t order_grid)
+        const void *sell, const int *cp, const int *cc, const V *cv, const V *x, V *y,
+        const vexhip_traversal *tr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL geometry");
     if (n == 0) return 0;
-    VEXHIP_REQUIRE(sc && sv && x && y && aligned16(sc) && aligned16(sv), "SELL arrays must be 16-byte aligned");
+    VEXHIP_REQUIRE(sell && x && y && aligned16(sell), "the SELL buffer must be 16-byte aligned");
+    const char *sc = static_cast<const char *>(sell);
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
     long long ns = (n + SELL_ROWS - 1) / SELL_ROWS;
-    long long grid = (order && order_grid > 0) ? order_grid : ns;
-    if (!(order && order_grid > 0)) order = nullptr;
+    const bool ordered = tr && tr->grid_blocks > 0;
+    long long grid = ordered ? tr->grid_blocks : ns;
+    trav_dev order = {nullptr, 0, 0, 0};
+    if (ordered) order = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
-#define CASE(W) case W: sell_kernel<V, W, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, sv, cp, cc, cv, x, y, order); break;
+#define CASE(W) case W: sell_kernel<V, W, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
-        default: sell_kernel<V, 0, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, sv, cp, cc, cv, x, y, order);
+        default: sell_kernel<V, 0, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order);
     }
 #undef CASE
     VEXHIP_LAUNCH_CHECK();
@@ -483,13 +513,13 @@ int spmv_sell(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
 }
 
 template <typename V>
-int sell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w, int *sc, V *sv) {
+int sell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w, void *sell) {
     VEXHIP_REQUIRE(n >= 0 && w >= 1, "bad SELL geometry");
     if (n == 0) return 0;
     VEXHIP_SET_DEVICE(dev);
     long long ns = (n + SELL_ROWS - 1) / SELL_ROWS;
     int grid = (int)std::min<int64_t>((ns * SELL_ROWS + 255) / 256, (int64_t)info(dev).cus * 16);
-    sell_fill_kernel<V><<<grid, 256, 0, as_stream(stream)>>>(n, ns, (int)w, ptr, col, val, sc, sv);
+    sell_fill_kernel<V><<<grid, 256, 0, as_stream(stream)>>>(n, ns, (int)w, ptr, col, val, static_cast<char *>(sell));
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -504,8 +534,9 @@ void ell_offset_agree_kernel(long long n, int w, long long pitch, const int *__r
         const long long off = ref[j];
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
              i += (long long)gridDim.x * blockDim.x) {
-            // pitch == 0: SELL-512 storage
-            long long e = pitch ? i + j * pitch : (i / SELL_ROWS) * (long long)w * SELL_ROWS + (long long)j * SELL_ROWS + i % SELL_ROWS;
+            // pitch < 0: SELL-512 storage with (-pitch)-byte values; index in ints from the buffer start
+            long long e = pitch > 0 ? i + j * pitch
+                                    : (i / SELL_ROWS) * ((long long)w * SELL_ROWS * (4 - pitch) / 4) + (long long)j * SELL_ROWS + i % SELL_ROWS;
             int c = ell_col[e];
             local += (c != -1 && (long long)c - i == off) ? 1ull : 0ull;
         }
@@ -528,14 +559,15 @@ extern "C" {
 // rows, plane after plane, inside each XCD's contiguous eighth of the matrix, so
 // the live part of x (3 tiles) stays in that XCD's 4 MiB L2 and x is fetched from
 // HBM about once instead of three times.  grid_blocks = 0: no reordering pays.
-static int build_order(int dev, void *stream, int64_t n, int64_t w, int64_t pitch /* 0 = SELL-512 */,
-        const int32_t *ell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks)
+static int build_order(int dev, void *stream, int64_t n, int64_t w, int64_t pitch /* < 0: SELL-512, -pitch = value bytes */,
+        const int32_t *ell_col, int mode, int32_t *order, int64_t capacity, vexhip_traversal *out)
 {
-    VEXHIP_REQUIRE(grid_blocks, "NULL output");
-    *grid_blocks = 0;
+    VEXHIP_REQUIRE(out, "NULL output");
+    std::memset(out, 0, sizeof(*out));
+    int64_t grid_value = 0, *grid_blocks = &grid_value;
     const int64_t rpb = kHellOrderRows;
     const int64_t tile_rows_max = 65536;                 // 3 tiles x 8 B = 1.5 MiB of x
-    if (w < 1 || w > 32 || n < 8 * tile_rows_max || (pitch % 16) != 0) return 0;
+    if (w < 1 || w > 32 || n < 8 * tile_rows_max || (pitch > 0 && (pitch % 16) != 0)) return 0;
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
 
@@ -549,8 +581,8 @@ static int build_order(int dev, void *stream, int64_t n, int64_t w, int64_t pitc
             rows[k] = (int64_t)(((unsigned long long)(k + 1) * 0x9E3779B97F4A7C15ull) % (unsigned long long)n);
             for (int j = 0; j < w; ++j)
                 VEXHIP_TRY(hipMemcpyAsync(&sample[(size_t)k * w + j],
-                            ell_col + (pitch ? rows[k] + j * pitch
-                                             : (rows[k] / SELL_ROWS) * w * SELL_ROWS + (int64_t)j * SELL_ROWS + rows[k] % SELL_ROWS),
+                            ell_col + (pitch > 0 ? rows[k] + j * pitch
+                                             : (rows[k] / SELL_ROWS) * (w * SELL_ROWS * (4 - pitch) / 4) + (int64_t)j * SELL_ROWS + rows[k] % SELL_ROWS),
                             sizeof(int), hipMemcpyDeviceToHost, s));
         }
         VEXHIP_TRY(hipStreamSynchronize(s));
@@ -637,70 +669,70 @@ static int build_order(int dev, void *stream, int64_t n, int64_t w, int64_t pitc
         (void)tile_blocks;
         const int64_t chunk = mode >= 100 ? std::max<int64_t>(1, mode - 100)
                                           : std::max<int64_t>(1, std::min<int64_t>(64, plane_blocks / 8));
+        // pure arithmetic in the kernel (traversal_block): no map, no dependent load
         const int64_t tb = 8 * chunk;
         const int64_t planes = (nb + plane_blocks - 1) / plane_blocks;
-        host.reserve((size_t)nb + 8);
-        for (int64_t t0 = 0; t0 < plane_blocks; t0 += tb)
-            for (int64_t p = 0; p < planes; ++p)
-                for (int64_t i = 0; i < chunk; ++i)
-                    for (int64_t k = 0; k < 8; ++k) {
-                        int64_t l = t0 + k * chunk + i;
-                        int64_t b = p * plane_blocks + l;
-                        host.push_back((l < plane_blocks && b < nb) ? (int)b : -1);
-                    }
-        g = (int64_t)host.size();
+        const int64_t tiles = (plane_blocks + tb - 1) / tb;
+        out->grid_blocks = tiles * planes * tb;
+        out->chunk = chunk; out->planes = planes; out->plane_blocks = plane_blocks; out->order = nullptr;
+        VEXHIP_REQUIRE(out->grid_blocks < (1ll << 31) && plane_blocks < (1ll << 31), "matrix too large for one launch");
+        return 0;
     }
     VEXHIP_REQUIRE(order && g <= capacity, "order buffer too small");
     VEXHIP_TRY(hipMemcpyAsync(order, host.data(), sizeof(int) * (size_t)g, hipMemcpyHostToDevice, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     *grid_blocks = g;
+    out->grid_blocks = g; out->order = order;
     return 0;
 }
 
 int vexhip_hell_order_i32(int dev, void *stream, int64_t n, int64_t w, int64_t pitch,
-        const int32_t *ell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks)
+        const int32_t *ell_col, int mode, int32_t *order, int64_t capacity, vexhip_traversal *out)
 {
     VEXHIP_REQUIRE(pitch > 0, "ELL pitch must be positive");
-    return build_order(dev, stream, n, w, pitch, ell_col, mode, order, capacity, grid_blocks);
+    return build_order(dev, stream, n, w, pitch, ell_col, mode, order, capacity, out);
 }
 
-int vexhip_sell_order_i32(int dev, void *stream, int64_t n, int64_t w,
-        const int32_t *sell_col, int mode, int32_t *order, int64_t capacity, int64_t *grid_blocks)
-{ return build_order(dev, stream, n, w, 0, sell_col, mode, order, capacity, grid_blocks); }
+int vexhip_sell_order_i32(int dev, void *stream, int64_t n, int64_t w, int value_bytes,
+        const void *sell, int mode, int32_t *order, int64_t capacity, vexhip_traversal *out)
+{
+    VEXHIP_REQUIRE(value_bytes == 4 || value_bytes == 8, "value_bytes must be 4 or 8");
+    return build_order(dev, stream, n, w, -(int64_t)value_bytes, static_cast<const int32_t *>(sell), mode, order, capacity, out);
+}
 
 int64_t vexhip_hell_order_capacity(int64_t n) { return 2 * ((n + kHellOrderRows - 1) / kHellOrderRows) + 4096; }
 
 int vexhip_spmv_hell_ordered_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
         int64_t w, int64_t pitch, const int32_t *ec, const double *ev,
         const int32_t *cp, const int32_t *cc, const double *cv, const double *x, double *y,
-        const int32_t *order, int64_t grid_blocks)
-{ return spmv_hell<double>(dev, stream, n, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, order, grid_blocks); }
+        const vexhip_traversal *traversal)
+{ return spmv_hell<double>(dev, stream, n, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, traversal); }
 
 int vexhip_spmv_hell_ordered_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
         int64_t w, int64_t pitch, const int32_t *ec, const float *ev,
         const int32_t *cp, const int32_t *cc, const float *cv, const float *x, float *y,
-        const int32_t *order, int64_t grid_blocks)
-{ return spmv_hell<float>(dev, stream, n, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, order, grid_blocks); }
+        const vexhip_traversal *traversal)
+{ return spmv_hell<float>(dev, stream, n, alpha, append, w, pitch, ec, ev, cp, cc, cv, x, y, traversal); }
 
-int64_t vexhip_sell_elems(int64_t n, int64_t w) { return (n + SELL_ROWS - 1) / SELL_ROWS * SELL_ROWS * w; }
+int64_t vexhip_sell_bytes(int64_t n, int64_t w, int value_bytes) { return (n + SELL_ROWS - 1) / SELL_ROWS * SELL_ROWS * w * (4 + value_bytes); }
 
 int vexhip_sell_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
-        int64_t w, int32_t *sell_col, double *sell_val)
-{ return sell_fill<double>(dev, stream, n, ptr, col, val, w, sell_col, sell_val); }
+        int64_t w, void *sell)
+{ return sell_fill<double>(dev, stream, n, ptr, col, val, w, sell); }
 
 int vexhip_sell_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
-        int64_t w, int32_t *sell_col, float *sell_val)
-{ return sell_fill<float>(dev, stream, n, ptr, col, val, w, sell_col, sell_val); }
+        int64_t w, void *sell)
+{ return sell_fill<float>(dev, stream, n, ptr, col, val, w, sell); }
 
 int vexhip_spmv_sell_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w,
-        const int32_t *sc, const double *sv, const int32_t *cp, const int32_t *cc, const double *cv,
-        const double *x, double *y, const int32_t *order, int64_t grid_blocks)
-{ return spmv_sell<double>(dev, stream, n, alpha, append, w, sc, sv, cp, cc, cv, x, y, order, grid_blocks); }
+        const void *sc, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *x, double *y, const vexhip_traversal *traversal)
+{ return spmv_sell<double>(dev, stream, n, alpha, append, w, sc, cp, cc, cv, x, y, traversal); }
 
 int vexhip_spmv_sell_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w,
-        const int32_t *sc, const float *sv, const int32_t *cp, const int32_t *cc, const float *cv,
-        const float *x, float *y, const int32_t *order, int64_t grid_blocks)
-{ return spmv_sell<float>(dev, stream, n, alpha, append, w, sc, sv, cp, cc, cv, x, y, order, grid_blocks); }
+        const void *sc, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *x, float *y, const vexhip_traversal *traversal)
+{ return spmv_sell<float>(dev, stream, n, alpha, append, w, sc, cp, cc, cv, x, y, traversal); }
 
 int vexhip_spmv_csr_set_variant(int variant) { g_csr_variant = variant; return 0; }
 int vexhip_spmv_hell_set_variant(int variant) { g_hell_variant = variant; return 0; }

@@ -115,7 +115,7 @@ class HybridELL:
     """Device-resident ELL(+CSR tail) built from device CSR
     (spmat/hybrid_ell.inl:55-216; device-side conversion sparse/ell.hpp:400-508)."""
 
-    def __init__(self, ptr, col, val, tiled=True, order_mode=2):
+    def __init__(self, ptr, col, val, tiled=True, order_mode=0):
         L = lib()
         self.n = n = ptr.numel() - 1
         self.dtype = val.dtype
@@ -137,14 +137,13 @@ class HybridELL:
         fill(dev, s, n, _p(ptr), _p(col), _p(val), self.width, self.pitch,
              _p(self.ell_col), _p(self.ell_val), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val))
         # L2-tiled traversal order for banded matrices (0 blocks = plain order)
-        self.order, self.order_grid = None, 0
+        self.order, self.trav = None, _capi.Traversal()
         if self.width and tiled:
-            cap = L.hell_order_capacity(n)
-            order = torch.empty(cap, dtype=torch.int32, device=d)
-            g = ctypes.c_int64(0)
-            L.hell_order_i32(dev, s, n, self.width, self.pitch, _p(self.ell_col), order_mode, _p(order), cap, ctypes.byref(g))
-            if g.value:
-                self.order, self.order_grid = order, int(g.value)
+            cap = L.hell_order_capacity(n) if order_mode in (1, 2) else 0
+            self.order = torch.empty(cap, dtype=torch.int32, device=d) if cap else None
+            L.hell_order_i32(dev, s, n, self.width, self.pitch, _p(self.ell_col), order_mode, _p(self.order), cap,
+                             ctypes.byref(self.trav))
+        self.order_grid = int(self.trav.grid_blocks)
 
     def mul(self, x, y, alpha=1.0, append=False, tiled=True):
         L = lib()
@@ -154,7 +153,7 @@ class HybridELL:
                 _p(self.ell_col), _p(self.ell_val), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val),
                 _p(x), _p(y))
         if tiled and self.order_grid:
-            (L.spmv_hell_ordered_f64_i32 if f64 else L.spmv_hell_ordered_f32_i32)(*args, _p(self.order), self.order_grid)
+            (L.spmv_hell_ordered_f64_i32 if f64 else L.spmv_hell_ordered_f32_i32)(*args, ctypes.byref(self.trav))
         else:
             (L.spmv_hell_f64_i32 if f64 else L.spmv_hell_f32_i32)(*args)
         return y
@@ -162,8 +161,8 @@ class HybridELL:
 
 class SlicedELL:
     """SELL-512 storage of the ELL part (include/vexhip.h `vexhip_spmv_sell_*`):
-    slice-major, one slice = the 512 rows of one workgroup, so a workgroup streams
-    two contiguous regions.  Width rule and CSR tail are those of hybrid ELL
+    slice-major, one slice = the 512 rows of one workgroup = one contiguous region
+    (its columns, then its values).  Width rule and CSR tail are those of hybrid ELL
     (spmat/hybrid_ell.inl:66-216); same arithmetic, same summation order."""
 
     def __init__(self, ptr, col, val, tiled=True, order_mode=0):
@@ -185,20 +184,18 @@ class SlicedELL:
             (L.hell_fill_f64_i32 if f64 else L.hell_fill_f32_i32)(
                 dev, s, n, _p(ptr), _p(col), _p(val), self.width, (n + 15) // 16 * 16, None, None,
                 _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val))
-        ne = L.sell_elems(n, self.width)
-        self.sell_col = torch.empty(ne, dtype=torch.int32, device=d)
-        self.sell_val = torch.empty(ne, dtype=val.dtype, device=d)
+        vb = val.element_size()
+        self.sell = torch.empty(L.sell_bytes(n, self.width, vb), dtype=torch.uint8, device=d)   # one region per slice
         (L.sell_fill_f64_i32 if f64 else L.sell_fill_f32_i32)(
-            dev, s, n, _p(ptr), _p(col), _p(val), self.width, _p(self.sell_col), _p(self.sell_val))
+            dev, s, n, _p(ptr), _p(col), _p(val), self.width, _p(self.sell))
         # traversal order for banded / stencil matrices (0 blocks = plain order)
-        self.order, self.order_grid = None, 0
+        self.order, self.trav = None, _capi.Traversal()
         if tiled:
-            cap = L.hell_order_capacity(n)
-            order = torch.empty(cap, dtype=torch.int32, device=d)
-            g = ctypes.c_int64(0)
-            L.sell_order_i32(dev, s, n, self.width, _p(self.sell_col), order_mode, _p(order), cap, ctypes.byref(g))
-            if g.value:
-                self.order, self.order_grid = order, int(g.value)
+            cap = L.hell_order_capacity(n) if order_mode in (1, 2) else 0
+            self.order = torch.empty(cap, dtype=torch.int32, device=d) if cap else None
+            L.sell_order_i32(dev, s, n, self.width, vb, _p(self.sell), order_mode, _p(self.order), cap,
+                             ctypes.byref(self.trav))
+        self.order_grid = int(self.trav.grid_blocks)
 
     def mul(self, x, y, alpha=1.0, append=False, tiled=True):
         L = lib()
@@ -206,9 +203,9 @@ class SlicedELL:
         a = ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha)
         use = bool(tiled and self.order_grid)
         (L.spmv_sell_f64_i32 if f64 else L.spmv_sell_f32_i32)(
-            _dev(y), _stream(y), self.n, a, int(bool(append)), self.width, _p(self.sell_col), _p(self.sell_val),
+            _dev(y), _stream(y), self.n, a, int(bool(append)), self.width, _p(self.sell),
             _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), _p(x), _p(y),
-            _p(self.order) if use else None, self.order_grid if use else 0)
+            ctypes.byref(self.trav) if use else None)
         return y
 
 
