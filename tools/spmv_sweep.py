@@ -36,7 +36,7 @@ def main():
     A_csr = ops.SpMat(ptr, col, val, fmt="csr")
     A_ell = ops.SpMat(ptr, col, val, fmt="hell")
     A_ell.hell = ops.HybridELL(ptr, col, val, order_mode=2)
-    H_slab = H_rr = None
+    H_slab = None; H_rr = A_ell.hell
     print("tiled order grid:", A_ell.hell.order_grid, flush=True)
 
     def timeit(fn):

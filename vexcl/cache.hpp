@@ -50,6 +50,30 @@ class object_cache : public cache_base {
 
 typedef object_cache<backend::kernel> kernel_cache;
 
+/// Per-context scratch buffers for the primitives (sort ping-pong arrays, scan and
+/// sort workspaces): grown on demand, reused across calls (hipMalloc / hipFree
+/// cost more than a 16 Mi-key sort), dropped with the context like the kernels.
+class scratch_pool : public cache_base {
+    public:
+        static scratch_pool &instance() { static scratch_pool p; return p; }
+        /// At least `bytes` bytes, private to (queue, slot) until the next request for that slot.
+        backend::device_vector<char> get(const backend::command_queue &q, unsigned slot, size_t bytes) {
+            std::lock_guard<std::mutex> l(mx);
+            // one set of buffers per QUEUE (two queues of a context may run primitives concurrently)
+            auto &b = store[std::make_pair(backend::get_context_id(q), std::make_pair(q.id(), slot))];
+            if (b.size() < bytes) b = backend::device_vector<char>(q, bytes + bytes / 8);
+            return b;
+        }
+        void purge(backend::context_id id) override {
+            std::lock_guard<std::mutex> l(mx);
+            for (auto it = store.begin(); it != store.end();) if (it->first.first == id) it = store.erase(it); else ++it;
+        }
+        void clear() override { std::lock_guard<std::mutex> l(mx); store.clear(); }
+    private:
+        std::mutex mx;
+        std::map<std::pair<backend::context_id, std::pair<size_t, unsigned>>, backend::device_vector<char>> store;
+};
+
 } // namespace detail
 
 /// Drops everything cached for the context of the queue (cache.hpp:170-183).

@@ -36,7 +36,7 @@ namespace detail {
             size_t n = input.part_size(d);
             if (!n) continue;
             int dev = queue[d].device_ordinal();
-            backend::device_vector<char> tmp(queue[d], vexhip_scan_tmp_bytes(prim_dtype<T>::value, (int64_t)n));
+            backend::device_vector<char> tmp = scratch_pool::instance().get(queue[d], 3, vexhip_scan_tmp_bytes(prim_dtype<T>::value, (int64_t)n));
             // multi-device: remember the last input element before an in-place scan overwrites it
             T last_in = T();
             if (nd > 1 && exclusive) input(d).read(queue[d], n - 1, 1, &last_in, true);
@@ -46,7 +46,7 @@ namespace detail {
             if (nd > 1) {
                 T last_out; output(d).read(queue[d], n - 1, 1, &last_out, true);
                 tail[d] = exclusive ? static_cast<T>(last_out - (d == 0 ? init : T()) + last_in) : last_out;
-            } else queue[d].finish();        // tmp is released at scope exit
+            }
         }
         if (nd > 1) {
             T carry = exclusive ? init : T();

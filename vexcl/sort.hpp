@@ -26,18 +26,19 @@ namespace detail {
     {
         if (n < 2) return;
         int dev = q.device_ordinal();
-        backend::device_vector<K> ktmp(q, n);
-        backend::device_vector<char> tmp(q, vexhip_sort_tmp_bytes(prim_dtype<K>::value, (int64_t)n));
+        // ping-pong arrays and workspace come from the context's scratch pool; the sort is
+        // enqueued like any other operation (no finish): later work on this queue is ordered after it
+        auto &pool = scratch_pool::instance();
+        backend::device_vector<char> ktmp = pool.get(q, 0, n * sizeof(K));
+        backend::device_vector<char> tmp = pool.get(q, 2, vexhip_sort_tmp_bytes(prim_dtype<K>::value, (int64_t)n));
         if (vals) {
             static_assert(sizeof(V) == 4 || sizeof(V) == 8, "sort_by_key values must be 4 or 8 bytes wide");
-            backend::device_vector<V> vtmp(q, n);
+            backend::device_vector<char> vtmp = pool.get(q, 1, n * sizeof(V));
             backend::check(vexhip_sort(dev, q.raw(), prim_dtype<K>::value, descending ? 1 : 0, keys.raw(), ktmp.raw(),
                         (int)sizeof(V), vals->raw(), vtmp.raw(), (int64_t)n, tmp.raw()));
-            q.finish();
         } else {
             backend::check(vexhip_sort(dev, q.raw(), prim_dtype<K>::value, descending ? 1 : 0, keys.raw(), ktmp.raw(),
                         0, nullptr, nullptr, (int64_t)n, tmp.raw()));
-            q.finish();
         }
     }
 
