@@ -13,7 +13,7 @@
 #include <vexcl/vexcl.hpp>
 
 static struct {
-    bool bm_saxpy = true, bm_vector = true, bm_reductor = true, bm_spmv = true, bm_sort = true, bm_scan = true, bm_cpu = true;
+    bool bm_saxpy = true, bm_vector = true, bm_reductor = true, bm_spmv = true, bm_spmv_ccsr = true, bm_sort = true, bm_scan = true, bm_cpu = true;
     size_t spmv_n = 128;
     size_t spmv_m = 1024;
 } options;
@@ -164,6 +164,53 @@ std::pair<double, double> benchmark_spmv(const vex::Context &ctx, vex::profiler<
     return std::make_pair(gflops, bwidth);
 }
 
+// examples/benchmark.cpp:481-606: the same operator in compressed-stencil form
+template <typename real>
+std::pair<double, double> benchmark_spmv_ccsr(const vex::Context &ctx, vex::profiler<> &prof) {
+    const size_t n = options.spmv_n, N = n * n * n, M = options.spmv_m;
+    const real h2i = (n - 1) * (n - 1);
+    std::vector<size_t> idx; idx.reserve(N);
+    std::vector<size_t> row = {0, 1, 8};
+    std::vector<int> col = {0, -static_cast<int>(n * n), -static_cast<int>(n), -1, 0, 1, static_cast<int>(n), static_cast<int>(n * n)};
+    std::vector<real> val = {1, -h2i, -h2i, -h2i, h2i * 6, -h2i, -h2i, -h2i};
+    std::vector<real> X(N, static_cast<real>(1e-2)), Y(N, 0);
+    for (size_t k = 0; k < n; k++) for (size_t j = 0; j < n; j++) for (size_t i = 0; i < n; i++)
+        idx.push_back((i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1) ? 0 : 1);
+    size_t nnz = 6 * (n - 2) * (n - 2) * (n - 2) + N;
+    vex::SpMatCCSR<real, int> A(ctx.queue(0), N, 2, idx.data(), row.data(), col.data(), val.data());
+    std::vector<vex::command_queue> q1(1, ctx.queue(0));
+    vex::vector<real> x(q1, X), y(q1, Y);
+    y += A * x;
+    y = 0;
+    prof.tic_cpu("OpenCL");
+    for (size_t i = 0; i < M; i++) y += A * x;
+    ctx.finish();
+    double t = prof.toc("OpenCL");
+    double gflops = M / t / 1e9 * (2.0 * nnz + N);
+    double bwidth = M / t / 1e9 * (2 * 8 * sizeof(real) + N * (3 * sizeof(real) + sizeof(size_t)) + 3 * sizeof(size_t));
+    double alg = M / t / 1e9 * (N * (3.0 * sizeof(real) + 4.0));
+    std::cout << "SpMV (CCSR) (" << vex::type_name<real>() << ")\n  OpenCL\n    GFLOPS:    " << gflops
+              << "\n    Bandwidth: " << bwidth << "\n    Algorithmic GB/s: " << alg << std::endl;
+    if (options.bm_cpu) {
+        const size_t Mc = std::max<size_t>(1, M / 64);
+        prof.tic_cpu("C++");
+        for (size_t k = 0; k < Mc; k++)
+            for (size_t i = 0; i < N; i++) {
+                real s = 0;
+                for (size_t j = row[idx[i]]; j < row[idx[i] + 1]; j++) s += val[j] * X[i + col[j]];
+                Y[i] += s;
+            }
+        double tc = prof.toc("C++");
+        std::cout << "  C++ (" << Mc << " products)\n    GFLOPS:    " << Mc / tc / 1e9 * (2.0 * nnz + N) << std::endl;
+        for (auto &v : Y) v *= real(M) / real(Mc);
+        vex::copy(Y, x);
+        y -= x;
+        vex::Reductor<real, vex::SUM> sum(q1);
+        std::cout << "  res = " << sum(y * y) << std::endl << std::endl;
+    }
+    return std::make_pair(gflops, bwidth);
+}
+
 template <typename real>
 double benchmark_sort(const vex::Context &ctx, vex::profiler<> &prof) {
     typedef typename std::conditional<std::is_same<float, real>::value, cl_uint, cl_ulong>::type key_type;
@@ -233,6 +280,7 @@ void run_tests(const vex::Context &ctx, vex::profiler<> &prof) {
     if (options.bm_vector) { auto r = benchmark_vector<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_reductor) { auto r = benchmark_reductor<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_spmv) { auto r = benchmark_spmv<real>(ctx, prof); log << r.first << " " << r.second << " "; }
+    if (options.bm_spmv_ccsr) { auto r = benchmark_spmv_ccsr<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_sort) log << benchmark_sort<real>(ctx, prof) << " ";
     if (options.bm_scan) log << benchmark_scan<real>(ctx, prof) << " ";
     prof.toc(vex::type_name<real>());
@@ -244,7 +292,7 @@ int main(int argc, char *argv[]) {
         std::string k = argv[i]; int v = std::atoi(argv[i + 1]);
         if (k == "--bm_saxpy") options.bm_saxpy = v; else if (k == "--bm_vector") options.bm_vector = v;
         else if (k == "--bm_reductor") options.bm_reductor = v; else if (k == "--bm_spmv") options.bm_spmv = v;
-        else if (k == "--bm_sort") options.bm_sort = v; else if (k == "--bm_scan") options.bm_scan = v;
+        else if (k == "--bm_spmv_ccsr") options.bm_spmv_ccsr = v; else if (k == "--bm_sort") options.bm_sort = v; else if (k == "--bm_scan") options.bm_scan = v;
         else if (k == "--bm_cpu") options.bm_cpu = v; else if (k == "--spmv_n") options.spmv_n = v;
         else if (k == "--spmv_m") options.spmv_m = v;
     }

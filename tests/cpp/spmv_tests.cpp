@@ -105,6 +105,35 @@ TEST_CASE(spmv_poisson_with_ghost_planes) {                          // spmv.cpp
     for (size_t i = 0; i < N; i += 17) CHECK_SMALL(got[i] - 6 * want[i], 1e-9 * 12 * h2i);
 }
 
+TEST_CASE(spmv_ccsr_poisson) {                                       // spmv.cpp:148-231
+    const size_t n = 32, N = n * n * n;
+    const double h2i = (n - 1) * (n - 1);
+    std::vector<size_t> idx; idx.reserve(N);
+    std::vector<size_t> row = {0, 1, 8};
+    std::vector<int> col = {0, -(int)(n * n), -(int)n, -1, 0, 1, (int)n, (int)(n * n)};
+    std::vector<double> val = {1, -h2i, -h2i, -h2i, 6 * h2i, -h2i, -h2i, -h2i};
+    for (size_t k = 0; k < n; k++) for (size_t j = 0; j < n; j++) for (size_t i = 0; i < n; i++)
+        idx.push_back((i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1) ? 0 : 1);
+    std::vector<double> x = random_vector<double>(N);
+    std::vector<vex::command_queue> q1(1, ctx.queue(0));
+    vex::SpMatCCSR<double, int> A(q1[0], N, 2, idx.data(), row.data(), col.data(), val.data());
+    vex::vector<double> X(q1, x), Y(q1, N);
+    // the same operator as an ordinary CSR matrix, checked on the host
+    std::vector<size_t> prow; std::vector<unsigned> pcol; std::vector<double> pval;
+    poisson(n, prow, pcol, pval);
+    auto want = host_spmv(prow, pcol, pval, x);
+    Y = A * X;
+    std::vector<double> got(N); vex::copy(Y, got);
+    for (size_t i = 0; i < N; ++i) CHECK_SMALL(got[i] - want[i], 1e-10 * 12 * h2i);
+    Y = X - A * X;                                                   // a terminal like any other
+    check_sample(Y, [&](size_t i, double v) { CHECK_SMALL(v - (x[i] - want[i]), 1e-9 * 12 * h2i); });
+    Y = 1; Y += A * X;
+    check_sample(Y, [&](size_t i, double v) { CHECK_SMALL(v - (1 + want[i]), 1e-9 * 12 * h2i); });
+    vex::Reductor<double, vex::SUM> sum(q1);
+    double dot = 0; for (size_t i = 0; i < N; ++i) dot += x[i] * want[i];
+    CHECK_CLOSE(sum(X * (A * X)), dot, 1e-6);
+}
+
 TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp:233-260
     const size_t n = 1024;
     std::vector<vex::command_queue> queue(1, ctx.queue(0));

@@ -24,6 +24,7 @@
 
 #include "operations.hpp"
 #include "vector.hpp"
+#include "spmat/ccsr.hpp"
 
 namespace vex {
 
