@@ -323,7 +323,62 @@ auto vector_part(const E &e) {
     }
 }
 
+/// Number of terminal positions a node consumes (its traversal passes all advance `pos` alike).
+template <class Node>
+int count_terminals(const Node &node, const backend::command_queue &q) {
+    backend::source_generator scratch;
+    gen_context c(scratch, q);
+    node.local_init(c);
+    return c.pos;
+}
+
 // ---- the fused elementwise kernel (operations.hpp:1818-1897) -------------------
+/// Source of the kernel `lhs OP rhs`.  Shape of the reference's kernel (SURVEY A.1:
+/// one parameter per terminal in traversal order, lhs first; the statement text is
+/// the reference's), with ONE change for MI355X: a lane handles TWO elements per
+/// trip of the grid-stride loop (idx and idx + grid_size, both fully coalesced).  Both
+/// right-hand sides are evaluated -- all their loads issued -- before either result is
+/// stored, so a lane keeps twice the memory requests in flight; gather-like terminals
+/// (permutation, sparse / CCSR products) are latency-bound without it.  The second
+/// element's index is clamped into range for the evaluation and only stored if real.
+template <class OP, class LHS, class RHS>
+std::string assignment_source(const LHS &lhs, const RHS &rhs, const backend::command_queue &q) {
+    backend::source_generator source(q);
+    { gen_context c(source, q); lhs.preamble(c); rhs.preamble(c); }
+    source.begin_kernel("vexcl_vector_kernel");
+    source.begin_kernel_parameters();
+    source.template parameter<size_t>("n");
+    { gen_context c(source, q); lhs.params(c); rhs.params(c); }
+    source.end_kernel_parameters();
+    const std::string R = type_name<typename RHS::value_type>();
+    source.new_line() << "const ulong grid_size = blockDim.x * (ulong)gridDim.x;";
+    source.new_line() << "for(ulong vex_i = blockDim.x * (ulong)blockIdx.x + threadIdx.x; vex_i < n; vex_i += 2 * grid_size)";
+    source.open("{");
+    source.new_line() << "const bool vex_two = vex_i + grid_size < n;";
+    source.new_line() << R << " vex_r0, vex_r1;";
+    for (int e = 0; e < 2; ++e) {
+        source.open("{");
+        source.new_line() << "const ulong idx = " << (e ? "vex_two ? vex_i + grid_size : vex_i" : "vex_i") << ";";
+        { gen_context c(source, q); lhs.local_init(c); rhs.local_init(c); }
+        source.new_line() << "vex_r" << e << " = ";
+        { gen_context c(source, q); c.pos = count_terminals(lhs, q); rhs.emit(c); }
+        source << ";";
+        source.close("}");
+    }
+    for (int e = 0; e < 2; ++e) {
+        if (e) source.new_line() << "if (vex_two)";
+        source.open("{");
+        source.new_line() << "const ulong idx = " << (e ? "vex_i + grid_size" : "vex_i") << ";";
+        source.new_line();
+        { gen_context c(source, q); lhs.emit(c); }
+        source << " " << OP::string() << " vex_r" << e << ";";
+        source.close("}");
+    }
+    source.close("}");
+    source.end_kernel();
+    return source.str();
+}
+
 template <class OP, class LHS, class RHS>
 void assign_expression(const LHS &lhs, const RHS &rhs,
         const std::vector<backend::command_queue> &queue, const std::vector<size_t> &part)
@@ -336,28 +391,8 @@ void assign_expression(const LHS &lhs, const RHS &rhs,
         if (!psize) continue;
 
         auto kernel = cache.find(queue[d]);
-        if (kernel == cache.end()) {
-            backend::source_generator source(queue[d]);
-            { gen_context c(source, queue[d]); lhs.preamble(c); rhs.preamble(c); }
-            source.begin_kernel("vexcl_vector_kernel");
-            source.begin_kernel_parameters();
-            source.template parameter<size_t>("n");
-            { gen_context c(source, queue[d]); lhs.params(c); rhs.params(c); }
-            source.end_kernel_parameters();
-            source.grid_stride_loop().open("{");
-            { gen_context c(source, queue[d]); lhs.local_init(c); rhs.local_init(c); }
-            source.new_line();
-            {
-                gen_context c(source, queue[d]);
-                lhs.emit(c);
-                source << " " << OP::string() << " ";
-                rhs.emit(c);
-                source << ";";
-            }
-            source.close("}");
-            source.end_kernel();
-            kernel = cache.insert(queue[d], backend::kernel(queue[d], source.str(), "vexcl_vector_kernel"));
-        }
+        if (kernel == cache.end())
+            kernel = cache.insert(queue[d], backend::kernel(queue[d], assignment_source<OP>(lhs, rhs, queue[d]), "vexcl_vector_kernel"));
 
         backend::kernel &krn = kernel->second;
         krn.push_arg(psize);
@@ -366,26 +401,6 @@ void assign_expression(const LHS &lhs, const RHS &rhs,
         rhs.set_args(a);
         krn(queue[d]);
     }
-}
-
-/// Source text of the kernel an assignment would generate (for tests and
-/// VEXCL_SHOW_KERNELS-style inspection).
-template <class OP, class LHS, class RHS>
-std::string assignment_source(const LHS &lhs, const RHS &rhs, const backend::command_queue &q) {
-    backend::source_generator source(q);
-    { gen_context c(source, q); lhs.preamble(c); rhs.preamble(c); }
-    source.begin_kernel("vexcl_vector_kernel");
-    source.begin_kernel_parameters();
-    source.template parameter<size_t>("n");
-    { gen_context c(source, q); lhs.params(c); rhs.params(c); }
-    source.end_kernel_parameters();
-    source.grid_stride_loop().open("{");
-    { gen_context c(source, q); lhs.local_init(c); rhs.local_init(c); }
-    source.new_line();
-    { gen_context c(source, q); lhs.emit(c); source << " " << OP::string() << " "; rhs.emit(c); source << ";"; }
-    source.close("}");
-    source.end_kernel();
-    return source.str();
 }
 
 /// Assignment of any assignable expression to an lvalue terminal:
