@@ -1,8 +1,8 @@
 // Port of the reference harness examples/benchmark.cpp (SAXPY :84-148, vector
 // arithmetic :153-216, reductor :220-278, SpMV :353-477, sort :669-757,
-// scan :761-846) onto the MI355X implementation.  Same problem sizes, same
+// scan :761-846, stencil :282-349, CCSR :481-606) onto the MI355X implementation.  Same problem sizes, same
 // work formulas, same printed fields; options are plain "--name value" pairs
-// (no Boost.program_options).  RNG / stencil / CCSR sections are out of scope.
+// (no Boost.program_options).  The RNG section is out of scope.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -13,7 +13,7 @@
 #include <vexcl/vexcl.hpp>
 
 static struct {
-    bool bm_saxpy = true, bm_vector = true, bm_reductor = true, bm_spmv = true, bm_spmv_ccsr = true, bm_sort = true, bm_scan = true, bm_cpu = true;
+    bool bm_saxpy = true, bm_vector = true, bm_reductor = true, bm_stencil = true, bm_spmv = true, bm_spmv_ccsr = true, bm_sort = true, bm_scan = true, bm_cpu = true;
     size_t spmv_n = 128;
     size_t spmv_m = 1024;
 } options;
@@ -102,6 +102,42 @@ std::pair<double, double> benchmark_reductor(const vex::Context &ctx, vex::profi
         std::cout << "  C++\n    GFLOPS:    " << 2.0 * N * M / tc / 1e9 << "\n    Bandwidth: "
                   << 2.0 * N * M * sizeof(real) / tc / 1e9 << std::endl;
         std::cout << "  res = " << std::fabs(sum_cl - sum_cpp) / std::fabs(sum_cpp) << std::endl << std::endl;
+    }
+    return std::make_pair(gflops, bwidth);
+}
+
+// examples/benchmark.cpp:282-349
+template <typename real>
+std::pair<double, double> benchmark_stencil(const vex::Context &ctx, vex::profiler<> &prof) {
+    const long N = 1024 * 1024, M = 1024;
+    std::vector<real> A(N), B(N);
+    for (long i = 0; i < N; ++i) A[i] = real(i % 29) / 29;
+    std::vector<real> S(21, static_cast<real>(1) / 21);
+    long center = S.size() / 2;
+    vex::stencil<real> s(ctx, S, center);
+    vex::vector<real> a(ctx, A), b(ctx, N);
+    b = a * s;
+    prof.tic_cpu("OpenCL");
+    for (long i = 0; i < M; i++) b = a * s;
+    ctx.finish();
+    double t = prof.toc("OpenCL");
+    double gflops = 2.0 * S.size() * N * M / t / 1e9, bwidth = 2.0 * S.size() * N * M * sizeof(real) / t / 1e9;
+    std::cout << "Stencil convolution (" << vex::type_name<real>() << ")\n  OpenCL\n    GFLOPS:    " << gflops
+              << "\n    Bandwidth: " << bwidth << std::endl;
+    if (options.bm_cpu) {
+        const long Mc = 16;
+        prof.tic_cpu("C++");
+        for (long j = 0; j < Mc; j++)
+            for (long i = 0; i < N; i++) {
+                real sum = 0;
+                for (long k = 0; k < (long)S.size(); k++) sum += S[k] * A[std::min<long>(N - 1, std::max<long>(0, i + k - center))];
+                B[i] = sum;
+            }
+        double tc = prof.toc("C++");
+        std::cout << "  C++ (" << Mc << " passes)\n    GFLOPS:    " << 2.0 * S.size() * N * Mc / tc / 1e9 << std::endl;
+        vex::Reductor<real, vex::MAX> max(ctx);
+        vex::copy(B, a);
+        std::cout << "  res = " << max(fabs(a - b)) << std::endl << std::endl;
     }
     return std::make_pair(gflops, bwidth);
 }
@@ -279,6 +315,7 @@ void run_tests(const vex::Context &ctx, vex::profiler<> &prof) {
     if (options.bm_saxpy) { auto r = benchmark_saxpy<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_vector) { auto r = benchmark_vector<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_reductor) { auto r = benchmark_reductor<real>(ctx, prof); log << r.first << " " << r.second << " "; }
+    if (options.bm_stencil) { auto r = benchmark_stencil<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_spmv) { auto r = benchmark_spmv<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_spmv_ccsr) { auto r = benchmark_spmv_ccsr<real>(ctx, prof); log << r.first << " " << r.second << " "; }
     if (options.bm_sort) log << benchmark_sort<real>(ctx, prof) << " ";
@@ -292,7 +329,7 @@ int main(int argc, char *argv[]) {
         std::string k = argv[i]; int v = std::atoi(argv[i + 1]);
         if (k == "--bm_saxpy") options.bm_saxpy = v; else if (k == "--bm_vector") options.bm_vector = v;
         else if (k == "--bm_reductor") options.bm_reductor = v; else if (k == "--bm_spmv") options.bm_spmv = v;
-        else if (k == "--bm_spmv_ccsr") options.bm_spmv_ccsr = v; else if (k == "--bm_sort") options.bm_sort = v; else if (k == "--bm_scan") options.bm_scan = v;
+        else if (k == "--bm_stn") options.bm_stencil = v; else if (k == "--bm_spmv_ccsr") options.bm_spmv_ccsr = v; else if (k == "--bm_sort") options.bm_sort = v; else if (k == "--bm_scan") options.bm_scan = v;
         else if (k == "--bm_cpu") options.bm_cpu = v; else if (k == "--spmv_n") options.spmv_n = v;
         else if (k == "--spmv_m") options.spmv_m = v;
     }

@@ -67,6 +67,16 @@ int main(int argc, char **argv) {
         report("reduce sum(a*b) f64 n=2^24 (incl. host readback)", n, 16, ms);
         (void)s;
     }
+    {   // next row: 21-point stencil convolution, LDS-staged
+        const size_t n = 100000000;
+        std::vector<double> S(21, 1.0 / 21);
+        vex::stencil<double> s(ctx, S, 10);
+        vex::vector<double> a(ctx, n), b(ctx, n);
+        a = 1e-8 * vex::element_index();
+        b = a * s; q.finish();
+        t.start(); for (int i = 0; i < reps; ++i) b = a * s; double ms = t.stop_ms() / reps;
+        report("stencil b = a * s (21 points) f64", (double)n, 16, ms);
+    }
     {   // next row: the 512^3 Poisson operator as SpMatCCSR -- no (col, val) stream at all
         const size_t n = 512, N = n * n * n;
         const double h2i = (n - 1.0) * (n - 1.0);

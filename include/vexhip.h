@@ -230,6 +230,16 @@ int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
         void *keys, void *keys_tmp, int value_bytes, void *vals, void *vals_tmp,
         int64_t n, void *tmp);
 
+/* ---- stencil convolution (stencil.hpp:306-405 `slow_conv` / `fast_conv`) ----
+ * y[i] = beta*y[i] + alpha * sum_{j=0}^{lhalo+rhalo} s[j] * X(i + j - lhalo), where
+ * X(g) = x[g] inside [0,n); outside it reads the halo buffer xrem (lhalo values of the
+ * left neighbour, then rhalo values of the right one) when has_left / has_right, else
+ * the edge element x[0] / x[n-1] (stencil.hpp:264-290).  LDS-staged.               */
+int vexhip_stencil_conv_f64(int dev, void *stream, int64_t n, int has_left, int has_right, int lhalo, int rhalo,
+        const double *s, const double *x, const double *xrem, double *y, double beta, double alpha);
+int vexhip_stencil_conv_f32(int dev, void *stream, int64_t n, int has_left, int has_right, int lhalo, int rhalo,
+        const float *s, const float *x, const float *xrem, float *y, float beta, float alpha);
+
 /* ---- benchmark input generators (examples/benchmark.cpp:364-415; SURVEY
  *      section 8(d): 512^3 is built on the device, never uploaded) ---------- */
 int64_t vexhip_poisson3d_nnz(int64_t n);

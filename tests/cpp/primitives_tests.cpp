@@ -59,3 +59,51 @@ TEST_CASE(sort_by_key_equals_stable_sort) {                          // sort.cpp
     std::vector<cl_ulong> gl(n); vex::copy(L, gl);
     CHECK(std::is_sorted(gl.begin(), gl.end()));
 }
+
+// ---- stencil convolution: the reference's tests/stencil.cpp:17-110 --------------------
+static size_t clamp_index(size_t n, size_t i, long shift) {
+    return std::min<size_t>(n - 1, std::max<long>(0, static_cast<long>(i) + shift));
+}
+
+static void check_stencil(size_t n, size_t width, int center) {
+    std::vector<double> s = random_vector<double>(width);
+    vex::stencil<double> S(ctx, s, center);
+    std::vector<double> x = random_vector<double>(n);
+    vex::vector<double> X(ctx, x), Y(ctx, n);
+    auto conv = [&](size_t i) { double sum = 0; long k = -center; for (size_t j = 0; j < s.size(); ++j, ++k) sum += s[j] * x[clamp_index(n, i, k)]; return sum; };
+    Y = 1; Y += X * S;                                               // stencil.cpp:33-45
+    std::vector<double> got(n); vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], 1 + conv(i), 1e-8);
+    Y = 42 * (X * S);                                                // :47-56
+    vex::copy(Y, got);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(got[i], 42 * conv(i), 1e-8);
+    Y = X - S * X;                                                   // mixed with a vector term, either operand order
+    vex::copy(Y, got);
+    for (size_t i = 0; i < n; i += 7) CHECK_SMALL(got[i] - (x[i] - conv(i)), 1e-10 * width);
+}
+
+TEST_CASE(stencil_convolution) {
+    check_stencil(1024, 1, 0);
+    check_stencil(1024, 3, 1);
+    check_stencil(1024, 17, 0);                                      // one-sided stencils
+    check_stencil(1024, 17, 16);
+    check_stencil(1024, 64, 23);
+    check_stencil(1 << 20, 33, 16);
+    check_stencil(5000, 9000, 4500);                                 // wider than LDS: direct-read kernel
+}
+
+TEST_CASE(stencil_small_vector_and_two_stencils) {                   // stencil.cpp:59-110
+    check_stencil(128, 64, 40);                                      // halos longer than a neighbour's segment
+    check_stencil(40, 37, 5);
+    const size_t n = 32;
+    std::vector<double> s(5, 1);
+    vex::stencil<double> S(ctx, s, 3);
+    vex::vector<double> X(ctx, n), Y(ctx, n);
+    X = 0;
+    Y = X * S + X * S;
+    CHECK(Y[0] == 0 && Y[16] == 0 && Y[31] == 0);
+    vex::stencil<float> F(ctx, {0.25f, 0.5f, 0.25f}, 1);            // initializer list, float
+    vex::vector<float> A(ctx, 1000), B(ctx, 1000);
+    A = 2.0f; B = A * F;
+    check_sample(B, [](size_t, float v) { CHECK_CLOSE(v, 2.0f, 1e-5); });
+}

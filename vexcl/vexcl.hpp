@@ -19,6 +19,7 @@
 #include "constants.hpp"
 #include "reductor.hpp"
 #include "spmat.hpp"
+#include "stencil.hpp"
 #include "sparse/csr.hpp"
 #include "sparse/ell.hpp"
 #include "sparse/matrix.hpp"
