@@ -230,6 +230,19 @@ int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
         void *keys, void *keys_tmp, int value_bytes, void *vals, void *vals_tmp,
         int64_t n, void *tmp);
 
+/* ---- compressed-stencil SpMV (spmat/ccsr.hpp:40-53,184-200; vex::SpMatCCSR) ----
+ * y[i] (=|+=) alpha * sum_{j in [row[idx[i]], row[idx[i]+1])} val[j] * x[i + col[j]];
+ * m unique rows, `entries` = row[m] table entries (device arrays; idx, row 32-bit).
+ * far_offset: the largest |col| shared by most rows (0 if unknown) -- used only to
+ * pick the strip traversal that keeps x in one XCD's L2.  Caller guarantees that
+ * every i + col[j] addressed lies inside x.                                          */
+int vexhip_spmv_ccsr_f64(int dev, void *stream, int64_t n, double alpha, int append, const uint32_t *idx, int64_t m,
+        const uint32_t *row, const int32_t *col, const double *val, int64_t entries, int64_t far_offset,
+        const double *x, double *y);
+int vexhip_spmv_ccsr_f32(int dev, void *stream, int64_t n, float alpha, int append, const uint32_t *idx, int64_t m,
+        const uint32_t *row, const int32_t *col, const float *val, int64_t entries, int64_t far_offset,
+        const float *x, float *y);
+
 /* ---- stencil convolution (stencil.hpp:306-405 `slow_conv` / `fast_conv`) ----
  * y[i] = beta*y[i] + alpha * sum_{j=0}^{lhalo+rhalo} s[j] * X(i + j - lhalo), where
  * X(g) = x[g] inside [0,n); outside it reads the halo buffer xrem (lhalo values of the

@@ -125,6 +125,12 @@ TEST_CASE(spmv_ccsr_poisson) {                                       // spmv.cpp
     Y = A * X;
     std::vector<double> got(N); vex::copy(Y, got);
     for (size_t i = 0; i < N; ++i) CHECK_SMALL(got[i] - want[i], 1e-10 * 12 * h2i);
+    Y = 7; Y = 2.5 * (A * X);                                        // hand-written kernel, scaled SET
+    vex::copy(Y, got);
+    for (size_t i = 0; i < N; ++i) CHECK_SMALL(got[i] - 2.5 * want[i], 1e-10 * 30 * h2i);
+    Y -= A * X;
+    vex::copy(Y, got);
+    for (size_t i = 0; i < N; i += 3) CHECK_SMALL(got[i] - 1.5 * want[i], 1e-10 * 30 * h2i);
     Y = X - A * X;                                                   // a terminal like any other
     check_sample(Y, [&](size_t i, double v) { CHECK_SMALL(v - (x[i] - want[i]), 1e-9 * 12 * h2i); });
     Y = 1; Y += A * X;

@@ -274,6 +274,11 @@ template <class F, class R, class... A> struct expr_kind<function_call<F, R, A..
 template <class C, class A, class B> struct expr_kind<ternary_expr<C, A, B>>
     : std::integral_constant<int, all_vector_kind<C, A, B>::value ? 0 : -1> {};
 
+/// Hook: an expression that is, as a whole, one product with a hand-written kernel
+/// (e.g. `y += A * x` with A a SpMatCCSR) nominates it here; it remains an ordinary
+/// terminal inside larger expressions.
+template <class E, class Enable = void> struct direct_assign : std::false_type {};
+
 /// Applies every A*x term of an additive expression to y
 /// (operations.hpp:1475-1576: negations pushed to the leaves, first term SET or ADD, rest ADD).
 template <class W, class E>
@@ -413,8 +418,16 @@ void assign_any(const LHS &lhs, W &target, const Expr &expr,
     constexpr int kind = expr_kind<Expr>::value;
     static_assert(kind >= 0, "this expression cannot be assigned: A*x terms may only be added, subtracted or scaled");
     if constexpr (kind == 0) {
-        (void)target;
-        assign_expression<OP>(lhs, expr, queue, part);
+        constexpr bool lin = std::is_same<OP, assign::SET>::value || std::is_same<OP, assign::ADD>::value || std::is_same<OP, assign::SUB>::value;
+        if constexpr (direct_assign<Expr>::value && lin) {
+            // the whole right-hand side is one product with a hand-written kernel
+            (void)lhs; (void)queue; (void)part;
+            direct_assign<Expr>::apply(target, expr, std::is_same<OP, assign::SUB>::value ? -1.0 : 1.0,
+                                       !std::is_same<OP, assign::SET>::value);
+        } else {
+            (void)target;
+            assign_expression<OP>(lhs, expr, queue, part);
+        }
     } else {
         constexpr bool set = std::is_same<OP, assign::SET>::value;
         constexpr bool add = std::is_same<OP, assign::ADD>::value;

@@ -37,9 +37,29 @@ struct SpMatCCSR {
         this->row = backend::device_vector<unsigned>(queue, m + 1, row32.data(), backend::MEM_READ_ONLY);
         this->col = backend::device_vector<int>(queue, col32.size(), col32.data(), backend::MEM_READ_ONLY);
         this->val = backend::device_vector<val_t>(queue, col32.size(), val, backend::MEM_READ_ONLY);
+        entries = col32.size();
+        far_offset = 0;
+        for (int c : col32) far_offset = std::max<long long>(far_offset, c < 0 ? -(long long)c : (long long)c);
     }
 
     size_t rows() const { return n; }
+
+    /// y = alpha * A * x  or  y += alpha * A * x with the hand-written kernel (libvexhip `vexhip_spmv_ccsr_*`).
+    void apply(const vector<val_t> &x, vector<val_t> &y, val_t alpha = 1, bool append = false) const {
+        precondition(x.nparts() == 1 && y.nparts() == 1 && x.size() == n && y.size() == n, "SpMatCCSR::apply: incompatible vectors");
+        backend::check(spmv(queue.device_ordinal(), queue.raw(), (int64_t)n, alpha, append ? 1 : 0, idx.raw(), (int64_t)m,
+                    row.raw(), col.raw(), val.raw(), (int64_t)entries, (int64_t)far_offset, x(0).raw(), y(0).raw()));
+    }
+
+    static int spmv(int dev, void *s, int64_t n, double a, int app, const unsigned *idx, int64_t m, const unsigned *row,
+            const int *col, const double *val, int64_t e, int64_t far, const double *x, double *y) {
+        return vexhip_spmv_ccsr_f64(dev, s, n, a, app, idx, m, row, col, val, e, far, x, y); }
+    static int spmv(int dev, void *s, int64_t n, float a, int app, const unsigned *idx, int64_t m, const unsigned *row,
+            const int *col, const float *val, int64_t e, int64_t far, const float *x, float *y) {
+        return vexhip_spmv_ccsr_f32(dev, s, n, a, app, idx, m, row, col, val, e, far, x, y); }
+
+    size_t entries = 0;
+    long long far_offset = 0;
 
     backend::command_queue queue;
     size_t n, m;
@@ -106,6 +126,24 @@ struct ccsr_product : expression_base {
     }
     void get_props(prop_context &p) const {
         if (p.empty()) { p.queue = std::vector<backend::command_queue>(1, A.queue); p.part = {0, A.n}; p.size = A.n; }
+    }
+};
+
+// `y (=|+=|-=) A * x` and `... s * (A * x)`: the hand-written kernel; anything larger: the fused kernel.
+template <typename val_t, typename col_t, typename idx_t>
+struct direct_assign<ccsr_product<val_t, col_t, idx_t, val_t>,
+        typename std::enable_if<std::is_same<val_t, double>::value || std::is_same<val_t, float>::value>::type> : std::true_type {
+    template <class W>
+    static void apply(W &y, const ccsr_product<val_t, col_t, idx_t, val_t> &p, double scale, bool append) {
+        p.A.apply(p.x, y, static_cast<val_t>(scale), append);
+    }
+};
+template <typename S, typename val_t, typename col_t, typename idx_t>
+struct direct_assign<binary_expr<tag::multiplies, scalar_terminal<S>, ccsr_product<val_t, col_t, idx_t, val_t>>,
+        typename std::enable_if<std::is_same<val_t, double>::value || std::is_same<val_t, float>::value>::type> : std::true_type {
+    template <class W, class E>
+    static void apply(W &y, const E &e, double scale, bool append) {
+        e.r.A.apply(e.r.x, y, static_cast<val_t>(scale * static_cast<double>(e.l.v)), append);
     }
 };
 
