@@ -243,3 +243,55 @@ def test_poisson512_properties(T):
     # linearity: A(2x) == 2 A x exactly (power-of-two scale)
     y3 = A_ell @ (x * 2)
     assert torch.equal(y3, y1 * 2)
+
+
+def _structured(kind, rng):
+    """Adversarial sparsity structures (beyond tests/random_matrix.hpp's 0..15 per row)."""
+    if kind == "one_row":
+        n, m = 1, 3000
+        widths = np.array([2999])
+    elif kind == "long_rows":                     # rows far longer than an LDS tile (2048) and than any ELL width
+        n, m = 300, 20000
+        widths = rng.integers(0, 4, size=n); widths[[7, 150, 299]] = [6000, 2048, 4097]
+    elif kind == "power_law":
+        n, m = 5000, 5000
+        widths = np.minimum((rng.pareto(1.2, size=n) * 3).astype(np.int64), 3000)
+    elif kind == "wide_regular":                  # ELL width 27 > 8: run-time width kernels
+        n, m = 4099, 4099
+        widths = np.full(n, 27)
+    elif kind == "tile_edges":                    # block nnz exactly at / around the 2048-entry LDS tile
+        n, m = 1024, 4096
+        widths = np.full(n, 8); widths[255] = 9; widths[511] = 7
+    elif kind == "all_empty":
+        n, m = 777, 100
+        widths = np.zeros(n, dtype=np.int64)
+    else:                                         # "slice_tail": n just past a 512-row slice
+        n, m = 513, 513
+        widths = rng.integers(1, 8, size=n)
+    widths = np.minimum(widths, m)
+    ptr = np.concatenate([[0], np.cumsum(widths)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(m, size=int(w), replace=False)) for w in widths] or [np.zeros(0)]).astype(np.int32)
+    val = rng.random(len(col)) - 0.5
+    return ptr, col, val, m
+
+
+@pytest.mark.parametrize("fmt", ["csr", "hell", "sell"])
+@pytest.mark.parametrize("kind", ["one_row", "long_rows", "power_law", "wide_regular", "tile_edges", "all_empty", "slice_tail"])
+def test_adversarial_structures(T, oracle, kind, fmt):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    ptr, col, val, m = _structured(kind, rng)
+    n = len(ptr) - 1
+    x = rng.random(m) - 0.5
+    y0 = rng.random(n)
+    A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), n_cols=m, fmt=fmt)
+    if kind == "all_empty":
+        assert A.fmt == ("csr" if fmt == "sell" else fmt)       # no ELL part: SELL degrades to CSR
+    want = y0.copy()
+    oracle.spmv_csr(ptr, col, val, x, want, -0.75, True)
+    y = T.up(y0.copy())
+    A.apply(T.up(x), y, -0.75, True)
+    assert np.array_equal(y.cpu().numpy(), want)                # same order, unfused: bit-exact
+    y = T.up(y0.copy())
+    A.apply(T.up(x), y, 2.0, False)
+    assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x, alpha=2.0))

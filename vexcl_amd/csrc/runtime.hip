@@ -33,9 +33,10 @@ int fail(const char *file, int line, const std::string &what) {
 
 const device_info &info(int dev) {
     static std::mutex mx;
-    static std::vector<device_info> cache;
+    static device_info cache[64];              // fixed storage: references stay valid across threads
+    static device_info fallback;
     std::lock_guard<std::mutex> lock(mx);
-    if (cache.size() <= (size_t)dev) cache.resize(dev + 1);
+    if (dev < 0 || dev >= 64) { fallback.cus = 256; return fallback; }
     if (!cache[dev].ok) {
         hipDeviceProp_t p;
         if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
