@@ -171,7 +171,10 @@ def main():
         alg_rank = algorithmic_bytes(r1 - r0, nnz_rank)
         gflops = 2.0 * nnz_total / per_step / 1e9
         gbps = alg_total / per_step / 1e9
-        kname = {"hell": "hell_kernel", "sell": "sell_kernel"}.get(fmt, "csr_stream_kernel")
+        hell = (A.hell if world == 1 and not args.dist else A.loc.hell)
+        if fmt == "sell" and getattr(hell, "deltas", None) is not None:
+            fmt = "sell8"                        # SELL-512 with 1-byte diagonal codes (banded matrix detected)
+        kname = {"hell": "hell_kernel", "sell": "sell_kernel", "sell8": "sell8_kernel"}.get(fmt, "csr_stream_kernel")
         traffic = read_traffic(kname) if (world == 1 and n == 512) else None
         out = {
             "metric": "fp64 CSR SpMV GFLOP/s, 3D Poisson %d^3 (y = A*x, vex::SpMat path)" % n,

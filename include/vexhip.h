@@ -172,6 +172,31 @@ int vexhip_spmv_sell_f32_i32(int dev, void *stream, int64_t n, float alpha, int 
         const void *sell, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y, const vexhip_traversal *traversal);
 
+/* SELL-512 with 8-bit diagonal codes ("SELL8").  For banded / stencil matrices (column -
+ * row) takes few distinct values: if the ELL part uses at most 255 distinct diagonals,
+ * every column index is stored as ONE byte (position of its diagonal in the sorted table
+ * `deltas`, 255 = padding) and rebuilt in the kernel as row + deltas[code]: 9 instead of
+ * 12 bytes per fp64 entry, same arithmetic, same order, bit-identical results.
+ *   analyze: *ndeltas = number of diagonals (table written to deltas[256], device memory),
+ *            or -1 if the matrix has more than 255 (keep 32-bit columns then);
+ *   fill:    encodes the ELL part (width/tail as for hybrid ELL) into `buf`
+ *            (vexhip_sell8_bytes) and returns the strip traversal for it;
+ *   slice layout: ceil(w/2) KiB of codes (word [jp][t] = codes of columns 2jp, 2jp+1 for
+ *            rows 2t, 2t+1), then w*512 values, j-major.                                 */
+int64_t vexhip_sell8_bytes(int64_t n, int64_t ell_width, int value_bytes);
+int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
+        int64_t ell_width, int32_t *deltas, int *ndeltas);
+int vexhip_sell8_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int64_t ell_width, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *traversal);
+int vexhip_sell8_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int64_t ell_width, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *traversal);
+int vexhip_spmv_sell8_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const vexhip_traversal *traversal);
+int vexhip_spmv_sell8_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const vexhip_traversal *traversal);
+
 /* CSR -> hybrid ELL conversion on the device (sparse/ell.hpp:400-508,
  * `convert_csr2ell` :348-397; width rule hybrid_ell.inl:66-114).
  * Step 1 (blocking): row-width histogram -> ELL width by the reference's

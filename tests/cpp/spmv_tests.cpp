@@ -153,6 +153,21 @@ TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp
     check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, std::sin(want[i]), 1e-8); });
     Y = X + 2 * vex::make_inline(A * X);
     check_sample(Y, [&](size_t i, double v) { CHECK_CLOSE(v, x[i] + 2 * want[i], 1e-8); });
+    // a banded matrix is stored with 1-byte diagonal codes (SELL8): same inline terminal, other decode branch
+    const size_t g = 24, N = g * g * g;
+    std::vector<size_t> prow; std::vector<unsigned> pcol; std::vector<double> pval;
+    poisson(g, prow, pcol, pval);
+    std::vector<double> px = random_vector<double>(N);
+    auto pwant = host_spmv(prow, pcol, pval, px);
+    vex::SpMat<double, unsigned> P(queue, N, N, prow.data(), pcol.data(), pval.data());
+    vex::vector<double> PX(queue, px), PY(queue, N);
+    PY = PX - vex::make_inline(P * PX);
+    std::vector<double> got(N); vex::copy(PY, got);
+    const double h2i = (g - 1) * (g - 1);
+    for (size_t i = 0; i < N; ++i) CHECK_SMALL(got[i] - (px[i] - pwant[i]), 1e-10 * 12 * h2i);
+    PY = P * PX;
+    vex::copy(PY, got);
+    for (size_t i = 0; i < N; ++i) CHECK_SMALL(got[i] - pwant[i], 1e-10 * 12 * h2i);
 }
 
 TEST_CASE(sparse_csr_ell_matrix_single_queue) {                      // sparse_matrices.cpp:66-151

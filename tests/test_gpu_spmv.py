@@ -295,3 +295,70 @@ def test_adversarial_structures(T, oracle, kind, fmt):
     y = T.up(y0.copy())
     A.apply(T.up(x), y, 2.0, False)
     assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x, alpha=2.0))
+
+
+def _banded(rng, n, offsets, density=0.8):
+    """Random banded matrix: each row keeps each in-range diagonal with probability `density`."""
+    rows, cols = [], []
+    for off in offsets:
+        i = np.arange(max(0, -off), min(n, n - off))
+        keep = rng.random(len(i)) < density
+        rows.append(i[keep]); cols.append(i[keep] + off)
+    r = np.concatenate(rows); c = np.concatenate(cols)
+    o = np.lexsort((c, r)); r, c = r[o], c[o]
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))]).astype(np.int32)
+    return ptr, c.astype(np.int32), rng.random(len(c)) - 0.5
+
+
+def test_sell8_diagonal_codes(T, oracle, built_lib):
+    """<= 255 distinct diagonals => 1-byte diagonal codes; layout, fallback and bit-exact products."""
+    rng = np.random.default_rng(8)
+    # (a) Poisson: 7 diagonals {-n^2, -n, -1, 0, 1, n, n^2}
+    n = 20
+    ptr, col, val = oracle.poisson3d(n)
+    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+    assert S.ndeltas == 7 and S.width == 7
+    assert S.deltas.cpu().numpy()[:7].tolist() == [-n * n, -n, -1, 0, 1, n, n * n]
+    N = n ** 3
+    raw = S.sell.cpu().numpy().reshape(-1, 4 * 1024 + 7 * 512 * 8)
+    codes = raw[:, :4096].copy().view(np.uint32).reshape(-1, 4, 256)      # word [jp][t]
+    vals = raw[:, 4096:].copy().view(np.float64).reshape(-1, 7, 512)
+    table = S.deltas.cpu().numpy()
+    for i in (0, 1, n * n + n + 1, 4321, N - 1):
+        s, t, q = i // 512, (i % 512) // 2, i % 2
+        got_cols, got_vals = [], []
+        for j in range(7):
+            code = (int(codes[s, j // 2, t]) >> (8 * ((j % 2) * 2 + q))) & 255
+            if code != 255:
+                got_cols.append(i + int(table[code])); got_vals.append(vals[s, j, 2 * t + q])
+        assert got_cols == col[ptr[i]:ptr[i + 1]].tolist() and got_vals == val[ptr[i]:ptr[i + 1]].tolist()
+    # (b) banded matrices with gaps, odd sizes, more diagonals than the unrolled widths, a CSR tail
+    for nn, offs in ((5000, [-700, -3, -1, 0, 2, 9, 1234]), (1537, list(range(-20, 21, 2))), (3000, [0]),
+                     (2048, [-1024, -512, -64, -8, -1, 0, 1, 8, 64, 512, 1024, 1500])):
+        ptr, col, val = _banded(rng, nn, offs)
+        x = rng.random(nn) - 0.5
+        y0 = rng.random(nn)
+        S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+        assert 1 <= S.ndeltas <= len(offs)
+        want = y0.copy(); oracle.spmv_csr(ptr, col, val, x, want, 1.25, True)
+        y = T.up(y0.copy()); S.mul(T.up(x), y, 1.25, True)
+        assert np.array_equal(y.cpu().numpy(), want)
+        S32 = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val), codes=False)      # 32-bit columns: same bits
+        y2 = T.up(y0.copy()); S32.mul(T.up(x), y2, 1.25, True)
+        assert T.torch.equal(y, y2)
+    # (c) not banded: more than 255 diagonals -> 32-bit columns are kept
+    ptr, col, val = oracle.random_matrix(9, 4000, 4000, 16)
+    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+    assert S.ndeltas == -1 and S.deltas is None
+    x = rng.random(4000)
+    y = T.torch.empty(4000, dtype=T.torch.float64, device=T.dev)
+    S.mul(T.up(x), y)
+    assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
+    # float matrices
+    ptr, col, val = _banded(rng, 3001, [-5, 0, 5, 77])
+    v32, x32 = val.astype(np.float32), (rng.random(3001) - 0.5).astype(np.float32)
+    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(v32))
+    assert S.ndeltas == 4
+    y = T.torch.empty(3001, dtype=T.torch.float32, device=T.dev)
+    S.mul(T.up(x32), y)
+    assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, x32))

@@ -17,7 +17,9 @@ x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
 y = torch.zeros(N, dtype=torch.float64, device=dev)
 A_csr = ops.SpMat(ptr, col, val, fmt="csr")
 A_ell = ops.SpMat(ptr, col, val, fmt="hell")
-A_sell = ops.SpMat(ptr, col, val, fmt="sell")
+A_sell = ops.SpMat(ptr, col, val, fmt="sell")            # SELL8 on this matrix
+A_sell32 = ops.SpMat(ptr, col, val, fmt="sell")
+A_sell32.hell = ops.SlicedELL(ptr, col, val, codes=False)
 # calibration stream: 2 GiB read by the reduction kernel (16-byte loads), known byte count
 cal = torch.empty(1 << 28, dtype=torch.float64, device=dev).normal_()
 r = ops.Reductor("SUM")
@@ -30,5 +32,7 @@ for _ in range(3):
     A_csr.apply(x, y)
 for _ in range(3):
     A_sell.apply(x, y)
+for _ in range(3):
+    A_sell32.apply(x, y)
 torch.cuda.synchronize()
 print("done")

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="csr0,hell5,tiled_rr,sell_plain,sell")
+    ap.add_argument("--variants", default="csr0,hell5,sell32,sell_plain,sell")
     ap.add_argument("--out", default="gpurun_out/spmv_sweep.json")
     args = ap.parse_args()
     import torch
@@ -71,6 +71,9 @@ def main():
             return lambda: H_rr.mul(x, y, tiled=True)
         if name == "sell":
             S = ops.SlicedELL(ptr, col, val)                      # default traversal order
+            return lambda: S.mul(x, y)
+        if name == "sell32":
+            S = ops.SlicedELL(ptr, col, val, codes=False)
             return lambda: S.mul(x, y)
         if name == "sell_plain":
             S = ops.SlicedELL(ptr, col, val, tiled=False)

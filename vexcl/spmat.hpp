@@ -80,7 +80,8 @@ class SpMat {
         struct matrix_arrays {
             size_t n = 0, nnz = 0;
             long ell_w = 0;
-            backend::device_vector<char> sell;                              // columns then values, per slice
+            backend::device_vector<char> sell;                              // columns (or 1-byte diagonal codes) then values, per slice
+            backend::device_vector<int> deltas; int ndeltas = -1;           // SELL8: sorted diagonal table (vexhip.h)
             vexhip_traversal trav = {0, 0, 0, 0, nullptr};                  // traversal order (grid 0 = plain)
             backend::device_vector<int> csr_ptr, csr_col; backend::device_vector<val_t> csr_val;
             size_t csr_nnz = 0;
@@ -144,17 +145,29 @@ class SpMat {
                 backend::check(vexhip_hell_analyze_i32(dev, q.raw(), (int64_t)n, dptr.raw(), &w, &tail));
                 if (w == 0) { A.csr_ptr = dptr; A.csr_col = dcol; A.csr_val = dval; A.csr_nnz = A.nnz; return; }
                 A.ell_w = (long)w; A.csr_nnz = (size_t)tail;
-                A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell_bytes((int64_t)n, w, (int)sizeof(val_t)));
-                if (tail) {
+                if (tail) {     // rows wider than the ELL width keep their tail in CSR (hybrid_ell.inl:166-198)
                     A.csr_ptr = backend::device_vector<int>(q, n + 1); A.csr_col = backend::device_vector<int>(q, tail); A.csr_val = backend::device_vector<val_t>(q, tail);
                     backend::check(fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, (int64_t)alignup(n, 16),
                                 nullptr, nullptr, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw()));
                 }
-                backend::check(sell_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, A.sell.raw()));
-                backend::check(vexhip_sell_order_i32(dev, q.raw(), (int64_t)n, w, (int)sizeof(val_t), A.sell.raw(), 0, nullptr, 0, &A.trav));
+                // banded / stencil matrices (<= 255 distinct diagonals): 1-byte diagonal codes instead of 32-bit columns
+                backend::device_vector<int> deltas(q, 256);
+                int nd = -1;
+                backend::check(vexhip_sell8_analyze_i32(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), w, deltas.raw(), &nd));
+                if (nd > 0) {
+                    A.deltas = deltas; A.ndeltas = nd;
+                    A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell8_bytes((int64_t)n, w, (int)sizeof(val_t)));
+                    backend::check(sell8_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, deltas.raw(), nd, A.sell.raw(), &A.trav));
+                } else {
+                    A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell_bytes((int64_t)n, w, (int)sizeof(val_t)));
+                    backend::check(sell_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, A.sell.raw()));
+                    backend::check(vexhip_sell_order_i32(dev, q.raw(), (int64_t)n, w, (int)sizeof(val_t), A.sell.raw(), 0, nullptr, 0, &A.trav));
+                }
                 q.finish();
             }
 
+            static int sell8_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, const int *d, int nd, void *sl, vexhip_traversal *t) { return vexhip_sell8_fill_f64_i32(dev, s, n, p, c, v, w, d, nd, sl, t); }
+            static int sell8_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, const int *d, int nd, void *sl, vexhip_traversal *t) { return vexhip_sell8_fill_f32_i32(dev, s, n, p, c, v, w, d, nd, sl, t); }
             static int sell_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, void *sl) { return vexhip_sell_fill_f64_i32(dev, s, n, p, c, v, w, sl); }
             static int sell_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, void *sl) { return vexhip_sell_fill_f32_i32(dev, s, n, p, c, v, w, sl); }
 
@@ -166,12 +179,18 @@ class SpMat {
             static int spmv(int dev, void *s, int64_t n, double a, int app, const matrix_arrays &A, const double *x, double *y) {
                 if (A.ell_w == 0 && A.csr_nnz)      // plain CSR storage: LDS-staged CSR kernel
                     return vexhip_spmv_csr_f64_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
+                if (A.ndeltas > 0)
+                    return vexhip_spmv_sell8_f64_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
                 return vexhip_spmv_sell_f64_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(),
                         A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
             }
             static int spmv(int dev, void *s, int64_t n, float a, int app, const matrix_arrays &A, const float *x, float *y) {
                 if (A.ell_w == 0 && A.csr_nnz)
                     return vexhip_spmv_csr_f32_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
+                if (A.ndeltas > 0)
+                    return vexhip_spmv_sell8_f32_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
                 return vexhip_spmv_sell_f32_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(),
                         A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
             }
@@ -304,13 +323,26 @@ struct inline_spmv : expression_base {
         c.src.begin_function(V, name + "_hell_spmv");
         c.src.begin_function_parameters();
         c.src.parameter("long", "ell_w");
-        c.src.parameter("const char *", "sell");
+        c.src.parameter("const char *", "sell"); c.src.parameter("const int *", "deltas");
         c.src.parameter("const int *", "csr_row"); c.src.parameter("const int *", "csr_col");
         c.src.parameter("const " + V + " *", "csr_val"); c.src.parameter("const " + V + " *", "in");
         c.src.parameter("ulong", "i");
         c.src.end_function_parameters();
         c.src.new_line() << V << " sum = 0;";
-        c.src.new_line() << "// SELL-512 storage: per slice of 512 rows, ell_w*512 columns then ell_w*512 values";
+        c.src.new_line() << "if (deltas)";            // SELL8: 1-byte diagonal codes (include/vexhip.h)
+        c.src.open("{");
+        c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
+        c.src.new_line() << "const char *slice = sell + (i >> 9) * (wp * 1024 + ell_w * 512 * sizeof(" << V << "));";
+        c.src.new_line() << "const uint *cw = (const uint *)slice + ((i & 511) >> 1);";
+        c.src.new_line() << "const " << V << " *ell_val = (const " << V << " *)(slice + wp * 1024) + (i & 511);";
+        c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
+        c.src.open("{");
+        c.src.new_line() << "const uint code = (cw[(j >> 1) * 256] >> (8 * ((j & 1) * 2 + (i & 1)))) & 255u;";
+        c.src.new_line() << "if (code != 255u) sum += ell_val[j * 512] * in[(long)i + deltas[code]];";
+        c.src.close("}");
+        c.src.close("}");
+        c.src.new_line() << "else";                   // SELL-512 with 32-bit columns
+        c.src.open("{");
         c.src.new_line() << "const char *slice = sell + (i >> 9) * (ell_w * 512 * (4 + sizeof(" << V << ")));";
         c.src.new_line() << "const int *ell_col = (const int *)slice + (i & 511);";
         c.src.new_line() << "const " << V << " *ell_val = (const " << V << " *)(slice + ell_w * 2048) + (i & 511);";
@@ -318,6 +350,7 @@ struct inline_spmv : expression_base {
         c.src.open("{");
         c.src.new_line() << "int c = ell_col[j * 512];";
         c.src.new_line() << "if (c != -1) sum += ell_val[j * 512] * in[c];";
+        c.src.close("}");
         c.src.close("}");
         c.src.new_line() << "if (csr_row)";
         c.src.open("{");
@@ -330,14 +363,14 @@ struct inline_spmv : expression_base {
         std::string name = c.next();
         const std::string V = type_name<T>();
         c.src.parameter("long", name + "_ell_w");
-        c.src.parameter("const char *", name + "_sell");
+        c.src.parameter("const char *", name + "_sell"); c.src.parameter("const int *", name + "_deltas");
         c.src.parameter("const int *", name + "_csr_row"); c.src.parameter("const int *", name + "_csr_col");
         c.src.parameter("const " + V + " *", name + "_csr_val"); c.src.parameter("const " + V + " *", name + "_vec");
     }
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
-        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, "
+        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, "
               << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, idx)";
     }
     void set_args(arg_context &a) const {
@@ -345,6 +378,7 @@ struct inline_spmv : expression_base {
         const auto &L = A.part_of(a.device).loc;
         a.krn.push_arg((long)L.ell_w);
         a.krn.push_arg(static_cast<const char *>(L.sell.raw()));
+        a.krn.push_arg(static_cast<const int *>(L.ndeltas > 0 ? L.deltas.raw() : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_nnz ? L.csr_ptr.raw() : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_col.raw())); a.krn.push_arg(static_cast<const T *>(L.csr_val.raw()));
         a.krn.push_arg(static_cast<const T *>(x(a.device).raw()));

@@ -16,6 +16,7 @@ int fail(const char *file, int line, const std::string &what);
 
 inline int check(hipError_t e, const char *file, int line) {
     if (e == hipSuccess) return 0;
+    (void)hipGetLastError();      // HIP's last-error slot is sticky: clear it so a later launch check does not report this failure again
     return fail(file, line, std::string(hipGetErrorName(e)) + ": " + hipGetErrorString(e));
 }
 

@@ -1,0 +1,368 @@
+// SELL-512 with 8-bit DIAGONAL CODES instead of 32-bit column indices.
+//
+// For banded / stencil matrices the difference (column - row) takes only a few
+// distinct values.  If the ELL part of a matrix uses at most 255 distinct
+// diagonals, each column index is stored as one byte -- the position of its
+// diagonal in a sorted table -- and re-built in the kernel as row + delta[code]
+// (code 255 = padding).  The matrix stream shrinks from 12 to 9 bytes per entry
+// (fp64), the arithmetic and its order are unchanged, results stay bit-identical
+// to hybrid ELL / CSR.  Matrices with more diagonals simply keep 32-bit columns
+// (vexhip_sell8_analyze_i32 reports -1).  The reference stores 32/64-bit columns
+// (spmat/hybrid_ell.inl:138-198); this is the HBM-byte lever of the MI355X design.
+//
+// Slice layout (one contiguous region per 512-row slice, w = ELL width):
+//     ceil(w/2) * 1 KiB of codes:  word [jp][t] = { (2jp, 2t), (2jp, 2t+1), (2jp+1, 2t), (2jp+1, 2t+1) }
+//     w * 512 values, j-major (value (r, j) at j*512 + r)
+// so lane t (rows 2t, 2t+1) reads one 4-byte word per column pair and 16 bytes of
+// values per column.  Compiled with -ffp-contract=off like spmv.hip.
+#include "common.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace vexhip {
+namespace {
+
+constexpr int S8_ROWS = 512;
+constexpr int S8_PAD = 255;
+constexpr int HASH_SLOTS = 1024;
+constexpr int LOCAL_SLOTS = 128;
+constexpr int EMPTY = INT_MIN;
+
+typedef double double2v __attribute__((ext_vector_type(2)));
+typedef float  float2v  __attribute__((ext_vector_type(2)));
+
+struct trav8 { const int *order; int chunk, planes, plane_blocks; };
+
+__device__ __forceinline__ long long trav_block(const trav8 &t, long long nblocks) {
+    const long long b = blockIdx.x;
+    if (t.order) return t.order[b];
+    if (t.chunk > 0) {
+        const long long k = b & 7, q = b >> 3;
+        const long long i = q % t.chunk, r = q / t.chunk;
+        const long long p = r % t.planes, tile = r / t.planes;
+        const long long l = tile * 8 * t.chunk + k * t.chunk + i;
+        const long long lb = p * t.plane_blocks + l;
+        return (l < t.plane_blocks && lb < nblocks) ? lb : -1;
+    }
+    return b < nblocks ? b : -1;
+}
+
+__host__ __device__ inline long long slice_bytes(long long w, long long value_bytes) {
+    return ((w + 1) / 2) * 1024 + w * S8_ROWS * value_bytes;
+}
+
+template <typename V> struct vec2;
+template <> struct vec2<double> { typedef double2v type; };
+template <> struct vec2<float> { typedef float2v type; };
+
+// ---------------------------------------------------------------------------
+template <typename V, int W>
+__global__ __launch_bounds__(256)
+void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
+        const char *__restrict__ buf, const int *__restrict__ deltas,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        const V *__restrict__ x, V *__restrict__ y, trav8 trav)
+{
+    __shared__ int s_delta[256];
+    s_delta[threadIdx.x] = deltas[threadIdx.x];
+    __syncthreads();
+
+    const long long s = trav_block(trav, nslices);
+    if (s < 0) return;
+    const int t = threadIdx.x;
+    const long long i = s * S8_ROWS + 2 * t;
+    const int w = W > 0 ? W : ell_w;
+    const int wp = (w + 1) / 2;
+    const char *slice = buf + s * slice_bytes(w, sizeof(V));
+    const unsigned *cw = reinterpret_cast<const unsigned *>(slice) + t;
+    const V *vp = reinterpret_cast<const V *>(slice + (long long)wp * 1024) + 2 * t;
+    typedef typename vec2<V>::type V2;
+
+    V sum[2] = {V(0), V(0)};
+    if constexpr (W > 0) {
+        constexpr int WP = (W + 1) / 2;
+        unsigned c[WP]; V2 v[W];
+#pragma unroll
+        for (int jp = 0; jp < WP; ++jp) c[jp] = __builtin_nontemporal_load(cw + jp * 256);
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * S8_ROWS));
+        V xv[W][2];
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
+                xv[j][q] = (code != S8_PAD) ? x[i + q + s_delta[code]] : V(0);
+            }
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
+                if (code != S8_PAD) sum[q] += v[j][q] * xv[j][q];
+            }
+    } else {
+        for (int j = 0; j < w; ++j) {
+            const unsigned cword = cw[(j >> 1) * 256];
+            const V2 vv = *reinterpret_cast<const V2 *>(vp + (long long)j * S8_ROWS);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned code = (cword >> (8 * ((j & 1) * 2 + q))) & 255u;
+                if (code != S8_PAD) sum[q] += vv[q] * x[i + q + s_delta[code]];
+            }
+        }
+    }
+    if (csr_ptr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (i + q < n)
+                for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (i + q < n) {
+            V o = alpha * sum[q];
+            if (append) o = y[i + q] + o;
+            y[i + q] = o;
+        }
+    }
+}
+
+// ---- set-up: which diagonals does the ELL part use? ------------------------------------
+__device__ __forceinline__ bool set_insert(int *set, int slots, int d, bool *is_new) {
+    unsigned h = ((unsigned)d * 2654435761u) % (unsigned)slots;
+    for (int probe = 0; probe < slots; ++probe) {
+        int old = atomicCAS(&set[h], EMPTY, d);
+        if (old == EMPTY) { if (is_new) *is_new = true; return true; }
+        if (old == d) return true;
+        h = (h + 1) % (unsigned)slots;
+    }
+    return false;
+}
+
+// gset: HASH_SLOTS ints (EMPTY-filled); info[0] = number of distinct diagonals, info[1] = overflow flag
+__global__ __launch_bounds__(256)
+void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const int *__restrict__ col,
+        int *gset, int *info)
+{
+    __shared__ int s_set[LOCAL_SLOTS];
+    __shared__ int s_over;
+    if (threadIdx.x < LOCAL_SLOTS) s_set[threadIdx.x] = EMPTY;
+    if (threadIdx.x == 0) s_over = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = ptr[i], e = ptr[i + 1];
+        int last = EMPTY;
+        for (int j = 0; j < w && b + j < e; ++j) {
+            long long dl = (long long)col[b + j] - i;
+            if (dl <= INT_MIN || dl > INT_MAX) { s_over = 1; continue; }
+            int d = (int)dl;
+            if (d == last) continue;
+            last = d;
+            if (!set_insert(s_set, LOCAL_SLOTS, d, nullptr)) s_over = 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < LOCAL_SLOTS && s_set[threadIdx.x] != EMPTY) {
+        bool is_new = false;
+        if (!set_insert(gset, HASH_SLOTS, s_set[threadIdx.x], &is_new)) atomicExch(&info[1], 1);
+        else if (is_new) atomicAdd(&info[0], 1);
+    }
+    if (threadIdx.x == 0 && s_over) atomicExch(&info[1], 1);
+}
+
+// table: sorted diagonals (ndeltas valid entries); counts[256]: entries per code; info[1]: set if a diagonal is missing
+template <typename V>
+__global__ __launch_bounds__(256)
+void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
+        const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        const int *__restrict__ table, char *__restrict__ buf, unsigned long long *counts, int *info)
+{
+    __shared__ int s_table[256];
+    __shared__ unsigned s_cnt[256];
+    s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int wp = (w + 1) / 2;
+    // one lane per row PAIR (the unit the product kernel reads)
+    for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (S8_ROWS / 2);
+         pr += (long long)gridDim.x * blockDim.x) {
+        const long long s = pr / (S8_ROWS / 2);
+        const int t = (int)(pr % (S8_ROWS / 2));
+        char *slice = buf + s * slice_bytes(w, sizeof(V));
+        unsigned *cw = reinterpret_cast<unsigned *>(slice) + t;
+        V *vp = reinterpret_cast<V *>(slice + (long long)wp * 1024) + 2 * t;
+        int b[2] = {0, 0}, e[2] = {0, 0};
+        const long long i = s * S8_ROWS + 2 * t;
+        for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
+        for (int jp = 0; jp < wp; ++jp) {
+            unsigned word = 0;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                for (int q = 0; q < 2; ++q) {
+                    unsigned code = S8_PAD;
+                    V v = V(0);
+                    if (j < w && b[q] + j < e[q]) {
+                        const int d = (int)((long long)col[b[q] + j] - (i + q));
+                        int lo = 0, hi = ndeltas;                    // first table entry >= d
+                        while (lo < hi) { int mid = (lo + hi) >> 1; if (s_table[mid] < d) lo = mid + 1; else hi = mid; }
+                        if (lo < ndeltas && s_table[lo] == d) { code = (unsigned)lo; atomicAdd(&s_cnt[lo], 1u); }
+                        else atomicExch(&info[1], 1);
+                        v = val[b[q] + j];
+                    }
+                    word |= code << (8 * (jj * 2 + q));
+                    if (j < w) vp[(long long)j * S8_ROWS + q] = v;
+                }
+            }
+            cw[jp * 256] = word;
+        }
+    }
+    __syncthreads();
+    if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+inline int grid_for(int dev, int64_t n) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16));
+}
+
+// Strip traversal from the diagonals every second row (or more) uses: see vexhip.h vexhip_traversal.
+void strip_traversal(int64_t n, const std::vector<int> &table, const std::vector<unsigned long long> &counts,
+        vexhip_traversal *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    const int64_t rpb = S8_ROWS, tile_rows_max = 65536;
+    if (n < 8 * tile_rows_max) return;
+    int64_t s_big = 0;
+    for (size_t k = 0; k < table.size(); ++k)
+        if (counts[k] * 2 >= (unsigned long long)n) s_big = std::max<int64_t>(s_big, table[k] < 0 ? -(int64_t)table[k] : table[k]);
+    if (s_big < 2 * tile_rows_max || (s_big % rpb) != 0) return;
+    const int64_t plane_blocks = s_big / rpb, nb = (n + rpb - 1) / rpb;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64, plane_blocks / 8));
+    const int64_t planes = (nb + plane_blocks - 1) / plane_blocks;
+    const int64_t tiles = (plane_blocks + 8 * chunk - 1) / (8 * chunk);
+    out->grid_blocks = tiles * planes * 8 * chunk;
+    out->chunk = chunk; out->planes = planes; out->plane_blocks = plane_blocks; out->order = nullptr;
+    if (out->grid_blocks >= (1ll << 31)) std::memset(out, 0, sizeof(*out));
+}
+
+template <typename V>
+int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w,
+        const int *deltas, int ndeltas, void *buf, vexhip_traversal *trav)
+{
+    VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 255, "bad SELL8 geometry");
+    if (trav) std::memset(trav, 0, sizeof(*trav));
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(ptr && col && val && deltas && buf, "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
+    unsigned long long *dcounts = nullptr;
+    VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 2 * sizeof(int)));
+    int *dinfo = reinterpret_cast<int *>(dcounts + 256);
+    VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
+    sell8_fill_kernel<V><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, ptr, col, val, deltas,
+            static_cast<char *>(buf), dcounts, dinfo);
+    std::vector<unsigned long long> counts(256);
+    std::vector<int> table(ndeltas);
+    int hinfo[2] = {0, 0};
+    VEXHIP_TRY(hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(hinfo, dinfo, sizeof(hinfo), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * ndeltas, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    VEXHIP_TRY(hipFree(dcounts));
+    VEXHIP_REQUIRE(hinfo[1] == 0, "SELL8 fill: the matrix uses a diagonal that is not in the table");
+    if (trav) strip_traversal(n, table, counts, trav);
+    return 0;
+}
+
+template <typename V>
+int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w, const void *buf, const int *deltas,
+        const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr)
+{
+    VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL8 geometry");
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(buf && deltas && x && y && (reinterpret_cast<uintptr_t>(buf) & 15) == 0, "SELL8 buffer must be 16-byte aligned");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
+    const bool ordered = tr && tr->grid_blocks > 0;
+    const long long grid = ordered ? tr->grid_blocks : ns;
+    trav8 t8 = {nullptr, 0, 0, 0};
+    if (ordered) t8 = trav8{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    const char *b = static_cast<const char *>(buf);
+#define CASE(W) case W: sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8); break;
+    switch (w) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        default: sell8_kernel<V, 0><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8);
+    }
+#undef CASE
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+} // namespace
+} // namespace vexhip
+
+using namespace vexhip;
+
+extern "C" {
+
+int64_t vexhip_sell8_bytes(int64_t n, int64_t w, int value_bytes) {
+    return (n + S8_ROWS - 1) / S8_ROWS * slice_bytes(w, value_bytes);
+}
+
+int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
+        int64_t w, int32_t *deltas, int *ndeltas)
+{
+    VEXHIP_REQUIRE(ndeltas && deltas, "NULL output");
+    *ndeltas = -1;
+    if (n <= 0 || w < 1) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    int *d = nullptr;
+    VEXHIP_TRY(hipMalloc(&d, sizeof(int) * (HASH_SLOTS + 2)));
+    std::vector<int> host(HASH_SLOTS + 2, EMPTY);
+    host[HASH_SLOTS] = 0; host[HASH_SLOTS + 1] = 0;
+    VEXHIP_TRY(hipMemcpyAsync(d, host.data(), sizeof(int) * host.size(), hipMemcpyHostToDevice, s));
+    delta_collect_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, d, d + HASH_SLOTS);
+    VEXHIP_TRY(hipMemcpyAsync(host.data(), d, sizeof(int) * host.size(), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    VEXHIP_TRY(hipFree(d));
+    if (std::getenv("VEXHIP_DEBUG")) std::fprintf(stderr, "sell8 analyze: count %d overflow %d\n", host[HASH_SLOTS], host[HASH_SLOTS + 1]);
+    if (host[HASH_SLOTS + 1] != 0 || host[HASH_SLOTS] > 255 || host[HASH_SLOTS] < 1) return 0;   // not a banded matrix
+    std::vector<int> table;
+    for (int k = 0; k < HASH_SLOTS; ++k) if (host[k] != EMPTY) table.push_back(host[k]);
+    std::sort(table.begin(), table.end());
+    if ((int)table.size() != host[HASH_SLOTS]) return fail(__FILE__, __LINE__, "diagonal set is inconsistent");
+    table.resize(256, INT_MAX);
+    VEXHIP_TRY(hipMemcpyAsync(deltas, table.data(), sizeof(int) * 256, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    *ndeltas = host[HASH_SLOTS];
+    return 0;
+}
+
+int vexhip_sell8_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *traversal)
+{ return sell8_fill<double>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, traversal); }
+
+int vexhip_sell8_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *traversal)
+{ return sell8_fill<float>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, traversal); }
+
+int vexhip_spmv_sell8_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w,
+        const void *buf, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *x, double *y, const vexhip_traversal *traversal)
+{ return spmv_sell8<double>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal); }
+
+int vexhip_spmv_sell8_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w,
+        const void *buf, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *x, float *y, const vexhip_traversal *traversal)
+{ return spmv_sell8<float>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal); }
+
+} // extern "C"

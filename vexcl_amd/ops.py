@@ -163,9 +163,12 @@ class SlicedELL:
     """SELL-512 storage of the ELL part (include/vexhip.h `vexhip_spmv_sell_*`):
     slice-major, one slice = the 512 rows of one workgroup = one contiguous region
     (its columns, then its values).  Width rule and CSR tail are those of hybrid ELL
-    (spmat/hybrid_ell.inl:66-216); same arithmetic, same summation order."""
+    (spmat/hybrid_ell.inl:66-216); same arithmetic, same summation order.
+    ``codes=True``: when the ELL part uses <= 255 distinct diagonals (banded /
+    stencil matrices) the columns are stored as 1-byte diagonal codes ("SELL8",
+    9 instead of 12 bytes per fp64 entry); other matrices keep 32-bit columns."""
 
-    def __init__(self, ptr, col, val, tiled=True, order_mode=0):
+    def __init__(self, ptr, col, val, tiled=True, order_mode=0, codes=True):
         L = lib()
         self.n = n = ptr.numel() - 1
         self.dtype = val.dtype
@@ -175,6 +178,7 @@ class SlicedELL:
         self.width, self.tail_nnz = int(w.value), int(tail.value)
         if not self.width:
             raise Error("SlicedELL needs a non-empty ELL part")
+        self.deltas, self.ndeltas = None, -1
         self.csr_ptr = self.csr_col = self.csr_val = None
         f64 = val.dtype == torch.float64
         if self.tail_nnz:
@@ -185,11 +189,27 @@ class SlicedELL:
                 dev, s, n, _p(ptr), _p(col), _p(val), self.width, (n + 15) // 16 * 16, None, None,
                 _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val))
         vb = val.element_size()
+        # traversal order for banded / stencil matrices (0 blocks = plain order)
+        self.order, self.trav = None, _capi.Traversal()
+        if codes:
+            # banded / stencil matrix (<= 255 distinct diagonals in the ELL part): 1-byte diagonal codes
+            deltas = torch.empty(256, dtype=torch.int32, device=d)
+            nd = ctypes.c_int(-1)
+            L.sell8_analyze_i32(dev, s, n, _p(ptr), _p(col), self.width, _p(deltas), ctypes.byref(nd))
+            if nd.value > 0:
+                self.deltas, self.ndeltas = deltas, int(nd.value)
+                self.sell = torch.empty(L.sell8_bytes(n, self.width, vb), dtype=torch.uint8, device=d)
+                trav = _capi.Traversal()
+                (L.sell8_fill_f64_i32 if f64 else L.sell8_fill_f32_i32)(
+                    dev, s, n, _p(ptr), _p(col), _p(val), self.width, _p(deltas), self.ndeltas, _p(self.sell),
+                    ctypes.byref(trav))
+                if tiled and order_mode == 0:
+                    self.trav = trav
+                self.order_grid = int(self.trav.grid_blocks)
+                return
         self.sell = torch.empty(L.sell_bytes(n, self.width, vb), dtype=torch.uint8, device=d)   # one region per slice
         (L.sell_fill_f64_i32 if f64 else L.sell_fill_f32_i32)(
             dev, s, n, _p(ptr), _p(col), _p(val), self.width, _p(self.sell))
-        # traversal order for banded / stencil matrices (0 blocks = plain order)
-        self.order, self.trav = None, _capi.Traversal()
         if tiled:
             cap = L.hell_order_capacity(n) if order_mode in (1, 2) else 0
             self.order = torch.empty(cap, dtype=torch.int32, device=d) if cap else None
@@ -202,6 +222,12 @@ class SlicedELL:
         f64 = self.dtype == torch.float64
         a = ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha)
         use = bool(tiled and self.order_grid)
+        if self.deltas is not None:
+            (L.spmv_sell8_f64_i32 if f64 else L.spmv_sell8_f32_i32)(
+                _dev(y), _stream(y), self.n, a, int(bool(append)), self.width, _p(self.sell), _p(self.deltas),
+                _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), _p(x), _p(y),
+                ctypes.byref(self.trav) if use else None)
+            return y
         (L.spmv_sell_f64_i32 if f64 else L.spmv_sell_f32_i32)(
             _dev(y), _stream(y), self.n, a, int(bool(append)), self.width, _p(self.sell),
             _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), _p(x), _p(y),
