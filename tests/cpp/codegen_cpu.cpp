@@ -146,6 +146,48 @@ TEST_CASE(additive_transform_classification) {
     CHECK(true);
 }
 
+// one kernel assigns all components: every rhs evaluated before the first store
+// (reference kernel shape: vexcl/multivector.hpp:486-600)
+template <class OP, class T, size_t N, class E, size_t... I>
+std::string multi_src(const multivector<T, N> &x, const E &expr, std::index_sequence<I...>) {
+    using namespace detail;
+    backend::command_queue q;
+    const auto &e = as_expr<E>::get(expr);
+    typedef typename std::decay<decltype(e)>::type node;
+    auto lhs = std::make_tuple(vector_ref<T>(x(I))...);
+    auto rhs = std::make_tuple(component_of<I, node>::get(e)...);
+    return multi_assignment_source<OP>(lhs, rhs, q);
+}
+
+TEST_CASE(multivector_kernel_shape) {
+    multivector<double, 2> x, y;
+    vector<double> v;
+    std::string s = multi_src<assign::SET>(x, std::make_tuple(1, 2.5) * y + sin(v), std::make_index_sequence<2>());
+    CHECK(has(s, "extern \"C\" __global__ void vexcl_multivector_kernel"));
+    // lhs terminals first (prm_1, prm_2), then component 0's (int, y(0), v), then component 1's (double, y(1), v)
+    CHECK(has(s, "double * prm_1") && has(s, "double * prm_2") && has(s, "int prm_3") && has(s, "double prm_6") && !has(s, "prm_9"));
+    CHECK(has(s, "double buf_1 = ( ( prm_3 * prm_4[idx] ) + sin( prm_5[idx] ) );"));
+    CHECK(has(s, "double buf_2 = ( ( prm_6 * prm_7[idx] ) + sin( prm_8[idx] ) );"));
+    CHECK(has(s, "prm_1[idx] = buf_1;") && has(s, "prm_2[idx] = buf_2;"));
+    CHECK(s.find("buf_2 = ") < s.find("prm_1[idx] = buf_1;"));
+    backend::check_sources(s);
+
+    s = multi_src<assign::MUL>(x, std::tie(y(1), sqr(y(0))), std::make_index_sequence<2>());
+    CHECK(has(s, "prm_1[idx] *= buf_1;") && has(s, "double buf_2 = sqr( prm_4[idx] );"));
+    CHECK_EQUAL(count(s, "double sqr"), size_t(1));
+    backend::check_sources(s);
+
+    using namespace detail;
+    typedef SpMat<double, int, int> M;
+    static_assert(mv_dim<mv_ref<double, 3>>::value == 3, "");
+    static_assert(mv_dim<std::decay<decltype(2 * x + 1)>::type>::value == 2, "");
+    static_assert(mv_dim<vector_ref<double>>::value == 0, "");
+    typedef additive_operator<M, multivector<double, 2>> AX;
+    static_assert(mv_dim<AX>::value == 2 && expr_kind<AX>::value == 1, "");
+    static_assert(std::is_same<component_of<1, AX>::type, additive_operator<M, vector<double>>>::value, "");
+    static_assert(std::is_same<AX::value_type, double>::value, "");
+}
+
 TEST_CASE(partition_and_util) {
     CHECK_EQUAL(alignup(17), size_t(32));
     CHECK_EQUAL(nextpow2(1000), size_t(1024));

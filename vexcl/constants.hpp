@@ -15,6 +15,22 @@ struct text_constant : expression_base {
     void set_args(arg_context &) const {} void get_props(prop_context &) const {}
 };
 }
+namespace detail {
+/// std::integral_constant<T, v> as an operand: the value is part of the kernel
+/// text (constants.hpp:60-90 of the reference), `x = std::integral_constant<int, 42>()`.
+template <class T, T v>
+struct integral_text : expression_base {
+    typedef T value_type;
+    void preamble(gen_context &) const {} void params(gen_context &) const {} void local_init(gen_context &) const {}
+    void emit(gen_context &c) const { c.src << "( " << v << " )"; }
+    void set_args(arg_context &) const {} void get_props(prop_context &) const {}
+};
+template <class T, T v> struct is_extra_operand<std::integral_constant<T, v>> : std::true_type {};
+template <class T, T v> struct as_expr<std::integral_constant<T, v>, void> {
+    typedef integral_text<T, v> type;
+    static type get(const std::integral_constant<T, v> &) { return type(); }
+};
+}
 namespace constants {
 #define VEXCL_CONSTANT(name, value)                                                         \
     struct name##_impl { static const char *text() { return #value; } };                   \

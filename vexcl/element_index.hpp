@@ -22,7 +22,7 @@ struct elem_index : expression_base {
 
 /// Index of the current element, shifted by offset; length gives a size to
 /// otherwise size-less expressions (element_index.hpp:52-66).
-inline detail::elem_index element_index(size_t offset = 0, size_t length = 0) {
+inline const detail::elem_index element_index(size_t offset = 0, size_t length = 0) {
     return detail::elem_index(offset, length);
 }
 } // namespace vex

@@ -39,7 +39,7 @@ struct UserFunction {
 
     template <class... Args>
     typename std::enable_if<(sizeof...(Args) > 0),
-        detail::function_call<UserFunction<Impl, R>, R, detail::as_expr_t<Args>...>>::type
+        const detail::function_call<UserFunction<Impl, R>, R, detail::as_expr_t<Args>...>>::type
     operator()(const Args &...args) const {
         return detail::function_call<UserFunction<Impl, R>, R, detail::as_expr_t<Args>...>(
                 detail::as_expr<Args>::get(args)...);
@@ -131,7 +131,7 @@ namespace detail {
     struct builtin_##fname { static const char *name() { return #fname; } };                        \
     template <class... Args>                                                                        \
     typename std::enable_if<any_expr<Args...>::value && all_operands<Args...>::value,               \
-        function_call<builtin_function<builtin_##fname>,                                            \
+        const function_call<builtin_function<builtin_##fname>,                                      \
             typename std::common_type<typename as_expr_t<Args>::value_type...>::type,               \
             as_expr_t<Args>...>>::type                                                              \
     fname(const Args &...args) {                                                                    \
@@ -165,14 +165,14 @@ namespace detail {
 struct builtin_abs_int { static const char *name() { return "abs"; } };
 template <class Arg>
 typename std::enable_if<is_expr<Arg>::value && std::is_floating_point<typename as_expr_t<Arg>::value_type>::value,
-    function_call<builtin_function<builtin_fabs>, typename as_expr_t<Arg>::value_type, as_expr_t<Arg>>>::type
+    const function_call<builtin_function<builtin_fabs>, typename as_expr_t<Arg>::value_type, as_expr_t<Arg>>>::type
 abs(const Arg &a) {
     return function_call<builtin_function<builtin_fabs>, typename as_expr_t<Arg>::value_type,
            as_expr_t<Arg>>(as_expr<Arg>::get(a));
 }
 template <class Arg>
 typename std::enable_if<is_expr<Arg>::value && !std::is_floating_point<typename as_expr_t<Arg>::value_type>::value,
-    function_call<builtin_function<builtin_abs_int>, typename as_expr_t<Arg>::value_type, as_expr_t<Arg>>>::type
+    const function_call<builtin_function<builtin_abs_int>, typename as_expr_t<Arg>::value_type, as_expr_t<Arg>>>::type
 abs(const Arg &a) {
     return function_call<builtin_function<builtin_abs_int>, typename as_expr_t<Arg>::value_type,
            as_expr_t<Arg>>(as_expr<Arg>::get(a));

@@ -117,7 +117,11 @@ template <class T> struct as_expr<T, typename std::enable_if<is_expr<T>::value &
 };
 template <class T> using as_expr_t = typename as_expr<T>::type;
 
-template <class T> struct is_operand : std::integral_constant<bool, is_expr<T>::value || is_scalar<T>::value> {};
+// operands that are neither nodes nor arithmetic values (std::tuple of per-component
+// operands -- multivector.hpp; std::integral_constant -- constants.hpp) opt in here
+template <class T> struct is_extra_operand : std::false_type {};
+template <class T> struct is_operand : std::integral_constant<bool,
+    is_expr<T>::value || is_scalar<T>::value || is_extra_operand<typename std::decay<T>::type>::value> {};
 
 // ---- operator tags -----------------------------------------------------------
 namespace tag {
@@ -228,9 +232,14 @@ struct ternary_expr : expression_base {
 // ---- additive transforms: A*x terms (operations.hpp:759-776) ------------------
 struct additive_transform_base : expression_base {};
 
+template <class V, class Enable = void> struct element_type_of { typedef typename V::value_type type; };
+template <class V> struct element_type_of<V, typename std::enable_if<!std::is_void<typename V::sub_value_type>::value>::type> {
+    typedef typename V::sub_value_type type;    // multivector: the type of one component's elements
+};
+
 template <class M, class V>
 struct additive_operator : additive_transform_base {
-    typedef typename V::value_type value_type;
+    typedef typename element_type_of<V>::type value_type;
     const M &A; const V &x;
     additive_operator(const M &A, const V &x) : A(A), x(x) {}
     template <class W> void apply(W &y, double scale, bool append) const {
@@ -273,6 +282,57 @@ template <class F, class R, class... A> struct expr_kind<function_call<F, R, A..
     : std::integral_constant<int, all_vector_kind<A...>::value ? 0 : -1> {};
 template <class C, class A, class B> struct expr_kind<ternary_expr<C, A, B>>
     : std::integral_constant<int, all_vector_kind<C, A, B>::value ? 0 : -1> {};
+
+// ---- multi-expressions (multivector.hpp) --------------------------------------
+// Number of components an expression carries: 0 for ordinary vector expressions,
+// N when it contains a multivector<T, N> or an N-tuple operand (multivector.hpp:70-150
+// of the reference: multivector grammar).
+constexpr size_t join_dim(size_t a, size_t b) { return a == 0 ? b : a; }
+template <class E, class Enable = void> struct mv_dim : std::integral_constant<size_t, 0> {};
+template <class Tag, class L, class R> struct mv_dim<binary_expr<Tag, L, R>>
+    : std::integral_constant<size_t, join_dim(mv_dim<L>::value, mv_dim<R>::value)> {
+    static_assert(mv_dim<L>::value == 0 || mv_dim<R>::value == 0 || mv_dim<L>::value == mv_dim<R>::value,
+            "operands of a multi-expression have different numbers of components");
+};
+template <class Tag, class A> struct mv_dim<unary_expr<Tag, A>> : mv_dim<A> {};
+template <class... A> struct mv_dim_all : std::integral_constant<size_t, 0> {};
+template <class H, class... T> struct mv_dim_all<H, T...>
+    : std::integral_constant<size_t, join_dim(mv_dim<H>::value, mv_dim_all<T...>::value)> {};
+template <class F, class R, class... A> struct mv_dim<function_call<F, R, A...>> : mv_dim_all<A...> {};
+template <class C, class A, class B> struct mv_dim<ternary_expr<C, A, B>> : mv_dim_all<C, A, B> {};
+
+/// Component I of a multi-expression, as an ordinary expression; ordinary
+/// sub-expressions are shared by all components (multivector.hpp subexpression extraction).
+template <size_t I, class E, class Enable = void> struct component_of {
+    typedef E type;
+    static const E &get(const E &e) { return e; }
+};
+template <size_t I, class Tag, class L, class R>
+struct component_of<I, binary_expr<Tag, L, R>, typename std::enable_if<(mv_dim<binary_expr<Tag, L, R>>::value > 0)>::type> {
+    typedef binary_expr<Tag, typename component_of<I, L>::type, typename component_of<I, R>::type> type;
+    static type get(const binary_expr<Tag, L, R> &e) { return type(component_of<I, L>::get(e.l), component_of<I, R>::get(e.r)); }
+};
+template <size_t I, class Tag, class A>
+struct component_of<I, unary_expr<Tag, A>, typename std::enable_if<(mv_dim<A>::value > 0)>::type> {
+    typedef unary_expr<Tag, typename component_of<I, A>::type> type;
+    static type get(const unary_expr<Tag, A> &e) { return type(component_of<I, A>::get(e.a)); }
+};
+template <size_t I, class F, class R, class... A>
+struct component_of<I, function_call<F, R, A...>, typename std::enable_if<(mv_dim_all<A...>::value > 0)>::type> {
+    typedef function_call<F, R, typename component_of<I, A>::type...> type;
+    template <size_t... K>
+    static type make(const function_call<F, R, A...> &e, std::index_sequence<K...>) {
+        return type(component_of<I, A>::get(std::get<K>(e.args))...);
+    }
+    static type get(const function_call<F, R, A...> &e) { return make(e, std::index_sequence_for<A...>()); }
+};
+template <size_t I, class C, class A, class B>
+struct component_of<I, ternary_expr<C, A, B>, typename std::enable_if<(mv_dim_all<C, A, B>::value > 0)>::type> {
+    typedef ternary_expr<typename component_of<I, C>::type, typename component_of<I, A>::type, typename component_of<I, B>::type> type;
+    static type get(const ternary_expr<C, A, B> &e) {
+        return type(component_of<I, C>::get(e.c_), component_of<I, A>::get(e.a), component_of<I, B>::get(e.b));
+    }
+};
 
 /// Hook: an expression that is, as a whole, one product with a hand-written kernel
 /// (e.g. `y += A * x` with A a SpMatCCSR) nominates it here; it remains an ordinary
@@ -445,6 +505,9 @@ void assign_any(const LHS &lhs, W &target, const Expr &expr,
 } // namespace detail
 
 // ---- operators ----------------------------------------------------------------
+// Results are CONST prvalues, as Boost.Proto's are in the reference: that is what lets
+// `std::tie(x + y, x - y)` bind them (std::tie takes lvalue references; a const prvalue
+// binds to `const E &`), tests/multivector_arithmetics.cpp:68.
 // Defined in vex::detail, where the node types live (ADL), and re-exported to vex::
 // for operands that are vex::vector / tagged terminals.
 namespace detail {
@@ -453,7 +516,7 @@ namespace detail {
     typename std::enable_if<                                                                                   \
         (is_expr<L>::value || is_expr<R>::value) &&                                            \
         is_operand<L>::value && is_operand<R>::value,                                          \
-        binary_expr<tag::tagname, as_expr_t<L>, as_expr_t<R>>>::type           \
+        const binary_expr<tag::tagname, as_expr_t<L>, as_expr_t<R>>>::type     \
     operator op(const L &l, const R &r) {                                                                      \
         return binary_expr<tag::tagname, as_expr_t<L>, as_expr_t<R>>(          \
                 as_expr<L>::get(l), as_expr<R>::get(r));                                       \
@@ -482,7 +545,7 @@ VEXCL_BINARY_OPERATOR(bitwise_xor, ^)
 #define VEXCL_UNARY_OPERATOR(tagname, op)                                                                      \
     template <class A>                                                                                         \
     typename std::enable_if<is_expr<A>::value,                                                         \
-        unary_expr<tag::tagname, as_expr_t<A>>>::type                                  \
+        const unary_expr<tag::tagname, as_expr_t<A>>>::type                            \
     operator op(const A &a) {                                                                                  \
         return unary_expr<tag::tagname, as_expr_t<A>>(as_expr<A>::get(a));     \
     }
@@ -496,7 +559,7 @@ VEXCL_UNARY_OPERATOR(complement, ~)
 template <class C, class A, class B>
 typename std::enable_if<is_operand<C>::value && is_operand<A>::value && is_operand<B>::value &&
     (is_expr<C>::value || is_expr<A>::value || is_expr<B>::value),
-    ternary_expr<as_expr_t<C>, as_expr_t<A>, as_expr_t<B>>>::type
+    const ternary_expr<as_expr_t<C>, as_expr_t<A>, as_expr_t<B>>>::type
 if_else(const C &c, const A &a, const B &b) {
     return ternary_expr<as_expr_t<C>, as_expr_t<A>, as_expr_t<B>>(
             as_expr<C>::get(c), as_expr<A>::get(a), as_expr<B>::get(b));

@@ -13,6 +13,7 @@
 #include <memory>
 #include "operations.hpp"
 #include "vector.hpp"
+#include "multivector.hpp"
 
 namespace vex {
 
@@ -96,7 +97,8 @@ class Reductor {
 
         /// Reduces the expression; blocking, returns a host value (reductor.hpp:302-439).
         template <class Expr>
-        result_type operator()(const Expr &expr_) const {
+        typename std::enable_if<detail::mv_dim<detail::as_expr_t<Expr>>::value == 0, result_type>::type
+        operator()(const Expr &expr_) const {
             using namespace detail;
             typedef as_expr_t<Expr> E;
             const E &expr = as_expr<Expr>::get(expr_);
@@ -138,7 +140,22 @@ class Reductor {
             return combine(host, active, std::integral_constant<bool, minmax>());
         }
 
+        /// Multi-expression: one result per component (reductor.hpp:443-470).
+        template <class Expr>
+        typename std::enable_if<(detail::mv_dim<detail::as_expr_t<Expr>>::value > 0),
+            std::array<result_type, detail::mv_dim<detail::as_expr_t<Expr>>::value>>::type
+        operator()(const Expr &expr) const {
+            return reduce_components(detail::as_expr<Expr>::get(expr),
+                    std::make_index_sequence<detail::mv_dim<detail::as_expr_t<Expr>>::value>());
+        }
+
     private:
+        template <class E, size_t... I>
+        std::array<result_type, sizeof...(I)> reduce_components(const E &expr, std::index_sequence<I...>) const {
+            std::array<result_type, sizeof...(I)> r = {{(*this)(detail::component_of<I, E>::get(expr))...}};
+            return r;
+        }
+
         std::vector<backend::command_queue> queue;
         std::vector<std::shared_ptr<detail::reductor_buffers>> bufs;
         std::vector<int> ngroups;

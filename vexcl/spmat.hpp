@@ -24,6 +24,7 @@
 
 #include "operations.hpp"
 #include "vector.hpp"
+#include "multivector.hpp"
 #include "spmat/ccsr.hpp"
 
 namespace vex {
@@ -307,6 +308,14 @@ operator*(const SpMat<val_t, col_t, idx_t> &A, const vector<T> &x) {
     return detail::additive_operator<SpMat<val_t, col_t, idx_t>, vector<T>>(A, x);
 }
 
+/// A * X with X a multivector: the product is applied to every component
+/// (spmat.hpp:388-400; tests/spmv.cpp:262-300).
+template <typename val_t, typename col_t, typename idx_t, typename T, size_t N>
+detail::additive_operator<SpMat<val_t, col_t, idx_t>, multivector<T, N>>
+operator*(const SpMat<val_t, col_t, idx_t> &A, const multivector<T, N> &x) {
+    return detail::additive_operator<SpMat<val_t, col_t, idx_t>, multivector<T, N>>(A, x);
+}
+
 // ---- make_inline (spmat/inline_spmv.hpp:70-198; device function body
 //      hybrid_ell.inl:322-351) ----------------------------------------------------------
 namespace detail {
@@ -391,9 +400,31 @@ struct inline_spmv : expression_base {
 
 /// sin(make_inline(A * x)): the product evaluated inside the fused kernel
 /// (single device; inline_spmv.hpp:70-76).
-template <class M, class V>
-detail::inline_spmv<M, typename V::value_type> make_inline(const detail::additive_operator<M, V> &op) {
-    return detail::inline_spmv<M, typename V::value_type>(op.A, op.x);
+template <class M, class T>
+detail::inline_spmv<M, T> make_inline(const detail::additive_operator<M, vector<T>> &op) {
+    return detail::inline_spmv<M, T>(op.A, op.x);
+}
+
+namespace detail {
+/// make_inline(A * X), X a multivector: component I is make_inline(A * X(I)).
+template <class M, class T, size_t N>
+struct mv_inline_spmv : expression_base {
+    typedef T value_type;
+    const M &A; const multivector<T, N> &x;
+    mv_inline_spmv(const M &A, const multivector<T, N> &x) : A(A), x(x) {}
+    void get_props(prop_context &p) const {
+        if (p.empty()) { p.queue = A.queue_list(); p.part = A.row_partition(); p.size = A.rows(); }
+    }
+};
+template <class M, class T, size_t N> struct mv_dim<mv_inline_spmv<M, T, N>> : std::integral_constant<size_t, N> {};
+template <size_t I, class M, class T, size_t N> struct component_of<I, mv_inline_spmv<M, T, N>, void> {
+    typedef inline_spmv<M, T> type;
+    static type get(const mv_inline_spmv<M, T, N> &p) { return type(p.A, p.x(I)); }
+};
+}
+template <class M, class T, size_t N>
+detail::mv_inline_spmv<M, T, N> make_inline(const detail::additive_operator<M, multivector<T, N>> &op) {
+    return detail::mv_inline_spmv<M, T, N>(op.A, op.x);
 }
 
 } // namespace vex
