@@ -188,6 +188,24 @@ TEST_CASE(multivector_kernel_shape) {
     static_assert(std::is_same<AX::value_type, double>::value, "");
 }
 
+VEX_FUNCTION(bool, keys_equal, (int, a1)(long, a2)(int, b1)(long, b2), return a1 == b1 && a2 == b2;);
+VEX_FUNCTION(double, dplus, (double, x)(double, y), return x + y;);
+
+TEST_CASE(by_key_kernels_compile) {                                   // scan_by_key.hpp / reduce_by_key.hpp sources
+    using namespace detail::sbk;
+    backend::command_queue q;
+    for (scan_mode m : {INCLUSIVE, EXCLUSIVE, REDUCE}) {
+        std::string s = source<double, decltype(keys_equal), decltype(dplus)>(q, {"int", "long"}, m);
+        CHECK(has(s, "vexcl_sbk_reduce") && has(s, "vexcl_sbk_carry") && has(s, "vexcl_sbk_scan"));
+        CHECK(has(s, "keys_equal(p0, p1, k0, k1)") && has(s, "dplus(a.v, b.v)"));
+        CHECK_EQUAL(has(s, "okey1[fin.c - 1] = key1[i];"), m == REDUCE);
+        backend::check_sources(s);
+    }
+    std::string s = source<int, equal_fn<unsigned>, plus_fn<int>>(q, {"uint"}, EXCLUSIVE);
+    CHECK(has(s, "sbk_plus(init, prev.v)"));
+    backend::check_sources(s);
+}
+
 TEST_CASE(partition_and_util) {
     CHECK_EQUAL(alignup(17), size_t(32));
     CHECK_EQUAL(nextpow2(1000), size_t(1024));

@@ -107,3 +107,149 @@ TEST_CASE(stencil_small_vector_and_two_stencils) {                   // stencil.
     A = 2.0f; B = A * F;
     check_sample(B, [](size_t, float v) { CHECK_CLOSE(v, 2.0f, 1e-5); });
 }
+
+// ---- scan_by_key / reduce_by_key (tests/scan_by_key.cpp, tests/reduce_by_key.cpp) -------------
+// Full comparison against a serial loop: bit-exact for integers; floating point sums are
+// associated as a tree on the device, so they are compared with the reference's 1e-8 % tolerance.
+template <class T> static bool all_close(const std::vector<T> &a, const std::vector<T> &b, double pct = 1e-8) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i) {
+        double d = std::fabs(double(a[i]) - double(b[i])), m = std::max(std::fabs(double(a[i])), std::fabs(double(b[i])));
+        if (d > pct * 0.01 * m) return false;
+    }
+    return true;
+}
+template <class K, class V>
+static void serial_scan_by_key(const std::vector<K> &k, const std::vector<V> &v, std::vector<V> &incl, std::vector<V> &excl, V init) {
+    incl.resize(v.size()); excl.resize(v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        bool head = i == 0 || !(k[i - 1] == k[i]);
+        incl[i] = head ? v[i] : incl[i - 1] + v[i];
+        excl[i] = head ? init : init + incl[i - 1];
+    }
+}
+
+TEST_CASE(scan_by_key_default_functions) {                           // scan_by_key.cpp:17-61
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    for (size_t n : {size_t(1), size_t(63), size_t(1000), size_t(2048), size_t(2049), size_t(1) << 20, (size_t(1) << 20) + 77}) {
+        std::vector<int> x = random_vector<int>(n), y = random_vector<int>(n);
+        std::sort(x.begin(), x.end());
+        if (n > 5000) for (size_t i = 3000; i < 3000 + 2 * 2048 + 100 && i < n; ++i) x[i] = x[3000];   // a run spanning whole tiles
+        std::sort(x.begin(), x.end());
+        vex::vector<int> ikeys(queue, x), ivals(queue, y), ovals(queue, n);
+        std::vector<int> incl, excl, got(n);
+        serial_scan_by_key(x, y, incl, excl, 0);
+        vex::inclusive_scan_by_key(ikeys, ivals, ovals);
+        vex::copy(ovals, got); CHECK(got == incl);
+        vex::exclusive_scan_by_key(ikeys, ivals, ovals);
+        vex::copy(ovals, got); CHECK(got == excl);
+        serial_scan_by_key(x, y, incl, excl, 5);
+        vex::exclusive_scan_by_key(ikeys, ivals, ovals, 5);
+        vex::copy(ovals, got); CHECK(got == excl);
+    }
+    // doubles
+    const size_t n = 300000;
+    std::vector<cl_long> k(n); for (size_t i = 0; i < n; ++i) k[i] = cl_long(i / 777);
+    std::vector<double> v = random_vector<double>(n), incl, excl, got(n);
+    serial_scan_by_key(k, v, incl, excl, 0.0);
+    vex::vector<cl_long> K(queue, k); vex::vector<double> V(queue, v), O(queue, n);
+    vex::inclusive_scan_by_key(K, V, O);
+    vex::copy(O, got); CHECK(all_close(got, incl));
+    std::vector<double> again(n);
+    vex::inclusive_scan_by_key(K, V, V);                               // in place; reproducible bit for bit
+    vex::copy(V, again); CHECK(again == got);
+}
+
+VEX_FUNCTION(bool, pair_equal, (int, a1)(int, a2)(int, b1)(int, b2), return a1 == b1 && a2 == b2;);
+VEX_FUNCTION(int, int_plus, (int, x)(int, y), return x + y;);
+VEX_FUNCTION(int, int_max, (int, x)(int, y), return x > y ? x : y;);
+
+TEST_CASE(scan_by_key_tuple_keys_user_functions) {                    // scan_by_key.cpp:63-124
+    const size_t n = 100000;
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    std::vector<int> x1(n), x2(n), y = random_vector<int>(n);
+    for (size_t i = 0; i < n; ++i) { x1[i] = int(i / 100); x2[i] = int((i % 100) / 7); }
+    vex::vector<int> k1(queue, x1), k2(queue, x2), ivals(queue, y), ovals(queue, n);
+    auto same = [&](size_t i) { return i > 0 && x1[i - 1] == x1[i] && x2[i - 1] == x2[i]; };
+
+    std::vector<int> want(n), got(n);
+    vex::inclusive_scan_by_key(std::tie(k1, k2), ivals, ovals, pair_equal, int_plus);
+    for (size_t i = 0; i < n; ++i) want[i] = same(i) ? want[i - 1] + y[i] : y[i];
+    vex::copy(ovals, got); CHECK(got == want);
+
+    vex::exclusive_scan_by_key(std::tie(k1, k2), ivals, ovals, pair_equal, int_plus);
+    std::vector<int> incl = want;
+    for (size_t i = 0; i < n; ++i) want[i] = same(i) ? incl[i - 1] : 0;
+    vex::copy(ovals, got); CHECK(got == want);
+
+    vex::inclusive_scan_by_key(std::tie(k1, k2), ivals, ovals, pair_equal, int_max);   // non-additive operator
+    for (size_t i = 0; i < n; ++i) want[i] = same(i) ? std::max(want[i - 1], y[i]) : y[i];
+    vex::copy(ovals, got); CHECK(got == want);
+}
+
+TEST_CASE(reduce_by_key_default_functions) {                          // reduce_by_key.cpp:9-43
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    for (size_t n : {size_t(1), size_t(100), size_t(2048), size_t(1024 * 1024), size_t(1024 * 1024 + 3)}) {
+        std::vector<int> x = random_vector<int>(n);
+        std::vector<double> y = random_vector<double>(n);
+        std::sort(x.begin(), x.end());
+        vex::vector<int> ikeys(queue, x), okeys;
+        vex::vector<double> ivals(queue, y), ovals;
+        int num_keys = vex::reduce_by_key(ikeys, ivals, okeys, ovals);
+
+        std::vector<int> uk; std::vector<double> us;
+        for (size_t i = 0; i < n; ++i) {
+            if (i == 0 || x[i - 1] != x[i]) { uk.push_back(x[i]); us.push_back(y[i]); } else us.back() += y[i];
+        }
+        CHECK_EQUAL(size_t(num_keys), uk.size());
+        CHECK_EQUAL(okeys.size(), uk.size());
+        CHECK_EQUAL(ovals.size(), uk.size());
+        std::vector<int> gk(uk.size()); std::vector<double> gs(uk.size());
+        vex::copy(okeys, gk); vex::copy(ovals, gs);
+        CHECK(gk == uk);
+        CHECK(all_close(gs, us));
+    }
+    vex::vector<int> ek(queue, 0), ok; vex::vector<double> ev(queue, 0), ov;
+    CHECK_EQUAL(vex::reduce_by_key(ek, ev, ok, ov), 0);              // empty input
+    // all keys distinct / all keys equal
+    const size_t n = 10000;
+    std::vector<int> x(n); std::iota(x.begin(), x.end(), 0);
+    std::vector<double> y = random_vector<double>(n);
+    vex::vector<int> ik(queue, x); vex::vector<double> iv(queue, y);
+    CHECK_EQUAL(vex::reduce_by_key(ik, iv, ok, ov), int(n));
+    std::vector<double> gs(n); vex::copy(ov, gs); CHECK(gs == y);
+    ik = 7;
+    CHECK_EQUAL(vex::reduce_by_key(ik, iv, ok, ov), 1);
+    CHECK_EQUAL(int(ok[0]), 7);
+    CHECK_CLOSE(double(ov[0]), std::accumulate(y.begin(), y.end(), 0.0), 1e-8);
+}
+
+VEX_FUNCTION(bool, key2_equal, (cl_int, a1)(cl_long, a2)(cl_int, b1)(cl_long, b2), return (a1 == b1) && (a2 == b2););
+VEX_FUNCTION(double, dbl_plus, (double, x)(double, y), return x + y;);
+
+TEST_CASE(reduce_by_key_tuple_keys) {                                 // reduce_by_key.cpp:45-129
+    const size_t n = 1000 * 1000;
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    std::vector<cl_int> k1(n); std::vector<cl_long> k2(n);
+    {
+        std::vector<cl_int> a = random_vector<cl_int>(n); std::vector<cl_long> b = random_vector<cl_long>(n);
+        std::vector<size_t> idx(n); std::iota(idx.begin(), idx.end(), 0);
+        std::sort(idx.begin(), idx.end(), [&](size_t i, size_t j) { return std::make_tuple(a[i], b[i]) < std::make_tuple(a[j], b[j]); });
+        for (size_t i = 0; i < n; ++i) { k1[i] = a[idx[i]]; k2[i] = b[idx[i]]; }
+    }
+    std::vector<double> y = random_vector<double>(n);
+    vex::vector<cl_int> ikey1(queue, k1), okey1; vex::vector<cl_long> ikey2(queue, k2), okey2;
+    vex::vector<double> ivals(queue, y), ovals;
+    int num_keys = vex::reduce_by_key(std::tie(ikey1, ikey2), ivals, std::tie(okey1, okey2), ovals, key2_equal, dbl_plus);
+
+    std::vector<cl_int> rk1; std::vector<cl_long> rk2; std::vector<double> rsum;
+    for (size_t i = 0; i < n; ++i) {
+        if (i > 0 && k1[i - 1] == k1[i] && k2[i - 1] == k2[i]) rsum.back() += y[i];
+        else { rk1.push_back(k1[i]); rk2.push_back(k2[i]); rsum.push_back(y[i]); }
+    }
+    CHECK_EQUAL(size_t(num_keys), rsum.size());
+    CHECK_EQUAL(okey1.size(), rsum.size()); CHECK_EQUAL(okey2.size(), rsum.size()); CHECK_EQUAL(ovals.size(), rsum.size());
+    std::vector<cl_int> g1(rsum.size()); std::vector<cl_long> g2(rsum.size()); std::vector<double> gs(rsum.size());
+    vex::copy(okey1, g1); vex::copy(okey2, g2); vex::copy(ovals, gs);
+    CHECK(g1 == rk1); CHECK(g2 == rk2); CHECK(all_close(gs, rsum));
+}

@@ -1,0 +1,321 @@
+#ifndef VEXCL_SCAN_BY_KEY_HPP
+#define VEXCL_SCAN_BY_KEY_HPP
+// vex::inclusive_scan_by_key / vex::exclusive_scan_by_key (reference:
+// vexcl/scan_by_key.hpp:713-757 API, :77-700 kernels; tests/scan_by_key.cpp) and
+// the engine shared with vex::reduce_by_key (reduce_by_key.hpp).
+//
+// MI355X design.  A segmented scan over triples (c, f, v): c = heads seen,
+// f = {bit 0: a head was seen, bit 1: non-empty}, v = running value of the LAST
+// segment; combine(a, b) = (a.c + b.c, a.f | b.f, b has a head ? b.v : oper(a.v, b.v)).
+// The operator is associative, so the scan is the usual three phases.  The tile
+// geometry is fixed (it does not depend on the device or on n), so results are
+// reproducible run to run; floating point sums are associated as a tree, not as
+// the serial loop would, and differ from it by rounding only:
+//   1. vexcl_sbk_reduce: one aggregate per tile of 4 waves x VT x 64 elements;
+//   2. vexcl_sbk_carry : ONE workgroup turns the aggregates into carries-in;
+//   3. vexcl_sbk_scan  : re-reads the tile, adds its carry, stores the result.
+// Inside a wave everything is wave-64 shuffles (no LDS ping-pong as in the
+// reference's 2-element-per-thread Hillis-Steele, scan_by_key.hpp:200-252): a
+// wave owns VT consecutive rows of 64 elements, all loads and stores are
+// coalesced, the head flag of element i comes from the neighbour lane (one extra
+// load per row for lane 0).  Keys may be a single vector or a std::tie of
+// vectors (the reference takes boost::fusion::vector_tie); comparison and
+// operator are VEX_FUNCTIONs pasted into the generated source.
+#include <sstream>
+#include <tuple>
+#include "vector.hpp"
+#include "function.hpp"
+
+namespace vex {
+namespace detail {
+namespace sbk {
+
+enum scan_mode { INCLUSIVE = 0, EXCLUSIVE = 1, REDUCE = 2 };
+
+static const int VT = 8;            // rows of 64 elements per wave
+static const int WAVES = 4;         // waves per workgroup
+static const int TILE = VT * WAVES * 64;
+
+// ---- key sequences: one vector or a tuple of vector references -----------------
+template <class T> struct key_seq;
+template <class K> struct key_seq<vector<K>> {
+    static const size_t size = 1;
+    typedef std::tuple<const vector<K> &> tuple_type;
+    static tuple_type get(const vector<K> &k) { return tuple_type(k); }
+};
+template <class... K> struct key_seq<std::tuple<K...>> {
+    static const size_t size = sizeof...(K);
+    typedef std::tuple<K...> tuple_type;
+    static const tuple_type &get(const std::tuple<K...> &k) { return k; }
+};
+template <class V> struct key_value;
+template <class K> struct key_value<vector<K>> { typedef K type; };
+
+template <class Tuple, size_t... I>
+std::vector<std::string> key_types(std::index_sequence<I...>) {
+    return {type_name<typename key_value<typename std::decay<typename std::tuple_element<I, Tuple>::type>::type>::type>()...};
+}
+
+struct kernels {
+    backend::kernel reduce, carry, scan;
+};
+
+/// Source of the three kernels for the given key types, value type, functions and mode.
+template <class V, class Comp, class Oper>
+std::string source(const backend::command_queue &q, const std::vector<std::string> &K, scan_mode mode) {
+    backend::source_generator src(q);
+    { gen_context c(src, q); Comp::preamble(c); Oper::preamble(c); }
+    const std::string T = type_name<V>();
+    const size_t nk = K.size();
+    std::ostringstream s;
+    s << "\n#define VT " << VT << "\n#define WAVES " << WAVES << "\n";
+    s << "typedef " << T << " val_t;\n"
+         "struct sbk_t { int c; int f; val_t v; };\n"
+         "__device__ inline sbk_t sbk_empty() { sbk_t r; r.c = 0; r.f = 0; r.v = val_t(); return r; }\n"
+         "__device__ inline sbk_t sbk_combine(sbk_t a, sbk_t b) {\n"
+         "  sbk_t r; r.c = a.c + b.c; r.f = a.f | b.f;\n"
+         "  if ((b.f & 1) || !(a.f & 2)) r.v = b.v;\n"
+         "  else if (b.f & 2) r.v = " << Oper::name() << "(a.v, b.v);\n"
+         "  else r.v = a.v;\n"
+         "  return r;\n"
+         "}\n"
+         "__device__ inline sbk_t sbk_up(sbk_t x, int o) { sbk_t r; r.c = __shfl_up(x.c, o, 64); r.f = __shfl_up(x.f, o, 64); r.v = __shfl_up(x.v, o, 64); return r; }\n"
+         "__device__ inline sbk_t sbk_from(sbk_t x, int l) { sbk_t r; r.c = __shfl(x.c, l, 64); r.f = __shfl(x.f, l, 64); r.v = __shfl(x.v, l, 64); return r; }\n"
+         "__device__ inline sbk_t sbk_wave_scan(sbk_t x, int lane) {\n"
+         "  for (int o = 1; o < 64; o <<= 1) { sbk_t y = sbk_up(x, o); if (lane >= o) x = sbk_combine(y, x); }\n"
+         "  return x;\n"
+         "}\n";
+    // per-wave scan of its VT rows: y[j] = inclusive prefix relative to the wave's first element
+    auto key_params = [&](bool trailing_comma) {
+        std::ostringstream p;
+        for (size_t k = 0; k < nk; ++k) p << "const " << K[k] << " *key" << k << (k + 1 < nk || trailing_comma ? ", " : "");
+        return p.str();
+    };
+    auto key_args = [&]() {
+        std::ostringstream p;
+        for (size_t k = 0; k < nk; ++k) p << "key" << k << ", ";
+        return p.str();
+    };
+    s << "__device__ inline sbk_t sbk_wave_tile(ulong n, ulong wbase, int lane, " << key_params(true) << "const val_t *vals, sbk_t *y) {\n"
+         "  sbk_t carry = sbk_empty();\n"
+         "  #pragma unroll\n"
+         "  for (int j = 0; j < VT; ++j) {\n"
+         "    const ulong i = wbase + j * 64 + lane;\n"
+         "    const bool in = i < n;\n";
+    for (size_t k = 0; k < nk; ++k) {
+        s << "    " << K[k] << " k" << k << " = in ? key" << k << "[i] : (" << K[k] << ")0;\n"
+          << "    " << K[k] << " p" << k << " = __shfl_up(k" << k << ", 1, 64);\n"
+          << "    if (lane == 0 && in && i > 0) p" << k << " = key" << k << "[i - 1];\n";
+    }
+    s << "    sbk_t x = sbk_empty();\n"
+         "    if (in) {\n"
+         "      const bool head = (i == 0) || !" << Comp::name() << "(";
+    for (size_t k = 0; k < nk; ++k) s << "p" << k << ", ";
+    for (size_t k = 0; k < nk; ++k) s << "k" << k << (k + 1 < nk ? ", " : "");
+    s << ");\n"
+         "      x.c = head; x.f = 2 | (int)head; x.v = vals[i];\n"
+         "    }\n"
+         "    x = sbk_combine(carry, sbk_wave_scan(x, lane));\n"
+         "    y[j] = x;\n"
+         "    carry = sbk_from(x, 63);\n"
+         "  }\n"
+         "  return carry;\n"
+         "}\n";
+
+    s << "extern \"C\" __global__ void __launch_bounds__(" << WAVES * 64 << ") vexcl_sbk_reduce(ulong n, " << key_params(true)
+      << "const val_t *vals, int *tc, int *tf, val_t *tv) {\n"
+         "  __shared__ sbk_t agg[WAVES];\n"
+         "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
+         "  sbk_t y[VT];\n"
+         "  sbk_t a = sbk_wave_tile(n, ((ulong)blockIdx.x * WAVES + wave) * (VT * 64), lane, " << key_args() << "vals, y);\n"
+         "  if (lane == 0) agg[wave] = a;\n"
+         "  __syncthreads();\n"
+         "  if (threadIdx.x == 0) {\n"
+         "    sbk_t t = agg[0];\n"
+         "    for (int w = 1; w < WAVES; ++w) t = sbk_combine(t, agg[w]);\n"
+         "    tc[blockIdx.x] = t.c; tf[blockIdx.x] = t.f; tv[blockIdx.x] = t.v;\n"
+         "  }\n"
+         "}\n";
+
+    s << "extern \"C\" __global__ void __launch_bounds__(1024) vexcl_sbk_carry(int ntiles, int *tc, int *tf, val_t *tv, int *total) {\n"
+         "  __shared__ sbk_t wagg[16];\n"
+         "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
+         "  sbk_t carry = sbk_empty();\n"
+         "  for (int base = 0; base < ntiles; base += 1024) {\n"
+         "    const int t = base + threadIdx.x;\n"
+         "    sbk_t x = sbk_empty();\n"
+         "    if (t < ntiles) { x.c = tc[t]; x.f = tf[t]; x.v = tv[t]; }\n"
+         "    sbk_t sc = sbk_wave_scan(x, lane);\n"
+         "    if (lane == 63) wagg[wave] = sc;\n"
+         "    __syncthreads();\n"
+         "    sbk_t pre = carry, all = carry;\n"
+         "    for (int w = 0; w < 16; ++w) { if (w == wave) pre = all; all = sbk_combine(all, wagg[w]); }\n"
+         "    sbk_t incl = sbk_combine(pre, sc);\n"
+         "    sbk_t excl = sbk_up(incl, 1);\n"
+         "    if (lane == 0) excl = pre;\n"
+         "    if (t < ntiles) { tc[t] = excl.c; tf[t] = excl.f; tv[t] = excl.v; }\n"
+         "    carry = all;\n"
+         "    __syncthreads();\n"
+         "  }\n"
+         "  if (threadIdx.x == 0) *total = carry.c;\n"
+         "}\n";
+
+    s << "extern \"C\" __global__ void __launch_bounds__(" << WAVES * 64 << ") vexcl_sbk_scan(ulong n, " << key_params(true)
+      << "const val_t *vals, const int *tc, const int *tf, const val_t *tv, ";
+    if (mode == REDUCE) {
+        for (size_t k = 0; k < nk; ++k) s << K[k] << " *okey" << k << ", ";
+        s << "val_t *ovals) {\n";
+    } else {
+        s << "val_t *ovals, val_t init) {\n";
+    }
+    s << "  __shared__ sbk_t agg[WAVES];\n"
+         "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
+         "  const ulong wbase = ((ulong)blockIdx.x * WAVES + wave) * (VT * 64);\n"
+         "  sbk_t y[VT];\n"
+         "  sbk_t a = sbk_wave_tile(n, wbase, lane, " << key_args() << "vals, y);\n"
+         "  if (lane == 0) agg[wave] = a;\n"
+         "  __syncthreads();\n"
+         "  sbk_t W; W.c = tc[blockIdx.x]; W.f = tf[blockIdx.x]; W.v = tv[blockIdx.x];\n"
+         "  for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n"
+         "  sbk_t before = W;\n"
+         "  #pragma unroll\n"
+         "  for (int j = 0; j < VT; ++j) {\n"
+         "    const ulong i = wbase + j * 64 + lane;\n"
+         "    const sbk_t fin = sbk_combine(W, y[j]);\n"
+         "    sbk_t prev = sbk_up(fin, 1);\n"
+         "    if (lane == 0) prev = before;\n"
+         "    before = sbk_from(fin, 63);\n"
+         "    if (i < n) {\n"
+         "      const bool head = fin.c != prev.c;\n";
+    if (mode == INCLUSIVE) {
+        s << "      (void)head; (void)init; ovals[i] = fin.v;\n";
+    } else if (mode == EXCLUSIVE) {
+        s << "      ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+    } else {
+        s << "      if (head) {\n";
+        for (size_t k = 0; k < nk; ++k) s << "        okey" << k << "[fin.c - 1] = key" << k << "[i];\n";
+        s << "        if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
+             "      }\n"
+             "      if (i == n - 1) ovals[fin.c - 1] = fin.v;\n";
+    }
+    s << "    }\n"
+         "  }\n"
+         "}\n";
+    return src.str() + s.str();
+}
+
+template <class Tuple, class F, size_t... I>
+void for_each_key(const Tuple &t, F &&f, std::index_sequence<I...>) {
+    int dummy[] = {0, (f(std::get<I>(t)), 0)...};
+    (void)dummy;
+}
+
+/// Runs phases 1 and 2; returns the number of segments.  `finish` then launches phase 3.
+template <scan_mode mode, class KTuple, class V, class Comp, class Oper, class PushOutputs>
+int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&push_outputs, bool need_count) {
+    constexpr size_t nk = std::tuple_size<KTuple>::value;
+    typedef std::make_index_sequence<nk> seq;
+    const auto &queue = ivals.queue_list();
+    precondition(queue.size() == 1, "scan_by_key / reduce_by_key are only supported for single-device contexts");
+    const backend::command_queue &q = queue[0];
+    const size_t n = ivals.size();
+    for_each_key(keys, [&](const auto &k) { precondition(k.size() == n, "keys and values have different sizes"); }, seq());
+    if (!n) return 0;
+
+    static object_cache<kernels> cache;
+    auto it = cache.find(q);
+    if (it == cache.end()) {
+        backend::program prog = backend::build_sources(q, source<V, Comp, Oper>(q, key_types<KTuple>(seq()), mode));
+        kernels k;
+        k.reduce = backend::kernel(q, prog, "vexcl_sbk_reduce");
+        k.carry = backend::kernel(q, prog, "vexcl_sbk_carry");
+        k.scan = backend::kernel(q, prog, "vexcl_sbk_scan");
+        it = cache.insert(q, std::move(k));
+    }
+    kernels &K = it->second;
+
+    const size_t ntiles = (n + TILE - 1) / TILE;
+    precondition(ntiles < (size_t(1) << 31), "input too large");
+    auto &pool = scratch_pool::instance();
+    backend::device_vector<char> tcb = pool.get(q, 4, (2 * ntiles + 1) * sizeof(int));
+    backend::device_vector<char> tvb = pool.get(q, 5, ntiles * sizeof(V));
+    int *tc = reinterpret_cast<int *>(tcb.raw()), *tf = tc + ntiles, *total = tf + ntiles;
+    V *tv = reinterpret_cast<V *>(tvb.raw());
+
+    K.reduce.push_arg(n);
+    for_each_key(keys, [&](const auto &k) { K.reduce.push_arg(k(0).raw()); }, seq());
+    K.reduce.push_arg(ivals(0).raw()); K.reduce.push_arg(tc); K.reduce.push_arg(tf); K.reduce.push_arg(tv);
+    K.reduce.config(ntiles, WAVES * 64);
+    K.reduce(q);
+
+    K.carry.push_arg(static_cast<int>(ntiles)); K.carry.push_arg(tc); K.carry.push_arg(tf); K.carry.push_arg(tv); K.carry.push_arg(total);
+    K.carry.config(1, 1024);
+    K.carry(q);
+
+    int count = 0;
+    if (need_count) {
+        backend::device_vector<int> t = backend::device_vector<int>::wrap(total, 1);
+        t.read(q, 0, 1, &count, true);
+    }
+
+    K.scan.push_arg(n);
+    for_each_key(keys, [&](const auto &k) { K.scan.push_arg(k(0).raw()); }, seq());
+    K.scan.push_arg(ivals(0).raw());
+    K.scan.push_arg(static_cast<const int *>(tc)); K.scan.push_arg(static_cast<const int *>(tf)); K.scan.push_arg(static_cast<const V *>(tv));
+    push_outputs(K.scan, count);
+    K.scan.config(ntiles, WAVES * 64);
+    K.scan(q);
+    return count;
+}
+
+template <bool exclusive, class KTuple, class V, class Comp, class Oper>
+void scan_by_key(const KTuple &keys, const vector<V> &ivals, vector<V> &ovals, Comp comp, Oper oper, V init) {
+    precondition(ivals.size() == ovals.size(), "input and output have different sizes");
+    run<exclusive ? EXCLUSIVE : INCLUSIVE>(keys, ivals, comp, oper,
+            [&](backend::kernel &k, int) { k.push_arg(ovals(0).raw()); k.push_arg(init); }, false);
+}
+
+} // namespace sbk
+} // namespace detail
+
+/// ovals[i] = init (+) ivals[first of i's run] (+) ... (+) ivals[i - 1]; init at the first
+/// element of every run of equal keys (scan_by_key.hpp:713-721).
+template <class K, typename V, class Comp, class Oper>
+void exclusive_scan_by_key(const K &keys, const vector<V> &ivals, vector<V> &ovals, Comp comp, Oper oper, V init = V()) {
+    detail::sbk::scan_by_key<true>(detail::sbk::key_seq<K>::get(keys), ivals, ovals, comp, oper, init);
+}
+/// ovals[i] = ivals[first of i's run] (+) ... (+) ivals[i] (scan_by_key.hpp:725-733).
+template <class K, typename V, class Comp, class Oper>
+void inclusive_scan_by_key(const K &keys, const vector<V> &ivals, vector<V> &ovals, Comp comp, Oper oper, V init = V()) {
+    detail::sbk::scan_by_key<false>(detail::sbk::key_seq<K>::get(keys), ivals, ovals, comp, oper, init);
+}
+
+namespace detail { namespace sbk {
+    // default functions: keys compared with ==, values added (scan_by_key.hpp:742-744)
+    template <class K> struct equal_fn : UserFunction<equal_fn<K>, bool> {
+        static std::string name() { return "sbk_equal"; }
+        static void params(std::vector<std::pair<std::string, std::string>> &p) {
+            p.push_back(std::make_pair(type_name<K>(), std::string("x"))); p.push_back(std::make_pair(type_name<K>(), std::string("y")));
+        }
+        static std::string body() { return "return x == y;"; }
+    };
+    template <class V> struct plus_fn : UserFunction<plus_fn<V>, V> {
+        static std::string name() { return "sbk_plus"; }
+        static void params(std::vector<std::pair<std::string, std::string>> &p) {
+            p.push_back(std::make_pair(type_name<V>(), std::string("x"))); p.push_back(std::make_pair(type_name<V>(), std::string("y")));
+        }
+        static std::string body() { return "return x + y;"; }
+    };
+}}
+
+template <typename K, typename V>
+void exclusive_scan_by_key(const vector<K> &keys, const vector<V> &ivals, vector<V> &ovals, V init = V()) {
+    exclusive_scan_by_key(keys, ivals, ovals, detail::sbk::equal_fn<K>(), detail::sbk::plus_fn<V>(), init);
+}
+template <typename K, typename V>
+void inclusive_scan_by_key(const vector<K> &keys, const vector<V> &ivals, vector<V> &ovals, V init = V()) {
+    inclusive_scan_by_key(keys, ivals, ovals, detail::sbk::equal_fn<K>(), detail::sbk::plus_fn<V>(), init);
+}
+
+} // namespace vex
+#endif
