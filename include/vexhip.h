@@ -197,6 +197,24 @@ int vexhip_spmv_sell8_f32_i32(int dev, void *stream, int64_t n, float alpha, int
         const void *buf, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y, const vexhip_traversal *traversal);
 
+/* Multi-right-hand-side products  y[k] (+)= alpha * A * x[k],  k < nrhs  -- `SpMat * multivector`
+ * (vexcl/spmat.hpp:388-398, which applies the product once per component; tests/spmv.cpp:262-305).
+ * One launch per group of up to four right-hand sides reads the matrix ONCE; each y[k] is
+ * bit-identical to the corresponding vexhip_spmv_sell*_ call.  x and y are HOST arrays of
+ * nrhs device pointers; every other argument is as in the single-vector calls.               */
+int vexhip_spmm_sell8_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell8_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
+        const void *sell, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t ell_width,
+        const void *sell, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal);
+
 /* CSR -> hybrid ELL conversion on the device (sparse/ell.hpp:400-508,
  * `convert_csr2ell` :348-397; width rule hybrid_ell.inl:66-114).
  * Step 1 (blocking): row-width histogram -> ELL width by the reference's

@@ -236,3 +236,50 @@ TEST_CASE(multivector_inline_spmv) {                                  // spmv.cp
         }
     });
 }
+
+TEST_CASE(multivector_spmv_single_device_fused) {                     // one pass over the matrix for all components
+    typedef std::array<double, 3> elem_t;
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    // (a) 3-D Poisson (1-byte diagonal codes), (b) random rows with a CSR tail (32-bit columns)
+    for (int kind = 0; kind < 2; ++kind) {
+        std::vector<int> row, col; std::vector<double> val;
+        size_t n;
+        if (kind == 0) {
+            const int m = 20; n = size_t(m) * m * m;
+            row.push_back(0);
+            for (int k = 0; k < m; ++k) for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) {
+                int idx = (k * m + j) * m + i;
+                if (i == 0 || i == m - 1 || j == 0 || j == m - 1 || k == 0 || k == m - 1) { col.push_back(idx); val.push_back(1); }
+                else {
+                    int nb[7] = {idx - m * m, idx - m, idx - 1, idx, idx + 1, idx + m, idx + m * m};
+                    for (int q = 0; q < 7; ++q) { col.push_back(nb[q]); val.push_back(q == 3 ? 6.0 : -1.0 - 0.01 * q); }
+                }
+                row.push_back((int)col.size());
+            }
+        } else {
+            n = 3000;
+            random_matrix(n, n, 16, row, col, val);
+        }
+        std::vector<double> x = random_vector<double>(n * 3), y0 = random_vector<double>(n * 3);
+        vex::SpMat<double, int, int> A(queue, n, n, row.data(), col.data(), val.data());
+        vex::multivector<double, 3> X(queue, x), Y(queue, y0), Z(queue, n);
+        auto rowsum = [&](size_t i, size_t k) {
+            double s = 0;
+            for (int j = row[i]; j < row[i + 1]; ++j) s += val[j] * x[k * n + col[j]];
+            return s;
+        };
+        Z = A * X;
+        for (size_t k = 0; k < 3; ++k) {                               // bit-identical to the single-vector product
+            vex::vector<double> z(queue, n);
+            z = A * X(k);
+            std::vector<double> a(n), b(n);
+            vex::copy(z, a); vex::copy(Z(k), b);
+            CHECK(a == b);
+        }
+        check_sample(Z, [&](size_t i, elem_t a) { for (size_t k = 0; k < 3; ++k) CHECK_CLOSE(a[k], rowsum(i, k), 1e-8); });
+        Y += 2 * (A * X) - X;
+        check_sample(Y, [&](size_t i, elem_t a) {
+            for (size_t k = 0; k < 3; ++k) CHECK_CLOSE(a[k] + 100, 100 + y0[k * n + i] + 2 * rowsum(i, k) - x[k * n + i], 1e-8);
+        });
+    }
+}

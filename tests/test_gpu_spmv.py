@@ -362,3 +362,49 @@ def test_sell8_diagonal_codes(T, oracle, built_lib):
     y = T.torch.empty(3001, dtype=T.torch.float32, device=T.dev)
     S.mul(T.up(x32), y)
     assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, x32))
+
+
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 4, 5, 7])
+def test_multi_rhs_products_are_bit_identical(T, oracle, built_lib, nrhs):
+    """`SpMat * multivector` (spmat.hpp:388-398): one pass over the matrix for up to four
+    right-hand sides; every result equals the single-vector product bit for bit."""
+    rng = np.random.default_rng(100 + nrhs)
+    cases = []
+    n = 24
+    cases.append(oracle.poisson3d(n))                                      # SELL8, unrolled width 7
+    cases.append(_banded(rng, 5000, [-700, -3, -1, 0, 2, 9]))              # SELL8, run-time width
+    cases.append(oracle.random_matrix(11, 3000, 3000, 16))                 # 32-bit columns + CSR tail
+    p, c, v = oracle.random_matrix(12, 2000, 2000, 6)
+    cases.append((p, c, v))
+    for ptr, col, val in cases:
+        rows, cols = len(ptr) - 1, len(ptr) - 1
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        xs = [T.up(rng.random(cols) - 0.5) for _ in range(nrhs)]
+        y0 = [rng.random(rows) for _ in range(nrhs)]
+        for alpha, append in ((1.0, False), (-2.5, True)):
+            want = [T.up(y.copy()) for y in y0]
+            for x, y in zip(xs, want):
+                A.apply(x, y, alpha, append)
+            got = [T.up(y.copy()) for y in y0]
+            A.apply_multi(xs, got, alpha, append)
+            for g, w in zip(got, want):
+                assert T.torch.equal(g, w)
+        # and against the oracle for the first component
+        y = oracle.spmv_csr(ptr, col, val, xs[0].cpu().numpy())
+        out = [T.torch.empty(rows, dtype=T.torch.float64, device=T.dev) for _ in range(nrhs)]
+        A.apply_multi(xs, out)
+        assert np.array_equal(out[0].cpu().numpy(), y)
+    # float32, CSR-only format falls back to one product per component
+    ptr, col, val = _banded(rng, 3001, [-5, 0, 5, 77])
+    v32 = val.astype(np.float32)
+    A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32))
+    xs = [T.up((rng.random(3001) - 0.5).astype(np.float32)) for _ in range(nrhs)]
+    out = [T.torch.empty(3001, dtype=T.torch.float32, device=T.dev) for _ in range(nrhs)]
+    A.apply_multi(xs, out)
+    for x, o in zip(xs, out):
+        assert np.array_equal(o.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, x.cpu().numpy()))
+    C = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), fmt="csr")
+    out2 = [T.torch.empty(3001, dtype=T.torch.float32, device=T.dev) for _ in range(nrhs)]
+    C.apply_multi(xs, out2)
+    for a, b in zip(out, out2):
+        assert T.torch.equal(a, b)

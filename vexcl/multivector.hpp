@@ -156,6 +156,14 @@ void assign_multiexpression(const std::tuple<L...> &lhs, const std::tuple<R...> 
     }
 }
 
+/// The left-hand sides of a multi-assignment, as the target of A*X terms
+/// (SpMat::apply(multivector, multi_target) writes all components in one pass).
+template <class... Ts> struct multi_target { std::tuple<vector<Ts> &...> v; };
+
+// a tuple operand holding A*x terms can only be assigned component by component
+template <class... E> struct expr_kind<tuple_node<E...>>
+    : std::integral_constant<int, all_vector_kind<E...>::value ? 0 : -1> {};
+
 template <class... C> struct all_fusable : std::true_type {};
 template <class H, class... T> struct all_fusable<H, T...>
     : std::integral_constant<bool, expr_kind<H>::value == 0 && !direct_assign<H>::value && all_fusable<T...>::value> {};
@@ -175,9 +183,28 @@ void assign_multi(const std::tuple<vector<Ts> &...> &lhs, const Expr &expr, std:
         precondition(p.size == 0 || p.empty() || p.size == first.size(), "Incompatible expression sizes");
     }
     auto rhs = std::make_tuple(component_of<I, Expr>::get(expr)...);
+    constexpr int kind = expr_kind<Expr>::value;
     if constexpr (all_fusable<typename component_of<I, Expr>::type...>::value) {
         auto l = std::make_tuple(vector_ref<Ts>(std::get<I>(lhs))...);
         assign_multiexpression<OP>(l, rhs, queue, part);
+    } else if constexpr (kind == 1 || kind == 2) {
+        // A*X terms joined by + / - / scalars with an (optional) vector part: one fused kernel
+        // for the vector parts of all components, then every product term once -- it writes
+        // all components in one pass over the matrix (operations.hpp assign_any, N-fold)
+        constexpr bool set = std::is_same<OP, assign::SET>::value;
+        constexpr bool sub = std::is_same<OP, assign::SUB>::value;
+        static_assert(set || sub || std::is_same<OP, assign::ADD>::value, "A*x terms support only =, += and -=");
+        bool append = !set;
+        if constexpr (kind == 2) {
+            auto vp = vector_part(expr);
+            typedef decltype(vp) VP;
+            auto l = std::make_tuple(vector_ref<Ts>(std::get<I>(lhs))...);
+            auto r = std::make_tuple(component_of<I, VP>::get(vp)...);
+            assign_multiexpression<OP>(l, r, queue, part);
+            append = true;
+        }
+        multi_target<Ts...> target = {lhs};
+        apply_transforms(target, expr, sub ? -1.0 : 1.0, append);
     } else {
         int dummy[] = {0, (assign_any<OP>(vector_ref<Ts>(std::get<I>(lhs)), std::get<I>(lhs), std::get<I>(rhs), queue, part), 0)...};
         (void)dummy;

@@ -70,6 +70,21 @@ class SpMat {
             if (exchange) finish_exchange(y, alpha);
         }
 
+        /// Y = alpha * A * X for a multivector (spmat.hpp:388-398).  Without a ghost exchange
+        /// (one device, or block-diagonal partitions) every device reads its matrix ONCE for
+        /// up to four components (vexhip_spmm_*); otherwise component by component.
+        template <class T, size_t N, class... Ts>
+        void apply(const multivector<T, N> &x, detail::multi_target<Ts...> &y, scalar_type alpha = 1, bool append = false) const {
+            static_assert(sizeof...(Ts) == N, "multivector product: component count mismatch");
+            static_assert(std::is_same<T, val_t>::value, "vector and matrix value types differ");
+            apply_components(x, y, alpha, append, std::make_index_sequence<N>());
+        }
+        /// One vector on the right, several on the left: the same product lands in every component.
+        template <class T, class... Ts>
+        void apply(const vex::vector<T> &x, detail::multi_target<Ts...> &y, scalar_type alpha = 1, bool append = false) const {
+            detail::tuple_for_each(y.v, [&](auto &yk, size_t) { this->apply(x, yk, alpha, append); });
+        }
+
         // ---- pieces used by make_inline (spmat.hpp:195-230) -------------------------
         struct device_part;
         const device_part &part_of(unsigned d) const { return *mtx[d]; }
@@ -196,6 +211,37 @@ class SpMat {
                         A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
             }
 
+            static int spmm(int dev, void *s, int64_t n, int k, double a, int app, const matrix_arrays &A, const double *const *x, double *const *y) {
+                if (A.ndeltas > 0)
+                    return vexhip_spmm_sell8_f64_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
+                return vexhip_spmm_sell_f64_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(),
+                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
+            }
+            static int spmm(int dev, void *s, int64_t n, int k, float a, int app, const matrix_arrays &A, const float *const *x, float *const *y) {
+                if (A.ndeltas > 0)
+                    return vexhip_spmm_sell8_f32_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
+                return vexhip_spmm_sell_f32_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(),
+                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
+            }
+
+            /// Local part times several vectors at once (pointers of this device's segments).
+            void mul_local_multi(const backend::command_queue &q, int k, const val_t *const *x, val_t *const *y,
+                    val_t alpha, bool append) const
+            {
+                const int dev = q.device_ordinal();
+                if (loc.empty()) {
+                    if (!append) for (int c = 0; c < k; ++c) backend::check(vexhip_memset(dev, y[c], 0, n * sizeof(val_t), q.raw()));
+                    return;
+                }
+                if (loc.ell_w == 0) {           // CSR-only storage: no multi-vector kernel, one product per component
+                    for (int c = 0; c < k; ++c) backend::check(spmv(dev, q.raw(), (int64_t)n, alpha, append ? 1 : 0, loc, x[c], y[c]));
+                    return;
+                }
+                backend::check(spmm(dev, q.raw(), (int64_t)n, k, alpha, append ? 1 : 0, loc, x, y));
+            }
+
             /// csr.inl:186-200: an empty local part zero-fills y on SET.
             void mul_local(const backend::command_queue &q, const backend::device_vector<val_t> &x,
                     backend::device_vector<val_t> &y, val_t alpha, bool append) const
@@ -219,6 +265,25 @@ class SpMat {
         std::vector<size_t> part, col_part;
         size_t nrows, ncols, nnz;
         std::vector<std::shared_ptr<device_part>> mtx;
+
+        template <class T, size_t N, class... Ts, size_t... I>
+        void apply_components(const multivector<T, N> &x, detail::multi_target<Ts...> &y, scalar_type alpha, bool append,
+                std::index_sequence<I...>) const
+        {
+            const bool exchange = queue.size() > 1 && !pairs.empty();
+            if (exchange) {       // the ghost buffers hold one vector: component by component
+                int dummy[] = {0, (apply(x(I), std::get<I>(y.v), alpha, append), 0)...};
+                (void)dummy;
+                return;
+            }
+            precondition(x.size() == ncols && std::get<0>(y.v).size() == nrows, "SpMat::apply: incompatible sizes");
+            for (unsigned d = 0; d < queue.size(); ++d) {
+                if (part[d + 1] == part[d]) continue;
+                const val_t *xs[] = {x(I)(d).raw()...};
+                val_t *ys[] = {std::get<I>(y.v)(d).raw()...};
+                mtx[d]->mul_local_multi(queue[d], (int)N, xs, ys, alpha, append);
+            }
+        }
 
         // one (owner -> consumer) transfer
         struct pair_t { unsigned owner, consumer; size_t send_off, recv_off, count; };

@@ -16,6 +16,7 @@
 // so lane t (rows 2t, 2t+1) reads one 4-byte word per column pair and 16 bytes of
 // values per column.  Compiled with -ffp-contract=off like spmv.hip.
 #include "common.hpp"
+#include "traversal.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -36,22 +37,6 @@ constexpr int EMPTY = INT_MIN;
 typedef double double2v __attribute__((ext_vector_type(2)));
 typedef float  float2v  __attribute__((ext_vector_type(2)));
 
-struct trav8 { const int *order; int chunk, planes, plane_blocks; };
-
-__device__ __forceinline__ long long trav_block(const trav8 &t, long long nblocks) {
-    const long long b = blockIdx.x;
-    if (t.order) return t.order[b];
-    if (t.chunk > 0) {
-        const long long k = b & 7, q = b >> 3;
-        const long long i = q % t.chunk, r = q / t.chunk;
-        const long long p = r % t.planes, tile = r / t.planes;
-        const long long l = tile * 8 * t.chunk + k * t.chunk + i;
-        const long long lb = p * t.plane_blocks + l;
-        return (l < t.plane_blocks && lb < nblocks) ? lb : -1;
-    }
-    return b < nblocks ? b : -1;
-}
-
 __host__ __device__ inline long long slice_bytes(long long w, long long value_bytes) {
     return ((w + 1) / 2) * 1024 + w * S8_ROWS * value_bytes;
 }
@@ -66,13 +51,13 @@ __global__ __launch_bounds__(256)
 void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
         const char *__restrict__ buf, const int *__restrict__ deltas,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, trav8 trav)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
 {
     __shared__ int s_delta[256];
     s_delta[threadIdx.x] = deltas[threadIdx.x];
     __syncthreads();
 
-    const long long s = trav_block(trav, nslices);
+    const long long s = traversal_block(trav, nslices);
     if (s < 0) return;
     const int t = threadIdx.x;
     const long long i = s * S8_ROWS + 2 * t;
@@ -292,8 +277,8 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
     const bool ordered = tr && tr->grid_blocks > 0;
     const long long grid = ordered ? tr->grid_blocks : ns;
-    trav8 t8 = {nullptr, 0, 0, 0};
-    if (ordered) t8 = trav8{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
+    trav_dev t8 = {nullptr, 0, 0, 0};
+    if (ordered) t8 = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
 #define CASE(W) case W: sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8); break;

@@ -13,6 +13,7 @@
 // built without FMA, so results are bit-identical to the oracle, not merely
 // within the stated 1e-10 tolerance.
 #include "common.hpp"
+#include "traversal.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -67,25 +68,6 @@ __device__ __forceinline__ long long logical_block(long long nblocks) {
         return lb;     // may be >= nblocks for the ragged tail: caller checks
     }
     return b;
-}
-
-// Traversal: which row-block a workgroup processes (include/vexhip.h
-// vexhip_traversal).  Strip order is pure arithmetic -- no dependent load at
-// workgroup start; an explicit map is one scalar load.
-struct trav_dev { const int *order; int chunk, planes, plane_blocks; };
-
-__device__ __forceinline__ long long traversal_block(const trav_dev &t, long long nblocks) {
-    const long long b = blockIdx.x;
-    if (t.order) return t.order[b];
-    if (t.chunk > 0) {
-        const long long k = b & 7, q = b >> 3;
-        const long long i = q % t.chunk, r = q / t.chunk;
-        const long long p = r % t.planes, tile = r / t.planes;
-        const long long l = tile * 8 * t.chunk + k * t.chunk + i;
-        const long long lb = p * t.plane_blocks + l;
-        return (l < t.plane_blocks && lb < nblocks) ? lb : -1;
-    }
-    return b < nblocks ? b : -1;
 }
 
 // ---------------------------------------------------------------------------

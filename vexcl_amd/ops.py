@@ -234,6 +234,30 @@ class SlicedELL:
             ctypes.byref(self.trav) if use else None)
         return y
 
+    def mul_multi(self, xs, ys, alpha=1.0, append=False, tiled=True):
+        """ys[k] (+)= alpha * A * xs[k] for all k in ONE pass over the matrix per group of four
+        right-hand sides (`SpMat * multivector`, spmat.hpp:388-398); each ys[k] is
+        bit-identical to ``mul(xs[k], ys[k])``."""
+        if len(xs) != len(ys) or not xs:
+            raise Error("mul_multi: need as many results as right-hand sides (at least one)")
+        L = lib()
+        f64 = self.dtype == torch.float64
+        a = ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha)
+        use = bool(tiled and self.order_grid)
+        k = len(xs)
+        xp = (ctypes.c_void_p * k)(*[_p(x) for x in xs])
+        yp = (ctypes.c_void_p * k)(*[_p(y) for y in ys])
+        trav = ctypes.byref(self.trav) if use else None
+        if self.deltas is not None:
+            (L.spmm_sell8_f64_i32 if f64 else L.spmm_sell8_f32_i32)(
+                _dev(ys[0]), _stream(ys[0]), self.n, k, a, int(bool(append)), self.width, _p(self.sell), _p(self.deltas),
+                _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), xp, yp, trav)
+        else:
+            (L.spmm_sell_f64_i32 if f64 else L.spmm_sell_f32_i32)(
+                _dev(ys[0]), _stream(ys[0]), self.n, k, a, int(bool(append)), self.width, _p(self.sell),
+                _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), xp, yp, trav)
+        return ys
+
 
 class SpMat:
     """vex::SpMat<val_t, col_t, idx_t> on one GPU (spmat.hpp:56-185).
@@ -280,6 +304,18 @@ class SpMat:
         if self.hell is not None:
             return self.hell.mul(x, y, alpha, append)
         return spmv_csr(self.ptr, self.col, self.val, x, y, alpha, append)
+
+    def apply_multi(self, xs, ys, alpha=1.0, append=False):
+        """`Y = alpha * A * X` for a multivector (lists of component vectors): the SELL
+        formats read the matrix once for up to four components; other formats loop."""
+        for x in xs:
+            if x.numel() != self.m:
+                raise Error("x has %d elements, matrix has %d columns" % (x.numel(), self.m))
+        if isinstance(self.hell, SlicedELL):
+            return self.hell.mul_multi(xs, ys, alpha, append)
+        for x, y in zip(xs, ys):
+            self.apply(x, y, alpha, append)
+        return ys
 
     def __matmul__(self, x):                      # y = A * x
         y = torch.empty(self.n, dtype=x.dtype, device=x.device)
