@@ -42,6 +42,19 @@ __device__ __forceinline__ K to_ordered(K k) {
     return k;
 }
 
+// One LDS counter bump per key.  Keys with a small range have constant upper digits: a wave
+// whose (active) lanes agree on the digit adds their number once instead of serialising up to
+// 64 same-address LDS atomics.
+__device__ __forceinline__ void count_digit(unsigned *s_h, unsigned d) {
+    const unsigned long long act = __ballot(1);
+    const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+    if (__ballot(d == d0) == act) {
+        if ((int)(threadIdx.x % kWave) == __ffsll((long long)act) - 1) atomicAdd(&s_h[d0], (unsigned)__popcll(act));
+    } else {
+        atomicAdd(&s_h[d], 1u);
+    }
+}
+
 template <typename K, int MODE, bool DESC, int KPT>
 __global__ __launch_bounds__(HB)
 void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsigned nblocks, unsigned *__restrict__ table, int vec_ok)
@@ -62,12 +75,12 @@ void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsig
             vtype q = kv[v];
 #pragma unroll
             for (int j = 0; j < VN; ++j)
-                atomicAdd(&s_h[(unsigned)(to_ordered<K, MODE, DESC>(q[j]) >> shift) & (RADIX - 1)], 1u);
+                count_digit(s_h, (unsigned)(to_ordered<K, MODE, DESC>(q[j]) >> shift) & (RADIX - 1));
         }
         done = nv * VN;
     }
     for (int i = done + threadIdx.x; i < count; i += HB)
-        atomicAdd(&s_h[(unsigned)(to_ordered<K, MODE, DESC>(keys[base + i]) >> shift) & (RADIX - 1)], 1u);
+        count_digit(s_h, (unsigned)(to_ordered<K, MODE, DESC>(keys[base + i]) >> shift) & (RADIX - 1));
     __syncthreads();
     table[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
 }
@@ -77,66 +90,95 @@ template <> struct valtype<0> { typedef char type; };
 template <> struct valtype<4> { typedef unsigned type; };
 template <> struct valtype<8> { typedef unsigned long long type; };
 
-template <typename K, int MODE, bool DESC, int VB, int KPT>
-__global__ __launch_bounds__(RB)
-void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
-        const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
+// LDS of one scatter workgroup.  `raw` holds the re-ordered tile (keys, then values) -- and,
+// while the keys are being ranked (the tile is still in registers), the per-wave digit
+// match masks.
+template <typename K, int VB, int KPT>
+struct scatter_lds {
+    static constexpr int TILE = RB * KPT;
+    static constexpr int TILE_BYTES = TILE * ((int)sizeof(K) + VB);
+    static constexpr int MATCH_BYTES = RW * RADIX * 8;
+    static constexpr int RAW_WORDS = ((TILE_BYTES > MATCH_BYTES ? TILE_BYTES : MATCH_BYTES) + 7) / 8;
+    unsigned long long raw[RAW_WORDS];
+    unsigned hist[RW][RADIX];
+    unsigned dstart[RADIX];
+    unsigned gbase[RADIX];
+    unsigned wtot[RADIX / kWave];
+};
+
+// FULL: every slot of the tile holds a key (all tiles but the last): no validity masks.
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL>
+__device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const unsigned tile,
+        const K *__restrict__ keys_in, K *__restrict__ keys_out,
+        const typename valtype<VB>::type *__restrict__ vals_in, typename valtype<VB>::type *__restrict__ vals_out,
         long long n, int shift, unsigned nblocks, const unsigned *__restrict__ table)
 {
     typedef typename valtype<VB>::type VT;
     constexpr int TILE = RB * KPT;
-    const VT *vals_in = reinterpret_cast<const VT *>(vals_in_);
-    VT *vals_out = reinterpret_cast<VT *>(vals_out_);
-
-    __shared__ K s_keys[TILE];
-    __shared__ VT s_vals[VB ? TILE : 1];
-    __shared__ unsigned s_hist[RW][RADIX];
-    __shared__ unsigned s_dstart[RADIX];
-    __shared__ unsigned s_gbase[RADIX];
-    __shared__ unsigned s_wtot[RADIX / kWave];
+    K *s_keys = reinterpret_cast<K *>(L.raw);
+    VT *s_vals = reinterpret_cast<VT *>(reinterpret_cast<char *>(L.raw) + (size_t)TILE * sizeof(K));
+    unsigned long long *s_match = L.raw;
 
     const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
-    const long long base = (long long)blockIdx.x * TILE;
+    const long long base = (long long)tile * TILE;
     const long long wbase = base + (long long)wave * (kWave * KPT);
-    const int nvalid = (int)((n - base < TILE) ? (n - base) : TILE);
+    const int nvalid = FULL ? TILE : (int)(n - base);
 
-    for (int i = t; i < RW * RADIX; i += RB) (&s_hist[0][0])[i] = 0;
+    for (int i = t; i < RW * RADIX; i += RB) { (&L.hist[0][0])[i] = 0; s_match[i] = 0ull; }
 
     K key[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
-        long long i = wbase + k * kWave + lane;
-        key[k] = (i < n) ? keys_in[i] : K(0);
+        const long long i = wbase + k * kWave + lane;
+        key[k] = (FULL || i < n) ? keys_in[i] : K(0);
+    }
+    // payloads are fetched with the keys: their latency hides behind the ranking
+    VT val[VB ? KPT : 1];
+    if constexpr (VB != 0) {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const long long i = wbase + k * kWave + lane;
+            val[k] = (FULL || i < n) ? vals_in[i] : VT(0);
+        }
     }
     __syncthreads();
 
-    unsigned short rank[KPT];
+    unsigned rd[KPT];          // rank within (wave, digit) | digit << 16; ~0u = padding slot
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
-        long long i = wbase + k * kWave + lane;
-        const bool valid = i < n;
-        K ok = to_ordered<K, MODE, DESC>(key[k]);
-        unsigned d = (unsigned)(ok >> shift) & (RADIX - 1);
-        // m = the real (non-padding) lanes of this wave holding the same digit
-        unsigned long long m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1;
-            unsigned long long bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+        const bool valid = FULL || (wbase + k * kWave + lane < n);
+        const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(key[k]) >> shift) & (RADIX - 1);
+        // m = the real (non-padding) lanes of this wave holding the same digit.  Every lane ORs
+        // its bit into the wave's mask word of its digit in LDS and reads the word back (three LDS
+        // operations instead of ~45 vector instructions for eight ballots and per-lane selects --
+        // the kernel is bound by vector-instruction issue, profiles/README.md); the group's first
+        // lane clears the word for the next key.  A wave whose keys agree on the digit (small key
+        // ranges: constant upper digits) skips LDS, where it would serialise 64 same-address atomics.
+        const unsigned long long act = FULL ? ~0ull : __ballot(valid);
+        unsigned long long m = act;
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__ballot(valid && d == d0) != act) {
+            unsigned long long *word = s_match + wave * RADIX + d;
+            if (valid) atomicOr(word, 1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            m = valid ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0ull;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (m & lt_mask) == 0) __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_wave_barrier();
+        } else if (!valid) {
+            m = 0ull;
         }
-        unsigned before = __popcll(m & lt_mask);
-        unsigned cnt = __popcll(m);
-        unsigned prev = s_hist[wave][d];
+        const unsigned before = __popcll(m & lt_mask);
+        const unsigned cnt = __popcll(m);
+        const unsigned prev = L.hist[wave][d];
         __builtin_amdgcn_wave_barrier();
-        // padding lanes take no rank and no slot: tile positions 0..nvalid-1
-        // are exactly the real keys
+        // padding lanes take no rank and no slot: tile positions 0..nvalid-1 are exactly the real keys
         if (valid) {
-            if (before == 0) s_hist[wave][d] = prev + cnt;
-            rank[k] = (unsigned short)(prev + before);
+            if (before == 0) L.hist[wave][d] = prev + cnt;
+            rd[k] = (prev + before) | (d << 16);
         } else {
-            rank[k] = 0xffff;
+            rd[k] = ~0u;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -146,46 +188,81 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
     unsigned count = 0, inc = 0;
     if (t < RADIX) {
 #pragma unroll
-        for (int w = 0; w < RW; ++w) { unsigned c = s_hist[w][t]; s_hist[w][t] = count; count += c; }
+        for (int w = 0; w < RW; ++w) { unsigned c = L.hist[w][t]; L.hist[w][t] = count; count += c; }
         inc = count;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             unsigned u = __shfl_up(inc, off, 64);
             if (lane >= off) inc += u;
         }
-        if (lane == kWave - 1) s_wtot[wave] = inc;
+        if (lane == kWave - 1) L.wtot[wave] = inc;
     }
     __syncthreads();
     if (t < RADIX) {
         unsigned woff = 0;
 #pragma unroll
-        for (int w = 0; w < RADIX / kWave; ++w) if (w < wave) woff += s_wtot[w];
+        for (int w = 0; w < RADIX / kWave; ++w) if (w < wave) woff += L.wtot[w];
         unsigned dstart = woff + inc - count;
-        s_dstart[t] = dstart;
-        s_gbase[t] = table[(size_t)t * nblocks + blockIdx.x] - dstart;
+        L.dstart[t] = dstart;
+        L.gbase[t] = table[(size_t)t * nblocks + tile] - dstart;
     }
     __syncthreads();
 
     // re-order the tile in LDS
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
-        if (rank[k] != 0xffff) {
-            K ok = to_ordered<K, MODE, DESC>(key[k]);
-            unsigned d = (unsigned)(ok >> shift) & (RADIX - 1);
-            unsigned pos = s_dstart[d] + s_hist[wave][d] + rank[k];
+        if (FULL || rd[k] != ~0u) {
+            const unsigned d = rd[k] >> 16;
+            const unsigned pos = L.dstart[d] + L.hist[wave][d] + (rd[k] & 0xffffu);
             s_keys[pos] = key[k];
-            if constexpr (VB != 0) s_vals[pos] = vals_in[wbase + k * kWave + lane];
+            if constexpr (VB != 0) s_vals[pos] = val[k];
         }
     }
     __syncthreads();
 
-    for (int i = t; i < nvalid; i += RB) {
-        K kk = s_keys[i];
-        unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(kk) >> shift) & (RADIX - 1);
-        unsigned g = s_gbase[d] + (unsigned)i;
-        keys_out[g] = kk;
-        if constexpr (VB != 0) vals_out[g] = s_vals[i];
+    if constexpr (FULL) {
+#pragma unroll 4
+        for (int k = 0; k < KPT; ++k) {
+            const K kk = s_keys[t + k * RB];
+            const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(kk) >> shift) & (RADIX - 1);
+            const unsigned g = L.gbase[d] + (unsigned)(t + k * RB);
+            keys_out[g] = kk;
+            if constexpr (VB != 0) vals_out[g] = s_vals[t + k * RB];
+        }
+    } else {
+        for (int i = t; i < nvalid; i += RB) {
+            K kk = s_keys[i];
+            unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(kk) >> shift) & (RADIX - 1);
+            unsigned g = L.gbase[d] + (unsigned)i;
+            keys_out[g] = kk;
+            if constexpr (VB != 0) vals_out[g] = s_vals[i];
+        }
     }
+}
+
+// 8 waves per SIMD = two 1024-lane workgroups per CU (<= 64 VGPRs)
+// FULL = true: launched over the complete tiles (first_tile = their number); FULL = false: one
+// workgroup for the ragged last tile (first_tile = its index).
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL>
+__global__ __launch_bounds__(RB, 8)
+void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+        const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
+        long long n, int shift, unsigned nblocks, unsigned first_tile, const unsigned *__restrict__ table)
+{
+    typedef typename valtype<VB>::type VT;
+    __shared__ scatter_lds<K, VB, KPT> L;
+    unsigned tile = first_tile + blockIdx.x;
+    if constexpr (FULL) {
+        // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD ONE contiguous range of
+        // tiles.  Tiles that are neighbours in the input write neighbouring runs of every digit
+        // (a run is 24-48 elements: a fraction of a cache line at either end); on the same XCD
+        // those partial lines meet in one L2 and leave it as full lines.
+        const unsigned per = (first_tile + 7) / 8;          // FULL launches pass the number of complete tiles here
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if (tile >= first_tile) return;
+    }
+    scatter_tile<K, MODE, DESC, VB, KPT, FULL>(L, tile, keys_in, keys_out,
+            reinterpret_cast<const VT *>(vals_in_), reinterpret_cast<VT *>(vals_out_), n, shift, nblocks, table);
 }
 
 template <typename K, int VB> constexpr int kpt_for() { return keys_per_lane((int)sizeof(K), VB); }
@@ -207,8 +284,15 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
         radix_hist_kernel<K, MODE, DESC, KPT><<<nblocks, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
         VEXHIP_LAUNCH_CHECK();
         if (int rc = scan_exclusive_u32_tmp(s, table, table, tn, scan_tmp)) return rc;
-        radix_scatter_kernel<K, MODE, DESC, VB, KPT><<<nblocks, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, table);
-        VEXHIP_LAUNCH_CHECK();
+        const unsigned nfull = (unsigned)(n / TILE);
+        if (nfull) {
+            radix_scatter_kernel<K, MODE, DESC, VB, KPT, true><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            VEXHIP_LAUNCH_CHECK();
+        }
+        if (nfull < nblocks) {
+            radix_scatter_kernel<K, MODE, DESC, VB, KPT, false><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            VEXHIP_LAUNCH_CHECK();
+        }
         std::swap(src, dst);
         std::swap(vsrc, vdst);
     }
