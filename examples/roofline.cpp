@@ -89,6 +89,7 @@ int main(int argc, char **argv) {
         std::vector<vex::command_queue> q1(1, q);
         vex::vector<double> x(q1, N), y(q1, N);
         x = 1e-2 + 1e-9 * vex::element_index();
+        if (const char *rpl = std::getenv("VEXHIP_CCSR_ROWS_PER_LANE")) vexhip_spmv_ccsr_set_rows_per_lane(std::atoi(rpl));   // A/B
         y = A * x; q.finish();
         t.start(); for (int i = 0; i < reps; ++i) y = A * x; double ms = t.stop_ms() / reps;
         report("SpMatCCSR y=A*x f64 512^3 (4 B idx + x + y per row)", (double)N, 20, ms, ", \"equiv_csr_gflops\": 0");

@@ -140,6 +140,48 @@ TEST_CASE(spmv_ccsr_poisson) {                                       // spmv.cpp
     CHECK_CLOSE(sum(X * (A * X)), dot, 1e-6);
 }
 
+TEST_CASE(spmv_ccsr_irregular_operators) {                          // beyond the reference's Poisson case
+    std::vector<vex::command_queue> q1(1, ctx.queue(0));
+    // (a) 3-D 7-point operator, odd size (ragged last block); (b), (c) 1-D operators with wide, irregular offsets
+    // and three unique rows
+    for (int kind = 0; kind < 3; ++kind) {
+        size_t N; std::vector<size_t> idx, row; std::vector<int> col; std::vector<double> val;
+        if (kind == 0) {
+            const size_t n = 37; N = n * n * n;
+            row = {0, 1, 8};
+            col = {0, -(int)(n * n), -(int)n, -1, 0, 1, (int)n, (int)(n * n)};
+            val = {1, -1.5, -2.5, -3.5, 20, -4.5, -5.5, -6.5};
+            for (size_t k = 0; k < n; k++) for (size_t j = 0; j < n; j++) for (size_t i = 0; i < n; i++)
+                idx.push_back((i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1) ? 0 : 1);
+        } else {
+            N = 100003;
+            const int far = kind == 1 ? 3000 : 40000;
+            row = {0, 1, 6, 9};
+            col = {0, -far, -700, -2, 0, 5, 0, 1, far};
+            val = {1, 0.5, -0.25, 2, 3, -1, 7, 0.125, -0.75};
+            for (size_t i = 0; i < N; ++i) idx.push_back(i < (size_t)far || i + far >= N ? 0 : (i % 5 == 0 ? 2 : 1));
+        }
+        vex::SpMatCCSR<double, int> A(q1[0], N, row.size() - 1, idx.data(), row.data(), col.data(), val.data());
+        std::vector<double> x = random_vector<double>(N), y0 = random_vector<double>(N), want(N), a(N), b(N);
+        for (size_t i = 0; i < N; ++i) {
+            double s = 0;
+            for (size_t j = row[idx[i]]; j < row[idx[i] + 1]; ++j) s += val[j] * x[i + col[j]];
+            want[i] = s;
+        }
+        vex::vector<double> X(q1, x), Y(q1, N);
+        Y = A * X; vex::copy(Y, b);
+        vex::vector<double> Y2(q1, N);
+        Y2 = 1.0 * (A * X) + 0.0 * X;                                // the same product inside a fused kernel
+        vex::copy(Y2, a);
+        for (size_t i = 0; i < N; i += 5) CHECK_CLOSE(a[i] + 100, b[i] + 100, 1e-10);
+        for (size_t i = 0; i < N; i += 7) CHECK_CLOSE(b[i] + 100, want[i] + 100, 1e-10);
+        vex::copy(y0, Y);
+        Y -= 0.5 * (A * X);                                          // scaled, appended
+        vex::copy(Y, b);
+        for (size_t i = 0; i < N; i += 7) CHECK_CLOSE(b[i] + 100, y0[i] - 0.5 * want[i] + 100, 1e-10);
+    }
+}
+
 TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp:233-260
     const size_t n = 1024;
     std::vector<vex::command_queue> queue(1, ctx.queue(0));
