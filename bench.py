@@ -70,6 +70,78 @@ def read_traffic(kernel):
     return best
 
 
+ELEMENTWISE_SRC = r'''
+// the reference's fused kernel for `a = b * c + sin(d)` (SURVEY appendix A.1 shape), two elements per trip
+extern "C" __global__ void vexcl_vector_kernel(ulong n, double *prm_1, const double *prm_2, const double *prm_3, const double *prm_4) {
+  const ulong grid_size = blockDim.x * (ulong)gridDim.x;
+  for (ulong vex_i = blockDim.x * (ulong)blockIdx.x + threadIdx.x; vex_i < n; vex_i += 2 * grid_size) {
+    const bool vex_two = vex_i + grid_size < n;
+    const ulong i1 = vex_two ? vex_i + grid_size : vex_i;
+    const double r0 = ( ( prm_2[vex_i] * prm_3[vex_i] ) + sin( prm_4[vex_i] ) );
+    const double r1 = ( ( prm_2[i1] * prm_3[i1] ) + sin( prm_4[i1] ) );
+    prm_1[vex_i] = r0;
+    if (vex_two) prm_1[i1] = r1;
+  }
+}
+'''
+
+
+def secondary_rows(torch, L, ops, dev, local_rank):
+    """BASELINE.json's secondary metrics (SURVEY 8(d)): elementwise, reduce, scan, sort and the
+    multi-right-hand-side product, each timed with HIP events after a warm-up, inputs resident.
+    Reported next to the headline value; never part of it."""
+    import ctypes
+    rows = {}
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    n = 10 ** 8
+    b, c, d = (ops.fill_hash(torch.empty(n, dtype=torch.float64, device=dev), s) for s in (1, 2, 3))
+    a = torch.empty_like(b)
+    mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
+    L.module_compile(local_rank, ELEMENTWISE_SRC.encode(), b"", ctypes.byref(mod))
+    L.module_get_function(local_rank, mod, b"vexcl_vector_kernel", ctypes.byref(fn))
+    args = [ctypes.c_uint64(n)] + [ctypes.c_void_p(t.data_ptr()) for t in (a, b, c, d)]
+    arr = (ctypes.c_void_p * len(args))(*[ctypes.cast(ctypes.pointer(v), ctypes.c_void_p) for v in args])
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ms = timed(lambda: L.launch(local_rank, fn, 8 * 256, 1, 1, 256, 1, 1, 0, stream, arr), 20)
+    rows["elementwise a=b*c+sin(d) f64 n=1e8"] = {"ms": round(ms, 4), "gbps": round(32.0 * n / ms / 1e6, 1)}
+    red = ops.Reductor("SUM")
+    ms = timed(lambda: red.dot(b, c), 20)
+    rows["reduce sum(a*b) f64 n=1e8 (incl. host readback)"] = {"ms": round(ms, 4), "gbps": round(16.0 * n / ms / 1e6, 1)}
+    L.module_unload(local_rank, mod)
+    del a, b, c, d
+
+    n = 10 ** 9
+    k = ops.fill_hash(torch.empty(n, dtype=torch.int32, device=dev), 42)
+    out = torch.empty_like(k)
+    ms = timed(lambda: ops.inclusive_scan(k, out, unsigned=True), 10)
+    rows["inclusive_scan u32 n=1e9"] = {"ms": round(ms, 4), "gbps": round(8.0 * n / ms / 1e6, 1)}
+    del out
+    # sort through the raw C-ABI call on pre-allocated buffers (in place: re-filled before every repetition)
+    ktmp = torch.empty_like(k)
+    tmp = torch.empty(L.sort_tmp_bytes(3, n), dtype=torch.uint8, device=dev)
+    best = None
+    for _ in range(3):
+        ops.fill_hash(k, 42); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.sort(local_rank, stream, 3, 0, ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(ktmp.data_ptr()), 0, None, None, n,
+               ctypes.c_void_p(tmp.data_ptr()))
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1)
+        best = t if best is None else min(best, t)
+    rows["sort u32 keys n=1e9 (stable LSD radix)"] = {"ms": round(best, 3), "gkeys_per_s": round(n / best / 1e6, 1)}
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--dist", action="store_true", help="use the partitioned SpMat even on one GPU (debug)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (elementwise, reduce, scan, sort, multi-rhs)")
     args = ap.parse_args()
 
     import torch
@@ -208,6 +281,29 @@ def main():
         }
         if world > 1:
             out["config"]["exchange_bytes_per_rank"] = A.exchange_bytes()
+        if world == 1 and not args.dist and not args.no_secondary:
+            try:
+                sec = {}
+                if fmt in ("sell", "sell8"):        # Y = A * X, X a multivector<double, 4>: one pass over the matrix
+                    xs = [ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 100 + k) for k in range(4)]
+                    ys = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(4)]
+                    A.apply_multi(xs, ys); torch.cuda.synchronize()
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    for _ in range(10):
+                        A.apply_multi(xs, ys)
+                    ev1.record(); torch.cuda.synchronize()
+                    t4 = ev0.elapsed_time(ev1) / 10
+                    sec["SpMV 4 right-hand sides (SpMat * multivector<double,4>), %d^3" % n] = {
+                        "ms": round(t4, 4), "gflops": round(8.0 * nnz_total / t4 / 1e6, 1)}
+                    del xs, ys
+                hell = None
+                del A
+                torch.cuda.empty_cache()
+                sec.update(secondary_rows(torch, L, ops, dev, local_rank))
+                out["secondary"] = sec
+            except Exception as e:                   # the headline must not depend on the secondary rows
+                out["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_seconds)
         print(json.dumps(out), flush=True)
