@@ -124,6 +124,62 @@ def test_distributed_spmv_gloo(world, case, oracle):
     assert list(out) == [1] * world
 
 
+def _scan_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from vexcl_amd.distributed import DistScan, partition
+
+        class HostScan:                                 # test double for the device scan of one segment
+            def inclusive_scan(self, inp, out):
+                out.copy_(torch.cumsum(inp, 0).to(inp.dtype)); return out
+            def exclusive_scan(self, inp, out, init):
+                c = torch.cumsum(inp, 0).to(inp.dtype)
+                res = torch.empty_like(inp)
+                if inp.numel():
+                    res[0] = init
+                    res[1:] = c[:-1] + init
+                out.copy_(res); return out
+
+        ok = True
+        for n in (0, 5, 1000, 4099):
+            rng = np.random.default_rng(50 + n)
+            x = rng.integers(-2**31, 2**31 - 1, size=n, dtype=np.int64).astype(np.int32)     # wraps mod 2^32
+            part = partition(n, world)
+            seg = torch.from_numpy(x[part[rank]:part[rank + 1]].copy())
+            with np.errstate(over="ignore"):
+                incl = np.cumsum(x.astype(np.int64)).astype(np.int32)
+                excl = (np.concatenate([[0], np.cumsum(x.astype(np.int64))[:-1]]) + 7).astype(np.int32) if n else incl
+            scan = DistScan(local=HostScan())
+            got = scan(seg.clone())
+            ok = ok and np.array_equal(got.numpy(), incl[part[rank]:part[rank + 1]])
+            buf = seg.clone()
+            got = scan(buf, buf, exclusive=True, init=7)                # in place
+            ok = ok and np.array_equal(got.numpy(), excl[part[rank]:part[rank + 1]])
+            xf = oracle.random_f64(60 + n, n)
+            segf = torch.from_numpy(xf[part[rank]:part[rank + 1]].copy())
+            gotf = scan(segf, exclusive=False)
+            ok = ok and np.allclose(gotf.numpy(), np.cumsum(xf)[part[rank]:part[rank + 1]], rtol=1e-12, atol=1e-12)
+        out[rank] = 1 if ok else 0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_scan_gloo(world, oracle):
+    ctx = mp.get_context("spawn")
+    out = ctx.Array("i", [0] * world)
+    port = _free_port()
+    procs = [ctx.Process(target=_scan_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert list(out) == [1] * world
+
+
 def test_device_kernels_refuse_cpu_tensors(built_lib):
     from vexcl_amd import ops, Error
     t = torch.zeros(4, dtype=torch.float64)

@@ -220,3 +220,54 @@ class DistReductor:
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(r, op=self._OPS[self.op], group=self.group)
         return r.cpu()[0].item()
+
+
+class DistScan:
+    """vex::inclusive_scan / vex::exclusive_scan of a vector partitioned across the ranks of a job.
+
+    The reference scans every device's partition and then adds, on the host, the sum of
+    the preceding partitions to each of them (scan.hpp:445-457, :489-506).  Here each rank
+    scans its segment on its GPU (vexcl_amd.ops: single-pass look-back scan for integers),
+    the ranks all-gather ONE element -- their segment's total -- over RCCL, and each rank
+    adds the sum of the totals before it with one elementwise pass.  Integer scans wrap
+    mod 2^k exactly as the single-device scan does (the carry is added in the same type).
+    """
+
+    def __init__(self, group=None, local=None):
+        self.group = group
+        self.local = local          # test double: object with inclusive_scan(inp, out) / exclusive_scan(inp, out, init)
+
+    def _scan(self, inp, out, exclusive, init):
+        if self.local is not None:
+            return self.local.exclusive_scan(inp, out, init) if exclusive else self.local.inclusive_scan(inp, out)
+        from . import ops
+        return ops.exclusive_scan(inp, out, init) if exclusive else ops.inclusive_scan(inp, out)
+
+    def __call__(self, inp, out=None, exclusive=False, init=0):
+        if out is None:
+            out = torch.empty_like(inp)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        n = inp.numel()
+        # the segment total must be taken before an in-place scan overwrites the input
+        last_in = inp[-1:].clone() if (n and exclusive) else None
+        self._scan(inp, out, exclusive, init if rank == 0 else 0)
+        if world == 1:
+            return out
+        if n:
+            total = out[-1:].clone()
+            if exclusive:
+                total = total + last_in
+                if rank == 0:
+                    total = total - init       # init belongs to the carry of every later rank once, added below
+        else:
+            total = torch.zeros(1, dtype=inp.dtype, device=inp.device)
+        totals = [torch.empty_like(total) for _ in range(world)]
+        dist.all_gather(totals, total, group=self.group)
+        if rank > 0:
+            carry = torch.stack(totals[:rank]).sum(0).to(inp.dtype)
+            if exclusive:
+                carry = carry + init
+            if n:
+                out.add_(carry)
+        return out
