@@ -206,6 +206,31 @@ TEST_CASE(by_key_kernels_compile) {                                   // scan_by
     backend::check_sources(s);
 }
 
+TEST_CASE(cast_and_temporaries) {                                    // cast.hpp / temporary.hpp
+    vector<double> x, y;
+    std::string s = src_of<assign::SET>(y, cast<float>(x) * 2 + cast<double>(5));
+    CHECK(has(s, "( (float)( prm_2[idx] ) )") && has(s, "( (double)( prm_4 ) )"));
+    backend::check_sources(s);
+
+    auto t1 = make_temp<1>(log(x));
+    auto t2 = make_temp<2>(t1 + sin(x));
+    s = src_of<assign::SET>(y, t1 * t2 + t1);
+    // declared once per element block, inner temporary first; its terminal is one parameter
+    CHECK_EQUAL(count(s, "double temp_1 = log( prm_temp_1_1[idx] );"), size_t(2));
+    CHECK_EQUAL(count(s, "double temp_2 = ( temp_1 + sin( prm_temp_2_1[idx] ) );"), size_t(2));
+    CHECK(s.find("double temp_1 = ") < s.find("double temp_2 = "));
+    CHECK(has(s, "= ( ( temp_1 * temp_2 ) + temp_1 );"));
+    CHECK_EQUAL(count(s, "double * prm_temp_1_1"), size_t(1));
+    backend::check_sources(s);
+
+    multivector<double, 2> X, Y;
+    auto tm = make_temp<7, double>(tan(X));
+    s = multi_src<assign::SET>(Y, tm * tm, std::make_index_sequence<2>());
+    // one temporary per component: names 2^20 + 64 * tag + component
+    CHECK(has(s, "double temp_1049024 = tan( prm_temp_1049024_1[idx] );") && has(s, "double buf_2 = ( temp_1049025 * temp_1049025 );"));
+    backend::check_sources(s);
+}
+
 TEST_CASE(partition_and_util) {
     CHECK_EQUAL(alignup(17), size_t(32));
     CHECK_EQUAL(nextpow2(1000), size_t(1024));

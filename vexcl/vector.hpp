@@ -225,6 +225,21 @@ class vector : public detail::expression_base {
         const std::vector<size_t> &partition() const { return part; }
         const std::vector<backend::command_queue> &queue_list() const { return queue; }
 
+        /// The same device memory seen as elements of another type (vector.hpp:472-494;
+        /// tests/reinterpret.cpp): sizes scale with sizeof(T) / sizeof(U), partitions stay in place.
+        template <class U>
+        vector<U> reinterpret() const {
+            vector<U> r;
+            r.queue = queue;
+            r.part.resize(part.size());
+            for (size_t d = 0; d < part.size(); ++d) {
+                precondition(part[d] * sizeof(T) % sizeof(U) == 0, "reinterpret: partition size is not a multiple of the new element size");
+                r.part[d] = part[d] * sizeof(T) / sizeof(U);
+            }
+            for (const auto &b : buf) r.buf.push_back(b.template reinterpret<U>());
+            return r;
+        }
+
         typename backend::device_vector<T>::mapped_array map(unsigned d = 0) { return buf[d].map(queue[d]); }
         typename backend::device_vector<T>::mapped_array map(unsigned d = 0) const { return buf[d].map(queue[d]); }
 
@@ -274,6 +289,7 @@ class vector : public detail::expression_base {
         void get_props(detail::prop_context &p) const { expr_ref_type(*this).get_props(p); }
 
     private:
+        template <class U> friend class vector;
         std::vector<backend::command_queue> queue;
         std::vector<size_t> part;
         std::vector<backend::device_vector<T>> buf;
