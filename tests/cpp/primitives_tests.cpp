@@ -90,6 +90,9 @@ TEST_CASE(stencil_convolution) {
     check_stencil(1024, 64, 23);
     check_stencil(1 << 20, 33, 16);
     check_stencil(5000, 9000, 4500);                                 // wider than LDS: direct-read kernel
+    check_stencil(1001, 5, 2);                                       // sizes that are not multiples of the 4 outputs a lane folds
+    check_stencil(4099, 21, 10);
+    check_stencil(2050, 2, 1);
 }
 
 TEST_CASE(stencil_small_vector_and_two_stencils) {                   // stencil.cpp:59-110

@@ -3,8 +3,14 @@
 // where X reads the local segment, the halo buffer of the neighbouring devices,
 // or -- at the ends of the whole vector -- the edge element (stencil.hpp:264-290
 // `read_x`).  The one place the expression path uses LDS: a workgroup stages its
-// 1024 outputs' inputs (+ halo) and the stencil itself in LDS, then every lane
-// folds its four outputs from LDS; each x element is read from HBM once.
+// 1024 outputs' inputs (+ halo) and the stencil itself in LDS; each x element is read
+// from HBM once.  A lane then folds FOUR CONSECUTIVE outputs with a sliding window
+// of four inputs in registers: one new LDS read of x and one (broadcast) read of the
+// stencil per tap serve four outputs -- 45 LDS reads per four outputs of a 21-point
+// stencil instead of 168; the first version was bound by exactly that LDS traffic
+// (33.6 GB at 69 TB/s aggregate = 0.49 ms; measured 0.46).  Element i lives at
+// i + i/16 in LDS: with lanes 32 bytes apart the skew spreads a wave's 8-byte reads
+// over all banks.
 #include "common.hpp"
 
 #include <algorithm>
@@ -25,6 +31,12 @@ __device__ __forceinline__ T read_x(long long g, long long n, int has_left, int 
     return has_right ? xrem[lhalo + (g - n)] : xloc[n - 1];
 }
 
+__device__ __forceinline__ int skew(int i) { return i + (i >> 4); }
+__host__ __device__ inline size_t lds_elems(int lhalo, int rhalo) {
+    const size_t span = (size_t)CTILE + lhalo + rhalo + CI;
+    return (size_t)(lhalo + rhalo + 1) + span + span / 16 + 2;
+}
+
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(CB)
 void stencil_conv_kernel(long long n, int has_left, int has_right, int lhalo, int rhalo,
@@ -39,19 +51,36 @@ void stencil_conv_kernel(long long n, int has_left, int has_right, int lhalo, in
         T *X = S + width;
         for (int j = threadIdx.x; j < width; j += CB) S[j] = s[j];
         const int span = CTILE + lhalo + rhalo;
-        for (int j = threadIdx.x; j < span; j += CB) {
+        for (int j = threadIdx.x; j < span + CI; j += CB) {       // + CI: the window reads a few elements past the last tap
             long long g = g0 - lhalo + j;
-            X[j] = (g < n + rhalo) ? read_x<T>(g, n, has_left, has_right, lhalo, xloc, xrem) : T(0);
+            X[skew(j)] = (j < span && g < n + rhalo) ? read_x<T>(g, n, has_left, has_right, lhalo, xloc, xrem) : T(0);
         }
         __syncthreads();
+        const int o = CI * threadIdx.x;                    // this lane's first output within the tile
+        T w0 = X[skew(o)], w1 = X[skew(o + 1)], w2 = X[skew(o + 2)], w3 = X[skew(o + 3)];
+        T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int j = 0; j < width; ++j) {                  // taps in ascending order for every output
+            const T sj = S[j];
+            a0 += sj * w0; a1 += sj * w1; a2 += sj * w2; a3 += sj * w3;
+            w0 = w1; w1 = w2; w2 = w3; w3 = X[skew(o + j + 4)];
+        }
+        const T acc[CI] = {a0, a1, a2, a3};
+        const long long i0 = g0 + o;
+        typedef T v2 __attribute__((ext_vector_type(2)));
+        if (i0 + CI <= n && (reinterpret_cast<unsigned long long>(y) & (2 * sizeof(T) - 1)) == 0) {
+            v2 *yp = reinterpret_cast<v2 *>(y + i0);           // i0 is a multiple of 4: two aligned vector stores
+            v2 lo, hi;
+            lo.x = alpha * acc[0]; lo.y = alpha * acc[1]; hi.x = alpha * acc[2]; hi.y = alpha * acc[3];
+            if (beta != T(0)) {
+                const v2 ol = yp[0], oh = yp[1];
+                lo.x = beta * ol.x + lo.x; lo.y = beta * ol.y + lo.y; hi.x = beta * oh.x + hi.x; hi.y = beta * oh.y + hi.y;
+            }
+            yp[0] = lo; yp[1] = hi;
+        } else {
 #pragma unroll
-        for (int k = 0; k < CI; ++k) {
-            const int o = threadIdx.x + k * CB;
-            const long long i = g0 + o;
-            if (i < n) {
-                T sum = 0;
-                for (int j = 0; j < width; ++j) sum += S[j] * X[o + j];
-                y[i] = (beta != T(0)) ? beta * y[i] + alpha * sum : alpha * sum;
+            for (int k = 0; k < CI; ++k) {
+                const long long i = i0 + k;
+                if (i < n) y[i] = (beta != T(0)) ? beta * y[i] + alpha * acc[k] : alpha * acc[k];
             }
         }
     } else {
@@ -78,7 +107,7 @@ int conv(int dev, void *stream, int64_t n, int has_left, int has_right, int lhal
     hipStream_t st = as_stream(stream);
     const int64_t grid = (n + CTILE - 1) / CTILE;
     VEXHIP_REQUIRE(grid < (1ll << 31), "vector too large for one launch");
-    const size_t lds = sizeof(T) * (size_t)(CTILE + 2 * (lhalo + rhalo) + 1);
+    const size_t lds = sizeof(T) * lds_elems(lhalo, rhalo);
     if (lds <= 64 * 1024)
         stencil_conv_kernel<T, true><<<(unsigned)grid, CB, lds, st>>>(n, has_left, has_right, lhalo, rhalo, s, x, xrem, y, beta, alpha);
     else   // stencil wider than LDS: every lane reads x directly (the reference's slow_conv)
