@@ -36,6 +36,7 @@ void eval(const Expr &expr_, const std::vector<backend::command_queue> &queue, c
         krn.push_arg(psize);
         arg_context a(krn, d, part[d]);
         expr.set_args(a);
+        krn.config_streaming(queue[d], psize);
         krn(queue[d]);
     }
 }

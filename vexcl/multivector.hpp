@@ -152,6 +152,7 @@ void assign_multiexpression(const std::tuple<L...> &lhs, const std::tuple<R...> 
         arg_context a(krn, d, part[d]);
         tuple_for_each(lhs, [&a](const auto &n, size_t) { n.set_args(a); });
         tuple_for_each(rhs, [&a](const auto &n, size_t) { n.set_args(a); });
+        krn.config_streaming(queue[d], psize, 1);
         krn(queue[d]);
     }
 }

@@ -464,6 +464,7 @@ void assign_expression(const LHS &lhs, const RHS &rhs,
         arg_context a(krn, d, part[d]);
         lhs.set_args(a);
         rhs.set_args(a);
+        krn.config_streaming(queue[d], psize);
         krn(queue[d]);
     }
 }
