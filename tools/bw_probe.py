@@ -68,6 +68,16 @@ NOLOOP(triad8u1, 1) NOLOOP(triad8u2, 2) NOLOOP(triad8u4, 4) NOLOOP(triad8u8, 8)
   _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; r[k] = i < n ? b[i] * c[i] + sin(d[i]) : 0; } \
   _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; if (i < n) a[i] = r[k]; } }
 NOLOOPS(sin8u2, 2) NOLOOPS(sin8u4, 4)
+#define NOLOOPNT(NAME, U) extern "C" __global__ void NAME(ulong n, double *a, const double *b, const double *c, const double *d) { \
+  const ulong base = (ulong)blockIdx.x * (256 * U) + threadIdx.x; double r[U]; \
+  _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; r[k] = i < n ? __builtin_nontemporal_load(b + i) * __builtin_nontemporal_load(c + i) + __builtin_nontemporal_load(d + i) : 0; } \
+  _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; if (i < n) __builtin_nontemporal_store(r[k], a + i); } }
+NOLOOPNT(triad8u2nt, 2)
+#define NOLOOPNTS(NAME, U) extern "C" __global__ void NAME(ulong n, double *a, const double *b, const double *c, const double *d) { \
+  const ulong base = (ulong)blockIdx.x * (256 * U) + threadIdx.x; double r[U]; \
+  _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; r[k] = i < n ? b[i] * c[i] + d[i] : 0; } \
+  _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; if (i < n) __builtin_nontemporal_store(r[k], a + i); } }
+NOLOOPNTS(triad8u2nts, 2)
 '''
 mod = ctypes.c_void_p(); L.module_compile(0, SRC.encode(), b"", ctypes.byref(mod))
 n = 100_000_000
@@ -97,3 +107,7 @@ for g in (2048, 8192, 32768, 131072):
     bench("triad8", g, 4, 32); bench("triad8two", g, 4, 32)
 for name, u in (("triad8u1", 1), ("triad8u2", 2), ("triad8u4", 4), ("triad8u8", 8), ("sin8u2", 2), ("sin8u4", 4)):
     bench(name, (n + 256 * u - 1) // (256 * u), 4, 32)
+
+for rep in range(2):
+    for name, u in (("triad8u2", 2), ("triad8u2nt", 2), ("triad8u2nts", 2)):
+        bench(name, (n + 256 * u - 1) // (256 * u), 4, 32)

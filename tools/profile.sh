@@ -5,7 +5,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline $BENCH_ARGS"
+CMD="python $ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary $BENCH_ARGS"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $CMD > $OUT/trace.log 2>&1
 echo "trace exit $?"
 CMD2="python $ROOT/tools/pmc_target.py"
