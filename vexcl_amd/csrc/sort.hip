@@ -72,7 +72,7 @@ void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsig
         const int nv = count / VN;
         const vtype *kv = reinterpret_cast<const vtype *>(keys + base);
         for (int v = threadIdx.x; v < nv; v += HB) {
-            vtype q = kv[v];
+            vtype q = __builtin_nontemporal_load(kv + v);
 #pragma unroll
             for (int j = 0; j < VN; ++j)
                 count_digit(s_h, (unsigned)(to_ordered<K, MODE, DESC>(q[j]) >> shift) & (RADIX - 1));
@@ -130,7 +130,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const long long i = wbase + k * kWave + lane;
-        key[k] = (FULL || i < n) ? keys_in[i] : K(0);
+        key[k] = (FULL || i < n) ? __builtin_nontemporal_load(keys_in + i) : K(0);      // read once per pass
     }
     // payloads are fetched with the keys: their latency hides behind the ranking
     VT val[VB ? KPT : 1];
@@ -138,7 +138,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const long long i = wbase + k * kWave + lane;
-            val[k] = (FULL || i < n) ? vals_in[i] : VT(0);
+            val[k] = (FULL || i < n) ? __builtin_nontemporal_load(vals_in + i) : VT(0);
         }
     }
     __syncthreads();
