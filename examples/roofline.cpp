@@ -118,5 +118,20 @@ int main(int argc, char **argv) {
         size_t inv = bad(vex::if_else(vex::permutation(vex::element_index(0, n - 1) + 1)(z) < vex::permutation(vex::element_index(0, n - 1))(z), 1, 0));
         std::printf("{\"row\": \"sort check\", \"inversions\": %zu}\n", inv);
     }
+    {   // by-key primitives: runs of ~64 equal keys, 1e8 (int key, double value) pairs
+        const size_t n = 100000000;
+        std::vector<vex::command_queue> q1(1, q);
+        vex::vector<int> keys(q1, n), okeys;
+        vex::vector<double> vals(q1, n), out(q1, n), ovals;
+        keys = vex::element_index() / 64;
+        vals = 1e-3 * (vex::element_index() % 1000);
+        vex::inclusive_scan_by_key(keys, vals, out); q.finish();
+        t.start(); for (int i = 0; i < 5; ++i) vex::inclusive_scan_by_key(keys, vals, out); double ms = t.stop_ms() / 5;
+        report("inclusive_scan_by_key (int, f64) n=1e8: 2 x (4+8) B read + 8 B written", (double)n, 20, ms);
+        int runs = vex::reduce_by_key(keys, vals, okeys, ovals); q.finish();
+        t.start(); for (int i = 0; i < 5; ++i) runs = vex::reduce_by_key(keys, vals, okeys, ovals); ms = t.stop_ms() / 5;
+        report("reduce_by_key (int, f64) n=1e8 (incl. run-count readback and output allocation)", (double)n, 12, ms);
+        std::printf("{\"row\": \"reduce_by_key runs\", \"runs\": %d}\n", runs);
+    }
     return 0;
 }

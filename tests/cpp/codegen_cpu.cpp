@@ -196,8 +196,8 @@ TEST_CASE(by_key_kernels_compile) {                                   // scan_by
     backend::command_queue q;
     for (scan_mode m : {INCLUSIVE, EXCLUSIVE, REDUCE}) {
         std::string s = source<double, decltype(keys_equal), decltype(dplus)>(q, {"int", "long"}, m);
-        CHECK(has(s, "vexcl_sbk_reduce") && has(s, "vexcl_sbk_carry") && has(s, "vexcl_sbk_scan"));
-        CHECK(has(s, "keys_equal(p0, p1, k0, k1)") && has(s, "dplus(a.v, b.v)"));
+        CHECK(has(s, "vexcl_sbk_reduce") && has(s, "vexcl_sbk_carry_local") && has(s, "vexcl_sbk_carry(") && has(s, "vexcl_sbk_scan"));
+        CHECK(has(s, "keys_equal(pk0, pk1, k0[j], k1[j])") && has(s, "dplus(a.v, b.v)"));
         CHECK_EQUAL(has(s, "okey1[fin.c - 1] = key1[i];"), m == REDUCE);
         backend::check_sources(s);
     }

@@ -78,6 +78,27 @@ NOLOOPNT(triad8u2nt, 2)
   _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; r[k] = i < n ? b[i] * c[i] + d[i] : 0; } \
   _Pragma("unroll") for (int k = 0; k < U; ++k) { const ulong i = base + k * 256; if (i < n) __builtin_nontemporal_store(r[k], a + i); } }
 NOLOOPNTS(triad8u2nts, 2)
+extern "C" __global__ void dot8(ulong n, double *a, const double *b, const double *c) {
+  double s = 0;
+  for (ulong i = blockDim.x * (ulong)blockIdx.x + threadIdx.x, g = blockDim.x * (ulong)gridDim.x; i < n; i += g) s += b[i] * c[i];
+  if (s == 12345.678) a[0] = s;
+}
+extern "C" __global__ void dot8x2(ulong n, double *a, const double *b, const double *c) {
+  double s = 0; const ulong g = blockDim.x * (ulong)gridDim.x;
+  for (ulong i = blockDim.x * (ulong)blockIdx.x + threadIdx.x; i < n; i += 2 * g) {
+    const ulong j = i + g < n ? i + g : i; const double w = i + g < n ? 1.0 : 0.0;
+    double v0 = b[i] * c[i], v1 = b[j] * c[j]; s += v0; s += w * v1; }
+  if (s == 12345.678) a[0] = s;
+}
+extern "C" __global__ void dot8x4(ulong n, double *a, const double *b, const double *c) {
+  double s = 0; const ulong g = blockDim.x * (ulong)gridDim.x;
+  for (ulong i = blockDim.x * (ulong)blockIdx.x + threadIdx.x; i < n; i += 4 * g) {
+    double v[4];
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) { const ulong j = i + k * g; v[k] = j < n ? b[j] * c[j] : 0.0; }
+    s += v[0]; s += v[1]; s += v[2]; s += v[3]; }
+  if (s == 12345.678) a[0] = s;
+}
 '''
 mod = ctypes.c_void_p(); L.module_compile(0, SRC.encode(), b"", ctypes.byref(mod))
 n = 100_000_000
@@ -111,3 +132,6 @@ for name, u in (("triad8u1", 1), ("triad8u2", 2), ("triad8u4", 4), ("triad8u8", 
 for rep in range(2):
     for name, u in (("triad8u2", 2), ("triad8u2nt", 2), ("triad8u2nts", 2)):
         bench(name, (n + 256 * u - 1) // (256 * u), 4, 32)
+
+for g in (2048, 4096, 8192, 32768):
+    bench("dot8", g, 3, 16); bench("dot8x2", g, 3, 16); bench("dot8x4", g, 3, 16)

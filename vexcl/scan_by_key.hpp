@@ -11,14 +11,17 @@
 // geometry is fixed (it does not depend on the device or on n), so results are
 // reproducible run to run; floating point sums are associated as a tree, not as
 // the serial loop would, and differ from it by rounding only:
-//   1. vexcl_sbk_reduce: one aggregate per tile of 4 waves x VT x 64 elements;
-//   2. vexcl_sbk_carry : ONE workgroup turns the aggregates into carries-in;
+//   1. vexcl_sbk_reduce: one aggregate per tile of 4 waves x 2 rows x 256 elements;
+//   2. vexcl_sbk_carry_local + vexcl_sbk_carry: the aggregates become carries-in
+//      (groups of 1024 tiles scanned in parallel, then ONE workgroup over the groups);
 //   3. vexcl_sbk_scan  : re-reads the tile, adds its carry, stores the result.
-// Inside a wave everything is wave-64 shuffles (no LDS ping-pong as in the
-// reference's 2-element-per-thread Hillis-Steele, scan_by_key.hpp:200-252): a
-// wave owns VT consecutive rows of 64 elements, all loads and stores are
-// coalesced, the head flag of element i comes from the neighbour lane (one extra
-// load per row for lane 0).  Keys may be a single vector or a std::tie of
+// A lane owns FOUR CONSECUTIVE elements: it folds them serially (head flags come
+// from its own previous element, the first one from the neighbour lane -- one
+// extra load per row for lane 0), and the wave scans ONE aggregate per lane with
+// wave-64 shuffles -- a quarter of the shuffle work of one element per lane (the
+// first version, 1.30 ms per 1e8 (int, double) pairs, was bound by it), and no LDS
+// ping-pong as in the reference's two-element-per-thread Hillis-Steele
+// (scan_by_key.hpp:200-252).  A wave's 256-element row is contiguous in memory.  Keys may be a single vector or a std::tie of
 // vectors (the reference takes boost::fusion::vector_tie); comparison and
 // operator are VEX_FUNCTIONs pasted into the generated source.
 #include <sstream>
@@ -32,9 +35,10 @@ namespace sbk {
 
 enum scan_mode { INCLUSIVE = 0, EXCLUSIVE = 1, REDUCE = 2 };
 
-static const int VT = 8;            // rows of 64 elements per wave
+static const int ITEMS = 4;         // consecutive elements per lane
+static const int ROWS = 2;          // rows of 64 x ITEMS elements per wave
 static const int WAVES = 4;         // waves per workgroup
-static const int TILE = VT * WAVES * 64;
+static const int TILE = ROWS * ITEMS * WAVES * 64;
 
 // ---- key sequences: one vector or a tuple of vector references -----------------
 template <class T> struct key_seq;
@@ -57,7 +61,7 @@ std::vector<std::string> key_types(std::index_sequence<I...>) {
 }
 
 struct kernels {
-    backend::kernel reduce, carry, scan;
+    backend::kernel reduce, carry_local, carry, scan;
 };
 
 /// Source of the three kernels for the given key types, value type, functions and mode.
@@ -68,7 +72,7 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
     const std::string T = type_name<V>();
     const size_t nk = K.size();
     std::ostringstream s;
-    s << "\n#define VT " << VT << "\n#define WAVES " << WAVES << "\n";
+    s << "\n#define ROWS " << ROWS << "\n#define ITEMS " << ITEMS << "\n#define WAVES " << WAVES << "\n";
     s << "typedef " << T << " val_t;\n"
          "struct sbk_t { int c; int f; val_t v; };\n"
          "__device__ inline sbk_t sbk_empty() { sbk_t r; r.c = 0; r.f = 0; r.v = val_t(); return r; }\n"
@@ -85,7 +89,6 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
          "  for (int o = 1; o < 64; o <<= 1) { sbk_t y = sbk_up(x, o); if (lane >= o) x = sbk_combine(y, x); }\n"
          "  return x;\n"
          "}\n";
-    // per-wave scan of its VT rows: y[j] = inclusive prefix relative to the wave's first element
     auto key_params = [&](bool trailing_comma) {
         std::ostringstream p;
         for (size_t k = 0; k < nk; ++k) p << "const " << K[k] << " *key" << k << (k + 1 < nk || trailing_comma ? ", " : "");
@@ -96,28 +99,46 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         for (size_t k = 0; k < nk; ++k) p << "key" << k << ", ";
         return p.str();
     };
+    // One wave, ROWS rows of 64 x ITEMS consecutive elements.  A lane folds its ITEMS consecutive
+    // elements serially (head flags against its own previous element: no shuffle), the wave scans
+    // ONE aggregate per lane, and the prefix comes back into the lane's elements:
+    // y[r * ITEMS + j] = inclusive prefix of element (r, lane, j) relative to the wave's first element.
     s << "__device__ inline sbk_t sbk_wave_tile(ulong n, ulong wbase, int lane, " << key_params(true) << "const val_t *vals, sbk_t *y) {\n"
          "  sbk_t carry = sbk_empty();\n"
          "  #pragma unroll\n"
-         "  for (int j = 0; j < VT; ++j) {\n"
-         "    const ulong i = wbase + j * 64 + lane;\n"
-         "    const bool in = i < n;\n";
+         "  for (int r = 0; r < ROWS; ++r) {\n"
+         "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n";
     for (size_t k = 0; k < nk; ++k) {
-        s << "    " << K[k] << " k" << k << " = in ? key" << k << "[i] : (" << K[k] << ")0;\n"
-          << "    " << K[k] << " p" << k << " = __shfl_up(k" << k << ", 1, 64);\n"
-          << "    if (lane == 0 && in && i > 0) p" << k << " = key" << k << "[i - 1];\n";
+        s << "    " << K[k] << " k" << k << "[ITEMS];\n"
+          << "    #pragma unroll\n"
+          << "    for (int j = 0; j < ITEMS; ++j) k" << k << "[j] = i0 + j < n ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n"
+          << "    " << K[k] << " p" << k << " = __shfl_up(k" << k << "[ITEMS - 1], 1, 64);\n"
+          << "    if (lane == 0 && i0 > 0 && i0 < n) p" << k << " = key" << k << "[i0 - 1];\n";
     }
-    s << "    sbk_t x = sbk_empty();\n"
-         "    if (in) {\n"
-         "      const bool head = (i == 0) || !" << Comp::name() << "(";
-    for (size_t k = 0; k < nk; ++k) s << "p" << k << ", ";
-    for (size_t k = 0; k < nk; ++k) s << "k" << k << (k + 1 < nk ? ", " : "");
+    s << "    sbk_t t[ITEMS];\n"
+         "    sbk_t acc = sbk_empty();\n"
+         "    #pragma unroll\n"
+         "    for (int j = 0; j < ITEMS; ++j) {\n"
+         "      sbk_t x = sbk_empty();\n"
+         "      if (i0 + j < n) {\n";
+    for (size_t k = 0; k < nk; ++k)
+        s << "        const " << K[k] << " pk" << k << " = j ? k" << k << "[j ? j - 1 : 0] : p" << k << ";\n";
+    s << "        const bool head = (i0 + j == 0) || !" << Comp::name() << "(";
+    for (size_t k = 0; k < nk; ++k) s << "pk" << k << ", ";
+    for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j]" << (k + 1 < nk ? ", " : "");
     s << ");\n"
-         "      x.c = head; x.f = 2 | (int)head; x.v = vals[i];\n"
+         "        x.c = head; x.f = 2 | (int)head; x.v = vals[i0 + j];\n"
+         "      }\n"
+         "      acc = sbk_combine(acc, x);\n"
+         "      t[j] = acc;\n"
          "    }\n"
-         "    x = sbk_combine(carry, sbk_wave_scan(x, lane));\n"
-         "    y[j] = x;\n"
-         "    carry = sbk_from(x, 63);\n"
+         "    const sbk_t incl = sbk_wave_scan(acc, lane);\n"
+         "    sbk_t pre = sbk_up(incl, 1);\n"
+         "    if (lane == 0) pre = sbk_empty();\n"
+         "    pre = sbk_combine(carry, pre);\n"
+         "    #pragma unroll\n"
+         "    for (int j = 0; j < ITEMS; ++j) y[r * ITEMS + j] = sbk_combine(pre, t[j]);\n"
+         "    carry = sbk_combine(carry, sbk_from(incl, 63));\n"
          "  }\n"
          "  return carry;\n"
          "}\n";
@@ -126,8 +147,8 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
       << "const val_t *vals, int *tc, int *tf, val_t *tv) {\n"
          "  __shared__ sbk_t agg[WAVES];\n"
          "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
-         "  sbk_t y[VT];\n"
-         "  sbk_t a = sbk_wave_tile(n, ((ulong)blockIdx.x * WAVES + wave) * (VT * 64), lane, " << key_args() << "vals, y);\n"
+         "  sbk_t y[ROWS * ITEMS];\n"
+         "  sbk_t a = sbk_wave_tile(n, ((ulong)blockIdx.x * WAVES + wave) * (ROWS * ITEMS * 64), lane, " << key_args() << "vals, y);\n"
          "  if (lane == 0) agg[wave] = a;\n"
          "  __syncthreads();\n"
          "  if (threadIdx.x == 0) {\n"
@@ -137,31 +158,55 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
          "  }\n"
          "}\n";
 
+    // groups of 1024 tiles: exclusive scan of the tile aggregates inside the group (in place) and the
+    // group's aggregate; the (few) group aggregates are then scanned by ONE workgroup below, and phase 3
+    // combines group carry and in-group carry.  Two tiny launches instead of a 48-step serial loop.
+    s << "extern \"C\" __global__ void __launch_bounds__(1024) vexcl_sbk_carry_local(int ntiles, int *tc, int *tf, val_t *tv, int *gc, int *gf, val_t *gv) {\n"
+         "  __shared__ sbk_t wagg[16];\n"
+         "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
+         "  const int t = blockIdx.x * 1024 + threadIdx.x;\n"
+         "  sbk_t x = sbk_empty();\n"
+         "  if (t < ntiles) { x.c = tc[t]; x.f = tf[t]; x.v = tv[t]; }\n"
+         "  const sbk_t sc = sbk_wave_scan(x, lane);\n"
+         "  if (lane == 63) wagg[wave] = sc;\n"
+         "  __syncthreads();\n"
+         "  sbk_t pre = sbk_empty();\n"
+         "  for (int w = 0; w < wave; ++w) pre = sbk_combine(pre, wagg[w]);\n"
+         "  const sbk_t incl = sbk_combine(pre, sc);\n"
+         "  sbk_t excl = sbk_up(incl, 1);\n"
+         "  if (lane == 0) excl = pre;\n"
+         "  if (t < ntiles) { tc[t] = excl.c; tf[t] = excl.f; tv[t] = excl.v; }\n"
+         "  if (threadIdx.x == 1023) { gc[blockIdx.x] = incl.c; gf[blockIdx.x] = incl.f; gv[blockIdx.x] = incl.v; }\n"
+         "}\n";
+
+    // one workgroup: lane t folds its own run of consecutive tile aggregates serially, ONE block scan
+    // orders the 1024 runs, and the lane writes the carries of its run back (runs are one element long
+    // up to 2^20 tiles = 2^31 elements)
     s << "extern \"C\" __global__ void __launch_bounds__(1024) vexcl_sbk_carry(int ntiles, int *tc, int *tf, val_t *tv, int *total) {\n"
          "  __shared__ sbk_t wagg[16];\n"
          "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
-         "  sbk_t carry = sbk_empty();\n"
-         "  for (int base = 0; base < ntiles; base += 1024) {\n"
-         "    const int t = base + threadIdx.x;\n"
-         "    sbk_t x = sbk_empty();\n"
-         "    if (t < ntiles) { x.c = tc[t]; x.f = tf[t]; x.v = tv[t]; }\n"
-         "    sbk_t sc = sbk_wave_scan(x, lane);\n"
-         "    if (lane == 63) wagg[wave] = sc;\n"
-         "    __syncthreads();\n"
-         "    sbk_t pre = carry, all = carry;\n"
-         "    for (int w = 0; w < 16; ++w) { if (w == wave) pre = all; all = sbk_combine(all, wagg[w]); }\n"
-         "    sbk_t incl = sbk_combine(pre, sc);\n"
-         "    sbk_t excl = sbk_up(incl, 1);\n"
-         "    if (lane == 0) excl = pre;\n"
-         "    if (t < ntiles) { tc[t] = excl.c; tf[t] = excl.f; tv[t] = excl.v; }\n"
-         "    carry = all;\n"
-         "    __syncthreads();\n"
+         "  const int per = (ntiles + 1023) / 1024;\n"
+         "  const int b = threadIdx.x * per, e = min(b + per, ntiles);\n"
+         "  sbk_t acc = sbk_empty();\n"
+         "  for (int t = b; t < e; ++t) { sbk_t x; x.c = tc[t]; x.f = tf[t]; x.v = tv[t]; acc = sbk_combine(acc, x); }\n"
+         "  const sbk_t sc = sbk_wave_scan(acc, lane);\n"
+         "  if (lane == 63) wagg[wave] = sc;\n"
+         "  __syncthreads();\n"
+         "  sbk_t pre = sbk_empty();\n"
+         "  for (int w = 0; w < wave; ++w) pre = sbk_combine(pre, wagg[w]);\n"
+         "  const sbk_t incl = sbk_combine(pre, sc);\n"
+         "  sbk_t run = sbk_up(incl, 1);\n"
+         "  if (lane == 0) run = pre;\n"
+         "  for (int t = b; t < e; ++t) {\n"
+         "    sbk_t x; x.c = tc[t]; x.f = tf[t]; x.v = tv[t];\n"
+         "    tc[t] = run.c; tf[t] = run.f; tv[t] = run.v;\n"
+         "    run = sbk_combine(run, x);\n"
          "  }\n"
-         "  if (threadIdx.x == 0) *total = carry.c;\n"
+         "  if (threadIdx.x == 1023) *total = incl.c;\n"
          "}\n";
 
     s << "extern \"C\" __global__ void __launch_bounds__(" << WAVES * 64 << ") vexcl_sbk_scan(ulong n, " << key_params(true)
-      << "const val_t *vals, const int *tc, const int *tf, const val_t *tv, ";
+      << "const val_t *vals, const int *tc, const int *tf, const val_t *tv, const int *gc, const int *gf, const val_t *gv, ";
     if (mode == REDUCE) {
         for (size_t k = 0; k < nk; ++k) s << K[k] << " *okey" << k << ", ";
         s << "val_t *ovals) {\n";
@@ -170,35 +215,43 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
     }
     s << "  __shared__ sbk_t agg[WAVES];\n"
          "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
-         "  const ulong wbase = ((ulong)blockIdx.x * WAVES + wave) * (VT * 64);\n"
-         "  sbk_t y[VT];\n"
+         "  const ulong wbase = ((ulong)blockIdx.x * WAVES + wave) * (ROWS * ITEMS * 64);\n"
+         "  sbk_t y[ROWS * ITEMS];\n"
          "  sbk_t a = sbk_wave_tile(n, wbase, lane, " << key_args() << "vals, y);\n"
          "  if (lane == 0) agg[wave] = a;\n"
          "  __syncthreads();\n"
-         "  sbk_t W; W.c = tc[blockIdx.x]; W.f = tf[blockIdx.x]; W.v = tv[blockIdx.x];\n"
+         "  sbk_t W, G; W.c = tc[blockIdx.x]; W.f = tf[blockIdx.x]; W.v = tv[blockIdx.x];\n"
+         "  G.c = gc[blockIdx.x >> 10]; G.f = gf[blockIdx.x >> 10]; G.v = gv[blockIdx.x >> 10];\n"
+         "  W = sbk_combine(G, W);\n"
          "  for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n"
-         "  sbk_t before = W;\n"
+         "  sbk_t before = W;                 // inclusive prefix of the element just before this lane's first one\n"
          "  #pragma unroll\n"
-         "  for (int j = 0; j < VT; ++j) {\n"
-         "    const ulong i = wbase + j * 64 + lane;\n"
-         "    const sbk_t fin = sbk_combine(W, y[j]);\n"
-         "    sbk_t prev = sbk_up(fin, 1);\n"
+         "  for (int r = 0; r < ROWS; ++r) {\n"
+         "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n"
+         "    const sbk_t last = sbk_combine(W, y[r * ITEMS + ITEMS - 1]);\n"
+         "    sbk_t prev = sbk_up(last, 1);\n"
          "    if (lane == 0) prev = before;\n"
-         "    before = sbk_from(fin, 63);\n"
-         "    if (i < n) {\n"
-         "      const bool head = fin.c != prev.c;\n";
+         "    before = sbk_from(last, 63);\n"
+         "    #pragma unroll\n"
+         "    for (int j = 0; j < ITEMS; ++j) {\n"
+         "      const ulong i = i0 + j;\n"
+         "      const sbk_t fin = sbk_combine(W, y[r * ITEMS + j]);\n"
+         "      if (i < n) {\n"
+         "        const bool head = fin.c != prev.c;\n";
     if (mode == INCLUSIVE) {
-        s << "      (void)head; (void)init; ovals[i] = fin.v;\n";
+        s << "        (void)head; (void)init; ovals[i] = fin.v;\n";
     } else if (mode == EXCLUSIVE) {
-        s << "      ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+        s << "        ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
     } else {
-        s << "      if (head) {\n";
-        for (size_t k = 0; k < nk; ++k) s << "        okey" << k << "[fin.c - 1] = key" << k << "[i];\n";
-        s << "        if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
-             "      }\n"
-             "      if (i == n - 1) ovals[fin.c - 1] = fin.v;\n";
+        s << "        if (head) {\n";
+        for (size_t k = 0; k < nk; ++k) s << "          okey" << k << "[fin.c - 1] = key" << k << "[i];\n";
+        s << "          if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
+             "        }\n"
+             "        if (i == n - 1) ovals[fin.c - 1] = fin.v;\n";
     }
-    s << "    }\n"
+    s << "      }\n"
+         "      prev = fin;\n"
+         "    }\n"
          "  }\n"
          "}\n";
     return src.str() + s.str();
@@ -228,6 +281,7 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
         backend::program prog = backend::build_sources(q, source<V, Comp, Oper>(q, key_types<KTuple>(seq()), mode));
         kernels k;
         k.reduce = backend::kernel(q, prog, "vexcl_sbk_reduce");
+        k.carry_local = backend::kernel(q, prog, "vexcl_sbk_carry_local");
         k.carry = backend::kernel(q, prog, "vexcl_sbk_carry");
         k.scan = backend::kernel(q, prog, "vexcl_sbk_scan");
         it = cache.insert(q, std::move(k));
@@ -237,10 +291,11 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
     const size_t ntiles = (n + TILE - 1) / TILE;
     precondition(ntiles < (size_t(1) << 31), "input too large");
     auto &pool = scratch_pool::instance();
-    backend::device_vector<char> tcb = pool.get(q, 4, (2 * ntiles + 1) * sizeof(int));
-    backend::device_vector<char> tvb = pool.get(q, 5, ntiles * sizeof(V));
-    int *tc = reinterpret_cast<int *>(tcb.raw()), *tf = tc + ntiles, *total = tf + ntiles;
-    V *tv = reinterpret_cast<V *>(tvb.raw());
+    const size_t ngroups = (ntiles + 1023) / 1024;
+    backend::device_vector<char> tcb = pool.get(q, 4, (2 * ntiles + 2 * ngroups + 1) * sizeof(int));
+    backend::device_vector<char> tvb = pool.get(q, 5, (ntiles + ngroups) * sizeof(V));
+    int *tc = reinterpret_cast<int *>(tcb.raw()), *tf = tc + ntiles, *gc = tf + ntiles, *gf = gc + ngroups, *total = gf + ngroups;
+    V *tv = reinterpret_cast<V *>(tvb.raw()), *gv = tv + ntiles;
 
     K.reduce.push_arg(n);
     for_each_key(keys, [&](const auto &k) { K.reduce.push_arg(k(0).raw()); }, seq());
@@ -248,7 +303,12 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
     K.reduce.config(ntiles, WAVES * 64);
     K.reduce(q);
 
-    K.carry.push_arg(static_cast<int>(ntiles)); K.carry.push_arg(tc); K.carry.push_arg(tf); K.carry.push_arg(tv); K.carry.push_arg(total);
+    K.carry_local.push_arg(static_cast<int>(ntiles)); K.carry_local.push_arg(tc); K.carry_local.push_arg(tf); K.carry_local.push_arg(tv);
+    K.carry_local.push_arg(gc); K.carry_local.push_arg(gf); K.carry_local.push_arg(gv);
+    K.carry_local.config(ngroups, 1024);
+    K.carry_local(q);
+
+    K.carry.push_arg(static_cast<int>(ngroups)); K.carry.push_arg(gc); K.carry.push_arg(gf); K.carry.push_arg(gv); K.carry.push_arg(total);
     K.carry.config(1, 1024);
     K.carry(q);
 
@@ -262,6 +322,7 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
     for_each_key(keys, [&](const auto &k) { K.scan.push_arg(k(0).raw()); }, seq());
     K.scan.push_arg(ivals(0).raw());
     K.scan.push_arg(static_cast<const int *>(tc)); K.scan.push_arg(static_cast<const int *>(tf)); K.scan.push_arg(static_cast<const V *>(tv));
+    K.scan.push_arg(static_cast<const int *>(gc)); K.scan.push_arg(static_cast<const int *>(gf)); K.scan.push_arg(static_cast<const V *>(gv));
     push_outputs(K.scan, count);
     K.scan.config(ntiles, WAVES * 64);
     K.scan(q);
