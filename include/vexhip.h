@@ -107,6 +107,19 @@ int vexhip_spmv_csr_f64_i64(int dev, void *stream, int64_t n, double alpha, int 
 /* tuning variant selector for the CSR kernel (bench / sweep tool only):
  * 0 = default. */
 int vexhip_spmv_csr_set_variant(int variant);
+/* The CSR product with the strip traversal of the SELL kernels (see vexhip_traversal below): for banded /
+ * stencil matrices whose far diagonals are "planes" apart, every XCD owns a strip of every plane, so x is
+ * fetched from HBM about once.  vexhip_csr_traversal_i32 inspects the first 64 entries of every row
+ * (blocking, set-up time); grid_blocks = 0 means "no reordering pays".  rows_per_block = 256 for the CSR kernel. */
+struct vexhip_traversal;
+int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
+        int rows_per_block, struct vexhip_traversal *traversal);
+int vexhip_spmv_csr_ordered_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
+        const int32_t *ptr, const int32_t *col, const double *val, const double *x, double *y,
+        const struct vexhip_traversal *traversal);
+int vexhip_spmv_csr_ordered_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
+        const int32_t *ptr, const int32_t *col, const float *val, const float *x, float *y,
+        const struct vexhip_traversal *traversal);
 int vexhip_spmv_hell_set_variant(int variant);
 
 /* ---- fixed primitive: hybrid ELL SpMV (spmat/hybrid_ell.inl:238-300) ----

@@ -211,23 +211,46 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
     if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
+// how many entries of the CSR matrix lie on each diagonal of the table (for the traversal heuristic)
+__global__ __launch_bounds__(256)
+void csr_delta_count_kernel(long long n, int w, int ndeltas, const int *__restrict__ ptr, const int *__restrict__ col,
+        const int *__restrict__ table, unsigned long long *counts)
+{
+    __shared__ int s_table[256];
+    __shared__ unsigned s_cnt[256];
+    s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = ptr[i], e = ptr[i + 1];
+        for (int j = 0; j < w && b + j < e; ++j) {
+            const int d = (int)((long long)col[b + j] - i);
+            int lo = 0, hi = ndeltas;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (s_table[mid] < d) lo = mid + 1; else hi = mid; }
+            if (lo < ndeltas && s_table[lo] == d) atomicAdd(&s_cnt[lo], 1u);
+        }
+    }
+    __syncthreads();
+    if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
 inline int grid_for(int dev, int64_t n) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16));
 }
 
 // Strip traversal from the diagonals every second row (or more) uses: see vexhip.h vexhip_traversal.
 void strip_traversal(int64_t n, const std::vector<int> &table, const std::vector<unsigned long long> &counts,
-        vexhip_traversal *out)
+        vexhip_traversal *out, int64_t rpb = S8_ROWS)
 {
     std::memset(out, 0, sizeof(*out));
-    const int64_t rpb = S8_ROWS, tile_rows_max = 65536;
+    const int64_t tile_rows_max = 65536;
     if (n < 8 * tile_rows_max) return;
     int64_t s_big = 0;
     for (size_t k = 0; k < table.size(); ++k)
         if (counts[k] * 2 >= (unsigned long long)n) s_big = std::max<int64_t>(s_big, table[k] < 0 ? -(int64_t)table[k] : table[k]);
     if (s_big < 2 * tile_rows_max || (s_big % rpb) != 0) return;
     const int64_t plane_blocks = s_big / rpb, nb = (n + rpb - 1) / rpb;
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64, plane_blocks / 8));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64 * S8_ROWS / rpb, plane_blocks / 8));   // 32 Ki rows per XCD strip
     const int64_t planes = (nb + plane_blocks - 1) / plane_blocks;
     const int64_t tiles = (plane_blocks + 8 * chunk - 1) / (8 * chunk);
     out->grid_blocks = tiles * planes * 8 * chunk;
@@ -330,6 +353,37 @@ int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *pt
     VEXHIP_TRY(hipStreamSynchronize(s));
     *ndeltas = host[HASH_SLOTS];
     return 0;
+}
+
+int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
+        int rows_per_block, vexhip_traversal *traversal)
+{
+    VEXHIP_REQUIRE(traversal && rows_per_block > 0, "bad argument");
+    std::memset(traversal, 0, sizeof(*traversal));
+    if (n <= 0) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    int *deltas = nullptr;
+    VEXHIP_TRY(hipMalloc(&deltas, sizeof(int) * 256 + sizeof(unsigned long long) * 256));
+    unsigned long long *dcounts = reinterpret_cast<unsigned long long *>(deltas + 256);
+    int nd = -1;
+    const int w = 64;                                    // the first 64 entries of every row decide
+    int rc = vexhip_sell8_analyze_i32(dev, stream, n, ptr, col, w, deltas, &nd);
+    if (rc == 0 && nd > 0) {
+        std::vector<unsigned long long> counts(256);
+        std::vector<int> table(nd);
+        hipError_t e = hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256, s);
+        if (e == hipSuccess) {
+            csr_delta_count_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, w, nd, ptr, col, deltas, dcounts);
+            e = hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(table.data(), deltas, sizeof(int) * nd, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { (void)hipFree(deltas); return check(e, __FILE__, __LINE__); }
+        strip_traversal(n, table, counts, traversal, rows_per_block);
+    }
+    VEXHIP_TRY(hipFree(deltas));
+    return rc;
 }
 
 int vexhip_sell8_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,

@@ -84,13 +84,14 @@ template <typename V, typename I, bool NT, bool SWZ>
 __global__ __launch_bounds__(CSR_BLOCK)
 void csr_stream_kernel(long long n, long long nblocks, V alpha, int append,
         const I *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
-        const V *__restrict__ x, V *__restrict__ y)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
 {
     __shared__ V s_prod[CSR_TILE];
     __shared__ I s_ptr[CSR_BLOCK + 1];
 
-    const long long lb = logical_block<SWZ>(nblocks);
-    if (lb >= nblocks) return;
+    // banded / stencil matrices: strip traversal in units of 256-row blocks (vexhip_csr_traversal_i32)
+    const long long lb = (trav.chunk > 0 || trav.order) ? traversal_block(trav, nblocks) : logical_block<SWZ>(nblocks);
+    if (lb < 0 || lb >= nblocks) return;
     const int t = threadIdx.x;
     const long long r0 = lb * CSR_BLOCK;
     const long long rows_here = (n - r0 < CSR_BLOCK) ? (n - r0) : CSR_BLOCK;
@@ -367,7 +368,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <typename V, typename I>
 int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
-        const I *ptr, const I *col, const V *val, const V *x, V *y)
+        const I *ptr, const I *col, const V *val, const V *x, V *y, const vexhip_traversal *tr = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0, "negative row count");
     if (n == 0) return 0;
@@ -384,9 +385,11 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
     int variant = g_csr_variant < 0 ? kCsrDefault : g_csr_variant;
     bool nt = variant & 1, swz = variant & 2;
     long long grid = swz ? ((nb + 7) / 8) * 8 : nb;
+    trav_dev order = {nullptr, 0, 0, 0};
+    if (tr && tr->grid_blocks > 0) order = make_traversal(tr, nb, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
 #define LAUNCH(NT, SWZ) csr_stream_kernel<V, I, NT, SWZ><<<(unsigned)grid, CSR_BLOCK, 0, s>>>( \
-        n, nb, alpha, append, ptr, col, val, x, y)
+        n, nb, alpha, append, ptr, col, val, x, y, order)
     if (nt) { if (swz) LAUNCH(true, true); else LAUNCH(true, false); }
     else    { if (swz) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -726,6 +729,14 @@ int vexhip_spmv_csr_f64_i32(int dev, void *stream, int64_t n, double alpha, int 
 int vexhip_spmv_csr_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
         const int32_t *ptr, const int32_t *col, const float *val, const float *x, float *y)
 { return spmv_csr<float, int>(dev, stream, n, alpha, append, ptr, col, val, x, y); }
+
+int vexhip_spmv_csr_ordered_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
+        const int32_t *ptr, const int32_t *col, const double *val, const double *x, double *y, const vexhip_traversal *traversal)
+{ return spmv_csr<double, int>(dev, stream, n, alpha, append, ptr, col, val, x, y, traversal); }
+
+int vexhip_spmv_csr_ordered_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
+        const int32_t *ptr, const int32_t *col, const float *val, const float *x, float *y, const vexhip_traversal *traversal)
+{ return spmv_csr<float, int>(dev, stream, n, alpha, append, ptr, col, val, x, y, traversal); }
 
 int vexhip_spmv_csr_f64_i64(int dev, void *stream, int64_t n, double alpha, int append,
         const int64_t *ptr, const int64_t *col, const double *val, const double *x, double *y)

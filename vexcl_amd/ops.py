@@ -56,7 +56,16 @@ def _chk(t, name):
 # --------------------------------------------------------------------------
 # raw kernels
 # --------------------------------------------------------------------------
-def spmv_csr(ptr, col, val, x, y, alpha=1.0, append=False):
+def csr_traversal(ptr, col):
+    """Strip traversal for the CSR kernel of a banded / stencil matrix (include/vexhip.h
+    `vexhip_csr_traversal_i32`); grid_blocks == 0 when no reordering pays."""
+    trav = _capi.Traversal()
+    if ptr.dtype == torch.int32 and col.dtype == torch.int32 and ptr.numel() > 1:
+        lib().csr_traversal_i32(_dev(col), _stream(col), ptr.numel() - 1, _p(ptr), _p(col), 256, ctypes.byref(trav))
+    return trav
+
+
+def spmv_csr(ptr, col, val, x, y, alpha=1.0, append=False, traversal=None):
     """y (=|+=) alpha * A x  -- `csr_spmv`, vexcl/spmat/csr.inl:153-185."""
     n = ptr.numel() - 1
     for t, nm in ((ptr, "ptr"), (col, "col"), (val, "val"), (x, "x"), (y, "y")):
@@ -72,6 +81,10 @@ def spmv_csr(ptr, col, val, x, y, alpha=1.0, append=False):
         fn, a = L.spmv_csr_f64_i64, ctypes.c_double(alpha)
     else:
         raise Error("unsupported CSR type combination %s/%s/%s" % (val.dtype, ptr.dtype, col.dtype))
+    if traversal is not None and traversal.grid_blocks > 0 and ptr.dtype == torch.int32:
+        fo = L.spmv_csr_ordered_f64_i32 if val.dtype == torch.float64 else L.spmv_csr_ordered_f32_i32
+        fo(_dev(y), _stream(y), n, a, int(bool(append)), _p(ptr), _p(col), _p(val), _p(x), _p(y), ctypes.byref(traversal))
+        return y
     fn(_dev(y), _stream(y), n, a, int(bool(append)), _p(ptr), _p(col), _p(val), _p(x), _p(y))
     return y
 
@@ -288,6 +301,8 @@ class SpMat:
         elif fmt == "hell":
             self.hell = HybridELL(ptr, col, val)
         self.fmt = fmt
+        # CSR arrays as given: banded / stencil matrices get the strip traversal too
+        self.csr_trav = csr_traversal(ptr, col) if (fmt == "csr" and val.is_cuda) else None
 
     def rows(self):
         return self.n
@@ -303,7 +318,7 @@ class SpMat:
             raise Error("x has %d elements, matrix has %d columns" % (x.numel(), self.m))
         if self.hell is not None:
             return self.hell.mul(x, y, alpha, append)
-        return spmv_csr(self.ptr, self.col, self.val, x, y, alpha, append)
+        return spmv_csr(self.ptr, self.col, self.val, x, y, alpha, append, traversal=self.csr_trav)
 
     def apply_multi(self, xs, ys, alpha=1.0, append=False):
         """`Y = alpha * A * X` for a multivector (lists of component vectors): the SELL
