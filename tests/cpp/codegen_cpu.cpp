@@ -231,6 +231,27 @@ TEST_CASE(cast_and_temporaries) {                                    // cast.hpp
     backend::check_sources(s);
 }
 
+TEST_CASE(slices_and_dimension_reductions) {                          // vector_view.hpp: gslice, slicer, reduce, reshape
+    vector<double> x, y;
+    size_t dims[2] = {32, 32};
+    slicer<2> sl(dims);
+    std::string s = src_of<assign::SET>(y, sl[range(2, 2, 11)][_](x));
+    CHECK(has(s, "double * prm_2_base") && has(s, "ulong prm_2_start") && has(s, "long prm_2_stride1"));
+    CHECK(has(s, "prm_2_base[ (ulong)( prm_2_start + (long)( idx % prm_2_length1 ) * prm_2_stride1 + (long)( idx / prm_2_length1 ) * prm_2_stride0 ) ]"));
+    backend::check_sources(s);
+    s = src_of<assign::ADD>(sl[5](y), 2 * x);                                    // a slice as the left-hand side
+    CHECK(has(s, "prm_1_base[ ") && has(s, " ] += vex_r0;"));
+    backend::check_sources(s);
+    s = src_of<assign::SET>(y, sl[_][3](x * x) + 1);                             // slice of an expression: idx re-declared
+    CHECK(has(s, "const ulong idx = vex_pos;") && has(s, "prm_2_val = ( prm_2_e_1[idx] * prm_2_e_2[idx] );"));
+    backend::check_sources(s);
+    s = src_of<assign::SET>(y, reduce<MAX>(sl[_], reduce<SUM>(extents[32][32][32], sin(x), 2), 1));
+    CHECK(has(s, "for(ulong vex_r0 = 0; vex_r0 < prm_2_rlen0; ++vex_r0)") && has(s, "sin( prm_2_e_1_e_1[idx] )"));
+    backend::check_sources(s);
+    s = src_of<assign::SET>(y, reshape(x, make_array<size_t>(4, 2), make_array<size_t>(1, 0)));
+    backend::check_sources(s);
+}
+
 TEST_CASE(partition_and_util) {
     CHECK_EQUAL(alignup(17), size_t(32));
     CHECK_EQUAL(nextpow2(1000), size_t(1024));
