@@ -1,0 +1,82 @@
+"""Two ranks on ONE GPU (the gpurun box has one): the real device kernels behind
+vexcl_amd.distributed -- strip generation, local / remote split, SELL8 local part,
+pack kernel, remote CSR part, DistReductor, DistScan -- with the exchange carried by
+gloo (RCCL refuses two ranks on one device).  Only the transport differs from the
+one-process-per-GPU job bench.py launches."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vexcl_amd import ops, lib
+        from vexcl_amd.distributed import DistReductor, DistScan, DistSpMat, partition
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        L = lib()
+        N = n ** 3
+        part = partition(N, world)
+        r0, r1 = part[rank], part[rank + 1]
+        ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
+        x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev), (42 + r0 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        y = torch.full((r1 - r0,), 7.0, dtype=torch.float64, device=dev)
+        A = DistSpMat(ptr, col, val, N, N)
+        for _ in range(2):                                  # exchange buffers are reused
+            y.fill_(7.0)
+            A.apply(x, y, 1.5, True)
+        # the same product on the whole matrix, one "device"
+        fp, fc, fv = ops.poisson3d(n, dev)
+        fx = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
+        fy = torch.full((N,), 7.0, dtype=torch.float64, device=dev)
+        ops.SpMat(fp, fc, fv).apply(fx, fy, 1.5, True)
+        ok = bool(torch.equal(fx[r0:r1], x))                 # x is a function of the global index
+        scale = float(fv.abs().max()) * 8
+        ok = ok and bool(((y - fy[r0:r1]).abs() <= 1e-12 * scale).all())
+        ok = ok and A.loc is not None and (world == 1 or A.rem is not None)
+        ok = ok and A.loc.fmt == "sell" and A.loc.hell.deltas is not None      # banded local part: 1-byte diagonal codes
+        tot = DistReductor("SUM")(y)
+        ok = ok and abs(tot - float(fy.sum())) <= 1e-9 * float(fy.abs().sum())
+        mx = DistReductor("MAX")(y)
+        ok = ok and mx == float(fy.max())
+        k = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.int32, device=dev), (5 + r0 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        fk = ops.fill_hash(torch.empty(N, dtype=torch.int32, device=dev), 5)
+        got = DistScan()(k.clone())
+        want = ops.inclusive_scan(fk.clone())
+        ok = ok and bool(torch.equal(got, want[r0:r1]))
+        got = DistScan()(k.clone(), exclusive=True, init=9)
+        want = ops.exclusive_scan(fk.clone(), init=9)
+        ok = ok and bool(torch.equal(got, want[r0:r1]))
+        out[rank] = 1 if ok else 0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 64), (3, 48)])
+def test_two_ranks_share_one_gpu(world, n, built_lib):
+    ctx = mp.get_context("spawn")
+    out = ctx.Array("i", [0] * world)
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert list(out) == [1] * world
