@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--dist", action="store_true", help="use the partitioned SpMat even on one GPU (debug)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: debug)")
+    ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (debug: exercises the N>1 path on a 1-GPU box; needs --backend gloo)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (elementwise, reduce, scan, sort, multi-rhs)")
     args = ap.parse_args()
 
@@ -169,11 +171,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     L = lib()
     n = args.grid
