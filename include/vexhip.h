@@ -106,6 +106,13 @@ int vexhip_spmv_csr_f64_i64(int dev, void *stream, int64_t n, double alpha, int 
         const int64_t *ptr, const int64_t *col, const double *val, const double *x, double *y);
 /* tuning variant selector for the CSR kernel (bench / sweep tool only):
  * 0 = default. */
+/* Row-subset CSR, always "+=": y[rows[k]] += alpha * sum_{j in [ptr[k], ptr[k+1])} val[j] * x[col[j]], k < nrows.
+ * The remote part of a partitioned matrix (spmat/csr.inl:92-131 `rem`, applied by `mul_remote`, spmat.hpp:177-183)
+ * has entries only in rows next to a partition boundary; rows = their (strictly increasing) local ids.   */
+int vexhip_spmv_csr_rows_f64_i32(int dev, void *stream, int64_t nrows, double alpha, const int32_t *rows,
+        const int32_t *ptr, const int32_t *col, const double *val, const double *x, double *y);
+int vexhip_spmv_csr_rows_f32_i32(int dev, void *stream, int64_t nrows, float alpha, const int32_t *rows,
+        const int32_t *ptr, const int32_t *col, const float *val, const float *x, float *y);
 int vexhip_spmv_csr_set_variant(int variant);
 /* The CSR product with the strip traversal of the SELL kernels (see vexhip_traversal below): for banded /
  * stencil matrices whose far diagonals are "planes" apart, every XCD owns a strip of every plane, so x is

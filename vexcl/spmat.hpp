@@ -136,8 +136,20 @@ class SpMat {
                 }
                 precondition(col_end - col_begin < (1ull << 31), "SpMat: more than 2^31 columns on one device");
                 upload(q, loc, lptr, lcol, lval, use_ell());
-                upload(q, rem, rptr, rcol, rval, false);
+                // remote part: only the rows that reach a ghost column are stored (row list + compact CSR)
+                rem.n = n; rem.nnz = rcol.size();
+                if (rem.nnz) {
+                    std::vector<int> rows, cptr(1, 0);
+                    for (size_t i = 0; i < n; ++i)
+                        if (rptr[i + 1] > rptr[i]) { rows.push_back(static_cast<int>(i)); cptr.push_back(rptr[i + 1]); }
+                    rem_rows = backend::device_vector<int>(q, rows.size(), rows.data());
+                    rem.csr_ptr = backend::device_vector<int>(q, cptr.size(), cptr.data());
+                    rem.csr_col = backend::device_vector<int>(q, rcol.size(), rcol.data());
+                    rem.csr_val = backend::device_vector<val_t>(q, rval.size(), rval.data());
+                    rem.csr_nnz = rem.nnz;
+                }
             }
+            backend::device_vector<int> rem_rows;
 
             static bool use_ell() {
 #ifdef VEXCL_SPMAT_CSR
@@ -242,6 +254,11 @@ class SpMat {
                 backend::check(spmm(dev, q.raw(), (int64_t)n, k, alpha, append ? 1 : 0, loc, x, y));
             }
 
+            static int spmv_rows(int dev, void *s, int64_t nr, double a, const int *rows, const int *p, const int *c, const double *v, const double *x, double *y) {
+                return vexhip_spmv_csr_rows_f64_i32(dev, s, nr, a, rows, p, c, v, x, y); }
+            static int spmv_rows(int dev, void *s, int64_t nr, float a, const int *rows, const int *p, const int *c, const float *v, const float *x, float *y) {
+                return vexhip_spmv_csr_rows_f32_i32(dev, s, nr, a, rows, p, c, v, x, y); }
+
             /// csr.inl:186-200: an empty local part zero-fills y on SET.
             void mul_local(const backend::command_queue &q, const backend::device_vector<val_t> &x,
                     backend::device_vector<val_t> &y, val_t alpha, bool append) const
@@ -256,7 +273,8 @@ class SpMat {
                     backend::device_vector<val_t> &y, val_t alpha) const
             {
                 if (rem.empty()) return;
-                backend::check(spmv(q.device_ordinal(), q.raw(), (int64_t)n, alpha, 1, rem, ghosts.raw(), y.raw()));
+                backend::check(spmv_rows(q.device_ordinal(), q.raw(), (int64_t)rem_rows.size(), alpha, rem_rows.raw(),
+                            rem.csr_ptr.raw(), rem.csr_col.raw(), rem.csr_val.raw(), ghosts.raw(), y.raw()));
             }
         };
 

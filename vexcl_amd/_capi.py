@@ -90,6 +90,8 @@ _PROTOS = {
     "vexhip_spmv_csr_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vexhip_spmv_csr_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vexhip_spmv_csr_f64_i64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vexhip_spmv_csr_rows_f64_i32": (None, [c_int, c_vp, c_i64, c_f64] + [c_vp] * 6),
+    "vexhip_spmv_csr_rows_f32_i32": (None, [c_int, c_vp, c_i64, c_f32] + [c_vp] * 6),
     "vexhip_spmv_csr_set_variant": (None, [c_int]),
     "vexhip_csr_traversal_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_int, ctypes.POINTER(Traversal)]),
     "vexhip_spmv_csr_ordered_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int] + [c_vp] * 5 + [ctypes.POINTER(Traversal)]),

@@ -143,6 +143,23 @@ void csr_stream_kernel(long long n, long long nblocks, V alpha, int append,
     }
 }
 
+// Row-subset CSR, always "+=":  y[rows[k]] += alpha * sum_j val[j] * x[col[j]],  j in [ptr[k], ptr[k+1]).
+// The remote part of a partitioned matrix touches only the rows next to a partition boundary
+// (2 x 260 100 of 16.8 M rows per GPU for 512^3 over 8 GPUs): the product then reads a row list
+// and those rows' entries instead of the row pointers of every row.
+template <typename V>
+__global__ __launch_bounds__(256)
+void csr_rows_kernel(long long nr, V alpha, const int *__restrict__ rows, const int *__restrict__ ptr,
+        const int *__restrict__ col, const V *__restrict__ val, const V *__restrict__ x, V *__restrict__ y)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nr; k += (long long)gridDim.x * blockDim.x) {
+        V sum = 0;
+        for (int j = ptr[k], e = ptr[k + 1]; j < e; ++j) sum += val[j] * x[col[j]];
+        const int r = rows[k];
+        y[r] = y[r] + alpha * sum;
+    }
+}
+
 // Fallback for CSR arrays that are not 16-byte aligned (sub-views): the
 // reference's one-row-per-work-item loop, unchanged.
 template <typename V, typename I>
@@ -393,6 +410,20 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
     if (nt) { if (swz) LAUNCH(true, true); else LAUNCH(true, false); }
     else    { if (swz) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename V>
+int spmv_csr_rows(int dev, void *stream, int64_t nr, V alpha, const int *rows, const int *ptr, const int *col,
+        const V *val, const V *x, V *y)
+{
+    VEXHIP_REQUIRE(nr >= 0, "negative row count");
+    if (nr == 0) return 0;
+    VEXHIP_REQUIRE(rows && ptr && x && y, "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    const int grid = (int)std::min<int64_t>((nr + 255) / 256, (int64_t)info(dev).cus * 32);
+    csr_rows_kernel<V><<<grid, 256, 0, as_stream(stream)>>>(nr, alpha, rows, ptr, col, val, x, y);
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -729,6 +760,14 @@ int vexhip_spmv_csr_f64_i32(int dev, void *stream, int64_t n, double alpha, int 
 int vexhip_spmv_csr_f32_i32(int dev, void *stream, int64_t n, float alpha, int append,
         const int32_t *ptr, const int32_t *col, const float *val, const float *x, float *y)
 { return spmv_csr<float, int>(dev, stream, n, alpha, append, ptr, col, val, x, y); }
+
+int vexhip_spmv_csr_rows_f64_i32(int dev, void *stream, int64_t nrows, double alpha, const int32_t *rows,
+        const int32_t *ptr, const int32_t *col, const double *val, const double *x, double *y)
+{ return spmv_csr_rows<double>(dev, stream, nrows, alpha, rows, ptr, col, val, x, y); }
+
+int vexhip_spmv_csr_rows_f32_i32(int dev, void *stream, int64_t nrows, float alpha, const int32_t *rows,
+        const int32_t *ptr, const int32_t *col, const float *val, const float *x, float *y)
+{ return spmv_csr_rows<float>(dev, stream, nrows, alpha, rows, ptr, col, val, x, y); }
 
 int vexhip_spmv_csr_ordered_f64_i32(int dev, void *stream, int64_t n, double alpha, int append,
         const int32_t *ptr, const int32_t *col, const double *val, const double *x, double *y, const vexhip_traversal *traversal)

@@ -89,6 +89,29 @@ def spmv_csr(ptr, col, val, x, y, alpha=1.0, append=False, traversal=None):
     return y
 
 
+class RowSubsetCSR:
+    """`y[rows[k]] += alpha * A_k . x`: a CSR matrix that has entries only in the listed rows
+    (the remote part of a partitioned matrix).  ptr has len(rows) + 1 entries."""
+
+    def __init__(self, rows, ptr, col, val):
+        for t, nm in ((rows, "rows"), (ptr, "ptr"), (col, "col"), (val, "val")):
+            _chk(t, nm)
+        if rows.dtype != torch.int32 or ptr.dtype != torch.int32 or col.dtype != torch.int32:
+            raise Error("RowSubsetCSR needs int32 indices")
+        self.rows, self.ptr, self.col, self.val = rows, ptr, col, val
+        self.fmt = "csr-rows"
+
+    def apply(self, x, y, alpha=1.0, append=True):
+        if not append:
+            raise Error("a row-subset product only adds to y")
+        L = lib()
+        f64 = self.val.dtype == torch.float64
+        a = ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha)
+        (L.spmv_csr_rows_f64_i32 if f64 else L.spmv_csr_rows_f32_i32)(
+            _dev(y), _stream(y), self.rows.numel(), a, _p(self.rows), _p(self.ptr), _p(self.col), _p(self.val), _p(x), _p(y))
+        return y
+
+
 def gather(idx, src, dst=None):
     """dst[i] = src[idx[i]] -- spmat.hpp:129-133 `permutation(cols_to_send)(x)`."""
     if dst is None:
