@@ -149,7 +149,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge (512 = BASELINE config)")
-    ap.add_argument("--format", default="auto", choices=["auto", "sell", "hell", "csr"])
+    ap.add_argument("--format", default="auto", choices=["auto", "sell", "sell8", "sell32", "hell", "csr"],
+                    help="auto/sell: best storage the matrix allows (value codes, diagonal codes, 32-bit columns); "
+                         "sell8: diagonal codes, values as they are; sell32: 32-bit columns; hell: reference layout; csr")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=256)
@@ -253,9 +255,11 @@ def main():
         gflops = 2.0 * nnz_total / per_step / 1e9
         gbps = alg_total / per_step / 1e9
         hell = (A.hell if world == 1 and not args.dist else A.loc.hell)
-        if fmt == "sell" and getattr(hell, "deltas", None) is not None:
+        if fmt == "sell" and getattr(hell, "values", None) is not None:
+            fmt = "sell8v"                       # ... and 1-byte value codes (<= 255 distinct values: constant-coefficient stencil)
+        elif fmt == "sell" and getattr(hell, "deltas", None) is not None:
             fmt = "sell8"                        # SELL-512 with 1-byte diagonal codes (banded matrix detected)
-        kname = {"hell": "hell_kernel", "sell": "sell_kernel", "sell8": "sell8_kernel"}.get(fmt, "csr_stream_kernel")
+        kname = {"hell": "hell_kernel", "sell": "sell_kernel", "sell8": "sell8_kernel", "sell8v": "sell8v_kernel"}.get(fmt, "csr_stream_kernel")
         traffic = read_traffic(kname) if (world == 1 and n == 512) else None
         out = {
             "metric": "fp64 CSR SpMV GFLOP/s, 3D Poisson %d^3 (y = A*x, vex::SpMat path)" % n,
@@ -296,7 +300,7 @@ def main():
         if world == 1 and not args.dist and not args.no_secondary:
             try:
                 sec = {}
-                if fmt in ("sell", "sell8"):        # Y = A * X, X a multivector<double, 4>: one pass over the matrix
+                if fmt in ("sell", "sell8", "sell8v"):   # Y = A * X, X a multivector<double, 4>
                     xs = [ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 100 + k) for k in range(4)]
                     ys = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(4)]
                     A.apply_multi(xs, ys); torch.cuda.synchronize()

@@ -217,6 +217,29 @@ int vexhip_spmv_sell8_f32_i32(int dev, void *stream, int64_t n, float alpha, int
         const void *buf, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y, const vexhip_traversal *traversal);
 
+/* SELL8V: SELL8 whose VALUES are coded too.  When the ELL part holds at most 255 distinct values (bit patterns;
+ * matrices assembled from a constant-coefficient stencil: the 7-point Poisson matrix has three), each value is
+ * stored as one byte -- its position in a sorted table kept in LDS by the kernel -- next to the diagonal code:
+ * 2 bytes per entry instead of 9 (fp64).  Same arithmetic in the same order: bit-identical to SELL8 / HELL / CSR.
+ * The reference keeps a separate class for such matrices (SpMatCCSR, spmat/ccsr.hpp:55-280); here vex::SpMat detects
+ * them.   values: 256 entries on the device, sorted by bit pattern, nvalues valid (-1: not applicable);
+ * slice layout: ceil(w/2) KiB of diagonal codes, then ceil(w/2) KiB of value codes, both packed as in SELL8.     */
+int64_t vexhip_sell8v_bytes(int64_t n, int64_t ell_width);
+int vexhip_sell8v_analyze_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const double *val,
+        int64_t ell_width, double *values, int *nvalues);
+int vexhip_sell8v_analyze_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const float *val,
+        int64_t ell_width, float *values, int *nvalues);
+int vexhip_sell8v_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int64_t ell_width, const int32_t *deltas, int ndeltas, const double *values, int nvalues, void *buf, vexhip_traversal *traversal);
+int vexhip_sell8v_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int64_t ell_width, const int32_t *deltas, int ndeltas, const float *values, int nvalues, void *buf, vexhip_traversal *traversal);
+int vexhip_spmv_sell8v_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const vexhip_traversal *traversal);
+int vexhip_spmv_sell8v_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const float *values, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const vexhip_traversal *traversal);
+
 /* Multi-right-hand-side products  y[k] (+)= alpha * A * x[k],  k < nrhs  -- `SpMat * multivector`
  * (vexcl/spmat.hpp:388-398, which applies the product once per component; tests/spmv.cpp:262-305).
  * One launch per group of up to four right-hand sides reads the matrix ONCE; each y[k] is

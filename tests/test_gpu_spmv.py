@@ -316,8 +316,8 @@ def test_sell8_diagonal_codes(T, oracle, built_lib):
     # (a) Poisson: 7 diagonals {-n^2, -n, -1, 0, 1, n, n^2}
     n = 20
     ptr, col, val = oracle.poisson3d(n)
-    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
-    assert S.ndeltas == 7 and S.width == 7
+    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val), value_codes=False)      # the values as they are (SELL8 proper)
+    assert S.ndeltas == 7 and S.width == 7 and S.values is None
     assert S.deltas.cpu().numpy()[:7].tolist() == [-n * n, -n, -1, 0, 1, n, n * n]
     N = n ** 3
     raw = S.sell.cpu().numpy().reshape(-1, 4 * 1024 + 7 * 512 * 8)
@@ -346,6 +346,16 @@ def test_sell8_diagonal_codes(T, oracle, built_lib):
         S32 = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val), codes=False)      # 32-bit columns: same bits
         y2 = T.up(y0.copy()); S32.mul(T.up(x), y2, 1.25, True)
         assert T.torch.equal(y, y2)
+    # (b2) up to 255 diagonals are coded, 256 are not
+    for nd, coded in ((255, True), (256, False)):
+        offs = list(range(-(nd // 2), nd - nd // 2))
+        ptr, col, val = _banded(rng, 3000, offs, density=1.0)
+        S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+        assert (S.ndeltas == nd) if coded else (S.ndeltas == -1)
+        x = rng.random(3000)
+        y = T.torch.empty(3000, dtype=T.torch.float64, device=T.dev)
+        S.mul(T.up(x), y)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
     # (c) not banded: more than 255 diagonals -> 32-bit columns are kept
     ptr, col, val = oracle.random_matrix(9, 4000, 4000, 16)
     S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
@@ -408,3 +418,67 @@ def test_multi_rhs_products_are_bit_identical(T, oracle, built_lib, nrhs):
     C.apply_multi(xs, out2)
     for a, b in zip(out, out2):
         assert T.torch.equal(a, b)
+
+
+def test_sell8v_value_codes(T, oracle, built_lib):
+    """<= 255 distinct values in the ELL part => 1-byte value codes next to the diagonal codes; layout,
+    fallbacks, bit-exact products (the same arithmetic in the same order as every other format)."""
+    rng = np.random.default_rng(21)
+    # (a) Poisson: 7 diagonals, 3 values
+    n = 20
+    ptr, col, val = oracle.poisson3d(n)
+    N = n ** 3
+    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+    assert S.ndeltas == 7 and S.nvalues == 3 and S.width == 7
+    vt = S.values.cpu().numpy()[:3]
+    assert sorted(vt.tolist()) == sorted(set(val.tolist()))
+    raw = S.sell.cpu().numpy().reshape(-1, 2 * 4 * 1024)                   # per slice: 4 KiB diagonal codes, 4 KiB value codes
+    ccodes = raw[:, :4096].copy().view(np.uint32).reshape(-1, 4, 256)
+    vcodes = raw[:, 4096:].copy().view(np.uint32).reshape(-1, 4, 256)
+    dt = S.deltas.cpu().numpy()
+    for i in (0, 1, n * n + n + 1, 4321, N - 1):
+        s, t, q = i // 512, (i % 512) // 2, i % 2
+        cols, vals = [], []
+        for j in range(7):
+            sh = 8 * ((j % 2) * 2 + q)
+            code = (int(ccodes[s, j // 2, t]) >> sh) & 255
+            if code != 255:
+                cols.append(i + int(dt[code])); vals.append(float(S.values[(int(vcodes[s, j // 2, t]) >> sh) & 255]))
+        assert cols == col[ptr[i]:ptr[i + 1]].tolist() and vals == val[ptr[i]:ptr[i + 1]].tolist()
+    x = rng.random(N) - 0.5
+    y0 = rng.random(N)
+    want = y0.copy(); oracle.spmv_csr(ptr, col, val, x, want, -0.75, True)
+    y = T.up(y0.copy()); S.mul(T.up(x), y, -0.75, True)
+    assert np.array_equal(y.cpu().numpy(), want)
+    # (b) banded matrices with few distinct values, signed zeros, odd sizes, widths beyond the unrolled ones, a CSR tail
+    for nn, offs, nvals in ((5000, [-700, -3, -1, 0, 2, 9, 1234], 5), (1537, list(range(-20, 21, 2)), 200), (2048, [-1024, -8, 0, 8, 1024, 1500], 1)):
+        ptr, col, val = _banded(rng, nn, offs)
+        pool = np.concatenate([rng.random(nvals) - 0.5, [0.0, -0.0]])[:max(nvals, 1)]
+        val = pool[rng.integers(0, len(pool), size=len(val))]
+        x = rng.random(nn) - 0.5
+        S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+        assert 1 <= S.nvalues <= len(pool)
+        S8 = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val), value_codes=False)
+        assert S8.values is None and S8.deltas is not None
+        ya = T.torch.empty(nn, dtype=T.torch.float64, device=T.dev); yb = T.torch.empty_like(ya)
+        S.mul(T.up(x), ya, 1.5, False); S8.mul(T.up(x), yb, 1.5, False)
+        assert T.torch.equal(ya, yb)
+        assert np.array_equal(ya.cpu().numpy(), 1.5 * oracle.spmv_csr(ptr, col, val, x))
+    # (c) more than 255 distinct values: diagonal codes only
+    ptr, col, val = _banded(rng, 4000, [-5, 0, 5, 77])
+    S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
+    assert S.nvalues == -1 and S.values is None and S.ndeltas == 4
+    # float matrices, and the SpMat front end
+    ptr, col, val = _banded(rng, 3001, [-5, 0, 5, 77])
+    v32 = np.float32(rng.integers(1, 9, size=len(val)) * 0.125)
+    x32 = (rng.random(3001) - 0.5).astype(np.float32)
+    A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32))
+    assert A.hell.nvalues == 8
+    y = T.torch.empty(3001, dtype=T.torch.float32, device=T.dev)
+    A.apply(T.up(x32), y)
+    assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, x32))
+    for fmt, has_codes, has_values in (("sell8", True, False), ("sell32", False, False), ("sell", True, True)):
+        B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), fmt=fmt)
+        assert (B.hell.deltas is not None) == has_codes and (B.hell.values is not None) == has_values
+        y2 = T.torch.empty_like(y); B.apply(T.up(x32), y2)
+        assert T.torch.equal(y, y2)

@@ -98,6 +98,7 @@ class SpMat {
             long ell_w = 0;
             backend::device_vector<char> sell;                              // columns (or 1-byte diagonal codes) then values, per slice
             backend::device_vector<int> deltas; int ndeltas = -1;           // SELL8: sorted diagonal table (vexhip.h)
+            backend::device_vector<val_t> values; int nvalues = -1;         // SELL8V: sorted value table, values coded too
             vexhip_traversal trav = {0, 0, 0, 0, nullptr};                  // traversal order (grid 0 = plain)
             backend::device_vector<int> csr_ptr, csr_col; backend::device_vector<val_t> csr_val;
             size_t csr_nnz = 0;
@@ -184,8 +185,19 @@ class SpMat {
                 backend::check(vexhip_sell8_analyze_i32(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), w, deltas.raw(), &nd));
                 if (nd > 0) {
                     A.deltas = deltas; A.ndeltas = nd;
-                    A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell8_bytes((int64_t)n, w, (int)sizeof(val_t)));
-                    backend::check(sell8_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, deltas.raw(), nd, A.sell.raw(), &A.trav));
+                    // ... and at most 255 distinct values (constant-coefficient stencils): 1-byte value codes too
+                    backend::device_vector<val_t> values(q, 256);
+                    int nv = -1;
+                    backend::check(sell8v_analyze(dev, q.raw(), (int64_t)n, dptr.raw(), dval.raw(), w, values.raw(), &nv));
+                    if (nv > 0) {
+                        A.values = values; A.nvalues = nv;
+                        A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell8v_bytes((int64_t)n, w));
+                        backend::check(sell8v_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, deltas.raw(), nd,
+                                    values.raw(), nv, A.sell.raw(), &A.trav));
+                    } else {
+                        A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell8_bytes((int64_t)n, w, (int)sizeof(val_t)));
+                        backend::check(sell8_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, deltas.raw(), nd, A.sell.raw(), &A.trav));
+                    }
                 } else {
                     A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell_bytes((int64_t)n, w, (int)sizeof(val_t)));
                     backend::check(sell_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, A.sell.raw()));
@@ -194,6 +206,10 @@ class SpMat {
                 q.finish();
             }
 
+            static int sell8v_analyze(int dev, void *s, int64_t n, const int *p, const double *v, int64_t w, double *vals, int *nv) { return vexhip_sell8v_analyze_f64_i32(dev, s, n, p, v, w, vals, nv); }
+            static int sell8v_analyze(int dev, void *s, int64_t n, const int *p, const float *v, int64_t w, float *vals, int *nv) { return vexhip_sell8v_analyze_f32_i32(dev, s, n, p, v, w, vals, nv); }
+            static int sell8v_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, const int *d, int nd, const double *vals, int nv, void *sl, vexhip_traversal *t) { return vexhip_sell8v_fill_f64_i32(dev, s, n, p, c, v, w, d, nd, vals, nv, sl, t); }
+            static int sell8v_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, const int *d, int nd, const float *vals, int nv, void *sl, vexhip_traversal *t) { return vexhip_sell8v_fill_f32_i32(dev, s, n, p, c, v, w, d, nd, vals, nv, sl, t); }
             static int sell8_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, const int *d, int nd, void *sl, vexhip_traversal *t) { return vexhip_sell8_fill_f64_i32(dev, s, n, p, c, v, w, d, nd, sl, t); }
             static int sell8_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, const int *d, int nd, void *sl, vexhip_traversal *t) { return vexhip_sell8_fill_f32_i32(dev, s, n, p, c, v, w, d, nd, sl, t); }
             static int sell_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, void *sl) { return vexhip_sell_fill_f64_i32(dev, s, n, p, c, v, w, sl); }
@@ -207,6 +223,9 @@ class SpMat {
             static int spmv(int dev, void *s, int64_t n, double a, int app, const matrix_arrays &A, const double *x, double *y) {
                 if (A.ell_w == 0 && A.csr_nnz)      // plain CSR storage: LDS-staged CSR kernel
                     return vexhip_spmv_csr_f64_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
+                if (A.nvalues > 0)
+                    return vexhip_spmv_sell8v_f64_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
                 if (A.ndeltas > 0)
                     return vexhip_spmv_sell8_f64_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
                             A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
@@ -216,6 +235,9 @@ class SpMat {
             static int spmv(int dev, void *s, int64_t n, float a, int app, const matrix_arrays &A, const float *x, float *y) {
                 if (A.ell_w == 0 && A.csr_nnz)
                     return vexhip_spmv_csr_f32_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
+                if (A.nvalues > 0)
+                    return vexhip_spmv_sell8v_f32_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
                 if (A.ndeltas > 0)
                     return vexhip_spmv_sell8_f32_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
                             A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
@@ -247,7 +269,7 @@ class SpMat {
                     if (!append) for (int c = 0; c < k; ++c) backend::check(vexhip_memset(dev, y[c], 0, n * sizeof(val_t), q.raw()));
                     return;
                 }
-                if (loc.ell_w == 0) {           // CSR-only storage: no multi-vector kernel, one product per component
+                if (loc.ell_w == 0 || loc.nvalues > 0) {   // CSR-only or value-coded storage: one (cheap) product per component
                     for (int c = 0; c < k; ++c) backend::check(spmv(dev, q.raw(), (int64_t)n, alpha, append ? 1 : 0, loc, x[c], y[c]));
                     return;
                 }
@@ -416,12 +438,25 @@ struct inline_spmv : expression_base {
         c.src.begin_function_parameters();
         c.src.parameter("long", "ell_w");
         c.src.parameter("const char *", "sell"); c.src.parameter("const int *", "deltas");
+        c.src.parameter("const " + V + " *", "values");
         c.src.parameter("const int *", "csr_row"); c.src.parameter("const int *", "csr_col");
         c.src.parameter("const " + V + " *", "csr_val"); c.src.parameter("const " + V + " *", "in");
         c.src.parameter("ulong", "i");
         c.src.end_function_parameters();
         c.src.new_line() << V << " sum = 0;";
-        c.src.new_line() << "if (deltas)";            // SELL8: 1-byte diagonal codes (include/vexhip.h)
+        c.src.new_line() << "if (values)";            // SELL8V: diagonal codes and value codes (include/vexhip.h)
+        c.src.open("{");
+        c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
+        c.src.new_line() << "const uint *cw = (const uint *)(sell + (i >> 9) * (wp * 2048)) + ((i & 511) >> 1);";
+        c.src.new_line() << "const uint *vw = cw + wp * 256;";
+        c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
+        c.src.open("{");
+        c.src.new_line() << "const int sh = 8 * ((j & 1) * 2 + (i & 1));";
+        c.src.new_line() << "const uint code = (cw[(j >> 1) * 256] >> sh) & 255u;";
+        c.src.new_line() << "if (code != 255u) sum += values[(vw[(j >> 1) * 256] >> sh) & 255u] * in[(long)i + deltas[code]];";
+        c.src.close("}");
+        c.src.close("}");
+        c.src.new_line() << "else if (deltas)";       // SELL8: 1-byte diagonal codes
         c.src.open("{");
         c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
         c.src.new_line() << "const char *slice = sell + (i >> 9) * (wp * 1024 + ell_w * 512 * sizeof(" << V << "));";
@@ -456,13 +491,14 @@ struct inline_spmv : expression_base {
         const std::string V = type_name<T>();
         c.src.parameter("long", name + "_ell_w");
         c.src.parameter("const char *", name + "_sell"); c.src.parameter("const int *", name + "_deltas");
+        c.src.parameter("const " + V + " *", name + "_values");
         c.src.parameter("const int *", name + "_csr_row"); c.src.parameter("const int *", name + "_csr_col");
         c.src.parameter("const " + V + " *", name + "_csr_val"); c.src.parameter("const " + V + " *", name + "_vec");
     }
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
-        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, "
+        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, "
               << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, idx)";
     }
     void set_args(arg_context &a) const {
@@ -471,6 +507,7 @@ struct inline_spmv : expression_base {
         a.krn.push_arg((long)L.ell_w);
         a.krn.push_arg(static_cast<const char *>(L.sell.raw()));
         a.krn.push_arg(static_cast<const int *>(L.ndeltas > 0 ? L.deltas.raw() : nullptr));
+        a.krn.push_arg(static_cast<const T *>(L.nvalues > 0 ? L.values.raw() : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_nnz ? L.csr_ptr.raw() : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_col.raw())); a.krn.push_arg(static_cast<const T *>(L.csr_val.raw()));
         a.krn.push_arg(static_cast<const T *>(x(a.device).raw()));

@@ -31,7 +31,7 @@ namespace {
 constexpr int S8_ROWS = 512;
 constexpr int S8_PAD = 255;
 constexpr int HASH_SLOTS = 1024;
-constexpr int LOCAL_SLOTS = 128;
+constexpr int LOCAL_SLOTS = 512;          // per-workgroup set: twice the 255 entries a table may hold
 constexpr int EMPTY = INT_MIN;
 
 typedef double double2v __attribute__((ext_vector_type(2)));
@@ -137,7 +137,7 @@ void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
 {
     __shared__ int s_set[LOCAL_SLOTS];
     __shared__ int s_over;
-    if (threadIdx.x < LOCAL_SLOTS) s_set[threadIdx.x] = EMPTY;
+    for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) s_set[k] = EMPTY;
     if (threadIdx.x == 0) s_over = 0;
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -153,9 +153,10 @@ void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
         }
     }
     __syncthreads();
-    if (threadIdx.x < LOCAL_SLOTS && s_set[threadIdx.x] != EMPTY) {
+    for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
+        if (s_set[k] == EMPTY) continue;
         bool is_new = false;
-        if (!set_insert(gset, HASH_SLOTS, s_set[threadIdx.x], &is_new)) atomicExch(&info[1], 1);
+        if (!set_insert(gset, HASH_SLOTS, s_set[k], &is_new)) atomicExch(&info[1], 1);
         else if (is_new) atomicAdd(&info[0], 1);
     }
     if (threadIdx.x == 0 && s_over) atomicExch(&info[1], 1);
@@ -205,6 +206,196 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
                 }
             }
             cw[jp * 256] = word;
+        }
+    }
+    __syncthreads();
+    if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// SELL8V: diagonal codes AND value codes.  Matrices assembled from a constant-
+// coefficient stencil hold a handful of distinct VALUES (the 7-point Poisson
+// matrix: 1, -h^-2, 6 h^-2).  When the ELL part uses at most 255 distinct values
+// (bit patterns), each value is stored as one byte -- its position in a sorted
+// table that the kernel keeps in LDS -- next to the one-byte diagonal code: 2
+// instead of 9 bytes per fp64 entry (the reference's answer to such matrices is a
+// separate class, SpMatCCSR; here SpMat detects them).  The arithmetic and its
+// order are unchanged: results stay bit-identical to SELL8 / hybrid ELL / CSR.
+// Slice layout: ceil(w/2) KiB of diagonal codes, then ceil(w/2) KiB of value codes,
+// both packed as in SELL8.
+// ---------------------------------------------------------------------------
+template <typename V> struct bits_of;
+template <> struct bits_of<double> { typedef unsigned long long type; };
+template <> struct bits_of<float> { typedef unsigned type; };
+
+template <typename V, int W>
+__global__ __launch_bounds__(256)
+void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
+        const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
+{
+    __shared__ int s_delta[256];
+    __shared__ V s_value[256];
+    s_delta[threadIdx.x] = deltas[threadIdx.x];
+    s_value[threadIdx.x] = values[threadIdx.x];
+    __syncthreads();
+
+    const long long s = traversal_block(trav, nslices);
+    if (s < 0) return;
+    const int t = threadIdx.x;
+    const long long i = s * S8_ROWS + 2 * t;
+    const int w = W > 0 ? W : ell_w;
+    const int wp = (w + 1) / 2;
+    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + s * ((long long)wp * 2048)) + t;
+    const unsigned *vw = cw + wp * 256;
+
+    V sum[2] = {V(0), V(0)};
+    if constexpr (W > 0) {
+        constexpr int WP = (W + 1) / 2;
+        unsigned c[WP], vc[WP];
+#pragma unroll
+        for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
+        V xv[W][2];
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
+                xv[j][q] = (code != S8_PAD) ? x[i + q + s_delta[code]] : V(0);
+            }
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sh = 8 * ((j & 1) * 2 + q);
+                const unsigned code = (c[j >> 1] >> sh) & 255u;
+                if (code != S8_PAD) sum[q] += s_value[(vc[j >> 1] >> sh) & 255u] * xv[j][q];
+            }
+    } else {
+        for (int j = 0; j < w; ++j) {
+            const unsigned cword = cw[(j >> 1) * 256], vword = vw[(j >> 1) * 256];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sh = 8 * ((j & 1) * 2 + q);
+                const unsigned code = (cword >> sh) & 255u;
+                if (code != S8_PAD) sum[q] += s_value[(vword >> sh) & 255u] * x[i + q + s_delta[code]];
+            }
+        }
+    }
+    if (csr_ptr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (i + q < n)
+                for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (i + q < n) {
+            V o = alpha * sum[q];
+            if (append) o = y[i + q] + o;
+            y[i + q] = o;
+        }
+    }
+}
+
+// distinct value bit patterns of the ELL part: gset = HASH_SLOTS words (all-ones = empty), info as delta_collect_kernel
+template <typename B>
+__device__ __forceinline__ bool vset_insert(B *set, int slots, B v, bool *is_new) {
+    const B empty = ~B(0);
+    unsigned h = (unsigned)((unsigned long long)v * 0x9E3779B97F4A7C15ull >> 40) % (unsigned)slots;
+    for (int probe = 0; probe < slots; ++probe) {
+        B old = atomicCAS(&set[h], empty, v);
+        if (old == empty) { if (is_new) *is_new = true; return true; }
+        if (old == v) return true;
+        h = (h + 1) % (unsigned)slots;
+    }
+    return false;
+}
+
+template <typename V>
+__global__ __launch_bounds__(256)
+void value_collect_kernel(long long n, int w, const int *__restrict__ ptr, const V *__restrict__ val,
+        typename bits_of<V>::type *gset, int *info)
+{
+    typedef typename bits_of<V>::type B;
+    __shared__ B s_set[LOCAL_SLOTS];
+    __shared__ int s_over;
+    for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) s_set[k] = ~B(0);
+    if (threadIdx.x == 0) s_over = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = ptr[i], e = ptr[i + 1];
+        B last = ~B(0);
+        for (int j = 0; j < w && b + j < e; ++j) {
+            B bits; V v = val[b + j];
+            __builtin_memcpy(&bits, &v, sizeof(B));
+            if (bits == ~B(0)) { s_over = 1; continue; }          // the one pattern that cannot be stored (a NaN payload)
+            if (bits == last) continue;
+            last = bits;
+            if (!vset_insert<B>(s_set, LOCAL_SLOTS, bits, nullptr)) s_over = 1;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
+        if (s_set[k] == ~B(0)) continue;
+        bool is_new = false;
+        if (!vset_insert<B>(gset, HASH_SLOTS, s_set[k], &is_new)) atomicExch(&info[1], 1);
+        else if (is_new) atomicAdd(&info[0], 1);
+    }
+    if (threadIdx.x == 0 && s_over) atomicExch(&info[1], 1);
+}
+
+// vtable: sorted value bit patterns (nvalues valid entries)
+template <typename V>
+__global__ __launch_bounds__(256)
+void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int nvalues,
+        const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        const int *__restrict__ table, const V *__restrict__ vtable, char *__restrict__ buf, unsigned long long *counts, int *info)
+{
+    typedef typename bits_of<V>::type B;
+    __shared__ int s_table[256];
+    __shared__ B s_vtable[256];
+    __shared__ unsigned s_cnt[256];
+    s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
+    { V v = threadIdx.x < nvalues ? vtable[threadIdx.x] : V(0); B b; __builtin_memcpy(&b, &v, sizeof(B)); s_vtable[threadIdx.x] = threadIdx.x < nvalues ? b : ~B(0); }
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int wp = (w + 1) / 2;
+    for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (S8_ROWS / 2);
+         pr += (long long)gridDim.x * blockDim.x) {
+        const long long s = pr / (S8_ROWS / 2);
+        const int t = (int)(pr % (S8_ROWS / 2));
+        unsigned *cw = reinterpret_cast<unsigned *>(buf + s * ((long long)wp * 2048)) + t;
+        unsigned *vw = cw + wp * 256;
+        int b[2] = {0, 0}, e[2] = {0, 0};
+        const long long i = s * S8_ROWS + 2 * t;
+        for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
+        for (int jp = 0; jp < wp; ++jp) {
+            unsigned word = 0, vword = 0;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                for (int q = 0; q < 2; ++q) {
+                    unsigned code = S8_PAD, vcode = 0;
+                    if (j < w && b[q] + j < e[q]) {
+                        const int d = (int)((long long)col[b[q] + j] - (i + q));
+                        int lo = 0, hi = ndeltas;
+                        while (lo < hi) { int mid = (lo + hi) >> 1; if (s_table[mid] < d) lo = mid + 1; else hi = mid; }
+                        if (lo < ndeltas && s_table[lo] == d) { code = (unsigned)lo; atomicAdd(&s_cnt[lo], 1u); }
+                        else atomicExch(&info[1], 1);
+                        B bits; V v = val[b[q] + j];
+                        __builtin_memcpy(&bits, &v, sizeof(B));
+                        lo = 0; hi = nvalues;
+                        while (lo < hi) { int mid = (lo + hi) >> 1; if (s_vtable[mid] < bits) lo = mid + 1; else hi = mid; }
+                        if (lo < nvalues && s_vtable[lo] == bits) vcode = (unsigned)lo;
+                        else atomicExch(&info[1], 1);
+                    }
+                    word |= code << (8 * (jj * 2 + q));
+                    vword |= vcode << (8 * (jj * 2 + q));
+                }
+            }
+            cw[jp * 256] = word;
+            vw[jp * 256] = vword;
         }
     }
     __syncthreads();
@@ -314,6 +505,94 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     return 0;
 }
 
+template <typename V>
+int sell8v_analyze(int dev, void *stream, int64_t n, const int *ptr, const V *val, int64_t w, V *values, int *nvalues)
+{
+    typedef typename bits_of<V>::type B;
+    VEXHIP_REQUIRE(nvalues && values, "NULL output");
+    *nvalues = -1;
+    if (n <= 0 || w < 1) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    B *d = nullptr;
+    VEXHIP_TRY(hipMalloc(&d, sizeof(B) * HASH_SLOTS + 2 * sizeof(int)));
+    int *dinfo = reinterpret_cast<int *>(d + HASH_SLOTS);
+    VEXHIP_TRY(hipMemsetAsync(d, 0xff, sizeof(B) * HASH_SLOTS, s));
+    VEXHIP_TRY(hipMemsetAsync(dinfo, 0, 2 * sizeof(int), s));
+    value_collect_kernel<V><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, val, d, dinfo);
+    std::vector<B> host(HASH_SLOTS);
+    int hinfo[2] = {0, 0};
+    VEXHIP_TRY(hipMemcpyAsync(host.data(), d, sizeof(B) * HASH_SLOTS, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(hinfo, dinfo, sizeof(hinfo), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    VEXHIP_TRY(hipFree(d));
+    if (hinfo[1] != 0 || hinfo[0] > 255 || hinfo[0] < 1) return 0;          // too many distinct values: keep them as they are
+    std::vector<B> table;
+    for (B b : host) if (b != ~B(0)) table.push_back(b);
+    std::sort(table.begin(), table.end());                                    // sorted by bit pattern (what the fill kernel searches)
+    if ((int)table.size() != hinfo[0]) return fail(__FILE__, __LINE__, "value set is inconsistent");
+    std::vector<V> vals(256, V(0));
+    for (size_t k = 0; k < table.size(); ++k) __builtin_memcpy(&vals[k], &table[k], sizeof(B));
+    VEXHIP_TRY(hipMemcpyAsync(values, vals.data(), sizeof(V) * 256, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    *nvalues = hinfo[0];
+    return 0;
+}
+
+template <typename V>
+int sell8v_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w,
+        const int *deltas, int ndeltas, const V *values, int nvalues, void *buf, vexhip_traversal *trav)
+{
+    VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 255 && nvalues >= 1 && nvalues <= 255, "bad SELL8V geometry");
+    if (trav) std::memset(trav, 0, sizeof(*trav));
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(ptr && col && val && deltas && values && buf, "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
+    unsigned long long *dcounts = nullptr;
+    VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 2 * sizeof(int)));
+    int *dinfo = reinterpret_cast<int *>(dcounts + 256);
+    VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
+    sell8v_fill_kernel<V><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, nvalues, ptr, col, val, deltas, values,
+            static_cast<char *>(buf), dcounts, dinfo);
+    std::vector<unsigned long long> counts(256);
+    std::vector<int> table(ndeltas);
+    int hinfo[2] = {0, 0};
+    VEXHIP_TRY(hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(hinfo, dinfo, sizeof(hinfo), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * ndeltas, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    VEXHIP_TRY(hipFree(dcounts));
+    VEXHIP_REQUIRE(hinfo[1] == 0, "SELL8V fill: a diagonal or a value of the matrix is not in its table");
+    if (trav) strip_traversal(n, table, counts, trav);
+    return 0;
+}
+
+template <typename V>
+int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w, const void *buf, const int *deltas, const V *values,
+        const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr)
+{
+    VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL8V geometry");
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(buf && deltas && values && x && y && (reinterpret_cast<uintptr_t>(buf) & 15) == 0, "SELL8V buffer must be 16-byte aligned");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
+    long long grid = 0;
+    const trav_dev t8 = make_traversal(tr, ns, &grid);
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    const char *b = static_cast<const char *>(buf);
+#define CASE(W) case W: sell8v_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8); break;
+    switch (w) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+        default: sell8v_kernel<V, 0><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8);
+    }
+#undef CASE
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 } // namespace
 } // namespace vexhip
 
@@ -354,6 +633,29 @@ int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *pt
     *ndeltas = host[HASH_SLOTS];
     return 0;
 }
+
+int64_t vexhip_sell8v_bytes(int64_t n, int64_t w) { return (n + S8_ROWS - 1) / S8_ROWS * ((w + 1) / 2) * 2048; }
+
+int vexhip_sell8v_analyze_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const double *val, int64_t w, double *values, int *nvalues)
+{ return sell8v_analyze<double>(dev, stream, n, ptr, val, w, values, nvalues); }
+int vexhip_sell8v_analyze_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const float *val, int64_t w, float *values, int *nvalues)
+{ return sell8v_analyze<float>(dev, stream, n, ptr, val, w, values, nvalues); }
+
+int vexhip_sell8v_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val, int64_t w,
+        const int32_t *deltas, int ndeltas, const double *values, int nvalues, void *buf, vexhip_traversal *traversal)
+{ return sell8v_fill<double>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, traversal); }
+int vexhip_sell8v_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val, int64_t w,
+        const int32_t *deltas, int ndeltas, const float *values, int nvalues, void *buf, vexhip_traversal *traversal)
+{ return sell8v_fill<float>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, traversal); }
+
+int vexhip_spmv_sell8v_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *buf,
+        const int32_t *deltas, const double *values, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *x, double *y, const vexhip_traversal *traversal)
+{ return spmv_sell8v<double>(dev, stream, n, alpha, append, w, buf, deltas, values, cp, cc, cv, x, y, traversal); }
+int vexhip_spmv_sell8v_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *buf,
+        const int32_t *deltas, const float *values, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *x, float *y, const vexhip_traversal *traversal)
+{ return spmv_sell8v<float>(dev, stream, n, alpha, append, w, buf, deltas, values, cp, cc, cv, x, y, traversal); }
 
 int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
         int rows_per_block, vexhip_traversal *traversal)

@@ -204,7 +204,7 @@ class SlicedELL:
     stencil matrices) the columns are stored as 1-byte diagonal codes ("SELL8",
     9 instead of 12 bytes per fp64 entry); other matrices keep 32-bit columns."""
 
-    def __init__(self, ptr, col, val, tiled=True, order_mode=0, codes=True):
+    def __init__(self, ptr, col, val, tiled=True, order_mode=0, codes=True, value_codes=True):
         L = lib()
         self.n = n = ptr.numel() - 1
         self.dtype = val.dtype
@@ -215,6 +215,7 @@ class SlicedELL:
         if not self.width:
             raise Error("SlicedELL needs a non-empty ELL part")
         self.deltas, self.ndeltas = None, -1
+        self.values, self.nvalues = None, -1
         self.csr_ptr = self.csr_col = self.csr_val = None
         f64 = val.dtype == torch.float64
         if self.tail_nnz:
@@ -234,8 +235,24 @@ class SlicedELL:
             L.sell8_analyze_i32(dev, s, n, _p(ptr), _p(col), self.width, _p(deltas), ctypes.byref(nd))
             if nd.value > 0:
                 self.deltas, self.ndeltas = deltas, int(nd.value)
-                self.sell = torch.empty(L.sell8_bytes(n, self.width, vb), dtype=torch.uint8, device=d)
                 trav = _capi.Traversal()
+                if value_codes:
+                    # ... and at most 255 distinct VALUES (constant-coefficient stencils): 1-byte value codes too
+                    values = torch.empty(256, dtype=val.dtype, device=d)
+                    nv = ctypes.c_int(-1)
+                    (L.sell8v_analyze_f64_i32 if f64 else L.sell8v_analyze_f32_i32)(
+                        dev, s, n, _p(ptr), _p(val), self.width, _p(values), ctypes.byref(nv))
+                    if nv.value > 0:
+                        self.values, self.nvalues = values, int(nv.value)
+                        self.sell = torch.empty(L.sell8v_bytes(n, self.width), dtype=torch.uint8, device=d)
+                        (L.sell8v_fill_f64_i32 if f64 else L.sell8v_fill_f32_i32)(
+                            dev, s, n, _p(ptr), _p(col), _p(val), self.width, _p(deltas), self.ndeltas, _p(values), self.nvalues,
+                            _p(self.sell), ctypes.byref(trav))
+                        if tiled and order_mode == 0:
+                            self.trav = trav
+                        self.order_grid = int(self.trav.grid_blocks)
+                        return
+                self.sell = torch.empty(L.sell8_bytes(n, self.width, vb), dtype=torch.uint8, device=d)
                 (L.sell8_fill_f64_i32 if f64 else L.sell8_fill_f32_i32)(
                     dev, s, n, _p(ptr), _p(col), _p(val), self.width, _p(deltas), self.ndeltas, _p(self.sell),
                     ctypes.byref(trav))
@@ -258,6 +275,12 @@ class SlicedELL:
         f64 = self.dtype == torch.float64
         a = ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha)
         use = bool(tiled and self.order_grid)
+        if self.values is not None:
+            (L.spmv_sell8v_f64_i32 if f64 else L.spmv_sell8v_f32_i32)(
+                _dev(y), _stream(y), self.n, a, int(bool(append)), self.width, _p(self.sell), _p(self.deltas), _p(self.values),
+                _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), _p(x), _p(y),
+                ctypes.byref(self.trav) if use else None)
+            return y
         if self.deltas is not None:
             (L.spmv_sell8_f64_i32 if f64 else L.spmv_sell8_f32_i32)(
                 _dev(y), _stream(y), self.n, a, int(bool(append)), self.width, _p(self.sell), _p(self.deltas),
@@ -284,6 +307,10 @@ class SlicedELL:
         xp = (ctypes.c_void_p * k)(*[_p(x) for x in xs])
         yp = (ctypes.c_void_p * k)(*[_p(y) for y in ys])
         trav = ctypes.byref(self.trav) if use else None
+        if self.values is not None:                  # value-coded storage: one (cheap) product per component
+            for x, y in zip(xs, ys):
+                self.mul(x, y, alpha, append, tiled)
+            return ys
         if self.deltas is not None:
             (L.spmm_sell8_f64_i32 if f64 else L.spmm_sell8_f32_i32)(
                 _dev(ys[0]), _stream(ys[0]), self.n, k, a, int(bool(append)), self.width, _p(self.sell), _p(self.deltas),
@@ -313,12 +340,14 @@ class SpMat:
         self.m = self.n if n_cols is None else n_cols
         if fmt == "auto":
             fmt = "sell" if (ptr.dtype == torch.int32 and col.dtype == torch.int32) else "csr"
-        if fmt not in ("sell", "hell", "csr"):
+        if fmt not in ("sell", "sell8", "sell32", "hell", "csr"):
             raise Error("unknown SpMat format %r" % fmt)
         self.hell = None
-        if fmt == "sell":
+        if fmt in ("sell", "sell8", "sell32"):
             try:
-                self.hell = SlicedELL(ptr, col, val)
+                # sell: the most compact storage the matrix allows; sell8 / sell32 pin a less compact one (A/B, tests)
+                self.hell = SlicedELL(ptr, col, val, codes=fmt != "sell32", value_codes=fmt == "sell")
+                fmt = "sell"
             except Error:                        # ELL width 0 (mostly empty rows): CSR is the format
                 fmt = "csr"
         elif fmt == "hell":
