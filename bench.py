@@ -282,6 +282,9 @@ def main():
                        "format": fmt, "rows_per_gpu": r1 - r0,
                        "parallelism": "row-partitioned x%d" % world},
             "roofline": {"bound": "hbm",
+                         # achieved / frac follow the contract: ALGORITHMIC (CSR-format) bytes over the launch time.  A
+                         # format that stores fewer bytes than CSR moves less than that -- `traffic` (PMC) says how much
+                         # -- so frac can exceed 1; traffic_gbps / traffic_frac_of_peak are what crosses the HBM pins.
                          "achieved": round(alg_rank / kern_s / 1e9, 1),
                          "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s",
@@ -316,6 +319,27 @@ def main():
                 hell = None
                 del A
                 torch.cuda.empty_cache()
+                if fmt in ("sell8v", "sell8"):
+                    # the same product with less compact storage of the same matrix, for comparison: values as they
+                    # are (diagonal codes only), and plain 32-bit columns (what a matrix without structure gets)
+                    p2, c2, v2 = ops.poisson3d(n, dev)
+                    xx = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
+                    yy = torch.empty_like(xx)
+                    for f2, label in (("sell8", "diagonal codes, fp64 values stored"), ("sell32", "32-bit columns, fp64 values stored")):
+                        if f2 == fmt:
+                            continue
+                        B = ops.SpMat(p2, c2, v2, fmt=f2)
+                        B.apply(xx, yy); torch.cuda.synchronize()
+                        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ev0.record()
+                        for _ in range(20):
+                            B.apply(xx, yy)
+                        ev1.record(); torch.cuda.synchronize()
+                        tb = ev0.elapsed_time(ev1) / 20
+                        sec["SpMV same matrix, %s" % label] = {"ms": round(tb, 4), "gflops": round(2.0 * nnz_total / tb / 1e6, 1)}
+                        del B
+                    del p2, c2, v2, xx, yy
+                    torch.cuda.empty_cache()
                 sec.update(secondary_rows(torch, L, ops, dev, local_rank))
                 out["secondary"] = sec
             except Exception as e:                   # the headline must not depend on the secondary rows

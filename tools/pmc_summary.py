@@ -21,7 +21,7 @@ def rows(pattern):
 
 
 def short(name):
-    for k in ("sell8_kernel", "sell_kernel", "hell_kernel", "csr_stream_kernel", "reduce_stage1", "reduce_stage2", "poisson_kernel",
+    for k in ("spmm_sell8_kernel", "spmm_sell_kernel", "sell8v_kernel", "sell8_kernel", "sell_kernel", "hell_kernel", "csr_stream_kernel", "reduce_stage1", "reduce_stage2", "poisson_kernel",
               "hell_fill_kernel", "fill_hash_kernel"):
         if k in name:
             return k
@@ -49,7 +49,7 @@ def main():
         raw = avg["reduce_stage1"]["FETCH_SIZE"] * 1024        # FETCH_SIZE is in KiB
         res["fetch_calibration"] = dict(known_bytes=cal_bytes, reported_bytes=raw, factor=cal_bytes / raw)
         f = cal_bytes / raw
-        for k in ("sell8_kernel", "sell_kernel", "hell_kernel", "csr_stream_kernel"):
+        for k in ("sell8v_kernel", "sell8_kernel", "sell_kernel", "hell_kernel", "csr_stream_kernel"):
             if k in avg and "FETCH_SIZE" in avg[k]:
                 rd = avg[k]["FETCH_SIZE"] * 1024 * f
                 wr = avg[k].get("WRITE_SIZE", 0.0) * 1024

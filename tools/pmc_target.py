@@ -17,9 +17,9 @@ x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
 y = torch.zeros(N, dtype=torch.float64, device=dev)
 A_csr = ops.SpMat(ptr, col, val, fmt="csr")
 A_ell = ops.SpMat(ptr, col, val, fmt="hell")
-A_sell = ops.SpMat(ptr, col, val, fmt="sell")            # SELL8 on this matrix
-A_sell32 = ops.SpMat(ptr, col, val, fmt="sell")
-A_sell32.hell = ops.SlicedELL(ptr, col, val, codes=False)
+A_sell = ops.SpMat(ptr, col, val, fmt="sell")            # SELL8V on this matrix (diagonal + value codes)
+A_sell8 = ops.SpMat(ptr, col, val, fmt="sell8")          # diagonal codes, values as they are
+A_sell32 = ops.SpMat(ptr, col, val, fmt="sell32")        # 32-bit columns
 # calibration stream: 2 GiB read by the reduction kernel (16-byte loads), known byte count
 cal = torch.empty(1 << 28, dtype=torch.float64, device=dev).normal_()
 r = ops.Reductor("SUM")
@@ -32,6 +32,8 @@ for _ in range(3):
     A_csr.apply(x, y)
 for _ in range(3):
     A_sell.apply(x, y)
+for _ in range(3):
+    A_sell8.apply(x, y)
 for _ in range(3):
     A_sell32.apply(x, y)
 torch.cuda.synchronize()
