@@ -251,6 +251,12 @@ int vexhip_spmm_sell8_f64_i32(int dev, void *stream, int64_t n, int nrhs, double
 int vexhip_spmm_sell8_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t ell_width,
         const void *buf, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *const *x, float *const *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell8v_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell8v_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t ell_width,
+        const void *buf, const int32_t *deltas, const float *values, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal);
 int vexhip_spmm_sell_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
         const void *sell, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
         const double *const *x, double *const *y, const vexhip_traversal *traversal);

@@ -246,6 +246,9 @@ class SpMat {
             }
 
             static int spmm(int dev, void *s, int64_t n, int k, double a, int app, const matrix_arrays &A, const double *const *x, double *const *y) {
+                if (A.nvalues > 0)
+                    return vexhip_spmm_sell8v_f64_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
                 if (A.ndeltas > 0)
                     return vexhip_spmm_sell8_f64_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
                             A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
@@ -253,6 +256,9 @@ class SpMat {
                         A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
             }
             static int spmm(int dev, void *s, int64_t n, int k, float a, int app, const matrix_arrays &A, const float *const *x, float *const *y) {
+                if (A.nvalues > 0)
+                    return vexhip_spmm_sell8v_f32_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
+                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
                 if (A.ndeltas > 0)
                     return vexhip_spmm_sell8_f32_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
                             A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
@@ -269,7 +275,7 @@ class SpMat {
                     if (!append) for (int c = 0; c < k; ++c) backend::check(vexhip_memset(dev, y[c], 0, n * sizeof(val_t), q.raw()));
                     return;
                 }
-                if (loc.ell_w == 0 || loc.nvalues > 0) {   // CSR-only or value-coded storage: one (cheap) product per component
+                if (loc.ell_w == 0) {           // CSR-only storage: no multi-vector kernel, one product per component
                     for (int c = 0; c < k; ++c) backend::check(spmv(dev, q.raw(), (int64_t)n, alpha, append ? 1 : 0, loc, x[c], y[c]));
                     return;
                 }

@@ -124,6 +124,8 @@ _PROTOS = {
     "vexhip_spmv_sell8v_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmm_sell8v_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmm_sell8v_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Traversal)]),
     "vexhip_hell_analyze_i32": (None, [c_int, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),

@@ -127,6 +127,79 @@ void spmm_sell8_kernel(long long n, long long nslices, V alpha, int append, int 
     tail_and_store<V, NR>(n, i, alpha, append, csr_ptr, csr_col, csr_val, io, sum);
 }
 
+// ---- SELL8V: diagonal codes and value codes (layout: sell8.hip) -----------------------------
+template <typename V, int W, int NR>
+__global__ __launch_bounds__(256)
+void spmm_sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
+        const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        rhs_set<V> io, trav_dev trav)
+{
+    __shared__ int s_delta[256];
+    __shared__ V s_value[256];
+    s_delta[threadIdx.x] = deltas[threadIdx.x];
+    s_value[threadIdx.x] = values[threadIdx.x];
+    __syncthreads();
+
+    const long long s = traversal_block(trav, nslices);
+    if (s < 0) return;
+    const int t = threadIdx.x;
+    const long long i = s * ROWS + 2 * t;
+    const int w = W > 0 ? W : ell_w;
+    const int wp = (w + 1) / 2;
+    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + s * ((long long)wp * 2048)) + t;
+    const unsigned *vw = cw + wp * 256;
+
+    V sum[NR][2];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { sum[k][0] = V(0); sum[k][1] = V(0); }
+
+    if constexpr (W > 0) {
+        constexpr int WP = (W + 1) / 2;
+        unsigned c[WP], vc[WP];
+#pragma unroll
+        for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
+        long long col[W][2]; V val[W][2];
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sh = 8 * ((j & 1) * 2 + q);
+                const unsigned code = (c[j >> 1] >> sh) & 255u;
+                col[j][q] = (code != PAD8) ? i + q + s_delta[code] : -1;
+                val[j][q] = s_value[(vc[j >> 1] >> sh) & 255u];
+            }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            V xv[W][2];
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xv[j][q] = (col[j][q] >= 0) ? io.x[k][col[j][q]] : V(0);
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) if (col[j][q] >= 0) sum[k][q] += val[j][q] * xv[j][q];
+        }
+    } else {
+        for (int j = 0; j < w; ++j) {
+            const unsigned cword = cw[(j >> 1) * 256], vword = vw[(j >> 1) * 256];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sh = 8 * ((j & 1) * 2 + q);
+                const unsigned code = (cword >> sh) & 255u;
+                if (code != PAD8) {
+                    const long long cidx = i + q + s_delta[code];
+                    const V v = s_value[(vword >> sh) & 255u];
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) sum[k][q] += v * io.x[k][cidx];
+                }
+            }
+        }
+    }
+    tail_and_store<V, NR>(n, i, alpha, append, csr_ptr, csr_col, csr_val, io, sum);
+}
+
 // ---- SELL-512 with 32-bit columns (layout: spmv.hip) ---------------------------------------
 template <typename V, int W, int NR>
 __global__ __launch_bounds__(256)
@@ -183,13 +256,15 @@ void spmm_sell_kernel(long long n, long long nslices, V alpha, int append, int e
     tail_and_store<V, NR>(n, i, alpha, append, csr_ptr, csr_col, csr_val, io, sum);
 }
 
-template <typename V, bool CODES, int NR>
+// CODES: 0 = 32-bit columns, 1 = diagonal codes, 2 = diagonal and value codes
+template <typename V, int CODES, int NR>
 void launch(hipStream_t s, long long grid, long long n, long long ns, V alpha, int append, int w, const char *buf,
-        const int *deltas, const int *cp, const int *cc, const V *cv, const rhs_set<V> &io, const trav_dev &t)
+        const int *deltas, const V *values, const int *cp, const int *cc, const V *cv, const rhs_set<V> &io, const trav_dev &t)
 {
 #define LAUNCH(W)                                                                                              \
     do {                                                                                                       \
-        if constexpr (CODES) spmm_sell8_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, cp, cc, cv, io, t); \
+        if constexpr (CODES == 2) spmm_sell8v_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, values, cp, cc, cv, io, t); \
+        else if constexpr (CODES == 1) spmm_sell8_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, cp, cc, cv, io, t); \
         else spmm_sell_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, cp, cc, cv, io, t);               \
     } while (0)
     switch (w) {          // unrolled for the usual stencil widths (1-D, 2-D 5/9-point, 3-D 7-point); any other width loops
@@ -202,13 +277,13 @@ void launch(hipStream_t s, long long grid, long long n, long long ns, V alpha, i
 #undef LAUNCH
 }
 
-template <typename V, bool CODES>
-int spmm(int dev, void *stream, int64_t n, int nrhs, V alpha, int append, int64_t w, const void *buf, const int *deltas,
+template <typename V, int CODES>
+int spmm(int dev, void *stream, int64_t n, int nrhs, V alpha, int append, int64_t w, const void *buf, const int *deltas, const V *values,
         const int *cp, const int *cc, const V *cv, const V *const *x, V *const *y, const vexhip_traversal *tr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20) && nrhs >= 1, "bad SpMM geometry");
     if (n == 0) return 0;
-    VEXHIP_REQUIRE(buf && x && y && (!CODES || deltas) && (reinterpret_cast<uintptr_t>(buf) & 15) == 0,
+    VEXHIP_REQUIRE(buf && x && y && (CODES == 0 || deltas) && (CODES != 2 || values) && (reinterpret_cast<uintptr_t>(buf) & 15) == 0,
             "NULL argument or misaligned matrix buffer");
     for (int k = 0; k < nrhs; ++k) VEXHIP_REQUIRE(x[k] && y[k], "NULL right-hand side or result");
     VEXHIP_SET_DEVICE(dev);
@@ -223,10 +298,10 @@ int spmm(int dev, void *stream, int64_t n, int nrhs, V alpha, int append, int64_
         rhs_set<V> io;
         for (int k = 0; k < MAX_NR; ++k) { io.x[k] = x[k0 + (k < nr ? k : 0)]; io.y[k] = y[k0 + (k < nr ? k : 0)]; }
         switch (nr) {
-            case 1: launch<V, CODES, 1>(s, grid, n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, io, t); break;
-            case 2: launch<V, CODES, 2>(s, grid, n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, io, t); break;
-            case 3: launch<V, CODES, 3>(s, grid, n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, io, t); break;
-            default: launch<V, CODES, 4>(s, grid, n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, io, t);
+            case 1: launch<V, CODES, 1>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t); break;
+            case 2: launch<V, CODES, 2>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t); break;
+            case 3: launch<V, CODES, 3>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t); break;
+            default: launch<V, CODES, 4>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t);
         }
         VEXHIP_LAUNCH_CHECK();
     }
@@ -243,21 +318,31 @@ extern "C" {
 int vexhip_spmm_sell8_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t w,
         const void *buf, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const double *cv,
         const double *const *x, double *const *y, const vexhip_traversal *traversal)
-{ return spmm<double, true>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal); }
+{ return spmm<double, 1>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, nullptr, cp, cc, cv, x, y, traversal); }
 
 int vexhip_spmm_sell8_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t w,
         const void *buf, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const float *cv,
         const float *const *x, float *const *y, const vexhip_traversal *traversal)
-{ return spmm<float, true>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal); }
+{ return spmm<float, 1>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, nullptr, cp, cc, cv, x, y, traversal); }
 
 int vexhip_spmm_sell_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t w,
         const void *sell, const int32_t *cp, const int32_t *cc, const double *cv,
         const double *const *x, double *const *y, const vexhip_traversal *traversal)
-{ return spmm<double, false>(dev, stream, n, nrhs, alpha, append, w, sell, nullptr, cp, cc, cv, x, y, traversal); }
+{ return spmm<double, 0>(dev, stream, n, nrhs, alpha, append, w, sell, nullptr, nullptr, cp, cc, cv, x, y, traversal); }
 
 int vexhip_spmm_sell_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t w,
         const void *sell, const int32_t *cp, const int32_t *cc, const float *cv,
         const float *const *x, float *const *y, const vexhip_traversal *traversal)
-{ return spmm<float, false>(dev, stream, n, nrhs, alpha, append, w, sell, nullptr, cp, cc, cv, x, y, traversal); }
+{ return spmm<float, 0>(dev, stream, n, nrhs, alpha, append, w, sell, nullptr, nullptr, cp, cc, cv, x, y, traversal); }
+
+int vexhip_spmm_sell8v_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t w,
+        const void *buf, const int32_t *deltas, const double *values, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal)
+{ return spmm<double, 2>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, values, cp, cc, cv, x, y, traversal); }
+
+int vexhip_spmm_sell8v_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t w,
+        const void *buf, const int32_t *deltas, const float *values, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal)
+{ return spmm<float, 2>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, values, cp, cc, cv, x, y, traversal); }
 
 } // extern "C"

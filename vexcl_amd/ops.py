@@ -307,9 +307,10 @@ class SlicedELL:
         xp = (ctypes.c_void_p * k)(*[_p(x) for x in xs])
         yp = (ctypes.c_void_p * k)(*[_p(y) for y in ys])
         trav = ctypes.byref(self.trav) if use else None
-        if self.values is not None:                  # value-coded storage: one (cheap) product per component
-            for x, y in zip(xs, ys):
-                self.mul(x, y, alpha, append, tiled)
+        if self.values is not None:
+            (L.spmm_sell8v_f64_i32 if f64 else L.spmm_sell8v_f32_i32)(
+                _dev(ys[0]), _stream(ys[0]), self.n, k, a, int(bool(append)), self.width, _p(self.sell), _p(self.deltas),
+                _p(self.values), _p(self.csr_ptr), _p(self.csr_col), _p(self.csr_val), xp, yp, trav)
             return ys
         if self.deltas is not None:
             (L.spmm_sell8_f64_i32 if f64 else L.spmm_sell8_f32_i32)(
