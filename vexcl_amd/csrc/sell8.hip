@@ -108,14 +108,7 @@ void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (i + q < n) {
-            V o = alpha * sum[q];
-            if (append) o = y[i + q] + o;
-            y[i + q] = o;
-        }
-    }
+    store_pair<V>(n, i, alpha, append, sum, y);
 }
 
 // ---- set-up: which diagonals does the ELL part use? ------------------------------------
@@ -289,14 +282,7 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (i + q < n) {
-            V o = alpha * sum[q];
-            if (append) o = y[i + q] + o;
-            y[i + q] = o;
-        }
-    }
+    store_pair<V>(n, i, alpha, append, sum, y);
 }
 
 // distinct value bit patterns of the ELL part: gset = HASH_SLOTS words (all-ones = empty), info as delta_collect_kernel

@@ -328,14 +328,7 @@ void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (i + q < n) {
-            V o = alpha * sum[q];
-            if (append) o = y[i + q] + o;
-            y[i + q] = o;
-        }
-    }
+    store_pair<V>(n, i, alpha, append, sum, y);
 }
 
 template <typename V>

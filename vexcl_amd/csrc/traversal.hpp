@@ -23,6 +23,27 @@ __device__ __forceinline__ long long traversal_block(const trav_dev &t, long lon
     return b < nblocks ? b : -1;
 }
 
+/// y[i], y[i+1] (=|+=) alpha * sum[0], sum[1] -- the two consecutive rows a lane of the SELL kernels owns.
+/// One 16-byte store (and load, for +=) when both rows exist and y is 16-byte aligned: i is even.
+template <typename V>
+__device__ __forceinline__ void store_pair(long long n, long long i, V alpha, int append, const V (&sum)[2], V *__restrict__ y) {
+    typedef V v2 __attribute__((ext_vector_type(2)));
+    if (i + 1 < n && (reinterpret_cast<unsigned long long>(y) & (2 * sizeof(V) - 1)) == 0) {
+        v2 *yp = reinterpret_cast<v2 *>(y + i);
+        v2 o; o.x = alpha * sum[0]; o.y = alpha * sum[1];
+        if (append) { const v2 old = *yp; o.x = old.x + o.x; o.y = old.y + o.y; *yp = o; }
+        else __builtin_nontemporal_store(o, yp);              // y is written once and not re-read by this kernel
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (i + q < n) {
+                V o = alpha * sum[q];
+                if (append) o = y[i + q] + o;
+                y[i + q] = o;
+            }
+    }
+}
+
 /// Grid size and device-side description of a host traversal (NULL / grid 0 = plain order).
 inline trav_dev make_traversal(const vexhip_traversal *tr, long long nblocks, long long *grid) {
     trav_dev t = {nullptr, 0, 0, 0};
