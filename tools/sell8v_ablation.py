@@ -43,7 +43,19 @@ extern "C" __global__ void __launch_bounds__(256) k(long long n, long long ns, c
   #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
-#if MODE == 1          /* no gathers: x[i+q] only */
+#if MODE == 7          /* rows 2t and 2t+1 on the same even diagonal: ONE 16-byte load of x */
+      if (q == 0) {
+        const unsigned code1 = (c[j >> 1] >> (8 * ((j & 1) * 2 + 1))) & 255u;
+        const int d0 = code != 255u ? s_delta[code] : 1;
+        if (code == code1 && !(d0 & 1)) {
+          const double2 p = *(const double2 *)(x + i + d0);
+          xv[j][0] = p.x; xv[j][1] = p.y;
+        } else {
+          xv[j][0] = code != 255u ? x[i + d0] : 0.0;
+          xv[j][1] = code1 != 255u ? x[i + 1 + s_delta[code1]] : 0.0;
+        }
+      }
+#elif MODE == 1          /* no gathers: x[i+q] only */
       xv[j][q] = code != 255u ? x[i + q] * (double)s_delta[code] : 0.0;
 #elif MODE == 4 || MODE == 5        /* no delta table: offsets by arithmetic on the code */
       xv[j][q] = code != 255u ? x[i + q + ((long long)code - 3)] : 0.0;
@@ -78,8 +90,8 @@ class Trav(ctypes.Structure):
     _fields_ = [("chunk", ctypes.c_int), ("planes", ctypes.c_int), ("plane_blocks", ctypes.c_int)]
 tr = Trav(int(S.trav.chunk), int(S.trav.planes), int(S.trav.plane_blocks))
 grid = int(S.trav.grid_blocks); ns = (N + 511) // 512
-names = {0: "full", 1: "no gathers (x[i] only)", 2: "no value table", 3: "no y store", 4: "no delta table (+-3 window)", 5: "no LDS at all", 6: "non-temporal y store"}
-for mode in (0, 6, 3, 0, 6):
+names = {0: "full", 1: "no gathers (x[i] only)", 2: "no value table", 3: "no y store", 4: "no delta table (+-3 window)", 5: "no LDS at all", 6: "non-temporal y store", 7: "paired 16-byte x loads"}
+for mode in (0, 7, 0, 7):
     mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
     L.module_compile(0, ("#define MODE %d\n" % mode + SRC).encode(), b"-ffp-contract=off", ctypes.byref(mod))
     L.module_get_function(0, mod, b"k", ctypes.byref(fn))

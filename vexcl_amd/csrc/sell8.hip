@@ -131,9 +131,12 @@ void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
     __shared__ int s_set[LOCAL_SLOTS];
     __shared__ int s_over;
     for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) s_set[k] = EMPTY;
-    if (threadIdx.x == 0) s_over = 0;
+    if (threadIdx.x == 0) s_over = *(volatile int *)&info[1];
     __syncthreads();
+    // a matrix without structure overflows the set at once: stop looking (a full set costs a whole probe
+    // sequence per insertion) -- s_over starts from the global flag, so later workgroups do not even begin
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (*(volatile int *)&s_over) break;
         const int b = ptr[i], e = ptr[i + 1];
         int last = EMPTY;
         for (int j = 0; j < w && b + j < e; ++j) {
@@ -308,9 +311,10 @@ void value_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
     __shared__ B s_set[LOCAL_SLOTS];
     __shared__ int s_over;
     for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) s_set[k] = ~B(0);
-    if (threadIdx.x == 0) s_over = 0;
+    if (threadIdx.x == 0) s_over = *(volatile int *)&info[1];
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (*(volatile int *)&s_over) break;
         const int b = ptr[i], e = ptr[i + 1];
         B last = ~B(0);
         for (int j = 0; j < w && b + j < e; ++j) {
