@@ -27,6 +27,19 @@ __device__ inline long long slot(const trav t, long long nblocks) {
 extern "C" __global__ void __launch_bounds__(256) k(long long n, long long ns, const char *buf, const int *deltas, const double *values,
     const double *x, double *y, trav tr) {
   __shared__ int s_delta[256]; __shared__ double s_value[256];
+#if MODE == 8
+  const long long s = slot(tr, ns);
+  const int t = threadIdx.x; const long long i = s * 512 + 2 * t;
+  unsigned c[WP], vc[WP];
+  if (s >= 0) {
+    const unsigned *cw = (const unsigned *)(buf + s * (WP * 2048ll)) + t; const unsigned *vw = cw + WP * 256;
+    #pragma unroll
+    for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
+  }
+  s_delta[threadIdx.x] = deltas[threadIdx.x]; s_value[threadIdx.x] = values[threadIdx.x];
+  __syncthreads();
+  if (s < 0) return;
+#else
 #if MODE != 5
   s_delta[threadIdx.x] = deltas[threadIdx.x]; s_value[threadIdx.x] = values[threadIdx.x];
   __syncthreads();
@@ -37,6 +50,7 @@ extern "C" __global__ void __launch_bounds__(256) k(long long n, long long ns, c
   unsigned c[WP], vc[WP];
   #pragma unroll
   for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
+#endif
   double sum[2] = {0, 0}, xv[W][2];
   #pragma unroll
   for (int j = 0; j < W; ++j)
@@ -90,8 +104,8 @@ class Trav(ctypes.Structure):
     _fields_ = [("chunk", ctypes.c_int), ("planes", ctypes.c_int), ("plane_blocks", ctypes.c_int)]
 tr = Trav(int(S.trav.chunk), int(S.trav.planes), int(S.trav.plane_blocks))
 grid = int(S.trav.grid_blocks); ns = (N + 511) // 512
-names = {0: "full", 1: "no gathers (x[i] only)", 2: "no value table", 3: "no y store", 4: "no delta table (+-3 window)", 5: "no LDS at all", 6: "non-temporal y store", 7: "paired 16-byte x loads"}
-for mode in (0, 7, 0, 7):
+names = {0: "full", 1: "no gathers (x[i] only)", 2: "no value table", 3: "no y store", 4: "no delta table (+-3 window)", 5: "no LDS at all", 6: "non-temporal y store", 7: "paired 16-byte x loads", 8: "code loads before the table barrier"}
+for mode in (0, 8, 0, 8):
     mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
     L.module_compile(0, ("#define MODE %d\n" % mode + SRC).encode(), b"-ffp-contract=off", ctypes.byref(mod))
     L.module_get_function(0, mod, b"k", ctypes.byref(fn))
