@@ -482,3 +482,46 @@ def test_sell8v_value_codes(T, oracle, built_lib):
         assert (B.hell.deltas is not None) == has_codes and (B.hell.values is not None) == has_values
         y2 = T.torch.empty_like(y); B.apply(T.up(x32), y2)
         assert T.torch.equal(y, y2)
+
+
+def test_randomized_structures_all_storages(T, oracle, built_lib):
+    """Fuzz: random sizes, diagonal sets, value pools, densities, alpha, SET / += -- every storage the matrix allows
+    (value codes, diagonal codes, 32-bit columns, reference ELL layout, CSR) must equal the oracle bit for bit."""
+    rng = np.random.default_rng(2024)
+    seen = {"sell8v": 0, "sell8": 0, "sell32": 0}
+    for trial in range(40):
+        n = int(rng.integers(1, 6000))
+        nd = int(rng.integers(1, 12))
+        offs = sorted(set(int(o) for o in rng.integers(-min(n, 2000), min(n, 2000) + 1, size=nd)) | {0})
+        ptr, col, val = _banded(rng, n, offs, density=float(rng.uniform(0.3, 1.0)))
+        if len(col) == 0:
+            continue
+        kind = trial % 3
+        if kind == 0:                                    # few distinct values
+            pool = rng.standard_normal(int(rng.integers(1, 40)))
+            val = pool[rng.integers(0, len(pool), size=len(val))]
+        elif kind == 1:                                  # a few rows much wider than the rest (CSR tail)
+            extra_rows = rng.integers(0, n, size=max(1, n // 50))
+            r = np.repeat(np.arange(n), np.diff(ptr)); c = col.astype(np.int64)
+            er = np.repeat(extra_rows, 20); ec = rng.integers(0, n, size=len(er))
+            r = np.concatenate([r, er]); c = np.concatenate([c, ec])
+            key = np.unique(r * n + c); r, c = key // n, key % n
+            ptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))]).astype(np.int32)
+            col = c.astype(np.int32); val = rng.standard_normal(len(col))
+        x = rng.standard_normal(n)
+        y0 = rng.standard_normal(n)
+        alpha = float(rng.choice([1.0, -1.0, 0.5, 3.25]))
+        append = bool(rng.integers(0, 2))
+        want = y0.copy() if append else np.zeros(n)
+        oracle.spmv_csr(ptr, col, val, x, want, alpha, append)
+        for fmt in ("sell", "sell8", "sell32", "hell", "csr"):
+            try:
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt=fmt)
+            except T.ops.Error:
+                continue
+            if fmt == "sell" and A.hell is not None:
+                seen["sell8v" if A.hell.values is not None else ("sell8" if A.hell.deltas is not None else "sell32")] += 1
+            y = T.up(y0.copy())
+            A.apply(T.up(x), y, alpha, append)
+            assert np.array_equal(y.cpu().numpy(), want), (trial, fmt, n, offs[:5], alpha, append)
+    assert seen["sell8v"] >= 5 and seen["sell8"] >= 5, seen
