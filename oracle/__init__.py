@@ -5,6 +5,8 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 
 PARITY UNPINNED: the reference ships no golden vectors and cannot be built in
 this image (Boost / CPU-OpenCL absent) -- see ``vex_oracle.c`` and DESIGN.md.
+One exception: the Philox / Threefry generators at the end of this file ARE pinned,
+by the known-answer vectors published with those algorithms (tests/test_oracle.py).
 
 The arithmetic lives in ``vex_oracle.c`` (plain C, ``-ffp-contract=off``); this
 module is its ctypes binding plus numpy restatements of the integer-only
@@ -316,3 +318,114 @@ def stable_sort(keys):
 def stable_sort_by_key(keys, vals):
     p = np.argsort(keys, kind="stable")
     return keys[p], vals[p]
+
+
+# ---------------------------------------------------------------------------
+# Counter-based random numbers (vexcl/random.hpp:60-275; generators vexcl/random/philox.hpp:95-160,
+# vexcl/random/threefry.hpp:150-215 -- Philox / Threefry of Salmon, Moraes, Dror, Shaw, SC'11).
+# numpy restatement; pinned by the known-answer vectors published with the algorithms
+# (tests/test_oracle.py).  Word arrays are uint32 with the counter words in the last axis.
+# ---------------------------------------------------------------------------
+def _mulhilo32(a, b):
+    p = a.astype(np.uint64) * b.astype(np.uint64)
+    return (p >> np.uint64(32)).astype(np.uint32), p.astype(np.uint32)
+
+
+def philox(ctr, key, rounds=10):
+    """Philox-Nx32-R, N = ctr.shape[-1] in (2, 4); key has N/2 words.  Returns the output words."""
+    ctr = np.array(ctr, dtype=np.uint32, copy=True)
+    key = np.array(np.broadcast_to(np.asarray(key, dtype=np.uint32), ctr.shape[:-1] + (ctr.shape[-1] // 2,)), copy=True)
+    n = ctr.shape[-1]
+    W = (np.uint32(0x9E3779B9), np.uint32(0xBB67AE85))
+    with np.errstate(over="ignore"):
+        for r in range(rounds):
+            if r:
+                for i in range(n // 2):
+                    key[..., i] += W[i]
+            if n == 2:
+                hi, lo = _mulhilo32(np.uint32(0xD256D193), ctr[..., 0])
+                ctr[..., 0], ctr[..., 1] = hi ^ key[..., 0] ^ ctr[..., 1], lo
+            else:
+                hi0, lo0 = _mulhilo32(np.uint32(0xD2511F53), ctr[..., 0])
+                hi1, lo1 = _mulhilo32(np.uint32(0xCD9E8D57), ctr[..., 2])
+                c0 = hi1 ^ ctr[..., 1] ^ key[..., 0]
+                c2 = hi0 ^ ctr[..., 3] ^ key[..., 1]
+                ctr[..., 0], ctr[..., 1], ctr[..., 2], ctr[..., 3] = c0, lo1, c2, lo0
+    return ctr
+
+
+_THREEFRY_ROT = {2: (13, 15, 26, 6, 17, 29, 16, 24), 4: (10, 26, 11, 21, 13, 27, 23, 5, 6, 20, 17, 11, 25, 10, 18, 20)}
+
+
+def threefry(ctr, key, rounds=20):
+    """Threefry-Nx32-R as the reference generates it: N = 2 is the published Threefry-2x32; N = 4 mixes the
+    word pairs (0,1) and (2,3) WITHOUT Threefish's word permutation (threefry.hpp:178-215)."""
+    ctr = np.array(ctr, dtype=np.uint32, copy=True)
+    n = ctr.shape[-1]
+    key = np.array(np.broadcast_to(np.asarray(key, dtype=np.uint32), ctr.shape[:-1] + (n,)), copy=True)
+    rot = _THREEFRY_ROT[n]
+    p = np.full(ctr.shape[:-1], 0x1BD11BDA, dtype=np.uint32)
+    for i in range(n):
+        p = p ^ key[..., i]
+    ks = [key[..., i] for i in range(n)] + [p]
+
+    def rotl(x, b):
+        return (x << np.uint32(b)) | (x >> np.uint32(32 - b))
+
+    with np.errstate(over="ignore"):
+        for i in range(n):
+            ctr[..., i] += ks[i]
+        for r in range(rounds):
+            if n == 2:
+                ctr[..., 0] += ctr[..., 1]; ctr[..., 1] = rotl(ctr[..., 1], rot[r % 8]); ctr[..., 1] ^= ctr[..., 0]
+            else:
+                b = 2 * (r % 8)
+                r0, r1 = rot[b + (r % 2)], rot[b + ((r + 1) % 2)]
+                ctr[..., 0] += ctr[..., 1]; ctr[..., 1] = rotl(ctr[..., 1], r0); ctr[..., 1] ^= ctr[..., 0]
+                ctr[..., 2] += ctr[..., 3]; ctr[..., 3] = rotl(ctr[..., 3], r1); ctr[..., 3] ^= ctr[..., 2]
+            if (r + 1) % 4 == 0:
+                j = r // 4 + 1
+                for i in range(n):
+                    ctr[..., i] += ks[(j + i) % (n + 1)]
+                ctr[..., n - 1] += np.uint32(j)
+    return ctr
+
+
+def _rng_words(idx, seed, n, generator):
+    idx = np.asarray(idx, dtype=np.uint64)
+    c = np.empty(idx.shape + (n,), dtype=np.uint32)
+    for i in range(0, n, 2):
+        c[..., i] = idx.astype(np.uint32)                 # (uint)prm1
+        c[..., i + 1] = np.uint32(np.uint64(seed) & np.uint64(0xFFFFFFFF))
+    gen = {"philox": philox, "threefry": threefry}[generator]
+    nk = n // 2 if generator == "philox" else n
+    return gen(c, np.full(nk, 0x12345678, dtype=np.uint32))
+
+
+def random_uniform(idx, seed, dtype=np.float64, generator="philox"):
+    """vex::Random<T, Generator>()(idx, seed) (random.hpp:60-150)."""
+    w = _rng_words(idx, seed, 2, generator)
+    dtype = np.dtype(dtype)
+    u64 = (w[..., 1].astype(np.uint64) << np.uint64(32)) | w[..., 0].astype(np.uint64)
+    if dtype == np.float32:
+        return w[..., 0].astype(np.float32) / np.float32(4294967295.0)
+    if dtype == np.float64:
+        return u64.astype(np.float64) / np.float64(18446744073709551615.0)
+    if dtype.itemsize == 4:
+        return w[..., 0].view(dtype) if dtype != np.uint32 else w[..., 0]
+    return u64.view(dtype) if dtype != np.uint64 else u64
+
+
+def random_normal(idx, seed, dtype=np.float64, generator="philox"):
+    """vex::RandomNormal<T, Generator>()(idx, seed): Box-Muller (random.hpp:155-275)."""
+    if np.dtype(dtype) == np.float32:
+        w = _rng_words(idx, seed, 2, generator)
+        u0 = w[..., 0].astype(np.float32) / np.float32(4294967295.0)
+        u1 = w[..., 1].astype(np.float32) / np.float32(4294967295.0)
+        return (np.sqrt(np.float32(-2) * np.log(u0)) * np.cos(np.float32(np.pi) * (np.float32(2) * u1))).astype(np.float32)
+    w = _rng_words(idx, seed, 4, generator)
+    a = (w[..., 1].astype(np.uint64) << np.uint64(32)) | w[..., 0].astype(np.uint64)
+    b = (w[..., 3].astype(np.uint64) << np.uint64(32)) | w[..., 2].astype(np.uint64)
+    u0 = a.astype(np.float64) / 18446744073709551615.0
+    u1 = b.astype(np.float64) / 18446744073709551615.0
+    return np.sqrt(-2 * np.log(u0)) * np.cos(np.pi * (2 * u1))

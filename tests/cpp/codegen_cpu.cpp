@@ -252,6 +252,17 @@ TEST_CASE(slices_and_dimension_reductions) {                          // vector_
     backend::check_sources(s);
 }
 
+TEST_CASE(random_functions_compile) {                                // random.hpp
+    vector<double> x; vector<float> f; vector<cl_uint> u;
+    Random<double> rd; RandomNormal<double> rn; Random<float, random::threefry> rf; RandomNormal<float, random::threefry> rnf; Random<cl_uint> ru;
+    std::string s = src_of<assign::SET>(x, rd(element_index(), 42) + rn(element_index(), 7));
+    CHECK(has(s, "philox_uint_2_10") && has(s, "philox_uint_4_10") && has(s, "random_normal_double_philox( ( prm_4 + idx ), prm_5 )"));
+    CHECK_EQUAL(count(s, "__device__ void philox_uint_2_10"), size_t(1));
+    backend::check_sources(s);
+    backend::check_sources(src_of<assign::SET>(f, rf(element_index(), 1) * rnf(element_index(), 2)));
+    backend::check_sources(src_of<assign::SET>(u, ru(element_index(), 3) + ru(element_index(), 4)));
+}
+
 TEST_CASE(partition_and_util) {
     CHECK_EQUAL(alignup(17), size_t(32));
     CHECK_EQUAL(nextpow2(1000), size_t(1024));

@@ -127,3 +127,100 @@ TEST_CASE(gather_scatter) {                                           // vector_
         CHECK_CLOSE(sum(Y), want, 1e-10);                             // nothing else was touched
     }
 }
+
+// ---- counter-based random numbers (reference: tests/random.cpp; generators pinned by the published
+//      known-answer vectors of Philox / Threefry, Salmon et al. SC'11) --------------------------------
+namespace {
+void host_philox2x32(uint32_t ctr[2], uint32_t key) {
+    for (int r = 0; r < 10; ++r) {
+        if (r) key += 0x9E3779B9u;
+        uint64_t p = uint64_t(0xD256D193u) * ctr[0];
+        uint32_t hi = uint32_t(p >> 32), lo = uint32_t(p);
+        ctr[0] = hi ^ key ^ ctr[1]; ctr[1] = lo;
+    }
+}
+void host_threefry2x32(uint32_t ctr[2], const uint32_t key[2]) {
+    static const unsigned rot[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+    const uint32_t ks[3] = {key[0], key[1], 0x1BD11BDAu ^ key[0] ^ key[1]};
+    ctr[0] += ks[0]; ctr[1] += ks[1];
+    for (int r = 0; r < 20; ++r) {
+        ctr[0] += ctr[1]; ctr[1] = (ctr[1] << rot[r % 8]) | (ctr[1] >> (32 - rot[r % 8])); ctr[1] ^= ctr[0];
+        if ((r + 1) % 4 == 0) { int j = r / 4 + 1; ctr[0] += ks[j % 3]; ctr[1] += ks[(j + 1) % 3] + j; }
+    }
+}
+}
+
+TEST_CASE(random_generators_match_the_published_vectors) {
+    {   // the host models first: Random123 known-answer vectors
+        uint32_t c[2] = {0, 0}; host_philox2x32(c, 0);
+        CHECK(c[0] == 0xff1dae59u && c[1] == 0x6cd10df2u);
+        uint32_t t[2] = {0, 0}, k0[2] = {0, 0}; host_threefry2x32(t, k0);
+        CHECK(t[0] == 0x6b200159u && t[1] == 0x99ba4efeu);
+        uint32_t p[2] = {0x243f6a88u, 0x85a308d3u}, kp[2] = {0x13198a2eu, 0x03707344u}; host_threefry2x32(p, kp);
+        CHECK(p[0] == 0xc4923a9cu && p[1] == 0x483df7a0u);
+    }
+    // the device streams: counter = ((uint)index, (uint)seed), key words 0x12345678 (vexcl/random.hpp:100-116)
+    const size_t n = 4096;
+    const cl_ulong seed = 0x1234567890ull;                             // only the low 32 bits enter the counter
+    vex::vector<cl_uint> U(ctx, n);
+    vex::vector<cl_ulong> L(ctx, n);
+    vex::vector<double> D(ctx, n);
+    vex::vector<float> F(ctx, n);
+    vex::Random<cl_uint> ru; vex::Random<cl_ulong> rl; vex::Random<double> rd; vex::Random<float> rf;
+    vex::Random<cl_ulong, vex::random::threefry> rt;
+    U = ru(vex::element_index(), seed);
+    L = rl(vex::element_index(), seed);
+    D = rd(vex::element_index(), seed);
+    F = rf(vex::element_index(), seed);
+    std::vector<cl_uint> u(n); std::vector<cl_ulong> l(n), t(n); std::vector<double> d(n); std::vector<float> f(n);
+    vex::copy(U, u); vex::copy(L, l); vex::copy(D, d); vex::copy(F, f);
+    L = rt(vex::element_index(), seed);
+    vex::copy(L, t);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t c[2] = {uint32_t(i), uint32_t(seed)};
+        host_philox2x32(c, 0x12345678u);
+        const uint64_t w = (uint64_t(c[1]) << 32) | c[0];
+        CHECK(u[i] == c[0]);
+        CHECK(l[i] == w);
+        CHECK(d[i] == double(w) / 18446744073709551615.0);
+        CHECK(f[i] == float(c[0]) / 4294967295.0f);
+        uint32_t c3[2] = {uint32_t(i), uint32_t(seed)}, k3[2] = {0x12345678u, 0x12345678u};
+        host_threefry2x32(c3, k3);
+        CHECK(t[i] == ((uint64_t(c3[1]) << 32) | c3[0]));
+    }
+}
+
+TEST_CASE(random_numbers_statistics_and_monte_carlo) {               // random.cpp:13-75
+    const size_t N = 1 << 20;
+    vex::Reductor<size_t, vex::SUM> sumi(ctx);
+    vex::Reductor<double, vex::SUM> sumd(ctx);
+    vex::Random<cl_double> rand3;
+    vex::vector<cl_double> x3(ctx, N);
+    x3 = rand3(vex::element_index(), 17);
+    CHECK(sumi(x3 > 1) == 0);
+    CHECK(sumi(x3 < 0) == 0);
+    CHECK(std::abs(sumd(x3) / N - 0.5) < 1e-2);
+    vex::RandomNormal<cl_double> rand4;
+    vex::vector<cl_double> x4(ctx, N);
+    x4 = rand4(vex::element_index(), 23);
+    CHECK(std::abs(sumd(x4) / N) < 1e-2);                             // E X = 0
+    CHECK(std::abs(sumd(fabs(x4)) / N - std::sqrt(2 / M_PI)) < 1e-2); // E |X| = sqrt(2 / pi)
+    CHECK(std::abs(sumd(x4 * x4) / N - 1) < 1e-2);                    // E X^2 = 1
+    vex::RandomNormal<float, vex::random::threefry> rand6;
+    vex::vector<float> x6(ctx, N);
+    x6 = rand6(vex::element_index(), 29);
+    CHECK(std::abs(sumd(x6) / N) < 1e-2);
+    vex::Random<cl_double, vex::random::threefry> rand5;
+    vex::vector<cl_double> x5(ctx, N);
+    x5 = rand5(vex::element_index(), 31);
+    CHECK(std::abs(sumd(x5) / N - 0.5) < 1e-2);
+
+    // pi by Monte Carlo in ONE fused kernel: two temporaries, a comparison, a reduction
+    vex::Random<double, vex::random::threefry> rnd;
+    vex::Reductor<size_t, vex::SUM> sum(ctx);
+    auto i = vex::tag<0>(vex::element_index(0, N));
+    auto x = vex::make_temp<1>(rnd(i, 1001));
+    auto y = vex::make_temp<2>(rnd(i, 2002));
+    double pi = 4.0 * sum((x * x + y * y) < 1) / N;
+    CHECK_CLOSE(pi, M_PI, 0.5);
+}

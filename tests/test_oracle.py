@@ -121,3 +121,26 @@ def test_scan_sort_golden(oracle):
 def test_elementwise(oracle):
     b, c, d = (oracle.random_f64(s, 1000) for s in (1, 2, 3))
     assert np.allclose(oracle.ew_mul_add_sin(b, c, d), b * c + np.sin(d), rtol=1e-15)
+
+
+def test_random_generators_known_answer_vectors(oracle):
+    """Philox / Threefry (vexcl/random/*.hpp) against the known-answer vectors published with the algorithms
+    (Random123 kat_vectors: Salmon, Moraes, Dror, Shaw, SC'11) -- this part of the oracle is pinned."""
+    import numpy as np
+    u = lambda *w: np.array(w, dtype=np.uint32)
+    pi4, pik2 = u(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), u(0xa4093822, 0x299f31d0)
+    assert oracle.philox(u(0, 0), u(0)).tolist() == [0xff1dae59, 0x6cd10df2]
+    assert oracle.philox(u(0, 0, 0, 0), u(0, 0)).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox(u(*[0xffffffff] * 4), u(0xffffffff, 0xffffffff)).tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox(pi4, pik2).tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert oracle.threefry(u(0, 0), u(0, 0)).tolist() == [0x6b200159, 0x99ba4efe]
+    assert oracle.threefry(u(0xffffffff, 0xffffffff), u(0xffffffff, 0xffffffff)).tolist() == [0x1cb996fc, 0xbb002be7]
+    assert oracle.threefry(u(0x243f6a88, 0x85a308d3), u(0x13198a2e, 0x03707344)).tolist() == [0xc4923a9c, 0x483df7a0]
+    # the streams of vex::Random: shapes, ranges, vectorised over the index
+    idx = np.arange(10000)
+    d = oracle.random_uniform(idx, 42)
+    assert d.dtype == np.float64 and d.min() >= 0 and d.max() <= 1 and abs(d.mean() - 0.5) < 0.02
+    assert oracle.random_uniform(idx, 42, np.uint32).dtype == np.uint32
+    z = oracle.random_normal(idx, 7)
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
+    assert not np.array_equal(oracle.random_uniform(idx, 1), oracle.random_uniform(idx, 2))

@@ -7,6 +7,9 @@
 // so that upper layers and user code (tests/custom_kernel.cpp style) compile
 // unchanged.  No HIP headers are needed here: host C++17 only.
 #include <cstring>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -535,6 +538,22 @@ class kernel {
         std::vector<char> stack_;
         std::vector<size_t> offsets_;
 };
+
+// ---- exclusive device locks (Filter::Exclusive) ---------------------------------
+/// Takes (once per process) the advisory lock file of a device; false if another process holds it.
+inline bool lock_device(int ordinal) {
+    static std::mutex mx;
+    static std::map<int, int> held;                      // ordinal -> open file descriptor, kept until exit
+    std::lock_guard<std::mutex> l(mx);
+    if (held.count(ordinal)) return true;
+    const char *dir = std::getenv("VEXCL_LOCK_DIR");
+    const std::string path = std::string(dir ? dir : "/tmp") + "/vexcl_device_" + std::to_string(ordinal) + ".lock";
+    int fd = ::open(path.c_str(), O_CREAT | O_RDWR, 0666);
+    if (fd < 0) return true;                             // cannot create lock files: exclusive mode is off (as the reference warns)
+    if (::flock(fd, LOCK_EX | LOCK_NB) != 0) { ::close(fd); return false; }
+    held[ordinal] = fd;
+    return true;
+}
 
 // ---- device enumeration (backend/cuda/context.hpp:383-413) ------------------
 inline int device_count() {

@@ -14,6 +14,7 @@ namespace Filter {
 
 struct AnyFilter { bool operator()(const backend::device &) const { return true; } };
 const AnyFilter Any = {};
+const AnyFilter All = {};
 
 /// Accepts devices with double precision support (every CDNA part).
 struct DoublePrecisionFilter { bool operator()(const backend::device &) const { return true; } };
@@ -23,6 +24,20 @@ struct GPUFilter { bool operator()(const backend::device &) const { return true;
 const GPUFilter GPU = {};
 struct CPUFilter { bool operator()(const backend::device &) const { return false; } };
 const CPUFilter CPU = {};
+const CPUFilter Accelerator = {};
+
+/// Vendor / platform name contains the given string: every device here is an AMD GPU on the HIP platform
+/// (backend/opencl/filter.hpp:62-84).
+struct Vendor {
+    explicit Vendor(std::string v) : name(std::move(v)) {}
+    bool operator()(const backend::device &) const { return std::string("Advanced Micro Devices, Inc. (AMD)").find(name) != std::string::npos; }
+    std::string name;
+};
+struct Platform {
+    explicit Platform(std::string v) : name(std::move(v)) {}
+    bool operator()(const backend::device &) const { return std::string("AMD HIP / ROCm").find(name) != std::string::npos; }
+    std::string name;
+};
 
 /// Device name contains the given string (devlist.hpp Filter::Name).
 struct Name {
@@ -71,6 +86,8 @@ template <> struct is_filter<DoublePrecisionFilter> : std::true_type {};
 template <> struct is_filter<GPUFilter> : std::true_type {};
 template <> struct is_filter<CPUFilter> : std::true_type {};
 template <> struct is_filter<Name> : std::true_type {};
+template <> struct is_filter<Vendor> : std::true_type {};
+template <> struct is_filter<Platform> : std::true_type {};
 template <> struct is_filter<Count> : std::true_type {};
 template <> struct is_filter<Position> : std::true_type {};
 template <> struct is_filter<General> : std::true_type {};
@@ -107,6 +124,21 @@ struct EnvFilter {
 };
 template <> struct is_filter<EnvFilter> : std::true_type {};
 const EnvFilter Env;
+
+/// Exclusive access to the selected devices across the processes of a node
+/// (backend/opencl/filter.hpp:203-320, there with Boost.Interprocess file locks): a device passes only if
+/// this process obtains the advisory lock on `$VEXCL_LOCK_DIR/vexcl_device_<ordinal>.lock` (default /tmp);
+/// the lock is held until the process exits.  One process per GPU is the deployment model on an 8-GPU node:
+/// `Context ctx(Filter::Exclusive(Filter::Env && Filter::Count(1)))` gives every process its own GPU.
+template <class F>
+struct ExclusiveFilter {
+    F filter;
+    bool operator()(const backend::device &d) const { return filter(d) && backend::lock_device(d.raw()); }
+};
+template <class F> struct is_filter<ExclusiveFilter<F>> : std::true_type {};
+template <class F>
+typename std::enable_if<is_filter<typename std::decay<F>::type>::value, ExclusiveFilter<typename std::decay<F>::type>>::type
+Exclusive(F &&f) { return ExclusiveFilter<typename std::decay<F>::type>{std::forward<F>(f)}; }
 
 } // namespace Filter
 
