@@ -10,8 +10,8 @@
 // Philox-2x32-10 by default; a double is the 64-bit output divided by 2^64 - 1, a float the first
 // word divided by 2^32 - 1, integers are the raw words; RandomNormal is Box-Muller on two uniforms
 // (doubles: the 4x32 generators with the counter repeated).  The device functions are written as
-// loops over the rounds (the reference unrolls them into the source text); oracle/__init__.py
-// holds the same generators in numpy, pinned by the published known-answer vectors.
+// loops over the rounds (the reference unrolls them into the source text); the test suite holds
+// the same generators in numpy and on the host, pinned by the published known-answer vectors.
 #include "operations.hpp"
 
 namespace vex {
