@@ -1,0 +1,42 @@
+#!/bin/bash
+# Builds the REFERENCE'S OWN test programs against this repository's vexcl/ headers.
+#
+# Test infrastructure.  The sources are compiled where they lie (/root/reference/tests/*.cpp, never
+# copied); Boost.Test is replaced by oracle/ref_shim/boost/test/unit_test.hpp (Boost is not in this
+# image).  Outputs go to oracle/_ref/ only (git-ignored, shipped to the GPU box by gpurun), where
+# tests/test_reference_suite.py runs them.  A test that builds and passes demonstrates source
+# compatibility of the vex:: API with the reference's own callers and the reference's own
+# assertions on the results.
+#
+# usage: oracle/build_ref.sh [-j N] [name ...]     (default: every test listed in TESTS)
+set -u
+here="$(cd "$(dirname "$0")" && pwd)"
+repo="$(dirname "$here")"
+ref="${VEXCL_REFERENCE:-/root/reference}"
+out="$here/_ref"
+jobs=8
+if [ "${1:-}" = "-j" ]; then jobs="$2"; shift 2; fi
+
+# Tests of the hot path and of the rows SURVEY.md §8 lists (vector / expression / reductor / SpMV /
+# scan / sort / stencil / views / multivectors / by-key / random).  Out of scope:
+# fft, image, svm, mba, generator, tensordot, custom_kernel, cusparse, boost_compute_*, clogs_*.
+TESTS="${*:-vector_create vector_copy vector_arithmetics vector_view vector_pointer vector_io \
+tagged_terminal temporary cast constants logical reinterpret deduce types eval events \
+multivector_create multivector_arithmetics multi_array spmv sparse_matrices stencil random sort scan \
+scan_by_key reduce_by_key context threads}"
+
+if [ ! -d "$ref/tests" ]; then echo "build_ref: $ref/tests not present, nothing to do"; exit 0; fi
+mkdir -p "$out"
+build_one() {
+    name="$1"
+    if g++ -std=c++17 -O1 -w -I "$here/ref_shim" -I "$repo" "$ref/tests/$name.cpp" -o "$out/$name" \
+        -L "$repo/vexcl_amd/lib" -lvexhip -Wl,-rpath,'$ORIGIN/../../vexcl_amd/lib' -pthread 2> "$out/$name.build.log"; then
+        rm -f "$out/$name.build.log"; echo "built   $name"
+    else
+        rm -f "$out/$name"; echo "FAILED  $name ($(grep -c 'error' "$out/$name.build.log") error lines, see oracle/_ref/$name.build.log)"
+    fi
+}
+export -f build_one; export here repo ref out
+printf '%s\n' $TESTS | xargs -P "$jobs" -I{} bash -c 'build_one {}'
+ls "$out" | grep -v '\.log$' > "$out/MANIFEST" || true
+exit 0

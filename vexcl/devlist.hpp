@@ -178,6 +178,14 @@ class Context {
             StaticContext<>::set(*this);
         }
 
+        /// Wraps contexts and queues the user already holds (devlist.hpp:300-310).
+        Context(std::vector<backend::context> contexts, std::vector<backend::command_queue> queues)
+            : c(std::move(contexts)), q(std::move(queues))
+        {
+            precondition(c.size() == q.size(), "Context: as many contexts as queues are expected");
+            StaticContext<>::set(*this);
+        }
+
         ~Context() { purge_caches(q); }
 
         const std::vector<backend::context> &context() const { return c; }

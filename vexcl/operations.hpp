@@ -600,5 +600,29 @@ void get_expression_properties(const Expr &expr, std::vector<backend::command_qu
     queue = p.queue; part = p.part; size = p.size;
 }
 
+/// (queues, size) of an expression or a tuple of expressions (operations.hpp:2370-2385 in the reference).
+template <class Expr>
+std::tuple<std::vector<backend::command_queue>, size_t> expression_properties(const Expr &expr) {
+    std::vector<backend::command_queue> queue; std::vector<size_t> part; size_t size = 0;
+    get_expression_properties(expr, queue, part, size);
+    return std::make_tuple(queue, size);
+}
+
+namespace detail {
+template <class Tuple, size_t... I>
+void tuple_props(const Tuple &t, prop_context &p, std::index_sequence<I...>) {
+    int dummy[] = {0, (as_expr<typename std::tuple_element<I, Tuple>::type>::get(std::get<I>(t)).get_props(p), 0)...};
+    (void)dummy;
+}
+} // namespace detail
+
+/// ... of a tuple of expressions: the first component that carries a queue list decides.
+template <class... Expr>
+std::tuple<std::vector<backend::command_queue>, size_t> expression_properties(const std::tuple<Expr...> &expr) {
+    detail::prop_context p;
+    detail::tuple_props(expr, p, std::index_sequence_for<Expr...>());
+    return std::make_tuple(p.queue, p.size);
+}
+
 } // namespace vex
 #endif
