@@ -326,51 +326,79 @@ def stable_sort_by_key(keys, vals):
 # numpy restatement; pinned by the known-answer vectors published with the algorithms
 # (tests/test_oracle.py).  Word arrays are uint32 with the counter words in the last axis.
 # ---------------------------------------------------------------------------
-def _mulhilo32(a, b):
-    p = a.astype(np.uint64) * b.astype(np.uint64)
-    return (p >> np.uint64(32)).astype(np.uint32), p.astype(np.uint32)
+def _mulhilo(a, b):
+    """(high, low) words of a * b for uint32 or uint64 arrays."""
+    if b.dtype == np.uint32:
+        p = np.uint64(a) * b.astype(np.uint64)
+        return (p >> np.uint64(32)).astype(np.uint32), p.astype(np.uint32)
+    m = np.uint64(0xFFFFFFFF)
+    a = np.uint64(a)
+    a0, a1 = a & m, a >> np.uint64(32)
+    b0, b1 = b & m, b >> np.uint64(32)
+    with np.errstate(over="ignore"):
+        lo = a * b
+        t = a1 * b0 + ((a0 * b0) >> np.uint64(32))          # < 2^64: (2^32-1)^2 + 2^32 - 1
+        w = a0 * b1 + (t & m)
+        hi = a1 * b1 + (t >> np.uint64(32)) + (w >> np.uint64(32))
+    return hi, lo
+
+
+_PHILOX = {
+    np.dtype(np.uint32): dict(weyl=(0x9E3779B9, 0xBB67AE85), m2=0xD256D193, m4=(0xD2511F53, 0xCD9E8D57)),
+    np.dtype(np.uint64): dict(weyl=(0x9E3779B97F4A7C15, 0xBB67AE8584CAA73B), m2=0xD2B74407B1CE6E93,
+                              m4=(0xD2E7470EE14C6C93, 0xCA5A826395121157)),
+}
 
 
 def philox(ctr, key, rounds=10):
-    """Philox-Nx32-R, N = ctr.shape[-1] in (2, 4); key has N/2 words.  Returns the output words."""
-    ctr = np.array(ctr, dtype=np.uint32, copy=True)
-    key = np.array(np.broadcast_to(np.asarray(key, dtype=np.uint32), ctr.shape[:-1] + (ctr.shape[-1] // 2,)), copy=True)
+    """Philox-NxW-R, N = ctr.shape[-1] in (2, 4), W = 32 or 64 bits by the dtype of ctr (uint32 unless it is
+    uint64); key has N/2 words.  Returns the output words."""
+    dt = np.dtype(np.uint64) if np.asarray(ctr).dtype == np.uint64 else np.dtype(np.uint32)
+    ctr = np.array(ctr, dtype=dt, copy=True)
+    key = np.array(np.broadcast_to(np.asarray(key, dtype=dt), ctr.shape[:-1] + (ctr.shape[-1] // 2,)), copy=True)
     n = ctr.shape[-1]
-    W = (np.uint32(0x9E3779B9), np.uint32(0xBB67AE85))
+    k = _PHILOX[dt]
+    W = tuple(dt.type(w) for w in k["weyl"])
     with np.errstate(over="ignore"):
         for r in range(rounds):
             if r:
                 for i in range(n // 2):
                     key[..., i] += W[i]
             if n == 2:
-                hi, lo = _mulhilo32(np.uint32(0xD256D193), ctr[..., 0])
+                hi, lo = _mulhilo(dt.type(k["m2"]), ctr[..., 0])
                 ctr[..., 0], ctr[..., 1] = hi ^ key[..., 0] ^ ctr[..., 1], lo
             else:
-                hi0, lo0 = _mulhilo32(np.uint32(0xD2511F53), ctr[..., 0])
-                hi1, lo1 = _mulhilo32(np.uint32(0xCD9E8D57), ctr[..., 2])
+                hi0, lo0 = _mulhilo(dt.type(k["m4"][0]), ctr[..., 0])
+                hi1, lo1 = _mulhilo(dt.type(k["m4"][1]), ctr[..., 2])
                 c0 = hi1 ^ ctr[..., 1] ^ key[..., 0]
                 c2 = hi0 ^ ctr[..., 3] ^ key[..., 1]
                 ctr[..., 0], ctr[..., 1], ctr[..., 2], ctr[..., 3] = c0, lo1, c2, lo0
     return ctr
 
 
-_THREEFRY_ROT = {2: (13, 15, 26, 6, 17, 29, 16, 24), 4: (10, 26, 11, 21, 13, 27, 23, 5, 6, 20, 17, 11, 25, 10, 18, 20)}
+_THREEFRY_ROT = {
+    (32, 2): (13, 15, 26, 6, 17, 29, 16, 24), (32, 4): (10, 26, 11, 21, 13, 27, 23, 5, 6, 20, 17, 11, 25, 10, 18, 20),
+    (64, 2): (16, 42, 12, 31, 16, 32, 24, 21), (64, 4): (14, 16, 52, 57, 23, 40, 5, 37, 25, 33, 46, 12, 58, 22, 32, 32),
+}
 
 
 def threefry(ctr, key, rounds=20):
-    """Threefry-Nx32-R as the reference generates it: N = 2 is the published Threefry-2x32; N = 4 mixes the
-    word pairs (0,1) and (2,3) WITHOUT Threefish's word permutation (threefry.hpp:178-215)."""
-    ctr = np.array(ctr, dtype=np.uint32, copy=True)
+    """Threefry-NxW-R as the reference generates it (W by the dtype of ctr, as for philox): N = 2 is the published
+    Threefry-2xW; N = 4 mixes the word pairs (0,1) and (2,3) WITHOUT Threefish's word permutation
+    (threefry.hpp:178-215)."""
+    dt = np.dtype(np.uint64) if np.asarray(ctr).dtype == np.uint64 else np.dtype(np.uint32)
+    bits = dt.itemsize * 8
+    ctr = np.array(ctr, dtype=dt, copy=True)
     n = ctr.shape[-1]
-    key = np.array(np.broadcast_to(np.asarray(key, dtype=np.uint32), ctr.shape[:-1] + (n,)), copy=True)
-    rot = _THREEFRY_ROT[n]
-    p = np.full(ctr.shape[:-1], 0x1BD11BDA, dtype=np.uint32)
+    key = np.array(np.broadcast_to(np.asarray(key, dtype=dt), ctr.shape[:-1] + (n,)), copy=True)
+    rot = _THREEFRY_ROT[(bits, n)]
+    p = np.full(ctr.shape[:-1], 0x1BD11BDA if bits == 32 else 0x1BD11BDAA9FC1A22, dtype=dt)
     for i in range(n):
         p = p ^ key[..., i]
     ks = [key[..., i] for i in range(n)] + [p]
 
     def rotl(x, b):
-        return (x << np.uint32(b)) | (x >> np.uint32(32 - b))
+        return (x << dt.type(b)) | (x >> dt.type(bits - b))
 
     with np.errstate(over="ignore"):
         for i in range(n):
@@ -387,19 +415,38 @@ def threefry(ctr, key, rounds=20):
                 j = r // 4 + 1
                 for i in range(n):
                     ctr[..., i] += ks[(j + i) % (n + 1)]
-                ctr[..., n - 1] += np.uint32(j)
+                ctr[..., n - 1] += dt.type(j)
     return ctr
 
 
-def _rng_words(idx, seed, n, generator):
+def _rng_words(idx, seed, n, generator, bits=32):
+    dt = np.uint32 if bits == 32 else np.uint64
     idx = np.asarray(idx, dtype=np.uint64)
-    c = np.empty(idx.shape + (n,), dtype=np.uint32)
+    c = np.empty(idx.shape + (n,), dtype=dt)
     for i in range(0, n, 2):
-        c[..., i] = idx.astype(np.uint32)                 # (uint)prm1
-        c[..., i + 1] = np.uint32(np.uint64(seed) & np.uint64(0xFFFFFFFF))
+        c[..., i] = idx.astype(dt)                        # (word)prm1
+        c[..., i + 1] = dt(np.uint64(seed) & np.uint64(0xFFFFFFFF if bits == 32 else 0xFFFFFFFFFFFFFFFF))
     gen = {"philox": philox, "threefry": threefry}[generator]
     nk = n // 2 if generator == "philox" else n
-    return gen(c, np.full(nk, 0x12345678, dtype=np.uint32))
+    return gen(c, np.full(nk, 0x12345678, dtype=dt))
+
+
+def random_vector(idx, seed, dtype, length, generator="philox"):
+    """vex::Random<cl_<T>N, Generator>()(idx, seed): shape idx.shape + (length,) (random.hpp:85-152).
+    Outputs below 32 bytes come from 32-bit words (two for up to 8 bytes, else four), 32-byte outputs from four
+    64-bit words; the words are the bytes of the result; reals are then word / (2^W - 1) of their own width."""
+    dtype = np.dtype(dtype)
+    nbytes = dtype.itemsize * length
+    assert nbytes in (1, 2, 4, 8, 16, 32)
+    bits = 32 if nbytes < 32 else 64
+    w = _rng_words(idx, seed, 2 if nbytes <= 8 else 4, generator, bits)
+    raw = np.ascontiguousarray(w).view(np.uint8)[..., :nbytes]
+    if dtype.kind == "f":
+        ints = np.ascontiguousarray(raw).view(np.uint32 if dtype.itemsize == 4 else np.uint64)
+        if dtype.itemsize == 4:
+            return ints.astype(np.float32) / np.float32(4294967295.0)
+        return ints.astype(np.float64) / np.float64(18446744073709551615.0)
+    return np.ascontiguousarray(raw).view(dtype)
 
 
 def random_uniform(idx, seed, dtype=np.float64, generator="philox"):

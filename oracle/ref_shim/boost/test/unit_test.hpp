@@ -16,6 +16,7 @@
 #include <vector>
 
 #include <tuple>
+#include <boost/math/constants/constants.hpp>   // the reference's constants.hpp makes these visible to its tests
 // boost::fusion::vector_tie, which the reference's headers bring in for tuples of keys / values: the
 // tuple type of this implementation is std::tuple.
 namespace boost { namespace fusion {

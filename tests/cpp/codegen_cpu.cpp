@@ -263,6 +263,29 @@ TEST_CASE(random_functions_compile) {                                // random.h
     backend::check_sources(src_of<assign::SET>(u, ru(element_index(), 3) + ru(element_index(), 4)));
 }
 
+TEST_CASE(short_vector_types_compile) {                              // types.hpp; random.hpp with vector outputs
+    static_assert(sizeof(cl_float4) == 16 && alignof(cl_float4) == 16 && sizeof(cl_double4) == 32 && sizeof(cl_char2) == 2, "layout");
+    static_assert(is_cl_native<cl_int8>::value && is_cl_vector<cl_ulong16>::value && !is_cl_vector<float>::value, "traits");
+    static_assert(cl_vector_length<cl_uint16>::value == 16 && std::is_same<cl_scalar_of<cl_short8>::type, short>::value, "traits");
+    static_assert(std::is_same<cl_vector_of<float, 4>::type, cl_float4>::value && std::is_same<cl_vector_of<int, 1>::type, int>::value, "vector_of");
+    CHECK_EQUAL(type_name<cl_double2>(), std::string("double2"));
+    CHECK_EQUAL(type_name<cl_uchar16>(), std::string("uchar16"));
+    cl_int4 a = {{1, 2, 3, 4}}, b = {{10, 20, 30, 40}};
+    CHECK((a + b) == (cl_int4{{11, 22, 33, 44}}) && (b - a) != a && (2 * a) == (cl_int4{{2, 4, 6, 8}}));
+    vector<cl_float4> f4; vector<cl_double4> d4; vector<cl_int8> i8; vector<cl_double2> d2; vector<double> x;
+    Random<cl_float4> rf; Random<cl_double4> rd; Random<cl_int8, random::threefry> ri;
+    std::string s = src_of<assign::SET>(f4, rf(element_index(), 42) * 2.0f);
+    CHECK(has(s, "float4 random_float4_philox") && has(s, "philox_uint_4_10(u.ctr, key)") && has(s, "float4 * prm_1"));
+    backend::check_sources(s);
+    s = src_of<assign::SET>(d4, rd(element_index(), 42));
+    CHECK(has(s, "philox_ulong_4_10") && has(s, "__umul64hi"));
+    backend::check_sources(s);
+    s = src_of<assign::ADD>(i8, ri(element_index(), 1) + i8);                  // length 8: the extended vectors of the standard header
+    CHECK(has(s, "threefry_ulong_4_20") && has(s, "typedef T T##8 __attribute__((ext_vector_type(8)))"));
+    backend::check_sources(s);
+    backend::check_sources(src_of<assign::SET>(d2, d2 * x + d2));               // short vector with scalar operands
+}
+
 TEST_CASE(partition_and_util) {
     CHECK_EQUAL(alignup(17), size_t(32));
     CHECK_EQUAL(nextpow2(1000), size_t(1024));

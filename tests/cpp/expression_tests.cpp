@@ -190,6 +190,58 @@ TEST_CASE(random_generators_match_the_published_vectors) {
     }
 }
 
+namespace {
+template <class W> struct philox4_constants;
+template <> struct philox4_constants<uint32_t> { static constexpr uint32_t m0 = 0xD2511F53u, m1 = 0xCD9E8D57u, w0 = 0x9E3779B9u, w1 = 0xBB67AE85u; };
+template <> struct philox4_constants<uint64_t> {
+    static constexpr uint64_t m0 = 0xD2E7470EE14C6C93ull, m1 = 0xCA5A826395121157ull, w0 = 0x9E3779B97F4A7C15ull, w1 = 0xBB67AE8584CAA73Bull;
+};
+inline void mulhilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) { uint64_t p = uint64_t(a) * b; hi = uint32_t(p >> 32); lo = uint32_t(p); }
+inline void mulhilo(uint64_t a, uint64_t b, uint64_t &hi, uint64_t &lo) { unsigned __int128 p = (unsigned __int128)a * b; hi = uint64_t(p >> 64); lo = uint64_t(p); }
+template <class W> void host_philox4(W ctr[4], W k0, W k1) {
+    typedef philox4_constants<W> C;
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += C::w0; k1 += C::w1; }
+        W hi0, lo0, hi1, lo1;
+        mulhilo(C::m0, ctr[0], hi0, lo0); mulhilo(C::m1, ctr[2], hi1, lo1);
+        const W c0 = hi1 ^ ctr[1] ^ k0, c2 = hi0 ^ ctr[3] ^ k1;
+        ctr[0] = c0; ctr[1] = lo1; ctr[2] = c2; ctr[3] = lo0;
+    }
+}
+}
+
+TEST_CASE(random_short_vectors_follow_the_reference_streams) {       // random.hpp:85-152; tests/random.cpp:24-30
+    {   // host models against the published vectors (Random123 kat_vectors: philox4x32, philox4x64)
+        uint32_t a[4] = {0x243f6a88u, 0x85a308d3u, 0x13198a2eu, 0x03707344u}; host_philox4<uint32_t>(a, 0xa4093822u, 0x299f31d0u);
+        CHECK(a[0] == 0xd16cfe09u && a[1] == 0x94fdccebu && a[2] == 0x5001e420u && a[3] == 0x24126ea1u);
+        uint64_t b[4] = {0x243f6a8885a308d3ull, 0x13198a2e03707344ull, 0xa4093822299f31d0ull, 0x082efa98ec4e6c89ull};
+        host_philox4<uint64_t>(b, 0x452821e638d01377ull, 0xbe5466cf34e90c6cull);
+        CHECK(b[0] == 0xa528f45403e61d95ull && b[1] == 0x38c72dbd566e9788ull && b[2] == 0xa5a1610e72fd18b5ull && b[3] == 0x57bd43b5e52b7fe6ull);
+    }
+    const size_t n = 2048;
+    const cl_ulong seed = 0xabcdef0123ull;                             // 64-bit counters take all of it, 32-bit ones the low half
+    vex::vector<cl_float4> F(ctx, n); vex::vector<cl_double4> D(ctx, n); vex::vector<cl_int2> I(ctx, n); vex::vector<cl_double2> D2(ctx, n);
+    vex::Random<cl_float4> rf; vex::Random<cl_double4> rd; vex::Random<cl_int2> ri; vex::Random<cl_double2> rd2;
+    F = rf(vex::element_index(), seed);
+    D = rd(vex::element_index(), seed);
+    I = ri(vex::element_index(), seed);
+    D2 = rd2(vex::element_index(), seed);
+    std::vector<cl_float4> f(n); std::vector<cl_double4> d(n); std::vector<cl_int2> iv(n); std::vector<cl_double2> d2(n);
+    vex::copy(F, f); vex::copy(D, d); vex::copy(I, iv); vex::copy(D2, d2);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t c[4] = {uint32_t(i), uint32_t(seed), uint32_t(i), uint32_t(seed)};
+        host_philox4<uint32_t>(c, 0x12345678u, 0x12345678u);
+        for (int k = 0; k < 4; ++k) CHECK(f[i].s[k] == float(c[k]) / 4294967295.0f);
+        for (int k = 0; k < 2; ++k) CHECK(d2[i].s[k] == double((uint64_t(c[2 * k + 1]) << 32) | c[2 * k]) / 18446744073709551615.0);
+        uint64_t w[4] = {uint64_t(i), seed, uint64_t(i), seed};
+        host_philox4<uint64_t>(w, 0x12345678ull, 0x12345678ull);
+        for (int k = 0; k < 4; ++k) CHECK(d[i].s[k] == double(w[k]) / 18446744073709551615.0);
+        uint32_t c2[2] = {uint32_t(i), uint32_t(seed)};
+        host_philox2x32(c2, 0x12345678u);
+        CHECK(uint32_t(iv[i].s[0]) == c2[0] && uint32_t(iv[i].s[1]) == c2[1]);
+    }
+}
+
 TEST_CASE(random_numbers_statistics_and_monte_carlo) {               // random.cpp:13-75
     const size_t N = 1 << 20;
     vex::Reductor<size_t, vex::SUM> sumi(ctx);

@@ -60,7 +60,7 @@ TEST_CASE(copy_and_element_access) {                                 // vector_c
     x[0] = x[N - 1]; CHECK_EQUAL(double(x[0]), 7.5);
     double s = 0; for (auto it = x.begin(); it != x.begin() + 4; ++it) s += *it;
     CHECK(s > 7.5);
-    bool thrown = false; try { x.at(N); } catch (const std::runtime_error &) { thrown = true; } CHECK(thrown);
+    bool thrown = false; try { x.at(N); } catch (const std::out_of_range &) { thrown = true; } CHECK(thrown);
     auto mapped = x.map(0); mapped[1] = 99.0; mapped.reset();       // unmap writes back
     CHECK_EQUAL(double(x[1]), 99.0);
 }

@@ -133,6 +133,16 @@ def test_random_generators_known_answer_vectors(oracle):
     assert oracle.philox(u(0, 0, 0, 0), u(0, 0)).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     assert oracle.philox(u(*[0xffffffff] * 4), u(0xffffffff, 0xffffffff)).tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert oracle.philox(pi4, pik2).tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # 64-bit words (Random123 kat_vectors: philox2x64, philox4x64, threefry2x64)
+    q = lambda *w: np.array(w, dtype=np.uint64)
+    F = 0xffffffffffffffff
+    assert oracle.philox(q(0, 0), q(0)).tolist() == [0xca00a0459843d731, 0x66c24222c9a845b5]
+    assert oracle.philox(q(0, 0, 0, 0), q(0, 0)).tolist() == [0x16554d9eca36314c, 0xdb20fe9d672d0fdc, 0xd7e772cee186176b, 0x7e68b68aec7ba23b]
+    assert oracle.philox(q(F, F, F, F), q(F, F)).tolist() == [0x87b092c3013fe90b, 0x438c3c67be8d0224, 0x9cc7d7c69cd777b6, 0xa09caebf594f0ba0]
+    assert oracle.philox(q(0x243f6a8885a308d3, 0x13198a2e03707344, 0xa4093822299f31d0, 0x082efa98ec4e6c89),
+                         q(0x452821e638d01377, 0xbe5466cf34e90c6c)).tolist() == [
+        0xa528f45403e61d95, 0x38c72dbd566e9788, 0xa5a1610e72fd18b5, 0x57bd43b5e52b7fe6]
+    assert oracle.threefry(q(0, 0), q(0, 0)).tolist() == [0xc2b6e3a8c2c69865, 0x6f81ed42f350084d]
     assert oracle.threefry(u(0, 0), u(0, 0)).tolist() == [0x6b200159, 0x99ba4efe]
     assert oracle.threefry(u(0xffffffff, 0xffffffff), u(0xffffffff, 0xffffffff)).tolist() == [0x1cb996fc, 0xbb002be7]
     assert oracle.threefry(u(0x243f6a88, 0x85a308d3), u(0x13198a2e, 0x03707344)).tolist() == [0xc4923a9c, 0x483df7a0]

@@ -388,8 +388,32 @@ inline void pop_program_header(const command_queue &q) {
     auto &v = detail_opts::stacks<>::headers[get_device_id(q)]; if (!v.empty()) v.pop_back();
 }
 
+inline void push_compile_options(const std::vector<command_queue> &queue, const std::string &s) { for (const auto &q : queue) push_compile_options(q, s); }
+inline void pop_compile_options(const std::vector<command_queue> &queue) { for (const auto &q : queue) pop_compile_options(q); }
+inline void push_program_header(const std::vector<command_queue> &queue, const std::string &s) { for (const auto &q : queue) push_program_header(q, s); }
+inline void pop_program_header(const std::vector<command_queue> &queue) { for (const auto &q : queue) pop_program_header(q); }
+
+/// Options / header in force for the lifetime of the object (backend/common.hpp:146-206).
+struct scoped_compile_options {
+    std::vector<command_queue> q;
+    scoped_compile_options(const std::vector<command_queue> &q, const std::string &s) : q(q) { push_compile_options(this->q, s); }
+    scoped_compile_options(const command_queue &q, const std::string &s) : q(1, q) { push_compile_options(this->q, s); }
+    ~scoped_compile_options() { pop_compile_options(q); }
+};
+struct scoped_program_header {
+    std::vector<command_queue> q;
+    scoped_program_header(const std::vector<command_queue> &q, const std::string &s) : q(q) { push_program_header(this->q, s); }
+    scoped_program_header(const command_queue &q, const std::string &s) : q(1, q) { push_program_header(this->q, s); }
+    ~scoped_program_header() { pop_program_header(q); }
+};
+
 inline std::string standard_kernel_header(const command_queue &q) {
-    return std::string("// vexcl kernel (gfx950)\n") + get_program_header(q);
+    // Lengths 8 and 16 of the short vector types: HIP itself stops at 4 (types.hpp).
+    static const char *wide =
+        "#define VEX_WIDE(T) typedef T T##8 __attribute__((ext_vector_type(8))); typedef T T##16 __attribute__((ext_vector_type(16)));\n"
+        "VEX_WIDE(char) VEX_WIDE(uchar) VEX_WIDE(short) VEX_WIDE(ushort) VEX_WIDE(int) VEX_WIDE(uint) VEX_WIDE(long) VEX_WIDE(ulong) VEX_WIDE(float) VEX_WIDE(double)\n"
+        "#undef VEX_WIDE\n";
+    return std::string("// vexcl kernel (gfx950)\n") + wide + get_program_header(q);
 }
 
 // ---- build_sources / program (backend/cuda/compiler.hpp:53-116) -------------
@@ -596,6 +620,9 @@ queue_list(DevFilter &&filter, command_queue_properties flags = 0) {
 
 using backend::command_queue;
 using backend::device_vector;
+using backend::push_compile_options; using backend::pop_compile_options;
+using backend::push_program_header; using backend::pop_program_header;
+using backend::scoped_compile_options; using backend::scoped_program_header;
 typedef backend::error error;
 using backend::operator<<;
 

@@ -19,6 +19,7 @@ struct elem_index : expression_base {
     void get_props(prop_context &p) const { if (p.size == 0 && length) p.size = length; }
 };
 } // namespace detail
+using detail::elem_index;
 
 /// Index of the current element, shifted by offset; length gives a size to
 /// otherwise size-less expressions (element_index.hpp:52-66).

@@ -104,11 +104,20 @@ namespace detail {
         static std::string body() { return body_str; }                                              \
     } const fname
 
-/// A functor usable on both sides (sort comparators, scan operators): function.hpp:243-247.
-#define VEX_DUAL_FUNCTOR(fname, rettype, args, ...)                                                 \
-    struct vex_dual_functor_##fname {                                                               \
-        VEX_FUNCTION_SINK(rettype, device, args, , #__VA_ARGS__);                                   \
-    } const fname
+// host parameter list of (t1, a)(t2, b)...: `t1 a, t2 b`
+#define VEXCL_ARG_FIRST(t, n) t n VEXCL_ARG_A
+#define VEXCL_ARG_A(t, n) , t n VEXCL_ARG_B
+#define VEXCL_ARG_B(t, n) , t n VEXCL_ARG_A
+#define VEXCL_ARG_A_END
+#define VEXCL_ARG_B_END
+#define VEXCL_ARG_SEQ(seq) VEXCL_CAT(VEXCL_ARG_FIRST seq, _END)
+
+/// Inside a struct: the same body as the device function `device` and as the host operator()
+/// (sort comparators, scan / reduce operators; function.hpp:228-247 of the reference):
+///     struct less { VEX_DUAL_FUNCTOR(bool, (int, a)(int, b), return a < b;) };
+#define VEX_DUAL_FUNCTOR(rettype, args, ...)                                                        \
+    VEX_FUNCTION(rettype, device, args, __VA_ARGS__);                                               \
+    rettype operator()(VEXCL_ARG_SEQ(args)) const { __VA_ARGS__ }
 
 namespace vex {
 

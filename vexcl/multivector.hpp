@@ -212,6 +212,8 @@ void assign_multi(const std::tuple<vector<Ts> &...> &lhs, const Expr &expr, std:
     }
 }
 
+template <class... T> struct all_exprs : std::true_type {};
+template <class H, class... T> struct all_exprs<H, T...> : std::integral_constant<bool, is_expr<H>::value && all_exprs<T...>::value> {};
 } // namespace detail
 
 #define VEXCL_MULTI_ASSIGN_ONE(Self, op, tag)                                                             \
@@ -418,6 +420,47 @@ class tied_vectors {
 
 template <class... Ts>
 tied_vectors<Ts...> tie(vector<Ts> &...v) { return tied_vectors<Ts...>(v...); }
+
+/// Writable expressions tied together -- slices of vectors, dereferenced pointer expressions:
+///     vex::tie(rows[1](x), rows[2](x)) = std::make_tuple(1, 2);     vex::tie(*if_else(c, &y, &z)) = 42;
+/// One kernel evaluates every right-hand side, then stores through every left-hand side.
+template <class... L>
+class tied_expressions {
+    public:
+        static const size_t dim = sizeof...(L);
+        explicit tied_expressions(const L &...l) : lhs(detail::as_expr<L>::get(l)...) {}
+
+#define VEXCL_TIED_ASSIGN(op, tag)                                                                        \
+        template <class Expr>                                                                             \
+        typename std::enable_if<detail::is_operand<Expr>::value, const tied_expressions &>::type          \
+        operator op(const Expr &expr) const {                                                             \
+            assign<assign::tag>(detail::as_expr<Expr>::get(expr), std::make_index_sequence<dim>());       \
+            return *this;                                                                                 \
+        }
+        VEXCL_TIED_ASSIGN(=, SET)   VEXCL_TIED_ASSIGN(+=, ADD)  VEXCL_TIED_ASSIGN(-=, SUB)  VEXCL_TIED_ASSIGN(*=, MUL)
+        VEXCL_TIED_ASSIGN(/=, DIV)  VEXCL_TIED_ASSIGN(%=, MOD)  VEXCL_TIED_ASSIGN(&=, AND)  VEXCL_TIED_ASSIGN(|=, OR)
+        VEXCL_TIED_ASSIGN(^=, XOR)  VEXCL_TIED_ASSIGN(<<=, LSH) VEXCL_TIED_ASSIGN(>>=, RSH)
+#undef VEXCL_TIED_ASSIGN
+    private:
+        std::tuple<detail::as_expr_t<L>...> lhs;
+
+        template <class OP, class Expr, size_t... I>
+        void assign(const Expr &expr, std::index_sequence<I...>) const {
+            static_assert(detail::mv_dim<Expr>::value == 0 || detail::mv_dim<Expr>::value == dim,
+                    "the expression and the tied left-hand sides have different numbers of components");
+            static_assert(detail::expr_kind<Expr>::value == 0, "tied expressions take vector expressions only");
+            detail::prop_context p;
+            detail::tuple_for_each(lhs, [&p](const auto &a, size_t) { a.get_props(p); });
+            expr.get_props(p);
+            precondition(!p.empty(), "vex::tie: can not determine the size and the queues of the assignment");
+            auto rhs = std::make_tuple(detail::component_of<I, Expr>::get(expr)...);
+            detail::assign_multiexpression<OP>(lhs, rhs, p.queue, p.part);
+        }
+};
+
+template <class... L>
+typename std::enable_if<(sizeof...(L) > 0) && detail::all_exprs<L...>::value, tied_expressions<L...>>::type
+tie(const L &...l) { return tied_expressions<L...>(l...); }
 
 #undef VEXCL_MULTI_ASSIGN_ONE
 

@@ -151,6 +151,16 @@ template <class Tag, class L, class R, class Enable = void>
 struct binary_result { typedef typename std::common_type<L, R>::type type; };
 template <class Tag, class L, class R>
 struct binary_result<Tag, L, R, typename std::enable_if<tag::is_comparison<Tag>::value>::type> { typedef cl_long type; };
+/// A short vector combined with a scalar (or with itself) stays that short vector.
+template <class Tag, class L, class R>
+struct binary_result<Tag, L, R, typename std::enable_if<
+    !tag::is_comparison<Tag>::value && !std::is_same<Tag, tag::shift_left>::value && !std::is_same<Tag, tag::shift_right>::value &&
+    (is_cl_vector<L>::value || is_cl_vector<R>::value)>::type>
+{ typedef typename std::conditional<is_cl_vector<L>::value, L, R>::type type; };
+/// pointer + offset, pointer - offset (vector_pointer.hpp: *(p + i)).
+template <class L, class R> struct binary_result<tag::plus, L *, R, typename std::enable_if<std::is_integral<R>::value>::type> { typedef L *type; };
+template <class L, class R> struct binary_result<tag::minus, L *, R, typename std::enable_if<std::is_integral<R>::value>::type> { typedef L *type; };
+template <class L, class R> struct binary_result<tag::plus, L, R *, typename std::enable_if<std::is_integral<L>::value>::type> { typedef R *type; };
 template <class L, class R> struct binary_result<tag::shift_left, L, R, void> { typedef L type; };
 template <class L, class R> struct binary_result<tag::shift_right, L, R, void> { typedef L type; };
 
@@ -229,6 +239,20 @@ struct ternary_expr : expression_base {
     void get_props(prop_context &p) const { c_.get_props(p); a.get_props(p); b.get_props(p); }
 };
 
+/// *p and p[i] for pointer-valued expressions; usable on the left of an assignment through vex::tie.
+template <class P>
+struct deref_expr : expression_base {
+    typedef typename std::remove_pointer<typename P::value_type>::type value_type;
+    P p;
+    explicit deref_expr(const P &p) : p(p) {}
+    void preamble(gen_context &c) const { p.preamble(c); }
+    void params(gen_context &c) const { p.params(c); }
+    void local_init(gen_context &c) const { p.local_init(c); }
+    void emit(gen_context &c) const { c.src << "( *"; p.emit(c); c.src << " )"; }
+    void set_args(arg_context &a) const { p.set_args(a); }
+    void get_props(prop_context &q) const { p.get_props(q); }
+};
+
 // ---- additive transforms: A*x terms (operations.hpp:759-776) ------------------
 struct additive_transform_base : expression_base {};
 
@@ -274,6 +298,8 @@ template <class Tag, class L, class R> struct expr_kind<binary_expr<Tag, L, R>>
 template <class A> struct expr_kind<unary_expr<tag::negate, A>> : std::integral_constant<int, expr_kind<A>::value> {};
 template <class Tag, class A> struct expr_kind<unary_expr<Tag, A>>
     : std::integral_constant<int, expr_kind<A>::value == 0 ? 0 : -1> {};
+
+template <class P> struct expr_kind<deref_expr<P>> : std::integral_constant<int, expr_kind<P>::value == 0 ? 0 : -1> {};
 
 template <class... A> struct all_vector_kind : std::true_type {};
 template <class H, class... T> struct all_vector_kind<H, T...>
@@ -556,6 +582,12 @@ VEXCL_UNARY_OPERATOR(logical_not, !)
 VEXCL_UNARY_OPERATOR(complement, ~)
 #undef VEXCL_UNARY_OPERATOR
 
+/// Dereference of a pointer-valued expression.
+template <class A>
+typename std::enable_if<is_expr<A>::value && std::is_pointer<typename as_expr_t<A>::value_type>::value,
+    const deref_expr<as_expr_t<A>>>::type
+operator*(const A &a) { return deref_expr<as_expr_t<A>>(as_expr<A>::get(a)); }
+
 /// Elementwise ternary: if_else(cond, a, b).
 template <class C, class A, class B>
 typename std::enable_if<is_operand<C>::value && is_operand<A>::value && is_operand<B>::value &&
@@ -598,6 +630,15 @@ void get_expression_properties(const Expr &expr, std::vector<backend::command_qu
     detail::prop_context p;
     detail::as_expr<Expr>::get(expr).get_props(p);
     queue = p.queue; part = p.part; size = p.size;
+}
+
+/// Tag of the reference's vector terminal (operations.hpp:560-580 there); kept for trait queries.
+struct vector_terminal {};
+namespace traits {
+/// What may stand as a leaf of a vector expression: values of device-native types and expression nodes.
+template <class T, class Enable = void>
+struct is_vector_expr_terminal : std::integral_constant<bool, is_cl_native<T>::value || detail::is_expr<T>::value> {};
+template <> struct is_vector_expr_terminal<vector_terminal, void> : std::true_type {};
 }
 
 /// (queues, size) of an expression or a tuple of expressions (operations.hpp:2370-2385 in the reference).

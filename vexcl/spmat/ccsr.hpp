@@ -15,6 +15,7 @@
 #include "../vector.hpp"
 
 namespace vex {
+template <class T, size_t N> class multivector;   // ../multivector.hpp
 
 template <typename val_t, typename col_t = ptrdiff_t, typename idx_t = size_t>
 struct SpMatCCSR {
@@ -153,6 +154,31 @@ template <typename val_t, typename col_t, typename idx_t, typename T>
 detail::ccsr_product<val_t, col_t, idx_t, T>
 operator*(const SpMatCCSR<val_t, col_t, idx_t> &A, const vector<T> &x) {
     return detail::ccsr_product<val_t, col_t, idx_t, T>(A, x);
+}
+
+namespace detail {
+/// A * X with X a multivector: component I of the multi-expression is the product A * X(I)
+/// (ccsr.hpp:240-280 of the reference; tests/spmv.cpp:345-437).
+template <typename val_t, typename col_t, typename idx_t, typename T, size_t N>
+struct ccsr_multi_product : expression_base {
+    typedef T value_type;
+    const SpMatCCSR<val_t, col_t, idx_t> &A; const multivector<T, N> &x;
+    ccsr_multi_product(const SpMatCCSR<val_t, col_t, idx_t> &A, const multivector<T, N> &x) : A(A), x(x) {}
+    void get_props(prop_context &p) const { ccsr_product<val_t, col_t, idx_t, T>(A, x(0)).get_props(p); }
+};
+template <typename val_t, typename col_t, typename idx_t, typename T, size_t N>
+struct mv_dim<ccsr_multi_product<val_t, col_t, idx_t, T, N>> : std::integral_constant<size_t, N> {};
+template <size_t I, typename val_t, typename col_t, typename idx_t, typename T, size_t N>
+struct component_of<I, ccsr_multi_product<val_t, col_t, idx_t, T, N>, void> {
+    typedef ccsr_product<val_t, col_t, idx_t, T> type;
+    static type get(const ccsr_multi_product<val_t, col_t, idx_t, T, N> &p) { return type(p.A, p.x(I)); }
+};
+} // namespace detail
+
+template <typename val_t, typename col_t, typename idx_t, typename T, size_t N>
+detail::ccsr_multi_product<val_t, col_t, idx_t, T, N>
+operator*(const SpMatCCSR<val_t, col_t, idx_t> &A, const multivector<T, N> &x) {
+    return detail::ccsr_multi_product<val_t, col_t, idx_t, T, N>(A, x);
 }
 
 } // namespace vex

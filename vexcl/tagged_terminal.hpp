@@ -60,7 +60,7 @@ struct tagged_terminal : detail::expression_base {
 
 /// Tags a terminal (tagged_terminal.hpp:51-80).
 template <size_t Tag, class Expr>
-typename std::enable_if<detail::is_operand<Expr>::value, tagged_terminal<Tag, detail::as_expr_t<Expr>>>::type
+typename std::enable_if<detail::is_operand<Expr>::value, const tagged_terminal<Tag, detail::as_expr_t<Expr>>>::type
 tag(const Expr &e) { return tagged_terminal<Tag, detail::as_expr_t<Expr>>(detail::as_expr<Expr>::get(e)); }
 
 } // namespace vex

@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <stdexcept>
 #include <vector>
 
 #include "backend.hpp"
@@ -215,8 +216,8 @@ class vector : public detail::expression_base {
             size_t d = owner(index);
             return element(queue[d], buf[d], index - part[d]);
         }
-        const element at(size_t index) const { precondition(index < size(), "Out of range"); return (*this)[index]; }
-        element at(size_t index) { precondition(index < size(), "Out of range"); return (*this)[index]; }
+        const element at(size_t index) const { if (index >= size()) throw std::out_of_range("vex::vector"); return (*this)[index]; }
+        element at(size_t index) { if (index >= size()) throw std::out_of_range("vex::vector"); return (*this)[index]; }
 
         size_t size() const { return part.empty() ? 0 : part.back(); }
         size_t nparts() const { return queue.size(); }
@@ -361,13 +362,40 @@ template <class T>
 std::ostream &operator<<(std::ostream &o, const vector<T> &t) {
     std::vector<T> data(t.size());
     copy(t, data);
-    o << "{";
+    // ten elements per line behind the index of the first; integers in 6 columns, reals as %14.6e
+    o << "{" << std::setprecision(6);
     for (size_t i = 0; i < data.size(); ++i) {
         if (i % 10 == 0) o << "\n" << std::setw(6) << i << ":";
-        o << " " << data[i];
+        if (std::is_integral<T>::value) o << " " << std::setw(6) << data[i];
+        else o << std::scientific << std::setw(14) << data[i];
     }
     return o << "\n}\n";
 }
+
+namespace detail {
+/// `&x` as an operand: the address of the current element of x (vector_arithmetics.cpp:263 of the
+/// reference's tests, `*if_else(c, &y, &z)`).
+template <class T>
+struct vector_address : expression_base {
+    typedef T *value_type;
+    const vector<T> *v;
+    explicit vector_address(const vector<T> *v) : v(v) {}
+    void preamble(gen_context &c) const { c.next(); }
+    void params(gen_context &c) const { c.src.template parameter<global_ptr<T>>(c.next()); }
+    void local_init(gen_context &c) const { c.next(); }
+    void emit(gen_context &c) const { c.src << "( " << c.next() << " + idx )"; }
+    void set_args(arg_context &a) const { a.next(); a.krn.push_arg((*v)(a.device)); }
+    void get_props(prop_context &p) const {
+        if (p.empty()) { p.queue = v->queue_list(); p.part = v->partition(); p.size = v->size(); }
+    }
+};
+template <class T> struct expr_kind<vector_address<T>> : std::integral_constant<int, 0> {};
+template <class T> struct is_extra_operand<vector<T> *> : std::true_type {};
+template <class T> struct as_expr<vector<T> *, void> {
+    typedef vector_address<T> type;
+    static type get(vector<T> *const &v) { return type(v); }
+};
+} // namespace detail
 
 } // namespace vex
 #endif

@@ -17,7 +17,16 @@ struct vector_pointer : expression_base {
     void emit(gen_context &c) const { c.src << c.next(); }
     void set_args(arg_context &a) const { a.next(); a.krn.push_arg((*v)(a.device)); }
     void get_props(prop_context &) const {}
+
+    /// p[i] with i an expression: the element i positions from the start (vector_pointer.hpp:100-140).
+    template <class I>
+    typename std::enable_if<is_operand<I>::value, const deref_expr<binary_expr<tag::plus, vector_pointer, as_expr_t<I>>>>::type
+    operator[](const I &i) const {
+        typedef binary_expr<tag::plus, vector_pointer, as_expr_t<I>> sum;
+        return deref_expr<sum>(sum(*this, as_expr<I>::get(i)));
+    }
 };
+template <class T> struct expr_kind<vector_pointer<T>> : std::integral_constant<int, 0> {};
 } // namespace detail
 
 template <class T>

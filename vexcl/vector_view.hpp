@@ -50,11 +50,66 @@ struct permutation_view : detail::expression_base {
 #undef VEXCL_VIEW_ASSIGN
 };
 
+/// permutation(index)(EXPRESSION): the expression evaluated at position index[idx] (an rvalue).  The
+/// expression is generated inside a block that re-declares `idx` as the mapped position.
+template <class E, class Index>
+struct expr_permutation_view : detail::expression_base {
+    typedef typename E::value_type value_type;
+    E expr; Index index;
+    expr_permutation_view(const E &e, const Index &i) : expr(e), index(i) {}
+    static std::string inner(const std::string &n) { return n + "_e"; }
+    static std::string where(const std::string &n) { return n + "_i"; }
+    void preamble(detail::gen_context &c) const {
+        const std::string n = c.next();
+        { detail::gen_context j(c, where(n)); index.preamble(j); }
+        { detail::gen_context i(c, inner(n)); expr.preamble(i); }
+    }
+    void params(detail::gen_context &c) const {
+        const std::string n = c.next();
+        { detail::gen_context j(c, where(n)); index.params(j); }
+        { detail::gen_context i(c, inner(n)); expr.params(i); }
+    }
+    void local_init(detail::gen_context &c) const {
+        const std::string n = c.next();
+        c.src.new_line() << type_name<value_type>() << " " << n << "_val;";
+        c.src.open("{");
+        { detail::gen_context j(c, where(n)); index.local_init(j); }
+        c.src.new_line() << "const ulong vex_pos = ";
+        { detail::gen_context j(c, where(n)); index.emit(j); }
+        c.src << ";";
+        c.src.open("{");
+        c.src.new_line() << "const ulong idx = vex_pos;";
+        { detail::gen_context i(c, inner(n)); expr.local_init(i); }
+        c.src.new_line() << n << "_val = ";
+        { detail::gen_context i(c, inner(n)); expr.emit(i); }
+        c.src << ";";
+        c.src.close("}");
+        c.src.close("}");
+    }
+    void emit(detail::gen_context &c) const { c.src << c.next() << "_val"; }
+    void set_args(detail::arg_context &a) const {
+        a.next();
+        { detail::arg_context j(a); index.set_args(j); }
+        { detail::arg_context i(a); expr.set_args(i); }
+    }
+    void get_props(detail::prop_context &p) const {
+        index.get_props(p);
+        detail::prop_context q; expr.get_props(q);
+        precondition(q.queue.size() <= 1, "permutation is only supported for single-device expressions");
+        if (p.queue.empty()) p.queue = q.queue;
+        if (p.part.empty() && p.size) p.part = {0, p.size};
+    }
+};
+
 template <class Index>
 struct permutation_builder {
     Index index;
     template <class T>
     permutation_view<T, Index> operator()(const vector<T> &base) const { return permutation_view<T, Index>(base, index); }
+    template <class Expr>
+    typename std::enable_if<detail::is_expr<Expr>::value && !detail::has_ref_type<Expr>::value,
+        expr_permutation_view<detail::as_expr_t<Expr>, Index>>::type
+    operator()(const Expr &e) const { return expr_permutation_view<detail::as_expr_t<Expr>, Index>(detail::as_expr<Expr>::get(e), index); }
 };
 
 /// permutation(index_expression)(vector)  (vector_view.hpp:602-700)
