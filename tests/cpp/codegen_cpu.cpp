@@ -206,6 +206,27 @@ TEST_CASE(by_key_kernels_compile) {                                   // scan_by
     backend::check_sources(s);
 }
 
+namespace {
+struct pair_less_t {                                                  // the reference's tests/sort.cpp:97-103 comparator
+    VEX_DUAL_FUNCTOR(bool, (int, a1)(float, a2)(int, b1)(float, b2), return (a1 == b1) ? (a2 < b2) : (a1 < b1);)
+};
+}
+
+TEST_CASE(merge_sort_kernels_compile) {                              // sort.hpp: detail::msort
+    using namespace detail::msort;
+    backend::command_queue q;
+    pair_less_t pl;
+    CHECK(pl(1, 2.0f, 1, 3.0f) && !pl(2, 0.0f, 1, 9.0f));              // the host side of the dual functor
+    typedef std::decay<decltype(pl.device)>::type dev;
+    std::string s = source<dev>(q, {"int", "float"}, items_per_lane(8));
+    CHECK(has(s, "vexcl_msort_block") && has(s, "vexcl_msort_partition") && has(s, "vexcl_msort_merge"));
+    CHECK(has(s, "return device(a.k0, a.k1, b.k0, b.k1);") && has(s, "#define VT 8"));
+    backend::check_sources(s);
+    typedef std::decay<decltype(vex::greater_equal<double>().device)>::type ge;
+    CHECK_EQUAL(items_per_lane(200), 1);
+    backend::check_sources(source<ge>(q, {"double"}, 2));
+}
+
 TEST_CASE(cast_and_temporaries) {                                    // cast.hpp / temporary.hpp
     vector<double> x, y;
     std::string s = src_of<assign::SET>(y, cast<float>(x) * 2 + cast<double>(5));

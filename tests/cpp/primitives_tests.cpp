@@ -60,6 +60,68 @@ TEST_CASE(sort_by_key_equals_stable_sort) {                          // sort.cpp
     CHECK(std::is_sorted(gl.begin(), gl.end()));
 }
 
+// ---- user comparators and tied keys: the generated merge sort (reference: tests/sort.cpp:47-200) ----
+namespace {
+struct low_nibble_first_t {                                          // many ties: 16 classes -- stability is visible
+    VEX_DUAL_FUNCTOR(bool, (int, a)(int, b), return (a & 15) < (b & 15);)
+};
+struct pair_less_t {
+    VEX_DUAL_FUNCTOR(bool, (int, a1)(float, a2)(int, b1)(float, b2), return (a1 == b1) ? (a2 < b2) : (a1 < b1);)
+};
+}
+
+TEST_CASE(sort_with_user_comparator_is_stable_at_every_size) {
+    low_nibble_first_t cmp;
+    for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(3), size_t(100), size_t(2047), size_t(2048), size_t(2049), size_t(4097),
+                     size_t(65536), size_t(100003), size_t(1 << 20) + 13}) {
+        std::vector<int> k(n);
+        for (size_t i = 0; i < n; ++i) k[i] = int((i * 2654435761u) >> 7);
+        std::vector<int> pos(n); std::iota(pos.begin(), pos.end(), 0);
+        vex::vector<int> K(ctx, n), P(ctx, n);
+        if (n) { vex::copy(k, K); vex::copy(pos, P); }
+        vex::sort_by_key(K, P, cmp);
+        std::vector<int> want(pos);
+        // per partition the device sort is stable; across partitions the host merge is: the whole is std::stable_sort
+        std::stable_sort(want.begin(), want.end(), [&](int a, int b) { return cmp(k[a], k[b]); });
+        std::vector<int> gk(n), gp(n);
+        if (n) { vex::copy(K, gk); vex::copy(P, gp); }
+        bool same = true;
+        for (size_t i = 0; i < n; ++i) same = same && gp[i] == want[i] && gk[i] == k[want[i]];
+        CHECK(same);
+        vex::vector<int> K2(ctx, n);
+        if (n) vex::copy(k, K2);
+        vex::sort(K2, cmp);                                            // keys only
+        if (n) vex::copy(K2, gk);
+        for (size_t i = 0; i < n; ++i) same = same && gk[i] == k[want[i]];
+        CHECK(same);
+    }
+}
+
+TEST_CASE(sort_tied_keys_and_tied_values) {                           // sort.cpp:85-200
+    pair_less_t less;
+    const size_t n = 300007;
+    std::vector<int> k1(n); std::vector<float> k2(n); std::vector<cl_long> v1(n); std::vector<short> v2(n);
+    for (size_t i = 0; i < n; ++i) { k1[i] = rand() % 50; k2[i] = float(rand() % 7); v1[i] = (cl_long)i * 1000003; v2[i] = short(i); }
+    vex::vector<int> K1(ctx, k1); vex::vector<float> K2(ctx, k2); vex::vector<cl_long> V1(ctx, v1); vex::vector<short> V2(ctx, v2);
+    std::vector<size_t> p(n); std::iota(p.begin(), p.end(), size_t(0));
+    std::stable_sort(p.begin(), p.end(), [&](size_t i, size_t j) { return less(k1[i], k2[i], k1[j], k2[j]); });
+    vex::sort_by_key(std::tie(K1, K2), std::tie(V1, V2), less);
+    std::vector<int> g1(n); std::vector<float> g2(n); std::vector<cl_long> w1(n); std::vector<short> w2(n);
+    vex::copy(K1, g1); vex::copy(K2, g2); vex::copy(V1, w1); vex::copy(V2, w2);
+    bool same = true;
+    for (size_t i = 0; i < n; ++i) same = same && g1[i] == k1[p[i]] && g2[i] == k2[p[i]] && w1[i] == v1[p[i]] && w2[i] == v2[p[i]];
+    CHECK(same);
+    // default comparator, values that the radix path cannot carry (2 bytes; two vectors): permuted afterwards
+    vex::vector<int> K(ctx, k1); vex::copy(v2, V2); vex::copy(v1, V1);
+    vex::sort_by_key(K, std::tie(V1, V2), vex::less<int>());
+    std::iota(p.begin(), p.end(), size_t(0));
+    std::stable_sort(p.begin(), p.end(), [&](size_t i, size_t j) { return k1[i] < k1[j]; });
+    vex::copy(K, g1); vex::copy(V1, w1); vex::copy(V2, w2);
+    same = true;
+    for (size_t i = 0; i < n; ++i) same = same && g1[i] == k1[p[i]] && w1[i] == v1[p[i]] && w2[i] == v2[p[i]];
+    CHECK(same);
+}
+
 // ---- stencil convolution: the reference's tests/stencil.cpp:17-110 --------------------
 static size_t clamp_index(size_t n, size_t i, long shift) {
     return std::min<size_t>(n - 1, std::max<long>(0, static_cast<long>(i) + shift));

@@ -105,9 +105,13 @@ namespace detail {
     } const fname
 
 // host parameter list of (t1, a)(t2, b)...: `t1 a, t2 b`
+// (the separating comma is produced one scan later than everything else, so that it never splits the
+// arguments of VEXCL_CAT)
+#define VEXCL_EMPTY()
+#define VEXCL_COMMA() ,
 #define VEXCL_ARG_FIRST(t, n) t n VEXCL_ARG_A
-#define VEXCL_ARG_A(t, n) , t n VEXCL_ARG_B
-#define VEXCL_ARG_B(t, n) , t n VEXCL_ARG_A
+#define VEXCL_ARG_A(t, n) VEXCL_COMMA VEXCL_EMPTY() () t n VEXCL_ARG_B
+#define VEXCL_ARG_B(t, n) VEXCL_COMMA VEXCL_EMPTY() () t n VEXCL_ARG_A
 #define VEXCL_ARG_A_END
 #define VEXCL_ARG_B_END
 #define VEXCL_ARG_SEQ(seq) VEXCL_CAT(VEXCL_ARG_FIRST seq, _END)
@@ -168,6 +172,37 @@ VEXCL_BUILTIN_FUNCTION(sin)    VEXCL_BUILTIN_FUNCTION(sinh)   VEXCL_BUILTIN_FUNC
 VEXCL_BUILTIN_FUNCTION(tan)    VEXCL_BUILTIN_FUNCTION(tanh)   VEXCL_BUILTIN_FUNCTION(tgamma)
 VEXCL_BUILTIN_FUNCTION(trunc)  VEXCL_BUILTIN_FUNCTION(isnan)  VEXCL_BUILTIN_FUNCTION(isinf)
 #undef VEXCL_BUILTIN_FUNCTION
+
+// ---- atomics (function.hpp:413-434): the first operand is a pointer-valued expression, `&view` or
+//      `p + i`; the value of the call is the value the location held before.  Both spellings.
+namespace detail {
+template <class P, class... V> struct atomic_result { typedef typename std::remove_pointer<typename as_expr_t<P>::value_type>::type type; };
+}
+#define VEXCL_ATOMIC_FUNCTION(fname, device_name)                                                   \
+    namespace detail {                                                                              \
+    struct builtin_##fname { static const char *name() { return #device_name; } };                  \
+    template <class P, class... V>                                                                  \
+    typename std::enable_if<is_expr<P>::value && std::is_pointer<typename as_expr_t<P>::value_type>::value && \
+        all_operands<V...>::value,                                                                  \
+        const function_call<builtin_function<builtin_##fname>, typename atomic_result<P>::type,     \
+            as_expr_t<P>, as_expr_t<V>...>>::type                                                   \
+    fname(const P &p, const V &...v) {                                                              \
+        return function_call<builtin_function<builtin_##fname>, typename atomic_result<P>::type,    \
+            as_expr_t<P>, as_expr_t<V>...>(as_expr<P>::get(p), as_expr<V>::get(v)...);              \
+    }                                                                                               \
+    }                                                                                               \
+    using detail::fname;
+VEXCL_ATOMIC_FUNCTION(atomicAdd, atomicAdd)   VEXCL_ATOMIC_FUNCTION(atomic_add, atomicAdd)
+VEXCL_ATOMIC_FUNCTION(atomicSub, atomicSub)   VEXCL_ATOMIC_FUNCTION(atomic_sub, atomicSub)
+VEXCL_ATOMIC_FUNCTION(atomicExch, atomicExch) VEXCL_ATOMIC_FUNCTION(atomic_xchg, atomicExch)
+VEXCL_ATOMIC_FUNCTION(atomicMin, atomicMin)   VEXCL_ATOMIC_FUNCTION(atomic_min, atomicMin)
+VEXCL_ATOMIC_FUNCTION(atomicMax, atomicMax)   VEXCL_ATOMIC_FUNCTION(atomic_max, atomicMax)
+VEXCL_ATOMIC_FUNCTION(atomicCAS, atomicCAS)   VEXCL_ATOMIC_FUNCTION(atomic_cmpxchg, atomicCAS)
+VEXCL_ATOMIC_FUNCTION(atomicAnd, atomicAnd)   VEXCL_ATOMIC_FUNCTION(atomic_and, atomicAnd)
+VEXCL_ATOMIC_FUNCTION(atomicOr, atomicOr)     VEXCL_ATOMIC_FUNCTION(atomic_or, atomicOr)
+VEXCL_ATOMIC_FUNCTION(atomicXor, atomicXor)   VEXCL_ATOMIC_FUNCTION(atomic_xor, atomicXor)
+VEXCL_ATOMIC_FUNCTION(atomicInc, atomicInc)   VEXCL_ATOMIC_FUNCTION(atomicDec, atomicDec)
+#undef VEXCL_ATOMIC_FUNCTION
 
 // abs(): fabs for floating point expressions, abs for integers (function.hpp:465-505)
 namespace detail {

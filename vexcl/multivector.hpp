@@ -171,13 +171,16 @@ template <class H, class... T> struct all_fusable<H, T...>
 
 /// lhs(I) OP component I of expr, for all I (multivector.hpp:486-650).
 template <class OP, class... Ts, class Expr, size_t... I>
-void assign_multi(const std::tuple<vector<Ts> &...> &lhs, const Expr &expr, std::index_sequence<I...>) {
+void assign_multi(const std::tuple<vector<Ts> &...> &lhs, const Expr &expr, std::index_sequence<I...>,
+        const std::vector<backend::command_queue> *on = nullptr)     // enqueue.hpp: queues to launch on
+{
     constexpr size_t N = sizeof...(Ts);
     static_assert(mv_dim<Expr>::value == 0 || mv_dim<Expr>::value == N,
             "the expression and the multivector it is assigned to have different numbers of components");
     auto &first = std::get<0>(lhs);
-    const auto &queue = first.queue_list();
+    const auto &queue = on ? *on : first.queue_list();
     const auto &part = first.partition();
+    precondition(queue.size() == first.queue_list().size(), "as many queues as the left-hand side has partitions are expected");
     {
         prop_context p;
         expr.get_props(p);
@@ -365,6 +368,9 @@ class multivector : public detail::expression_base {
         VEXCL_MULTI_ASSIGN_ONE(multivector, >>=, RSH)
 
         void get_props(detail::prop_context &p) const { vec[0]->get_props(p); }
+
+        /// The components as a tuple of references (what the assignment machinery works on).
+        auto components() const { return refs(); }
 
     private:
         std::array<std::unique_ptr<subtype>, N> vec;

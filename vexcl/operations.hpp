@@ -253,6 +253,21 @@ struct deref_expr : expression_base {
     void get_props(prop_context &q) const { p.get_props(q); }
 };
 
+/// &view: the address of the element a writable view designates (eval.cpp of the reference's tests:
+/// `atomic_add(&permutation(i)(y), 1)`).
+template <class V>
+struct address_expr : expression_base {
+    typedef typename V::value_type *value_type;
+    V v;
+    explicit address_expr(const V &v) : v(v) {}
+    void preamble(gen_context &c) const { v.preamble(c); }
+    void params(gen_context &c) const { v.params(c); }
+    void local_init(gen_context &c) const { v.local_init(c); }
+    void emit(gen_context &c) const { c.src << "( &"; v.emit(c); c.src << " )"; }
+    void set_args(arg_context &a) const { v.set_args(a); }
+    void get_props(prop_context &p) const { v.get_props(p); }
+};
+
 // ---- additive transforms: A*x terms (operations.hpp:759-776) ------------------
 struct additive_transform_base : expression_base {};
 

@@ -47,7 +47,7 @@ class csr {
             vex::detail::gen_context i(c, name + "_x"); x.params(i);
         }
         template <class R, class X> static void product_local_init(const X &x, vex::detail::gen_context &c, const std::string &name) {
-            c.src.new_line() << type_name<R>() << " " << name << "_sum = 0;";
+            spmv_ops_impl<Val, R>::decl_accum_var(c.src, name + "_sum");      // R: the value type of x
             c.src.new_line() << "if (" << name << "_ptr)";
             c.src.open("{");
             c.src.new_line() << type_name<Ptr>() << " row_beg = " << name << "_ptr[idx];";
@@ -55,7 +55,7 @@ class csr {
             c.src.new_line() << "for(" << type_name<Ptr>() << " j = row_beg; j < row_end; ++j)";
             c.src.open("{");
             c.src.new_line() << type_name<Col>() << " idx = " << name << "_col[j];";
-            detail::append_product(x, c, name, name + "_val[j]");
+            detail::append_product<Val>(x, c, name, name + "_val[j]");
             c.src.close("}");
             c.src.close("}");
         }

@@ -15,8 +15,9 @@ class ell {
         typedef Val value_type; typedef Val val_type; typedef Col col_type; typedef Ptr ptr_type;
         static_assert(std::is_same<Col, int>::value && std::is_same<Ptr, int>::value,
                 "sparse::ell on MI355X stores int32 indices");
-        static_assert(std::is_same<Val, double>::value || std::is_same<Val, float>::value,
-                "sparse::ell value type must be float or double (block values are out of scope)");
+        // float / double: converted on the device; any other value type (blocks, with rhs_of and
+        // spmv_ops_impl specialized): the same layout filled on the host
+        static const bool device_fill = std::is_same<Val, double>::value || std::is_same<Val, float>::value;
 
         template <class PtrRange, class ColRange, class ValRange>
         ell(const std::vector<backend::command_queue> &q, size_t nrows, size_t ncols,
@@ -26,9 +27,13 @@ class ell {
             precondition(q.size() == 1, "sparse::ell is only supported for single-device contexts");
             if (!n || !nnz) return;
             backend::device_vector<int> dptr(this->q, ptr.size(), &ptr[0]);
-            backend::device_vector<int> dcol(this->q, col.size(), &col[0]);
-            backend::device_vector<Val> dval(this->q, val.size(), &val[0]);
-            convert(dptr, dcol, dval);
+            if constexpr (device_fill) {
+                backend::device_vector<int> dcol(this->q, col.size(), &col[0]);
+                backend::device_vector<Val> dval(this->q, val.size(), &val[0]);
+                convert(dptr, dcol, dval);
+            } else {
+                convert_on_host(dptr, ptr, col, val);
+            }
         }
         ell(const backend::command_queue &q) : q(q), n(0), m(0), nnz(0), ell_width(0), ell_pitch(0), csr_nnz(0) {}
 
@@ -61,7 +66,7 @@ class ell {
             vex::detail::gen_context i(c, name + "_x"); x.params(i);
         }
         template <class R, class X> static void product_local_init(const X &x, vex::detail::gen_context &c, const std::string &name) {
-            c.src.new_line() << type_name<R>() << " " << name << "_sum = 0;";
+            spmv_ops_impl<Val, R>::decl_accum_var(c.src, name + "_sum");      // R: the value type of x
             c.src.open("{");
             c.src.new_line() << "for(size_t j = 0; j < " << name << "_ell_width; ++j)";
             c.src.open("{");
@@ -70,7 +75,7 @@ class ell {
             c.src.new_line() << "if (c != (" << type_name<Col>() << ")(-1))";
             c.src.open("{");
             c.src.new_line() << type_name<Col>() << " idx = c;";
-            detail::append_product(x, c, name, name + "_ell_val[nnz_idx]");
+            detail::append_product<Val>(x, c, name, name + "_ell_val[nnz_idx]");
             c.src.close("} else break;");
             c.src.close("}");
             c.src.new_line() << "if (" << name << "_csr_ptr)";
@@ -80,7 +85,7 @@ class ell {
             c.src.new_line() << "for(" << type_name<Ptr>() << " j = csr_beg; j < csr_end; ++j)";
             c.src.open("{");
             c.src.new_line() << type_name<Col>() << " idx = " << name << "_csr_col[j];";
-            detail::append_product(x, c, name, name + "_csr_val[j]");
+            detail::append_product<Val>(x, c, name, name + "_csr_val[j]");
             c.src.close("}");
             c.src.close("}");
             c.src.close("}");
@@ -102,6 +107,31 @@ class ell {
                 int *ec, double *ev, int *cp, int *cc, double *cv) { return vexhip_hell_fill_f64_i32(dev, s, n, p, c, v, w, pitch, ec, ev, cp, cc, cv); }
         static int fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, int64_t pitch,
                 int *ec, float *ev, int *cp, int *cc, float *cv) { return vexhip_hell_fill_f32_i32(dev, s, n, p, c, v, w, pitch, ec, ev, cp, cc, cv); }
+
+        /// Same split as the device conversion: the first `width` entries of a row go to the ELL part
+        /// (column -1 marks padding), the rest to the CSR tail.
+        template <class PtrRange, class ColRange, class ValRange>
+        void convert_on_host(const backend::device_vector<int> &dptr, const PtrRange &ptr, const ColRange &col, const ValRange &val) {
+            int64_t w = 0, tail = 0;
+            backend::check(vexhip_hell_analyze_i32(q.device_ordinal(), q.raw(), (int64_t)n, dptr.raw(), &w, &tail));
+            ell_width = (size_t)w; csr_nnz = (size_t)tail;
+            std::vector<Col> ec(ell_pitch * ell_width, Col(-1)), cc; std::vector<Val> ev(ell_pitch * ell_width, Val()), cv;
+            std::vector<Ptr> cp(n + 1, 0);
+            for (size_t i = 0; i < n; ++i) {
+                size_t j = 0;
+                for (Ptr k = ptr[i]; k < ptr[i + 1]; ++k, ++j) {
+                    if (j < ell_width) { ec[i + j * ell_pitch] = col[k]; ev[i + j * ell_pitch] = val[k]; }
+                    else { cc.push_back(col[k]); cv.push_back(val[k]); }
+                }
+                cp[i + 1] = (Ptr)cc.size();
+            }
+            precondition(cc.size() == csr_nnz, "sparse::ell: host and device disagree on the CSR tail");
+            if (ell_width) { ell_col = backend::device_vector<Col>(q, ec.size(), ec.data()); ell_val = backend::device_vector<Val>(q, ev.size(), ev.data()); }
+            if (csr_nnz) {
+                csr_ptr = backend::device_vector<Ptr>(q, cp.size(), cp.data());
+                csr_col = backend::device_vector<Col>(q, cc.size(), cc.data()); csr_val = backend::device_vector<Val>(q, cv.size(), cv.data());
+            }
+        }
 
         void convert(const backend::device_vector<int> &dptr, const backend::device_vector<int> &dcol, const backend::device_vector<Val> &dval) {
             int dev = q.device_ordinal();

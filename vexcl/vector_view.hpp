@@ -37,6 +37,9 @@ struct permutation_view : detail::expression_base {
         if (p.part.empty() && p.size) { p.part = {0, p.size}; }
     }
 
+    /// Address of the designated element, for atomics.
+    const detail::address_expr<permutation_view> operator&() const { return detail::address_expr<permutation_view>(*this); }
+
 #define VEXCL_VIEW_ASSIGN(op, tag)                                                                      \
     template <class Expr>                                                                               \
     typename std::enable_if<detail::is_operand<Expr>::value, const permutation_view &>::type            \
