@@ -60,6 +60,47 @@ TEST_CASE(sort_by_key_equals_stable_sort) {                          // sort.cpp
     CHECK(std::is_sorted(gl.begin(), gl.end()));
 }
 
+// ---- scans with a user operator (reference API: scan.hpp:426-518, `oper.device` + host operator()) ----
+namespace {
+struct running_max_t { VEX_DUAL_FUNCTOR(int, (int, a)(int, b), return a > b ? a : b;) };
+struct affine_t {                                                    // composition of x -> a*x + b packed in a long: NOT commutative
+    VEX_DUAL_FUNCTOR(long, (long, f)(long, g),
+        const long fa = f >> 32, fb = f & 0xffffffffl, ga = g >> 32, gb = g & 0xffffffffl;
+        return (((fa * ga) & 0xffffl) << 32) | ((ga * fb + gb) & 0xffffl);)
+};
+}
+
+TEST_CASE(scan_with_user_operators) {
+    running_max_t mx; affine_t comp;
+    for (size_t n : {size_t(1), size_t(777), size_t(4096), size_t(250001)}) {
+        std::vector<int> h(n);
+        for (size_t i = 0; i < n; ++i) h[i] = int((i * 2654435761u) % 100000) - 50000 + int(i / 8);
+        vex::vector<int> X(ctx, h), Y(ctx, n);
+        const int lowest = std::numeric_limits<int>::min();
+        vex::inclusive_scan(X, Y, lowest, mx);
+        std::vector<int> got(n), want(n);
+        vex::copy(Y, got);
+        int run = lowest;
+        for (size_t i = 0; i < n; ++i) { run = mx(run, h[i]); want[i] = run; }
+        CHECK(got == want);
+        vex::exclusive_scan(X, Y, lowest, mx);
+        vex::copy(Y, got);
+        run = lowest;
+        for (size_t i = 0; i < n; ++i) { want[i] = run; run = mx(run, h[i]); }
+        CHECK(got == want);
+
+        std::vector<long> f(n);
+        for (size_t i = 0; i < n; ++i) f[i] = (long(1 + i % 5) << 32) | long(i % 97);
+        vex::vector<long> F(ctx, f), G(ctx, n);
+        vex::inclusive_scan(F, G, long(1) << 32, comp);                // identity: x -> 1*x + 0
+        std::vector<long> gl(n), wl(n);
+        vex::copy(G, gl);
+        long acc = f[0]; wl[0] = acc;
+        for (size_t i = 1; i < n; ++i) { acc = comp(acc, f[i]); wl[i] = acc; }
+        CHECK(gl == wl);                                               // associativity holds exactly (integer arithmetic mod 2^k)
+    }
+}
+
 // ---- user comparators and tied keys: the generated merge sort (reference: tests/sort.cpp:47-200) ----
 namespace {
 struct low_nibble_first_t {                                          // many ties: 16 classes -- stability is visible

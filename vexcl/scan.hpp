@@ -10,9 +10,12 @@
 
 namespace vex {
 
-/// The only scan operator of the measured path; user operators are out of scope.
+/// The default scan operator (scan.hpp:419-424 of the reference): the library's look-back /
+/// reduce-then-scan kernels.  Any other operator -- a struct with VEX_DUAL_FUNCTOR, as in the
+/// reference -- goes through the generated segmented-scan kernels of scan_by_key.hpp with one
+/// segment (generic_scan below).
 template <class T> struct plus {
-    T operator()(T a, T b) const { return a + b; }
+    VEX_DUAL_FUNCTOR(T, (T, x)(T, y), return x + y;)
 };
 
 namespace detail {
@@ -62,22 +65,29 @@ namespace detail {
     }
 }
 
+namespace detail {
+    template <class T, class Oper>
+    void generic_scan(const vector<T> &input, vector<T> &output, bool exclusive, T init, Oper oper);   // scan_by_key.hpp
+}
+
 /// output[i] = input[0] + ... + input[i]; in-place allowed (scan.hpp:461-469).
 template <class T> void inclusive_scan(const vector<T> &input, vector<T> &output) {
     detail::scan_impl(input, output, false, T());
 }
-template <class T, class Oper> void inclusive_scan(const vector<T> &input, vector<T> &output, T, Oper) {
-    static_assert(std::is_same<Oper, plus<T>>::value, "only vex::plus<T> is supported by the MI355X scan");
-    detail::scan_impl(input, output, false, T());
+template <class T, class Oper> void inclusive_scan(const vector<T> &input, vector<T> &output, T init, Oper oper) {
+    if constexpr (std::is_same<Oper, plus<T>>::value) detail::scan_impl(input, output, false, T());
+    else detail::generic_scan(input, output, false, init, oper);
 }
 /// output[i] = init + input[0] + ... + input[i-1] (scan.hpp:510-518).
 template <class T> void exclusive_scan(const vector<T> &input, vector<T> &output, T init = T()) {
     detail::scan_impl(input, output, true, init);
 }
-template <class T, class Oper> void exclusive_scan(const vector<T> &input, vector<T> &output, T init, Oper) {
-    static_assert(std::is_same<Oper, plus<T>>::value, "only vex::plus<T> is supported by the MI355X scan");
-    detail::scan_impl(input, output, true, init);
+template <class T, class Oper> void exclusive_scan(const vector<T> &input, vector<T> &output, T init, Oper oper) {
+    if constexpr (std::is_same<Oper, plus<T>>::value) detail::scan_impl(input, output, true, init);
+    else detail::generic_scan(input, output, true, init, oper);
 }
 
 } // namespace vex
+
+#include "scan_by_key.hpp"
 #endif

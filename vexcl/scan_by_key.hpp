@@ -378,5 +378,50 @@ void inclusive_scan_by_key(const vector<K> &keys, const vector<V> &ivals, vector
     inclusive_scan_by_key(keys, ivals, ovals, detail::sbk::equal_fn<K>(), detail::sbk::plus_fn<V>(), init);
 }
 
+namespace detail {
+/// Scan with a user operator: per device one segment of the segmented scan (all keys equal); between
+/// devices the carry of the preceding partitions is applied with one fused kernel per device, the
+/// reference's scheme (scan.hpp:436-457, :478-506).
+template <class T, class Oper>
+void generic_scan(const vector<T> &input, vector<T> &output, bool exclusive, T init, Oper oper) {
+    precondition(input.size() == output.size() && input.nparts() == output.nparts(), "scan: incompatible vectors");
+    typedef typename std::decay<decltype(oper.device)>::type device_oper;
+    const auto &queue = input.queue_list();
+    const unsigned nd = static_cast<unsigned>(queue.size());
+    std::vector<T> last_in(nd, T()), tail(nd, T());
+    std::vector<char> used(nd, 0);
+    for (unsigned d = 0; d < nd; ++d) {
+        const size_t n = input.part_size(d);
+        if (!n) continue;
+        used[d] = 1;
+        if (nd > 1 && exclusive) input(d).read(queue[d], n - 1, 1, &last_in[d], true);
+        std::vector<backend::command_queue> one(1, queue[d]);
+        vector<int> key(one, n);
+        key = 0;
+        vector<T> in(queue[d], input(d), n), out(queue[d], output(d), n);
+        auto keys = std::tuple<const vector<int> &>(key);
+        if (exclusive) sbk::scan_by_key<true>(keys, in, out, sbk::equal_fn<int>(), device_oper(), init);
+        else           sbk::scan_by_key<false>(keys, in, out, sbk::equal_fn<int>(), device_oper(), init);
+        if (nd > 1) {
+            T last_out; output(d).read(queue[d], n - 1, 1, &last_out, true);
+            tail[d] = exclusive ? oper(last_out, last_in[d]) : last_out;     // the partition's total (exclusive: includes init)
+        }
+    }
+    if (nd > 1) {
+        // exclusive partitions after the first were started from init as well: the carry replaces it only
+        // when init is the operator's identity -- the reference makes the same assumption (scan.hpp:489-506)
+        bool have = false; T carry = T();
+        for (unsigned d = 0; d < nd; ++d) {
+            if (!used[d]) continue;
+            if (have) {
+                vector<T> seg(queue[d], output(d), input.part_size(d));
+                seg = oper.device(carry, seg);
+                carry = oper(carry, tail[d]);
+            } else { carry = tail[d]; have = true; }
+        }
+    }
+}
+} // namespace detail
+
 } // namespace vex
 #endif
