@@ -66,6 +66,9 @@ int vexhip_event_elapsed_ms(int dev, void *start, void *stop, float *ms);
 /* ---- device_vector<T> storage (backend/cuda/device_vector.hpp:66-214) --- */
 int vexhip_malloc(int dev, size_t bytes, void **ptr);
 int vexhip_free(int dev, void *ptr);
+/* svm_vector<T> storage (backend/cuda/svm_vector.hpp:57-62: cuMemAllocManaged): memory addressable by the host and
+ * the device alike (hipMallocManaged); released with vexhip_free. */
+int vexhip_malloc_managed(int dev, size_t bytes, void **ptr);
 int vexhip_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes, void *stream, int blocking); /* device_vector::write */
 int vexhip_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes, void *stream, int blocking); /* device_vector::read  */
 int vexhip_memcpy_d2d(int dev, void *dst, const void *src, size_t bytes, void *stream);
@@ -345,6 +348,21 @@ int vexhip_stencil_conv_f64(int dev, void *stream, int64_t n, int has_left, int 
         const double *s, const double *x, const double *xrem, double *y, double beta, double alpha);
 int vexhip_stencil_conv_f32(int dev, void *stream, int64_t n, int has_left, int has_right, int lhalo, int rhalo,
         const float *s, const float *x, const float *xrem, float *y, float beta, float alpha);
+
+/* ---- vex::FFT (vexcl/fft.hpp:69-148; fft/plan.hpp:214-330 plan + transform) -------------------------------
+ * Complex-to-complex transforms of interleaved (re, im) data, dtype VEXHIP_F32 / VEXHIP_F64 = the scalar type.
+ * `sizes` are row-major (last dimension contiguous); `dirs[j]` says what happens along dimension j -- a `none`
+ * dimension is a batch.  Any length: 2,3,5,7,11,13-smooth lengths run in the LDS row kernel (four-step
+ * beyond one row of LDS), others through Bluestein.  Unnormalized in both directions (the header applies 1/n
+ * for inverse dimensions, plan.hpp:236-241).  Out of place: `in` and `out` are distinct buffers of
+ * prod(sizes) complex elements on the plan's device.                                                        */
+enum { VEXHIP_FFT_FORWARD = 0, VEXHIP_FFT_INVERSE = 1, VEXHIP_FFT_NONE = 2 };      /* fft::direction, plan.hpp:49-53 */
+size_t vexhip_fft_best_size(size_t n);     /* fft::planner::best_size: smallest 2^a 3^b 5^c 7^d >= n (plan.hpp:126-128) */
+int vexhip_fft_plan_create(int dev, int dtype, int ndim, const size_t *sizes, const int *dirs, void **plan);
+int vexhip_fft_plan_destroy(void *plan);
+int vexhip_fft_exec(void *plan, void *stream, const void *in, void *out);
+/* what the plan consists of: LDS row passes, transposes, other launches (Bluestein, copy) */
+int vexhip_fft_plan_steps(void *plan, int *row_passes, int *transposes, int *others);
 
 /* ---- benchmark input generators (examples/benchmark.cpp:364-415; SURVEY
  *      section 8(d): 512^3 is built on the device, never uploaded) ---------- */

@@ -476,3 +476,51 @@ def random_normal(idx, seed, dtype=np.float64, generator="philox"):
     u0 = a.astype(np.float64) / 18446744073709551615.0
     u1 = b.astype(np.float64) / 18446744073709551615.0
     return np.sqrt(-2 * np.log(u0)) * np.cos(np.pi * (2 * u1))
+
+
+# ---- FFT (vexcl/fft.hpp:42-66, fft/plan.hpp:214-257) ---------------------------------------------------
+FFT_FORWARD, FFT_INVERSE, FFT_NONE = 0, 1, 2
+
+
+def dft_definition(x, inverse=False):
+    """The transform the reference computes along one dimension, by its definition:
+    X[k] = sum_j x[j] exp(-+ 2 pi i j k / n); the inverse divided by n (plan.hpp:236-241: scale = 1 / prod of the
+    inverse dimensions).  O(n^2), in extended precision: pins `fft_nd` for small n."""
+    x = np.asarray(x, dtype=np.clongdouble)
+    n = x.shape[-1]
+    j = np.arange(n)
+    ang = (-2 if not inverse else 2) * np.pi * ((np.outer(j, j) % n).astype(np.longdouble)) / np.longdouble(n)
+    w = np.cos(ang) + 1j * np.sin(ang)
+    y = x @ w
+    return (y / n if inverse else y).astype(np.complex128)
+
+
+def fft_nd(x, sizes, dirs):
+    """vex::FFT over a row-major array of shape `sizes`, one direction per dimension (FFT_NONE: batch dimension).
+    Real input is extended with a zero imaginary part (fft.hpp:44-48).  numpy's pocketfft per axis."""
+    a = np.asarray(x).reshape(sizes).astype(np.complex128)
+    for ax, d in enumerate(dirs):
+        if d == FFT_FORWARD:
+            a = np.fft.fft(a, axis=ax)
+        elif d == FFT_INVERSE:
+            a = np.fft.ifft(a, axis=ax)
+    return a.reshape(-1)
+
+
+def fft_best_size(n):
+    """fft::planner::best_size with the primes 2, 3, 5, 7: the smallest such number >= n (plan.hpp:103-128)."""
+    best = None
+    p7 = 1
+    while p7 < 2 * max(n, 1):
+        p5 = p7
+        while p5 < 2 * max(n, 1):
+            p3 = p5
+            while p3 < 2 * max(n, 1):
+                v = p3
+                while v < n:
+                    v *= 2
+                best = v if best is None else min(best, v)
+                p3 *= 3
+            p5 *= 5
+        p7 *= 7
+    return best

@@ -28,7 +28,7 @@ if [ "${1:-}" = "-j" ]; then jobs="$2"; shift 2; fi
 TESTS="${*:-vector_create vector_copy vector_arithmetics vector_view vector_pointer vector_io \
 tagged_terminal temporary cast constants logical reinterpret types eval events \
 multivector_create multivector_arithmetics spmv sparse_matrices stencil random sort scan \
-scan_by_key reduce_by_key context threads}"
+scan_by_key reduce_by_key context threads custom_kernel tensordot multi_array mba deduce svm generator}"
 
 if [ ! -d "$ref/tests" ]; then echo "build_ref: $ref/tests not present, nothing to do"; exit 0; fi
 mkdir -p "$out"

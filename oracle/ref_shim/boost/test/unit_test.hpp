@@ -23,6 +23,13 @@ namespace boost { namespace fusion {
 template <class... T> std::tuple<T &...> vector_tie(T &... t) { return std::tuple<T &...>(t...); }
 } }
 
+// boost::proto::display_expr(as_child(e)) in tests/deduce.cpp prints the Proto tree of an expression; the
+// expression templates here are not Proto trees, so the print is a no-op (the test's assertions are on types).
+namespace boost { namespace proto {
+template <class T> const T &as_child(const T &t) { return t; }
+template <class T> void display_expr(const T &) {}
+} }
+
 namespace shim {
 struct state {
     static int &failures() { static int f = 0; return f; }

@@ -154,3 +154,22 @@ def test_random_generators_known_answer_vectors(oracle):
     z = oracle.random_normal(idx, 7)
     assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
     assert not np.array_equal(oracle.random_uniform(idx, 1), oracle.random_uniform(idx, 2))
+
+
+def test_fft_oracle_matches_the_definition(oracle):
+    """oracle.fft_nd (numpy's pocketfft per axis) against the transform's definition in extended precision,
+    forward and inverse, 1-D and along each axis of an n-D array with batch dimensions."""
+    rng = np.random.default_rng(11)
+    for n in [1, 2, 3, 4, 5, 7, 8, 12, 17, 30, 64, 101]:
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        assert np.abs(oracle.fft_nd(x, [n], [oracle.FFT_FORWARD]) - oracle.dft_definition(x)).max() <= 1e-13 * n
+        assert np.abs(oracle.fft_nd(x, [n], [oracle.FFT_INVERSE]) - oracle.dft_definition(x, True)).max() <= 1e-13
+    sizes, dirs = [3, 5, 4], [oracle.FFT_NONE, oracle.FFT_FORWARD, oracle.FFT_INVERSE]
+    x = rng.standard_normal(60) + 1j * rng.standard_normal(60)
+    a = x.reshape(sizes)
+    want = np.empty_like(a)
+    for b in range(3):
+        t = np.stack([oracle.dft_definition(a[b, :, c]) for c in range(4)], axis=1)             # forward along dim 1
+        want[b] = np.stack([oracle.dft_definition(t[r, :], True) for r in range(5)], axis=0)   # inverse along dim 2
+    assert np.abs(oracle.fft_nd(x, sizes, dirs) - want.reshape(-1)).max() <= 1e-12
+    assert [oracle.fft_best_size(n) for n in (1, 2, 11, 17, 1025, 4097)] == [1, 2, 12, 18, 1029, 4116]

@@ -12,6 +12,7 @@
 // Terminals are numbered in traversal order, lhs first, exactly as the
 // reference does (prm_1, prm_2, ...), so generated kernels have the shape of
 // SURVEY appendix A.1 and are cached per expression TYPE per context.
+#include <limits>
 #include <set>
 #include <sstream>
 #include <string>
@@ -44,11 +45,15 @@ struct gen_context {
     int pos;
     std::set<std::string> own_seen;
     std::set<std::string> &seen;    // functions / tagged terminals already handled in this pass
+    bool symbolic;                  // generator.hpp: scalars are printed as literals, there are no parameters
     gen_context(backend::source_generator &s, const backend::command_queue &q, const std::string &p = "prm")
-        : src(s), queue(q), prefix(p), pos(0), seen(own_seen) {}
+        : src(s), queue(q), prefix(p), pos(0), seen(own_seen), symbolic(false) {}
     /// Child context with its own numbering (tagged terminals, the x operand of a sparse product).
     gen_context(gen_context &parent, const std::string &p)
-        : src(parent.src), queue(parent.queue), prefix(p), pos(0), seen(parent.seen) {}
+        : src(parent.src), queue(parent.queue), prefix(p), pos(0), seen(parent.seen), symbolic(parent.symbolic) {}
+    /// Recording context of the symbolic generator: the set of emitted functions outlives the context.
+    gen_context(backend::source_generator &s, const backend::command_queue &q, std::set<std::string> &seen_functions)
+        : src(s), queue(q), prefix("prm"), pos(0), seen(seen_functions), symbolic(true) {}
     gen_context(const gen_context &) = delete;
     std::string next() { std::ostringstream n; n << prefix << "_" << ++pos; return n.str(); }
 };
@@ -92,7 +97,15 @@ struct scalar_terminal : expression_base {
     void preamble(gen_context &c) const { c.next(); }
     void params(gen_context &c) const { c.src.template parameter<T>(c.next()); }
     void local_init(gen_context &c) const { c.next(); }
-    void emit(gen_context &c) const { c.src << c.next(); }
+    void emit(gen_context &c) const {
+        const std::string n = c.next();
+        if (!c.symbolic) { c.src << n; return; }
+        std::ostringstream lit;                 // recorded code: the value itself (generator.hpp:374-388 of the reference)
+        lit.precision(std::numeric_limits<T>::max_digits10);
+        if (std::is_floating_point<T>::value) lit << std::scientific;
+        lit << +v;
+        c.src << lit.str();
+    }
     void set_args(arg_context &a) const { a.next(); a.krn.push_arg(v); }
     void get_props(prop_context &) const {}
 };
@@ -156,7 +169,11 @@ template <class Tag, class L, class R>
 struct binary_result<Tag, L, R, typename std::enable_if<
     !tag::is_comparison<Tag>::value && !std::is_same<Tag, tag::shift_left>::value && !std::is_same<Tag, tag::shift_right>::value &&
     (is_cl_vector<L>::value || is_cl_vector<R>::value)>::type>
-{ typedef typename std::conditional<is_cl_vector<L>::value, L, R>::type type; };
+{   // the vector length of the vector operand over the common type of the scalars (double * cl_int2 is a cl_double2)
+    typedef typename cl_vector_of<
+        typename std::common_type<typename cl_scalar_of<L>::type, typename cl_scalar_of<R>::type>::type,
+        (cl_vector_length<L>::value > cl_vector_length<R>::value ? cl_vector_length<L>::value : cl_vector_length<R>::value)>::type type;
+};
 /// pointer + offset, pointer - offset (vector_pointer.hpp: *(p + i)).
 template <class L, class R> struct binary_result<tag::plus, L *, R, typename std::enable_if<std::is_integral<R>::value>::type> { typedef L *type; };
 template <class L, class R> struct binary_result<tag::minus, L *, R, typename std::enable_if<std::is_integral<R>::value>::type> { typedef L *type; };
@@ -226,9 +243,15 @@ struct function_call : expression_base {
 };
 
 /// ( c ? a : b ) -- vex::if_else (operations.hpp ternary, tests/vector_arithmetics.cpp:238-250).
+/// Type of ( c ? a : b ): the common type; for pointers to different types, a pointer to the
+/// common type of what they point to (type deduction only: `*if_else(c, &x, &y)`, tests/deduce.cpp:126).
+template <class A, class B, class Enable = void> struct ternary_result { typedef typename std::common_type<A, B>::type type; };
+template <class A, class B>
+struct ternary_result<A *, B *, typename std::enable_if<!std::is_same<A, B>::value>::type> { typedef typename std::common_type<A, B>::type *type; };
+
 template <class C, class A, class B>
 struct ternary_expr : expression_base {
-    typedef typename std::common_type<typename A::value_type, typename B::value_type>::type value_type;
+    typedef typename ternary_result<typename A::value_type, typename B::value_type>::type value_type;
     C c_; A a; B b;
     ternary_expr(const C &c, const A &a, const B &b) : c_(c), a(a), b(b) {}
     void preamble(gen_context &c) const { c_.preamble(c); a.preamble(c); b.preamble(c); }
@@ -645,6 +668,11 @@ void get_expression_properties(const Expr &expr, std::vector<backend::command_qu
     detail::prop_context p;
     detail::as_expr<Expr>::get(expr).get_props(p);
     queue = p.queue; part = p.part; size = p.size;
+}
+
+namespace detail {
+/// The value type an expression (or a plain value used as one) evaluates to (operations.hpp:1680-1812).
+template <class Expr> struct return_type { typedef typename as_expr_t<Expr>::value_type type; };
 }
 
 /// Tag of the reference's vector terminal (operations.hpp:560-580 there); kept for trait queries.

@@ -51,6 +51,13 @@ struct permutation_view : detail::expression_base {
     VEXCL_VIEW_ASSIGN(=, SET) VEXCL_VIEW_ASSIGN(+=, ADD) VEXCL_VIEW_ASSIGN(-=, SUB)
     VEXCL_VIEW_ASSIGN(*=, MUL) VEXCL_VIEW_ASSIGN(/=, DIV)
 #undef VEXCL_VIEW_ASSIGN
+    /// view = view copies ELEMENTS.
+    const permutation_view &operator=(const permutation_view &other) const {
+        detail::prop_context p; get_props(p);
+        detail::assign_expression<assign::SET>(*this, other, p.queue, p.part);
+        return *this;
+    }
+    permutation_view(const permutation_view &) = default;
 };
 
 /// permutation(index)(EXPRESSION): the expression evaluated at position index[idx] (an rvalue).  The
@@ -155,6 +162,25 @@ std::array<T, 1 + sizeof...(Tail)> make_array(T t, Tail... tail) {
     return a;
 }
 
+/// indices[i][range][_]...: one index or range per dimension (vector_view.hpp:470-503).  `Dims` records
+/// WHICH positions were given as ranges -- the dimensions a view of the result still has (multi_array.hpp).
+template <size_t NR, class Dims = std::index_sequence<>> struct index_gen;
+template <size_t NR, size_t... D>
+struct index_gen<NR, std::index_sequence<D...>> {
+    std::array<range, NR> ranges;
+    index_gen() {}
+    index_gen<NR + 1, std::index_sequence<D..., NR>> operator[](const range &r) const { return append<std::index_sequence<D..., NR>>(r); }
+    index_gen<NR + 1, std::index_sequence<D...>> operator[](size_t i) const { return append<std::index_sequence<D...>>(range((ptrdiff_t)i)); }
+    private:
+        template <class Next> index_gen<NR + 1, Next> append(const range &r) const {
+            index_gen<NR + 1, Next> idx;
+            std::copy(ranges.begin(), ranges.end(), idx.ranges.begin());
+            idx.ranges.back() = r;
+            return idx;
+        }
+};
+static const index_gen<0> indices;
+
 template <class E, size_t NDIM> struct expr_slice_view;
 template <class T, size_t NDIM> struct vector_slice_view;
 
@@ -246,6 +272,13 @@ struct vector_slice_view : detail::expression_base {
     VEXCL_SLICE_ASSIGN(=, SET) VEXCL_SLICE_ASSIGN(+=, ADD) VEXCL_SLICE_ASSIGN(-=, SUB)
     VEXCL_SLICE_ASSIGN(*=, MUL) VEXCL_SLICE_ASSIGN(/=, DIV)
 #undef VEXCL_SLICE_ASSIGN
+    /// slice = slice copies ELEMENTS (y(indices[_][_][i]).vec() = x(indices[i][_][_]).vec(), tests/multi_array.cpp:63).
+    const vector_slice_view &operator=(const vector_slice_view &other) const {
+        std::vector<size_t> part = {0, slice.size()};
+        detail::assign_expression<assign::SET>(*this, other, base->queue_list(), part);
+        return *this;
+    }
+    vector_slice_view(const vector_slice_view &) = default;
 };
 
 template <class E, size_t NDIM>
@@ -316,6 +349,19 @@ struct slicer {
             }
     };
     slice<0> operator[](const range &r) const { return slice<0>(*this, r.empty() ? range(0, (ptrdiff_t)dim[0]) : r); }
+    /// slicer(indices[...][...]): the slice in one call (vector_view.hpp:532-547).
+    template <class Dims>
+    gslice<NR> operator()(const index_gen<NR, Dims> &idx) const {
+        size_t start = 0;
+        std::array<size_t, NR> len; std::array<ptrdiff_t, NR> str;
+        for (size_t i = 0; i < NR; ++i) {
+            const range r = idx.ranges[i].empty() ? range(0, (ptrdiff_t)dim[i]) : idx.ranges[i];
+            start += (size_t)(r.start * (ptrdiff_t)stride[i]);
+            len[i] = r.length();
+            str[i] = r.stride * (ptrdiff_t)stride[i];
+        }
+        return gslice<NR>(start, len, str);
+    }
 
     private:
         template <class T> void init(const T *d) {
@@ -441,22 +487,27 @@ reduced_view<detail::vector_ref<T>, NDIM, 1, RDC> reduce(const vector_slice_view
     return reduce<RDC>(v, d);
 }
 
-/// reshape(expr, dst_dims, src_dims): result dimension j is source dimension src_dims[j]
-/// (vector_view.hpp:1012-1130): a slice with permuted strides.
-template <class Expr, size_t N>
-auto reshape(const Expr &expr, const std::array<size_t, N> &dst_dims, const std::array<size_t, N> &src_dims)
-    -> decltype(gslice<N>()(expr))
+/// reshape(expr, dst_dims, src_dims): an expression shaped `dst_dims` made from one shaped
+/// `dst_dims[src_dims]` (row-major); `src_dims` are indices into `dst_dims`
+/// (vector_view.hpp:1003-1124).  Destination dimensions that `src_dims` does not name are
+/// broadcast (stride 0) -- `reshape(b, extents[N][N], extents[1])` repeats the vector b along
+/// dimension 0.  A slice with permuted strides.
+template <class Expr, size_t Nout, size_t Nin>
+auto reshape(const Expr &expr, const std::array<size_t, Nout> &dst_dims, const std::array<size_t, Nin> &src_dims)
+    -> decltype(gslice<Nout>()(expr))
 {
-    std::array<size_t, N> src_len, src_stride;
-    for (size_t j = 0; j < N; ++j) { precondition(src_dims[j] < N, "reshape: bad source dimension"); src_len[src_dims[j]] = dst_dims[j]; }
-    src_stride.back() = 1;
-    for (size_t d = N - 1; d-- > 0;) src_stride[d] = src_stride[d + 1] * src_len[d + 1];
-    std::array<ptrdiff_t, N> stride;
-    for (size_t j = 0; j < N; ++j) stride[j] = (ptrdiff_t)src_stride[src_dims[j]];
-    return gslice<N>(0, dst_dims, stride)(expr);
+    static_assert(Nin >= 1 && Nin <= Nout, "reshape: the source has more dimensions than the destination");
+    std::array<size_t, Nin> src_stride;
+    for (size_t k = 0; k < Nin; ++k) precondition(src_dims[k] < Nout, "reshape: bad source dimension");
+    src_stride[Nin - 1] = 1;
+    for (size_t k = Nin - 1; k-- > 0;) src_stride[k] = src_stride[k + 1] * dst_dims[src_dims[k + 1]];
+    std::array<ptrdiff_t, Nout> stride;
+    stride.fill(0);
+    for (size_t k = 0; k < Nin; ++k) stride[src_dims[k]] = (ptrdiff_t)src_stride[k];
+    return gslice<Nout>(0, dst_dims, stride)(expr);
 }
-template <class Expr, size_t N>
-auto reshape(const Expr &expr, const extent_gen<N> &dst_dims, const extent_gen<N> &src_dims)
+template <class Expr, size_t Nout, size_t Nin>
+auto reshape(const Expr &expr, const extent_gen<Nout> &dst_dims, const extent_gen<Nin> &src_dims)
     -> decltype(reshape(expr, dst_dims.dim, src_dims.dim)) { return reshape(expr, dst_dims.dim, src_dims.dim); }
 
 } // namespace vex

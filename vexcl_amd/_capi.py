@@ -72,6 +72,7 @@ _PROTOS = {
     "vexhip_stream_wait_event": (None, [c_int, c_vp, c_vp]),
     "vexhip_event_elapsed_ms": (None, [c_int, c_vp, c_vp, ctypes.POINTER(c_f32)]),
     "vexhip_malloc": (None, [c_int, c_size, ctypes.POINTER(c_vp)]),
+    "vexhip_malloc_managed": (None, [c_int, c_size, ctypes.POINTER(c_vp)]),
     "vexhip_free": (None, [c_int, c_vp]),
     "vexhip_memcpy_h2d": (None, [c_int, c_vp, c_vp, c_size, c_vp, c_int]),
     "vexhip_memcpy_d2h": (None, [c_int, c_vp, c_vp, c_size, c_vp, c_int]),
@@ -154,6 +155,11 @@ _PROTOS = {
     "vexhip_poisson3d_strip_f64_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "vexhip_fill_hash": (None, [c_int, c_vp, c_int, c_u64, c_vp, c_i64]),
     "vexhip_fill_value": (None, [c_int, c_vp, c_int, c_vp, c_vp, c_i64]),
+    "vexhip_fft_best_size": (c_size, [c_size]),
+    "vexhip_fft_plan_create": (None, [c_int, c_int, c_int, ctypes.POINTER(c_size), ctypes.POINTER(c_int), ctypes.POINTER(c_vp)]),
+    "vexhip_fft_plan_destroy": (None, [c_vp]),
+    "vexhip_fft_exec": (None, [c_vp, c_vp, c_vp, c_vp]),
+    "vexhip_fft_plan_steps": (None, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
 }
 
 EXPORTS = tuple(sorted(_PROTOS))

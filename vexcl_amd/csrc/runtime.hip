@@ -241,6 +241,15 @@ int vexhip_malloc(int dev, size_t bytes, void **ptr) {
     return 0;
 }
 
+int vexhip_malloc_managed(int dev, size_t bytes, void **ptr) {
+    VEXHIP_REQUIRE(ptr, "ptr is NULL");
+    VEXHIP_SET_DEVICE(dev);
+    *ptr = nullptr;
+    if (bytes == 0) return 0;
+    VEXHIP_TRY(hipMallocManaged(ptr, bytes, hipMemAttachGlobal));
+    return 0;
+}
+
 int vexhip_free(int dev, void *ptr) {
     if (!ptr) return 0;
     VEXHIP_SET_DEVICE(dev);

@@ -493,3 +493,69 @@ def sort(keys, descending=False, unsigned=False):
 def sort_by_key(keys, vals, descending=False, unsigned=False):
     """vex::sort_by_key(keys, vals) -- in place, stable (sort.hpp:2170-2182)."""
     return _sort(keys, vals, descending, unsigned)
+
+
+# --------------------------------------------------------------------------
+# FFT (vexcl/fft.hpp:69-148)
+# --------------------------------------------------------------------------
+FORWARD, INVERSE, NONE = 0, 1, 2        # vex::fft::direction
+
+
+def fft_best_size(n):
+    """vex::fft::planner::best_size: smallest 2^a 3^b 5^c 7^d >= n."""
+    return int(lib().fft_best_size(n))
+
+
+class FFT:
+    """vex::FFT<cl_double2> / <cl_float2> over a complex torch tensor: ``sizes`` row-major, one direction per
+    dimension (NONE = batch).  Like the reference, inverse dimensions are scaled by 1/n (fft/plan.hpp:236-241)."""
+
+    def __init__(self, sizes, dirs=FORWARD, dtype=torch.complex128, device="cuda"):
+        self.sizes = [int(s) for s in (sizes if hasattr(sizes, "__len__") else [sizes])]
+        self.dirs = [int(d) for d in (dirs if hasattr(dirs, "__len__") else [dirs] * len(self.sizes))]
+        if len(self.dirs) != len(self.sizes):
+            raise Error("one direction per dimension is required")
+        if dtype not in (torch.complex128, torch.complex64):
+            raise Error("only complex64 / complex128 data are supported")
+        self.dtype = dtype
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise Error("vexcl_amd.FFT runs on the GPU only; there is no CPU fallback")
+        self.dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.scale = 1.0
+        for s, d in zip(self.sizes, self.dirs):
+            if d == INVERSE:
+                self.scale /= s
+        sz = (ctypes.c_size_t * len(self.sizes))(*self.sizes)
+        dr = (ctypes.c_int * len(self.dirs))(*self.dirs)
+        self._plan = ctypes.c_void_p()
+        lib().fft_plan_create(self.dev, _capi.F64 if dtype == torch.complex128 else _capi.F32, len(self.sizes), sz, dr,
+                              ctypes.byref(self._plan))
+
+    def steps(self):
+        r, t, o = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib().fft_plan_steps(self._plan, ctypes.byref(r), ctypes.byref(t), ctypes.byref(o))
+        return r.value, t.value, o.value
+
+    def __call__(self, x, out=None, scaled=True):
+        total = 1
+        for s in self.sizes:
+            total *= s
+        if x.dtype != self.dtype or x.numel() != total:
+            raise Error("FFT plan is for %d %s elements" % (total, self.dtype))
+        _chk(x, "x")
+        if out is None:
+            out = torch.empty_like(x)
+        if total:
+            lib().fft_exec(self._plan, _stream(x), _p(x), _p(out))
+        if scaled and self.scale != 1.0:
+            out.mul_(self.scale)
+        return out
+
+    def __del__(self):
+        try:
+            if self._plan:
+                lib().fft_plan_destroy(self._plan)
+                self._plan = ctypes.c_void_p()
+        except Exception:
+            pass
