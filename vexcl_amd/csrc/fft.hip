@@ -2,18 +2,31 @@
 // global-memory radix passes, one launch per radix, plus a transpose per dimension).
 //
 // MI355X design.  A transform is HBM-bound, so the plan is built around ONE kernel that moves every element
-// once: `fft_rows_kernel` brings a batch of contiguous rows into LDS with 16-byte coalesced loads, runs ALL
-// radix stages of the row there (Stockham autosort between two LDS buffers, 256 lanes, radix 8/4/2 for the
-// power-of-two part and 3/5/7/11/13 for the rest, twiddles from a per-length table that stays in L2) and writes
-// the rows back -- 1 read + 1 write of the data per row pass, whatever the number of stages (the reference
-// launches one global-memory pass per radix: 3-4 for n = 4096).  A row of up to 2048 (fp64) / 4096 (fp32)
-// complex elements fits (2 x 32 KiB of LDS, two workgroups per CU).  On top of that kernel:
-//   * longer rows: four-step decomposition n = n1 * n2 (transpose, n2 x FFT(n1) with the W_n^(j2 k1) twiddle fused
-//     into the store, transpose, n1 x FFT(n2) -- recursively --, transpose);
-//   * lengths with a prime factor above 13: Bluestein's chirp-z over a 2^a 3^b 5^c 7^d convolution length;
-//   * n-D transforms and batches: the reference's scheme of rotating the dimensions with one tiled LDS transpose
-//     per transformed dimension (plan.hpp:243-256), rows always contiguous; `none` dimensions on the left cost nothing.
-// The plan (factorizations, twiddle / chirp tables, work buffers) is native C++ behind four C entry points.
+// once per pass and does as much of the transform as fits in LDS in that pass.  `fft_lines_kernel` brings a
+// tile of LINES (1-D sub-sequences of the data: any element stride, line offsets given by a small mixed-radix
+// table) into LDS, runs ALL radix stages of their length there (Stockham autosort between two LDS buffers,
+// 256 lanes, radix 8/4/2 for the power-of-two part and 3/5/7/11/13 for the rest, twiddles from a per-length
+// table that stays in L2), optionally multiplies by the inter-pass twiddle, and writes the lines back through
+// a second offset table.  Global accesses are coalesced along whichever direction is contiguous: along the
+// line when its element stride is 1, ACROSS the lines of the tile otherwise (LDS rows are padded by one element
+// so both directions are conflict-free).  With that one kernel
+//   * a contiguous row of up to 2048 (fp64) / 4096 (fp32) elements is ONE pass, whatever its number of radix
+//     stages (the reference launches one global-memory pass per radix: 3-4 for n = 4096);
+//   * a longer length n = n1 n2 [n3] is 2 [3] passes and NO transpose: pass t transforms digit t in place (lines
+//     strided by the product of the later factors, tile = neighbouring lines, twiddle W^(k_t J) fused into the
+//     store), the last pass reads contiguous lines and scatters them to the digit-reversed position -- a scatter
+//     whose tile writes runs of consecutive elements, because the tile's lines are enumerated in output order;
+//   * the dimensions of an n-D transform (and batches) need no transposes either: a dimension with element
+//     stride s is a set of lines with stride s, neighbouring lines adjacent in memory.
+// The reference rotates the array with one transpose per dimension and the textbook four-step algorithm
+// has three; here 4096 x 4096 fp64 is 4 passes over the data instead of 12.  Lengths with a prime factor above
+// 13 go through Bluestein's chirp-z over a 2^a 3^b 5^c 7^d convolution length (rows gathered by a tiled LDS
+// transpose when the dimension is strided).  The plan (factorizations, passes, twiddle / chirp tables, work
+// buffers) is native C++ behind four C entry points.
+// Measured on MI355X (tools/fft_bench.py): fp64 1024-point rows 0.76 ms per 2.1 GB moved (2.8 TB/s; rocFFT 0.77 ms),
+// 2^24 points 0.77 ms in 3 passes (rocFFT 0.60), 4096 x 4096 0.87 ms in 4 passes (0.50).  Tried and dropped: an LDS
+// layout skewed by one element per eight (removes the bank conflicts of the first stage's writes, but the extra
+// index arithmetic on every access cost more: 0.76 -> 0.94 ms on the 1024-point rows).
 #include "common.hpp"
 
 #include <algorithm>
@@ -41,24 +54,34 @@ struct stage_list { int count; int radix[MAX_STAGES]; };
 template <typename T, int R> struct dft;
 
 template <typename T> struct dft<T, 2> {
-    static __device__ __forceinline__ void run(cx<T> (&v)[2], const cx<T> *) {
+    static __device__ __forceinline__ void run(cx<T> (&v)[2], const cx<T> *, bool) {
         const cx<T> a = v[0], b = v[1];
         v[0] = a + b; v[1] = a - b;
     }
 };
-template <typename T> __device__ __forceinline__ void dft4(cx<T> &a, cx<T> &b, cx<T> &c, cx<T> &d, cx<T> w4) {
-    const cx<T> t0 = a + c, t1 = a - c, t2 = b + d, t3 = (b - d) * w4;
+/// v * (-i) for the forward transform, v * (+i) for the inverse.
+template <typename T> __device__ __forceinline__ cx<T> mul_w4(cx<T> v, bool inverse) {
+    return inverse ? cx<T>{-v.y, v.x} : cx<T>{v.y, -v.x};
+}
+template <typename T> __device__ __forceinline__ void dft4(cx<T> &a, cx<T> &b, cx<T> &c, cx<T> &d, bool inverse) {
+    const cx<T> t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_w4(b - d, inverse);
     a = t0 + t2; b = t1 + t3; c = t0 - t2; d = t1 - t3;
 }
 template <typename T> struct dft<T, 4> {
-    static __device__ __forceinline__ void run(cx<T> (&v)[4], const cx<T> *root) { dft4(v[0], v[1], v[2], v[3], root[1]); }
+    static __device__ __forceinline__ void run(cx<T> (&v)[4], const cx<T> *, bool inverse) { dft4(v[0], v[1], v[2], v[3], inverse); }
 };
 template <typename T> struct dft<T, 8> {
-    static __device__ __forceinline__ void run(cx<T> (&v)[8], const cx<T> *root) {
-        dft4(v[0], v[2], v[4], v[6], root[2]);          // even samples -> E[0..3] in v[0], v[2], v[4], v[6]
-        dft4(v[1], v[3], v[5], v[7], root[2]);          // odd samples  -> O[0..3]
+    static __device__ __forceinline__ void run(cx<T> (&v)[8], const cx<T> *, bool inverse) {
+        dft4(v[0], v[2], v[4], v[6], inverse);          // even samples -> E[0..3] in v[0], v[2], v[4], v[6]
+        dft4(v[1], v[3], v[5], v[7], inverse);          // odd samples  -> O[0..3]
+        const T h = (T)0.70710678118654752440;
         const cx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-        const cx<T> o0 = v[1], o1 = v[3] * root[1], o2 = v[5] * root[2], o3 = v[7] * root[3];
+        // O[k] * W_8^k: W_8 = (1 -+ i) / sqrt 2, W_8^2 = -+i, W_8^3 = (-1 -+ i) / sqrt 2
+        const cx<T> o0 = v[1];
+        const cx<T> r1 = mul_w4(v[3], inverse), r3 = mul_w4(v[7], inverse);
+        const cx<T> o1 = {(v[3].x + r1.x) * h, (v[3].y + r1.y) * h};
+        const cx<T> o2 = mul_w4(v[5], inverse);
+        const cx<T> o3 = {(r3.x - v[7].x) * h, (r3.y - v[7].y) * h};
         v[0] = e0 + o0; v[4] = e0 - o0;
         v[1] = e1 + o1; v[5] = e1 - o1;
         v[2] = e2 + o2; v[6] = e2 - o2;
@@ -67,7 +90,7 @@ template <typename T> struct dft<T, 8> {
 };
 /// Odd primes: the definition, unrolled (the exponents fold to constants).
 template <typename T, int R> struct dft {
-    static __device__ __forceinline__ void run(cx<T> (&v)[R], const cx<T> *root) {
+    static __device__ __forceinline__ void run(cx<T> (&v)[R], const cx<T> *root, bool) {
         cx<T> out[R];
 #pragma unroll
         for (int s = 0; s < R; ++s) {
@@ -81,21 +104,36 @@ template <typename T, int R> struct dft {
     }
 };
 
-/// One Stockham stage over the rows held in LDS: `src` -> `dst`, sub-transform length p -> p * R.
+/// Division by a run-time constant that is usually a power of two (shift < 0: not a power of two).
+struct divisor {
+    int d, shift;
+    __host__ __device__ static divisor make(int v) {
+        divisor r; r.d = v; r.shift = -1;
+        if (v > 0 && (v & (v - 1)) == 0) { r.shift = 0; while ((1 << r.shift) < v) ++r.shift; }
+        return r;
+    }
+    __device__ __forceinline__ int div(int x) const { return shift >= 0 ? (x >> shift) : (x / d); }
+};
+
+/// One Stockham stage over the lines held in LDS (line l at l * pitch): `src` -> `dst`, sub-transform length p -> p * R.
 template <typename T, int R>
 __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__restrict__ dst,
-        const cx<T> *__restrict__ tw, int n, int p, int nrows, bool inverse)
+        const cx<T> *__restrict__ tw, int n, int pitch, int p, int nlines, bool inverse)
 {
-    const int nb = n / R;                        // butterflies per row
+    const int nb = n / R;                        // butterflies per line
     const int tstride = n / (p * R);             // W_(pR)^k = tw[k * tstride]
-    cx<T> root[R];
+    const divisor dnb = divisor::make(nb), dp = divisor::make(p);
+    constexpr bool needs_roots = R != 2 && R != 4 && R != 8;
+    cx<T> root[needs_roots ? R : 1];
+    if constexpr (needs_roots) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) { root[t] = tw[(size_t)t * nb]; if (inverse) root[t].y = -root[t].y; }
-    const int total = nrows * nb;
+        for (int t = 0; t < R; ++t) { root[t] = tw[(size_t)t * nb]; if (inverse) root[t].y = -root[t].y; }
+    }
+    const int total = nlines * nb;
     for (int b = threadIdx.x; b < total; b += FB) {
-        const int row = b / nb, j = b - row * nb;
-        const int k = j % p;
-        const cx<T> *in = src + (size_t)row * n + j;
+        const int line = dnb.div(b), j = b - line * nb;
+        const int k = j - dp.div(j) * p;
+        const cx<T> *in = src + line * pitch + j;
         cx<T> v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = in[q * nb];
@@ -106,62 +144,108 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
 #pragma unroll
             for (int q = 1; q < R; ++q) { v[q] = v[q] * w; if (q + 1 < R) w = w * w1; }
         }
-        dft<T, R>::run(v, root);
-        cx<T> *out = dst + (size_t)row * n + (size_t)(j - k) * R + k;
+        dft<T, R>::run(v, root, inverse);
+        cx<T> *out = dst + line * pitch + (j - k) * R + k;
 #pragma unroll
         for (int s = 0; s < R; ++s) out[s * p] = v[s];
     }
 }
 
-/// A batch of contiguous rows, each transformed completely in LDS.
-/// Optional post-multiplication of element (row, k) by W_N^((row % tw_rows) * k) (four-step twiddle), tw_rows = 0: none.
-template <typename T>
+/// Where the lines of a pass live: line g (counted over the whole launch) is decomposed in the mixed radix
+/// `extent[0]` (fastest) ... `extent[nlv - 1]`; its first element is at sum digit_i * in_stride[i] in the source and at
+/// sum digit_i * out_stride[i] in the destination; element k of the line is k * in_es / k * out_es further.
+constexpr int MAX_LEVELS = 4;
+struct line_map {
+    int nlv;
+    long long extent[MAX_LEVELS], in_stride[MAX_LEVELS], out_stride[MAX_LEVELS];
+    long long in_es, out_es;
+    // inter-pass twiddle: element k of line g is multiplied by W_M^(k * J), J = (g / tw_div) % tw_mod; tw_M = 0: none
+    long long tw_M, tw_div, tw_mod;
+};
+
+constexpr int MAX_LINES = 256;                   // lines per workgroup (size of the offset tables in LDS)
+
+/// A tile of lines, each transformed completely in LDS.
+/// ODD = false: the instantiation for lengths 2^a (radix 2 / 4 / 8 stages only: half the registers of the general one).
+template <typename T, bool ODD>
 __global__ __launch_bounds__(FB)
-void fft_rows_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, const cx<T> *__restrict__ tw,
-        int n, long long rows, int rows_per_wg, stage_list st, int inverse, long long tw_N, long long tw_rows)
+void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, const cx<T> *__restrict__ tw,
+        int n, long long lines, int lines_per_wg, int pitch, stage_list st, int inverse, line_map map)
 {
     extern __shared__ __attribute__((aligned(16))) char fft_smem[];
-    const long long r0 = (long long)blockIdx.x * rows_per_wg;
-    const int nrows = (int)min((long long)rows_per_wg, rows - r0);
-    const int E = nrows * n;
+    __shared__ long long in_off[MAX_LINES], out_off[MAX_LINES], tw_j[MAX_LINES];
+    const long long g0 = (long long)blockIdx.x * lines_per_wg;
+    const int nl = (int)min((long long)lines_per_wg, lines - g0);
+    const int E = nl * n;
     cx<T> *A = reinterpret_cast<cx<T> *>(fft_smem);
-    cx<T> *B = A + (size_t)rows_per_wg * n;
+    cx<T> *B = A + (size_t)lines_per_wg * pitch;
 
-    const cx<T> *gin = in + r0 * n;
-    for (int e = threadIdx.x; e < E; e += FB) A[e] = gin[e];
+    if ((int)threadIdx.x < nl) {
+        long long g = g0 + threadIdx.x, io = 0, oo = 0;
+        tw_j[threadIdx.x] = map.tw_M ? (g / map.tw_div) % map.tw_mod : 0;
+        for (int i = 0; i < map.nlv; ++i) {
+            const long long q = (i + 1 < map.nlv) ? g / map.extent[i] : 0;
+            const long long d = (i + 1 < map.nlv) ? g - q * map.extent[i] : g;
+            io += d * map.in_stride[i]; oo += d * map.out_stride[i];
+            g = q;
+        }
+        in_off[threadIdx.x] = io; out_off[threadIdx.x] = oo;
+    }
+    __syncthreads();
+
+    const divisor dn = divisor::make(n), dl = divisor::make(nl);
+    if (map.in_es == 1) {                        // contiguous lines: neighbouring lanes read neighbouring elements of a line
+        for (int e = threadIdx.x; e < E; e += FB) {
+            const int l = dn.div(e), k = e - l * n;
+            A[l * pitch + k] = in[in_off[l] + k];
+        }
+    } else {                                     // strided lines: neighbouring lanes read the same element of neighbouring lines
+        for (int e = threadIdx.x; e < E; e += FB) {
+            const int k = dl.div(e), l = e - k * nl;
+            A[l * pitch + k] = in[in_off[l] + k * map.in_es];
+        }
+    }
     __syncthreads();
 
     int p = 1;
     for (int s = 0; s < st.count; ++s) {
         const int R = st.radix[s];
-        switch (R) {
-            case 2:  stage<T, 2>(A, B, tw, n, p, nrows, inverse); break;
-            case 3:  stage<T, 3>(A, B, tw, n, p, nrows, inverse); break;
-            case 4:  stage<T, 4>(A, B, tw, n, p, nrows, inverse); break;
-            case 5:  stage<T, 5>(A, B, tw, n, p, nrows, inverse); break;
-            case 7:  stage<T, 7>(A, B, tw, n, p, nrows, inverse); break;
-            case 8:  stage<T, 8>(A, B, tw, n, p, nrows, inverse); break;
-            case 11: stage<T, 11>(A, B, tw, n, p, nrows, inverse); break;
-            default: stage<T, 13>(A, B, tw, n, p, nrows, inverse); break;
+        if constexpr (ODD) {
+            switch (R) {
+                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 3:  stage<T, 3>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 5:  stage<T, 5>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 7:  stage<T, 7>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 8:  stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 11: stage<T, 11>(A, B, tw, n, pitch, p, nl, inverse); break;
+                default: stage<T, 13>(A, B, tw, n, pitch, p, nl, inverse); break;
+            }
+        } else {
+            switch (R) {
+                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse); break;
+                default: stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse); break;
+            }
         }
         p *= R;
         cx<T> *t = A; A = B; B = t;
         __syncthreads();
     }
 
-    cx<T> *gout = out + r0 * n;
-    if (tw_rows == 0) {
-        for (int e = threadIdx.x; e < E; e += FB) gout[e] = A[e];
-    } else {
-        for (int e = threadIdx.x; e < E; e += FB) {
-            const int row = e / n, k = e - row * n;
-            const long long j2 = (r0 + row) % tw_rows;
-            const double frac = 2.0 * (double)(j2 * k) / (double)tw_N;        // j2 * k < N: no reduction needed
+    const bool along = map.out_es == 1;
+    for (int e = threadIdx.x; e < E; e += FB) {
+        int l, k;
+        if (along) { l = dn.div(e); k = e - l * n; } else { k = dl.div(e); l = e - k * nl; }
+        cx<T> v = A[l * pitch + k];
+        if (map.tw_M) {
+            const double frac = 2.0 * (double)(tw_j[l] * k) / (double)map.tw_M;        // J * k < M: no reduction needed
             double sn, cs;
             sincospi(frac, &sn, &cs);
-            cx<T> w = {(T)cs, (T)(inverse ? sn : -sn)};
-            gout[e] = A[e] * w;
+            const cx<T> w = {(T)cs, (T)(inverse ? sn : -sn)};
+            v = v * w;
         }
+        out[out_off[l] + k * map.out_es] = v;
     }
 }
 
@@ -259,16 +343,35 @@ size_t best_size(size_t n) {
 enum buf_id { B_IN = 0, B_OUT = 1, B_WORK = 2, B_FIRST_OWNED = 3 };
 
 struct step {
-    enum kind_t { ROWS, TRANSPOSE, BLUE_IN, BLUE_MUL, BLUE_OUT, COPY } kind;
+    enum kind_t { LINES, TRANSPOSE, BLUE_IN, BLUE_MUL, BLUE_OUT, COPY } kind;
     int src, dst;
-    // ROWS
-    int n = 0; long long rows = 0; stage_list st{}; int inverse = 0; int table = -1; long long tw_N = 0, tw_rows = 0;
+    // LINES
+    int n = 0; long long lines = 0; int lines_per_wg = 1, pitch = 0; stage_list st{}; int inverse = 0; int table = -1; line_map map{};
     // TRANSPOSE: [batch][R][C] -> [batch][C][R]
     long long batch = 0, R = 0, C = 0;
     // BLUESTEIN
-    long long bn = 0, bm = 0; int chirp = -1, bhat = -1;
+    long long rows = 0, bn = 0, bm = 0; int chirp = -1, bhat = -1;
     long long elems = 0;        // COPY
 };
+
+/// Split n (smooth) into m factors, each as close to n^(1/m) as its divisors allow; the largest last.
+std::vector<size_t> split(size_t n, int m) {
+    std::vector<size_t> f;
+    size_t rest = n;
+    for (int left = m; left > 1; --left) {
+        const double target = std::pow((double)rest, 1.0 / left);
+        size_t best = 1;
+        for (size_t d = 1; d * d <= rest; ++d) if (rest % d == 0) {
+            for (size_t c : {d, rest / d})
+                if (std::fabs(std::log((double)c / target)) < std::fabs(std::log((double)best / target))) best = c;
+        }
+        f.push_back(best);
+        rest /= best;
+    }
+    f.push_back(rest);
+    std::sort(f.begin(), f.end());
+    return f;
+}
 
 template <typename T>
 struct plan_t {
@@ -276,7 +379,6 @@ struct plan_t {
     size_t total = 0;
     std::vector<step> steps;
     std::vector<void *> owned;                 // device buffers of the plan: work buffer, Bluestein buffers, tables
-    std::vector<size_t> owned_bytes;
     std::vector<std::pair<size_t, int>> tw_tables;     // (n, owned index) twiddle tables already built
 
     ~plan_t() { (void)hipSetDevice(dev); for (void *p : owned) if (p) (void)hipFree(p); }
@@ -284,7 +386,7 @@ struct plan_t {
     int alloc(size_t bytes, int &id) {
         void *p = nullptr;
         VEXHIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
-        owned.push_back(p); owned_bytes.push_back(bytes);
+        owned.push_back(p);
         id = B_FIRST_OWNED + (int)owned.size() - 1;
         return 0;
     }
@@ -306,50 +408,100 @@ struct plan_t {
 
     static bool writable(int b) { return b != B_IN; }
 
-    /// Transform `rows` contiguous rows of length n held in `cur`; (a, b) are two writable buffers of at least
-    /// rows * n elements that the steps may alternate between.  Returns the buffer holding the result in `res`.
-    int emit_rows(size_t n, long long rows, bool inverse, int cur, int a, int b, int &res, long long tw_N = 0, long long tw_rows = 0) {
-        auto other = [&](int c) { return c == a ? b : a; };
-        if (n == 1) {                                   // nothing to transform (a twiddle on k = 0 is 1 as well)
-            res = cur;
-            return 0;
+    /// One launch of the lines kernel.  `in_place`: source and destination offsets coincide, so a writable source
+    /// is transformed where it is; otherwise the pass goes to the other buffer of the pair (a, b).
+    int emit_pass(size_t n, bool inverse, const line_map &map, long long lines, bool in_place, int cur, int a, int b, int &res) {
+        step s; s.kind = step::LINES; s.src = cur;
+        s.dst = (in_place && writable(cur)) ? cur : (cur == a ? b : a);
+        s.n = (int)n; s.lines = lines; s.inverse = inverse; s.map = map;
+        if (!factor(n, s.st)) return fail(__FILE__, __LINE__, "fft: internal error, unsupported pass length");
+        if (int rc = twiddles(n, s.table)) return rc;
+        // lines per workgroup: what fits the LDS buffers (one padding element per line when there are several);
+        // contiguous lines may take fewer to keep >= ~4 workgroups per CU, strided ones keep the tile wide
+        // (the tile's width IS the contiguous run of the global accesses)
+        long long L = std::min<long long>(MAX_LINES, std::max<long long>(1, lds_elems<T>() / (long long)n));
+        while (L > 1 && L * ((long long)n + 1) > lds_elems<T>() + MAX_LINES) --L;
+        if (map.in_es == 1 && map.out_es == 1) {
+            L = std::max<long long>(1, std::min(L, (long long)(lds_elems<T>() / 2) / (long long)n));      // <= 16 KiB per buffer
+            L = std::max<long long>(1, std::min(L, (lines + 2047) / 2048));
         }
-        stage_list st;
-        if (n <= (size_t)lds_elems<T>() && factor(n, st)) {
-            step s; s.kind = step::ROWS; s.src = cur; s.dst = writable(cur) ? cur : a;
-            s.n = (int)n; s.rows = rows; s.st = st; s.inverse = inverse; s.tw_N = tw_N; s.tw_rows = tw_rows;
-            if (int rc = twiddles(n, s.table)) return rc;
-            steps.push_back(s);
-            res = s.dst;
-            return 0;
-        }
-        if (smooth(n)) {
-            if (tw_rows) return fail(__FILE__, __LINE__, "fft: nested four-step twiddle is not supported");    // n1 always fits the kernel
-            // four-step: n = n1 * n2, n1 the largest divisor that fits the row kernel
-            size_t n1 = 1;
-            for (size_t d = std::min<size_t>(n, lds_elems<T>()); d >= 2; --d) if (n % d == 0) { n1 = d; break; }
-            const size_t n2 = n / n1;
-            // x[j1 * n2 + j2] viewed as [rows][n1][n2] -> [rows][n2][n1]
-            step t1; t1.kind = step::TRANSPOSE; t1.src = cur; t1.dst = writable(cur) ? other(cur) : a; t1.batch = rows; t1.R = (long long)n1; t1.C = (long long)n2;
+        L = std::min(L, std::max<long long>(lines, 1));
+        s.lines_per_wg = (int)L;
+        s.pitch = (int)n + (L > 1 ? 1 : 0);
+        steps.push_back(s);
+        res = s.dst;
+        return 0;
+    }
+
+    /// Transform along one dimension: `outer` blocks of [w][s] elements, lines of length w with element stride s.
+    int emit_dim(size_t w, size_t s, size_t outer, bool inverse, int cur, int a, int b, int &res) {
+        res = cur;
+        if (w == 1) return 0;
+        const long long W = (long long)w, S = (long long)s, O = (long long)outer;
+        if (!smooth(w)) {
+            if (s == 1) return emit_bluestein(w, O, inverse, cur, a, b, res);
+            // gather the lines into rows, chirp-z them, scatter back: [outer][w][s] -> [outer][s][w] -> ... -> [outer][w][s]
+            auto other = [&](int c) { return c == a ? b : a; };
+            step t1; t1.kind = step::TRANSPOSE; t1.src = cur; t1.dst = writable(cur) ? other(cur) : a; t1.batch = O; t1.R = W; t1.C = S;
             steps.push_back(t1);
             int c = t1.dst;
-            // n2 transforms of length n1 per row, each multiplied by W_n^(j2 k1)
-            if (int rc = emit_rows(n1, rows * (long long)n2, inverse, c, a, b, c, (long long)n, (long long)n2)) return rc;
-            // [rows][n2][n1] -> [rows][n1][n2]
-            step t2; t2.kind = step::TRANSPOSE; t2.src = c; t2.dst = other(c); t2.batch = rows; t2.R = (long long)n2; t2.C = (long long)n1;
+            if (int rc = emit_bluestein(w, O * S, inverse, c, a, b, c)) return rc;
+            step t2; t2.kind = step::TRANSPOSE; t2.src = c; t2.dst = other(c); t2.batch = O; t2.R = S; t2.C = W;
             steps.push_back(t2);
-            c = t2.dst;
-            // n1 transforms of length n2
-            if (int rc = emit_rows(n2, rows * (long long)n1, inverse, c, a, b, c)) return rc;
-            // Z[k1][k2] = X[k1 + n1 k2]: [rows][n1][n2] -> [rows][n2][n1]
-            step t3; t3.kind = step::TRANSPOSE; t3.src = c; t3.dst = other(c); t3.batch = rows; t3.R = (long long)n1; t3.C = (long long)n2;
-            steps.push_back(t3);
-            c = t3.dst;
-            res = c;
+            res = t2.dst;
             return 0;
         }
-        // Bluestein: a prime factor above 13.  X[k] = c[k] * sum_j (x[j] c[j]) conj(c)[k - j], c[t] = exp(-+ pi i t^2 / n)
-        if (tw_rows) return fail(__FILE__, __LINE__, "fft: Bluestein inside a four-step pass is not supported");
+        // one pass when a useful tile of lines fits LDS: any contiguous row that fits; strided lines need >= 4 per tile
+        const size_t cap = s == 1 ? (size_t)lds_elems<T>() : (size_t)lds_elems<T>() / 4;
+        if (w <= cap) {
+            line_map m{};
+            m.in_es = m.out_es = S;
+            m.nlv = 0;
+            if (s > 1) { m.extent[m.nlv] = S; m.in_stride[m.nlv] = m.out_stride[m.nlv] = 1; ++m.nlv; }
+            m.extent[m.nlv] = O; m.in_stride[m.nlv] = m.out_stride[m.nlv] = W * S; ++m.nlv;
+            return emit_pass(w, inverse, m, O * S, true, cur, a, b, res);
+        }
+        // w = n_1 ... n_m: pass t transforms digit t of the index j = j_1 (n_2..n_m) + ... + j_m
+        const int nf = w <= (size_t)1 << 16 ? 2 : 3;
+        const std::vector<size_t> f = split(w, nf);
+        for (size_t x : f) if (x > (size_t)lds_elems<T>()) return fail(__FILE__, __LINE__, "fft: length too large");
+        long long M = W;                                 // n_t ... n_m
+        long long done = 1;                              // n_1 ... n_(t-1)
+        for (int t = 0; t + 1 < nf; ++t) {
+            const long long nt = (long long)f[t], rest = M / nt;
+            line_map m{};
+            m.in_es = m.out_es = rest * S;
+            m.nlv = 0;
+            m.extent[m.nlv] = rest * S; m.in_stride[m.nlv] = m.out_stride[m.nlv] = 1; ++m.nlv;            // (j_(t+1..m), i)
+            if (done > 1) { m.extent[m.nlv] = done; m.in_stride[m.nlv] = m.out_stride[m.nlv] = M * S; ++m.nlv; }   // (k_1..k_(t-1))
+            m.extent[m.nlv] = O; m.in_stride[m.nlv] = m.out_stride[m.nlv] = W * S; ++m.nlv;
+            m.tw_M = M; m.tw_div = S; m.tw_mod = rest;
+            if (int rc = emit_pass((size_t)nt, inverse, m, O * (W / nt) * S, true, res, a, b, res)) return rc;
+            M = rest; done *= nt;
+        }
+        {   // last digit: lines contiguous in the source when s == 1; written to the digit-reversed position,
+            // lines enumerated in OUTPUT order (i, k_1, k_2, ...) so that a tile writes runs of consecutive elements
+            const long long nm = (long long)f[nf - 1];
+            line_map m{};
+            m.in_es = S; m.out_es = (W / nm) * S;
+            m.nlv = 0;
+            if (s > 1) { m.extent[m.nlv] = S; m.in_stride[m.nlv] = m.out_stride[m.nlv] = 1; ++m.nlv; }
+            long long in_str = W * S, out_str = S;
+            for (int q = 0; q + 1 < nf; ++q) {
+                in_str /= (long long)f[q];
+                m.extent[m.nlv] = (long long)f[q]; m.in_stride[m.nlv] = in_str; m.out_stride[m.nlv] = out_str; ++m.nlv;
+                out_str *= (long long)f[q];
+            }
+            m.extent[m.nlv] = O; m.in_stride[m.nlv] = m.out_stride[m.nlv] = W * S; ++m.nlv;
+            if (m.nlv > MAX_LEVELS) return fail(__FILE__, __LINE__, "fft: internal error, too many levels");
+            if (int rc = emit_pass((size_t)nm, inverse, m, O * (W / nm) * S, false, res, a, b, res)) return rc;
+        }
+        return 0;
+    }
+
+    /// Bluestein on `rows` contiguous rows of length n (a prime factor above 13):
+    /// X[k] = c[k] * sum_j (x[j] c[j]) conj(c)[k - j], c[t] = exp(-+ pi i t^2 / n)
+    int emit_bluestein(size_t n, long long rows, bool inverse, int cur, int a, int b, int &res) {
         if (n >= (size_t(1) << 31)) return fail(__FILE__, __LINE__, "fft: length too large for the chirp-z path");
         const size_t m = best_size(2 * n - 1);
         std::vector<cx<T>> chirp(n), bseq(m, cx<T>{T(0), T(0)});
@@ -369,56 +521,39 @@ struct plan_t {
         if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), bb)) return rc;
         {   // bhat = FFT_m(b), computed once with a plan of its own
             plan_t<T> sub; sub.dev = dev; sub.total = m;
-            int in_id, r;
+            int in_id, r, w1;
             if (int rc = upload(bseq, in_id)) return rc;
             if (int rc = alloc(m * sizeof(cx<T>), bhat_id)) return rc;
-            int w1;
             if (int rc = sub.alloc(m * sizeof(cx<T>), w1)) return rc;
-            if (int rc = sub.emit_rows(m, 1, false, B_IN, B_OUT, B_WORK, r)) return rc;
+            if (int rc = sub.emit_dim(m, 1, 1, false, B_IN, B_OUT, B_WORK, r)) return rc;
             void *dst = owned[bhat_id - B_FIRST_OWNED];
-            if (int rc = sub.run(nullptr, owned[in_id - B_FIRST_OWNED], dst, sub.owned[w1 - B_FIRST_OWNED], r)) return rc;
+            if (int rc = sub.run(nullptr, owned[in_id - B_FIRST_OWNED], dst, sub.owned[w1 - B_FIRST_OWNED])) return rc;
             if (r == B_WORK) VEXHIP_TRY(hipMemcpyAsync(dst, sub.owned[w1 - B_FIRST_OWNED], m * sizeof(cx<T>), hipMemcpyDeviceToDevice, nullptr));
             VEXHIP_TRY(hipDeviceSynchronize());
         }
         step s1; s1.kind = step::BLUE_IN; s1.src = cur; s1.dst = ba; s1.bn = (long long)n; s1.bm = (long long)m; s1.rows = rows; s1.chirp = chirp_id;
         steps.push_back(s1);
         int c = ba;
-        if (int rc = emit_rows(m, rows, false, c, ba, bb, c)) return rc;
+        if (int rc = emit_dim(m, 1, (size_t)rows, false, c, ba, bb, c)) return rc;
         step s2; s2.kind = step::BLUE_MUL; s2.src = c; s2.dst = c; s2.bm = (long long)m; s2.rows = rows; s2.bhat = bhat_id;
         steps.push_back(s2);
-        if (int rc = emit_rows(m, rows, true, c, ba, bb, c)) return rc;
+        if (int rc = emit_dim(m, 1, (size_t)rows, true, c, ba, bb, c)) return rc;
         step s3; s3.kind = step::BLUE_OUT; s3.src = c; s3.dst = writable(cur) ? cur : a; s3.bn = (long long)n; s3.bm = (long long)m; s3.rows = rows; s3.chirp = chirp_id;
         steps.push_back(s3);
         res = s3.dst;
         return 0;
     }
 
-    /// n-D: rotate the dimensions, last first (plan.hpp:243-256 of the reference); `none` dimensions are skipped and,
-    /// once no transformed dimension remains on the left, the rotation is undone with one transpose.
+    /// n-D: every dimension in place where it is (last first), `none` dimensions are batches.
     int build(const std::vector<size_t> &sizes, const std::vector<int> &dirs, int a, int b, int &res) {
         steps.clear();
-        auto other = [&](int c) { return c == a ? b : a; };
         int cur = B_IN;
-        int leftmost = -1;
-        for (size_t j = 0; j < sizes.size(); ++j) if (dirs[j] != VEXHIP_FFT_NONE && sizes[j] > 1) { leftmost = (int)j; break; }
-        size_t P = 1;                               // product of the dimensions already rotated to the front
-        if (leftmost >= 0) {
-            for (int j = (int)sizes.size() - 1; j >= leftmost; --j) {
-                const size_t w = sizes[j], h = total / w;
-                if (dirs[j] != VEXHIP_FFT_NONE && w > 1)
-                    if (int rc = emit_rows(w, (long long)h, dirs[j] == VEXHIP_FFT_INVERSE, cur, a, b, cur)) return rc;
-                if (j > leftmost && w > 1 && h > 1) {
-                    step t; t.kind = step::TRANSPOSE; t.src = cur; t.dst = writable(cur) ? other(cur) : a; t.batch = 1; t.R = (long long)h; t.C = (long long)w;
-                    steps.push_back(t);
-                    cur = t.dst;
-                    P *= w;
-                }
-            }
-            if (P > 1) {                                // [P][Q] -> [Q][P]
-                step t; t.kind = step::TRANSPOSE; t.src = cur; t.dst = writable(cur) ? other(cur) : a; t.batch = 1; t.R = (long long)P; t.C = (long long)(total / P);
-                steps.push_back(t);
-                cur = t.dst;
-            }
+        size_t inner = 1;
+        for (size_t j = sizes.size(); j-- > 0;) {
+            const size_t w = sizes[j];
+            if (dirs[j] != VEXHIP_FFT_NONE && w > 1)
+                if (int rc = emit_dim(w, inner, total / (w * inner), dirs[j] == VEXHIP_FFT_INVERSE, cur, a, b, cur)) return rc;
+            inner *= w;
         }
         res = cur;
         return 0;
@@ -431,20 +566,22 @@ struct plan_t {
         return owned[id - B_FIRST_OWNED];
     }
 
-    /// Executes the steps; the result is left in buffer `res` (the caller knows which one that is).
-    int run(hipStream_t stream, const void *in, void *out, void *work, int /*res*/) const {
+    /// Executes the steps.
+    int run(hipStream_t stream, const void *in, void *out, void *work) const {
         for (const step &s : steps) {
             const cx<T> *src = static_cast<const cx<T> *>(resolve(s.src, in, out, work));
             cx<T> *dst = static_cast<cx<T> *>(resolve(s.dst, in, out, work));
             switch (s.kind) {
-                case step::ROWS: {
-                    // rows per workgroup: as many as fit the LDS buffers, but keep >= ~4 workgroups per CU when the batch allows
-                    long long rpw = std::max<long long>(1, lds_elems<T>() / s.n);
-                    rpw = std::max<long long>(1, std::min(rpw, (s.rows + 1023) / 1024));
-                    const long long grid = (s.rows + rpw - 1) / rpw;
-                    const size_t lds = 2 * (size_t)rpw * s.n * sizeof(cx<T>);
-                    fft_rows_kernel<T><<<dim3((unsigned)grid), dim3(FB), lds, stream>>>(src, dst,
-                            static_cast<const cx<T> *>(owned[s.table - B_FIRST_OWNED]), s.n, s.rows, (int)rpw, s.st, s.inverse, s.tw_N, s.tw_rows);
+                case step::LINES: {
+                    const long long grid = (s.lines + s.lines_per_wg - 1) / s.lines_per_wg;
+                    const size_t lds = 2 * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
+                    const bool pow2 = (s.n & (s.n - 1)) == 0;
+                    auto kernel = pow2 ? &fft_lines_kernel<T, false> : &fft_lines_kernel<T, true>;
+                    if (lds > 48 * 1024)          // per device, and cheap: raise the dynamic LDS limit for the padded tiles
+                        VEXHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (lds_elems<T>() + MAX_LINES) * (int)sizeof(cx<T>)));
+                    kernel<<<dim3((unsigned)grid), dim3(FB), lds, stream>>>(src, dst,
+                            static_cast<const cx<T> *>(owned[s.table - B_FIRST_OWNED]), s.n, s.lines, s.lines_per_wg, s.pitch, s.st, s.inverse, s.map);
                     break;
                 }
                 case step::TRANSPOSE: {
@@ -495,20 +632,20 @@ int make_plan(int dev, const std::vector<size_t> &sizes, const std::vector<int> 
     for (size_t s : sizes) p->total *= s;
     if (int rc = p->alloc(p->total * sizeof(cx<T>), work_id)) return rc;
     int res;
-    // the steps alternate between two buffers; which of them receives the first write decides where the result
-    // ends: build with (OUT, WORK) and, if the result lands in WORK, again with the roles swapped
+    // out-of-place passes alternate between two buffers; which of them receives the first write decides where
+    // the result ends: build with (OUT, WORK) and, if the result lands in WORK, again with the roles swapped
     if (int rc = p->build(sizes, dirs, B_OUT, work_id, res)) return rc;
     if (res == work_id) {
         std::unique_ptr<plan_t<T>> q(new plan_t<T>);
         q->dev = dev; q->total = p->total;
         int w2;
+        p.reset();                                  // release the first attempt's buffers before building the second
         if (int rc = q->alloc(q->total * sizeof(cx<T>), w2)) return rc;
-        p.reset();                                  // release the first attempt's tables before building the second
         if (int rc = q->build(sizes, dirs, w2, B_OUT, res)) return rc;
         p = std::move(q);
         work_id = w2;
     }
-    if (res != B_OUT) {                             // no step at all (res == B_IN), or a parity the swap did not fix
+    if (res != B_OUT) {                             // no pass at all (res == B_IN), or a parity the swap did not fix
         step c; c.kind = step::COPY; c.src = res; c.dst = B_OUT; c.elems = (long long)p->total;
         p->steps.push_back(c);
     }
@@ -550,7 +687,7 @@ int vexhip_fft_plan_steps(void *plan, int *rows_passes, int *transposes, int *ot
     any_plan *p = static_cast<any_plan *>(plan);
     int r = 0, t = 0, o = 0;
     auto count = [&](const std::vector<step> &steps) {
-        for (const step &s : steps) { if (s.kind == step::ROWS) ++r; else if (s.kind == step::TRANSPOSE) ++t; else ++o; }
+        for (const step &s : steps) { if (s.kind == step::LINES) ++r; else if (s.kind == step::TRANSPOSE) ++t; else ++o; }
     };
     if (p->f) count(p->f->steps); else count(p->d->steps);
     if (rows_passes) *rows_passes = r;
@@ -565,10 +702,10 @@ int vexhip_fft_exec(void *plan, void *stream, const void *in, void *out) {
     any_plan *p = static_cast<any_plan *>(plan);
     if (p->f) {
         VEXHIP_SET_DEVICE(p->f->dev);
-        return p->f->run(as_stream(stream), in, out, p->f->owned[p->work_id - B_FIRST_OWNED], B_OUT);
+        return p->f->run(as_stream(stream), in, out, p->f->owned[p->work_id - B_FIRST_OWNED]);
     }
     VEXHIP_SET_DEVICE(p->d->dev);
-    return p->d->run(as_stream(stream), in, out, p->d->owned[p->work_id - B_FIRST_OWNED], B_OUT);
+    return p->d->run(as_stream(stream), in, out, p->d->owned[p->work_id - B_FIRST_OWNED]);
 }
 
 } // extern "C"
