@@ -1,0 +1,210 @@
+// GPU: the components around the hot path that the reference's remaining test sources drive --
+// vex::tensordot (tests/tensordot.cpp), vex::multi_array (tests/multi_array.cpp), vex::mba (tests/mba.cpp),
+// vex::svm_vector (tests/svm.cpp), the symbolic kernel generator (tests/generator.cpp), vex::FFT (tests/fft.cpp),
+// vex::reshape with broadcast and 3-cycles.  Every result is compared with a host model written here.
+#include "vex_test.hpp"
+#include <vexcl/tensordot.hpp>
+#include <vexcl/multi_array.hpp>
+#include <vexcl/mba.hpp>
+#include <vexcl/svm_vector.hpp>
+#include <vexcl/generator.hpp>
+#include <vexcl/fft.hpp>
+#include <complex>
+
+namespace {
+std::vector<vex::command_queue> one_queue() { return std::vector<vex::command_queue>(1, ctx.queue(0)); }
+template <class T> std::vector<T> download(const vex::vector<T> &v) { std::vector<T> h(v.size()); vex::copy(v, h); return h; }
+}
+
+TEST_CASE(tensordot_matrix_products_and_double_contraction) {         // tensordot.cpp: mat_mat, mat_vec, vec_mat
+    using vex::_; using vex::extents;
+    auto q = one_queue();
+    const size_t N = 24, M = 17, K = 9;
+    std::vector<double> a = random_vector<double>(N * K), b = random_vector<double>(K * M);
+    vex::vector<double> A(q, a), B(q, b), C(q, N * M);
+    vex::slicer<2> sa(extents[N][K]), sb(extents[K][M]);
+    C = vex::tensordot(sa[_](A), sb[_](B), vex::axes_pairs(1, 0));    // C = A B
+    auto c = download(C);
+    for (size_t i = 0; i < N; ++i) for (size_t j = 0; j < M; ++j) {
+        double s = 0; for (size_t k = 0; k < K; ++k) s += a[i * K + k] * b[k * M + j];
+        CHECK_CLOSE(c[i * M + j] + 100, s + 100, 1e-10);
+    }
+    // contraction over the FIRST axes: C2 = A^T A2, operands are expressions
+    std::vector<double> a2 = random_vector<double>(N * M);
+    vex::vector<double> A2(q, a2), C2(q, K * M);
+    vex::slicer<2> sa2(extents[N][M]);
+    C2 = 2 * vex::tensordot(sa[_](A * A), sa2[_](A2 + 1), vex::axes_pairs(0, 0));
+    auto c2 = download(C2);
+    for (size_t i = 0; i < K; ++i) for (size_t j = 0; j < M; ++j) {
+        double s = 0; for (size_t k = 0; k < N; ++k) s += a[k * K + i] * a[k * K + i] * (a2[k * M + j] + 1);
+        CHECK_CLOSE(c2[i * M + j] + 100, 2 * s + 100, 1e-10);
+    }
+    // both axes contracted: a scalar (one output element), Frobenius product with a transposed operand
+    vex::vector<double> S(q, 1);
+    vex::slicer<2> st(extents[K][N]);
+    std::vector<double> t = random_vector<double>(K * N);
+    vex::vector<double> Tt(q, t);
+    S = vex::tensordot(sa[_](A), st[_](Tt), vex::axes_pairs(0, 1, 1, 0));
+    double s = 0; for (size_t i = 0; i < N; ++i) for (size_t k = 0; k < K; ++k) s += a[i * K + k] * t[k * N + i];
+    CHECK_CLOSE(download(S)[0] + 100, s + 100, 1e-10);
+    // matrix * vector through a 1-D slicer
+    std::vector<double> x = random_vector<double>(K);
+    vex::vector<double> X(q, x), Y(q, N);
+    vex::slicer<1> sx(extents[K]);
+    Y = vex::tensordot(sa[_](A), sx[_](X), vex::axes_pairs(1, 0));
+    auto y = download(Y);
+    for (size_t i = 0; i < N; ++i) { double r = 0; for (size_t k = 0; k < K; ++k) r += a[i * K + k] * x[k]; CHECK_CLOSE(y[i] + 100, r + 100, 1e-10); }
+}
+
+TEST_CASE(reshape_broadcast_and_three_cycle) {                        // vector_view.hpp:1003-1124 semantics
+    using vex::extents;
+    auto q = one_queue();
+    const size_t d0 = 3, d1 = 4, d2 = 5;
+    // source shaped dst_dims[src_dims] = [d2][d0][d1], row-major; src_dims = (2, 0, 1)
+    std::vector<int> h(d0 * d1 * d2); std::iota(h.begin(), h.end(), 0);
+    vex::vector<int> X(q, h), Y(q, d0 * d1 * d2);
+    Y = vex::reshape(X, extents[d0][d1][d2], extents[2][0][1]);
+    auto y = download(Y);
+    for (size_t i = 0; i < d0; ++i) for (size_t j = 0; j < d1; ++j) for (size_t k = 0; k < d2; ++k)
+        CHECK_EQUAL(y[(i * d1 + j) * d2 + k], h[(k * d0 + i) * d1 + j]);
+    // fewer source dimensions: the vector is repeated along the dimensions it does not name
+    std::vector<int> v(d1); std::iota(v.begin(), v.end(), 100);
+    vex::vector<int> V(q, v), Z(q, d0 * d1);
+    Z = vex::reshape(V, extents[d0][d1], extents[1]);
+    auto z = download(Z);
+    for (size_t i = 0; i < d0; ++i) for (size_t j = 0; j < d1; ++j) CHECK_EQUAL(z[i * d1 + j], v[j]);
+}
+
+TEST_CASE(multi_array_views_and_reduction) {                          // multi_array.cpp: create, slicing, reducing
+    using vex::extents; using vex::indices; using vex::range; using vex::_;
+    auto q = one_queue();
+    vex::multi_array<double, 3> x(q, extents[6][7][8]), y(q, extents[6][7][8]);
+    CHECK_EQUAL(x.size<0>(), 6u); CHECK_EQUAL(x.size<2>(), 8u);
+    auto view = x(indices[2][range(1, 5)][_]);
+    CHECK_EQUAL(view.size<0>(), 4u); CHECK_EQUAL(view.size<1>(), 8u);
+    x.vec() = vex::element_index();
+    y.vec() = 0;
+    for (size_t j = 0; j < 7; ++j) y(indices[_][j][_]).vec() = 10 * x(indices[_][6 - j][_]).vec();   // slice = slice copies elements
+    auto hy = download(y.vec());
+    for (size_t i = 0; i < 6; ++i) for (size_t j = 0; j < 7; ++j) for (size_t k = 0; k < 8; ++k)
+        CHECK_EQUAL(hy[(i * 7 + j) * 8 + k], 10.0 * ((i * 7 + (6 - j)) * 8 + k));
+    vex::vector<double> s(q, 6 * 8);
+    s = vex::reduce<vex::SUM>(x, 1);
+    auto hs = download(s);
+    for (size_t i = 0; i < 6; ++i) for (size_t k = 0; k < 8; ++k) {
+        double r = 0; for (size_t j = 0; j < 7; ++j) r += (i * 7 + j) * 8 + k;
+        CHECK_EQUAL(hs[i * 8 + k], r);
+    }
+}
+
+TEST_CASE(mba_interpolates_the_data_points) {                         // mba.cpp; host model: the data itself
+    // a smooth function sampled on scattered points; with enough levels the surface passes through the data
+    const size_t np = 200;
+    std::vector<std::array<double, 2>> p(np); std::vector<double> v(np);
+    std::mt19937 rng(3); std::uniform_real_distribution<double> U(0.0, 1.0);
+    for (size_t i = 0; i < np; ++i) { p[i] = {{U(rng), U(rng)}}; v[i] = std::sin(3 * p[i][0]) * std::cos(2 * p[i][1]); }
+    std::array<double, 2> lo = {{-0.01, -0.01}}, hi = {{1.01, 1.01}};
+    std::array<size_t, 2> grid = {{3, 3}};
+    vex::mba<2> surf(ctx, lo, hi, p, v, grid, 12, 1e-12);
+    std::vector<double> px(np), py(np);
+    for (size_t i = 0; i < np; ++i) { px[i] = p[i][0]; py[i] = p[i][1]; }
+    vex::vector<double> X(ctx, px), Y(ctx, py), Z(ctx, np);
+    Z = surf(X, Y);
+    auto z = download(Z);
+    double worst = 0; for (size_t i = 0; i < np; ++i) worst = std::max(worst, std::fabs(z[i] - v[i]));
+    CHECK_SMALL(worst, 1e-4);
+    Z = 2 * surf(X * 1.0, Y + 0.0) + 1;                               // coordinates are expressions, the value is a term
+    auto z2 = download(Z);
+    for (size_t i = 0; i < np; i += 13) CHECK_CLOSE(z2[i] + 10, 2 * z[i] + 1 + 10, 1e-10);
+}
+
+TEST_CASE(svm_vector_is_shared_with_the_host) {                       // svm.cpp
+    auto q = one_queue();
+    const int n = 3000;
+    vex::svm_vector<int> x(q[0], n);
+    { auto p = x.map(vex::backend::MAP_WRITE); for (int i = 0; i < n; ++i) p[i] = 3 * i; }
+    vex::vector<int> y(q, n);
+    y = x + 1;
+    auto hy = download(y);
+    for (int i = 0; i < n; i += 7) CHECK_EQUAL(hy[i], 3 * i + 1);
+    x -= y;                                                            // lvalue of a fused kernel
+    { auto p = x.map(vex::backend::MAP_READ); for (int i = 0; i < n; i += 11) CHECK_EQUAL(p[i], -1); }
+    VEX_FUNCTION(int, at, (size_t, i)(int *, p), return p[i] * 2;);
+    y = at(vex::element_index(), vex::raw_pointer(x));
+    hy = download(y);
+    for (int i = 0; i < n; i += 5) CHECK_EQUAL(hy[i], -2);
+}
+
+namespace {
+template <class S> S logistic(const S &x, double r) { return r * x * (1 - x); }
+template <class S> void iterate3(S &x, double r) { S a = logistic(x, r); S b = logistic(a, r); x = logistic(b, r); }
+}
+
+TEST_CASE(symbolic_generator_records_generic_code) {                  // generator.cpp: kernel_generator, function_adapter
+    const size_t n = 5000;
+    std::ostringstream body;
+    vex::generator::set_recorder(body);
+    typedef vex::symbolic<double> sym;
+    sym sx(sym::VectorParameter), sr(sym::ScalarParameter, sym::Const);
+    {   // r is a kernel parameter here: the recorded code multiplies by the variable, not a literal
+        sym a = sr * sx * (1 - sx);
+        sx = sr * a * (1 - a);
+    }
+    auto kernel = vex::generator::build_kernel(ctx, "logistic2", body.str(), sx, sr);
+    std::vector<double> h = random_vector<double>(n);
+    vex::vector<double> X(ctx, h);
+    for (int it = 0; it < 5; ++it) kernel(X, 3.7);
+    auto got = download(X);
+    for (size_t i = 0; i < n; i += 17) {
+        double s = h[i];
+        for (int it = 0; it < 10; ++it) s = logistic(s, 3.7);
+        CHECK_CLOSE(got[i] + 1, s + 1, 1e-9);
+    }
+    // a generic functor becomes a device function usable in expressions; literals are recorded exactly
+    auto step3 = vex::generator::make_function<double(double)>([](const sym &x) { sym y = x; iterate3(y, 3.625); return y; });
+    vex::vector<double> Y(ctx, h), Z(ctx, n);
+    Z = step3(Y) + 1;
+    got = download(Z);
+    for (size_t i = 0; i < n; i += 19) { double s = h[i]; iterate3(s, 3.625); CHECK_CLOSE(got[i], s + 1, 1e-10); }
+}
+
+TEST_CASE(fft_against_the_definition_and_round_trips) {              // fft.cpp: check_correctness, test_dimensions
+    auto q = one_queue();
+    // 1-D complex, awkward length (Bluestein), against the O(n^2) definition
+    const size_t n = 211;
+    std::vector<cl_double2> h(n);
+    std::mt19937 rng(5); std::uniform_real_distribution<double> U(-1.0, 1.0);
+    for (auto &c : h) { c.s[0] = U(rng); c.s[1] = U(rng); }
+    vex::vector<cl_double2> in(q, h), out(q, n), back(q, n);
+    vex::FFT<cl_double2> fft(q, n), ifft(q, n, vex::fft::inverse);
+    out = fft(in);
+    auto ho = download(out);
+    const double pi = 3.14159265358979323846;
+    for (size_t k = 0; k < n; k += 10) {
+        std::complex<long double> s = 0;
+        for (size_t j = 0; j < n; ++j) s += std::complex<long double>(h[j].s[0], h[j].s[1]) * std::polar<long double>(1.0L, -2.0L * pi * (long double)((j * k) % n) / n);
+        CHECK_SMALL(ho[k].s[0] - (double)s.real(), 1e-10); CHECK_SMALL(ho[k].s[1] - (double)s.imag(), 1e-10);
+    }
+    back = ifft(out);
+    auto hb = download(back);
+    for (size_t j = 0; j < n; ++j) { CHECK_SMALL(hb[j].s[0] - h[j].s[0], 1e-12); CHECK_SMALL(hb[j].s[1] - h[j].s[1], 1e-12); }
+
+    // real input, real output, batch of 2-D transforms with one four-step dimension; result used inside an expression
+    const size_t B = 3, H = 6, W = 4100;
+    std::vector<double> r = random_vector<double>(B * H * W);
+    vex::vector<double> R(q, r), R2(q, B * H * W);
+    vex::vector<cl_double2> F(q, B * H * W);
+    vex::FFT<double, cl_double2> f2(q, {B, H, W}, {vex::fft::none, vex::fft::forward, vex::fft::forward});
+    vex::FFT<cl_double2, double> i2(q, {B, H, W}, {vex::fft::none, vex::fft::inverse, vex::fft::inverse});
+    F = f2(R);
+    R2 = 0.5 * i2(F) + R;                                             // = 1.5 R
+    auto h2 = download(R2);
+    double worst = 0; for (size_t i = 0; i < h2.size(); ++i) worst = std::max(worst, std::fabs(h2[i] - 1.5 * r[i]));
+    CHECK_SMALL(worst, 1e-12);
+    auto hf = download(F);                                            // DC term of every batch = the sum of its elements
+    for (size_t b = 0; b < B; ++b) {
+        double s = 0; for (size_t i = 0; i < H * W; ++i) s += r[b * H * W + i];
+        CHECK_CLOSE(hf[b * H * W].s[0], s, 1e-9); CHECK_SMALL(hf[b * H * W].s[1], 1e-9);
+    }
+    CHECK_EQUAL(vex::fft::planner().best_size(1025), 1029u);
+}

@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
-GPU_TESTS = ["vector_tests", "spmv_tests", "primitives_tests", "multivector_tests", "expression_tests", "view_tests"]
+GPU_TESTS = ["vector_tests", "spmv_tests", "primitives_tests", "multivector_tests", "expression_tests", "view_tests", "extras_tests"]
 
 
 def _build(name):
