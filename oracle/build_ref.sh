@@ -41,7 +41,20 @@ build_one() {
         rm -f "$out/$name"; echo "FAILED  $name ($(grep -c 'error' "$out/$name.build.log") error lines, see oracle/_ref/$name.build.log)"
     fi
 }
-export -f build_one; export here repo ref out
+# The reference's example programs that need nothing but vex:: (no Boost.program_options / odeint / cuFFT /
+# ViennaCL): built the same way as example_<name>; the pytest module checks that they run to completion.
+EXAMPLES="devlist complex_simple complex_spmv mba_benchmark fft_profile exclusive simple/hello"
+build_example() {
+    src="$1"; name="example_$(basename "$1")"
+    if g++ -std=c++17 -O1 -w -DVEXCL_BACKEND_CUDA -I "$here/ref_shim" -I "$repo" "$ref/examples/$src.cpp" -o "$out/$name" \
+        -L "$repo/vexcl_amd/lib" -lvexhip -Wl,-rpath,'$ORIGIN/../../vexcl_amd/lib' -pthread 2> "$out/$name.build.log"; then
+        rm -f "$out/$name.build.log"; echo "built   $name"
+    else
+        rm -f "$out/$name"; echo "FAILED  $name (see oracle/_ref/$name.build.log)"
+    fi
+}
+export -f build_one build_example; export here repo ref out
 printf '%s\n' $TESTS | xargs -P "$jobs" -I{} bash -c 'build_one {}'
+if [ $# -eq 0 ]; then printf '%s\n' $EXAMPLES | xargs -P "$jobs" -I{} bash -c 'build_example {}'; fi
 ls "$out" | grep -v '\.log$' > "$out/MANIFEST" || true
 exit 0

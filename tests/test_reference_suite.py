@@ -32,7 +32,9 @@ NAMES = _names()
 def test_reference_program(name):
     exe = os.path.join(REF, name)
     env = dict(os.environ)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    args = {"example_mba_benchmark": ["65536"]}.get(name, [])
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT, stdin=subprocess.DEVNULL)
     tail = (r.stdout[-3000:] + "\n" + r.stderr[-3000:])
-    assert r.returncode == 0, f"reference test program {name} failed:\n{tail}"
-    assert "0 failures" in r.stdout, tail
+    assert r.returncode == 0, f"reference program {name} failed:\n{tail}"
+    if not name.startswith("example_"):          # the reference's examples/*.cpp print results, not a test summary
+        assert "0 failures" in r.stdout, tail

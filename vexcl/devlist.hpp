@@ -203,10 +203,12 @@ class Context {
         std::vector<backend::command_queue> q;
 };
 
-inline std::ostream &operator<<(std::ostream &os, const backend::device &d) {
+namespace backend {      // next to the types they print, so that `std::cout << device` finds them from any namespace
+inline std::ostream &operator<<(std::ostream &os, const device &d) {
     return os << d.name() << " (" << d.arch() << ", " << d.multiprocessor_count() << " CUs)";
 }
-inline std::ostream &operator<<(std::ostream &os, const backend::command_queue &q) { return os << q.device(); }
+inline std::ostream &operator<<(std::ostream &os, const command_queue &q) { return os << q.device(); }
+}
 inline std::ostream &operator<<(std::ostream &os, const std::vector<backend::command_queue> &queue) {
     unsigned p = 0;
     for (const auto &q : queue) os << ++p << ". " << q << std::endl;

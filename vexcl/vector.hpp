@@ -16,6 +16,7 @@
 
 #include "backend.hpp"
 #include "devlist.hpp"
+#include "profiler.hpp"
 #include "operations.hpp"
 
 namespace vex {
