@@ -9,6 +9,7 @@
 #include <vexcl/svm_vector.hpp>
 #include <vexcl/generator.hpp>
 #include <vexcl/fft.hpp>
+#include <vexcl/constant_address_space.hpp>
 #include <complex>
 
 namespace {
@@ -207,4 +208,22 @@ TEST_CASE(fft_against_the_definition_and_round_trips) {              // fft.cpp:
         CHECK_CLOSE(hf[b * H * W].s[0], s, 1e-9); CHECK_SMALL(hf[b * H * W].s[1], 1e-9);
     }
     CHECK_EQUAL(vex::fft::planner().best_size(1025), 1029u);
+}
+
+TEST_CASE(constant_vectors_and_pointers) {                            // vector_arithmetics.cpp:300-316, vector_pointer.cpp:84-120
+    auto q = one_queue();
+    const size_t N = 1000;
+    int table[] = {5, 7, 11, 13};
+    vex::vector<int> x(q, 4, table, vex::backend::MEM_READ_ONLY), y(q, N);
+    y = vex::permutation(vex::element_index() % 4)(vex::constant(x)) + 1;
+    auto h = download(y);
+    for (size_t i = 0; i < N; ++i) CHECK_EQUAL(h[i], table[i % 4] + 1);
+    auto X = vex::constant_pointer(x);
+    y = X[vex::element_index() % 4];
+    h = download(y);
+    for (size_t i = 0; i < N; ++i) CHECK_EQUAL(h[i], table[i % 4]);
+    VEX_FUNCTION(int, lookup, (int, idx)(vex::constant_ptr<int>, t), return t[idx % 4];);
+    y = lookup(vex::element_index(), vex::constant_pointer(x));
+    h = download(y);
+    for (size_t i = 0; i < N; ++i) CHECK_EQUAL(h[i], table[i % 4]);
 }

@@ -240,12 +240,17 @@ template <class T> struct constant_ptr {};
 using backend::global_ptr;
 using backend::shared_ptr;
 using backend::regstr_ptr;
+using backend::constant_ptr;
 
 template <class T> struct type_name_impl< backend::global_ptr<T> > {
     static std::string get() { return type_name<T>() + " *"; }
 };
 template <class T> struct type_name_impl< backend::global_ptr<const T> > {
     static std::string get() { return "const " + type_name<T>() + " *"; }
+};
+/// OpenCL's __constant pointers: read-only, non-aliasing data (scalar loads where the index is wave-uniform).
+template <class T> struct type_name_impl< backend::constant_ptr<T> > {
+    static std::string get() { return "const " + type_name<T>() + " * __restrict__"; }
 };
 template <class T> struct type_name_impl< backend::shared_ptr<T> > {
     static std::string get() { return type_name<T>() + " *"; }

@@ -265,7 +265,7 @@ struct ternary_expr : expression_base {
 /// *p and p[i] for pointer-valued expressions; usable on the left of an assignment through vex::tie.
 template <class P>
 struct deref_expr : expression_base {
-    typedef typename std::remove_pointer<typename P::value_type>::type value_type;
+    typedef typename std::remove_cv<typename std::remove_pointer<typename P::value_type>::type>::type value_type;
     P p;
     explicit deref_expr(const P &p) : p(p) {}
     void preamble(gen_context &c) const { p.preamble(c); }
