@@ -116,9 +116,13 @@ struct divisor {
 };
 
 /// One Stockham stage over the lines held in LDS (line l at l * pitch): `src` -> `dst`, sub-transform length p -> p * R.
+/// `gin` / `gout` non-null: the stage reads its inputs straight from global memory (first stage of contiguous lines:
+/// lane j reads elements j + q * nb, coalesced for every q) / writes its outputs straight to global memory (last
+/// stage: p = nb, so lane j writes elements j + s * nb) instead of going through LDS.
 template <typename T, int R>
 __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__restrict__ dst,
-        const cx<T> *__restrict__ tw, int n, int pitch, int p, int nlines, bool inverse)
+        const cx<T> *__restrict__ tw, int n, int pitch, int p, int nlines, bool inverse,
+        const cx<T> *__restrict__ gin, const long long *in_off, cx<T> *__restrict__ gout, const long long *out_off)
 {
     const int nb = n / R;                        // butterflies per line
     const int tstride = n / (p * R);             // W_(pR)^k = tw[k * tstride]
@@ -133,10 +137,16 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
     for (int b = threadIdx.x; b < total; b += FB) {
         const int line = dnb.div(b), j = b - line * nb;
         const int k = j - dp.div(j) * p;
-        const cx<T> *in = src + line * pitch + j;
         cx<T> v[R];
+        if (gin) {
+            const cx<T> *in = gin + in_off[line] + j;
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = in[q * nb];
+            for (int q = 0; q < R; ++q) v[q] = in[q * nb];
+        } else {
+            const cx<T> *in = src + line * pitch + j;
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[q] = in[q * nb];
+        }
         if (p > 1) {
             cx<T> w1 = tw[(size_t)k * tstride];
             if (inverse) w1.y = -w1.y;
@@ -145,9 +155,15 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
             for (int q = 1; q < R; ++q) { v[q] = v[q] * w; if (q + 1 < R) w = w * w1; }
         }
         dft<T, R>::run(v, root, inverse);
-        cx<T> *out = dst + line * pitch + (j - k) * R + k;
+        if (gout) {
+            cx<T> *out = gout + out_off[line] + (j - k) * R + k;
 #pragma unroll
-        for (int s = 0; s < R; ++s) out[s * p] = v[s];
+            for (int s = 0; s < R; ++s) out[s * p] = v[s];
+        } else {
+            cx<T> *out = dst + line * pitch + (j - k) * R + k;
+#pragma unroll
+            for (int s = 0; s < R; ++s) out[s * p] = v[s];
+        }
     }
 }
 
@@ -194,38 +210,38 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
     __syncthreads();
 
     const divisor dn = divisor::make(n), dl = divisor::make(nl);
-    if (map.in_es == 1) {                        // contiguous lines: neighbouring lanes read neighbouring elements of a line
-        for (int e = threadIdx.x; e < E; e += FB) {
-            const int l = dn.div(e), k = e - l * n;
-            A[l * pitch + k] = in[in_off[l] + k];
-        }
-    } else {                                     // strided lines: neighbouring lanes read the same element of neighbouring lines
+    // contiguous lines: the first stage reads global memory itself, the last one writes it (no staging copy in LDS);
+    // strided lines: neighbouring lanes move the same element of neighbouring lines through LDS
+    const bool direct_in = map.in_es == 1, direct_out = map.out_es == 1 && map.tw_M == 0;
+    if (!direct_in) {
         for (int e = threadIdx.x; e < E; e += FB) {
             const int k = dl.div(e), l = e - k * nl;
             A[l * pitch + k] = in[in_off[l] + k * map.in_es];
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     int p = 1;
     for (int s = 0; s < st.count; ++s) {
         const int R = st.radix[s];
+        const cx<T> *gi = (s == 0 && direct_in) ? in : nullptr;
+        cx<T> *go = (s + 1 == st.count && direct_out) ? out : nullptr;
         if constexpr (ODD) {
             switch (R) {
-                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse); break;
-                case 3:  stage<T, 3>(A, B, tw, n, pitch, p, nl, inverse); break;
-                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse); break;
-                case 5:  stage<T, 5>(A, B, tw, n, pitch, p, nl, inverse); break;
-                case 7:  stage<T, 7>(A, B, tw, n, pitch, p, nl, inverse); break;
-                case 8:  stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse); break;
-                case 11: stage<T, 11>(A, B, tw, n, pitch, p, nl, inverse); break;
-                default: stage<T, 13>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 3:  stage<T, 3>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 5:  stage<T, 5>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 7:  stage<T, 7>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 8:  stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 11: stage<T, 11>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                default: stage<T, 13>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
             }
         } else {
             switch (R) {
-                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse); break;
-                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse); break;
-                default: stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse); break;
+                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                default: stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
             }
         }
         p *= R;
@@ -233,6 +249,7 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
         __syncthreads();
     }
 
+    if (direct_out) return;
     const bool along = map.out_es == 1;
     for (int e = threadIdx.x; e < E; e += FB) {
         int l, k;
