@@ -21,7 +21,33 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def tune():
+    """Row-kernel knobs (VEXHIP_FFT_ROW_ELEMS: elements per tile of contiguous lines; VEXHIP_FFT_LANES_DIV: lanes per
+    workgroup = butterflies of the widest stage / div), read by the plan at creation."""
+    dev = torch.device("cuda:0")
+    out = {}
+    for dtype, name in ((torch.complex128, "fp64"), (torch.complex64, "fp32")):
+        for n in (256, 1024, 2048, 4096 if name == "fp32" else 1000):
+            sizes = [(1 << 26) // n, n]
+            total = sizes[0] * sizes[1]
+            x = torch.randn(total, dtype=torch.float64 if name == "fp64" else torch.float32, device=dev).to(dtype)
+            y = torch.empty_like(x)
+            for elems in (512, 1024, 2048, 4096):
+                for div in (1, 2, 4):
+                    os.environ["VEXHIP_FFT_ROW_ELEMS"] = str(elems)
+                    os.environ["VEXHIP_FFT_LANES_DIV"] = str(div)
+                    f = ops.FFT(sizes, [2, 0], dtype=dtype)
+                    ms = timed(lambda: f(x, out=y, scaled=False), 10)
+                    out["%s n=%d elems=%d div=%d" % (name, n, elems, div)] = round(ms, 4)
+                    del f
+            del x, y
+            torch.cuda.empty_cache()
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "tune":
+        return tune()
     dev = torch.device("cuda:0")
     cases = [
         ("1-D n=1024, batch 65536", [65536, 1024], [2, 0]),

@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -134,7 +135,7 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
         for (int t = 0; t < R; ++t) { root[t] = tw[(size_t)t * nb]; if (inverse) root[t].y = -root[t].y; }
     }
     const int total = nlines * nb;
-    for (int b = threadIdx.x; b < total; b += FB) {
+    for (int b = threadIdx.x; b < total; b += (int)blockDim.x) {
         const int line = dnb.div(b), j = b - line * nb;
         const int k = j - dp.div(j) * p;
         cx<T> v[R];
@@ -196,16 +197,16 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
     cx<T> *A = reinterpret_cast<cx<T> *>(fft_smem);
     cx<T> *B = A + (size_t)lines_per_wg * pitch;
 
-    if ((int)threadIdx.x < nl) {
-        long long g = g0 + threadIdx.x, io = 0, oo = 0;
-        tw_j[threadIdx.x] = map.tw_M ? (g / map.tw_div) % map.tw_mod : 0;
+    for (int l = threadIdx.x; l < nl; l += (int)blockDim.x) {
+        long long g = g0 + l, io = 0, oo = 0;
+        tw_j[l] = map.tw_M ? (g / map.tw_div) % map.tw_mod : 0;
         for (int i = 0; i < map.nlv; ++i) {
             const long long q = (i + 1 < map.nlv) ? g / map.extent[i] : 0;
             const long long d = (i + 1 < map.nlv) ? g - q * map.extent[i] : g;
             io += d * map.in_stride[i]; oo += d * map.out_stride[i];
             g = q;
         }
-        in_off[threadIdx.x] = io; out_off[threadIdx.x] = oo;
+        in_off[l] = io; out_off[l] = oo;
     }
     __syncthreads();
 
@@ -214,7 +215,7 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
     // strided lines: neighbouring lanes move the same element of neighbouring lines through LDS
     const bool direct_in = map.in_es == 1, direct_out = map.out_es == 1 && map.tw_M == 0;
     if (!direct_in) {
-        for (int e = threadIdx.x; e < E; e += FB) {
+        for (int e = threadIdx.x; e < E; e += (int)blockDim.x) {
             const int k = dl.div(e), l = e - k * nl;
             A[l * pitch + k] = in[in_off[l] + k * map.in_es];
         }
@@ -251,7 +252,7 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
 
     if (direct_out) return;
     const bool along = map.out_es == 1;
-    for (int e = threadIdx.x; e < E; e += FB) {
+    for (int e = threadIdx.x; e < E; e += (int)blockDim.x) {
         int l, k;
         if (along) { l = dn.div(e); k = e - l * n; } else { k = dl.div(e); l = e - k * nl; }
         cx<T> v = A[l * pitch + k];
@@ -363,7 +364,7 @@ struct step {
     enum kind_t { LINES, TRANSPOSE, BLUE_IN, BLUE_MUL, BLUE_OUT, COPY } kind;
     int src, dst;
     // LINES
-    int n = 0; long long lines = 0; int lines_per_wg = 1, pitch = 0; stage_list st{}; int inverse = 0; int table = -1; line_map map{};
+    int n = 0; long long lines = 0; int lines_per_wg = 1, pitch = 0, threads = FB; stage_list st{}; int inverse = 0; int table = -1; line_map map{};
     // TRANSPOSE: [batch][R][C] -> [batch][C][R]
     long long batch = 0, R = 0, C = 0;
     // BLUESTEIN
@@ -438,13 +439,21 @@ struct plan_t {
         // (the tile's width IS the contiguous run of the global accesses)
         long long L = std::min<long long>(MAX_LINES, std::max<long long>(1, lds_elems<T>() / (long long)n));
         while (L > 1 && L * ((long long)n + 1) > lds_elems<T>() + MAX_LINES) --L;
+        long long row_elems = lds_elems<T>() / 2;                     // contiguous lines: <= 16 KiB per buffer
+        if (const char *e = getenv("VEXHIP_FFT_ROW_ELEMS")) row_elems = std::max(1, atoi(e));      // tuning knob (tools/fft_bench.py)
         if (map.in_es == 1 && map.out_es == 1) {
-            L = std::max<long long>(1, std::min(L, (long long)(lds_elems<T>() / 2) / (long long)n));      // <= 16 KiB per buffer
+            L = std::max<long long>(1, std::min(L, row_elems / (long long)n));
             L = std::max<long long>(1, std::min(L, (lines + 2047) / 2048));
         }
         L = std::min(L, std::max<long long>(lines, 1));
         s.lines_per_wg = (int)L;
         s.pitch = (int)n + (L > 1 ? 1 : 0);
+        // lanes: one per butterfly of the widest stage, in whole waves
+        int min_radix = s.st.radix[0];
+        for (int i = 1; i < s.st.count; ++i) min_radix = std::min(min_radix, s.st.radix[i]);
+        long long want = L * ((long long)n / min_radix);
+        if (const char *e = getenv("VEXHIP_FFT_LANES_DIV")) want /= std::max(1, atoi(e));
+        s.threads = (int)std::min<long long>(FB, std::max<long long>(kWave, (want + kWave - 1) / kWave * kWave));
         steps.push_back(s);
         res = s.dst;
         return 0;
@@ -597,7 +606,7 @@ struct plan_t {
                     if (lds > 48 * 1024)          // per device, and cheap: raise the dynamic LDS limit for the padded tiles
                         VEXHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (lds_elems<T>() + MAX_LINES) * (int)sizeof(cx<T>)));
-                    kernel<<<dim3((unsigned)grid), dim3(FB), lds, stream>>>(src, dst,
+                    kernel<<<dim3((unsigned)grid), dim3(s.threads), lds, stream>>>(src, dst,
                             static_cast<const cx<T> *>(owned[s.table - B_FIRST_OWNED]), s.n, s.lines, s.lines_per_wg, s.pitch, s.st, s.inverse, s.map);
                     break;
                 }
