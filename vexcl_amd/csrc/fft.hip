@@ -116,14 +116,20 @@ struct divisor {
     __device__ __forceinline__ int div(int x) const { return shift >= 0 ? (x >> shift) : (x / d); }
 };
 
+/// Pointwise work fused into the global accesses of contiguous lines (Bluestein): element i of a line is read as
+/// i < pre_n ? x[i] * pre[i] : 0 (pre_n = 0: no limit, pre = null: no factor) and written, only if i < post_n, as
+/// X[i] * post[i] * scale.
+template <typename T> struct io_ops { const cx<T> *pre; int pre_n; const cx<T> *post; int post_n; T scale; };
+
 /// One Stockham stage over the lines held in LDS (line l at l * pitch): `src` -> `dst`, sub-transform length p -> p * R.
 /// `gin` / `gout` non-null: the stage reads its inputs straight from global memory (first stage of contiguous lines:
 /// lane j reads elements j + q * nb, coalesced for every q) / writes its outputs straight to global memory (last
 /// stage: p = nb, so lane j writes elements j + s * nb) instead of going through LDS.
-template <typename T, int R>
+template <typename T, int R, bool FUSED>
 __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__restrict__ dst,
         const cx<T> *__restrict__ tw, int n, int pitch, int p, int nlines, bool inverse,
-        const cx<T> *__restrict__ gin, const long long *in_off, cx<T> *__restrict__ gout, const long long *out_off)
+        const cx<T> *__restrict__ gin, const long long *in_off, cx<T> *__restrict__ gout, const long long *out_off,
+        const io_ops<T> &io)
 {
     const int nb = n / R;                        // butterflies per line
     const int tstride = n / (p * R);             // W_(pR)^k = tw[k * tstride]
@@ -141,8 +147,19 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
         cx<T> v[R];
         if (gin) {
             const cx<T> *in = gin + in_off[line] + j;
+            if constexpr (!FUSED) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = in[q * nb];
+                for (int q = 0; q < R; ++q) v[q] = in[q * nb];
+            } else {
+                // all loads unconditional (clamped index), so that they stay in flight together; the cut is a select
+                const cx<T> *line0 = gin + in_off[line];
+                const int last = (io.pre_n ? io.pre_n : n) - 1;
+                cx<T> f[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) { const int i = min(j + q * nb, last); v[q] = line0[i]; f[q] = io.pre ? io.pre[i] : cx<T>{T(1), T(0)}; }
+#pragma unroll
+                for (int q = 0; q < R; ++q) { const cx<T> x = v[q] * f[q]; v[q] = (j + q * nb <= last) ? x : cx<T>{T(0), T(0)}; }
+            }
         } else {
             const cx<T> *in = src + line * pitch + j;
 #pragma unroll
@@ -157,9 +174,21 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
         }
         dft<T, R>::run(v, root, inverse);
         if (gout) {
-            cx<T> *out = gout + out_off[line] + (j - k) * R + k;
+            const int o = (j - k) * R + k;
+            cx<T> *out = gout + out_off[line] + o;
+            if constexpr (!FUSED) {
 #pragma unroll
-            for (int s = 0; s < R; ++s) out[s * p] = v[s];
+                for (int s = 0; s < R; ++s) out[s * p] = v[s];
+            } else {
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const int i = o + s * p;
+                    if (io.post_n == 0 || i < io.post_n) {
+                        const cx<T> x = io.post ? v[s] * io.post[i] : v[s];
+                        out[s * p] = {x.x * io.scale, x.y * io.scale};
+                    }
+                }
+            }
         } else {
             cx<T> *out = dst + line * pitch + (j - k) * R + k;
 #pragma unroll
@@ -178,13 +207,16 @@ struct line_map {
     long long in_es, out_es;
     // inter-pass twiddle: element k of line g is multiplied by W_M^(k * J), J = (g / tw_div) % tw_mod; tw_M = 0: none
     long long tw_M, tw_div, tw_mod;
+    // pointwise factors fused into the global accesses (io_ops), contiguous lines only
+    const void *pre, *post; int pre_n, post_n; double post_scale;
 };
 
 constexpr int MAX_LINES = 256;                   // lines per workgroup (size of the offset tables in LDS)
 
 /// A tile of lines, each transformed completely in LDS.
 /// ODD = false: the instantiation for lengths 2^a (radix 2 / 4 / 8 stages only: half the registers of the general one).
-template <typename T, bool ODD>
+/// FUSED = true: the instantiation whose global accesses carry pointwise factors (io_ops; Bluestein).
+template <typename T, bool ODD, bool FUSED>
 __global__ __launch_bounds__(FB)
 void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, const cx<T> *__restrict__ tw,
         int n, long long lines, int lines_per_wg, int pitch, stage_list st, int inverse, line_map map)
@@ -214,6 +246,7 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
     // contiguous lines: the first stage reads global memory itself, the last one writes it (no staging copy in LDS);
     // strided lines: neighbouring lanes move the same element of neighbouring lines through LDS
     const bool direct_in = map.in_es == 1, direct_out = map.out_es == 1 && map.tw_M == 0;
+    const io_ops<T> io = {static_cast<const cx<T> *>(map.pre), map.pre_n, static_cast<const cx<T> *>(map.post), map.post_n, (T)map.post_scale};
     if (!direct_in) {
         for (int e = threadIdx.x; e < E; e += (int)blockDim.x) {
             const int k = dl.div(e), l = e - k * nl;
@@ -229,20 +262,20 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
         cx<T> *go = (s + 1 == st.count && direct_out) ? out : nullptr;
         if constexpr (ODD) {
             switch (R) {
-                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 3:  stage<T, 3>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 5:  stage<T, 5>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 7:  stage<T, 7>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 8:  stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 11: stage<T, 11>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                default: stage<T, 13>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 2:  stage<T, 2, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 3:  stage<T, 3, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 4:  stage<T, 4, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 5:  stage<T, 5, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 7:  stage<T, 7, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 8:  stage<T, 8, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 11: stage<T, 11, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                default: stage<T, 13, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
             }
         } else {
             switch (R) {
-                case 2:  stage<T, 2>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 4:  stage<T, 4>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                default: stage<T, 8>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 2:  stage<T, 2, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 4:  stage<T, 4, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                default: stage<T, 8, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
             }
         }
         p *= R;
@@ -428,9 +461,9 @@ struct plan_t {
 
     /// One launch of the lines kernel.  `in_place`: source and destination offsets coincide, so a writable source
     /// is transformed where it is; otherwise the pass goes to the other buffer of the pair (a, b).
-    int emit_pass(size_t n, bool inverse, const line_map &map, long long lines, bool in_place, int cur, int a, int b, int &res) {
+    int emit_pass(size_t n, bool inverse, const line_map &map, long long lines, bool in_place, int cur, int a, int b, int &res, int dst = -1) {
         step s; s.kind = step::LINES; s.src = cur;
-        s.dst = (in_place && writable(cur)) ? cur : (cur == a ? b : a);
+        s.dst = dst >= 0 ? dst : (in_place && writable(cur)) ? cur : (cur == a ? b : a);
         s.n = (int)n; s.lines = lines; s.inverse = inverse; s.map = map;
         if (!factor(n, s.st)) return fail(__FILE__, __LINE__, "fft: internal error, unsupported pass length");
         if (int rc = twiddles(n, s.table)) return rc;
@@ -544,7 +577,9 @@ struct plan_t {
         int chirp_id, bhat_id, ba, bb;
         if (int rc = upload(chirp, chirp_id)) return rc;
         if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), ba)) return rc;
-        if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), bb)) return rc;
+        bb = ba;
+        if (m > (size_t)lds_elems<T>())            // multi-pass convolution transforms alternate between two buffers
+            if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), bb)) return rc;
         {   // bhat = FFT_m(b), computed once with a plan of its own
             plan_t<T> sub; sub.dev = dev; sub.total = m;
             int in_id, r, w1;
@@ -556,6 +591,21 @@ struct plan_t {
             if (int rc = sub.run(nullptr, owned[in_id - B_FIRST_OWNED], dst, sub.owned[w1 - B_FIRST_OWNED])) return rc;
             if (r == B_WORK) VEXHIP_TRY(hipMemcpyAsync(dst, sub.owned[w1 - B_FIRST_OWNED], m * sizeof(cx<T>), hipMemcpyDeviceToDevice, nullptr));
             VEXHIP_TRY(hipDeviceSynchronize());
+        }
+        if (m <= (size_t)lds_elems<T>()) {
+            // two row passes carry all the pointwise work: chirp + zero padding on the way in and the product with
+            // FFT(b) on the way out of the forward transform; chirp, 1/m and the cut to n on the way out of the inverse
+            const int final_dst = writable(cur) ? cur : a;
+            line_map f{};
+            f.in_es = f.out_es = 1; f.nlv = 1; f.extent[0] = rows; f.in_stride[0] = (long long)n; f.out_stride[0] = (long long)m;
+            f.pre = owned[chirp_id - B_FIRST_OWNED]; f.pre_n = (int)n;
+            f.post = owned[bhat_id - B_FIRST_OWNED]; f.post_n = 0; f.post_scale = 1.0;
+            int c;
+            if (int rc = emit_pass(m, false, f, rows, false, cur, ba, bb, c, ba)) return rc;
+            line_map g{};
+            g.in_es = g.out_es = 1; g.nlv = 1; g.extent[0] = rows; g.in_stride[0] = (long long)m; g.out_stride[0] = (long long)n;
+            g.post = owned[chirp_id - B_FIRST_OWNED]; g.post_n = (int)n; g.post_scale = 1.0 / (double)m;
+            return emit_pass(m, true, g, rows, false, c, ba, bb, res, final_dst);
         }
         step s1; s1.kind = step::BLUE_IN; s1.src = cur; s1.dst = ba; s1.bn = (long long)n; s1.bm = (long long)m; s1.rows = rows; s1.chirp = chirp_id;
         steps.push_back(s1);
@@ -602,7 +652,9 @@ struct plan_t {
                     const long long grid = (s.lines + s.lines_per_wg - 1) / s.lines_per_wg;
                     const size_t lds = 2 * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
                     const bool pow2 = (s.n & (s.n - 1)) == 0;
-                    auto kernel = pow2 ? &fft_lines_kernel<T, false> : &fft_lines_kernel<T, true>;
+                    const bool fused = s.map.pre || s.map.pre_n || s.map.post || s.map.post_n;
+                    auto kernel = fused ? (pow2 ? &fft_lines_kernel<T, false, true> : &fft_lines_kernel<T, true, true>)
+                                        : (pow2 ? &fft_lines_kernel<T, false, false> : &fft_lines_kernel<T, true, false>);
                     if (lds > 48 * 1024)          // per device, and cheap: raise the dynamic LDS limit for the padded tiles
                         VEXHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (lds_elems<T>() + MAX_LINES) * (int)sizeof(cx<T>)));
