@@ -53,8 +53,23 @@ build_example() {
         rm -f "$out/$name"; echo "FAILED  $name (see oracle/_ref/$name.build.log)"
     fi
 }
-export -f build_one build_example; export here repo ref out
+# The reference's size checks are a compile-time option (VEXCL_CHECK_SIZES, CMakeLists.txt:23); the tests that hold
+# `#if (VEXCL_CHECK_SIZES > 0)` cases are built a second time with it as <name>_checked.
+CHECKED="vector_arithmetics vector_view multivector_arithmetics"
+build_checked() {
+    name="$1"
+    if g++ -std=c++17 -O1 -w -DVEXCL_BACKEND_CUDA -DVEXCL_CHECK_SIZES=2 -I "$here/ref_shim" -I "$repo" "$ref/tests/$name.cpp" -o "$out/${name}_checked" \
+        -L "$repo/vexcl_amd/lib" -lvexhip -Wl,-rpath,'$ORIGIN/../../vexcl_amd/lib' -pthread 2> "$out/${name}_checked.build.log"; then
+        rm -f "$out/${name}_checked.build.log"; echo "built   ${name}_checked"
+    else
+        rm -f "$out/${name}_checked"; echo "FAILED  ${name}_checked (see oracle/_ref/${name}_checked.build.log)"
+    fi
+}
+export -f build_one build_example build_checked; export here repo ref out
 printf '%s\n' $TESTS | xargs -P "$jobs" -I{} bash -c 'build_one {}'
-if [ $# -eq 0 ]; then printf '%s\n' $EXAMPLES | xargs -P "$jobs" -I{} bash -c 'build_example {}'; fi
+if [ $# -eq 0 ]; then
+    printf '%s\n' $EXAMPLES | xargs -P "$jobs" -I{} bash -c 'build_example {}'
+    printf '%s\n' $CHECKED | xargs -P "$jobs" -I{} bash -c 'build_checked {}'
+fi
 ls "$out" | grep -v '\.log$' > "$out/MANIFEST" || true
 exit 0

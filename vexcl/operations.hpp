@@ -76,6 +76,16 @@ struct prop_context {
     size_t size;
     prop_context() : size(0) {}
     bool empty() const { return queue.empty(); }
+    /// A further sized terminal joins the expression.  With VEXCL_CHECK_SIZES > 0 (a compile-time option of the
+    /// reference, operations.hpp:1442-1457) it must agree with what the expression already has.
+    void also(size_t nqueues, size_t n) const {
+#if defined(VEXCL_CHECK_SIZES) && (VEXCL_CHECK_SIZES > 0)
+        precondition(nqueues == 0 || queue.empty() || nqueues == queue.size(), "Incompatible queue lists");
+        precondition(n == 0 || size == 0 || n == size, "Incompatible expression sizes");
+#else
+        (void)nqueues; (void)n;
+#endif
+    }
 };
 
 // ---- node classification ------------------------------------------------------
@@ -514,6 +524,14 @@ void assign_expression(const LHS &lhs, const RHS &rhs,
 {
     static_assert(expr_kind<RHS>::value == 0, "expression contains terms that cannot be fused into a kernel");
     static kernel_cache cache;
+#if defined(VEXCL_CHECK_SIZES) && (VEXCL_CHECK_SIZES > 0)
+    {   // operations.hpp:1824-1840 of the reference
+        prop_context p;
+        lhs.get_props(p); rhs.get_props(p);
+        precondition(p.queue.empty() || p.queue.size() == queue.size(), "Incompatible queue lists");
+        precondition(p.size == 0 || p.size == part.back(), "Incompatible expression sizes");
+    }
+#endif
 
     for (unsigned d = 0; d < queue.size(); ++d) {
         size_t psize = part[d + 1] - part[d];

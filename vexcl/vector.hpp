@@ -87,6 +87,7 @@ struct vector_ref : expression_base {
     void set_args(arg_context &a) const { a.next(); a.krn.push_arg((*v)(a.device)); }
     void get_props(prop_context &p) const {
         if (p.empty()) { p.queue = v->queue_list(); p.part = v->partition(); p.size = v->size(); }
+        else p.also(v->queue_list().size(), v->size());
     }
 };
 

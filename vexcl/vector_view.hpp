@@ -115,11 +115,25 @@ template <class Index>
 struct permutation_builder {
     Index index;
     template <class T>
-    permutation_view<T, Index> operator()(const vector<T> &base) const { return permutation_view<T, Index>(base, index); }
+    permutation_view<T, Index> operator()(const vector<T> &base) const { check_overrun(base); return permutation_view<T, Index>(base, index); }
     template <class Expr>
     typename std::enable_if<detail::is_expr<Expr>::value && !detail::has_ref_type<Expr>::value,
         expr_permutation_view<detail::as_expr_t<Expr>, Index>>::type
-    operator()(const Expr &e) const { return expr_permutation_view<detail::as_expr_t<Expr>, Index>(detail::as_expr<Expr>::get(e), index); }
+    operator()(const Expr &e) const { check_overrun(e); return expr_permutation_view<detail::as_expr_t<Expr>, Index>(detail::as_expr<Expr>::get(e), index); }
+
+    /// VEXCL_CHECK_SIZES > 1: the largest index (a device reduction) must exist in the base (vector_view.hpp:659-677).
+    template <class Base> void check_overrun(const Base &base) const {
+#if defined(VEXCL_CHECK_SIZES) && (VEXCL_CHECK_SIZES > 1)
+        detail::prop_context b; detail::as_expr<Base>::get(base).get_props(b);
+        precondition(!b.queue.empty(), "Can not permute stateless expression");
+        detail::prop_context i; index.get_props(i);
+        if (i.size == 0 && b.size == 0) return;
+        Reductor<size_t, MAX> max(b.queue);
+        precondition(max(index) < b.size, "Permutation will result in array overrun");
+#else
+        (void)base;
+#endif
+    }
 };
 
 /// permutation(index_expression)(vector)  (vector_view.hpp:602-700)
@@ -230,11 +244,28 @@ struct gslice {
     static std::vector<size_t> all_dims() { std::vector<size_t> d(NDIM); std::iota(d.begin(), d.end(), size_t(0)); return d; }
 
     /// slice(vector): indexes the vector in place, an lvalue; slice(expression): an rvalue.
-    template <class T> vector_slice_view<T, NDIM> operator()(const vector<T> &base) const { return vector_slice_view<T, NDIM>(base, *this); }
+    template <class T> vector_slice_view<T, NDIM> operator()(const vector<T> &base) const { check_overrun(base); return vector_slice_view<T, NDIM>(base, *this); }
     template <class Expr>
     typename std::enable_if<detail::is_expr<Expr>::value && !detail::has_ref_type<typename std::decay<Expr>::type>::value,
         expr_slice_view<detail::as_expr_t<Expr>, NDIM>>::type
-    operator()(const Expr &e) const { return expr_slice_view<detail::as_expr_t<Expr>, NDIM>(detail::as_expr<Expr>::get(e), *this); }
+    operator()(const Expr &e) const { check_overrun(e); return expr_slice_view<detail::as_expr_t<Expr>, NDIM>(detail::as_expr<Expr>::get(e), *this); }
+
+    /// VEXCL_CHECK_SIZES > 0: the last element of the slice must exist in the sliced expression (vector_view.hpp:398-409).
+    template <class Expr> void check_overrun(const Expr &e) const {
+#if defined(VEXCL_CHECK_SIZES) && (VEXCL_CHECK_SIZES > 0)
+        ptrdiff_t lo = (ptrdiff_t)start, hi = (ptrdiff_t)start;
+        bool empty = false;
+        for (size_t d = 0; d < NDIM; ++d) {
+            if (!length[d]) empty = true;
+            const ptrdiff_t span = ((ptrdiff_t)length[d] - 1) * stride[d];
+            if (span > 0) hi += span; else lo += span;
+        }
+        detail::prop_context p; detail::as_expr<Expr>::get(e).get_props(p);
+        precondition(empty || p.size == 0 || (lo >= 0 && (size_t)hi < p.size), "Slice will result in array overrun");
+#else
+        (void)e;
+#endif
+    }
 };
 
 template <class T, size_t NDIM>
