@@ -364,6 +364,16 @@ int vexhip_fft_exec(void *plan, void *stream, const void *in, void *out);
 /* what the plan consists of: LDS row passes, transposes, other launches (Bluestein, copy) */
 int vexhip_fft_plan_steps(void *plan, int *row_passes, int *transposes, int *others);
 
+/* ---- vex::mba (vexcl/mba.hpp:233-330: lattice hierarchy fitted on the host in the reference) ------------------
+ * Multilevel B-spline fit of `npts` scattered points (coo: npts x ndim row-major, val: npts, both on the device;
+ * val is overwritten with the final residuals) over the domain [cmin, cmax], starting from control grid `grid`,
+ * at most `levels` levels, stopping when the squared residual falls below tol * its initial value.  ndim 1..3.
+ * Outputs the final lattice: origin, inverse spacing, extents, strides and a device buffer of the control values
+ * (allocated here, released by the caller with vexhip_free).                                                     */
+int vexhip_mba_fit(int dev, void *stream, int dtype, int ndim, const double *cmin, const double *cmax,
+        const void *coo, void *val, int64_t npts, const size_t *grid, int levels, double tol,
+        double *xmin, double *hinv, size_t *n, size_t *stride, void **phi, size_t *phi_elems);
+
 /* ---- benchmark input generators (examples/benchmark.cpp:364-415; SURVEY
  *      section 8(d): 512^3 is built on the device, never uploaded) ---------- */
 int64_t vexhip_poisson3d_nnz(int64_t n);

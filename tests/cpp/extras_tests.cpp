@@ -119,6 +119,59 @@ TEST_CASE(mba_interpolates_the_data_points) {                         // mba.cpp
     for (size_t i = 0; i < np; i += 13) CHECK_CLOSE(z2[i] + 10, 2 * z[i] + 1 + 10, 1e-10);
 }
 
+TEST_CASE(mba_device_fit_agrees_with_the_host_fit) {
+    // the same cloud fitted in HBM (default) and by the host loop (VEXCL_MBA_HOST_FIT): lattices and values agree to rounding
+    const size_t np = 5000;
+    std::vector<std::array<double, 2>> p(np); std::vector<double> v(np);
+    std::mt19937 rng(9); std::uniform_real_distribution<double> U(0.0, 1.0);
+    for (size_t i = 0; i < np; ++i) { p[i] = {{U(rng), U(rng)}}; v[i] = std::exp(-3 * p[i][0]) * std::sin(5 * p[i][1]) + 0.1 * p[i][0]; }
+    p[0] = {{2.0, 2.0}};                                              // a point outside the domain is ignored by the fit
+    std::array<double, 2> lo = {{-0.01, -0.01}}, hi = {{1.01, 1.01}};
+    std::array<size_t, 2> grid = {{2, 3}};
+    vex::mba<2> dev_fit(ctx, lo, hi, p, v, grid, 6, 1e-10);
+    setenv("VEXCL_MBA_HOST_FIT", "1", 1);
+    vex::mba<2> host_fit(ctx, lo, hi, p, v, grid, 6, 1e-10);
+    unsetenv("VEXCL_MBA_HOST_FIT");
+    for (size_t d = 0; d < 2; ++d) { CHECK_EQUAL(dev_fit.n[d], host_fit.n[d]); CHECK_EQUAL(dev_fit.stride[d], host_fit.stride[d]); CHECK_CLOSE(dev_fit.hinv[d], host_fit.hinv[d], 1e-12); }
+    const size_t m = 4000;
+    std::vector<double> px(m), py(m);
+    for (size_t i = 0; i < m; ++i) { px[i] = U(rng); py[i] = U(rng); }
+    vex::vector<double> X(ctx, px), Y(ctx, py), Zd(ctx, m), Zh(ctx, m);
+    Zd = dev_fit(X, Y); Zh = host_fit(X, Y);
+    auto zd = download(Zd), zh = download(Zh);
+    double worst = 0; for (size_t i = 0; i < m; ++i) worst = std::max(worst, std::fabs(zd[i] - zh[i]));
+    CHECK_SMALL(worst, 1e-10);
+    // 1-D and 3-D, float: the device fit reproduces smooth data
+    {
+        std::vector<std::array<float, 1>> q1(300); std::vector<float> v1(300);
+        for (size_t i = 0; i < 300; ++i) { q1[i] = {{(float)U(rng)}}; v1[i] = std::cos(4 * q1[i][0]); }
+        std::array<float, 1> l1 = {{-0.01f}}, h1 = {{1.01f}}; std::array<size_t, 1> g1 = {{3}};
+        vex::mba<1, float> s1(ctx, l1, h1, q1, v1, g1, 10, 1e-9f);
+        std::vector<float> x1(300); for (size_t i = 0; i < 300; ++i) x1[i] = q1[i][0];
+        vex::vector<float> X1(ctx, x1), Z1(ctx, 300);
+        Z1 = s1(X1);
+        auto z1 = download(Z1);
+        float w1 = 0; for (size_t i = 0; i < 300; ++i) w1 = std::max(w1, std::fabs(z1[i] - v1[i]));
+        CHECK_SMALL(w1, 2e-3);
+    }
+    {
+        std::vector<std::array<double, 3>> q3(2000); std::vector<double> v3(2000);
+        for (size_t i = 0; i < 2000; ++i) { q3[i] = {{U(rng), U(rng), U(rng)}}; v3[i] = q3[i][0] + 2 * q3[i][1] * q3[i][2]; }
+        std::array<double, 3> l3 = {{-0.01, -0.01, -0.01}}, h3 = {{1.01, 1.01, 1.01}}; std::array<size_t, 3> g3 = {{2, 2, 2}};
+        vex::mba<3> s3(ctx, l3, h3, q3, v3, g3, 7, 1e-12);
+        setenv("VEXCL_MBA_HOST_FIT", "1", 1);
+        vex::mba<3> h3fit(ctx, l3, h3, q3, v3, g3, 7, 1e-12);
+        unsetenv("VEXCL_MBA_HOST_FIT");
+        std::vector<double> a(500), b(500), c(500);
+        for (size_t i = 0; i < 500; ++i) { a[i] = U(rng); b[i] = U(rng); c[i] = U(rng); }
+        vex::vector<double> A(ctx, a), B(ctx, b), C(ctx, c), R1(ctx, 500), R2(ctx, 500);
+        R1 = s3(A, B, C); R2 = h3fit(A, B, C);
+        auto r1 = download(R1), r2 = download(R2);
+        double w3 = 0; for (size_t i = 0; i < 500; ++i) w3 = std::max(w3, std::fabs(r1[i] - r2[i]));
+        CHECK_SMALL(w3, 1e-10);
+    }
+}
+
 TEST_CASE(svm_vector_is_shared_with_the_host) {                       // svm.cpp
     auto q = one_queue();
     const int n = 3000;

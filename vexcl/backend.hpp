@@ -196,6 +196,13 @@ class device_vector {
             device_vector v; v.n_ = n; v.buf_.reset(reinterpret_cast<char *>(ptr), [](char *) {}); return v;
         }
 
+        /// Takes ownership of a device buffer allocated by libvexhip (released with vexhip_free).
+        static device_vector adopt(const command_queue &q, T *ptr, size_t n) {
+            device_vector v; v.n_ = n; int dev = q.device_ordinal();
+            v.buf_.reset(reinterpret_cast<char *>(ptr), [dev](char *p) { vexhip_free(dev, p); });
+            return v;
+        }
+
         void write(const command_queue &q, size_t offset, size_t size, const T *host, bool blocking = false) const {
             if (size) check(vexhip_memcpy_h2d(q.device_ordinal(), raw() + offset, host, size * sizeof(T), q.raw(), blocking));
         }

@@ -39,6 +39,24 @@ struct Platform {
     std::string name;
 };
 
+/// OpenCL extension by name (backend/opencl/filter.hpp:144-160).  There are no OpenCL extensions here; the two
+/// capability names user code asks about are answered by what the hardware does: fp64 and 64-bit atomics exist.
+struct Extension {
+    explicit Extension(std::string e) : extension(std::move(e)) {}
+    bool operator()(const backend::device &) const {
+        return extension == "cl_khr_fp64" || extension == "cl_khr_int64_base_atomics" || extension == "cl_khr_int64_extended_atomics";
+    }
+    std::string extension;
+};
+const Extension GLSharing("cl_khr_gl_sharing");
+/// OpenCL version (backend/opencl/filter.hpp:165-180): asked for by code that wants OpenCL 2.0 features -- shared
+/// virtual memory (vex::svm_vector: hipMallocManaged) and generic address spaces, both present.
+struct CLVersion {
+    CLVersion(int major, int minor) : major_(major), minor_(minor) {}
+    bool operator()(const backend::device &) const { return major_ < 2 || (major_ == 2 && minor_ <= 0); }
+    int major_, minor_;
+};
+
 /// Device name contains the given string (devlist.hpp Filter::Name).
 struct Name {
     explicit Name(std::string name) : devname(std::move(name)) {}
@@ -86,6 +104,8 @@ template <> struct is_filter<DoublePrecisionFilter> : std::true_type {};
 template <> struct is_filter<GPUFilter> : std::true_type {};
 template <> struct is_filter<CPUFilter> : std::true_type {};
 template <> struct is_filter<Name> : std::true_type {};
+template <> struct is_filter<Extension> : std::true_type {};
+template <> struct is_filter<CLVersion> : std::true_type {};
 template <> struct is_filter<Vendor> : std::true_type {};
 template <> struct is_filter<Platform> : std::true_type {};
 template <> struct is_filter<Count> : std::true_type {};

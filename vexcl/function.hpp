@@ -92,6 +92,9 @@ namespace detail {
 /// With dependencies: VEX_FUNCTION_D(double, f, (double, x), (g)(h), return g(x) + h(x););
 #define VEX_FUNCTION_D(rettype, fname, args, deps, ...) VEX_FUNCTION_SINK(rettype, fname, args, VEXCL_DEP_SEQ(deps), #__VA_ARGS__)
 #define VEX_FUNCTION_DS(rettype, fname, args, deps, body) VEX_FUNCTION_SINK(rettype, fname, args, VEXCL_DEP_SEQ(deps), body)
+#define VEX_FUNCTION_SD VEX_FUNCTION_DS                       /* the reference's spelling (function.hpp:194-203) */
+/// Unquoted source text as a string (function.hpp:46).
+#define VEX_STRINGIZE_SOURCE(...) #__VA_ARGS__
 
 /// Old style: VEX_FUNCTION_V1(name, double(double, double), "return prm1 + prm2;");
 #define VEX_FUNCTION_V1(fname, signature, body_str)                                                 \

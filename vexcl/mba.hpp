@@ -7,15 +7,19 @@
 //   vex::mba<2> surf(ctx, lo, hi, points, values, grid [, levels, tol]);
 //   z = sin(surf(x, y));          // evaluated inside the fused kernel
 //
-// The fit runs on the host, as in the reference (a hierarchy of control lattices, each
-// fitted to the residual of the previous ones and folded into the next finer lattice by
-// B-spline refinement; the coarse lattices are tiny and the data arrives in host memory).
-// What lives on the device is the final lattice, one read-only copy per queue, and the
-// evaluation: a device function doing the 4^NDIM-point tensor-product cubic B-spline sum
-// around the cell of (x0, x1, ...).  The coordinate operands are arbitrary expressions.
+// The fit is a hierarchy of control lattices, each fitted to the residual of the previous ones
+// and folded into the next finer lattice by B-spline refinement.  The reference fits on the
+// host; here the data is uploaded once and every level is fitted in HBM (vexhip_mba_fit:
+// one lane per data point with hardware floating-point atomics into the lattice, refinement
+// gathered per fine node), for 1 to 3 dimensions; more dimensions, or VEXCL_MBA_HOST_FIT in the
+// environment, take the host loop below (the same algorithm; the two agree to rounding).
+// What the kernels of user expressions see is the final lattice, one read-only copy per queue,
+// and the evaluation: a device function doing the 4^NDIM-point tensor-product cubic B-spline
+// sum around the cell of (x0, x1, ...).  The coordinate operands are arbitrary expressions.
 #include <array>
 #include <cassert>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 #include <vector>
@@ -213,11 +217,43 @@ class mba {
                 }
         };
 
+        /// The fit in HBM (vexhip_mba_fit: atomics-based accumulation, gathered refinement; 1 to 3 dimensions): the data
+        /// is uploaded once, every level runs on the first queue's device, the host reads one residual per level.
+        template <class CooIter, class ValIter>
+        void fit_on_device(const point &cmin, const point &cmax, CooIter coo_begin, CooIter coo_end, ValIter val_begin,
+                           const std::array<size_t, NDIM> &grid, size_t levels, real tol)
+        {
+            const size_t np = (size_t)(coo_end - coo_begin);
+            std::vector<real> flat(np * NDIM), vals(np);
+            { size_t i = 0; ValIter v = val_begin; for (CooIter c = coo_begin; c != coo_end; ++c, ++v, ++i) { for (size_t d = 0; d < NDIM; ++d) flat[i * NDIM + d] = (*c)[d]; vals[i] = *v; } }
+            const backend::command_queue &q = queue[0];
+            backend::device_vector<real> dcoo(q, flat.size(), flat.data()), dval(q, vals.size(), vals.data());
+            double lo[NDIM], hi[NDIM], xm[NDIM], hv[NDIM]; size_t g[NDIM], nn[NDIM], st[NDIM];
+            for (size_t d = 0; d < NDIM; ++d) { lo[d] = cmin[d]; hi[d] = cmax[d]; g[d] = grid[d]; }
+            void *p = nullptr; size_t elems = 0;
+            backend::check(vexhip_mba_fit(q.device_ordinal(), q.raw(), std::is_same<real, float>::value ? VEXHIP_F32 : VEXHIP_F64,
+                    (int)NDIM, lo, hi, np ? dcoo.raw() : nullptr, np ? dval.raw() : nullptr, (int64_t)np, g, (int)levels, (double)tol,
+                    xm, hv, nn, st, &p, &elems));
+            for (size_t d = 0; d < NDIM; ++d) { xmin[d] = (real)xm[d]; hinv[d] = (real)hv[d]; n[d] = nn[d]; stride[d] = st[d]; }
+            phi.reserve(queue.size());
+            phi.push_back(backend::device_vector<real>::adopt(q, static_cast<real *>(p), elems));
+            if (queue.size() > 1) {                      // one read-only copy per further queue
+                std::vector<real> host(elems);
+                phi[0].read(q, 0, elems, host.data(), true);
+                for (size_t k = 1; k < queue.size(); ++k)
+                    phi.push_back(backend::device_vector<real>(queue[k], elems, host.data(), backend::MEM_READ_ONLY));
+            }
+        }
+
         template <class CooIter, class ValIter>
         void init(const point &cmin, const point &cmax, CooIter coo_begin, CooIter coo_end, ValIter val_begin,
                   std::array<size_t, NDIM> grid, size_t levels, real tol)
         {
             for (size_t k = 0; k < NDIM; ++k) precondition(grid[k] > 1, "mba: the control grid needs at least 2 points per dimension");
+            if (NDIM <= 3 && !queue.empty() && !std::getenv("VEXCL_MBA_HOST_FIT")) {
+                fit_on_device(cmin, cmax, coo_begin, coo_end, val_begin, grid, levels, tol);
+                return;
+            }
             double res0 = 0;
             { ValIter v = val_begin; for (CooIter c = coo_begin; c != coo_end; ++c, ++v) res0 += (*v) * (*v); }
 

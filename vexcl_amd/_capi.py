@@ -155,6 +155,9 @@ _PROTOS = {
     "vexhip_poisson3d_strip_f64_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "vexhip_fill_hash": (None, [c_int, c_vp, c_int, c_u64, c_vp, c_i64]),
     "vexhip_fill_value": (None, [c_int, c_vp, c_int, c_vp, c_vp, c_i64]),
+    "vexhip_mba_fit": (None, [c_int, c_vp, c_int, c_int, ctypes.POINTER(c_f64), ctypes.POINTER(c_f64), c_vp, c_vp, c_i64,
+                       ctypes.POINTER(c_size), c_int, c_f64, ctypes.POINTER(c_f64), ctypes.POINTER(c_f64),
+                       ctypes.POINTER(c_size), ctypes.POINTER(c_size), ctypes.POINTER(c_vp), ctypes.POINTER(c_size)]),
     "vexhip_fft_best_size": (c_size, [c_size]),
     "vexhip_fft_plan_create": (None, [c_int, c_int, c_int, ctypes.POINTER(c_size), ctypes.POINTER(c_int), ctypes.POINTER(c_vp)]),
     "vexhip_fft_plan_destroy": (None, [c_vp]),
