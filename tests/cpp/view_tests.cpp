@@ -177,11 +177,12 @@ TEST_CASE(nested_reductions_and_reshape) {                            // vector_
         CHECK_CLOSE(got[k], best, 1e-8);
     }
 
-    // reshape = permutation of dimensions: a 3 x 5 x 2 array read as 2 x 3 x 5 (result dim j is source dim src[j])
+    // reshape = permutation of dimensions: a 3 x 5 x 2 array read as 2 x 3 x 5.  src_dims[k] names the RESULT dimension
+    // that source dimension k becomes (the source is shaped dst_dims[src_dims], vector_view.hpp:1092-1097 of the reference)
     const size_t d0 = 3, d1 = 5, d2 = 2;
     vex::vector<int> a(q, d0 * d1 * d2);
     a = vex::element_index();
-    vex::vector<int> b = vex::reshape(a, vex::make_array<size_t>(d2, d0, d1), vex::make_array<size_t>(2, 0, 1));
+    vex::vector<int> b = vex::reshape(a, vex::make_array<size_t>(d2, d0, d1), vex::make_array<size_t>(1, 2, 0));
     auto gb = download(b);
     for (size_t c = 0; c < d2; ++c) for (size_t i = 0; i < d0; ++i) for (size_t j = 0; j < d1; ++j)
         CHECK_EQUAL(gb[(c * d0 + i) * d1 + j], int((i * d1 + j) * d2 + c));
