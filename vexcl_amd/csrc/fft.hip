@@ -23,8 +23,8 @@
 // 13 go through Bluestein's chirp-z over a 2^a 3^b 5^c 7^d convolution length (rows gathered by a tiled LDS
 // transpose when the dimension is strided).  The plan (factorizations, passes, twiddle / chirp tables, work
 // buffers) is native C++ behind four C entry points.
-// Measured on MI355X (tools/fft_bench.py): fp64 1024-point rows 0.76 ms per 2.1 GB moved (2.8 TB/s; rocFFT 0.77 ms),
-// 2^24 points 0.77 ms in 3 passes (rocFFT 0.60), 4096 x 4096 0.87 ms in 4 passes (0.50).  Tried and dropped: an LDS
+// Measured on MI355X (tools/fft_bench.py): fp64 1024-point rows 0.54 ms per 2.1 GB moved (3.9 TB/s; torch.fft 0.81 ms, rocFFT's
+// kernel alone 0.38), 2^24 points 0.51 ms in 3 passes (torch.fft 0.63), 4096 x 4096 0.59 ms in 4 passes (0.50).  Tried and dropped: an LDS
 // layout skewed by one element per eight (removes the bank conflicts of the first stage's writes, but the extra
 // index arithmetic on every access cost more: 0.76 -> 0.94 ms on the 1024-point rows).
 #include "common.hpp"
@@ -197,6 +197,52 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
     }
 }
 
+/// The same stage for the register-resident organisation of power-of-two lengths: the workgroup has one lane per EPT (8 or
+/// 16) elements of its tile, so a lane owns EPT / R butterflies of every stage and keeps its elements in registers;
+/// all of them are read before the workgroup's barrier and written after it, which lets the stage work IN PLACE in a
+/// single LDS buffer (half the LDS of the two-buffer scheme: twice the workgroups per CU).
+template <typename T, int R, int EPT>
+__device__ __forceinline__ void stage_inplace(cx<T> *__restrict__ buf, const cx<T> *__restrict__ tw, int n, int pitch, int p,
+        int nlines, bool inverse, const cx<T> *__restrict__ gin, const long long *in_off, cx<T> *__restrict__ gout, const long long *out_off)
+{
+    constexpr int K = EPT / R;                   // butterflies per lane (EPT elements per lane: 8, or 16 for fp32 tiles of 4096)
+    const int nb = n / R, tstride = n / (p * R);
+    const divisor dnb = divisor::make(nb), dp = divisor::make(p);
+    const int total = nlines * nb;
+    cx<T> v[K][R];
+    int line[K], j[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const int b = threadIdx.x + t * (int)blockDim.x;
+        line[t] = dnb.div(b); j[t] = b - line[t] * nb;
+        if (b < total) {
+            const cx<T> *in = gin ? gin + in_off[line[t]] + j[t] : buf + line[t] * pitch + j[t];
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[t][q] = in[q * nb];
+        }
+    }
+    if (!gin) __syncthreads();                   // every lane has its inputs: the buffer may be overwritten
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const int b = threadIdx.x + t * (int)blockDim.x;
+        if (b < total) {
+            const int k = j[t] - dp.div(j[t]) * p;
+            if (p > 1) {
+                cx<T> w1 = tw[(size_t)k * tstride];
+                if (inverse) w1.y = -w1.y;
+                cx<T> w = w1;
+#pragma unroll
+                for (int q = 1; q < R; ++q) { v[t][q] = v[t][q] * w; if (q + 1 < R) w = w * w1; }
+            }
+            dft<T, R>::run(v[t], nullptr, inverse);
+            const int o = (j[t] - k) * R + k;
+            cx<T> *out = gout ? gout + out_off[line[t]] + o : buf + line[t] * pitch + o;
+#pragma unroll
+            for (int s = 0; s < R; ++s) out[s * p] = v[t][s];
+        }
+    }
+}
+
 /// Where the lines of a pass live: line g (counted over the whole launch) is decomposed in the mixed radix
 /// `extent[0]` (fastest) ... `extent[nlv - 1]`; its first element is at sum digit_i * in_stride[i] in the source and at
 /// sum digit_i * out_stride[i] in the destination; element k of the line is k * in_es / k * out_es further.
@@ -216,7 +262,8 @@ constexpr int MAX_LINES = 256;                   // lines per workgroup (size of
 /// A tile of lines, each transformed completely in LDS.
 /// ODD = false: the instantiation for lengths 2^a (radix 2 / 4 / 8 stages only: half the registers of the general one).
 /// FUSED = true: the instantiation whose global accesses carry pointwise factors (io_ops; Bluestein).
-template <typename T, bool ODD, bool FUSED>
+/// EPT > 0 (2^a lengths, no fused factors): register-resident stages in one LDS buffer, blockDim = tile elements / EPT.
+template <typename T, bool ODD, bool FUSED, int EPT>
 __global__ __launch_bounds__(FB)
 void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, const cx<T> *__restrict__ tw,
         int n, long long lines, int lines_per_wg, int pitch, stage_list st, int inverse, line_map map)
@@ -227,7 +274,8 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
     const int nl = (int)min((long long)lines_per_wg, lines - g0);
     const int E = nl * n;
     cx<T> *A = reinterpret_cast<cx<T> *>(fft_smem);
-    cx<T> *B = A + (size_t)lines_per_wg * pitch;
+    constexpr bool SINGLE = EPT > 0;
+    cx<T> *B = SINGLE ? A : A + (size_t)lines_per_wg * pitch;
 
     for (int l = threadIdx.x; l < nl; l += (int)blockDim.x) {
         long long g = g0 + l, io = 0, oo = 0;
@@ -260,7 +308,13 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
         const int R = st.radix[s];
         const cx<T> *gi = (s == 0 && direct_in) ? in : nullptr;
         cx<T> *go = (s + 1 == st.count && direct_out) ? out : nullptr;
-        if constexpr (ODD) {
+        if constexpr (SINGLE) {
+            switch (R) {
+                case 2:  stage_inplace<T, 2, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 4:  stage_inplace<T, 4, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                default: stage_inplace<T, 8, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+            }
+        } else if constexpr (ODD) {
             switch (R) {
                 case 2:  stage<T, 2, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
                 case 3:  stage<T, 3, FUSED>(A, B, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
@@ -397,7 +451,7 @@ struct step {
     enum kind_t { LINES, TRANSPOSE, BLUE_IN, BLUE_MUL, BLUE_OUT, COPY } kind;
     int src, dst;
     // LINES
-    int n = 0; long long lines = 0; int lines_per_wg = 1, pitch = 0, threads = FB; stage_list st{}; int inverse = 0; int table = -1; line_map map{};
+    int n = 0; long long lines = 0; int lines_per_wg = 1, pitch = 0, threads = FB, ept = 0; stage_list st{}; int inverse = 0; int table = -1; line_map map{};
     // TRANSPOSE: [batch][R][C] -> [batch][C][R]
     long long batch = 0, R = 0, C = 0;
     // BLUESTEIN
@@ -487,6 +541,17 @@ struct plan_t {
         long long want = L * ((long long)n / min_radix);
         if (const char *e = getenv("VEXHIP_FFT_LANES_DIV")) want /= std::max(1, atoi(e));
         s.threads = (int)std::min<long long>(FB, std::max<long long>(kWave, (want + kWave - 1) / kWave * kWave));
+        // power-of-two lengths: one lane per eight elements of the tile, stages in place in one LDS buffer
+        const long long E = L * (long long)n;
+        const bool pow2 = (n & (n - 1)) == 0, plain = !map.pre && !map.pre_n && !map.post && !map.post_n;
+        if (pow2 && plain && !getenv("VEXHIP_FFT_NO_SINGLE")) {
+            for (int ept : {8, 16})
+                if (n >= (size_t)ept && E % (ept * kWave) == 0 && E / ept <= FB && (ept == 8 || sizeof(T) == 4)) {
+                    s.ept = ept;
+                    s.threads = (int)(E / ept);
+                    break;
+                }
+        }
         steps.push_back(s);
         res = s.dst;
         return 0;
@@ -650,11 +715,13 @@ struct plan_t {
             switch (s.kind) {
                 case step::LINES: {
                     const long long grid = (s.lines + s.lines_per_wg - 1) / s.lines_per_wg;
-                    const size_t lds = 2 * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
+                    const size_t lds = (s.ept ? 1 : 2) * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
                     const bool pow2 = (s.n & (s.n - 1)) == 0;
                     const bool fused = s.map.pre || s.map.pre_n || s.map.post || s.map.post_n;
-                    auto kernel = fused ? (pow2 ? &fft_lines_kernel<T, false, true> : &fft_lines_kernel<T, true, true>)
-                                        : (pow2 ? &fft_lines_kernel<T, false, false> : &fft_lines_kernel<T, true, false>);
+                    auto kernel = fused ? (pow2 ? &fft_lines_kernel<T, false, true, 0> : &fft_lines_kernel<T, true, true, 0>)
+                                : s.ept == 8 ? &fft_lines_kernel<T, false, false, 8>
+                                : s.ept == 16 ? &fft_lines_kernel<T, false, false, 16>
+                                : (pow2 ? &fft_lines_kernel<T, false, false, 0> : &fft_lines_kernel<T, true, false, 0>);
                     if (lds > 48 * 1024)          // per device, and cheap: raise the dynamic LDS limit for the padded tiles
                         VEXHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (lds_elems<T>() + MAX_LINES) * (int)sizeof(cx<T>)));
