@@ -545,13 +545,14 @@ struct plan_t {
         const long long E = L * (long long)n;
         const bool pow2 = (n & (n - 1)) == 0, plain = !map.pre && !map.pre_n && !map.post && !map.post_n;
         if (pow2 && plain && !getenv("VEXHIP_FFT_NO_SINGLE")) {
-            for (int ept : {8, 16})
-                if (n >= (size_t)ept && E % (ept * kWave) == 0 && E / ept <= FB && (ept == 8 || sizeof(T) == 4)) {
+            for (int ept : {8, 16, 32})
+                if (n >= (size_t)ept && E % (ept * kWave) == 0 && E / ept <= FB && (ept == 8 || sizeof(T) == 4 || (ept == 16 && E > 2048))) {
                     s.ept = ept;
                     s.threads = (int)(E / ept);
                     break;
                 }
         }
+        if ((long long)n > lds_elems<T>() && !s.ept) return fail(__FILE__, __LINE__, "fft: internal error, row does not fit LDS");
         steps.push_back(s);
         res = s.dst;
         return 0;
@@ -576,7 +577,9 @@ struct plan_t {
             return 0;
         }
         // one pass when a useful tile of lines fits LDS: any contiguous row that fits; strided lines need >= 4 per tile
-        const size_t cap = s == 1 ? (size_t)lds_elems<T>() : (size_t)lds_elems<T>() / 4;
+        size_t cap = s == 1 ? (size_t)lds_elems<T>() : (size_t)lds_elems<T>() / 4;
+        // a contiguous power-of-two row of twice that length still fits the single-buffer organisation (64 KiB of LDS)
+        if (s == 1 && (w & (w - 1)) == 0 && !getenv("VEXHIP_FFT_NO_SINGLE")) cap = 2 * (size_t)lds_elems<T>();
         if (w <= cap) {
             line_map m{};
             m.in_es = m.out_es = S;
@@ -721,6 +724,7 @@ struct plan_t {
                     auto kernel = fused ? (pow2 ? &fft_lines_kernel<T, false, true, 0> : &fft_lines_kernel<T, true, true, 0>)
                                 : s.ept == 8 ? &fft_lines_kernel<T, false, false, 8>
                                 : s.ept == 16 ? &fft_lines_kernel<T, false, false, 16>
+                                : s.ept == 32 ? &fft_lines_kernel<T, false, false, (sizeof(T) == 4 ? 32 : 16)>
                                 : (pow2 ? &fft_lines_kernel<T, false, false, 0> : &fft_lines_kernel<T, true, false, 0>);
                     if (lds > 48 * 1024)          // per device, and cheap: raise the dynamic LDS limit for the padded tiles
                         VEXHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
