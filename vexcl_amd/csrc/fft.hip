@@ -205,10 +205,16 @@ template <typename T, int R, int EPT>
 __device__ __forceinline__ void stage_inplace(cx<T> *__restrict__ buf, const cx<T> *__restrict__ tw, int n, int pitch, int p,
         int nlines, bool inverse, const cx<T> *__restrict__ gin, const long long *in_off, cx<T> *__restrict__ gout, const long long *out_off)
 {
-    constexpr int K = EPT / R;                   // butterflies per lane (EPT elements per lane: 8, or 16 for fp32 tiles of 4096)
+    constexpr int K = (EPT + R - 1) / R;         // butterflies per lane: blockDim >= tile elements / EPT covers every stage
     const int nb = n / R, tstride = n / (p * R);
     const divisor dnb = divisor::make(nb), dp = divisor::make(p);
     const int total = nlines * nb;
+    constexpr bool needs_roots = R != 2 && R != 4 && R != 8;
+    cx<T> root[needs_roots ? R : 1];
+    if constexpr (needs_roots) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) { root[t] = tw[(size_t)t * nb]; if (inverse) root[t].y = -root[t].y; }
+    }
     cx<T> v[K][R];
     int line[K], j[K];
 #pragma unroll
@@ -234,7 +240,7 @@ __device__ __forceinline__ void stage_inplace(cx<T> *__restrict__ buf, const cx<
 #pragma unroll
                 for (int q = 1; q < R; ++q) { v[t][q] = v[t][q] * w; if (q + 1 < R) w = w * w1; }
             }
-            dft<T, R>::run(v[t], nullptr, inverse);
+            dft<T, R>::run(v[t], root, inverse);
             const int o = (j[t] - k) * R + k;
             cx<T> *out = gout ? gout + out_off[line[t]] + o : buf + line[t] * pitch + o;
 #pragma unroll
@@ -308,7 +314,18 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
         const int R = st.radix[s];
         const cx<T> *gi = (s == 0 && direct_in) ? in : nullptr;
         cx<T> *go = (s + 1 == st.count && direct_out) ? out : nullptr;
-        if constexpr (SINGLE) {
+        if constexpr (SINGLE && ODD) {
+            switch (R) {
+                case 2:  stage_inplace<T, 2, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 3:  stage_inplace<T, 3, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 4:  stage_inplace<T, 4, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 5:  stage_inplace<T, 5, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 7:  stage_inplace<T, 7, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 8:  stage_inplace<T, 8, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 11: stage_inplace<T, 11, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                default: stage_inplace<T, 13, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+            }
+        } else if constexpr (SINGLE) {
             switch (R) {
                 case 2:  stage_inplace<T, 2, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
                 case 4:  stage_inplace<T, 4, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
@@ -541,16 +558,15 @@ struct plan_t {
         long long want = L * ((long long)n / min_radix);
         if (const char *e = getenv("VEXHIP_FFT_LANES_DIV")) want /= std::max(1, atoi(e));
         s.threads = (int)std::min<long long>(FB, std::max<long long>(kWave, (want + kWave - 1) / kWave * kWave));
-        // power-of-two lengths: one lane per eight elements of the tile, stages in place in one LDS buffer
+        // register-resident stages in place in one LDS buffer: one lane per 8 (16, 32) elements of the tile
         const long long E = L * (long long)n;
         const bool pow2 = (n & (n - 1)) == 0, plain = !map.pre && !map.pre_n && !map.post && !map.post_n;
-        if (pow2 && plain && !getenv("VEXHIP_FFT_NO_SINGLE")) {
-            for (int ept : {8, 16, 32})
-                if (n >= (size_t)ept && E % (ept * kWave) == 0 && E / ept <= FB && (ept == 8 || sizeof(T) == 4 || (ept == 16 && E > 2048))) {
-                    s.ept = ept;
-                    s.threads = (int)(E / ept);
-                    break;
-                }
+        if (plain && !getenv("VEXHIP_FFT_NO_SINGLE")) {
+            for (int ept : {8, 16, 32}) {
+                const long long lanes = ((E + ept - 1) / ept + kWave - 1) / kWave * kWave;
+                const bool allowed = ept == 8 || (ept == 16 && (sizeof(T) == 4 || (pow2 && E > 2048))) || (ept == 32 && sizeof(T) == 4 && pow2);
+                if (allowed && lanes <= FB) { s.ept = ept; s.threads = (int)lanes; break; }
+            }
         }
         if ((long long)n > lds_elems<T>() && !s.ept) return fail(__FILE__, __LINE__, "fft: internal error, row does not fit LDS");
         steps.push_back(s);
@@ -722,8 +738,8 @@ struct plan_t {
                     const bool pow2 = (s.n & (s.n - 1)) == 0;
                     const bool fused = s.map.pre || s.map.pre_n || s.map.post || s.map.post_n;
                     auto kernel = fused ? (pow2 ? &fft_lines_kernel<T, false, true, 0> : &fft_lines_kernel<T, true, true, 0>)
-                                : s.ept == 8 ? &fft_lines_kernel<T, false, false, 8>
-                                : s.ept == 16 ? &fft_lines_kernel<T, false, false, 16>
+                                : s.ept == 8 ? (pow2 ? &fft_lines_kernel<T, false, false, 8> : &fft_lines_kernel<T, true, false, 8>)
+                                : s.ept == 16 ? (pow2 ? &fft_lines_kernel<T, false, false, 16> : &fft_lines_kernel<T, true, false, 16>)
                                 : s.ept == 32 ? &fft_lines_kernel<T, false, false, (sizeof(T) == 4 ? 32 : 16)>
                                 : (pow2 ? &fft_lines_kernel<T, false, false, 0> : &fft_lines_kernel<T, true, false, 0>);
                     if (lds > 48 * 1024)          // per device, and cheap: raise the dynamic LDS limit for the padded tiles
