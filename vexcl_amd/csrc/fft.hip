@@ -646,7 +646,10 @@ struct plan_t {
     /// X[k] = c[k] * sum_j (x[j] c[j]) conj(c)[k - j], c[t] = exp(-+ pi i t^2 / n)
     int emit_bluestein(size_t n, long long rows, bool inverse, int cur, int a, int b, int &res) {
         if (n >= (size_t(1) << 31)) return fail(__FILE__, __LINE__, "fft: length too large for the chirp-z path");
-        const size_t m = best_size(2 * n - 1);
+        // convolution length: the radix-8 stages of a power of two are much cheaper per element than stages of 3s and 5s
+        size_t m = best_size(2 * n - 1), m2 = 1;
+        while (m2 < 2 * n - 1) m2 *= 2;
+        if (m2 <= m + m / 2) m = m2;
         std::vector<cx<T>> chirp(n), bseq(m, cx<T>{T(0), T(0)});
         const long double pi = 3.141592653589793238462643383279502884L;
         for (size_t t = 0; t < n; ++t) {
