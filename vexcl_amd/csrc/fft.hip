@@ -201,9 +201,10 @@ __device__ __forceinline__ void stage(const cx<T> *__restrict__ src, cx<T> *__re
 /// 16) elements of its tile, so a lane owns EPT / R butterflies of every stage and keeps its elements in registers;
 /// all of them are read before the workgroup's barrier and written after it, which lets the stage work IN PLACE in a
 /// single LDS buffer (half the LDS of the two-buffer scheme: twice the workgroups per CU).
-template <typename T, int R, int EPT>
+template <typename T, int R, int EPT, bool FUSED>
 __device__ __forceinline__ void stage_inplace(cx<T> *__restrict__ buf, const cx<T> *__restrict__ tw, int n, int pitch, int p,
-        int nlines, bool inverse, const cx<T> *__restrict__ gin, const long long *in_off, cx<T> *__restrict__ gout, const long long *out_off)
+        int nlines, bool inverse, const cx<T> *__restrict__ gin, const long long *in_off, cx<T> *__restrict__ gout, const long long *out_off,
+        const io_ops<T> &io)
 {
     constexpr int K = (EPT + R - 1) / R;         // butterflies per lane: blockDim >= tile elements / EPT covers every stage
     const int nb = n / R, tstride = n / (p * R);
@@ -222,9 +223,20 @@ __device__ __forceinline__ void stage_inplace(cx<T> *__restrict__ buf, const cx<
         const int b = threadIdx.x + t * (int)blockDim.x;
         line[t] = dnb.div(b); j[t] = b - line[t] * nb;
         if (b < total) {
-            const cx<T> *in = gin ? gin + in_off[line[t]] + j[t] : buf + line[t] * pitch + j[t];
+            if (FUSED && gin) {                  // clamped, unconditional loads; the cut at pre_n is a select
+                const cx<T> *line0 = gin + in_off[line[t]];
+                const int last = (io.pre_n ? io.pre_n : n) - 1;
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[t][q] = in[q * nb];
+                for (int q = 0; q < R; ++q) {
+                    const int i = min(j[t] + q * nb, last);
+                    const cx<T> x = io.pre ? line0[i] * io.pre[i] : line0[i];
+                    v[t][q] = (j[t] + q * nb <= last) ? x : cx<T>{T(0), T(0)};
+                }
+            } else {
+                const cx<T> *in = gin ? gin + in_off[line[t]] + j[t] : buf + line[t] * pitch + j[t];
+#pragma unroll
+                for (int q = 0; q < R; ++q) v[t][q] = in[q * nb];
+            }
         }
     }
     if (!gin) __syncthreads();                   // every lane has its inputs: the buffer may be overwritten
@@ -243,8 +255,19 @@ __device__ __forceinline__ void stage_inplace(cx<T> *__restrict__ buf, const cx<
             dft<T, R>::run(v[t], root, inverse);
             const int o = (j[t] - k) * R + k;
             cx<T> *out = gout ? gout + out_off[line[t]] + o : buf + line[t] * pitch + o;
+            if (FUSED && gout) {
 #pragma unroll
-            for (int s = 0; s < R; ++s) out[s * p] = v[t][s];
+                for (int s = 0; s < R; ++s) {
+                    const int i = o + s * p;
+                    if (io.post_n == 0 || i < io.post_n) {
+                        const cx<T> x = io.post ? v[t][s] * io.post[i] : v[t][s];
+                        out[s * p] = {x.x * io.scale, x.y * io.scale};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < R; ++s) out[s * p] = v[t][s];
+            }
         }
     }
 }
@@ -316,20 +339,20 @@ void fft_lines_kernel(const cx<T> *__restrict__ in, cx<T> *__restrict__ out, con
         cx<T> *go = (s + 1 == st.count && direct_out) ? out : nullptr;
         if constexpr (SINGLE && ODD) {
             switch (R) {
-                case 2:  stage_inplace<T, 2, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 3:  stage_inplace<T, 3, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 4:  stage_inplace<T, 4, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 5:  stage_inplace<T, 5, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 7:  stage_inplace<T, 7, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 8:  stage_inplace<T, 8, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 11: stage_inplace<T, 11, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                default: stage_inplace<T, 13, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 2:  stage_inplace<T, 2, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 3:  stage_inplace<T, 3, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 4:  stage_inplace<T, 4, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 5:  stage_inplace<T, 5, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 7:  stage_inplace<T, 7, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 8:  stage_inplace<T, 8, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 11: stage_inplace<T, 11, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                default: stage_inplace<T, 13, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
             }
         } else if constexpr (SINGLE) {
             switch (R) {
-                case 2:  stage_inplace<T, 2, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                case 4:  stage_inplace<T, 4, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
-                default: stage_inplace<T, 8, EPT>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off); break;
+                case 2:  stage_inplace<T, 2, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                case 4:  stage_inplace<T, 4, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
+                default: stage_inplace<T, 8, EPT, FUSED>(A, tw, n, pitch, p, nl, inverse, gi, in_off, go, out_off, io); break;
             }
         } else if constexpr (ODD) {
             switch (R) {
@@ -561,10 +584,10 @@ struct plan_t {
         // register-resident stages in place in one LDS buffer: one lane per 8 (16, 32) elements of the tile
         const long long E = L * (long long)n;
         const bool pow2 = (n & (n - 1)) == 0, plain = !map.pre && !map.pre_n && !map.post && !map.post_n;
-        if (plain && !getenv("VEXHIP_FFT_NO_SINGLE")) {
+        if ((plain || pow2) && !getenv("VEXHIP_FFT_NO_SINGLE")) {
             for (int ept : {8, 16, 32}) {
                 const long long lanes = ((E + ept - 1) / ept + kWave - 1) / kWave * kWave;
-                const bool allowed = ept == 8 || (ept == 16 && (sizeof(T) == 4 || (pow2 && E > 2048))) || (ept == 32 && sizeof(T) == 4 && pow2);
+                const bool allowed = ept == 8 || (ept == 16 && (sizeof(T) == 4 || (pow2 && E > 2048))) || (ept == 32 && sizeof(T) == 4 && pow2 && plain);
                 if (allowed && lanes <= FB) { s.ept = ept; s.threads = (int)lanes; break; }
             }
         }
@@ -740,7 +763,9 @@ struct plan_t {
                     const size_t lds = (s.ept ? 1 : 2) * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
                     const bool pow2 = (s.n & (s.n - 1)) == 0;
                     const bool fused = s.map.pre || s.map.pre_n || s.map.post || s.map.post_n;
-                    auto kernel = fused ? (pow2 ? &fft_lines_kernel<T, false, true, 0> : &fft_lines_kernel<T, true, true, 0>)
+                    auto kernel = fused ? (pow2 ? (s.ept == 8 ? &fft_lines_kernel<T, false, true, 8> : s.ept == 16 ? &fft_lines_kernel<T, false, true, 16>
+                                                                     : &fft_lines_kernel<T, false, true, 0>)
+                                                : &fft_lines_kernel<T, true, true, 0>)
                                 : s.ept == 8 ? (pow2 ? &fft_lines_kernel<T, false, false, 8> : &fft_lines_kernel<T, true, false, 8>)
                                 : s.ept == 16 ? (pow2 ? &fft_lines_kernel<T, false, false, 16> : &fft_lines_kernel<T, true, false, 16>)
                                 : s.ept == 32 ? &fft_lines_kernel<T, false, false, (sizeof(T) == 4 ? 32 : 16)>
