@@ -140,6 +140,23 @@ def secondary_rows(torch, L, ops, dev, local_rank):
         t = e0.elapsed_time(e1)
         best = t if best is None else min(best, t)
     rows["sort u32 keys n=1e9 (stable LSD radix)"] = {"ms": round(best, 3), "gkeys_per_s": round(n / best / 1e6, 1)}
+    del k, ktmp, tmp
+    torch.cuda.empty_cache()
+
+    # vex::FFT (outside BASELINE.json's configs): complex fp64, algorithmic bytes = one read + one write
+    for label, sizes, dirs in (("fft c2c f64, 65536 rows x 1024", [65536, 1024], [ops.NONE, ops.FORWARD]),
+                               ("fft c2c f64, 2^24 points", [1 << 24], [ops.FORWARD]),
+                               ("fft c2c f64, 4096 x 4096", [4096, 4096], [ops.FORWARD, ops.FORWARD])):
+        total = 1
+        for s in sizes:
+            total *= s
+        z = torch.view_as_complex(ops.fill_hash(torch.empty(2 * total, dtype=torch.float64, device=dev), 7).view(total, 2))
+        w = torch.empty_like(z)
+        f = ops.FFT(sizes, dirs)
+        ms = timed(lambda: f(z, out=w, scaled=False), 10)
+        rows[label] = {"ms": round(ms, 4), "gbps": round(32.0 * total / ms / 1e6, 1), "passes": f.steps()[0]}
+        del f, z, w
+        torch.cuda.empty_cache()
     return rows
 
 
