@@ -41,9 +41,9 @@ build_one() {
         rm -f "$out/$name"; echo "FAILED  $name ($(grep -c 'error' "$out/$name.build.log") error lines, see oracle/_ref/$name.build.log)"
     fi
 }
-# The reference's example programs that need nothing but vex:: (no Boost.program_options / odeint / cuFFT /
-# ViennaCL): built the same way as example_<name>; the pytest module checks that they run to completion.
-EXAMPLES="devlist complex_simple complex_spmv mba_benchmark fft_profile exclusive simple/hello"
+# The reference's example programs that need nothing but vex:: and the small stand-ins of oracle/ref_shim (Boost.Test,
+# program_options, ios_state, two Phoenix placeholders; not odeint / cuFFT / ViennaCL): built the same way as example_<name>; the pytest module checks that they run to completion.
+EXAMPLES="benchmark fft_benchmark devlist complex_simple complex_spmv mba_benchmark fft_profile exclusive simple/hello"
 build_example() {
     src="$1"; name="example_$(basename "$1")"
     if g++ -std=c++17 -O1 -w -DVEXCL_BACKEND_CUDA -I "$here/ref_shim" -I "$repo" "$ref/examples/$src.cpp" -o "$out/$name" \

@@ -32,7 +32,9 @@ NAMES = _names()
 def test_reference_program(name):
     exe = os.path.join(REF, name)
     env = dict(os.environ)
-    args = {"example_mba_benchmark": ["65536"]}.get(name, [])
+    args = {"example_mba_benchmark": ["65536"],
+            "example_benchmark": ["--bm_cpu", "0"],                     # BASELINE.json configs[0]; the host-CPU comparison loops are skipped
+            "example_fft_benchmark": ["--runs", "20", "--max", "65536", "-p", "-c"]}.get(name, [])
     r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT, stdin=subprocess.DEVNULL)
     tail = (r.stdout[-3000:] + "\n" + r.stderr[-3000:])
     assert r.returncode == 0, f"reference program {name} failed:\n{tail}"
