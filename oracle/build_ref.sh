@@ -42,8 +42,8 @@ build_one() {
     fi
 }
 # The reference's example programs that need nothing but vex:: and the small stand-ins of oracle/ref_shim (Boost.Test,
-# program_options, ios_state, two Phoenix placeholders; not odeint / cuFFT / ViennaCL): built the same way as example_<name>; the pytest module checks that they run to completion.
-EXAMPLES="benchmark fft_benchmark devlist complex_simple complex_spmv mba_benchmark fft_profile exclusive simple/hello"
+# program_options, ios_state, two Phoenix placeholders, odeint's Runge-Kutta stepper; not cuFFT / ViennaCL): built the same way as example_<name>; the pytest module checks that they run to completion.
+EXAMPLES="benchmark fft_benchmark symbolic devlist complex_simple complex_spmv mba_benchmark fft_profile exclusive simple/hello"
 build_example() {
     src="$1"; name="example_$(basename "$1")"
     if g++ -std=c++17 -O1 -w -DVEXCL_BACKEND_CUDA -I "$here/ref_shim" -I "$repo" "$ref/examples/$src.cpp" -o "$out/$name" \
