@@ -21,14 +21,12 @@ out="$here/_ref"
 jobs=8
 if [ "${1:-}" = "-j" ]; then jobs="$2"; shift 2; fi
 
-# Tests of the hot path and of the rows SURVEY.md §8 lists (vector / expression / reductor / SpMV /
-# scan / sort / stencil / views / multivectors / by-key / random).  Out of scope:
-# fft, image, svm, mba, generator, tensordot, multi_array, custom_kernel, cusparse, boost_compute_*, clogs_*, and
-# deduce (its source includes mba.hpp).
+# Every test source of the reference except image (OpenCL images / CUDA texture objects through the vendor API),
+# cusparse, boost_compute_*, clogs_* (adapters to other libraries) and boost_version (prints Boost's version).
 TESTS="${*:-vector_create vector_copy vector_arithmetics vector_view vector_pointer vector_io \
 tagged_terminal temporary cast constants logical reinterpret types eval events \
 multivector_create multivector_arithmetics spmv sparse_matrices stencil random sort scan \
-scan_by_key reduce_by_key context threads custom_kernel tensordot multi_array mba deduce svm generator}"
+scan_by_key reduce_by_key context threads custom_kernel tensordot multi_array mba deduce svm generator fft}"
 
 if [ ! -d "$ref/tests" ]; then echo "build_ref: $ref/tests not present, nothing to do"; exit 0; fi
 mkdir -p "$out"

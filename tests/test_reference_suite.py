@@ -40,3 +40,13 @@ def test_reference_program(name):
     assert r.returncode == 0, f"reference program {name} failed:\n{tail}"
     if not name.startswith("example_"):          # the reference's examples/*.cpp print results, not a test summary
         assert "0 failures" in r.stdout, tail
+
+
+def test_every_listed_reference_program_built():
+    """CPU: where oracle/build_ref.sh has run (oracle/_ref exists), none of the programs it lists failed to compile
+    against vexcl/ -- a failed build leaves <name>.build.log behind and drops the program from the GPU run."""
+    if not os.path.isdir(REF):
+        pytest.skip("oracle/_ref absent (oracle/build_ref.sh was not run)")
+    failed = sorted(f for f in os.listdir(REF) if f.endswith(".build.log"))
+    assert not failed, "reference programs that no longer compile: %s" % failed
+    assert len(NAMES) >= 49, "expected 36 test programs, 3 of them a second time with VEXCL_CHECK_SIZES, and 10 examples; found %d" % len(NAMES)
