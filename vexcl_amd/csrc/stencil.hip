@@ -51,9 +51,24 @@ void stencil_conv_kernel(long long n, int has_left, int has_right, int lhalo, in
         T *X = S + width;
         for (int j = threadIdx.x; j < width; j += CB) S[j] = s[j];
         const int span = CTILE + lhalo + rhalo;
-        for (int j = threadIdx.x; j < span + CI; j += CB) {       // + CI: the window reads a few elements past the last tap
-            long long g = g0 - lhalo + j;
-            X[skew(j)] = (j < span && g < n + rhalo) ? read_x<T>(g, n, has_left, has_right, lhalo, xloc, xrem) : T(0);
+        typedef T v2 __attribute__((ext_vector_type(2)));
+        const long long first = g0 - lhalo;                       // global index of X[0]
+        const long long a = first & ~1ll;                          // ... rounded down to an aligned pair
+        if (first >= 1 && a + 2 * (long long)((span + CI + 2) / 2) <= n && (reinterpret_cast<unsigned long long>(xloc) & (2 * sizeof(T) - 1)) == 0) {
+            // interior tile: everything it reads is in the local segment -- aligned 16-byte loads, two elements per lane
+            const int off = (int)(first - a);
+            const v2 *xp = reinterpret_cast<const v2 *>(xloc + a);
+            for (int p = threadIdx.x; 2 * p < span + CI + off; p += CB) {
+                const v2 xx = xp[p];
+                const int j = 2 * p - off;
+                if (j >= 0) X[skew(j)] = xx.x;
+                if (j + 1 < span + CI) X[skew(j + 1)] = xx.y;
+            }
+        } else {
+            for (int j = threadIdx.x; j < span + CI; j += CB) {       // + CI: the window reads a few elements past the last tap
+                long long g = g0 - lhalo + j;
+                X[skew(j)] = (j < span && g < n + rhalo) ? read_x<T>(g, n, has_left, has_right, lhalo, xloc, xrem) : T(0);
+            }
         }
         __syncthreads();
         const int o = CI * threadIdx.x;                    // this lane's first output within the tile
