@@ -280,3 +280,14 @@ TEST_CASE(constant_vectors_and_pointers) {                            // vector_
     h = download(y);
     for (size_t i = 0; i < N; ++i) CHECK_EQUAL(h[i], table[i % 4]);
 }
+
+TEST_CASE(device_filters_of_the_other_backends) {                     // backend/opencl/filter.hpp, backend/cuda/filter.hpp
+    const auto dev = ctx.queue(0).device();
+    CHECK(vex::Filter::CC(9, 0)(dev));                                // gfx9xx
+    CHECK(!vex::Filter::CC(99, 0)(dev));
+    CHECK(vex::Filter::Extension("cl_khr_fp64")(dev));
+    CHECK(!vex::Filter::GLSharing(dev));
+    CHECK(vex::Filter::CLVersion(2, 0)(dev));
+    vex::Context one(vex::Filter::CC(9, 0) && vex::Filter::CLVersion(1, 2) && vex::Filter::Count(1));
+    CHECK_EQUAL(one.size(), 1u);
+}

@@ -1,6 +1,7 @@
 #ifndef VEXCL_DEVLIST_HPP
 #define VEXCL_DEVLIST_HPP
 // vex::Filter::* and vex::Context (reference: vexcl/devlist.hpp:53-391).
+#include <cctype>
 #include <cstdlib>
 #include <iostream>
 #include <functional>
@@ -57,6 +58,23 @@ struct CLVersion {
     int major_, minor_;
 };
 
+/// Compute capability at least major.minor (backend/cuda/filter.hpp:71-83).  For an AMD GPU the corresponding
+/// number is the ISA version: gfx950 is 9.5, gfx942 is 9.4, gfx1100 is 11.0.
+struct CC {
+    CC(int major, int minor) : major_(major), minor_(minor) {}
+    bool operator()(const backend::device &d) const {
+        const std::string a = d.arch();                       // "gfx950:sramecc+:xnack-"
+        size_t b = a.find("gfx"), e = b == std::string::npos ? 0 : b + 3;
+        while (e < a.size() && std::isalnum((unsigned char)a[e])) ++e;
+        if (b == std::string::npos || e - (b + 3) < 3) return false;
+        const std::string v = a.substr(b + 3, e - (b + 3));
+        const int major = std::atoi(v.substr(0, v.size() - 2).c_str());
+        const int minor = std::isdigit((unsigned char)v[v.size() - 2]) ? v[v.size() - 2] - '0' : 10 + (std::tolower(v[v.size() - 2]) - 'a');
+        return major > major_ || (major == major_ && minor >= minor_);
+    }
+    int major_, minor_;
+};
+
 /// Device name contains the given string (devlist.hpp Filter::Name).
 struct Name {
     explicit Name(std::string name) : devname(std::move(name)) {}
@@ -105,6 +123,7 @@ template <> struct is_filter<GPUFilter> : std::true_type {};
 template <> struct is_filter<CPUFilter> : std::true_type {};
 template <> struct is_filter<Name> : std::true_type {};
 template <> struct is_filter<Extension> : std::true_type {};
+template <> struct is_filter<CC> : std::true_type {};
 template <> struct is_filter<CLVersion> : std::true_type {};
 template <> struct is_filter<Vendor> : std::true_type {};
 template <> struct is_filter<Platform> : std::true_type {};
