@@ -760,7 +760,8 @@ struct plan_t {
             switch (s.kind) {
                 case step::LINES: {
                     const long long grid = (s.lines + s.lines_per_wg - 1) / s.lines_per_wg;
-                    const size_t lds = (s.ept ? 1 : 2) * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
+                    size_t lds = (s.ept ? 1 : 2) * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
+                    if (const char *e = getenv("VEXHIP_FFT_EXTRA_LDS")) lds += (size_t)atoi(e);       // occupancy experiments
                     const bool pow2 = (s.n & (s.n - 1)) == 0;
                     const bool fused = s.map.pre || s.map.pre_n || s.map.post || s.map.post_n;
                     auto kernel = fused ? (pow2 ? (s.ept == 8 ? &fft_lines_kernel<T, false, true, 8> : s.ept == 16 ? &fft_lines_kernel<T, false, true, 16>
