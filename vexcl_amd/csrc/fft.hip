@@ -566,6 +566,11 @@ struct plan_t {
         // (the tile's width IS the contiguous run of the global accesses)
         long long L = std::min<long long>(MAX_LINES, std::max<long long>(1, lds_elems<T>() / (long long)n));
         while (L > 1 && L * ((long long)n + 1) > lds_elems<T>() + MAX_LINES) --L;
+        if (!(map.in_es == 1 && map.out_es == 1)) {                    // strided passes: tiles of 2048 elements measured best for
+            long long cap = 2048;                                      // both types (tools/fft_strided_experiment.py)
+            if (const char *e = getenv("VEXHIP_FFT_STRIDED_ELEMS")) cap = std::max(1, atoi(e));
+            if (cap >= (long long)n) L = std::max<long long>(1, std::min<long long>(L, cap / (long long)n));
+        }
         long long row_elems = lds_elems<T>() / 2;                     // contiguous lines: <= 16 KiB per buffer
         if (const char *e = getenv("VEXHIP_FFT_ROW_ELEMS")) row_elems = std::max(1, atoi(e));      // tuning knob (tools/fft_bench.py)
         if (map.in_es == 1 && map.out_es == 1) {
