@@ -33,7 +33,7 @@ def _rel(a, b):
 # lengths: trivial, every radix, mixed radix, one LDS row (2048), four-step (4096 ... 2^20), 11 * 1365 (four-step with
 # an odd split), primes and composites with a large prime factor (Bluestein), Bluestein over a four-step convolution
 LENGTHS = [1, 2, 3, 4, 5, 7, 8, 11, 13, 16, 64, 100, 243, 1000, 1024, 2048, 2187, 4096, 5000, 15015, 1 << 16, 1 << 20,
-           17, 1009, 2018, 4099, 65537]
+           17, 1009, 2018, 2039, 4099, 65537]
 
 
 @pytest.mark.parametrize("n", LENGTHS)
@@ -49,7 +49,7 @@ def test_fft_1d_fp64(T, oracle, n):
     assert _rel(yi, oracle.fft_nd(x, [n], [oracle.FFT_INVERSE])) < 1e-12
 
 
-@pytest.mark.parametrize("n", [1, 8, 100, 1024, 4096, 8192, 15015, 1009, 1 << 18])
+@pytest.mark.parametrize("n", [1, 8, 100, 1024, 4096, 8192, 15015, 1009, 2039, 4093, 1 << 18])
 def test_fft_1d_fp32(T, oracle, n):
     x = _rand(n + 1, n).astype(np.complex64)
     f = T.ops.FFT([n], T.ops.FORWARD, dtype=T.torch.complex64)

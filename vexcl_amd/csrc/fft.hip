@@ -592,7 +592,7 @@ struct plan_t {
         if ((plain || pow2) && !getenv("VEXHIP_FFT_NO_SINGLE")) {
             for (int ept : {8, 16, 32}) {
                 const long long lanes = ((E + ept - 1) / ept + kWave - 1) / kWave * kWave;
-                const bool allowed = ept == 8 || (ept == 16 && (sizeof(T) == 4 || (pow2 && E > 2048))) || (ept == 32 && sizeof(T) == 4 && pow2 && plain);
+                const bool allowed = ept == 8 || (ept == 16 && (sizeof(T) == 4 || (pow2 && E > 2048))) || (ept == 32 && sizeof(T) == 4 && pow2);
                 if (allowed && lanes <= FB) { s.ept = ept; s.threads = (int)lanes; break; }
             }
         }
@@ -693,7 +693,8 @@ struct plan_t {
         if (int rc = upload(chirp, chirp_id)) return rc;
         if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), ba)) return rc;
         bb = ba;
-        if (m > (size_t)lds_elems<T>())            // multi-pass convolution transforms alternate between two buffers
+        const bool fused = m <= (size_t)lds_elems<T>() || (m <= 2 * (size_t)lds_elems<T>() && (m & (m - 1)) == 0 && !getenv("VEXHIP_FFT_NO_SINGLE"));
+        if (!fused)                                // multi-pass convolution transforms alternate between two buffers
             if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), bb)) return rc;
         {   // bhat = FFT_m(b), computed once with a plan of its own
             plan_t<T> sub; sub.dev = dev; sub.total = m;
@@ -707,7 +708,7 @@ struct plan_t {
             if (r == B_WORK) VEXHIP_TRY(hipMemcpyAsync(dst, sub.owned[w1 - B_FIRST_OWNED], m * sizeof(cx<T>), hipMemcpyDeviceToDevice, nullptr));
             VEXHIP_TRY(hipDeviceSynchronize());
         }
-        if (m <= (size_t)lds_elems<T>()) {
+        if (m <= (size_t)lds_elems<T>() || (m <= 2 * (size_t)lds_elems<T>() && (m & (m - 1)) == 0 && !getenv("VEXHIP_FFT_NO_SINGLE"))) {
             // two row passes carry all the pointwise work: chirp + zero padding on the way in and the product with
             // FFT(b) on the way out of the forward transform; chirp, 1/m and the cut to n on the way out of the inverse
             const int final_dst = writable(cur) ? cur : a;
@@ -770,6 +771,7 @@ struct plan_t {
                     const bool pow2 = (s.n & (s.n - 1)) == 0;
                     const bool fused = s.map.pre || s.map.pre_n || s.map.post || s.map.post_n;
                     auto kernel = fused ? (pow2 ? (s.ept == 8 ? &fft_lines_kernel<T, false, true, 8> : s.ept == 16 ? &fft_lines_kernel<T, false, true, 16>
+                                                                     : s.ept == 32 ? &fft_lines_kernel<T, false, true, (sizeof(T) == 4 ? 32 : 16)>
                                                                      : &fft_lines_kernel<T, false, true, 0>)
                                                 : &fft_lines_kernel<T, true, true, 0>)
                                 : s.ept == 8 ? (pow2 ? &fft_lines_kernel<T, false, false, 8> : &fft_lines_kernel<T, true, false, 8>)
