@@ -831,25 +831,24 @@ int make_plan(int dev, const std::vector<size_t> &sizes, const std::vector<int> 
     p->dev = dev;
     p->total = 1;
     for (size_t s : sizes) p->total *= s;
-    if (int rc = p->alloc(p->total * sizeof(cx<T>), work_id)) return rc;
     int res;
     // out-of-place passes alternate between two buffers; which of them receives the first write decides where
     // the result ends: build with (OUT, WORK) and, if the result lands in WORK, again with the roles swapped
-    if (int rc = p->build(sizes, dirs, B_OUT, work_id, res)) return rc;
-    if (res == work_id) {
+    if (int rc = p->build(sizes, dirs, B_OUT, B_WORK, res)) return rc;
+    if (res == B_WORK) {
         std::unique_ptr<plan_t<T>> q(new plan_t<T>);
         q->dev = dev; q->total = p->total;
-        int w2;
         p.reset();                                  // release the first attempt's buffers before building the second
-        if (int rc = q->alloc(q->total * sizeof(cx<T>), w2)) return rc;
-        if (int rc = q->build(sizes, dirs, w2, B_OUT, res)) return rc;
+        if (int rc = q->build(sizes, dirs, B_WORK, B_OUT, res)) return rc;
         p = std::move(q);
-        work_id = w2;
     }
     if (res != B_OUT) {                             // no pass at all (res == B_IN), or a parity the swap did not fix
         step c; c.kind = step::COPY; c.src = res; c.dst = B_OUT; c.elems = (long long)p->total;
         p->steps.push_back(c);
     }
+    // the work buffer exists only if some step touches it (a single in-place row pass needs none)
+    work_id = -1;
+    for (const step &s : p->steps) if (s.src == B_WORK || s.dst == B_WORK) { if (int rc = p->alloc(p->total * sizeof(cx<T>), work_id)) return rc; break; }
     out = std::move(p);
     return 0;
 }
@@ -903,10 +902,10 @@ int vexhip_fft_exec(void *plan, void *stream, const void *in, void *out) {
     any_plan *p = static_cast<any_plan *>(plan);
     if (p->f) {
         VEXHIP_SET_DEVICE(p->f->dev);
-        return p->f->run(as_stream(stream), in, out, p->f->owned[p->work_id - B_FIRST_OWNED]);
+        return p->f->run(as_stream(stream), in, out, p->work_id >= 0 ? p->f->owned[p->work_id - B_FIRST_OWNED] : nullptr);
     }
     VEXHIP_SET_DEVICE(p->d->dev);
-    return p->d->run(as_stream(stream), in, out, p->d->owned[p->work_id - B_FIRST_OWNED]);
+    return p->d->run(as_stream(stream), in, out, p->work_id >= 0 ? p->d->owned[p->work_id - B_FIRST_OWNED] : nullptr);
 }
 
 } // extern "C"
