@@ -11,8 +11,8 @@
 //   y += fft(x * x) * 5;                               // the result is an ordinary vector expression
 //
 // The transform itself is the native plan of libvexhip (vexhip_fft_*: LDS row kernel, four-step for long rows,
-// Bluestein for awkward lengths, transposes between dimensions); this header evaluates the operand expression
-// into the plan's complex input buffer with one fused kernel (r2c conversion included), runs the plan on the
+// Bluestein for awkward lengths); this header evaluates the operand expression into the plan's complex input
+// buffer with one fused kernel (r2c conversion included; a complex VECTOR operand is used where it is), runs the plan on the
 // queue, and hands back `scale * c2r(out)` / `scl(out, scale)` as an expression over the output buffer, exactly
 // the reference's shape (plan.hpp:336-357), so the 1/n of inverse transforms and any further arithmetic fuse
 // into the consumer's kernel.  Single-device, as in the reference (plan.hpp:226-229).
@@ -112,7 +112,7 @@ struct plan {
         precondition(!sizes.empty() && sizes.size() == dirs.size(), "FFT: one direction per dimension is required");
         precondition(queues.size() == 1, "FFT is only supported for single-device contexts.");
         const size_t total = std::accumulate(sizes.begin(), sizes.end(), size_t(1), std::multiplies<size_t>());
-        bufs.push_back(vex::vector<T2>(queues, total));
+        bufs.push_back(vex::vector<T2>());                   // input staging: allocated by the first operand that needs it
         bufs.push_back(vex::vector<T2>(queues, total));
         size_t inv_n = 1;
         std::vector<int> d(sizes.size());
@@ -129,10 +129,20 @@ struct plan {
     void transform(const Expr &in) {
         if (profile) { profile->tic_cl(desc()); profile->tic_cl("in"); }
         vector<T2> &in_c = bufs[input];
+        if (in_c.size() != bufs[output].size()) in_c = vex::vector<T2>(queues, bufs[output].size());
         assign_input(in_c, in, std::integral_constant<bool, cl_vector_length<Tv>::value == 1>());
         if (profile) { profile->toc("in"); profile->tic_cl("transform"); }
         if (in_c.size())
             backend::check(vexhip_fft_exec(handle.get(), queues[0].raw(), in_c(0).raw(), bufs[output](0).raw()));
+        if (profile) { profile->toc("transform"); profile->toc(""); }
+    }
+
+    /// A complex VECTOR operand is transformed where it is: no copy into the plan's input buffer.
+    void transform(const vector<T2> &in) {
+        precondition(in.nparts() == 1 && in.size() == bufs[output].size(), "FFT: the operand does not match the plan");
+        if (profile) { profile->tic_cl(desc()); profile->tic_cl("transform"); }
+        if (in.size())
+            backend::check(vexhip_fft_exec(handle.get(), queues[0].raw(), in(0).raw(), bufs[output](0).raw()));
         if (profile) { profile->toc("transform"); profile->toc(""); }
     }
 
