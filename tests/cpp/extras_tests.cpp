@@ -261,6 +261,43 @@ TEST_CASE(fft_against_the_definition_and_round_trips) {              // fft.cpp:
         CHECK_CLOSE(hf[b * H * W].s[0], s, 1e-9); CHECK_SMALL(hf[b * H * W].s[1], 1e-9);
     }
     CHECK_EQUAL(vex::fft::planner().best_size(1025), 1029u);
+
+    // real input, forward along an even last dimension, batch of rows: the half-length path (rows transformed as n/2 complex
+    // numbers, unpacked inside the consumer's kernel) against the definition; vector operand and expression operand
+    const size_t RB = 5, RN = 1000;
+    std::vector<double> rr = random_vector<double>(RB * RN);
+    vex::vector<double> RR(q, rr);
+    vex::vector<cl_double2> RF(q, RB * RN), RG(q, RB * RN);
+    vex::FFT<double, cl_double2> rf(q, {RB, RN}, {vex::fft::none, vex::fft::forward});
+    RF = rf(RR);
+    RG = rf(2 * RR + 1);
+    auto hrf = download(RF), hrg = download(RG);
+    for (size_t b = 0; b < RB; b += 2) for (size_t k = 0; k < RN; k += 37) {
+        std::complex<long double> s1 = 0, s2 = 0;
+        for (size_t j = 0; j < RN; ++j) {
+            const auto w = std::polar<long double>(1.0L, -2.0L * pi * (long double)((j * k) % RN) / RN);
+            s1 += (long double)rr[b * RN + j] * w; s2 += (long double)(2 * rr[b * RN + j] + 1) * w;
+        }
+        CHECK_SMALL(hrf[b * RN + k].s[0] - (double)s1.real(), 1e-10); CHECK_SMALL(hrf[b * RN + k].s[1] - (double)s1.imag(), 1e-10);
+        CHECK_SMALL(hrg[b * RN + k].s[0] - (double)s2.real(), 1e-10); CHECK_SMALL(hrg[b * RN + k].s[1] - (double)s2.imag(), 1e-10);
+    }
+    // real in, real out (the real part of the spectrum), and the odd-length fallback
+    vex::vector<double> RE(q, RB * RN);
+    vex::FFT<double, double> rre(q, {RB, RN}, {vex::fft::none, vex::fft::forward});
+    RE = rre(RR);
+    auto hre = download(RE);
+    for (size_t i = 0; i < RB * RN; i += 41) CHECK_SMALL(hre[i] - hrf[i].s[0], 1e-12);
+    const size_t ON = 999;
+    vex::vector<double> OR_(q, std::vector<double>(rr.begin(), rr.begin() + ON));
+    vex::vector<cl_double2> OF(q, ON);
+    vex::FFT<double, cl_double2> of(q, ON);
+    OF = of(OR_);
+    auto hof = download(OF);
+    for (size_t k = 0; k < ON; k += 53) {
+        std::complex<long double> s1 = 0;
+        for (size_t j = 0; j < ON; ++j) s1 += (long double)rr[j] * std::polar<long double>(1.0L, -2.0L * pi * (long double)((j * k) % ON) / ON);
+        CHECK_SMALL(hof[k].s[0] - (double)s1.real(), 1e-10); CHECK_SMALL(hof[k].s[1] - (double)s1.imag(), 1e-10);
+    }
 }
 
 TEST_CASE(constant_vectors_and_pointers) {                            // vector_arithmetics.cpp:300-316, vector_pointer.cpp:84-120

@@ -25,6 +25,8 @@
 #include "vector.hpp"
 #include "function.hpp"
 #include "profiler.hpp"
+#include "element_index.hpp"
+#include "vector_pointer.hpp"
 
 namespace vex {
 namespace fft {
@@ -95,9 +97,28 @@ struct plan {
     VEX_FUNCTION_S(Ts, c2r, (T2, v), "return v.x;");
     VEX_FUNCTION_S(T2, scl, (T2, v)(Ts, s), "v.x *= s; v.y *= s; return v;");
 
+    /// Value idx of the result for REAL input, read from the plan's output.  mode 0: the output holds the full
+    /// transform, the value is z[idx] * scale.  mode 1 (forward transform of rows of even length n = 2 h): the rows were
+    /// transformed as h complex numbers z = x[2k] + i x[2k+1]; X[k] = E[k] + W_n^k O[k] with E, O recovered from z[k] and
+    /// conj(z[h-k]), and X[n-k] = conj(X[k]) -- half the data through the transform, the unpacking fused into whatever
+    /// kernel consumes the result.
+    VEX_FUNCTION_S(T2, rpost, (size_t, idx)(T2 *, z)(size_t, h)(int, mode)(Ts, scale),
+        type_name<T2>() + " r;\n"
+        "if (mode == 0) { r = z[idx]; r.x *= scale; r.y *= scale; return r; }\n"
+        "const ulong n = 2 * h, row = idx / n, k = idx - row * n;\n"
+        "const bool upper = k > h; const ulong kk = upper ? n - k : k;\n"
+        + type_name<T2>() + " a = z[row * h + (kk == h ? 0 : kk)], b = z[row * h + (kk == 0 || kk == h ? 0 : h - kk)];\n"
+        + type_name<Ts>() + " er = (a.x + b.x) / 2, ei = (a.y - b.y) / 2, pr = (a.x - b.x) / 2, pi = (a.y + b.y) / 2, sn, cs;\n"
+        + std::string(std::is_same<Ts, cl_float>::value ? "sincospif" : "sincospi") + "((" + type_name<Ts>() + ")(-2) * (" + type_name<Ts>() + ")kk / (" + type_name<Ts>() + ")n, &sn, &cs);\n"
+        "r.x = er + cs * pi + sn * pr; r.y = ei - cs * pr + sn * pi;\n"
+        "if (upper) r.y = -r.y;\n"
+        "r.x *= scale; r.y *= scale; return r;");
+
     std::vector<backend::command_queue> queues;
     Planner planner_;
     Ts scale;
+    bool half;                               // real input through a half-length complex transform (see rpost)
+    vex::vector<Ts> rbuf;                    // staging for real EXPRESSION operands of the half-length path
     const std::vector<size_t> sizes;
     std::vector<direction> dirs;
     std::vector<vex::vector<T2>> bufs;       // [0] input of the transform, [1] its output
@@ -112,21 +133,27 @@ struct plan {
         precondition(!sizes.empty() && sizes.size() == dirs.size(), "FFT: one direction per dimension is required");
         precondition(queues.size() == 1, "FFT is only supported for single-device contexts.");
         const size_t total = std::accumulate(sizes.begin(), sizes.end(), size_t(1), std::multiplies<size_t>());
-        bufs.push_back(vex::vector<T2>());                   // input staging: allocated by the first operand that needs it
-        bufs.push_back(vex::vector<T2>(queues, total));
         size_t inv_n = 1;
         std::vector<int> d(sizes.size());
         for (size_t i = 0; i < sizes.size(); ++i) { d[i] = (int)dirs[i]; if (dirs[i] == inverse) inv_n *= sizes[i]; }
         scale = (Ts)1 / inv_n;
+        // real input, forward along the (even) last dimension, every other dimension a batch: half-length transform
+        half = cl_vector_length<Tv>::value == 1 && dirs.back() == forward && sizes.back() >= 2 && sizes.back() % 2 == 0;
+        for (size_t i = 0; i + 1 < sizes.size(); ++i) if (dirs[i] != none) half = false;
+        std::vector<size_t> native = sizes;
+        if (half) native.back() /= 2;
+        bufs.push_back(vex::vector<T2>());                   // input staging: allocated by the first operand that needs it
+        bufs.push_back(vex::vector<T2>(queues, half ? total / 2 : total));
         void *p = nullptr;
         backend::check(vexhip_fft_plan_create(queues[0].device_ordinal(),
-                std::is_same<Ts, cl_float>::value ? VEXHIP_F32 : VEXHIP_F64, (int)sizes.size(), sizes.data(), d.data(), &p));
+                std::is_same<Ts, cl_float>::value ? VEXHIP_F32 : VEXHIP_F64, (int)native.size(), native.data(), d.data(), &p));
         handle.reset(p, [](void *h) { vexhip_fft_plan_destroy(h); });
     }
 
     /// Evaluates `in` into the complex input buffer (real input: zero imaginary part) and runs the transform.
     template <class Expr>
     void transform(const Expr &in) {
+        if (half) { transform_half(in); return; }
         if (profile) { profile->tic_cl(desc()); profile->tic_cl("in"); }
         vector<T2> &in_c = bufs[input];
         if (in_c.size() != bufs[output].size()) in_c = vex::vector<T2>(queues, bufs[output].size());
@@ -137,8 +164,26 @@ struct plan {
         if (profile) { profile->toc("transform"); profile->toc(""); }
     }
 
+    /// Real operand of the half-length path: a real vector IS the packed complex input; an expression is evaluated into
+    /// a real staging buffer first.
+    void transform_half(const vector<Ts> &in) { run_half(in); }
+    template <class Expr> void transform_half(const Expr &in) {
+        const size_t total = 2 * bufs[output].size();
+        if (rbuf.size() != total) rbuf = vex::vector<Ts>(queues, total);
+        rbuf = in;
+        run_half(rbuf);
+    }
+    void run_half(const vector<Ts> &in) {
+        precondition(in.nparts() == 1 && in.size() == 2 * bufs[output].size(), "FFT: the operand does not match the plan");
+        if (profile) { profile->tic_cl(desc()); profile->tic_cl("transform"); }
+        if (in.size())
+            backend::check(vexhip_fft_exec(handle.get(), queues[0].raw(), in(0).raw(), bufs[output](0).raw()));
+        if (profile) { profile->toc("transform"); profile->toc(""); }
+    }
+
     /// A complex VECTOR operand is transformed where it is: no copy into the plan's input buffer.
     void transform(const vector<T2> &in) {
+        precondition(!half, "FFT: a real-input plan was given a complex operand");
         precondition(in.nparts() == 1 && in.size() == bufs[output].size(), "FFT: the operand does not match the plan");
         if (profile) { profile->tic_cl(desc()); profile->tic_cl("transform"); }
         if (in.size())
@@ -146,20 +191,38 @@ struct plan {
         if (profile) { profile->toc("transform"); profile->toc(""); }
     }
 
+    static const bool real_input = cl_vector_length<Tv>::value == 1;
+
     template <typename Tout, class Expr>
-    auto apply(const Expr &expr) -> typename std::enable_if<cl_vector_length<Tout>::value == 1,
+    auto apply(const Expr &expr) -> typename std::enable_if<!real_input && cl_vector_length<Tout>::value == 1,
             decltype(std::declval<Ts>() * c2r(std::declval<vex::vector<T2> &>()))>::type
     {
         transform(expr);
         return scale * c2r(bufs[output]);
     }
     template <typename Tout, class Expr>
-    auto apply(const Expr &expr) -> typename std::enable_if<cl_vector_length<Tout>::value == 2,
+    auto apply(const Expr &expr) -> typename std::enable_if<!real_input && cl_vector_length<Tout>::value == 2,
             decltype(scl(std::declval<vex::vector<T2> &>(), std::declval<Ts>()))>::type
     {
         transform(expr);
         return scl(bufs[output], scale);
     }
+    // real input: the result is read through rpost (which also covers the full-length case, mode 0)
+    template <typename Tout, class Expr>
+    auto apply(const Expr &expr) -> typename std::enable_if<real_input && cl_vector_length<Tout>::value == 2,
+            decltype(rpost(vex::element_index(0, 0), vex::raw_pointer(std::declval<vex::vector<T2> &>()), size_t(), int(), std::declval<Ts>()))>::type
+    {
+        transform(expr);
+        return rpost(vex::element_index(0, result_size()), vex::raw_pointer(bufs[output]), sizes.back() / 2, half ? 1 : 0, scale);
+    }
+    template <typename Tout, class Expr>
+    auto apply(const Expr &expr) -> typename std::enable_if<real_input && cl_vector_length<Tout>::value == 1,
+            decltype(c2r(rpost(vex::element_index(0, 0), vex::raw_pointer(std::declval<vex::vector<T2> &>()), size_t(), int(), std::declval<Ts>())))>::type
+    {
+        transform(expr);
+        return c2r(rpost(vex::element_index(0, result_size()), vex::raw_pointer(bufs[output]), sizes.back() / 2, half ? 1 : 0, scale));
+    }
+    size_t result_size() const { return half ? 2 * bufs[output].size() : bufs[output].size(); }
 
     std::string desc() const {
         std::ostringstream o;

@@ -304,33 +304,53 @@ struct mba_interp : expression_base {
         }
         src.template parameter<global_ptr<const real>>("phi");
         src.end_function_parameters();
-        // per dimension: the cell and the four basis values at the position inside it
+        // per dimension: the cell and the four basis values at the position inside it, in scalars (no indexed arrays:
+        // they would live in scratch memory)
         for (size_t k = 0; k < NDIM; ++k) {
-            src.new_line() << R << " w" << k << "[4]; ulong i" << k << ";";
+            src.new_line() << R << " w" << k << "_0, w" << k << "_1, w" << k << "_2, w" << k << "_3; ulong i" << k << ";";
             src.open("{");
             src.new_line() << "const " << R << " u = (x" << k << " - c" << k << ") * h" << k << ";";
             src.new_line() << "const " << R << " fl = floor(u), t = u - fl;";
             src.new_line() << "i" << k << " = (ulong)(long)(fl - 1);";
-            src.new_line() << "w" << k << "[0] = (t * (t * (-t + 3) - 3) + 1) / 6;";
-            src.new_line() << "w" << k << "[1] = (t * t * (3 * t - 6) + 4) / 6;";
-            src.new_line() << "w" << k << "[2] = (t * (t * (-3 * t + 3) + 3) + 1) / 6;";
-            src.new_line() << "w" << k << "[3] = t * t * t / 6;";
+            src.new_line() << "w" << k << "_0 = (t * (t * (-t + 3) - 3) + 1) / 6;";
+            src.new_line() << "w" << k << "_1 = (t * t * (3 * t - 6) + 4) / 6;";
+            src.new_line() << "w" << k << "_2 = (t * (t * (-3 * t + 3) + 3) + 1) / 6;";
+            src.new_line() << "w" << k << "_3 = t * t * t / 6;";
             src.close("}");
         }
         src.new_line() << R << " f = 0;";
-        for (size_t k = 0; k < NDIM; ++k) {
-            src.new_line() << "#pragma unroll";
-            src.new_line() << "for(int d" << k << " = 0; d" << k << " < 4; ++d" << k << ")";
-            src.open("{");
-            src.new_line() << "const ulong j" << k << " = i" << k << " + d" << k << ";";
-            src.new_line() << "if (j" << k << " >= n" << k << ") continue;";
+        // the 4^NDIM terms, written out; a lane whose whole stencil is inside the lattice (the usual case) takes the
+        // branch-free sum
+        src.new_line() << "if (";
+        for (size_t k = 0; k < NDIM; ++k) src << (k ? " && " : "") << "i" << k << " + 3 < n" << k;
+        src << ")";
+        src.open("{");
+        src.new_line() << "const ulong base = ";
+        for (size_t k = 0; k < NDIM; ++k) src << (k ? " + " : "") << "i" << k << " * m" << k;
+        src << ";";
+        size_t combos = 1; for (size_t k = 0; k < NDIM; ++k) combos *= 4;
+        for (size_t t = 0; t < combos; ++t) {
+            const auto d = unflatten<NDIM>(t, 4);
+            src.new_line() << "f += ";
+            for (size_t k = 0; k < NDIM; ++k) src << "w" << k << "_" << d[k] << " * ";
+            src << "phi[base";
+            for (size_t k = 0; k < NDIM; ++k) if (d[k]) src << " + " << d[k] << " * m" << k;
+            src << "];";
         }
-        src.new_line() << "f += ";
-        for (size_t k = 0; k < NDIM; ++k) src << "w" << k << "[d" << k << "] * ";
-        src << "phi[";
-        for (size_t k = 0; k < NDIM; ++k) src << (k ? " + " : "") << "j" << k << " * m" << k;
-        src << "];";
-        for (size_t k = 0; k < NDIM; ++k) src.close("}");
+        src.close("}");
+        src.new_line() << "else";
+        src.open("{");
+        for (size_t t = 0; t < combos; ++t) {
+            const auto d = unflatten<NDIM>(t, 4);
+            src.new_line() << "if (";
+            for (size_t k = 0; k < NDIM; ++k) src << (k ? " && " : "") << "i" << k << " + " << d[k] << " < n" << k;
+            src << ") f += ";
+            for (size_t k = 0; k < NDIM; ++k) src << "w" << k << "_" << d[k] << " * ";
+            src << "phi[";
+            for (size_t k = 0; k < NDIM; ++k) src << (k ? " + " : "") << "(i" << k << " + " << d[k] << ") * m" << k;
+            src << "];";
+        }
+        src.close("}");
         src.new_line() << "return f;";
         src.end_function();
     }

@@ -43,6 +43,7 @@ class profiler {
         void tic_cl(const std::string &name) {
             for (const auto &q : queue) q.finish();
             enter(name);
+            stack.back()->cl = true;             // toc() waits for the queues before reading the clock (profiler.hpp:249-269)
         }
         double toc(const std::string & /*name*/ = "") {
             precondition(stack.size() > 1, "profiler::toc() without tic");
