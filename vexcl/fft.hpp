@@ -16,6 +16,7 @@
 // queue, and hands back `scale * c2r(out)` / `scl(out, scale)` as an expression over the output buffer, exactly
 // the reference's shape (plan.hpp:336-357), so the 1/n of inverse transforms and any further arithmetic fuse
 // into the consumer's kernel.  Single-device, as in the reference (plan.hpp:226-229).
+#include <cstdlib>
 #include <iostream>
 #include <memory>
 #include <numeric>
@@ -138,7 +139,8 @@ struct plan {
         for (size_t i = 0; i < sizes.size(); ++i) { d[i] = (int)dirs[i]; if (dirs[i] == inverse) inv_n *= sizes[i]; }
         scale = (Ts)1 / inv_n;
         // real input, forward along the (even) last dimension, every other dimension a batch: half-length transform
-        half = cl_vector_length<Tv>::value == 1 && dirs.back() == forward && sizes.back() >= 2 && sizes.back() % 2 == 0;
+        half = cl_vector_length<Tv>::value == 1 && dirs.back() == forward && sizes.back() >= 2 && sizes.back() % 2 == 0
+            && !std::getenv("VEXCL_FFT_NO_HALF");           // (measurement switch: full-length transform of the widened input)
         for (size_t i = 0; i + 1 < sizes.size(); ++i) if (dirs[i] != none) half = false;
         std::vector<size_t> native = sizes;
         if (half) native.back() /= 2;
