@@ -110,7 +110,8 @@ struct plan {
         "const bool upper = k > h; const ulong kk = upper ? n - k : k;\n"
         + type_name<T2>() + " a = z[row * h + (kk == h ? 0 : kk)], b = z[row * h + (kk == 0 || kk == h ? 0 : h - kk)];\n"
         + type_name<Ts>() + " er = (a.x + b.x) / 2, ei = (a.y - b.y) / 2, pr = (a.x - b.x) / 2, pi = (a.y + b.y) / 2, sn, cs;\n"
-        + std::string(std::is_same<Ts, cl_float>::value ? "sincospif" : "sincospi") + "((" + type_name<Ts>() + ")(-2) * (" + type_name<Ts>() + ")kk / (" + type_name<Ts>() + ")n, &sn, &cs);\n"
+        "const " + type_name<Ts>() + " ang = (" + type_name<Ts>() + ")(-2) * (" + type_name<Ts>() + ")kk / (" + type_name<Ts>() + ")n;\n"
+        + std::string(std::is_same<Ts, cl_float>::value ? "sn = sinpif(ang); cs = cospif(ang);" : "sn = sinpi(ang); cs = cospi(ang);") + "\n"   // (sincospi's out-parameters cost scratch memory)
         "r.x = er + cs * pi + sn * pr; r.y = ei - cs * pr + sn * pi;\n"
         "if (upper) r.y = -r.y;\n"
         "r.x *= scale; r.y *= scale; return r;");

@@ -421,6 +421,15 @@ int vexhip_module_get_function(int dev, void *module, const char *name, void **f
     hipFunction_t f;
     VEXHIP_TRY(hipModuleGetFunction(&f, (hipModule_t)module, name));
     *function = f;
+    // VEXCL_SHOW_SCRATCH: report generated kernels whose private arrays ended up in scratch memory (a performance trap
+    // of generated code: an array indexed by a loop the compiler did not unroll)
+    if (std::getenv("VEXCL_SHOW_SCRATCH")) {
+        int local = 0, regs = 0;
+        if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) == hipSuccess && local > 0) {
+            (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, f);
+            std::fprintf(stderr, "[vexhip] kernel %s uses %d bytes of scratch per lane (%d registers)\n", name, local, regs);
+        }
+    }
     return 0;
 }
 
