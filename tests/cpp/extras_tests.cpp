@@ -328,3 +328,16 @@ TEST_CASE(device_filters_of_the_other_backends) {                     // backend
     vex::Context one(vex::Filter::CC(9, 0) && vex::Filter::CLVersion(1, 2) && vex::Filter::Count(1));
     CHECK_EQUAL(one.size(), 1u);
 }
+
+TEST_CASE(profiler_device_sections_wait_for_the_device) {             // profiler.hpp:249-269: toc of a tic_cl section finishes the queues
+    const size_t n = size_t(1) << 26;
+    vex::vector<double> x(ctx, n);
+    x = 1;
+    vex::profiler<> prof(ctx);
+    prof.tic_cl("twenty passes");
+    for (int i = 0; i < 20; ++i) x = sin(x) + 1;
+    const double t = prof.toc("twenty passes");
+    CHECK(t > 1e-3);                                                  // 20 x 1 GiB cannot cross the HBM pins in less (8 TB/s: 2.7 ms)
+    prof.tic_cpu("host section");
+    CHECK(prof.toc("host section") < 1e-3);
+}
