@@ -281,6 +281,20 @@ TEST_CASE(fft_against_the_definition_and_round_trips) {              // fft.cpp:
         CHECK_SMALL(hrf[b * RN + k].s[0] - (double)s1.real(), 1e-10); CHECK_SMALL(hrf[b * RN + k].s[1] - (double)s1.imag(), 1e-10);
         CHECK_SMALL(hrg[b * RN + k].s[0] - (double)s2.real(), 1e-10); CHECK_SMALL(hrg[b * RN + k].s[1] - (double)s2.imag(), 1e-10);
     }
+    {   // the same path in single precision, 2 batch dimensions
+        const size_t FB = 3, FC = 2, FN = 64;
+        std::vector<float> fr = random_vector<float>(FB * FC * FN);
+        vex::vector<float> FR(q, fr);
+        vex::vector<cl_float2> FF(q, FB * FC * FN);
+        vex::FFT<float, cl_float2> ff(q, {FB, FC, FN}, {vex::fft::none, vex::fft::none, vex::fft::forward});
+        FF = ff(FR);
+        auto hff = download(FF);
+        for (size_t row = 0; row < FB * FC; ++row) for (size_t k = 0; k < FN; k += 5) {
+            std::complex<double> s1 = 0;
+            for (size_t j = 0; j < FN; ++j) s1 += (double)fr[row * FN + j] * std::polar<double>(1.0, -2.0 * pi * (double)((j * k) % FN) / FN);
+            CHECK_SMALL(hff[row * FN + k].s[0] - (float)s1.real(), 2e-4); CHECK_SMALL(hff[row * FN + k].s[1] - (float)s1.imag(), 2e-4);
+        }
+    }
     // real in, real out (the real part of the spectrum), and the odd-length fallback
     vex::vector<double> RE(q, RB * RN);
     vex::FFT<double, double> rre(q, {RB, RN}, {vex::fft::none, vex::fft::forward});
