@@ -10,7 +10,8 @@
 // a second offset table.  Global accesses are coalesced along whichever direction is contiguous: along the
 // line when its element stride is 1, ACROSS the lines of the tile otherwise (LDS rows are padded by one element
 // so both directions are conflict-free).  With that one kernel
-//   * a contiguous row of up to 2048 (fp64) / 4096 (fp32) elements is ONE pass, whatever its number of radix
+//   * a contiguous row of up to 2048 (fp64) / 4096 (fp32) elements -- twice that for powers of two, which run their
+//     stages register-resident in ONE LDS buffer (stage_inplace) -- is ONE pass, whatever its number of radix
 //     stages (the reference launches one global-memory pass per radix: 3-4 for n = 4096);
 //   * a longer length n = n1 n2 [n3] is 2 [3] passes and NO transpose: pass t transforms digit t in place (lines
 //     strided by the product of the later factors, tile = neighbouring lines, twiddle W^(k_t J) fused into the
@@ -19,12 +20,12 @@
 //   * the dimensions of an n-D transform (and batches) need no transposes either: a dimension with element
 //     stride s is a set of lines with stride s, neighbouring lines adjacent in memory.
 // The reference rotates the array with one transpose per dimension and the textbook four-step algorithm
-// has three; here 4096 x 4096 fp64 is 4 passes over the data instead of 12.  Lengths with a prime factor above
+// has three; here 4096 x 4096 fp64 is 3 passes over the data instead of 12.  Lengths with a prime factor above
 // 13 go through Bluestein's chirp-z over a 2^a 3^b 5^c 7^d convolution length (rows gathered by a tiled LDS
 // transpose when the dimension is strided).  The plan (factorizations, passes, twiddle / chirp tables, work
 // buffers) is native C++ behind four C entry points.
 // Measured on MI355X (tools/fft_bench.py): fp64 1024-point rows 0.54 ms per 2.1 GB moved (3.9 TB/s; torch.fft 0.81 ms, rocFFT's
-// kernel alone 0.38), 2^24 points 0.51 ms in 3 passes (torch.fft 0.63), 4096 x 4096 0.59 ms in 4 passes (0.50).  Tried and dropped: an LDS
+// kernel alone 0.38), 2^24 points 0.50 ms in 3 passes (torch.fft 0.61), 4096 x 4096 0.48 ms in 3 passes (0.50).  Tried and dropped: an LDS
 // layout skewed by one element per eight (removes the bank conflicts of the first stage's writes, but the extra
 // index arithmetic on every access cost more: 0.76 -> 0.94 ms on the 1024-point rows).
 #include "common.hpp"
