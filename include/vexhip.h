@@ -243,6 +243,12 @@ int vexhip_spmv_sell8v_f32_i32(int dev, void *stream, int64_t n, float alpha, in
         const void *buf, const int32_t *deltas, const float *values, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y, const vexhip_traversal *traversal);
 
+/* A/B switch of the SELL / SELL8 / SELL8V products (results are bit-identical either way):
+ *   variant 0 (default): pair kernels -- a lane reads x for its two rows with ONE 16-byte load per ELL column
+ *                        wherever the fill kernels could align the two rows (see the storage notes above);
+ *   variant 1:           one 8-byte gather per entry (round 1).                                                     */
+int vexhip_spmv_sell8_set_variant(int variant);
+
 /* Multi-right-hand-side products  y[k] (+)= alpha * A * x[k],  k < nrhs  -- `SpMat * multivector`
  * (vexcl/spmat.hpp:388-398, which applies the product once per component; tests/spmv.cpp:262-305).
  * One launch per group of up to four right-hand sides reads the matrix ONCE; each y[k] is

@@ -156,6 +156,55 @@ def spmv_hell(h, x, y=None, alpha=1.0, append=False):
 
 
 # --------------------------------------------------------------------------
+# Row-pair placement of the SELL storages of THIS implementation (not a
+# reference format): vexcl_amd/csrc/pairing.hpp.  The first w entries of rows
+# 2k and 2k+1 are merged by diagonal (column - row); equal diagonals share an
+# ELL column, otherwise the smaller takes the column alone.  If the merged
+# list is longer than w the pair keeps the plain packing (entry j in column j).
+# The empty half of a column is PAD_SAFE when a 16-byte load of x that starts
+# at (partner column - partner half) stays inside [0, max_col], else PAD_UNSAFE.
+# Restated in plain Python so that the layout tests have something to compare.
+# --------------------------------------------------------------------------
+def sell_pair_slots(ptr, col, row0, w, max_col):
+    """Returns for rows row0, row0+1 two lists of length w holding CSR entry offsets, 'safe' or 'unsafe'."""
+    n = len(ptr) - 1
+    ent = []
+    for q in (0, 1):
+        r = row0 + q
+        b, e = (int(ptr[r]), int(ptr[r + 1])) if r < n else (0, 0)
+        ent.append(list(range(b, min(e, b + w))))
+    diag = [[int(col[k]) - (row0 + q) for k in ent[q]] for q in (0, 1)]
+    slots, pa, pb = [], 0, 0
+    while pa < len(ent[0]) or pb < len(ent[1]):
+        if pa < len(ent[0]) and pb < len(ent[1]):
+            da, db = diag[0][pa], diag[1][pb]
+            if da == db:
+                slots.append((ent[0][pa], ent[1][pb])); pa += 1; pb += 1
+            elif da < db:
+                slots.append((ent[0][pa], None)); pa += 1
+            else:
+                slots.append((None, ent[1][pb])); pb += 1
+        elif pa < len(ent[0]):
+            slots.append((ent[0][pa], None)); pa += 1
+        else:
+            slots.append((None, ent[1][pb])); pb += 1
+    if len(slots) > w:          # plain packing
+        slots = [(ent[0][j] if j < len(ent[0]) else None, ent[1][j] if j < len(ent[1]) else None) for j in range(w)]
+    slots += [(None, None)] * (w - len(slots))
+    out = [[], []]
+    for e0, e1 in slots:
+        for q, (mine, other) in enumerate(((e0, e1), (e1, e0))):
+            if mine is not None:
+                out[q].append(mine)
+            elif other is None:
+                out[q].append("safe")
+            else:
+                first = int(col[other]) - (1 - q)
+                out[q].append("safe" if first >= 0 and first + 1 <= max_col else "unsafe")
+    return out
+
+
+# --------------------------------------------------------------------------
 # Elementwise / reductions
 # --------------------------------------------------------------------------
 def ew_mul_add_sin(b, c, d):

@@ -111,11 +111,28 @@ def test_sell_layout_and_tail(T, oracle):
     raw = S.sell.cpu().numpy().reshape(-1, w * 512 * 12)               # one region per slice: columns, then values
     sc = raw[:, :w * 512 * 4].copy().view(np.int32).reshape(-1, w, 512)
     sv = raw[:, w * 512 * 4:].copy().view(np.float64).reshape(-1, w, 512)
-    ec = h["ell_col"].reshape(w, h["pitch"])
-    ev = h["ell_val"].reshape(w, h["pitch"])
-    for i in (0, 1, 511, 512, 1023, 1499):
-        assert np.array_equal(sc[i // 512, :, i % 512], ec[:, i]) and np.array_equal(sv[i // 512, :, i % 512], ev[:, i])
-    assert np.all(sc[2, :, 1500 - 1024:] == -1)          # padding rows of the last slice
+    # rows 2k and 2k+1 are placed together: entries merged by diagonal, each row in its CSR order, padding -1 where a
+    # 16-byte load of the partner stays inside x and -2 where it would not (oracle.sell_pair_slots restates the rule)
+    max_col = int(max(col[ptr[r]:ptr[r] + w].max() for r in range(n) if ptr[r + 1] > ptr[r]))
+    for i in (0, 1, 510, 511, 512, 1022, 1023, 1498, 1499):
+        slots = oracle.sell_pair_slots(ptr, col, i - (i % 2), w, max_col)[i % 2]
+        want_c = [int(col[e]) if not isinstance(e, str) else (-1 if e == "safe" else -2) for e in slots]
+        want_v = [float(val[e]) if not isinstance(e, str) else 0.0 for e in slots]
+        assert sc[i // 512, :, i % 512].tolist() == want_c and sv[i // 512, :, i % 512].tolist() == want_v
+        assert [c for c in want_c if c >= 0] == col[ptr[i]:min(ptr[i + 1], ptr[i] + w)].tolist()      # the row's ELL entries, in order
+    assert np.all(sc[2, :, 1500 - 1024:] < 0)            # padding rows of the last slice
+    # a 16-byte load that would leave x is ruled out by the padding code -2: the last row of an odd-sized matrix has no
+    # partner, and its entry sits in the last column
+    tp, tc, tv = np.array([0, 1, 3, 4], dtype=np.int32), np.array([0, 0, 2, 2], dtype=np.int32), np.array([1.0, 2.0, 3.0, 4.0])
+    S3 = T.ops.SlicedELL(T.up(tp), T.up(tc), T.up(tv), codes=False)
+    assert S3.width == 2
+    raw3 = S3.sell.cpu().numpy()
+    c3 = raw3[:2 * 512 * 4].copy().view(np.int32).reshape(2, 512)
+    assert c3[:, :4].tolist() == [[0, 0, 2, -2], [-1, 2, -1, -1]]
+    y3 = T.torch.empty(3, dtype=T.torch.float64, device=T.dev)
+    x3 = T.up(np.array([1.0, np.inf, 0.5]))              # x[1] is never referenced: it must not reach any sum (inf * 0 = NaN)
+    S3.mul(x3, y3)
+    assert y3.cpu().numpy().tolist() == [1.0, 2.0 * 1.0 + 3.0 * 0.5, 4.0 * 0.5]
     assert np.array_equal(S.csr_ptr.cpu().numpy(), h["csr_ptr"]) and np.array_equal(S.csr_val.cpu().numpy(), h["csr_val"])
 
 
@@ -311,7 +328,8 @@ def _banded(rng, n, offsets, density=0.8):
 
 
 def test_sell8_diagonal_codes(T, oracle, built_lib):
-    """<= 255 distinct diagonals => 1-byte diagonal codes; layout, fallback and bit-exact products."""
+    """<= 254 distinct diagonals => 1-byte diagonal codes (254 / 255 are the two padding codes); layout, pair
+    alignment, fallback and bit-exact products."""
     rng = np.random.default_rng(8)
     # (a) Poisson: 7 diagonals {-n^2, -n, -1, 0, 1, n, n^2}
     n = 20
@@ -329,9 +347,23 @@ def test_sell8_diagonal_codes(T, oracle, built_lib):
         got_cols, got_vals = [], []
         for j in range(7):
             code = (int(codes[s, j // 2, t]) >> (8 * ((j % 2) * 2 + q))) & 255
-            if code != 255:
+            if code < 254:
                 got_cols.append(i + int(table[code])); got_vals.append(vals[s, j, 2 * t + q])
+            else:
+                assert vals[s, j, 2 * t + q] == 0.0
         assert got_cols == col[ptr[i]:ptr[i + 1]].tolist() and got_vals == val[ptr[i]:ptr[i + 1]].tolist()
+    # pair alignment (oracle.sell_pair_slots): rows 2k, 2k+1 share an ELL column where they share a diagonal -- the
+    # identity row of a grid boundary sits where its interior neighbour has its diagonal entry -- and the empty half is
+    # code 255 (the partner's 16-byte load may cover it) or 254 (that load would leave x: first / last column)
+    max_col = N - 1
+    for i0 in (0, n * n + n, n * n + 2 * n - 2, 4320, N - 2):
+        for q, slots in enumerate(oracle.sell_pair_slots(ptr, col, i0, 7, max_col)):
+            s, t = i0 // 512, (i0 % 512) // 2
+            for j, e in enumerate(slots):
+                code = (int(codes[s, j // 2, t]) >> (8 * ((j % 2) * 2 + q))) & 255
+                want = {"safe": 255, "unsafe": 254}[e] if isinstance(e, str) else [-n * n, -n, -1, 0, 1, n, n * n].index(int(col[e]) - (i0 + q))
+                assert code == want, (i0, q, j, code, want)
+    assert oracle.sell_pair_slots(ptr, col, n * n + n, 7, max_col)[0] == ["safe"] * 3 + [int(ptr[n * n + n])] + ["safe"] * 3
     # (b) banded matrices with gaps, odd sizes, more diagonals than the unrolled widths, a CSR tail
     for nn, offs in ((5000, [-700, -3, -1, 0, 2, 9, 1234]), (1537, list(range(-20, 21, 2))), (3000, [0]),
                      (2048, [-1024, -512, -64, -8, -1, 0, 1, 8, 64, 512, 1024, 1500])):
@@ -346,8 +378,8 @@ def test_sell8_diagonal_codes(T, oracle, built_lib):
         S32 = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val), codes=False)      # 32-bit columns: same bits
         y2 = T.up(y0.copy()); S32.mul(T.up(x), y2, 1.25, True)
         assert T.torch.equal(y, y2)
-    # (b2) up to 255 diagonals are coded, 256 are not
-    for nd, coded in ((255, True), (256, False)):
+    # (b2) up to 254 diagonals are coded, 255 are not
+    for nd, coded in ((254, True), (255, False)):
         offs = list(range(-(nd // 2), nd - nd // 2))
         ptr, col, val = _banded(rng, 3000, offs, density=1.0)
         S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
@@ -356,7 +388,7 @@ def test_sell8_diagonal_codes(T, oracle, built_lib):
         y = T.torch.empty(3000, dtype=T.torch.float64, device=T.dev)
         S.mul(T.up(x), y)
         assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
-    # (c) not banded: more than 255 diagonals -> 32-bit columns are kept
+    # (c) not banded: more than 254 diagonals -> 32-bit columns are kept
     ptr, col, val = oracle.random_matrix(9, 4000, 4000, 16)
     S = T.ops.SlicedELL(T.up(ptr), T.up(col), T.up(val))
     assert S.ndeltas == -1 and S.deltas is None
@@ -442,7 +474,7 @@ def test_sell8v_value_codes(T, oracle, built_lib):
         for j in range(7):
             sh = 8 * ((j % 2) * 2 + q)
             code = (int(ccodes[s, j // 2, t]) >> sh) & 255
-            if code != 255:
+            if code < 254:                        # 254 / 255: padding
                 cols.append(i + int(dt[code])); vals.append(float(S.values[(int(vcodes[s, j // 2, t]) >> sh) & 255]))
         assert cols == col[ptr[i]:ptr[i + 1]].tolist() and vals == val[ptr[i]:ptr[i + 1]].tolist()
     x = rng.random(N) - 0.5

@@ -1,0 +1,35 @@
+#!/bin/bash
+# SQ / TCP / TA / TCC counters of the SELL products at 512^3 (diagnostic): one rocprofv3 --pmc pass per group over
+# tools/pmc_target.py; per-kernel averages to gpurun_out/r02_sq_summary.txt
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/sq; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > $OUT/counters_list.txt 2>&1
+CMD="python $ROOT/tools/pmc_target.py"
+i=0
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
+           "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+           "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_DATA_STALL_CYCLES_sum" \
+           "TA_BUSY_avr TA_BUSY_max TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
+           "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
+           "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_TAG_STALL_sum TCC_BUSY_avr"; do
+  i=$((i+1))
+  timeout 240 rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o pmc --output-format csv -- $CMD > $OUT/g$i.log 2>&1
+  echo "group $i ($grp) exit $?"
+done
+python - <<PY > $ROOT/gpurun_out/r02_sq_summary.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        for tag in ("sell8v_kernel", "sell8_kernel", "sell_kernel", "csr_stream_kernel", "hell_kernel", "reduce"):
+            if tag in k:
+                a = agg[tag][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+                break
+for tag in agg:
+    print("==", tag)
+    for k in sorted(agg[tag]): print("  %-36s %.6g per launch (%d launches)" % (k, agg[tag][k][1] / agg[tag][k][0], agg[tag][k][0]))
+PY
+cat $ROOT/gpurun_out/r02_sq_summary.txt

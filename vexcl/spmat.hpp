@@ -459,7 +459,7 @@ struct inline_spmv : expression_base {
         c.src.open("{");
         c.src.new_line() << "const int sh = 8 * ((j & 1) * 2 + (i & 1));";
         c.src.new_line() << "const uint code = (cw[(j >> 1) * 256] >> sh) & 255u;";
-        c.src.new_line() << "if (code != 255u) sum += values[(vw[(j >> 1) * 256] >> sh) & 255u] * in[(long)i + deltas[code]];";
+        c.src.new_line() << "if (code < 254u) sum += values[(vw[(j >> 1) * 256] >> sh) & 255u] * in[(long)i + deltas[code]];";
         c.src.close("}");
         c.src.close("}");
         c.src.new_line() << "else if (deltas)";       // SELL8: 1-byte diagonal codes
@@ -471,7 +471,7 @@ struct inline_spmv : expression_base {
         c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
         c.src.open("{");
         c.src.new_line() << "const uint code = (cw[(j >> 1) * 256] >> (8 * ((j & 1) * 2 + (i & 1)))) & 255u;";
-        c.src.new_line() << "if (code != 255u) sum += ell_val[j * 512] * in[(long)i + deltas[code]];";
+        c.src.new_line() << "if (code < 254u) sum += ell_val[j * 512] * in[(long)i + deltas[code]];";
         c.src.close("}");
         c.src.close("}");
         c.src.new_line() << "else";                   // SELL-512 with 32-bit columns
@@ -482,7 +482,7 @@ struct inline_spmv : expression_base {
         c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
         c.src.open("{");
         c.src.new_line() << "int c = ell_col[j * 512];";
-        c.src.new_line() << "if (c != -1) sum += ell_val[j * 512] * in[c];";
+        c.src.new_line() << "if (c >= 0) sum += ell_val[j * 512] * in[c];";
         c.src.close("}");
         c.src.close("}");
         c.src.new_line() << "if (csr_row)";

@@ -116,6 +116,7 @@ _PROTOS = {
     "vexhip_sell8_fill_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmv_sell8_set_variant": (None, [c_int]),
     "vexhip_sell8v_bytes": (c_i64, [c_i64, c_i64]),
     "vexhip_sell8v_analyze_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_int)]),
     "vexhip_sell8v_analyze_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_int)]),

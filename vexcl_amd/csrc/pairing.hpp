@@ -1,0 +1,70 @@
+// Row-pair alignment for the SELL storages (sell8.hip, spmv.hip fill kernels).
+//
+// A lane of the SELL product kernels owns rows 2t and 2t+1 and reads x for both with ONE
+// 16-byte load per ELL column when the two rows hold the same diagonal there (pair kernels,
+// sell8.hip).  The fill kernels therefore place the first w entries of the two rows by a
+// two-pointer merge of their diagonal lists (diagonal = column - row): equal diagonals share
+// a column, otherwise the smaller one takes the column alone and the partner gets padding.
+// A merge keeps the entries of EACH row in their CSR order whatever the rows look like
+// (sorted or not), so the summation order of a row -- and with it every bit of the result --
+// is unchanged.  If the merged list does not fit the ELL width the pair keeps the plain
+// packing (entry k in column k).
+#pragma once
+
+namespace vexhip {
+
+struct pair_walk {
+    const int *col;
+    long long row;             // first row of the pair
+    int b[2], n[2];            // CSR begin and number of ELL entries (min(row length, w)) of the two rows
+    int p[2];                  // entries consumed so far
+    bool aligned;
+
+    __device__ __forceinline__ long long diag(int q, int k) const { return (long long)col[b[q] + k] - (row + q); }
+
+    __device__ void init(const int *col_, long long row_, int b0, int n0, int b1, int n1, int w) {
+        col = col_; row = row_; b[0] = b0; b[1] = b1; n[0] = n0; n[1] = n1;
+        int pa = 0, pb = 0, merged = 0;
+        while (pa < n0 || pb < n1) {
+            if (pa < n0 && pb < n1) {
+                const long long da = diag(0, pa), db = diag(1, pb);
+                if (da == db) { ++pa; ++pb; } else if (da < db) ++pa; else ++pb;
+            } else if (pa < n0) ++pa; else ++pb;
+            ++merged;
+        }
+        aligned = merged <= w;
+        p[0] = p[1] = 0;
+    }
+
+    /// Entries (offsets into the CSR arrays, -1 = none) that go to the next ELL column.
+    __device__ void next(int &e0, int &e1) {
+        e0 = e1 = -1;
+        const bool h0 = p[0] < n[0], h1 = p[1] < n[1];
+        if (!aligned) {
+            if (h0) e0 = b[0] + p[0]++;
+            if (h1) e1 = b[1] + p[1]++;
+            return;
+        }
+        if (h0 && h1) {
+            const long long da = diag(0, p[0]), db = diag(1, p[1]);
+            if (da <= db) e0 = b[0] + p[0]++;
+            if (db <= da) e1 = b[1] + p[1]++;
+        } else if (h0) e0 = b[0] + p[0]++;
+        else if (h1) e1 = b[1] + p[1]++;
+    }
+};
+
+/// Largest column index among the first w entries of every row (atomicMax into *out, which starts at -1):
+/// x holds at least that many + 1 elements, so a 16-byte load that ends at x[max] stays inside x.
+static __global__ __launch_bounds__(256)
+void ell_max_col_kernel(long long n, int w, const int *__restrict__ ptr, const int *__restrict__ col, int *out) {
+    int m = -1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = ptr[i], e = ptr[i + 1];
+        for (int j = 0; j < w && b + j < e; ++j) { const int c = col[b + j]; m = c > m ? c : m; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_down(m, o, 64); m = v > m ? v : m; }
+    if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(out, m);
+}
+
+} // namespace vexhip

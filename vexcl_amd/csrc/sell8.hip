@@ -17,6 +17,7 @@
 // values per column.  Compiled with -ffp-contract=off like spmv.hip.
 #include "common.hpp"
 #include "traversal.hpp"
+#include "pairing.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -26,10 +27,17 @@
 #include <vector>
 
 namespace vexhip {
+
+// A/B switch of the SELL products (vexhip_spmv_sell8_set_variant, shared with spmv.hip):
+// 0 = pair kernels (one 16-byte gather per lane and column; default), 1 = one 8-byte gather per entry (round 1).
+int g_sell8_variant = 0;
+
 namespace {
 
 constexpr int S8_ROWS = 512;
-constexpr int S8_PAD = 255;
+constexpr int S8_PAD = 255;              // padding (254 = padding too, see the pair kernels)
+constexpr unsigned S8_FIRST_PAD = 254;
+constexpr unsigned S8_PAD_UNSAFE = 254;     // padding whose partner must not use the 16-byte load (pair kernels)
 constexpr int HASH_SLOTS = 1024;
 constexpr int LOCAL_SLOTS = 512;          // per-workgroup set: twice the 255 entries a table may hold
 constexpr int EMPTY = INT_MIN;
@@ -82,14 +90,14 @@ void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
-                xv[j][q] = (code != S8_PAD) ? x[i + q + s_delta[code]] : V(0);
+                xv[j][q] = (code < S8_FIRST_PAD) ? x[i + q + s_delta[code]] : V(0);
             }
 #pragma unroll
         for (int j = 0; j < W; ++j)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
-                if (code != S8_PAD) sum[q] += v[j][q] * xv[j][q];
+                if (code < S8_FIRST_PAD) sum[q] += v[j][q] * xv[j][q];
             }
     } else {
         for (int j = 0; j < w; ++j) {
@@ -98,7 +106,7 @@ void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned code = (cword >> (8 * ((j & 1) * 2 + q))) & 255u;
-                if (code != S8_PAD) sum[q] += vv[q] * x[i + q + s_delta[code]];
+                if (code < S8_FIRST_PAD) sum[q] += vv[q] * x[i + q + s_delta[code]];
             }
         }
     }
@@ -158,18 +166,37 @@ void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
     if (threadIdx.x == 0 && s_over) atomicExch(&info[1], 1);
 }
 
-// table: sorted diagonals (ndeltas valid entries); counts[256]: entries per code; info[1]: set if a diagonal is missing
+// code of a diagonal (binary search in the sorted table), S8_PAD if it is not there
+__device__ __forceinline__ unsigned delta_code(const int *s_table, int ndeltas, long long dl) {
+    if (dl < INT_MIN || dl > INT_MAX) return S8_PAD;
+    const int d = (int)dl;
+    int lo = 0, hi = ndeltas;                    // first table entry >= d
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (s_table[mid] < d) lo = mid + 1; else hi = mid; }
+    return (lo < ndeltas && s_table[lo] == d) ? (unsigned)lo : (unsigned)S8_PAD;
+}
+
+// padding code of the empty half of a column whose other half holds column index `c` of row half `q`:
+// 255 when the 16-byte load of the pair kernels (x[c - q], x[c - q + 1]) stays inside x, 254 otherwise
+__device__ __forceinline__ unsigned pad_code(int partner_col, int partner_q, int max_col) {
+    if (partner_col < 0) return S8_PAD;                                 // both halves empty
+    const long long first = (long long)partner_col - partner_q;        // element the 16-byte load starts at
+    return (first >= 0 && first + 1 <= max_col) ? (unsigned)S8_PAD : S8_PAD_UNSAFE;
+}
+
+// table: sorted diagonals (ndeltas valid entries); counts[256]: entries per code; info[1]: set if a diagonal is missing;
+// max_col: largest column index of the ELL part (ell_max_col_kernel)
 template <typename V>
 __global__ __launch_bounds__(256)
 void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
         const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
-        const int *__restrict__ table, char *__restrict__ buf, unsigned long long *counts, int *info)
+        const int *__restrict__ table, const int *__restrict__ max_col_p, char *__restrict__ buf, unsigned long long *counts, int *info)
 {
     __shared__ int s_table[256];
     __shared__ unsigned s_cnt[256];
     s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
+    const int max_col = *max_col_p;
     const int wp = (w + 1) / 2;
     // one lane per row PAIR (the unit the product kernel reads)
     for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (S8_ROWS / 2);
@@ -182,21 +209,22 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
         int b[2] = {0, 0}, e[2] = {0, 0};
         const long long i = s * S8_ROWS + 2 * t;
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
+        pair_walk pw;
+        pw.init(col, i, b[0], min(e[0] - b[0], w), b[1], min(e[1] - b[1], w), w);
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
+                int en[2] = {-1, -1};
+                if (j < w) pw.next(en[0], en[1]);
                 for (int q = 0; q < 2; ++q) {
-                    unsigned code = S8_PAD;
+                    unsigned code;
                     V v = V(0);
-                    if (j < w && b[q] + j < e[q]) {
-                        const int d = (int)((long long)col[b[q] + j] - (i + q));
-                        int lo = 0, hi = ndeltas;                    // first table entry >= d
-                        while (lo < hi) { int mid = (lo + hi) >> 1; if (s_table[mid] < d) lo = mid + 1; else hi = mid; }
-                        if (lo < ndeltas && s_table[lo] == d) { code = (unsigned)lo; atomicAdd(&s_cnt[lo], 1u); }
-                        else atomicExch(&info[1], 1);
-                        v = val[b[q] + j];
-                    }
+                    if (en[q] >= 0) {
+                        code = delta_code(s_table, ndeltas, (long long)col[en[q]] - (i + q));
+                        if (code != S8_PAD) atomicAdd(&s_cnt[code], 1u); else atomicExch(&info[1], 1);
+                        v = val[en[q]];
+                    } else code = pad_code(en[1 - q] >= 0 ? col[en[1 - q]] : -1, 1 - q, max_col);
                     word |= code << (8 * (jj * 2 + q));
                     if (j < w) vp[(long long)j * S8_ROWS + q] = v;
                 }
@@ -258,7 +286,7 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
-                xv[j][q] = (code != S8_PAD) ? x[i + q + s_delta[code]] : V(0);
+                xv[j][q] = (code < S8_FIRST_PAD) ? x[i + q + s_delta[code]] : V(0);
             }
 #pragma unroll
         for (int j = 0; j < W; ++j)
@@ -266,7 +294,7 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
             for (int q = 0; q < 2; ++q) {
                 const int sh = 8 * ((j & 1) * 2 + q);
                 const unsigned code = (c[j >> 1] >> sh) & 255u;
-                if (code != S8_PAD) sum[q] += s_value[(vc[j >> 1] >> sh) & 255u] * xv[j][q];
+                if (code < S8_FIRST_PAD) sum[q] += s_value[(vc[j >> 1] >> sh) & 255u] * xv[j][q];
             }
     } else {
         for (int j = 0; j < w; ++j) {
@@ -275,10 +303,122 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
             for (int q = 0; q < 2; ++q) {
                 const int sh = 8 * ((j & 1) * 2 + q);
                 const unsigned code = (cword >> sh) & 255u;
-                if (code != S8_PAD) sum[q] += s_value[(vword >> sh) & 255u] * x[i + q + s_delta[code]];
+                if (code < S8_FIRST_PAD) sum[q] += s_value[(vword >> sh) & 255u] * x[i + q + s_delta[code]];
             }
         }
     }
+    if (csr_ptr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (i + q < n)
+                for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+    }
+    store_pair<V>(n, i, alpha, append, sum, y);
+}
+
+// ---------------------------------------------------------------------------
+// PAIR kernels (round 2; the default for W <= 8): one 16-byte gather per lane and
+// ELL column instead of two 8-byte gathers.
+//
+// What bounds these products is the number of vector-memory instructions a wave
+// issues, not HBM and not latency (profiles/r02_sell8v_ablation.json: with all 14
+// gathers pointed at ONE cache line the value-coded product takes the same
+// 0.90 ms; with seven 16-byte gathers it takes 0.77 ms; a resident, software-
+// pipelined grid is slower).  A lane owns rows 2t and 2t+1; when both rows hold
+// the same diagonal d in ELL column j, x[2t+d] and x[2t+1+d] are adjacent: ONE
+// 16-byte load (4-byte alignment is enough for global_load_dwordx4).  The fill
+// kernels make that the normal case:
+//   * the entries of the two rows of a lane are ALIGNED by diagonal (a two-pointer
+//     merge of the two ascending diagonal lists; each row keeps its entries in
+//     their order, padding is inserted where the partner has a diagonal the row
+//     lacks) whenever the merged list fits the ELL width -- e.g. the identity row
+//     at a grid boundary sits in the column where its interior neighbour has its
+//     diagonal entry;
+//   * a padding entry next to a real one is code 255 ("the 16-byte load of the
+//     partner may cover me") unless that load would leave x -- the partner is in
+//     column 0 resp. the last column -- then it is code 254.
+// Per column a lane therefore does one unconditional 16-byte load when its codes are
+// {d, d}, {d, 255}, {255, d} or both padding (then from a harmless address), and
+// falls back to one 8-byte load per real entry otherwise (a rarely taken branch).
+// Values gathered for padding entries are replaced by 0 before use, their matrix
+// value is 0: sum + (+-0) == sum bit for bit (sum starts at +0 and cannot become
+// -0 in round-to-nearest), so every row still adds its own products in their
+// stored order: bit-identical to CSR.
+// ---------------------------------------------------------------------------
+
+template <typename V, int W, bool VCODED>
+__global__ __launch_bounds__(256)
+void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
+        const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
+{
+    constexpr int WP = (W + 1) / 2;
+    constexpr long long SLICE = VCODED ? (long long)WP * 2048 : ((long long)WP * 1024 + (long long)W * S8_ROWS * (long long)sizeof(V));
+    typedef typename vec2<V>::type V2;
+    __shared__ int s_delta[256];
+    __shared__ V s_value[VCODED ? 256 : 1];
+    s_delta[threadIdx.x] = deltas[threadIdx.x];
+    if constexpr (VCODED) s_value[threadIdx.x] = values[threadIdx.x];
+    __syncthreads();
+
+    const long long s = traversal_block(trav, nslices);
+    if (s < 0) return;
+    const int t = threadIdx.x;
+    const long long i = s * S8_ROWS + 2 * t;
+    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + s * SLICE) + t;
+    unsigned c[WP], vc[VCODED ? WP : 1];
+#pragma unroll
+    for (int jp = 0; jp < WP; ++jp) {
+        c[jp] = __builtin_nontemporal_load(cw + jp * 256);
+        if constexpr (VCODED) vc[jp] = __builtin_nontemporal_load(cw + (WP + jp) * 256);
+    }
+    V2 v[VCODED ? 1 : W];
+    if constexpr (!VCODED) {
+        const V *vp = reinterpret_cast<const V *>(buf + s * SLICE + (long long)WP * 1024) + 2 * t;
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * S8_ROWS));
+    }
+    // table look-ups for every column first, then every gather
+    int d[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+        d[j] = s_delta[c0 < S8_PAD_UNSAFE ? c0 : c1];
+    }
+    V xv[W][2];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+        const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
+        const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+        // the 16-byte load is skipped only when NO lane of the wave has a pair in this column (matrices without
+        // band structure); lanes without one read the diagonal table instead
+        const bool use16 = pair && (m0 || m1);
+        V2 p = {V(0), V(0)};
+        if (__builtin_amdgcn_ballot_w64(use16) != 0) {
+            const V *px = use16 ? x + (i + d[j]) : reinterpret_cast<const V *>(deltas);
+            __builtin_memcpy(&p, px, sizeof(V2));
+        }
+        xv[j][0] = p.x; xv[j][1] = p.y;
+        if (!pair) {                       // different diagonals in one lane, or a 16-byte load that would leave x
+            if (m0) xv[j][0] = x[i + s_delta[c0]];
+            if (m1) xv[j][1] = x[i + 1 + s_delta[c1]];
+        }
+        xv[j][0] = m0 ? xv[j][0] : V(0);
+        xv[j][1] = m1 ? xv[j][1] : V(0);
+    }
+    V sum[2] = {V(0), V(0)};
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int sh = 16 * (j & 1) + 8 * q;
+            V a;
+            if constexpr (VCODED) a = s_value[((c[j >> 1] >> sh) & 255u) < S8_PAD_UNSAFE ? (vc[j >> 1] >> sh) & 255u : 255u];   // entry 255 is 0.0
+            else a = v[j][q];                                                                                              // stored as 0 for padding
+            sum[q] += a * xv[j][q];
+        }
     if (csr_ptr) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -341,7 +481,8 @@ template <typename V>
 __global__ __launch_bounds__(256)
 void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int nvalues,
         const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
-        const int *__restrict__ table, const V *__restrict__ vtable, char *__restrict__ buf, unsigned long long *counts, int *info)
+        const int *__restrict__ table, const V *__restrict__ vtable, const int *__restrict__ max_col_p,
+        char *__restrict__ buf, unsigned long long *counts, int *info)
 {
     typedef typename bits_of<V>::type B;
     __shared__ int s_table[256];
@@ -351,6 +492,7 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
     { V v = threadIdx.x < nvalues ? vtable[threadIdx.x] : V(0); B b; __builtin_memcpy(&b, &v, sizeof(B)); s_vtable[threadIdx.x] = threadIdx.x < nvalues ? b : ~B(0); }
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
+    const int max_col = *max_col_p;
     const int wp = (w + 1) / 2;
     for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (S8_ROWS / 2);
          pr += (long long)gridDim.x * blockDim.x) {
@@ -361,25 +503,26 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
         int b[2] = {0, 0}, e[2] = {0, 0};
         const long long i = s * S8_ROWS + 2 * t;
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
+        pair_walk pw;
+        pw.init(col, i, b[0], min(e[0] - b[0], w), b[1], min(e[1] - b[1], w), w);
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0, vword = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
+                int en[2] = {-1, -1};
+                if (j < w) pw.next(en[0], en[1]);
                 for (int q = 0; q < 2; ++q) {
-                    unsigned code = S8_PAD, vcode = 0;
-                    if (j < w && b[q] + j < e[q]) {
-                        const int d = (int)((long long)col[b[q] + j] - (i + q));
-                        int lo = 0, hi = ndeltas;
-                        while (lo < hi) { int mid = (lo + hi) >> 1; if (s_table[mid] < d) lo = mid + 1; else hi = mid; }
-                        if (lo < ndeltas && s_table[lo] == d) { code = (unsigned)lo; atomicAdd(&s_cnt[lo], 1u); }
-                        else atomicExch(&info[1], 1);
-                        B bits; V v = val[b[q] + j];
+                    unsigned code, vcode = 255;                     // value code of padding: table entry 255 = 0.0
+                    if (en[q] >= 0) {
+                        code = delta_code(s_table, ndeltas, (long long)col[en[q]] - (i + q));
+                        if (code != S8_PAD) atomicAdd(&s_cnt[code], 1u); else atomicExch(&info[1], 1);
+                        B bits; V v = val[en[q]];
                         __builtin_memcpy(&bits, &v, sizeof(B));
-                        lo = 0; hi = nvalues;
+                        int lo = 0, hi = nvalues;
                         while (lo < hi) { int mid = (lo + hi) >> 1; if (s_vtable[mid] < bits) lo = mid + 1; else hi = mid; }
                         if (lo < nvalues && s_vtable[lo] == bits) vcode = (unsigned)lo;
                         else atomicExch(&info[1], 1);
-                    }
+                    } else code = pad_code(en[1 - q] >= 0 ? col[en[1 - q]] : -1, 1 - q, max_col);
                     word |= code << (8 * (jj * 2 + q));
                     vword |= vcode << (8 * (jj * 2 + q));
                 }
@@ -443,7 +586,7 @@ template <typename V>
 int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w,
         const int *deltas, int ndeltas, void *buf, vexhip_traversal *trav)
 {
-    VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 255, "bad SELL8 geometry");
+    VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 254, "bad SELL8 geometry");
     if (trav) std::memset(trav, 0, sizeof(*trav));
     if (n == 0) return 0;
     VEXHIP_REQUIRE(ptr && col && val && deltas && buf, "NULL argument");
@@ -451,11 +594,13 @@ int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col,
     hipStream_t s = as_stream(stream);
     const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
     unsigned long long *dcounts = nullptr;
-    VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 2 * sizeof(int)));
-    int *dinfo = reinterpret_cast<int *>(dcounts + 256);
+    VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 4 * sizeof(int)));
+    int *dinfo = reinterpret_cast<int *>(dcounts + 256);                    // [0] unused, [1] error flag, [2] largest ELL column
     VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
+    VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
+    ell_max_col_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
     sell8_fill_kernel<V><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, ptr, col, val, deltas,
-            static_cast<char *>(buf), dcounts, dinfo);
+            dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
     int hinfo[2] = {0, 0};
@@ -485,7 +630,8 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     if (ordered) t8 = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
-#define CASE(W) case W: sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8); break;
+#define CASE(W) case W: if (g_sell8_variant == 0) sell8_pair_kernel<V, W, false><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, t8); \
+        else sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
         default: sell8_kernel<V, 0><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8);
@@ -533,7 +679,7 @@ template <typename V>
 int sell8v_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w,
         const int *deltas, int ndeltas, const V *values, int nvalues, void *buf, vexhip_traversal *trav)
 {
-    VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 255 && nvalues >= 1 && nvalues <= 255, "bad SELL8V geometry");
+    VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 254 && nvalues >= 1 && nvalues <= 255, "bad SELL8V geometry");
     if (trav) std::memset(trav, 0, sizeof(*trav));
     if (n == 0) return 0;
     VEXHIP_REQUIRE(ptr && col && val && deltas && values && buf, "NULL argument");
@@ -541,11 +687,13 @@ int sell8v_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col
     hipStream_t s = as_stream(stream);
     const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
     unsigned long long *dcounts = nullptr;
-    VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 2 * sizeof(int)));
-    int *dinfo = reinterpret_cast<int *>(dcounts + 256);
+    VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 4 * sizeof(int)));
+    int *dinfo = reinterpret_cast<int *>(dcounts + 256);                    // [0] unused, [1] error flag, [2] largest ELL column
     VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
+    VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
+    ell_max_col_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
     sell8v_fill_kernel<V><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, nvalues, ptr, col, val, deltas, values,
-            static_cast<char *>(buf), dcounts, dinfo);
+            dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
     int hinfo[2] = {0, 0};
@@ -573,7 +721,8 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     const trav_dev t8 = make_traversal(tr, ns, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
-#define CASE(W) case W: sell8v_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8); break;
+#define CASE(W) case W: if (g_sell8_variant == 0 && W <= 8) sell8_pair_kernel<V, (W <= 8 ? W : 8), true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8); \
+        else sell8v_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
         default: sell8v_kernel<V, 0><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8);
@@ -612,7 +761,7 @@ int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *pt
     VEXHIP_TRY(hipStreamSynchronize(s));
     VEXHIP_TRY(hipFree(d));
     if (std::getenv("VEXHIP_DEBUG")) std::fprintf(stderr, "sell8 analyze: count %d overflow %d\n", host[HASH_SLOTS], host[HASH_SLOTS + 1]);
-    if (host[HASH_SLOTS + 1] != 0 || host[HASH_SLOTS] > 255 || host[HASH_SLOTS] < 1) return 0;   // not a banded matrix
+    if (host[HASH_SLOTS + 1] != 0 || host[HASH_SLOTS] > 254 || host[HASH_SLOTS] < 1) return 0;   // not a banded matrix (codes 254 and 255 are padding)
     std::vector<int> table;
     for (int k = 0; k < HASH_SLOTS; ++k) if (host[k] != EMPTY) table.push_back(host[k]);
     std::sort(table.begin(), table.end());
@@ -623,6 +772,8 @@ int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *pt
     *ndeltas = host[HASH_SLOTS];
     return 0;
 }
+
+int vexhip_spmv_sell8_set_variant(int variant) { g_sell8_variant = variant; return 0; }
 
 int64_t vexhip_sell8v_bytes(int64_t n, int64_t w) { return (n + S8_ROWS - 1) / S8_ROWS * ((w + 1) / 2) * 2048; }
 

@@ -17,7 +17,7 @@ namespace vexhip {
 namespace {
 
 constexpr int ROWS = 512;
-constexpr int PAD8 = 255;
+constexpr unsigned PAD8 = 254;        // codes 254 and 255 are padding (sell8.hip, pair kernels)
 constexpr int MAX_NR = 4;
 
 typedef int    int2v    __attribute__((ext_vector_type(2)));
@@ -95,7 +95,7 @@ void spmm_sell8_kernel(long long n, long long nslices, V alpha, int append, int 
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
-                col[j][q] = (code != PAD8) ? i + q + s_delta[code] : -1;
+                col[j][q] = (code < PAD8) ? i + q + s_delta[code] : -1;
             }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
@@ -116,7 +116,7 @@ void spmm_sell8_kernel(long long n, long long nslices, V alpha, int append, int 
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned code = (cword >> (8 * ((j & 1) * 2 + q))) & 255u;
-                if (code != PAD8) {
+                if (code < PAD8) {
                     const long long cidx = i + q + s_delta[code];
 #pragma unroll
                     for (int k = 0; k < NR; ++k) sum[k][q] += vv[q] * io.x[k][cidx];
@@ -166,7 +166,7 @@ void spmm_sell8v_kernel(long long n, long long nslices, V alpha, int append, int
             for (int q = 0; q < 2; ++q) {
                 const int sh = 8 * ((j & 1) * 2 + q);
                 const unsigned code = (c[j >> 1] >> sh) & 255u;
-                col[j][q] = (code != PAD8) ? i + q + s_delta[code] : -1;
+                col[j][q] = (code < PAD8) ? i + q + s_delta[code] : -1;
                 val[j][q] = s_value[(vc[j >> 1] >> sh) & 255u];
             }
 #pragma unroll
@@ -188,7 +188,7 @@ void spmm_sell8v_kernel(long long n, long long nslices, V alpha, int append, int
             for (int q = 0; q < 2; ++q) {
                 const int sh = 8 * ((j & 1) * 2 + q);
                 const unsigned code = (cword >> sh) & 255u;
-                if (code != PAD8) {
+                if (code < PAD8) {
                     const long long cidx = i + q + s_delta[code];
                     const V v = s_value[(vword >> sh) & 255u];
 #pragma unroll
@@ -235,11 +235,11 @@ void spmm_sell_kernel(long long n, long long nslices, V alpha, int append, int e
 #pragma unroll
             for (int j = 0; j < W; ++j)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) xv[j][q] = (c[j][q] != -1) ? io.x[k][c[j][q]] : V(0);
+                for (int q = 0; q < 2; ++q) xv[j][q] = (c[j][q] >= 0) ? io.x[k][c[j][q]] : V(0);
 #pragma unroll
             for (int j = 0; j < W; ++j)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) if (c[j][q] != -1) sum[k][q] += v[j][q] * xv[j][q];
+                for (int q = 0; q < 2; ++q) if (c[j][q] >= 0) sum[k][q] += v[j][q] * xv[j][q];
         }
     } else {
         for (int j = 0; j < w; ++j) {
@@ -247,7 +247,7 @@ void spmm_sell_kernel(long long n, long long nslices, V alpha, int append, int e
             const V2 v = *reinterpret_cast<const V2 *>(vp + (long long)j * ROWS);
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                if (c[q] != -1) {
+                if (c[q] >= 0) {
 #pragma unroll
                     for (int k = 0; k < NR; ++k) sum[k][q] += v[q] * io.x[k][c[q]];
                 }

@@ -14,12 +14,15 @@
 // within the stated 1e-10 tolerance.
 #include "common.hpp"
 #include "traversal.hpp"
+#include "pairing.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cstring>
 #include <vector>
 
 namespace vexhip {
+extern int g_sell8_variant;                                   // sell8.hip: 0 = pair kernels (default), 1 = one gather per entry
 namespace {
 
 typedef int    int2v  __attribute__((ext_vector_type(2)));
@@ -309,17 +312,17 @@ void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
 #pragma unroll
         for (int j = 0; j < W; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) xv[j][q] = (c[j][q] != -1) ? x[c[j][q]] : V(0);
+            for (int q = 0; q < 2; ++q) xv[j][q] = (c[j][q] >= 0) ? x[c[j][q]] : V(0);
 #pragma unroll
         for (int j = 0; j < W; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) if (c[j][q] != -1) sum[q] += v[j][q] * xv[j][q];
+            for (int q = 0; q < 2; ++q) if (c[j][q] >= 0) sum[q] += v[j][q] * xv[j][q];
     } else {
         for (int j = 0; j < w; ++j) {
             int c[2]; V v[2];
             ell_load<V, 2, NT>(cp + j * SELL_ROWS, vp + j * SELL_ROWS, c, v);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) if (c[q] != -1) sum[q] += v[q] * x[c[q]];
+            for (int q = 0; q < 2; ++q) if (c[q] >= 0) sum[q] += v[q] * x[c[q]];
         }
     }
     if (csr_ptr) {
@@ -331,23 +334,99 @@ void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
     store_pair<V>(n, i, alpha, append, sum, y);
 }
 
+// Pair form of sell_kernel (the default for W <= 8; reasoning and measurements: sell8.hip, "PAIR kernels").
+// The two rows of a lane are aligned by diagonal at fill time, so in almost every ELL column their columns are
+// c and c + 1: ONE 16-byte load of x instead of two 8-byte gathers -- these products are bound by the number of
+// vector-memory instructions.  Padding is -1 ("the partner's 16-byte load may cover me") or -2 (it would leave
+// x); lanes whose two columns are not adjacent take an 8-byte load per real entry (rare branch).  Gathered values
+// of padding entries are replaced by 0 and their stored value is 0: adding +-0 leaves the sum bit-identical.
+template <typename V, int W>
+__global__ __launch_bounds__(256)
+void sell_pair_kernel(long long n, long long nslices, V alpha, int append,
+        const char *__restrict__ sell,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
+{
+    constexpr long long SLICE = (long long)W * SELL_ROWS * (4 + (long long)sizeof(V));
+    typedef V V2 __attribute__((ext_vector_type(2)));
+    const long long s = traversal_block(trav, nslices);
+    if (s < 0) return;
+    const int r = 2 * threadIdx.x;
+    const long long i = s * SELL_ROWS + r;
+    const int *cp = reinterpret_cast<const int *>(sell + s * SLICE) + r;
+    const V *vp = reinterpret_cast<const V *>(sell + s * SLICE + (long long)W * SELL_ROWS * 4) + r;
+    int c[W][2]; V v[W][2];
+#pragma unroll
+    for (int j = 0; j < W; ++j) ell_load<V, 2, true>(cp + j * SELL_ROWS, vp + j * SELL_ROWS, c[j], v[j]);
+    V xv[W][2];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int c0 = c[j][0], c1 = c[j][1];
+        const bool m0 = c0 >= 0, m1 = c1 >= 0;
+        const bool pair = (m0 && m1) ? (c1 == c0 + 1) : (m0 ? c1 == -1 : (m1 ? c0 == -1 : true));
+        // the 16-byte load is skipped only when NO lane of the wave has a pair in this column (matrices without
+        // band structure); lanes without one read their own stored values instead
+        const bool use16 = pair && (m0 || m1);
+        V2 p = {V(0), V(0)};
+        if (__builtin_amdgcn_ballot_w64(use16) != 0) {
+            const V *px = use16 ? x + (m0 ? (long long)c0 : (long long)c1 - 1) : vp;
+            __builtin_memcpy(&p, px, sizeof(V2));
+        }
+        xv[j][0] = p.x; xv[j][1] = p.y;
+        if (!pair) {
+            if (m0) xv[j][0] = x[c0];
+            if (m1) xv[j][1] = x[c1];
+        }
+        xv[j][0] = m0 ? xv[j][0] : V(0);
+        xv[j][1] = m1 ? xv[j][1] : V(0);
+    }
+    V sum[2] = {V(0), V(0)};
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sum[q] += v[j][q] * xv[j][q];
+    if (csr_ptr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (i + q < n)
+                for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+    }
+    store_pair<V>(n, i, alpha, append, sum, y);
+}
+
+// One lane per row PAIR: the entries of rows 2t and 2t+1 are aligned by diagonal (pairing.hpp); the empty half of
+// a column is -1 when the partner's 16-byte load stays inside x (max_col: largest column of the ELL part), else -2.
 template <typename V>
 __global__ __launch_bounds__(256)
 void sell_fill_kernel(long long n, long long nslices, int w,
         const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
-        char *__restrict__ sell)
+        const int *__restrict__ max_col_p, char *__restrict__ sell)
 {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nslices * SELL_ROWS;
-         i += (long long)gridDim.x * blockDim.x) {
-        int b = 0, e = 0;
-        if (i < n) { b = ptr[i]; e = ptr[i + 1]; }
+    const int max_col = *max_col_p;
+    for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (SELL_ROWS / 2);
+         pr += (long long)gridDim.x * blockDim.x) {
+        const long long i = 2 * pr;
+        int b[2] = {0, 0}, e[2] = {0, 0};
+        for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
         char *slice = sell + (i / SELL_ROWS) * ((long long)w * SELL_ROWS * (4 + (long long)sizeof(V)));
         int *sc = reinterpret_cast<int *>(slice) + (i % SELL_ROWS);
         V *sv = reinterpret_cast<V *>(slice + (long long)w * SELL_ROWS * 4) + (i % SELL_ROWS);
+        pair_walk pw;
+        pw.init(col, i, b[0], min(e[0] - b[0], w), b[1], min(e[1] - b[1], w), w);
         for (int j = 0; j < w; ++j) {
-            bool in = b + j < e;
-            sc[j * SELL_ROWS] = in ? col[b + j] : -1;
-            sv[j * SELL_ROWS] = in ? val[b + j] : V(0);
+            int en[2];
+            pw.next(en[0], en[1]);
+            for (int q = 0; q < 2; ++q) {
+                int c; V v = V(0);
+                if (en[q] >= 0) { c = col[en[q]]; v = val[en[q]]; }
+                else if (en[1 - q] < 0) c = -1;
+                else {
+                    const long long first = (long long)col[en[1 - q]] - (1 - q);     // where the partner's 16-byte load starts
+                    c = (first >= 0 && first + 1 <= max_col) ? -1 : -2;
+                }
+                sc[j * SELL_ROWS + q] = c;
+                sv[j * SELL_ROWS + q] = v;
+            }
         }
     }
 }
@@ -511,7 +590,8 @@ int spmv_sell(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     trav_dev order = {nullptr, 0, 0, 0};
     if (ordered) order = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
-#define CASE(W) case W: sell_kernel<V, W, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order); break;
+#define CASE(W) case W: if (g_sell8_variant == 0) sell_pair_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, sc, cp, cc, cv, x, y, order); \
+        else sell_kernel<V, W, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
         default: sell_kernel<V, 0, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order);
@@ -527,10 +607,19 @@ int sell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, 
     if (n == 0) return 0;
     VEXHIP_SET_DEVICE(dev);
     long long ns = (n + SELL_ROWS - 1) / SELL_ROWS;
-    int grid = (int)std::min<int64_t>((ns * SELL_ROWS + 255) / 256, (int64_t)info(dev).cus * 16);
-    sell_fill_kernel<V><<<grid, 256, 0, as_stream(stream)>>>(n, ns, (int)w, ptr, col, val, static_cast<char *>(sell));
-    VEXHIP_LAUNCH_CHECK();
-    return 0;
+    int grid = (int)std::min<int64_t>((ns * (SELL_ROWS / 2) + 255) / 256, (int64_t)info(dev).cus * 16);
+    int *max_col = nullptr;                                   // largest column of the ELL part (bounds the 16-byte gathers)
+    VEXHIP_TRY(hipMalloc(&max_col, sizeof(int)));
+    hipError_t e = hipMemsetAsync(max_col, 0xff, sizeof(int), as_stream(stream));
+    if (e == hipSuccess) {
+        ell_max_col_kernel<<<std::max(1, (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16)), 256, 0, as_stream(stream)>>>(
+                n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, max_col);
+        sell_fill_kernel<V><<<std::max(1, grid), 256, 0, as_stream(stream)>>>(n, ns, (int)w, ptr, col, val, max_col, static_cast<char *>(sell));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    (void)hipFree(max_col);
+    return check(e, __FILE__, __LINE__);
 }
 
 // Agreement of every ELL column j with a constant offset col - row == ref[j].
@@ -547,7 +636,7 @@ void ell_offset_agree_kernel(long long n, int w, long long pitch, const int *__r
             long long e = pitch > 0 ? i + j * pitch
                                     : (i / SELL_ROWS) * ((long long)w * SELL_ROWS * (4 - pitch) / 4) + (long long)j * SELL_ROWS + i % SELL_ROWS;
             int c = ell_col[e];
-            local += (c != -1 && (long long)c - i == off) ? 1ull : 0ull;
+            local += (c >= 0 && (long long)c - i == off) ? 1ull : 0ull;
         }
         for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
         if ((threadIdx.x & 63) == 0 && local) atomicAdd(&agree[j], local);
@@ -597,7 +686,7 @@ static int build_order(int dev, void *stream, int64_t n, int64_t w, int64_t pitc
         VEXHIP_TRY(hipStreamSynchronize(s));
         for (int j = 0; j < w; ++j) {
             std::vector<long long> offs;
-            for (int k = 0; k < ns; ++k) if (sample[(size_t)k * w + j] != -1) offs.push_back((long long)sample[(size_t)k * w + j] - rows[k]);
+            for (int k = 0; k < ns; ++k) if (sample[(size_t)k * w + j] >= 0) offs.push_back((long long)sample[(size_t)k * w + j] - rows[k]);
             std::sort(offs.begin(), offs.end());
             size_t best = 0;
             for (size_t a = 0; a < offs.size();) {

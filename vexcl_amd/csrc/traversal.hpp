@@ -9,18 +9,26 @@ namespace vexhip {
 
 struct trav_dev { const int *order; int chunk, planes, plane_blocks; };
 
-__device__ __forceinline__ long long traversal_block(const trav_dev &t, long long nblocks) {
-    const long long b = blockIdx.x;
-    if (t.order) return t.order[b];
+/// Slice of virtual block `vb` (the kernels that loop over several slices pass vb = blockIdx.x + k * gridDim.x;
+/// a grid that is a multiple of 8 keeps every block on the XCD strip it started on).  Launch grids are
+/// < 2^31 (checked on the host), so the strip arithmetic is 32-bit: a 64-bit division costs a
+/// workgroup ~100 instructions of prologue, and the looping kernels pay it per slice.
+__device__ __forceinline__ long long traversal_slice(const trav_dev &t, long long nblocks, unsigned vb) {
+    if (t.order) return t.order[vb];
     if (t.chunk > 0) {
-        const long long k = b & 7, q = b >> 3;
-        const long long i = q % t.chunk, r = q / t.chunk;
-        const long long p = r % t.planes, tile = r / t.planes;
-        const long long l = tile * 8 * t.chunk + k * t.chunk + i;
-        const long long lb = p * t.plane_blocks + l;
+        const unsigned k = vb & 7u, q = vb >> 3;
+        const unsigned chunk = (unsigned)t.chunk, planes = (unsigned)t.planes;
+        const unsigned r = q / chunk, i = q - r * chunk;
+        const unsigned tile = r / planes, p = r - tile * planes;
+        const long long l = (long long)tile * (8 * chunk) + k * chunk + i;
+        const long long lb = (long long)p * t.plane_blocks + l;
         return (l < t.plane_blocks && lb < nblocks) ? lb : -1;
     }
-    return b < nblocks ? b : -1;
+    return vb < nblocks ? (long long)vb : -1;
+}
+
+__device__ __forceinline__ long long traversal_block(const trav_dev &t, long long nblocks) {
+    return traversal_slice(t, nblocks, blockIdx.x);
 }
 
 /// y[i], y[i+1] (=|+=) alpha * sum[0], sum[1] -- the two consecutive rows a lane of the SELL kernels owns.
