@@ -249,6 +249,42 @@ int vexhip_spmv_sell8v_f32_i32(int dev, void *stream, int64_t n, float alpha, in
  *   variant 1:           one 8-byte gather per entry (round 1).                                                     */
 int vexhip_spmv_sell8_set_variant(int variant);
 
+/* ---- vex::SpMat on one device: ONE object that owns the storage selection -------------------------------------
+ * Replaces the per-device matrix objects the reference builds in SpMat's constructor (vexcl/spmat.hpp:84-104:
+ * SpMatCSR for CPU devices, SpMatHELL for GPUs; spmat/hybrid_ell.inl:60-216) and their mul() entry points
+ * (spmat/csr.inl:186-232, hybrid_ell.inl:218-300).  Built from DEVICE CSR arrays (int32 indices, sorted or not);
+ * nothing is staged through the host.  create() decides, in this order: hybrid-ELL width and CSR tail
+ * (hybrid_ell.inl:103-110) -> 1-byte diagonal codes if the ELL part uses <= 254 diagonals -> 1-byte value codes if
+ * it holds <= 255 distinct values -> otherwise 32-bit columns; plain CSR when the ELL part would be empty.
+ * `format` pins a less compact storage (tests, A/B): AUTO = most compact the matrix allows.
+ * apply: y (=|+=) alpha * A * x, bit-identical for every storage (products rounded, rows folded in CSR order).   */
+typedef struct vexhip_spmat vexhip_spmat;
+enum { VEXHIP_SPMAT_AUTO = 0,      /* create(): most compact storage; info: never reported                     */
+       VEXHIP_SPMAT_SELL8V = 1,    /* diagonal codes + value codes (2 B per entry)                                */
+       VEXHIP_SPMAT_SELL8 = 2,     /* diagonal codes, values as they are (1 + sizeof(V) B per entry)              */
+       VEXHIP_SPMAT_SELL = 3,      /* 32-bit columns (4 + sizeof(V) B per entry)                                  */
+       VEXHIP_SPMAT_CSR = 4 };     /* the CSR arrays themselves (csr_stream_kernel)                               */
+enum { VEXHIP_SPMAT_BORROW_CSR = 1 };   /* format CSR: keep the caller's arrays instead of copying them (caller keeps them alive) */
+typedef struct vexhip_spmat_info {
+    int32_t format, value_type, device, ndeltas, nvalues, reserved;
+    int64_t rows, nnz, ell_width, tail_nnz, sell_bytes;
+    int64_t matrix_bytes;           /* bytes of matrix data one product streams (storage actually read)          */
+    const void *sell; const int32_t *deltas; const void *values;           /* SELL storage (make_inline reads it)  */
+    const int32_t *csr_ptr, *csr_col; const void *csr_val;                 /* CSR tail, or the matrix (format CSR) */
+    vexhip_traversal traversal;
+} vexhip_spmat_info;
+int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int format, int flags, vexhip_spmat **out);
+int vexhip_spmat_create_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int format, int flags, vexhip_spmat **out);
+int vexhip_spmat_destroy(vexhip_spmat *A);
+int vexhip_spmat_apply_f64(const vexhip_spmat *A, void *stream, double alpha, int append, const double *x, double *y);
+int vexhip_spmat_apply_f32(const vexhip_spmat *A, void *stream, float alpha, int append, const float *x, float *y);
+/* Y[k] (=|+=) alpha * A * X[k], k < nrhs, reading the matrix once per group of four (x, y: HOST arrays of device pointers) */
+int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, double alpha, int append, const double *const *x, double *const *y);
+int vexhip_spmat_apply_multi_f32(const vexhip_spmat *A, void *stream, int nrhs, float alpha, int append, const float *const *x, float *const *y);
+int vexhip_spmat_get_info(const vexhip_spmat *A, vexhip_spmat_info *info);
+
 /* Multi-right-hand-side products  y[k] (+)= alpha * A * x[k],  k < nrhs  -- `SpMat * multivector`
  * (vexcl/spmat.hpp:388-398, which applies the product once per component; tests/spmv.cpp:262-305).
  * One launch per group of up to four right-hand sides reads the matrix ONCE; each y[k] is
@@ -389,6 +425,11 @@ int vexhip_poisson3d_csr_f64_i32(int dev, void *stream, int64_t n, int32_t *ptr,
 int vexhip_poisson3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end,
         int32_t *ptr, int32_t *col, double *val);
 int64_t vexhip_poisson3d_strip_nnz(int64_t n, int64_t row_begin, int64_t row_end);
+/* The same 7-point pattern with a different coefficient on every face: -div(k grad u), k = 0.5 + u(hash(seed, face)),
+ * u in [0,1) -- nnz distinct values, what a finite-volume code assembles (no value coding applies).  Same row strip
+ * convention and nnz as the Poisson generator; restated on the host in oracle/vex_oracle.c (bit-identical values).   */
+int vexhip_diffusion3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end, uint64_t seed,
+        int32_t *ptr, int32_t *col, double *val);
 /* counter-hash pseudo-random fill (same hash on host: tests restate it):
  * u32: full range; f64/f32: U[0,1).                                           */
 int vexhip_fill_hash(int dev, void *stream, int dtype, uint64_t seed, void *out, int64_t n);

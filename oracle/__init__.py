@@ -78,6 +78,18 @@ def poisson3d(n, index_dtype=np.int32, val_dtype=np.float64):
     return ptr, col, val
 
 
+def diffusion3d(n, seed=7):
+    """Variable-coefficient 7-point operator (nnz distinct values); restates vexhip_diffusion3d_* bit for bit."""
+    L = lib()
+    N = n ** 3
+    nnz = L.vxo_poisson3d_nnz(_i64(n))
+    ptr = np.empty(N + 1, dtype=np.int32)
+    col = np.empty(nnz, dtype=np.int32)
+    val = np.empty(nnz, dtype=np.float64)
+    L.vxo_diffusion3d_csr_i32(_i64(n), ctypes.c_uint64(seed), _p(ptr), _p(col), _p(val))
+    return ptr, col, val
+
+
 def poisson3d_nnz(n):
     return int(lib().vxo_poisson3d_nnz(_i64(n)))
 

@@ -70,6 +70,52 @@ void vxo_poisson3d_csr_f32_i32(int64_t n, int32_t *ptr, int32_t *col, float *val
 { POISSON_BODY(int32_t, int32_t) }
 
 /* ------------------------------------------------------------------------- */
+/* Variable-coefficient 7-point operator (bench.py's general-matrix row; NOT  */
+/* a reference generator): the Poisson pattern above with a coefficient per   */
+/* face, k = 0.5 + u, u = (splitmix64 finalizer of seed + (3*lo + axis + 1)*g) */
+/* >> 11 scaled by 2^-53; lo = the lower grid point of the face.  Restates     */
+/* vexcl_amd/csrc/misc.hip poisson_kernel<V, true> operation for operation.    */
+/* ------------------------------------------------------------------------- */
+static uint64_t vxo_mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static double vxo_face(uint64_t seed, int64_t lo, int axis)
+{
+    uint64_t h = vxo_mix64(seed + ((uint64_t)lo * 3ull + (uint64_t)axis + 1ull) * 0x9E3779B97F4A7C15ull);
+    return 0.5 + (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+void vxo_diffusion3d_csr_i32(int64_t n, uint64_t seed, int32_t *ptr, int32_t *col, double *val)
+{
+    const double h2i = (double)(n - 1) * (double)(n - 1);
+    const int64_t nn = n * n;
+    int64_t idx = 0, nz = 0;
+    ptr[0] = 0;
+    for (int64_t k = 0; k < n; k++)
+        for (int64_t j = 0; j < n; j++)
+            for (int64_t i = 0; i < n; i++, idx++) {
+                if (i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1) {
+                    col[nz] = (int32_t)idx; val[nz] = 1; nz++;
+                } else {
+                    const double k0 = vxo_face(seed, idx - nn, 2), k1 = vxo_face(seed, idx - n, 1), k2 = vxo_face(seed, idx - 1, 0);
+                    const double k4 = vxo_face(seed, idx, 0), k5 = vxo_face(seed, idx, 1), k6 = vxo_face(seed, idx, 2);
+                    col[nz] = (int32_t)(idx - nn); val[nz] = -h2i * k0; nz++;
+                    col[nz] = (int32_t)(idx - n);  val[nz] = -h2i * k1; nz++;
+                    col[nz] = (int32_t)(idx - 1);  val[nz] = -h2i * k2; nz++;
+                    col[nz] = (int32_t)(idx);      val[nz] = h2i * (((((k0 + k1) + k2) + k4) + k5) + k6); nz++;
+                    col[nz] = (int32_t)(idx + 1);  val[nz] = -h2i * k4; nz++;
+                    col[nz] = (int32_t)(idx + n);  val[nz] = -h2i * k5; nz++;
+                    col[nz] = (int32_t)(idx + nn); val[nz] = -h2i * k6; nz++;
+                }
+                ptr[idx + 1] = (int32_t)nz;
+            }
+}
+
+/* ------------------------------------------------------------------------- */
 /* CSR SpMV.  Kernel text vexcl/spmat/csr.inl:163-170:                        */
 /*     sum = 0; for j in [row[i], row[i+1]): sum += val[j]*in[col[j]];        */
 /*     out[i] (= | +=) scale*sum;                                             */

@@ -54,9 +54,28 @@ class SpMat {
             if (queue.size() > 1) setup_exchange(ghosts);
         }
 
+        /// From DEVICE CSR arrays (int32 row pointers and columns, `nonzeros` entries): nothing is staged through the
+        /// host -- the library converts on the device (vexhip_spmat_create).  The reference only builds from host
+        /// arrays (spmat.hpp:71-106: 12 GB of host CSR at 512^3); this is the constructor the headline runs through.
+        /// Single-device contexts; a multi-device context partitions with the host-array constructor above.
+        SpMat(const std::vector<backend::command_queue> &queue, size_t n, size_t m, size_t nonzeros,
+              const backend::device_vector<int> &row, const backend::device_vector<int> &col, const backend::device_vector<val_t> &val)
+            : queue(queue), part(vex::partition(n, queue)), col_part(vex::partition(m, queue)),
+              nrows(n), ncols(m), nnz(nonzeros), mtx(queue.size())
+        {
+            static_assert(std::is_same<val_t, double>::value || std::is_same<val_t, float>::value,
+                    "SpMat value type must be float or double");
+            precondition(queue.size() == 1, "SpMat from device arrays: single-device contexts only");
+            precondition(row.size() == n + 1 && col.size() >= nonzeros && val.size() >= nonzeros, "SpMat: inconsistent CSR arrays");
+            squeue.push_back(backend::duplicate_queue(queue[0]));
+            mtx[0] = std::make_shared<device_part>(queue[0], n, nonzeros, row, col, val);
+        }
+
         size_t rows() const { return nrows; }
         size_t cols() const { return ncols; }
         size_t nonzeros() const { return nnz; }
+        /// Storage the library chose for device d's local part (VEXHIP_SPMAT_*; info.matrix_bytes = bytes a product streams).
+        const vexhip_spmat_info &storage_info(unsigned d = 0) const { return mtx[d]->loc.info; }
 
         /// y = alpha * A * x  or  y += alpha * A * x  (spmat.hpp:120-185).
         template <class T>
@@ -91,19 +110,25 @@ class SpMat {
         const std::vector<backend::command_queue> &queue_list() const { return queue; }
         const std::vector<size_t> &row_partition() const { return part; }
 
-        // ELL part in SELL-512 storage (include/vexhip.h): slice-major, one slice = the 512
-        // rows of one workgroup; element (r, j) of slice s at s*w*512 + j*512 + r.
+        // One device's LOCAL matrix: a vexhip_spmat (include/vexhip.h) -- the library object that owns the storage
+        // selection (hybrid-ELL width, diagonal / value codes, 32-bit columns or plain CSR) -- plus what
+        // vexhip_spmat_get_info reports about it (make_inline reads the arrays in generated code).
         struct matrix_arrays {
             size_t n = 0, nnz = 0;
-            long ell_w = 0;
-            backend::device_vector<char> sell;                              // columns (or 1-byte diagonal codes) then values, per slice
-            backend::device_vector<int> deltas; int ndeltas = -1;           // SELL8: sorted diagonal table (vexhip.h)
-            backend::device_vector<val_t> values; int nvalues = -1;         // SELL8V: sorted value table, values coded too
-            vexhip_traversal trav = {0, 0, 0, 0, nullptr};                  // traversal order (grid 0 = plain)
+            std::shared_ptr<vexhip_spmat> handle;
+            vexhip_spmat_info info = vexhip_spmat_info();
+            // row-subset CSR of the REMOTE part (and the borrowed arrays of a local part kept in CSR)
             backend::device_vector<int> csr_ptr, csr_col; backend::device_vector<val_t> csr_val;
             size_t csr_nnz = 0;
             bool empty() const { return nnz == 0; }
         };
+
+        static int spmat_create(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int fmt, int flags, vexhip_spmat **o) { return vexhip_spmat_create_f64_i32(dev, s, n, p, c, v, fmt, flags, o); }
+        static int spmat_create(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int fmt, int flags, vexhip_spmat **o) { return vexhip_spmat_create_f32_i32(dev, s, n, p, c, v, fmt, flags, o); }
+        static int spmat_apply(const vexhip_spmat *A, void *s, double a, int app, const double *x, double *y) { return vexhip_spmat_apply_f64(A, s, a, app, x, y); }
+        static int spmat_apply(const vexhip_spmat *A, void *s, float a, int app, const float *x, float *y) { return vexhip_spmat_apply_f32(A, s, a, app, x, y); }
+        static int spmat_apply_multi(const vexhip_spmat *A, void *s, int k, double a, int app, const double *const *x, double *const *y) { return vexhip_spmat_apply_multi_f64(A, s, k, a, app, x, y); }
+        static int spmat_apply_multi(const vexhip_spmat *A, void *s, int k, float a, int app, const float *const *x, float *const *y) { return vexhip_spmat_apply_multi_f32(A, s, k, a, app, x, y); }
 
         struct device_part {
             matrix_arrays loc, rem;
@@ -136,7 +161,12 @@ class SpMat {
                     rptr.push_back(static_cast<int>(rcol.size()));
                 }
                 precondition(col_end - col_begin < (1ull << 31), "SpMat: more than 2^31 columns on one device");
-                upload(q, loc, lptr, lcol, lval, use_ell());
+                {
+                    backend::device_vector<int> dptr(q, lptr.size(), lptr.data());
+                    backend::device_vector<int> dcol(q, lcol.size(), lcol.data());
+                    backend::device_vector<val_t> dval(q, lval.size(), lval.data());
+                    set_local(q, dptr, dcol, dval, lcol.size());
+                }
                 // remote part: only the rows that reach a ghost column are stored (row list + compact CSR)
                 rem.n = n; rem.nnz = rcol.size();
                 if (rem.nnz) {
@@ -150,6 +180,16 @@ class SpMat {
                     rem.csr_nnz = rem.nnz;
                 }
             }
+
+            /// One device holding the whole matrix, given as DEVICE CSR arrays (int32 indices): no host staging.
+            device_part(const backend::command_queue &q, size_t rows, size_t nonzeros, const backend::device_vector<int> &dptr,
+                    const backend::device_vector<int> &dcol, const backend::device_vector<val_t> &dval)
+                : n(rows)
+            {
+                set_local(q, dptr, dcol, dval, nonzeros);
+                rem.n = n; rem.nnz = 0;
+            }
+
             backend::device_vector<int> rem_rows;
 
             static bool use_ell() {
@@ -160,110 +200,18 @@ class SpMat {
 #endif
             }
 
-            void upload(const backend::command_queue &q, matrix_arrays &A, const std::vector<int> &ptr,
-                    const std::vector<int> &col, const std::vector<val_t> &val, bool ell)
+            /// The local part from device CSR arrays (columns already local): the library picks the storage.
+            void set_local(const backend::command_queue &q, const backend::device_vector<int> &dptr,
+                    const backend::device_vector<int> &dcol, const backend::device_vector<val_t> &dval, size_t nonzeros)
             {
-                A.n = n; A.nnz = col.size();
-                if (!A.nnz || !n) return;
-                backend::device_vector<int> dptr(q, ptr.size(), ptr.data());
-                backend::device_vector<int> dcol(q, col.size(), col.data());
-                backend::device_vector<val_t> dval(q, val.size(), val.data());
-                if (!ell) { A.csr_ptr = dptr; A.csr_col = dcol; A.csr_val = dval; A.csr_nnz = A.nnz; return; }
-                int dev = q.device_ordinal();
-                int64_t w = 0, tail = 0;
-                backend::check(vexhip_hell_analyze_i32(dev, q.raw(), (int64_t)n, dptr.raw(), &w, &tail));
-                if (w == 0) { A.csr_ptr = dptr; A.csr_col = dcol; A.csr_val = dval; A.csr_nnz = A.nnz; return; }
-                A.ell_w = (long)w; A.csr_nnz = (size_t)tail;
-                if (tail) {     // rows wider than the ELL width keep their tail in CSR (hybrid_ell.inl:166-198)
-                    A.csr_ptr = backend::device_vector<int>(q, n + 1); A.csr_col = backend::device_vector<int>(q, tail); A.csr_val = backend::device_vector<val_t>(q, tail);
-                    backend::check(fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, (int64_t)alignup(n, 16),
-                                nullptr, nullptr, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw()));
-                }
-                // banded / stencil matrices (<= 255 distinct diagonals): 1-byte diagonal codes instead of 32-bit columns
-                backend::device_vector<int> deltas(q, 256);
-                int nd = -1;
-                backend::check(vexhip_sell8_analyze_i32(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), w, deltas.raw(), &nd));
-                if (nd > 0) {
-                    A.deltas = deltas; A.ndeltas = nd;
-                    // ... and at most 255 distinct values (constant-coefficient stencils): 1-byte value codes too
-                    backend::device_vector<val_t> values(q, 256);
-                    int nv = -1;
-                    backend::check(sell8v_analyze(dev, q.raw(), (int64_t)n, dptr.raw(), dval.raw(), w, values.raw(), &nv));
-                    if (nv > 0) {
-                        A.values = values; A.nvalues = nv;
-                        A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell8v_bytes((int64_t)n, w));
-                        backend::check(sell8v_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, deltas.raw(), nd,
-                                    values.raw(), nv, A.sell.raw(), &A.trav));
-                    } else {
-                        A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell8_bytes((int64_t)n, w, (int)sizeof(val_t)));
-                        backend::check(sell8_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, deltas.raw(), nd, A.sell.raw(), &A.trav));
-                    }
-                } else {
-                    A.sell = backend::device_vector<char>(q, (size_t)vexhip_sell_bytes((int64_t)n, w, (int)sizeof(val_t)));
-                    backend::check(sell_fill(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), w, A.sell.raw()));
-                    backend::check(vexhip_sell_order_i32(dev, q.raw(), (int64_t)n, w, (int)sizeof(val_t), A.sell.raw(), 0, nullptr, 0, &A.trav));
-                }
-                q.finish();
-            }
-
-            static int sell8v_analyze(int dev, void *s, int64_t n, const int *p, const double *v, int64_t w, double *vals, int *nv) { return vexhip_sell8v_analyze_f64_i32(dev, s, n, p, v, w, vals, nv); }
-            static int sell8v_analyze(int dev, void *s, int64_t n, const int *p, const float *v, int64_t w, float *vals, int *nv) { return vexhip_sell8v_analyze_f32_i32(dev, s, n, p, v, w, vals, nv); }
-            static int sell8v_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, const int *d, int nd, const double *vals, int nv, void *sl, vexhip_traversal *t) { return vexhip_sell8v_fill_f64_i32(dev, s, n, p, c, v, w, d, nd, vals, nv, sl, t); }
-            static int sell8v_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, const int *d, int nd, const float *vals, int nv, void *sl, vexhip_traversal *t) { return vexhip_sell8v_fill_f32_i32(dev, s, n, p, c, v, w, d, nd, vals, nv, sl, t); }
-            static int sell8_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, const int *d, int nd, void *sl, vexhip_traversal *t) { return vexhip_sell8_fill_f64_i32(dev, s, n, p, c, v, w, d, nd, sl, t); }
-            static int sell8_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, const int *d, int nd, void *sl, vexhip_traversal *t) { return vexhip_sell8_fill_f32_i32(dev, s, n, p, c, v, w, d, nd, sl, t); }
-            static int sell_fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, void *sl) { return vexhip_sell_fill_f64_i32(dev, s, n, p, c, v, w, sl); }
-            static int sell_fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, void *sl) { return vexhip_sell_fill_f32_i32(dev, s, n, p, c, v, w, sl); }
-
-            static int fill(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t w, int64_t pitch,
-                    int *ec, double *ev, int *cp, int *cc, double *cv) { return vexhip_hell_fill_f64_i32(dev, s, n, p, c, v, w, pitch, ec, ev, cp, cc, cv); }
-            static int fill(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t w, int64_t pitch,
-                    int *ec, float *ev, int *cp, int *cc, float *cv) { return vexhip_hell_fill_f32_i32(dev, s, n, p, c, v, w, pitch, ec, ev, cp, cc, cv); }
-
-            static int spmv(int dev, void *s, int64_t n, double a, int app, const matrix_arrays &A, const double *x, double *y) {
-                if (A.ell_w == 0 && A.csr_nnz)      // plain CSR storage: LDS-staged CSR kernel
-                    return vexhip_spmv_csr_f64_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
-                if (A.nvalues > 0)
-                    return vexhip_spmv_sell8v_f64_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                if (A.ndeltas > 0)
-                    return vexhip_spmv_sell8_f64_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                return vexhip_spmv_sell_f64_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(),
-                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-            }
-            static int spmv(int dev, void *s, int64_t n, float a, int app, const matrix_arrays &A, const float *x, float *y) {
-                if (A.ell_w == 0 && A.csr_nnz)
-                    return vexhip_spmv_csr_f32_i32(dev, s, n, a, app, A.csr_ptr.raw(), A.csr_col.raw(), A.csr_val.raw(), x, y);
-                if (A.nvalues > 0)
-                    return vexhip_spmv_sell8v_f32_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                if (A.ndeltas > 0)
-                    return vexhip_spmv_sell8_f32_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                return vexhip_spmv_sell_f32_i32(dev, s, n, a, app, A.ell_w, A.sell.raw(),
-                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-            }
-
-            static int spmm(int dev, void *s, int64_t n, int k, double a, int app, const matrix_arrays &A, const double *const *x, double *const *y) {
-                if (A.nvalues > 0)
-                    return vexhip_spmm_sell8v_f64_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                if (A.ndeltas > 0)
-                    return vexhip_spmm_sell8_f64_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                return vexhip_spmm_sell_f64_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(),
-                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-            }
-            static int spmm(int dev, void *s, int64_t n, int k, float a, int app, const matrix_arrays &A, const float *const *x, float *const *y) {
-                if (A.nvalues > 0)
-                    return vexhip_spmm_sell8v_f32_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(), A.values.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                if (A.ndeltas > 0)
-                    return vexhip_spmm_sell8_f32_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(), A.deltas.raw(),
-                            A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
-                return vexhip_spmm_sell_f32_i32(dev, s, n, k, a, app, A.ell_w, A.sell.raw(),
-                        A.csr_nnz ? A.csr_ptr.raw() : nullptr, A.csr_col.raw(), A.csr_val.raw(), x, y, &A.trav);
+                loc.n = n; loc.nnz = nonzeros;
+                if (!loc.nnz || !n) return;
+                vexhip_spmat *h = nullptr;
+                backend::check(spmat_create(q.device_ordinal(), q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(),
+                            use_ell() ? VEXHIP_SPMAT_AUTO : VEXHIP_SPMAT_CSR, VEXHIP_SPMAT_BORROW_CSR, &h));
+                loc.handle = std::shared_ptr<vexhip_spmat>(h, [](vexhip_spmat *p) { vexhip_spmat_destroy(p); });
+                backend::check(vexhip_spmat_get_info(h, &loc.info));
+                if (loc.info.format == VEXHIP_SPMAT_CSR) { loc.csr_ptr = dptr; loc.csr_col = dcol; loc.csr_val = dval; loc.csr_nnz = loc.nnz; }   // borrowed: keep alive
             }
 
             /// Local part times several vectors at once (pointers of this device's segments).
@@ -275,11 +223,7 @@ class SpMat {
                     if (!append) for (int c = 0; c < k; ++c) backend::check(vexhip_memset(dev, y[c], 0, n * sizeof(val_t), q.raw()));
                     return;
                 }
-                if (loc.ell_w == 0) {           // CSR-only storage: no multi-vector kernel, one product per component
-                    for (int c = 0; c < k; ++c) backend::check(spmv(dev, q.raw(), (int64_t)n, alpha, append ? 1 : 0, loc, x[c], y[c]));
-                    return;
-                }
-                backend::check(spmm(dev, q.raw(), (int64_t)n, k, alpha, append ? 1 : 0, loc, x, y));
+                backend::check(spmat_apply_multi(loc.handle.get(), q.raw(), k, alpha, append ? 1 : 0, x, y));
             }
 
             static int spmv_rows(int dev, void *s, int64_t nr, double a, const int *rows, const int *p, const int *c, const double *v, const double *x, double *y) {
@@ -295,7 +239,7 @@ class SpMat {
                     if (!append) backend::check(vexhip_memset(q.device_ordinal(), y.raw(), 0, n * sizeof(val_t), q.raw()));
                     return;
                 }
-                backend::check(spmv(q.device_ordinal(), q.raw(), (int64_t)n, alpha, append ? 1 : 0, loc, x.raw(), y.raw()));
+                backend::check(spmat_apply(loc.handle.get(), q.raw(), alpha, append ? 1 : 0, x.raw(), y.raw()));
             }
             void mul_remote(const backend::command_queue &q, const backend::device_vector<val_t> &ghosts,
                     backend::device_vector<val_t> &y, val_t alpha) const
@@ -509,13 +453,14 @@ struct inline_spmv : expression_base {
     }
     void set_args(arg_context &a) const {
         a.next();
-        const auto &L = A.part_of(a.device).loc;
-        a.krn.push_arg((long)L.ell_w);
-        a.krn.push_arg(static_cast<const char *>(L.sell.raw()));
-        a.krn.push_arg(static_cast<const int *>(L.ndeltas > 0 ? L.deltas.raw() : nullptr));
-        a.krn.push_arg(static_cast<const T *>(L.nvalues > 0 ? L.values.raw() : nullptr));
-        a.krn.push_arg(static_cast<const int *>(L.csr_nnz ? L.csr_ptr.raw() : nullptr));
-        a.krn.push_arg(static_cast<const int *>(L.csr_col.raw())); a.krn.push_arg(static_cast<const T *>(L.csr_val.raw()));
+        const auto &L = A.part_of(a.device).loc.info;      // zero-initialised when the local part is empty
+        const bool csr_rows = L.format == VEXHIP_SPMAT_CSR || L.tail_nnz > 0;
+        a.krn.push_arg((long)L.ell_width);
+        a.krn.push_arg(static_cast<const char *>(L.sell));
+        a.krn.push_arg(static_cast<const int *>(L.ndeltas > 0 ? L.deltas : nullptr));
+        a.krn.push_arg(static_cast<const T *>(L.nvalues > 0 ? L.values : nullptr));
+        a.krn.push_arg(static_cast<const int *>(csr_rows ? L.csr_ptr : nullptr));
+        a.krn.push_arg(static_cast<const int *>(L.csr_col)); a.krn.push_arg(static_cast<const T *>(L.csr_val));
         a.krn.push_arg(static_cast<const T *>(x(a.device).raw()));
     }
     void get_props(prop_context &p) const {

@@ -54,6 +54,21 @@ class Traversal(ctypes.Structure):
                 ("plane_blocks", ctypes.c_int64), ("order", ctypes.c_void_p)]
 
 
+class SpMatInfo(ctypes.Structure):
+    """vexhip_spmat_info (include/vexhip.h)."""
+    _fields_ = [("format", ctypes.c_int32), ("value_type", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("ndeltas", ctypes.c_int32), ("nvalues", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("rows", ctypes.c_int64), ("nnz", ctypes.c_int64), ("ell_width", ctypes.c_int64),
+                ("tail_nnz", ctypes.c_int64), ("sell_bytes", ctypes.c_int64), ("matrix_bytes", ctypes.c_int64),
+                ("sell", ctypes.c_void_p), ("deltas", ctypes.c_void_p), ("values", ctypes.c_void_p),
+                ("csr_ptr", ctypes.c_void_p), ("csr_col", ctypes.c_void_p), ("csr_val", ctypes.c_void_p),
+                ("traversal", Traversal)]
+
+
+SPMAT_AUTO, SPMAT_SELL8V, SPMAT_SELL8, SPMAT_SELL, SPMAT_CSR = range(5)
+SPMAT_BORROW_CSR = 1
+SPMAT_NAMES = {SPMAT_SELL8V: "sell8v", SPMAT_SELL8: "sell8", SPMAT_SELL: "sell32", SPMAT_CSR: "csr"}
+
 # name -> (restype, argtypes); restype None means "int status, checked"
 _PROTOS = {
     "vexhip_last_error": (ctypes.c_char_p, []),
@@ -124,6 +139,14 @@ _PROTOS = {
     "vexhip_sell8v_fill_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8v_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8v_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmat_create_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_spmat_create_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_spmat_destroy": (None, [c_vp]),
+    "vexhip_spmat_apply_f64": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp]),
+    "vexhip_spmat_apply_f32": (None, [c_vp, c_vp, c_f32, c_int, c_vp, c_vp]),
+    "vexhip_spmat_apply_multi_f64": (None, [c_vp, c_vp, c_int, c_f64, c_int, c_vp, c_vp]),
+    "vexhip_spmat_apply_multi_f32": (None, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp]),
+    "vexhip_spmat_get_info": (None, [c_vp, ctypes.POINTER(SpMatInfo)]),
     "vexhip_spmm_sell8_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8v_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
@@ -154,6 +177,7 @@ _PROTOS = {
     "vexhip_poisson3d_strip_nnz": (c_i64, [c_i64, c_i64, c_i64]),
     "vexhip_poisson3d_csr_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vexhip_poisson3d_strip_f64_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "vexhip_diffusion3d_strip_f64_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_u64, c_vp, c_vp, c_vp]),
     "vexhip_fill_hash": (None, [c_int, c_vp, c_int, c_u64, c_vp, c_i64]),
     "vexhip_fill_value": (None, [c_int, c_vp, c_int, c_vp, c_vp, c_i64]),
     "vexhip_mba_fit": (None, [c_int, c_vp, c_int, c_int, ctypes.POINTER(c_f64), ctypes.POINTER(c_f64), c_vp, c_vp, c_i64,

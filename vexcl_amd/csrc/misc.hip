@@ -68,9 +68,20 @@ __device__ __host__ inline long long poisson_nnz_before(long long idx, long long
     return idx + 6 * cnt;
 }
 
-template <typename V>
+// Coefficient of the face between grid points `lo` and `lo + step` (axis = 0, 1, 2) of the variable-coefficient
+// operator below: 0.5 + u, u in [0, 1) from a counter hash of (seed, lo, axis).  Integer arithmetic and one
+// exactly rounded conversion, so the host restatement (oracle/vex_oracle.c vxo_diffusion3d_*) gives the same bits.
+__device__ __forceinline__ double face_coefficient(unsigned long long seed, long long lo, int axis) {
+    const unsigned long long h = mix64(seed + ((unsigned long long)lo * 3ull + (unsigned long long)axis + 1ull) * 0x9E3779B97F4A7C15ull);
+    return 0.5 + (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// VAR = false: the benchmark's Poisson matrix.  VAR = true: the same 7-point pattern with a different coefficient on
+// every face -- -div(k grad u), k in [0.5, 1.5) -- i.e. nnz distinct values: what a finite-volume code assembles, and
+// the matrix no value coding applies to (bench.py's "variable coefficient" row).  Symmetric; boundary rows identity.
+template <typename V, bool VAR>
 __global__ __launch_bounds__(256)
-void poisson_kernel(long long n, long long row_begin, long long row_end,
+void poisson_kernel(long long n, long long row_begin, long long row_end, unsigned long long seed,
         int *__restrict__ ptr, int *__restrict__ col, V *__restrict__ val)
 {
     const long long nn = n * n;
@@ -85,6 +96,16 @@ void poisson_kernel(long long n, long long row_begin, long long row_end,
         bool bnd = (i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1);
         if (bnd) {
             col[p] = (int)idx; val[p] = V(1);
+        } else if constexpr (VAR) {
+            const double k0 = face_coefficient(seed, idx - nn, 2), k1 = face_coefficient(seed, idx - n, 1), k2 = face_coefficient(seed, idx - 1, 0);
+            const double k4 = face_coefficient(seed, idx, 0), k5 = face_coefficient(seed, idx, 1), k6 = face_coefficient(seed, idx, 2);
+            col[p + 0] = (int)(idx - nn); val[p + 0] = (V)(-(double)h2i * k0);
+            col[p + 1] = (int)(idx - n);  val[p + 1] = (V)(-(double)h2i * k1);
+            col[p + 2] = (int)(idx - 1);  val[p + 2] = (V)(-(double)h2i * k2);
+            col[p + 3] = (int)(idx);      val[p + 3] = (V)((double)h2i * (((((k0 + k1) + k2) + k4) + k5) + k6));
+            col[p + 4] = (int)(idx + 1);  val[p + 4] = (V)(-(double)h2i * k4);
+            col[p + 5] = (int)(idx + n);  val[p + 5] = (V)(-(double)h2i * k5);
+            col[p + 6] = (int)(idx + nn); val[p + 6] = (V)(-(double)h2i * k6);
         } else {
             col[p + 0] = (int)(idx - nn); val[p + 0] = -h2i;
             col[p + 1] = (int)(idx - n);  val[p + 1] = -h2i;
@@ -229,7 +250,19 @@ int vexhip_poisson3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t rb,
     VEXHIP_REQUIRE(n * n * n < (1ll << 31) && vexhip_poisson3d_strip_nnz(n, rb, re) < (1ll << 31),
                    "Poisson problem too large for int32 indices");
     VEXHIP_SET_DEVICE(dev);
-    poisson_kernel<double><<<grid_for(dev, re - rb + 1), 256, 0, as_stream(stream)>>>(n, rb, re, ptr, col, val);
+    poisson_kernel<double, false><<<grid_for(dev, re - rb + 1), 256, 0, as_stream(stream)>>>(n, rb, re, 0ull, ptr, col, val);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int vexhip_diffusion3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t rb, int64_t re, uint64_t seed,
+        int32_t *ptr, int32_t *col, double *val)
+{
+    VEXHIP_REQUIRE(n >= 1 && rb >= 0 && re >= rb && re <= n * n * n, "bad strip");
+    VEXHIP_REQUIRE(n * n * n < (1ll << 31) && vexhip_poisson3d_strip_nnz(n, rb, re) < (1ll << 31),
+                   "problem too large for int32 indices");
+    VEXHIP_SET_DEVICE(dev);
+    poisson_kernel<double, true><<<grid_for(dev, re - rb + 1), 256, 0, as_stream(stream)>>>(n, rb, re, (unsigned long long)seed, ptr, col, val);
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }

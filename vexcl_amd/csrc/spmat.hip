@@ -1,0 +1,291 @@
+// vexhip_spmat: ONE device-resident sparse matrix object behind the C ABI.
+//
+// It owns what vex::SpMat decides at construction (reference: vexcl/spmat.hpp:84-104 picks
+// SpMatCSR for CPU devices and SpMatHELL for GPUs; spmat/hybrid_ell.inl:60-216 builds the
+// hybrid ELL part): here the storage selection
+//     hybrid-ELL width / CSR tail  ->  <= 254 diagonals? 1-byte diagonal codes (SELL8)
+//                                  ->  <= 255 values?    1-byte value codes   (SELL8V)
+//                                  ->  otherwise 32-bit columns (SELL), or plain CSR when the ELL part is empty
+// lives in this file once, instead of once in vexcl/spmat.hpp and once in vexcl_amd/ops.py (round 1).
+// Both front ends now call create / apply / destroy.  Built from DEVICE CSR arrays: no host staging.
+#include "common.hpp"
+
+#include <cstring>
+#include <new>
+
+namespace vexhip {
+namespace {
+
+struct spmat {
+    int dev = 0;
+    int value_type = VEXHIP_F64;
+    int format = VEXHIP_SPMAT_CSR;
+    int64_t n = 0, nnz = 0, ell_w = 0, tail = 0;
+    void *sell = nullptr; int64_t sell_bytes = 0;
+    int32_t *deltas = nullptr; int ndeltas = -1;
+    void *values = nullptr; int nvalues = -1;
+    int32_t *csr_ptr = nullptr, *csr_col = nullptr; void *csr_val = nullptr;   // CSR tail, or the whole matrix (format CSR)
+    bool owns_csr = false;
+    vexhip_traversal trav = {0, 0, 0, 0, nullptr};
+};
+
+template <typename T> int dmalloc(T **p, size_t count) {
+    *p = nullptr;
+    if (!count) return 0;
+    return check(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)), __FILE__, __LINE__);
+}
+
+void release(spmat *A) {
+    if (!A) return;
+    (void)hipSetDevice(A->dev);
+    if (A->sell) (void)hipFree(A->sell);
+    if (A->deltas) (void)hipFree(A->deltas);
+    if (A->values) (void)hipFree(A->values);
+    if (A->owns_csr) {
+        if (A->csr_ptr) (void)hipFree(A->csr_ptr);
+        if (A->csr_col) (void)hipFree(A->csr_col);
+        if (A->csr_val) (void)hipFree(A->csr_val);
+    }
+    delete A;
+}
+
+template <typename V> struct api;
+template <> struct api<double> {
+    static constexpr int type = VEXHIP_F64;
+    static int hell_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const double *v, int64_t w, int64_t pitch, int32_t *cp, int32_t *cc, double *cv)
+    { return vexhip_hell_fill_f64_i32(d, s, n, p, c, v, w, pitch, nullptr, nullptr, cp, cc, cv); }
+    static int v_analyze(int d, void *s, int64_t n, const int32_t *p, const double *v, int64_t w, double *vals, int *nv) { return vexhip_sell8v_analyze_f64_i32(d, s, n, p, v, w, vals, nv); }
+    static int v_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const double *v, int64_t w, const int32_t *dl, int nd, const double *vals, int nv, void *b, vexhip_traversal *t)
+    { return vexhip_sell8v_fill_f64_i32(d, s, n, p, c, v, w, dl, nd, vals, nv, b, t); }
+    static int d_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const double *v, int64_t w, const int32_t *dl, int nd, void *b, vexhip_traversal *t)
+    { return vexhip_sell8_fill_f64_i32(d, s, n, p, c, v, w, dl, nd, b, t); }
+    static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const double *v, int64_t w, void *b) { return vexhip_sell_fill_f64_i32(d, s, n, p, c, v, w, b); }
+    static int mul_v(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8v_f64_i32(d, s, n, a, ap, w, b, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
+    static int mul_d(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8_f64_i32(d, s, n, a, ap, w, b, dl, cp, cc, (const double *)cv, x, y, t); }
+    static int mul_s(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell_f64_i32(d, s, n, a, ap, w, b, cp, cc, (const double *)cv, x, y, t); }
+    static int mul_c(int d, void *s, int64_t n, double a, int ap, const int32_t *p, const int32_t *c, const void *v, const double *x, double *y, const vexhip_traversal *t)
+    { return vexhip_spmv_csr_ordered_f64_i32(d, s, n, a, ap, p, c, (const double *)v, x, y, t); }
+    static int mm_v(int d, void *s, int64_t n, int k, double a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *const *x, double *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8v_f64_i32(d, s, n, k, a, ap, w, b, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
+    static int mm_d(int d, void *s, int64_t n, int k, double a, int ap, int64_t w, const void *b, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *const *x, double *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8_f64_i32(d, s, n, k, a, ap, w, b, dl, cp, cc, (const double *)cv, x, y, t); }
+    static int mm_s(int d, void *s, int64_t n, int k, double a, int ap, int64_t w, const void *b, const int32_t *cp, const int32_t *cc, const void *cv, const double *const *x, double *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell_f64_i32(d, s, n, k, a, ap, w, b, cp, cc, (const double *)cv, x, y, t); }
+};
+template <> struct api<float> {
+    static constexpr int type = VEXHIP_F32;
+    static int hell_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const float *v, int64_t w, int64_t pitch, int32_t *cp, int32_t *cc, float *cv)
+    { return vexhip_hell_fill_f32_i32(d, s, n, p, c, v, w, pitch, nullptr, nullptr, cp, cc, cv); }
+    static int v_analyze(int d, void *s, int64_t n, const int32_t *p, const float *v, int64_t w, float *vals, int *nv) { return vexhip_sell8v_analyze_f32_i32(d, s, n, p, v, w, vals, nv); }
+    static int v_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const float *v, int64_t w, const int32_t *dl, int nd, const float *vals, int nv, void *b, vexhip_traversal *t)
+    { return vexhip_sell8v_fill_f32_i32(d, s, n, p, c, v, w, dl, nd, vals, nv, b, t); }
+    static int d_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const float *v, int64_t w, const int32_t *dl, int nd, void *b, vexhip_traversal *t)
+    { return vexhip_sell8_fill_f32_i32(d, s, n, p, c, v, w, dl, nd, b, t); }
+    static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const float *v, int64_t w, void *b) { return vexhip_sell_fill_f32_i32(d, s, n, p, c, v, w, b); }
+    static int mul_v(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8v_f32_i32(d, s, n, a, ap, w, b, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
+    static int mul_d(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8_f32_i32(d, s, n, a, ap, w, b, dl, cp, cc, (const float *)cv, x, y, t); }
+    static int mul_s(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell_f32_i32(d, s, n, a, ap, w, b, cp, cc, (const float *)cv, x, y, t); }
+    static int mul_c(int d, void *s, int64_t n, float a, int ap, const int32_t *p, const int32_t *c, const void *v, const float *x, float *y, const vexhip_traversal *t)
+    { return vexhip_spmv_csr_ordered_f32_i32(d, s, n, a, ap, p, c, (const float *)v, x, y, t); }
+    static int mm_v(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8v_f32_i32(d, s, n, k, a, ap, w, b, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
+    static int mm_d(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8_f32_i32(d, s, n, k, a, ap, w, b, dl, cp, cc, (const float *)cv, x, y, t); }
+    static int mm_s(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell_f32_i32(d, s, n, k, a, ap, w, b, cp, cc, (const float *)cv, x, y, t); }
+};
+
+template <typename V>
+int build(spmat *A, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const V *val, int format, int flags)
+{
+    typedef api<V> F;
+    const int dev = A->dev;
+    A->n = n; A->value_type = F::type;
+    if (n == 0) { A->format = VEXHIP_SPMAT_CSR; return 0; }
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    int32_t last = 0;
+    VEXHIP_TRY(hipMemcpyAsync(&last, ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    A->nnz = last;
+
+    int64_t w = 0, tail = 0;
+    if (format != VEXHIP_SPMAT_CSR && A->nnz > 0)
+        if (int rc = vexhip_hell_analyze_i32(dev, stream, n, ptr, &w, &tail)) return rc;
+    if (format == VEXHIP_SPMAT_CSR || w == 0) {
+        // the CSR arrays as they are: borrowed (the caller keeps them alive) or copied
+        A->format = VEXHIP_SPMAT_CSR;
+        if (flags & VEXHIP_SPMAT_BORROW_CSR) {
+            A->csr_ptr = const_cast<int32_t *>(ptr); A->csr_col = const_cast<int32_t *>(col); A->csr_val = const_cast<V *>(val);
+        } else {
+            A->owns_csr = true;
+            V *cv = nullptr;
+            if (int rc = dmalloc(&A->csr_ptr, (size_t)n + 1)) return rc;
+            if (int rc = dmalloc(&A->csr_col, (size_t)A->nnz)) return rc;
+            if (int rc = dmalloc(&cv, (size_t)A->nnz)) return rc;
+            A->csr_val = cv;
+            VEXHIP_TRY(hipMemcpyAsync(A->csr_ptr, ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToDevice, s));
+            if (A->nnz) {
+                VEXHIP_TRY(hipMemcpyAsync(A->csr_col, col, sizeof(int32_t) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
+                VEXHIP_TRY(hipMemcpyAsync(cv, val, sizeof(V) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        if (A->nnz) (void)vexhip_csr_traversal_i32(dev, stream, n, A->csr_ptr, A->csr_col, 256, &A->trav);   // strips for banded matrices
+        VEXHIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
+
+    A->ell_w = w; A->tail = tail;
+    if (tail) {      // rows wider than the ELL width keep their tail in CSR (hybrid_ell.inl:166-198)
+        A->owns_csr = true;
+        V *cv = nullptr;
+        if (int rc = dmalloc(&A->csr_ptr, (size_t)n + 1)) return rc;
+        if (int rc = dmalloc(&A->csr_col, (size_t)tail)) return rc;
+        if (int rc = dmalloc(&cv, (size_t)tail)) return rc;
+        A->csr_val = cv;
+        if (int rc = F::hell_fill(dev, stream, n, ptr, col, val, w, (n + 15) / 16 * 16, A->csr_ptr, A->csr_col, cv)) return rc;
+    }
+    int nd = -1;
+    if (format != VEXHIP_SPMAT_SELL) {
+        if (int rc = dmalloc(&A->deltas, 256)) return rc;
+        if (int rc = vexhip_sell8_analyze_i32(dev, stream, n, ptr, col, w, A->deltas, &nd)) return rc;
+    }
+    if (nd > 0) {
+        A->ndeltas = nd;
+        int nv = -1;
+        if (format != VEXHIP_SPMAT_SELL8) {
+            V *vals = nullptr;
+            if (int rc = dmalloc(&vals, 256)) return rc;
+            A->values = vals;
+            if (int rc = F::v_analyze(dev, stream, n, ptr, val, w, vals, &nv)) return rc;
+        }
+        if (nv > 0) {
+            A->nvalues = nv; A->format = VEXHIP_SPMAT_SELL8V;
+            A->sell_bytes = vexhip_sell8v_bytes(n, w);
+            VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
+            if (int rc = F::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
+        } else {
+            if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
+            A->format = VEXHIP_SPMAT_SELL8;
+            A->sell_bytes = vexhip_sell8_bytes(n, w, (int)sizeof(V));
+            VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
+            if (int rc = F::d_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, A->sell, &A->trav)) return rc;
+        }
+    } else {
+        if (A->deltas) { (void)hipFree(A->deltas); A->deltas = nullptr; }
+        A->format = VEXHIP_SPMAT_SELL;
+        A->sell_bytes = vexhip_sell_bytes(n, w, (int)sizeof(V));
+        VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
+        if (int rc = F::s_fill(dev, stream, n, ptr, col, val, w, A->sell)) return rc;
+        if (int rc = vexhip_sell_order_i32(dev, stream, n, w, (int)sizeof(V), A->sell, 0, nullptr, 0, &A->trav)) return rc;
+    }
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+template <typename V>
+int create(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const V *val, int format, int flags, vexhip_spmat **out)
+{
+    VEXHIP_REQUIRE(out, "NULL output");
+    *out = nullptr;
+    VEXHIP_REQUIRE(n >= 0 && format >= VEXHIP_SPMAT_AUTO && format <= VEXHIP_SPMAT_CSR, "bad argument");
+    VEXHIP_REQUIRE(n == 0 || ptr, "NULL row pointers");
+    spmat *A = new (std::nothrow) spmat;
+    VEXHIP_REQUIRE(A, "out of host memory");
+    A->dev = dev;
+    if (int rc = build<V>(A, stream, n, ptr, col, val, format, flags)) { release(A); return rc; }
+    *out = reinterpret_cast<vexhip_spmat *>(A);
+    return 0;
+}
+
+template <typename V>
+int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
+{
+    typedef api<V> F;
+    VEXHIP_REQUIRE(A && A->value_type == F::type, "matrix and vector value types differ");
+    if (A->n == 0) return 0;
+    if (A->nnz == 0) {          // csr.inl:186-200: an empty matrix zero-fills y on "="
+        if (!append) { VEXHIP_SET_DEVICE(A->dev); VEXHIP_TRY(hipMemsetAsync(y, 0, sizeof(V) * (size_t)A->n, as_stream(stream))); }
+        return 0;
+    }
+    const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
+    switch (A->format) {
+        case VEXHIP_SPMAT_SELL8V: return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case VEXHIP_SPMAT_SELL8:  return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case VEXHIP_SPMAT_SELL:   return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        default:                  return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
+    }
+}
+
+template <typename V>
+int apply_multi(const spmat *A, void *stream, int k, V alpha, int append, const V *const *x, V *const *y)
+{
+    typedef api<V> F;
+    VEXHIP_REQUIRE(A && A->value_type == F::type, "matrix and vector value types differ");
+    VEXHIP_REQUIRE(k >= 1 && x && y, "bad argument");
+    if (A->n == 0) return 0;
+    if (A->nnz == 0 || A->format == VEXHIP_SPMAT_CSR) {          // no multi-vector kernel: one product per component
+        for (int c = 0; c < k; ++c) if (int rc = apply<V>(A, stream, alpha, append, x[c], y[c])) return rc;
+        return 0;
+    }
+    const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
+    switch (A->format) {
+        case VEXHIP_SPMAT_SELL8V: return F::mm_v(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case VEXHIP_SPMAT_SELL8:  return F::mm_d(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        default:                  return F::mm_s(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+    }
+}
+
+} // namespace
+} // namespace vexhip
+
+using namespace vexhip;
+
+extern "C" {
+
+int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int format, int flags, vexhip_spmat **out)
+{ return create<double>(dev, stream, n, ptr, col, val, format, flags, out); }
+
+int vexhip_spmat_create_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int format, int flags, vexhip_spmat **out)
+{ return create<float>(dev, stream, n, ptr, col, val, format, flags, out); }
+
+int vexhip_spmat_destroy(vexhip_spmat *A) { release(reinterpret_cast<spmat *>(A)); return 0; }
+
+int vexhip_spmat_apply_f64(const vexhip_spmat *A, void *stream, double alpha, int append, const double *x, double *y)
+{ return apply<double>(reinterpret_cast<const spmat *>(A), stream, alpha, append, x, y); }
+int vexhip_spmat_apply_f32(const vexhip_spmat *A, void *stream, float alpha, int append, const float *x, float *y)
+{ return apply<float>(reinterpret_cast<const spmat *>(A), stream, alpha, append, x, y); }
+
+int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, double alpha, int append, const double *const *x, double *const *y)
+{ return apply_multi<double>(reinterpret_cast<const spmat *>(A), stream, nrhs, alpha, append, x, y); }
+int vexhip_spmat_apply_multi_f32(const vexhip_spmat *A, void *stream, int nrhs, float alpha, int append, const float *const *x, float *const *y)
+{ return apply_multi<float>(reinterpret_cast<const spmat *>(A), stream, nrhs, alpha, append, x, y); }
+
+int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
+    VEXHIP_REQUIRE(h && o, "NULL argument");
+    const spmat *A = reinterpret_cast<const spmat *>(h);
+    std::memset(o, 0, sizeof(*o));
+    o->format = A->format; o->value_type = A->value_type; o->device = A->dev;
+    o->rows = A->n; o->nnz = A->nnz; o->ell_width = A->ell_w; o->tail_nnz = A->tail;
+    o->ndeltas = A->ndeltas; o->nvalues = A->nvalues;
+    o->sell = A->sell; o->sell_bytes = A->sell_bytes; o->deltas = A->deltas; o->values = A->values;
+    o->csr_ptr = A->csr_ptr; o->csr_col = A->csr_col; o->csr_val = A->csr_val;
+    o->traversal = A->trav;
+    // bytes one product moves through HBM at least: the stored matrix + x once + y once (+ y read for "+=" not counted)
+    const int64_t vb = A->value_type == VEXHIP_F64 ? 8 : 4;
+    int64_t m = A->sell_bytes;
+    if (A->format == VEXHIP_SPMAT_CSR) m = A->nnz * (4 + vb) + (A->n + 1) * 4;
+    else if (A->tail) m += A->tail * (4 + vb) + (A->n + 1) * 4;
+    o->matrix_bytes = m;
+    return 0;
+}
+
+} // extern "C"

@@ -139,6 +139,21 @@ def poisson3d(n, device="cuda", rows=None):
     return ptr, col, val
 
 
+def diffusion3d(n, device="cuda", rows=None, seed=7):
+    """Variable-coefficient 7-point operator -div(k grad u) on the n^3 grid (k differs on every face: nnz distinct
+    values), built in HBM; same pattern, strip convention and nnz as `poisson3d`."""
+    L = lib()
+    dev = torch.device(device)
+    N = n ** 3
+    r0, r1 = (0, N) if rows is None else rows
+    nnz = L.poisson3d_strip_nnz(n, r0, r1)
+    ptr = torch.empty(r1 - r0 + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    L.diffusion3d_strip_f64_i32(_dev(ptr), _stream(ptr), n, r0, r1, ctypes.c_uint64(seed), _p(ptr), _p(col), _p(val))
+    return ptr, col, val
+
+
 def fill_hash(t, seed):
     lib().fill_hash(_dev(t), _stream(t), _dtype_code(t), ctypes.c_uint64(seed), _p(t), t.numel())
     return t
@@ -335,27 +350,49 @@ class SpMat:
     ``y = alpha*A*x`` or ``y += alpha*A*x``.
     """
 
+    _FORMATS = {"sell": _capi.SPMAT_AUTO, "sell8": _capi.SPMAT_SELL8, "sell32": _capi.SPMAT_SELL, "csr": _capi.SPMAT_CSR}
+
     def __init__(self, ptr, col, val, n_cols=None, fmt="auto"):
         self.ptr, self.col, self.val = ptr, col, val
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
+        i32 = ptr.dtype == torch.int32 and col.dtype == torch.int32
         if fmt == "auto":
-            fmt = "sell" if (ptr.dtype == torch.int32 and col.dtype == torch.int32) else "csr"
+            fmt = "sell" if i32 else "csr"
         if fmt not in ("sell", "sell8", "sell32", "hell", "csr"):
             raise Error("unknown SpMat format %r" % fmt)
-        self.hell = None
-        if fmt in ("sell", "sell8", "sell32"):
-            try:
-                # sell: the most compact storage the matrix allows; sell8 / sell32 pin a less compact one (A/B, tests)
-                self.hell = SlicedELL(ptr, col, val, codes=fmt != "sell32", value_codes=fmt == "sell")
-                fmt = "sell"
-            except Error:                        # ELL width 0 (mostly empty rows): CSR is the format
-                fmt = "csr"
-        elif fmt == "hell":
+        self.hell, self.handle, self.csr_trav = None, None, None
+        self.dtype = val.dtype
+        if fmt == "hell":                        # the reference's column-major hybrid ELL (kept for A/B and sparse::ell)
             self.hell = HybridELL(ptr, col, val)
-        self.fmt = fmt
-        # CSR arrays as given: banded / stencil matrices get the strip traversal too
-        self.csr_trav = csr_traversal(ptr, col) if (fmt == "csr" and val.is_cuda) else None
+            self.fmt = self.storage = "hell"
+            return
+        if not i32 or not val.is_cuda:           # 64-bit indices: the CSR kernel on the arrays as given
+            self.fmt = self.storage = "csr"
+            return
+        # one C-ABI object owns the storage selection (include/vexhip.h vexhip_spmat_*): the C++ vex::SpMat calls the same
+        L = lib()
+        f64 = val.dtype == torch.float64
+        h = ctypes.c_void_p()
+        (L.spmat_create_f64_i32 if f64 else L.spmat_create_f32_i32)(
+            _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
+            _capi.SPMAT_BORROW_CSR, ctypes.byref(h))
+        self.handle = h
+        info = _capi.SpMatInfo()
+        L.spmat_get_info(h, ctypes.byref(info))
+        self.info = info
+        self.storage = _capi.SPMAT_NAMES[info.format]              # sell8v | sell8 | sell32 | csr
+        self.fmt = "csr" if self.storage == "csr" else "sell"      # SELL without an ELL part degrades to CSR
+        if self.fmt == "sell":
+            self.hell = _SellInfo(info)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                lib().spmat_destroy(h)
+            except Exception:
+                pass
 
     def rows(self):
         return self.n
@@ -366,9 +403,22 @@ class SpMat:
     def nonzeros(self):
         return self.col.numel()
 
+    def matrix_bytes(self):
+        """Bytes of matrix data one product streams (the storage actually read)."""
+        if self.handle:
+            return int(self.info.matrix_bytes)
+        if self.storage == "hell":
+            return int(self.hell.width * self.hell.pitch * (4 + self.val.element_size()))
+        return int(self.col.numel() * (self.col.element_size() + self.val.element_size()) + self.ptr.numel() * self.ptr.element_size())
+
     def apply(self, x, y, alpha=1.0, append=False):
         if x.numel() != self.m:
             raise Error("x has %d elements, matrix has %d columns" % (x.numel(), self.m))
+        if self.handle:
+            f64 = self.dtype == torch.float64
+            (lib().spmat_apply_f64 if f64 else lib().spmat_apply_f32)(
+                self.handle, _stream(y), ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha), int(bool(append)), _p(x), _p(y))
+            return y
         if self.hell is not None:
             return self.hell.mul(x, y, alpha, append)
         return spmv_csr(self.ptr, self.col, self.val, x, y, alpha, append, traversal=self.csr_trav)
@@ -379,8 +429,16 @@ class SpMat:
         for x in xs:
             if x.numel() != self.m:
                 raise Error("x has %d elements, matrix has %d columns" % (x.numel(), self.m))
-        if isinstance(self.hell, SlicedELL):
-            return self.hell.mul_multi(xs, ys, alpha, append)
+        if len(xs) != len(ys) or not xs:
+            raise Error("apply_multi: need as many results as right-hand sides (at least one)")
+        if self.handle:
+            f64 = self.dtype == torch.float64
+            k = len(xs)
+            xp = (ctypes.c_void_p * k)(*[_p(x) for x in xs])
+            yp = (ctypes.c_void_p * k)(*[_p(y) for y in ys])
+            (lib().spmat_apply_multi_f64 if f64 else lib().spmat_apply_multi_f32)(
+                self.handle, _stream(ys[0]), k, ctypes.c_double(alpha) if f64 else ctypes.c_float(alpha), int(bool(append)), xp, yp)
+            return ys
         for x, y in zip(xs, ys):
             self.apply(x, y, alpha, append)
         return ys
@@ -388,6 +446,18 @@ class SpMat:
     def __matmul__(self, x):                      # y = A * x
         y = torch.empty(self.n, dtype=x.dtype, device=x.device)
         return self.apply(x, y, 1.0, False)
+
+
+class _SellInfo:
+    """What vexhip_spmat_get_info reports about a SELL storage (read-only view for tests and the bench)."""
+
+    def __init__(self, info):
+        self.width, self.tail_nnz = int(info.ell_width), int(info.tail_nnz)
+        self.ndeltas, self.nvalues = int(info.ndeltas), int(info.nvalues)
+        self.deltas = info.deltas if info.ndeltas > 0 else None        # device addresses (None = not coded)
+        self.values = info.values if info.nvalues > 0 else None
+        self.order_grid = int(info.traversal.grid_blocks)
+        self.sell_bytes = int(info.sell_bytes)
 
 
 # --------------------------------------------------------------------------
