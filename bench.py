@@ -5,17 +5,29 @@ on the 3-D Poisson matrix (examples/benchmark.cpp:353-477), 512^3 grid.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one product y = A*x through vex::SpMat's path (libvexhip.so).
-The matrix is built directly in HBM; inputs are resident before
-the timed region.  N > 1: the SAME 512^3 problem row-partitioned over the ranks
-(strong scaling), ghost planes exchanged over RCCL (vexcl_amd/distributed.py).
+One "step" = one product y = A*x through vex::SpMat's path: the C-ABI object `vexhip_spmat`
+(include/vexhip.h) that both front ends -- the C++ headers (vexcl/spmat.hpp) and the Python
+mirror used here (vexcl_amd/ops.py) -- create and apply.  The matrix is built directly in HBM
+(SURVEY 8(d)); inputs are resident before the timed region.  N > 1: the SAME 512^3 problem
+row-partitioned over the ranks (strong scaling), ghost planes exchanged over RCCL.
 
-Algorithmic work per product (independent of the internal
-storage format):  bytes = nnz*12 + (N+1)*4 + N*8 + N*8,  flops = 2*nnz.
+What the line reports, and how to read it:
+  value / hbm_gbps    2*nnz / t and CSR-ALGORITHMIC bytes / t (nnz*12 + (N+1)*4 + 16*N):
+                      the metric's own definition, independent of how the matrix is stored.
+  roofline            the launched kernel against the HBM roofline by the bytes it REALLY moves: the stored matrix
+                      (vexhip_spmat_get_info: matrix_bytes) + x once + y once.  frac <= 1 by construction.  `traffic`
+                      = HBM bytes per launch measured in THIS run (rocprofv3 FETCH_SIZE / WRITE_SIZE passes over
+                      tools/pmc_headline.py, FETCH calibrated on a stream of known size), or null.
+  roofline_csr        the same product by kernels that stream fp64 values + int32 columns (no compression), priced
+                      with the CSR-algorithmic bytes: SELL-512 with 32-bit columns and the CSR arrays themselves.
+  variable_coefficient  the same 7-point pattern with nnz distinct values (no value coding applies) through the
+                      default SpMat: the general-matrix figure.
+  checksum            sum(y) asserted against an independent evaluation of the stencil (torch slicing, no matrix).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true>", "sell8": "sell8_pair_kernel<double, 7, false>",
+             "sell32": "sell_pair_kernel<double, 7>", "csr": "csr_stream_kernel<double, int, ...>", "hell": "hell_kernel"}
 
 
 def algorithmic_bytes(n_rows, nnz):
@@ -30,101 +44,150 @@ def algorithmic_bytes(n_rows, nnz):
 
 
 def cpu_baseline(grid, seconds):
-    """The reference's CPU-device path restated (oracle/vex_oracle.c,
-    vxo_spmv_csr_f64_i32_omp: 8 x threads contiguous row chunks), timed on the
-    host cores of this box on a bounded sample of the same workload."""
-    import numpy as np
+    """The reference's CPU-device path restated (oracle/vex_oracle.c: 8 x threads contiguous row chunks, OpenMP --
+    backend/opencl/source.hpp:255-268, kernel.hpp:166-171,193-194), every array first-touched by the thread that uses
+    it, on the 512^3 matrix when host memory allows; plus the single-thread loop the reference harness itself prints as
+    its "C++" line (examples/benchmark.cpp:447-453)."""
     import oracle
-    ptr, col, val = oracle.poisson3d(grid)
-    N, nnz = grid ** 3, len(col)
-    x = np.full(N, 1e-2)
-    y = np.zeros(N)
-    oracle.spmv_csr(ptr, col, val, x, y, omp=True)          # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.spmv_csr(ptr, col, val, x, y, omp=True)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 1000:
-            break
-    per = dt / reps
-    return {"value": round(2.0 * nnz / per / 1e9, 3), "unit": "GFLOP/s", "cores": oracle.num_threads(),
-            "kind": "port", "hbm_equiv_gbps": round(algorithmic_bytes(N, nnz) / per / 1e9, 2),
-            "sample": "%d products of the %d^3 Poisson matrix (N=%d, nnz=%d), OpenMP chunked csr_spmv restatement"
-                      % (reps, grid, N, nnz)}
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 0
+    g = grid
+    while g > 64 and algorithmic_bytes(g ** 3, 7 * g ** 3) * 1.3 > avail:
+        g //= 2
+    r = oracle.cpu_baseline_poisson(g, seconds, 1)
+    if r is None:
+        return {"error": "host arrays for %d^3 could not be allocated" % g}
+    N, nnz = g ** 3, oracle.poisson3d_nnz(g)
+    per, per1 = r["seconds_per_product"], r["single_thread_seconds_per_product"]
+    return {"value": round(2.0 * nnz / per / 1e9, 3), "unit": "GFLOP/s", "cores": r["threads"], "kind": "port",
+            "hbm_equiv_gbps": round(algorithmic_bytes(N, nnz) / per / 1e9, 2),
+            "single_thread": {"value": round(2.0 * nnz / per1 / 1e9, 3), "unit": "GFLOP/s",
+                              "what": "the harness's own host loop, examples/benchmark.cpp:447-453"},
+            "sample": "%d products of the %d^3 Poisson matrix (N=%d, nnz=%d) in %.1f s, OpenMP chunked csr_spmv restatement, "
+                      "arrays first-touched in parallel by the chunks' owners" % (r["products"], g, N, nnz, per * r["products"])}
 
 
-def read_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/*pmc_summary.json written by tools/profile.sh + tools/pmc_summary.py:
-    FETCH_SIZE calibrated x2 on a stream of known size, + WRITE_SIZE), or None."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json"))):
-        try:
-            d = json.load(open(f))
-            if kernel in d and "hbm_bytes_per_launch" in d[kernel]:
-                best = int(d[kernel]["hbm_bytes_per_launch"])
-        except Exception:
-            pass
-    return best
+def independent_product(torch, x, n, variable_seed=None):
+    """y = A*x for the Poisson matrix WITHOUT the matrix: boundary rows are identity, interior rows the 7-point stencil
+    (examples/benchmark.cpp:364-415), evaluated with torch slicing.  Also returns sum |terms| for the tolerance."""
+    h2i = float((n - 1) * (n - 1))
+    X = x.view(n, n, n)
+    y = x.clone()
+    Y = y.view(n, n, n)
+    c = X[1:-1, 1:-1, 1:-1]
+    nb = (X[:-2, 1:-1, 1:-1], X[1:-1, :-2, 1:-1], X[1:-1, 1:-1, :-2], X[1:-1, 1:-1, 2:], X[1:-1, 2:, 1:-1], X[2:, 1:-1, 1:-1])
+    acc = 6.0 * h2i * c
+    mag = 6.0 * h2i * c.abs()
+    for t in nb:
+        acc = acc - h2i * t
+        mag = mag + h2i * t.abs()
+    Y[1:-1, 1:-1, 1:-1] = acc
+    bound = float(mag.sum()) + float(x.abs().sum())
+    return y, bound
 
 
-ELEMENTWISE_SRC = r'''
-// the reference's fused kernel for `a = b * c + sin(d)` (SURVEY appendix A.1 shape), two elements per trip
-extern "C" __global__ void vexcl_vector_kernel(ulong n, double *prm_1, const double *prm_2, const double *prm_3, const double *prm_4) {
-  const ulong grid_size = blockDim.x * (ulong)gridDim.x;
-  for (ulong vex_i = blockDim.x * (ulong)blockIdx.x + threadIdx.x; vex_i < n; vex_i += 2 * grid_size) {
-    const bool vex_two = vex_i + grid_size < n;
-    const ulong i1 = vex_two ? vex_i + grid_size : vex_i;
-    const double r0 = ( ( prm_2[vex_i] * prm_3[vex_i] ) + sin( prm_4[vex_i] ) );
-    const double r1 = ( ( prm_2[i1] * prm_3[i1] ) + sin( prm_4[i1] ) );
-    prm_1[vex_i] = r0;
-    if (vex_two) prm_1[i1] = r1;
-  }
-}
-'''
+def timed_events(torch, fn, reps):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measure_traffic(grid, timeout=240):
+    """HBM bytes per launch of the headline kernels measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE need
+    separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots) over tools/pmc_headline.py.  FETCH_SIZE is calibrated on
+    a 2 GiB 16-byte-per-lane stream captured in the same pass (gfx950 reports half the bytes of such a stream)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None, "already running under a profiler"
+    out = tempfile.mkdtemp(prefix="vexpmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", GRID=str(grid))
+    res = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            p = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "pmc_headline.py")],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited %d" % (ctr, p.returncode)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] != ctr:
+                        continue
+                    name = r["Kernel_Name"]
+                    key = None
+                    for k in ("sell8_pair_kernel", "sell_pair_kernel", "csr_stream_kernel", "reduce_stage1"):
+                        if k in name:
+                            key = k
+                            if k == "sell8_pair_kernel":
+                                key += "_vcoded" if ("true" in name.split("sell8_pair_kernel")[1][:24] or ", 1>" in name.split("sell8_pair_kernel")[1][:24]) else "_values"
+                    if key:
+                        res.setdefault(key, {}).setdefault(ctr, []).append(float(r["Counter_Value"]))
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 pass timed out"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    cal = res.get("reduce_stage1", {}).get("FETCH_SIZE")
+    if not cal:
+        return None, "no calibration kernel in the counter output"
+    factor = float((1 << 28) * 8) / (sum(cal) / len(cal) * 1024.0)
+    out = {"fetch_calibration_factor": round(factor, 4)}
+    for k, d in res.items():
+        if k == "reduce_stage1" or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+            continue
+        rd = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 1024.0 * factor
+        wr = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024.0
+        out[k] = {"read": int(rd), "written": int(wr), "total": int(rd + wr)}
+    return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run (tools/pmc_headline.py)"
+
+
+def cpp_rows(args_list, timeout=300):
+    """Rows printed by a C++ example (JSON objects, one per line): the vex:: header API end to end."""
+    exe = os.path.join(ROOT, "examples", "build", args_list[0])
+    if not os.path.exists(exe):
+        return [{"error": "%s is not built (python -c 'import __graft_entry__ as g; g.build()')" % args_list[0]}]
+    p = subprocess.run([exe] + [str(a) for a in args_list[1:]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout,
+                       env=dict(os.environ, TMPDIR="/tmp"))
+    rows = []
+    for line in p.stdout.decode(errors="replace").splitlines():
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                rows.append(json.loads(line))
+            except Exception:
+                pass
+    if p.returncode != 0:
+        rows.append({"error": "%s exited %d" % (args_list[0], p.returncode)})
+    return rows
 
 
 def secondary_rows(torch, L, ops, dev, local_rank):
-    """BASELINE.json's secondary metrics (SURVEY 8(d)): elementwise, reduce, scan, sort and the
-    multi-right-hand-side product, each timed with HIP events after a warm-up, inputs resident.
-    Reported next to the headline value; never part of it."""
+    """BASELINE.json's secondary metrics.  Elementwise and reduce come from the C++ expression engine
+    itself (examples/roofline.cpp: the kernels vexcl/operations.hpp and vexcl/reductor.hpp generate); scan and sort are
+    timed through the C ABI on pre-allocated buffers.  Reported next to the headline value; never part of it."""
     import ctypes
     rows = {}
-
-    def timed(fn, reps):
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    n = 10 ** 8
-    b, c, d = (ops.fill_hash(torch.empty(n, dtype=torch.float64, device=dev), s) for s in (1, 2, 3))
-    a = torch.empty_like(b)
-    mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
-    L.module_compile(local_rank, ELEMENTWISE_SRC.encode(), b"", ctypes.byref(mod))
-    L.module_get_function(local_rank, mod, b"vexcl_vector_kernel", ctypes.byref(fn))
-    args = [ctypes.c_uint64(n)] + [ctypes.c_void_p(t.data_ptr()) for t in (a, b, c, d)]
-    arr = (ctypes.c_void_p * len(args))(*[ctypes.cast(ctypes.pointer(v), ctypes.c_void_p) for v in args])
+    for r in cpp_rows(["roofline", 1000000, "e"]):
+        if "row" in r:
+            rows["C++ vex:: " + r["row"]] = {k: r[k] for k in ("ms", "alg_gbps", "frac_of_8TBps") if k in r}
+        elif "error" in r:
+            rows["C++ roofline"] = r
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    blocks = (n + 511) // 512                      # one trip per lane (vexcl/backend.hpp config_streaming)
-    ms = timed(lambda: L.launch(local_rank, fn, blocks, 1, 1, 256, 1, 1, 0, stream, arr), 20)
-    rows["elementwise a=b*c+sin(d) f64 n=1e8"] = {"ms": round(ms, 4), "gbps": round(32.0 * n / ms / 1e6, 1)}
-    red = ops.Reductor("SUM")
-    ms = timed(lambda: red.dot(b, c), 20)
-    rows["reduce sum(a*b) f64 n=1e8 (incl. host readback)"] = {"ms": round(ms, 4), "gbps": round(16.0 * n / ms / 1e6, 1)}
-    L.module_unload(local_rank, mod)
-    del a, b, c, d
-
     n = 10 ** 9
     k = ops.fill_hash(torch.empty(n, dtype=torch.int32, device=dev), 42)
     out = torch.empty_like(k)
-    ms = timed(lambda: ops.inclusive_scan(k, out, unsigned=True), 10)
-    rows["inclusive_scan u32 n=1e9"] = {"ms": round(ms, 4), "gbps": round(8.0 * n / ms / 1e6, 1)}
+    ms = timed_events(torch, lambda: ops.inclusive_scan(k, out, unsigned=True), 10)
+    rows["inclusive_scan u32 n=1e9"] = {"ms": round(ms, 4), "gbps": round(8.0 * n / ms / 1e6, 1), "frac_of_8TBps": round(8.0 * n / ms / 1e6 / HBM_PEAK_GBPS, 4)}
     del out
     # sort through the raw C-ABI call on pre-allocated buffers (in place: re-filled before every repetition)
     ktmp = torch.empty_like(k)
@@ -139,24 +202,10 @@ def secondary_rows(torch, L, ops, dev, local_rank):
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1)
         best = t if best is None else min(best, t)
-    rows["sort u32 keys n=1e9 (stable LSD radix)"] = {"ms": round(best, 3), "gkeys_per_s": round(n / best / 1e6, 1)}
+    rows["sort u32 keys n=1e9 (stable LSD radix)"] = {"ms": round(best, 3), "gkeys_per_s": round(n / best / 1e6, 1),
+                                                      "lower_bound_frac_of_8TBps": round(8.0 * n / best / 1e6 / HBM_PEAK_GBPS, 4)}
     del k, ktmp, tmp
     torch.cuda.empty_cache()
-
-    # vex::FFT (outside BASELINE.json's configs): complex fp64, algorithmic bytes = one read + one write
-    for label, sizes, dirs in (("fft c2c f64, 65536 rows x 1024", [65536, 1024], [ops.NONE, ops.FORWARD]),
-                               ("fft c2c f64, 2^24 points", [1 << 24], [ops.FORWARD]),
-                               ("fft c2c f64, 4096 x 4096", [4096, 4096], [ops.FORWARD, ops.FORWARD])):
-        total = 1
-        for s in sizes:
-            total *= s
-        z = torch.view_as_complex(ops.fill_hash(torch.empty(2 * total, dtype=torch.float64, device=dev), 7).view(total, 2))
-        w = torch.empty_like(z)
-        f = ops.FFT(sizes, dirs)
-        ms = timed(lambda: f(z, out=w, scaled=False), 10)
-        rows[label] = {"ms": round(ms, 4), "gbps": round(32.0 * total / ms / 1e6, 1), "passes": f.steps()[0]}
-        del f, z, w
-        torch.cuda.empty_cache()
     return rows
 
 
@@ -171,11 +220,12 @@ def main():
                          "sell8: diagonal codes, values as they are; sell32: 32-bit columns; hell: reference layout; csr")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-grid", type=int, default=256)
+    ap.add_argument("--cpu-grid", type=int, default=512)
     ap.add_argument("--dist", action="store_true", help="use the partitioned SpMat even on one GPU (debug)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: debug)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (debug: exercises the N>1 path on a 1-GPU box; needs --backend gloo)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (elementwise, reduce, scan, sort, multi-rhs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (CSR-bytes kernels, variable coefficients, C++ front end, elementwise, reduce, scan, sort)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic = null)")
     args = ap.parse_args()
 
     import torch
@@ -207,6 +257,7 @@ def main():
     nnz_total = L.poisson3d_nnz(n)
     part = partition(N, world)
     r0, r1 = part[rank], part[rank + 1]
+    single = world == 1 and not args.dist
 
     # ---- inputs resident in HBM before the timed region
     ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
@@ -214,16 +265,18 @@ def main():
     x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev),
                       (42 + r0 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
     y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
-    if world == 1 and not args.dist:
+    if single:
         A = ops.SpMat(ptr, col, val, fmt=args.format)
-        fmt = A.fmt
-        if fmt in ("hell", "sell"):
-            del ptr, col, val                    # the product only needs the ELL arrays
+        storage = A.storage
+        matrix_bytes = A.matrix_bytes()
+        if storage not in ("csr",):
+            del ptr, col, val                    # the product only needs the converted storage
             A.ptr = A.col = A.val = None
         step = lambda: A.apply(x, y, 1.0, False)
     else:
         A = DistSpMat(ptr, col, val, N, N, local_fmt=args.format)
-        fmt = A.loc.fmt
+        storage = A.loc.storage
+        matrix_bytes = A.loc.matrix_bytes()
         step = lambda: A.apply(x, y, 1.0, False)
     torch.cuda.synchronize()
 
@@ -265,21 +318,29 @@ def main():
     per_step = elapsed / args.steps
     kern_s = ms.value / 1e3 / args.steps         # average launch duration of the product on this rank
 
+    # ---- the result is checked inside the run: an evaluation of the stencil that never touches the matrix
+    check = None
+    if single:
+        yref, bound = independent_product(torch, x, n)
+        err = float((y - yref).abs().max())
+        sum_ref = float(yref.sum(dtype=torch.float64))
+        tol = 1e-10 * bound
+        check = {"sum_y": checksum, "sum_y_independent": sum_ref, "max_abs_err": err,
+                 "tolerance": "1e-10 * sum|terms| = %.3e (SURVEY 8c)" % tol,
+                 "what": "torch slicing of x on the n^3 grid, no matrix involved"}
+        assert abs(checksum - sum_ref) <= tol and err <= tol, "product does not match the independent stencil evaluation: %r" % check
+        del yref
+
     if rank == 0:
         nnz_rank = L.poisson3d_strip_nnz(n, r0, r1)
+        rows_rank = r1 - r0
         alg_total = algorithmic_bytes(N, nnz_total)
-        alg_rank = algorithmic_bytes(r1 - r0, nnz_rank)
+        alg_rank = algorithmic_bytes(rows_rank, nnz_rank)
+        moved_rank = matrix_bytes + 16 * rows_rank                 # what the launched kernel streams: stored matrix + x + y
         gflops = 2.0 * nnz_total / per_step / 1e9
         gbps = alg_total / per_step / 1e9
-        hell = (A.hell if world == 1 and not args.dist else A.loc.hell)
-        if fmt == "sell" and getattr(hell, "values", None) is not None:
-            fmt = "sell8v"                       # ... and 1-byte value codes (<= 255 distinct values: constant-coefficient stencil)
-        elif fmt == "sell" and getattr(hell, "deltas", None) is not None:
-            fmt = "sell8"                        # SELL-512 with 1-byte diagonal codes (banded matrix detected)
-        kname = {"hell": "hell_kernel", "sell": "sell_kernel", "sell8": "sell8_kernel", "sell8v": "sell8v_kernel"}.get(fmt, "csr_stream_kernel")
-        traffic = read_traffic(kname) if (world == 1 and n == 512) else None
         out = {
-            "metric": "fp64 CSR SpMV GFLOP/s, 3D Poisson %d^3 (y = A*x, vex::SpMat path)" % n,
+            "metric": "fp64 CSR SpMV GFLOP/s, 3D Poisson %d^3 (y = A*x through vex::SpMat's library object vexhip_spmat)" % n,
             "value": round(gflops, 2),
             "unit": "GFLOP/s",
             "n_gpus": world,
@@ -291,77 +352,99 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "checksum_sum_y": checksum,
+            "front_end": "vexcl_amd/ops.py SpMat -> vexhip_spmat_create / vexhip_spmat_apply_f64 (the C++ vex::SpMat calls the same two; "
+                         "its own timing of this product is under secondary['C++ front end'])",
+            "checksum": check if check else {"sum_y": checksum},
             "hbm_gbps": round(gbps, 1),
-            "hbm_frac_of_peak": round(gbps / (HBM_PEAK_GBPS * world), 4),
+            "hbm_gbps_note": "CSR-algorithmic bytes / time (the metric's definition); the kernel's own traffic is under roofline",
             "config": {"workload": "configs[%d]: 7-point 3D Poisson %d^3, N=%d rows, nnz=%d, fp64 values, int32 indices"
                                    % (2 if world == 1 else 3, n, N, nnz_total),
-                       "format": fmt, "rows_per_gpu": r1 - r0,
+                       "format": storage, "rows_per_gpu": rows_rank,
                        "parallelism": "row-partitioned x%d" % world},
             "roofline": {"bound": "hbm",
-                         # achieved / frac follow the contract: ALGORITHMIC (CSR-format) bytes over the launch time.  A
-                         # format that stores fewer bytes than CSR moves less than that -- `traffic` (PMC) says how much
-                         # -- so frac can exceed 1; traffic_gbps / traffic_frac_of_peak are what crosses the HBM pins.
-                         "achieved": round(alg_rank / kern_s / 1e9, 1),
+                         "kernel": KERNEL_OF.get(storage, storage),
+                         "achieved": round(moved_rank / kern_s / 1e9, 1),
                          "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s",
-                         "frac": round(alg_rank / kern_s / 1e9 / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic,
-                         # the stored matrix is smaller than the CSR-based algorithmic figure (1-byte diagonal codes):
-                         # what actually crosses the HBM pins, for comparison with the 6.3 TB/s a stream reaches
-                         "traffic_gbps": (round(traffic / kern_s / 1e9, 1) if traffic else None),
-                         "traffic_frac_of_peak": (round(traffic / kern_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None),
-                         "kernel": kname,
+                         "frac": round(moved_rank / kern_s / 1e9 / HBM_PEAK_GBPS, 4),
+                         "bytes_per_launch": moved_rank,
+                         "bytes_per_launch_what": "stored matrix (%d B: %s) + x once + y once" % (matrix_bytes, storage),
                          "algorithmic_bytes_per_launch": alg_rank,
+                         "algorithmic_gbps": round(alg_rank / kern_s / 1e9, 1),
+                         "traffic": None,
                          "avg_launch_ms": round(kern_s * 1e3, 5)},
         }
         if world > 1:
             out["config"]["exchange_bytes_per_rank"] = A.exchange_bytes()
-        if world == 1 and not args.dist and not args.no_secondary:
+        if single and not args.no_secondary:
+            sec = {}
             try:
-                sec = {}
-                if fmt in ("sell", "sell8", "sell8v"):   # Y = A * X, X a multivector<double, 4>
-                    xs = [ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 100 + k) for k in range(4)]
-                    ys = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(4)]
-                    A.apply_multi(xs, ys); torch.cuda.synchronize()
-                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    ev0.record()
-                    for _ in range(10):
-                        A.apply_multi(xs, ys)
-                    ev1.record(); torch.cuda.synchronize()
-                    t4 = ev0.elapsed_time(ev1) / 10
-                    sec["SpMV 4 right-hand sides (SpMat * multivector<double,4>), %d^3" % n] = {
-                        "ms": round(t4, 4), "gflops": round(8.0 * nnz_total / t4 / 1e6, 1)}
-                    del xs, ys
-                hell = None
+                # ---- kernels that stream what the metric counts: fp64 values + 32-bit columns, no compression
                 del A
                 torch.cuda.empty_cache()
-                if fmt in ("sell8v", "sell8"):
-                    # the same product with less compact storage of the same matrix, for comparison: values as they
-                    # are (diagonal codes only), and plain 32-bit columns (what a matrix without structure gets)
-                    p2, c2, v2 = ops.poisson3d(n, dev)
-                    xx = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
-                    yy = torch.empty_like(xx)
-                    for f2, label in (("sell8", "diagonal codes, fp64 values stored"), ("sell32", "32-bit columns, fp64 values stored")):
-                        if f2 == fmt:
-                            continue
-                        B = ops.SpMat(p2, c2, v2, fmt=f2)
-                        B.apply(xx, yy); torch.cuda.synchronize()
-                        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        ev0.record()
-                        for _ in range(20):
-                            B.apply(xx, yy)
-                        ev1.record(); torch.cuda.synchronize()
-                        tb = ev0.elapsed_time(ev1) / 20
-                        sec["SpMV same matrix, %s" % label] = {"ms": round(tb, 4), "gflops": round(2.0 * nnz_total / tb / 1e6, 1)}
-                        del B
-                    del p2, c2, v2, xx, yy
-                    torch.cuda.empty_cache()
+                p2, c2, v2 = ops.poisson3d(n, dev)
+                rcsr = []
+                for f2, label in (("sell32", "SELL-512, 32-bit columns + fp64 values (vexhip_spmat format SELL)"),
+                                  ("csr", "the CSR arrays themselves (row pointers + columns + values)")):
+                    B = ops.SpMat(p2, c2, v2, fmt=f2)
+                    tb = timed_events(torch, lambda: B.apply(x, y), 20)
+                    assert abs(DistReductor("SUM_Kahan")(y) - checksum) <= 1e-10 * abs(checksum) + 1e-300
+                    rcsr.append({"kernel": KERNEL_OF[B.storage], "what": label, "avg_launch_ms": round(tb, 5),
+                                 "gflops": round(2.0 * nnz_total / tb / 1e6, 1),
+                                 "achieved": round(alg_total / tb / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": round(alg_total / tb / 1e6 / HBM_PEAK_GBPS, 4),
+                                 "bytes_per_launch": B.matrix_bytes() + 16 * N, "algorithmic_bytes_per_launch": alg_total})
+                    del B
+                out["roofline_csr"] = rcsr
+                del p2, c2, v2
+                torch.cuda.empty_cache()
+                # ---- the general matrix: same pattern, nnz distinct values, default SpMat
+                p3, c3, v3 = ops.diffusion3d(n, dev)
+                V = ops.SpMat(p3, c3, v3)
+                del p3, c3, v3
+                V.ptr = V.col = V.val = None
+                tv = timed_events(torch, lambda: V.apply(x, y), 20)
+                mv = V.matrix_bytes() + 16 * N
+                out["variable_coefficient"] = {
+                    "workload": "7-point -div(k grad u) on %d^3, k different on every face: nnz = %d distinct values (vexhip_diffusion3d_strip_f64_i32)" % (n, nnz_total),
+                    "format": V.storage, "kernel": KERNEL_OF.get(V.storage, V.storage), "avg_launch_ms": round(tv, 5),
+                    "gflops": round(2.0 * nnz_total / tv / 1e6, 1),
+                    "roofline": {"bound": "hbm", "achieved": round(mv / tv / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": round(mv / tv / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": mv,
+                                 "algorithmic_bytes_per_launch": alg_total, "algorithmic_gbps": round(alg_total / tv / 1e6, 1)},
+                    "sum_y": DistReductor("SUM_Kahan")(y)}
+                # multi-right-hand-side product on the general matrix
+                xs = [ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 100 + k) for k in range(4)]
+                ys = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(4)]
+                t4 = timed_events(torch, lambda: V.apply_multi(xs, ys), 10)
+                sec["SpMV 4 right-hand sides (SpMat * multivector<double,4>), variable coefficients %d^3" % n] = {
+                    "ms": round(t4, 4), "gflops": round(8.0 * nnz_total / t4 / 1e6, 1)}
+                del V, xs, ys
+                torch.cuda.empty_cache()
+                # ---- the C++ front end on the same two matrices (examples/spmv_headline.cpp)
+                sec["C++ front end"] = cpp_rows(["spmv_headline", n, 50])
                 sec.update(secondary_rows(torch, L, ops, dev, local_rank))
-                out["secondary"] = sec
+            except AssertionError:
+                raise
             except Exception as e:                   # the headline must not depend on the secondary rows
-                out["secondary"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+                sec["error"] = repr(e)
+            out["secondary"] = sec
+        A = None
+        if single and not args.no_pmc:
+            torch.cuda.empty_cache()
+            try:
+                tr, how = measure_traffic(n)
+            except Exception as e:
+                tr, how = None, repr(e)
+            out["roofline"]["traffic_source"] = how
+            if tr:
+                key = {"sell8v": "sell8_pair_kernel_vcoded", "sell8": "sell8_pair_kernel_values", "sell32": "sell_pair_kernel", "csr": "csr_stream_kernel"}.get(storage)
+                if key in tr:
+                    out["roofline"]["traffic"] = tr[key]["total"]
+                    out["roofline"]["traffic_read_written"] = [tr[key]["read"], tr[key]["written"]]
+                    out["roofline"]["traffic_over_bytes_per_launch"] = round(tr[key]["total"] / float(moved_rank), 4)
+                out["roofline"]["traffic_all_kernels"] = tr
+        if single and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -2,6 +2,9 @@
 // HIP events on the compute queue:  C2 elementwise a = b*c + sin(d) (n = 1e8),
 // reduce sum(a*b) (n = 2^24 and 1e8), inclusive scan and sort of 1e9 uint32
 // keys.  Prints one JSON object per row: algorithmic GB/s and fraction of 8 TB/s.
+// Usage: roofline [n_big = 1e9] [sections = "escpk"]   (e elementwise + reduce, s stencil, c SpMatCCSR,
+// p scan + sort, k by-key primitives); bench.py runs section "e" for its elementwise / reduce rows, so that
+// those rows come from the kernels the expression engine itself generates.
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -32,13 +35,15 @@ static void report(const char *row, double n, double bytes_per_elem, double ms, 
 
 int main(int argc, char **argv) {
     size_t big = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000000000ull;
+    const std::string sections = argc > 2 ? argv[2] : "escpk";
+    auto on = [&](char c) { return sections.find(c) != std::string::npos; };
     vex::Context ctx(vex::Filter::Env && vex::Filter::Count(1));
     if (!ctx) { std::cerr << "no device" << std::endl; return 1; }
     std::cout << ctx << std::endl;
     const vex::backend::command_queue &q = ctx.queue(0);
     timer t(q);
     const int reps = 20;
-    {   // C2
+    if (on('e')) {   // C2
         const size_t n = 100000000;
         vex::vector<double> a(ctx, n), b(ctx, n), c(ctx, n), d(ctx, n);
         b = 0.5 + 1e-9 * vex::element_index(); c = 1.5; d = 1e-8 * vex::element_index();
@@ -58,7 +63,7 @@ int main(int argc, char **argv) {
         report("reduce sum(a*b) f64 n=1e8", n, 16, ms);
         (void)s;
     }
-    {
+    if (on('e')) {
         const size_t n = 1 << 24;
         vex::vector<double> a(ctx, n), b(ctx, n); a = 1.0; b = 0.5;
         vex::Reductor<double, vex::SUM> sum(ctx);
@@ -67,7 +72,7 @@ int main(int argc, char **argv) {
         report("reduce sum(a*b) f64 n=2^24 (incl. host readback)", n, 16, ms);
         (void)s;
     }
-    {   // next row: 21-point stencil convolution, LDS-staged
+    if (on('s')) {   // next row: 21-point stencil convolution, LDS-staged
         const size_t n = 100000000;
         std::vector<double> S(21, 1.0 / 21);
         vex::stencil<double> s(ctx, S, 10);
@@ -77,7 +82,7 @@ int main(int argc, char **argv) {
         t.start(); for (int i = 0; i < reps; ++i) b = a * s; double ms = t.stop_ms() / reps;
         report("stencil b = a * s (21 points) f64", (double)n, 16, ms);
     }
-    {   // next row: the 512^3 Poisson operator as SpMatCCSR -- no (col, val) stream at all
+    if (on('c')) {   // next row: the 512^3 Poisson operator as SpMatCCSR -- no (col, val) stream at all
         const size_t n = 512, N = n * n * n;
         const double h2i = (n - 1.0) * (n - 1.0);
         std::vector<size_t> idx(N), row = {0, 1, 8};
@@ -96,7 +101,7 @@ int main(int argc, char **argv) {
         std::printf("{\"row\": \"SpMatCCSR vs CSR-algorithmic\", \"gflops\": %.1f, \"csr_equiv_gbps\": %.1f}\n",
                 2.0 * 930123728.0 / ms / 1e6, 13845839300.0 / ms / 1e6);
     }
-    {   // C5 scan
+    if (on('p')) {   // C5 scan
         const size_t n = big;
         vex::vector<cl_uint> x(ctx, n), y(ctx, n);
         vex::backend::check(vexhip_fill_hash(q.device_ordinal(), q.raw(), VEXHIP_U32, 42, x(0).raw(), (int64_t)n));
@@ -118,7 +123,7 @@ int main(int argc, char **argv) {
         size_t inv = bad(vex::if_else(vex::permutation(vex::element_index(0, n - 1) + 1)(z) < vex::permutation(vex::element_index(0, n - 1))(z), 1, 0));
         std::printf("{\"row\": \"sort check\", \"inversions\": %zu}\n", inv);
     }
-    {   // by-key primitives: runs of ~64 equal keys, 1e8 (int key, double value) pairs
+    if (on('k')) {   // by-key primitives: runs of ~64 equal keys, 1e8 (int key, double value) pairs
         const size_t n = 100000000;
         std::vector<vex::command_queue> q1(1, q);
         vex::vector<int> keys(q1, n), okeys;

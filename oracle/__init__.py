@@ -119,6 +119,20 @@ def spmv_csr(ptr, col, val, x, y=None, alpha=1.0, append=False, omp=False):
     return y
 
 
+def cpu_baseline_poisson(n, seconds, single_reps=1):
+    """bench.py's CPU leg: the reference's CPU-device csr_spmv shape (8 x threads contiguous row chunks, OpenMP) on the
+    n^3 Poisson matrix, arrays first-touched by the threads that use them; plus the single-thread loop of the
+    reference harness (examples/benchmark.cpp:447-453).  Returns a dict, or None if the arrays do not fit."""
+    L = lib()
+    out = (ctypes.c_double * 5)()
+    L.vxo_cpu_baseline_poisson.restype = ctypes.c_int
+    rc = L.vxo_cpu_baseline_poisson(_i64(n), ctypes.c_double(seconds), ctypes.c_int(single_reps), out)
+    if rc != 0:
+        return None
+    return {"seconds_per_product": out[0], "threads": int(out[1]), "single_thread_seconds_per_product": out[2],
+            "sum_y": out[3], "products": int(out[4])}
+
+
 def num_threads():
     return int(lib().vxo_num_threads())
 

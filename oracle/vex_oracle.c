@@ -174,6 +174,87 @@ void vxo_spmv_csr_f32_i32(int64_t n, float alpha, int append,
 { for (int64_t i = 0; i < n; ++i) SPMV_ROW(i) }
 #undef VAL_T
 
+/*
+ * bench.py's cpu_baseline in one call, with the arrays first-touched by the threads that use them.
+ * Builds the n^3 Poisson matrix (generator above; offsets from the closed form of the row lengths) in
+ * malloc'ed memory, every one of the 8 x threads row chunks written by the thread that will multiply
+ * it (same static schedule as vxo_spmv_csr_f64_i32_omp), then times
+ *   out[0] = seconds per product, OpenMP chunked csr_spmv (the reference's CPU-device shape), run for >= `seconds`
+ *   out[1] = threads used
+ *   out[2] = seconds per product of the single-thread loop examples/benchmark.cpp:447-453 ("C++" line of the
+ *            reference harness), `single_reps` products
+ *   out[3] = sum(y) of the last product (x = 0.01, as benchmark.cpp:369)      out[4] = products timed
+ * Returns 0, or -1 if the arrays cannot be allocated.
+ */
+static int64_t vxo_interior_below(int64_t t, int64_t n) { int64_t v = t - 1; if (v < 0) v = 0; if (v > n - 2) v = n - 2; return v; }
+static int64_t vxo_poisson_nnz_before(int64_t idx, int64_t n)
+{
+    if (n < 3) return idx;
+    int64_t N = n * n * n;
+    if (idx >= N) return N + 6 * (n - 2) * (n - 2) * (n - 2);
+    int64_t i = idx % n, j = (idx / n) % n, k = idx / (n * n), m = n - 2;
+    int64_t cnt = vxo_interior_below(k, n) * m * m;
+    if (k >= 1 && k <= n - 2) { cnt += vxo_interior_below(j, n) * m; if (j >= 1 && j <= n - 2) cnt += vxo_interior_below(i, n); }
+    return idx + 6 * cnt;
+}
+
+int vxo_cpu_baseline_poisson(int64_t n, double seconds, int single_reps, double *out)
+{
+    const int64_t N = n * n * n, nnz = vxo_poisson3d_nnz(n), nn = n * n;
+    int32_t *ptr = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N + 1));
+    int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)nnz);
+    double *val = (double *)malloc(sizeof(double) * (size_t)nnz);
+    double *x = (double *)malloc(sizeof(double) * (size_t)N), *y = (double *)malloc(sizeof(double) * (size_t)N);
+    if (!ptr || !col || !val || !x || !y) { free(ptr); free(col); free(val); free(x); free(y); return -1; }
+    int P = 1;
+#ifdef _OPENMP
+    P = omp_get_max_threads();
+#endif
+    const int64_t G = 8 * (int64_t)P, chunk = (N + G - 1) / G;
+    const double h2i = (double)(n - 1) * (double)(n - 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < G; ++g) {
+        int64_t b = g * chunk, e = b + chunk; if (e > N) e = N;
+        for (int64_t idx = b; idx < e; ++idx) {
+            int64_t nz = vxo_poisson_nnz_before(idx, n);
+            ptr[idx] = (int32_t)nz;
+            int64_t i = idx % n, j = (idx / n) % n, k = idx / nn;
+            if (i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1) { col[nz] = (int32_t)idx; val[nz] = 1; }
+            else {
+                col[nz] = (int32_t)(idx - nn); val[nz++] = -h2i; col[nz] = (int32_t)(idx - n); val[nz++] = -h2i;
+                col[nz] = (int32_t)(idx - 1);  val[nz++] = -h2i; col[nz] = (int32_t)idx;       val[nz++] = 6 * h2i;
+                col[nz] = (int32_t)(idx + 1);  val[nz++] = -h2i; col[nz] = (int32_t)(idx + n); val[nz++] = -h2i;
+                col[nz] = (int32_t)(idx + nn); val[nz] = -h2i;
+            }
+            x[idx] = 0.01; y[idx] = 0;
+        }
+    }
+    ptr[N] = (int32_t)nnz;
+    double t0 = 0, t1 = 0;
+    int64_t reps = 0;
+    vxo_spmv_csr_f64_i32_omp(N, 1.0, 0, ptr, col, val, x, y);      /* warm-up */
+#ifdef _OPENMP
+    t0 = omp_get_wtime();
+    do { vxo_spmv_csr_f64_i32_omp(N, 1.0, 0, ptr, col, val, x, y); ++reps; t1 = omp_get_wtime(); } while (t1 - t0 < seconds && reps < 100000);
+#else
+    reps = 1;
+#endif
+    out[0] = reps ? (t1 - t0) / (double)reps : 0; out[1] = P; out[4] = (double)reps;
+    out[2] = 0;
+    if (single_reps > 0) {
+#ifdef _OPENMP
+        double s0 = omp_get_wtime();
+        for (int r = 0; r < single_reps; ++r) vxo_spmv_csr_f64_i32(N, 1.0, 0, ptr, col, val, x, y);
+        out[2] = (omp_get_wtime() - s0) / single_reps;
+#endif
+    }
+    double sum = 0;
+    for (int64_t i = 0; i < N; ++i) sum += y[i];
+    out[3] = sum;
+    free(ptr); free(col); free(val); free(x); free(y);
+    return 0;
+}
+
 int vxo_num_threads(void)
 {
 #ifdef _OPENMP

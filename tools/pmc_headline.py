@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Workload of bench.py's counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): a calibration stream of known
+size (2 GiB read with 16-byte loads by the reduction kernel), then three products with each storage of the 512^3
+matrices bench.py times -- the default SpMat on the Poisson matrix (value codes), on the variable-coefficient matrix
+(diagonal codes + fp64 values), 32-bit columns, and the CSR arrays.  Counter values are read per dispatch from
+rocprofv3's CSV by bench.py (measure_traffic)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vexcl_amd import ops
+
+dev = torch.device("cuda:0")
+n = int(os.environ.get("GRID", "512"))
+N = n ** 3
+x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
+y = torch.zeros(N, dtype=torch.float64, device=dev)
+cal = torch.empty(1 << 28, dtype=torch.float64, device=dev).normal_()
+r = ops.Reductor("SUM")
+torch.cuda.synchronize()
+for _ in range(3):
+    r.device_result(cal)
+del cal
+ptr, col, val = ops.poisson3d(n, dev)
+for fmt in ("auto", "sell32", "csr"):
+    A = ops.SpMat(ptr, col, val, fmt=fmt)
+    for _ in range(3):
+        A.apply(x, y)
+    torch.cuda.synchronize()
+    del A
+del ptr, col, val
+torch.cuda.empty_cache()
+ptr, col, val = ops.diffusion3d(n, dev)
+A = ops.SpMat(ptr, col, val)
+for _ in range(3):
+    A.apply(x, y)
+torch.cuda.synchronize()
+print("done")
