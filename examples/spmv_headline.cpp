@@ -44,7 +44,8 @@ int main(int argc, char **argv) {
             A = vex::SpMat<double, int, int>(ctx.queue(), N, N, nnz, ptr, col, val);
         }       // the CSR arrays are released here unless the matrix kept them (plain CSR storage)
         vex::vector<double> x(ctx, N), y(ctx, N);
-        x = 1e-2 + 1e-9 * vex::element_index();
+        // the same x as bench.py (counter hash, seed 42): sum(y) of the Poisson row must equal bench.py's checksum
+        vex::backend::check(vexhip_fill_hash(dev, q.raw(), VEXHIP_F64, 42, x(0).raw(), (int64_t)N));
         y = A * x;                                                   // warm-up
         q.finish();
         vex::backend::check(vexhip_event_record(dev, e0, q.raw()));

@@ -285,6 +285,50 @@ int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, 
 int vexhip_spmat_apply_multi_f32(const vexhip_spmat *A, void *stream, int nrhs, float alpha, int append, const float *const *x, float *const *y);
 int vexhip_spmat_get_info(const vexhip_spmat *A, vexhip_spmat_info *info);
 
+/* ---- RCCL transport over xGMI -------------------------------------------------------------
+ * Replaces the host-staged ghost exchange of vexcl/spmat.hpp:125-183 / sparse/distributed.hpp:347-428 (device ->
+ * host -> device, four finish() fences), the host fold of the Reductor partials (reductor.hpp:412-436) and the host
+ * carry of multi-device scans (scan.hpp:445-457).  librccl is loaded on first use.
+ * A communicator spans the devices of ONE process (vexhip_comm_init: the reference's model, one Context drives every
+ * GPU; every call then takes arrays with one entry per local device and issues ONE RCCL group) or is one rank of a
+ * one-process-per-GPU job (vexhip_comm_init_rank; rank 0 makes the 128-byte id, the launcher distributes it).        */
+typedef struct vexhip_comm vexhip_comm;
+int vexhip_comm_unique_id(void *id128);
+enum { VEXHIP_COMM_AUTO = 0,   /* RCCL when the devices are distinct GPUs and there are at least two, else PEER          */
+       VEXHIP_COMM_RCCL = 1,   /* grouped ncclSend / ncclRecv, ncclAllReduce, ncclAllGather                               */
+       VEXHIP_COMM_PEER = 2 }; /* single process only: event-ordered device-to-device copies (no communicator; the only  *
+                                * option when logical devices share one GPU -- the reference's own test fixture,           *
+                                * tests/context_setup.hpp:24-39 -- and the host fold of the reference for reductions)      */
+int vexhip_comm_init(int ndev, const int *devs, int transport, vexhip_comm **out);
+int vexhip_comm_init_rank(int dev, int rank, int world, const void *id128, vexhip_comm **out);
+int vexhip_comm_destroy(vexhip_comm *comm);
+int vexhip_comm_size(const vexhip_comm *comm, int *world, int *nlocal, int *transport);
+/* Ghost exchange: local device d sends send_counts[d*world + p] elements to rank p, taken from send_bufs[d] in rank
+ * order (contiguous), and receives recv_counts[d*world + p] from it into recv_bufs[d] in rank order: grouped
+ * ncclSend / ncclRecv on streams[d].  A rank's share for itself is a device copy.                                  */
+int vexhip_halo_exchange(vexhip_comm *comm, int dtype, const void *const *send_bufs, const int64_t *send_counts,
+        void *const *recv_bufs, const int64_t *recv_counts, void *const *streams);
+/* In-place all-reduce of `count` elements per device (op: VEXHIP_SUM / SUM_KAHAN -> sum, MIN, MAX) */
+int vexhip_allreduce_scalar(vexhip_comm *comm, int op, int dtype, void *const *bufs, int64_t count, void *const *streams);
+/* recv[d] = concatenation over ranks of their `count` elements */
+int vexhip_allgather(vexhip_comm *comm, int dtype, const void *const *send, void *const *recv, int64_t count, void *const *streams);
+
+/* One rank's product step of a row-partitioned SpMat, issued from C++: pack (gather of the owned values the peers
+ * need) -> grouped send/recv on a second stream -> local part (overlapped) -> remote part after the receive
+ * (the five phases of spmat.hpp:125-183 with one xGMI hop).  All arrays are device memory owned by the caller:
+ * local = vexhip_spmat of the owned columns (NULL: none); remote part = row-subset CSR over the ghost buffer
+ * (rows_idx[rem_rows], rem_ptr[rem_rows + 1], columns = positions in ghost_buf); send_idx[nsend] = local ids packed
+ * into send_buf in peer order; send_counts / recv_counts[world].  set_graph(1): the step is captured into a hipGraph
+ * on first use and replayed while the operands stay the same (needs a non-default stream).                          */
+typedef struct vexhip_dist_spmv vexhip_dist_spmv;
+int vexhip_dist_spmv_create(vexhip_comm *comm, int dtype, int64_t rows, const vexhip_spmat *local,
+        int64_t rem_rows, const int32_t *rows_idx, const int32_t *rem_ptr, const int32_t *rem_col, const void *rem_val,
+        int64_t nsend, const int32_t *send_idx, void *send_buf, const int64_t *send_counts,
+        int64_t nghost, void *ghost_buf, const int64_t *recv_counts, vexhip_dist_spmv **out);
+int vexhip_dist_spmv_destroy(vexhip_dist_spmv *step);
+int vexhip_dist_spmv_set_graph(vexhip_dist_spmv *step, int enable);
+int vexhip_dist_spmv_apply(vexhip_dist_spmv *step, void *stream, double alpha, int append, const void *x, void *y);
+
 /* Multi-right-hand-side products  y[k] (+)= alpha * A * x[k],  k < nrhs  -- `SpMat * multivector`
  * (vexcl/spmat.hpp:388-398, which applies the product once per component; tests/spmv.cpp:262-305).
  * One launch per group of up to four right-hand sides reads the matrix ONCE; each y[k] is

@@ -69,5 +69,8 @@ if [ $# -eq 0 ]; then
     printf '%s\n' $EXAMPLES | xargs -P "$jobs" -I{} bash -c 'build_example {}'
     printf '%s\n' $CHECKED | xargs -P "$jobs" -I{} bash -c 'build_checked {}'
 fi
-ls "$out" | grep -v '\.log$' > "$out/MANIFEST" || true
+ls "$out" | grep -v '\.log$' | grep -v '^HEADERS_SHA256$' > "$out/MANIFEST" || true
+# the binaries embed the vexcl/ headers (code generators included): record what they were built from, so that
+# tests/test_reference_suite.py can refuse to run binaries that are older than the headers they claim to test
+python3 "$here/headers_hash.py" > "$out/HEADERS_SHA256"
 exit 0

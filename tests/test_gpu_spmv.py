@@ -27,6 +27,8 @@ def T():
         pass
     ns = NS()
     ns.torch, ns.ops, ns.dev = torch, ops, torch.device("cuda:0")
+    from vexcl_amd import lib
+    ns.L = lib()
     ns.up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ns.dev)
     return ns
 
@@ -209,6 +211,41 @@ def test_poisson128_benchmark_size(T, oracle):
     for fmt in ("csr", "hell", "sell"):
         y = T.ops.SpMat(dp, dc, dv, fmt=fmt) @ T.up(x)
         assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_variable_coefficient_128_every_storage(T, oracle):
+    """The general banded matrix -- the 7-point pattern with a different coefficient on every face, nnz distinct values
+    (what bench.py's variable-coefficient row runs at 512^3) -- at 128^3: the device generator equals its host
+    restatement bit for bit, the default SpMat picks diagonal codes WITHOUT value codes, and every storage the matrix
+    allows (sell8, sell32, csr, the reference's hybrid-ELL layout; `y = ` and `y += alpha *`) equals the oracle's CSR
+    loop bit for bit.  The pair kernels must also run the per-entry kernels' arithmetic: A/B switch."""
+    n = 128
+    N = n ** 3
+    ptr, col, val = oracle.diffusion3d(n)
+    dp, dc, dv = T.ops.diffusion3d(n, T.dev)
+    assert np.array_equal(dp.cpu().numpy(), ptr) and np.array_equal(dc.cpu().numpy(), col) and np.array_equal(dv.cpu().numpy(), val)
+    assert len(np.unique(val)) > 0.99 * (len(val) - (N - (n - 2) ** 3))            # every interior entry its own value
+    x = oracle.random_f64(11, N) - 0.5
+    y0 = oracle.random_f64(12, N)
+    want = oracle.spmv_csr(ptr, col, val, x, omp=True)
+    want_app = y0.copy(); oracle.spmv_csr(ptr, col, val, x, want_app, -1.75, True)
+    A = T.ops.SpMat(dp, dc, dv)
+    assert A.storage == "sell8" and A.hell.ndeltas == 7 and A.hell.values is None
+    for fmt in ("sell", "sell32", "csr", "hell"):
+        for variant in ((0, 1) if fmt in ("sell", "sell32") else (0,)):
+            T.L.spmv_sell8_set_variant(variant)
+            try:
+                B = T.ops.SpMat(dp, dc, dv, fmt=fmt)
+                y = B @ T.up(x)
+                assert np.array_equal(y.cpu().numpy(), want), (fmt, variant)
+                ya = T.up(y0.copy()); B.apply(T.up(x), ya, -1.75, True)
+                assert np.array_equal(ya.cpu().numpy(), want_app), (fmt, variant)
+            finally:
+                T.L.spmv_sell8_set_variant(0)
+    # symmetric, and interior rows sum to ~0 (diagonal = minus the sum of the six couplings)
+    ones = T.torch.ones(N, dtype=T.torch.float64, device=T.dev)
+    r = (A @ ones).view(n, n, n)[1:-1, 1:-1, 1:-1]
+    assert float(r.abs().max()) <= 1e-9 * float(np.abs(val).max())
 
 
 def test_poisson512_properties(T):

@@ -173,3 +173,53 @@ def test_fft_oracle_matches_the_definition(oracle):
         want[b] = np.stack([oracle.dft_definition(t[r, :], True) for r in range(5)], axis=0)   # inverse along dim 2
     assert np.abs(oracle.fft_nd(x, sizes, dirs) - want.reshape(-1)).max() <= 1e-12
     assert [oracle.fft_best_size(n) for n in (1, 2, 11, 17, 1025, 4097)] == [1, 2, 12, 18, 1029, 4116]
+
+
+def test_variable_coefficient_generator(oracle):
+    """The general-matrix generator of bench.py's variable-coefficient row: the Poisson pattern, symmetric, interior rows
+    summing to zero, (almost) every entry its own value; deterministic in the seed."""
+    import scipy.sparse as sp
+    n = 12
+    ptr, col, val = oracle.diffusion3d(n)
+    pp, cc, vv = oracle.poisson3d(n)
+    assert np.array_equal(ptr, pp) and np.array_equal(col, cc)
+    A = sp.csr_matrix((val, col, ptr), shape=(n ** 3, n ** 3))
+    interior = np.diff(ptr) == 7
+    B = A[interior][:, interior]
+    assert abs(B - B.T).max() == 0.0                                  # couplings between interior points are symmetric
+    assert np.abs(A @ np.ones(n ** 3))[interior].max() <= 1e-9 * np.abs(val).max()
+    assert np.all(val[np.isin(np.arange(len(val)), ptr[:-1][~interior])] == 1.0)      # boundary rows: identity
+    assert len(np.unique(val[val != 1.0])) > 0.45 * np.count_nonzero(val != 1.0)      # each coupling appears in two rows
+    p2, c2, v2 = oracle.diffusion3d(n, seed=8)
+    assert not np.array_equal(val, v2) and np.array_equal(oracle.diffusion3d(n)[2], val)
+
+
+def test_sell_pair_slots_keep_row_order(oracle):
+    """Row-pair placement of the SELL storages (restated for the layout tests): whatever the two rows look like, each
+    row's entries keep their CSR order, equal diagonals share a column, and a pair that does not fit stays packed."""
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n, m, w = 2, int(rng.integers(3, 40)), int(rng.integers(1, 9))
+        rows = [np.sort(rng.choice(m, size=int(rng.integers(0, min(m, 10))), replace=False)) if rng.random() < 0.7
+                else rng.integers(0, m, size=int(rng.integers(0, 10))) for _ in range(n)]
+        ptr = np.array([0, len(rows[0]), len(rows[0]) + len(rows[1])], dtype=np.int32)
+        col = np.concatenate(rows).astype(np.int32) if ptr[-1] else np.zeros(0, dtype=np.int32)
+        slots = oracle.sell_pair_slots(ptr, col, 0, w, m - 1)
+        for q in (0, 1):
+            assert len(slots[q]) == w
+            real = [e for e in slots[q] if not isinstance(e, str)]
+            assert real == list(range(int(ptr[q]), min(int(ptr[q + 1]), int(ptr[q]) + w)))
+        for e0, e1 in zip(*slots):
+            if isinstance(e0, str) or isinstance(e1, str):
+                continue
+            aligned = all(isinstance(a, str) or isinstance(b, str) or int(col[a]) - 0 == int(col[b]) - 1 for a, b in zip(*slots))
+            packed = [e for e in slots[0] if not isinstance(e, str)] == slots[0][:len([e for e in slots[0] if not isinstance(e, str)])]
+            assert aligned or packed
+
+
+def test_cpu_baseline_runs(oracle):
+    r = oracle.cpu_baseline_poisson(24, 0.05, 1)
+    ptr, col, val = oracle.poisson3d(24)
+    y = oracle.spmv_csr(ptr, col, val, np.full(24 ** 3, 0.01))
+    assert r["threads"] >= 1 and r["products"] >= 1 and r["seconds_per_product"] > 0
+    assert abs(r["sum_y"] - y.sum()) <= 1e-9 * np.abs(y).sum()

@@ -1,18 +1,36 @@
 #ifndef VEXCL_EXCHANGE_HPP
 #define VEXCL_EXCHANGE_HPP
-// Ghost-value exchange between the devices of one context, shared by
-// vex::sparse::distributed (reference: vexcl/sparse/distributed.hpp:347-428 --
-// gather kernel, blocking D2H, host scatter, H2D).  Here: per consumer, each
-// owner packs exactly the values that consumer needs (gather kernel) and the
-// consumer pulls them with one peer copy per (owner, consumer) pair on a
-// secondary queue: xGMI between GPUs, a device-to-device copy between logical
-// devices of one GPU; no host hop, no finish().
+// Ghost-value exchange between the devices of one context, shared by vex::SpMat and
+// vex::sparse::distributed (reference: vexcl/spmat.hpp:125-183 and sparse/distributed.hpp:347-428 --
+// gather kernel, blocking D2H, host scatter, H2D, four finish() fences).  Here: every owner packs,
+// per consumer, exactly the values that consumer needs (gather kernel on its primary queue), then
+// ONE call ships everything on the secondary queues: vexhip_halo_exchange (include/vexhip.h) --
+// grouped ncclSend / ncclRecv over xGMI when the context's devices are distinct GPUs, event-ordered
+// device-to-device copies when logical devices share a GPU (the reference's test fixture) or when
+// VEXCL_EXCHANGE=peer asks for it.  No host hop, no finish(); the local product overlaps the exchange.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <vector>
 #include "backend.hpp"
 #include "util.hpp"
 
 namespace vex {
 namespace detail {
+
+/// One communicator per device list (shared by matrices, reductors and scans of the same context).
+inline std::shared_ptr<vexhip_comm> make_comm(const std::vector<backend::command_queue> &q) {
+    std::vector<int> devs;
+    for (const auto &qq : q) devs.push_back(qq.device_ordinal());
+    int transport = VEXHIP_COMM_AUTO;
+    if (const char *e = std::getenv("VEXCL_EXCHANGE")) {
+        if (!std::strcmp(e, "peer")) transport = VEXHIP_COMM_PEER;
+        else if (!std::strcmp(e, "rccl")) transport = VEXHIP_COMM_RCCL;
+    }
+    vexhip_comm *c = nullptr;
+    backend::check(vexhip_comm_init(static_cast<int>(devs.size()), devs.data(), transport, &c));
+    return std::shared_ptr<vexhip_comm>(c, [](vexhip_comm *p) { vexhip_comm_destroy(p); });
+}
 
 template <class T>
 class ghost_exchange {
@@ -24,11 +42,16 @@ class ghost_exchange {
         void setup(const std::vector<backend::command_queue> &q, const std::vector<size_t> &col_part,
                 const std::vector<std::vector<C>> &ghosts)
         {
+            static_assert(sizeof(T) % 4 == 0, "ghost values travel as 32-bit words");
             queue = q;
             for (const auto &qq : q) squeue.push_back(backend::duplicate_queue(qq));
             const unsigned nd = static_cast<unsigned>(q.size());
             dev.resize(nd);
+            send_counts.assign(size_t(nd) * nd, 0); recv_counts.assign(size_t(nd) * nd, 0);
             std::vector<std::vector<int>> send_idx(nd);
+            // consumers in rank order, so that owner o's send buffer is grouped by consumer in rank order; every
+            // consumer's sorted ghost list splits into one contiguous run per owner (owners hold contiguous columns),
+            // so what it receives, concatenated in owner order, IS its ghost vector (spmat.hpp:291-378)
             for (unsigned d = 0; d < nd; ++d) {
                 const auto &g = ghosts[d];
                 dev[d].nghost = g.size();
@@ -37,9 +60,10 @@ class ghost_exchange {
                     unsigned o = static_cast<unsigned>(column_owner(static_cast<size_t>(g[i]), col_part));
                     size_t j = i;
                     while (j < g.size() && static_cast<size_t>(g[j]) < col_part[o + 1]) ++j;
-                    pair_t p; p.owner = o; p.consumer = d; p.send_off = send_idx[o].size(); p.recv_off = i; p.count = j - i;
                     for (size_t k = i; k < j; ++k) send_idx[o].push_back(static_cast<int>(static_cast<size_t>(g[k]) - col_part[o]));
-                    pairs.push_back(p);
+                    send_counts[size_t(o) * nd + d] += static_cast<int64_t>((j - i) * words);
+                    recv_counts[size_t(d) * nd + o] += static_cast<int64_t>((j - i) * words);
+                    any = true;
                     i = j;
                 }
             }
@@ -52,49 +76,78 @@ class ghost_exchange {
                 // never empty: kernels always receive a valid pointer
                 dev[d].ghost_buf = backend::device_vector<T>(q[d], std::max<size_t>(1, dev[d].nghost));
             }
+            if (any) {
+                comm = make_comm(q);
+                ev = std::make_shared<events>();
+                ev->devs.resize(nd); ev->packed.assign(nd, nullptr); ev->shipped.assign(nd, nullptr);
+                for (unsigned d = 0; d < nd; ++d) {
+                    ev->devs[d] = q[d].device_ordinal();
+                    backend::check(vexhip_event_create(ev->devs[d], 0, &ev->packed[d]));
+                    backend::check(vexhip_event_create(ev->devs[d], 0, &ev->shipped[d]));
+                }
+            }
         }
 
-        bool active() const { return !pairs.empty(); }
+        bool active() const { return any; }
         size_t ghosts(unsigned d) const { return dev[d].nghost; }
         const backend::device_vector<T> &ghost_buffer(unsigned d) const { return dev[d].ghost_buf; }
 
-        /// Packs and ships the ghosts of x; the primary queues wait for their arrival.
+        /// Packs the ghosts of x and ships them on the secondary queues; returns without waiting.
         template <class Parts>
-        void run(const Parts &x) const {
+        void start(const Parts &x) const {
             const unsigned nd = static_cast<unsigned>(queue.size());
+            // (1) the previous exchange must be done with the send buffers before they are packed again
             for (unsigned o = 0; o < nd; ++o)
-                if (dev[o].nsend && !copies_done.empty()) backend::enqueue_barrier(queue[o], copies_done);
-            std::vector<backend::event> packed(nd);
+                if (dev[o].nsend && ev->live) wait(queue[o], ev->shipped[o]);
             for (unsigned o = 0; o < nd; ++o) {
                 if (!dev[o].nsend) continue;
                 backend::check(gather(queue[o].device_ordinal(), queue[o].raw(), (int64_t)dev[o].nsend,
                             dev[o].send_idx.raw(), x(o).raw(), dev[o].send_buf.raw()));
-                packed[o] = backend::enqueue_marker(queue[o]);
             }
-            copies_done.assign(nd, backend::event());
-            for (const auto &p : pairs) {
-                const backend::command_queue &sq = squeue[p.consumer];
-                backend::enqueue_barrier(sq, backend::wait_list(1, packed[p.owner]));
-                backend::check(vexhip_memcpy_peer(sq.device_ordinal(), dev[p.consumer].ghost_buf.raw() + p.recv_off,
-                            queue[p.owner].device_ordinal(), dev[p.owner].send_buf.raw() + p.send_off,
-                            p.count * sizeof(T), sq.raw()));
+            // (2) a marker on every primary queue: behind it lie this product's pack AND the previous product's kernel
+            // that still reads the ghost buffer (the reference fences with finish() at the top of every apply,
+            // spmat.hpp:125-128); the secondary queue waits for it before anything lands in that buffer
+            std::vector<const void *> sbuf(nd); std::vector<void *> rbuf(nd), str(nd);
+            for (unsigned d = 0; d < nd; ++d) {
+                record(queue[d], ev->packed[d]);
+                wait(squeue[d], ev->packed[d]);
+                sbuf[d] = dev[d].nsend ? dev[d].send_buf.raw() : nullptr;
+                rbuf[d] = dev[d].ghost_buf.raw();
+                str[d] = squeue[d].raw();
             }
-            for (unsigned d = 0; d < nd; ++d)
-                if (dev[d].nghost) {
-                    copies_done[d] = backend::enqueue_marker(squeue[d]);
-                    backend::enqueue_barrier(queue[d], backend::wait_list(1, copies_done[d]));
-                }
+            backend::check(vexhip_halo_exchange(comm.get(), VEXHIP_U32, sbuf.data(), send_counts.data(), rbuf.data(), recv_counts.data(), str.data()));
+            for (unsigned d = 0; d < nd; ++d) record(squeue[d], ev->shipped[d]);
+            ev->live = true;
+        }
+
+        /// The primary queue of device d waits for its ghosts.
+        void finish(unsigned d) const { if (ev && ev->live) wait(queue[d], ev->shipped[d]); }
+
+        /// start + finish on every device (sparse::distributed: the fused kernel needs the ghosts at once).
+        template <class Parts>
+        void run(const Parts &x) const {
+            start(x);
+            for (unsigned d = 0; d < queue.size(); ++d) finish(d);
         }
     private:
-        struct pair_t { unsigned owner, consumer; size_t send_off, recv_off, count; };
+        static constexpr size_t words = sizeof(T) / 4;
         struct dev_t {
             backend::device_vector<int> send_idx; backend::device_vector<T> send_buf, ghost_buf;
             size_t nsend = 0, nghost = 0;
         };
         std::vector<backend::command_queue> queue, squeue;
-        std::vector<pair_t> pairs;
         std::vector<dev_t> dev;
-        mutable std::vector<backend::event> copies_done;
+        std::vector<int64_t> send_counts, recv_counts;      // [device][peer], in 32-bit words
+        std::shared_ptr<vexhip_comm> comm;
+        bool any = false;
+        // events re-recorded every product (created once: an event per marker would cost a create/destroy per step)
+        struct events {
+            std::vector<int> devs; std::vector<void *> packed, shipped; bool live = false;
+            ~events() { for (size_t d = 0; d < devs.size(); ++d) { if (packed[d]) vexhip_event_destroy(devs[d], packed[d]); if (shipped[d]) vexhip_event_destroy(devs[d], shipped[d]); } }
+        };
+        std::shared_ptr<events> ev;
+        static void record(const backend::command_queue &q, void *e) { backend::check(vexhip_event_record(q.device_ordinal(), e, q.raw())); }
+        static void wait(const backend::command_queue &q, void *e) { backend::check(vexhip_stream_wait_event(q.device_ordinal(), q.raw(), e)); }
 
         static int gather(int d, void *s, int64_t n, const int *idx, const double *src, double *dst) { return vexhip_gather_f64_i32(d, s, n, idx, src, dst); }
         static int gather(int d, void *s, int64_t n, const int *idx, const float *src, float *dst) { return vexhip_gather_f32_i32(d, s, n, idx, src, dst); }

@@ -5,24 +5,23 @@
 // setup_exchange; per-device parts spmat/csr.inl:34-256, spmat/hybrid_ell.inl:34-401;
 // inline form spmat/inline_spmv.hpp).
 //
-// Each device keeps a LOCAL part (columns it owns, renumbered c - col_begin) and
-// a REMOTE part (ghost columns renumbered to their rank in the device's sorted
-// ghost set).  Device storage is int32-indexed; the local part is hybrid ELL
-// (the reference's GPU choice, spmat.hpp:98-103), the sparse remote part CSR.
-// Kernels: libvexhip (vexhip_spmv_hell_* / vexhip_spmv_csr_*).
+// Each device keeps a LOCAL part (columns it owns, renumbered c - col_begin): a vexhip_spmat, the library
+// object that picks the storage (hybrid-ELL width as spmat/hybrid_ell.inl:103-110, then 1-byte diagonal /
+// value codes, 32-bit columns or plain CSR; include/vexhip.h) -- and a REMOTE part (ghost columns renumbered
+// to their rank in the device's sorted ghost set), a row-subset CSR because it is very sparse.
 //
-// Ghost exchange: the reference stages ghosts device -> host -> device in five
-// finish()-fenced phases (spmat.hpp:125-183).  Here every owner packs, per
-// consumer, exactly the values that consumer needs (gather kernel on the
-// primary queue) and the consumer pulls them with one peer copy per
-// (owner, consumer) pair on its secondary queue -- xGMI, no host hop -- while
-// the local product runs; the remote product waits on an event.
+// Ghost exchange: the reference stages ghosts device -> host -> device in five finish()-fenced phases
+// (spmat.hpp:125-183).  Here (vexcl/exchange.hpp) every owner packs, per consumer, exactly the values that
+// consumer needs (gather kernel on the primary queue) and ONE vexhip_halo_exchange ships them on the
+// secondary queues -- grouped ncclSend / ncclRecv over xGMI between GPUs, event-ordered copies between
+// logical devices of one GPU -- while the local product runs; the remote product waits on an event.
 #include <memory>
 #include <set>
 #include <unordered_map>
 #include <vector>
 
 #include "operations.hpp"
+#include "exchange.hpp"
 #include "vector.hpp"
 #include "multivector.hpp"
 #include "spmat/ccsr.hpp"
@@ -45,13 +44,12 @@ class SpMat {
         {
             static_assert(std::is_same<val_t, double>::value || std::is_same<val_t, float>::value,
                     "SpMat value type must be float or double");
-            for (const auto &q : queue) squeue.push_back(backend::duplicate_queue(q));   // spmat.hpp:81-82
 
             std::vector<std::vector<col_t>> ghosts(queue.size());
             for (unsigned d = 0; d < queue.size(); ++d)
                 mtx[d] = std::make_shared<device_part>(queue[d], row + part[d], row + part[d + 1], col, val,
                         col_part[d], col_part[d + 1], ghosts[d]);
-            if (queue.size() > 1) setup_exchange(ghosts);
+            if (queue.size() > 1) exc.setup(queue, col_part, ghosts);
         }
 
         /// From DEVICE CSR arrays (int32 row pointers and columns, `nonzeros` entries): nothing is staged through the
@@ -67,7 +65,6 @@ class SpMat {
                     "SpMat value type must be float or double");
             precondition(queue.size() == 1, "SpMat from device arrays: single-device contexts only");
             precondition(row.size() == n + 1 && col.size() >= nonzeros && val.size() >= nonzeros, "SpMat: inconsistent CSR arrays");
-            squeue.push_back(backend::duplicate_queue(queue[0]));
             mtx[0] = std::make_shared<device_part>(queue[0], n, nonzeros, row, col, val);
         }
 
@@ -82,11 +79,16 @@ class SpMat {
         void apply(const vex::vector<T> &x, vex::vector<T> &y, scalar_type alpha = 1, bool append = false) const {
             static_assert(std::is_same<T, val_t>::value, "vector and matrix value types differ");
             precondition(x.size() == ncols && y.size() == nrows, "SpMat::apply: incompatible sizes");
-            const bool exchange = queue.size() > 1 && !pairs.empty();
-            if (exchange) start_exchange(x);
-            for (unsigned d = 0; d < queue.size(); ++d)
+            const bool exchange = queue.size() > 1 && exc.active();
+            if (exchange) exc.start(x);                  // pack + ship on the secondary queues
+            for (unsigned d = 0; d < queue.size(); ++d)   // local part, overlapped with the exchange
                 if (part[d + 1] > part[d]) mtx[d]->mul_local(queue[d], x(d), y(d), alpha, append);
-            if (exchange) finish_exchange(y, alpha);
+            if (exchange)
+                for (unsigned d = 0; d < queue.size(); ++d) {
+                    if (!exc.ghosts(d) || part[d + 1] == part[d]) continue;
+                    exc.finish(d);                        // queue[d] waits for its ghosts
+                    mtx[d]->mul_remote(queue[d], exc.ghost_buffer(d), y(d), alpha);
+                }
         }
 
         /// Y = alpha * A * X for a multivector (spmat.hpp:388-398).  Without a ghost exchange
@@ -251,7 +253,7 @@ class SpMat {
         };
 
     private:
-        std::vector<backend::command_queue> queue, squeue;
+        std::vector<backend::command_queue> queue;
         std::vector<size_t> part, col_part;
         size_t nrows, ncols, nnz;
         std::vector<std::shared_ptr<device_part>> mtx;
@@ -260,7 +262,7 @@ class SpMat {
         void apply_components(const multivector<T, N> &x, detail::multi_target<Ts...> &y, scalar_type alpha, bool append,
                 std::index_sequence<I...>) const
         {
-            const bool exchange = queue.size() > 1 && !pairs.empty();
+            const bool exchange = queue.size() > 1 && exc.active();
             if (exchange) {       // the ghost buffers hold one vector: component by component
                 int dummy[] = {0, (apply(x(I), std::get<I>(y.v), alpha, append), 0)...};
                 (void)dummy;
@@ -275,84 +277,9 @@ class SpMat {
             }
         }
 
-        // one (owner -> consumer) transfer
-        struct pair_t { unsigned owner, consumer; size_t send_off, recv_off, count; };
-        std::vector<pair_t> pairs;
-        struct exchange_t {
-            backend::device_vector<int> send_idx;     // local ids of everything this device sends, grouped by consumer
-            backend::device_vector<val_t> send_buf;   // packed values, same order
-            backend::device_vector<val_t> ghost_buf;  // what this device receives, ordered by global column
-            size_t nsend = 0, nghost = 0;
-        };
-        mutable std::vector<exchange_t> exc;
-        mutable std::vector<backend::event> copies_done;   // per consumer: previous product's peer copies
-
-        static int gather(int dev, void *s, int64_t n, const int *idx, const double *src, double *dst) { return vexhip_gather_f64_i32(dev, s, n, idx, src, dst); }
-        static int gather(int dev, void *s, int64_t n, const int *idx, const float *src, float *dst) { return vexhip_gather_f32_i32(dev, s, n, idx, src, dst); }
-
-        /// spmat.hpp:291-378, point-to-point: for every consumer, its sorted ghost
-        /// list splits into one contiguous run per owner (owners hold contiguous
-        /// column ranges), so owner o packs run (o -> d) and d receives it in place.
-        void setup_exchange(const std::vector<std::vector<col_t>> &ghosts) {
-            const unsigned nd = static_cast<unsigned>(queue.size());
-            exc.resize(nd);
-            std::vector<std::vector<int>> send_idx(nd);
-            for (unsigned d = 0; d < nd; ++d) {
-                const auto &g = ghosts[d];
-                exc[d].nghost = g.size();
-                size_t i = 0;
-                while (i < g.size()) {
-                    unsigned o = static_cast<unsigned>(column_owner(static_cast<size_t>(g[i]), col_part));
-                    size_t j = i;
-                    while (j < g.size() && static_cast<size_t>(g[j]) < col_part[o + 1]) ++j;
-                    pair_t p; p.owner = o; p.consumer = d; p.send_off = send_idx[o].size(); p.recv_off = i; p.count = j - i;
-                    for (size_t k = i; k < j; ++k) send_idx[o].push_back(static_cast<int>(static_cast<size_t>(g[k]) - col_part[o]));
-                    pairs.push_back(p);
-                    i = j;
-                }
-            }
-            for (unsigned d = 0; d < nd; ++d) {
-                exc[d].nsend = send_idx[d].size();
-                if (exc[d].nsend) {
-                    exc[d].send_idx = backend::device_vector<int>(queue[d], send_idx[d].size(), send_idx[d].data());
-                    exc[d].send_buf = backend::device_vector<val_t>(queue[d], send_idx[d].size());
-                }
-                if (exc[d].nghost) exc[d].ghost_buf = backend::device_vector<val_t>(queue[d], exc[d].nghost);
-            }
-        }
-
-        template <class T>
-        void start_exchange(const vex::vector<T> &x) const {
-            const unsigned nd = static_cast<unsigned>(queue.size());
-            // the previous product's copies must have drained the send buffers
-            for (unsigned o = 0; o < nd; ++o)
-                if (exc[o].nsend && !copies_done.empty()) backend::enqueue_barrier(queue[o], copies_done);
-            std::vector<backend::event> packed(nd);
-            for (unsigned o = 0; o < nd; ++o) {
-                if (!exc[o].nsend) continue;
-                backend::check(gather(queue[o].device_ordinal(), queue[o].raw(), (int64_t)exc[o].nsend,
-                            exc[o].send_idx.raw(), x(o).raw(), exc[o].send_buf.raw()));
-                packed[o] = backend::enqueue_marker(queue[o]);
-            }
-            copies_done.assign(nd, backend::event());
-            for (const auto &p : pairs) {
-                const backend::command_queue &sq = squeue[p.consumer];
-                backend::enqueue_barrier(sq, backend::wait_list(1, packed[p.owner]));
-                backend::check(vexhip_memcpy_peer(sq.device_ordinal(), exc[p.consumer].ghost_buf.raw() + p.recv_off,
-                            queue[p.owner].device_ordinal(), exc[p.owner].send_buf.raw() + p.send_off,
-                            p.count * sizeof(val_t), sq.raw()));
-            }
-            for (unsigned d = 0; d < nd; ++d) if (exc[d].nghost) copies_done[d] = backend::enqueue_marker(squeue[d]);
-        }
-
-        template <class T>
-        void finish_exchange(vex::vector<T> &y, val_t alpha) const {
-            for (unsigned d = 0; d < queue.size(); ++d) {
-                if (!exc[d].nghost || part[d + 1] == part[d]) continue;
-                backend::enqueue_barrier(queue[d], backend::wait_list(1, copies_done[d]));
-                mtx[d]->mul_remote(queue[d], exc[d].ghost_buf, y(d), alpha);
-            }
-        }
+        // ghost exchange (vexcl/exchange.hpp): pack kernels + ONE vexhip_halo_exchange per product (RCCL over xGMI
+        // between distinct GPUs, event-ordered copies between logical devices of one GPU)
+        detail::ghost_exchange<val_t> exc;
 };
 
 /// A * x: a term that can only be assigned, added, subtracted or scaled

@@ -147,6 +147,19 @@ _PROTOS = {
     "vexhip_spmat_apply_multi_f64": (None, [c_vp, c_vp, c_int, c_f64, c_int, c_vp, c_vp]),
     "vexhip_spmat_apply_multi_f32": (None, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp]),
     "vexhip_spmat_get_info": (None, [c_vp, ctypes.POINTER(SpMatInfo)]),
+    "vexhip_comm_unique_id": (None, [c_vp]),
+    "vexhip_comm_init": (None, [c_int, ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_comm_init_rank": (None, [c_int, c_int, c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "vexhip_comm_destroy": (None, [c_vp]),
+    "vexhip_comm_size": (None, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "vexhip_halo_exchange": (None, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp)]),
+    "vexhip_allreduce_scalar": (None, [c_vp, c_int, c_int, ctypes.POINTER(c_vp), c_i64, ctypes.POINTER(c_vp)]),
+    "vexhip_allgather": (None, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_i64, ctypes.POINTER(c_vp)]),
+    "vexhip_dist_spmv_create": (None, [c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64),
+                                       c_i64, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_vp)]),
+    "vexhip_dist_spmv_destroy": (None, [c_vp]),
+    "vexhip_dist_spmv_set_graph": (None, [c_vp, c_int]),
+    "vexhip_dist_spmv_apply": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp]),
     "vexhip_spmm_sell8_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8v_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),

@@ -1,0 +1,513 @@
+// RCCL transport behind the C ABI:
+//   vexhip_comm_*            communicator over the devices of ONE process (the reference's model: one vex::Context
+//                            drives every GPU) or one rank of a one-process-per-GPU job;
+//   vexhip_halo_exchange     the ghost exchange of SpMat::apply as ONE grouped ncclSend / ncclRecv step over xGMI --
+//                            replaces the two PCIe hops and four finish() fences of vexcl/spmat.hpp:125-183 and
+//                            sparse/distributed.hpp:347-428;
+//   vexhip_allreduce_scalar  the Reductor's final combine (reductor.hpp:412-436 folds D x 8*CU partials on the host);
+//   vexhip_allgather         the scan carry (scan.hpp:445-457);
+//   vexhip_dist_spmv_*       one rank's whole product step -- pack, exchange, local part, remote part -- issued from
+//                            C++ on two streams (optionally replayed from a hipGraph): the per-step host cost is a
+//                            handful of launches instead of a Python loop over torch.distributed requests.
+// librccl is loaded on first use (dlopen): a single-GPU user of libvexhip.so never pays for it.
+#include "common.hpp"
+
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace vexhip {
+namespace {
+
+struct rccl_api {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+rccl_api &rccl() {
+    static rccl_api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { api.error = std::string("cannot load librccl: ") + dlerror(); return; }
+#define SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name)); \
+        if (!api.field) { api.error = std::string("librccl lacks ") + name; return; }
+        SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommInitAll, "ncclCommInitAll")
+        SYM(CommDestroy, "ncclCommDestroy") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
+        SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather")
+        SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    });
+    return api;
+}
+
+int nccl_fail(ncclResult_t r, const char *file, int line) {
+    const rccl_api &a = rccl();
+    return fail(file, line, std::string("RCCL: ") + (a.GetErrorString ? a.GetErrorString(r) : "error"));
+}
+#define NCCL_TRY(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) return nccl_fail(_r, __FILE__, __LINE__); } while (0)
+#define RCCL_READY() do { if (!rccl().error.empty()) return fail(__FILE__, __LINE__, rccl().error); } while (0)
+
+size_t type_bytes(int dtype) { return (dtype == VEXHIP_F32 || dtype == VEXHIP_I32 || dtype == VEXHIP_U32) ? 4 : 8; }
+
+struct comm {
+    int world = 0;                 // ranks in the communicator
+    std::vector<int> devs;         // local devices
+    std::vector<int> ranks;        // rank of every local device
+    std::vector<ncclComm_t> comms; // one per local device (RCCL transport)
+    // PEER transport (single process only): the same exchange as direct device-to-device copies ordered by events --
+    // what a process that sees every buffer can do without a communicator, and the only option when two logical
+    // devices share one GPU (the reference's own test fixture, tests/context_setup.hpp:24-39; RCCL refuses that)
+    bool peer = false;
+    std::vector<hipEvent_t> ready, done;
+};
+
+bool distinct(const std::vector<int> &v) {
+    for (size_t a = 0; a < v.size(); ++a) for (size_t b = a + 1; b < v.size(); ++b) if (v[a] == v[b]) return false;
+    return true;
+}
+
+// The exchange of vexhip_halo_exchange by copies: every device's send buffer is ready in ITS stream's order (as for
+// ncclSend); the consumer's stream waits for that and pulls its share; the owner's stream then waits for the pulls,
+// so that -- as after ncclSend -- work issued on it afterwards may overwrite the send buffer.
+int peer_exchange(comm *c, int dtype, const void *const *send_bufs, const int64_t *send_counts,
+        void *const *recv_bufs, const int64_t *recv_counts, void *const *streams)
+{
+    const int nd = (int)c->devs.size();
+    const size_t b = type_bytes(dtype);
+    for (int o = 0; o < nd; ++o) { VEXHIP_SET_DEVICE(c->devs[o]); VEXHIP_TRY(hipEventRecord(c->ready[o], as_stream(streams[o]))); }
+    for (int d = 0; d < nd; ++d) {
+        VEXHIP_SET_DEVICE(c->devs[d]);
+        int64_t ro = 0;
+        for (int o = 0; o < nd; ++o) {
+            const int64_t n = recv_counts[d * nd + o];
+            if (n) {
+                VEXHIP_REQUIRE(send_counts[o * nd + d] == n, "halo exchange: send and receive counts differ");
+                int64_t so = 0;
+                for (int p = 0; p < d; ++p) so += send_counts[o * nd + p];
+                if (o != d) VEXHIP_TRY(hipStreamWaitEvent(as_stream(streams[d]), c->ready[o], 0));
+                const char *src = static_cast<const char *>(send_bufs[o]) + so * b;
+                char *dst = static_cast<char *>(recv_bufs[d]) + ro * b;
+                if (c->devs[o] == c->devs[d]) VEXHIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * b, hipMemcpyDeviceToDevice, as_stream(streams[d])));
+                else VEXHIP_TRY(hipMemcpyPeerAsync(dst, c->devs[d], src, c->devs[o], (size_t)n * b, as_stream(streams[d])));
+            }
+            ro += n;
+        }
+        VEXHIP_TRY(hipEventRecord(c->done[d], as_stream(streams[d])));
+    }
+    for (int o = 0; o < nd; ++o) {
+        VEXHIP_SET_DEVICE(c->devs[o]);
+        for (int d = 0; d < nd; ++d)
+            if (d != o && send_counts[o * nd + d]) VEXHIP_TRY(hipStreamWaitEvent(as_stream(streams[o]), c->done[d], 0));
+    }
+    return 0;
+}
+
+int nccl_type(int dtype, ncclDataType_t *t) {
+    switch (dtype) {
+        case VEXHIP_F64: *t = ncclFloat64; return 0;
+        case VEXHIP_F32: *t = ncclFloat32; return 0;
+        case VEXHIP_I32: *t = ncclInt32; return 0;
+        case VEXHIP_U32: *t = ncclUint32; return 0;
+        case VEXHIP_I64: *t = ncclInt64; return 0;
+        case VEXHIP_U64: *t = ncclUint64; return 0;
+    }
+    return fail(__FILE__, __LINE__, "unknown dtype");
+}
+
+// ---- one rank's product step -----------------------------------------------------------------------------------
+struct dist_spmv {
+    comm *c = nullptr;
+    int dev = 0, dtype = VEXHIP_F64;
+    const vexhip_spmat *loc = nullptr;         // local part (may be NULL: no local entries)
+    int64_t rows = 0;
+    int64_t rem_rows = 0;                      // remote part: row-subset CSR (vexhip_spmv_csr_rows_*), may be 0
+    const int32_t *rows_idx = nullptr, *rem_ptr = nullptr, *rem_col = nullptr; const void *rem_val = nullptr;
+    int64_t nsend = 0, nghost = 0;
+    const int32_t *send_idx = nullptr; void *send_buf = nullptr, *ghost_buf = nullptr;
+    std::vector<int64_t> send_counts, recv_counts;       // per peer rank
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t packed = nullptr, received = nullptr;
+    // optional replay of the whole step from a hipGraph (same x, y, alpha, append, stream as at capture)
+    bool use_graph = false;
+    hipGraphExec_t exec = nullptr;
+    const void *gx = nullptr; void *gy = nullptr; double galpha = 0; int gappend = 0; hipStream_t gstream = nullptr;
+};
+
+int exchange_one(comm *c, int slot, int dtype, const void *send, const int64_t *scount, void *recv, const int64_t *rcount, hipStream_t s) {
+    rccl_api &a = rccl();
+    ncclDataType_t t;
+    if (int rc = nccl_type(dtype, &t)) return rc;
+    const size_t b = type_bytes(dtype);
+    const int me = c->ranks[slot];
+    int64_t so = 0, ro = 0;
+    for (int peer = 0; peer < c->world; ++peer) {
+        const int64_t ns = scount[peer], nr = rcount[peer];
+        static const bool self_over_rccl = std::getenv("VEXHIP_RCCL_SELF") != nullptr;      // tests: force ncclSend/ncclRecv to self
+        if (peer == me && ns == nr && ns > 0 && !self_over_rccl) {
+            // a rank's own share never crosses a link: device copy instead of a send/recv pair to itself
+            VEXHIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + ro * b, static_cast<const char *>(send) + so * b, (size_t)ns * b, hipMemcpyDeviceToDevice, s));
+        } else {
+            if (ns) NCCL_TRY(a.Send(static_cast<const char *>(send) + so * b, (size_t)ns, t, peer, c->comms[slot], s));
+            if (nr) NCCL_TRY(a.Recv(static_cast<char *>(recv) + ro * b, (size_t)nr, t, peer, c->comms[slot], s));
+        }
+        so += ns; ro += nr;
+    }
+    return 0;
+}
+
+int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
+    const bool f64 = D->dtype == VEXHIP_F64;
+    const bool exch = D->nsend > 0 || D->nghost > 0;
+    if (exch) {
+        // the previous product's remote part must have read the ghosts before they are overwritten, and its sends must
+        // have left send_buf before it is re-packed: both are ordered on `s` itself (the remote part and the wait for
+        // `received` were issued on it), so recording after them and making the comm stream wait is enough
+        if (D->nsend) {
+            int rc = f64 ? vexhip_gather_f64_i32(D->dev, s, D->nsend, D->send_idx, static_cast<const double *>(x), static_cast<double *>(D->send_buf))
+                         : vexhip_gather_f32_i32(D->dev, s, D->nsend, D->send_idx, static_cast<const float *>(x), static_cast<float *>(D->send_buf));
+            if (rc) return rc;
+        }
+        VEXHIP_TRY(hipEventRecord(D->packed, s));
+        VEXHIP_TRY(hipStreamWaitEvent(D->comm_stream, D->packed, 0));
+        NCCL_TRY(rccl().GroupStart());
+        int rc = exchange_one(D->c, 0, D->dtype, D->send_buf, D->send_counts.data(), D->ghost_buf, D->recv_counts.data(), D->comm_stream);
+        ncclResult_t ge = rccl().GroupEnd();
+        if (rc) return rc;
+        NCCL_TRY(ge);
+        VEXHIP_TRY(hipEventRecord(D->received, D->comm_stream));
+    }
+    // local part, overlapped with the exchange
+    if (D->loc) {
+        int rc = f64 ? vexhip_spmat_apply_f64(D->loc, s, alpha, append, static_cast<const double *>(x), static_cast<double *>(y))
+                     : vexhip_spmat_apply_f32(D->loc, s, (float)alpha, append, static_cast<const float *>(x), static_cast<float *>(y));
+        if (rc) return rc;
+    } else if (!append && D->rows) {
+        VEXHIP_TRY(hipMemsetAsync(y, 0, (size_t)D->rows * type_bytes(D->dtype), s));          // csr.inl:196-199
+    }
+    if (exch) VEXHIP_TRY(hipStreamWaitEvent(s, D->received, 0));
+    if (D->rem_rows) {
+        int rc = f64 ? vexhip_spmv_csr_rows_f64_i32(D->dev, s, D->rem_rows, alpha, D->rows_idx, D->rem_ptr, D->rem_col, static_cast<const double *>(D->rem_val),
+                                                    static_cast<const double *>(D->ghost_buf), static_cast<double *>(y))
+                     : vexhip_spmv_csr_rows_f32_i32(D->dev, s, D->rem_rows, (float)alpha, D->rows_idx, D->rem_ptr, D->rem_col, static_cast<const float *>(D->rem_val),
+                                                    static_cast<const float *>(D->ghost_buf), static_cast<float *>(y));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+template <typename T>
+void fold(int op, std::vector<char> &host, size_t nd, size_t count) {
+    T *v = reinterpret_cast<T *>(host.data());
+    for (size_t k = 0; k < count; ++k) {
+        T r = v[k];
+        for (size_t d = 1; d < nd; ++d) {
+            const T o = v[d * count + k];
+            r = (op == VEXHIP_MIN) ? (o < r ? o : r) : (op == VEXHIP_MAX) ? (o > r ? o : r) : (T)(r + o);
+        }
+        v[k] = r;
+    }
+}
+
+} // namespace
+} // namespace vexhip
+
+using namespace vexhip;
+
+extern "C" {
+
+int vexhip_comm_unique_id(void *id128) {
+    VEXHIP_REQUIRE(id128, "NULL argument");
+    RCCL_READY();
+    ncclUniqueId id;
+    NCCL_TRY(rccl().GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int vexhip_comm_init(int ndev, const int *devs, int transport, vexhip_comm **out) {
+    VEXHIP_REQUIRE(out && ndev >= 1 && devs, "bad argument");
+    VEXHIP_REQUIRE(transport >= VEXHIP_COMM_AUTO && transport <= VEXHIP_COMM_PEER, "unknown transport");
+    *out = nullptr;
+    comm *c = new (std::nothrow) comm;
+    VEXHIP_REQUIRE(c, "out of host memory");
+    c->world = ndev;
+    c->devs.assign(devs, devs + ndev);
+    c->ranks.resize(ndev);
+    for (int d = 0; d < ndev; ++d) c->ranks[d] = d;
+    // RCCL needs one GPU per rank; one device, or logical devices that share a GPU, exchange by copies
+    bool want_rccl = transport == VEXHIP_COMM_RCCL || (transport == VEXHIP_COMM_AUTO && ndev > 1 && distinct(c->devs));
+    if (transport == VEXHIP_COMM_AUTO && std::getenv("VEXHIP_COMM_PEER")) want_rccl = false;
+    if (want_rccl) {
+        if (!rccl().error.empty()) {
+            if (transport == VEXHIP_COMM_RCCL) { delete c; return fail(__FILE__, __LINE__, rccl().error); }
+            want_rccl = false;
+        } else {
+            c->comms.assign(ndev, nullptr);
+            ncclResult_t r = rccl().CommInitAll(c->comms.data(), ndev, devs);
+            if (r != ncclSuccess) {
+                if (transport == VEXHIP_COMM_RCCL) { delete c; return nccl_fail(r, __FILE__, __LINE__); }
+                c->comms.clear(); want_rccl = false;
+            }
+        }
+    }
+    if (!want_rccl) {
+        c->peer = true;
+        c->ready.assign(ndev, nullptr); c->done.assign(ndev, nullptr);
+        for (int d = 0; d < ndev; ++d) {
+            hipError_t e = hipSetDevice(devs[d]);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready[d], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[d], hipEventDisableTiming);
+            if (e != hipSuccess) { vexhip_comm_destroy(reinterpret_cast<vexhip_comm *>(c)); return check(e, __FILE__, __LINE__); }
+        }
+    }
+    *out = reinterpret_cast<vexhip_comm *>(c);
+    return 0;
+}
+
+int vexhip_comm_init_rank(int dev, int rank, int world, const void *id128, vexhip_comm **out) {
+    VEXHIP_REQUIRE(out && id128 && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    *out = nullptr;
+    RCCL_READY();
+    VEXHIP_SET_DEVICE(dev);
+    comm *c = new (std::nothrow) comm;
+    VEXHIP_REQUIRE(c, "out of host memory");
+    c->world = world; c->devs.assign(1, dev); c->ranks.assign(1, rank); c->comms.assign(1, nullptr);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = rccl().CommInitRank(&c->comms[0], world, id, rank);
+    if (r != ncclSuccess) { delete c; return nccl_fail(r, __FILE__, __LINE__); }
+    *out = reinterpret_cast<vexhip_comm *>(c);
+    return 0;
+}
+
+int vexhip_comm_destroy(vexhip_comm *h) {
+    comm *c = reinterpret_cast<comm *>(h);
+    if (!c) return 0;
+    for (size_t d = 0; d < c->comms.size(); ++d)
+        if (c->comms[d]) { (void)hipSetDevice(c->devs[d]); (void)rccl().CommDestroy(c->comms[d]); }
+    for (size_t d = 0; d < c->ready.size(); ++d) {
+        (void)hipSetDevice(c->devs[d]);
+        if (c->ready[d]) (void)hipEventDestroy(c->ready[d]);
+        if (c->done[d]) (void)hipEventDestroy(c->done[d]);
+    }
+    delete c;
+    return 0;
+}
+
+int vexhip_comm_size(const vexhip_comm *h, int *world, int *nlocal, int *transport) {
+    const comm *c = reinterpret_cast<const comm *>(h);
+    VEXHIP_REQUIRE(c, "NULL communicator");
+    if (world) *world = c->world;
+    if (nlocal) *nlocal = (int)c->devs.size();
+    if (transport) *transport = c->peer ? VEXHIP_COMM_PEER : VEXHIP_COMM_RCCL;
+    return 0;
+}
+
+int vexhip_halo_exchange(vexhip_comm *h, int dtype, const void *const *send_bufs, const int64_t *send_counts,
+        void *const *recv_bufs, const int64_t *recv_counts, void *const *streams)
+{
+    comm *c = reinterpret_cast<comm *>(h);
+    VEXHIP_REQUIRE(c && send_bufs && send_counts && recv_bufs && recv_counts && streams, "NULL argument");
+    if (c->peer) return peer_exchange(c, dtype, send_bufs, send_counts, recv_bufs, recv_counts, streams);
+    RCCL_READY();
+    NCCL_TRY(rccl().GroupStart());
+    int rc = 0;
+    for (size_t d = 0; d < c->devs.size() && !rc; ++d) {
+        if (hipSetDevice(c->devs[d]) != hipSuccess) { rc = fail(__FILE__, __LINE__, "hipSetDevice failed"); break; }
+        rc = exchange_one(c, (int)d, dtype, send_bufs[d], send_counts + d * c->world, recv_bufs[d], recv_counts + d * c->world, as_stream(streams[d]));
+    }
+    ncclResult_t ge = rccl().GroupEnd();
+    if (rc) return rc;
+    NCCL_TRY(ge);
+    return 0;
+}
+
+int vexhip_allreduce_scalar(vexhip_comm *h, int op, int dtype, void *const *bufs, int64_t count, void *const *streams) {
+    comm *c = reinterpret_cast<comm *>(h);
+    VEXHIP_REQUIRE(c && bufs && streams && count >= 1, "bad argument");
+    VEXHIP_REQUIRE(op == VEXHIP_SUM || op == VEXHIP_SUM_KAHAN || op == VEXHIP_MIN || op == VEXHIP_MAX, "unsupported reduction for the all-reduce");
+    if (c->peer) {
+        // one process sees every device: read the D partial results, fold on the host in device order (what the reference
+        // does with its 8 x CU partials per device, reductor.hpp:420-436), write the result back
+        const size_t nd = c->devs.size(), b = type_bytes(dtype);
+        std::vector<char> host(nd * (size_t)count * b);
+        for (size_t d = 0; d < nd; ++d) {
+            VEXHIP_SET_DEVICE(c->devs[d]);
+            VEXHIP_TRY(hipMemcpyAsync(host.data() + d * count * b, bufs[d], (size_t)count * b, hipMemcpyDeviceToHost, as_stream(streams[d])));
+        }
+        for (size_t d = 0; d < nd; ++d) { VEXHIP_SET_DEVICE(c->devs[d]); VEXHIP_TRY(hipStreamSynchronize(as_stream(streams[d]))); }
+        switch (dtype) {
+            case VEXHIP_F64: fold<double>(op, host, nd, (size_t)count); break;
+            case VEXHIP_F32: fold<float>(op, host, nd, (size_t)count); break;
+            case VEXHIP_I32: fold<int32_t>(op, host, nd, (size_t)count); break;
+            case VEXHIP_U32: fold<uint32_t>(op, host, nd, (size_t)count); break;
+            case VEXHIP_I64: fold<int64_t>(op, host, nd, (size_t)count); break;
+            case VEXHIP_U64: fold<uint64_t>(op, host, nd, (size_t)count); break;
+            default: return fail(__FILE__, __LINE__, "unknown dtype");
+        }
+        for (size_t d = 0; d < nd; ++d) {
+            VEXHIP_SET_DEVICE(c->devs[d]);
+            VEXHIP_TRY(hipMemcpyAsync(bufs[d], host.data(), (size_t)count * b, hipMemcpyHostToDevice, as_stream(streams[d])));
+            VEXHIP_TRY(hipStreamSynchronize(as_stream(streams[d])));
+        }
+        return 0;
+    }
+    RCCL_READY();
+    ncclDataType_t t;
+    if (int rc = nccl_type(dtype, &t)) return rc;
+    const ncclRedOp_t ro = op == VEXHIP_MIN ? ncclMin : op == VEXHIP_MAX ? ncclMax : ncclSum;
+    NCCL_TRY(rccl().GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (size_t d = 0; d < c->devs.size() && r == ncclSuccess; ++d) {
+        (void)hipSetDevice(c->devs[d]);
+        r = rccl().AllReduce(bufs[d], bufs[d], (size_t)count, t, ro, c->comms[d], as_stream(streams[d]));
+    }
+    ncclResult_t ge = rccl().GroupEnd();
+    NCCL_TRY(r);
+    NCCL_TRY(ge);
+    return 0;
+}
+
+int vexhip_allgather(vexhip_comm *h, int dtype, const void *const *send, void *const *recv, int64_t count, void *const *streams) {
+    comm *c = reinterpret_cast<comm *>(h);
+    VEXHIP_REQUIRE(c && send && recv && streams && count >= 0, "bad argument");
+    if (count == 0) return 0;
+    if (c->peer) {
+        const size_t nd = c->devs.size(), b = type_bytes(dtype);
+        for (size_t o = 0; o < nd; ++o) { VEXHIP_SET_DEVICE(c->devs[o]); VEXHIP_TRY(hipEventRecord(c->ready[o], as_stream(streams[o]))); }
+        for (size_t d = 0; d < nd; ++d) {
+            VEXHIP_SET_DEVICE(c->devs[d]);
+            for (size_t o = 0; o < nd; ++o) {
+                if (o != d) VEXHIP_TRY(hipStreamWaitEvent(as_stream(streams[d]), c->ready[o], 0));
+                char *dst = static_cast<char *>(recv[d]) + o * (size_t)count * b;
+                if (c->devs[o] == c->devs[d]) VEXHIP_TRY(hipMemcpyAsync(dst, send[o], (size_t)count * b, hipMemcpyDeviceToDevice, as_stream(streams[d])));
+                else VEXHIP_TRY(hipMemcpyPeerAsync(dst, c->devs[d], send[o], c->devs[o], (size_t)count * b, as_stream(streams[d])));
+            }
+            VEXHIP_TRY(hipEventRecord(c->done[d], as_stream(streams[d])));
+        }
+        for (size_t o = 0; o < nd; ++o) {
+            VEXHIP_SET_DEVICE(c->devs[o]);
+            for (size_t d = 0; d < nd; ++d) if (d != o) VEXHIP_TRY(hipStreamWaitEvent(as_stream(streams[o]), c->done[d], 0));
+        }
+        return 0;
+    }
+    RCCL_READY();
+    ncclDataType_t t;
+    if (int rc = nccl_type(dtype, &t)) return rc;
+    NCCL_TRY(rccl().GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (size_t d = 0; d < c->devs.size() && r == ncclSuccess; ++d) {
+        (void)hipSetDevice(c->devs[d]);
+        r = rccl().AllGather(send[d], recv[d], (size_t)count, t, c->comms[d], as_stream(streams[d]));
+    }
+    ncclResult_t ge = rccl().GroupEnd();
+    NCCL_TRY(r);
+    NCCL_TRY(ge);
+    return 0;
+}
+
+// ---- one rank's product step ---------------------------------------------------------------------------------------
+int vexhip_dist_spmv_create(vexhip_comm *hc, int dtype, int64_t rows, const vexhip_spmat *local,
+        int64_t rem_rows, const int32_t *rows_idx, const int32_t *rem_ptr, const int32_t *rem_col, const void *rem_val,
+        int64_t nsend, const int32_t *send_idx, void *send_buf, const int64_t *send_counts,
+        int64_t nghost, void *ghost_buf, const int64_t *recv_counts, vexhip_dist_spmv **out)
+{
+    comm *c = reinterpret_cast<comm *>(hc);
+    VEXHIP_REQUIRE(out, "NULL output");
+    *out = nullptr;
+    VEXHIP_REQUIRE(c && c->devs.size() == 1 && !c->peer, "vexhip_dist_spmv needs a one-device RCCL communicator (vexhip_comm_init_rank)");
+    VEXHIP_REQUIRE(dtype == VEXHIP_F64 || dtype == VEXHIP_F32, "value type must be f64 or f32");
+    VEXHIP_REQUIRE(rows >= 0 && rem_rows >= 0 && nsend >= 0 && nghost >= 0, "negative size");
+    VEXHIP_REQUIRE((!nsend || (send_idx && send_buf && send_counts)) && (!nghost || (ghost_buf && recv_counts)), "NULL exchange buffers");
+    VEXHIP_REQUIRE(!rem_rows || (rows_idx && rem_ptr && rem_col && rem_val && ghost_buf), "NULL remote part");
+    dist_spmv *D = new (std::nothrow) dist_spmv;
+    VEXHIP_REQUIRE(D, "out of host memory");
+    D->c = c; D->dev = c->devs[0]; D->dtype = dtype; D->loc = local; D->rows = rows;
+    D->rem_rows = rem_rows; D->rows_idx = rows_idx; D->rem_ptr = rem_ptr; D->rem_col = rem_col; D->rem_val = rem_val;
+    D->nsend = nsend; D->send_idx = send_idx; D->send_buf = send_buf; D->nghost = nghost; D->ghost_buf = ghost_buf;
+    D->send_counts.assign(c->world, 0); D->recv_counts.assign(c->world, 0);
+    int64_t ts = 0, tr = 0;
+    for (int p = 0; p < c->world; ++p) {
+        if (nsend) D->send_counts[p] = send_counts[p];
+        if (nghost) D->recv_counts[p] = recv_counts[p];
+        ts += D->send_counts[p]; tr += D->recv_counts[p];
+    }
+    if (ts != nsend || tr != nghost) { delete D; return fail(__FILE__, __LINE__, "exchange counts do not add up to the buffer sizes"); }
+    hipError_t e = hipSetDevice(D->dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&D->packed, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&D->received, hipEventDisableTiming);
+    if (e != hipSuccess) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return check(e, __FILE__, __LINE__); }
+    *out = reinterpret_cast<vexhip_dist_spmv *>(D);
+    return 0;
+}
+
+int vexhip_dist_spmv_destroy(vexhip_dist_spmv *h) {
+    dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
+    if (!D) return 0;
+    (void)hipSetDevice(D->dev);
+    if (D->exec) (void)hipGraphExecDestroy(D->exec);
+    if (D->comm_stream) { (void)hipStreamSynchronize(D->comm_stream); (void)hipStreamDestroy(D->comm_stream); }
+    if (D->packed) (void)hipEventDestroy(D->packed);
+    if (D->received) (void)hipEventDestroy(D->received);
+    delete D;
+    return 0;
+}
+
+int vexhip_dist_spmv_set_graph(vexhip_dist_spmv *h, int enable) {
+    dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
+    VEXHIP_REQUIRE(D, "NULL argument");
+    D->use_graph = enable != 0;
+    if (!enable && D->exec) { (void)hipGraphExecDestroy(D->exec); D->exec = nullptr; }
+    return 0;
+}
+
+int vexhip_dist_spmv_apply(vexhip_dist_spmv *h, void *stream, double alpha, int append, const void *x, void *y) {
+    dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
+    VEXHIP_REQUIRE(D && (x || !D->rows) && (y || !D->rows), "NULL argument");
+    if (D->nsend || D->nghost) RCCL_READY();
+    VEXHIP_SET_DEVICE(D->dev);
+    hipStream_t s = as_stream(stream);
+    if (!D->use_graph) return issue_step(D, s, alpha, append, x, y);
+    // replay: the captured step is valid for exactly these operands
+    if (D->exec && (D->gx != x || D->gy != y || D->galpha != alpha || D->gappend != append || D->gstream != s)) {
+        (void)hipGraphExecDestroy(D->exec); D->exec = nullptr;
+    }
+    if (!D->exec) {
+        VEXHIP_REQUIRE(s != nullptr, "graph replay needs an explicit (non-default) stream");
+        hipGraph_t g = nullptr;
+        VEXHIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = issue_step(D, s, alpha, append, x, y);
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        VEXHIP_TRY(e);
+        e = hipGraphInstantiate(&D->exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        VEXHIP_TRY(e);
+        D->gx = x; D->gy = y; D->galpha = alpha; D->gappend = append; D->gstream = s;
+    }
+    VEXHIP_TRY(hipGraphLaunch(D->exec, s));
+    return 0;
+}
+
+} // extern "C"

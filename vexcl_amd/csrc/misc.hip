@@ -70,7 +70,7 @@ __device__ __host__ inline long long poisson_nnz_before(long long idx, long long
 
 // Coefficient of the face between grid points `lo` and `lo + step` (axis = 0, 1, 2) of the variable-coefficient
 // operator below: 0.5 + u, u in [0, 1) from a counter hash of (seed, lo, axis).  Integer arithmetic and one
-// exactly rounded conversion, so the host restatement (oracle/vex_oracle.c vxo_diffusion3d_*) gives the same bits.
+// exactly rounded conversion, so the host restatement the tests compare with (vxo_diffusion3d_*) gives the same bits.
 __device__ __forceinline__ double face_coefficient(unsigned long long seed, long long lo, int axis) {
     const unsigned long long h = mix64(seed + ((unsigned long long)lo * 3ull + (unsigned long long)axis + 1ull) * 0x9E3779B97F4A7C15ull);
     return 0.5 + (double)(h >> 11) * (1.0 / 9007199254740992.0);

@@ -131,6 +131,71 @@ class DistSpMat:
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._p2p = self._plan_p2p()
         self._ops = None
+        self._native, self._comm, self.native_error = None, None, None
+
+    # ---- the product step issued from C++ (include/vexhip.h vexhip_dist_spmv_*) --------------------------------------
+    def enable_native(self, graph=False):
+        """Replace the per-product Python step (gather launch, torch.distributed request objects, two ctypes launches)
+        by ONE call into libvexhip: pack -> grouped ncclSend/ncclRecv on a second stream -> local part -> remote part,
+        with its own RCCL communicator (the unique id travels over this process group).  Returns True when active;
+        on any failure the torch.distributed transport stays in place and `native_error` says why."""
+        import ctypes
+        from . import _capi
+        try:
+            if self.dev.type != "cuda" or not hasattr(self.k, "make_remote"):
+                raise RuntimeError("native step needs the device kernels")
+            if self.loc is not None and not getattr(self.loc, "handle", None):
+                raise RuntimeError("local part is not a vexhip_spmat")
+            L = _capi.lib()
+            idbuf = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                raw = (ctypes.c_char * 128)()
+                L.comm_unique_id(ctypes.cast(raw, ctypes.c_void_p))
+                idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            if self.world > 1:
+                t = idbuf.to(self.dev) if dist.get_backend(self.group) == "nccl" else idbuf
+                dist.broadcast(t, src=self._global_rank(0), group=self.group)
+                idbuf = t.cpu()
+            idbytes = (ctypes.c_char * 128).from_buffer_copy(bytes(idbuf.numpy().tobytes()))
+            comm = ctypes.c_void_p()
+            L.comm_init_rank(self.dev.index or 0, self.rank, self.world, ctypes.cast(idbytes, ctypes.c_void_p), ctypes.byref(comm))
+            self._comm = comm
+            p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+            sc = (ctypes.c_int64 * self.world)(*[int(c) for c in self.send_counts])
+            rc = (ctypes.c_int64 * self.world)(*[int(c) for c in self.recv_counts])
+            rem = self.rem
+            step = ctypes.c_void_p()
+            L.dist_spmv_create(comm, _capi.F64 if self.send_buf.dtype == torch.float64 else _capi.F32, self.rows,
+                               self.loc.handle if self.loc is not None else None,
+                               rem.rows.numel() if rem is not None else 0,
+                               p(rem.rows) if rem is not None else None, p(rem.ptr) if rem is not None else None,
+                               p(rem.col) if rem is not None else None, p(rem.val) if rem is not None else None,
+                               self.send_idx.numel(), p(self.send_idx), p(self.send_buf), sc,
+                               self.ghost_buf.numel(), p(self.ghost_buf), rc, ctypes.byref(step))
+            if graph:
+                L.dist_spmv_set_graph(step, 1)
+            self._native = step
+            return True
+        except Exception as e:          # keep the torch.distributed transport
+            self.native_error = repr(e)
+            self._native = None
+            return False
+
+    def disable_native(self):
+        from . import _capi
+        if self._native:
+            _capi.lib().dist_spmv_destroy(self._native)
+        self._native = None
+
+    def __del__(self):
+        try:
+            from . import _capi
+            if getattr(self, "_native", None):
+                _capi.lib().dist_spmv_destroy(self._native)
+            if getattr(self, "_comm", None):
+                _capi.lib().comm_destroy(self._comm)
+        except Exception:
+            pass
 
     # ---- collectives used only at setup (portable across nccl / gloo) -------
     def _all_to_all_single(self, out, inp):
@@ -189,6 +254,12 @@ class DistSpMat:
         """y (=|+=) alpha * A * x on this rank's strip (spmat.hpp:120-185)."""
         if x.numel() != self.local_cols or y.numel() != self.rows:
             raise ValueError("segment sizes do not match the partition")
+        if self._native:
+            import ctypes
+            from . import _capi
+            _capi.lib().dist_spmv_apply(self._native, ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream),
+                                        float(alpha), int(bool(append)), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()))
+            return y
         reqs = ()
         if self._p2p:
             self.k.gather(self.send_idx, x, self.send_buf)                  # phase 1: pack
