@@ -20,8 +20,8 @@ What the line reports, and how to read it:
                       tools/pmc_headline.py, FETCH calibrated on a stream of known size), or null.
   roofline_csr        the same product by kernels that stream fp64 values + int32 columns (no compression), priced
                       with the CSR-algorithmic bytes: SELL-512 with 32-bit columns and the CSR arrays themselves.
-  variable_coefficient  the same 7-point pattern with nnz distinct values (no value coding applies) through the
-                      default SpMat: the general-matrix figure.
+  variable_coefficient  the same 7-point pattern with a coefficient per face (~4 N distinct values: no value coding
+                      applies) through the default SpMat: the general-matrix figure.
   checksum            sum(y) asserted against an independent evaluation of the stencil (torch slicing, no matrix).
 """
 import argparse
@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: debug)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (debug: exercises the N>1 path on a 1-GPU box; needs --backend gloo)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (CSR-bytes kernels, variable coefficients, C++ front end, elementwise, reduce, scan, sort)")
+    ap.add_argument("--no-native", action="store_true", help="N > 1: keep the torch.distributed transport (do not try the C++ product step)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic = null)")
     args = ap.parse_args()
 
@@ -278,6 +279,33 @@ def main():
         storage = A.loc.storage
         matrix_bytes = A.loc.matrix_bytes()
         step = lambda: A.apply(x, y, 1.0, False)
+        # The product step issued from C++ over its own RCCL communicator (vexhip_dist_spmv_*: ~50 us of host time per
+        # step instead of a Python loop over torch.distributed requests).  It is used only if EVERY rank could set it
+        # up and its first product equals the torch.distributed transport's bit for bit; otherwise that one stays.
+        transport = "torch.distributed batch_isend_irecv (%s)" % args.backend
+        if world > 1 and args.backend == "nccl" and not args.no_native:
+            yref = torch.zeros_like(y)
+            A.apply(x, yref, 1.0, False)
+            torch.cuda.synchronize()
+            ok = 1 if A.enable_native() else 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]):
+                try:
+                    ynat = torch.full_like(y, 7.0)
+                    A.apply(x, ynat, 1.0, False)
+                    torch.cuda.synchronize()
+                    ok = 1 if torch.equal(ynat, yref) else 0
+                except Exception as e:
+                    A.native_error = repr(e); ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]):
+                transport = "vexhip_dist_spmv_apply: pack + grouped ncclSend/ncclRecv + local + remote part issued from C++ (own RCCL communicator)"
+            else:
+                A.disable_native()
+                transport += "; native step not used: %s" % (A.native_error or "another rank could not set it up, or results differed")
+            del yref
     torch.cuda.synchronize()
 
     def barrier():
@@ -376,6 +404,7 @@ def main():
         }
         if world > 1:
             out["config"]["exchange_bytes_per_rank"] = A.exchange_bytes()
+            out["config"]["exchange_transport"] = transport
         if single and not args.no_secondary:
             sec = {}
             try:
@@ -398,7 +427,7 @@ def main():
                 out["roofline_csr"] = rcsr
                 del p2, c2, v2
                 torch.cuda.empty_cache()
-                # ---- the general matrix: same pattern, nnz distinct values, default SpMat
+                # ---- the general matrix: same pattern, a coefficient per face (~4 N distinct values), default SpMat
                 p3, c3, v3 = ops.diffusion3d(n, dev)
                 V = ops.SpMat(p3, c3, v3)
                 del p3, c3, v3
@@ -406,7 +435,7 @@ def main():
                 tv = timed_events(torch, lambda: V.apply(x, y), 20)
                 mv = V.matrix_bytes() + 16 * N
                 out["variable_coefficient"] = {
-                    "workload": "7-point -div(k grad u) on %d^3, k different on every face: nnz = %d distinct values (vexhip_diffusion3d_strip_f64_i32)" % (n, nnz_total),
+                    "workload": "7-point -div(k grad u) on %d^3, k different on every face: ~4 distinct values per row of the %d entries (vexhip_diffusion3d_strip_f64_i32)" % (n, nnz_total),
                     "format": V.storage, "kernel": KERNEL_OF.get(V.storage, V.storage), "avg_launch_ms": round(tv, 5),
                     "gflops": round(2.0 * nnz_total / tv / 1e6, 1),
                     "roofline": {"bound": "hbm", "achieved": round(mv / tv / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

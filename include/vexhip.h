@@ -318,8 +318,9 @@ int vexhip_allgather(vexhip_comm *comm, int dtype, const void *const *send, void
  * (the five phases of spmat.hpp:125-183 with one xGMI hop).  All arrays are device memory owned by the caller:
  * local = vexhip_spmat of the owned columns (NULL: none); remote part = row-subset CSR over the ghost buffer
  * (rows_idx[rem_rows], rem_ptr[rem_rows + 1], columns = positions in ghost_buf); send_idx[nsend] = local ids packed
- * into send_buf in peer order; send_counts / recv_counts[world].  set_graph(1): the step is captured into a hipGraph
- * on first use and replayed while the operands stay the same (needs a non-default stream).                          */
+ * into send_buf in peer order; send_counts / recv_counts[world].  set_graph(1): a step WITHOUT exchange (one rank, or
+ * a block-diagonal partition) is captured into a hipGraph on first use and replayed while the operands stay the same
+ * (needs a non-default stream); steps with RCCL operations are always issued directly.                              */
 typedef struct vexhip_dist_spmv vexhip_dist_spmv;
 int vexhip_dist_spmv_create(vexhip_comm *comm, int dtype, int64_t rows, const vexhip_spmat *local,
         int64_t rem_rows, const int32_t *rows_idx, const int32_t *rem_ptr, const int32_t *rem_col, const void *rem_val,
@@ -470,7 +471,7 @@ int vexhip_poisson3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t row
         int32_t *ptr, int32_t *col, double *val);
 int64_t vexhip_poisson3d_strip_nnz(int64_t n, int64_t row_begin, int64_t row_end);
 /* The same 7-point pattern with a different coefficient on every face: -div(k grad u), k = 0.5 + u(hash(seed, face)),
- * u in [0,1) -- nnz distinct values, what a finite-volume code assembles (no value coding applies).  Same row strip
+ * u in [0,1) -- about 4 N distinct values (every coupling appears in the two rows it joins), what a finite-volume code assembles (no value coding applies).  Same row strip
  * convention and nnz as the Poisson generator; restated on the host in oracle/vex_oracle.c (bit-identical values).   */
 int vexhip_diffusion3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end, uint64_t seed,
         int32_t *ptr, int32_t *col, double *val);

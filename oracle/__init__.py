@@ -79,7 +79,7 @@ def poisson3d(n, index_dtype=np.int32, val_dtype=np.float64):
 
 
 def diffusion3d(n, seed=7):
-    """Variable-coefficient 7-point operator (nnz distinct values); restates vexhip_diffusion3d_* bit for bit."""
+    """Variable-coefficient 7-point operator (about 4 N distinct values); restates vexhip_diffusion3d_* bit for bit."""
     L = lib()
     N = n ** 3
     nnz = L.vxo_poisson3d_nnz(_i64(n))

@@ -214,7 +214,7 @@ def test_poisson128_benchmark_size(T, oracle):
 
 
 def test_variable_coefficient_128_every_storage(T, oracle):
-    """The general banded matrix -- the 7-point pattern with a different coefficient on every face, nnz distinct values
+    """The general banded matrix -- the 7-point pattern with a different coefficient on every face (~4 N distinct values)
     (what bench.py's variable-coefficient row runs at 512^3) -- at 128^3: the device generator equals its host
     restatement bit for bit, the default SpMat picks diagonal codes WITHOUT value codes, and every storage the matrix
     allows (sell8, sell32, csr, the reference's hybrid-ELL layout; `y = ` and `y += alpha *`) equals the oracle's CSR
@@ -224,7 +224,7 @@ def test_variable_coefficient_128_every_storage(T, oracle):
     ptr, col, val = oracle.diffusion3d(n)
     dp, dc, dv = T.ops.diffusion3d(n, T.dev)
     assert np.array_equal(dp.cpu().numpy(), ptr) and np.array_equal(dc.cpu().numpy(), col) and np.array_equal(dv.cpu().numpy(), val)
-    assert len(np.unique(val)) > 0.99 * (len(val) - (N - (n - 2) ** 3))            # every interior entry its own value
+    assert len(np.unique(val)) > 3.9 * (n - 2) ** 3            # every face its own coefficient: ~4 distinct values per row, no value coding
     x = oracle.random_f64(11, N) - 0.5
     y0 = oracle.random_f64(12, N)
     want = oracle.spmv_csr(ptr, col, val, x, omp=True)

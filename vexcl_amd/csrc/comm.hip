@@ -488,7 +488,10 @@ int vexhip_dist_spmv_apply(vexhip_dist_spmv *h, void *stream, double alpha, int 
     if (D->nsend || D->nghost) RCCL_READY();
     VEXHIP_SET_DEVICE(D->dev);
     hipStream_t s = as_stream(stream);
-    if (!D->use_graph) return issue_step(D, s, alpha, append, x, y);
+    // Steps with a ghost exchange are always issued directly: capturing ncclSend / ncclRecv into a hipGraph crashes in
+    // this RCCL (2.26.6, measured with tools/r02_dist_step.py), and the direct step costs ~50 us of host time against
+    // ~130 us on the device for a 1/8 strip of the 512^3 problem.
+    if (!D->use_graph || D->nsend || D->nghost) return issue_step(D, s, alpha, append, x, y);
     // replay: the captured step is valid for exactly these operands
     if (D->exec && (D->gx != x || D->gy != y || D->galpha != alpha || D->gappend != append || D->gstream != s)) {
         (void)hipGraphExecDestroy(D->exec); D->exec = nullptr;

@@ -77,7 +77,7 @@ __device__ __forceinline__ double face_coefficient(unsigned long long seed, long
 }
 
 // VAR = false: the benchmark's Poisson matrix.  VAR = true: the same 7-point pattern with a different coefficient on
-// every face -- -div(k grad u), k in [0.5, 1.5) -- i.e. nnz distinct values: what a finite-volume code assembles, and
+// every face -- -div(k grad u), k in [0.5, 1.5) -- i.e. about 4 N distinct values: what a finite-volume code assembles, and
 // the matrix no value coding applies to (bench.py's "variable coefficient" row).  Symmetric; boundary rows identity.
 template <typename V, bool VAR>
 __global__ __launch_bounds__(256)

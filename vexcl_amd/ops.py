@@ -140,8 +140,8 @@ def poisson3d(n, device="cuda", rows=None):
 
 
 def diffusion3d(n, device="cuda", rows=None, seed=7):
-    """Variable-coefficient 7-point operator -div(k grad u) on the n^3 grid (k differs on every face: nnz distinct
-    values), built in HBM; same pattern, strip convention and nnz as `poisson3d`."""
+    """Variable-coefficient 7-point operator -div(k grad u) on the n^3 grid (k differs on every face: about 4 N
+    distinct values), built in HBM; same pattern, strip convention and nnz as `poisson3d`."""
     L = lib()
     dev = torch.device(device)
     N = n ** 3
