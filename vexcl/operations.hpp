@@ -478,8 +478,8 @@ int count_terminals(const Node &node, const backend::command_queue &q) {
 /// trip of the grid-stride loop (idx and idx + grid_size, both fully coalesced).  Both
 /// right-hand sides are evaluated -- all their loads issued -- before either result is
 /// stored, so a lane keeps twice the memory requests in flight; gather-like terminals
-/// (permutation, sparse / CCSR products) are latency-bound without it.  The second
-/// element's index is clamped into range for the evaluation and only stored if real.
+/// (permutation, sparse / CCSR products) are latency-bound without it.  The pair loop runs
+/// while both elements exist; a lane's leftover element is handled once after it.
 template <class OP, class LHS, class RHS>
 std::string assignment_source(const LHS &lhs, const RHS &rhs, const backend::command_queue &q) {
     backend::source_generator source(q);
@@ -491,13 +491,14 @@ std::string assignment_source(const LHS &lhs, const RHS &rhs, const backend::com
     source.end_kernel_parameters();
     const std::string R = type_name<typename RHS::value_type>();
     source.new_line() << "const ulong grid_size = blockDim.x * (ulong)gridDim.x;";
-    source.new_line() << "for(ulong vex_i = blockDim.x * (ulong)blockIdx.x + threadIdx.x; vex_i < n; vex_i += 2 * grid_size)";
+    source.new_line() << "ulong vex_i = blockDim.x * (ulong)blockIdx.x + threadIdx.x;";
+    // pairs while BOTH elements exist ...
+    source.new_line() << "for(; vex_i + grid_size < n; vex_i += 2 * grid_size)";
     source.open("{");
-    source.new_line() << "const bool vex_two = vex_i + grid_size < n;";
     source.new_line() << R << " vex_r0, vex_r1;";
     for (int e = 0; e < 2; ++e) {
         source.open("{");
-        source.new_line() << "const ulong idx = " << (e ? "vex_two ? vex_i + grid_size : vex_i" : "vex_i") << ";";
+        source.new_line() << "const ulong idx = " << (e ? "vex_i + grid_size" : "vex_i") << ";";
         { gen_context c(source, q); lhs.local_init(c); rhs.local_init(c); }
         source.new_line() << "vex_r" << e << " = ";
         { gen_context c(source, q); c.pos = count_terminals(lhs, q); rhs.emit(c); }
@@ -505,7 +506,6 @@ std::string assignment_source(const LHS &lhs, const RHS &rhs, const backend::com
         source.close("}");
     }
     for (int e = 0; e < 2; ++e) {
-        if (e) source.new_line() << "if (vex_two)";
         source.open("{");
         source.new_line() << "const ulong idx = " << (e ? "vex_i + grid_size" : "vex_i") << ";";
         source.new_line();
@@ -513,6 +513,19 @@ std::string assignment_source(const LHS &lhs, const RHS &rhs, const backend::com
         source << " " << OP::string() << " vex_r" << e << ";";
         source.close("}");
     }
+    source.close("}");
+    // ... then at most ONE leftover element per lane: every element is evaluated exactly once, as in the reference's
+    // one-element loop (an expression may have side effects: atomics in a user function, writes through raw pointers)
+    source.new_line() << "if (vex_i < n)";
+    source.open("{");
+    source.new_line() << "const ulong idx = vex_i;";
+    { gen_context c(source, q); lhs.local_init(c); rhs.local_init(c); }
+    source.new_line() << "const " << R << " vex_r0 = ";
+    { gen_context c(source, q); c.pos = count_terminals(lhs, q); rhs.emit(c); }
+    source << ";";
+    source.new_line();
+    { gen_context c(source, q); lhs.emit(c); }
+    source << " " << OP::string() << " vex_r0;";
     source.close("}");
     source.end_kernel();
     return source.str();

@@ -47,6 +47,7 @@ void stencil_halo<T>::exchange_halos(const vex::vector<T> &x) const {
     const long long N = (long long)x.size();
     std::vector<backend::event> ready(nd);                 // producers' pending writes to x
     for (unsigned o = 0; o < nd; ++o) if (x.part_size(o)) ready[o] = backend::enqueue_marker(queue[o]);
+    std::vector<std::vector<unsigned>> read_from(nd);      // read_from[d]: owners whose segment device d copies from
     for (unsigned d = 0; d < nd; ++d) {
         if (!x.part_size(d)) continue;
         const long long start = (long long)part[d], end = (long long)part[d + 1];
@@ -65,8 +66,16 @@ void stencil_halo<T>::exchange_halos(const vex::vector<T> &x) const {
             backend::enqueue_barrier(queue[d], backend::wait_list(1, ready[o]));
             backend::check(vexhip_memcpy_peer(queue[d].device_ordinal(), dbuf[d].raw() + k,
                         queue[o].device_ordinal(), x(o).raw() + (g - (long long)part[o]), (size_t)run * sizeof(T), queue[d].raw()));
+            if (o != d) read_from[d].push_back(o);
             k += run - 1;
         }
+    }
+    // the copies read x(o) on the CONSUMER's queue: a later write to x on queue[o] (`y = x * s; x = ...;` with no host
+    // synchronisation) must wait for them -- the reference stages the halos through the host behind finish()
+    for (unsigned d = 0; d < nd; ++d) {
+        if (read_from[d].empty()) continue;
+        backend::event copied = backend::enqueue_marker(queue[d]);
+        for (unsigned o : read_from[d]) backend::enqueue_barrier(queue[o], backend::wait_list(1, copied));
     }
 }
 } // namespace detail

@@ -155,7 +155,11 @@ void tile_scan_kernel(const T *in, T *out, long long n, const T *__restrict__ of
 // scans keep the deterministic reduce-then-scan path.
 // ---------------------------------------------------------------------------
 enum : unsigned { ST_INVALID = 0u, ST_AGGREGATE = 1u, ST_INCLUSIVE = 2u };
-constexpr long long kSpinLimit = 1ll << 24;
+// A tile only waits for tiles with SMALLER tickets, and a ticket is taken by a workgroup that already runs: the walk
+// cannot deadlock, it can only be slow (a predecessor preempted by a debugger, a profiler or another process).  The
+// limit is therefore a guard against a bug, minutes away (2^30 polls of ~0.2 us), and hitting it ABORTS the kernel
+// (trap -> the next synchronisation reports an error) -- never a truncated prefix that every later tile would consume.
+constexpr long long kSpinLimit = 1ll << 30;
 
 __device__ __forceinline__ unsigned long long ld_status(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -197,7 +201,7 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
-// ws[0] = ticket counter, ws[1] = error flag, ws + 2 = tile status words (all zero before launch)
+// ws[0] = ticket counter, ws[1] = reserved, ws + 2 = tile status words (all zero before launch)
 template <typename T, bool EXCLUSIVE, int SK, int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 void lookback_scan_kernel(const T *in, T *out, long long n, T init, unsigned long long *ws, int vec_ok) {
@@ -232,7 +236,6 @@ void lookback_scan_kernel(const T *in, T *out, long long n, T init, unsigned lon
         T exclusive = T(0);
         long long base = tile - 1;
         long long spins = 0;
-        bool failed = false;
         while (base >= 0) {
             const long long idx = base - lane;
             T v = T(0);
@@ -241,9 +244,8 @@ void lookback_scan_kernel(const T *in, T *out, long long n, T init, unsigned lon
             while (__any(flag == ST_INVALID)) {
                 __builtin_amdgcn_s_sleep(8);
                 if (idx >= 0 && flag == ST_INVALID) flag = tile_status<T>::read(status, idx, v);
-                if (++spins > kSpinLimit) { failed = true; break; }
+                if (++spins > kSpinLimit) __builtin_trap();
             }
-            if (failed) break;
             const unsigned long long incl = __ballot(flag == ST_INCLUSIVE);
             if (incl) {
                 const int first = __builtin_ctzll(incl);  // nearest predecessor with a complete prefix
@@ -254,7 +256,6 @@ void lookback_scan_kernel(const T *in, T *out, long long n, T init, unsigned lon
             base -= kWave;
         }
         if (lane == 0) {
-            if (failed) atomicExch(&ws[1], 1ull);
             if (tile > 0) tile_status<T>::publish(status, tile, exclusive + aggregate, ST_INCLUSIVE);
             s_prefix = exclusive;
         }
