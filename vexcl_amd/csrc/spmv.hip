@@ -146,6 +146,82 @@ void csr_stream_kernel(long long n, long long nblocks, V alpha, int append,
     }
 }
 
+// Second form (round 2, the default; bit 2 of the variant word selects the first form for A/B).
+// The first form gathers x in STREAM order: a wave instruction covers 256 consecutive entries, i.e. ~37 rows x 7
+// different diagonals -- ~30 cache lines per gather instruction, 529 L1 accesses per 64 rows against 478 per 128 rows
+// for SELL (profiles/r02_sq_summary.txt): the kernel is bound by the L1 / address path, not by HBM (61 %).  Removing
+// its barrier and LDS row-pointer table changed nothing (tools/r02_csr_ab.py).  Here the stream is only STAGED in
+// stream order -- (col, val) with coalesced 16-byte loads into LDS -- and then every lane walks ITS OWN ROW: in step
+// j the lanes of a wave gather x[col(row + lane, j)], which for a banded matrix are adjacent elements (8-9 lines per
+// instruction, the ELL pattern), up to eight entries in flight per lane.  The row is folded in the same loop: no
+// product staging.  Same products, same order: bit-identical.  24 KiB of LDS per workgroup (6 workgroups per CU).
+// 512^3: 2.74-2.89 -> 2.61 ms (66 % of 8 TB/s by CSR bytes).  Tried and dropped: half the lanes folding two rows each
+// with 16-byte pair gathers (3.42 ms: the fold becomes the serial part of every workgroup).
+constexpr int CSR2_TILE = 2048;
+
+template <typename V, typename I, bool SWZ>
+__global__ __launch_bounds__(CSR_BLOCK)
+void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
+        const I *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
+{
+    __shared__ V s_val[CSR2_TILE];
+    __shared__ I s_col[CSR2_TILE];
+    const long long lb = (trav.chunk > 0 || trav.order) ? traversal_block(trav, nblocks) : logical_block<SWZ>(nblocks);
+    if (lb < 0 || lb >= nblocks) return;
+    const int t = threadIdx.x;
+    const long long r0 = lb * CSR_BLOCK;
+    const long long rows_here = (n - r0 < CSR_BLOCK) ? (n - r0) : CSR_BLOCK;
+    const long long base = ptr[r0], end = ptr[r0 + rows_here];            // uniform addresses: scalar loads
+    long long my_lo = 0, my_hi = 0;
+    if (t < rows_here) { my_lo = ptr[r0 + t]; my_hi = ptr[r0 + t + 1]; }
+
+    V sum = 0;
+    for (long long tb = base & ~3ll; tb < end; tb += CSR2_TILE) {
+        const long long te = (end - tb > CSR2_TILE) ? tb + CSR2_TILE : end;
+        // stage the tile: 4 entries per lane per step, whole groups with 16-byte loads
+#pragma unroll 2
+        for (long long k = tb + 4 * t; k < te; k += 4 * CSR_BLOCK) {
+            const int o = (int)(k - tb);
+            if (te - k >= 4) {
+                I c[4]; V v[4];
+                load4<false>(col + k, c); load4<false>(val + k, v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { s_col[o + q] = c[q]; s_val[o + q] = v[q]; }
+            } else {
+                for (long long q = k; q < te; ++q) { s_col[(int)(q - tb)] = col[q]; s_val[(int)(q - tb)] = val[q]; }
+            }
+        }
+        __syncthreads();
+        // every lane folds the part of its row that lies in this tile, up to 8 entries in flight
+        const int lo = (int)((my_lo > tb ? my_lo : tb) - tb);
+        const int hi = (int)((my_hi < te ? my_hi : te) - tb);
+        for (int j = lo; j < hi; j += 8) {
+            I c[8]; V v[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = j + u < hi ? j + u : hi - 1;               // clamped: a harmless re-read of the last entry
+                c[u] = s_col[p]; v[u] = s_val[p];
+            }
+            // a gather no lane of the wave needs is not issued (7-entry rows: the eighth): these kernels are bound by
+            // the number of vector-memory instructions
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xv[u] = V(0); if (j + u < hi) xv[u] = x[c[u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const V added = sum + v[u] * xv[u];
+                sum = (j + u < hi) ? added : sum;
+            }
+        }
+        if (te < end) __syncthreads();
+    }
+    if (t < rows_here && !(append && my_lo == my_hi)) {
+        V r = alpha * sum;
+        if (append) r = y[r0 + t] + r;
+        y[r0 + t] = r;
+    }
+}
+
 // Row-subset CSR, always "+=":  y[rows[k]] += alpha * sum_j val[j] * x[col[j]],  j in [ptr[k], ptr[k+1]).
 // The remote part of a partitioned matrix touches only the rows next to a partition boundary
 // (2 x 260 100 of 16.8 M rows per GPU for 512^3 over 8 GPUs): the product then reads a row list
@@ -479,7 +555,11 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
 #define LAUNCH(NT, SWZ) csr_stream_kernel<V, I, NT, SWZ><<<(unsigned)grid, CSR_BLOCK, 0, s>>>( \
         n, nb, alpha, append, ptr, col, val, x, y, order)
-    if (nt) { if (swz) LAUNCH(true, true); else LAUNCH(true, false); }
+    if (!(variant & 4)) {             // second form (default)
+        if (swz) csr_stream2_kernel<V, I, true><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
+        else csr_stream2_kernel<V, I, false><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
+    }
+    else if (nt) { if (swz) LAUNCH(true, true); else LAUNCH(true, false); }
     else    { if (swz) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     VEXHIP_LAUNCH_CHECK();
