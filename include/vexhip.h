@@ -424,7 +424,7 @@ int vexhip_spmv_ccsr_f64(int dev, void *stream, int64_t n, double alpha, int app
 int vexhip_spmv_ccsr_f32(int dev, void *stream, int64_t n, float alpha, int append, const uint32_t *idx, int64_t m,
         const uint32_t *row, const int32_t *col, const float *val, int64_t entries, int64_t far_offset,
         const float *x, float *y);
-int vexhip_spmv_ccsr_set_rows_per_lane(int rows);    /* rows per lane: 4 (default), 1, 2 or 8 -- A/B switch for the kernel geometry */
+int vexhip_spmv_ccsr_set_rows_per_lane(int rows);    /* 0 (default): pair form, rows 2t and 2t+1 per lane with 16-byte x loads; 1, 2, 4, 8: rows per lane of the first form (A/B) */
 
 /* ---- stencil convolution (stencil.hpp:306-405 `slow_conv` / `fast_conv`) ----
  * y[i] = beta*y[i] + alpha * sum_{j=0}^{lhalo+rhalo} s[j] * X(i + j - lhalo), where

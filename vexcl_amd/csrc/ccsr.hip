@@ -19,17 +19,19 @@ constexpr int KTABLE = 1024;           // max entries / unique rows staged in LD
 
 struct strip { int chunk, planes, plane_blocks; };
 
+// 32-bit arithmetic: launch grids are < 2^31 (checked on the host) and a 64-bit division costs ~100 instructions,
+// four of them per workgroup in the 64-bit version of this function
 __device__ __forceinline__ long long strip_block(const strip &t, long long nblocks) {
-    const long long b = blockIdx.x;
+    const unsigned b = blockIdx.x;
     if (t.chunk > 0) {
-        const long long k = b & 7, q = b >> 3;
-        const long long i = q % t.chunk, r = q / t.chunk;
-        const long long p = r % t.planes, tile = r / t.planes;
-        const long long l = tile * 8 * t.chunk + k * t.chunk + i;
-        const long long lb = p * t.plane_blocks + l;
+        const unsigned k = b & 7u, q = b >> 3, chunk = (unsigned)t.chunk, planes = (unsigned)t.planes;
+        const unsigned r = q / chunk, i = q - r * chunk;
+        const unsigned tile = r / planes, p = r - tile * planes;
+        const long long l = (long long)tile * (8 * chunk) + k * chunk + i;
+        const long long lb = (long long)p * t.plane_blocks + l;
         return (l < t.plane_blocks && lb < nblocks) ? lb : -1;
     }
-    return b < nblocks ? b : -1;
+    return b < nblocks ? (long long)b : -1;
 }
 
 // A lane handles RPL rows that are 256 apart (row = block + q*256 + lane): every load of x,
@@ -87,7 +89,99 @@ void ccsr_kernel(long long n, long long nblocks, V alpha, int append,
     }
 }
 
-int g_ccsr_rpl = 4;
+// Pair form (round 2, the default): a lane owns rows 2t and 2t+1 of a 512-row block and reads x for both with ONE
+// 16-byte load per stencil entry when the two rows use the same unique row (idx equal: everywhere but next to a
+// boundary); otherwise each row walks its own entries with 8-byte loads.  Half the vector-memory instructions of the
+// kernel above (4.5 instead of 9 per row).  Measured at 512^3: 0.89 -> 0.87 ms -- unlike the SELL products
+// (sell8.hip, "PAIR kernels": 0.90 -> 0.80 ms) this one is NOT bound by instruction issue: with 20 bytes of HBM
+// traffic per row it runs at the same ~155-168 G rows/s as the value-coded SELL product, whatever the geometry
+// (1, 2, 4, 8 rows per lane, pairs, 64- or 32-bit strip arithmetic); what holds both at that row rate is not
+// identified (not TCP accesses, L2 or HBM bytes: profiles/r02_sq_summary.txt).
+// Entries are taken eight at a time: table reads, gathers, then the fold in row order (same order as the reference's
+// loop, ccsr.hpp:184-200): bit-identical to the kernel above.
+template <typename V, bool LDS>
+__global__ __launch_bounds__(KB)
+void ccsr_pair_kernel(long long n, long long nblocks, V alpha, int append,
+        const unsigned *__restrict__ idx, int m, const unsigned *__restrict__ row,
+        const int *__restrict__ col, const V *__restrict__ val, int entries,
+        const V *__restrict__ x, V *__restrict__ y, strip tr)
+{
+    typedef V V2 __attribute__((ext_vector_type(2)));
+    __shared__ unsigned s_row[LDS ? KTABLE + 1 : 1];
+    __shared__ int s_col[LDS ? KTABLE : 1];
+    __shared__ V s_val[LDS ? KTABLE : 1];
+    if constexpr (LDS) {
+        for (int j = threadIdx.x; j <= m; j += KB) s_row[j] = row[j];
+        for (int j = threadIdx.x; j < entries; j += KB) { s_col[j] = col[j]; s_val[j] = val[j]; }
+        __syncthreads();
+    }
+    const long long lb = strip_block(tr, nblocks);
+    if (lb < 0) return;
+    const long long i = lb * (2 * KB) + 2 * threadIdx.x;
+    if (i >= n) return;
+    const bool two = i + 1 < n;
+    unsigned p0, p1;
+    if (two && (reinterpret_cast<unsigned long long>(idx) & 7) == 0) {
+        const uint2 pp = *reinterpret_cast<const uint2 *>(idx + i);
+        p0 = pp.x; p1 = pp.y;
+    } else { p0 = idx[i]; p1 = two ? idx[i + 1] : p0; }
+    V s0 = 0, s1 = 0;
+    if (p0 == p1 && two) {
+        unsigned j = LDS ? s_row[p0] : row[p0];
+        const unsigned end = LDS ? s_row[p0 + 1] : row[p0 + 1];
+        for (; j < end; j += 8) {
+            int c[8]; V v[8]; V2 xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in = j + k < end;
+                c[k] = in ? (LDS ? s_col[j + k] : col[j + k]) : 0;
+                v[k] = in ? (LDS ? s_val[j + k] : val[j + k]) : V(0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {          // a load no lane of the wave needs is not issued
+                xv[k].x = V(0); xv[k].y = V(0);
+                if (j + k < end) __builtin_memcpy(&xv[k], x + (i + c[k]), sizeof(V2));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (j + k < end) { s0 += v[k] * xv[k].x; s1 += v[k] * xv[k].y; }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1 && !two) break;
+            const unsigned pos = q ? p1 : p0;
+            unsigned j = LDS ? s_row[pos] : row[pos];
+            const unsigned end = LDS ? s_row[pos + 1] : row[pos + 1];
+            V s = 0;
+            for (; j < end; j += 8) {
+                int c[8]; V v[8], xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool in = j + k < end;
+                    c[k] = in ? (LDS ? s_col[j + k] : col[j + k]) : 0;
+                    v[k] = in ? (LDS ? s_val[j + k] : val[j + k]) : V(0);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { xv[k] = V(0); if (j + k < end) xv[k] = x[i + q + c[k]]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (j + k < end) s += v[k] * xv[k];
+            }
+            if (q) s1 = s; else s0 = s;
+        }
+    }
+    if (two && (reinterpret_cast<unsigned long long>(y) & (2 * sizeof(V) - 1)) == 0) {
+        V2 *yp = reinterpret_cast<V2 *>(y + i);
+        V2 o; o.x = alpha * s0; o.y = alpha * s1;
+        if (append) { const V2 old = *yp; o.x = old.x + o.x; o.y = old.y + o.y; *yp = o; }
+        else __builtin_nontemporal_store(o, yp);
+    } else {
+        V o = alpha * s0; if (append) o = y[i] + o; y[i] = o;
+        if (two) { V o1 = alpha * s1; if (append) o1 = y[i + 1] + o1; y[i + 1] = o1; }
+    }
+}
+
+int g_ccsr_rpl = 0;      // 0: pair form (default); 1, 2, 4, 8: rows per lane of the first form (A/B)
 
 template <typename V, int RPL>
 int launch_ccsr(hipStream_t st, int64_t n, V alpha, int append, const uint32_t *idx, int64_t m,
@@ -125,6 +219,27 @@ int spmv_ccsr(int dev, void *stream, int64_t n, V alpha, int append, const uint3
     VEXHIP_REQUIRE(idx && row && x && y && (entries == 0 || (col && val)), "NULL argument");
         VEXHIP_SET_DEVICE(dev);
     hipStream_t st = as_stream(stream);
+    if (g_ccsr_rpl == 0) {
+        constexpr long long ROWS = 2 * KB;
+        const long long nb = (n + ROWS - 1) / ROWS;
+        strip tr = {0, 0, 0};
+        long long grid = nb;
+        if (s_big >= 2 * 65536 && s_big % ROWS == 0 && n >= 8 * 65536) {       // strip traversal, as launch_ccsr
+            const long long plane_blocks = s_big / ROWS;
+            const long long chunk = std::max<long long>(1, std::min<long long>(64, plane_blocks / 8));
+            const long long planes = (nb + plane_blocks - 1) / plane_blocks;
+            const long long tiles = (plane_blocks + 8 * chunk - 1) / (8 * chunk);
+            tr = strip{(int)chunk, (int)planes, (int)plane_blocks};
+            grid = tiles * planes * 8 * chunk;
+        }
+        VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+        if (m <= KTABLE && entries <= KTABLE)
+            ccsr_pair_kernel<V, true><<<(unsigned)grid, KB, 0, st>>>(n, nb, alpha, append, idx, (int)m, row, col, val, (int)entries, x, y, tr);
+        else
+            ccsr_pair_kernel<V, false><<<(unsigned)grid, KB, 0, st>>>(n, nb, alpha, append, idx, (int)m, row, col, val, (int)entries, x, y, tr);
+        VEXHIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (g_ccsr_rpl == 4)
         return launch_ccsr<V, 4>(st, n, alpha, append, idx, m, row, col, val, entries, s_big, x, y);
     if (g_ccsr_rpl == 8)
