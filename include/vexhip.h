@@ -285,6 +285,22 @@ int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, 
 int vexhip_spmat_apply_multi_f32(const vexhip_spmat *A, void *stream, int nrhs, float alpha, int append, const float *const *x, float *const *y);
 int vexhip_spmat_get_info(const vexhip_spmat *A, vexhip_spmat_info *info);
 
+/* ---- partition set-up on the device (vexcl/spmat.hpp:291-378, spmat/csr.inl:92-131, hybrid_ell.inl:132-136) -------
+ * One device's row strip, in HBM with GLOBAL column ids, is split into the LOCAL part (columns inside [col_begin,
+ * col_end), renumbered c - col_begin), the REMOTE part as a row-subset CSR (only the rows that reach a column outside
+ * the range; columns renumbered to their rank in the ghost set) and the sorted ghost set -- the reference builds all
+ * of this on the host from a std::set per device.  Two calls: sizes() -> {local nnz, remote nnz, rows with remote
+ * entries, -1}; the caller allocates lptr[n+1], lcol/lval[local nnz], rem_rows[rows], rem_ptr[rows+1],
+ * rem_col/rem_val[remote nnz], ghosts[remote nnz] (capacity); split() fills them and sets sizes[3] = ghost count.   */
+int vexhip_csr_split_sizes_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
+        int64_t col_begin, int64_t col_end, int64_t *sizes);
+int vexhip_csr_split_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
+        int64_t col_begin, int64_t col_end, int64_t *sizes, int32_t *lptr, int32_t *lcol, double *lval,
+        int32_t *rem_rows, int32_t *rem_ptr, int32_t *rem_col, double *rem_val, int32_t *ghosts);
+int vexhip_csr_split_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
+        int64_t col_begin, int64_t col_end, int64_t *sizes, int32_t *lptr, int32_t *lcol, float *lval,
+        int32_t *rem_rows, int32_t *rem_ptr, int32_t *rem_col, float *rem_val, int32_t *ghosts);
+
 /* ---- RCCL transport over xGMI -------------------------------------------------------------
  * Replaces the host-staged ghost exchange of vexcl/spmat.hpp:125-183 / sparse/distributed.hpp:347-428 (device ->
  * host -> device, four finish() fences), the host fold of the Reductor partials (reductor.hpp:412-436) and the host

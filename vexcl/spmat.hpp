@@ -16,8 +16,6 @@
 // secondary queues -- grouped ncclSend / ncclRecv over xGMI between GPUs, event-ordered copies between
 // logical devices of one GPU -- while the local product runs; the remote product waits on an event.
 #include <memory>
-#include <set>
-#include <unordered_map>
 #include <vector>
 
 #include "operations.hpp"
@@ -140,48 +138,46 @@ class SpMat {
                     const col_t *col, const val_t *val, size_t col_begin, size_t col_end, std::vector<col_t> &ghost_cols)
                 : n(row_end - row_begin)
             {
-                // split rows into local / remote CSR (csr.inl:92-131, hybrid_ell.inl:166-216)
-                std::set<col_t> gset;
-                for (auto r = row_begin; r != row_end; ++r)
-                    for (idx_t j = r[0]; j < r[1]; ++j)
-                        if (!(static_cast<size_t>(col[j]) >= col_begin && static_cast<size_t>(col[j]) < col_end)) gset.insert(col[j]);
-                ghost_cols.assign(gset.begin(), gset.end());
-                std::unordered_map<col_t, int> r2l(2 * ghost_cols.size() + 1);
-                for (size_t g = 0; g < ghost_cols.size(); ++g) r2l[ghost_cols[g]] = static_cast<int>(g);
-
-                std::vector<int> lptr(1, 0), lcol, rptr(1, 0), rcol;
-                std::vector<val_t> lval, rval;
-                lptr.reserve(n + 1); rptr.reserve(n + 1);
-                for (auto r = row_begin; r != row_end; ++r) {
-                    for (idx_t j = r[0]; j < r[1]; ++j) {
-                        size_t c = static_cast<size_t>(col[j]);
-                        if (c >= col_begin && c < col_end) { lcol.push_back(static_cast<int>(c - col_begin)); lval.push_back(val[j]); }
-                        else { rcol.push_back(r2l[col[j]]); rval.push_back(val[j]); }
-                    }
-                    precondition(lcol.size() < (1ull << 31) && rcol.size() < (1ull << 31), "SpMat: more than 2^31 nonzeros on one device");
-                    lptr.push_back(static_cast<int>(lcol.size()));
-                    rptr.push_back(static_cast<int>(rcol.size()));
+                // The strip goes to the device as it is (row pointers rebased, indices narrowed to int32: one host pass,
+                // no std::set, no second host copy) and is split THERE into the local part, the row-subset remote part
+                // and the sorted ghost set (vexhip_csr_split_*; the reference does all of it on the host with a
+                // std::set per device: spmat.hpp:291-378, csr.inl:92-131, hybrid_ell.inl:132-136).
+                const size_t first = static_cast<size_t>(row_begin[0]), strip_nnz = static_cast<size_t>(row_end[0]) - first;
+                precondition(strip_nnz < (1ull << 31) && col_end < (1ull << 31), "SpMat: more than 2^31 nonzeros or columns on one device");
+                std::vector<int> sptr(n + 1), scol(strip_nnz);
+                for (size_t i = 0; i <= n; ++i) sptr[i] = static_cast<int>(static_cast<size_t>(row_begin[i]) - first);
+                for (size_t j = 0; j < strip_nnz; ++j) {
+                    precondition(static_cast<size_t>(col[first + j]) < (1ull << 31), "SpMat: column index beyond 2^31");
+                    scol[j] = static_cast<int>(col[first + j]);
                 }
-                precondition(col_end - col_begin < (1ull << 31), "SpMat: more than 2^31 columns on one device");
-                {
-                    backend::device_vector<int> dptr(q, lptr.size(), lptr.data());
-                    backend::device_vector<int> dcol(q, lcol.size(), lcol.data());
-                    backend::device_vector<val_t> dval(q, lval.size(), lval.data());
-                    set_local(q, dptr, dcol, dval, lcol.size());
-                }
-                // remote part: only the rows that reach a ghost column are stored (row list + compact CSR)
-                rem.n = n; rem.nnz = rcol.size();
+                const int dev = q.device_ordinal();
+                backend::device_vector<int> dptr(q, n + 1, sptr.data()), dcol(q, strip_nnz, scol.data());
+                backend::device_vector<val_t> dval(q, strip_nnz, val + first);
+                std::vector<int>().swap(sptr); std::vector<int>().swap(scol);
+                int64_t sz[4] = {0, 0, 0, 0};
+                backend::check(vexhip_csr_split_sizes_i32(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), (int64_t)col_begin, (int64_t)col_end, sz));
+                backend::device_vector<int> lptr(q, n + 1), lcol(q, (size_t)sz[0]);
+                backend::device_vector<val_t> lval(q, (size_t)sz[0]);
+                backend::device_vector<int> rrows(q, (size_t)sz[2]), rptr(q, (size_t)sz[2] + 1), rcol(q, (size_t)sz[1]), dghost(q, (size_t)sz[1]);
+                backend::device_vector<val_t> rval(q, (size_t)sz[1]);
+                backend::check(csr_split(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(), (int64_t)col_begin, (int64_t)col_end, sz,
+                            lptr.raw(), lcol.raw(), lval.raw(), rrows.raw(), rptr.raw(), rcol.raw(), rval.raw(), dghost.raw()));
+                set_local(q, lptr, lcol, lval, (size_t)sz[0]);
+                rem.n = n; rem.nnz = (size_t)sz[1];
                 if (rem.nnz) {
-                    std::vector<int> rows, cptr(1, 0);
-                    for (size_t i = 0; i < n; ++i)
-                        if (rptr[i + 1] > rptr[i]) { rows.push_back(static_cast<int>(i)); cptr.push_back(rptr[i + 1]); }
-                    rem_rows = backend::device_vector<int>(q, rows.size(), rows.data());
-                    rem.csr_ptr = backend::device_vector<int>(q, cptr.size(), cptr.data());
-                    rem.csr_col = backend::device_vector<int>(q, rcol.size(), rcol.data());
-                    rem.csr_val = backend::device_vector<val_t>(q, rval.size(), rval.data());
-                    rem.csr_nnz = rem.nnz;
+                    rem_rows = rrows; rem.csr_ptr = rptr; rem.csr_col = rcol; rem.csr_val = rval; rem.csr_nnz = rem.nnz;
+                    std::vector<int> g((size_t)sz[3]);
+                    dghost.read(q, 0, g.size(), g.data(), true);
+                    ghost_cols.assign(g.begin(), g.end());
                 }
             }
+
+            static int csr_split(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int64_t c0, int64_t c1, int64_t *sz,
+                    int *lp, int *lc, double *lv, int *rr, int *rp, int *rc, double *rv, int *g)
+            { return vexhip_csr_split_f64_i32(dev, s, n, p, c, v, c0, c1, sz, lp, lc, lv, rr, rp, rc, rv, g); }
+            static int csr_split(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int64_t c0, int64_t c1, int64_t *sz,
+                    int *lp, int *lc, float *lv, int *rr, int *rp, int *rc, float *rv, int *g)
+            { return vexhip_csr_split_f32_i32(dev, s, n, p, c, v, c0, c1, sz, lp, lc, lv, rr, rp, rc, rv, g); }
 
             /// One device holding the whole matrix, given as DEVICE CSR arrays (int32 indices): no host staging.
             device_part(const backend::command_queue &q, size_t rows, size_t nonzeros, const backend::device_vector<int> &dptr,

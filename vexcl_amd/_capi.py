@@ -147,6 +147,9 @@ _PROTOS = {
     "vexhip_spmat_apply_multi_f64": (None, [c_vp, c_vp, c_int, c_f64, c_int, c_vp, c_vp]),
     "vexhip_spmat_apply_multi_f32": (None, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp]),
     "vexhip_spmat_get_info": (None, [c_vp, ctypes.POINTER(SpMatInfo)]),
+    "vexhip_csr_split_sizes_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, ctypes.POINTER(c_i64)]),
+    "vexhip_csr_split_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.POINTER(c_i64)] + [c_vp] * 8),
+    "vexhip_csr_split_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.POINTER(c_i64)] + [c_vp] * 8),
     "vexhip_comm_unique_id": (None, [c_vp]),
     "vexhip_comm_init": (None, [c_int, ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_vp)]),
     "vexhip_comm_init_rank": (None, [c_int, c_int, c_int, c_vp, ctypes.POINTER(c_vp)]),
