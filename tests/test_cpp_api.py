@@ -64,3 +64,16 @@ def test_cpp_api_single_device_context():
     env = dict(os.environ, VEX_TEST_SINGLE_DEVICE="1")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["vector_tests", "primitives_tests"])
+def test_cpp_reductor_combine_through_the_comm_layer(name):
+    """VEXCL_REDUCTOR_COMBINE=rccl: the per-device scalars of vex::Reductor are combined by vexhip_allreduce_scalar
+    (RCCL between distinct GPUs; on the two logical devices of this box the PEER transport's fold) instead of the host
+    fold -- every reduction assertion of the suite must still hold."""
+    exe = _build(name)
+    env = dict(os.environ, VEXCL_REDUCTOR_COMBINE="rccl")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-3000:]
+    assert "0 failures" in out.stdout

@@ -12,6 +12,7 @@
 #include <map>
 #include <memory>
 #include "operations.hpp"
+#include "exchange.hpp"
 #include "vector.hpp"
 #include "multivector.hpp"
 
@@ -134,7 +135,26 @@ class Reductor {
                 krn(queue[d]);
                 backend::check(vexhip_reduce_finish(queue[d].device_ordinal(), queue[d].raw(), op,
                             reduce_dtype<ScalarType>::value, bufs[d]->partials.raw(), ngroups[d], bufs[d]->result.raw()));
-                bufs[d]->result.read(queue[d], 0, nout * sizeof(ScalarType), reinterpret_cast<char *>(&host[2 * d]), false);
+                if (!rccl_combine(minmax))
+                    bufs[d]->result.read(queue[d], 0, nout * sizeof(ScalarType), reinterpret_cast<char *>(&host[2 * d]), false);
+            }
+            if (rccl_combine(minmax)) {
+                // VEXCL_REDUCTOR_COMBINE=rccl: the D per-device scalars are combined by ONE all-reduce over xGMI
+                // (vexhip_allreduce_scalar) and a single 8-byte read-back, instead of D read-backs and a host fold
+                // (reductor.hpp:412-436).  Used when every device holds a part; the host fold is the default.
+                bool all = true;
+                for (char a : active) all = all && a;
+                if constexpr (!minmax) if (all) {
+                    if (!comm) comm = detail::make_comm(queue);
+                    std::vector<void *> b(queue.size()), st(queue.size());
+                    for (unsigned d = 0; d < queue.size(); ++d) { b[d] = bufs[d]->result.raw(); st[d] = queue[d].raw(); }
+                    backend::check(vexhip_allreduce_scalar(comm.get(), op, reduce_dtype<ScalarType>::value, b.data(), 1, st.data()));
+                    bufs[0]->result.read(queue[0], 0, sizeof(ScalarType), reinterpret_cast<char *>(&host[0]), true);
+                    for (unsigned d = 1; d < queue.size(); ++d) queue[d].finish();
+                    return static_cast<result_type>(host[0]);
+                }
+                for (unsigned d = 0; d < queue.size(); ++d)
+                    if (active[d]) bufs[d]->result.read(queue[d], 0, nout * sizeof(ScalarType), reinterpret_cast<char *>(&host[2 * d]), false);
             }
             for (unsigned d = 0; d < queue.size(); ++d) if (active[d]) queue[d].finish();
             return combine(host, active, std::integral_constant<bool, minmax>());
@@ -159,6 +179,12 @@ class Reductor {
         std::vector<backend::command_queue> queue;
         std::vector<std::shared_ptr<detail::reductor_buffers>> bufs;
         std::vector<int> ngroups;
+        mutable std::shared_ptr<vexhip_comm> comm;       // created on first use of the RCCL combine
+
+        bool rccl_combine(bool minmax) const {
+            static const bool on = [] { const char *e = std::getenv("VEXCL_REDUCTOR_COMBINE"); return e && std::string(e) == "rccl"; }();
+            return on && !minmax && queue.size() > 1;
+        }
 
         static int op_code() {
             if (std::is_same<RDC, SUM>::value) return VEXHIP_SUM;
