@@ -137,14 +137,14 @@ void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
         int *gset, int *info)
 {
     __shared__ int s_set[LOCAL_SLOTS];
-    __shared__ int s_over;
+    __shared__ int s_over, s_count;
     for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) s_set[k] = EMPTY;
-    if (threadIdx.x == 0) s_over = *(volatile int *)&info[1];
+    if (threadIdx.x == 0) { s_over = *(volatile int *)&info[1]; s_count = 0; }
     __syncthreads();
     // a matrix without structure overflows the set at once: stop looking (a full set costs a whole probe
     // sequence per insertion) -- s_over starts from the global flag, so later workgroups do not even begin
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        if (*(volatile int *)&s_over) break;
+        if (*(volatile int *)&s_over || *(volatile int *)&info[1]) break;
         const int b = ptr[i], e = ptr[i + 1];
         int last = EMPTY;
         for (int j = 0; j < w && b + j < e; ++j) {
@@ -153,10 +153,13 @@ void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
             int d = (int)dl;
             if (d == last) continue;
             last = d;
-            if (!set_insert(s_set, LOCAL_SLOTS, d, nullptr)) s_over = 1;
+            bool fresh = false;
+            if (!set_insert(s_set, LOCAL_SLOTS, d, &fresh)) s_over = 1;
+            else if (fresh && atomicAdd(&s_count, 1) >= 254) { s_over = 1; atomicExch(&info[1], 1); }   // a 255th diagonal: not coded
         }
     }
     __syncthreads();
+    if (s_over) { if (threadIdx.x == 0) atomicExch(&info[1], 1); return; }
     for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
         if (s_set[k] == EMPTY) continue;
         bool is_new = false;
@@ -449,12 +452,16 @@ void value_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
 {
     typedef typename bits_of<V>::type B;
     __shared__ B s_set[LOCAL_SLOTS];
-    __shared__ int s_over;
+    __shared__ int s_over, s_count;
     for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) s_set[k] = ~B(0);
-    if (threadIdx.x == 0) s_over = *(volatile int *)&info[1];
+    if (threadIdx.x == 0) { s_over = *(volatile int *)&info[1]; s_count = 0; }
     __syncthreads();
+    // A matrix whose values are all different fills the set at once.  Stop at the 256th distinct value (a half-full
+    // table: short probe sequences), tell the other workgroups through the global flag, and do not merge: with the
+    // first version of this loop (probe until the 512-slot table is FULL, flag raised only at the end) the analysis of
+    // the 512^3 variable-coefficient matrix took 143 ms (profiles/r02_*cpp_kernel_stats.csv).
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        if (*(volatile int *)&s_over) break;
+        if (*(volatile int *)&s_over || *(volatile int *)&info[1]) break;
         const int b = ptr[i], e = ptr[i + 1];
         B last = ~B(0);
         for (int j = 0; j < w && b + j < e; ++j) {
@@ -463,10 +470,13 @@ void value_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
             if (bits == ~B(0)) { s_over = 1; continue; }          // the one pattern that cannot be stored (a NaN payload)
             if (bits == last) continue;
             last = bits;
-            if (!vset_insert<B>(s_set, LOCAL_SLOTS, bits, nullptr)) s_over = 1;
+            bool fresh = false;
+            if (!vset_insert<B>(s_set, LOCAL_SLOTS, bits, &fresh)) s_over = 1;
+            else if (fresh && atomicAdd(&s_count, 1) >= 255) { s_over = 1; atomicExch(&info[1], 1); }
         }
     }
     __syncthreads();
+    if (s_over) { if (threadIdx.x == 0) atomicExch(&info[1], 1); return; }
     for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
         if (s_set[k] == ~B(0)) continue;
         bool is_new = false;

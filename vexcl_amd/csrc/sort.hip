@@ -71,7 +71,21 @@ void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsig
     if (vec_ok) {
         const int nv = count / VN;
         const vtype *kv = reinterpret_cast<const vtype *>(keys + base);
-        for (int v = threadIdx.x; v < nv; v += HB) {
+        // six 16-byte loads in flight per lane before the first counter bump: with one load per trip the kernel sat
+        // at 4.3 TB/s with its waves parked 89 % of the time (profiles/r02_sort_sq.txt) -- latency, not HBM
+        constexpr int UN = 6;
+        int v = threadIdx.x;
+        for (; v + (UN - 1) * HB < nv; v += UN * HB) {
+            vtype q[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) q[u] = __builtin_nontemporal_load(kv + v + u * HB);
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int j = 0; j < VN; ++j)
+                    count_digit(s_h, (unsigned)(to_ordered<K, MODE, DESC>(q[u][j]) >> shift) & (RADIX - 1));
+        }
+        for (; v < nv; v += HB) {
             vtype q = __builtin_nontemporal_load(kv + v);
 #pragma unroll
             for (int j = 0; j < VN; ++j)
