@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true>", "sell8": "sell8_pair_kernel<double, 7, false>",
-             "sell32": "sell_pair_kernel<double, 7>", "csr": "csr_stream_kernel<double, int, ...>", "hell": "hell_kernel"}
+             "sell32": "sell_pair_kernel<double, 7>", "csr": "csr_stream2_kernel<double, int, false>", "hell": "hell_kernel"}
 
 
 def algorithmic_bytes(n_rows, nnz):
@@ -126,7 +126,7 @@ def measure_traffic(grid, timeout=240):
                         continue
                     name = r["Kernel_Name"]
                     key = None
-                    for k in ("sell8_pair_kernel", "sell_pair_kernel", "csr_stream_kernel", "reduce_stage1"):
+                    for k in ("sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
                         if k in name:
                             key = k
                             if k == "sell8_pair_kernel":
@@ -467,7 +467,7 @@ def main():
                 tr, how = None, repr(e)
             out["roofline"]["traffic_source"] = how
             if tr:
-                key = {"sell8v": "sell8_pair_kernel_vcoded", "sell8": "sell8_pair_kernel_values", "sell32": "sell_pair_kernel", "csr": "csr_stream_kernel"}.get(storage)
+                key = {"sell8v": "sell8_pair_kernel_vcoded", "sell8": "sell8_pair_kernel_values", "sell32": "sell_pair_kernel", "csr": "csr_stream2_kernel"}.get(storage)
                 if key in tr:
                     out["roofline"]["traffic"] = tr[key]["total"]
                     out["roofline"]["traffic_read_written"] = [tr[key]["read"], tr[key]["written"]]
