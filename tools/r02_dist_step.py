@@ -84,5 +84,18 @@ for _ in range(300):
 e1.record(); torch.cuda.synchronize()
 out["local part alone"] = {"device_us_per_step": round(e0.elapsed_time(e1) * 1e3 / 300, 2)}
 print("local part alone", out["local part alone"], flush=True)
+rem = ops.RowSubsetCSR(rows_with, cp, rc, rv)
+for label, fn in (("remote part alone", lambda: rem.apply(ghost_buf, y, 1.0, True)),
+                  ("pack alone", lambda: ops.gather(send_idx, x, send_buf)),
+                  ("local + remote, no exchange", lambda: (loc.apply(x, y), rem.apply(ghost_buf, y, 1.0, True)))):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(300):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    out[label] = {"device_us_per_step": round(e0.elapsed_time(e1) * 1e3 / 300, 2)}
+    print(label, out[label], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/r02_dist_step.json", "w"), indent=1)

@@ -179,16 +179,18 @@ int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void
     const bool f64 = D->dtype == VEXHIP_F64;
     const bool exch = D->nsend > 0 || D->nghost > 0;
     if (exch) {
-        // the previous product's remote part must have read the ghosts before they are overwritten, and its sends must
-        // have left send_buf before it is re-packed: both are ordered on `s` itself (the remote part and the wait for
-        // `received` were issued on it), so recording after them and making the comm stream wait is enough
+        // The pack kernel and the exchange run on the SECOND stream, beside the local part (which needs neither):
+        //   compute stream s:   [x ready] ............ local part ............ wait(received) remote part [consumed]
+        //   comm stream:        wait(x ready, consumed of the previous step)  pack -> send/recv  [received]
+        // Ordering: the pack re-uses send_buf after the previous step's sends (same stream, in order); the receive
+        // overwrites ghost_buf only after the previous step's remote part has read it (`consumed`, recorded on s).
+        VEXHIP_TRY(hipEventRecord(D->packed, s));                         // "x is ready" (and, transitively, `consumed`)
+        VEXHIP_TRY(hipStreamWaitEvent(D->comm_stream, D->packed, 0));
         if (D->nsend) {
-            int rc = f64 ? vexhip_gather_f64_i32(D->dev, s, D->nsend, D->send_idx, static_cast<const double *>(x), static_cast<double *>(D->send_buf))
-                         : vexhip_gather_f32_i32(D->dev, s, D->nsend, D->send_idx, static_cast<const float *>(x), static_cast<float *>(D->send_buf));
+            int rc = f64 ? vexhip_gather_f64_i32(D->dev, D->comm_stream, D->nsend, D->send_idx, static_cast<const double *>(x), static_cast<double *>(D->send_buf))
+                         : vexhip_gather_f32_i32(D->dev, D->comm_stream, D->nsend, D->send_idx, static_cast<const float *>(x), static_cast<float *>(D->send_buf));
             if (rc) return rc;
         }
-        VEXHIP_TRY(hipEventRecord(D->packed, s));
-        VEXHIP_TRY(hipStreamWaitEvent(D->comm_stream, D->packed, 0));
         NCCL_TRY(rccl().GroupStart());
         int rc = exchange_one(D->c, 0, D->dtype, D->send_buf, D->send_counts.data(), D->ghost_buf, D->recv_counts.data(), D->comm_stream);
         ncclResult_t ge = rccl().GroupEnd();
@@ -196,7 +198,7 @@ int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void
         NCCL_TRY(ge);
         VEXHIP_TRY(hipEventRecord(D->received, D->comm_stream));
     }
-    // local part, overlapped with the exchange
+    // local part, overlapped with pack + exchange
     if (D->loc) {
         int rc = f64 ? vexhip_spmat_apply_f64(D->loc, s, alpha, append, static_cast<const double *>(x), static_cast<double *>(y))
                      : vexhip_spmat_apply_f32(D->loc, s, (float)alpha, append, static_cast<const float *>(x), static_cast<float *>(y));
