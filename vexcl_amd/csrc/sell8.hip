@@ -361,15 +361,16 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
     typedef typename vec2<V>::type V2;
     __shared__ int s_delta[256];
     __shared__ V s_value[VCODED ? 256 : 1];
-    s_delta[threadIdx.x] = deltas[threadIdx.x];
-    if constexpr (VCODED) s_value[threadIdx.x] = values[threadIdx.x];
-    __syncthreads();
-
+    // The slice's own loads are issued BEFORE the tables are staged: they do not depend on them, and the chain
+    // tables -> barrier -> codes -> look-ups -> gathers -> store of a workgroup is what bounds these products (rows in
+    // flight per CU / length of that chain: DESIGN.md 3.0): 0.808 -> 0.793 ms.  Tried and dropped: tables of <= 64
+    // entries kept in registers and looked up with lane permutes (no LDS table, no barrier): 0.819 ms -- ds_bpermute
+    // costs more than the LDS reads it replaces.
     const long long s = traversal_block(trav, nslices);
-    if (s < 0) return;
+    const long long sl = s < 0 ? 0 : s;                       // holes of the strip order: load slice 0, store nothing
     const int t = threadIdx.x;
-    const long long i = s * S8_ROWS + 2 * t;
-    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + s * SLICE) + t;
+    const long long i = sl * S8_ROWS + 2 * t;
+    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + sl * SLICE) + t;
     unsigned c[WP], vc[VCODED ? WP : 1];
 #pragma unroll
     for (int jp = 0; jp < WP; ++jp) {
@@ -378,10 +379,14 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
     }
     V2 v[VCODED ? 1 : W];
     if constexpr (!VCODED) {
-        const V *vp = reinterpret_cast<const V *>(buf + s * SLICE + (long long)WP * 1024) + 2 * t;
+        const V *vp = reinterpret_cast<const V *>(buf + sl * SLICE + (long long)WP * 1024) + 2 * t;
 #pragma unroll
         for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * S8_ROWS));
     }
+    s_delta[threadIdx.x] = deltas[threadIdx.x];
+    if constexpr (VCODED) s_value[threadIdx.x] = values[threadIdx.x];
+    __syncthreads();
+    if (s < 0) return;
     // table look-ups for every column first, then every gather
     int d[W];
 #pragma unroll
