@@ -183,6 +183,83 @@ extern "C" __global__ void __launch_bounds__(256) k(long long n, long long ns, u
   }
 }
 '''
+
+SRC_PIPE = r"""
+#define W 7
+#define WP 4
+typedef double d2 __attribute__((ext_vector_type(2)));
+struct trav { int chunk, planes, plane_blocks; };
+__device__ inline long long slot_of(const trav t, long long nblocks, const unsigned vb) {
+  if (t.chunk > 0) {
+    const unsigned k = vb & 7u, q = vb >> 3, chunk = t.chunk, planes = t.planes;
+    const unsigned r = q / chunk, i = q - r * chunk, tile = r / planes, p = r - tile * planes;
+    const long long l = (long long)tile * (8 * chunk) + k * chunk + i, lb = (long long)p * t.plane_blocks + l;
+    return (l < t.plane_blocks && lb < nblocks) ? lb : -1;
+  }
+  return vb < nblocks ? (long long)vb : -1;
+}
+// resident grid; per slice: seven 16-byte gathers (both rows take the lane's first code: timing only), the NEXT slice's
+// codes are loaded behind the gathers
+extern "C" __global__ void __launch_bounds__(256) kp(long long n, long long ns, unsigned nvirtual, const char *buf, const int *deltas,
+    const double *values, const double *x, double *y, trav tr) {
+  __shared__ int s_delta[256]; __shared__ double s_value[256];
+  const int t = threadIdx.x;
+  unsigned vb = blockIdx.x;
+  long long s = -1;
+  for (; vb < nvirtual; vb += gridDim.x) { s = slot_of(tr, ns, vb); if (s >= 0) break; }
+  unsigned c[WP], vc[WP];
+  { const unsigned *cw = (const unsigned *)(buf + (s < 0 ? 0 : s) * (WP * 2048ll)) + t;
+    #pragma unroll
+    for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(cw + (WP + jp) * 256); } }
+  s_delta[t] = deltas[t]; s_value[t] = values[t];
+  __syncthreads();
+  if (s < 0) return;
+  for (;;) {
+    const long long i = s * 512 + 2 * t;
+    int dl[W];
+    #pragma unroll
+    for (int j = 0; j < W; ++j) dl[j] = s_delta[(c[j >> 1] >> (16 * (j & 1))) & 255u];
+    d2 xv[W];
+    #pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const unsigned code = (c[j >> 1] >> (16 * (j & 1))) & 255u;
+      const double *px = code < 254u ? x + (i + dl[j]) : values + 254;
+      __builtin_memcpy(&xv[j], px, 16);
+    }
+    long long sn = -1;
+    for (vb += gridDim.x; vb < nvirtual; vb += gridDim.x) { sn = slot_of(tr, ns, vb); if (sn >= 0) break; }
+    unsigned cn[WP], vn[WP];
+#if PIPE
+    { const unsigned *cw = (const unsigned *)(buf + (sn >= 0 ? sn : s) * (WP * 2048ll)) + t;
+      __builtin_amdgcn_sched_barrier(0);
+      #pragma unroll
+      for (int jp = 0; jp < WP; ++jp) { cn[jp] = __builtin_nontemporal_load(cw + jp * 256); vn[jp] = __builtin_nontemporal_load(cw + (WP + jp) * 256); }
+      __builtin_amdgcn_sched_barrier(0); }
+#endif
+    double sum[2] = {0, 0};
+    #pragma unroll
+    for (int j = 0; j < W; ++j)
+    #pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int sh = 16 * (j & 1) + 8 * q;
+        const unsigned code = (c[j >> 1] >> sh) & 255u;
+        const double a = s_value[code < 254u ? (vc[j >> 1] >> sh) & 255u : 255u];
+        sum[q] += a * (q ? xv[j].y : xv[j].x);
+      }
+    if (i + 1 < n) { d2 o; o.x = sum[0]; o.y = sum[1]; __builtin_nontemporal_store(o, (d2 *)(y + i)); }
+    if (sn < 0) break;
+    s = sn;
+#if PIPE
+    #pragma unroll
+    for (int jp = 0; jp < WP; ++jp) { c[jp] = cn[jp]; vc[jp] = vn[jp]; }
+#else
+    { const unsigned *cw = (const unsigned *)(buf + s * (WP * 2048ll)) + t;
+      #pragma unroll
+      for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(cw + (WP + jp) * 256); } }
+#endif
+  }
+}
+"""
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 class Trav(ctypes.Structure):
     _fields_ = [("chunk", ctypes.c_int), ("planes", ctypes.c_int), ("plane_blocks", ctypes.c_int)]
@@ -225,6 +302,17 @@ def launcher(f, fn):
     arr = (ctypes.c_void_p * len(args))(*[ctypes.cast(ctypes.pointer(a), ctypes.c_void_p) for a in args])
     return lambda keep=(args, arr): L.launch(0, fn, grid, 1, 1, 256, 1, 1, 0, stream, arr)
 runs = [(label, f, launcher(f, fn)) for label, f, mod, fn in mods]
+for pipe in (0, 1):
+    for bpc in (2, 4, 8):
+        mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
+        L.module_compile(0, ("#define PIPE %d\n" % pipe + SRC_PIPE).encode(), b"-ffp-contract=off", ctypes.byref(mod))
+        L.module_get_function(0, mod, b"kp", ctypes.byref(fn))
+        def mk(fn=fn, g=bpc * 256):
+            args = [ctypes.c_longlong(N), ctypes.c_longlong(ns), ctypes.c_uint(nvirtual), ctypes.c_void_p(S.sell.data_ptr()), ctypes.c_void_p(S.deltas.data_ptr()),
+                    ctypes.c_void_p(S.values.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), tr]
+            arr = (ctypes.c_void_p * len(args))(*[ctypes.cast(ctypes.pointer(a), ctypes.c_void_p) for a in args])
+            return lambda keep=(args, arr): L.launch(0, fn, g, 1, 1, 256, 1, 1, 0, stream, arr)
+        runs.append(("seven 16-byte gathers, resident grid %d workgroups per CU, %s" % (bpc, "next codes prefetched behind the gathers" if pipe else "no prefetch"), dict(), mk()))
 times = {label: [] for label, _, _ in runs}
 same = {}
 for rnd in range(3):
