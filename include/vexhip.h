@@ -424,6 +424,9 @@ int vexhip_scan(int dev, void *stream, int dtype, int exclusive, const void *ini
  * keys are sorted in place; keys_tmp (n keys) and, for pairs, vals_tmp are
  * ping-pong buffers; tmp holds vexhip_sort_tmp_bytes().  value_bytes in {0,4,8}. */
 size_t vexhip_sort_tmp_bytes(int key_dtype, int64_t n);
+/* How the scatter ranks the keys of a wave: -1 (default) = atomic ranks if the device passes the lane-order self-test of
+ * LDS atomics (run once per device), else match words; 0 = match words; 1 = atomic ranks (A/B, tests).                 */
+int vexhip_sort_set_rank(int mode);
 int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
         void *keys, void *keys_tmp, int value_bytes, void *vals, void *vals_tmp,
         int64_t n, void *tmp);

@@ -135,6 +135,32 @@ def test_sort_by_key_is_stable(T, oracle, n):
     assert np.array_equal(di.cpu().numpy(), np.argsort(k, kind="stable"))
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sort_rank_schemes_give_the_stable_permutation(T, oracle, mode):
+    """Both ranking schemes of the scatter kernel -- match words (0) and one returning LDS atomic per key (1: relies on
+    gfx950 serving same-address lanes of one LDS atomic in lane order; the library checks that on the device before it
+    picks the scheme) -- must produce std::stable_sort's permutation (sort.cpp:22-45), for few and for many distinct
+    keys, ragged sizes, 4- and 8-byte keys and payloads."""
+    from vexcl_amd import lib
+    L = lib()
+    L.sort_set_rank(mode)
+    try:
+        for n, hi in ((12288 * 3 + 17, 3), (1 << 20, 100), (777777, 1 << 30), (1 << 22, 255)):
+            k = oracle.random_i32(n, n, 0, hi)
+            idx = np.arange(n, dtype=np.int64)
+            dk, di = T.up(k), T.up(idx)
+            T.ops.sort_by_key(dk, di)
+            assert np.array_equal(di.cpu().numpy(), np.argsort(k, kind="stable")), (mode, n, hi)
+            assert np.array_equal(dk.cpu().numpy(), np.sort(k, kind="stable"))
+        l = oracle.random_i32(5, 300001, -50, 50).astype(np.int64) * 3000000007
+        v = np.arange(300001, dtype=np.int32)
+        dk, dv = T.up(l), T.up(v)
+        T.ops.sort_by_key(dk, dv)
+        assert np.array_equal(dv.cpu().numpy(), np.argsort(l, kind="stable").astype(np.int32))
+    finally:
+        L.sort_set_rank(-1)
+
+
 def test_sort_golden_signed_and_64bit(T, oracle):
     dk, dv = T.up(G["sort_keys"]), T.up(G["sort_vals"])
     T.ops.sort_by_key(dk, dv)

@@ -9,7 +9,8 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**9
 
 def run(keys0, vals0, code, reps=3):
     out = {}
-    for variant in (0,):
+    for variant in (0, 1):
+        L.sort_set_rank(variant)
         keys, ktmp = keys0.clone(), torch.empty_like(keys0)
         vals = vals0.clone() if vals0 is not None else None
         vtmp = torch.empty_like(vals0) if vals0 is not None else None
@@ -32,8 +33,11 @@ def run(keys0, vals0, code, reps=3):
     return out
 
 def report(name, out, nkeys, check_sorted):
-    ok = check_sorted(out[0][1])
-    print("%-34s %8.3f ms  %6.1f Gkeys/s  sorted: %s" % (name, out[0][0], nkeys / out[0][0] / 1e6, ok), flush=True)
+    for variant, label in ((0, "match words"), (1, "atomic ranks")):
+        ok = check_sorted(out[variant][1])
+        print("%-34s %-13s %8.3f ms  %6.1f Gkeys/s  sorted: %s" % (name, label, out[variant][0], nkeys / out[variant][0] / 1e6, ok), flush=True)
+    if out[0][2] is not None:
+        print("%-34s payloads identical: %s" % (name, bool(torch.equal(out[0][2], out[1][2]))), flush=True)
 
 def sorted_u32(k):
     a = k.view(torch.int32).to(torch.int64) & 0xffffffff if k.numel() <= 2**28 else None
@@ -55,3 +59,4 @@ k2 = keys[:m].contiguous(); v2 = torch.arange(m, dtype=torch.int32, device=dev)
 report("u32 keys + u32 values n=%.0e" % m, run(k2, v2, _capi.U32), m, sorted_u32)
 k3 = ops.fill_hash(torch.empty(m, dtype=torch.int64, device=dev), 7)
 report("i64 keys n=%.0e" % m, run(k3, None, _capi.I64), m, lambda k: bool((k[1:] >= k[:-1]).all()))
+L.sort_set_rank(-1)

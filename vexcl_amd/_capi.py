@@ -183,6 +183,7 @@ _PROTOS = {
     "vexhip_scan_tmp_bytes": (c_size, [c_int, c_i64]),
     "vexhip_scan": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vexhip_sort_tmp_bytes": (c_size, [c_int, c_i64]),
+    "vexhip_sort_set_rank": (None, [c_int]),
     "vexhip_sort": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp]),
     "vexhip_spmv_ccsr_f64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "vexhip_spmv_ccsr_set_rows_per_lane": (None, [c_int]),

@@ -65,7 +65,13 @@ void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsig
     __shared__ unsigned s_h[RADIX];
     s_h[threadIdx.x] = 0;
     __syncthreads();
-    const long long base = (long long)blockIdx.x * TILE;
+    // XCD-contiguous tile order (as the scatter): workgroup b runs on XCD b % 8.  A tile writes ONE 4-byte counter into
+    // each of 256 table rows; the counters of neighbouring tiles share a cache line, and on the same XCD they meet in one
+    // L2 and leave it as full lines instead of 256 partial-line writes per tile.
+    const unsigned per = (nblocks + 7) / 8;
+    const unsigned tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (tile >= nblocks) return;
+    const long long base = (long long)tile * TILE;
     const int count = (int)((n - base < TILE) ? (n - base) : TILE);
     int done = 0;
     if (vec_ok) {
@@ -96,7 +102,7 @@ void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsig
     for (int i = done + threadIdx.x; i < count; i += HB)
         count_digit(s_h, (unsigned)(to_ordered<K, MODE, DESC>(keys[base + i]) >> shift) & (RADIX - 1));
     __syncthreads();
-    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
+    table[(size_t)threadIdx.x * nblocks + tile] = s_h[threadIdx.x];
 }
 
 template <int VB> struct valtype;
@@ -121,7 +127,7 @@ struct scatter_lds {
 };
 
 // FULL: every slot of the tile holds a key (all tiles but the last): no validity masks.
-template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL>
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOMIC_RANK>
 __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const unsigned tile,
         const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const typename valtype<VB>::type *__restrict__ vals_in, typename valtype<VB>::type *__restrict__ vals_out,
@@ -163,16 +169,34 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
     for (int k = 0; k < KPT; ++k) {
         const bool valid = FULL || (wbase + k * kWave + lane < n);
         const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(key[k]) >> shift) & (RADIX - 1);
+        const unsigned long long act = FULL ? ~0ull : __ballot(valid);
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+        const bool uniform = __ballot(valid && d == d0) == act;      // small key ranges: constant upper digits
+        if constexpr (ATOMIC_RANK) {
+            // ONE LDS operation per key: the returned old value of the wave's digit counter IS the key's rank within
+            // (wave, digit), because gfx950 services the lanes of one LDS atomic that hit the same address in lane order
+            // (not an architectural promise: vexhip_sort verifies it on the device before it uses this path,
+            // tools/r02_lds_atomic_order.py: 0 violations in 9.4e8 returned values) and a wave's LDS operations execute in
+            // program order (k ascending = tile order).  The match-word scheme below needs five conflicting LDS operations
+            // per key and left the kernel LDS-bound (500 of 838 LDS-active cycles per wave were bank conflicts).
+            unsigned r;
+            if (uniform) {                                           // one counter bump instead of 64 same-address atomics
+                const unsigned prev = L.hist[wave][d0];
+                __builtin_amdgcn_wave_barrier();
+                r = prev + (unsigned)__popcll(act & lt_mask);
+                if (valid && (act & lt_mask) == 0) L.hist[wave][d0] = prev + (unsigned)__popcll(act);
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                r = valid ? atomicAdd(&L.hist[wave][d], 1u) : 0u;
+            }
+            rd[k] = valid ? (r | (d << 16)) : ~0u;
+        } else {
         // m = the real (non-padding) lanes of this wave holding the same digit.  Every lane ORs
         // its bit into the wave's mask word of its digit in LDS and reads the word back (three LDS
-        // operations instead of ~45 vector instructions for eight ballots and per-lane selects --
-        // the kernel is bound by vector-instruction issue, profiles/README.md); the group's first
-        // lane clears the word for the next key.  A wave whose keys agree on the digit (small key
-        // ranges: constant upper digits) skips LDS, where it would serialise 64 same-address atomics.
-        const unsigned long long act = FULL ? ~0ull : __ballot(valid);
+        // operations instead of ~45 vector instructions for eight ballots and per-lane selects);
+        // the group's first lane clears the word for the next key.
         unsigned long long m = act;
-        const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__ballot(valid && d == d0) != act) {
+        if (!uniform) {
             unsigned long long *word = s_match + wave * RADIX + d;
             if (valid) atomicOr(word, 1ull << lane);
             __builtin_amdgcn_wave_barrier();
@@ -195,6 +219,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
             rd[k] = ~0u;
         }
         __builtin_amdgcn_wave_barrier();
+        }
     }
     __syncthreads();
 
@@ -219,6 +244,9 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
         unsigned dstart = woff + inc - count;
         L.dstart[t] = dstart;
         L.gbase[t] = table[(size_t)t * nblocks + tile] - dstart;
+        // fold the digit's tile-local start into the per-wave offsets: one table read per key in the re-order below
+#pragma unroll
+        for (int w = 0; w < RW; ++w) L.hist[w][t] += dstart;
     }
     __syncthreads();
 
@@ -227,7 +255,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
     for (int k = 0; k < KPT; ++k) {
         if (FULL || rd[k] != ~0u) {
             const unsigned d = rd[k] >> 16;
-            const unsigned pos = L.dstart[d] + L.hist[wave][d] + (rd[k] & 0xffffu);
+            const unsigned pos = L.hist[wave][d] + (rd[k] & 0xffffu);
             s_keys[pos] = key[k];
             if constexpr (VB != 0) s_vals[pos] = val[k];
         }
@@ -257,7 +285,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
 // 8 waves per SIMD = two 1024-lane workgroups per CU (<= 64 VGPRs)
 // FULL = true: launched over the complete tiles (first_tile = their number); FULL = false: one
 // workgroup for the ragged last tile (first_tile = its index).
-template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL>
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOMIC_RANK>
 __global__ __launch_bounds__(RB, 8)
 void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
@@ -275,14 +303,14 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
         tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
         if (tile >= first_tile) return;
     }
-    scatter_tile<K, MODE, DESC, VB, KPT, FULL>(L, tile, keys_in, keys_out,
+    scatter_tile<K, MODE, DESC, VB, KPT, FULL, ATOMIC_RANK>(L, tile, keys_in, keys_out,
             reinterpret_cast<const VT *>(vals_in_), reinterpret_cast<VT *>(vals_out_), n, shift, nblocks, table);
 }
 
 template <typename K, int VB> constexpr int kpt_for() { return keys_per_lane((int)sizeof(K), VB); }
 
 template <typename K, int MODE, bool DESC, int VB>
-int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp) {
+int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp, bool atomic_rank) {
     constexpr int KPT = kpt_for<K, VB>();
     constexpr int TILE = RB * KPT;
     const unsigned nblocks = (unsigned)((n + TILE - 1) / TILE);
@@ -295,16 +323,18 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
     const int vec_ok = ((reinterpret_cast<uintptr_t>(keys) & 15) == 0) && ((reinterpret_cast<uintptr_t>(keys_tmp) & 15) == 0);
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        radix_hist_kernel<K, MODE, DESC, KPT><<<nblocks, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
+        radix_hist_kernel<K, MODE, DESC, KPT><<<(nblocks + 7) / 8 * 8, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
         VEXHIP_LAUNCH_CHECK();
         if (int rc = scan_exclusive_u32_tmp(s, table, table, tn, scan_tmp)) return rc;
         const unsigned nfull = (unsigned)(n / TILE);
         if (nfull) {
-            radix_scatter_kernel<K, MODE, DESC, VB, KPT, true><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            if (atomic_rank) radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
             VEXHIP_LAUNCH_CHECK();
         }
         if (nfull < nblocks) {
-            radix_scatter_kernel<K, MODE, DESC, VB, KPT, false><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            if (atomic_rank) radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, true><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            else radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, false><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
             VEXHIP_LAUNCH_CHECK();
         }
         std::swap(src, dst);
@@ -316,12 +346,54 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
 }
 
 template <typename K, int MODE>
-int sort_dispatch(hipStream_t s, int desc, int vb, void *keys, void *keys_tmp, void *vals, void *vals_tmp, int64_t n, void *tmp) {
-#define GO(DESC, VB) return sort_passes<K, MODE, DESC, VB>(s, (K *)keys, (K *)keys_tmp, vals, vals_tmp, n, (unsigned *)tmp)
+int sort_dispatch(hipStream_t s, int desc, int vb, void *keys, void *keys_tmp, void *vals, void *vals_tmp, int64_t n, void *tmp, bool atomic_rank) {
+#define GO(DESC, VB) return sort_passes<K, MODE, DESC, VB>(s, (K *)keys, (K *)keys_tmp, vals, vals_tmp, n, (unsigned *)tmp, atomic_rank)
     if (desc) { if (vb == 0) GO(true, 0); if (vb == 4) GO(true, 4); if (vb == 8) GO(true, 8); }
     else      { if (vb == 0) GO(false, 0); if (vb == 4) GO(false, 4); if (vb == 8) GO(false, 8); }
 #undef GO
     return fail(__FILE__, __LINE__, "value_bytes must be 0, 4 or 8");
+}
+
+// ---- does this device service same-address lanes of one LDS atomic in lane order?  (checked once per device) ----
+__global__ __launch_bounds__(1024)
+void lds_atomic_order_kernel(unsigned seed, int rounds, unsigned *violations) {
+    __shared__ unsigned cnt[RW][RADIX];
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+    unsigned bad = 0;
+    unsigned h = seed ^ (blockIdx.x * 0x9E3779B9u) ^ (t * 0x85EBCA6Bu);
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = t; i < RW * RADIX; i += RB) (&cnt[0][0])[i] = 0;
+        __syncthreads();
+        h = h * 1664525u + 1013904223u;
+        const unsigned nd = 1u << (r % 9);                        // 1 .. 256 distinct digits
+        const unsigned d = (h >> 16) & (nd - 1);
+        const unsigned old = atomicAdd(&cnt[wave][d], 1u);
+        unsigned expect = 0;
+        for (int l = 0; l < kWave; ++l) { const unsigned dl = __shfl(d, l, 64); if (l < lane && dl == d) ++expect; }
+        if (old != expect) ++bad;
+        __syncthreads();
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+int g_sort_rank = -1;               // -1: decide by the self-test; 0: match words; 1: atomic ranks (A/B)
+
+int atomic_rank_ok(int dev, hipStream_t s, bool *ok) {
+    static int verdict[64];          // 0 unknown, 1 in order, 2 not
+    if (dev < 0 || dev >= 64) { *ok = false; return 0; }
+    if (!verdict[dev]) {
+        unsigned *d = nullptr, h = 1;
+        VEXHIP_TRY(hipMalloc(&d, sizeof(unsigned)));
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned), s);
+        if (e == hipSuccess) { lds_atomic_order_kernel<<<512, RB, 0, s>>>(12345u, 72, d); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(d);
+        VEXHIP_TRY(e);
+        verdict[dev] = h == 0 ? 1 : 2;
+    }
+    *ok = verdict[dev] == 1;
+    return 0;
 }
 
 } // namespace
@@ -330,6 +402,8 @@ int sort_dispatch(hipStream_t s, int desc, int vb, void *keys, void *keys_tmp, v
 using namespace vexhip;
 
 extern "C" {
+
+int vexhip_sort_set_rank(int mode) { g_sort_rank = mode; return 0; }
 
 size_t vexhip_sort_tmp_bytes(int key_dtype, int64_t n) {
     (void)key_dtype;
@@ -349,13 +423,15 @@ int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
     VEXHIP_REQUIRE(value_bytes == 0 || (vals && vals_tmp), "NULL value buffers");
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
+    bool ar = g_sort_rank == 1;
+    if (g_sort_rank < 0) if (int rc = atomic_rank_ok(dev, s, &ar)) return rc;
     switch (key_dtype) {
-        case VEXHIP_U32: return sort_dispatch<unsigned, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
-        case VEXHIP_I32: return sort_dispatch<unsigned, KEY_SIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
-        case VEXHIP_F32: return sort_dispatch<unsigned, KEY_FLOAT>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
-        case VEXHIP_U64: return sort_dispatch<unsigned long long, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
-        case VEXHIP_I64: return sort_dispatch<unsigned long long, KEY_SIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
-        case VEXHIP_F64: return sort_dispatch<unsigned long long, KEY_FLOAT>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp);
+        case VEXHIP_U32: return sort_dispatch<unsigned, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
+        case VEXHIP_I32: return sort_dispatch<unsigned, KEY_SIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
+        case VEXHIP_F32: return sort_dispatch<unsigned, KEY_FLOAT>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
+        case VEXHIP_U64: return sort_dispatch<unsigned long long, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
+        case VEXHIP_I64: return sort_dispatch<unsigned long long, KEY_SIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
+        case VEXHIP_F64: return sort_dispatch<unsigned long long, KEY_FLOAT>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
     }
     return fail(__FILE__, __LINE__, "unknown key dtype");
 }
