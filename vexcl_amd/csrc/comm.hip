@@ -456,7 +456,13 @@ int vexhip_dist_spmv_create(vexhip_comm *hc, int dtype, int64_t rows, const vexh
     }
     if (ts != nsend || tr != nghost) { delete D; return fail(__FILE__, __LINE__, "exchange counts do not add up to the buffer sizes"); }
     hipError_t e = hipSetDevice(D->dev);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // highest priority: the pack kernel and the RCCL kernels are small and must not queue behind the 32 768
+        // workgroups of the local part they are meant to overlap with
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        e = hipStreamCreateWithPriority(&D->comm_stream, hipStreamNonBlocking, hi);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->packed, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->received, hipEventDisableTiming);
     if (e != hipSuccess) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return check(e, __FILE__, __LINE__); }
