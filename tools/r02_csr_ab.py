@@ -1,6 +1,7 @@
 """Round 2 A/B of the CSR kernel at 512^3 (Poisson and variable coefficients): first form (x gathered in stream order, products staged in LDS;
-variant word bit 2 set) against the second form ((col, val) staged in LDS, every lane gathers along its own row).
-Interleaved, bit-identity checked.  Output: gpurun_out/r02_csr_ab.json"""
+variant word bit 2 set) against the second form ((col, val) staged in LDS with all loads of a tile in flight, every lane gathers along
+its own row).  Interleaved, bit-identity checked.  The variants tried on the way (tile sizes, G row blocks per workgroup with the next
+tile prefetched) are recorded in profiles/r02_csr_ab_variants.log and in the comment above csr_stream2_kernel.  Output: gpurun_out/r02_csr_ab.json"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +9,24 @@ from vexcl_amd import ops, lib
 L = lib(); dev = torch.device("cuda:0")
 n = 512; N = n ** 3
 out = {}
+# the second form on irregular matrices first (empty rows, rows longer than a tile, ragged last block), against the first form: empty rows, rows longer than a tile, ragged last block
+g = torch.Generator(device="cpu"); g.manual_seed(7)
+for rows, longrow in ((1, 0), (255, 0), (1000, 5000), (70001, 2500), (300000, 0)):
+    cnt = torch.randint(0, 12, (rows,), generator=g); cnt[torch.rand(rows, generator=g) < 0.2] = 0
+    if longrow: cnt[rows // 2] = longrow
+    p_ = torch.zeros(rows + 1, dtype=torch.int64); p_[1:] = torch.cumsum(cnt, 0)
+    nz = int(p_[-1]); m = rows + 13
+    c_ = torch.randint(0, m, (nz,), generator=g).to(torch.int32).to(dev); v_ = torch.randn(nz, generator=g, dtype=torch.float64).to(dev)
+    p_ = p_.to(torch.int32).to(dev); x_ = torch.randn(m, generator=g, dtype=torch.float64).to(dev)
+    for app in (False, True):
+        ya = torch.full((rows,), 3.0, dtype=torch.float64, device=dev)
+        L.spmv_csr_set_variant(4); ops.spmv_csr(p_, c_, v_, x_, ya, alpha=0.5, append=app)
+        yb = torch.full((rows,), 3.0, dtype=torch.float64, device=dev)
+        L.spmv_csr_set_variant(0); ops.spmv_csr(p_, c_, v_, x_, yb, alpha=0.5, append=app)
+        ok = torch.equal(ya, yb)
+        print("irregular rows=%d long=%d append=%s identical=%s" % (rows, longrow, app, ok), flush=True)
+        assert ok
+L.spmv_csr_set_variant(-1)
 for name, gen in (("poisson", ops.poisson3d), ("variable", ops.diffusion3d)):
     ptr, col, val = gen(n, device=dev)
     nnz = col.numel()

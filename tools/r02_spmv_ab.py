@@ -57,5 +57,32 @@ for name, kw, bytes_entry in (("sell8v", dict(), 2), ("sell8", dict(value_codes=
     del S
     torch.cuda.empty_cache()
 L.spmv_sell8_set_variant(0)
+
+# compressed-stencil product (vex::SpMatCCSR): 2 unique rows; pair form (0) against the first form with 2 rows per lane
+import ctypes
+r_in = (n // 2) * (n * n + n + 1)
+b0, e0 = int(ptr[r_in]), int(ptr[r_in + 1])
+offs = torch.cat([col[int(ptr[0]):int(ptr[1])].long() - 0, col[b0:e0].long() - r_in]).to(torch.int32).contiguous()
+vals = torch.cat([val[int(ptr[0]):int(ptr[1])], val[b0:e0]]).contiguous()
+rowt = torch.tensor([0, int(ptr[1]) - int(ptr[0]), int(ptr[1]) - int(ptr[0]) + e0 - b0], dtype=torch.int32, device=dev)
+idx = ((ptr[1:] - ptr[:-1]) > 1).to(torch.int32).contiguous()
+yref = torch.empty_like(x); y = torch.empty_like(x)
+ops.SpMat(ptr, col, val).apply(x, yref)
+pp = lambda t: ctypes.c_void_p(t.data_ptr())
+cur = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def ccsr(yy): L.spmv_ccsr_f64(0, cur, N, 1.0, 0, pp(idx), 2, pp(rowt), pp(offs), pp(vals), int(rowt[2]), n * n, pp(x), pp(yy))
+best = {}
+for rnd in range(3):
+    for rpl in (2, 0):
+        L.spmv_ccsr_set_rows_per_lane(rpl)
+        ms = timed(lambda: ccsr(y), 30)
+        k = "rows_per_lane_%d" % rpl if rpl else "pair_form"
+        best.setdefault(k, {"ms": [], "identical": True})
+        best[k]["ms"].append(round(ms, 4)); best[k]["identical"] &= bool(torch.equal(y, yref))
+for k, r in best.items():
+    r["best_ms"] = min(r["ms"])
+    print("ccsr    %-16s %s best %.4f ms identical %s" % (k, r["ms"], r["best_ms"], r["identical"]), flush=True)
+out["results"]["ccsr"] = best
+L.spmv_ccsr_set_rows_per_lane(0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/r02_spmv_ab.json", "w"), indent=1)

@@ -96,7 +96,9 @@ void ccsr_kernel(long long n, long long nblocks, V alpha, int append,
 // (sell8.hip, "PAIR kernels": 0.90 -> 0.80 ms) this one is NOT bound by instruction issue: with 20 bytes of HBM
 // traffic per row it runs at the same ~155-168 G rows/s as the value-coded SELL product, whatever the geometry
 // (1, 2, 4, 8 rows per lane, pairs, 64- or 32-bit strip arithmetic); what holds both at that row rate is not
-// identified (not TCP accesses, L2 or HBM bytes: profiles/r02_sq_summary.txt).
+// identified (not TCP accesses, L2 or HBM bytes: profiles/r02_sq_summary.txt; not the length of the dependent chain
+// either: loading the rows' table positions BEFORE the tables are staged, so that both are in flight together, gives
+// 0.864 against 0.867 ms, tools/r02_spmv_ab.py).
 // Entries are taken eight at a time: table reads, gathers, then the fold in row order (same order as the reference's
 // loop, ccsr.hpp:184-200): bit-identical to the kernel above.
 template <typename V, bool LDS>

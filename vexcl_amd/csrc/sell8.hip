@@ -361,11 +361,15 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
     typedef typename vec2<V>::type V2;
     __shared__ int s_delta[256];
     __shared__ V s_value[VCODED ? 256 : 1];
-    // The slice's own loads are issued BEFORE the tables are staged: they do not depend on them, and the chain
-    // tables -> barrier -> codes -> look-ups -> gathers -> store of a workgroup is what bounds these products (rows in
-    // flight per CU / length of that chain: DESIGN.md 3.0): 0.808 -> 0.793 ms.  Tried and dropped: tables of <= 64
-    // entries kept in registers and looked up with lane permutes (no LDS table, no barrier): 0.819 ms -- ds_bpermute
-    // costs more than the LDS reads it replaces.
+    // Order of the loads.  The code words are written first in this source, but they are only used after the early
+    // return below, so the compiler SINKS them there: the machine code stages the tables, passes the barrier and only then
+    // loads the slice's codes.  That order is the fast one (tools/r02_spmv_ab.py, profiles/r02_spmv_ab_staging_order.json,
+    // same box, value codes / stored values): 0.789 / 1.868 ms as compiled; 0.829 / 1.893 ms with every load issued before
+    // the barrier (no early return: codes and tables in flight together); 0.825 / 1.902 ms with a private 64-entry table
+    // per wave and no barrier at all.  Shortening the chain tables -> barrier -> codes -> look-ups -> gathers -> store does
+    // NOT help: the streaming loads issued early sit in the same queues the x gathers need.  (The CSR kernel, which is
+    // bound by its stream, gains from the opposite: spmv.hip, second form.)  Also tried and dropped: tables of <= 64 entries
+    // kept in registers and looked up with lane permutes (0.819 ms -- ds_bpermute costs more than the LDS reads it replaces).
     const long long s = traversal_block(trav, nslices);
     const long long sl = s < 0 ? 0 : s;                       // holes of the strip order: load slice 0, store nothing
     const int t = threadIdx.x;

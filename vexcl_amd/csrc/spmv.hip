@@ -155,16 +155,20 @@ void csr_stream_kernel(long long n, long long nblocks, V alpha, int append,
 // j the lanes of a wave gather x[col(row + lane, j)], which for a banded matrix are adjacent elements (8-9 lines per
 // instruction, the ELL pattern), up to eight entries in flight per lane.  The row is folded in the same loop: no
 // product staging.  Same products, same order: bit-identical.  24 KiB of LDS per workgroup (6 workgroups per CU).
-// 512^3: 2.74-2.89 -> 2.61 ms (66 % of 8 TB/s by CSR bytes).  Tried and dropped: half the lanes folding two rows each
-// with 16-byte pair gathers (3.42 ms: the fold becomes the serial part of every workgroup).
-constexpr int CSR2_TILE = 2048;
-
-template <typename V, typename I, bool SWZ>
+// 512^3, same box: first form 2.86 ms, this one 2.48 ms (70 % of 8 TB/s by CSR bytes); of that, 2.75 -> 2.56 ms came from
+// issuing all loads of a tile before the first LDS write (see the staging loop).  Tried and dropped
+// (tools/r02_csr_ab.py, profiles/r02_csr_ab.json): half the lanes folding two rows each with 16-byte pair gathers (3.42 ms:
+// the fold becomes the serial part of every workgroup); tiles of 1856 / 1920 entries for 7 instead of 6 workgroups per CU
+// (no change) and 3072 (4 per CU: 2.65 ms); a workgroup that owns G consecutive row blocks and keeps the next tile's
+// loads in flight while it folds the current one (G = 1 2.56, 2 2.58, 3 2.67, 4 2.69 ms: a workgroup's span of the
+// traversal grows with G and the x planes fall out of its XCD's L2).
+template <typename V, typename I, bool SWZ, int CSR2_TILE>
 __global__ __launch_bounds__(CSR_BLOCK)
 void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
         const I *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
         const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
 {
+    constexpr int CSR2_GROUPS = (CSR2_TILE + 4 * CSR_BLOCK - 1) / (4 * CSR_BLOCK);
     __shared__ V s_val[CSR2_TILE];
     __shared__ I s_col[CSR2_TILE];
     const long long lb = (trav.chunk > 0 || trav.order) ? traversal_block(trav, nblocks) : logical_block<SWZ>(nblocks);
@@ -179,19 +183,30 @@ void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
     V sum = 0;
     for (long long tb = base & ~3ll; tb < end; tb += CSR2_TILE) {
         const long long te = (end - tb > CSR2_TILE) ? tb + CSR2_TILE : end;
-        // stage the tile: 4 entries per lane per step, whole groups with 16-byte loads
-#pragma unroll 2
-        for (long long k = tb + 4 * t; k < te; k += 4 * CSR_BLOCK) {
-            const int o = (int)(k - tb);
-            if (te - k >= 4) {
-                I c[4]; V v[4];
-                load4<false>(col + k, c); load4<false>(val + k, v);
+        // stage the tile: 2 groups of 4 entries per lane, whole groups with 16-byte loads.  ALL loads of the tile are
+        // issued before the first LDS write (a loop that loads and writes group after group costs the workgroup one
+        // more memory round trip: 2.75 -> 2.56 ms at 512^3 on the same box, tools/r02_csr_ab.py)
+        I pc[CSR2_GROUPS][4]; V pv[CSR2_GROUPS][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { s_col[o + q] = c[q]; s_val[o + q] = v[q]; }
-            } else {
-                for (long long q = k; q < te; ++q) { s_col[(int)(q - tb)] = col[q]; s_val[(int)(q - tb)] = val[q]; }
+        for (int u = 0; u < CSR2_GROUPS; ++u) {
+            const long long k = tb + 4 * t + u * (4 * CSR_BLOCK);
+            if (te - k >= 4) { load4<false>(col + k, pc[u]); load4<false>(val + k, pv[u]); }
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pc[u][q] = 0; pv[u][q] = V(0);
+                    if (k + q < te) { pc[u][q] = col[k + q]; pv[u][q] = val[k + q]; }
+                }
             }
         }
+#pragma unroll
+        for (int u = 0; u < CSR2_GROUPS; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((u + 1) * (4 * CSR_BLOCK) <= CSR2_TILE || 4 * t + u * (4 * CSR_BLOCK) + q < CSR2_TILE) {
+                    s_col[4 * t + u * (4 * CSR_BLOCK) + q] = pc[u][q];
+                    s_val[4 * t + u * (4 * CSR_BLOCK) + q] = pv[u][q];
+                }
         __syncthreads();
         // every lane folds the part of its row that lies in this tile, up to 8 entries in flight
         const int lo = (int)((my_lo > tb ? my_lo : tb) - tb);
@@ -556,8 +571,8 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
 #define LAUNCH(NT, SWZ) csr_stream_kernel<V, I, NT, SWZ><<<(unsigned)grid, CSR_BLOCK, 0, s>>>( \
         n, nb, alpha, append, ptr, col, val, x, y, order)
     if (!(variant & 4)) {             // second form (default)
-        if (swz) csr_stream2_kernel<V, I, true><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
-        else csr_stream2_kernel<V, I, false><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
+        if (swz) csr_stream2_kernel<V, I, true, 2048><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
+        else csr_stream2_kernel<V, I, false, 2048><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
     }
     else if (nt) { if (swz) LAUNCH(true, true); else LAUNCH(true, false); }
     else    { if (swz) LAUNCH(false, true); else LAUNCH(false, false); }
