@@ -120,6 +120,23 @@ extern "C" __global__ void __launch_bounds__(256) k(long long n, long long ns, u
         unsigned long long lo = ((unsigned long long)r.y << 32) | r.x, hi = ((unsigned long long)r.w << 32) | r.z;
         xv[j][0] = __builtin_bit_cast(double, lo); xv[j][1] = __builtin_bit_cast(double, hi);
       } }
+#elif GATHER == 9
+    // x for EVERY diagonal of the table (7 here: uniform offsets, no dependence on the slice's codes) loaded up front with
+    // 16-byte loads, parked in a lane-private LDS slot (no barrier) and picked by code afterwards
+    { __shared__ d2 xs[W][256];
+      d2 xr[W];
+      #pragma unroll
+      for (int j = 0; j < W; ++j) __builtin_memcpy(&xr[j], x + (i + deltas[j]), 16);
+      #pragma unroll
+      for (int j = 0; j < W; ++j) xs[j][t] = xr[j];
+      #pragma unroll
+      for (int j = 0; j < W; ++j)
+      #pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
+          const double v = ((const double *)&xs[code < 254u ? code : 0][t])[q];
+          xv[j][q] = code < 254u ? v : 0.0;
+        } }
 #elif GATHER == 5
     { const d2 p = *(const d2 *)(x + i);
       const double left = __shfl_up(p.y, 1, 64), right = __shfl_down(p.x, 1, 64);
@@ -286,6 +303,8 @@ variants = [
     ("seven 16-byte raw buffer loads", dict(GATHER=8)),
     ("seven 16-byte raw buffer loads, codes 2 x 16 B", dict(GATHER=8, CODES=2)),
     ("+-1 taps by lane shuffle, four far gathers, codes 2 x 16 B", dict(GATHER=5, CODES=2)),
+    ("x of all 7 table diagonals loaded up front (16-byte, independent of the codes), picked by code via lane-private LDS", dict(GATHER=9)),
+    ("x of all 7 table diagonals up front, no store", dict(GATHER=9, STORE=1)),
 ]
 res = []
 mods = []

@@ -92,13 +92,12 @@ void ccsr_kernel(long long n, long long nblocks, V alpha, int append,
 // Pair form (round 2, the default): a lane owns rows 2t and 2t+1 of a 512-row block and reads x for both with ONE
 // 16-byte load per stencil entry when the two rows use the same unique row (idx equal: everywhere but next to a
 // boundary); otherwise each row walks its own entries with 8-byte loads.  Half the vector-memory instructions of the
-// kernel above (4.5 instead of 9 per row).  Measured at 512^3: 0.89 -> 0.87 ms -- unlike the SELL products
-// (sell8.hip, "PAIR kernels": 0.90 -> 0.80 ms) this one is NOT bound by instruction issue: with 20 bytes of HBM
-// traffic per row it runs at the same ~155-168 G rows/s as the value-coded SELL product, whatever the geometry
-// (1, 2, 4, 8 rows per lane, pairs, 64- or 32-bit strip arithmetic); what holds both at that row rate is not
-// identified (not TCP accesses, L2 or HBM bytes: profiles/r02_sq_summary.txt; not the length of the dependent chain
-// either: loading the rows' table positions BEFORE the tables are staged, so that both are in flight together, gives
-// 0.864 against 0.867 ms, tools/r02_spmv_ab.py).
+// kernel above (4.5 instead of 9 per row).  Measured at 512^3 (tools/r02_spmv_ab.py): 0.89 -> 0.87 ms with the gathers
+// under per-lane conditions, 0.83 ms with unconditional gathers (see below).  With 20 bytes of HBM traffic per row this
+// product is not bound by HBM; the ablation of the value-coded SELL product (profiles/r02_sell8v_ablation.json) prices
+// its ingredients: x and y streamed once 0.33 ms, seven 16-byte gathers +0.27 ms, a per-row code stream the gathers
+// depend on +0.16 ms -- the position word here plays the role of the codes there.  Loading the positions BEFORE the
+// tables are staged, so that both are in flight together, changes nothing (0.864 against 0.867 ms).
 // Entries are taken eight at a time: table reads, gathers, then the fold in row order (same order as the reference's
 // loop, ccsr.hpp:184-200): bit-identical to the kernel above.
 template <typename V, bool LDS>
@@ -127,6 +126,11 @@ void ccsr_pair_kernel(long long n, long long nblocks, V alpha, int append,
         const uint2 pp = *reinterpret_cast<const uint2 *>(idx + i);
         p0 = pp.x; p1 = pp.y;
     } else { p0 = idx[i]; p1 = two ? idx[i + 1] : p0; }
+    // Gathers are UNCONDITIONAL inside a wave-uniform branch: a load under a per-lane condition (`if (j + k < end)`) is
+    // compiled as an exec-masked block with a full vmcnt(0) wait behind it, which serialises the gathers of a row (one
+    // memory round trip each; that was the 0.87 ms of the first version of this kernel).  Lanes without an entry k read
+    // x[i] (a valid address: the operator is square) and discard it; their table value is 0 and the sum is kept by a
+    // select, so NaN / Inf in x cannot leak into rows that do not reference them.
     V s0 = 0, s1 = 0;
     if (p0 == p1 && two) {
         unsigned j = LDS ? s_row[p0] : row[p0];
@@ -136,17 +140,22 @@ void ccsr_pair_kernel(long long n, long long nblocks, V alpha, int append,
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const bool in = j + k < end;
-                c[k] = in ? (LDS ? s_col[j + k] : col[j + k]) : 0;
-                v[k] = in ? (LDS ? s_val[j + k] : val[j + k]) : V(0);
+                const unsigned e = in ? j + k : j;
+                c[k] = LDS ? s_col[e] : col[e];
+                v[k] = LDS ? s_val[e] : val[e];
+                c[k] = in ? c[k] : 0;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {          // a load no lane of the wave needs is not issued
                 xv[k].x = V(0); xv[k].y = V(0);
-                if (j + k < end) __builtin_memcpy(&xv[k], x + (i + c[k]), sizeof(V2));
+                if (__builtin_amdgcn_ballot_w64(j + k < end) != 0) __builtin_memcpy(&xv[k], x + (i + c[k]), sizeof(V2));
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (j + k < end) { s0 += v[k] * xv[k].x; s1 += v[k] * xv[k].y; }
+            for (int k = 0; k < 8; ++k) {
+                const V t0 = s0 + v[k] * xv[k].x, t1 = s1 + v[k] * xv[k].y;
+                const bool in = j + k < end;
+                s0 = in ? t0 : s0; s1 = in ? t1 : s1;
+            }
         }
     } else {
 #pragma unroll
@@ -161,13 +170,15 @@ void ccsr_pair_kernel(long long n, long long nblocks, V alpha, int append,
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const bool in = j + k < end;
-                    c[k] = in ? (LDS ? s_col[j + k] : col[j + k]) : 0;
-                    v[k] = in ? (LDS ? s_val[j + k] : val[j + k]) : V(0);
+                    const unsigned e = in ? j + k : j;
+                    c[k] = LDS ? s_col[e] : col[e];
+                    v[k] = LDS ? s_val[e] : val[e];
+                    c[k] = in ? c[k] : 0;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { xv[k] = V(0); if (j + k < end) xv[k] = x[i + q + c[k]]; }
+                for (int k = 0; k < 8; ++k) { xv[k] = V(0); if (__builtin_amdgcn_ballot_w64(j + k < end) != 0) xv[k] = x[i + q + c[k]]; }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) if (j + k < end) s += v[k] * xv[k];
+                for (int k = 0; k < 8; ++k) { const V t = s + v[k] * xv[k]; s = (j + k < end) ? t : s; }
             }
             if (q) s1 = s; else s0 = s;
         }
