@@ -177,8 +177,11 @@ void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
     const long long r0 = lb * CSR_BLOCK;
     const long long rows_here = (n - r0 < CSR_BLOCK) ? (n - r0) : CSR_BLOCK;
     const long long base = ptr[r0], end = ptr[r0 + rows_here];            // uniform addresses: scalar loads
-    long long my_lo = 0, my_hi = 0;
-    if (t < rows_here) { my_lo = ptr[r0 + t]; my_hi = ptr[r0 + t + 1]; }
+    // this lane's row bounds: loaded unconditionally from a clamped row (a load under `if (t < rows_here)` is an exec-
+    // masked block that ends in a full vmcnt(0) wait -- one more round trip before the tile loads can be issued)
+    // -- and used only behind the barrier (the empty asm keeps the compiler from waiting for them any earlier)
+    const long long my_row = t < rows_here ? r0 + t : r0 + rows_here - 1;
+    I raw_lo = ptr[my_row], raw_hi = ptr[my_row + 1];
 
     V sum = 0;
     for (long long tb = base & ~3ll; tb < end; tb += CSR2_TILE) {
@@ -209,6 +212,8 @@ void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
                 }
         __syncthreads();
         // every lane folds the part of its row that lies in this tile, up to 8 entries in flight
+        asm volatile("" : "+v"(raw_lo), "+v"(raw_hi));
+        const long long my_lo = t < rows_here ? (long long)raw_lo : 0, my_hi = t < rows_here ? (long long)raw_hi : 0;
         const int lo = (int)((my_lo > tb ? my_lo : tb) - tb);
         const int hi = (int)((my_hi < te ? my_hi : te) - tb);
         for (int j = lo; j < hi; j += 8) {
@@ -230,7 +235,7 @@ void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
         }
         if (te < end) __syncthreads();
     }
-    if (t < rows_here && !(append && my_lo == my_hi)) {
+    if (t < rows_here && !(append && raw_lo == raw_hi)) {
         V r = alpha * sum;
         if (append) r = y[r0 + t] + r;
         y[r0 + t] = r;
