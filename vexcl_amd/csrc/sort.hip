@@ -262,6 +262,9 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
     }
     __syncthreads();
 
+    // Tried (round 2, tools/r02_sort_ab.py): a lane writing 4 consecutive tile positions with ONE 16-byte store when they lie
+    // in one run (15 of 16 groups; 3 store instructions per lane instead of 12): 10.93 against 10.20 ms -- the runs start at
+    // arbitrary 4-byte offsets and the wide stores straddle cache lines.
     if constexpr (FULL) {
 #pragma unroll 4
         for (int k = 0; k < KPT; ++k) {
