@@ -70,7 +70,7 @@ def cpu_baseline(grid, seconds):
                       "arrays first-touched in parallel by the chunks' owners" % (r["products"], g, N, nnz, per * r["products"])}
 
 
-def independent_product(torch, x, n, variable_seed=None):
+def independent_product(torch, x, n, variable_seed=None, lazy=False):
     """y = A*x for the Poisson matrix WITHOUT the matrix: boundary rows are identity, interior rows the 7-point stencil
     (examples/benchmark.cpp:364-415), evaluated with torch slicing.  Also returns sum |terms| for the tolerance."""
     h2i = float((n - 1) * (n - 1))
@@ -85,6 +85,8 @@ def independent_product(torch, x, n, variable_seed=None):
         acc = acc - h2i * t
         mag = mag + h2i * t.abs()
     Y[1:-1, 1:-1, 1:-1] = acc
+    if lazy:                                   # device scalar, no host synchronisation (read back by the caller later)
+        return y, mag.sum() + x.abs().sum()
     bound = float(mag.sum()) + float(x.abs().sum())
     return y, bound
 
@@ -226,6 +228,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (debug: exercises the N>1 path on a 1-GPU box; needs --backend gloo)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (CSR-bytes kernels, variable coefficients, C++ front end, elementwise, reduce, scan, sort)")
     ap.add_argument("--no-native", action="store_true", help="N > 1: keep the torch.distributed transport (do not try the C++ product step)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the ~3 s back-to-back run of the product after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic = null)")
     args = ap.parse_args()
 
@@ -312,10 +315,23 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # ---- the result is checked inside the run: an evaluation of the stencil that never touches the matrix.  Its kernels are
+    #      QUEUED here, ahead of the warm-up, and their three scalars are read back after the timed region.  Where it stands
+    #      matters for the clock: after >= 5 ms without work the next ~20 launches of this product run up to 12 % slow
+    #      (tools/r02_ramp.py), and with the driver's W = 5, K = 20 the whole timed region would sit in that transient; this
+    #      way the device goes from the set-up kernels through the check straight into the warm-up without draining.
+    def queue_check():
+        yref, bound_dev = independent_product(torch, x, n, lazy=True)
+        return ((y - yref).abs().max(), yref.sum(dtype=torch.float64), bound_dev)
+
+    check_dev = None
+    if single:
+        # The first evaluation only loads torch's kernels and fills its allocator's cache (both stall the host for
+        # milliseconds at a time: the device drains); the second one, which is the check, then runs without a gap.
         step()
-    torch.cuda.synchronize()
-    barrier()
+        queue_check()
+        step()
+        check_dev = queue_check()
 
     # HIP events on the stream the kernels are launched on (torch's current stream)
     import ctypes
@@ -324,6 +340,8 @@ def main():
     L.event_create(local_rank, 1, ctypes.byref(e0))
     L.event_create(local_rank, 1, ctypes.byref(e1))
 
+    for _ in range(args.warmup):
+        step()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -346,18 +364,30 @@ def main():
     per_step = elapsed / args.steps
     kern_s = ms.value / 1e3 / args.steps         # average launch duration of the product on this rank
 
-    # ---- the result is checked inside the run: an evaluation of the stencil that never touches the matrix
     check = None
     if single:
-        yref, bound = independent_product(torch, x, n)
-        err = float((y - yref).abs().max())
-        sum_ref = float(yref.sum(dtype=torch.float64))
+        err, sum_ref, bound = (float(v) for v in check_dev)
         tol = 1e-10 * bound
         check = {"sum_y": checksum, "sum_y_independent": sum_ref, "max_abs_err": err,
                  "tolerance": "1e-10 * sum|terms| = %.3e (SURVEY 8c)" % tol,
-                 "what": "torch slicing of x on the n^3 grid, no matrix involved"}
+                 "what": "torch slicing of x on the n^3 grid, no matrix involved; evaluated before the warm-up, read back after the timed region"}
         assert abs(checksum - sum_ref) <= tol and err <= tol, "product does not match the independent stencil evaluation: %r" % check
-        del yref
+
+    # ---- the same product launched back to back for ~3 s: a cross-check of the K-step figure against a long run (and GPU
+    #      activity an outside sampler of the device can see; the timed region above lasts K x 0.8 ms)
+    sustained = None
+    if single and not args.no_sustained:
+        nsoak = min(6000, max(args.steps, int(3.0 / per_step)))
+        L.event_record(local_rank, e0, stream)
+        for _ in range(nsoak):
+            step()
+        L.event_record(local_rank, e1, stream)
+        torch.cuda.synchronize()
+        ms2 = ctypes.c_float()
+        L.event_elapsed_ms(local_rank, e0, e1, ctypes.byref(ms2))
+        sustained = {"steps": nsoak, "ms_per_step": round(ms2.value / nsoak, 5),
+                     "gflops": round(2.0 * nnz_total / (ms2.value / nsoak) / 1e6, 1),
+                     "what": "the same product launched back to back after the timed region (HIP events on the launch stream)"}
 
     if rank == 0:
         nnz_rank = L.poisson3d_strip_nnz(n, r0, r1)
@@ -402,6 +432,8 @@ def main():
                          "traffic": None,
                          "avg_launch_ms": round(kern_s * 1e3, 5)},
         }
+        if sustained:
+            out["sustained"] = sustained
         if world > 1:
             out["config"]["exchange_bytes_per_rank"] = A.exchange_bytes()
             out["config"]["exchange_transport"] = transport
