@@ -92,8 +92,12 @@ def independent_product(torch, x, n, variable_seed=None, lazy=False):
 
 
 def timed_events(torch, fn, reps):
-    fn(); torch.cuda.synchronize()
+    """Average duration of fn over `reps` launches, after ~30 ms of the same launches: these rows run after host-side work
+    (matrix set-up, subprocesses), and after >= 5 ms without work the first ~16 ms of launches are up to 12 % slow."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+    for _ in range(min(200, int(30.0 / max(e0.elapsed_time(e1), 0.05)))):
+        fn()
     e0.record()
     for _ in range(reps):
         fn()
