@@ -29,6 +29,32 @@ template <> struct vec2<float> { typedef float2v type; };
 
 template <typename V> struct rhs_set { const V *x[MAX_NR]; V *y[MAX_NR]; };
 
+// x for the two rows of a lane in ELL column j of a diagonal-coded slice, as the single-vector pair kernels read it
+// (sell8.hip, "PAIR kernels"): ONE 16-byte load when both rows sit on the same diagonal or one of them is padding that
+// allows it (code 255), an 8-byte load per real entry otherwise; padding reads as 0.  c0 / c1: the two rows' codes,
+// d: s_delta[c0 is real ? c0 : c1], looked up once per column by the caller.
+template <typename V>
+__device__ __forceinline__ void gather_pair(const V *__restrict__ x, long long i, unsigned c0, unsigned c1, int d,
+        const int *s_delta, const int *__restrict__ safe, V &x0, V &x1)
+{
+    typedef typename vec2<V>::type V2;
+    const bool m0 = c0 < PAD8, m1 = c1 < PAD8;
+    const bool pair = (c0 == c1) || (c0 == 255u && m1) || (c1 == 255u && m0);
+    const bool use16 = pair && (m0 || m1);
+    V2 p = {V(0), V(0)};
+    if (__builtin_amdgcn_ballot_w64(use16) != 0) {          // skipped only when no lane of the wave has a pair here
+        const V *px = use16 ? x + (i + d) : reinterpret_cast<const V *>(safe);
+        __builtin_memcpy(&p, px, sizeof(V2));
+    }
+    x0 = p.x; x1 = p.y;
+    if (!pair) {
+        if (m0) x0 = x[i + s_delta[c0]];
+        if (m1) x1 = x[i + 1 + s_delta[c1]];
+    }
+    x0 = m0 ? x0 : V(0);
+    x1 = m1 ? x1 : V(0);
+}
+
 template <typename V, int NR>
 __device__ __forceinline__ void tail_and_store(long long n, long long i, V alpha, int append,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
@@ -89,25 +115,25 @@ void spmm_sell8_kernel(long long n, long long nslices, V alpha, int append, int 
         for (int jp = 0; jp < WP; ++jp) c[jp] = __builtin_nontemporal_load(cw + jp * 256);
 #pragma unroll
         for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * ROWS));
-        long long col[W][2];
+        int d[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const unsigned code = (c[j >> 1] >> (8 * ((j & 1) * 2 + q))) & 255u;
-                col[j][q] = (code < PAD8) ? i + q + s_delta[code] : -1;
-            }
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            d[j] = s_delta[c0 < PAD8 ? c0 : c1];
+        }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             V xv[W][2];
 #pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+                gather_pair<V>(io.x[k], i, c0, c1, d[j], s_delta, deltas, xv[j][0], xv[j][1]);
+            }
+            // padding: stored value 0, gathered value 0 -- sum + (+-0) == sum bit for bit (the sum starts at +0)
+#pragma unroll
             for (int j = 0; j < W; ++j)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) xv[j][q] = (col[j][q] >= 0) ? io.x[k][col[j][q]] : V(0);
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) if (col[j][q] >= 0) sum[k][q] += v[j][q] * xv[j][q];
+                for (int q = 0; q < 2; ++q) sum[k][q] += v[j][q] * xv[j][q];
         }
     } else {
         for (int j = 0; j < w; ++j) {
@@ -159,27 +185,26 @@ void spmm_sell8v_kernel(long long n, long long nslices, V alpha, int append, int
         unsigned c[WP], vc[WP];
 #pragma unroll
         for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
-        long long col[W][2]; V val[W][2];
+        int d[W]; V val[W][2];
 #pragma unroll
-        for (int j = 0; j < W; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int sh = 8 * ((j & 1) * 2 + q);
-                const unsigned code = (c[j >> 1] >> sh) & 255u;
-                col[j][q] = (code < PAD8) ? i + q + s_delta[code] : -1;
-                val[j][q] = s_value[(vc[j >> 1] >> sh) & 255u];
-            }
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            d[j] = s_delta[c0 < PAD8 ? c0 : c1];
+            val[j][0] = s_value[c0 < PAD8 ? (vc[j >> 1] >> (16 * (j & 1))) & 255u : 255u];          // entry 255 is 0.0
+            val[j][1] = s_value[c1 < PAD8 ? (vc[j >> 1] >> (16 * (j & 1) + 8)) & 255u : 255u];
+        }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             V xv[W][2];
 #pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+                gather_pair<V>(io.x[k], i, c0, c1, d[j], s_delta, deltas, xv[j][0], xv[j][1]);
+            }
+#pragma unroll
             for (int j = 0; j < W; ++j)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) xv[j][q] = (col[j][q] >= 0) ? io.x[k][col[j][q]] : V(0);
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) if (col[j][q] >= 0) sum[k][q] += val[j][q] * xv[j][q];
+                for (int q = 0; q < 2; ++q) sum[k][q] += val[j][q] * xv[j][q];
         }
     } else {
         for (int j = 0; j < w; ++j) {
