@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
-KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true>", "sell8": "sell8_pair_kernel<double, 7, false>",
+KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true, false>", "sell8": "sell8_pair_kernel<double, 7, false, false>",
              "sell32": "sell_pair_kernel<double, 7>", "csr": "csr_stream2_kernel<double, int, false>", "hell": "hell_kernel"}
 
 
@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (debug: exercises the N>1 path on a 1-GPU box; needs --backend gloo)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (CSR-bytes kernels, variable coefficients, C++ front end, elementwise, reduce, scan, sort)")
     ap.add_argument("--no-native", action="store_true", help="N > 1: keep the torch.distributed transport (do not try the C++ product step)")
+    ap.add_argument("--no-dictionary", action="store_true", help="value-coded storage with one code block per slice (no slice dictionary)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the ~3 s back-to-back run of the product after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic = null)")
     args = ap.parse_args()
@@ -274,9 +275,10 @@ def main():
                       (42 + r0 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
     y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
     if single:
-        A = ops.SpMat(ptr, col, val, fmt=args.format)
+        A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary)
         storage = A.storage
         matrix_bytes = A.matrix_bytes()
+        dict_blocks = A.dictionary_blocks
         if storage not in ("csr",):
             del ptr, col, val                    # the product only needs the converted storage
             A.ptr = A.col = A.val = None
@@ -285,6 +287,7 @@ def main():
         A = DistSpMat(ptr, col, val, N, N, local_fmt=args.format)
         storage = A.loc.storage
         matrix_bytes = A.loc.matrix_bytes()
+        dict_blocks = getattr(A.loc, "dictionary_blocks", 0)
         step = lambda: A.apply(x, y, 1.0, False)
         # The product step issued from C++ over its own RCCL communicator (vexhip_dist_spmv_*: ~50 us of host time per
         # step instead of a Python loop over torch.distributed requests).  It is used only if EVERY rank could set it
@@ -432,13 +435,14 @@ def main():
                        "format": storage, "rows_per_gpu": rows_rank,
                        "parallelism": "row-partitioned x%d" % world},
             "roofline": {"bound": "hbm",
-                         "kernel": KERNEL_OF.get(storage, storage),
+                         "kernel": ("sell8_pair_kernel<double, 7, true, true>" if (storage == "sell8v" and dict_blocks) else KERNEL_OF.get(storage, storage)),
                          "achieved": round(moved_rank / kern_s / 1e9, 1),
                          "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s",
                          "frac": round(moved_rank / kern_s / 1e9 / HBM_PEAK_GBPS, 4),
                          "bytes_per_launch": moved_rank,
-                         "bytes_per_launch_what": "stored matrix (%d B: %s) + x once + y once" % (matrix_bytes, storage),
+                         "bytes_per_launch_what": "stored matrix (%d B: %s%s) + x once + y once" % (
+                             matrix_bytes, storage, (", %d distinct 512-row code blocks + 4 B per slice" % dict_blocks) if dict_blocks else ""),
                          "algorithmic_bytes_per_launch": alg_rank,
                          "algorithmic_gbps": round(alg_rank / kern_s / 1e9, 1),
                          "traffic": None,
@@ -458,6 +462,19 @@ def main():
                 torch.cuda.empty_cache()
                 p2, c2, v2 = ops.poisson3d(n, dev)
                 rcsr = []
+                if storage == "sell8v" and dict_blocks:
+                    # the value-coded storage WITHOUT the slice dictionary: one code block per slice, streamed from HBM
+                    B = ops.SpMat(p2, c2, v2, fmt=args.format, dictionary=False)
+                    tb = timed_events(torch, lambda: B.apply(x, y), 40)
+                    assert abs(DistReductor("SUM_Kahan")(y) - checksum) <= 1e-10 * abs(checksum) + 1e-300
+                    mb = B.matrix_bytes() + 16 * N
+                    out["value_codes_streamed"] = {
+                        "kernel": "sell8_pair_kernel<double, 7, true, false>",
+                        "what": "the same matrix with one code block per slice (VEXHIP_SPMAT_NO_DICTIONARY): 2 B per entry streamed from HBM",
+                        "avg_launch_ms": round(tb, 5), "gflops": round(2.0 * nnz_total / tb / 1e6, 1),
+                        "roofline": {"bound": "hbm", "achieved": round(mb / tb / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": round(mb / tb / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": mb}}
+                    del B
                 for f2, label in (("sell32", "SELL-512, 32-bit columns + fp64 values (vexhip_spmat format SELL)"),
                                   ("csr", "the CSR arrays themselves (row pointers + columns + values)")):
                     B = ops.SpMat(p2, c2, v2, fmt=f2)

@@ -228,6 +228,28 @@ int vexhip_spmv_sell8_f32_i32(int dev, void *stream, int64_t n, float alpha, int
  * them.   values: 256 entries on the device, sorted by bit pattern, nvalues valid (-1: not applicable);
  * slice layout: ceil(w/2) KiB of diagonal codes, then ceil(w/2) KiB of value codes, both packed as in SELL8.     */
 int64_t vexhip_sell8v_bytes(int64_t n, int64_t ell_width);
+/* Slice dictionary.  Value-coded slices are nothing but codes, and a constant-coefficient stencil on a structured grid
+ * repeats them: the 262 144 slices of the 512^3 Poisson matrix hold TWO distinct blocks.  vexhip_slice_dictionary
+ * numbers the distinct slices of `buf` (nslices x slice_bytes, device) in order of first appearance -- 64-bit hash per
+ * slice, then a word-by-word comparison of every slice with the representative of its number -- writes the number of
+ * every slice to blocks[nslices] (device) and the representatives to pool[*nblocks x slice_bytes] (device, capacity
+ * max_blocks slices).  *nblocks = -1 when there are more than max_blocks distinct slices (or two different slices
+ * share a hash): nothing valid was written.  The _dict products read slice s at pool + blocks[s] * slice_bytes: the
+ * code stream is replaced by 4 bytes per slice, the pool stays in L1 / L2; same codes, same arithmetic, same results. */
+int vexhip_slice_dictionary(int dev, void *stream, int64_t nslices, int64_t slice_bytes, const void *buf, int64_t max_blocks,
+        int32_t *blocks, void *pool, int64_t *nblocks);
+int vexhip_spmv_sell8v_dict_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const vexhip_traversal *traversal);
+int vexhip_spmv_sell8v_dict_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const float *values, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell8v_dict_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
+        const void *pool, const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell8v_dict_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t ell_width,
+        const void *pool, const int32_t *blocks, const int32_t *deltas, const float *values, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal);
 int vexhip_sell8v_analyze_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const double *val,
         int64_t ell_width, double *values, int *nvalues);
 int vexhip_sell8v_analyze_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const float *val,
@@ -264,7 +286,8 @@ enum { VEXHIP_SPMAT_AUTO = 0,      /* create(): most compact storage; info: neve
        VEXHIP_SPMAT_SELL8 = 2,     /* diagonal codes, values as they are (1 + sizeof(V) B per entry)              */
        VEXHIP_SPMAT_SELL = 3,      /* 32-bit columns (4 + sizeof(V) B per entry)                                  */
        VEXHIP_SPMAT_CSR = 4 };     /* the CSR arrays themselves (csr_stream_kernel)                               */
-enum { VEXHIP_SPMAT_BORROW_CSR = 1 };   /* format CSR: keep the caller's arrays instead of copying them (caller keeps them alive) */
+enum { VEXHIP_SPMAT_BORROW_CSR = 1,      /* format CSR: keep the caller's arrays instead of copying them (caller keeps them alive) */
+       VEXHIP_SPMAT_NO_DICTIONARY = 2 };  /* value-coded storage: keep one block per slice even if the slices repeat (A/B, tests)   */
 typedef struct vexhip_spmat_info {
     int32_t format, value_type, device, ndeltas, nvalues, reserved;
     int64_t rows, nnz, ell_width, tail_nnz, sell_bytes;
@@ -272,6 +295,9 @@ typedef struct vexhip_spmat_info {
     const void *sell; const int32_t *deltas; const void *values;           /* SELL storage (make_inline reads it)  */
     const int32_t *csr_ptr, *csr_col; const void *csr_val;                 /* CSR tail, or the matrix (format CSR) */
     vexhip_traversal traversal;
+    const int32_t *slice_blocks;    /* slice dictionary (SELL8V only; NULL = none): slice s is block slice_blocks[s] of `sell`,
+                                       which then holds dictionary_blocks distinct slices instead of one per 512 rows          */
+    int64_t dictionary_blocks;
 } vexhip_spmat_info;
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int format, int flags, vexhip_spmat **out);

@@ -266,6 +266,26 @@ TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp
     PY = P * PX;
     vex::copy(PY, got);
     for (size_t i = 0; i < N; ++i) CHECK_SMALL(got[i] - pwant[i], 1e-10 * 12 * h2i);
+    // 64^3: 512 slices that repeat -- the matrix keeps a dictionary of the distinct ones (vexhip_spmat_info.
+    // dictionary_blocks); the inline terminal and the product read the same slices through it
+    {
+        const size_t g2 = 64, N2 = g2 * g2 * g2;
+        std::vector<size_t> row2; std::vector<unsigned> col2; std::vector<double> val2;
+        poisson(g2, row2, col2, val2);
+        std::vector<double> x2 = random_vector<double>(N2);
+        vex::SpMat<double, unsigned> D(queue, N2, N2, row2.data(), col2.data(), val2.data());
+        CHECK(D.storage_info(0).dictionary_blocks > 0 && D.storage_info(0).slice_blocks != nullptr);
+        vex::vector<double> DX(queue, x2), DY(queue, N2), DZ(queue, N2);
+        DY = D * DX;
+        DZ = vex::make_inline(D * DX);
+        std::vector<double> a(N2), b(N2); vex::copy(DY, a); vex::copy(DZ, b);
+        auto want2 = host_spmv(row2, col2, val2, x2);
+        const double h2 = (g2 - 1.0) * (g2 - 1.0);
+        for (size_t i = 0; i < N2; ++i) {         // (the fused kernel is free to contract a*b+c: tolerance, not bits)
+            CHECK_SMALL(a[i] - want2[i], 1e-10 * 12 * h2);
+            CHECK_SMALL(b[i] - want2[i], 1e-10 * 12 * h2);
+        }
+    }
 }
 
 TEST_CASE(sparse_csr_ell_matrix_single_queue) {                      // sparse_matrices.cpp:66-151

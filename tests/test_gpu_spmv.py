@@ -594,3 +594,75 @@ def test_randomized_structures_all_storages(T, oracle, built_lib):
             A.apply(T.up(x), y, alpha, append)
             assert np.array_equal(y.cpu().numpy(), want), (trial, fmt, n, offs[:5], alpha, append)
     assert seen["sell8v"] >= 5 and seen["sell8"] >= 5, seen
+
+
+def test_slice_dictionary_function(T):
+    """vexhip_slice_dictionary: numbering in order of first appearance, pool = the representatives, -1 past the capacity."""
+    import ctypes
+    torch, L = T.torch, T.L
+    rng = np.random.default_rng(5)
+    for ns, words, kinds, cap in ((1, 8, 1, 4), (200, 2048, 3, 8), (777, 96, 8, 8), (300, 64, 9, 8), (64, 512, 64, 128)):
+        patterns = rng.integers(0, 2 ** 32, size=(kinds, words), dtype=np.uint64).astype(np.uint32)
+        if kinds > 1:
+            patterns[1] = patterns[0]; patterns[1, -1] ^= 1                       # two patterns that differ in ONE bit of the last word
+        which = rng.integers(0, kinds, size=ns); which[:min(ns, kinds)] = np.arange(min(ns, kinds))
+        buf = T.up(patterns[which].view(np.int32))
+        blocks = torch.full((ns,), -7, dtype=torch.int32, device=T.dev)
+        pool = torch.zeros((cap, words), dtype=torch.int32, device=T.dev)
+        nb = ctypes.c_int64(-5)
+        L.slice_dictionary(0, None, ns, words * 4, ctypes.c_void_p(buf.data_ptr()), cap, ctypes.c_void_p(blocks.data_ptr()),
+                           ctypes.c_void_p(pool.data_ptr()), ctypes.byref(nb))
+        distinct = len(np.unique(which))
+        if distinct > cap:
+            assert nb.value == -1
+            continue
+        assert nb.value == distinct
+        first = {}
+        want = np.array([first.setdefault(int(k), len(first)) for k in which], dtype=np.int32)
+        assert np.array_equal(blocks.cpu().numpy(), want)
+        reps = [int(np.nonzero(want == b)[0][0]) for b in range(distinct)]
+        assert np.array_equal(pool[:distinct].cpu().numpy().view(np.uint32), patterns[which[reps]])
+
+
+@pytest.mark.parametrize("n", [40, 64])
+def test_spmat_slice_dictionary_is_bit_identical(T, oracle, built_lib, n):
+    """The value-coded Poisson matrix repeats its slices: vex::SpMat stores the distinct ones once (vexhip_spmat_info.
+    dictionary_blocks) and every product -- single, multi-vector, '=' and '+=' -- equals the streamed layout's and the CSR
+    oracle's bit for bit.  Matrices whose slices differ, and small ones, keep one block per slice."""
+    torch = T.torch
+    ptr, col, val = oracle.poisson3d(n)
+    N = n ** 3
+    A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+    B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), dictionary=False)
+    assert A.storage == "sell8v" and B.storage == "sell8v" and B.dictionary_blocks == 0
+    ns = (N + 511) // 512
+    if n == 64:          # 8 grid lines per slice, 8 slices per plane: a handful of distinct slices out of 512
+        assert 1 <= A.dictionary_blocks <= 16 and A.matrix_bytes() < B.matrix_bytes() // 8
+    if A.dictionary_blocks:      # n = 40: slices and grid lines do not line up; whatever the count, the products must agree
+        assert A.dictionary_blocks <= 128 and A.matrix_bytes() == A.dictionary_blocks * (B.matrix_bytes() // ns) + 4 * ns
+    x = oracle.random_f64(3, N); y0 = oracle.random_f64(4, N)
+    want = oracle.spmv_csr(ptr, col, val, x)
+    for alpha, append in ((1.0, False), (-0.75, True)):
+        ya, yb = T.up(y0.copy()), T.up(y0.copy())
+        A.apply(T.up(x), ya, alpha, append); B.apply(T.up(x), yb, alpha, append)
+        assert torch.equal(ya, yb)
+        ref = (y0 + alpha * want) if append else alpha * want
+        assert np.array_equal(ya.cpu().numpy(), ref)
+    xs = [T.up(oracle.random_f64(10 + k, N)) for k in range(3)]
+    ya = [torch.empty(N, dtype=torch.float64, device=T.dev) for _ in range(3)]; yb = [torch.empty_like(v) for v in ya]
+    A.apply_multi(xs, ya); B.apply_multi(xs, yb)
+    for k in range(3):
+        assert torch.equal(ya[k], yb[k])
+        assert np.array_equal(ya[k].cpu().numpy(), oracle.spmv_csr(ptr, col, val, xs[k].cpu().numpy()))
+    # the per-entry kernels (A/B switch) read through the dictionary too
+    T.L.spmv_sell8_set_variant(1)
+    try:
+        yc = torch.empty(N, dtype=torch.float64, device=T.dev); A.apply(T.up(x), yc)
+        assert np.array_equal(yc.cpu().numpy(), want)
+    finally:
+        T.L.spmv_sell8_set_variant(0)
+    # stored values (variable coefficients): nothing to pool; fewer than 64 slices: not tried
+    p2, c2, v2 = oracle.diffusion3d(32, 7)
+    assert T.ops.SpMat(T.up(p2), T.up(c2), T.up(v2)).dictionary_blocks == 0
+    p3, c3, v3 = oracle.poisson3d(16)
+    assert T.ops.SpMat(T.up(p3), T.up(c3), T.up(v3)).dictionary_blocks == 0

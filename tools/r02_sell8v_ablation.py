@@ -53,10 +53,21 @@ extern "C" __global__ void __launch_bounds__(256) k(long long n, long long ns, u
     const long long i = s * 512 + 2 * t; const int rstride = 1;
 #endif
     unsigned c[WP], vc[WP];
-#if CODES == 0
-    const unsigned *cw = (const unsigned *)(buf + s * (WP * 2048ll)) + t; const unsigned *vw = cw + WP * 256;
+#if CODES == 0 || CODES == 3 || CODES == 4
+    // CODES 3: every slice reads the code block of ONE interior slice (what a dictionary of distinct slice blocks would make of
+    // this matrix: the block stays in L2; wrong results on the boundary slices)
+#if CODES == 3 || CODES == 4
+    const long long sc = 300 * 512 + 300 + (s & 7);
+#else
+    const long long sc = s;
+#endif
+    const unsigned *cw = (const unsigned *)(buf + sc * (WP * 2048ll)) + t; const unsigned *vw = cw + WP * 256;
     #pragma unroll
+#if CODES == 4
+    for (int jp = 0; jp < WP; ++jp) { c[jp] = cw[jp * 256]; vc[jp] = vw[jp * 256]; }      // plain (cached) loads
+#else
     for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
+#endif
 #elif CODES == 2
     { typedef unsigned u4 __attribute__((ext_vector_type(4)));
       // lane t: 16 bytes at t*16 of the first 4 KiB (its four diagonal-code words) and of the second 4 KiB (value codes)
@@ -305,6 +316,9 @@ variants = [
     ("+-1 taps by lane shuffle, four far gathers, codes 2 x 16 B", dict(GATHER=5, CODES=2)),
     ("x of all 7 table diagonals loaded up front (16-byte, independent of the codes), picked by code via lane-private LDS", dict(GATHER=9)),
     ("x of all 7 table diagonals up front, no store", dict(GATHER=9, STORE=1)),
+    ("seven 16-byte gathers, codes read from 8 fixed slices (L2-resident code blocks)", dict(GATHER=3, CODES=3)),
+    ("full, codes read from 8 fixed slices (L2-resident code blocks)", dict(CODES=3)),
+    ("seven 16-byte gathers, codes from 8 fixed slices with plain (L1-cached) loads", dict(GATHER=3, CODES=4)),
 ]
 res = []
 mods = []

@@ -311,7 +311,7 @@ struct inline_spmv : expression_base {
         c.src.begin_function_parameters();
         c.src.parameter("long", "ell_w");
         c.src.parameter("const char *", "sell"); c.src.parameter("const int *", "deltas");
-        c.src.parameter("const " + V + " *", "values");
+        c.src.parameter("const " + V + " *", "values"); c.src.parameter("const int *", "blocks");
         c.src.parameter("const int *", "csr_row"); c.src.parameter("const int *", "csr_col");
         c.src.parameter("const " + V + " *", "csr_val"); c.src.parameter("const " + V + " *", "in");
         c.src.parameter("ulong", "i");
@@ -320,7 +320,8 @@ struct inline_spmv : expression_base {
         c.src.new_line() << "if (values)";            // SELL8V: diagonal codes and value codes (include/vexhip.h)
         c.src.open("{");
         c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
-        c.src.new_line() << "const uint *cw = (const uint *)(sell + (i >> 9) * (wp * 2048)) + ((i & 511) >> 1);";
+        c.src.new_line() << "const long slice = blocks ? (long)blocks[i >> 9] : (long)(i >> 9);";   // slice dictionary (include/vexhip.h)
+        c.src.new_line() << "const uint *cw = (const uint *)(sell + slice * (wp * 2048)) + ((i & 511) >> 1);";
         c.src.new_line() << "const uint *vw = cw + wp * 256;";
         c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
         c.src.open("{");
@@ -364,14 +365,14 @@ struct inline_spmv : expression_base {
         const std::string V = type_name<T>();
         c.src.parameter("long", name + "_ell_w");
         c.src.parameter("const char *", name + "_sell"); c.src.parameter("const int *", name + "_deltas");
-        c.src.parameter("const " + V + " *", name + "_values");
+        c.src.parameter("const " + V + " *", name + "_values"); c.src.parameter("const int *", name + "_blocks");
         c.src.parameter("const int *", name + "_csr_row"); c.src.parameter("const int *", name + "_csr_col");
         c.src.parameter("const " + V + " *", name + "_csr_val"); c.src.parameter("const " + V + " *", name + "_vec");
     }
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
-        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, "
+        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, " << n << "_blocks, "
               << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, idx)";
     }
     void set_args(arg_context &a) const {
@@ -382,6 +383,7 @@ struct inline_spmv : expression_base {
         a.krn.push_arg(static_cast<const char *>(L.sell));
         a.krn.push_arg(static_cast<const int *>(L.ndeltas > 0 ? L.deltas : nullptr));
         a.krn.push_arg(static_cast<const T *>(L.nvalues > 0 ? L.values : nullptr));
+        a.krn.push_arg(static_cast<const int *>(L.slice_blocks));
         a.krn.push_arg(static_cast<const int *>(csr_rows ? L.csr_ptr : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_col)); a.krn.push_arg(static_cast<const T *>(L.csr_val));
         a.krn.push_arg(static_cast<const T *>(x(a.device).raw()));

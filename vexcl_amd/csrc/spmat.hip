@@ -22,6 +22,7 @@ struct spmat {
     int format = VEXHIP_SPMAT_CSR;
     int64_t n = 0, nnz = 0, ell_w = 0, tail = 0;
     void *sell = nullptr; int64_t sell_bytes = 0;
+    int32_t *blocks = nullptr; int64_t dict_blocks = 0;                         // slice dictionary (SELL8V): sell = pool of distinct slices
     int32_t *deltas = nullptr; int ndeltas = -1;
     void *values = nullptr; int nvalues = -1;
     int32_t *csr_ptr = nullptr, *csr_col = nullptr; void *csr_val = nullptr;   // CSR tail, or the whole matrix (format CSR)
@@ -39,6 +40,7 @@ void release(spmat *A) {
     if (!A) return;
     (void)hipSetDevice(A->dev);
     if (A->sell) (void)hipFree(A->sell);
+    if (A->blocks) (void)hipFree(A->blocks);
     if (A->deltas) (void)hipFree(A->deltas);
     if (A->values) (void)hipFree(A->values);
     if (A->owns_csr) {
@@ -62,6 +64,10 @@ template <> struct api<double> {
     static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const double *v, int64_t w, void *b) { return vexhip_sell_fill_f64_i32(d, s, n, p, c, v, w, b); }
     static int mul_v(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_f64_i32(d, s, n, a, ap, w, b, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
+    static int mul_vd(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8v_dict_f64_i32(d, s, n, a, ap, w, b, bl, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
+    static int mm_vd(int d, void *s, int64_t n, int k, double a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *const *x, double *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8v_dict_f64_i32(d, s, n, k, a, ap, w, b, bl, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
     static int mul_d(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8_f64_i32(d, s, n, a, ap, w, b, dl, cp, cc, (const double *)cv, x, y, t); }
     static int mul_s(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
@@ -87,6 +93,10 @@ template <> struct api<float> {
     static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const float *v, int64_t w, void *b) { return vexhip_sell_fill_f32_i32(d, s, n, p, c, v, w, b); }
     static int mul_v(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_f32_i32(d, s, n, a, ap, w, b, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
+    static int mul_vd(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8v_dict_f32_i32(d, s, n, a, ap, w, b, bl, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
+    static int mm_vd(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8v_dict_f32_i32(d, s, n, k, a, ap, w, b, bl, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
     static int mul_d(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8_f32_i32(d, s, n, a, ap, w, b, dl, cp, cc, (const float *)cv, x, y, t); }
     static int mul_s(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
@@ -170,6 +180,29 @@ int build(spmat *A, void *stream, int64_t n, const int32_t *ptr, const int32_t *
             A->sell_bytes = vexhip_sell8v_bytes(n, w);
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
             if (int rc = F::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
+            // Slice dictionary (sell8.hip): do the slices repeat?  Up to 128 distinct 512-row blocks (<= 1 MiB for width 7-8:
+            // L2-resident) replace one block per slice; anything less regular keeps the streamed layout.
+            const int64_t ns = (n + 511) / 512, sb = A->sell_bytes / ns;
+            if (!(flags & VEXHIP_SPMAT_NO_DICTIONARY) && ns >= 64) {
+                const int64_t cap = 128;
+                void *pool = nullptr; int64_t nb = -1;
+                if (int rc = dmalloc(&A->blocks, (size_t)ns)) return rc;
+                VEXHIP_TRY(hipMalloc(&pool, (size_t)(cap * sb)));
+                int rc = vexhip_slice_dictionary(dev, stream, ns, sb, A->sell, cap, A->blocks, pool, &nb);
+                if (rc == 0 && nb > 0) {
+                    void *small = nullptr;                                  // the pool at its real size; the full storage goes
+                    hipError_t e = hipMalloc(&small, (size_t)(nb * sb));
+                    if (e == hipSuccess) e = hipMemcpyAsync(small, pool, (size_t)(nb * sb), hipMemcpyDeviceToDevice, s);
+                    if (e == hipSuccess) e = hipStreamSynchronize(s);
+                    (void)hipFree(pool);
+                    if (e != hipSuccess) { if (small) (void)hipFree(small); return check(e, __FILE__, __LINE__); }
+                    (void)hipFree(A->sell);
+                    A->sell = small; A->dict_blocks = nb; A->sell_bytes = nb * sb + ns * 4;
+                } else {
+                    (void)hipFree(pool); (void)hipFree(A->blocks); A->blocks = nullptr;
+                    if (rc) return rc;
+                }
+            }
         } else {
             if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
             A->format = VEXHIP_SPMAT_SELL8;
@@ -216,7 +249,9 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
     }
     const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
     switch (A->format) {
-        case VEXHIP_SPMAT_SELL8V: return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case VEXHIP_SPMAT_SELL8V:
+            if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+            return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL8:  return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL:   return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         default:                  return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
@@ -236,7 +271,9 @@ int apply_multi(const spmat *A, void *stream, int k, V alpha, int append, const 
     }
     const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
     switch (A->format) {
-        case VEXHIP_SPMAT_SELL8V: return F::mm_v(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case VEXHIP_SPMAT_SELL8V:
+            if (A->blocks) return F::mm_vd(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+            return F::mm_v(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL8:  return F::mm_d(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         default:                  return F::mm_s(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
     }
@@ -279,6 +316,7 @@ int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
     o->sell = A->sell; o->sell_bytes = A->sell_bytes; o->deltas = A->deltas; o->values = A->values;
     o->csr_ptr = A->csr_ptr; o->csr_col = A->csr_col; o->csr_val = A->csr_val;
     o->traversal = A->trav;
+    o->slice_blocks = A->blocks; o->dictionary_blocks = A->dict_blocks;
     // bytes one product moves through HBM at least: the stored matrix + x once + y once (+ y read for "+=" not counted)
     const int64_t vb = A->value_type == VEXHIP_F64 ? 8 : 4;
     int64_t m = A->sell_bytes;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256)
 void spmm_sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
         const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        rhs_set<V> io, trav_dev trav)
+        rhs_set<V> io, trav_dev trav, const int *__restrict__ blocks)
 {
     __shared__ int s_delta[256];
     __shared__ V s_value[256];
@@ -173,7 +173,8 @@ void spmm_sell8v_kernel(long long n, long long nslices, V alpha, int append, int
     const long long i = s * ROWS + 2 * t;
     const int w = W > 0 ? W : ell_w;
     const int wp = (w + 1) / 2;
-    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + s * ((long long)wp * 2048)) + t;
+    const long long sb = blocks ? (long long)blocks[s] : s;                 // slice dictionary (sell8.hip)
+    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + sb * ((long long)wp * 2048)) + t;
     const unsigned *vw = cw + wp * 256;
 
     V sum[NR][2];
@@ -184,7 +185,10 @@ void spmm_sell8v_kernel(long long n, long long nslices, V alpha, int append, int
         constexpr int WP = (W + 1) / 2;
         unsigned c[WP], vc[WP];
 #pragma unroll
-        for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
+        for (int jp = 0; jp < WP; ++jp) {
+            if (blocks) { c[jp] = cw[jp * 256]; vc[jp] = vw[jp * 256]; }           // pooled blocks: cached loads
+            else { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
+        }
         int d[W]; V val[W][2];
 #pragma unroll
         for (int j = 0; j < W; ++j) {
@@ -284,11 +288,12 @@ void spmm_sell_kernel(long long n, long long nslices, V alpha, int append, int e
 // CODES: 0 = 32-bit columns, 1 = diagonal codes, 2 = diagonal and value codes
 template <typename V, int CODES, int NR>
 void launch(hipStream_t s, long long grid, long long n, long long ns, V alpha, int append, int w, const char *buf,
-        const int *deltas, const V *values, const int *cp, const int *cc, const V *cv, const rhs_set<V> &io, const trav_dev &t)
+        const int *deltas, const V *values, const int *cp, const int *cc, const V *cv, const rhs_set<V> &io, const trav_dev &t,
+        const int *blocks)
 {
 #define LAUNCH(W)                                                                                              \
     do {                                                                                                       \
-        if constexpr (CODES == 2) spmm_sell8v_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, values, cp, cc, cv, io, t); \
+        if constexpr (CODES == 2) spmm_sell8v_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, values, cp, cc, cv, io, t, blocks); \
         else if constexpr (CODES == 1) spmm_sell8_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, cp, cc, cv, io, t); \
         else spmm_sell_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, cp, cc, cv, io, t);               \
     } while (0)
@@ -304,7 +309,7 @@ void launch(hipStream_t s, long long grid, long long n, long long ns, V alpha, i
 
 template <typename V, int CODES>
 int spmm(int dev, void *stream, int64_t n, int nrhs, V alpha, int append, int64_t w, const void *buf, const int *deltas, const V *values,
-        const int *cp, const int *cc, const V *cv, const V *const *x, V *const *y, const vexhip_traversal *tr)
+        const int *cp, const int *cc, const V *cv, const V *const *x, V *const *y, const vexhip_traversal *tr, const int *blocks = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20) && nrhs >= 1, "bad SpMM geometry");
     if (n == 0) return 0;
@@ -323,10 +328,10 @@ int spmm(int dev, void *stream, int64_t n, int nrhs, V alpha, int append, int64_
         rhs_set<V> io;
         for (int k = 0; k < MAX_NR; ++k) { io.x[k] = x[k0 + (k < nr ? k : 0)]; io.y[k] = y[k0 + (k < nr ? k : 0)]; }
         switch (nr) {
-            case 1: launch<V, CODES, 1>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t); break;
-            case 2: launch<V, CODES, 2>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t); break;
-            case 3: launch<V, CODES, 3>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t); break;
-            default: launch<V, CODES, 4>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t);
+            case 1: launch<V, CODES, 1>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks); break;
+            case 2: launch<V, CODES, 2>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks); break;
+            case 3: launch<V, CODES, 3>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks); break;
+            default: launch<V, CODES, 4>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks);
         }
         VEXHIP_LAUNCH_CHECK();
     }
@@ -369,5 +374,15 @@ int vexhip_spmm_sell8v_f32_i32(int dev, void *stream, int64_t n, int nrhs, float
         const void *buf, const int32_t *deltas, const float *values, const int32_t *cp, const int32_t *cc, const float *cv,
         const float *const *x, float *const *y, const vexhip_traversal *traversal)
 { return spmm<float, 2>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, values, cp, cc, cv, x, y, traversal); }
+
+int vexhip_spmm_sell8v_dict_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t w,
+        const void *pool, const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal)
+{ return spmm<double, 2>(dev, stream, n, nrhs, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks); }
+
+int vexhip_spmm_sell8v_dict_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t w,
+        const void *pool, const int32_t *blocks, const int32_t *deltas, const float *values, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal)
+{ return spmm<float, 2>(dev, stream, n, nrhs, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks); }
 
 } // extern "C"
