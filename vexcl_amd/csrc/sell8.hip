@@ -341,6 +341,10 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
 //   * a padding entry next to a real one is code 255 ("the 16-byte load of the
 //     partner may cover me") unless that load would leave x -- the partner is in
 //     column 0 resp. the last column -- then it is code 254.
+// Tried on top of this and dropped (round 2, with the slice dictionary in place): three columns on consecutive diagonals
+// d, d+1, d+2 -- the -1 / 0 / +1 entries of a stencil row -- need x[i+d .. i+d+3], which the loads of the OUTER two
+// columns already hold, so the middle load was skipped per wave (one gather in seven).  Bit-identical, but 0.68 -> 0.84 ms:
+// the bookkeeping (per-column ballots, the raw pairs kept apart from the masked values) costs far more than the load.
 // Per column a lane therefore does one unconditional 16-byte load when its codes are
 // {d, d}, {d, 255}, {255, d} or both padding (then from a harmless address), and
 // falls back to one 8-byte load per real entry otherwise (a rarely taken branch).
