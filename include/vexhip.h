@@ -228,16 +228,31 @@ int vexhip_spmv_sell8_f32_i32(int dev, void *stream, int64_t n, float alpha, int
  * them.   values: 256 entries on the device, sorted by bit pattern, nvalues valid (-1: not applicable);
  * slice layout: ceil(w/2) KiB of diagonal codes, then ceil(w/2) KiB of value codes, both packed as in SELL8.     */
 int64_t vexhip_sell8v_bytes(int64_t n, int64_t ell_width);
-/* Slice dictionary.  Value-coded slices are nothing but codes, and a constant-coefficient stencil on a structured grid
- * repeats them: the 262 144 slices of the 512^3 Poisson matrix hold TWO distinct blocks.  vexhip_slice_dictionary
- * numbers the distinct slices of `buf` (nslices x slice_bytes, device) in order of first appearance -- 64-bit hash per
- * slice, then a word-by-word comparison of every slice with the representative of its number -- writes the number of
- * every slice to blocks[nslices] (device) and the representatives to pool[*nblocks x slice_bytes] (device, capacity
- * max_blocks slices).  *nblocks = -1 when there are more than max_blocks distinct slices (or two different slices
- * share a hash): nothing valid was written.  The _dict products read slice s at pool + blocks[s] * slice_bytes: the
- * code stream is replaced by 4 bytes per slice, the pool stays in L1 / L2; same codes, same arithmetic, same results. */
-int vexhip_slice_dictionary(int dev, void *stream, int64_t nslices, int64_t slice_bytes, const void *buf, int64_t max_blocks,
-        int32_t *blocks, void *pool, int64_t *nblocks);
+/* Slice dictionary.  The CODES of a 512-row slice repeat on a structured grid: the 262 144 slices of the 512^3 Poisson
+ * matrix hold TWO distinct code blocks, and so do those of a variable-coefficient operator with the same pattern.
+ * vexhip_slice_dictionary numbers the distinct code blocks -- the first slice_bytes bytes of every slice of `buf`
+ * (nslices slices, stride_bytes apart, device memory) -- in order of first appearance: a 64-bit hash per block, then a
+ * word-by-word comparison of every block with the representative of its number.  It writes the number of every slice to
+ * blocks[nslices] (device) and the representatives to pool[*nblocks x slice_bytes] (device, capacity max_blocks).
+ * *nblocks = -1 when there are more than max_blocks distinct blocks (or two different blocks share a hash): nothing
+ * valid was written.  The _dict products read the codes of slice s at pool + blocks[s] * slice_bytes -- value-coded
+ * storage (SELL8V): the whole slice, `pool` replaces the buffer; diagonal codes with stored values (SELL8): the code
+ * part, the values stay in `buf`.  4 bytes per slice instead of the code stream, the pool stays in L1 / L2; same
+ * codes, same arithmetic, same results.                                                                             */
+int vexhip_slice_dictionary(int dev, void *stream, int64_t nslices, int64_t stride_bytes, int64_t slice_bytes, const void *buf,
+        int64_t max_blocks, int32_t *blocks, void *pool, int64_t *nblocks);
+int vexhip_spmv_sell8_dict_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const vexhip_traversal *traversal);
+int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell8_dict_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
+        const void *buf, const void *pool, const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal);
+int vexhip_spmm_sell8_dict_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t ell_width,
+        const void *buf, const void *pool, const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal);
 int vexhip_spmv_sell8v_dict_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
         const double *x, double *y, const vexhip_traversal *traversal);
@@ -295,9 +310,9 @@ typedef struct vexhip_spmat_info {
     const void *sell; const int32_t *deltas; const void *values;           /* SELL storage (make_inline reads it)  */
     const int32_t *csr_ptr, *csr_col; const void *csr_val;                 /* CSR tail, or the matrix (format CSR) */
     vexhip_traversal traversal;
-    const int32_t *slice_blocks;    /* slice dictionary (SELL8V only; NULL = none): slice s is block slice_blocks[s] of `sell`,
-                                       which then holds dictionary_blocks distinct slices instead of one per 512 rows          */
-    int64_t dictionary_blocks;
+    const int32_t *slice_blocks;    /* slice dictionary (NULL = none): the codes of slice s are block slice_blocks[s] of       */
+    const void *code_pool;          /* code_pool, which holds dictionary_blocks distinct code blocks.  SELL8V: `sell` IS the   */
+    int64_t dictionary_blocks;      /* pool (no per-slice storage left); SELL8: `sell` keeps the values, slice-major           */
 } vexhip_spmat_info;
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int format, int flags, vexhip_spmat **out);

@@ -285,6 +285,19 @@ TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp
             CHECK_SMALL(a[i] - want2[i], 1e-10 * 12 * h2);
             CHECK_SMALL(b[i] - want2[i], 1e-10 * 12 * h2);
         }
+        // the same pattern with a different value in every entry: diagonal codes + stored values; the code part of the
+        // slices is pooled, the values are read where they are
+        for (size_t k = 0; k < val2.size(); ++k) val2[k] *= 1.0 + 1e-6 * (double)(k % 100003);
+        vex::SpMat<double, unsigned> E(queue, N2, N2, row2.data(), col2.data(), val2.data());
+        CHECK(E.storage_info(0).format == VEXHIP_SPMAT_SELL8 && E.storage_info(0).dictionary_blocks > 0 && E.storage_info(0).code_pool != nullptr);
+        DY = E * DX;
+        DZ = vex::make_inline(E * DX);
+        vex::copy(DY, a); vex::copy(DZ, b);
+        auto want3 = host_spmv(row2, col2, val2, x2);
+        for (size_t i = 0; i < N2; ++i) {
+            CHECK_SMALL(a[i] - want3[i], 1e-10 * 13 * h2);
+            CHECK_SMALL(b[i] - want3[i], 1e-10 * 13 * h2);
+        }
     }
 }
 

@@ -601,16 +601,20 @@ def test_slice_dictionary_function(T):
     import ctypes
     torch, L = T.torch, T.L
     rng = np.random.default_rng(5)
-    for ns, words, kinds, cap in ((1, 8, 1, 4), (200, 2048, 3, 8), (777, 96, 8, 8), (300, 64, 9, 8), (64, 512, 64, 128)):
+    # (slices, words compared per slice, words between slices, distinct patterns, capacity)
+    for ns, words, stride, kinds, cap in ((1, 8, 8, 1, 4), (200, 2048, 2048, 3, 8), (777, 96, 96, 8, 8), (300, 64, 64, 9, 8),
+                                          (64, 512, 512, 64, 128), (500, 256, 2048, 5, 8)):
         patterns = rng.integers(0, 2 ** 32, size=(kinds, words), dtype=np.uint64).astype(np.uint32)
         if kinds > 1:
             patterns[1] = patterns[0]; patterns[1, -1] ^= 1                       # two patterns that differ in ONE bit of the last word
         which = rng.integers(0, kinds, size=ns); which[:min(ns, kinds)] = np.arange(min(ns, kinds))
-        buf = T.up(patterns[which].view(np.int32))
+        full = rng.integers(0, 2 ** 32, size=(ns, stride), dtype=np.uint64).astype(np.uint32)   # what follows the compared part differs everywhere
+        full[:, :words] = patterns[which]
+        buf = T.up(full.view(np.int32))
         blocks = torch.full((ns,), -7, dtype=torch.int32, device=T.dev)
         pool = torch.zeros((cap, words), dtype=torch.int32, device=T.dev)
         nb = ctypes.c_int64(-5)
-        L.slice_dictionary(0, None, ns, words * 4, ctypes.c_void_p(buf.data_ptr()), cap, ctypes.c_void_p(blocks.data_ptr()),
+        L.slice_dictionary(0, None, ns, stride * 4, words * 4, ctypes.c_void_p(buf.data_ptr()), cap, ctypes.c_void_p(blocks.data_ptr()),
                            ctypes.c_void_p(pool.data_ptr()), ctypes.byref(nb))
         distinct = len(np.unique(which))
         if distinct > cap:
@@ -661,8 +665,27 @@ def test_spmat_slice_dictionary_is_bit_identical(T, oracle, built_lib, n):
         assert np.array_equal(yc.cpu().numpy(), want)
     finally:
         T.L.spmv_sell8_set_variant(0)
-    # stored values (variable coefficients): nothing to pool; fewer than 64 slices: not tried
-    p2, c2, v2 = oracle.diffusion3d(32, 7)
-    assert T.ops.SpMat(T.up(p2), T.up(c2), T.up(v2)).dictionary_blocks == 0
+    # stored values (variable coefficients): the CODE part of the slices is pooled, the values stay in the slices
+    p2, c2, v2 = oracle.diffusion3d(n, 7)
+    C = T.ops.SpMat(T.up(p2), T.up(c2), T.up(v2)); D = T.ops.SpMat(T.up(p2), T.up(c2), T.up(v2), dictionary=False)
+    assert C.storage == "sell8" and D.storage == "sell8" and D.dictionary_blocks == 0
+    if n == 64:
+        assert 1 <= C.dictionary_blocks <= 16 and C.matrix_bytes() < D.matrix_bytes()
+    want2 = oracle.spmv_csr(p2, c2, v2, x)
+    for alpha, append in ((1.0, False), (0.5, True)):
+        ya, yb = T.up(y0.copy()), T.up(y0.copy())
+        C.apply(T.up(x), ya, alpha, append); D.apply(T.up(x), yb, alpha, append)
+        assert torch.equal(ya, yb)
+        assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want2) if append else alpha * want2)
+    C.apply_multi(xs, ya_ := [torch.empty(N, dtype=torch.float64, device=T.dev) for _ in range(3)])
+    for k in range(3):
+        assert np.array_equal(ya_[k].cpu().numpy(), oracle.spmv_csr(p2, c2, v2, xs[k].cpu().numpy()))
+    T.L.spmv_sell8_set_variant(1)
+    try:
+        yc = torch.empty(N, dtype=torch.float64, device=T.dev); C.apply(T.up(x), yc)
+        assert np.array_equal(yc.cpu().numpy(), want2)
+    finally:
+        T.L.spmv_sell8_set_variant(0)
+    # fewer than 64 slices: not tried
     p3, c3, v3 = oracle.poisson3d(16)
     assert T.ops.SpMat(T.up(p3), T.up(c3), T.up(v3)).dictionary_blocks == 0

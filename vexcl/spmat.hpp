@@ -311,7 +311,7 @@ struct inline_spmv : expression_base {
         c.src.begin_function_parameters();
         c.src.parameter("long", "ell_w");
         c.src.parameter("const char *", "sell"); c.src.parameter("const int *", "deltas");
-        c.src.parameter("const " + V + " *", "values"); c.src.parameter("const int *", "blocks");
+        c.src.parameter("const " + V + " *", "values"); c.src.parameter("const int *", "blocks"); c.src.parameter("const char *", "pool");
         c.src.parameter("const int *", "csr_row"); c.src.parameter("const int *", "csr_col");
         c.src.parameter("const " + V + " *", "csr_val"); c.src.parameter("const " + V + " *", "in");
         c.src.parameter("ulong", "i");
@@ -334,7 +334,7 @@ struct inline_spmv : expression_base {
         c.src.open("{");
         c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
         c.src.new_line() << "const char *slice = sell + (i >> 9) * (wp * 1024 + ell_w * 512 * sizeof(" << V << "));";
-        c.src.new_line() << "const uint *cw = (const uint *)slice + ((i & 511) >> 1);";
+        c.src.new_line() << "const uint *cw = (const uint *)(blocks ? pool + (long)blocks[i >> 9] * (wp * 1024) : slice) + ((i & 511) >> 1);";
         c.src.new_line() << "const " << V << " *ell_val = (const " << V << " *)(slice + wp * 1024) + (i & 511);";
         c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
         c.src.open("{");
@@ -366,13 +366,14 @@ struct inline_spmv : expression_base {
         c.src.parameter("long", name + "_ell_w");
         c.src.parameter("const char *", name + "_sell"); c.src.parameter("const int *", name + "_deltas");
         c.src.parameter("const " + V + " *", name + "_values"); c.src.parameter("const int *", name + "_blocks");
+        c.src.parameter("const char *", name + "_pool");
         c.src.parameter("const int *", name + "_csr_row"); c.src.parameter("const int *", name + "_csr_col");
         c.src.parameter("const " + V + " *", name + "_csr_val"); c.src.parameter("const " + V + " *", name + "_vec");
     }
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
-        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, " << n << "_blocks, "
+        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, " << n << "_blocks, " << n << "_pool, "
               << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, idx)";
     }
     void set_args(arg_context &a) const {
@@ -384,6 +385,7 @@ struct inline_spmv : expression_base {
         a.krn.push_arg(static_cast<const int *>(L.ndeltas > 0 ? L.deltas : nullptr));
         a.krn.push_arg(static_cast<const T *>(L.nvalues > 0 ? L.values : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.slice_blocks));
+        a.krn.push_arg(static_cast<const char *>(L.code_pool));
         a.krn.push_arg(static_cast<const int *>(csr_rows ? L.csr_ptr : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_col)); a.krn.push_arg(static_cast<const T *>(L.csr_val));
         a.krn.push_arg(static_cast<const T *>(x(a.device).raw()));

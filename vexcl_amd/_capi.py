@@ -62,7 +62,8 @@ class SpMatInfo(ctypes.Structure):
                 ("tail_nnz", ctypes.c_int64), ("sell_bytes", ctypes.c_int64), ("matrix_bytes", ctypes.c_int64),
                 ("sell", ctypes.c_void_p), ("deltas", ctypes.c_void_p), ("values", ctypes.c_void_p),
                 ("csr_ptr", ctypes.c_void_p), ("csr_col", ctypes.c_void_p), ("csr_val", ctypes.c_void_p),
-                ("traversal", Traversal), ("slice_blocks", ctypes.c_void_p), ("dictionary_blocks", ctypes.c_int64)]
+                ("traversal", Traversal), ("slice_blocks", ctypes.c_void_p), ("code_pool", ctypes.c_void_p),
+                ("dictionary_blocks", ctypes.c_int64)]
 
 
 SPMAT_AUTO, SPMAT_SELL8V, SPMAT_SELL8, SPMAT_SELL, SPMAT_CSR = range(5)
@@ -141,7 +142,11 @@ _PROTOS = {
     "vexhip_spmv_sell8v_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8v_dict_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8v_dict_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
-    "vexhip_slice_dictionary": (None, [c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64)]),
+    "vexhip_slice_dictionary": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64)]),
+    "vexhip_spmv_sell8_dict_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmv_sell8_dict_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmm_sell8_dict_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
+    "vexhip_spmm_sell8_dict_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8v_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmat_create_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
     "vexhip_spmat_create_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256)
 void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
         const char *__restrict__ buf, const int *__restrict__ deltas,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks)
 {
     __shared__ int s_delta[256];
     s_delta[threadIdx.x] = deltas[threadIdx.x];
@@ -72,7 +72,8 @@ void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w
     const int w = W > 0 ? W : ell_w;
     const int wp = (w + 1) / 2;
     const char *slice = buf + s * slice_bytes(w, sizeof(V));
-    const unsigned *cw = reinterpret_cast<const unsigned *>(slice) + t;
+    // slice dictionary (below): the codes of slice s are block blocks[s] of the pool; the values stay where they are
+    const unsigned *cw = reinterpret_cast<const unsigned *>(blocks ? pool + (long long)blocks[s] * ((long long)wp * 1024) : slice) + t;
     const V *vp = reinterpret_cast<const V *>(slice + (long long)wp * 1024) + 2 * t;
     typedef typename vec2<V>::type V2;
 
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256)
 void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
         const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const int *__restrict__ blocks)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks)
 {
     constexpr int WP = (W + 1) / 2;
     constexpr long long SLICE = VCODED ? (long long)WP * 2048 : ((long long)WP * 1024 + (long long)W * S8_ROWS * (long long)sizeof(V));
@@ -379,10 +380,11 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
     const long long sl = s < 0 ? 0 : s;                       // holes of the strip order: load slice 0, store nothing
     const int t = threadIdx.x;
     const long long i = sl * S8_ROWS + 2 * t;
-    // DICT (slice dictionary, below): slice s is stored as block blocks[s] of a small pool of DISTINCT blocks; the pool lives
-    // in L1 / L2, so its loads are plain (cached) ones -- the streamed layout keeps its non-temporal loads
-    const long long sb = DICT ? (long long)blocks[sl] : sl;
-    const unsigned *cw = reinterpret_cast<const unsigned *>(buf + sb * SLICE) + t;
+    // DICT (slice dictionary, below): the CODES of slice s are block blocks[s] of a small pool of distinct code blocks; the
+    // pool lives in L1 / L2, so its loads are plain (cached) ones -- streamed codes keep their non-temporal loads.  Stored
+    // values (VCODED = false) stay in the slice.
+    constexpr long long CODE_BYTES = VCODED ? (long long)WP * 2048 : (long long)WP * 1024;
+    const unsigned *cw = reinterpret_cast<const unsigned *>(DICT ? pool + (long long)blocks[sl] * CODE_BYTES : buf + sl * SLICE) + t;
     unsigned c[WP], vc[VCODED ? WP : 1];
 #pragma unroll
     for (int jp = 0; jp < WP; ++jp) {
@@ -648,11 +650,13 @@ int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col,
 
 template <typename V>
 int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w, const void *buf, const int *deltas,
-        const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr)
+        const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr,
+        const void *pool_ = nullptr, const int *blocks = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL8 geometry");
     if (n == 0) return 0;
     VEXHIP_REQUIRE(buf && deltas && x && y && (reinterpret_cast<uintptr_t>(buf) & 15) == 0, "SELL8 buffer must be 16-byte aligned");
+    VEXHIP_REQUIRE((pool_ == nullptr) == (blocks == nullptr), "code pool and slice numbers go together");
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
     const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
@@ -661,14 +665,16 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (ordered) t8 = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
-    const char *b = static_cast<const char *>(buf);
-#define CASE(W) case W: if (g_sell8_variant == 0) sell8_pair_kernel<V, W, false, false><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, t8, nullptr); \
-        else sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8); break;
+    const char *b = static_cast<const char *>(buf), *pool = static_cast<const char *>(pool_);
+#define PAIR(W, DICT) sell8_pair_kernel<V, W, false, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, t8, pool, blocks)
+#define CASE(W) case W: if (g_sell8_variant == 0) { if (blocks) PAIR(W, true); else PAIR(W, false); } \
+        else sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8, pool, blocks); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
-        default: sell8_kernel<V, 0><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8);
+        default: sell8_kernel<V, 0><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8, pool, blocks);
     }
 #undef CASE
+#undef PAIR
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -753,7 +759,7 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     const trav_dev t8 = make_traversal(tr, ns, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
-#define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, blocks)
+#define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, b, blocks)
 #define CASE(W) case W: if (g_sell8_variant == 0 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \
         else sell8v_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8, blocks); break;
     switch (w) {
@@ -779,11 +785,11 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
 // blocks): 0.764 -> 0.641 ms with cached loads, 0.808 ms with the non-temporal loads of the streamed layout.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void slice_hash_kernel(long long nslices, long long slice_words, const unsigned *__restrict__ buf, unsigned long long *__restrict__ hash)
+void slice_hash_kernel(long long nslices, long long stride_words, long long slice_words, const unsigned *__restrict__ buf, unsigned long long *__restrict__ hash)
 {
     __shared__ unsigned long long s_part[4];
     for (long long s = blockIdx.x; s < nslices; s += gridDim.x) {
-        const unsigned *w = buf + s * slice_words;
+        const unsigned *w = buf + s * stride_words;
         unsigned long long h = 0;
         for (long long k = threadIdx.x; k < slice_words; k += 256) {
             unsigned long long z = ((unsigned long long)w[k] + 0x9E3779B97F4A7C15ull) * (2 * (unsigned long long)k + 0xD1B54A32D192ED03ull);
@@ -799,13 +805,13 @@ void slice_hash_kernel(long long nslices, long long slice_words, const unsigned 
 }
 
 __global__ __launch_bounds__(256)
-void slice_verify_kernel(long long nslices, long long slice_words, const unsigned *__restrict__ buf,
+void slice_verify_kernel(long long nslices, long long stride_words, long long slice_words, const unsigned *__restrict__ buf,
         const int *__restrict__ blocks, const int *__restrict__ reps, int *__restrict__ mismatch)
 {
     for (long long s = blockIdx.x; s < nslices; s += gridDim.x) {
         const long long r = reps[blocks[s]];
         if (r == s) continue;
-        const unsigned *a = buf + s * slice_words, *b = buf + r * slice_words;
+        const unsigned *a = buf + s * stride_words, *b = buf + r * stride_words;
         bool bad = false;
         for (long long k = threadIdx.x; k < slice_words; k += 256) bad |= a[k] != b[k];
         if (bad) atomicExch(mismatch, 1);
@@ -813,28 +819,29 @@ void slice_verify_kernel(long long nslices, long long slice_words, const unsigne
 }
 
 __global__ __launch_bounds__(256)
-void slice_pool_kernel(long long slice_words, const unsigned *__restrict__ buf, const int *__restrict__ reps, unsigned *__restrict__ pool)
+void slice_pool_kernel(long long stride_words, long long slice_words, const unsigned *__restrict__ buf, const int *__restrict__ reps, unsigned *__restrict__ pool)
 {
-    const unsigned *a = buf + (long long)reps[blockIdx.x] * slice_words;
+    const unsigned *a = buf + (long long)reps[blockIdx.x] * stride_words;
     unsigned *o = pool + (long long)blockIdx.x * slice_words;
     for (long long k = threadIdx.x; k < slice_words; k += 256) o[k] = a[k];
 }
 
-int slice_dictionary(int dev, void *stream, int64_t nslices, int64_t slice_bytes, const void *buf, int64_t max_blocks,
+int slice_dictionary(int dev, void *stream, int64_t nslices, int64_t stride_bytes, int64_t slice_bytes, const void *buf, int64_t max_blocks,
         int32_t *blocks, void *pool, int64_t *nblocks)
 {
     VEXHIP_REQUIRE(nblocks, "NULL output");
     *nblocks = -1;
-    VEXHIP_REQUIRE(nslices >= 0 && slice_bytes > 0 && slice_bytes % 4 == 0 && max_blocks >= 1 && max_blocks < (1ll << 31), "bad dictionary geometry");
+    VEXHIP_REQUIRE(nslices >= 0 && slice_bytes > 0 && slice_bytes % 4 == 0 && stride_bytes >= slice_bytes && stride_bytes % 4 == 0 &&
+            max_blocks >= 1 && max_blocks < (1ll << 31), "bad dictionary geometry");
     if (nslices == 0) { *nblocks = 0; return 0; }
     VEXHIP_REQUIRE(buf && blocks && pool, "NULL argument");
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
-    const long long words = slice_bytes / 4;
+    const long long words = slice_bytes / 4, stride = stride_bytes / 4;
     unsigned long long *dh = nullptr;
     VEXHIP_TRY(hipMalloc(&dh, sizeof(unsigned long long) * (size_t)nslices));
     const int grid = (int)std::min<int64_t>(nslices, (int64_t)info(dev).cus * 32);
-    slice_hash_kernel<<<grid, 256, 0, s>>>(nslices, words, static_cast<const unsigned *>(buf), dh);
+    slice_hash_kernel<<<grid, 256, 0, s>>>(nslices, stride, words, static_cast<const unsigned *>(buf), dh);
     std::vector<unsigned long long> h((size_t)nslices);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), dh, sizeof(unsigned long long) * (size_t)nslices, hipMemcpyDeviceToHost, s);
@@ -870,8 +877,8 @@ int slice_dictionary(int dev, void *stream, int64_t nslices, int64_t slice_bytes
     if (e == hipSuccess) e = hipMemcpyAsync(dreps, reps.data(), sizeof(int32_t) * reps.size(), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(dflag, 0, sizeof(int), s);
     if (e == hipSuccess) {
-        slice_verify_kernel<<<grid, 256, 0, s>>>(nslices, words, static_cast<const unsigned *>(buf), blocks, dreps, dflag);
-        slice_pool_kernel<<<(unsigned)reps.size(), 256, 0, s>>>(words, static_cast<const unsigned *>(buf), dreps, static_cast<unsigned *>(pool));
+        slice_verify_kernel<<<grid, 256, 0, s>>>(nslices, stride, words, static_cast<const unsigned *>(buf), blocks, dreps, dflag);
+        slice_pool_kernel<<<(unsigned)reps.size(), 256, 0, s>>>(stride, words, static_cast<const unsigned *>(buf), dreps, static_cast<unsigned *>(pool));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, s);
@@ -957,9 +964,18 @@ int vexhip_spmv_sell8v_dict_f32_i32(int dev, void *stream, int64_t n, float alph
         const float *x, float *y, const vexhip_traversal *traversal)
 { return spmv_sell8v<float>(dev, stream, n, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks); }
 
-int vexhip_slice_dictionary(int dev, void *stream, int64_t nslices, int64_t slice_bytes, const void *buf, int64_t max_blocks,
+int vexhip_slice_dictionary(int dev, void *stream, int64_t nslices, int64_t stride_bytes, int64_t slice_bytes, const void *buf, int64_t max_blocks,
         int32_t *blocks, void *pool, int64_t *nblocks)
-{ return slice_dictionary(dev, stream, nslices, slice_bytes, buf, max_blocks, blocks, pool, nblocks); }
+{ return slice_dictionary(dev, stream, nslices, stride_bytes, slice_bytes, buf, max_blocks, blocks, pool, nblocks); }
+
+int vexhip_spmv_sell8_dict_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *x, double *y, const vexhip_traversal *traversal)
+{ return spmv_sell8<double>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal, pool, blocks); }
+int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *x, float *y, const vexhip_traversal *traversal)
+{ return spmv_sell8<float>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal, pool, blocks); }
 
 int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
         int rows_per_block, vexhip_traversal *traversal)

@@ -22,7 +22,9 @@ struct spmat {
     int format = VEXHIP_SPMAT_CSR;
     int64_t n = 0, nnz = 0, ell_w = 0, tail = 0;
     void *sell = nullptr; int64_t sell_bytes = 0;
-    int32_t *blocks = nullptr; int64_t dict_blocks = 0;                         // slice dictionary (SELL8V): sell = pool of distinct slices
+    // slice dictionary (sell8.hip): the codes of slice s are block blocks[s] of `pool` (dict_blocks distinct code blocks of
+    // code_bytes each).  SELL8V: the slices are nothing but codes -- `sell` is freed; SELL8: `sell` keeps the values.
+    int32_t *blocks = nullptr; void *pool = nullptr; int64_t dict_blocks = 0, code_bytes = 0;
     int32_t *deltas = nullptr; int ndeltas = -1;
     void *values = nullptr; int nvalues = -1;
     int32_t *csr_ptr = nullptr, *csr_col = nullptr; void *csr_val = nullptr;   // CSR tail, or the whole matrix (format CSR)
@@ -41,6 +43,7 @@ void release(spmat *A) {
     (void)hipSetDevice(A->dev);
     if (A->sell) (void)hipFree(A->sell);
     if (A->blocks) (void)hipFree(A->blocks);
+    if (A->pool) (void)hipFree(A->pool);
     if (A->deltas) (void)hipFree(A->deltas);
     if (A->values) (void)hipFree(A->values);
     if (A->owns_csr) {
@@ -64,6 +67,10 @@ template <> struct api<double> {
     static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const double *v, int64_t w, void *b) { return vexhip_sell_fill_f64_i32(d, s, n, p, c, v, w, b); }
     static int mul_v(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_f64_i32(d, s, n, a, ap, w, b, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
+    static int mul_dd(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8_dict_f64_i32(d, s, n, a, ap, w, b, pl, bl, dl, cp, cc, (const double *)cv, x, y, t); }
+    static int mm_dd(int d, void *s, int64_t n, int k, double a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *const *x, double *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8_dict_f64_i32(d, s, n, k, a, ap, w, b, pl, bl, dl, cp, cc, (const double *)cv, x, y, t); }
     static int mul_vd(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_dict_f64_i32(d, s, n, a, ap, w, b, bl, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
     static int mm_vd(int d, void *s, int64_t n, int k, double a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *const *x, double *const *y, const vexhip_traversal *t)
@@ -93,6 +100,10 @@ template <> struct api<float> {
     static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const float *v, int64_t w, void *b) { return vexhip_sell_fill_f32_i32(d, s, n, p, c, v, w, b); }
     static int mul_v(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_f32_i32(d, s, n, a, ap, w, b, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
+    static int mul_dd(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8_dict_f32_i32(d, s, n, a, ap, w, b, pl, bl, dl, cp, cc, (const float *)cv, x, y, t); }
+    static int mm_dd(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
+    { return vexhip_spmm_sell8_dict_f32_i32(d, s, n, k, a, ap, w, b, pl, bl, dl, cp, cc, (const float *)cv, x, y, t); }
     static int mul_vd(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_dict_f32_i32(d, s, n, a, ap, w, b, bl, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
     static int mm_vd(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
@@ -110,6 +121,33 @@ template <> struct api<float> {
     static int mm_s(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
     { return vexhip_spmm_sell_f32_i32(d, s, n, k, a, ap, w, b, cp, cc, (const float *)cv, x, y, t); }
 };
+
+// Slice dictionary (sell8.hip): do the code blocks of the slices repeat?  Up to 128 distinct blocks (<= 1 MiB for width 7-8:
+// L1 / L2 resident) replace the code stream; anything less regular keeps it.  whole_slice: the slice is nothing but codes
+// (SELL8V) -- the per-slice storage is released; otherwise (SELL8) the values stay where they are.
+int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool whole_slice)
+{
+    const int64_t ns = (A->n + 511) / 512, stride = A->sell_bytes / ns;
+    if ((flags & VEXHIP_SPMAT_NO_DICTIONARY) || ns < 64 || A->ell_w > 8) return 0;
+    hipStream_t s = as_stream(stream);
+    const int64_t cap = 128;
+    void *big = nullptr; int64_t nb = -1;
+    if (int rc = dmalloc(&A->blocks, (size_t)ns)) return rc;
+    VEXHIP_TRY(hipMalloc(&big, (size_t)(cap * code_bytes)));
+    int rc = vexhip_slice_dictionary(A->dev, stream, ns, stride, code_bytes, A->sell, cap, A->blocks, big, &nb);
+    if (rc == 0 && nb > 0) {
+        hipError_t e = hipMalloc(&A->pool, (size_t)(nb * code_bytes));          // the pool at its real size
+        if (e == hipSuccess) e = hipMemcpyAsync(A->pool, big, (size_t)(nb * code_bytes), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(big);
+        if (e != hipSuccess) return check(e, __FILE__, __LINE__);
+        A->dict_blocks = nb; A->code_bytes = code_bytes;
+        if (whole_slice) { (void)hipFree(A->sell); A->sell = nullptr; A->sell_bytes = 0; }
+        return 0;
+    }
+    (void)hipFree(big); (void)hipFree(A->blocks); A->blocks = nullptr;
+    return rc;
+}
 
 template <typename V>
 int build(spmat *A, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const V *val, int format, int flags)
@@ -180,35 +218,14 @@ int build(spmat *A, void *stream, int64_t n, const int32_t *ptr, const int32_t *
             A->sell_bytes = vexhip_sell8v_bytes(n, w);
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
             if (int rc = F::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
-            // Slice dictionary (sell8.hip): do the slices repeat?  Up to 128 distinct 512-row blocks (<= 1 MiB for width 7-8:
-            // L2-resident) replace one block per slice; anything less regular keeps the streamed layout.
-            const int64_t ns = (n + 511) / 512, sb = A->sell_bytes / ns;
-            if (!(flags & VEXHIP_SPMAT_NO_DICTIONARY) && ns >= 64) {
-                const int64_t cap = 128;
-                void *pool = nullptr; int64_t nb = -1;
-                if (int rc = dmalloc(&A->blocks, (size_t)ns)) return rc;
-                VEXHIP_TRY(hipMalloc(&pool, (size_t)(cap * sb)));
-                int rc = vexhip_slice_dictionary(dev, stream, ns, sb, A->sell, cap, A->blocks, pool, &nb);
-                if (rc == 0 && nb > 0) {
-                    void *small = nullptr;                                  // the pool at its real size; the full storage goes
-                    hipError_t e = hipMalloc(&small, (size_t)(nb * sb));
-                    if (e == hipSuccess) e = hipMemcpyAsync(small, pool, (size_t)(nb * sb), hipMemcpyDeviceToDevice, s);
-                    if (e == hipSuccess) e = hipStreamSynchronize(s);
-                    (void)hipFree(pool);
-                    if (e != hipSuccess) { if (small) (void)hipFree(small); return check(e, __FILE__, __LINE__); }
-                    (void)hipFree(A->sell);
-                    A->sell = small; A->dict_blocks = nb; A->sell_bytes = nb * sb + ns * 4;
-                } else {
-                    (void)hipFree(pool); (void)hipFree(A->blocks); A->blocks = nullptr;
-                    if (rc) return rc;
-                }
-            }
+            if (int rc = make_dictionary(A, stream, flags, A->sell_bytes / ((n + 511) / 512), true)) return rc;
         } else {
             if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
             A->format = VEXHIP_SPMAT_SELL8;
             A->sell_bytes = vexhip_sell8_bytes(n, w, (int)sizeof(V));
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
             if (int rc = F::d_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, A->sell, &A->trav)) return rc;
+            if (int rc = make_dictionary(A, stream, flags, ((w + 1) / 2) * 1024, false)) return rc;
         }
     } else {
         if (A->deltas) { (void)hipFree(A->deltas); A->deltas = nullptr; }
@@ -250,9 +267,11 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
     const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
     switch (A->format) {
         case VEXHIP_SPMAT_SELL8V:
-            if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+            if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
             return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
-        case VEXHIP_SPMAT_SELL8:  return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case VEXHIP_SPMAT_SELL8:
+            if (A->blocks) return F::mul_dd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+            return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL:   return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         default:                  return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
     }
@@ -272,9 +291,11 @@ int apply_multi(const spmat *A, void *stream, int k, V alpha, int append, const 
     const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
     switch (A->format) {
         case VEXHIP_SPMAT_SELL8V:
-            if (A->blocks) return F::mm_vd(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+            if (A->blocks) return F::mm_vd(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
             return F::mm_v(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
-        case VEXHIP_SPMAT_SELL8:  return F::mm_d(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case VEXHIP_SPMAT_SELL8:
+            if (A->blocks) return F::mm_dd(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+            return F::mm_d(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         default:                  return F::mm_s(A->dev, stream, A->n, k, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
     }
 }
@@ -313,13 +334,18 @@ int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
     o->format = A->format; o->value_type = A->value_type; o->device = A->dev;
     o->rows = A->n; o->nnz = A->nnz; o->ell_width = A->ell_w; o->tail_nnz = A->tail;
     o->ndeltas = A->ndeltas; o->nvalues = A->nvalues;
-    o->sell = A->sell; o->sell_bytes = A->sell_bytes; o->deltas = A->deltas; o->values = A->values;
+    // value-coded storage with a dictionary: the pool takes the place of the per-slice buffer (make_inline reads `sell`)
+    o->sell = A->sell ? A->sell : A->pool; o->sell_bytes = A->sell_bytes; o->deltas = A->deltas; o->values = A->values;
     o->csr_ptr = A->csr_ptr; o->csr_col = A->csr_col; o->csr_val = A->csr_val;
     o->traversal = A->trav;
-    o->slice_blocks = A->blocks; o->dictionary_blocks = A->dict_blocks;
+    o->slice_blocks = A->blocks; o->code_pool = A->pool; o->dictionary_blocks = A->dict_blocks;
     // bytes one product moves through HBM at least: the stored matrix + x once + y once (+ y read for "+=" not counted)
     const int64_t vb = A->value_type == VEXHIP_F64 ? 8 : 4;
     int64_t m = A->sell_bytes;
+    if (A->blocks) {                        // codes come from the pool: the per-slice code parts (if still stored) are not read
+        const int64_t ns = (A->n + 511) / 512;
+        m += A->dict_blocks * A->code_bytes + ns * 4 - (A->sell ? ns * A->code_bytes : 0);
+    }
     if (A->format == VEXHIP_SPMAT_CSR) m = A->nnz * (4 + vb) + (A->n + 1) * 4;
     else if (A->tail) m += A->tail * (4 + vb) + (A->n + 1) * 4;
     o->matrix_bytes = m;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256)
 void spmm_sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
         const char *__restrict__ buf, const int *__restrict__ deltas,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        rhs_set<V> io, trav_dev trav)
+        rhs_set<V> io, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks)
 {
     __shared__ int s_delta[256];
     s_delta[threadIdx.x] = deltas[threadIdx.x];
@@ -100,7 +100,8 @@ void spmm_sell8_kernel(long long n, long long nslices, V alpha, int append, int 
     const int w = W > 0 ? W : ell_w;
     const int wp = (w + 1) / 2;
     const char *slice = buf + s * ((long long)wp * 1024 + (long long)w * ROWS * sizeof(V));
-    const unsigned *cw = reinterpret_cast<const unsigned *>(slice) + t;
+    // slice dictionary (sell8.hip): codes from the pool of distinct code blocks, values from the slice
+    const unsigned *cw = reinterpret_cast<const unsigned *>(blocks ? pool + (long long)blocks[s] * ((long long)wp * 1024) : slice) + t;
     const V *vp = reinterpret_cast<const V *>(slice + (long long)wp * 1024) + 2 * t;
     typedef typename vec2<V>::type V2;
 
@@ -112,7 +113,7 @@ void spmm_sell8_kernel(long long n, long long nslices, V alpha, int append, int 
         constexpr int WP = (W + 1) / 2;
         unsigned c[WP]; V2 v[W];
 #pragma unroll
-        for (int jp = 0; jp < WP; ++jp) c[jp] = __builtin_nontemporal_load(cw + jp * 256);
+        for (int jp = 0; jp < WP; ++jp) c[jp] = blocks ? cw[jp * 256] : __builtin_nontemporal_load(cw + jp * 256);
 #pragma unroll
         for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * ROWS));
         int d[W];
@@ -289,12 +290,12 @@ void spmm_sell_kernel(long long n, long long nslices, V alpha, int append, int e
 template <typename V, int CODES, int NR>
 void launch(hipStream_t s, long long grid, long long n, long long ns, V alpha, int append, int w, const char *buf,
         const int *deltas, const V *values, const int *cp, const int *cc, const V *cv, const rhs_set<V> &io, const trav_dev &t,
-        const int *blocks)
+        const char *pool, const int *blocks)
 {
 #define LAUNCH(W)                                                                                              \
     do {                                                                                                       \
         if constexpr (CODES == 2) spmm_sell8v_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, values, cp, cc, cv, io, t, blocks); \
-        else if constexpr (CODES == 1) spmm_sell8_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, cp, cc, cv, io, t); \
+        else if constexpr (CODES == 1) spmm_sell8_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, deltas, cp, cc, cv, io, t, pool, blocks); \
         else spmm_sell_kernel<V, W, NR><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, w, buf, cp, cc, cv, io, t);               \
     } while (0)
     switch (w) {          // unrolled for the usual stencil widths (1-D, 2-D 5/9-point, 3-D 7-point); any other width loops
@@ -309,7 +310,7 @@ void launch(hipStream_t s, long long grid, long long n, long long ns, V alpha, i
 
 template <typename V, int CODES>
 int spmm(int dev, void *stream, int64_t n, int nrhs, V alpha, int append, int64_t w, const void *buf, const int *deltas, const V *values,
-        const int *cp, const int *cc, const V *cv, const V *const *x, V *const *y, const vexhip_traversal *tr, const int *blocks = nullptr)
+        const int *cp, const int *cc, const V *cv, const V *const *x, V *const *y, const vexhip_traversal *tr, const int *blocks = nullptr, const void *pool_ = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20) && nrhs >= 1, "bad SpMM geometry");
     if (n == 0) return 0;
@@ -322,16 +323,16 @@ int spmm(int dev, void *stream, int64_t n, int nrhs, V alpha, int append, int64_
     long long grid = 0;
     const trav_dev t = make_traversal(tr, ns, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
-    const char *b = static_cast<const char *>(buf);
+    const char *b = static_cast<const char *>(buf), *pool = static_cast<const char *>(pool_);
     for (int k0 = 0; k0 < nrhs; k0 += MAX_NR) {
         const int nr = nrhs - k0 < MAX_NR ? nrhs - k0 : MAX_NR;
         rhs_set<V> io;
         for (int k = 0; k < MAX_NR; ++k) { io.x[k] = x[k0 + (k < nr ? k : 0)]; io.y[k] = y[k0 + (k < nr ? k : 0)]; }
         switch (nr) {
-            case 1: launch<V, CODES, 1>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks); break;
-            case 2: launch<V, CODES, 2>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks); break;
-            case 3: launch<V, CODES, 3>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks); break;
-            default: launch<V, CODES, 4>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, blocks);
+            case 1: launch<V, CODES, 1>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, pool, blocks); break;
+            case 2: launch<V, CODES, 2>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, pool, blocks); break;
+            case 3: launch<V, CODES, 3>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, pool, blocks); break;
+            default: launch<V, CODES, 4>(s, grid, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, io, t, pool, blocks);
         }
         VEXHIP_LAUNCH_CHECK();
     }
@@ -374,6 +375,16 @@ int vexhip_spmm_sell8v_f32_i32(int dev, void *stream, int64_t n, int nrhs, float
         const void *buf, const int32_t *deltas, const float *values, const int32_t *cp, const int32_t *cc, const float *cv,
         const float *const *x, float *const *y, const vexhip_traversal *traversal)
 { return spmm<float, 2>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, values, cp, cc, cv, x, y, traversal); }
+
+int vexhip_spmm_sell8_dict_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t w,
+        const void *buf, const void *pool, const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *const *x, double *const *y, const vexhip_traversal *traversal)
+{ return spmm<double, 1>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, nullptr, cp, cc, cv, x, y, traversal, blocks, pool); }
+
+int vexhip_spmm_sell8_dict_f32_i32(int dev, void *stream, int64_t n, int nrhs, float alpha, int append, int64_t w,
+        const void *buf, const void *pool, const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *const *x, float *const *y, const vexhip_traversal *traversal)
+{ return spmm<float, 1>(dev, stream, n, nrhs, alpha, append, w, buf, deltas, nullptr, cp, cc, cv, x, y, traversal, blocks, pool); }
 
 int vexhip_spmm_sell8v_dict_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t w,
         const void *pool, const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *cp, const int32_t *cc, const double *cv,
