@@ -68,11 +68,16 @@ extern "C" __global__ void __launch_bounds__(256) k(long long n, long long ns, u
 #else
     for (int jp = 0; jp < WP; ++jp) { c[jp] = __builtin_nontemporal_load(cw + jp * 256); vc[jp] = __builtin_nontemporal_load(vw + jp * 256); }
 #endif
-#elif CODES == 2
+#elif CODES == 2 || CODES == 5
     { typedef unsigned u4 __attribute__((ext_vector_type(4)));
       // lane t: 16 bytes at t*16 of the first 4 KiB (its four diagonal-code words) and of the second 4 KiB (value codes)
+#if CODES == 5   // ... of one of 8 fixed slices, plain (cached) loads: a lane-major pool of distinct code blocks
+      const u4 *cw4 = (const u4 *)(buf + (300 * 512 + 300 + (s & 7)) * (WP * 2048ll)) + t;
+      const u4 a4 = cw4[0], b4 = cw4[256];
+#else
       const u4 *cw4 = (const u4 *)(buf + s * (WP * 2048ll)) + t;
       const u4 a4 = __builtin_nontemporal_load(cw4), b4 = __builtin_nontemporal_load(cw4 + 256);
+#endif
       const unsigned never = (a4.x == 0xdeadbeefu) + (a4.y == 0xdeadbeefu) + (a4.z == 0xdeadbeefu) + (a4.w == 0xdeadbeefu)
                            + (b4.x == 0xdeadbeefu) + (b4.y == 0xdeadbeefu) + (b4.z == 0xdeadbeefu) + (b4.w == 0xdeadbeefu);
       c[0] = 0x01010000u + never; c[1] = 0x03030202u; c[2] = 0x05050404u; c[3] = 0xffff0606u;
@@ -319,6 +324,9 @@ variants = [
     ("seven 16-byte gathers, codes read from 8 fixed slices (L2-resident code blocks)", dict(GATHER=3, CODES=3)),
     ("full, codes read from 8 fixed slices (L2-resident code blocks)", dict(CODES=3)),
     ("seven 16-byte gathers, codes from 8 fixed slices with plain (L1-cached) loads", dict(GATHER=3, CODES=4)),
+    ("seven 16-byte gathers, codes from 8 fixed slices, two cached 16-byte loads per lane", dict(GATHER=3, CODES=5)),
+    ("+-1 taps by lane shuffle, four far gathers, codes from 8 fixed slices with cached loads", dict(GATHER=5, CODES=4)),
+    ("+-1 taps by lane shuffle, four far gathers, codes two cached 16-byte loads", dict(GATHER=5, CODES=5)),
 ]
 res = []
 mods = []

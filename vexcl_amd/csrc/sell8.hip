@@ -346,6 +346,9 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
 // d, d+1, d+2 -- the -1 / 0 / +1 entries of a stencil row -- need x[i+d .. i+d+3], which the loads of the OUTER two
 // columns already hold, so the middle load was skipped per wave (one gather in seven).  Bit-identical, but 0.68 -> 0.84 ms:
 // the bookkeeping (per-column ballots, the raw pairs kept apart from the masked values) costs far more than the load.
+// Also tried: the -1 / +1 columns taken from the centre column's load by lane shifts, the two wave-edge values by scalar
+// loads (two gathers in seven; the ablation harness promised 0.642 -> 0.593 ms): 4-5 % in this kernel before any of the
+// guards a correct version needs -- not pursued.
 // Per column a lane therefore does one unconditional 16-byte load when its codes are
 // {d, d}, {d, 255}, {255, d} or both padding (then from a harmless address), and
 // falls back to one 8-byte load per real entry otherwise (a rarely taken branch).
