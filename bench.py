@@ -136,7 +136,8 @@ def measure_traffic(grid, timeout=240):
                         if k in name:
                             key = k
                             if k == "sell8_pair_kernel":
-                                key += "_vcoded" if ("true" in name.split("sell8_pair_kernel")[1][:24] or ", 1>" in name.split("sell8_pair_kernel")[1][:24]) else "_values"
+                                targs = [a.strip() for a in name.split("sell8_pair_kernel<")[1].split(">")[0].split(",")]   # <V, W, VCODED, DICT>
+                                key += "_vcoded" if targs[2] in ("true", "1") else "_values"
                     if key:
                         res.setdefault(key, {}).setdefault(ctr, []).append(float(r["Counter_Value"]))
     except subprocess.TimeoutExpired:
@@ -440,6 +441,7 @@ def main():
                          "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s",
                          "frac": round(moved_rank / kern_s / 1e9 / HBM_PEAK_GBPS, 4),
+                         "dictionary_blocks": dict_blocks,
                          "bytes_per_launch": moved_rank,
                          "bytes_per_launch_what": "stored matrix (%d B: %s%s) + x once + y once" % (
                              matrix_bytes, storage, (", %d distinct 512-row code blocks + 4 B per slice" % dict_blocks) if dict_blocks else ""),
@@ -498,7 +500,9 @@ def main():
                 mv = V.matrix_bytes() + 16 * N
                 out["variable_coefficient"] = {
                     "workload": "7-point -div(k grad u) on %d^3, k different on every face: ~4 distinct values per row of the %d entries (vexhip_diffusion3d_strip_f64_i32)" % (n, nnz_total),
-                    "format": V.storage, "kernel": KERNEL_OF.get(V.storage, V.storage), "avg_launch_ms": round(tv, 5),
+                    "format": V.storage, "dictionary_blocks": V.dictionary_blocks,
+                    "kernel": ("sell8_pair_kernel<double, 7, false, true>" if (V.storage == "sell8" and V.dictionary_blocks) else KERNEL_OF.get(V.storage, V.storage)),
+                    "avg_launch_ms": round(tv, 5),
                     "gflops": round(2.0 * nnz_total / tv / 1e6, 1),
                     "roofline": {"bound": "hbm", "achieved": round(mv / tv / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": round(mv / tv / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": mv,

@@ -25,8 +25,9 @@ for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "sell8_pair_kernel" in k:
-            k = "sell8_pair_kernel_vcoded" if "true" in k.split("sell8_pair_kernel")[1][:24] else "sell8_pair_kernel_values"
-        for tag in ("sell8_pair_kernel_vcoded", "sell8_pair_kernel_values", "sell_pair_kernel", "csr_stream2_kernel", "sell8v_kernel", "sell8_kernel",
+            targs = [a.strip() for a in k.split("sell8_pair_kernel<")[1].split(">")[0].split(",")]          # <V, W, VCODED, DICT>
+            k = ("sell8_pair_kernel_vcoded" if targs[2] in ("true", "1") else "sell8_pair_kernel_values") + ("_dict" if targs[3] in ("true", "1") else "")
+        for tag in ("sell8_pair_kernel_vcoded_dict", "sell8_pair_kernel_values_dict", "sell8_pair_kernel_vcoded", "sell8_pair_kernel_values", "sell_pair_kernel", "csr_stream2_kernel", "sell8v_kernel", "sell8_kernel",
                     "sell_kernel", "csr_stream_kernel", "hell_kernel", "reduce_stage1"):
             if tag in k:
                 a = agg[tag][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
