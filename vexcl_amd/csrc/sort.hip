@@ -144,7 +144,10 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
     const long long wbase = base + (long long)wave * (kWave * KPT);
     const int nvalid = FULL ? TILE : (int)(n - base);
 
-    for (int i = t; i < RW * RADIX; i += RB) { (&L.hist[0][0])[i] = 0; s_match[i] = 0ull; }
+    for (int i = t; i < RW * RADIX; i += RB) {
+        (&L.hist[0][0])[i] = 0;
+        if constexpr (!ATOMIC_RANK) s_match[i] = 0ull;            // the match words are only used by the fallback ranking
+    }
 
     K key[KPT];
 #pragma unroll
