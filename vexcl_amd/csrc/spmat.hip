@@ -135,7 +135,7 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
     if (int rc = dmalloc(&A->blocks, (size_t)ns)) return rc;
     VEXHIP_TRY(hipMalloc(&big, (size_t)(cap * code_bytes)));
     int rc = vexhip_slice_dictionary(A->dev, stream, ns, stride, code_bytes, A->sell, cap, A->blocks, big, &nb);
-    if (rc == 0 && nb > 0) {
+    if (rc == 0 && nb > 0 && nb * 4 <= ns) {                                   // worth it only if the slices really repeat
         hipError_t e = hipMalloc(&A->pool, (size_t)(nb * code_bytes));          // the pool at its real size
         if (e == hipSuccess) e = hipMemcpyAsync(A->pool, big, (size_t)(nb * code_bytes), hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
