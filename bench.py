@@ -450,6 +450,15 @@ def main():
                          "traffic": None,
                          "avg_launch_ms": round(kern_s * 1e3, 5)},
         }
+        if storage == "sell8v" and dict_blocks:
+            # not HBM-bound any more: what the kernel pulls through L1 per product (ELL width 7: seven 16-byte x gathers per
+            # lane and row pair = 56 B/row, 16 B/row of codes from the pooled blocks, 8 B/row stored), against the L2 rate
+            l1_bytes = (56 + 16 + 8) * rows_rank
+            out["roofline"]["on_chip"] = {
+                "what": "bytes through L1 per launch: x gathers 56 B/row + pooled codes 16 B/row + y 8 B/row; HBM sees x and y once",
+                "bytes_per_launch": l1_bytes, "achieved": round(l1_bytes / kern_s / 1e9, 1), "peak_l2": 34500.0, "unit": "GB/s",
+                "frac_of_l2": round(l1_bytes / kern_s / 1e9 / 34500.0, 4),
+                "peak_source": "MI355X_MICROARCH.md: L2 ~34.5 TB/s aggregate"}
         if sustained:
             out["sustained"] = sustained
         if world > 1:
