@@ -484,6 +484,13 @@ int vexhip_spmv_ccsr_f64(int dev, void *stream, int64_t n, double alpha, int app
 int vexhip_spmv_ccsr_f32(int dev, void *stream, int64_t n, float alpha, int append, const uint32_t *idx, int64_t m,
         const uint32_t *row, const int32_t *col, const float *val, int64_t entries, int64_t far_offset,
         const float *x, float *y);
+/* CCSR -> CSR on the device (so that vex::SpMatCCSR can hand its operator to vexhip_spmat).  Two calls: with out_col = NULL
+ * it writes the row pointers ptr[n + 1] and *nnz; with out_col / out_val (nnz entries each) it fills them in table order
+ * (the CCSR product's summation order) and sets *nnz = -1 if an entry refers to a column outside [0, n), else 0.          */
+int vexhip_ccsr_to_csr_f64_i32(int dev, void *stream, int64_t n, const uint32_t *idx, const uint32_t *row, const int32_t *col, const double *val,
+        int32_t *ptr, int32_t *out_col, double *out_val, int64_t *nnz);
+int vexhip_ccsr_to_csr_f32_i32(int dev, void *stream, int64_t n, const uint32_t *idx, const uint32_t *row, const int32_t *col, const float *val,
+        int32_t *ptr, int32_t *out_col, float *out_val, int64_t *nnz);
 int vexhip_spmv_ccsr_set_rows_per_lane(int rows);    /* 0 (default): pair form, rows 2t and 2t+1 per lane with 16-byte x loads; 1, 2, 4, 8: rows per lane of the first form (A/B) */
 
 /* ---- stencil convolution (stencil.hpp:306-405 `slow_conv` / `fast_conv`) ----

@@ -198,6 +198,8 @@ _PROTOS = {
     "vexhip_sort": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp]),
     "vexhip_spmv_ccsr_f64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "vexhip_spmv_ccsr_set_rows_per_lane": (None, [c_int]),
+    "vexhip_ccsr_to_csr_f64_i32": (None, [c_int, c_vp, c_i64] + [c_vp] * 7 + [ctypes.POINTER(c_i64)]),
+    "vexhip_ccsr_to_csr_f32_i32": (None, [c_int, c_vp, c_i64] + [c_vp] * 7 + [ctypes.POINTER(c_i64)]),
     "vexhip_spmv_ccsr_f32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "vexhip_stencil_conv_f64": (None, [c_int, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_f64, c_f64]),
     "vexhip_stencil_conv_f32": (None, [c_int, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32]),

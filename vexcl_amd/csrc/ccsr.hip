@@ -264,6 +264,73 @@ int spmv_ccsr(int dev, void *stream, int64_t n, V alpha, int append, const uint3
     return launch_ccsr<V, 2>(st, n, alpha, append, idx, m, row, col, val, entries, s_big, x, y);
 }
 
+// ---- CCSR -> CSR on the device: row i becomes the table row idx[i] with its offsets made absolute.  vex::SpMatCCSR uses it
+//      to hand its operator to vexhip_spmat (diagonal / value codes + slice dictionary: the faster product for such matrices).
+__global__ __launch_bounds__(256)
+void ccsr_len_kernel(long long n, const unsigned *__restrict__ idx, const unsigned *__restrict__ row, int *__restrict__ ptr)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x)
+        ptr[i] = i < n ? (int)(row[idx[i] + 1] - row[idx[i]]) : 0;
+}
+
+template <typename V>
+__global__ __launch_bounds__(256)
+void ccsr_expand_kernel(long long n, const unsigned *__restrict__ idx, const unsigned *__restrict__ row,
+        const int *__restrict__ col, const V *__restrict__ val, const int *__restrict__ ptr, int *__restrict__ out_col, V *__restrict__ out_val,
+        int *__restrict__ out_of_range)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned p = idx[i];
+        long long o = ptr[i];
+        for (unsigned j = row[p], e = row[p + 1]; j < e; ++j, ++o) {
+            const long long c = i + col[j];
+            if (c < 0 || c >= n) atomicExch(out_of_range, 1);
+            out_col[o] = (int)c; out_val[o] = val[j];
+        }
+    }
+}
+
+template <typename V>
+int ccsr_to_csr(int dev, void *stream, int64_t n, const uint32_t *idx, const uint32_t *row, const int32_t *col, const V *val,
+        int32_t *ptr, int32_t *out_col, V *out_val, int64_t *nnz)
+{
+    VEXHIP_REQUIRE(n >= 0 && nnz, "bad argument");
+    *nnz = 0;
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(idx && row && ptr, "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const int grid = (int)std::min<int64_t>((n + 256) / 256, (int64_t)info(dev).cus * 32);
+    if (!out_col) {                       // phase 1: row pointers and the number of entries
+        ccsr_len_kernel<<<grid, 256, 0, s>>>(n, idx, row, ptr);
+        VEXHIP_LAUNCH_CHECK();
+        void *tmp = nullptr;
+        const size_t tb = vexhip_scan_tmp_bytes(VEXHIP_I32, n + 1);
+        if (tb) VEXHIP_TRY(hipMalloc(&tmp, tb));
+        const int zero = 0; int last = 0;
+        int rc = vexhip_scan(dev, stream, VEXHIP_I32, 1, &zero, ptr, ptr, n + 1, tmp);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(&last, ptr + n, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(s);
+        if (tmp) (void)hipFree(tmp);
+        if (rc) return rc;
+        VEXHIP_TRY(e);
+        VEXHIP_REQUIRE(last >= 0, "CCSR operator has 2^31 or more entries");
+        *nnz = last;
+        return 0;
+    }
+    VEXHIP_REQUIRE(col && val && out_val, "NULL argument");
+    int *flag = nullptr, h = 0;
+    VEXHIP_TRY(hipMalloc(&flag, sizeof(int)));
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e == hipSuccess) { ccsr_expand_kernel<V><<<grid, 256, 0, s>>>(n, idx, row, col, val, ptr, out_col, out_val, flag); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(flag);
+    VEXHIP_TRY(e);
+    *nnz = h ? -1 : 0;                    // -1: an entry refers to a column outside [0, n)
+    return 0;
+}
+
 } // namespace
 } // namespace vexhip
 
@@ -280,6 +347,13 @@ int vexhip_spmv_ccsr_f32(int dev, void *stream, int64_t n, float alpha, int appe
         const uint32_t *row, const int32_t *col, const float *val, int64_t entries, int64_t far_offset,
         const float *x, float *y)
 { return spmv_ccsr<float>(dev, stream, n, alpha, append, idx, m, row, col, val, entries, far_offset, x, y); }
+
+int vexhip_ccsr_to_csr_f64_i32(int dev, void *stream, int64_t n, const uint32_t *idx, const uint32_t *row, const int32_t *col, const double *val,
+        int32_t *ptr, int32_t *out_col, double *out_val, int64_t *nnz)
+{ return ccsr_to_csr<double>(dev, stream, n, idx, row, col, val, ptr, out_col, out_val, nnz); }
+int vexhip_ccsr_to_csr_f32_i32(int dev, void *stream, int64_t n, const uint32_t *idx, const uint32_t *row, const int32_t *col, const float *val,
+        int32_t *ptr, int32_t *out_col, float *out_val, int64_t *nnz)
+{ return ccsr_to_csr<float>(dev, stream, n, idx, row, col, val, ptr, out_col, out_val, nnz); }
 
 int vexhip_spmv_ccsr_set_rows_per_lane(int rpl) { g_ccsr_rpl = rpl; return 0; }
 
