@@ -689,3 +689,38 @@ def test_spmat_slice_dictionary_is_bit_identical(T, oracle, built_lib, n):
     # fewer than 64 slices: not tried
     p3, c3, v3 = oracle.poisson3d(16)
     assert T.ops.SpMat(T.up(p3), T.up(c3), T.up(v3)).dictionary_blocks == 0
+
+
+def test_ccsr_to_csr_expansion(T):
+    """vexhip_ccsr_to_csr_*: row i of the CSR matrix = table row idx[i] with absolute columns, entries in table order; a
+    column outside [0, n) is reported."""
+    import ctypes
+    torch, L = T.torch, T.L
+    rng = np.random.default_rng(11)
+    n = 5000
+    row = np.array([0, 1, 4, 4, 9], dtype=np.uint32)                     # 4 unique rows, one of them empty
+    col = np.array([0, -1, 0, 1, -3, -1, 0, 2, 3], dtype=np.int32)
+    val = rng.random(9)
+    idx = rng.integers(0, 4, size=n).astype(np.uint32)
+    idx[:3] = 0; idx[-3:] = 0                                            # rows whose offsets would leave [0, n) use the 1-entry row
+    d = lambda a: T.up(a.view(np.int32) if a.dtype == np.uint32 else a)
+    didx, drow, dcol, dval = d(idx), d(row), d(col), d(val)
+    ptr = torch.empty(n + 1, dtype=torch.int32, device=T.dev)
+    nnz = ctypes.c_int64(-1)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.ccsr_to_csr_f64_i32(0, None, n, p(didx), p(drow), p(dcol), p(dval), p(ptr), None, None, ctypes.byref(nnz))
+    lens = (row[idx + 1] - row[idx]).astype(np.int64)
+    want_ptr = np.concatenate([[0], np.cumsum(lens)])
+    assert nnz.value == want_ptr[-1] and np.array_equal(ptr.cpu().numpy(), want_ptr)
+    oc = torch.empty(nnz.value, dtype=torch.int32, device=T.dev); ov = torch.empty(nnz.value, dtype=torch.float64, device=T.dev)
+    bad = ctypes.c_int64(-5)
+    L.ccsr_to_csr_f64_i32(0, None, n, p(didx), p(drow), p(dcol), p(dval), p(ptr), p(oc), p(ov), ctypes.byref(bad))
+    assert bad.value == 0
+    wc = np.concatenate([np.arange(n)[i] + col[row[idx[i]]:row[idx[i] + 1]] for i in range(n)])
+    wv = np.concatenate([val[row[idx[i]]:row[idx[i] + 1]] for i in range(n)])
+    assert np.array_equal(oc.cpu().numpy(), wc) and np.array_equal(ov.cpu().numpy(), wv)
+    idx[0] = 3                                                           # row 0 with offset -3: column -3
+    L.ccsr_to_csr_f64_i32(0, None, n, p(d(idx)), p(drow), p(dcol), p(dval), p(ptr), None, None, ctypes.byref(nnz))
+    oc = torch.empty(nnz.value, dtype=torch.int32, device=T.dev); ov = torch.empty(nnz.value, dtype=torch.float64, device=T.dev)
+    L.ccsr_to_csr_f64_i32(0, None, n, p(d(idx)), p(drow), p(dcol), p(dval), p(ptr), p(oc), p(ov), ctypes.byref(bad))
+    assert bad.value == -1
