@@ -49,6 +49,32 @@ assert v.tolist() == [3.25, -1.0]
 g = torch.zeros(2, dtype=torch.float64, device=dev)
 L.allgather(comm, _capi.F64, (ctypes.c_void_p * 1)(v.data_ptr()), (ctypes.c_void_p * 1)(g.data_ptr()), 2, st); s.synchronize()
 assert g.tolist() == [3.25, -1.0]
+# one rank's product step with a REAL exchange (the rank's ghosts are elements of its own x, sent to itself): the share as one run
+# of consecutive elements (sent straight out of x) and as a permutation (packed by the gather kernel first)
+from vexcl_amd import ops
+rows, ng = 6000, 1500
+ptr = torch.arange(rows + 1, dtype=torch.int32, device=dev); col = torch.arange(rows, dtype=torch.int32, device=dev)
+loc = ops.SpMat(ptr, col, torch.full((rows,), 2.0, dtype=torch.float64, device=dev))                      # local part: 2 I
+rw = torch.arange(ng, dtype=torch.int32, device=dev) * 3                                                   # rows 0, 3, 6, ... reach one ghost each
+cp = torch.arange(ng + 1, dtype=torch.int32, device=dev); rc = torch.arange(ng, dtype=torch.int32, device=dev)
+rv = torch.full((ng,), 3.0, dtype=torch.float64, device=dev)
+x = torch.rand(rows, dtype=torch.float64, device=dev)
+cnts = (ctypes.c_int64 * 1)(ng)
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+for label, sidx in (("run", torch.arange(ng, device=dev) + 777), ("perm", torch.randperm(rows, device=dev)[:ng])):
+    sidx = sidx.to(torch.int32).contiguous()
+    sbuf = torch.zeros(ng, dtype=torch.float64, device=dev); gbuf = torch.zeros(ng, dtype=torch.float64, device=dev)
+    step = ctypes.c_void_p()
+    L.dist_spmv_create(comm, _capi.F64, rows, loc.handle, ng, p(rw), p(cp), p(rc), p(rv), ng, p(sidx), p(sbuf), cnts, ng, p(gbuf), cnts, ctypes.byref(step))
+    want = 2.0 * x
+    want[rw.long()] += 3.0 * x[sidx.long()]
+    y = torch.empty(rows, dtype=torch.float64, device=dev)
+    for _ in range(3):
+        L.dist_spmv_apply(step, ctypes.c_void_p(s.cuda_stream), 1.0, 0, p(x), p(y))
+    s.synchronize()
+    assert torch.equal(y, want), label
+    assert (float(sbuf.abs().sum()) == 0.0) == (label == "run"), label      # the run never touches the pack buffer
+    L.dist_spmv_destroy(step)
 L.comm_destroy(comm)
 print("rccl self ok")
 '''

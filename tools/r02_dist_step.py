@@ -36,7 +36,11 @@ cnt = rp[1:] - rp[:-1]
 rows_with = torch.nonzero(cnt > 0).flatten().to(torch.int32)
 cp = torch.zeros(rows_with.numel() + 1, dtype=torch.int32, device=dev); cp[1:] = torch.cumsum(cnt[rows_with.long()], 0).to(torch.int32)
 ng = int(ghosts.numel())
-send_idx = (ghosts % rows).to(torch.int32).contiguous()          # stand-in: this rank's own values travel to itself
+# stand-in: this rank's own values travel to itself.  Default: the two planes next to its boundaries (two runs for the ONE peer
+# it has here: packed by the gather kernel); "direct" on the command line: one run of consecutive elements -- what each of the two
+# neighbours of a plane partition gets -- which vexhip_dist_spmv sends straight out of x, without a pack kernel
+direct = "direct" in sys.argv[1:]
+send_idx = (torch.arange(ghosts.numel(), device=dev) if direct else ghosts % rows).to(torch.int32).contiguous()
 send_buf = torch.empty(ng, dtype=torch.float64, device=dev); ghost_buf = torch.zeros(ng, dtype=torch.float64, device=dev)
 del row_of, is_loc, ptr, col, val
 
@@ -49,7 +53,7 @@ L.dist_spmv_create(comm, _capi.F64, rows, loc.handle, rows_with.numel(), p(rows_
                    ng, p(send_idx), p(send_buf), cnts, ng, p(ghost_buf), cnts, ctypes.byref(step))
 x = ops.fill_hash(torch.empty(rows, dtype=torch.float64, device=dev), 42); y = torch.empty_like(x)
 s = torch.cuda.Stream(); sp = ctypes.c_void_p(s.cuda_stream)
-out = {"strip_rows": rows, "local_storage": loc.storage, "ghosts": ng, "remote_rows": int(rows_with.numel()),
+out = {"send": "one consecutive run, sent out of x" if direct else "two runs, packed", "strip_rows": rows, "local_storage": loc.storage, "ghosts": ng, "remote_rows": int(rows_with.numel()),
        "exchange_bytes_each_way": ng * 8}
 
 
@@ -98,4 +102,4 @@ for label, fn in (("remote part alone", lambda: rem.apply(ghost_buf, y, 1.0, Tru
     out[label] = {"device_us_per_step": round(e0.elapsed_time(e1) * 1e3 / 300, 2)}
     print(label, out[label], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/r02_dist_step.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r02_dist_step%s.json" % ("_direct" if direct else ""), "w"), indent=1)

@@ -145,6 +145,10 @@ struct dist_spmv {
     int64_t nsend = 0, nghost = 0;
     const int32_t *send_idx = nullptr; void *send_buf = nullptr, *ghost_buf = nullptr;
     std::vector<int64_t> send_counts, recv_counts;       // per peer rank
+    // every peer's share of x is ONE ascending run of consecutive elements (plane partitions: a boundary plane):
+    // send_first[peer] = its first element, the sends read x itself and no pack kernel runs
+    bool direct = false;
+    std::vector<int64_t> send_first;
     hipStream_t comm_stream = nullptr;
     hipEvent_t packed = nullptr, received = nullptr;
     // optional replay of the whole step from a hipGraph (same x, y, alpha, append, stream as at capture)
@@ -153,7 +157,8 @@ struct dist_spmv {
     const void *gx = nullptr; void *gy = nullptr; double galpha = 0; int gappend = 0; hipStream_t gstream = nullptr;
 };
 
-int exchange_one(comm *c, int slot, int dtype, const void *send, const int64_t *scount, void *recv, const int64_t *rcount, hipStream_t s) {
+int exchange_one(comm *c, int slot, int dtype, const void *send, const int64_t *scount, void *recv, const int64_t *rcount, hipStream_t s,
+        const int64_t *send_first = nullptr) {
     rccl_api &a = rccl();
     ncclDataType_t t;
     if (int rc = nccl_type(dtype, &t)) return rc;
@@ -163,11 +168,13 @@ int exchange_one(comm *c, int slot, int dtype, const void *send, const int64_t *
     for (int peer = 0; peer < c->world; ++peer) {
         const int64_t ns = scount[peer], nr = rcount[peer];
         static const bool self_over_rccl = std::getenv("VEXHIP_RCCL_SELF") != nullptr;      // tests: force ncclSend/ncclRecv to self
+        // send_first: `send` is the vector itself and this peer's share starts at element send_first[peer] (no packed buffer)
+        const char *src = static_cast<const char *>(send) + (send_first ? send_first[peer] : so) * (int64_t)b;
         if (peer == me && ns == nr && ns > 0 && !self_over_rccl) {
             // a rank's own share never crosses a link: device copy instead of a send/recv pair to itself
-            VEXHIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + ro * b, static_cast<const char *>(send) + so * b, (size_t)ns * b, hipMemcpyDeviceToDevice, s));
+            VEXHIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + ro * b, src, (size_t)ns * b, hipMemcpyDeviceToDevice, s));
         } else {
-            if (ns) NCCL_TRY(a.Send(static_cast<const char *>(send) + so * b, (size_t)ns, t, peer, c->comms[slot], s));
+            if (ns) NCCL_TRY(a.Send(src, (size_t)ns, t, peer, c->comms[slot], s));
             if (nr) NCCL_TRY(a.Recv(static_cast<char *>(recv) + ro * b, (size_t)nr, t, peer, c->comms[slot], s));
         }
         so += ns; ro += nr;
@@ -186,13 +193,15 @@ int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void
         // overwrites ghost_buf only after the previous step's remote part has read it (`consumed`, recorded on s).
         VEXHIP_TRY(hipEventRecord(D->packed, s));                         // "x is ready" (and, transitively, `consumed`)
         VEXHIP_TRY(hipStreamWaitEvent(D->comm_stream, D->packed, 0));
-        if (D->nsend) {
+        if (D->nsend && !D->direct) {
             int rc = f64 ? vexhip_gather_f64_i32(D->dev, D->comm_stream, D->nsend, D->send_idx, static_cast<const double *>(x), static_cast<double *>(D->send_buf))
                          : vexhip_gather_f32_i32(D->dev, D->comm_stream, D->nsend, D->send_idx, static_cast<const float *>(x), static_cast<float *>(D->send_buf));
             if (rc) return rc;
         }
         NCCL_TRY(rccl().GroupStart());
-        int rc = exchange_one(D->c, 0, D->dtype, D->send_buf, D->send_counts.data(), D->ghost_buf, D->recv_counts.data(), D->comm_stream);
+        // (direct: the sends read x; x stays untouched until `received`, which follows sends and receives alike)
+        int rc = D->direct ? exchange_one(D->c, 0, D->dtype, x, D->send_counts.data(), D->ghost_buf, D->recv_counts.data(), D->comm_stream, D->send_first.data())
+                           : exchange_one(D->c, 0, D->dtype, D->send_buf, D->send_counts.data(), D->ghost_buf, D->recv_counts.data(), D->comm_stream);
         ncclResult_t ge = rccl().GroupEnd();
         if (rc) return rc;
         NCCL_TRY(ge);
@@ -465,6 +474,26 @@ int vexhip_dist_spmv_create(vexhip_comm *hc, int dtype, int64_t rows, const vexh
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->packed, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->received, hipEventDisableTiming);
+    // are the shares single runs of consecutive elements?  (one read of the index list at set-up)
+    if (e == hipSuccess && nsend > 0 && !std::getenv("VEXHIP_DIST_PACK")) {
+        std::vector<int32_t> h((size_t)nsend);
+        e = hipMemcpy(h.data(), send_idx, sizeof(int32_t) * (size_t)nsend, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            D->send_first.assign(c->world, 0);
+            bool runs = true;
+            int64_t o = 0;
+            for (int p = 0; p < c->world && runs; ++p) {
+                const int64_t k = D->send_counts[p];
+                if (k) {
+                    D->send_first[p] = h[(size_t)o];
+                    for (int64_t j = 1; j < k && runs; ++j) runs = h[(size_t)(o + j)] == h[(size_t)o] + (int32_t)j;
+                    runs = runs && h[(size_t)o] >= 0 && (int64_t)h[(size_t)o] + k <= rows;
+                }
+                o += k;
+            }
+            D->direct = runs;
+        }
+    }
     if (e != hipSuccess) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return check(e, __FILE__, __LINE__); }
     *out = reinterpret_cast<vexhip_dist_spmv *>(D);
     return 0;
