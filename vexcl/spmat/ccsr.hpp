@@ -79,10 +79,11 @@ struct SpMatCCSR {
         if (bad) return;
         vexhip_spmat *h = nullptr;
         backend::check(spmat_create(dev, queue.raw(), (int64_t)n, ptr.raw(), ccol.raw(), cval.raw(), &h));
+        std::shared_ptr<vexhip_spmat> owner(h, [](vexhip_spmat *p) { vexhip_spmat_destroy(p); });
         vexhip_spmat_info info;
         backend::check(vexhip_spmat_get_info(h, &info));
-        if (info.format == VEXHIP_SPMAT_SELL8V || info.format == VEXHIP_SPMAT_SELL8) fast.reset(h, [](vexhip_spmat *p) { vexhip_spmat_destroy(p); });
-        else vexhip_spmat_destroy(h);      // no diagonal structure to exploit: the CCSR kernel reads less
+        // without diagonal structure to exploit the CCSR kernel reads less: keep it (the object is released with `owner`)
+        if (info.format == VEXHIP_SPMAT_SELL8V || info.format == VEXHIP_SPMAT_SELL8) fast = owner;
     }
     static int to_csr(int d, void *s, int64_t n, const unsigned *idx, const unsigned *row, const int *col, const double *val, int *ptr, int *oc, double *ov, int64_t *nnz)
     { return vexhip_ccsr_to_csr_f64_i32(d, s, n, idx, row, col, val, ptr, oc, ov, nnz); }
