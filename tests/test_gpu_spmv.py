@@ -686,6 +686,36 @@ def test_spmat_slice_dictionary_is_bit_identical(T, oracle, built_lib, n):
         assert np.array_equal(yc.cpu().numpy(), want2)
     finally:
         T.L.spmv_sell8_set_variant(0)
+    # single precision, both storages, and a matrix with a CSR tail (a few rows wider than the ELL width)
+    if n == 64:
+        v32 = val.astype(np.float32); x32 = x.astype(np.float32)
+        F = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32)); Fn = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), dictionary=False)
+        assert F.storage == "sell8v" and F.dictionary_blocks > 0
+        yf = torch.empty(N, dtype=torch.float32, device=T.dev); yg = torch.empty_like(yf)
+        F.apply(T.up(x32), yf); Fn.apply(T.up(x32), yg)
+        assert torch.equal(yf, yg) and np.array_equal(yf.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, x32))
+        w32 = v2.astype(np.float32)
+        Gm = T.ops.SpMat(T.up(p2), T.up(c2), T.up(w32))
+        assert Gm.storage == "sell8" and Gm.dictionary_blocks > 0
+        Gm.apply(T.up(x32), yf)
+        assert np.array_equal(yf.cpu().numpy(), oracle.spmv_csr(p2, c2, w32, x32))
+        # tail: 40 rows get 3 extra entries each -> hybrid ELL keeps width 7 and a CSR tail; the ELL slices still repeat
+        rng = np.random.default_rng(9)
+        rows_extra = np.sort(rng.choice(np.arange(N // 4, N // 2), size=40, replace=False))
+        cnt = np.diff(ptr).astype(np.int64); add = np.zeros(N, dtype=np.int64); add[rows_extra] = 3
+        ptr_t = np.concatenate([[0], np.cumsum(cnt + add)]).astype(np.int32)
+        col_t = np.empty(ptr_t[-1], dtype=np.int32); val_t = np.empty(ptr_t[-1], dtype=np.float64)
+        for i in range(N):
+            b, e = ptr[i], ptr[i + 1]; bt = ptr_t[i]
+            col_t[bt:bt + e - b] = col[b:e]; val_t[bt:bt + e - b] = val[b:e]
+        for i in rows_extra:
+            bt = ptr_t[i] + cnt[i]
+            col_t[bt:bt + 3] = [i - 7 * n, i + 5, i + 9 * n]; val_t[bt:bt + 3] = val[ptr[i]]      # values from the table: still value-coded
+        Tm = T.ops.SpMat(T.up(ptr_t), T.up(col_t), T.up(val_t)); Tn = T.ops.SpMat(T.up(ptr_t), T.up(col_t), T.up(val_t), dictionary=False)
+        assert Tm.hell.tail_nnz > 0 and Tm.storage == Tn.storage
+        yt = torch.empty(N, dtype=torch.float64, device=T.dev); yu = torch.empty_like(yt)
+        Tm.apply(T.up(x), yt); Tn.apply(T.up(x), yu)
+        assert torch.equal(yt, yu) and np.array_equal(yt.cpu().numpy(), oracle.spmv_csr(ptr_t, col_t, val_t, x))
     # fewer than 64 slices: not tried
     p3, c3, v3 = oracle.poisson3d(16)
     assert T.ops.SpMat(T.up(p3), T.up(c3), T.up(v3)).dictionary_blocks == 0
