@@ -91,6 +91,63 @@ def independent_product(torch, x, n, variable_seed=None, lazy=False):
     return y, bound
 
 
+GOLD = 0x9E3779B97F4A7C15
+
+
+def independent_strip(torch, ops, n, r0, r1, dev):
+    """Rows [r0, r1) of y = A*x for the Poisson matrix WITHOUT the matrix and WITHOUT any transport: x is a hash of the
+    GLOBAL index, so the rank generates x on its planes plus one ghost plane on each side itself and evaluates the
+    stencil there (boundary rows identity, interior rows the 7-point stencil, examples/benchmark.cpp:364-415).
+    Returns (x[r0:r1], y[r0:r1], sum|terms| per row)."""
+    nn = n * n
+    p0, p1 = r0 // nn, (r1 + nn - 1) // nn                   # planes that hold rows of the strip
+    q0, q1 = max(p0 - 1, 0), min(p1 + 1, n)                  # ... plus the neighbours their stencils reach
+    xs = ops.fill_hash(torch.empty((q1 - q0) * nn, dtype=torch.float64, device=dev), (42 + q0 * nn * GOLD) & 0xFFFFFFFFFFFFFFFF)
+    X = xs.view(q1 - q0, n, n)
+    Y = X[p0 - q0:p1 - q0].clone()
+    M = Y.abs()
+    k0, k1 = max(p0, 1), min(p1, n - 1)                      # interior planes of the strip
+    if k1 > k0 and n > 2:
+        h2i = float((n - 1) * (n - 1))
+        a, b = k0 - q0, k1 - q0
+        c = X[a:b, 1:-1, 1:-1]
+        nb = (X[a - 1:b - 1, 1:-1, 1:-1], X[a:b, :-2, 1:-1], X[a:b, 1:-1, :-2], X[a:b, 1:-1, 2:], X[a:b, 2:, 1:-1], X[a + 1:b + 1, 1:-1, 1:-1])
+        acc = 6.0 * h2i * c
+        mag = 6.0 * h2i * c.abs()
+        for t in nb:
+            acc = acc - h2i * t
+            mag = mag + h2i * t.abs()
+        Y[k0 - p0:k1 - p0, 1:-1, 1:-1] = acc
+        M[k0 - p0:k1 - p0, 1:-1, 1:-1] = mag
+    lo = r0 - p0 * nn
+    sl = slice(lo, lo + (r1 - r0))
+    return xs[(p0 - q0) * nn:][sl].clone(), Y.reshape(-1)[sl].clone(), M.reshape(-1)[sl].clone()
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here (one process per GPU) -- and refuse
+    when the box has fewer GPUs than ranks instead of quietly measuring one."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if have < args.gpus and not args.one_device:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU%s (hipGetDeviceCount); one process per GPU is the only mode "
+                         "that is measured -- use --one-device --backend gloo to exercise the %d-rank path on one GPU (debug, not a result)"
+                         % (args.gpus, have, "" if have == 1 else "s", args.gpus))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    extra = []
+    if args.one_device and "--backend" not in " ".join(argv):
+        extra = ["--backend", "gloo"]                       # RCCL refuses two ranks on one device
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv + extra
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def timed_events(torch, fn, reps):
     """Average duration of fn over `reps` launches, after ~30 ms of the same launches: these rows run after host-side work
     (matrix set-up, subprocesses), and after >= 5 ms without work the first ~16 ms of launches are up to 12 % slow."""
@@ -233,10 +290,17 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (debug: exercises the N>1 path on a 1-GPU box; needs --backend gloo)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (CSR-bytes kernels, variable coefficients, C++ front end, elementwise, reduce, scan, sort)")
     ap.add_argument("--no-native", action="store_true", help="N > 1: keep the torch.distributed transport (do not try the C++ product step)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "ipc", "torch"],
+                    help="N > 1 ghost exchange: rccl = grouped ncclSend/ncclRecv issued from C++; ipc = peer-mapped ghost windows "
+                         "(hipIpcGetMemHandle); torch = torch.distributed requests; auto = every one that validates, fastest wins")
+    ap.add_argument("--trial-steps", type=int, default=100, help="N > 1, --transport auto: products timed per candidate transport")
     ap.add_argument("--no-dictionary", action="store_true", help="value-coded storage with one code block per slice (no slice dictionary)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the ~3 s back-to-back run of the product after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic = null)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args, sys.argv[1:])                      # does not return
 
     import torch
     import torch.distributed as dist
@@ -246,12 +310,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     if args.one_device:
         local_rank = 0
+        if world > 1 and args.backend == "nccl":
+            raise SystemExit("--one-device puts every rank on cuda:0, which RCCL refuses: add --backend gloo")
+    elif torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); one process per GPU is the only mode that is measured"
+                         % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -290,33 +359,94 @@ def main():
         matrix_bytes = A.loc.matrix_bytes()
         dict_blocks = getattr(A.loc, "dictionary_blocks", 0)
         step = lambda: A.apply(x, y, 1.0, False)
-        # The product step issued from C++ over its own RCCL communicator (vexhip_dist_spmv_*: ~50 us of host time per
-        # step instead of a Python loop over torch.distributed requests).  It is used only if EVERY rank could set it
-        # up and its first product equals the torch.distributed transport's bit for bit; otherwise that one stays.
-        transport = "torch.distributed batch_isend_irecv (%s)" % args.backend
-        if world > 1 and args.backend == "nccl" and not args.no_native:
-            yref = torch.zeros_like(y)
-            A.apply(x, yref, 1.0, False)
-            torch.cuda.synchronize()
-            ok = 1 if A.enable_native() else 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]):
-                try:
-                    ynat = torch.full_like(y, 7.0)
-                    A.apply(x, ynat, 1.0, False)
+
+        # ---- every transport is validated against an evaluation that trusts NO transport: x is a hash of the global index,
+        #      so the rank regenerates x on its planes + one ghost plane per side and evaluates the stencil matrix-free
+        x_ind, y_ind, mag_ind = independent_strip(torch, ops, n, r0, r1, dev)
+        assert torch.equal(x_ind, x), "x of this rank is not the hash of the global index"
+        del x_ind
+        tol_ind = 1e-10 * mag_ind                                # per row: 1e-10 * sum |terms|
+
+        def validate(products=3):
+            """`products` consecutive products (the exchange buffers / step counters are reused) into a poisoned y, each
+            compared row by row with the independent evaluation; the verdict is the same on every rank."""
+            ok, worst = True, 0.0
+            try:
+                for k in range(products):
+                    y.fill_(7.0 + k)
+                    A.apply(x, y, 1.0, False)
                     torch.cuda.synchronize()
-                    ok = 1 if torch.equal(ynat, yref) else 0
-                except Exception as e:
-                    A.native_error = repr(e); ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]):
-                transport = "vexhip_dist_spmv_apply: pack + grouped ncclSend/ncclRecv + local + remote part issued from C++ (own RCCL communicator)"
-            else:
-                A.disable_native()
-                transport += "; native step not used: %s" % (A.native_error or "another rank could not set it up, or results differed")
-            del yref
+                    d = (y - y_ind).abs()
+                    ok = ok and bool((d <= tol_ind).all())
+                    worst = max(worst, float(d.max()))
+                st = A.native_status()
+                if st and st["timed_out"]:
+                    ok = False
+                    A.native_error = "a flag wait of the IPC transport ran into its 4 s bound"
+            except Exception as e:
+                A.native_error = repr(e)
+                ok = False
+            return A._agree(ok), worst
+
+        def trial(steps):
+            """ms per product over `steps` products between barriers (max over the ranks), after a settle run"""
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize(); barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(); barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=A._coll_device())
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.cpu()[0]) / steps * 1e3
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+
+        tried = {}
+        ok, worst = validate()
+        tried["torch"] = {"valid": ok, "max_abs_err": worst, "what": "torch.distributed batch_isend_irecv (%s), pack and products launched from Python" % args.backend}
+        candidates = []
+        if not args.no_native and args.transport != "torch":
+            if args.transport in ("auto", "ipc"):
+                candidates.append("ipc")
+            if args.transport in ("auto", "rccl") and (args.backend == "nccl" or world == 1):
+                candidates.append("rccl")
+        if args.transport == "auto" or not candidates:
+            if tried["torch"]["valid"]:
+                tried["torch"]["trial_ms_per_step"] = round(trial(args.trial_steps), 5)
+        for tr in candidates:
+            torch.cuda.synchronize(); barrier()
+            rec = {"valid": False}
+            if A.enable_native(transport=tr):
+                rec["valid"], rec["max_abs_err"] = validate()
+                if rec["valid"]:
+                    rec["trial_ms_per_step"] = round(trial(args.trial_steps), 5)
+                    rec["status"] = A.native_status()
+                    if tr == "rccl":
+                        rec["rccl"] = A.rccl_info()
+            if not rec["valid"]:
+                rec["error"] = A.native_error or "results differ from the independent evaluation on some rank"
+            tried[tr] = rec
+            torch.cuda.synchronize(); barrier()
+            A.disable_native()
+        valid = [k for k in tried if tried[k]["valid"] and "trial_ms_per_step" in tried[k]]
+        if not valid:
+            valid = [k for k in tried if tried[k]["valid"]]
+        if not valid:
+            raise SystemExit("no ghost-exchange transport reproduces the independent evaluation of the product: %r" % tried)
+        chosen = min(valid, key=lambda k: tried[k].get("trial_ms_per_step", 1e30))
+        if chosen != "torch":
+            assert A.enable_native(transport=chosen), A.native_error
+            ok, _ = validate(1)
+            assert ok, "transport %s does not validate after it was re-enabled: %s" % (chosen, A.native_error)
+        transport = {"torch": "torch.distributed batch_isend_irecv (%s)" % args.backend,
+                     "rccl": "vexhip_dist_spmv_apply: pack + grouped ncclSend/ncclRecv + local + remote part issued from C++ (own RCCL communicator)",
+                     "ipc": "vexhip_dist_spmv_apply over peer-mapped ghost windows (hipIpcGetMemHandle): owners write their neighbours' shares "
+                            "into the consumers' windows, step-numbered flags, no communicator"}[chosen]
     torch.cuda.synchronize()
 
     def barrier():
@@ -344,7 +474,7 @@ def main():
     # N > 1: the set-up above (partition exchange plan, validation of the C++ step) ends in host-side waits; the same 200
     # products on every rank bring the devices out of the post-idle transient before the W warm-ups (reported as settle_steps)
     settle_steps = 0
-    if world > 1:
+    if not single:
         settle_steps = 200
         for _ in range(settle_steps):
             step()
@@ -381,6 +511,37 @@ def main():
     kern_s = ms.value / 1e3 / args.steps         # average launch duration of the product on this rank
 
     check = None
+    dist_extra = None
+    if not single:
+        # the y of the timed steps against the independent evaluation, then the slowest rank's phases
+        d = (y - y_ind).abs()
+        row_ok = bool((d <= tol_ind).all())
+        st = A.native_status()
+        mine = {"rank": rank, "rows": r1 - r0, "avg_launch_ms": round(ms.value / args.steps, 5), "max_abs_err": float(d.max()),
+                "rows_within_tolerance": row_ok, "timed_out": (st or {}).get("timed_out", 0)}
+        prof = None
+        if chosen != "torch":
+            reps = [A.profile_step(x, y) for _ in range(7)]
+            prof = {k: round(sorted(r[k] for r in reps)[3], 5) for k in reps[0]}       # median of 7
+        mine["step_ms"] = prof
+        everyone = [None] * world
+        if world > 1:
+            dist.all_gather_object(everyone, mine)
+        else:
+            everyone = [mine]
+        sum_ind = DistReductor("SUM_Kahan")(y_ind)
+        bound_all = DistReductor("SUM")(mag_ind)
+        slowest = max(everyone, key=lambda r: r["avg_launch_ms"])
+        check = {"sum_y": checksum, "sum_y_independent": sum_ind, "max_abs_err": max(r["max_abs_err"] for r in everyone),
+                 "tolerance": "per row 1e-10 * sum|terms| of that row (SURVEY 8c); sum(y) within 1e-10 * %.3e" % bound_all,
+                 "what": "every rank regenerates x (a hash of the global index) on its planes + one ghost plane per side and evaluates "
+                         "the stencil matrix-free: no matrix, no transport involved; compared with the y of the timed steps"}
+        assert all(r["rows_within_tolerance"] and not r["timed_out"] for r in everyone), "a rank's product does not match the independent evaluation: %r" % everyone
+        assert abs(checksum - sum_ind) <= 1e-10 * bound_all, "sum(y) does not match the independent evaluation: %r" % check
+        dist_extra = {"per_rank": everyone, "slowest_rank": slowest["rank"], "slowest_rank_step_ms": slowest["step_ms"],
+                      "step_ms_what": "median of 7 products with HIP events on both streams (vexhip_dist_spmv_profile): total, local part, wait "
+                                      "for the ghosts after the local part, remote part; pack and exchange run beside the local part",
+                      "transports_tried": tried, "transport_chosen": chosen, "rccl": A.rccl_info()}
     if single:
         err, sum_ref, bound = (float(v) for v in check_dev)
         tol = 1e-10 * bound
@@ -461,10 +622,13 @@ def main():
                 "peak_source": "MI355X_MICROARCH.md: L2 ~34.5 TB/s aggregate"}
         if sustained:
             out["sustained"] = sustained
-        if world > 1:
+        if not single:
             out["config"]["settle_steps"] = settle_steps
             out["config"]["exchange_bytes_per_rank"] = A.exchange_bytes()
             out["config"]["exchange_transport"] = transport
+            out["config"]["backend"] = args.backend
+            out["config"]["one_device_debug"] = bool(args.one_device)
+            out["distributed"] = dist_extra
         if single and not args.no_secondary:
             sec = {}
             try:

@@ -353,9 +353,11 @@ typedef struct vexhip_comm vexhip_comm;
 int vexhip_comm_unique_id(void *id128);
 enum { VEXHIP_COMM_AUTO = 0,   /* RCCL when the devices are distinct GPUs and there are at least two, else PEER          */
        VEXHIP_COMM_RCCL = 1,   /* grouped ncclSend / ncclRecv, ncclAllReduce, ncclAllGather                               */
-       VEXHIP_COMM_PEER = 2 }; /* single process only: event-ordered device-to-device copies (no communicator; the only  *
+       VEXHIP_COMM_PEER = 2,   /* single process only: event-ordered device-to-device copies (no communicator; the only  *
                                 * option when logical devices share one GPU -- the reference's own test fixture,           *
                                 * tests/context_setup.hpp:24-39 -- and the host fold of the reference for reductions)      */
+       VEXHIP_COMM_IPC = 3 };  /* one process per GPU: peer-mapped ghost windows (vexhip_ipc_window_*), reported by       *
+                                * vexhip_dist_spmv_status; not a value for vexhip_comm_init                               */
 int vexhip_comm_init(int ndev, const int *devs, int transport, vexhip_comm **out);
 int vexhip_comm_init_rank(int dev, int rank, int world, const void *id128, vexhip_comm **out);
 int vexhip_comm_destroy(vexhip_comm *comm);
@@ -386,6 +388,35 @@ int vexhip_dist_spmv_create(vexhip_comm *comm, int dtype, int64_t rows, const ve
 int vexhip_dist_spmv_destroy(vexhip_dist_spmv *step);
 int vexhip_dist_spmv_set_graph(vexhip_dist_spmv *step, int enable);
 int vexhip_dist_spmv_apply(vexhip_dist_spmv *step, void *stream, double alpha, int append, const void *x, void *y);
+/* What RCCL itself reports for the communicator of local device 0 (ncclCommCount / ncclCommCuDevice / ncclCommUserRank);
+ * for the PEER transport: the values the communicator was built with.                                                  */
+int vexhip_comm_rccl_info(const vexhip_comm *comm, int *nranks, int *device, int *user_rank);
+
+/* The same product step over PEER-MAPPED GHOST WINDOWS instead of a communicator (second transport of the
+ * one-process-per-GPU job; replaces the host staging of vexcl/spmat.hpp:125-183 like the RCCL step does).  Every rank
+ * allocates one uncached window (its ghost values + two arrays of 64-bit step counters), exports it
+ * (hipIpcGetMemHandle; the launcher distributes the 64-byte handles) and opens the windows of the ranks it exchanges
+ * with.  Per product ONE kernel per rank writes every neighbour's share straight into that neighbour's window over
+ * xGMI and raises `arrive` there; the consumer's stream waits on its own flags with a one-wave kernel, runs the remote
+ * part on the window and raises `consumed` at the owners, which gates their next write.  No pack buffer, no receive,
+ * no collective kernel.  Spins are bounded (4 s): a missing peer sets a sticky flag (vexhip_dist_spmv_status) instead
+ * of hanging the device.  dst_offsets[p] = element offset of this rank's share in rank p's ghost set.               */
+typedef struct vexhip_ipc_window vexhip_ipc_window;
+int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, vexhip_ipc_window **out);
+int vexhip_ipc_window_export(const vexhip_ipc_window *win, void *handle64);
+int vexhip_ipc_window_open(vexhip_ipc_window *win, int peer, const void *handle64);
+int vexhip_ipc_window_data(const vexhip_ipc_window *win, void **data);
+int vexhip_ipc_window_destroy(vexhip_ipc_window *win);
+int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *win, int dtype, int64_t rows, const vexhip_spmat *local,
+        int64_t rem_rows, const int32_t *rows_idx, const int32_t *rem_ptr, const int32_t *rem_col, const void *rem_val,
+        int64_t nsend, const int32_t *send_idx, const int64_t *send_counts, const int64_t *dst_offsets,
+        int64_t nghost, const int64_t *recv_counts, vexhip_dist_spmv **out);
+/* timed_out: a flag wait ran into its bound; transport: VEXHIP_COMM_RCCL or VEXHIP_COMM_IPC; direct: the shares are
+ * runs of x and no pack kernel / index list is used.                                                                 */
+int vexhip_dist_spmv_status(vexhip_dist_spmv *step, int *timed_out, int *transport, int *direct);
+/* One product with its phases timed (HIP events on both streams; synchronises): ms6 = total, local part, wait for the
+ * ghosts after the local part, remote part, pack, exchange (the last two run beside the local part).                 */
+int vexhip_dist_spmv_profile(vexhip_dist_spmv *step, void *stream, double alpha, int append, const void *x, void *y, float *ms6);
 
 /* Multi-right-hand-side products  y[k] (+)= alpha * A * x[k],  k < nrhs  -- `SpMat * multivector`
  * (vexcl/spmat.hpp:388-398, which applies the product once per component; tests/spmv.cpp:262-305).

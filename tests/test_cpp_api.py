@@ -59,6 +59,29 @@ def test_cpp_api_on_gpu(name):
 
 
 @pytest.mark.gpu
+def test_every_baseline_config_is_verified_at_its_stated_size():
+    """BASELINE.json configs[1] (a = b*c + sin(d), n = 1e8) and configs[4] (vex::sort + vex::inclusive_scan of 1e9 uint32
+    keys; sort_by_key at 2.5e8) through the vex:: API at FULL size, every element checked on the host
+    (tests/cpp/configs_at_size.cpp): sortedness + multiset equality, scan differences, elementwise against libm."""
+    import json
+    exe = _build("configs_at_size")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=1800)
+    print(out.stdout[-4000:])
+    assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-3000:]
+    assert "0 failures" in out.stdout
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    by = {r["what"]: r for r in rows}
+    assert by["a = b*c + sin(d)"]["n"] == 100000000 and by["a = b*c + sin(d)"]["outside_tolerance"] == 0
+    assert by["vex::sort uint32"]["n"] == 1000000000 and by["vex::sort uint32"]["inversions"] == 0 and by["vex::sort uint32"]["multiset_equal"] is True
+    assert by["vex::inclusive_scan uint32"]["n"] == 1000000000 and by["vex::inclusive_scan uint32"]["differences_wrong"] == 0
+    assert by["vex::sort_by_key uint32 -> uint32"]["n"] == 250000000 and by["vex::sort_by_key uint32 -> uint32"]["violations"] == 0
+
+
+def test_configs_at_size_compiles():
+    assert os.path.exists(_build("configs_at_size"))
+
+
+@pytest.mark.gpu
 def test_cpp_api_single_device_context():
     exe = _build("spmv_tests")
     env = dict(os.environ, VEX_TEST_SINGLE_DEVICE="1")

@@ -76,6 +76,32 @@ for label, sidx in (("run", torch.arange(ng, device=dev) + 777), ("perm", torch.
     assert (float(sbuf.abs().sum()) == 0.0) == (label == "run"), label      # the run never touches the pack buffer
     L.dist_spmv_destroy(step)
 L.comm_destroy(comm)
+# the same step over a peer-mapped ghost WINDOW (IPC transport): the rank writes its own share into its own window, waits on its
+# own flags and releases them -- the whole protocol with one participant; 40 products: the step counters gate every reuse
+win = ctypes.c_void_p(); L.ipc_window_create(0, 0, 1, ng * 8, ctypes.byref(win))
+hnd = (ctypes.c_char * 64)(); L.ipc_window_export(win, ctypes.cast(hnd, ctypes.c_void_p))
+assert any(b != 0 for b in hnd.raw)
+zero = (ctypes.c_int64 * 1)(0)
+for label, sidx in (("run", torch.arange(ng, device=dev) + 777), ("perm", torch.randperm(rows, device=dev)[:ng])):
+    sidx = sidx.to(torch.int32).contiguous()
+    step = ctypes.c_void_p()
+    L.dist_spmv_create_ipc(win, _capi.F64, rows, loc.handle, ng, p(rw), p(cp), p(rc), p(rv), ng, p(sidx), cnts, zero, ng, cnts, ctypes.byref(step))
+    y = torch.empty(rows, dtype=torch.float64, device=dev)
+    for k in range(40):
+        xk = x * (k + 1)
+        L.dist_spmv_apply(step, ctypes.c_void_p(s.cuda_stream), 1.0, 0, p(xk), p(y))
+        s.synchronize()
+        want = 2.0 * xk
+        want[rw.long()] += 3.0 * xk[sidx.long()]
+        assert torch.equal(y, want), (label, k)
+    to, tr, di = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    L.dist_spmv_status(step, ctypes.byref(to), ctypes.byref(tr), ctypes.byref(di))
+    assert (to.value, tr.value, di.value) == (0, 3, 1 if label == "run" else 0), (to.value, tr.value, di.value)
+    ms = (ctypes.c_float * 6)()
+    L.dist_spmv_profile(step, ctypes.c_void_p(s.cuda_stream), 1.0, 0, p(x), p(y), ms)
+    assert ms[0] > 0 and all(v >= 0 for v in ms), list(ms)
+    L.dist_spmv_destroy(step)
+L.ipc_window_destroy(win)
 print("rccl self ok")
 '''
 

@@ -22,7 +22,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, out):
+def _worker(rank, world, port, n, out, ipc=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -63,6 +63,33 @@ def _worker(rank, world, port, n, out):
         got = DistScan()(k.clone(), exclusive=True, init=9)
         want = ops.exclusive_scan(fk.clone(), init=9)
         ok = ok and bool(torch.equal(got, want[r0:r1]))
+        # the product step issued from C++ over peer-mapped ghost windows (IPC transport): every rank maps its neighbours'
+        # windows (hipIpcGetMemHandle / hipIpcOpenMemHandle between the processes that share this GPU) -- 60 products with
+        # a changing x, each against the one-device product, then back to the torch.distributed transport
+        if ipc:
+            assert A.enable_native(transport="ipc"), A.native_error
+            assert A.native_status()["transport"] == "ipc"
+            for k in range(60):
+                xk = x * (1.0 + k)
+                y.fill_(-3.0)
+                A.apply(xk, y, 1.0, False)
+                if k % 20 == 0:
+                    fy.zero_()
+                    ops.SpMat(fp, fc, fv).apply(fx * (1.0 + k), fy, 1.0, False)
+                    torch.cuda.synchronize()
+                    ok = ok and bool(((y - fy[r0:r1]).abs() <= 1e-12 * scale * (1.0 + k)).all())
+            torch.cuda.synchronize()
+            st = A.native_status()
+            ok = ok and st["timed_out"] == 0
+            prof = A.profile_step(x, y)
+            ok = ok and prof["total"] > 0
+            dist.barrier()
+            A.disable_native()
+            y.fill_(7.0)
+            A.apply(x, y, 1.5, True)
+            ref = torch.full((N,), 7.0, dtype=torch.float64, device=dev)
+            ops.SpMat(fp, fc, fv).apply(fx, ref, 1.5, True)
+            ok = ok and bool(((y - ref[r0:r1]).abs() <= 1e-12 * scale).all())
         out[rank] = 1 if ok else 0
     finally:
         dist.destroy_process_group()

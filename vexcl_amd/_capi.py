@@ -172,6 +172,16 @@ _PROTOS = {
     "vexhip_dist_spmv_destroy": (None, [c_vp]),
     "vexhip_dist_spmv_set_graph": (None, [c_vp, c_int]),
     "vexhip_dist_spmv_apply": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp]),
+    "vexhip_comm_rccl_info": (None, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "vexhip_ipc_window_create": (None, [c_int, c_int, c_int, c_i64, ctypes.POINTER(c_vp)]),
+    "vexhip_ipc_window_export": (None, [c_vp, c_vp]),
+    "vexhip_ipc_window_open": (None, [c_vp, c_int, c_vp]),
+    "vexhip_ipc_window_data": (None, [c_vp, ctypes.POINTER(c_vp)]),
+    "vexhip_ipc_window_destroy": (None, [c_vp]),
+    "vexhip_dist_spmv_create_ipc": (None, [c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64),
+                                           ctypes.POINTER(c_i64), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_vp)]),
+    "vexhip_dist_spmv_status": (None, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "vexhip_dist_spmv_profile": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp, ctypes.POINTER(c_f32)]),
     "vexhip_spmm_sell8_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 7 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8v_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),

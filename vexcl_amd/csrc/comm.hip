@@ -37,6 +37,9 @@ struct rccl_api {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;          // optional (diagnostics)
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     std::string error;
 };
 
@@ -56,6 +59,9 @@ rccl_api &rccl() {
         SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather")
         SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+        api.CommCuDevice = reinterpret_cast<decltype(api.CommCuDevice)>(dlsym(api.lib, "ncclCommCuDevice"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
     });
     return api;
 }
@@ -134,6 +140,88 @@ int nccl_type(int dtype, ncclDataType_t *t) {
     return fail(__FILE__, __LINE__, "unknown dtype");
 }
 
+
+// ---- IPC transport: peer-mapped ghost windows ------------------------------------------------------------------
+// One window per rank, allocated UNCACHED (hipDeviceMallocUncached: neither this GPU's L2 nor its L1 keeps a line of
+// it, so what a peer writes over xGMI -- which lands in HBM without probing this GPU's caches -- is what the next
+// load returns) and exported with hipIpcGetMemHandle:
+//     [ arrive[world] | consumed[world] | pad to 256 B | ghost values ]
+// arrive[o]   (written by owner o):    number of the latest product whose share owner o has written into this window;
+// consumed[p] (written by consumer p): number of the latest product for which p has finished reading what THIS rank
+//                                      wrote into p's window -- this rank may overwrite it then.
+// The flags are 64-bit step numbers that only grow: nothing is ever reset, a late reader can not miss an update.
+constexpr unsigned long long kSpinTicks = 400000000ull;        // wall_clock64() counts at 100 MHz: 4 s
+
+struct ipc_window {
+    int dev = 0, rank = 0, world = 1;
+    int64_t data_bytes = 0;
+    size_t bytes = 0;
+    char *base = nullptr;
+    std::vector<char *> peer;                  // base address of every opened window (own pointer for this rank)
+    std::vector<char> opened;                  // mapped with hipIpcOpenMemHandle (to be closed)
+};
+inline size_t window_header(int world) { return ((size_t)world * 16 + 255) / 256 * 256; }
+inline unsigned long long *window_arrive(char *base, int o) { return reinterpret_cast<unsigned long long *>(base) + o; }
+inline unsigned long long *window_consumed(char *base, int world, int p) { return reinterpret_cast<unsigned long long *>(base) + world + p; }
+
+struct push_peer {
+    void *dst;                                 // where this rank's share starts in the destination's window
+    unsigned long long *arrive;                // destination's arrive[me]
+    const unsigned long long *consumed;        // my consumed[destination]
+    long long first, count, direct_first, blk0;
+};
+constexpr int kPushPerBlock = 2048;
+
+__device__ inline void spin_until(const unsigned long long *flag, unsigned long long want, int *err) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // a peer is gone: do not wait again
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > kSpinTicks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
+}
+
+// Every owner writes, per destination, exactly the values that destination needs straight into its window (idx: the
+// packed order; NULL: the share is one run of x starting at direct_first), then raises arrive[me] there.
+template <typename T>
+__global__ __launch_bounds__(256)
+void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned long long step, const int32_t *__restrict__ idx,
+        const T *__restrict__ x, unsigned long long *done, int *err)
+{
+    int j = 0;
+    while (j + 1 < npeers && (long long)blockIdx.x >= peers[j + 1].blk0) ++j;
+    const push_peer P = peers[j];
+    if (threadIdx.x == 0) spin_until(P.consumed, step - 1, err);          // the destination has read the previous product's share
+    __syncthreads();
+    T *dst = static_cast<T *>(P.dst);
+    const long long i0 = ((long long)blockIdx.x - P.blk0) * kPushPerBlock;
+#pragma unroll
+    for (int k = 0; k < kPushPerBlock / 256; ++k) {
+        const long long i = i0 + k * 256 + threadIdx.x;
+        if (i < P.count) dst[i] = idx ? x[idx[P.first + i]] : x[P.direct_first + i];
+    }
+    __threadfence_system();                                               // this lane's stores are performed before ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long nblk = (unsigned long long)((P.count + kPushPerBlock - 1) / kPushPerBlock);
+        const unsigned long long old = __hip_atomic_fetch_add(&done[j], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == nblk * step) {                                     // ... the last block of this destination raises the flag
+            __threadfence_system();
+            __hip_atomic_store(P.arrive, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64)
+void ipc_wait_kernel(const unsigned long long *const *flags, int n, unsigned long long step, int *err) {
+    if ((int)threadIdx.x < n) spin_until(flags[threadIdx.x], step, err);
+}
+
+__global__ __launch_bounds__(64)
+void ipc_signal_kernel(unsigned long long *const *flags, int n, unsigned long long step) {
+    if ((int)threadIdx.x < n) __hip_atomic_store(flags[threadIdx.x], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- one rank's product step -----------------------------------------------------------------------------------
 struct dist_spmv {
     comm *c = nullptr;
@@ -155,6 +243,16 @@ struct dist_spmv {
     bool use_graph = false;
     hipGraphExec_t exec = nullptr;
     const void *gx = nullptr; void *gy = nullptr; double galpha = 0; int gappend = 0; hipStream_t gstream = nullptr;
+    // IPC transport (peer-mapped ghost windows): the owners WRITE their shares into the consumer's window
+    ipc_window *win = nullptr;
+    unsigned long long step = 0;               // products issued so far (the flags carry step numbers)
+    push_peer *d_push = nullptr; int npush = 0; int64_t push_blocks = 0;
+    unsigned long long *d_done = nullptr;      // per destination: blocks of the push kernel that have finished (monotonic)
+    int *d_err = nullptr;                      // sticky: a flag was not raised within kSpinTicks
+    const unsigned long long **d_arrive = nullptr; unsigned long long **d_consumed = nullptr; int nown = 0;
+    hipEvent_t pushed = nullptr;
+    // optional phase timing of one step (vexhip_dist_spmv_profile)
+    hipEvent_t *prof = nullptr;                // [0..3] compute stream: start, local done, ghosts here, end; [4..6] comm stream: start, packed, exchanged
 };
 
 int exchange_one(comm *c, int slot, int dtype, const void *send, const int64_t *scount, void *recv, const int64_t *rcount, hipStream_t s,
@@ -182,9 +280,66 @@ int exchange_one(comm *c, int slot, int dtype, const void *send, const int64_t *
     return 0;
 }
 
+#define PROF(k, stream) do { if (D->prof) VEXHIP_TRY(hipEventRecord(D->prof[k], stream)); } while (0)
+
+int remote_part(dist_spmv *D, hipStream_t s, double alpha, void *y) {
+    if (!D->rem_rows) return 0;
+    return D->dtype == VEXHIP_F64
+        ? vexhip_spmv_csr_rows_f64_i32(D->dev, s, D->rem_rows, alpha, D->rows_idx, D->rem_ptr, D->rem_col, static_cast<const double *>(D->rem_val),
+                                       static_cast<const double *>(D->ghost_buf), static_cast<double *>(y))
+        : vexhip_spmv_csr_rows_f32_i32(D->dev, s, D->rem_rows, (float)alpha, D->rows_idx, D->rem_ptr, D->rem_col, static_cast<const float *>(D->rem_val),
+                                       static_cast<const float *>(D->ghost_buf), static_cast<float *>(y));
+}
+
+int local_part(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
+    if (D->loc)
+        return D->dtype == VEXHIP_F64 ? vexhip_spmat_apply_f64(D->loc, s, alpha, append, static_cast<const double *>(x), static_cast<double *>(y))
+                                      : vexhip_spmat_apply_f32(D->loc, s, (float)alpha, append, static_cast<const float *>(x), static_cast<float *>(y));
+    if (!append && D->rows) VEXHIP_TRY(hipMemsetAsync(y, 0, (size_t)D->rows * type_bytes(D->dtype), s));          // csr.inl:196-199
+    return 0;
+}
+
+// The step over peer-mapped windows: no communicator, no pack buffer, no receive --
+//   compute stream s:  [x ready] ...... local part ...... wait kernel (arrive flags) -> remote part -> signal kernel (consumed flags) -> wait(pushed)
+//   comm stream:       wait(x ready) -> push kernel: per destination wait for consumed >= step-1, write the share into ITS window, raise arrive = step
+int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
+    const unsigned long long step = ++D->step;
+    PROF(0, s);
+    if (D->npush) {
+        VEXHIP_TRY(hipEventRecord(D->packed, s));
+        VEXHIP_TRY(hipStreamWaitEvent(D->comm_stream, D->packed, 0));
+        PROF(4, D->comm_stream); PROF(5, D->comm_stream);
+        const int32_t *idx = D->direct ? nullptr : D->send_idx;
+        if (D->dtype == VEXHIP_F64)
+            ipc_push_kernel<double><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const double *>(x), D->d_done, D->d_err);
+        else
+            ipc_push_kernel<float><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const float *>(x), D->d_done, D->d_err);
+        VEXHIP_LAUNCH_CHECK();
+        PROF(6, D->comm_stream);
+        VEXHIP_TRY(hipEventRecord(D->pushed, D->comm_stream));
+    } else if (D->prof) { PROF(4, s); PROF(5, s); PROF(6, s); }
+    if (int rc = local_part(D, s, alpha, append, x, y)) return rc;
+    PROF(1, s);
+    if (D->nown) {
+        ipc_wait_kernel<<<1, 64, 0, s>>>(D->d_arrive, D->nown, step, D->d_err);
+        VEXHIP_LAUNCH_CHECK();
+    }
+    PROF(2, s);
+    if (int rc = remote_part(D, s, alpha, y)) return rc;
+    if (D->nown) {
+        ipc_signal_kernel<<<1, 64, 0, s>>>(D->d_consumed, D->nown, step);
+        VEXHIP_LAUNCH_CHECK();
+    }
+    if (D->npush) VEXHIP_TRY(hipStreamWaitEvent(s, D->pushed, 0));       // x may be overwritten by what the caller issues next
+    PROF(3, s);
+    return 0;
+}
+
 int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
+    if (D->win) return issue_step_ipc(D, s, alpha, append, x, y);
     const bool f64 = D->dtype == VEXHIP_F64;
     const bool exch = D->nsend > 0 || D->nghost > 0;
+    PROF(0, s);
     if (exch) {
         // The pack kernel and the exchange run on the SECOND stream, beside the local part (which needs neither):
         //   compute stream s:   [x ready] ............ local part ............ wait(received) remote part [consumed]
@@ -193,11 +348,13 @@ int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void
         // overwrites ghost_buf only after the previous step's remote part has read it (`consumed`, recorded on s).
         VEXHIP_TRY(hipEventRecord(D->packed, s));                         // "x is ready" (and, transitively, `consumed`)
         VEXHIP_TRY(hipStreamWaitEvent(D->comm_stream, D->packed, 0));
+        PROF(4, D->comm_stream);
         if (D->nsend && !D->direct) {
             int rc = f64 ? vexhip_gather_f64_i32(D->dev, D->comm_stream, D->nsend, D->send_idx, static_cast<const double *>(x), static_cast<double *>(D->send_buf))
                          : vexhip_gather_f32_i32(D->dev, D->comm_stream, D->nsend, D->send_idx, static_cast<const float *>(x), static_cast<float *>(D->send_buf));
             if (rc) return rc;
         }
+        PROF(5, D->comm_stream);
         NCCL_TRY(rccl().GroupStart());
         // (direct: the sends read x; x stays untouched until `received`, which follows sends and receives alike)
         int rc = D->direct ? exchange_one(D->c, 0, D->dtype, x, D->send_counts.data(), D->ghost_buf, D->recv_counts.data(), D->comm_stream, D->send_first.data())
@@ -205,25 +362,39 @@ int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void
         ncclResult_t ge = rccl().GroupEnd();
         if (rc) return rc;
         NCCL_TRY(ge);
+        PROF(6, D->comm_stream);
         VEXHIP_TRY(hipEventRecord(D->received, D->comm_stream));
-    }
+    } else if (D->prof) { PROF(4, s); PROF(5, s); PROF(6, s); }
     // local part, overlapped with pack + exchange
-    if (D->loc) {
-        int rc = f64 ? vexhip_spmat_apply_f64(D->loc, s, alpha, append, static_cast<const double *>(x), static_cast<double *>(y))
-                     : vexhip_spmat_apply_f32(D->loc, s, (float)alpha, append, static_cast<const float *>(x), static_cast<float *>(y));
-        if (rc) return rc;
-    } else if (!append && D->rows) {
-        VEXHIP_TRY(hipMemsetAsync(y, 0, (size_t)D->rows * type_bytes(D->dtype), s));          // csr.inl:196-199
-    }
+    if (int rc = local_part(D, s, alpha, append, x, y)) return rc;
+    PROF(1, s);
     if (exch) VEXHIP_TRY(hipStreamWaitEvent(s, D->received, 0));
-    if (D->rem_rows) {
-        int rc = f64 ? vexhip_spmv_csr_rows_f64_i32(D->dev, s, D->rem_rows, alpha, D->rows_idx, D->rem_ptr, D->rem_col, static_cast<const double *>(D->rem_val),
-                                                    static_cast<const double *>(D->ghost_buf), static_cast<double *>(y))
-                     : vexhip_spmv_csr_rows_f32_i32(D->dev, s, D->rem_rows, (float)alpha, D->rows_idx, D->rem_ptr, D->rem_col, static_cast<const float *>(D->rem_val),
-                                                    static_cast<const float *>(D->ghost_buf), static_cast<float *>(y));
-        if (rc) return rc;
-    }
+    PROF(2, s);
+    if (int rc = remote_part(D, s, alpha, y)) return rc;
+    PROF(3, s);
     return 0;
+}
+#undef PROF
+
+// are the shares single runs of consecutive elements?  (one read of the index list at set-up)
+hipError_t detect_runs(dist_spmv *D, const int32_t *send_idx, int world) {
+    std::vector<int32_t> h((size_t)D->nsend);
+    hipError_t e = hipMemcpy(h.data(), send_idx, sizeof(int32_t) * (size_t)D->nsend, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    D->send_first.assign(world, 0);
+    bool runs = true;
+    int64_t o = 0;
+    for (int p = 0; p < world && runs; ++p) {
+        const int64_t k = D->send_counts[p];
+        if (k) {
+            D->send_first[p] = h[(size_t)o];
+            for (int64_t j = 1; j < k && runs; ++j) runs = h[(size_t)(o + j)] == h[(size_t)o] + (int32_t)j;
+            runs = runs && h[(size_t)o] >= 0 && (int64_t)h[(size_t)o] + k <= D->rows;
+        }
+        o += k;
+    }
+    D->direct = runs;
+    return hipSuccess;
 }
 
 template <typename T>
@@ -474,26 +645,7 @@ int vexhip_dist_spmv_create(vexhip_comm *hc, int dtype, int64_t rows, const vexh
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->packed, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->received, hipEventDisableTiming);
-    // are the shares single runs of consecutive elements?  (one read of the index list at set-up)
-    if (e == hipSuccess && nsend > 0 && !std::getenv("VEXHIP_DIST_PACK")) {
-        std::vector<int32_t> h((size_t)nsend);
-        e = hipMemcpy(h.data(), send_idx, sizeof(int32_t) * (size_t)nsend, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) {
-            D->send_first.assign(c->world, 0);
-            bool runs = true;
-            int64_t o = 0;
-            for (int p = 0; p < c->world && runs; ++p) {
-                const int64_t k = D->send_counts[p];
-                if (k) {
-                    D->send_first[p] = h[(size_t)o];
-                    for (int64_t j = 1; j < k && runs; ++j) runs = h[(size_t)(o + j)] == h[(size_t)o] + (int32_t)j;
-                    runs = runs && h[(size_t)o] >= 0 && (int64_t)h[(size_t)o] + k <= rows;
-                }
-                o += k;
-            }
-            D->direct = runs;
-        }
-    }
+    if (e == hipSuccess && nsend > 0 && !std::getenv("VEXHIP_DIST_PACK")) e = detect_runs(D, send_idx, c->world);
     if (e != hipSuccess) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return check(e, __FILE__, __LINE__); }
     *out = reinterpret_cast<vexhip_dist_spmv *>(D);
     return 0;
@@ -507,6 +659,13 @@ int vexhip_dist_spmv_destroy(vexhip_dist_spmv *h) {
     if (D->comm_stream) { (void)hipStreamSynchronize(D->comm_stream); (void)hipStreamDestroy(D->comm_stream); }
     if (D->packed) (void)hipEventDestroy(D->packed);
     if (D->received) (void)hipEventDestroy(D->received);
+    if (D->pushed) (void)hipEventDestroy(D->pushed);
+    if (D->prof) { for (int k = 0; k < 7; ++k) if (D->prof[k]) (void)hipEventDestroy(D->prof[k]); delete[] D->prof; }
+    if (D->d_push) (void)hipFree(D->d_push);
+    if (D->d_done) (void)hipFree(D->d_done);
+    if (D->d_err) (void)hipFree(D->d_err);
+    if (D->d_arrive) (void)hipFree(D->d_arrive);
+    if (D->d_consumed) (void)hipFree(D->d_consumed);
     delete D;
     return 0;
 }
@@ -522,9 +681,10 @@ int vexhip_dist_spmv_set_graph(vexhip_dist_spmv *h, int enable) {
 int vexhip_dist_spmv_apply(vexhip_dist_spmv *h, void *stream, double alpha, int append, const void *x, void *y) {
     dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
     VEXHIP_REQUIRE(D && (x || !D->rows) && (y || !D->rows), "NULL argument");
-    if (D->nsend || D->nghost) RCCL_READY();
+    if (!D->win && (D->nsend || D->nghost)) RCCL_READY();
     VEXHIP_SET_DEVICE(D->dev);
     hipStream_t s = as_stream(stream);
+    if (D->win) return issue_step(D, s, alpha, append, x, y);             // the flags carry step numbers: nothing to replay
     // Steps with a ghost exchange are always issued directly: capturing ncclSend / ncclRecv into a hipGraph crashes in
     // this RCCL (2.26.6, measured with tools/r02_dist_step.py), and the direct step costs ~50 us of host time against
     // ~130 us on the device for a 1/8 strip of the 512^3 problem.
@@ -547,6 +707,211 @@ int vexhip_dist_spmv_apply(vexhip_dist_spmv *h, void *stream, double alpha, int 
         D->gx = x; D->gy = y; D->galpha = alpha; D->gappend = append; D->gstream = s;
     }
     VEXHIP_TRY(hipGraphLaunch(D->exec, s));
+    return 0;
+}
+
+// ---- IPC windows + the product step over them --------------------------------------------------------------------
+int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, vexhip_ipc_window **out) {
+    VEXHIP_REQUIRE(out && world >= 1 && rank >= 0 && rank < world && data_bytes >= 0, "bad argument");
+    *out = nullptr;
+    VEXHIP_SET_DEVICE(dev);
+    ipc_window *w = new (std::nothrow) ipc_window;
+    VEXHIP_REQUIRE(w, "out of host memory");
+    w->dev = dev; w->rank = rank; w->world = world; w->data_bytes = data_bytes;
+    w->bytes = window_header(world) + (((size_t)data_bytes + 255) / 256 * 256) + 256;
+    w->peer.assign(world, nullptr); w->opened.assign(world, 0);
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, w->bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(p, 0, w->bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { if (p) (void)hipFree(p); delete w; return check(e, __FILE__, __LINE__); }
+    w->base = static_cast<char *>(p);
+    w->peer[rank] = w->base;
+    *out = reinterpret_cast<vexhip_ipc_window *>(w);
+    return 0;
+}
+
+int vexhip_ipc_window_export(const vexhip_ipc_window *h, void *handle64) {
+    const ipc_window *w = reinterpret_cast<const ipc_window *>(h);
+    VEXHIP_REQUIRE(w && handle64, "NULL argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    VEXHIP_SET_DEVICE(w->dev);
+    hipIpcMemHandle_t mh;
+    VEXHIP_TRY(hipIpcGetMemHandle(&mh, w->base));
+    std::memcpy(handle64, &mh, sizeof(mh));
+    return 0;
+}
+
+int vexhip_ipc_window_open(vexhip_ipc_window *h, int peer, const void *handle64) {
+    ipc_window *w = reinterpret_cast<ipc_window *>(h);
+    VEXHIP_REQUIRE(w && handle64 && peer >= 0 && peer < w->world, "bad argument");
+    if (w->peer[peer]) return 0;
+    VEXHIP_SET_DEVICE(w->dev);
+    hipIpcMemHandle_t mh;
+    std::memcpy(&mh, handle64, sizeof(mh));
+    void *p = nullptr;
+    VEXHIP_TRY(hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
+    w->peer[peer] = static_cast<char *>(p); w->opened[peer] = 1;
+    return 0;
+}
+
+int vexhip_ipc_window_data(const vexhip_ipc_window *h, void **data) {
+    const ipc_window *w = reinterpret_cast<const ipc_window *>(h);
+    VEXHIP_REQUIRE(w && data, "NULL argument");
+    *data = w->base + window_header(w->world);
+    return 0;
+}
+
+int vexhip_ipc_window_destroy(vexhip_ipc_window *h) {
+    ipc_window *w = reinterpret_cast<ipc_window *>(h);
+    if (!w) return 0;
+    (void)hipSetDevice(w->dev);
+    (void)hipDeviceSynchronize();
+    for (int p = 0; p < w->world; ++p) if (w->opened[p] && w->peer[p]) (void)hipIpcCloseMemHandle(w->peer[p]);
+    if (w->base) (void)hipFree(w->base);
+    delete w;
+    return 0;
+}
+
+int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, const vexhip_spmat *local,
+        int64_t rem_rows, const int32_t *rows_idx, const int32_t *rem_ptr, const int32_t *rem_col, const void *rem_val,
+        int64_t nsend, const int32_t *send_idx, const int64_t *send_counts, const int64_t *dst_offsets,
+        int64_t nghost, const int64_t *recv_counts, vexhip_dist_spmv **out)
+{
+    ipc_window *w = reinterpret_cast<ipc_window *>(hw);
+    VEXHIP_REQUIRE(out, "NULL output");
+    *out = nullptr;
+    VEXHIP_REQUIRE(w, "NULL window");
+    VEXHIP_REQUIRE(dtype == VEXHIP_F64 || dtype == VEXHIP_F32, "value type must be f64 or f32");
+    VEXHIP_REQUIRE(rows >= 0 && rem_rows >= 0 && nsend >= 0 && nghost >= 0, "negative size");
+    VEXHIP_REQUIRE((!nsend || (send_idx && send_counts && dst_offsets)) && (!nghost || recv_counts), "NULL exchange plan");
+    VEXHIP_REQUIRE(!rem_rows || (rows_idx && rem_ptr && rem_col && rem_val), "NULL remote part");
+    VEXHIP_REQUIRE((int64_t)type_bytes(dtype) * nghost <= w->data_bytes, "the window is smaller than the ghost set");
+    VEXHIP_REQUIRE(w->world <= 64, "more than 64 ranks");
+    dist_spmv *D = new (std::nothrow) dist_spmv;
+    VEXHIP_REQUIRE(D, "out of host memory");
+    D->win = w; D->dev = w->dev; D->dtype = dtype; D->loc = local; D->rows = rows;
+    D->rem_rows = rem_rows; D->rows_idx = rows_idx; D->rem_ptr = rem_ptr; D->rem_col = rem_col; D->rem_val = rem_val;
+    D->nsend = nsend; D->send_idx = send_idx; D->nghost = nghost;
+    D->ghost_buf = w->base + window_header(w->world);
+    D->send_counts.assign(w->world, 0); D->recv_counts.assign(w->world, 0);
+    int64_t ts = 0, tr = 0;
+    for (int p = 0; p < w->world; ++p) {
+        if (nsend) D->send_counts[p] = send_counts[p];
+        if (nghost) D->recv_counts[p] = recv_counts[p];
+        ts += D->send_counts[p]; tr += D->recv_counts[p];
+    }
+    auto bail = [&](int rc) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return rc; };
+    if (ts != nsend || tr != nghost) return bail(fail(__FILE__, __LINE__, "exchange counts do not add up to the buffer sizes"));
+    hipError_t e = hipSetDevice(D->dev);
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        e = hipStreamCreateWithPriority(&D->comm_stream, hipStreamNonBlocking, hi);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&D->packed, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&D->pushed, hipEventDisableTiming);
+    if (e == hipSuccess && nsend > 0 && !std::getenv("VEXHIP_DIST_PACK")) e = detect_runs(D, send_idx, w->world);
+    if (e != hipSuccess) return bail(check(e, __FILE__, __LINE__));
+    // the push plan: one entry per destination with a share, blocks of kPushPerBlock elements
+    std::vector<push_peer> plan;
+    const size_t b = type_bytes(dtype);
+    int64_t first = 0, blk = 0;
+    for (int p = 0; p < w->world; ++p) {
+        const int64_t k = D->send_counts[p];
+        if (k) {
+            if (!w->peer[p]) return bail(fail(__FILE__, __LINE__, "the window of a rank this rank sends to has not been opened (vexhip_ipc_window_open)"));
+            push_peer q;
+            q.dst = w->peer[p] + window_header(w->world) + (size_t)dst_offsets[p] * b;
+            q.arrive = window_arrive(w->peer[p], w->rank);
+            q.consumed = window_consumed(w->base, w->world, p);
+            q.first = first; q.count = k; q.direct_first = D->direct ? D->send_first[p] : 0; q.blk0 = blk;
+            plan.push_back(q);
+            blk += (k + kPushPerBlock - 1) / kPushPerBlock;
+        }
+        first += k;
+    }
+    D->npush = (int)plan.size(); D->push_blocks = blk;
+    // the owners this rank waits for, and where it tells them that their share has been read
+    std::vector<const unsigned long long *> arr; std::vector<unsigned long long *> con;
+    for (int o = 0; o < w->world; ++o)
+        if (D->recv_counts[o]) {
+            if (!w->peer[o]) return bail(fail(__FILE__, __LINE__, "the window of a rank this rank receives from has not been opened (vexhip_ipc_window_open)"));
+            arr.push_back(window_arrive(w->base, o));
+            con.push_back(window_consumed(w->peer[o], w->world, w->rank));
+        }
+    D->nown = (int)arr.size();
+    e = hipMalloc(reinterpret_cast<void **>(&D->d_err), sizeof(int));
+    if (e == hipSuccess) e = hipMemset(D->d_err, 0, sizeof(int));
+    if (e == hipSuccess && D->npush) {
+        e = hipMalloc(reinterpret_cast<void **>(&D->d_push), sizeof(push_peer) * plan.size());
+        if (e == hipSuccess) e = hipMemcpy(D->d_push, plan.data(), sizeof(push_peer) * plan.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&D->d_done), sizeof(unsigned long long) * plan.size());
+        if (e == hipSuccess) e = hipMemset(D->d_done, 0, sizeof(unsigned long long) * plan.size());
+    }
+    if (e == hipSuccess && D->nown) {
+        e = hipMalloc(reinterpret_cast<void **>(&D->d_arrive), sizeof(void *) * arr.size());
+        if (e == hipSuccess) e = hipMemcpy(D->d_arrive, arr.data(), sizeof(void *) * arr.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&D->d_consumed), sizeof(void *) * con.size());
+        if (e == hipSuccess) e = hipMemcpy(D->d_consumed, con.data(), sizeof(void *) * con.size(), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) return bail(check(e, __FILE__, __LINE__));
+    *out = reinterpret_cast<vexhip_dist_spmv *>(D);
+    return 0;
+}
+
+int vexhip_dist_spmv_status(vexhip_dist_spmv *h, int *timed_out, int *transport, int *direct) {
+    dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
+    VEXHIP_REQUIRE(D, "NULL argument");
+    if (timed_out) {
+        *timed_out = 0;
+        if (D->d_err) { VEXHIP_SET_DEVICE(D->dev); VEXHIP_TRY(hipMemcpy(timed_out, D->d_err, sizeof(int), hipMemcpyDeviceToHost)); }
+    }
+    if (transport) *transport = D->win ? VEXHIP_COMM_IPC : VEXHIP_COMM_RCCL;
+    if (direct) *direct = D->direct ? 1 : 0;
+    return 0;
+}
+
+int vexhip_dist_spmv_profile(vexhip_dist_spmv *h, void *stream, double alpha, int append, const void *x, void *y, float *ms6) {
+    dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
+    VEXHIP_REQUIRE(D && ms6 && (x || !D->rows) && (y || !D->rows), "NULL argument");
+    if (!D->win && (D->nsend || D->nghost)) RCCL_READY();
+    VEXHIP_SET_DEVICE(D->dev);
+    hipStream_t s = as_stream(stream);
+    hipEvent_t *ev = new (std::nothrow) hipEvent_t[7]();
+    VEXHIP_REQUIRE(ev, "out of host memory");
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 7 && e == hipSuccess; ++k) e = hipEventCreate(&ev[k]);
+    int rc = 0;
+    if (e == hipSuccess) {
+        D->prof = ev;
+        rc = issue_step(D, s, alpha, append, x, y);
+        D->prof = nullptr;
+        if (!rc) e = hipStreamSynchronize(s);
+        if (!rc && e == hipSuccess && D->comm_stream) e = hipStreamSynchronize(D->comm_stream);
+        // total, local part, wait for the ghosts after the local part, remote part, pack, exchange
+        const int pair[6][2] = {{0, 3}, {0, 1}, {1, 2}, {2, 3}, {4, 5}, {5, 6}};
+        for (int k = 0; k < 6 && !rc && e == hipSuccess; ++k) e = hipEventElapsedTime(&ms6[k], ev[pair[k][0]], ev[pair[k][1]]);
+    }
+    for (int k = 0; k < 7; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
+    delete[] ev;
+    if (rc) return rc;
+    VEXHIP_TRY(e);
+    return 0;
+}
+
+int vexhip_comm_rccl_info(const vexhip_comm *h, int *nranks, int *device, int *user_rank) {
+    const comm *c = reinterpret_cast<const comm *>(h);
+    VEXHIP_REQUIRE(c, "NULL communicator");
+    if (nranks) *nranks = c->world;
+    if (device) *device = c->devs.empty() ? -1 : c->devs[0];
+    if (user_rank) *user_rank = c->ranks.empty() ? -1 : c->ranks[0];
+    if (c->peer || c->comms.empty() || !c->comms[0]) return 0;
+    RCCL_READY();
+    rccl_api &a = rccl();
+    if (nranks && a.CommCount) NCCL_TRY(a.CommCount(c->comms[0], nranks));            // what RCCL itself says
+    if (device && a.CommCuDevice) NCCL_TRY(a.CommCuDevice(c->comms[0], device));
+    if (user_rank && a.CommUserRank) NCCL_TRY(a.CommUserRank(c->comms[0], user_rank));
     return 0;
 }
 

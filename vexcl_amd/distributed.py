@@ -131,69 +131,202 @@ class DistSpMat:
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._p2p = self._plan_p2p()
         self._ops = None
-        self._native, self._comm, self.native_error = None, None, None
+        self._native, self._comm, self._window, self.native_error, self.native_transport = None, None, None, None, None
 
     # ---- the product step issued from C++ (include/vexhip.h vexhip_dist_spmv_*) --------------------------------------
-    def enable_native(self, graph=False):
+    def _coll_device(self):
+        """where tensors of set-up collectives live: the GPU for nccl, the host for gloo"""
+        return self.dev if (dist.is_initialized() and dist.get_backend(self.group) == "nccl") else torch.device("cpu")
+
+    def _agree(self, ok):
+        """True only if EVERY rank says ok (all-reduce MIN).  Every stage of enable_native ends in one of these, so a rank
+        that fails early never leaves the others blocked in a later broadcast / ncclCommInitRank / all-gather."""
+        if self.world == 1 or not dist.is_initialized():
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._coll_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.cpu()[0]))
+
+    def _stage(self, fn):
+        """run one local set-up stage; remember why it failed; agree with the other ranks"""
+        ok = True
+        try:
+            fn()
+        except Exception as e:
+            self.native_error = repr(e)
+            ok = False
+        if not self._agree(ok):
+            if ok:
+                self.native_error = self.native_error or "another rank could not set the step up"
+            return False
+        return True
+
+    def enable_native(self, graph=False, transport="rccl"):
         """Replace the per-product Python step (gather launch, torch.distributed request objects, two ctypes launches)
-        by ONE call into libvexhip: pack -> grouped ncclSend/ncclRecv on a second stream -> local part -> remote part,
-        with its own RCCL communicator (the unique id travels over this process group).  Returns True when active;
-        on any failure the torch.distributed transport stays in place and `native_error` says why."""
+        by ONE call into libvexhip.  transport "rccl": pack -> grouped ncclSend/ncclRecv on a second stream -> local
+        part -> remote part, over its own RCCL communicator (the unique id travels over this process group);
+        transport "ipc": peer-mapped ghost windows -- every owner writes its neighbours' shares straight into their
+        windows (hipIpcGetMemHandle; the handles travel over this process group), no communicator at all.
+        Collective: every rank must call it; it becomes active on all ranks or on none (`native_error` says why)."""
         import ctypes
         from . import _capi
-        try:
+        self.disable_native()
+        self.native_error = None
+        L = None
+        st = {}
+
+        def pre():
+            nonlocal L
+            if transport not in ("rccl", "ipc"):
+                raise ValueError("unknown transport %r" % (transport,))
             if self.dev.type != "cuda" or not hasattr(self.k, "make_remote"):
                 raise RuntimeError("native step needs the device kernels")
             if self.loc is not None and not getattr(self.loc, "handle", None):
                 raise RuntimeError("local part is not a vexhip_spmat")
             L = _capi.lib()
-            idbuf = torch.zeros(128, dtype=torch.uint8)
-            if self.rank == 0:
-                raw = (ctypes.c_char * 128)()
-                L.comm_unique_id(ctypes.cast(raw, ctypes.c_void_p))
-                idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-            if self.world > 1:
-                t = idbuf.to(self.dev) if dist.get_backend(self.group) == "nccl" else idbuf
-                dist.broadcast(t, src=self._global_rank(0), group=self.group)
-                idbuf = t.cpu()
-            idbytes = (ctypes.c_char * 128).from_buffer_copy(bytes(idbuf.numpy().tobytes()))
-            comm = ctypes.c_void_p()
-            L.comm_init_rank(self.dev.index or 0, self.rank, self.world, ctypes.cast(idbytes, ctypes.c_void_p), ctypes.byref(comm))
-            self._comm = comm
-            p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
-            sc = (ctypes.c_int64 * self.world)(*[int(c) for c in self.send_counts])
-            rc = (ctypes.c_int64 * self.world)(*[int(c) for c in self.recv_counts])
-            rem = self.rem
-            step = ctypes.c_void_p()
-            L.dist_spmv_create(comm, _capi.F64 if self.send_buf.dtype == torch.float64 else _capi.F32, self.rows,
-                               self.loc.handle if self.loc is not None else None,
-                               rem.rows.numel() if rem is not None else 0,
-                               p(rem.rows) if rem is not None else None, p(rem.ptr) if rem is not None else None,
-                               p(rem.col) if rem is not None else None, p(rem.val) if rem is not None else None,
-                               self.send_idx.numel(), p(self.send_idx), p(self.send_buf), sc,
-                               self.ghost_buf.numel(), p(self.ghost_buf), rc, ctypes.byref(step))
-            if graph:
-                L.dist_spmv_set_graph(step, 1)
-            self._native = step
-            return True
-        except Exception as e:          # keep the torch.distributed transport
-            self.native_error = repr(e)
-            self._native = None
+        if not self._stage(pre):
             return False
 
-    def disable_native(self):
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        sc = (ctypes.c_int64 * self.world)(*[int(c) for c in self.send_counts])
+        rc = (ctypes.c_int64 * self.world)(*[int(c) for c in self.recv_counts])
+        rem = self.rem
+        dt = _capi.F64 if self.send_buf.dtype == torch.float64 else _capi.F32
+        rem_args = (rem.rows.numel() if rem is not None else 0,
+                    p(rem.rows) if rem is not None else None, p(rem.ptr) if rem is not None else None,
+                    p(rem.col) if rem is not None else None, p(rem.val) if rem is not None else None)
+        cdev = self._coll_device()
+        try:
+            if transport == "rccl":
+                def make_id():
+                    st["id"] = torch.zeros(128, dtype=torch.uint8)
+                    if self.rank == 0:
+                        raw = (ctypes.c_char * 128)()
+                        L.comm_unique_id(ctypes.cast(raw, ctypes.c_void_p))
+                        st["id"] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+                if not self._stage(make_id):
+                    return False
+                idbuf = st["id"]
+                if self.world > 1:
+                    t = idbuf.to(cdev)
+                    dist.broadcast(t, src=self._global_rank(0), group=self.group)
+                    idbuf = t.cpu()
+                idbytes = (ctypes.c_char * 128).from_buffer_copy(bytes(idbuf.numpy().tobytes()))
+
+                def make_step():
+                    comm = ctypes.c_void_p()
+                    L.comm_init_rank(self.dev.index or 0, self.rank, self.world, ctypes.cast(idbytes, ctypes.c_void_p), ctypes.byref(comm))
+                    self._comm = comm
+                    step = ctypes.c_void_p()
+                    L.dist_spmv_create(comm, dt, self.rows, self.loc.handle if self.loc is not None else None, *rem_args,
+                                       self.send_idx.numel(), p(self.send_idx), p(self.send_buf), sc,
+                                       self.ghost_buf.numel(), p(self.ghost_buf), rc, ctypes.byref(step))
+                    st["step"] = step
+                if not self._stage(make_step):
+                    self._drop_native(st.get("step"))
+                    return False
+            else:
+                def make_window():
+                    win = ctypes.c_void_p()
+                    L.ipc_window_create(self.dev.index or 0, self.rank, self.world,
+                                        int(self.ghost_buf.numel()) * self.ghost_buf.element_size(), ctypes.byref(win))
+                    self._window = win
+                    raw = (ctypes.c_char * 64)()
+                    L.ipc_window_export(win, ctypes.cast(raw, ctypes.c_void_p))
+                    st["handle"] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+                if not self._stage(make_window):
+                    self._drop_native(None)
+                    return False
+                handles = [st["handle"]]
+                counts = [torch.tensor([int(c) for c in self.recv_counts], dtype=torch.int64)]
+                if self.world > 1:
+                    hs = [torch.empty(64, dtype=torch.uint8, device=cdev) for _ in range(self.world)]
+                    dist.all_gather(hs, st["handle"].to(cdev), group=self.group)
+                    cs = [torch.empty(self.world, dtype=torch.int64, device=cdev) for _ in range(self.world)]
+                    dist.all_gather(cs, counts[0].to(cdev), group=self.group)
+                    handles, counts = [h.cpu() for h in hs], [c.cpu() for c in cs]
+
+                def make_step():
+                    for peer in range(self.world):
+                        if peer != self.rank and (self.send_counts[peer] or self.recv_counts[peer]):
+                            hb = (ctypes.c_char * 64).from_buffer_copy(bytes(handles[peer].numpy().tobytes()))
+                            L.ipc_window_open(self._window, peer, ctypes.cast(hb, ctypes.c_void_p))
+                    # my share sits in peer p's ghost set behind the shares of the owners before me
+                    offs = (ctypes.c_int64 * self.world)(*[int(counts[peer][:self.rank].sum()) for peer in range(self.world)])
+                    if any(int(counts[peer][self.rank]) != int(self.send_counts[peer]) for peer in range(self.world)):
+                        raise RuntimeError("exchange plans of the ranks do not match")
+                    step = ctypes.c_void_p()
+                    L.dist_spmv_create_ipc(self._window, dt, self.rows, self.loc.handle if self.loc is not None else None, *rem_args,
+                                           self.send_idx.numel(), p(self.send_idx), sc, offs,
+                                           self.ghost_buf.numel(), rc, ctypes.byref(step))
+                    st["step"] = step
+                if not self._stage(make_step):
+                    self._drop_native(st.get("step"))
+                    return False
+        except Exception as e:              # a failed collective: nothing sensible is left to agree on
+            self.native_error = repr(e)
+            self._drop_native(st.get("step"))
+            return False
+        if graph:
+            L.dist_spmv_set_graph(st["step"], 1)
+        self._native = st["step"]
+        self.native_transport = transport
+        return True
+
+    def _drop_native(self, step):
         from . import _capi
-        if self._native:
-            _capi.lib().dist_spmv_destroy(self._native)
-        self._native = None
+        L = _capi.lib()
+        if step:
+            L.dist_spmv_destroy(step)
+        if getattr(self, "_comm", None):
+            L.comm_destroy(self._comm)
+            self._comm = None
+        if getattr(self, "_window", None):
+            L.ipc_window_destroy(self._window)
+            self._window = None
+
+    def disable_native(self):
+        step, self._native = getattr(self, "_native", None), None
+        self.native_transport = None
+        if step or getattr(self, "_comm", None) or getattr(self, "_window", None):
+            if self.dev.type == "cuda":
+                torch.cuda.synchronize(self.dev)
+            self._drop_native(step)
+
+    def native_status(self):
+        """(timed_out, transport, direct) of the active C++ step: timed_out != 0 means a flag wait of the IPC transport ran
+        into its bound (a peer did not show up)."""
+        import ctypes
+        from . import _capi
+        if not self._native:
+            return None
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _capi.lib().dist_spmv_status(self._native, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return {"timed_out": a.value, "transport": {1: "rccl", 3: "ipc"}.get(b.value, b.value), "direct": bool(c.value)}
+
+    def rccl_info(self):
+        import ctypes
+        from . import _capi
+        if not getattr(self, "_comm", None):
+            return None
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _capi.lib().comm_rccl_info(self._comm, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return {"ncclCommCount": a.value, "ncclCommCuDevice": b.value, "ncclCommUserRank": c.value}
+
+    def profile_step(self, x, y, alpha=1.0, append=False):
+        """One product through the C++ step with its phases timed (ms): total, local, wait, remote, pack, exchange."""
+        import ctypes
+        from . import _capi
+        if not self._native:
+            return None
+        ms = (ctypes.c_float * 6)()
+        _capi.lib().dist_spmv_profile(self._native, ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream),
+                                      float(alpha), int(bool(append)), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ms)
+        return dict(zip(("total", "local", "wait_for_ghosts", "remote", "pack", "exchange"), [float(v) for v in ms]))
 
     def __del__(self):
         try:
-            from . import _capi
-            if getattr(self, "_native", None):
-                _capi.lib().dist_spmv_destroy(self._native)
-            if getattr(self, "_comm", None):
-                _capi.lib().comm_destroy(self._comm)
+            self._drop_native(getattr(self, "_native", None))
         except Exception:
             pass
 
