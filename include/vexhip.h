@@ -247,6 +247,33 @@ int vexhip_spmv_sell8_dict_f64_i32(int dev, void *stream, int64_t n, double alph
 int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *buf, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y, const vexhip_traversal *traversal);
+/* March products (round 3): the _dict products with the x window of the NEAR diagonals staged in an LDS ring that a
+ * workgroup carries along a run of consecutive slices -- one coalesced load of the 512 new elements per slice instead of
+ * one gather per near column; far diagonals (+-n^2 of a 3-D grid operator) still gather.  Replaces, like every SELL
+ * product, the per-row gathers of the reference's ELL kernel (vexcl/spmat/hybrid_ell.inl:238-269).  Bit-identical to
+ * the _dict products.  vexhip_sell8_march_plan decides from the diagonal table and the slice numbers whether it applies
+ * (usable = 0: call the _dict product): the code block must rarely change from slice to slice, and the near diagonals
+ * (grown from 0 outwards) are those whose window fits a ring of <= 32 KiB.  x_last = largest valid index of x (the
+ * fills report the largest ELL column through vexhip_sell8_last_fill_max_col, per thread).                            */
+typedef struct vexhip_march { int32_t lo, hi;      /* smallest / largest NEAR diagonal (lo <= 0 <= hi)                */
+                              int32_t run;         /* consecutive slices per workgroup (divides the strip length)     */
+                              int32_t usable;
+                              int64_t x_last; } vexhip_march;
+int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
+        int value_bytes, const vexhip_traversal *traversal, int64_t x_last, vexhip_march *out);
+int64_t vexhip_sell8_last_fill_max_col(void);
+int vexhip_spmv_sell8v_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const vexhip_traversal *traversal, const vexhip_march *march);
+int vexhip_spmv_sell8v_march_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const float *values, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march);
+int vexhip_spmv_sell8_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
+        const double *x, double *y, const vexhip_traversal *traversal, const vexhip_march *march);
+int vexhip_spmv_sell8_march_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
+        const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march);
 int vexhip_spmm_sell8_dict_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
         const void *buf, const void *pool, const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
         const double *const *x, double *const *y, const vexhip_traversal *traversal);
@@ -283,7 +310,8 @@ int vexhip_spmv_sell8v_f32_i32(int dev, void *stream, int64_t n, float alpha, in
 /* A/B switch of the SELL / SELL8 / SELL8V products (results are bit-identical either way):
  *   variant 0 (default): pair kernels -- a lane reads x for its two rows with ONE 16-byte load per ELL column
  *                        wherever the fill kernels could align the two rows (see the storage notes above);
- *   variant 1:           one 8-byte gather per entry (round 1).                                                     */
+ *   variant 1:           one 8-byte gather per entry (round 1);
+ *   variant 2:           pair kernels even where a march plan is given (the _march entry points then behave as _dict). */
 int vexhip_spmv_sell8_set_variant(int variant);
 
 /* ---- vex::SpMat on one device: ONE object that owns the storage selection -------------------------------------
@@ -302,7 +330,8 @@ enum { VEXHIP_SPMAT_AUTO = 0,      /* create(): most compact storage; info: neve
        VEXHIP_SPMAT_SELL = 3,      /* 32-bit columns (4 + sizeof(V) B per entry)                                  */
        VEXHIP_SPMAT_CSR = 4 };     /* the CSR arrays themselves (csr_stream_kernel)                               */
 enum { VEXHIP_SPMAT_BORROW_CSR = 1,      /* format CSR: keep the caller's arrays instead of copying them (caller keeps them alive) */
-       VEXHIP_SPMAT_NO_DICTIONARY = 2 };  /* value-coded storage: keep one block per slice even if the slices repeat (A/B, tests)   */
+       VEXHIP_SPMAT_NO_DICTIONARY = 2,   /* value-coded storage: keep one block per slice even if the slices repeat (A/B, tests)   */
+       VEXHIP_SPMAT_NO_MARCH = 4 };      /* keep the pair products where the march products would apply (A/B, tests)               */
 typedef struct vexhip_spmat_info {
     int32_t format, value_type, device, ndeltas, nvalues, reserved;
     int64_t rows, nnz, ell_width, tail_nnz, sell_bytes;
@@ -313,6 +342,7 @@ typedef struct vexhip_spmat_info {
     const int32_t *slice_blocks;    /* slice dictionary (NULL = none): the codes of slice s are block slice_blocks[s] of       */
     const void *code_pool;          /* code_pool, which holds dictionary_blocks distinct code blocks.  SELL8V: `sell` IS the   */
     int64_t dictionary_blocks;      /* pool (no per-slice storage left); SELL8: `sell` keeps the values, slice-major           */
+    vexhip_march march;             /* march product (usable = 1: apply() runs it; see vexhip_sell8_march_plan)                */
 } vexhip_spmat_info;
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int format, int flags, vexhip_spmat **out);

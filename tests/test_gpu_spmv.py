@@ -248,6 +248,96 @@ def test_variable_coefficient_128_every_storage(T, oracle):
     assert float(r.abs().max()) <= 1e-9 * float(np.abs(val).max())
 
 
+def _band(n, offsets, seed, dtype=np.float64, constant=False):
+    """banded matrix with the given diagonals (CSR, columns ascending); constant: one value per diagonal"""
+    rng = np.random.default_rng(seed)
+    rows = np.arange(n, dtype=np.int64)
+    cols = np.stack([rows + o for o in offsets], axis=1)
+    ok = (cols >= 0) & (cols < n)
+    vals = np.stack([(np.full(n, 0.5 + k) if constant else rng.random(n) + 0.25) for k in range(len(offsets))], axis=1)
+    ptr = np.zeros(n + 1, dtype=np.int32)
+    ptr[1:] = np.cumsum(ok.sum(axis=1))
+    return ptr, cols[ok].astype(np.int32), vals[ok].astype(dtype)
+
+
+@pytest.mark.parametrize("run", [2, 5, 16, 64])
+def test_march_product_is_bit_identical(T, oracle, built_lib, run):
+    """The march product (round 3: x window of the near diagonals in an LDS ring carried along a run of slices, far
+    diagonals gathered) against the pair product it replaces AND the CSR oracle, bit for bit: Poisson 128^3 (value codes:
+    near -128..128, far +-16384), the variable-coefficient operator on the same pattern (stored values), a banded matrix
+    whose diagonals are all near and whose last slice is ragged, single precision, '=' and '+= alpha', several run
+    lengths (the ring wraps after 2 / 4 slices; run 64 > slices per plane)."""
+    torch = T.torch
+    os.environ["VEXHIP_MARCH_RUN"] = str(run)
+    try:
+        n = 128
+        N = n ** 3
+        x = oracle.random_f64(3, N); y0 = oracle.random_f64(4, N)
+        for label, (ptr, col, val) in (("poisson", oracle.poisson3d(n)), ("diffusion", oracle.diffusion3d(n, 11))):
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+            B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+            assert A.march is not None and A.march["run"] == run and B.march is None, (label, A.march)
+            assert (A.march["lo"], A.march["hi"]) == (-128, 128) and A.march["x_last"] == N - 1
+            assert A.storage == ("sell8v" if label == "poisson" else "sell8") and A.dictionary_blocks > 0
+            want = oracle.spmv_csr(ptr, col, val, x)
+            for alpha, append in ((1.0, False), (-0.75, True)):
+                ya, yb = T.up(y0.copy()), T.up(y0.copy())
+                A.apply(T.up(x), ya, alpha, append); B.apply(T.up(x), yb, alpha, append)
+                assert torch.equal(ya, yb), (label, alpha)
+                assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (label, alpha)
+            # variant 2 = the pair kernels through the march entry points
+            T.L.spmv_sell8_set_variant(2)
+            try:
+                yc = torch.empty(N, dtype=torch.float64, device=T.dev); A.apply(T.up(x), yc)
+                assert np.array_equal(yc.cpu().numpy(), want)
+            finally:
+                T.L.spmv_sell8_set_variant(0)
+            if label == "poisson":
+                v32, x32 = val.astype(np.float32), x.astype(np.float32)
+                F = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32)); Fp = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), march=False)
+                assert F.march is not None and Fp.march is None
+                yf = torch.empty(N, dtype=torch.float32, device=T.dev); yp = torch.empty_like(yf)
+                F.apply(T.up(x32), yf); Fp.apply(T.up(x32), yp)
+                assert torch.equal(yf, yp)
+        # every diagonal near (odd and even offsets, one beyond the slice length), ragged last slice, constant values -> value codes
+        m = 200 * 512 + 77
+        offs = (-700, -513, -2, -1, 0, 1, 3, 512)
+        for constant in (True, False):
+            ptr, col, val = _band(m, offs, 5, constant=constant)
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+            assert A.storage == ("sell8v" if constant else "sell8")
+            assert A.march is not None and (A.march["lo"], A.march["hi"]) == (-700, 512), A.march
+            xb = oracle.random_f64(8, m)
+            ya = torch.empty(m, dtype=torch.float64, device=T.dev); yb = torch.empty_like(ya)
+            A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
+            assert torch.equal(ya, yb)
+            assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
+    finally:
+        os.environ.pop("VEXHIP_MARCH_RUN", None)
+
+
+def test_march_product_on_strips(T, built_lib):
+    """384^3 (56.6 M rows): large enough for the XCD strip order (36 slices per strip -> runs of 12), too large for the
+    CPU oracle in seconds: march == pair bit for bit, and both against an independent stencil evaluation."""
+    torch, ops = T.torch, T.ops
+    n = 384
+    N = n ** 3
+    dp, dc, dv = ops.poisson3d(n, T.dev)
+    A = ops.SpMat(dp, dc, dv); B = ops.SpMat(dp, dc, dv, march=False)
+    assert A.march is not None and A.info.traversal.chunk > 0 and A.info.traversal.chunk % A.march["run"] == 0, (A.march, A.info.traversal.chunk)
+    x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=T.dev), 7)
+    ya = torch.full((N,), 3.0, dtype=torch.float64, device=T.dev); yb = ya.clone()
+    A.apply(x, ya, 0.5, True); B.apply(x, yb, 0.5, True)
+    assert torch.equal(ya, yb)
+    h2i = float((n - 1) ** 2)
+    X = x.view(n, n, n)
+    ref = X.clone()
+    c = X[1:-1, 1:-1, 1:-1]
+    nb = (X[:-2, 1:-1, 1:-1] + X[2:, 1:-1, 1:-1] + X[1:-1, :-2, 1:-1] + X[1:-1, 2:, 1:-1] + X[1:-1, 1:-1, :-2] + X[1:-1, 1:-1, 2:])
+    ref[1:-1, 1:-1, 1:-1] = h2i * (6 * c - nb)
+    assert float((ya.view(n, n, n) - (3.0 + 0.5 * ref)).abs().max()) <= TOL * 12 * h2i
+
+
 def test_poisson512_properties(T):
     """BASELINE.json's full size (134 217 728 rows, 930 123 728 nnz): no CPU
     oracle in seconds at this size, so size-independent properties:

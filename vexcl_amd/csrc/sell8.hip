@@ -30,7 +30,10 @@ namespace vexhip {
 
 // A/B switch of the SELL products (vexhip_spmv_sell8_set_variant, shared with spmv.hip):
 // 0 = pair kernels (one 16-byte gather per lane and column; default), 1 = one 8-byte gather per entry (round 1).
+// 2 = pair kernels even where the march kernel applies.
 int g_sell8_variant = 0;
+// largest column index of the ELL part seen by the last sell8 / sell8v fill on this thread (x holds at least that + 1 elements)
+thread_local long long g_fill_max_col = -1;
 
 namespace {
 
@@ -458,6 +461,176 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
     store_pair<V>(n, i, alpha, append, sum, y);
 }
 
+// ---------------------------------------------------------------------------
+// MARCH kernels (round 3): the pair product with the x window of a slice staged in LDS and carried from slice to slice.
+//
+// With its codes on chip (slice dictionary) the pair kernel is bound by what it pulls through L1: seven 16-byte gathers
+// per lane and slice, 195 L1 accesses per wave, TA busy 70 % (profiles/r02_sq_summary.txt) -- 0.72 ms against 0.34 ms for
+// x and y alone.  But the NEAR diagonals of a banded matrix (|d| <= ~1000: the -n, -1, 0, +1, +n taps of a grid operator)
+// read one contiguous window of x per slice, x[i0 + lo .. i0 + 511 + hi], and the window of the NEXT slice is the same
+// window moved by 512 elements.  So a workgroup owns a RUN of consecutive slices and keeps that window in an LDS ring:
+//   per slice ONE coalesced 16-byte load per lane brings the 512 new elements (issued one slice ahead, written into the
+//   ring slot the previous slice has left), the near columns are served by ds_read_b128 / ds_read_b64, and only the FAR
+//   diagonals (+-n^2) still gather from global memory -- 4 vector-memory instructions per lane and slice instead of 18.
+//   The codes of a slice are decoded again only when its block number differs from the previous slice's.
+// Everything is still driven by the codes: a column is looked up in the diagonal table, near -> ring, far -> global, per
+// lane; same products, same order => bit-identical to the pair kernel (tests/test_gpu_spmv.py).  The host picks this
+// kernel when the matrix has a slice dictionary whose block numbers rarely change from slice to slice and the near
+// diagonals fit a ring of <= 32 KiB (vexhip_sell8_march_plan); otherwise the pair kernel runs as before.
+// ---------------------------------------------------------------------------
+struct march_dev { int lo, hi, lo_e, hi_e, mask, run; long long x_last; };
+
+__device__ __forceinline__ void march_run(const trav_dev &t, long long nblocks, int R, unsigned mb, long long &first, int &count) {
+    long long c;
+    if (t.chunk > 0) {       // strip order (traversal.hpp) in runs of R slices: R divides the strip length
+        const unsigned k = mb & 7u, q = mb >> 3;
+        const unsigned chunk = (unsigned)t.chunk, planes = (unsigned)t.planes, rpc = chunk / (unsigned)R;
+        const unsigned r = q / rpc, ri = q - r * rpc;
+        const unsigned tile = r / planes, p = r - tile * planes;
+        const long long l = (long long)tile * (8 * chunk) + k * chunk + ri * (unsigned)R;
+        first = (long long)p * t.plane_blocks + l;
+        c = t.plane_blocks - l; if (c > R) c = R;
+        if (c > nblocks - first) c = nblocks - first;
+    } else {
+        first = (long long)mb * R;
+        c = nblocks - first; if (c > R) c = R;
+    }
+    count = c > 0 ? (int)c : 0;
+}
+
+template <typename V>
+__device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__restrict__ x, long long g, long long x_last) {
+    typename vec2<V>::type v = {V(0), V(0)};
+    if (g >= 0 && g + 1 <= x_last) __builtin_memcpy(&v, x + g, sizeof(v));
+    else {
+        if (g >= 0 && g <= x_last) v.x = x[g];
+        if (g + 1 >= 0 && g + 1 <= x_last) v.y = x[g + 1];
+    }
+    return v;
+}
+
+template <typename V, int W, bool VCODED>
+__global__ __launch_bounds__(256)
+void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
+        const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks, march_dev mp)
+{
+    constexpr int WP = (W + 1) / 2;
+    constexpr long long SLICE = VCODED ? (long long)WP * 2048 : ((long long)WP * 1024 + (long long)W * S8_ROWS * (long long)sizeof(V));
+    constexpr long long CODE_BYTES = VCODED ? (long long)WP * 2048 : (long long)WP * 1024;
+    typedef typename vec2<V>::type V2;
+    extern __shared__ __align__(16) unsigned char s_ring_raw[];
+    V *ring = reinterpret_cast<V *>(s_ring_raw);
+    __shared__ int s_delta[256];
+    __shared__ V s_value[VCODED ? 256 : 1];
+
+    const int t = threadIdx.x;
+    long long first; int count;
+    march_run(trav, nslices, mp.run, blockIdx.x, first, count);
+    if (count <= 0) return;                                   // the whole workgroup: holes of the strip order
+    s_delta[t] = deltas[t];
+    if constexpr (VCODED) s_value[t] = values[t];
+
+    const int mask = mp.mask;
+    const long long i00 = first * S8_ROWS;
+    const long long g0 = i00 + mp.lo_e;                       // the element at ring position 0
+    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e), and -- in registers -- the 512 elements the second needs
+    const int wpairs = (S8_ROWS + mp.hi_e - mp.lo_e) / 2;
+    for (int p = t; p < wpairs; p += 256)
+        *reinterpret_cast<V2 *>(ring + ((2 * p) & mask)) = load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last);
+    V2 chunk = {V(0), V(0)};
+    if (count > 1) chunk = load_pair_clamped<V>(x, i00 + S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
+    __syncthreads();
+
+    int cur = -1;
+    unsigned c[WP], vc[VCODED ? WP : 1];
+    int d[W];
+    for (int k = 0; k < count; ++k) {
+        const long long s = first + k;
+        const long long i = s * S8_ROWS + 2 * t;
+        const int rel = k * S8_ROWS - mp.lo_e + 2 * t;          // ring position of x[i] (before masking)
+        // the elements slice k + 1 adds to the window arrived during slice k - 1: into the slot slice k - 1 has left
+        if (k + 1 < count) *reinterpret_cast<V2 *>(ring + ((rel + S8_ROWS + mp.hi_e) & mask)) = chunk;
+        if (k + 2 < count) chunk = load_pair_clamped<V>(x, i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
+        // stored values of this slice (general banded matrices): streamed once
+        V2 v[VCODED ? 1 : W];
+        if constexpr (!VCODED) {
+            const V *vp = reinterpret_cast<const V *>(buf + s * SLICE + (long long)WP * 1024) + 2 * t;
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * S8_ROWS));
+        }
+        const int blk = blocks[s];
+        if (blk != cur) {                                        // uniform: a new code block -- load and decode it
+            cur = blk;
+            const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
+#pragma unroll
+            for (int jp = 0; jp < WP; ++jp) {
+                c[jp] = cw[jp * 256];
+                if constexpr (VCODED) vc[jp] = cw[(WP + jp) * 256];
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+                d[j] = s_delta[c0 < S8_PAD_UNSAFE ? c0 : c1];
+            }
+        }
+        V xv[W][2];
+        // far columns first (global gathers in flight while the ring is read)
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
+            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
+            const bool use16 = pair && (m0 || m1) && !near;
+            V2 p = {V(0), V(0)};
+            if (__builtin_amdgcn_ballot_w64(use16) != 0) {
+                const V *px = use16 ? x + (i + d[j]) : reinterpret_cast<const V *>(deltas);
+                __builtin_memcpy(&p, px, sizeof(V2));
+            }
+            xv[j][0] = p.x; xv[j][1] = p.y;
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
+            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
+            if (pair && (m0 || m1) && near) {
+                const int pos = (rel + d[j]) & mask;
+                if ((d[j] & 1) == 0) { const V2 p = *reinterpret_cast<const V2 *>(ring + pos); xv[j][0] = p.x; xv[j][1] = p.y; }
+                else { xv[j][0] = ring[pos]; xv[j][1] = ring[(pos + 1) & mask]; }
+            }
+            if (!pair) {                   // different diagonals in one lane, or a 16-byte load that would leave x
+                if (m0) { const int d0 = s_delta[c0]; xv[j][0] = (d0 >= mp.lo && d0 <= mp.hi) ? ring[(rel + d0) & mask] : x[i + d0]; }
+                if (m1) { const int d1 = s_delta[c1]; xv[j][1] = (d1 >= mp.lo && d1 <= mp.hi) ? ring[(rel + 1 + d1) & mask] : x[i + 1 + d1]; }
+            }
+            xv[j][0] = m0 ? xv[j][0] : V(0);
+            xv[j][1] = m1 ? xv[j][1] : V(0);
+        }
+        V sum[2] = {V(0), V(0)};
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sh = 16 * (j & 1) + 8 * q;
+                V a;
+                if constexpr (VCODED) a = s_value[((c[j >> 1] >> sh) & 255u) < S8_PAD_UNSAFE ? (vc[j >> 1] >> sh) & 255u : 255u];
+                else a = v[j][q];
+                sum[q] += a * xv[j][q];
+            }
+        if (csr_ptr) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (i + q < n)
+                    for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+        }
+        store_pair<V>(n, i, alpha, append, sum, y);
+        __syncthreads();          // slice k is done with the ring: its oldest 512 elements may be overwritten
+    }
+}
+
 // distinct value bit patterns of the ELL part: gset = HASH_SLOTS words (all-ones = empty), info as delta_collect_kernel
 template <typename B>
 __device__ __forceinline__ bool vset_insert(B *set, int slots, B v, bool *is_new) {
@@ -595,6 +768,33 @@ void csr_delta_count_kernel(long long n, int w, int ndeltas, const int *__restri
     if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
+template <typename V, bool VCODED>
+int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int append, int w, const char *buf, const int *deltas, const V *values,
+        const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr, const char *pool, const int *blocks,
+        const vexhip_march *m)
+{
+    const int lo_e = m->lo & ~1, hi_e = (m->hi + 1) & ~1;                 // window bounds on even elements (16-byte ring accesses)
+    int cap = 1024;
+    while (cap < S8_ROWS + hi_e - lo_e + S8_ROWS) cap <<= 1;
+    VEXHIP_REQUIRE(m->lo <= 0 && m->hi >= 0 && m->run >= 1 && (size_t)cap * sizeof(V) <= 64 * 1024, "bad march plan");
+    const bool strips = tr && tr->grid_blocks > 0 && tr->chunk > 0;
+    VEXHIP_REQUIRE(!strips || tr->chunk % m->run == 0, "march run does not divide the strip length");
+    const long long grid = strips ? tr->grid_blocks / m->run : (ns + m->run - 1) / m->run;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    trav_dev t8 = {nullptr, 0, 0, 0};
+    if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
+    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, (long long)m->x_last};
+    const size_t lds = (size_t)cap * sizeof(V);
+#define MARCH(W) case W: sell8_march_kernel<V, W, VCODED><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, buf, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
+    switch (w) {
+        MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
+        default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
+    }
+#undef MARCH
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 inline int grid_for(int dev, int64_t n) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16));
 }
@@ -640,12 +840,13 @@ int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col,
             dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
-    int hinfo[2] = {0, 0};
+    int hinfo[3] = {0, 0, -1};
     VEXHIP_TRY(hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipMemcpyAsync(hinfo, dinfo, sizeof(hinfo), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * ndeltas, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     VEXHIP_TRY(hipFree(dcounts));
+    g_fill_max_col = hinfo[2];
     VEXHIP_REQUIRE(hinfo[1] == 0, "SELL8 fill: the matrix uses a diagonal that is not in the table");
     if (trav) strip_traversal(n, table, counts, trav);
     return 0;
@@ -654,7 +855,7 @@ int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col,
 template <typename V>
 int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w, const void *buf, const int *deltas,
         const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr,
-        const void *pool_ = nullptr, const int *blocks = nullptr)
+        const void *pool_ = nullptr, const int *blocks = nullptr, const vexhip_march *march = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL8 geometry");
     if (n == 0) return 0;
@@ -669,8 +870,10 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     if (ordered) t8 = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf), *pool = static_cast<const char *>(pool_);
+    if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
+        return march_launch<V, false>(dev, s, n, ns, alpha, append, (int)w, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, tr, pool, blocks, march);
 #define PAIR(W, DICT) sell8_pair_kernel<V, W, false, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, t8, pool, blocks)
-#define CASE(W) case W: if (g_sell8_variant == 0) { if (blocks) PAIR(W, true); else PAIR(W, false); } \
+#define CASE(W) case W: if (g_sell8_variant != 1) { if (blocks) PAIR(W, true); else PAIR(W, false); } \
         else sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8, pool, blocks); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -737,12 +940,13 @@ int sell8v_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col
             dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
-    int hinfo[2] = {0, 0};
+    int hinfo[3] = {0, 0, -1};
     VEXHIP_TRY(hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipMemcpyAsync(hinfo, dinfo, sizeof(hinfo), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * ndeltas, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     VEXHIP_TRY(hipFree(dcounts));
+    g_fill_max_col = hinfo[2];
     VEXHIP_REQUIRE(hinfo[1] == 0, "SELL8V fill: a diagonal or a value of the matrix is not in its table");
     if (trav) strip_traversal(n, table, counts, trav);
     return 0;
@@ -750,7 +954,8 @@ int sell8v_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col
 
 template <typename V>
 int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w, const void *buf, const int *deltas, const V *values,
-        const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr, const int *blocks = nullptr)
+        const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr, const int *blocks = nullptr,
+        const vexhip_march *march = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL8V geometry");
     if (n == 0) return 0;
@@ -762,8 +967,10 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     const trav_dev t8 = make_traversal(tr, ns, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
+    if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
+        return march_launch<V, true>(dev, s, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);
 #define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, b, blocks)
-#define CASE(W) case W: if (g_sell8_variant == 0 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \
+#define CASE(W) case W: if (g_sell8_variant != 1 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \
         else sell8v_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8, blocks); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
@@ -979,6 +1186,65 @@ int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha
         const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const float *cv,
         const float *x, float *y, const vexhip_traversal *traversal)
 { return spmv_sell8<float>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal, pool, blocks); }
+
+// ---- march plan -------------------------------------------------------------------------------------------------------
+int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
+        int value_bytes, const vexhip_traversal *traversal, int64_t x_last, vexhip_march *out)
+{
+    VEXHIP_REQUIRE(out, "NULL output");
+    std::memset(out, 0, sizeof(*out));
+    if (ndeltas < 1 || ndeltas > 254 || !deltas || !blocks || nslices < 8 || x_last < 0) return 0;
+    if (traversal && traversal->order) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    std::vector<int> table((size_t)ndeltas), id((size_t)nslices);
+    VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * (size_t)ndeltas, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(id.data(), blocks, sizeof(int) * (size_t)nslices, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    // the code block must rarely change from one slice to the next (a change costs a dependent load + decode)
+    int64_t changes = 0;
+    for (int64_t k = 1; k < nslices; ++k) changes += id[(size_t)k] != id[(size_t)k - 1];
+    if (changes * 2 > nslices) return 0;
+    // near diagonals: as many as a ring of <= 32 KiB holds (two slices + the span of the diagonals), grown from 0 outwards
+    const int max_elems = (int)(32 * 1024 / value_bytes);
+    int lo = 0, hi = 0;
+    std::vector<int> by_abs(table);
+    std::sort(by_abs.begin(), by_abs.end(), [](int a, int b) { return std::llabs((long long)a) < std::llabs((long long)b); });
+    for (int dlt : by_abs) {
+        const int nlo = std::min(lo, dlt), nhi = std::max(hi, dlt);
+        const long long span = 2ll * S8_ROWS + (((long long)nhi + 1) & ~1ll) - ((long long)nlo & ~1ll);
+        long long cap = 1024; while (cap < span) cap <<= 1;
+        if (cap > max_elems) break;
+        lo = nlo; hi = nhi;
+    }
+    int run = 16;
+    if (const char *e = std::getenv("VEXHIP_MARCH_RUN")) run = std::max(1, std::atoi(e));
+    if (traversal && traversal->grid_blocks > 0 && traversal->chunk > 0) {
+        while (run > 1 && traversal->chunk % run != 0) --run;
+    }
+    if (run < 2) return 0;
+    out->lo = lo; out->hi = hi; out->run = run; out->x_last = x_last; out->usable = 1;
+    return 0;
+}
+
+int64_t vexhip_sell8_last_fill_max_col(void) { return g_fill_max_col; }
+
+int vexhip_spmv_sell8v_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *x, double *y, const vexhip_traversal *traversal, const vexhip_march *march)
+{ return spmv_sell8v<double>(dev, stream, n, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks, (march && march->usable) ? march : nullptr); }
+int vexhip_spmv_sell8v_march_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const float *values, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march)
+{ return spmv_sell8v<float>(dev, stream, n, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks, (march && march->usable) ? march : nullptr); }
+int vexhip_spmv_sell8_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const double *cv,
+        const double *x, double *y, const vexhip_traversal *traversal, const vexhip_march *march)
+{ return spmv_sell8<double>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal, pool, blocks, (march && march->usable) ? march : nullptr); }
+int vexhip_spmv_sell8_march_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *buf, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const float *cv,
+        const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march)
+{ return spmv_sell8<float>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal, pool, blocks, (march && march->usable) ? march : nullptr); }
 
 int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
         int rows_per_block, vexhip_traversal *traversal)

@@ -352,9 +352,10 @@ class SpMat:
 
     _FORMATS = {"sell": _capi.SPMAT_AUTO, "sell8": _capi.SPMAT_SELL8, "sell32": _capi.SPMAT_SELL, "csr": _capi.SPMAT_CSR}
 
-    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True):
+    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True, march=True):
         """dictionary=False keeps one code block per slice even when the slices of a value-coded matrix repeat
-        (VEXHIP_SPMAT_NO_DICTIONARY: A/B and tests)."""
+        (VEXHIP_SPMAT_NO_DICTIONARY: A/B and tests); march=False keeps the pair product where the march product (x window
+        of the near diagonals in an LDS ring carried along a run of slices) would apply (VEXHIP_SPMAT_NO_MARCH)."""
         self.ptr, self.col, self.val = ptr, col, val
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
@@ -365,6 +366,7 @@ class SpMat:
             raise Error("unknown SpMat format %r" % fmt)
         self.hell, self.handle, self.csr_trav = None, None, None
         self.dictionary_blocks = 0
+        self.march = None
         self.dtype = val.dtype
         if fmt == "hell":                        # the reference's column-major hybrid ELL (kept for A/B and sparse::ell)
             self.hell = HybridELL(ptr, col, val)
@@ -379,13 +381,15 @@ class SpMat:
         h = ctypes.c_void_p()
         (L.spmat_create_f64_i32 if f64 else L.spmat_create_f32_i32)(
             _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
-            _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY), ctypes.byref(h))
+            _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH), ctypes.byref(h))
         self.handle = h
         info = _capi.SpMatInfo()
         L.spmat_get_info(h, ctypes.byref(info))
         self.info = info
         self.storage = _capi.SPMAT_NAMES[info.format]              # sell8v | sell8 | sell32 | csr
         self.dictionary_blocks = int(info.dictionary_blocks)       # > 0: the value-coded slices are stored once per DISTINCT slice
+        self.march = ({"lo": int(info.march.lo), "hi": int(info.march.hi), "run": int(info.march.run), "x_last": int(info.march.x_last)}
+                      if info.march.usable else None)              # not None: apply() runs the march product
         self.fmt = "csr" if self.storage == "csr" else "sell"      # SELL without an ELL part degrades to CSR
         if self.fmt == "sell":
             self.hell = _SellInfo(info)
