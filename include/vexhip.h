@@ -252,13 +252,16 @@ int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha
  * one gather per near column; far diagonals (+-n^2 of a 3-D grid operator) still gather.  Replaces, like every SELL
  * product, the per-row gathers of the reference's ELL kernel (vexcl/spmat/hybrid_ell.inl:238-269).  Bit-identical to
  * the _dict products.  vexhip_sell8_march_plan decides from the diagonal table and the slice numbers whether it applies
- * (usable = 0: call the _dict product): the code block must rarely change from slice to slice, and the near diagonals
+ * (usable = 0: call the _dict product; value-coded storage only -- with stored values the product is bound by the value
+ * stream, which the pair kernel already moves at 0.9 of the copy rate): the code block must rarely change from slice to slice, and the near diagonals
  * (grown from 0 outwards) are those whose window fits a ring of <= 32 KiB.  x_last = largest valid index of x (the
  * fills report the largest ELL column through vexhip_sell8_last_fill_max_col, per thread).                            */
 typedef struct vexhip_march { int32_t lo, hi;      /* smallest / largest NEAR diagonal (lo <= 0 <= hi)                */
                               int32_t run;         /* consecutive slices per workgroup (divides the strip length)     */
                               int32_t usable;
-                              int64_t x_last; } vexhip_march;
+                              int64_t x_last;
+                              int32_t nfar, far[3]; /* far diagonals requested one slice ahead (at most 2; the rest gather) */
+                            } vexhip_march;
 int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
         int value_bytes, const vexhip_traversal *traversal, int64_t x_last, vexhip_march *out);
 int64_t vexhip_sell8_last_fill_max_col(void);
@@ -267,12 +270,6 @@ int vexhip_spmv_sell8v_march_f64_i32(int dev, void *stream, int64_t n, double al
         const double *x, double *y, const vexhip_traversal *traversal, const vexhip_march *march);
 int vexhip_spmv_sell8v_march_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const float *values, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
-        const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march);
-int vexhip_spmv_sell8_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *buf, const void *pool,
-        const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
-        const double *x, double *y, const vexhip_traversal *traversal, const vexhip_march *march);
-int vexhip_spmv_sell8_march_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *buf, const void *pool,
-        const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const float *csr_val,
         const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march);
 int vexhip_spmm_sell8_dict_f64_i32(int dev, void *stream, int64_t n, int nrhs, double alpha, int append, int64_t ell_width,
         const void *buf, const void *pool, const int32_t *blocks, const int32_t *deltas, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,

@@ -276,9 +276,12 @@ def test_march_product_is_bit_identical(T, oracle, built_lib, run):
         for label, (ptr, col, val) in (("poisson", oracle.poisson3d(n)), ("diffusion", oracle.diffusion3d(n, 11))):
             A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
             B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
-            assert A.march is not None and A.march["run"] == run and B.march is None, (label, A.march)
-            assert (A.march["lo"], A.march["hi"]) == (-128, 128) and A.march["x_last"] == N - 1
-            assert A.storage == ("sell8v" if label == "poisson" else "sell8") and A.dictionary_blocks > 0
+            assert A.storage == ("sell8v" if label == "poisson" else "sell8") and A.dictionary_blocks > 0 and B.march is None
+            if label == "poisson":
+                assert A.march is not None and A.march["run"] == run, A.march
+                assert (A.march["lo"], A.march["hi"]) == (-128, 128) and A.march["x_last"] == N - 1 and A.march["far"] == [-16384, 16384]
+            else:
+                assert A.march is None            # stored values: bound by the value stream, the pair product stays
             want = oracle.spmv_csr(ptr, col, val, x)
             for alpha, append in ((1.0, False), (-0.75, True)):
                 ya, yb = T.up(y0.copy()), T.up(y0.copy())
@@ -299,36 +302,42 @@ def test_march_product_is_bit_identical(T, oracle, built_lib, run):
                 yf = torch.empty(N, dtype=torch.float32, device=T.dev); yp = torch.empty_like(yf)
                 F.apply(T.up(x32), yf); Fp.apply(T.up(x32), yp)
                 assert torch.equal(yf, yp)
-        # every diagonal near (odd and even offsets, one beyond the slice length), ragged last slice, constant values -> value codes
+        # banded matrices with a ragged last slice and one value per diagonal (value codes): (a) every diagonal near, odd and
+        # even offsets, one beyond the slice length; (b) three far diagonals -- two are requested a slice ahead, the third is
+        # gathered -- whose windows leave x at both ends of the matrix
         m = 200 * 512 + 77
-        offs = (-700, -513, -2, -1, 0, 1, 3, 512)
-        for constant in (True, False):
-            ptr, col, val = _band(m, offs, 5, constant=constant)
-            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
-            assert A.storage == ("sell8v" if constant else "sell8")
-            assert A.march is not None and (A.march["lo"], A.march["hi"]) == (-700, 512), A.march
-            xb = oracle.random_f64(8, m)
-            ya = torch.empty(m, dtype=torch.float64, device=T.dev); yb = torch.empty_like(ya)
-            A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
-            assert torch.equal(ya, yb)
-            assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
+        for offs, near, far in (((-700, -513, -2, -1, 0, 1, 3, 512), (-700, 512), []),
+                                ((-9000, -5000, -700, -2, 0, 1, 512, 7001), (-700, 512), [-5000, 7001])):
+            for constant in (True, False):
+                ptr, col, val = _band(m, offs, 5, constant=constant)
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+                assert A.storage == ("sell8v" if constant else "sell8")
+                if constant:
+                    assert A.march is not None and (A.march["lo"], A.march["hi"]) == near and A.march["far"] == far, A.march
+                else:
+                    assert A.march is None
+                xb = oracle.random_f64(8, m)
+                ya = torch.empty(m, dtype=torch.float64, device=T.dev); yb = torch.empty_like(ya)
+                A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
+                assert torch.equal(ya, yb)
+                assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
     finally:
         os.environ.pop("VEXHIP_MARCH_RUN", None)
 
 
-def test_march_product_on_strips(T, built_lib):
-    """384^3 (56.6 M rows): large enough for the XCD strip order (36 slices per strip -> runs of 12), too large for the
-    CPU oracle in seconds: march == pair bit for bit, and both against an independent stencil evaluation."""
+def test_march_needs_slices_that_repeat_in_runs(T, built_lib):
+    """384^3: a grid line is 384 rows, a slice 512 -- the code blocks of consecutive slices cycle with period 3, every
+    slice would decode anew, so the plan declines and the pair product runs (checked against an independent stencil
+    evaluation; the strip order with the march product is covered at 512^3 below)."""
     torch, ops = T.torch, T.ops
     n = 384
     N = n ** 3
     dp, dc, dv = ops.poisson3d(n, T.dev)
-    A = ops.SpMat(dp, dc, dv); B = ops.SpMat(dp, dc, dv, march=False)
-    assert A.march is not None and A.info.traversal.chunk > 0 and A.info.traversal.chunk % A.march["run"] == 0, (A.march, A.info.traversal.chunk)
+    A = ops.SpMat(dp, dc, dv)
+    assert A.march is None and A.dictionary_blocks > 0
     x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=T.dev), 7)
-    ya = torch.full((N,), 3.0, dtype=torch.float64, device=T.dev); yb = ya.clone()
-    A.apply(x, ya, 0.5, True); B.apply(x, yb, 0.5, True)
-    assert torch.equal(ya, yb)
+    ya = torch.full((N,), 3.0, dtype=torch.float64, device=T.dev)
+    A.apply(x, ya, 0.5, True)
     h2i = float((n - 1) ** 2)
     X = x.view(n, n, n)
     ref = X.clone()
@@ -359,6 +368,12 @@ def test_poisson512_properties(T):
     y1 = A_csr @ x
     y2 = A_ell @ x
     assert torch.equal(y1, y2)
+    # the default product here is the march product on the XCD strip order (64 slices per strip, runs of 16); the pair product
+    # of the same storage must give the same bits
+    assert A_ell.march is not None and A_ell.march["far"] == [-262144, 262144] and A_ell.info.traversal.chunk % A_ell.march["run"] == 0
+    A_pair = ops.SpMat(dp, dc, dv, march=False)
+    assert A_pair.march is None and torch.equal(A_pair @ x, y2)
+    del A_pair
     assert torch.equal(y1, A_hell @ x)
     y0 = torch.empty_like(y1)
     A_hell.hell.mul(x, y0, tiled=False)

@@ -56,7 +56,8 @@ class Traversal(ctypes.Structure):
 
 class March(ctypes.Structure):
     """vexhip_march (include/vexhip.h)."""
-    _fields_ = [("lo", ctypes.c_int32), ("hi", ctypes.c_int32), ("run", ctypes.c_int32), ("usable", ctypes.c_int32), ("x_last", ctypes.c_int64)]
+    _fields_ = [("lo", ctypes.c_int32), ("hi", ctypes.c_int32), ("run", ctypes.c_int32), ("usable", ctypes.c_int32), ("x_last", ctypes.c_int64),
+                ("nfar", ctypes.c_int32), ("far", ctypes.c_int32 * 3)]
 
 
 class SpMatInfo(ctypes.Structure):
@@ -155,8 +156,6 @@ _PROTOS = {
     "vexhip_sell8_last_fill_max_col": (c_i64, []),
     "vexhip_spmv_sell8v_march_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),
     "vexhip_spmv_sell8v_march_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),
-    "vexhip_spmv_sell8_march_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),
-    "vexhip_spmv_sell8_march_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),
     "vexhip_spmm_sell8_dict_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmm_sell8_dict_f32_i32": (None, [c_int, c_vp, c_i64, c_int, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmv_sell8v_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),

@@ -159,6 +159,9 @@ struct ipc_window {
     char *base = nullptr;
     std::vector<char *> peer;                  // base address of every opened window (own pointer for this rank)
     std::vector<char> opened;                  // mapped with hipIpcOpenMemHandle (to be closed)
+    unsigned long long step = 0;               // products issued over this window so far: the flags carry these numbers, so a
+                                               // second vexhip_dist_spmv on the same windows continues the count (every rank
+                                               // issues the same products in the same order)
 };
 inline size_t window_header(int world) { return ((size_t)world * 16 + 255) / 256 * 256; }
 inline unsigned long long *window_arrive(char *base, int o) { return reinterpret_cast<unsigned long long *>(base) + o; }
@@ -186,7 +189,7 @@ __device__ inline void spin_until(const unsigned long long *flag, unsigned long 
 template <typename T>
 __global__ __launch_bounds__(256)
 void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned long long step, const int32_t *__restrict__ idx,
-        const T *__restrict__ x, unsigned long long *done, int *err)
+        const T *__restrict__ x, unsigned long long *done, unsigned long long step0, int *err)
 {
     int j = 0;
     while (j + 1 < npeers && (long long)blockIdx.x >= peers[j + 1].blk0) ++j;
@@ -205,7 +208,7 @@ void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned l
     if (threadIdx.x == 0) {
         const unsigned long long nblk = (unsigned long long)((P.count + kPushPerBlock - 1) / kPushPerBlock);
         const unsigned long long old = __hip_atomic_fetch_add(&done[j], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == nblk * step) {                                     // ... the last block of this destination raises the flag
+        if (old + 1 == nblk * (step - step0)) {                                     // ... the last block of this destination raises the flag
             __threadfence_system();
             __hip_atomic_store(P.arrive, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -245,7 +248,7 @@ struct dist_spmv {
     const void *gx = nullptr; void *gy = nullptr; double galpha = 0; int gappend = 0; hipStream_t gstream = nullptr;
     // IPC transport (peer-mapped ghost windows): the owners WRITE their shares into the consumer's window
     ipc_window *win = nullptr;
-    unsigned long long step = 0;               // products issued so far (the flags carry step numbers)
+    unsigned long long step0 = 0;              // the window's product count when this plan was made (the `done` counters start there)
     push_peer *d_push = nullptr; int npush = 0; int64_t push_blocks = 0;
     unsigned long long *d_done = nullptr;      // per destination: blocks of the push kernel that have finished (monotonic)
     int *d_err = nullptr;                      // sticky: a flag was not raised within kSpinTicks
@@ -303,7 +306,7 @@ int local_part(dist_spmv *D, hipStream_t s, double alpha, int append, const void
 //   compute stream s:  [x ready] ...... local part ...... wait kernel (arrive flags) -> remote part -> signal kernel (consumed flags) -> wait(pushed)
 //   comm stream:       wait(x ready) -> push kernel: per destination wait for consumed >= step-1, write the share into ITS window, raise arrive = step
 int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
-    const unsigned long long step = ++D->step;
+    const unsigned long long step = ++D->win->step;
     PROF(0, s);
     if (D->npush) {
         VEXHIP_TRY(hipEventRecord(D->packed, s));
@@ -311,9 +314,9 @@ int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const 
         PROF(4, D->comm_stream); PROF(5, D->comm_stream);
         const int32_t *idx = D->direct ? nullptr : D->send_idx;
         if (D->dtype == VEXHIP_F64)
-            ipc_push_kernel<double><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const double *>(x), D->d_done, D->d_err);
+            ipc_push_kernel<double><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const double *>(x), D->d_done, D->step0, D->d_err);
         else
-            ipc_push_kernel<float><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const float *>(x), D->d_done, D->d_err);
+            ipc_push_kernel<float><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const float *>(x), D->d_done, D->step0, D->d_err);
         VEXHIP_LAUNCH_CHECK();
         PROF(6, D->comm_stream);
         VEXHIP_TRY(hipEventRecord(D->pushed, D->comm_stream));
@@ -790,7 +793,7 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
     VEXHIP_REQUIRE(w->world <= 64, "more than 64 ranks");
     dist_spmv *D = new (std::nothrow) dist_spmv;
     VEXHIP_REQUIRE(D, "out of host memory");
-    D->win = w; D->dev = w->dev; D->dtype = dtype; D->loc = local; D->rows = rows;
+    D->win = w; D->step0 = w->step; D->dev = w->dev; D->dtype = dtype; D->loc = local; D->rows = rows;
     D->rem_rows = rem_rows; D->rows_idx = rows_idx; D->rem_ptr = rem_ptr; D->rem_col = rem_col; D->rem_val = rem_val;
     D->nsend = nsend; D->send_idx = send_idx; D->nghost = nghost;
     D->ghost_buf = w->base + window_header(w->world);

@@ -478,7 +478,13 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
 // kernel when the matrix has a slice dictionary whose block numbers rarely change from slice to slice and the near
 // diagonals fit a ring of <= 32 KiB (vexhip_sell8_march_plan); otherwise the pair kernel runs as before.
 // ---------------------------------------------------------------------------
-struct march_dev { int lo, hi, lo_e, hi_e, mask, run; long long x_last; };
+#ifndef MARCH_WAVES
+#define MARCH_WAVES 4
+#endif
+#ifndef MARCH_BATCH
+#define MARCH_BATCH 4
+#endif
+struct march_dev { int lo, hi, lo_e, hi_e, mask, run, nfar, far0, far1; long long x_last; };
 
 __device__ __forceinline__ void march_run(const trav_dev &t, long long nblocks, int R, unsigned mb, long long &first, int &count) {
     long long c;
@@ -509,117 +515,106 @@ __device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__r
     return v;
 }
 
-template <typename V, int W, bool VCODED>
-__global__ __launch_bounds__(256)
+// Value-coded storage with a slice dictionary only: with stored values the product is bound by the value stream and the
+// pair kernel already moves it at 0.9 of the copy rate (a first version of this kernel with stored values: 1.85 against
+// 1.69 ms, profiles/r03_march_ab.json).
+template <typename V, int W>
+__global__ __launch_bounds__(256, MARCH_WAVES)
 void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
-        const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
+        const int *__restrict__ deltas, const V *__restrict__ values,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
         const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks, march_dev mp)
 {
     constexpr int WP = (W + 1) / 2;
-    constexpr long long SLICE = VCODED ? (long long)WP * 2048 : ((long long)WP * 1024 + (long long)W * S8_ROWS * (long long)sizeof(V));
-    constexpr long long CODE_BYTES = VCODED ? (long long)WP * 2048 : (long long)WP * 1024;
+    constexpr long long CODE_BYTES = (long long)WP * 2048;
     typedef typename vec2<V>::type V2;
     extern __shared__ __align__(16) unsigned char s_ring_raw[];
     V *ring = reinterpret_cast<V *>(s_ring_raw);
     __shared__ int s_delta[256];
-    __shared__ V s_value[VCODED ? 256 : 1];
+    __shared__ V s_value[256];
 
     const int t = threadIdx.x;
     long long first; int count;
     march_run(trav, nslices, mp.run, blockIdx.x, first, count);
     if (count <= 0) return;                                   // the whole workgroup: holes of the strip order
     s_delta[t] = deltas[t];
-    if constexpr (VCODED) s_value[t] = values[t];
+    s_value[t] = values[t];
 
     const int mask = mp.mask;
     const long long i00 = first * S8_ROWS;
     const long long g0 = i00 + mp.lo_e;                       // the element at ring position 0
-    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e), and -- in registers -- the 512 elements the second needs
+    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e), and -- in registers -- the 512 elements the second
+    // slice adds and the far diagonals' elements of the first slice
     const int wpairs = (S8_ROWS + mp.hi_e - mp.lo_e) / 2;
     for (int p = t; p < wpairs; p += 256)
         *reinterpret_cast<V2 *>(ring + ((2 * p) & mask)) = load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last);
     V2 chunk = {V(0), V(0)};
     if (count > 1) chunk = load_pair_clamped<V>(x, i00 + S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
+    V2 f0 = {V(0), V(0)}, f1 = {V(0), V(0)};
+    if (mp.nfar > 0) f0 = load_pair_clamped<V>(x, i00 + 2 * t + mp.far0, mp.x_last);
+    if (mp.nfar > 1) f1 = load_pair_clamped<V>(x, i00 + 2 * t + mp.far1, mp.x_last);
     __syncthreads();
 
     int cur = -1;
-    unsigned c[WP], vc[VCODED ? WP : 1];
+    unsigned c[WP], vc[WP];
     int d[W];
+    unsigned kinds = 0;             // 2 bits per column: 0 near (ring), 1 / 2 the prefetched far diagonals, 3 gathered from global memory
     for (int k = 0; k < count; ++k) {
         const long long s = first + k;
         const long long i = s * S8_ROWS + 2 * t;
         const int rel = k * S8_ROWS - mp.lo_e + 2 * t;          // ring position of x[i] (before masking)
-        // the elements slice k + 1 adds to the window arrived during slice k - 1: into the slot slice k - 1 has left
+        // Everything slice k + 1 reads from global memory is requested NOW, one slice ahead: the 512 elements it adds to the
+        // window (kept in registers until the ring slot is free) and its far diagonals.  What arrived during slice k - 1
+        // goes into the slot slice k - 1 has left.
         if (k + 1 < count) *reinterpret_cast<V2 *>(ring + ((rel + S8_ROWS + mp.hi_e) & mask)) = chunk;
         if (k + 2 < count) chunk = load_pair_clamped<V>(x, i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
-        // stored values of this slice (general banded matrices): streamed once
-        V2 v[VCODED ? 1 : W];
-        if constexpr (!VCODED) {
-            const V *vp = reinterpret_cast<const V *>(buf + s * SLICE + (long long)WP * 1024) + 2 * t;
-#pragma unroll
-            for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * S8_ROWS));
+        V2 n0 = {V(0), V(0)}, n1 = {V(0), V(0)};
+        if (k + 1 < count) {
+            if (mp.nfar > 0) n0 = load_pair_clamped<V>(x, i + S8_ROWS + mp.far0, mp.x_last);
+            if (mp.nfar > 1) n1 = load_pair_clamped<V>(x, i + S8_ROWS + mp.far1, mp.x_last);
         }
         const int blk = blocks[s];
         if (blk != cur) {                                        // uniform: a new code block -- load and decode it
             cur = blk;
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
 #pragma unroll
-            for (int jp = 0; jp < WP; ++jp) {
-                c[jp] = cw[jp * 256];
-                if constexpr (VCODED) vc[jp] = cw[(WP + jp) * 256];
-            }
+            for (int jp = 0; jp < WP; ++jp) { c[jp] = cw[jp * 256]; vc[jp] = cw[(WP + jp) * 256]; }
+            kinds = 0;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
                 d[j] = s_delta[c0 < S8_PAD_UNSAFE ? c0 : c1];
+                const unsigned kind = (d[j] >= mp.lo && d[j] <= mp.hi) ? 0u : (mp.nfar > 0 && d[j] == mp.far0) ? 1u : (mp.nfar > 1 && d[j] == mp.far1) ? 2u : 3u;
+                kinds |= kind << (2 * j);
             }
-        }
-        V xv[W][2];
-        // far columns first (global gathers in flight while the ring is read)
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
-            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
-            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
-            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
-            const bool use16 = pair && (m0 || m1) && !near;
-            V2 p = {V(0), V(0)};
-            if (__builtin_amdgcn_ballot_w64(use16) != 0) {
-                const V *px = use16 ? x + (i + d[j]) : reinterpret_cast<const V *>(deltas);
-                __builtin_memcpy(&p, px, sizeof(V2));
-            }
-            xv[j][0] = p.x; xv[j][1] = p.y;
-        }
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
-            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
-            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
-            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
-            if (pair && (m0 || m1) && near) {
-                const int pos = (rel + d[j]) & mask;
-                if ((d[j] & 1) == 0) { const V2 p = *reinterpret_cast<const V2 *>(ring + pos); xv[j][0] = p.x; xv[j][1] = p.y; }
-                else { xv[j][0] = ring[pos]; xv[j][1] = ring[(pos + 1) & mask]; }
-            }
-            if (!pair) {                   // different diagonals in one lane, or a 16-byte load that would leave x
-                if (m0) { const int d0 = s_delta[c0]; xv[j][0] = (d0 >= mp.lo && d0 <= mp.hi) ? ring[(rel + d0) & mask] : x[i + d0]; }
-                if (m1) { const int d1 = s_delta[c1]; xv[j][1] = (d1 >= mp.lo && d1 <= mp.hi) ? ring[(rel + 1 + d1) & mask] : x[i + 1 + d1]; }
-            }
-            xv[j][0] = m0 ? xv[j][0] : V(0);
-            xv[j][1] = m1 ? xv[j][1] : V(0);
         }
         V sum[2] = {V(0), V(0)};
 #pragma unroll
-        for (int j = 0; j < W; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int sh = 16 * (j & 1) + 8 * q;
-                V a;
-                if constexpr (VCODED) a = s_value[((c[j >> 1] >> sh) & 255u) < S8_PAD_UNSAFE ? (vc[j >> 1] >> sh) & 255u : 255u];
-                else a = v[j][q];
-                sum[q] += a * xv[j][q];
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
+            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+            const unsigned kind = (kinds >> (2 * j)) & 3u;
+            V2 p = kind == 1u ? f0 : f1;
+            if (pair && (m0 || m1)) {
+                if (kind == 0u) {
+                    const int pos = (rel + d[j]) & mask;
+                    if ((d[j] & 1) == 0) p = *reinterpret_cast<const V2 *>(ring + pos);
+                    else { p.x = ring[pos]; p.y = ring[(pos + 1) & mask]; }
+                } else if (kind == 3u) __builtin_memcpy(&p, x + (i + d[j]), sizeof(V2));       // a far diagonal beyond the prefetched ones
             }
+            if (!pair) {                   // different diagonals in one lane, or a 16-byte load that would leave x
+                if (m0) { const int d0 = s_delta[c0]; p.x = (d0 >= mp.lo && d0 <= mp.hi) ? ring[(rel + d0) & mask] : x[i + d0]; }
+                if (m1) { const int d1 = s_delta[c1]; p.y = (d1 >= mp.lo && d1 <= mp.hi) ? ring[(rel + 1 + d1) & mask] : x[i + 1 + d1]; }
+            }
+            // value codes -> table (entry 255 is 0.0); gathered values of padding entries are replaced by 0: sum + (+-0) == sum
+            const unsigned vw = vc[j >> 1] >> (16 * (j & 1));
+            const V a0 = s_value[m0 ? (vw & 255u) : 255u], a1 = s_value[m1 ? ((vw >> 8) & 255u) : 255u];
+            sum[0] += a0 * (m0 ? p.x : V(0));
+            sum[1] += a1 * (m1 ? p.y : V(0));
+            // keep the LDS reads of at most MARCH_BATCH columns in flight: hoisting all of them costs 110+ registers
+            if constexpr (W > MARCH_BATCH) if (j % MARCH_BATCH == MARCH_BATCH - 1) __builtin_amdgcn_sched_barrier(0);
+        }
         if (csr_ptr) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -627,6 +622,7 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
                     for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
         }
         store_pair<V>(n, i, alpha, append, sum, y);
+        f0 = n0; f1 = n1;
         __syncthreads();          // slice k is done with the ring: its oldest 512 elements may be overwritten
     }
 }
@@ -768,24 +764,24 @@ void csr_delta_count_kernel(long long n, int w, int ndeltas, const int *__restri
     if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
-template <typename V, bool VCODED>
-int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int append, int w, const char *buf, const int *deltas, const V *values,
+template <typename V>
+int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int append, int w, const int *deltas, const V *values,
         const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr, const char *pool, const int *blocks,
         const vexhip_march *m)
 {
     const int lo_e = m->lo & ~1, hi_e = (m->hi + 1) & ~1;                 // window bounds on even elements (16-byte ring accesses)
     int cap = 1024;
     while (cap < S8_ROWS + hi_e - lo_e + S8_ROWS) cap <<= 1;
-    VEXHIP_REQUIRE(m->lo <= 0 && m->hi >= 0 && m->run >= 1 && (size_t)cap * sizeof(V) <= 64 * 1024, "bad march plan");
+    VEXHIP_REQUIRE(m->lo <= 0 && m->hi >= 0 && m->run >= 1 && m->nfar >= 0 && m->nfar <= 2 && (size_t)cap * sizeof(V) <= 64 * 1024, "bad march plan");
     const bool strips = tr && tr->grid_blocks > 0 && tr->chunk > 0;
     VEXHIP_REQUIRE(!strips || tr->chunk % m->run == 0, "march run does not divide the strip length");
     const long long grid = strips ? tr->grid_blocks / m->run : (ns + m->run - 1) / m->run;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
-    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, (long long)m->x_last};
+    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
     const size_t lds = (size_t)cap * sizeof(V);
-#define MARCH(W) case W: sell8_march_kernel<V, W, VCODED><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, buf, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
+#define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
     switch (w) {
         MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
         default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
@@ -855,7 +851,7 @@ int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col,
 template <typename V>
 int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w, const void *buf, const int *deltas,
         const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr,
-        const void *pool_ = nullptr, const int *blocks = nullptr, const vexhip_march *march = nullptr)
+        const void *pool_ = nullptr, const int *blocks = nullptr)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && w < (1 << 20), "bad SELL8 geometry");
     if (n == 0) return 0;
@@ -870,8 +866,6 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     if (ordered) t8 = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf), *pool = static_cast<const char *>(pool_);
-    if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
-        return march_launch<V, false>(dev, s, n, ns, alpha, append, (int)w, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, tr, pool, blocks, march);
 #define PAIR(W, DICT) sell8_pair_kernel<V, W, false, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, t8, pool, blocks)
 #define CASE(W) case W: if (g_sell8_variant != 1) { if (blocks) PAIR(W, true); else PAIR(W, false); } \
         else sell8_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, cp, cc, cv, x, y, t8, pool, blocks); break;
@@ -968,7 +962,7 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
     if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
-        return march_launch<V, true>(dev, s, n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);
+        return march_launch<V>(dev, s, n, ns, alpha, append, (int)w, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);
 #define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, b, blocks)
 #define CASE(W) case W: if (g_sell8_variant != 1 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \
         else sell8v_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8, blocks); break;
@@ -1223,6 +1217,10 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
         while (run > 1 && traversal->chunk % run != 0) --run;
     }
     if (run < 2) return 0;
+    // the (up to two) far diagonals nearest to the window are requested one slice ahead; any other far diagonal is gathered
+    out->nfar = 0;
+    for (int dlt : by_abs)
+        if ((dlt < lo || dlt > hi) && out->nfar < 2) out->far[out->nfar++] = dlt;
     out->lo = lo; out->hi = hi; out->run = run; out->x_last = x_last; out->usable = 1;
     return 0;
 }
@@ -1237,15 +1235,6 @@ int vexhip_spmv_sell8v_march_f32_i32(int dev, void *stream, int64_t n, float alp
         const int32_t *blocks, const int32_t *deltas, const float *values, const int32_t *cp, const int32_t *cc, const float *cv,
         const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march)
 { return spmv_sell8v<float>(dev, stream, n, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks, (march && march->usable) ? march : nullptr); }
-int vexhip_spmv_sell8_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *buf, const void *pool,
-        const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const double *cv,
-        const double *x, double *y, const vexhip_traversal *traversal, const vexhip_march *march)
-{ return spmv_sell8<double>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal, pool, blocks, (march && march->usable) ? march : nullptr); }
-int vexhip_spmv_sell8_march_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *buf, const void *pool,
-        const int32_t *blocks, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const float *cv,
-        const float *x, float *y, const vexhip_traversal *traversal, const vexhip_march *march)
-{ return spmv_sell8<float>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal, pool, blocks, (march && march->usable) ? march : nullptr); }
-
 int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
         int rows_per_block, vexhip_traversal *traversal)
 {

@@ -30,7 +30,7 @@ struct spmat {
     int32_t *csr_ptr = nullptr, *csr_col = nullptr; void *csr_val = nullptr;   // CSR tail, or the whole matrix (format CSR)
     bool owns_csr = false;
     vexhip_traversal trav = {0, 0, 0, 0, nullptr};
-    vexhip_march march = {0, 0, 0, 0, 0};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
+    vexhip_march march = {0, 0, 0, 0, 0, 0, {0, 0, 0}};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
 };
 
 template <typename T> int dmalloc(T **p, size_t count) {
@@ -68,8 +68,8 @@ template <> struct api<double> {
     static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const double *v, int64_t w, void *b) { return vexhip_sell_fill_f64_i32(d, s, n, p, c, v, w, b); }
     static int mul_v(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_f64_i32(d, s, n, a, ap, w, b, dl, (const double *)vals, cp, cc, (const double *)cv, x, y, t); }
-    static int mul_dd(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t, const vexhip_march *m)
-    { return vexhip_spmv_sell8_march_f64_i32(d, s, n, a, ap, w, b, pl, bl, dl, cp, cc, (const double *)cv, x, y, t, m); }
+    static int mul_dd(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8_dict_f64_i32(d, s, n, a, ap, w, b, pl, bl, dl, cp, cc, (const double *)cv, x, y, t); }
     static int mm_dd(int d, void *s, int64_t n, int k, double a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const double *const *x, double *const *y, const vexhip_traversal *t)
     { return vexhip_spmm_sell8_dict_f64_i32(d, s, n, k, a, ap, w, b, pl, bl, dl, cp, cc, (const double *)cv, x, y, t); }
     static int mul_vd(int d, void *s, int64_t n, double a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const double *x, double *y, const vexhip_traversal *t, const vexhip_march *m)
@@ -101,8 +101,8 @@ template <> struct api<float> {
     static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const float *v, int64_t w, void *b) { return vexhip_sell_fill_f32_i32(d, s, n, p, c, v, w, b); }
     static int mul_v(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
     { return vexhip_spmv_sell8v_f32_i32(d, s, n, a, ap, w, b, dl, (const float *)vals, cp, cc, (const float *)cv, x, y, t); }
-    static int mul_dd(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t, const vexhip_march *m)
-    { return vexhip_spmv_sell8_march_f32_i32(d, s, n, a, ap, w, b, pl, bl, dl, cp, cc, (const float *)cv, x, y, t, m); }
+    static int mul_dd(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t)
+    { return vexhip_spmv_sell8_dict_f32_i32(d, s, n, a, ap, w, b, pl, bl, dl, cp, cc, (const float *)cv, x, y, t); }
     static int mm_dd(int d, void *s, int64_t n, int k, float a, int ap, int64_t w, const void *b, const void *pl, const int32_t *bl, const int32_t *dl, const int32_t *cp, const int32_t *cc, const void *cv, const float *const *x, float *const *y, const vexhip_traversal *t)
     { return vexhip_spmm_sell8_dict_f32_i32(d, s, n, k, a, ap, w, b, pl, bl, dl, cp, cc, (const float *)cv, x, y, t); }
     static int mul_vd(int d, void *s, int64_t n, float a, int ap, int64_t w, const void *b, const int32_t *bl, const int32_t *dl, const void *vals, const int32_t *cp, const int32_t *cc, const void *cv, const float *x, float *y, const vexhip_traversal *t, const vexhip_march *m)
@@ -144,7 +144,7 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
         if (e != hipSuccess) return check(e, __FILE__, __LINE__);
         A->dict_blocks = nb; A->code_bytes = code_bytes;
         if (whole_slice) { (void)hipFree(A->sell); A->sell = nullptr; A->sell_bytes = 0; }
-        if (!(flags & VEXHIP_SPMAT_NO_MARCH))
+        if (whole_slice && !(flags & VEXHIP_SPMAT_NO_MARCH))
             if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, A->value_type == VEXHIP_F64 ? 8 : 4,
                                                   &A->trav, vexhip_sell8_last_fill_max_col(), &A->march)) return rc2;
         return 0;
@@ -274,7 +274,7 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
             if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
             return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL8:
-            if (A->blocks) return F::mul_dd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
+            if (A->blocks) return F::mul_dd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
             return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL:   return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         default:                  return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
