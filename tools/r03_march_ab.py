@@ -12,6 +12,7 @@ from vexcl_amd import ops  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 runs = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "8,16,32,64").split(",")]
+pfs = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "4").split(",")]
 dev = torch.device("cuda:0")
 N = n ** 3
 x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
@@ -34,14 +35,18 @@ def timed(fn, reps=30, rounds=3):
 
 
 out = {"grid": n, "rows": N}
-for label, gen in (("poisson_value_codes", ops.poisson3d), ("variable_coefficient_stored_values", ops.diffusion3d)):
+for label, gen in (("poisson_value_codes", ops.poisson3d),):
     p, c, v = gen(n, dev)
     mats = {"pair": ops.SpMat(p, c, v, march=False)}
     for r in runs:
-        os.environ["VEXHIP_MARCH_RUN"] = str(r)
-        A = ops.SpMat(p, c, v)
-        mats["march_run%d" % (A.march["run"] if A.march else 0)] = A
-    os.environ.pop("VEXHIP_MARCH_RUN", None)
+        for pf in pfs:
+            os.environ["VEXHIP_MARCH_RUN"] = str(r)
+            os.environ["VEXHIP_MARCH_PF"] = str(pf)
+            A = ops.SpMat(p, c, v)
+            if A.march is None:
+                continue
+            mats["march_run%d_pf%d" % (A.march["run"], A.march["prefetch"])] = A
+    os.environ.pop("VEXHIP_MARCH_RUN", None); os.environ.pop("VEXHIP_MARCH_PF", None)
     del p, c, v
     for A in mats.values():
         A.ptr = A.col = A.val = None

@@ -478,13 +478,7 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
 // kernel when the matrix has a slice dictionary whose block numbers rarely change from slice to slice and the near
 // diagonals fit a ring of <= 32 KiB (vexhip_sell8_march_plan); otherwise the pair kernel runs as before.
 // ---------------------------------------------------------------------------
-#ifndef MARCH_WAVES
-#define MARCH_WAVES 4
-#endif
-#ifndef MARCH_BATCH
-#define MARCH_BATCH 4
-#endif
-struct march_dev { int lo, hi, lo_e, hi_e, mask, run, nfar, far0, far1; long long x_last; };
+struct march_dev { int lo, hi, lo_e, hi_e, mask, run, nfar, far0, far1, pf_dist; long long x_last; };
 
 __device__ __forceinline__ void march_run(const trav_dev &t, long long nblocks, int R, unsigned mb, long long &first, int &count) {
     long long c;
@@ -518,12 +512,20 @@ __device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__r
 // Value-coded storage with a slice dictionary only: with stored values the product is bound by the value stream and the
 // pair kernel already moves it at 0.9 of the copy rate (a first version of this kernel with stored values: 1.85 against
 // 1.69 ms, profiles/r03_march_ab.json).
+// FRONTIER PREFETCH.  The product is bound by LATENCY, not by bytes: a slice in flight waits ~4 us for its first-touch
+// stream -- the window of the largest diagonal, x[i + n^2 ..] for a grid operator, which nobody has read yet and which comes
+// from HBM -- while every other read of x hits the L2 (same XCD strip, one plane earlier).  Requesting everything one slice
+// ahead into registers did not help (0.84 against 0.67 ms: 114 registers = 4 workgroups per CU, and one slice of lead is a
+// tenth of the latency).  So lanes 0..31 of the workgroup's first wave touch the 32 cache lines of the frontier window of
+// slice k + pf_dist with one 4-byte load each (the value is folded into a checksum that is never stored): the lines are in
+// L2 when the slice gets there.  One vector-memory instruction of one wave per slice.
 template <typename V, int W>
-__global__ __launch_bounds__(256, MARCH_WAVES)
+__global__ __launch_bounds__(256, 6)
 void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
         const int *__restrict__ deltas, const V *__restrict__ values,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks, march_dev mp)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks, march_dev mp,
+        int *__restrict__ sink)
 {
     constexpr int WP = (W + 1) / 2;
     constexpr long long CODE_BYTES = (long long)WP * 2048;
@@ -543,78 +545,94 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
     const int mask = mp.mask;
     const long long i00 = first * S8_ROWS;
     const long long g0 = i00 + mp.lo_e;                       // the element at ring position 0
-    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e), and -- in registers -- the 512 elements the second
-    // slice adds and the far diagonals' elements of the first slice
+    // frontier prefetch: the first pf_dist slices' lines at once, then one slice per slice
+    const int frontier = mp.nfar > 0 ? (mp.far1 > mp.far0 && mp.nfar > 1 ? mp.far1 : mp.far0) : 0;
+    const bool pf_on = mp.pf_dist > 0 && frontier > mp.hi && t < 32;
+    int pf_acc = 0, pf_prev = 0;
+    constexpr int PF_STRIDE = 128 / (int)sizeof(V);          // one load per 128-byte line
+    if (pf_on)
+        for (int k = 0; k < mp.pf_dist; ++k) {
+            const long long g = i00 + (long long)k * S8_ROWS + frontier + (long long)t * PF_STRIDE;
+            if (g >= 0 && g <= mp.x_last) pf_acc ^= *reinterpret_cast<const int *>(x + g);
+        }
+    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e), and -- in registers -- the 512 elements the second needs
     const int wpairs = (S8_ROWS + mp.hi_e - mp.lo_e) / 2;
     for (int p = t; p < wpairs; p += 256)
         *reinterpret_cast<V2 *>(ring + ((2 * p) & mask)) = load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last);
     V2 chunk = {V(0), V(0)};
     if (count > 1) chunk = load_pair_clamped<V>(x, i00 + S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
-    V2 f0 = {V(0), V(0)}, f1 = {V(0), V(0)};
-    if (mp.nfar > 0) f0 = load_pair_clamped<V>(x, i00 + 2 * t + mp.far0, mp.x_last);
-    if (mp.nfar > 1) f1 = load_pair_clamped<V>(x, i00 + 2 * t + mp.far1, mp.x_last);
     __syncthreads();
 
     int cur = -1;
     unsigned c[WP], vc[WP];
     int d[W];
-    unsigned kinds = 0;             // 2 bits per column: 0 near (ring), 1 / 2 the prefetched far diagonals, 3 gathered from global memory
     for (int k = 0; k < count; ++k) {
         const long long s = first + k;
         const long long i = s * S8_ROWS + 2 * t;
         const int rel = k * S8_ROWS - mp.lo_e + 2 * t;          // ring position of x[i] (before masking)
-        // Everything slice k + 1 reads from global memory is requested NOW, one slice ahead: the 512 elements it adds to the
-        // window (kept in registers until the ring slot is free) and its far diagonals.  What arrived during slice k - 1
-        // goes into the slot slice k - 1 has left.
+        if (pf_on) {
+            pf_acc ^= pf_prev;                                   // the value requested one slice ago: long since here
+            const long long g = i00 + (long long)(k + mp.pf_dist) * S8_ROWS + frontier + (long long)t * PF_STRIDE;
+            pf_prev = (g >= 0 && g <= mp.x_last) ? *reinterpret_cast<const int *>(x + g) : 0;
+        }
+        // the elements slice k + 1 adds to the window arrived during slice k - 1: into the slot slice k - 1 has left
         if (k + 1 < count) *reinterpret_cast<V2 *>(ring + ((rel + S8_ROWS + mp.hi_e) & mask)) = chunk;
         if (k + 2 < count) chunk = load_pair_clamped<V>(x, i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
-        V2 n0 = {V(0), V(0)}, n1 = {V(0), V(0)};
-        if (k + 1 < count) {
-            if (mp.nfar > 0) n0 = load_pair_clamped<V>(x, i + S8_ROWS + mp.far0, mp.x_last);
-            if (mp.nfar > 1) n1 = load_pair_clamped<V>(x, i + S8_ROWS + mp.far1, mp.x_last);
-        }
         const int blk = blocks[s];
         if (blk != cur) {                                        // uniform: a new code block -- load and decode it
             cur = blk;
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
 #pragma unroll
             for (int jp = 0; jp < WP; ++jp) { c[jp] = cw[jp * 256]; vc[jp] = cw[(WP + jp) * 256]; }
-            kinds = 0;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
                 d[j] = s_delta[c0 < S8_PAD_UNSAFE ? c0 : c1];
-                const unsigned kind = (d[j] >= mp.lo && d[j] <= mp.hi) ? 0u : (mp.nfar > 0 && d[j] == mp.far0) ? 1u : (mp.nfar > 1 && d[j] == mp.far1) ? 2u : 3u;
-                kinds |= kind << (2 * j);
             }
         }
-        V sum[2] = {V(0), V(0)};
+        V xv[W][2];
+        // far columns first (global gathers in flight while the ring is read)
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
             const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
             const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
-            const unsigned kind = (kinds >> (2 * j)) & 3u;
-            V2 p = kind == 1u ? f0 : f1;
-            if (pair && (m0 || m1)) {
-                if (kind == 0u) {
-                    const int pos = (rel + d[j]) & mask;
-                    if ((d[j] & 1) == 0) p = *reinterpret_cast<const V2 *>(ring + pos);
-                    else { p.x = ring[pos]; p.y = ring[(pos + 1) & mask]; }
-                } else if (kind == 3u) __builtin_memcpy(&p, x + (i + d[j]), sizeof(V2));       // a far diagonal beyond the prefetched ones
+            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
+            const bool use16 = pair && (m0 || m1) && !near;
+            V2 p = {V(0), V(0)};
+            if (__builtin_amdgcn_ballot_w64(use16) != 0) {
+                const V *px = use16 ? x + (i + d[j]) : reinterpret_cast<const V *>(deltas);
+                __builtin_memcpy(&p, px, sizeof(V2));
+            }
+            xv[j][0] = p.x; xv[j][1] = p.y;
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
+            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
+            if (pair && (m0 || m1) && near) {
+                const int pos = (rel + d[j]) & mask;
+                if ((d[j] & 1) == 0) { const V2 p = *reinterpret_cast<const V2 *>(ring + pos); xv[j][0] = p.x; xv[j][1] = p.y; }
+                else { xv[j][0] = ring[pos]; xv[j][1] = ring[(pos + 1) & mask]; }
             }
             if (!pair) {                   // different diagonals in one lane, or a 16-byte load that would leave x
-                if (m0) { const int d0 = s_delta[c0]; p.x = (d0 >= mp.lo && d0 <= mp.hi) ? ring[(rel + d0) & mask] : x[i + d0]; }
-                if (m1) { const int d1 = s_delta[c1]; p.y = (d1 >= mp.lo && d1 <= mp.hi) ? ring[(rel + 1 + d1) & mask] : x[i + 1 + d1]; }
+                if (m0) { const int d0 = s_delta[c0]; xv[j][0] = (d0 >= mp.lo && d0 <= mp.hi) ? ring[(rel + d0) & mask] : x[i + d0]; }
+                if (m1) { const int d1 = s_delta[c1]; xv[j][1] = (d1 >= mp.lo && d1 <= mp.hi) ? ring[(rel + 1 + d1) & mask] : x[i + 1 + d1]; }
             }
-            // value codes -> table (entry 255 is 0.0); gathered values of padding entries are replaced by 0: sum + (+-0) == sum
-            const unsigned vw = vc[j >> 1] >> (16 * (j & 1));
-            const V a0 = s_value[m0 ? (vw & 255u) : 255u], a1 = s_value[m1 ? ((vw >> 8) & 255u) : 255u];
-            sum[0] += a0 * (m0 ? p.x : V(0));
-            sum[1] += a1 * (m1 ? p.y : V(0));
-            // keep the LDS reads of at most MARCH_BATCH columns in flight: hoisting all of them costs 110+ registers
-            if constexpr (W > MARCH_BATCH) if (j % MARCH_BATCH == MARCH_BATCH - 1) __builtin_amdgcn_sched_barrier(0);
+            xv[j][0] = m0 ? xv[j][0] : V(0);
+            xv[j][1] = m1 ? xv[j][1] : V(0);
         }
+        V sum[2] = {V(0), V(0)};
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sh = 16 * (j & 1) + 8 * q;
+                const V a = s_value[((c[j >> 1] >> sh) & 255u) < S8_PAD_UNSAFE ? (vc[j >> 1] >> sh) & 255u : 255u];     // entry 255 is 0.0
+                sum[q] += a * xv[j][q];
+            }
         if (csr_ptr) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -622,9 +640,9 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
                     for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
         }
         store_pair<V>(n, i, alpha, append, sum, y);
-        f0 = n0; f1 = n1;
         __syncthreads();          // slice k is done with the ring: its oldest 512 elements may be overwritten
     }
+    if (sink && (pf_acc ^ pf_prev) == 0x5EED1234) *sink = pf_acc;       // sink is NULL: keeps the prefetch loads alive, never stores
 }
 
 // distinct value bit patterns of the ELL part: gset = HASH_SLOTS words (all-ones = empty), info as delta_collect_kernel
@@ -779,9 +797,9 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
-    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
+    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], m->far[2], (long long)m->x_last};
     const size_t lds = (size_t)cap * sizeof(V);
-#define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
+#define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp, (int *)nullptr); break;
     switch (w) {
         MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
         default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
@@ -1221,6 +1239,8 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
     out->nfar = 0;
     for (int dlt : by_abs)
         if ((dlt < lo || dlt > hi) && out->nfar < 2) out->far[out->nfar++] = dlt;
+    out->far[2] = 4;                                   // frontier prefetch distance in slices (0 = off)
+    if (const char *e = std::getenv("VEXHIP_MARCH_PF")) out->far[2] = std::max(0, std::atoi(e));
     out->lo = lo; out->hi = hi; out->run = run; out->x_last = x_last; out->usable = 1;
     return 0;
 }
