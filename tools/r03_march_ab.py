@@ -53,7 +53,9 @@ for label, gen in (("poisson_value_codes", ops.poisson3d),):
     torch.cuda.empty_cache()
     mats["pair"].apply(x, yref)
     res = {}
-    for rnd in range(2):
+    for waves in ("4", "6"):
+      os.environ["VEXHIP_MARCH_WAVES"] = waves        # read once per process by the launcher: the second value has no effect
+      for rnd in range(2):
         for k, A in mats.items():
             A.apply(x, y)
             assert torch.equal(y, yref), k

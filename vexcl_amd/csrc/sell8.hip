@@ -512,26 +512,30 @@ __device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__r
 // Value-coded storage with a slice dictionary only: with stored values the product is bound by the value stream and the
 // pair kernel already moves it at 0.9 of the copy rate (a first version of this kernel with stored values: 1.85 against
 // 1.69 ms, profiles/r03_march_ab.json).
-// FRONTIER PREFETCH.  The product is bound by LATENCY, not by bytes: a slice in flight waits ~4 us for its first-touch
-// stream -- the window of the largest diagonal, x[i + n^2 ..] for a grid operator, which nobody has read yet and which comes
-// from HBM -- while every other read of x hits the L2 (same XCD strip, one plane earlier).  Requesting everything one slice
-// ahead into registers did not help (0.84 against 0.67 ms: 114 registers = 4 workgroups per CU, and one slice of lead is a
-// tenth of the latency).  So lanes 0..31 of the workgroup's first wave touch the 32 cache lines of the frontier window of
-// slice k + pf_dist with one 4-byte load each (the value is folded into a checksum that is never stored): the lines are in
-// L2 when the slice gets there.  One vector-memory instruction of one wave per slice.
-template <typename V, int W>
-__global__ __launch_bounds__(256, 6)
+//
+// What the kernel is bound by (tools/r03_march_ablate.py, profiles/r03_march_ablate.json): INSTRUCTION ISSUE.  A first
+// version that decoded the codes of every slice like the pair kernel does -- extract two codes per column, compare against
+// the padding codes, look the diagonal and the two values up, select -- took 0.53 ms with every memory access removed, and
+// neither requesting the far diagonals a slice ahead (0.84 ms: 114 registers, 4 workgroups per CU) nor touching the frontier
+// lines ahead of time (0.75 -> 0.78 ... 0.86 ms) helped.  So the DECODE is hoisted: when the code block of a slice equals
+// the previous slice's (a grid line inside the domain follows a grid line inside the domain) the lane keeps, per column,
+// the byte offset into the ring or the far diagonal, the two matrix values and the validity of its two entries, and a
+// slice costs per column one address, one LDS read (or one gather), two selects and two multiply-adds.  Waves in which a
+// lane holds two different diagonals in one column (matrices without band structure: no run of equal blocks would have
+// been planned for them anyway) take a compact per-entry loop for that block.
+template <typename V, int W, int MINW>
+__global__ __launch_bounds__(256, MINW)
 void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
         const int *__restrict__ deltas, const V *__restrict__ values,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks, march_dev mp,
-        int *__restrict__ sink)
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks, march_dev mp)
 {
     constexpr int WP = (W + 1) / 2;
     constexpr long long CODE_BYTES = (long long)WP * 2048;
+    constexpr int VB = (int)sizeof(V);
     typedef typename vec2<V>::type V2;
     extern __shared__ __align__(16) unsigned char s_ring_raw[];
-    V *ring = reinterpret_cast<V *>(s_ring_raw);
+    unsigned char *ringb = s_ring_raw;
     __shared__ int s_delta[256];
     __shared__ V s_value[256];
 
@@ -542,97 +546,85 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
     s_delta[t] = deltas[t];
     s_value[t] = values[t];
 
-    const int mask = mp.mask;
+    const int maskb = (mp.mask + 1) * VB - 1;                 // ring size in bytes - 1
     const long long i00 = first * S8_ROWS;
     const long long g0 = i00 + mp.lo_e;                       // the element at ring position 0
-    // frontier prefetch: the first pf_dist slices' lines at once, then one slice per slice
-    const int frontier = mp.nfar > 0 ? (mp.far1 > mp.far0 && mp.nfar > 1 ? mp.far1 : mp.far0) : 0;
-    const bool pf_on = mp.pf_dist > 0 && frontier > mp.hi && t < 32;
-    int pf_acc = 0, pf_prev = 0;
-    constexpr int PF_STRIDE = 128 / (int)sizeof(V);          // one load per 128-byte line
-    if (pf_on)
-        for (int k = 0; k < mp.pf_dist; ++k) {
-            const long long g = i00 + (long long)k * S8_ROWS + frontier + (long long)t * PF_STRIDE;
-            if (g >= 0 && g <= mp.x_last) pf_acc ^= *reinterpret_cast<const int *>(x + g);
-        }
     // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e), and -- in registers -- the 512 elements the second needs
     const int wpairs = (S8_ROWS + mp.hi_e - mp.lo_e) / 2;
     for (int p = t; p < wpairs; p += 256)
-        *reinterpret_cast<V2 *>(ring + ((2 * p) & mask)) = load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last);
+        *reinterpret_cast<V2 *>(ringb + ((2 * p * VB) & maskb)) = load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last);
     V2 chunk = {V(0), V(0)};
     if (count > 1) chunk = load_pair_clamped<V>(x, i00 + S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
     __syncthreads();
 
     int cur = -1;
-    unsigned c[WP], vc[WP];
-    int d[W];
+    bool slow = false;                                        // this wave, this block: per-entry loop
+    int off[W];                                               // near: byte offset of the lane's pair from the ring position of x[i0 + lo_e]; far: the diagonal
+    V a0[W], a1[W];                                           // the matrix values of the lane's two rows (0 for padding)
+    bool m0[W], m1[W], nr[W];                                 // entry valid (row 2t, row 2t + 1); column served by the ring
+    const int lane_b = 2 * t * VB;
     for (int k = 0; k < count; ++k) {
         const long long s = first + k;
-        const long long i = s * S8_ROWS + 2 * t;
-        const int rel = k * S8_ROWS - mp.lo_e + 2 * t;          // ring position of x[i] (before masking)
-        if (pf_on) {
-            pf_acc ^= pf_prev;                                   // the value requested one slice ago: long since here
-            const long long g = i00 + (long long)(k + mp.pf_dist) * S8_ROWS + frontier + (long long)t * PF_STRIDE;
-            pf_prev = (g >= 0 && g <= mp.x_last) ? *reinterpret_cast<const int *>(x + g) : 0;
-        }
+        const V *xs = x + s * S8_ROWS + 2 * t;                  // &x[i]
+        const int kb = k * S8_ROWS * VB + lane_b;               // ring byte position of x[i + lo_e] (before masking)
         // the elements slice k + 1 adds to the window arrived during slice k - 1: into the slot slice k - 1 has left
-        if (k + 1 < count) *reinterpret_cast<V2 *>(ring + ((rel + S8_ROWS + mp.hi_e) & mask)) = chunk;
-        if (k + 2 < count) chunk = load_pair_clamped<V>(x, i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
+        if (k + 1 < count) *reinterpret_cast<V2 *>(ringb + ((kb + (S8_ROWS + mp.hi_e - mp.lo_e) * VB) & maskb)) = chunk;
+        if (k + 2 < count) {
+            const long long gb = i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e;           // uniform: the 512 elements slice k + 2 adds
+            if (gb >= 0 && gb + S8_ROWS - 1 <= mp.x_last) chunk = *reinterpret_cast<const V2 *>(x + gb + 2 * t);
+            else chunk = load_pair_clamped<V>(x, gb + 2 * t, mp.x_last);
+        }
         const int blk = blocks[s];
         if (blk != cur) {                                        // uniform: a new code block -- load and decode it
             cur = blk;
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
-#pragma unroll
-            for (int jp = 0; jp < WP; ++jp) { c[jp] = cw[jp * 256]; vc[jp] = cw[(WP + jp) * 256]; }
+            bool odd_one_out = false;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
-                d[j] = s_delta[c0 < S8_PAD_UNSAFE ? c0 : c1];
+                const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
+                const unsigned c0 = cword & 255u, c1 = (cword >> 8) & 255u;
+                m0[j] = c0 < S8_PAD_UNSAFE; m1[j] = c1 < S8_PAD_UNSAFE;
+                const bool pair = (c0 == c1) || (c0 == S8_PAD && m1[j]) || (c1 == S8_PAD && m0[j]);
+                odd_one_out |= !pair && (m0[j] || m1[j]);
+                const int d = (m0[j] || m1[j]) ? s_delta[m0[j] ? c0 : c1] : 0;
+                nr[j] = d >= mp.lo && d <= mp.hi;
+                off[j] = nr[j] ? (d - mp.lo_e) * VB : d;
+                a0[j] = s_value[m0[j] ? (vword & 255u) : 255u];          // entry 255 is 0.0
+                a1[j] = s_value[m1[j] ? ((vword >> 8) & 255u) : 255u];
             }
+            slow = __builtin_amdgcn_ballot_w64(odd_one_out) != 0;
         }
-        V xv[W][2];
-        // far columns first (global gathers in flight while the ring is read)
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
-            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
-            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
-            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
-            const bool use16 = pair && (m0 || m1) && !near;
-            V2 p = {V(0), V(0)};
-            if (__builtin_amdgcn_ballot_w64(use16) != 0) {
-                const V *px = use16 ? x + (i + d[j]) : reinterpret_cast<const V *>(deltas);
-                __builtin_memcpy(&p, px, sizeof(V2));
-            }
-            xv[j][0] = p.x; xv[j][1] = p.y;
-        }
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
-            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
-            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
-            const bool near = d[j] >= mp.lo && d[j] <= mp.hi;
-            if (pair && (m0 || m1) && near) {
-                const int pos = (rel + d[j]) & mask;
-                if ((d[j] & 1) == 0) { const V2 p = *reinterpret_cast<const V2 *>(ring + pos); xv[j][0] = p.x; xv[j][1] = p.y; }
-                else { xv[j][0] = ring[pos]; xv[j][1] = ring[(pos + 1) & mask]; }
-            }
-            if (!pair) {                   // different diagonals in one lane, or a 16-byte load that would leave x
-                if (m0) { const int d0 = s_delta[c0]; xv[j][0] = (d0 >= mp.lo && d0 <= mp.hi) ? ring[(rel + d0) & mask] : x[i + d0]; }
-                if (m1) { const int d1 = s_delta[c1]; xv[j][1] = (d1 >= mp.lo && d1 <= mp.hi) ? ring[(rel + 1 + d1) & mask] : x[i + 1 + d1]; }
-            }
-            xv[j][0] = m0 ? xv[j][0] : V(0);
-            xv[j][1] = m1 ? xv[j][1] : V(0);
-        }
+        const long long i = s * S8_ROWS + 2 * t;
         V sum[2] = {V(0), V(0)};
+        if (!slow) {
+            V2 p[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j)
+            for (int j = 0; j < W; ++j)                          // the gathers first: in flight while the ring is read
+                if (!nr[j]) __builtin_memcpy(&p[j], xs + off[j], sizeof(V2));
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int sh = 16 * (j & 1) + 8 * q;
-                const V a = s_value[((c[j >> 1] >> sh) & 255u) < S8_PAD_UNSAFE ? (vc[j >> 1] >> sh) & 255u : 255u];     // entry 255 is 0.0
-                sum[q] += a * xv[j][q];
+            for (int j = 0; j < W; ++j)
+                if (nr[j]) {
+                    const int pb = (kb + off[j]) & maskb;
+                    if ((off[j] & VB) == 0) p[j] = *reinterpret_cast<const V2 *>(ringb + pb);
+                    else { p[j].x = *reinterpret_cast<const V *>(ringb + pb); p[j].y = *reinterpret_cast<const V *>(ringb + ((pb + VB) & maskb)); }
+                }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {                        // gathered values of padding entries are replaced by 0: sum + (+-0) == sum
+                sum[0] += a0[j] * (m0[j] ? p[j].x : V(0));
+                sum[1] += a1[j] * (m1[j] ? p[j].y : V(0));
             }
+        } else {
+            const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
+#pragma unroll 1
+            for (int j = 0; j < W; ++j) {
+                const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned code = (cword >> (8 * q)) & 255u;
+                    if (code < S8_PAD_UNSAFE) sum[q] += s_value[(vword >> (8 * q)) & 255u] * x[i + q + s_delta[code]];
+                }
+            }
+        }
         if (csr_ptr) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -642,7 +634,6 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
         store_pair<V>(n, i, alpha, append, sum, y);
         __syncthreads();          // slice k is done with the ring: its oldest 512 elements may be overwritten
     }
-    if (sink && (pf_acc ^ pf_prev) == 0x5EED1234) *sink = pf_acc;       // sink is NULL: keeps the prefetch loads alive, never stores
 }
 
 // distinct value bit patterns of the ELL part: gset = HASH_SLOTS words (all-ones = empty), info as delta_collect_kernel
@@ -799,7 +790,9 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], m->far[2], (long long)m->x_last};
     const size_t lds = (size_t)cap * sizeof(V);
-#define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp, (int *)nullptr); break;
+    static const int minw = std::getenv("VEXHIP_MARCH_WAVES") ? std::atoi(std::getenv("VEXHIP_MARCH_WAVES")) : 4;     // A/B: registers (4 waves per SIMD, no spills) against occupancy (6, spills)
+#define MARCH(W) case W: if (minw >= 6) sell8_march_kernel<V, W, 6><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); \
+                         else sell8_march_kernel<V, W, 4><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
     switch (w) {
         MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
         default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
