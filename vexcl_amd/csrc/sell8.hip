@@ -519,12 +519,14 @@ __device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__r
 // neither requesting the far diagonals a slice ahead (0.84 ms: 114 registers, 4 workgroups per CU) nor touching the frontier
 // lines ahead of time (0.75 -> 0.78 ... 0.86 ms) helped.  So the DECODE is hoisted: when the code block of a slice equals
 // the previous slice's (a grid line inside the domain follows a grid line inside the domain) the lane keeps, per column,
-// the byte offset into the ring or the far diagonal, the two matrix values and the validity of its two entries, and a
-// slice costs per column one address, one LDS read (or one gather), two selects and two multiply-adds.  Waves in which a
-// lane holds two different diagonals in one column (matrices without band structure: no run of equal blocks would have
-// been planned for them anyway) take a compact per-entry loop for that block.
-template <typename V, int W, int MINW>
-__global__ __launch_bounds__(256, MINW)
+// its two matrix values and the validity of its two entries, and the WAVE keeps -- in scalar registers -- where the column's
+// x comes from: a slice then costs per column one address, one LDS read (or nothing: the far diagonals of the next slice
+// are requested one slice ahead into registers), two selects and two multiply-adds.  That form needs every lane of the wave
+// with an entry in column j to sit on the same diagonal (true wherever the rows of a slice are rows of one stencil; lanes at
+// the boundary hold padding there); a wave where that fails -- or that meets a far diagonal beyond the two prefetched ones --
+// takes a compact per-entry loop for that code block.
+template <typename V, int W>
+__global__ __launch_bounds__(256, 4)
 void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
         const int *__restrict__ deltas, const V *__restrict__ values,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
@@ -549,69 +551,82 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
     const int maskb = (mp.mask + 1) * VB - 1;                 // ring size in bytes - 1
     const long long i00 = first * S8_ROWS;
     const long long g0 = i00 + mp.lo_e;                       // the element at ring position 0
-    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e), and -- in registers -- the 512 elements the second needs
+    // one aligned pair per lane of the 512 elements starting at x[gb] (gb uniform): unconditional when they all exist
+    auto load512 = [&](long long gb) -> V2 {
+        if (gb >= 0 && gb + S8_ROWS - 1 <= mp.x_last) { V2 v; __builtin_memcpy(&v, x + gb + 2 * t, sizeof(V2)); return v; }
+        return load_pair_clamped<V>(x, gb + 2 * t, mp.x_last);
+    };
+    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e); in registers: the 512 elements the second slice adds
+    // and the far diagonals of the first slice
     const int wpairs = (S8_ROWS + mp.hi_e - mp.lo_e) / 2;
     for (int p = t; p < wpairs; p += 256)
         *reinterpret_cast<V2 *>(ringb + ((2 * p * VB) & maskb)) = load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last);
-    V2 chunk = {V(0), V(0)};
-    if (count > 1) chunk = load_pair_clamped<V>(x, i00 + S8_ROWS + mp.hi_e + 2 * t, mp.x_last);
+    V2 chunk = {V(0), V(0)}, f0 = {V(0), V(0)}, f1 = {V(0), V(0)};
+    if (count > 1) chunk = load512(i00 + S8_ROWS + mp.hi_e);
+    if (mp.nfar > 0) f0 = load512(i00 + mp.far0);
+    if (mp.nfar > 1) f1 = load512(i00 + mp.far1);
     __syncthreads();
 
     int cur = -1;
     bool slow = false;                                        // this wave, this block: per-entry loop
-    int off[W];                                               // near: byte offset of the lane's pair from the ring position of x[i0 + lo_e]; far: the diagonal
+    int src[W];                                               // uniform: >= 0 ring byte offset of the column's diagonal; -1 / -2 far diagonal 0 / 1
     V a0[W], a1[W];                                           // the matrix values of the lane's two rows (0 for padding)
-    bool m0[W], m1[W], nr[W];                                 // entry valid (row 2t, row 2t + 1); column served by the ring
+    bool m0[W], m1[W];                                        // entry valid (row 2t, row 2t + 1)
     const int lane_b = 2 * t * VB;
     for (int k = 0; k < count; ++k) {
         const long long s = first + k;
-        const V *xs = x + s * S8_ROWS + 2 * t;                  // &x[i]
+        const long long i0 = s * S8_ROWS;
         const int kb = k * S8_ROWS * VB + lane_b;               // ring byte position of x[i + lo_e] (before masking)
-        // the elements slice k + 1 adds to the window arrived during slice k - 1: into the slot slice k - 1 has left
+        // Everything slice k + 1 reads from global memory is requested NOW: the 512 elements it adds to the window (kept in
+        // registers until the ring slot is free) and its far diagonals.  What arrived during slice k - 1 goes into the slot
+        // slice k - 1 has left.
         if (k + 1 < count) *reinterpret_cast<V2 *>(ringb + ((kb + (S8_ROWS + mp.hi_e - mp.lo_e) * VB) & maskb)) = chunk;
-        if (k + 2 < count) {
-            const long long gb = i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e;           // uniform: the 512 elements slice k + 2 adds
-            if (gb >= 0 && gb + S8_ROWS - 1 <= mp.x_last) chunk = *reinterpret_cast<const V2 *>(x + gb + 2 * t);
-            else chunk = load_pair_clamped<V>(x, gb + 2 * t, mp.x_last);
+        if (k + 2 < count) chunk = load512(i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e);
+        V2 n0 = {V(0), V(0)}, n1 = {V(0), V(0)};
+        if (k + 1 < count) {
+            if (mp.nfar > 0) n0 = load512(i0 + S8_ROWS + mp.far0);
+            if (mp.nfar > 1) n1 = load512(i0 + S8_ROWS + mp.far1);
         }
         const int blk = blocks[s];
         if (blk != cur) {                                        // uniform: a new code block -- load and decode it
             cur = blk;
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
-            bool odd_one_out = false;
+            bool bad = false;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
                 const unsigned c0 = cword & 255u, c1 = (cword >> 8) & 255u;
                 m0[j] = c0 < S8_PAD_UNSAFE; m1[j] = c1 < S8_PAD_UNSAFE;
+                const bool any = m0[j] || m1[j];
                 const bool pair = (c0 == c1) || (c0 == S8_PAD && m1[j]) || (c1 == S8_PAD && m0[j]);
-                odd_one_out |= !pair && (m0[j] || m1[j]);
-                const int d = (m0[j] || m1[j]) ? s_delta[m0[j] ? c0 : c1] : 0;
-                nr[j] = d >= mp.lo && d <= mp.hi;
-                off[j] = nr[j] ? (d - mp.lo_e) * VB : d;
+                const int d = any ? s_delta[m0[j] ? c0 : c1] : 0;
+                // the wave's diagonal in this column: that of its first lane with an entry
+                const unsigned long long have = __builtin_amdgcn_ballot_w64(any);
+                const int du = have ? __builtin_amdgcn_readlane(d, __ffsll((long long)have) - 1) : 0;
+                bad |= any && (!pair || d != du);
+                src[j] = (du >= mp.lo && du <= mp.hi) ? (du - mp.lo_e) * VB : (mp.nfar > 0 && du == mp.far0) ? -1 : (mp.nfar > 1 && du == mp.far1) ? -2 : -3;
                 a0[j] = s_value[m0[j] ? (vword & 255u) : 255u];          // entry 255 is 0.0
                 a1[j] = s_value[m1[j] ? ((vword >> 8) & 255u) : 255u];
+                bad |= have && src[j] == -3;
             }
-            slow = __builtin_amdgcn_ballot_w64(odd_one_out) != 0;
+            slow = __builtin_amdgcn_ballot_w64(bad) != 0;
         }
-        const long long i = s * S8_ROWS + 2 * t;
+        const long long i = i0 + 2 * t;
         V sum[2] = {V(0), V(0)};
         if (!slow) {
-            V2 p[W];
 #pragma unroll
-            for (int j = 0; j < W; ++j)                          // the gathers first: in flight while the ring is read
-                if (!nr[j]) __builtin_memcpy(&p[j], xs + off[j], sizeof(V2));
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-                if (nr[j]) {
-                    const int pb = (kb + off[j]) & maskb;
-                    if ((off[j] & VB) == 0) p[j] = *reinterpret_cast<const V2 *>(ringb + pb);
-                    else { p[j].x = *reinterpret_cast<const V *>(ringb + pb); p[j].y = *reinterpret_cast<const V *>(ringb + ((pb + VB) & maskb)); }
+            for (int j = 0; j < W; ++j) {
+                V2 p;
+                if (src[j] == -1) p = f0;
+                else if (src[j] == -2) p = f1;
+                else {
+                    const int pb = (kb + src[j]) & maskb;
+                    if ((src[j] & VB) == 0) p = *reinterpret_cast<const V2 *>(ringb + pb);
+                    else { p.x = *reinterpret_cast<const V *>(ringb + pb); p.y = *reinterpret_cast<const V *>(ringb + ((pb + VB) & maskb)); }
                 }
-#pragma unroll
-            for (int j = 0; j < W; ++j) {                        // gathered values of padding entries are replaced by 0: sum + (+-0) == sum
-                sum[0] += a0[j] * (m0[j] ? p[j].x : V(0));
-                sum[1] += a1[j] * (m1[j] ? p[j].y : V(0));
+                // gathered values of padding entries are replaced by 0 (their matrix value is 0): sum + (+-0) == sum
+                sum[0] += a0[j] * (m0[j] ? p.x : V(0));
+                sum[1] += a1[j] * (m1[j] ? p.y : V(0));
             }
         } else {
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
@@ -632,6 +647,7 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
                     for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
         }
         store_pair<V>(n, i, alpha, append, sum, y);
+        f0 = n0; f1 = n1;
         __syncthreads();          // slice k is done with the ring: its oldest 512 elements may be overwritten
     }
 }
@@ -790,9 +806,7 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], m->far[2], (long long)m->x_last};
     const size_t lds = (size_t)cap * sizeof(V);
-    static const int minw = std::getenv("VEXHIP_MARCH_WAVES") ? std::atoi(std::getenv("VEXHIP_MARCH_WAVES")) : 4;     // A/B: registers (4 waves per SIMD, no spills) against occupancy (6, spills)
-#define MARCH(W) case W: if (minw >= 6) sell8_march_kernel<V, W, 6><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); \
-                         else sell8_march_kernel<V, W, 4><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
+#define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
     switch (w) {
         MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
         default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
