@@ -513,20 +513,25 @@ __device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__r
 // pair kernel already moves it at 0.9 of the copy rate (a first version of this kernel with stored values: 1.85 against
 // 1.69 ms, profiles/r03_march_ab.json).
 //
-// What the kernel is bound by (tools/r03_march_ablate.py, profiles/r03_march_ablate.json): INSTRUCTION ISSUE.  A first
-// version that decoded the codes of every slice like the pair kernel does -- extract two codes per column, compare against
-// the padding codes, look the diagonal and the two values up, select -- took 0.53 ms with every memory access removed, and
-// neither requesting the far diagonals a slice ahead (0.84 ms: 114 registers, 4 workgroups per CU) nor touching the frontier
-// lines ahead of time (0.75 -> 0.78 ... 0.86 ms) helped.  So the DECODE is hoisted: when the code block of a slice equals
-// the previous slice's (a grid line inside the domain follows a grid line inside the domain) the lane keeps, per column,
-// its two matrix values and the validity of its two entries, and the WAVE keeps -- in scalar registers -- where the column's
-// x comes from: a slice then costs per column one address, one LDS read (or nothing: the far diagonals of the next slice
-// are requested one slice ahead into registers), two selects and two multiply-adds.  That form needs every lane of the wave
-// with an entry in column j to sit on the same diagonal (true wherever the rows of a slice are rows of one stencil; lanes at
-// the boundary hold padding there); a wave where that fails -- or that meets a far diagonal beyond the two prefetched ones --
-// takes a compact per-entry loop for that code block.
+// What bounds it (profiles/r03_sq_summary.txt, tools/r03_march_ablate.py): instruction issue and exposed LDS latency, not
+// bytes.  Version by version at 512^3, pair kernel 0.69 ms on the same box:
+//   decode per slice as the pair kernel does (extract two codes per column, compare, three table look-ups, select) 0.67 ms;
+//   + far diagonals requested one slice ahead into registers (114 registers, 4 workgroups per CU)                    0.84 ms;
+//   + the 32 frontier lines of slice k + 1..16 touched ahead of time instead                                          0.78-0.86 ms;
+//   decode hoisted out of the slice loop (per lane: the two values and validities per column; per column a branch on
+//   where x comes from)                                                                                               0.59 ms
+//     -- 161 vector + 140 scalar instructions per wave and slice, waves parked 60 % of their life: the per-column branches
+//     keep the seven LDS reads of a slice from being in flight together.
+// Hence the form below: when the code block of a slice equals the previous slice's, a slice is STRAIGHT-LINE code -- per
+// column one address (three vector instructions), ONE LDS read of the lane's pair (ds_read2: the two elements of a pair
+// are adjacent for either parity of the diagonal; the ring carries a copy of its first element behind its last), a masked
+// multiply-add per row.  Far diagonals go the same way: their elements for the next slice are requested one slice ahead
+// into registers and parked in a lane-private LDS slot, so that every column is "an LDS read at base + position".
+// That form needs every lane of the wave with an entry in column j to sit on the same diagonal (true wherever the rows of
+// a slice are rows of one stencil; lanes at the boundary hold padding there); a wave where that fails -- or that meets a
+// far diagonal beyond the two prefetched ones -- takes a compact per-entry loop for that code block.
 template <typename V, int W>
-__global__ __launch_bounds__(256, 4)
+__global__ __launch_bounds__(256)
 void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
         const int *__restrict__ deltas, const V *__restrict__ values,
         const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
@@ -535,9 +540,10 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
     constexpr int WP = (W + 1) / 2;
     constexpr long long CODE_BYTES = (long long)WP * 2048;
     constexpr int VB = (int)sizeof(V);
+    constexpr int SLB = S8_ROWS * VB;                          // bytes of x per slice
     typedef typename vec2<V>::type V2;
     extern __shared__ __align__(16) unsigned char s_ring_raw[];
-    unsigned char *ringb = s_ring_raw;
+    unsigned char *ringb = s_ring_raw;                        // [ring: cap elements][copy of element 0, padded to 16 B][far 0: 512][far 1: 512]
     __shared__ int s_delta[256];
     __shared__ V s_value[256];
 
@@ -548,19 +554,24 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
     s_delta[t] = deltas[t];
     s_value[t] = values[t];
 
-    const int maskb = (mp.mask + 1) * VB - 1;                 // ring size in bytes - 1
+    const int capb = (mp.mask + 1) * VB, maskb = capb - 1;    // ring size in bytes
+    const int farb = capb + 16;                               // where the far slots start
     const long long i00 = first * S8_ROWS;
     const long long g0 = i00 + mp.lo_e;                       // the element at ring position 0
+    const int lane_b = 2 * t * VB;
     // one aligned pair per lane of the 512 elements starting at x[gb] (gb uniform): unconditional when they all exist
     auto load512 = [&](long long gb) -> V2 {
         if (gb >= 0 && gb + S8_ROWS - 1 <= mp.x_last) { V2 v; __builtin_memcpy(&v, x + gb + 2 * t, sizeof(V2)); return v; }
         return load_pair_clamped<V>(x, gb + 2 * t, mp.x_last);
     };
+    auto ring_put = [&](int pb, V2 v) {                       // pb: masked byte position of an aligned pair
+        *reinterpret_cast<V2 *>(ringb + pb) = v;
+        if (pb == 0) *reinterpret_cast<V *>(ringb + capb) = v.x;
+    };
     // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e); in registers: the 512 elements the second slice adds
     // and the far diagonals of the first slice
     const int wpairs = (S8_ROWS + mp.hi_e - mp.lo_e) / 2;
-    for (int p = t; p < wpairs; p += 256)
-        *reinterpret_cast<V2 *>(ringb + ((2 * p * VB) & maskb)) = load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last);
+    for (int p = t; p < wpairs; p += 256) ring_put((2 * p * VB) & maskb, load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last));
     V2 chunk = {V(0), V(0)}, f0 = {V(0), V(0)}, f1 = {V(0), V(0)};
     if (count > 1) chunk = load512(i00 + S8_ROWS + mp.hi_e);
     if (mp.nfar > 0) f0 = load512(i00 + mp.far0);
@@ -569,64 +580,68 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
 
     int cur = -1;
     bool slow = false;                                        // this wave, this block: per-entry loop
-    int src[W];                                               // uniform: >= 0 ring byte offset of the column's diagonal; -1 / -2 far diagonal 0 / 1
+    int ustep[W], ubase[W];                                   // uniform per column: ring (moves SLB per slice, base 0) or a far slot (fixed)
+    int pos0[W];                                              // the lane's byte position in column j at slice 0 of the run
     V a0[W], a1[W];                                           // the matrix values of the lane's two rows (0 for padding)
-    bool m0[W], m1[W];                                        // entry valid (row 2t, row 2t + 1)
-    const int lane_b = 2 * t * VB;
+    unsigned valid = 0;                                       // bit 2j: row 2t has an entry in column j; bit 2j + 1: row 2t + 1
     for (int k = 0; k < count; ++k) {
         const long long s = first + k;
         const long long i0 = s * S8_ROWS;
-        const int kb = k * S8_ROWS * VB + lane_b;               // ring byte position of x[i + lo_e] (before masking)
+        const int kb = k * SLB;
         // Everything slice k + 1 reads from global memory is requested NOW: the 512 elements it adds to the window (kept in
         // registers until the ring slot is free) and its far diagonals.  What arrived during slice k - 1 goes into the slot
-        // slice k - 1 has left.
-        if (k + 1 < count) *reinterpret_cast<V2 *>(ringb + ((kb + (S8_ROWS + mp.hi_e - mp.lo_e) * VB) & maskb)) = chunk;
+        // slice k - 1 has left; this slice's far elements go into the lane's own slots.
+        if (k + 1 < count) ring_put((kb + lane_b + (S8_ROWS + mp.hi_e - mp.lo_e) * VB) & maskb, chunk);
+        if (mp.nfar > 0) *reinterpret_cast<V2 *>(ringb + farb + lane_b) = f0;
+        if (mp.nfar > 1) *reinterpret_cast<V2 *>(ringb + farb + SLB + lane_b) = f1;
         if (k + 2 < count) chunk = load512(i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e);
-        V2 n0 = {V(0), V(0)}, n1 = {V(0), V(0)};
         if (k + 1 < count) {
-            if (mp.nfar > 0) n0 = load512(i0 + S8_ROWS + mp.far0);
-            if (mp.nfar > 1) n1 = load512(i0 + S8_ROWS + mp.far1);
+            if (mp.nfar > 0) f0 = load512(i0 + S8_ROWS + mp.far0);
+            if (mp.nfar > 1) f1 = load512(i0 + S8_ROWS + mp.far1);
         }
         const int blk = blocks[s];
         if (blk != cur) {                                        // uniform: a new code block -- load and decode it
             cur = blk;
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
             bool bad = false;
+            valid = 0;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
                 const unsigned c0 = cword & 255u, c1 = (cword >> 8) & 255u;
-                m0[j] = c0 < S8_PAD_UNSAFE; m1[j] = c1 < S8_PAD_UNSAFE;
-                const bool any = m0[j] || m1[j];
-                const bool pair = (c0 == c1) || (c0 == S8_PAD && m1[j]) || (c1 == S8_PAD && m0[j]);
-                const int d = any ? s_delta[m0[j] ? c0 : c1] : 0;
+                const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE, any = m0 || m1;
+                const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+                const int d = any ? s_delta[m0 ? c0 : c1] : 0;
                 // the wave's diagonal in this column: that of its first lane with an entry
                 const unsigned long long have = __builtin_amdgcn_ballot_w64(any);
                 const int du = have ? __builtin_amdgcn_readlane(d, __ffsll((long long)have) - 1) : 0;
                 bad |= any && (!pair || d != du);
-                src[j] = (du >= mp.lo && du <= mp.hi) ? (du - mp.lo_e) * VB : (mp.nfar > 0 && du == mp.far0) ? -1 : (mp.nfar > 1 && du == mp.far1) ? -2 : -3;
-                a0[j] = s_value[m0[j] ? (vword & 255u) : 255u];          // entry 255 is 0.0
-                a1[j] = s_value[m1[j] ? ((vword >> 8) & 255u) : 255u];
-                bad |= have && src[j] == -3;
+                const bool nearcol = du >= mp.lo && du <= mp.hi;
+                const int slot = (mp.nfar > 0 && du == mp.far0) ? 0 : (mp.nfar > 1 && du == mp.far1) ? 1 : -1;
+                bad |= have && !nearcol && slot < 0;
+                ustep[j] = nearcol ? SLB : 0;
+                ubase[j] = nearcol ? 0 : farb + (slot > 0 ? SLB : 0);
+                pos0[j] = lane_b + (nearcol ? (du - mp.lo_e) * VB : 0);
+                valid |= (m0 ? 1u : 0u) << (2 * j) | (m1 ? 1u : 0u) << (2 * j + 1);
+                a0[j] = s_value[m0 ? (vword & 255u) : 255u];          // entry 255 is 0.0
+                a1[j] = s_value[m1 ? ((vword >> 8) & 255u) : 255u];
             }
             slow = __builtin_amdgcn_ballot_w64(bad) != 0;
         }
         const long long i = i0 + 2 * t;
         V sum[2] = {V(0), V(0)};
         if (!slow) {
+            V2 p[W];
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                V2 p;
-                if (src[j] == -1) p = f0;
-                else if (src[j] == -2) p = f1;
-                else {
-                    const int pb = (kb + src[j]) & maskb;
-                    if ((src[j] & VB) == 0) p = *reinterpret_cast<const V2 *>(ringb + pb);
-                    else { p.x = *reinterpret_cast<const V *>(ringb + pb); p.y = *reinterpret_cast<const V *>(ringb + ((pb + VB) & maskb)); }
-                }
-                // gathered values of padding entries are replaced by 0 (their matrix value is 0): sum + (+-0) == sum
-                sum[0] += a0[j] * (m0[j] ? p.x : V(0));
-                sum[1] += a1[j] * (m1[j] ? p.y : V(0));
+                const V *q = reinterpret_cast<const V *>(ringb + (((pos0[j] + (ustep[j] ? kb : 0)) & maskb) + ubase[j]));
+                p[j].x = q[0]; p[j].y = q[1];                        // one ds_read2: the pair is adjacent, the ring's first element is repeated behind its last
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                // what a padding entry "covers" is replaced by 0 (its matrix value is 0): sum + (+-0) == sum, whatever x holds there
+                sum[0] += a0[j] * ((valid >> (2 * j)) & 1u ? p[j].x : V(0));
+                sum[1] += a1[j] * ((valid >> (2 * j + 1)) & 1u ? p[j].y : V(0));
             }
         } else {
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
@@ -647,7 +662,6 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
                     for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
         }
         store_pair<V>(n, i, alpha, append, sum, y);
-        f0 = n0; f1 = n1;
         __syncthreads();          // slice k is done with the ring: its oldest 512 elements may be overwritten
     }
 }
@@ -805,7 +819,7 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], m->far[2], (long long)m->x_last};
-    const size_t lds = (size_t)cap * sizeof(V);
+    const size_t lds = (size_t)cap * sizeof(V) + 16 + 2 * S8_ROWS * sizeof(V);       // ring + copy of its first element + two far slots
 #define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
     switch (w) {
         MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
