@@ -509,6 +509,21 @@ __device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__r
     return v;
 }
 
+// v for the lanes of `lanes`, +0 elsewhere: v_cndmask with the lane mask taken straight from a scalar register pair (the
+// compiler, given a bool per lane, keeps it in a vector register and rebuilds the mask with two instructions per use)
+template <typename V> __device__ __forceinline__ V masked(V v, unsigned long long lanes);
+template <> __device__ __forceinline__ double masked<double>(double v, unsigned long long lanes) {
+    unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32), rlo, rhi;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rlo) : "v"(lo), "s"(lanes));
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"(hi), "s"(lanes));
+    return __longlong_as_double((long long)(((unsigned long long)rhi << 32) | rlo));
+}
+template <> __device__ __forceinline__ float masked<float>(float v, unsigned long long lanes) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(__float_as_uint(v)), "s"(lanes));
+    return __uint_as_float(r);
+}
+
 // Value-coded storage with a slice dictionary only: with stored values the product is bound by the value stream and the
 // pair kernel already moves it at 0.9 of the copy rate (a first version of this kernel with stored values: 1.85 against
 // 1.69 ms, profiles/r03_march_ab.json).
@@ -580,10 +595,10 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
 
     int cur = -1;
     bool slow = false;                                        // this wave, this block: per-entry loop
-    int ustep[W], ubase[W];                                   // uniform per column: ring (moves SLB per slice, base 0) or a far slot (fixed)
-    int pos0[W];                                              // the lane's byte position in column j at slice 0 of the run
+    int ustep[W], umask[W];                                   // uniform per column: the ring (moves SLB per slice, wraps) or a far slot (fixed)
+    int pos[W];                                               // the lane's LDS byte address in column j for the slice at hand
     V a0[W], a1[W];                                           // the matrix values of the lane's two rows (0 for padding)
-    unsigned valid = 0;                                       // bit 2j: row 2t has an entry in column j; bit 2j + 1: row 2t + 1
+    unsigned long long v0[W], v1[W];                          // uniform: the lanes whose row 2t / 2t + 1 has an entry in column j (lane masks in scalar registers)
     for (int k = 0; k < count; ++k) {
         const long long s = first + k;
         const long long i0 = s * S8_ROWS;
@@ -604,7 +619,6 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
             cur = blk;
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
             bool bad = false;
-            valid = 0;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
@@ -620,9 +634,9 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
                 const int slot = (mp.nfar > 0 && du == mp.far0) ? 0 : (mp.nfar > 1 && du == mp.far1) ? 1 : -1;
                 bad |= have && !nearcol && slot < 0;
                 ustep[j] = nearcol ? SLB : 0;
-                ubase[j] = nearcol ? 0 : farb + (slot > 0 ? SLB : 0);
-                pos0[j] = lane_b + (nearcol ? (du - mp.lo_e) * VB : 0);
-                valid |= (m0 ? 1u : 0u) << (2 * j) | (m1 ? 1u : 0u) << (2 * j + 1);
+                umask[j] = nearcol ? maskb : -1;
+                pos[j] = nearcol ? ((kb + lane_b + (du - mp.lo_e) * VB) & maskb) : farb + (slot > 0 ? SLB : 0) + lane_b;
+                v0[j] = __builtin_amdgcn_ballot_w64(m0); v1[j] = __builtin_amdgcn_ballot_w64(m1);
                 a0[j] = s_value[m0 ? (vword & 255u) : 255u];          // entry 255 is 0.0
                 a1[j] = s_value[m1 ? ((vword >> 8) & 255u) : 255u];
             }
@@ -634,14 +648,15 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
             V2 p[W];
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                const V *q = reinterpret_cast<const V *>(ringb + (((pos0[j] + (ustep[j] ? kb : 0)) & maskb) + ubase[j]));
+                const V *q = reinterpret_cast<const V *>(ringb + pos[j]);
                 p[j].x = q[0]; p[j].y = q[1];                        // one ds_read2: the pair is adjacent, the ring's first element is repeated behind its last
+                pos[j] = (pos[j] + ustep[j]) & umask[j];             // where the column's pair sits for the next slice
             }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 // what a padding entry "covers" is replaced by 0 (its matrix value is 0): sum + (+-0) == sum, whatever x holds there
-                sum[0] += a0[j] * ((valid >> (2 * j)) & 1u ? p[j].x : V(0));
-                sum[1] += a1[j] * ((valid >> (2 * j + 1)) & 1u ? p[j].y : V(0));
+                sum[0] += a0[j] * masked<V>(p[j].x, v0[j]);
+                sum[1] += a1[j] * masked<V>(p[j].y, v1[j]);
             }
         } else {
             const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
