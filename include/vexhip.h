@@ -260,7 +260,7 @@ typedef struct vexhip_march { int32_t lo, hi;      /* smallest / largest NEAR di
                               int32_t run;         /* consecutive slices per workgroup (divides the strip length)     */
                               int32_t usable;
                               int64_t x_last;
-                              int32_t nfar, far[3]; /* far[0..nfar-1]: the (<= 2) far diagonals nearest to the window; far[2]: frontier prefetch distance in slices */
+                              int32_t nfar, far[3]; /* far[0..nfar-1]: the (<= 2) far diagonals nearest to the window, requested one slice ahead; far[2] reserved */
                             } vexhip_march;
 int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
         int value_bytes, const vexhip_traversal *traversal, int64_t x_last, vexhip_march *out);

@@ -1,6 +1,7 @@
 """A/B of the march products against the pair products they replace, 512^3, same process, interleaved:
 value-coded Poisson (headline) and the variable-coefficient operator (stored values).  Bit-identity is asserted.
-Usage: python tools/r03_march_ab.py [grid=512] [runs=8,16,32,64]  -> JSON on stdout"""
+Usage: python tools/r03_march_ab.py [grid=512] [runs=8,16,32,64]  -> JSON on stdout
+(profiles/r03_march_ab_v*.json: one file per version of the kernel, see the comment above sell8_march_kernel)"""
 import json
 import os
 import sys
@@ -12,7 +13,7 @@ from vexcl_amd import ops  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 runs = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "8,16,32,64").split(",")]
-pfs = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "4").split(",")]
+
 dev = torch.device("cuda:0")
 N = n ** 3
 x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
@@ -39,22 +40,19 @@ for label, gen in (("poisson_value_codes", ops.poisson3d),):
     p, c, v = gen(n, dev)
     mats = {"pair": ops.SpMat(p, c, v, march=False)}
     for r in runs:
-        for pf in pfs:
-            os.environ["VEXHIP_MARCH_RUN"] = str(r)
-            os.environ["VEXHIP_MARCH_PF"] = str(pf)
-            A = ops.SpMat(p, c, v)
-            if A.march is None:
-                continue
-            mats["march_run%d_pf%d" % (A.march["run"], A.march["prefetch"])] = A
-    os.environ.pop("VEXHIP_MARCH_RUN", None); os.environ.pop("VEXHIP_MARCH_PF", None)
+        os.environ["VEXHIP_MARCH_RUN"] = str(r)
+        A = ops.SpMat(p, c, v)
+        if A.march is None:
+            continue
+        mats["march_run%d" % A.march["run"]] = A
+    os.environ.pop("VEXHIP_MARCH_RUN", None)
     del p, c, v
     for A in mats.values():
         A.ptr = A.col = A.val = None
     torch.cuda.empty_cache()
     mats["pair"].apply(x, yref)
     res = {}
-    for waves in ("4", "6"):
-      os.environ["VEXHIP_MARCH_WAVES"] = waves        # read once per process by the launcher: the second value has no effect
+    for waves in ("4",):
       for rnd in range(2):
         for k, A in mats.items():
             A.apply(x, y)

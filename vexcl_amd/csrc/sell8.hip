@@ -478,7 +478,7 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
 // kernel when the matrix has a slice dictionary whose block numbers rarely change from slice to slice and the near
 // diagonals fit a ring of <= 32 KiB (vexhip_sell8_march_plan); otherwise the pair kernel runs as before.
 // ---------------------------------------------------------------------------
-struct march_dev { int lo, hi, lo_e, hi_e, mask, run, nfar, far0, far1, pf_dist; long long x_last; };
+struct march_dev { int lo, hi, lo_e, hi_e, mask, run, nfar, far0, far1; long long x_last; };
 
 __device__ __forceinline__ void march_run(const trav_dev &t, long long nblocks, int R, unsigned mb, long long &first, int &count) {
     long long c;
@@ -833,7 +833,7 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
-    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], m->far[2], (long long)m->x_last};
+    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
     const size_t lds = (size_t)cap * sizeof(V) + 16 + 2 * S8_ROWS * sizeof(V);       // ring + copy of its first element + two far slots
 #define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
     switch (w) {
@@ -1265,7 +1265,7 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
         if (cap > max_elems) break;
         lo = nlo; hi = nhi;
     }
-    int run = 16;
+    int run = 32;                                       // 8 / 16 / 32 / 64: 0.69 / 0.63 / 0.59 / 0.61 ms (v4), 0.60 / 0.554 / 0.550 from 16 up (v6): the prologue of a run costs about a slice
     if (const char *e = std::getenv("VEXHIP_MARCH_RUN")) run = std::max(1, std::atoi(e));
     if (traversal && traversal->grid_blocks > 0 && traversal->chunk > 0) {
         while (run > 1 && traversal->chunk % run != 0) --run;
@@ -1275,8 +1275,7 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
     out->nfar = 0;
     for (int dlt : by_abs)
         if ((dlt < lo || dlt > hi) && out->nfar < 2) out->far[out->nfar++] = dlt;
-    out->far[2] = 4;                                   // frontier prefetch distance in slices (0 = off)
-    if (const char *e = std::getenv("VEXHIP_MARCH_PF")) out->far[2] = std::max(0, std::atoi(e));
+    out->far[2] = 0;
     out->lo = lo; out->hi = hi; out->run = run; out->x_last = x_last; out->usable = 1;
     return 0;
 }

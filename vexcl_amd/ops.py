@@ -389,7 +389,7 @@ class SpMat:
         self.storage = _capi.SPMAT_NAMES[info.format]              # sell8v | sell8 | sell32 | csr
         self.dictionary_blocks = int(info.dictionary_blocks)       # > 0: the value-coded slices are stored once per DISTINCT slice
         self.march = ({"lo": int(info.march.lo), "hi": int(info.march.hi), "run": int(info.march.run), "x_last": int(info.march.x_last),
-                       "far": [int(info.march.far[k]) for k in range(info.march.nfar)], "prefetch": int(info.march.far[2])}
+                       "far": [int(info.march.far[k]) for k in range(info.march.nfar)]}
                       if info.march.usable else None)              # not None: apply() runs the march product
         self.fmt = "csr" if self.storage == "csr" else "sell"      # SELL without an ELL part degrades to CSR
         if self.fmt == "sell":
