@@ -145,10 +145,15 @@ int main(int argc, char **argv) {
         vals = 1e-3 * (vex::element_index() % 1000);
         vex::inclusive_scan_by_key(keys, vals, out); q.finish();
         t.start(); for (int i = 0; i < 5; ++i) vex::inclusive_scan_by_key(keys, vals, out); double ms = t.stop_ms() / 5;
-        report("inclusive_scan_by_key (int, f64) n=1e8: 2 x (4+8) B read + 8 B written", (double)n, 20, ms);
+        report("inclusive_scan_by_key (int, f64) n=1e8: single pass, (4+8) B read + 8 B written", (double)n, 20, ms);
+        setenv("VEXCL_SCAN_BY_KEY", "tree", 1);
+        vex::inclusive_scan_by_key(keys, vals, out); q.finish();
+        t.start(); for (int i = 0; i < 5; ++i) vex::inclusive_scan_by_key(keys, vals, out); ms = t.stop_ms() / 5;
+        report("inclusive_scan_by_key (int, f64) n=1e8, VEXCL_SCAN_BY_KEY=tree: three phases, 2 x (4+8) B read + 8 B written", (double)n, 20, ms);
+        unsetenv("VEXCL_SCAN_BY_KEY");
         int runs = vex::reduce_by_key(keys, vals, okeys, ovals); q.finish();
         t.start(); for (int i = 0; i < 5; ++i) runs = vex::reduce_by_key(keys, vals, okeys, ovals); ms = t.stop_ms() / 5;
-        report("reduce_by_key (int, f64) n=1e8 (incl. run-count readback and output allocation)", (double)n, 12, ms);
+        report("reduce_by_key (int, f64) n=1e8: keys-only run count + 4-byte readback + single pass (outputs re-used)", (double)n, 12, ms);
         std::printf("{\"row\": \"reduce_by_key runs\", \"runs\": %d}\n", runs);
     }
     return 0;

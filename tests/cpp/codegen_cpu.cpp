@@ -200,7 +200,16 @@ TEST_CASE(by_key_kernels_compile) {                                   // scan_by
         CHECK(has(s, "vexcl_sbk_reduce") && has(s, "vexcl_sbk_carry_local") && has(s, "vexcl_sbk_carry(") && has(s, "vexcl_sbk_scan"));
         CHECK(has(s, "keys_equal(pk0, pk1, k0[j], k1[j])") && has(s, "dplus(a.v, b.v)"));
         CHECK_EQUAL(has(s, "okey1[fin.c - 1] = key1[i];"), m == REDUCE);
+        // the single-pass form (round 3): look-back kernel + keys-only run count, 3 status words per tile for an 8-byte value
+        CHECK(has(s, "vexcl_sbk_lookback") && has(s, "vexcl_sbk_count") && has(s, "#define NW 3"));
+        CHECK(has(s, "keys_equal(k0[j], k1[j], k0[j + 1], k1[j + 1])"));
         backend::check_sources(s);
+    }
+    {   // 4-byte values: 2 status words; a value type the look-back does not carry keeps the three phases only
+        std::string f = source<float, equal_fn<int>, plus_fn<float>>(q, {"int"}, INCLUSIVE);
+        CHECK(has(f, "vexcl_sbk_lookback") && has(f, "#define NW 2"));
+        backend::check_sources(f);
+        CHECK(!lookback_value<cl_double2>::value && lookback_value<long>::value && lookback_value<unsigned>::value);
     }
     std::string s = source<int, equal_fn<unsigned>, plus_fn<int>>(q, {"uint"}, EXCLUSIVE);
     CHECK(has(s, "sbk_plus(init, prev.v)"));

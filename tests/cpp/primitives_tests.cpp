@@ -266,6 +266,61 @@ TEST_CASE(scan_by_key_default_functions) {                           // scan_by_
     vex::copy(V, again); CHECK(again == got);
 }
 
+TEST_CASE(by_key_single_pass_against_three_phases) {
+    // Round 3: the single-pass look-back form (default) against the serial loop AND against the three deterministic phases
+    // (VEXCL_SCAN_BY_KEY=tree), on runs of every length -- one element up to 40 tiles of 4096 -- with values whose sums are
+    // exact (integers; doubles holding small integers), so every comparison is bit for bit.
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    std::mt19937_64 rng(77);
+    for (size_t n : {size_t(4095), size_t(4096), size_t(4097), size_t(1000003), size_t(5 * 1024 * 1024 + 11)}) {
+        std::vector<int> k(n); std::vector<double> v(n); std::vector<int> vi(n);
+        int key = 0;
+        for (size_t i = 0; i < n;) {
+            const size_t choices[] = {1, 2, 63, 64, 65, 777, 4096, 4097, 9000, 40 * 4096 + 5};
+            size_t len = choices[rng() % 10];
+            for (size_t j = 0; j < len && i < n; ++j, ++i) { k[i] = key; vi[i] = int(rng() % 1000) - 500; v[i] = double(vi[i]); }
+            ++key;
+        }
+        vex::vector<int> K(queue, k), VI(queue, vi), OI(queue, n);
+        vex::vector<double> V(queue, v), O(queue, n);
+        std::vector<double> incl, excl, got(n), tree(n);
+        std::vector<int> incli, excli, goti(n);
+        serial_scan_by_key(k, v, incl, excl, 3.0);
+        serial_scan_by_key(k, vi, incli, excli, 3);
+        vex::inclusive_scan_by_key(K, V, O); vex::copy(O, got); CHECK(got == incl);
+        vex::exclusive_scan_by_key(K, V, O, 3.0); vex::copy(O, got); CHECK(got == excl);
+        vex::inclusive_scan_by_key(K, VI, OI); vex::copy(OI, goti); CHECK(goti == incli);
+        vex::exclusive_scan_by_key(K, VI, OI, 3); vex::copy(OI, goti); CHECK(goti == excli);
+        setenv("VEXCL_SCAN_BY_KEY", "tree", 1);
+        vex::inclusive_scan_by_key(K, V, O); vex::copy(O, tree); CHECK(tree == incl);
+        unsetenv("VEXCL_SCAN_BY_KEY");
+        // reduce_by_key: run count by the keys-only kernel, sums by the single pass; outputs of the right size are re-used
+        vex::vector<int> OK; vex::vector<double> OV;
+        std::vector<int> uk; std::vector<double> us;
+        for (size_t i = 0; i < n; ++i) { if (i == 0 || k[i - 1] != k[i]) { uk.push_back(k[i]); us.push_back(v[i]); } else us.back() += v[i]; }
+        for (int rep = 0; rep < 2; ++rep) {
+            const int runs = vex::reduce_by_key(K, V, OK, OV);
+            CHECK_EQUAL(size_t(runs), uk.size());
+            std::vector<int> gk(uk.size()); std::vector<double> gs(uk.size());
+            vex::copy(OK, gk); vex::copy(OV, gs);
+            CHECK(gk == uk); CHECK(gs == us);
+        }
+        setenv("VEXCL_SCAN_BY_KEY", "tree", 1);
+        CHECK_EQUAL(size_t(vex::reduce_by_key(K, V, OK, OV)), uk.size());
+        unsetenv("VEXCL_SCAN_BY_KEY");
+        std::vector<double> gs(uk.size()); vex::copy(OV, gs); CHECK(gs == us);
+    }
+    // single precision values (two status words per tile) and 64-bit integer values (three)
+    const size_t n = 700001;
+    std::vector<cl_long> k(n); std::vector<float> f(n); std::vector<cl_long> l(n);
+    for (size_t i = 0; i < n; ++i) { k[i] = cl_long(i / 5000); f[i] = float(int(i % 17) - 8); l[i] = cl_long(i) * 1000003; }
+    vex::vector<cl_long> K(queue, k), L(queue, l), OL(queue, n); vex::vector<float> F(queue, f), OF(queue, n);
+    std::vector<float> fi, fe, gf(n); std::vector<cl_long> li, le, gl(n);
+    serial_scan_by_key(k, f, fi, fe, 0.f); serial_scan_by_key(k, l, li, le, cl_long(0));
+    vex::inclusive_scan_by_key(K, F, OF); vex::copy(OF, gf); CHECK(gf == fi);
+    vex::exclusive_scan_by_key(K, L, OL); vex::copy(OL, gl); CHECK(gl == le);
+}
+
 VEX_FUNCTION(bool, pair_equal, (int, a1)(int, a2)(int, b1)(int, b2), return a1 == b1 && a2 == b2;);
 VEX_FUNCTION(int, int_plus, (int, x)(int, y), return x + y;);
 VEX_FUNCTION(int, int_max, (int, x)(int, y), return x > y ? x : y;);

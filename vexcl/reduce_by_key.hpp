@@ -5,21 +5,30 @@
 // kernels, final scatter; tests/reduce_by_key.cpp).
 //
 // MI355X design: ONE segmented scan (scan_by_key.hpp) whose triples also count the
-// run heads, so the output slot of every run is known inside the scan itself.  The
-// host reads the run count after phase 2 (4 bytes), sizes the outputs, and phase 3
+// run heads, so the output slot of every run is known inside the scan itself: it
 // stores -- at every run head -- the head's key and the finished sum of the run
-// before it; the last element stores the last run.  Inputs are read twice and
-// nothing the size of the input is written (the reference writes an offsets array
-// and a scanned-values array of the input's size, reduce_by_key.hpp:470-500).
+// before it; the last element stores the last run.  The outputs must be sized first:
+// round 3 counts the run heads with a keys-only kernel (4 of the 12 bytes per (int,
+// double) element), reads the count back (4 bytes) and then runs the single-pass
+// look-back scan -- keys twice, values once, nothing the size of the input written
+// (the reference writes an offsets array and a scanned-values array of the input's
+// size, reduce_by_key.hpp:470-500).  Value types the look-back does not carry (and
+// VEXCL_SCAN_BY_KEY=tree) take the three phases with the count read after phase 2.
 #include "scan_by_key.hpp"
 
 namespace vex {
 namespace detail {
 namespace rbk {
 
+// (an output that already has the right size on the right queue is kept: a solver that reduces the same keys every
+// iteration does not allocate per call)
+template <class Vec>
+void size_output(Vec &v, const std::vector<backend::command_queue> &q, size_t n) {
+    if (v.size() != n || v.nparts() != q.size() || (n && v.queue_list()[0].id() != q[0].id())) v.resize(q, n);
+}
 template <class OTuple, size_t... I>
 void resize_outputs(const OTuple &okeys, const std::vector<backend::command_queue> &q, size_t n, std::index_sequence<I...>) {
-    int dummy[] = {0, (std::get<I>(okeys).resize(q, n), 0)...};
+    int dummy[] = {0, (size_output(std::get<I>(okeys), q, n), 0)...};
     (void)dummy;
 }
 
@@ -46,7 +55,7 @@ int reduce_by_key_sink(const IKTuple &ikeys, const vector<V> &ivals, const OKTup
     return sbk::run<sbk::REDUCE>(ikeys, ivals, comp, oper,
             [&](backend::kernel &k, int count) {
                 resize_outputs(okeys, queue, count, seq());
-                ovals.resize(queue, count);
+                size_output(ovals, queue, count);
                 sbk::for_each_key(okeys, [&](auto &o) { k.push_arg(o(0).raw()); }, seq());
                 k.push_arg(ovals(0).raw());
             }, true);

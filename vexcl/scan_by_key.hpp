@@ -15,6 +15,15 @@
 //   2. vexcl_sbk_carry_local + vexcl_sbk_carry: the aggregates become carries-in
 //      (groups of 1024 tiles scanned in parallel, then ONE workgroup over the groups);
 //   3. vexcl_sbk_scan  : re-reads the tile, adds its carry, stores the result.
+// Round 3: arithmetic value types of 4 or 8 bytes take ONE pass instead of the three phases -- vexcl_sbk_lookback, a
+// decoupled look-back over the tile triples (the scheme of scan.hip: tiles handed out by an atomic ticket, every tile
+// publishes its aggregate and later its inclusive prefix in 8-byte words that carry their state, predecessors are read
+// 64 at a time by the tile's first wave and folded IN ORDER with wave shuffles): inputs are read once (12 + 8 instead of
+// 24 + 8 bytes per (int, double) element).  reduce_by_key counts the run heads first (keys only) so that the outputs can
+// be sized, then runs the same single pass.  Floating point: the carried value of a run that spans SEVERAL tiles is
+// associated as the look-back happened to find its predecessors (aggregate or inclusive), i.e. it can differ in the last
+// bits from run to run; runs inside one tile -- and integer values -- do not depend on it.  VEXCL_SCAN_BY_KEY=tree keeps
+// the three deterministic phases (and vex::inclusive_scan / exclusive_scan with a user operator always use them).
 // A lane owns FOUR CONSECUTIVE elements: it folds them serially (head flags come
 // from its own previous element, the first one from the neighbour lane -- one
 // extra load per row for lane 0), and the wave scans ONE aggregate per lane with
@@ -24,8 +33,11 @@
 // (scan_by_key.hpp:200-252).  A wave's 256-element row is contiguous in memory.  Keys may be a single vector or a std::tie of
 // vectors (the reference takes boost::fusion::vector_tie); comparison and
 // operator are VEX_FUNCTIONs pasted into the generated source.
+#include <algorithm>
+#include <cstdlib>
 #include <sstream>
 #include <tuple>
+#include <type_traits>
 #include "vector.hpp"
 #include "function.hpp"
 
@@ -62,7 +74,13 @@ std::vector<std::string> key_types(std::index_sequence<I...>) {
 
 struct kernels {
     backend::kernel reduce, carry_local, carry, scan;
+    backend::kernel lookback, count;       // single-pass form (valid when has_lookback)
+    bool has_lookback = false;
 };
+
+static const int LB_WAVES = 8;          // waves per workgroup of the single-pass kernel: 4096 elements per tile
+template <class V> struct lookback_value { static const bool value = std::is_arithmetic<V>::value && (sizeof(V) == 4 || sizeof(V) == 8); };
+inline bool lookback_enabled() { const char *e = std::getenv("VEXCL_SCAN_BY_KEY"); return !(e && std::string(e) == "tree"); }
 
 /// Source of the three kernels for the given key types, value type, functions and mode.
 template <class V, class Comp, class Oper>
@@ -213,6 +231,39 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
     } else {
         s << "val_t *ovals, val_t init) {\n";
     }
+    // the store phase, shared by the three-phase kernel and the single-pass kernel: W = exclusive prefix of the wave's first element
+    auto epilogue = [&](std::ostringstream &o) {
+        o << "  sbk_t before = W;                 // inclusive prefix of the element just before this lane's first one\n"
+             "  #pragma unroll\n"
+             "  for (int r = 0; r < ROWS; ++r) {\n"
+             "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n"
+             "    const sbk_t last = sbk_combine(W, y[r * ITEMS + ITEMS - 1]);\n"
+             "    sbk_t prev = sbk_up(last, 1);\n"
+             "    if (lane == 0) prev = before;\n"
+             "    before = sbk_from(last, 63);\n"
+             "    #pragma unroll\n"
+             "    for (int j = 0; j < ITEMS; ++j) {\n"
+             "      const ulong i = i0 + j;\n"
+             "      const sbk_t fin = sbk_combine(W, y[r * ITEMS + j]);\n"
+             "      if (i < n) {\n"
+             "        const bool head = fin.c != prev.c;\n";
+        if (mode == INCLUSIVE) {
+            o << "        (void)head; (void)init; ovals[i] = fin.v;\n";
+        } else if (mode == EXCLUSIVE) {
+            o << "        ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+        } else {
+            o << "        if (head) {\n";
+            for (size_t k = 0; k < nk; ++k) o << "          okey" << k << "[fin.c - 1] = key" << k << "[i];\n";
+            o << "          if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
+                 "        }\n"
+                 "        if (i == n - 1) ovals[fin.c - 1] = fin.v;\n";
+        }
+        o << "      }\n"
+             "      prev = fin;\n"
+             "    }\n"
+             "  }\n"
+             "}\n";
+    };
     s << "  __shared__ sbk_t agg[WAVES];\n"
          "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
          "  const ulong wbase = ((ulong)blockIdx.x * WAVES + wave) * (ROWS * ITEMS * 64);\n"
@@ -223,37 +274,118 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
          "  sbk_t W, G; W.c = tc[blockIdx.x]; W.f = tf[blockIdx.x]; W.v = tv[blockIdx.x];\n"
          "  G.c = gc[blockIdx.x >> 10]; G.f = gf[blockIdx.x >> 10]; G.v = gv[blockIdx.x >> 10];\n"
          "  W = sbk_combine(G, W);\n"
-         "  for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n"
-         "  sbk_t before = W;                 // inclusive prefix of the element just before this lane's first one\n"
-         "  #pragma unroll\n"
-         "  for (int r = 0; r < ROWS; ++r) {\n"
-         "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n"
-         "    const sbk_t last = sbk_combine(W, y[r * ITEMS + ITEMS - 1]);\n"
-         "    sbk_t prev = sbk_up(last, 1);\n"
-         "    if (lane == 0) prev = before;\n"
-         "    before = sbk_from(last, 63);\n"
-         "    #pragma unroll\n"
-         "    for (int j = 0; j < ITEMS; ++j) {\n"
-         "      const ulong i = i0 + j;\n"
-         "      const sbk_t fin = sbk_combine(W, y[r * ITEMS + j]);\n"
-         "      if (i < n) {\n"
-         "        const bool head = fin.c != prev.c;\n";
-    if (mode == INCLUSIVE) {
-        s << "        (void)head; (void)init; ovals[i] = fin.v;\n";
-    } else if (mode == EXCLUSIVE) {
-        s << "        ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
-    } else {
-        s << "        if (head) {\n";
-        for (size_t k = 0; k < nk; ++k) s << "          okey" << k << "[fin.c - 1] = key" << k << "[i];\n";
-        s << "          if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
-             "        }\n"
-             "        if (i == n - 1) ovals[fin.c - 1] = fin.v;\n";
+         "  for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n";
+    epilogue(s);
+
+    if (lookback_value<V>::value) {
+        const int NW = sizeof(V) == 8 ? 3 : 2;       // status words per tile: {count, flags, state}, value bits (+ state) in one or two words
+        s << "\n#define LBW " << LB_WAVES << "\n#define NW " << NW << "\n"
+             "typedef unsigned long long sbk_word;\n"
+             "__device__ inline sbk_word sbk_ld(const sbk_word *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+             "__device__ inline void sbk_st(sbk_word *p, sbk_word v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+             // every word carries the state (1 aggregate, 2 inclusive): a reader accepts a triple only when all its words agree
+             "__device__ inline void sbk_publish(sbk_word *st, long tile, sbk_t x, unsigned state) {\n"
+             "  sbk_st(st + NW * tile, ((sbk_word)((state << 8) | (unsigned)x.f) << 32) | (unsigned)x.c);\n";
+        if (NW == 3)
+            s << "  sbk_word b; __builtin_memcpy(&b, &x.v, 8);\n"
+                 "  sbk_st(st + NW * tile + 1, ((sbk_word)state << 32) | (unsigned)b);\n"
+                 "  sbk_st(st + NW * tile + 2, ((sbk_word)state << 32) | (unsigned)(b >> 32));\n";
+        else
+            s << "  unsigned b; __builtin_memcpy(&b, &x.v, 4);\n"
+                 "  sbk_st(st + NW * tile + 1, ((sbk_word)state << 32) | b);\n";
+        s << "}\n"
+             "__device__ inline unsigned sbk_read(const sbk_word *st, long tile, sbk_t &x) {\n"
+             "  const sbk_word w0 = sbk_ld(st + NW * tile), w1 = sbk_ld(st + NW * tile + 1);\n"
+             "  unsigned s0 = (unsigned)(w0 >> 40), s1 = (unsigned)(w1 >> 32);\n"
+             "  x.c = (int)(unsigned)w0; x.f = (int)((w0 >> 32) & 255u);\n";
+        if (NW == 3)
+            s << "  const sbk_word w2 = sbk_ld(st + NW * tile + 2);\n"
+                 "  const sbk_word b = (w2 << 32) | (w1 & 0xffffffffull); __builtin_memcpy(&x.v, &b, 8);\n"
+                 "  if ((unsigned)(w2 >> 32) != s0) s0 = 0;\n";
+        else
+            s << "  const unsigned b = (unsigned)w1; __builtin_memcpy(&x.v, &b, 4);\n";
+        s << "  return s0 == s1 ? s0 : 0u;\n"
+             "}\n"
+             "__device__ inline sbk_t sbk_down(sbk_t x, int o) { sbk_t r; r.c = __shfl_down(x.c, o, 64); r.f = __shfl_down(x.f, o, 64); r.v = __shfl_down(x.v, o, 64); return r; }\n";
+        // ws[0] = ticket counter, ws[1] = reserved, ws + 2 = tile status words (all zero before launch)
+        s << "extern \"C\" __global__ void __launch_bounds__(" << LB_WAVES * 64 << ") vexcl_sbk_lookback(ulong n, " << key_params(true)
+          << "const val_t *vals, sbk_word *ws, ";
+        if (mode == REDUCE) {
+            for (size_t k = 0; k < nk; ++k) s << K[k] << " *okey" << k << ", ";
+            s << "val_t *ovals) {\n";
+        } else {
+            s << "val_t *ovals, val_t init) {\n";
+        }
+        s << "  __shared__ sbk_t agg[LBW];\n"
+             "  __shared__ long s_tile;\n"
+             "  __shared__ sbk_t s_pre;\n"
+             "  sbk_word *status = ws + 2;\n"
+             "  if (threadIdx.x == 0) s_tile = (long)atomicAdd(&ws[0], 1ull);\n"     // tiles in launch order: a tile only waits for tiles that already run
+             "  __syncthreads();\n"
+             "  const long tile = s_tile;\n"
+             "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
+             "  const ulong wbase = ((ulong)tile * LBW + wave) * (ROWS * ITEMS * 64);\n"
+             "  sbk_t y[ROWS * ITEMS];\n"
+             "  sbk_t a = sbk_wave_tile(n, wbase, lane, " << key_args() << "vals, y);\n"
+             "  if (lane == 0) agg[wave] = a;\n"
+             "  __syncthreads();\n"
+             "  if (wave == 0) {\n"
+             "    sbk_t t = agg[0];\n"
+             "    for (int w = 1; w < LBW; ++w) t = sbk_combine(t, agg[w]);\n"
+             "    if (lane == 0) sbk_publish(status, tile, t, tile == 0 ? 2u : 1u);\n"
+             "    sbk_t excl = sbk_empty();\n"
+             "    long base = tile - 1, spins = 0;\n"
+             "    while (base >= 0) {\n"
+             "      const long idx = base - lane;\n"                                    // lane 0 = the nearest predecessor
+             "      sbk_t v = sbk_empty();\n"
+             "      unsigned st = 2u;\n"                                                // lanes before tile 0 end the walk with the identity
+             "      if (idx >= 0) st = sbk_read(status, idx, v);\n"
+             "      while (__any(st == 0u)) {\n"
+             "        __builtin_amdgcn_s_sleep(8);\n"
+             "        if (idx >= 0 && st == 0u) st = sbk_read(status, idx, v);\n"
+             "        if (++spins > (1l << 30)) __builtin_trap();\n"                   // a bug, never a truncated prefix (scan.hip)
+             "      }\n"
+             "      const unsigned long long incl = __ballot(st == 2u);\n"
+             "      const int first = incl ? __builtin_ctzll(incl) : 63;\n"           // nearest predecessor with a complete prefix
+             "      if (lane > first) v = sbk_empty();\n"
+             "      for (int o = 1; o < 64; o <<= 1) {\n"                               // ordered fold: older tiles (higher lanes) on the left
+             "        sbk_t u = sbk_down(v, o);\n"
+             "        if (lane + o < 64) v = sbk_combine(u, v);\n"
+             "      }\n"
+             "      excl = sbk_combine(sbk_from(v, 0), excl);\n"
+             "      if (incl) break;\n"
+             "      base -= 64;\n"
+             "    }\n"
+             "    if (lane == 0) {\n"
+             "      if (tile > 0) sbk_publish(status, tile, sbk_combine(excl, t), 2u);\n"
+             "      s_pre = excl;\n"
+             "    }\n"
+             "  }\n"
+             "  __syncthreads();\n"
+             "  sbk_t W = s_pre;\n"
+             "  for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n";
+        epilogue(s);
+        // number of run heads (keys only): sizes the outputs of reduce_by_key before its single pass
+        s << "extern \"C\" __global__ void __launch_bounds__(256) vexcl_sbk_count(ulong n, " << key_params(true) << "int *total) {\n"
+             "  int c = 0;\n"
+             "  for (ulong i0 = ((ulong)blockIdx.x * 256 + threadIdx.x) * ITEMS; i0 < n; i0 += (ulong)gridDim.x * 256 * ITEMS) {\n";
+        for (size_t k = 0; k < nk; ++k) {
+            s << "    " << K[k] << " k" << k << "[ITEMS + 1];\n"
+              << "    k" << k << "[0] = i0 ? key" << k << "[i0 - 1] : (" << K[k] << ")0;\n"
+              << "    #pragma unroll\n"
+              << "    for (int j = 0; j < ITEMS; ++j) k" << k << "[j + 1] = i0 + j < n ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n";
+        }
+        s << "    #pragma unroll\n"
+             "    for (int j = 0; j < ITEMS; ++j)\n"
+             "      if (i0 + j < n) c += (i0 + j == 0) || !" << Comp::name() << "(";
+        for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j], ";
+        for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j + 1]" << (k + 1 < nk ? ", " : "");
+        s << ");\n"
+             "  }\n"
+             "  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);\n"
+             "  if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);\n"
+             "}\n";
     }
-    s << "      }\n"
-         "      prev = fin;\n"
-         "    }\n"
-         "  }\n"
-         "}\n";
     return src.str() + s.str();
 }
 
@@ -265,7 +397,7 @@ void for_each_key(const Tuple &t, F &&f, std::index_sequence<I...>) {
 
 /// Runs phases 1 and 2; returns the number of segments.  `finish` then launches phase 3.
 template <scan_mode mode, class KTuple, class V, class Comp, class Oper, class PushOutputs>
-int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&push_outputs, bool need_count) {
+int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&push_outputs, bool need_count, bool three_phases = false) {
     constexpr size_t nk = std::tuple_size<KTuple>::value;
     typedef std::make_index_sequence<nk> seq;
     const auto &queue = ivals.queue_list();
@@ -284,9 +416,44 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
         k.carry_local = backend::kernel(q, prog, "vexcl_sbk_carry_local");
         k.carry = backend::kernel(q, prog, "vexcl_sbk_carry");
         k.scan = backend::kernel(q, prog, "vexcl_sbk_scan");
+        if (lookback_value<V>::value) {
+            k.lookback = backend::kernel(q, prog, "vexcl_sbk_lookback");
+            k.count = backend::kernel(q, prog, "vexcl_sbk_count");
+            k.has_lookback = true;
+        }
         it = cache.insert(q, std::move(k));
     }
     kernels &K = it->second;
+
+    if (K.has_lookback && !three_phases && lookback_enabled()) {
+        // ---- single pass: [count the run heads (keys only) -> size the outputs] -> decoupled look-back over the tiles
+        const size_t LT = size_t(ROWS) * ITEMS * LB_WAVES * 64;
+        const size_t nt = (n + LT - 1) / LT;
+        precondition(nt < (size_t(1) << 31), "input too large");
+        const size_t words = 2 + (sizeof(V) == 8 ? 3 : 2) * nt;
+        backend::device_vector<char> wsb = scratch_pool::instance().get(q, 4, words * 8);
+        unsigned long long *ws = reinterpret_cast<unsigned long long *>(wsb.raw());
+        backend::check(vexhip_memset(q.device_ordinal(), ws, 0, words * 8, q.raw()));      // ticket, run count, tile states
+        int count = 0;
+        if (need_count) {
+            int *total = reinterpret_cast<int *>(ws + 1);
+            K.count.push_arg(n);
+            for_each_key(keys, [&](const auto &k) { K.count.push_arg(k(0).raw()); }, seq());
+            K.count.push_arg(total);
+            K.count.config(std::min<size_t>((n + 256 * ITEMS - 1) / (256 * ITEMS), size_t(256) * 64), 256);
+            K.count(q);
+            backend::device_vector<int> t = backend::device_vector<int>::wrap(total, 1);
+            t.read(q, 0, 1, &count, true);
+        }
+        K.lookback.push_arg(n);
+        for_each_key(keys, [&](const auto &k) { K.lookback.push_arg(k(0).raw()); }, seq());
+        K.lookback.push_arg(ivals(0).raw());
+        K.lookback.push_arg(ws);
+        push_outputs(K.lookback, count);
+        K.lookback.config(nt, LB_WAVES * 64);
+        K.lookback(q);
+        return count;
+    }
 
     const size_t ntiles = (n + TILE - 1) / TILE;
     precondition(ntiles < (size_t(1) << 31), "input too large");
@@ -330,10 +497,10 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
 }
 
 template <bool exclusive, class KTuple, class V, class Comp, class Oper>
-void scan_by_key(const KTuple &keys, const vector<V> &ivals, vector<V> &ovals, Comp comp, Oper oper, V init) {
+void scan_by_key(const KTuple &keys, const vector<V> &ivals, vector<V> &ovals, Comp comp, Oper oper, V init, bool three_phases = false) {
     precondition(ivals.size() == ovals.size(), "input and output have different sizes");
     run<exclusive ? EXCLUSIVE : INCLUSIVE>(keys, ivals, comp, oper,
-            [&](backend::kernel &k, int) { k.push_arg(ovals(0).raw()); k.push_arg(init); }, false);
+            [&](backend::kernel &k, int) { k.push_arg(ovals(0).raw()); k.push_arg(init); }, false, three_phases);
 }
 
 } // namespace sbk
@@ -400,8 +567,9 @@ void generic_scan(const vector<T> &input, vector<T> &output, bool exclusive, T i
         key = 0;
         vector<T> in(queue[d], input(d), n), out(queue[d], output(d), n);
         auto keys = std::tuple<const vector<int> &>(key);
-        if (exclusive) sbk::scan_by_key<true>(keys, in, out, sbk::equal_fn<int>(), device_oper(), init);
-        else           sbk::scan_by_key<false>(keys, in, out, sbk::equal_fn<int>(), device_oper(), init);
+        // one run as long as the partition: the three deterministic phases (a look-back would associate the carry as it goes)
+        if (exclusive) sbk::scan_by_key<true>(keys, in, out, sbk::equal_fn<int>(), device_oper(), init, true);
+        else           sbk::scan_by_key<false>(keys, in, out, sbk::equal_fn<int>(), device_oper(), init, true);
         if (nd > 1) {
             T last_out; output(d).read(queue[d], n - 1, 1, &last_out, true);
             tail[d] = exclusive ? oper(last_out, last_in[d]) : last_out;     // the partition's total (exclusive: includes init)
