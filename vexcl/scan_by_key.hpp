@@ -78,7 +78,8 @@ struct kernels {
     bool has_lookback = false;
 };
 
-static const int LB_WAVES = 8;          // waves per workgroup of the single-pass kernel: 4096 elements per tile
+static const int LB_WAVES = 16;         // waves per workgroup of the single-pass kernel
+static const int LB_ROWS = 4;           // rows of 64 x ITEMS elements per wave: 16 Ki elements per tile
 template <class V> struct lookback_value { static const bool value = std::is_arithmetic<V>::value && (sizeof(V) == 4 || sizeof(V) == 8); };
 inline bool lookback_enabled() { const char *e = std::getenv("VEXCL_SCAN_BY_KEY"); return !(e && std::string(e) == "tree"); }
 
@@ -307,8 +308,15 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         s << "  return s0 == s1 ? s0 : 0u;\n"
              "}\n"
              "__device__ inline sbk_t sbk_down(sbk_t x, int o) { sbk_t r; r.c = __shfl_down(x.c, o, 64); r.f = __shfl_down(x.f, o, 64); r.v = __shfl_down(x.v, o, 64); return r; }\n";
-        // ws[0] = ticket counter, ws[1] = reserved, ws + 2 = tile status words (all zero before launch)
-        s << "extern \"C\" __global__ void __launch_bounds__(" << LB_WAVES * 64 << ") vexcl_sbk_lookback(ulong n, " << key_params(true)
+        // ws[0] = ticket counter, ws[1] = run count (reduce_by_key), ws + 2 = tile status words (all zero before launch).
+        // Tile = 16 waves x LBR rows x 64 lanes x ITEMS consecutive elements = 16 Ki elements: a first version with 4 Ki
+        // elements per tile (what the three phases use) took 0.85 ms per 1e8 (int, double) pairs against 0.77 ms for the
+        // three phases -- 24 000 tiles start at 60 per microsecond, so every look-back met a few hundred predecessors
+        // that had only published their aggregate.  The lane keeps its 16 VALUES in registers between the two passes
+        // over them (aggregate before the look-back, results after it); keys are only needed for the head flags (one bit
+        // per element) and, in reduce_by_key, re-read at the run heads.
+        s << "#define LBR " << LB_ROWS << "\n"
+             "extern \"C\" __global__ void __launch_bounds__(" << LB_WAVES * 64 << ") vexcl_sbk_lookback(ulong n, " << key_params(true)
           << "const val_t *vals, sbk_word *ws, ";
         if (mode == REDUCE) {
             for (size_t k = 0; k < nk; ++k) s << K[k] << " *okey" << k << ", ";
@@ -324,10 +332,46 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "  __syncthreads();\n"
              "  const long tile = s_tile;\n"
              "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n"
-             "  const ulong wbase = ((ulong)tile * LBW + wave) * (ROWS * ITEMS * 64);\n"
-             "  sbk_t y[ROWS * ITEMS];\n"
-             "  sbk_t a = sbk_wave_tile(n, wbase, lane, " << key_args() << "vals, y);\n"
-             "  if (lane == 0) agg[wave] = a;\n"
+             "  const ulong wbase = ((ulong)tile * LBW + wave) * (LBR * ITEMS * 64);\n"
+             "  val_t v[LBR][ITEMS];\n"
+             "  sbk_t pre[LBR];\n"                  // prefix of everything in this wave before the lane's first element of row r
+             "  unsigned heads = 0;\n"              // bit r * ITEMS + j: element (r, lane, j) starts a run
+             "  sbk_t carry = sbk_empty();\n"
+             "  #pragma unroll\n"
+             "  for (int r = 0; r < LBR; ++r) {\n"
+             "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n";
+        for (size_t k = 0; k < nk; ++k) {
+            s << "    " << K[k] << " k" << k << "[ITEMS];\n"
+              << "    #pragma unroll\n"
+              << "    for (int j = 0; j < ITEMS; ++j) k" << k << "[j] = i0 + j < n ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n"
+              << "    " << K[k] << " p" << k << " = __shfl_up(k" << k << "[ITEMS - 1], 1, 64);\n"
+              << "    if (lane == 0 && i0 > 0 && i0 < n) p" << k << " = key" << k << "[i0 - 1];\n";
+        }
+        s << "    sbk_t acc = sbk_empty();\n"
+             "    #pragma unroll\n"
+             "    for (int j = 0; j < ITEMS; ++j) {\n"
+             "      sbk_t x = sbk_empty();\n"
+             "      v[r][j] = val_t();\n"
+             "      if (i0 + j < n) {\n";
+        for (size_t k = 0; k < nk; ++k)
+            s << "        const " << K[k] << " pk" << k << " = j ? k" << k << "[j ? j - 1 : 0] : p" << k << ";\n";
+        s << "        const bool head = (i0 + j == 0) || !" << Comp::name() << "(";
+        for (size_t k = 0; k < nk; ++k) s << "pk" << k << ", ";
+        for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j]" << (k + 1 < nk ? ", " : "");
+        s << ");\n"
+             "        v[r][j] = vals[i0 + j];\n"
+             "        heads |= (unsigned)head << (r * ITEMS + j);\n"
+             "        x.c = head; x.f = 2 | (int)head; x.v = v[r][j];\n"
+             "      }\n"
+             "      acc = sbk_combine(acc, x);\n"
+             "    }\n"
+             "    const sbk_t incl = sbk_wave_scan(acc, lane);\n"
+             "    sbk_t p = sbk_up(incl, 1);\n"
+             "    if (lane == 0) p = sbk_empty();\n"
+             "    pre[r] = sbk_combine(carry, p);\n"
+             "    carry = sbk_combine(carry, sbk_from(incl, 63));\n"
+             "  }\n"
+             "  if (lane == 0) agg[wave] = carry;\n"
              "  __syncthreads();\n"
              "  if (wave == 0) {\n"
              "    sbk_t t = agg[0];\n"
@@ -337,22 +381,22 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "    long base = tile - 1, spins = 0;\n"
              "    while (base >= 0) {\n"
              "      const long idx = base - lane;\n"                                    // lane 0 = the nearest predecessor
-             "      sbk_t v = sbk_empty();\n"
+             "      sbk_t q = sbk_empty();\n"
              "      unsigned st = 2u;\n"                                                // lanes before tile 0 end the walk with the identity
-             "      if (idx >= 0) st = sbk_read(status, idx, v);\n"
+             "      if (idx >= 0) st = sbk_read(status, idx, q);\n"
              "      while (__any(st == 0u)) {\n"
              "        __builtin_amdgcn_s_sleep(8);\n"
-             "        if (idx >= 0 && st == 0u) st = sbk_read(status, idx, v);\n"
+             "        if (idx >= 0 && st == 0u) st = sbk_read(status, idx, q);\n"
              "        if (++spins > (1l << 30)) __builtin_trap();\n"                   // a bug, never a truncated prefix (scan.hip)
              "      }\n"
              "      const unsigned long long incl = __ballot(st == 2u);\n"
              "      const int first = incl ? __builtin_ctzll(incl) : 63;\n"           // nearest predecessor with a complete prefix
-             "      if (lane > first) v = sbk_empty();\n"
+             "      if (lane > first) q = sbk_empty();\n"
              "      for (int o = 1; o < 64; o <<= 1) {\n"                               // ordered fold: older tiles (higher lanes) on the left
-             "        sbk_t u = sbk_down(v, o);\n"
-             "        if (lane + o < 64) v = sbk_combine(u, v);\n"
+             "        sbk_t u = sbk_down(q, o);\n"
+             "        if (lane + o < 64) q = sbk_combine(u, q);\n"
              "      }\n"
-             "      excl = sbk_combine(sbk_from(v, 0), excl);\n"
+             "      excl = sbk_combine(sbk_from(q, 0), excl);\n"
              "      if (incl) break;\n"
              "      base -= 64;\n"
              "    }\n"
@@ -363,8 +407,35 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "  }\n"
              "  __syncthreads();\n"
              "  sbk_t W = s_pre;\n"
-             "  for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n";
-        epilogue(s);
+             "  for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n"
+             // second pass over the lane's values: prev = inclusive prefix of the element before, fin = of the element itself
+             "  #pragma unroll\n"
+             "  for (int r = 0; r < LBR; ++r) {\n"
+             "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n"
+             "    sbk_t prev = sbk_combine(W, pre[r]);\n"
+             "    #pragma unroll\n"
+             "    for (int j = 0; j < ITEMS; ++j) {\n"
+             "      const ulong i = i0 + j;\n"
+             "      if (i < n) {\n"
+             "        const bool head = (heads >> (r * ITEMS + j)) & 1u;\n"
+             "        sbk_t x; x.c = head; x.f = 2 | (int)head; x.v = v[r][j];\n"
+             "        const sbk_t fin = sbk_combine(prev, x);\n";
+        if (mode == INCLUSIVE) {
+            s << "        (void)init; ovals[i] = fin.v;\n";
+        } else if (mode == EXCLUSIVE) {
+            s << "        ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+        } else {
+            s << "        if (head) {\n";
+            for (size_t k = 0; k < nk; ++k) s << "          okey" << k << "[fin.c - 1] = key" << k << "[i];\n";
+            s << "          if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
+                 "        }\n"
+                 "        if (i == n - 1) ovals[fin.c - 1] = fin.v;\n";
+        }
+        s << "        prev = fin;\n"
+             "      }\n"
+             "    }\n"
+             "  }\n"
+             "}\n";
         // number of run heads (keys only): sizes the outputs of reduce_by_key before its single pass
         s << "extern \"C\" __global__ void __launch_bounds__(256) vexcl_sbk_count(ulong n, " << key_params(true) << "int *total) {\n"
              "  int c = 0;\n"
@@ -427,7 +498,7 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
 
     if (K.has_lookback && !three_phases && lookback_enabled()) {
         // ---- single pass: [count the run heads (keys only) -> size the outputs] -> decoupled look-back over the tiles
-        const size_t LT = size_t(ROWS) * ITEMS * LB_WAVES * 64;
+        const size_t LT = size_t(LB_ROWS) * ITEMS * LB_WAVES * 64;
         const size_t nt = (n + LT - 1) / LT;
         precondition(nt < (size_t(1) << 31), "input too large");
         const size_t words = 2 + (sizeof(V) == 8 ? 3 : 2) * nt;
