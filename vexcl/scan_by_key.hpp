@@ -78,8 +78,10 @@ struct kernels {
     bool has_lookback = false;
 };
 
-static const int LB_WAVES = 16;         // waves per workgroup of the single-pass kernel
-static const int LB_ROWS = 4;           // rows of 64 x ITEMS elements per wave: 16 Ki elements per tile
+// geometry of the single-pass kernel: waves per workgroup, rows of 64 x ITEMS elements per wave (tuning: VEXCL_SBK_WAVES / _ROWS)
+inline int lb_env(const char *name, int def) { const char *e = std::getenv(name); return e ? std::atoi(e) : def; }
+static const int LB_WAVES = lb_env("VEXCL_SBK_WAVES", 16);
+static const int LB_ROWS = lb_env("VEXCL_SBK_ROWS", 4);
 template <class V> struct lookback_value { static const bool value = std::is_arithmetic<V>::value && (sizeof(V) == 4 || sizeof(V) == 8); };
 inline bool lookback_enabled() { const char *e = std::getenv("VEXCL_SCAN_BY_KEY"); return !(e && std::string(e) == "tree"); }
 
@@ -337,39 +339,71 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "  sbk_t pre[LBR];\n"                  // prefix of everything in this wave before the lane's first element of row r
              "  unsigned heads = 0;\n"              // bit r * ITEMS + j: element (r, lane, j) starts a run
              "  sbk_t carry = sbk_empty();\n"
+             "  const unsigned long long below = (1ull << lane) - 1ull;\n"
              "  #pragma unroll\n"
              "  for (int r = 0; r < LBR; ++r) {\n"
-             "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n";
-        for (size_t k = 0; k < nk; ++k) {
-            s << "    " << K[k] << " k" << k << "[ITEMS];\n"
-              << "    #pragma unroll\n"
-              << "    for (int j = 0; j < ITEMS; ++j) k" << k << "[j] = i0 + j < n ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n"
-              << "    " << K[k] << " p" << k << " = __shfl_up(k" << k << "[ITEMS - 1], 1, 64);\n"
-              << "    if (lane == 0 && i0 > 0 && i0 < n) p" << k << " = key" << k << "[i0 - 1];\n";
-        }
-        s << "    sbk_t acc = sbk_empty();\n"
-             "    #pragma unroll\n"
-             "    for (int j = 0; j < ITEMS; ++j) {\n"
-             "      sbk_t x = sbk_empty();\n"
-             "      v[r][j] = val_t();\n"
-             "      if (i0 + j < n) {\n";
+             "    const ulong row0 = wbase + (ulong)r * (64 * ITEMS), i0 = row0 + (ulong)lane * ITEMS;\n"
+             "    const bool full = row0 + 64 * ITEMS <= n;\n"       // uniform: no bounds checks, the loads of a lane merge into 16-byte loads
+             "    unsigned h = 0, ok = 0;\n";
+        for (size_t k = 0; k < nk; ++k) s << "    " << K[k] << " k" << k << "[ITEMS];\n";
+        s << "    if (full) {\n"
+             "      ok = (1u << ITEMS) - 1u;\n"
+             "      #pragma unroll\n"
+             "      for (int j = 0; j < ITEMS; ++j) {\n";
+        for (size_t k = 0; k < nk; ++k) s << "        k" << k << "[j] = key" << k << "[i0 + j];\n";
+        s << "        v[r][j] = vals[i0 + j];\n"
+             "      }\n"
+             "    } else {\n"
+             "      #pragma unroll\n"
+             "      for (int j = 0; j < ITEMS; ++j) {\n"
+             "        const bool in = i0 + j < n;\n"
+             "        ok |= (unsigned)in << j;\n";
+        for (size_t k = 0; k < nk; ++k) s << "        k" << k << "[j] = in ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n";
+        s << "        v[r][j] = in ? vals[i0 + j] : val_t();\n"
+             "      }\n"
+             "    }\n";
         for (size_t k = 0; k < nk; ++k)
-            s << "        const " << K[k] << " pk" << k << " = j ? k" << k << "[j ? j - 1 : 0] : p" << k << ";\n";
-        s << "        const bool head = (i0 + j == 0) || !" << Comp::name() << "(";
+            s << "    " << K[k] << " p" << k << " = __shfl_up(k" << k << "[ITEMS - 1], 1, 64);\n"
+              << "    if (lane == 0 && i0 > 0 && i0 < n) p" << k << " = key" << k << "[i0 - 1];\n";
+        // the lane's own four elements: head flags, running value since the lane's last head
+        s << "    val_t tail = val_t();\n"
+             "    #pragma unroll\n"
+             "    for (int j = 0; j < ITEMS; ++j) {\n";
+        for (size_t k = 0; k < nk; ++k)
+            s << "      const " << K[k] << " pk" << k << " = j ? k" << k << "[j ? j - 1 : 0] : p" << k << ";\n";
+        s << "      const bool hd = ((ok >> j) & 1u) && ((i0 + j == 0) || !" << Comp::name() << "(";
         for (size_t k = 0; k < nk; ++k) s << "pk" << k << ", ";
         for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j]" << (k + 1 < nk ? ", " : "");
-        s << ");\n"
-             "        v[r][j] = vals[i0 + j];\n"
-             "        heads |= (unsigned)head << (r * ITEMS + j);\n"
-             "        x.c = head; x.f = 2 | (int)head; x.v = v[r][j];\n"
-             "      }\n"
-             "      acc = sbk_combine(acc, x);\n"
+        s << "));\n"
+             "      h |= (unsigned)hd << j;\n"
+             "      if ((ok >> j) & 1u) tail = (hd || j == 0) ? v[r][j] : " << Oper::name() << "(tail, v[r][j]);\n"
              "    }\n"
-             "    const sbk_t incl = sbk_wave_scan(acc, lane);\n"
-             "    sbk_t p = sbk_up(incl, 1);\n"
+             "    heads |= h << (r * ITEMS);\n"
+             // Across the lanes: which lanes hold a head is a ballot, so the segmented scan of the tails needs no flag
+             // traffic -- lane L adds the value of lane L - o exactly when no lane in (L - o, L] holds a head, i.e. when
+             // L - o is not below the nearest head lane at or before L; the number of heads before a lane is a popcount.
+             "    const unsigned long long H = __ballot(h != 0u), any = __ballot(ok != 0u);\n"
+             "    const unsigned long long upto = H & (below | (1ull << lane));\n"
+             "    const int hl = upto ? 63 - __builtin_clzll(upto) : 0;\n"
+             "    val_t T = tail;\n"
+             "    #pragma unroll\n"
+             "    for (int o = 1; o < 64; o <<= 1) {\n"
+             "      const val_t u = __shfl_up(T, o, 64);\n"
+             "      if (lane - o >= hl && ((any >> lane) & 1ull)) T = " << Oper::name() << "(u, T);\n"
+             "    }\n"
+             "    int cb = 0;\n"
+             "    #pragma unroll\n"
+             "    for (int j = 0; j < ITEMS; ++j) cb += __popcll(__ballot((h >> j) & 1u) & below);\n"
+             "    sbk_t p; p.c = cb; p.f = ((any & below) ? 2 : 0) | ((H & below) ? 1 : 0); p.v = __shfl_up(T, 1, 64);\n"
              "    if (lane == 0) p = sbk_empty();\n"
              "    pre[r] = sbk_combine(carry, p);\n"
-             "    carry = sbk_combine(carry, sbk_from(incl, 63));\n"
+             // the row's aggregate: all its heads, the value of the run that is open at its end
+             "    sbk_t ra; ra.c = 0;\n"
+             "    #pragma unroll\n"
+             "    for (int j = 0; j < ITEMS; ++j) ra.c += __popcll(__ballot((h >> j) & 1u));\n"
+             "    ra.f = (any ? 2 : 0) | (H ? 1 : 0);\n"
+             "    ra.v = __shfl(T, any ? 63 - __builtin_clzll(any) : 0, 64);\n"
+             "    carry = sbk_combine(carry, ra);\n"
              "  }\n"
              "  if (lane == 0) agg[wave] = carry;\n"
              "  __syncthreads();\n"
@@ -379,6 +413,7 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "    if (lane == 0) sbk_publish(status, tile, t, tile == 0 ? 2u : 1u);\n"
              "    sbk_t excl = sbk_empty();\n"
              "    long base = tile - 1, spins = 0;\n"
+          << (std::getenv("VEXCL_SBK_ABLATE_LOOKBACK") ? "    base = -1;\n" : "") <<       // timing experiment only: wrong results
              "    while (base >= 0) {\n"
              "      const long idx = base - lane;\n"                                    // lane 0 = the nearest predecessor
              "      sbk_t q = sbk_empty();\n"
