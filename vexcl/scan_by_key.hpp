@@ -314,7 +314,10 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         // Tile = 16 waves x LBR rows x 64 lanes x ITEMS consecutive elements = 16 Ki elements: a first version with 4 Ki
         // elements per tile (what the three phases use) took 0.85 ms per 1e8 (int, double) pairs against 0.77 ms for the
         // three phases -- 24 000 tiles start at 60 per microsecond, so every look-back met a few hundred predecessors
-        // that had only published their aggregate.  The lane keeps its 16 VALUES in registers between the two passes
+        // that had only published their aggregate.  Measured per 1e8 pairs (scan / reduce_by_key, ms; VEXCL_SBK_WAVES x
+        // _ROWS): 16 x 4 0.60 / 0.56, 16 x 3 0.61 / 0.57, 8 x 4 0.64 / 0.56, 16 x 2 0.65 / 0.63, 4 x 4 0.77 / 0.65,
+        // 8 x 2 0.78 / 0.73; without the look-back loop (wrong results) 16 x 4 takes 0.54 ms: what is left is the
+        // 104-register, one-workgroup-per-CU body, not the look-back.  The lane keeps its 16 VALUES in registers between the two passes
         // over them (aggregate before the look-back, results after it); keys are only needed for the head flags (one bit
         // per element) and, in reduce_by_key, re-read at the run heads.
         s << "#define LBR " << LB_ROWS << "\n"
@@ -413,7 +416,7 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "    if (lane == 0) sbk_publish(status, tile, t, tile == 0 ? 2u : 1u);\n"
              "    sbk_t excl = sbk_empty();\n"
              "    long base = tile - 1, spins = 0;\n"
-          << (std::getenv("VEXCL_SBK_ABLATE_LOOKBACK") ? "    base = -1;\n" : "") <<       // timing experiment only: wrong results
+          <<
              "    while (base >= 0) {\n"
              "      const long idx = base - lane;\n"                                    // lane 0 = the nearest predecessor
              "      sbk_t q = sbk_empty();\n"
@@ -471,25 +474,45 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "    }\n"
              "  }\n"
              "}\n";
-        // number of run heads (keys only): sizes the outputs of reduce_by_key before its single pass
+        // number of run heads (keys only): sizes the outputs of reduce_by_key before its single pass.  A lane owns ITEMS
+        // consecutive keys (one 16-byte load for 4-byte keys on full blocks); the key before its first one comes from the
+        // neighbour lane.  (First version: five guarded 4-byte loads per lane and step, 0.76 ms per 1e8 keys.)
         s << "extern \"C\" __global__ void __launch_bounds__(256) vexcl_sbk_count(ulong n, " << key_params(true) << "int *total) {\n"
+             "  const int lane = threadIdx.x & 63;\n"
              "  int c = 0;\n"
-             "  for (ulong i0 = ((ulong)blockIdx.x * 256 + threadIdx.x) * ITEMS; i0 < n; i0 += (ulong)gridDim.x * 256 * ITEMS) {\n";
-        for (size_t k = 0; k < nk; ++k) {
-            s << "    " << K[k] << " k" << k << "[ITEMS + 1];\n"
-              << "    k" << k << "[0] = i0 ? key" << k << "[i0 - 1] : (" << K[k] << ")0;\n"
-              << "    #pragma unroll\n"
-              << "    for (int j = 0; j < ITEMS; ++j) k" << k << "[j + 1] = i0 + j < n ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n";
-        }
+             "  for (ulong b0 = (ulong)blockIdx.x * (256 * ITEMS); b0 < n; b0 += (ulong)gridDim.x * (256 * ITEMS)) {\n"
+             "    const ulong i0 = b0 + (ulong)threadIdx.x * ITEMS;\n"
+             "    const bool full = b0 + 256 * ITEMS <= n;\n";
+        for (size_t k = 0; k < nk; ++k) s << "    " << K[k] << " k" << k << "[ITEMS];\n";
+        s << "    if (full) {\n"
+             "      #pragma unroll\n"
+             "      for (int j = 0; j < ITEMS; ++j) {\n";
+        for (size_t k = 0; k < nk; ++k) s << "        k" << k << "[j] = key" << k << "[i0 + j];\n";
+        s << "      }\n"
+             "    } else {\n"
+             "      #pragma unroll\n"
+             "      for (int j = 0; j < ITEMS; ++j) {\n";
+        for (size_t k = 0; k < nk; ++k) s << "        k" << k << "[j] = i0 + j < n ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n";
+        s << "      }\n"
+             "    }\n";
+        for (size_t k = 0; k < nk; ++k)
+            s << "    " << K[k] << " p" << k << " = __shfl_up(k" << k << "[ITEMS - 1], 1, 64);\n"
+              << "    if (lane == 0 && i0 > 0 && i0 < n) p" << k << " = key" << k << "[i0 - 1];\n";
         s << "    #pragma unroll\n"
-             "    for (int j = 0; j < ITEMS; ++j)\n"
-             "      if (i0 + j < n) c += (i0 + j == 0) || !" << Comp::name() << "(";
-        for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j], ";
-        for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j + 1]" << (k + 1 < nk ? ", " : "");
+             "    for (int j = 0; j < ITEMS; ++j) {\n";
+        for (size_t k = 0; k < nk; ++k)
+            s << "      const " << K[k] << " pk" << k << " = j ? k" << k << "[j ? j - 1 : 0] : p" << k << ";\n";
+        s << "      if (i0 + j < n) c += (i0 + j == 0) || !" << Comp::name() << "(";
+        for (size_t k = 0; k < nk; ++k) s << "pk" << k << ", ";
+        for (size_t k = 0; k < nk; ++k) s << "k" << k << "[j]" << (k + 1 < nk ? ", " : "");
         s << ");\n"
+             "    }\n"
              "  }\n"
              "  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);\n"
-             "  if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);\n"
+             "  __shared__ int wc[4];\n"                    // one atomic per workgroup: 390 000 per-wave atomics on one word took 0.75 ms
+             "  if (lane == 0) wc[threadIdx.x >> 6] = c;\n"
+             "  __syncthreads();\n"
+             "  if (threadIdx.x == 0 && (wc[0] + wc[1] + wc[2] + wc[3])) atomicAdd(total, wc[0] + wc[1] + wc[2] + wc[3]);\n"
              "}\n";
     }
     return src.str() + s.str();
@@ -546,7 +569,7 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
             K.count.push_arg(n);
             for_each_key(keys, [&](const auto &k) { K.count.push_arg(k(0).raw()); }, seq());
             K.count.push_arg(total);
-            K.count.config(std::min<size_t>((n + 256 * ITEMS - 1) / (256 * ITEMS), size_t(256) * 64), 256);
+            K.count.config(std::min<size_t>((n + 256 * ITEMS - 1) / (256 * ITEMS), size_t(256) * 16), 256);
             K.count(q);
             backend::device_vector<int> t = backend::device_vector<int>::wrap(total, 1);
             t.read(q, 0, 1, &count, true);
