@@ -345,6 +345,13 @@ int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t 
         int format, int flags, vexhip_spmat **out);
 int vexhip_spmat_create_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
         int format, int flags, vexhip_spmat **out);
+/* The same with 64-bit ROW POINTERS (a device may hold 2^31 entries or more: the reference's default index type is
+ * size_t, vexcl/spmat.hpp:56-57; a 288 GB part holds such matrices).  Columns stay 32-bit (< 2^31 columns per device);
+ * the CSR tail of a hybrid-ELL storage must stay below 2^31 entries.  Same storage selection, same products.        */
+int vexhip_spmat_create_f64_p64(int dev, void *stream, int64_t n, const int64_t *ptr, const int32_t *col, const double *val,
+        int format, int flags, vexhip_spmat **out);
+int vexhip_spmat_create_f32_p64(int dev, void *stream, int64_t n, const int64_t *ptr, const int32_t *col, const float *val,
+        int format, int flags, vexhip_spmat **out);
 int vexhip_spmat_destroy(vexhip_spmat *A);
 int vexhip_spmat_apply_f64(const vexhip_spmat *A, void *stream, double alpha, int append, const double *x, double *y);
 int vexhip_spmat_apply_f32(const vexhip_spmat *A, void *stream, float alpha, int append, const float *x, float *y);
@@ -595,6 +602,9 @@ int vexhip_poisson3d_csr_f64_i32(int dev, void *stream, int64_t n, int32_t *ptr,
 int vexhip_poisson3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end,
         int32_t *ptr, int32_t *col, double *val);
 int64_t vexhip_poisson3d_strip_nnz(int64_t n, int64_t row_begin, int64_t row_end);
+/* the same strip with 64-bit row pointers: grids with 2^31 entries and more (700^3: 2.39e9); columns stay 32-bit */
+int vexhip_poisson3d_strip_f64_p64(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end,
+        int64_t *ptr, int32_t *col, double *val);
 /* The same 7-point pattern with a different coefficient on every face: -div(k grad u), k = 0.5 + u(hash(seed, face)),
  * u in [0,1) -- about 4 N distinct values (every coupling appears in the two rows it joins), what a finite-volume code assembles (no value coding applies).  Same row strip
  * convention and nnz as the Poisson generator; restated on the host in oracle/vex_oracle.c (bit-identical values).   */

@@ -347,6 +347,69 @@ def test_march_needs_slices_that_repeat_in_runs(T, built_lib):
     assert float((ya.view(n, n, n) - (3.0 + 0.5 * ref)).abs().max()) <= TOL * 12 * h2i
 
 
+def test_row_pointers_64bit(T, oracle, built_lib):
+    """64-bit row pointers through vexhip_spmat_create_*_p64 (round 3): every storage built from int64 pointers equals the
+    one built from int32 pointers and the CSR oracle bit for bit (Poisson 48^3, the variable-coefficient operator, a matrix
+    with a CSR tail, single precision)."""
+    torch = T.torch
+    n = 48
+    N = n ** 3
+    x = oracle.random_f64(3, N)
+    for label, (ptr, col, val) in (("poisson", oracle.poisson3d(n)), ("diffusion", oracle.diffusion3d(n, 5))):
+        want = oracle.spmv_csr(ptr, col, val, x)
+        for fmt in ("auto", "sell8", "sell32", "csr"):
+            A = T.ops.SpMat(T.up(ptr.astype(np.int64)), T.up(col), T.up(val), fmt=fmt)
+            B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt=fmt)
+            assert A.handle and A.storage == B.storage, (label, fmt, A.storage, B.storage)
+            y = torch.full((N,), 2.0, dtype=torch.float64, device=T.dev)
+            A.apply(T.up(x), y, -0.5, True)
+            assert np.array_equal(y.cpu().numpy(), 2.0 - 0.5 * want), (label, fmt)
+    # rows wider than the ELL width keep a CSR tail (32-bit pointers inside the library)
+    ptr, col, val = oracle.random_matrix(105, 700, 5000, 900)
+    xr = oracle.random_f64(9, 5000)
+    A = T.ops.SpMat(T.up(ptr.astype(np.int64)), T.up(col), T.up(val), n_cols=5000)
+    y = torch.empty(700, dtype=torch.float64, device=T.dev)
+    A.apply(T.up(xr), y)
+    _check(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xr), oracle.spmv_abs_bound(ptr, col, val, xr))
+    ptr, col, val = oracle.poisson3d(n)
+    F = T.ops.SpMat(T.up(ptr.astype(np.int64)), T.up(col), T.up(val.astype(np.float32)))
+    G = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val.astype(np.float32)))
+    yf = torch.empty(N, dtype=torch.float32, device=T.dev); yg = torch.empty_like(yf)
+    F.apply(T.up(x.astype(np.float32)), yf); G.apply(T.up(x.astype(np.float32)), yg)
+    assert torch.equal(yf, yg)
+
+
+def test_more_than_2_31_nonzeros(T, built_lib):
+    """700^3 Poisson: 343 000 000 rows, 2 390 437 192 entries -- more than 2^31 on one device (the reference's default index
+    type is size_t, vexcl/spmat.hpp:56-57).  Built in HBM with 64-bit row pointers, stored with diagonal and value codes,
+    checked against an evaluation of the stencil that never touches the matrix; the CSR arrays themselves (row bounds
+    read as 64-bit values) must give the same bits."""
+    torch, ops = T.torch, T.ops
+    n = 700
+    N = n ** 3
+    dp, dc, dv = ops.poisson3d(n, T.dev)
+    assert dp.dtype == torch.int64 and int(dp[-1]) == 2390437192 and dc.numel() == 2390437192
+    A = ops.SpMat(dp, dc, dv)
+    assert A.storage == "sell8v" and A.info.nnz == 2390437192
+    x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=T.dev), 11)
+    y = torch.empty(N, dtype=torch.float64, device=T.dev)
+    A.apply(x, y)
+    C = ops.SpMat(dp, dc, dv, fmt="csr")
+    yc = torch.empty_like(y)
+    C.apply(x, yc)
+    assert torch.equal(y, yc)
+    del C, yc, dp, dc, dv
+    A.ptr = A.col = A.val = None
+    torch.cuda.empty_cache()
+    h2i = float((n - 1) ** 2)
+    X = x.view(n, n, n)
+    ref = X.clone()
+    c = X[1:-1, 1:-1, 1:-1]
+    nb = (X[:-2, 1:-1, 1:-1] + X[2:, 1:-1, 1:-1] + X[1:-1, :-2, 1:-1] + X[1:-1, 2:, 1:-1] + X[1:-1, 1:-1, :-2] + X[1:-1, 1:-1, 2:])
+    ref[1:-1, 1:-1, 1:-1] = h2i * (6 * c - nb)
+    assert float((y.view(n, n, n) - ref).abs().max()) <= TOL * 12 * h2i
+
+
 def test_poisson512_properties(T):
     """BASELINE.json's full size (134 217 728 rows, 930 123 728 nnz): no CPU
     oracle in seconds at this size, so size-independent properties:

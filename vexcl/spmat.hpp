@@ -46,7 +46,7 @@ class SpMat {
             std::vector<std::vector<col_t>> ghosts(queue.size());
             for (unsigned d = 0; d < queue.size(); ++d)
                 mtx[d] = std::make_shared<device_part>(queue[d], row + part[d], row + part[d + 1], col, val,
-                        col_part[d], col_part[d + 1], ghosts[d]);
+                        col_part[d], col_part[d + 1], ghosts[d], queue.size() == 1);
             if (queue.size() > 1) exc.setup(queue, col_part, ghosts);
         }
 
@@ -63,6 +63,20 @@ class SpMat {
                     "SpMat value type must be float or double");
             precondition(queue.size() == 1, "SpMat from device arrays: single-device contexts only");
             precondition(row.size() == n + 1 && col.size() >= nonzeros && val.size() >= nonzeros, "SpMat: inconsistent CSR arrays");
+            mtx[0] = std::make_shared<device_part>(queue[0], n, nonzeros, row, col, val);
+        }
+
+        /// The same with 64-bit ROW POINTERS: matrices with 2^31 entries and more on one device (the reference's default
+        /// index type is size_t, spmat.hpp:56-57; vexhip_spmat_create_*_p64).  Columns stay 32-bit.
+        SpMat(const std::vector<backend::command_queue> &queue, size_t n, size_t m, size_t nonzeros,
+              const backend::device_vector<long long> &row, const backend::device_vector<int> &col, const backend::device_vector<val_t> &val)
+            : queue(queue), part(vex::partition(n, queue)), col_part(vex::partition(m, queue)),
+              nrows(n), ncols(m), nnz(nonzeros), mtx(queue.size())
+        {
+            static_assert(std::is_same<val_t, double>::value || std::is_same<val_t, float>::value,
+                    "SpMat value type must be float or double");
+            precondition(queue.size() == 1, "SpMat from device arrays: single-device contexts only");
+            precondition(row.size() == n + 1 && col.size() >= nonzeros && val.size() >= nonzeros && m < (size_t(1) << 31), "SpMat: inconsistent CSR arrays");
             mtx[0] = std::make_shared<device_part>(queue[0], n, nonzeros, row, col, val);
         }
 
@@ -125,6 +139,8 @@ class SpMat {
 
         static int spmat_create(int dev, void *s, int64_t n, const int *p, const int *c, const double *v, int fmt, int flags, vexhip_spmat **o) { return vexhip_spmat_create_f64_i32(dev, s, n, p, c, v, fmt, flags, o); }
         static int spmat_create(int dev, void *s, int64_t n, const int *p, const int *c, const float *v, int fmt, int flags, vexhip_spmat **o) { return vexhip_spmat_create_f32_i32(dev, s, n, p, c, v, fmt, flags, o); }
+        static int spmat_create(int dev, void *s, int64_t n, const long long *p, const int *c, const double *v, int fmt, int flags, vexhip_spmat **o) { return vexhip_spmat_create_f64_p64(dev, s, n, reinterpret_cast<const int64_t *>(p), c, v, fmt, flags, o); }
+        static int spmat_create(int dev, void *s, int64_t n, const long long *p, const int *c, const float *v, int fmt, int flags, vexhip_spmat **o) { return vexhip_spmat_create_f32_p64(dev, s, n, reinterpret_cast<const int64_t *>(p), c, v, fmt, flags, o); }
         static int spmat_apply(const vexhip_spmat *A, void *s, double a, int app, const double *x, double *y) { return vexhip_spmat_apply_f64(A, s, a, app, x, y); }
         static int spmat_apply(const vexhip_spmat *A, void *s, float a, int app, const float *x, float *y) { return vexhip_spmat_apply_f32(A, s, a, app, x, y); }
         static int spmat_apply_multi(const vexhip_spmat *A, void *s, int k, double a, int app, const double *const *x, double *const *y) { return vexhip_spmat_apply_multi_f64(A, s, k, a, app, x, y); }
@@ -135,7 +151,7 @@ class SpMat {
             size_t n;
 
             device_part(const backend::command_queue &q, const idx_t *row_begin, const idx_t *row_end,
-                    const col_t *col, const val_t *val, size_t col_begin, size_t col_end, std::vector<col_t> &ghost_cols)
+                    const col_t *col, const val_t *val, size_t col_begin, size_t col_end, std::vector<col_t> &ghost_cols, bool whole)
                 : n(row_end - row_begin)
             {
                 // The strip goes to the device as it is (row pointers rebased, indices narrowed to int32: one host pass,
@@ -143,7 +159,31 @@ class SpMat {
                 // and the sorted ghost set (vexhip_csr_split_*; the reference does all of it on the host with a
                 // std::set per device: spmat.hpp:291-378, csr.inl:92-131, hybrid_ell.inl:132-136).
                 const size_t first = static_cast<size_t>(row_begin[0]), strip_nnz = static_cast<size_t>(row_end[0]) - first;
-                precondition(strip_nnz < (1ull << 31) && col_end < (1ull << 31), "SpMat: more than 2^31 nonzeros or columns on one device");
+                if (strip_nnz >= (1ull << 31)) {
+                    // 2^31 entries or more on this device: 64-bit row pointers (vexhip_spmat_create_*_p64).  The device-side
+                    // split into local / remote parts works on 32-bit pointers, so this needs the device to own every
+                    // column (a single-device context); a larger matrix on several devices stays below 2^31 per device.
+                    precondition(whole && col_end < (1ull << 31), "SpMat: 2^31 or more nonzeros on one device of a multi-device context, or 2^31 or more columns");
+                    std::vector<long long> sptr(n + 1);
+                    for (size_t i = 0; i <= n; ++i) sptr[i] = static_cast<long long>(static_cast<size_t>(row_begin[i]) - first);
+                    backend::device_vector<long long> dptr(q, n + 1, sptr.data());
+                    std::vector<long long>().swap(sptr);
+                    backend::device_vector<int> dcol(q, strip_nnz);
+                    {   // columns narrowed in chunks: no second host copy of the whole array
+                        const size_t chunk = size_t(1) << 26;
+                        std::vector<int> buf(std::min(chunk, strip_nnz));
+                        for (size_t o = 0; o < strip_nnz; o += chunk) {
+                            const size_t k = std::min(chunk, strip_nnz - o);
+                            for (size_t j = 0; j < k; ++j) buf[j] = static_cast<int>(col[first + o + j]);
+                            dcol.write(q, o, k, buf.data(), true);
+                        }
+                    }
+                    backend::device_vector<val_t> dval(q, strip_nnz, val + first);
+                    set_local(q, dptr, dcol, dval, strip_nnz);
+                    rem.n = n; rem.nnz = 0;
+                    return;
+                }
+                precondition(col_end < (1ull << 31), "SpMat: more than 2^31 columns on one device");
                 std::vector<int> sptr(n + 1), scol(strip_nnz);
                 for (size_t i = 0; i <= n; ++i) sptr[i] = static_cast<int>(static_cast<size_t>(row_begin[i]) - first);
                 for (size_t j = 0; j < strip_nnz; ++j) {
@@ -188,6 +228,15 @@ class SpMat {
                 rem.n = n; rem.nnz = 0;
             }
 
+            /// ... with 64-bit row pointers
+            device_part(const backend::command_queue &q, size_t rows, size_t nonzeros, const backend::device_vector<long long> &dptr,
+                    const backend::device_vector<int> &dcol, const backend::device_vector<val_t> &dval)
+                : n(rows)
+            {
+                set_local(q, dptr, dcol, dval, nonzeros);
+                rem.n = n; rem.nnz = 0;
+            }
+
             backend::device_vector<int> rem_rows;
 
             static bool use_ell() {
@@ -210,6 +259,18 @@ class SpMat {
                 loc.handle = std::shared_ptr<vexhip_spmat>(h, [](vexhip_spmat *p) { vexhip_spmat_destroy(p); });
                 backend::check(vexhip_spmat_get_info(h, &loc.info));
                 if (loc.info.format == VEXHIP_SPMAT_CSR) { loc.csr_ptr = dptr; loc.csr_col = dcol; loc.csr_val = dval; loc.csr_nnz = loc.nnz; }   // borrowed: keep alive
+            }
+            /// ... 64-bit row pointers: the library keeps its own copy of what it needs (nothing is borrowed)
+            void set_local(const backend::command_queue &q, const backend::device_vector<long long> &dptr,
+                    const backend::device_vector<int> &dcol, const backend::device_vector<val_t> &dval, size_t nonzeros)
+            {
+                loc.n = n; loc.nnz = nonzeros;
+                if (!loc.nnz || !n) return;
+                vexhip_spmat *h = nullptr;
+                backend::check(spmat_create(q.device_ordinal(), q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), dval.raw(),
+                            use_ell() ? VEXHIP_SPMAT_AUTO : VEXHIP_SPMAT_CSR, 0, &h));
+                loc.handle = std::shared_ptr<vexhip_spmat>(h, [](vexhip_spmat *p) { vexhip_spmat_destroy(p); });
+                backend::check(vexhip_spmat_get_info(h, &loc.info));
             }
 
             /// Local part times several vectors at once (pointers of this device's segments).
@@ -380,6 +441,8 @@ struct inline_spmv : expression_base {
         a.next();
         const auto &L = A.part_of(a.device).loc.info;      // zero-initialised when the local part is empty
         const bool csr_rows = L.format == VEXHIP_SPMAT_CSR || L.tail_nnz > 0;
+        // (a matrix kept in CSR with 64-bit row pointers has no 32-bit pointer array for the generated terminal)
+        precondition(!(L.format == VEXHIP_SPMAT_CSR && L.nnz > 0 && !L.csr_ptr), "make_inline: CSR storage with 64-bit row pointers is not supported in generated code");
         a.krn.push_arg((long)L.ell_width);
         a.krn.push_arg(static_cast<const char *>(L.sell));
         a.krn.push_arg(static_cast<const int *>(L.ndeltas > 0 ? L.deltas : nullptr));

@@ -161,6 +161,8 @@ _PROTOS = {
     "vexhip_spmv_sell8v_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 8 + [ctypes.POINTER(Traversal)]),
     "vexhip_spmat_create_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
     "vexhip_spmat_create_f32_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_spmat_create_f64_p64": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_spmat_create_f32_p64": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
     "vexhip_spmat_destroy": (None, [c_vp]),
     "vexhip_spmat_apply_f64": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp]),
     "vexhip_spmat_apply_f32": (None, [c_vp, c_vp, c_f32, c_int, c_vp, c_vp]),
@@ -228,6 +230,7 @@ _PROTOS = {
     "vexhip_poisson3d_strip_nnz": (c_i64, [c_i64, c_i64, c_i64]),
     "vexhip_poisson3d_csr_f64_i32": (None, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vexhip_poisson3d_strip_f64_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "vexhip_poisson3d_strip_f64_p64": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "vexhip_diffusion3d_strip_f64_i32": (None, [c_int, c_vp, c_i64, c_i64, c_i64, c_u64, c_vp, c_vp, c_vp]),
     "vexhip_fill_hash": (None, [c_int, c_vp, c_int, c_u64, c_vp, c_i64]),
     "vexhip_fill_value": (None, [c_int, c_vp, c_int, c_vp, c_vp, c_i64]),

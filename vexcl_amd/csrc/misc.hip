@@ -79,10 +79,10 @@ __device__ __forceinline__ double face_coefficient(unsigned long long seed, long
 // VAR = false: the benchmark's Poisson matrix.  VAR = true: the same 7-point pattern with a different coefficient on
 // every face -- -div(k grad u), k in [0.5, 1.5) -- i.e. about 4 N distinct values: what a finite-volume code assembles, and
 // the matrix no value coding applies to (bench.py's "variable coefficient" row).  Symmetric; boundary rows identity.
-template <typename V, bool VAR>
+template <typename V, bool VAR, typename P = int>
 __global__ __launch_bounds__(256)
 void poisson_kernel(long long n, long long row_begin, long long row_end, unsigned long long seed,
-        int *__restrict__ ptr, int *__restrict__ col, V *__restrict__ val)
+        P *__restrict__ ptr, int *__restrict__ col, V *__restrict__ val)
 {
     const long long nn = n * n;
     const V h2i = (V)((double)(n - 1) * (double)(n - 1));
@@ -90,7 +90,7 @@ void poisson_kernel(long long n, long long row_begin, long long row_end, unsigne
     for (long long idx = row_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; idx <= row_end;
          idx += (long long)gridDim.x * blockDim.x) {
         long long p = poisson_nnz_before(idx, n) - base;
-        ptr[idx - row_begin] = (int)p;
+        ptr[idx - row_begin] = (P)p;
         if (idx == row_end) break;
         long long i = idx % n, j = (idx / n) % n, k = idx / nn;
         bool bnd = (i == 0 || i == n - 1 || j == 0 || j == n - 1 || k == 0 || k == n - 1);
@@ -119,12 +119,13 @@ void poisson_kernel(long long n, long long row_begin, long long row_end, unsigne
 }
 
 // ---- hybrid ELL analysis / fill -------------------------------------------
+template <typename P>
 __global__ __launch_bounds__(256)
-void width_max_kernel(long long n, const int *__restrict__ ptr, int *maxw) {
+void width_max_kernel(long long n, const P *__restrict__ ptr, int *maxw) {
     int m = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        int w = ptr[i + 1] - ptr[i];
+        int w = (int)(ptr[i + 1] - ptr[i]);
         m = w > m ? w : m;
     }
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(m, o, 64); m = v > m ? v : m; }
@@ -132,8 +133,9 @@ void width_max_kernel(long long n, const int *__restrict__ ptr, int *maxw) {
 }
 
 // histogram of min(width, cap) -- cap bucket collects everything wider
+template <typename P>
 __global__ __launch_bounds__(256)
-void width_hist_kernel(long long n, const int *__restrict__ ptr, int cap, unsigned long long *hist) {
+void width_hist_kernel(long long n, const P *__restrict__ ptr, int cap, unsigned long long *hist) {
     // widths below 256 (every practical matrix) are counted in LDS first: a
     // regular matrix would otherwise serialise all rows on one global atomic
     __shared__ unsigned s_h[256];
@@ -141,7 +143,7 @@ void width_hist_kernel(long long n, const int *__restrict__ ptr, int cap, unsign
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        int w = ptr[i + 1] - ptr[i];
+        int w = (int)(ptr[i + 1] - ptr[i]);
         if (w > cap) w = cap;
         if (w < 256) atomicAdd(&s_h[w], 1u);
         else atomicAdd(&hist[w], 1ull);
@@ -150,12 +152,13 @@ void width_hist_kernel(long long n, const int *__restrict__ ptr, int cap, unsign
     if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
 }
 
+template <typename P>
 __global__ __launch_bounds__(256)
-void tail_count_kernel(long long n, const int *__restrict__ ptr, int w, int *cnt, unsigned long long *total) {
+void tail_count_kernel(long long n, const P *__restrict__ ptr, int w, int *cnt, unsigned long long *total) {
     unsigned long long local = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        int rw = ptr[i + 1] - ptr[i];
+        int rw = (int)(ptr[i + 1] - ptr[i]);
         int t = rw > w ? rw - w : 0;
         if (cnt) cnt[i] = t;
         local += (unsigned long long)t;
@@ -164,16 +167,16 @@ void tail_count_kernel(long long n, const int *__restrict__ ptr, int w, int *cnt
     if (total && (threadIdx.x & 63) == 0 && local) atomicAdd(total, local);
 }
 
-template <typename V>
+template <typename V, typename P>
 __global__ __launch_bounds__(256)
 void hell_fill_kernel(long long n, long long pitch, int w,
-        const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
         int *__restrict__ ell_col, V *__restrict__ ell_val,
         const int *__restrict__ csr_ptr, int *__restrict__ csr_col, V *__restrict__ csr_val)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pitch;
          i += (long long)gridDim.x * blockDim.x) {
-        int b = 0, e = 0;
+        P b = 0, e = 0;
         if (i < n) { b = ptr[i]; e = ptr[i + 1]; }
         if (ell_col) {                       // NULL: only the CSR tail is wanted (SELL storage)
             int j = 0;
@@ -188,7 +191,7 @@ void hell_fill_kernel(long long n, long long pitch, int w,
         }
         if (csr_ptr && i < n) {
             int o = csr_ptr[i];
-            for (int q = b + w; q < e; ++q, ++o) { csr_col[o] = col[q]; csr_val[o] = val[q]; }
+            for (P q = b + w; q < e; ++q, ++o) { csr_col[o] = col[q]; csr_val[o] = val[q]; }
         }
     }
 }
@@ -202,8 +205,8 @@ inline int grid_for(int dev, int64_t n) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16));
 }
 
-template <typename V>
-int hell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val,
+template <typename V, typename P>
+int hell_fill(int dev, void *stream, int64_t n, const P *ptr, const int *col, const V *val,
         int64_t w, int64_t pitch, int *ell_col, V *ell_val, int *csr_ptr, int *csr_col, V *csr_val)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 0 && pitch >= n, "bad ELL geometry");
@@ -213,24 +216,73 @@ int hell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, 
     if (csr_ptr) {
         int *cnt = nullptr;
         VEXHIP_TRY(hipMalloc(&cnt, sizeof(int) * (size_t)n));
-        tail_count_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, ptr, (int)w, cnt, nullptr);
+        tail_count_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, ptr, (int)w, cnt, nullptr);
         int rc = scan_exclusive_i32_internal(dev, s, cnt, csr_ptr, n);
         if (rc) { (void)hipFree(cnt); return rc; }
         set_last_kernel<<<1, 1, 0, s>>>(csr_ptr, n, cnt);
-        hell_fill_kernel<V><<<grid_for(dev, pitch), 256, 0, s>>>(n, pitch, (int)w, ptr, col, val,
+        hell_fill_kernel<V, P><<<grid_for(dev, pitch), 256, 0, s>>>(n, pitch, (int)w, ptr, col, val,
                 ell_col, ell_val, csr_ptr, csr_col, csr_val);
         VEXHIP_LAUNCH_CHECK();
         VEXHIP_TRY(hipStreamSynchronize(s));
         VEXHIP_TRY(hipFree(cnt));
     } else {
-        hell_fill_kernel<V><<<grid_for(dev, pitch), 256, 0, s>>>(n, pitch, (int)w, ptr, col, val,
+        hell_fill_kernel<V, P><<<grid_for(dev, pitch), 256, 0, s>>>(n, pitch, (int)w, ptr, col, val,
                 ell_col, ell_val, nullptr, nullptr, nullptr);
         VEXHIP_LAUNCH_CHECK();
     }
     return 0;
 }
 
+template <typename P>
+int hell_analyze(int dev, void *stream, int64_t n, const P *ptr,
+        int64_t *ell_width, int64_t *tail_nnz)
+{
+    VEXHIP_REQUIRE(ell_width && tail_nnz, "NULL output");
+    *ell_width = 0; *tail_nnz = 0;
+    if (n <= 0) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const int cap = 4096;                      // widths above this share one bucket
+    unsigned long long *d = nullptr;           // [0] max (as int), [1] tail total, [2..] histogram
+    size_t bytes = sizeof(unsigned long long) * (size_t)(cap + 3);
+    VEXHIP_TRY(hipMalloc(&d, bytes));
+    VEXHIP_TRY(hipMemsetAsync(d, 0, bytes, s));
+    width_max_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, ptr, reinterpret_cast<int *>(d));
+    width_hist_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, ptr, cap, d + 2);
+    std::vector<unsigned long long> h(cap + 3);
+    VEXHIP_TRY(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    int64_t maxw = (int64_t)(int)(h[0] & 0xffffffffu);
+    // hybrid_ell.inl:103-110: smallest i with 3 * (#rows wider than i) < n
+    const double ell_vs_csr = 3.0;
+    int64_t w = maxw, rows = n;
+    for (int64_t i = 0; i < maxw && i <= cap; ++i) {
+        rows -= (int64_t)h[2 + i];
+        if (ell_vs_csr * (double)rows < (double)n) { w = i; break; }
+    }
+    if (w < maxw) {
+        tail_count_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, ptr, (int)w, nullptr, d + 1);
+        unsigned long long t = 0;
+        VEXHIP_TRY(hipMemcpyAsync(&t, d + 1, sizeof(t), hipMemcpyDeviceToHost, s));
+        VEXHIP_TRY(hipStreamSynchronize(s));
+        *tail_nnz = (int64_t)t;
+    }
+    VEXHIP_TRY(hipFree(d));
+    *ell_width = w;
+    return 0;
+}
+
+
 } // namespace
+
+// 64-bit row pointers: internal entry points for spmat.hip (the tail CSR keeps 32-bit pointers: it must stay below 2^31 entries)
+int hell_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, int64_t *ell_width, int64_t *tail_nnz)
+{ return hell_analyze<long long>(dev, stream, n, ptr, ell_width, tail_nnz); }
+int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, int32_t *csr_ptr, int32_t *csr_col, double *csr_val)
+{ return hell_fill<double, long long>(dev, stream, n, ptr, col, val, w, (n + 15) / 16 * 16, nullptr, nullptr, csr_ptr, csr_col, csr_val); }
+int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, int32_t *csr_ptr, int32_t *csr_col, float *csr_val)
+{ return hell_fill<float, long long>(dev, stream, n, ptr, col, val, w, (n + 15) / 16 * 16, nullptr, nullptr, csr_ptr, csr_col, csr_val); }
+
 } // namespace vexhip
 
 using namespace vexhip;
@@ -251,6 +303,19 @@ int vexhip_poisson3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t rb,
                    "Poisson problem too large for int32 indices");
     VEXHIP_SET_DEVICE(dev);
     poisson_kernel<double, false><<<grid_for(dev, re - rb + 1), 256, 0, as_stream(stream)>>>(n, rb, re, 0ull, ptr, col, val);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+/* the same strip with 64-bit row pointers: 2^31 entries and more (columns stay 32-bit: n^3 < 2^31) */
+int vexhip_poisson3d_strip_f64_p64(int dev, void *stream, int64_t n, int64_t rb, int64_t re,
+        int64_t *ptr, int32_t *col, double *val)
+{
+    VEXHIP_REQUIRE(n >= 1 && rb >= 0 && re >= rb && re <= n * n * n, "bad Poisson strip");
+    VEXHIP_REQUIRE(n * n * n < (1ll << 31), "Poisson problem too large for int32 column indices");
+    VEXHIP_SET_DEVICE(dev);
+    poisson_kernel<double, false, long long><<<grid_for(dev, re - rb + 1), 256, 0, as_stream(stream)>>>(n, rb, re, 0ull,
+            reinterpret_cast<long long *>(ptr), col, val);
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -310,52 +375,18 @@ int vexhip_fill_value(int dev, void *stream, int dtype, const void *v, void *out
 
 int vexhip_hell_analyze_i32(int dev, void *stream, int64_t n, const int32_t *ptr,
         int64_t *ell_width, int64_t *tail_nnz)
-{
-    VEXHIP_REQUIRE(ell_width && tail_nnz, "NULL output");
-    *ell_width = 0; *tail_nnz = 0;
-    if (n <= 0) return 0;
-    VEXHIP_SET_DEVICE(dev);
-    hipStream_t s = as_stream(stream);
-    const int cap = 4096;                      // widths above this share one bucket
-    unsigned long long *d = nullptr;           // [0] max (as int), [1] tail total, [2..] histogram
-    size_t bytes = sizeof(unsigned long long) * (size_t)(cap + 3);
-    VEXHIP_TRY(hipMalloc(&d, bytes));
-    VEXHIP_TRY(hipMemsetAsync(d, 0, bytes, s));
-    width_max_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, ptr, reinterpret_cast<int *>(d));
-    width_hist_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, ptr, cap, d + 2);
-    std::vector<unsigned long long> h(cap + 3);
-    VEXHIP_TRY(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, s));
-    VEXHIP_TRY(hipStreamSynchronize(s));
-    int64_t maxw = (int64_t)(int)(h[0] & 0xffffffffu);
-    // hybrid_ell.inl:103-110: smallest i with 3 * (#rows wider than i) < n
-    const double ell_vs_csr = 3.0;
-    int64_t w = maxw, rows = n;
-    for (int64_t i = 0; i < maxw && i <= cap; ++i) {
-        rows -= (int64_t)h[2 + i];
-        if (ell_vs_csr * (double)rows < (double)n) { w = i; break; }
-    }
-    if (w < maxw) {
-        tail_count_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, ptr, (int)w, nullptr, d + 1);
-        unsigned long long t = 0;
-        VEXHIP_TRY(hipMemcpyAsync(&t, d + 1, sizeof(t), hipMemcpyDeviceToHost, s));
-        VEXHIP_TRY(hipStreamSynchronize(s));
-        *tail_nnz = (int64_t)t;
-    }
-    VEXHIP_TRY(hipFree(d));
-    *ell_width = w;
-    return 0;
-}
+{ return hell_analyze<int32_t>(dev, stream, n, ptr, ell_width, tail_nnz); }
 
 int vexhip_hell_fill_f64_i32(int dev, void *stream, int64_t n,
         const int32_t *ptr, const int32_t *col, const double *val,
         int64_t w, int64_t pitch, int32_t *ell_col, double *ell_val,
         int32_t *csr_ptr, int32_t *csr_col, double *csr_val)
-{ return hell_fill<double>(dev, stream, n, ptr, col, val, w, pitch, ell_col, ell_val, csr_ptr, csr_col, csr_val); }
+{ return hell_fill<double, int32_t>(dev, stream, n, ptr, col, val, w, pitch, ell_col, ell_val, csr_ptr, csr_col, csr_val); }
 
 int vexhip_hell_fill_f32_i32(int dev, void *stream, int64_t n,
         const int32_t *ptr, const int32_t *col, const float *val,
         int64_t w, int64_t pitch, int32_t *ell_col, float *ell_val,
         int32_t *csr_ptr, int32_t *csr_col, float *csr_val)
-{ return hell_fill<float>(dev, stream, n, ptr, col, val, w, pitch, ell_col, ell_val, csr_ptr, csr_col, csr_val); }
+{ return hell_fill<float, int32_t>(dev, stream, n, ptr, col, val, w, pitch, ell_col, ell_val, csr_ptr, csr_col, csr_val); }
 
 } // extern "C"

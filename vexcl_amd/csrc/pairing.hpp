@@ -13,16 +13,18 @@
 
 namespace vexhip {
 
+// Entry offsets are 64-bit: a device may hold 2^31 entries or more (row pointers of type long long, round 3).
 struct pair_walk {
     const int *col;
     long long row;             // first row of the pair
-    int b[2], n[2];            // CSR begin and number of ELL entries (min(row length, w)) of the two rows
+    long long b[2];            // CSR begin of the two rows
+    int n[2];                  // number of ELL entries (min(row length, w)) of the two rows
     int p[2];                  // entries consumed so far
     bool aligned;
 
     __device__ __forceinline__ long long diag(int q, int k) const { return (long long)col[b[q] + k] - (row + q); }
 
-    __device__ void init(const int *col_, long long row_, int b0, int n0, int b1, int n1, int w) {
+    __device__ void init(const int *col_, long long row_, long long b0, int n0, long long b1, int n1, int w) {
         col = col_; row = row_; b[0] = b0; b[1] = b1; n[0] = n0; n[1] = n1;
         int pa = 0, pb = 0, merged = 0;
         while (pa < n0 || pb < n1) {
@@ -37,7 +39,7 @@ struct pair_walk {
     }
 
     /// Entries (offsets into the CSR arrays, -1 = none) that go to the next ELL column.
-    __device__ void next(int &e0, int &e1) {
+    __device__ void next(long long &e0, long long &e1) {
         e0 = e1 = -1;
         const bool h0 = p[0] < n[0], h1 = p[1] < n[1];
         if (!aligned) {
@@ -56,11 +58,12 @@ struct pair_walk {
 
 /// Largest column index among the first w entries of every row (atomicMax into *out, which starts at -1):
 /// x holds at least that many + 1 elements, so a 16-byte load that ends at x[max] stays inside x.
+template <typename P>
 static __global__ __launch_bounds__(256)
-void ell_max_col_kernel(long long n, int w, const int *__restrict__ ptr, const int *__restrict__ col, int *out) {
+void ell_max_col_kernel(long long n, int w, const P *__restrict__ ptr, const int *__restrict__ col, int *out) {
     int m = -1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int b = ptr[i], e = ptr[i + 1];
+        const P b = ptr[i], e = ptr[i + 1];
         for (int j = 0; j < w && b + j < e; ++j) { const int c = col[b + j]; m = c > m ? c : m; }
     }
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_down(m, o, 64); m = v > m ? v : m; }

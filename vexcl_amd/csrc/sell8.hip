@@ -136,8 +136,9 @@ __device__ __forceinline__ bool set_insert(int *set, int slots, int d, bool *is_
 }
 
 // gset: HASH_SLOTS ints (EMPTY-filled); info[0] = number of distinct diagonals, info[1] = overflow flag
+template <typename P>
 __global__ __launch_bounds__(256)
-void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const int *__restrict__ col,
+void delta_collect_kernel(long long n, int w, const P *__restrict__ ptr, const int *__restrict__ col,
         int *gset, int *info)
 {
     __shared__ int s_set[LOCAL_SLOTS];
@@ -149,7 +150,7 @@ void delta_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
     // sequence per insertion) -- s_over starts from the global flag, so later workgroups do not even begin
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         if (*(volatile int *)&s_over || *(volatile int *)&info[1]) break;
-        const int b = ptr[i], e = ptr[i + 1];
+        const P b = ptr[i], e = ptr[i + 1];
         int last = EMPTY;
         for (int j = 0; j < w && b + j < e; ++j) {
             long long dl = (long long)col[b + j] - i;
@@ -192,10 +193,10 @@ __device__ __forceinline__ unsigned pad_code(int partner_col, int partner_q, int
 
 // table: sorted diagonals (ndeltas valid entries); counts[256]: entries per code; info[1]: set if a diagonal is missing;
 // max_col: largest column index of the ELL part (ell_max_col_kernel)
-template <typename V>
+template <typename V, typename P>
 __global__ __launch_bounds__(256)
 void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
-        const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
         const int *__restrict__ table, const int *__restrict__ max_col_p, char *__restrict__ buf, unsigned long long *counts, int *info)
 {
     __shared__ int s_table[256];
@@ -213,16 +214,16 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
         char *slice = buf + s * slice_bytes(w, sizeof(V));
         unsigned *cw = reinterpret_cast<unsigned *>(slice) + t;
         V *vp = reinterpret_cast<V *>(slice + (long long)wp * 1024) + 2 * t;
-        int b[2] = {0, 0}, e[2] = {0, 0};
+        long long b[2] = {0, 0}, e[2] = {0, 0};
         const long long i = s * S8_ROWS + 2 * t;
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
         pair_walk pw;
-        pw.init(col, i, b[0], min(e[0] - b[0], w), b[1], min(e[1] - b[1], w), w);
+        pw.init(col, i, b[0], (int)min(e[0] - b[0], (long long)w), b[1], (int)min(e[1] - b[1], (long long)w), w);
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
-                int en[2] = {-1, -1};
+                long long en[2] = {-1, -1};
                 if (j < w) pw.next(en[0], en[1]);
                 for (int q = 0; q < 2; ++q) {
                     unsigned code;
@@ -695,9 +696,9 @@ __device__ __forceinline__ bool vset_insert(B *set, int slots, B v, bool *is_new
     return false;
 }
 
-template <typename V>
+template <typename V, typename P>
 __global__ __launch_bounds__(256)
-void value_collect_kernel(long long n, int w, const int *__restrict__ ptr, const V *__restrict__ val,
+void value_collect_kernel(long long n, int w, const P *__restrict__ ptr, const V *__restrict__ val,
         typename bits_of<V>::type *gset, int *info)
 {
     typedef typename bits_of<V>::type B;
@@ -712,7 +713,7 @@ void value_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
     // the 512^3 variable-coefficient matrix took 143 ms (profiles/r02_*cpp_kernel_stats.csv).
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         if (*(volatile int *)&s_over || *(volatile int *)&info[1]) break;
-        const int b = ptr[i], e = ptr[i + 1];
+        const P b = ptr[i], e = ptr[i + 1];
         B last = ~B(0);
         for (int j = 0; j < w && b + j < e; ++j) {
             B bits; V v = val[b + j];
@@ -737,10 +738,10 @@ void value_collect_kernel(long long n, int w, const int *__restrict__ ptr, const
 }
 
 // vtable: sorted value bit patterns (nvalues valid entries)
-template <typename V>
+template <typename V, typename P>
 __global__ __launch_bounds__(256)
 void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int nvalues,
-        const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
         const int *__restrict__ table, const V *__restrict__ vtable, const int *__restrict__ max_col_p,
         char *__restrict__ buf, unsigned long long *counts, int *info)
 {
@@ -760,16 +761,16 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
         const int t = (int)(pr % (S8_ROWS / 2));
         unsigned *cw = reinterpret_cast<unsigned *>(buf + s * ((long long)wp * 2048)) + t;
         unsigned *vw = cw + wp * 256;
-        int b[2] = {0, 0}, e[2] = {0, 0};
+        long long b[2] = {0, 0}, e[2] = {0, 0};
         const long long i = s * S8_ROWS + 2 * t;
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
         pair_walk pw;
-        pw.init(col, i, b[0], min(e[0] - b[0], w), b[1], min(e[1] - b[1], w), w);
+        pw.init(col, i, b[0], (int)min(e[0] - b[0], (long long)w), b[1], (int)min(e[1] - b[1], (long long)w), w);
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0, vword = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
-                int en[2] = {-1, -1};
+                long long en[2] = {-1, -1};
                 if (j < w) pw.next(en[0], en[1]);
                 for (int q = 0; q < 2; ++q) {
                     unsigned code, vcode = 255;                     // value code of padding: table entry 255 = 0.0
@@ -796,8 +797,9 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
 }
 
 // how many entries of the CSR matrix lie on each diagonal of the table (for the traversal heuristic)
+template <typename P>
 __global__ __launch_bounds__(256)
-void csr_delta_count_kernel(long long n, int w, int ndeltas, const int *__restrict__ ptr, const int *__restrict__ col,
+void csr_delta_count_kernel(long long n, int w, int ndeltas, const P *__restrict__ ptr, const int *__restrict__ col,
         const int *__restrict__ table, unsigned long long *counts)
 {
     __shared__ int s_table[256];
@@ -806,7 +808,7 @@ void csr_delta_count_kernel(long long n, int w, int ndeltas, const int *__restri
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int b = ptr[i], e = ptr[i + 1];
+        const P b = ptr[i], e = ptr[i + 1];
         for (int j = 0; j < w && b + j < e; ++j) {
             const int d = (int)((long long)col[b + j] - i);
             int lo = 0, hi = ndeltas;
@@ -869,8 +871,8 @@ void strip_traversal(int64_t n, const std::vector<int> &table, const std::vector
     if (out->grid_blocks >= (1ll << 31)) std::memset(out, 0, sizeof(*out));
 }
 
-template <typename V>
-int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w,
+template <typename V, typename P>
+int sell8_fill(int dev, void *stream, int64_t n, const P *ptr, const int *col, const V *val, int64_t w,
         const int *deltas, int ndeltas, void *buf, vexhip_traversal *trav)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 254, "bad SELL8 geometry");
@@ -885,8 +887,8 @@ int sell8_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col,
     int *dinfo = reinterpret_cast<int *>(dcounts + 256);                    // [0] unused, [1] error flag, [2] largest ELL column
     VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
     VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
-    ell_max_col_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
-    sell8_fill_kernel<V><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, ptr, col, val, deltas,
+    ell_max_col_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
+    sell8_fill_kernel<V, P><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, ptr, col, val, deltas,
             dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
@@ -933,8 +935,8 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     return 0;
 }
 
-template <typename V>
-int sell8v_analyze(int dev, void *stream, int64_t n, const int *ptr, const V *val, int64_t w, V *values, int *nvalues)
+template <typename V, typename P>
+int sell8v_analyze(int dev, void *stream, int64_t n, const P *ptr, const V *val, int64_t w, V *values, int *nvalues)
 {
     typedef typename bits_of<V>::type B;
     VEXHIP_REQUIRE(nvalues && values, "NULL output");
@@ -947,7 +949,7 @@ int sell8v_analyze(int dev, void *stream, int64_t n, const int *ptr, const V *va
     int *dinfo = reinterpret_cast<int *>(d + HASH_SLOTS);
     VEXHIP_TRY(hipMemsetAsync(d, 0xff, sizeof(B) * HASH_SLOTS, s));
     VEXHIP_TRY(hipMemsetAsync(dinfo, 0, 2 * sizeof(int), s));
-    value_collect_kernel<V><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, val, d, dinfo);
+    value_collect_kernel<V, P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, val, d, dinfo);
     std::vector<B> host(HASH_SLOTS);
     int hinfo[2] = {0, 0};
     VEXHIP_TRY(hipMemcpyAsync(host.data(), d, sizeof(B) * HASH_SLOTS, hipMemcpyDeviceToHost, s));
@@ -967,8 +969,8 @@ int sell8v_analyze(int dev, void *stream, int64_t n, const int *ptr, const V *va
     return 0;
 }
 
-template <typename V>
-int sell8v_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w,
+template <typename V, typename P>
+int sell8v_fill(int dev, void *stream, int64_t n, const P *ptr, const int *col, const V *val, int64_t w,
         const int *deltas, int ndeltas, const V *values, int nvalues, void *buf, vexhip_traversal *trav)
 {
     VEXHIP_REQUIRE(n >= 0 && w >= 1 && ndeltas >= 1 && ndeltas <= 254 && nvalues >= 1 && nvalues <= 255, "bad SELL8V geometry");
@@ -983,8 +985,8 @@ int sell8v_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col
     int *dinfo = reinterpret_cast<int *>(dcounts + 256);                    // [0] unused, [1] error flag, [2] largest ELL column
     VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
     VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
-    ell_max_col_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
-    sell8v_fill_kernel<V><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, nvalues, ptr, col, val, deltas, values,
+    ell_max_col_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
+    sell8v_fill_kernel<V, P><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, nvalues, ptr, col, val, deltas, values,
             dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
@@ -1147,18 +1149,8 @@ int slice_dictionary(int dev, void *stream, int64_t nslices, int64_t stride_byte
     return 0;
 }
 
-} // namespace
-} // namespace vexhip
-
-using namespace vexhip;
-
-extern "C" {
-
-int64_t vexhip_sell8_bytes(int64_t n, int64_t w, int value_bytes) {
-    return (n + S8_ROWS - 1) / S8_ROWS * slice_bytes(w, value_bytes);
-}
-
-int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
+template <typename P>
+int sell8_analyze(int dev, void *stream, int64_t n, const P *ptr, const int32_t *col,
         int64_t w, int32_t *deltas, int *ndeltas)
 {
     VEXHIP_REQUIRE(ndeltas && deltas, "NULL output");
@@ -1171,7 +1163,7 @@ int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *pt
     std::vector<int> host(HASH_SLOTS + 2, EMPTY);
     host[HASH_SLOTS] = 0; host[HASH_SLOTS + 1] = 0;
     VEXHIP_TRY(hipMemcpyAsync(d, host.data(), sizeof(int) * host.size(), hipMemcpyHostToDevice, s));
-    delta_collect_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, d, d + HASH_SLOTS);
+    delta_collect_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, d, d + HASH_SLOTS);
     VEXHIP_TRY(hipMemcpyAsync(host.data(), d, sizeof(int) * host.size(), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     VEXHIP_TRY(hipFree(d));
@@ -1188,21 +1180,59 @@ int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *pt
     return 0;
 }
 
+
+} // namespace
+
+// ---- 64-bit row pointers (a device may hold 2^31 entries or more; columns stay 32-bit): internal entry points used by
+//      spmat.hip -- vexhip_spmat_create_*_p64 is the C-ABI door (reference: size_t row pointers, vexcl/spmat.hpp:56-57)
+int sell8_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int64_t w, int32_t *deltas, int *ndeltas)
+{ return sell8_analyze<long long>(dev, stream, n, ptr, col, w, deltas, ndeltas); }
+int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const double *val, int64_t w, double *values, int *nvalues)
+{ return sell8v_analyze<double, long long>(dev, stream, n, ptr, val, w, values, nvalues); }
+int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const float *val, int64_t w, float *values, int *nvalues)
+{ return sell8v_analyze<float, long long>(dev, stream, n, ptr, val, w, values, nvalues); }
+int sell8v_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w,
+        const int32_t *deltas, int ndeltas, const double *values, int nvalues, void *buf, vexhip_traversal *trav)
+{ return sell8v_fill<double, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, trav); }
+int sell8v_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w,
+        const int32_t *deltas, int ndeltas, const float *values, int nvalues, void *buf, vexhip_traversal *trav)
+{ return sell8v_fill<float, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, trav); }
+int sell8_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w,
+        const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *trav)
+{ return sell8_fill<double, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, trav); }
+int sell8_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w,
+        const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *trav)
+{ return sell8_fill<float, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, trav); }
+
+} // namespace vexhip
+
+using namespace vexhip;
+
+extern "C" {
+
+int64_t vexhip_sell8_bytes(int64_t n, int64_t w, int value_bytes) {
+    return (n + S8_ROWS - 1) / S8_ROWS * slice_bytes(w, value_bytes);
+}
+
+int vexhip_sell8_analyze_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
+        int64_t w, int32_t *deltas, int *ndeltas)
+{ return sell8_analyze<int32_t>(dev, stream, n, ptr, col, w, deltas, ndeltas); }
+
 int vexhip_spmv_sell8_set_variant(int variant) { g_sell8_variant = variant; return 0; }
 
 int64_t vexhip_sell8v_bytes(int64_t n, int64_t w) { return (n + S8_ROWS - 1) / S8_ROWS * ((w + 1) / 2) * 2048; }
 
 int vexhip_sell8v_analyze_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const double *val, int64_t w, double *values, int *nvalues)
-{ return sell8v_analyze<double>(dev, stream, n, ptr, val, w, values, nvalues); }
+{ return sell8v_analyze<double, int32_t>(dev, stream, n, ptr, val, w, values, nvalues); }
 int vexhip_sell8v_analyze_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const float *val, int64_t w, float *values, int *nvalues)
-{ return sell8v_analyze<float>(dev, stream, n, ptr, val, w, values, nvalues); }
+{ return sell8v_analyze<float, int32_t>(dev, stream, n, ptr, val, w, values, nvalues); }
 
 int vexhip_sell8v_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val, int64_t w,
         const int32_t *deltas, int ndeltas, const double *values, int nvalues, void *buf, vexhip_traversal *traversal)
-{ return sell8v_fill<double>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, traversal); }
+{ return sell8v_fill<double, int32_t>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, traversal); }
 int vexhip_sell8v_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val, int64_t w,
         const int32_t *deltas, int ndeltas, const float *values, int nvalues, void *buf, vexhip_traversal *traversal)
-{ return sell8v_fill<float>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, traversal); }
+{ return sell8v_fill<float, int32_t>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues, buf, traversal); }
 
 int vexhip_spmv_sell8v_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *buf,
         const int32_t *deltas, const double *values, const int32_t *cp, const int32_t *cc, const double *cv,
@@ -1309,7 +1339,7 @@ int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *pt
         std::vector<int> table(nd);
         hipError_t e = hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256, s);
         if (e == hipSuccess) {
-            csr_delta_count_kernel<<<grid_for(dev, n), 256, 0, s>>>(n, w, nd, ptr, col, deltas, dcounts);
+            csr_delta_count_kernel<int32_t><<<grid_for(dev, n), 256, 0, s>>>(n, w, nd, ptr, col, deltas, dcounts);
             e = hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(table.data(), deltas, sizeof(int) * nd, hipMemcpyDeviceToHost, s);
@@ -1323,11 +1353,11 @@ int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *pt
 
 int vexhip_sell8_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *traversal)
-{ return sell8_fill<double>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, traversal); }
+{ return sell8_fill<double, int32_t>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, traversal); }
 
 int vexhip_sell8_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
         int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *traversal)
-{ return sell8_fill<float>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, traversal); }
+{ return sell8_fill<float, int32_t>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, traversal); }
 
 int vexhip_spmv_sell8_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w,
         const void *buf, const int32_t *deltas, const int32_t *cp, const int32_t *cc, const double *cv,

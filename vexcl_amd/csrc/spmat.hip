@@ -12,8 +12,26 @@
 
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 namespace vexhip {
+
+// 64-bit row pointers (sell8.hip, spmv.hip, misc.hip): set-up and the CSR product for matrices with 2^31 entries or more
+int hell_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, int64_t *ell_width, int64_t *tail_nnz);
+int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, int32_t *csr_ptr, int32_t *csr_col, double *csr_val);
+int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, int32_t *csr_ptr, int32_t *csr_col, float *csr_val);
+int sell8_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int64_t w, int32_t *deltas, int *ndeltas);
+int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const double *val, int64_t w, double *values, int *nvalues);
+int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const float *val, int64_t w, float *values, int *nvalues);
+int sell8v_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, const int32_t *deltas, int ndeltas, const double *values, int nvalues, void *buf, vexhip_traversal *trav);
+int sell8v_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, const int32_t *deltas, int ndeltas, const float *values, int nvalues, void *buf, vexhip_traversal *trav);
+int sell8_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *trav);
+int sell8_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *trav);
+int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, void *sell);
+int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, void *sell);
+int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y);
+int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y);
+
 namespace {
 
 struct spmat {
@@ -28,6 +46,7 @@ struct spmat {
     int32_t *deltas = nullptr; int ndeltas = -1;
     void *values = nullptr; int nvalues = -1;
     int32_t *csr_ptr = nullptr, *csr_col = nullptr; void *csr_val = nullptr;   // CSR tail, or the whole matrix (format CSR)
+    long long *csr_ptr64 = nullptr;        // format CSR built from 64-bit row pointers (csr_ptr is NULL then)
     bool owns_csr = false;
     vexhip_traversal trav = {0, 0, 0, 0, nullptr};
     vexhip_march march = {0, 0, 0, 0, 0, 0, {0, 0, 0}};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
@@ -49,6 +68,7 @@ void release(spmat *A) {
     if (A->values) (void)hipFree(A->values);
     if (A->owns_csr) {
         if (A->csr_ptr) (void)hipFree(A->csr_ptr);
+        if (A->csr_ptr64) (void)hipFree(A->csr_ptr64);       // (both only when owned: a borrowed CSR matrix keeps the caller's arrays)
         if (A->csr_col) (void)hipFree(A->csr_col);
         if (A->csr_val) (void)hipFree(A->csr_val);
     }
@@ -153,60 +173,89 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
     return rc;
 }
 
-template <typename V>
-int build(spmat *A, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const V *val, int format, int flags)
+// set-up steps by row-pointer type
+template <typename V> struct setup32 {
+    typedef api<V> F;
+    static int analyze(int d, void *s, int64_t n, const int32_t *p, int64_t *w, int64_t *t) { return vexhip_hell_analyze_i32(d, s, n, p, w, t); }
+    static int tail(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, int32_t *cp, int32_t *cc, V *cv) { return F::hell_fill(d, s, n, p, c, v, w, (n + 15) / 16 * 16, cp, cc, cv); }
+    static int d_analyze(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, int64_t w, int32_t *dl, int *nd) { return vexhip_sell8_analyze_i32(d, s, n, p, c, w, dl, nd); }
+    static int v_analyze(int d, void *s, int64_t n, const int32_t *p, const V *v, int64_t w, V *vals, int *nv) { return F::v_analyze(d, s, n, p, v, w, vals, nv); }
+    static int v_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, const V *vals, int nv, void *b, vexhip_traversal *t) { return F::v_fill(d, s, n, p, c, v, w, dl, nd, vals, nv, b, t); }
+    static int d_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, void *b, vexhip_traversal *t) { return F::d_fill(d, s, n, p, c, v, w, dl, nd, b, t); }
+    static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, void *b) { return F::s_fill(d, s, n, p, c, v, w, b); }
+};
+template <typename V> struct setup64 {
+    static int analyze(int d, void *s, int64_t n, const long long *p, int64_t *w, int64_t *t) { return hell_analyze_p64(d, s, n, p, w, t); }
+    static int tail(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, int32_t *cp, int32_t *cc, V *cv) { return hell_tail_p64(d, s, n, p, c, v, w, cp, cc, cv); }
+    static int d_analyze(int d, void *s, int64_t n, const long long *p, const int32_t *c, int64_t w, int32_t *dl, int *nd) { return sell8_analyze_p64(d, s, n, p, c, w, dl, nd); }
+    static int v_analyze(int d, void *s, int64_t n, const long long *p, const V *v, int64_t w, V *vals, int *nv) { return sell8v_analyze_p64(d, s, n, p, v, w, vals, nv); }
+    static int v_fill(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, const V *vals, int nv, void *b, vexhip_traversal *t) { return sell8v_fill_p64(d, s, n, p, c, v, w, dl, nd, vals, nv, b, t); }
+    static int d_fill(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, void *b, vexhip_traversal *t) { return sell8_fill_p64(d, s, n, p, c, v, w, dl, nd, b, t); }
+    static int s_fill(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, void *b) { return sell_fill_p64(d, s, n, p, c, v, w, b); }
+};
+
+// P = int32_t or long long (row pointers); columns are 32-bit either way
+template <typename V, typename P>
+int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, const V *val, int format, int flags)
 {
     typedef api<V> F;
+    typedef typename std::conditional<sizeof(P) == 4, setup32<V>, setup64<V>>::type S;
+    constexpr bool p64 = sizeof(P) == 8;
     const int dev = A->dev;
     A->n = n; A->value_type = F::type;
     if (n == 0) { A->format = VEXHIP_SPMAT_CSR; return 0; }
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
-    int32_t last = 0;
-    VEXHIP_TRY(hipMemcpyAsync(&last, ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    P last = 0;
+    VEXHIP_TRY(hipMemcpyAsync(&last, ptr + n, sizeof(P), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
-    A->nnz = last;
+    A->nnz = (int64_t)last;
 
     int64_t w = 0, tail = 0;
     if (format != VEXHIP_SPMAT_CSR && A->nnz > 0)
-        if (int rc = vexhip_hell_analyze_i32(dev, stream, n, ptr, &w, &tail)) return rc;
+        if (int rc = S::analyze(dev, stream, n, ptr, &w, &tail)) return rc;
     if (format == VEXHIP_SPMAT_CSR || w == 0) {
         // the CSR arrays as they are: borrowed (the caller keeps them alive) or copied
         A->format = VEXHIP_SPMAT_CSR;
+        P *own_ptr = nullptr;
         if (flags & VEXHIP_SPMAT_BORROW_CSR) {
-            A->csr_ptr = const_cast<int32_t *>(ptr); A->csr_col = const_cast<int32_t *>(col); A->csr_val = const_cast<V *>(val);
+            own_ptr = const_cast<P *>(ptr); A->csr_col = const_cast<int32_t *>(col); A->csr_val = const_cast<V *>(val);
         } else {
             A->owns_csr = true;
             V *cv = nullptr;
-            if (int rc = dmalloc(&A->csr_ptr, (size_t)n + 1)) return rc;
+            if (int rc = dmalloc(&own_ptr, (size_t)n + 1)) return rc;
+            if constexpr (p64) A->csr_ptr64 = own_ptr; else A->csr_ptr = own_ptr;      // owned from here on (release frees it)
             if (int rc = dmalloc(&A->csr_col, (size_t)A->nnz)) return rc;
             if (int rc = dmalloc(&cv, (size_t)A->nnz)) return rc;
             A->csr_val = cv;
-            VEXHIP_TRY(hipMemcpyAsync(A->csr_ptr, ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToDevice, s));
+            VEXHIP_TRY(hipMemcpyAsync(own_ptr, ptr, sizeof(P) * ((size_t)n + 1), hipMemcpyDeviceToDevice, s));
             if (A->nnz) {
                 VEXHIP_TRY(hipMemcpyAsync(A->csr_col, col, sizeof(int32_t) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
                 VEXHIP_TRY(hipMemcpyAsync(cv, val, sizeof(V) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
             }
         }
-        if (A->nnz) (void)vexhip_csr_traversal_i32(dev, stream, n, A->csr_ptr, A->csr_col, 256, &A->trav);   // strips for banded matrices
+        if constexpr (p64) A->csr_ptr64 = own_ptr; else A->csr_ptr = own_ptr;
+        if constexpr (!p64)
+            if (A->nnz) (void)vexhip_csr_traversal_i32(dev, stream, n, A->csr_ptr, A->csr_col, 256, &A->trav);   // strips for banded matrices
         VEXHIP_TRY(hipStreamSynchronize(s));
         return 0;
     }
 
     A->ell_w = w; A->tail = tail;
     if (tail) {      // rows wider than the ELL width keep their tail in CSR (hybrid_ell.inl:166-198)
+        VEXHIP_REQUIRE(tail < (1ll << 31), "the CSR tail of the hybrid-ELL storage holds 2^31 or more entries");
         A->owns_csr = true;
         V *cv = nullptr;
         if (int rc = dmalloc(&A->csr_ptr, (size_t)n + 1)) return rc;
         if (int rc = dmalloc(&A->csr_col, (size_t)tail)) return rc;
         if (int rc = dmalloc(&cv, (size_t)tail)) return rc;
         A->csr_val = cv;
-        if (int rc = F::hell_fill(dev, stream, n, ptr, col, val, w, (n + 15) / 16 * 16, A->csr_ptr, A->csr_col, cv)) return rc;
+        if (int rc = S::tail(dev, stream, n, ptr, col, val, w, A->csr_ptr, A->csr_col, cv)) return rc;
     }
     int nd = -1;
     if (format != VEXHIP_SPMAT_SELL) {
         if (int rc = dmalloc(&A->deltas, 256)) return rc;
-        if (int rc = vexhip_sell8_analyze_i32(dev, stream, n, ptr, col, w, A->deltas, &nd)) return rc;
+        if (int rc = S::d_analyze(dev, stream, n, ptr, col, w, A->deltas, &nd)) return rc;
     }
     if (nd > 0) {
         A->ndeltas = nd;
@@ -215,20 +264,20 @@ int build(spmat *A, void *stream, int64_t n, const int32_t *ptr, const int32_t *
             V *vals = nullptr;
             if (int rc = dmalloc(&vals, 256)) return rc;
             A->values = vals;
-            if (int rc = F::v_analyze(dev, stream, n, ptr, val, w, vals, &nv)) return rc;
+            if (int rc = S::v_analyze(dev, stream, n, ptr, val, w, vals, &nv)) return rc;
         }
         if (nv > 0) {
             A->nvalues = nv; A->format = VEXHIP_SPMAT_SELL8V;
             A->sell_bytes = vexhip_sell8v_bytes(n, w);
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
-            if (int rc = F::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
+            if (int rc = S::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
             if (int rc = make_dictionary(A, stream, flags, A->sell_bytes / ((n + 511) / 512), true)) return rc;
         } else {
             if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
             A->format = VEXHIP_SPMAT_SELL8;
             A->sell_bytes = vexhip_sell8_bytes(n, w, (int)sizeof(V));
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
-            if (int rc = F::d_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, A->sell, &A->trav)) return rc;
+            if (int rc = S::d_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, A->sell, &A->trav)) return rc;
             if (int rc = make_dictionary(A, stream, flags, ((w + 1) / 2) * 1024, false)) return rc;
         }
     } else {
@@ -236,15 +285,15 @@ int build(spmat *A, void *stream, int64_t n, const int32_t *ptr, const int32_t *
         A->format = VEXHIP_SPMAT_SELL;
         A->sell_bytes = vexhip_sell_bytes(n, w, (int)sizeof(V));
         VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
-        if (int rc = F::s_fill(dev, stream, n, ptr, col, val, w, A->sell)) return rc;
+        if (int rc = S::s_fill(dev, stream, n, ptr, col, val, w, A->sell)) return rc;
         if (int rc = vexhip_sell_order_i32(dev, stream, n, w, (int)sizeof(V), A->sell, 0, nullptr, 0, &A->trav)) return rc;
     }
     VEXHIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
-template <typename V>
-int create(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const V *val, int format, int flags, vexhip_spmat **out)
+template <typename V, typename P>
+int create(int dev, void *stream, int64_t n, const P *ptr, const int32_t *col, const V *val, int format, int flags, vexhip_spmat **out)
 {
     VEXHIP_REQUIRE(out, "NULL output");
     *out = nullptr;
@@ -253,7 +302,7 @@ int create(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *
     spmat *A = new (std::nothrow) spmat;
     VEXHIP_REQUIRE(A, "out of host memory");
     A->dev = dev;
-    if (int rc = build<V>(A, stream, n, ptr, col, val, format, flags)) { release(A); return rc; }
+    if (int rc = build<V, P>(A, stream, n, ptr, col, val, format, flags)) { release(A); return rc; }
     *out = reinterpret_cast<vexhip_spmat *>(A);
     return 0;
 }
@@ -277,7 +326,9 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
             if (A->blocks) return F::mul_dd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
             return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL:   return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
-        default:                  return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
+        default:
+            if (A->csr_ptr64) return spmv_csr_p64(A->dev, stream, A->n, alpha, append, A->csr_ptr64, A->csr_col, (const V *)A->csr_val, x, y);
+            return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
     }
 }
 
@@ -313,11 +364,19 @@ extern "C" {
 
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int format, int flags, vexhip_spmat **out)
-{ return create<double>(dev, stream, n, ptr, col, val, format, flags, out); }
+{ return create<double, int32_t>(dev, stream, n, ptr, col, val, format, flags, out); }
 
 int vexhip_spmat_create_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
         int format, int flags, vexhip_spmat **out)
-{ return create<float>(dev, stream, n, ptr, col, val, format, flags, out); }
+{ return create<float, int32_t>(dev, stream, n, ptr, col, val, format, flags, out); }
+
+int vexhip_spmat_create_f64_p64(int dev, void *stream, int64_t n, const int64_t *ptr, const int32_t *col, const double *val,
+        int format, int flags, vexhip_spmat **out)
+{ return create<double, long long>(dev, stream, n, reinterpret_cast<const long long *>(ptr), col, val, format, flags, out); }
+
+int vexhip_spmat_create_f32_p64(int dev, void *stream, int64_t n, const int64_t *ptr, const int32_t *col, const float *val,
+        int format, int flags, vexhip_spmat **out)
+{ return create<float, long long>(dev, stream, n, reinterpret_cast<const long long *>(ptr), col, val, format, flags, out); }
 
 int vexhip_spmat_destroy(vexhip_spmat *A) { release(reinterpret_cast<spmat *>(A)); return 0; }
 
@@ -351,7 +410,7 @@ int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
         const int64_t ns = (A->n + 511) / 512;
         m += A->dict_blocks * A->code_bytes + ns * 4 - (A->sell ? ns * A->code_bytes : 0);
     }
-    if (A->format == VEXHIP_SPMAT_CSR) m = A->nnz * (4 + vb) + (A->n + 1) * 4;
+    if (A->format == VEXHIP_SPMAT_CSR) m = A->nnz * (4 + vb) + (A->n + 1) * (A->csr_ptr64 ? 8 : 4);
     else if (A->tail) m += A->tail * (4 + vb) + (A->n + 1) * 4;
     o->matrix_bytes = m;
     return 0;

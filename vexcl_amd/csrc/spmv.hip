@@ -162,10 +162,10 @@ void csr_stream_kernel(long long n, long long nblocks, V alpha, int append,
 // (no change) and 3072 (4 per CU: 2.65 ms); a workgroup that owns G consecutive row blocks and keeps the next tile's
 // loads in flight while it folds the current one (G = 1 2.56, 2 2.58, 3 2.67, 4 2.69 ms: a workgroup's span of the
 // traversal grows with G and the x planes fall out of its XCD's L2).
-template <typename V, typename I, bool SWZ, int CSR2_TILE>
+template <typename V, typename I, bool SWZ, int CSR2_TILE, typename P = I>
 __global__ __launch_bounds__(CSR_BLOCK)
 void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
-        const I *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
+        const P *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
         const V *__restrict__ x, V *__restrict__ y, trav_dev trav)
 {
     constexpr int CSR2_GROUPS = (CSR2_TILE + 4 * CSR_BLOCK - 1) / (4 * CSR_BLOCK);
@@ -181,7 +181,7 @@ void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
     // masked block that ends in a full vmcnt(0) wait -- one more round trip before the tile loads can be issued)
     // -- and used only behind the barrier (the empty asm keeps the compiler from waiting for them any earlier)
     const long long my_row = t < rows_here ? r0 + t : r0 + rows_here - 1;
-    I raw_lo = ptr[my_row], raw_hi = ptr[my_row + 1];
+    P raw_lo = ptr[my_row], raw_hi = ptr[my_row + 1];
 
     V sum = 0;
     for (long long tb = base & ~3ll; tb < end; tb += CSR2_TILE) {
@@ -492,25 +492,25 @@ void sell_pair_kernel(long long n, long long nslices, V alpha, int append,
 
 // One lane per row PAIR: the entries of rows 2t and 2t+1 are aligned by diagonal (pairing.hpp); the empty half of
 // a column is -1 when the partner's 16-byte load stays inside x (max_col: largest column of the ELL part), else -2.
-template <typename V>
+template <typename V, typename P>
 __global__ __launch_bounds__(256)
 void sell_fill_kernel(long long n, long long nslices, int w,
-        const int *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
         const int *__restrict__ max_col_p, char *__restrict__ sell)
 {
     const int max_col = *max_col_p;
     for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (SELL_ROWS / 2);
          pr += (long long)gridDim.x * blockDim.x) {
         const long long i = 2 * pr;
-        int b[2] = {0, 0}, e[2] = {0, 0};
+        long long b[2] = {0, 0}, e[2] = {0, 0};
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
         char *slice = sell + (i / SELL_ROWS) * ((long long)w * SELL_ROWS * (4 + (long long)sizeof(V)));
         int *sc = reinterpret_cast<int *>(slice) + (i % SELL_ROWS);
         V *sv = reinterpret_cast<V *>(slice + (long long)w * SELL_ROWS * 4) + (i % SELL_ROWS);
         pair_walk pw;
-        pw.init(col, i, b[0], min(e[0] - b[0], w), b[1], min(e[1] - b[1], w), w);
+        pw.init(col, i, b[0], (int)min(e[0] - b[0], (long long)w), b[1], (int)min(e[1] - b[1], (long long)w), w);
         for (int j = 0; j < w; ++j) {
-            int en[2];
+            long long en[2];
             pw.next(en[0], en[1]);
             for (int q = 0; q < 2; ++q) {
                 int c; V v = V(0);
@@ -701,8 +701,8 @@ int spmv_sell(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     return 0;
 }
 
-template <typename V>
-int sell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, const V *val, int64_t w, void *sell) {
+template <typename V, typename P>
+int sell_fill(int dev, void *stream, int64_t n, const P *ptr, const int *col, const V *val, int64_t w, void *sell) {
     VEXHIP_REQUIRE(n >= 0 && w >= 1, "bad SELL geometry");
     if (n == 0) return 0;
     VEXHIP_SET_DEVICE(dev);
@@ -712,9 +712,9 @@ int sell_fill(int dev, void *stream, int64_t n, const int *ptr, const int *col, 
     VEXHIP_TRY(hipMalloc(&max_col, sizeof(int)));
     hipError_t e = hipMemsetAsync(max_col, 0xff, sizeof(int), as_stream(stream));
     if (e == hipSuccess) {
-        ell_max_col_kernel<<<std::max(1, (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16)), 256, 0, as_stream(stream)>>>(
+        ell_max_col_kernel<P><<<std::max(1, (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16)), 256, 0, as_stream(stream)>>>(
                 n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, max_col);
-        sell_fill_kernel<V><<<std::max(1, grid), 256, 0, as_stream(stream)>>>(n, ns, (int)w, ptr, col, val, max_col, static_cast<char *>(sell));
+        sell_fill_kernel<V, P><<<std::max(1, grid), 256, 0, as_stream(stream)>>>(n, ns, (int)w, ptr, col, val, max_col, static_cast<char *>(sell));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
@@ -744,6 +744,32 @@ void ell_offset_agree_kernel(long long n, int w, long long pitch, const int *__r
 }
 
 } // namespace
+
+// ---- 64-bit row pointers with 32-bit columns (round 3): internal entry points for spmat.hip ---------------------------
+int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, void *sell)
+{ return sell_fill<double, long long>(dev, stream, n, ptr, col, val, w, sell); }
+int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, void *sell)
+{ return sell_fill<float, long long>(dev, stream, n, ptr, col, val, w, sell); }
+
+// the CSR arrays themselves: the staged kernel with the row bounds read as 64-bit values
+template <typename V>
+int spmv_csr_p64_impl(int dev, void *stream, int64_t n, V alpha, int append, const long long *ptr, const int32_t *col, const V *val, const V *x, V *y) {
+    VEXHIP_REQUIRE(n >= 0, "negative row count");
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(ptr && x && y && aligned16(col) && aligned16(val), "CSR arrays must be 16-byte aligned");
+    VEXHIP_SET_DEVICE(dev);
+    const long long nb = (n + CSR_BLOCK - 1) / CSR_BLOCK;
+    VEXHIP_REQUIRE(nb < (1ll << 31), "matrix too large for one launch");
+    trav_dev order = {nullptr, 0, 0, 0};
+    csr_stream2_kernel<V, int, false, 2048, long long><<<(unsigned)nb, CSR_BLOCK, 0, as_stream(stream)>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y)
+{ return spmv_csr_p64_impl<double>(dev, stream, n, alpha, append, ptr, col, val, x, y); }
+int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y)
+{ return spmv_csr_p64_impl<float>(dev, stream, n, alpha, append, ptr, col, val, x, y); }
+
 } // namespace vexhip
 
 using namespace vexhip;
@@ -916,11 +942,11 @@ int64_t vexhip_sell_bytes(int64_t n, int64_t w, int value_bytes) { return (n + S
 
 int vexhip_sell_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int64_t w, void *sell)
-{ return sell_fill<double>(dev, stream, n, ptr, col, val, w, sell); }
+{ return sell_fill<double, int32_t>(dev, stream, n, ptr, col, val, w, sell); }
 
 int vexhip_sell_fill_f32_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val,
         int64_t w, void *sell)
-{ return sell_fill<float>(dev, stream, n, ptr, col, val, w, sell); }
+{ return sell_fill<float, int32_t>(dev, stream, n, ptr, col, val, w, sell); }
 
 int vexhip_spmv_sell_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w,
         const void *sc, const int32_t *cp, const int32_t *cc, const double *cv,

@@ -124,18 +124,21 @@ def gather(idx, src, dst=None):
     return dst
 
 
-def poisson3d(n, device="cuda", rows=None):
+def poisson3d(n, device="cuda", rows=None, ptr64=None):
     """3-D Poisson matrix of examples/benchmark.cpp:364-415, built in HBM.
-    rows=(r0, r1): only that row strip (global column ids, strip-local ptr)."""
+    rows=(r0, r1): only that row strip (global column ids, strip-local ptr).
+    ptr64: row pointers as int64 (default: when the strip holds 2^31 entries or more); columns are int32."""
     L = lib()
     dev = torch.device(device)
     N = n ** 3
     r0, r1 = (0, N) if rows is None else rows
     nnz = L.poisson3d_strip_nnz(n, r0, r1)
-    ptr = torch.empty(r1 - r0 + 1, dtype=torch.int32, device=dev)
+    if ptr64 is None:
+        ptr64 = nnz >= 2 ** 31
+    ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64 if ptr64 else torch.int32, device=dev)
     col = torch.empty(nnz, dtype=torch.int32, device=dev)
     val = torch.empty(nnz, dtype=torch.float64, device=dev)
-    L.poisson3d_strip_f64_i32(_dev(ptr), _stream(ptr), n, r0, r1, _p(ptr), _p(col), _p(val))
+    (L.poisson3d_strip_f64_p64 if ptr64 else L.poisson3d_strip_f64_i32)(_dev(ptr), _stream(ptr), n, r0, r1, _p(ptr), _p(col), _p(val))
     return ptr, col, val
 
 
@@ -359,7 +362,8 @@ class SpMat:
         self.ptr, self.col, self.val = ptr, col, val
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
-        i32 = ptr.dtype == torch.int32 and col.dtype == torch.int32
+        p64 = ptr.dtype == torch.int64 and col.dtype == torch.int32       # 64-bit row pointers, 32-bit columns (round 3)
+        i32 = (ptr.dtype == torch.int32 and col.dtype == torch.int32) or p64
         if fmt == "auto":
             fmt = "sell" if i32 else "csr"
         if fmt not in ("sell", "sell8", "sell32", "hell", "csr"):
@@ -379,7 +383,9 @@ class SpMat:
         L = lib()
         f64 = val.dtype == torch.float64
         h = ctypes.c_void_p()
-        (L.spmat_create_f64_i32 if f64 else L.spmat_create_f32_i32)(
+        create = ((L.spmat_create_f64_p64 if f64 else L.spmat_create_f32_p64) if p64 else
+                  (L.spmat_create_f64_i32 if f64 else L.spmat_create_f32_i32))
+        create(
             _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
             _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH), ctypes.byref(h))
         self.handle = h
