@@ -602,7 +602,7 @@ int vexhip_poisson3d_csr_f64_i32(int dev, void *stream, int64_t n, int32_t *ptr,
 int vexhip_poisson3d_strip_f64_i32(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end,
         int32_t *ptr, int32_t *col, double *val);
 int64_t vexhip_poisson3d_strip_nnz(int64_t n, int64_t row_begin, int64_t row_end);
-/* the same strip with 64-bit row pointers: grids with 2^31 entries and more (700^3: 2.39e9); columns stay 32-bit */
+/* the same strip with 64-bit row pointers: grids with 2^31 entries and more (700^3: 2.38e9); columns stay 32-bit */
 int vexhip_poisson3d_strip_f64_p64(int dev, void *stream, int64_t n, int64_t row_begin, int64_t row_end,
         int64_t *ptr, int32_t *col, double *val);
 /* The same 7-point pattern with a different coefficient on every face: -div(k grad u), k = 0.5 + u(hash(seed, face)),
