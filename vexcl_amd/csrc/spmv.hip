@@ -261,16 +261,16 @@ void csr_rows_kernel(long long nr, V alpha, const int *__restrict__ rows, const 
 
 // Fallback for CSR arrays that are not 16-byte aligned (sub-views): the
 // reference's one-row-per-work-item loop, unchanged.
-template <typename V, typename I>
+template <typename V, typename I, typename P = I>
 __global__ __launch_bounds__(256)
 void csr_scalar_kernel(long long n, V alpha, int append,
-        const I *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
+        const P *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
         const V *__restrict__ x, V *__restrict__ y)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         V sum = 0;
-        for (I j = ptr[i], e = ptr[i + 1]; j < e; ++j) sum += val[j] * x[col[j]];
+        for (P j = ptr[i], e = ptr[i + 1]; j < e; ++j) sum += val[j] * x[col[j]];
         V r = alpha * sum;
         if (append) r = y[i] + r;
         y[i] = r;
@@ -751,17 +751,18 @@ int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const 
 int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, void *sell)
 { return sell_fill<float, long long>(dev, stream, n, ptr, col, val, w, sell); }
 
-// the CSR arrays themselves: the staged kernel with the row bounds read as 64-bit values
+// The CSR arrays themselves with 64-bit row pointers: the reference's one-row-per-work-item loop (spmat/csr.inl:153-171).
+// The staged kernel above, instantiated with 64-bit row bounds, gave correct results but took 120 s at 700^3 and faulted on
+// a small matrix whose pointer VALUES crossed 2^31 (tools/r03_p64_debug.py) -- not understood (its machine code keeps every
+// entry offset in 64 bits); the plain loop is what a matrix kept in CSR with 2^31 entries or more runs until it is.
 template <typename V>
 int spmv_csr_p64_impl(int dev, void *stream, int64_t n, V alpha, int append, const long long *ptr, const int32_t *col, const V *val, const V *x, V *y) {
     VEXHIP_REQUIRE(n >= 0, "negative row count");
     if (n == 0) return 0;
-    VEXHIP_REQUIRE(ptr && x && y && aligned16(col) && aligned16(val), "CSR arrays must be 16-byte aligned");
+    VEXHIP_REQUIRE(ptr && x && y, "NULL argument");
     VEXHIP_SET_DEVICE(dev);
-    const long long nb = (n + CSR_BLOCK - 1) / CSR_BLOCK;
-    VEXHIP_REQUIRE(nb < (1ll << 31), "matrix too large for one launch");
-    trav_dev order = {nullptr, 0, 0, 0};
-    csr_stream2_kernel<V, int, false, 2048, long long><<<(unsigned)nb, CSR_BLOCK, 0, as_stream(stream)>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 32);
+    csr_scalar_kernel<V, int, long long><<<grid, 256, 0, as_stream(stream)>>>(n, alpha, append, ptr, col, val, x, y);
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
