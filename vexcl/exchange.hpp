@@ -10,7 +10,9 @@
 // VEXCL_EXCHANGE=peer asks for it.  No host hop, no finish(); the local product overlaps the exchange.
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 #include "backend.hpp"
 #include "util.hpp"
@@ -18,18 +20,31 @@
 namespace vex {
 namespace detail {
 
-/// One communicator per device list (shared by matrices, reductors and scans of the same context).
+/// ONE communicator per (device list, transport), shared by every matrix, reductor and scan that works on those devices
+/// (round 3: each SpMat / sparse::distributed / Reductor used to call ncclCommInitAll for itself -- seconds of set-up per
+/// level of an AMG hierarchy, and several RCCL communicators driven from different streams on the same GPUs, which NCCL
+/// documents as a deadlock hazard; with a single communicator its operations serialise in issue order).  The cache
+/// holds weak references: the communicator goes away with its last user.
 inline std::shared_ptr<vexhip_comm> make_comm(const std::vector<backend::command_queue> &q) {
-    std::vector<int> devs;
-    for (const auto &qq : q) devs.push_back(qq.device_ordinal());
+    std::vector<int> key;
+    for (const auto &qq : q) key.push_back(qq.device_ordinal());
     int transport = VEXHIP_COMM_AUTO;
     if (const char *e = std::getenv("VEXCL_EXCHANGE")) {
         if (!std::strcmp(e, "peer")) transport = VEXHIP_COMM_PEER;
         else if (!std::strcmp(e, "rccl")) transport = VEXHIP_COMM_RCCL;
     }
+    const int ndev = static_cast<int>(key.size());
+    key.push_back(transport);
+    static std::mutex mx;
+    static std::map<std::vector<int>, std::weak_ptr<vexhip_comm>> cache;
+    std::lock_guard<std::mutex> lock(mx);
+    auto it = cache.find(key);
+    if (it != cache.end()) if (auto live = it->second.lock()) return live;
     vexhip_comm *c = nullptr;
-    backend::check(vexhip_comm_init(static_cast<int>(devs.size()), devs.data(), transport, &c));
-    return std::shared_ptr<vexhip_comm>(c, [](vexhip_comm *p) { vexhip_comm_destroy(p); });
+    backend::check(vexhip_comm_init(ndev, key.data(), transport, &c));
+    std::shared_ptr<vexhip_comm> made(c, [](vexhip_comm *p) { vexhip_comm_destroy(p); });
+    cache[key] = made;
+    return made;
 }
 
 template <class T>

@@ -46,7 +46,11 @@ struct SpMatCCSR {
         entries = col32.size();
         far_offset = 0;
         for (int c : col32) far_offset = std::max<long long>(far_offset, c < 0 ? -(long long)c : (long long)c);
-        build_fast();
+        // entries of the expanded operator, in 64 bits (the device-side expansion scans 32-bit row lengths)
+        expanded = 0;
+        for (size_t i = 0; i < n; ++i) expanded += (unsigned long long)(row32[idx32[i] + 1] - row32[idx32[i]]);
+        try { build_fast(); }
+        catch (const backend::error &) { fast.reset(); }     // out of memory, ...: the CCSR kernel needs none of it
     }
 
     size_t rows() const { return n; }
@@ -67,7 +71,15 @@ struct SpMatCCSR {
     void build_fast() {
         if (!(std::is_same<val_t, double>::value || std::is_same<val_t, float>::value)) return;
         if (n < 32768 || entries == 0 || std::getenv("VEXCL_CCSR_KERNEL")) return;
+        // The expansion is a transient CSR matrix (12 or 8 bytes per entry + the row pointers) next to the storage built from
+        // it: an operator whose CSR form has 2^31 entries or more, or does not fit in what is free now (with a margin
+        // for the SELL storage), simply keeps the CCSR kernel -- being compact is the point of this class.
+        if (expanded == 0 || expanded >= (1ull << 31)) return;
         const int dev = queue.device_ordinal();
+        uint64_t free_b = 0, total_b = 0;
+        backend::check(vexhip_mem_info(dev, &free_b, &total_b));
+        const unsigned long long need = expanded * (4 + sizeof(val_t)) + (n + 1) * 4ull + expanded * (1 + sizeof(val_t)) + (64ull << 20);
+        if (need > free_b) return;
         backend::device_vector<int> ptr(queue, n + 1);
         int64_t nnz = 0;
         backend::check(to_csr(dev, queue.raw(), (int64_t)n, idx.raw(), row.raw(), col.raw(), val.raw(), ptr.raw(), nullptr, nullptr, &nnz));
@@ -105,6 +117,7 @@ struct SpMatCCSR {
         return vexhip_spmv_ccsr_f32(dev, s, n, a, app, idx, m, row, col, val, e, far, x, y); }
 
     size_t entries = 0;
+    unsigned long long expanded = 0;             // entries of the operator written out as CSR
     long long far_offset = 0;
     std::shared_ptr<vexhip_spmat> fast;           // the same operator as a vexhip_spmat (build_fast); copies of *this share it
 

@@ -85,6 +85,10 @@ struct comm {
     // devices share one GPU (the reference's own test fixture, tests/context_setup.hpp:24-39; RCCL refuses that)
     bool peer = false;
     std::vector<hipEvent_t> ready, done;
+    // One communicator is shared by every object that works on its device list (vexcl/exchange.hpp make_comm): calls from
+    // different host threads are serialised, so that the record / wait pairs of one exchange (PEER) and the operations of
+    // one RCCL group are never interleaved with another call's.
+    std::mutex mx;
 };
 
 bool distinct(const std::vector<int> &v) {
@@ -513,6 +517,7 @@ int vexhip_halo_exchange(vexhip_comm *h, int dtype, const void *const *send_bufs
 {
     comm *c = reinterpret_cast<comm *>(h);
     VEXHIP_REQUIRE(c && send_bufs && send_counts && recv_bufs && recv_counts && streams, "NULL argument");
+    std::lock_guard<std::mutex> serialise(c->mx);
     if (c->peer) return peer_exchange(c, dtype, send_bufs, send_counts, recv_bufs, recv_counts, streams);
     RCCL_READY();
     NCCL_TRY(rccl().GroupStart());
@@ -530,6 +535,7 @@ int vexhip_halo_exchange(vexhip_comm *h, int dtype, const void *const *send_bufs
 int vexhip_allreduce_scalar(vexhip_comm *h, int op, int dtype, void *const *bufs, int64_t count, void *const *streams) {
     comm *c = reinterpret_cast<comm *>(h);
     VEXHIP_REQUIRE(c && bufs && streams && count >= 1, "bad argument");
+    std::lock_guard<std::mutex> serialise(c->mx);
     VEXHIP_REQUIRE(op == VEXHIP_SUM || op == VEXHIP_SUM_KAHAN || op == VEXHIP_MIN || op == VEXHIP_MAX, "unsupported reduction for the all-reduce");
     if (c->peer) {
         // one process sees every device: read the D partial results, fold on the host in device order (what the reference
@@ -576,6 +582,7 @@ int vexhip_allreduce_scalar(vexhip_comm *h, int op, int dtype, void *const *bufs
 int vexhip_allgather(vexhip_comm *h, int dtype, const void *const *send, void *const *recv, int64_t count, void *const *streams) {
     comm *c = reinterpret_cast<comm *>(h);
     VEXHIP_REQUIRE(c && send && recv && streams && count >= 0, "bad argument");
+    std::lock_guard<std::mutex> serialise(c->mx);
     if (count == 0) return 0;
     if (c->peer) {
         const size_t nd = c->devs.size(), b = type_bytes(dtype);

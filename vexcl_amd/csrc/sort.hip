@@ -12,6 +12,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 
 namespace vexhip {
 
@@ -193,6 +194,15 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
                 r = valid ? atomicAdd(&L.hist[wave][d], 1u) : 0u;
             }
             rd[k] = valid ? (r | (d << 16)) : ~0u;
+            // Tripwire (round 3): two NEIGHBOURING lanes with the same digit must have received consecutive ranks.  Lane order
+            // of same-address LDS atomics is what the hardware does, not what the ISA promises; the once-per-device self-test
+            // samples it under its own conditions.  Should a part ever serve the lanes differently, a sort must fail loudly
+            // (the trap surfaces as an error at the next synchronisation) and not return a silently unstable pass.  Costs
+            // one DPP move and three ALU operations per key; ~1/256 of all neighbour pairs are checked with random digits.
+            {
+                const unsigned left = (unsigned)__builtin_amdgcn_update_dpp((int)~0u, (int)rd[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                if (valid && left != ~0u && (left >> 16) == d && ((left + 1u) & 0xffffu) != (r & 0xffffu)) __builtin_trap();
+            }
         } else {
         // m = the real (non-padding) lanes of this wave holding the same digit.  Every lane ORs
         // its bit into the wave's mask word of its digit in LDS and reads the word back (three LDS
@@ -388,9 +398,9 @@ void lds_atomic_order_kernel(unsigned seed, int rounds, unsigned *violations) {
 int g_sort_rank = -1;               // -1: decide by the self-test; 0: match words; 1: atomic ranks (A/B)
 
 int atomic_rank_ok(int dev, hipStream_t s, bool *ok) {
-    static int verdict[64];          // 0 unknown, 1 in order, 2 not
+    static std::atomic<int> verdict[64];          // 0 unknown, 1 in order, 2 not (two threads may both run the test: same answer)
     if (dev < 0 || dev >= 64) { *ok = false; return 0; }
-    if (!verdict[dev]) {
+    if (!verdict[dev].load()) {
         unsigned *d = nullptr, h = 1;
         VEXHIP_TRY(hipMalloc(&d, sizeof(unsigned)));
         hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned), s);
@@ -399,9 +409,9 @@ int atomic_rank_ok(int dev, hipStream_t s, bool *ok) {
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         (void)hipFree(d);
         VEXHIP_TRY(e);
-        verdict[dev] = h == 0 ? 1 : 2;
+        verdict[dev].store(h == 0 ? 1 : 2);
     }
-    *ok = verdict[dev] == 1;
+    *ok = verdict[dev].load() == 1;
     return 0;
 }
 
