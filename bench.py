@@ -2,14 +2,17 @@
 """bench.py -- BASELINE.json's metric: fp64 CSR SpMV GFLOP/s + achieved HBM GB/s
 on the 3-D Poisson matrix (examples/benchmark.cpp:353-477), 512^3 grid.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its N ranks itself,
+                                                            and refuses when the box has fewer GPUs than ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one product y = A*x through vex::SpMat's path: the C-ABI object `vexhip_spmat`
 (include/vexhip.h) that both front ends -- the C++ headers (vexcl/spmat.hpp) and the Python
 mirror used here (vexcl_amd/ops.py) -- create and apply.  The matrix is built directly in HBM
 (SURVEY 8(d)); inputs are resident before the timed region.  N > 1: the SAME 512^3 problem
-row-partitioned over the ranks (strong scaling), ghost planes exchanged over RCCL.
+row-partitioned over the ranks (strong scaling); the ghost planes travel by the fastest transport that reproduces an
+evaluation of the stencil that involves no matrix and no transport (RCCL send/recv issued from C++, peer-mapped ghost
+windows, or torch.distributed requests; `distributed.transports_tried`).
 
 What the line reports, and how to read it:
   value / hbm_gbps    2*nnz / t and CSR-ALGORITHMIC bytes / t (nnz*12 + (N+1)*4 + 16*N):
@@ -22,7 +25,9 @@ What the line reports, and how to read it:
                       with the CSR-algorithmic bytes: SELL-512 with 32-bit columns and the CSR arrays themselves.
   variable_coefficient  the same 7-point pattern with a coefficient per face (~4 N distinct values: no value coding
                       applies) through the default SpMat: the general-matrix figure.
-  checksum            sum(y) asserted against an independent evaluation of the stencil (torch slicing, no matrix).
+  checksum            sum(y) asserted against an independent evaluation of the stencil (torch slicing, no matrix); for N > 1 every
+                      rank checks its rows against x regenerated from the global index (no transport involved).
+  setup               what building the storage from CSR arrays in HBM costs (ms, bytes, products to amortise it).
 """
 import argparse
 import json
@@ -35,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
-KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true, false>", "sell8": "sell8_pair_kernel<double, 7, false, false>",
+KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true, false>", "sell8v_march": "sell8_march_kernel<double, 7>", "sell8": "sell8_pair_kernel<double, 7, false, false>",
              "sell32": "sell_pair_kernel<double, 7>", "csr": "csr_stream2_kernel<double, int, false>", "hell": "hell_kernel"}
 
 
@@ -189,7 +194,7 @@ def measure_traffic(grid, timeout=240):
                         continue
                     name = r["Kernel_Name"]
                     key = None
-                    for k in ("sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
+                    for k in ("sell8_march_kernel", "sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
                         if k in name:
                             key = k
                             if k == "sell8_pair_kernel":
@@ -295,6 +300,7 @@ def main():
                          "(hipIpcGetMemHandle); torch = torch.distributed requests; auto = every one that validates, fastest wins")
     ap.add_argument("--trial-steps", type=int, default=100, help="N > 1, --transport auto: products timed per candidate transport")
     ap.add_argument("--no-dictionary", action="store_true", help="value-coded storage with one code block per slice (no slice dictionary)")
+    ap.add_argument("--no-march", action="store_true", help="keep the pair product where the march product (x window in an LDS ring, round 3) would apply")
     ap.add_argument("--no-sustained", action="store_true", help="skip the ~3 s back-to-back run of the product after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic = null)")
     args = ap.parse_args()
@@ -344,11 +350,26 @@ def main():
     x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev),
                       (42 + r0 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
     y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
+    setup = None
+    march = None
     if single:
-        A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary)
+        # set-up is timed (not part of `value`): CSR arrays in HBM -> the storage the product runs on.  A solver that rebuilds
+        # its matrices (AMG set-up, a nonlinear iteration) pays this once per matrix.
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        ts0 = time.perf_counter()
+        A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary, march=not args.no_march)
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - ts0) * 1e3
         storage = A.storage
         matrix_bytes = A.matrix_bytes()
         dict_blocks = A.dictionary_blocks
+        march = A.march
+        setup = {"setup_ms": round(setup_ms, 3),
+                 "what": "vexhip_spmat_create on CSR arrays resident in HBM: hybrid-ELL analysis, diagonal / value tables, fill, slice dictionary, march plan (host wall time, synchronised)",
+                 "csr_input_bytes": int(ptr.numel() * ptr.element_size() + col.numel() * col.element_size() + val.numel() * val.element_size()),
+                 "stored_bytes": int(matrix_bytes),
+                 "held_after_setup_bytes": int(free0 - torch.cuda.mem_get_info(dev)[0])}
         if storage not in ("csr",):
             del ptr, col, val                    # the product only needs the converted storage
             A.ptr = A.col = A.val = None
@@ -358,6 +379,7 @@ def main():
         storage = A.loc.storage
         matrix_bytes = A.loc.matrix_bytes()
         dict_blocks = getattr(A.loc, "dictionary_blocks", 0)
+        march = getattr(A.loc, "march", None)
         step = lambda: A.apply(x, y, 1.0, False)
 
         # ---- every transport is validated against an evaluation that trusts NO transport: x is a hash of the global index,
@@ -566,6 +588,8 @@ def main():
                      "gflops": round(2.0 * nnz_total / (ms2.value / nsoak) / 1e6, 1),
                      "what": "the same product launched back to back after the timed region (HIP events on the launch stream)"}
 
+    if setup is not None:
+        setup["products_to_amortise"] = round(setup["setup_ms"] / (per_step * 1e3), 1)
     if rank == 0:
         nnz_rank = L.poisson3d_strip_nnz(n, r0, r1)
         rows_rank = r1 - r0
@@ -597,7 +621,9 @@ def main():
                        "format": storage, "rows_per_gpu": rows_rank,
                        "parallelism": "row-partitioned x%d" % world},
             "roofline": {"bound": "hbm",
-                         "kernel": ("sell8_pair_kernel<double, 7, true, true>" if (storage == "sell8v" and dict_blocks) else KERNEL_OF.get(storage, storage)),
+                         "kernel": (KERNEL_OF["sell8v_march"] if (storage == "sell8v" and march) else
+                                    "sell8_pair_kernel<double, 7, true, true>" if (storage == "sell8v" and dict_blocks) else KERNEL_OF.get(storage, storage)),
+                         "march": march,
                          "achieved": round(moved_rank / kern_s / 1e9, 1),
                          "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s",
@@ -611,7 +637,18 @@ def main():
                          "traffic": None,
                          "avg_launch_ms": round(kern_s * 1e3, 5)},
         }
-        if storage == "sell8v" and dict_blocks:
+        if setup is not None:
+            out["setup"] = setup
+        if storage == "sell8v" and dict_blocks and march:
+            # the march product: the near diagonals' window of x comes once per slice (8 B/row + the overlap of a run's first
+            # window), the two far diagonals are gathered (16 B/row), y is stored (8 B/row); codes are decoded once per run
+            l1_bytes = (8 + 16 + 8) * rows_rank
+            out["roofline"]["on_chip"] = {
+                "what": "bytes through L1 per launch: window 8 B/row + far diagonals 16 B/row + y 8 B/row; HBM sees x and y once; the "
+                        "kernel is bound by instruction issue and LDS latency (profiles/r03_sq_summary_march_v6.txt), not by bytes",
+                "bytes_per_launch": l1_bytes, "achieved": round(l1_bytes / kern_s / 1e9, 1), "peak_l2": 34500.0, "unit": "GB/s",
+                "frac_of_l2": round(l1_bytes / kern_s / 1e9 / 34500.0, 4)}
+        elif storage == "sell8v" and dict_blocks:
             # not HBM-bound any more: what the kernel pulls through L1 per product (ELL width 7: seven 16-byte x gathers per
             # lane and row pair = 56 B/row, 16 B/row of codes from the pooled blocks, 8 B/row stored), against the L2 rate
             l1_bytes = (56 + 16 + 8) * rows_rank
@@ -637,6 +674,15 @@ def main():
                 torch.cuda.empty_cache()
                 p2, c2, v2 = ops.poisson3d(n, dev)
                 rcsr = []
+                if storage == "sell8v" and march:
+                    # the pair product of round 2 on the same storage (the march product replaces it where it applies)
+                    B = ops.SpMat(p2, c2, v2, fmt=args.format, march=False)
+                    tb = timed_events(torch, lambda: B.apply(x, y), 40)
+                    assert abs(DistReductor("SUM_Kahan")(y) - checksum) <= 1e-10 * abs(checksum) + 1e-300
+                    out["pair_product"] = {"kernel": "sell8_pair_kernel<double, 7, true, true>", "avg_launch_ms": round(tb, 5),
+                                           "gflops": round(2.0 * nnz_total / tb / 1e6, 1),
+                                           "what": "the same storage through the round-2 kernel (VEXHIP_SPMAT_NO_MARCH): seven 16-byte gathers per lane and slice"}
+                    del B
                 if storage == "sell8v" and dict_blocks:
                     # the value-coded storage WITHOUT the slice dictionary: one code block per slice, streamed from HBM
                     B = ops.SpMat(p2, c2, v2, fmt=args.format, dictionary=False)
@@ -707,6 +753,8 @@ def main():
             out["roofline"]["traffic_source"] = how
             if tr:
                 key = {"sell8v": "sell8_pair_kernel_vcoded", "sell8": "sell8_pair_kernel_values", "sell32": "sell_pair_kernel", "csr": "csr_stream2_kernel"}.get(storage)
+                if storage == "sell8v" and march:
+                    key = "sell8_march_kernel"
                 if key in tr:
                     out["roofline"]["traffic"] = tr[key]["total"]
                     out["roofline"]["traffic_read_written"] = [tr[key]["read"], tr[key]["written"]]
