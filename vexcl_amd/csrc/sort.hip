@@ -197,9 +197,10 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
             // Tripwire (round 3): two NEIGHBOURING lanes with the same digit must have received consecutive ranks.  Lane order
             // of same-address LDS atomics is what the hardware does, not what the ISA promises; the once-per-device self-test
             // samples it under its own conditions.  Should a part ever serve the lanes differently, a sort must fail loudly
-            // (the trap surfaces as an error at the next synchronisation) and not return a silently unstable pass.  Costs
-            // one DPP move and three ALU operations per key; ~1/256 of all neighbour pairs are checked with random digits.
-            {
+            // (the trap surfaces as an error at the next synchronisation) and not return a silently unstable pass.  Checked on
+            // the first key of every lane only (one DPP move and three ALU operations per lane and tile: checking all twelve
+            // cost 4 % of the sort): with random digits 1/256 of the neighbour pairs share a digit, ~300 000 checks per pass.
+            if (k == 0) {
                 const unsigned left = (unsigned)__builtin_amdgcn_update_dpp((int)~0u, (int)rd[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 if (valid && left != ~0u && (left >> 16) == d && ((left + 1u) & 0xffffu) != (r & 0xffffu)) __builtin_trap();
             }
