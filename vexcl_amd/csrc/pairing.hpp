@@ -13,23 +13,20 @@
 
 namespace vexhip {
 
-// Entry offsets are 64-bit: a device may hold 2^31 entries or more (row pointers of type long long, round 3).
-struct pair_walk {
-    const int *col;
-    long long row;             // first row of the pair
-    long long b[2];            // CSR begin of the two rows
+// The merge itself, over any source of diagonals: d(q, k) = diagonal of the k-th ELL entry of row q of the pair.
+template <typename Diag>
+struct pair_merge {
+    Diag d;
     int n[2];                  // number of ELL entries (min(row length, w)) of the two rows
     int p[2];                  // entries consumed so far
     bool aligned;
 
-    __device__ __forceinline__ long long diag(int q, int k) const { return (long long)col[b[q] + k] - (row + q); }
-
-    __device__ void init(const int *col_, long long row_, long long b0, int n0, long long b1, int n1, int w) {
-        col = col_; row = row_; b[0] = b0; b[1] = b1; n[0] = n0; n[1] = n1;
+    __device__ void init(const Diag &d_, int n0, int n1, int w) {
+        d = d_; n[0] = n0; n[1] = n1;
         int pa = 0, pb = 0, merged = 0;
         while (pa < n0 || pb < n1) {
             if (pa < n0 && pb < n1) {
-                const long long da = diag(0, pa), db = diag(1, pb);
+                const long long da = d(0, pa), db = d(1, pb);
                 if (da == db) { ++pa; ++pb; } else if (da < db) ++pa; else ++pb;
             } else if (pa < n0) ++pa; else ++pb;
             ++merged;
@@ -38,21 +35,49 @@ struct pair_walk {
         p[0] = p[1] = 0;
     }
 
-    /// Entries (offsets into the CSR arrays, -1 = none) that go to the next ELL column.
-    __device__ void next(long long &e0, long long &e1) {
-        e0 = e1 = -1;
+    /// Entries (index within the row, -1 = none) that go to the next ELL column.
+    __device__ void next(int &k0, int &k1) {
+        k0 = k1 = -1;
         const bool h0 = p[0] < n[0], h1 = p[1] < n[1];
         if (!aligned) {
-            if (h0) e0 = b[0] + p[0]++;
-            if (h1) e1 = b[1] + p[1]++;
+            if (h0) k0 = p[0]++;
+            if (h1) k1 = p[1]++;
             return;
         }
         if (h0 && h1) {
-            const long long da = diag(0, p[0]), db = diag(1, p[1]);
-            if (da <= db) e0 = b[0] + p[0]++;
-            if (db <= da) e1 = b[1] + p[1]++;
-        } else if (h0) e0 = b[0] + p[0]++;
-        else if (h1) e1 = b[1] + p[1]++;
+            const long long da = d(0, p[0]), db = d(1, p[1]);
+            if (da <= db) k0 = p[0]++;
+            if (db <= da) k1 = p[1]++;
+        } else if (h0) k0 = p[0]++;
+        else if (h1) k1 = p[1]++;
+    }
+};
+
+// diagonals read from the CSR arrays (entry offsets are 64-bit: a device may hold 2^31 entries or more)
+struct diag_global {
+    const int *col; long long row, b[2];
+    __device__ __forceinline__ long long operator()(int q, int k) const { return (long long)col[b[q] + k] - (row + q); }
+};
+// diagonals of a pair whose first <= 8 columns per row were staged in LDS, entry (q, k) of lane t at s[(q * 8 + k) * 256 + t]
+// (round 3: the fill kernels load a pair's entries with one batch of independent loads instead of walking the CSR arrays
+// entry by entry -- the merge is a chain of dependent look-ups: 23 ms of the 512^3 set-up)
+struct diag_staged {
+    const int *s; int t; long long row;
+    __device__ __forceinline__ long long operator()(int q, int k) const { return (long long)s[(q * 8 + k) * 256 + t] - (row + q); }
+};
+
+struct pair_walk {
+    pair_merge<diag_global> m;
+    __device__ void init(const int *col_, long long row_, long long b0, int n0, long long b1, int n1, int w) {
+        diag_global g; g.col = col_; g.row = row_; g.b[0] = b0; g.b[1] = b1;
+        m.init(g, n0, n1, w);
+    }
+    /// Entries (offsets into the CSR arrays, -1 = none) that go to the next ELL column.
+    __device__ void next(long long &e0, long long &e1) {
+        int k0, k1;
+        m.next(k0, k1);
+        e0 = k0 >= 0 ? m.d.b[0] + k0 : -1;
+        e1 = k1 >= 0 ? m.d.b[1] + k1 : -1;
     }
 };
 

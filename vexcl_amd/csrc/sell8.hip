@@ -34,6 +34,11 @@ namespace vexhip {
 int g_sell8_variant = 0;
 // largest column index of the ELL part seen by the last sell8 / sell8v fill on this thread (x holds at least that + 1 elements)
 thread_local long long g_fill_max_col = -1;
+// set by the fused analysis (below) for the fill that follows it on this thread: the largest ELL column is known, the fill
+// skips its own pass over the column indices
+thread_local long long g_max_col_hint = -1;
+thread_local const void *g_hint_ptr = nullptr;
+thread_local long long g_hint_n = -1;
 
 namespace {
 
@@ -193,7 +198,7 @@ __device__ __forceinline__ unsigned pad_code(int partner_col, int partner_q, int
 
 // table: sorted diagonals (ndeltas valid entries); counts[256]: entries per code; info[1]: set if a diagonal is missing;
 // max_col: largest column index of the ELL part (ell_max_col_kernel)
-template <typename V, typename P>
+template <typename V, typename P, bool STAGED>
 __global__ __launch_bounds__(256)
 void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
         const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
@@ -201,11 +206,14 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
 {
     __shared__ int s_table[256];
     __shared__ unsigned s_cnt[256];
+    __shared__ int s_c[STAGED ? 16 * 256 : 1];          // STAGED (w <= 8): the pair's entries in lane-private LDS slots (sell8v_fill_kernel)
+    __shared__ V s_v[STAGED ? 16 * 256 : 1];
     s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int max_col = *max_col_p;
     const int wp = (w + 1) / 2;
+    const int lt = threadIdx.x;
     // one lane per row PAIR (the unit the product kernel reads)
     for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (S8_ROWS / 2);
          pr += (long long)gridDim.x * blockDim.x) {
@@ -217,24 +225,42 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
         long long b[2] = {0, 0}, e[2] = {0, 0};
         const long long i = s * S8_ROWS + 2 * t;
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
+        const int n0 = (int)min(e[0] - b[0], (long long)w), n1 = (int)min(e[1] - b[1], (long long)w);
         pair_walk pw;
-        pw.init(col, i, b[0], (int)min(e[0] - b[0], (long long)w), b[1], (int)min(e[1] - b[1], (long long)w), w);
+        pair_merge<diag_staged> pm;
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < (q ? n1 : n0)) { s_c[(q * 8 + k) * 256 + lt] = col[b[q] + k]; s_v[(q * 8 + k) * 256 + lt] = val[b[q] + k]; }
+            diag_staged g; g.s = s_c; g.t = lt; g.row = i;
+            pm.init(g, n0, n1, w);
+        } else {
+            pw.init(col, i, b[0], n0, b[1], n1, w);
+        }
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
-                long long en[2] = {-1, -1};
-                if (j < w) pw.next(en[0], en[1]);
+                int ec[2] = {-1, -1}; V ev[2] = {V(0), V(0)}; bool has[2] = {false, false};
+                if (j < w) {
+                    if constexpr (STAGED) {
+                        int k[2]; pm.next(k[0], k[1]);
+                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[(q * 8 + k[q]) * 256 + lt]; ev[q] = s_v[(q * 8 + k[q]) * 256 + lt]; }
+                    } else {
+                        long long en[2]; pw.next(en[0], en[1]);
+                        for (int q = 0; q < 2; ++q) if (en[q] >= 0) { has[q] = true; ec[q] = col[en[q]]; ev[q] = val[en[q]]; }
+                    }
+                }
                 for (int q = 0; q < 2; ++q) {
                     unsigned code;
-                    V v = V(0);
-                    if (en[q] >= 0) {
-                        code = delta_code(s_table, ndeltas, (long long)col[en[q]] - (i + q));
+                    if (has[q]) {
+                        code = delta_code(s_table, ndeltas, (long long)ec[q] - (i + q));
                         if (code != S8_PAD) atomicAdd(&s_cnt[code], 1u); else atomicExch(&info[1], 1);
-                        v = val[en[q]];
-                    } else code = pad_code(en[1 - q] >= 0 ? col[en[1 - q]] : -1, 1 - q, max_col);
+                    } else code = pad_code(has[1 - q] ? ec[1 - q] : -1, 1 - q, max_col);
                     word |= code << (8 * (jj * 2 + q));
-                    if (j < w) vp[(long long)j * S8_ROWS + q] = v;
+                    if (j < w) vp[(long long)j * S8_ROWS + q] = ev[q];
                 }
             }
             cw[jp * 256] = word;
@@ -738,7 +764,82 @@ void value_collect_kernel(long long n, int w, const P *__restrict__ ptr, const V
 }
 
 // vtable: sorted value bit patterns (nvalues valid entries)
+// Diagonals, values and the largest column of the ELL part in ONE pass over the CSR arrays (round 3: delta_collect +
+// value_collect + ell_max_col read ptr / col / val three times, 12 ms of the 512^3 set-up).  Same sets, same overflow rules
+// as the two collect kernels; a lane loads its row's first <= 8 entries with one batch of independent loads.
 template <typename V, typename P>
+__global__ __launch_bounds__(256)
+void analyze_fused_kernel(long long n, int w, const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
+        int *gset_d, int *info_d, typename bits_of<V>::type *gset_v, int *info_v, int *max_col)
+{
+    typedef typename bits_of<V>::type B;
+    __shared__ int s_set[LOCAL_SLOTS];
+    __shared__ B s_vset[LOCAL_SLOTS];
+    __shared__ int s_over, s_count, s_vover, s_vcount;
+    for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) { s_set[k] = EMPTY; s_vset[k] = ~B(0); }
+    if (threadIdx.x == 0) { s_over = *(volatile int *)&info_d[1]; s_count = 0; s_vover = *(volatile int *)&info_v[1]; s_vcount = 0; }
+    __syncthreads();
+    int m = -1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const P b = ptr[i], e = ptr[i + 1];
+        const bool dstop = *(volatile int *)&s_over || *(volatile int *)&info_d[1];
+        const bool vstop = *(volatile int *)&s_vover || *(volatile int *)&info_v[1];
+        int last = EMPTY; B vlast = ~B(0);
+        for (int j0 = 0; j0 < w && b + j0 < e; j0 += 8) {
+            int c[8]; V v[8]; int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < w && b + j0 + u < e) { c[u] = col[b + j0 + u]; v[u] = val[b + j0 + u]; cnt = u + 1; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u >= cnt) break;
+                m = c[u] > m ? c[u] : m;
+                if (!dstop) {
+                    const long long dl = (long long)c[u] - i;
+                    if (dl <= INT_MIN || dl > INT_MAX) s_over = 1;
+                    else if ((int)dl != last) {
+                        last = (int)dl;
+                        bool fresh = false;
+                        if (!set_insert(s_set, LOCAL_SLOTS, last, &fresh)) s_over = 1;
+                        else if (fresh && atomicAdd(&s_count, 1) >= 254) { s_over = 1; atomicExch(&info_d[1], 1); }
+                    }
+                }
+                if (!vstop) {
+                    B bits; __builtin_memcpy(&bits, &v[u], sizeof(B));
+                    if (bits == ~B(0)) s_vover = 1;
+                    else if (bits != vlast) {
+                        vlast = bits;
+                        bool fresh = false;
+                        if (!vset_insert<B>(s_vset, LOCAL_SLOTS, bits, &fresh)) s_vover = 1;
+                        else if (fresh && atomicAdd(&s_vcount, 1) >= 255) { s_vover = 1; atomicExch(&info_v[1], 1); }
+                    }
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_down(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(max_col, m);
+    __syncthreads();
+    if (s_over) { if (threadIdx.x == 0) atomicExch(&info_d[1], 1); }
+    else
+        for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
+            if (s_set[k] == EMPTY) continue;
+            bool is_new = false;
+            if (!set_insert(gset_d, HASH_SLOTS, s_set[k], &is_new)) atomicExch(&info_d[1], 1);
+            else if (is_new) atomicAdd(&info_d[0], 1);
+        }
+    if (s_vover) { if (threadIdx.x == 0) atomicExch(&info_v[1], 1); }
+    else
+        for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
+            if (s_vset[k] == ~B(0)) continue;
+            bool is_new = false;
+            if (!vset_insert<B>(gset_v, HASH_SLOTS, s_vset[k], &is_new)) atomicExch(&info_v[1], 1);
+            else if (is_new) atomicAdd(&info_v[0], 1);
+        }
+}
+
+// STAGED (w <= 8): the pair's entries are loaded with one batch of independent loads into lane-private LDS slots and the
+// merge, the code look-ups and the stores work from there (48 KiB of LDS per workgroup for fp64).
+template <typename V, typename P, bool STAGED>
 __global__ __launch_bounds__(256)
 void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int nvalues,
         const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
@@ -749,12 +850,15 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
     __shared__ int s_table[256];
     __shared__ B s_vtable[256];
     __shared__ unsigned s_cnt[256];
+    __shared__ int s_c[STAGED ? 16 * 256 : 1];
+    __shared__ V s_v[STAGED ? 16 * 256 : 1];
     s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
     { V v = threadIdx.x < nvalues ? vtable[threadIdx.x] : V(0); B b; __builtin_memcpy(&b, &v, sizeof(B)); s_vtable[threadIdx.x] = threadIdx.x < nvalues ? b : ~B(0); }
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int max_col = *max_col_p;
     const int wp = (w + 1) / 2;
+    const int lt = threadIdx.x;
     for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < nslices * (S8_ROWS / 2);
          pr += (long long)gridDim.x * blockDim.x) {
         const long long s = pr / (S8_ROWS / 2);
@@ -764,26 +868,46 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
         long long b[2] = {0, 0}, e[2] = {0, 0};
         const long long i = s * S8_ROWS + 2 * t;
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
+        const int n0 = (int)min(e[0] - b[0], (long long)w), n1 = (int)min(e[1] - b[1], (long long)w);
         pair_walk pw;
-        pw.init(col, i, b[0], (int)min(e[0] - b[0], (long long)w), b[1], (int)min(e[1] - b[1], (long long)w), w);
+        pair_merge<diag_staged> pm;
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < (q ? n1 : n0)) { s_c[(q * 8 + k) * 256 + lt] = col[b[q] + k]; s_v[(q * 8 + k) * 256 + lt] = val[b[q] + k]; }
+            diag_staged g; g.s = s_c; g.t = lt; g.row = i;
+            pm.init(g, n0, n1, w);
+        } else {
+            pw.init(col, i, b[0], n0, b[1], n1, w);
+        }
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0, vword = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
-                long long en[2] = {-1, -1};
-                if (j < w) pw.next(en[0], en[1]);
+                int ec[2] = {-1, -1}; V ev[2] = {V(0), V(0)}; bool has[2] = {false, false};      // the column's two entries: column index, value
+                if (j < w) {
+                    if constexpr (STAGED) {
+                        int k[2]; pm.next(k[0], k[1]);
+                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[(q * 8 + k[q]) * 256 + lt]; ev[q] = s_v[(q * 8 + k[q]) * 256 + lt]; }
+                    } else {
+                        long long en[2]; pw.next(en[0], en[1]);
+                        for (int q = 0; q < 2; ++q) if (en[q] >= 0) { has[q] = true; ec[q] = col[en[q]]; ev[q] = val[en[q]]; }
+                    }
+                }
                 for (int q = 0; q < 2; ++q) {
                     unsigned code, vcode = 255;                     // value code of padding: table entry 255 = 0.0
-                    if (en[q] >= 0) {
-                        code = delta_code(s_table, ndeltas, (long long)col[en[q]] - (i + q));
+                    if (has[q]) {
+                        code = delta_code(s_table, ndeltas, (long long)ec[q] - (i + q));
                         if (code != S8_PAD) atomicAdd(&s_cnt[code], 1u); else atomicExch(&info[1], 1);
-                        B bits; V v = val[en[q]];
+                        B bits; V v = ev[q];
                         __builtin_memcpy(&bits, &v, sizeof(B));
                         int lo = 0, hi = nvalues;
                         while (lo < hi) { int mid = (lo + hi) >> 1; if (s_vtable[mid] < bits) lo = mid + 1; else hi = mid; }
                         if (lo < nvalues && s_vtable[lo] == bits) vcode = (unsigned)lo;
                         else atomicExch(&info[1], 1);
-                    } else code = pad_code(en[1 - q] >= 0 ? col[en[1 - q]] : -1, 1 - q, max_col);
+                    } else code = pad_code(has[1 - q] ? ec[1 - q] : -1, 1 - q, max_col);
                     word |= code << (8 * (jj * 2 + q));
                     vword |= vcode << (8 * (jj * 2 + q));
                 }
@@ -886,10 +1010,21 @@ int sell8_fill(int dev, void *stream, int64_t n, const P *ptr, const int *col, c
     VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 4 * sizeof(int)));
     int *dinfo = reinterpret_cast<int *>(dcounts + 256);                    // [0] unused, [1] error flag, [2] largest ELL column
     VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
-    VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
-    ell_max_col_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
-    sell8_fill_kernel<V, P><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, ptr, col, val, deltas,
-            dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
+    if (g_max_col_hint >= 0 && g_hint_ptr == static_cast<const void *>(ptr) && g_hint_n == n) {   // the fused analysis of THIS matrix ran just before on this thread
+        const int known = (int)g_max_col_hint;
+        g_max_col_hint = -1;
+        VEXHIP_TRY(hipMemcpyAsync(dinfo + 2, &known, sizeof(int), hipMemcpyHostToDevice, s));
+        VEXHIP_TRY(hipStreamSynchronize(s));
+    } else {
+        VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
+        ell_max_col_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
+    }
+    if (w <= 8)
+        sell8_fill_kernel<V, P, true><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, ptr, col, val, deltas,
+                dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
+    else
+        sell8_fill_kernel<V, P, false><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, ptr, col, val, deltas,
+                dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
     int hinfo[3] = {0, 0, -1};
@@ -969,6 +1104,68 @@ int sell8v_analyze(int dev, void *stream, int64_t n, const P *ptr, const V *val,
     return 0;
 }
 
+// deltas[256] / values[256]: device tables as the two separate analyses write them; *ndeltas / *nvalues = -1 when not applicable
+template <typename V, typename P>
+int analyze_fused(int dev, void *stream, int64_t n, const P *ptr, const int *col, const V *val, int64_t w,
+        int32_t *deltas, int *ndeltas, V *values, int *nvalues)
+{
+    typedef typename bits_of<V>::type B;
+    *ndeltas = -1; *nvalues = -1; g_max_col_hint = -1;
+    if (n <= 0 || w < 1) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    // [int set: HASH_SLOTS + 2 info][value set: HASH_SLOTS B + 2 int info][max col]
+    const size_t dbytes = sizeof(int) * (HASH_SLOTS + 2), vbytes = sizeof(B) * HASH_SLOTS + 2 * sizeof(int);
+    char *d = nullptr;
+    VEXHIP_TRY(hipMalloc(&d, dbytes + vbytes + sizeof(int) + 64));
+    int *dset = reinterpret_cast<int *>(d);
+    B *vset = reinterpret_cast<B *>(d + ((dbytes + 15) / 16) * 16);
+    int *vinfo = reinterpret_cast<int *>(vset + HASH_SLOTS);
+    int *dmax = vinfo + 2;
+    std::vector<int> hd(HASH_SLOTS + 2, EMPTY);
+    hd[HASH_SLOTS] = 0; hd[HASH_SLOTS + 1] = 0;
+    hipError_t e = hipMemcpyAsync(dset, hd.data(), dbytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(vset, 0xff, sizeof(B) * HASH_SLOTS, s);
+    if (e == hipSuccess) e = hipMemsetAsync(vinfo, 0, 2 * sizeof(int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dmax, 0xff, sizeof(int), s);
+    std::vector<B> hv(HASH_SLOTS);
+    int vi[2] = {0, 0}, hmax = -1;
+    if (e == hipSuccess) {
+        analyze_fused_kernel<V, P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, val, dset, dset + HASH_SLOTS, vset, vinfo, dmax);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), dset, dbytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(hv.data(), vset, sizeof(B) * HASH_SLOTS, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(vi, vinfo, sizeof(vi), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    VEXHIP_TRY(e);
+    g_max_col_hint = hmax; g_hint_ptr = ptr; g_hint_n = n;
+    if (!(hd[HASH_SLOTS + 1] != 0 || hd[HASH_SLOTS] > 254 || hd[HASH_SLOTS] < 1)) {
+        std::vector<int> table;
+        for (int k = 0; k < HASH_SLOTS; ++k) if (hd[k] != EMPTY) table.push_back(hd[k]);
+        std::sort(table.begin(), table.end());
+        if ((int)table.size() != hd[HASH_SLOTS]) return fail(__FILE__, __LINE__, "diagonal set is inconsistent");
+        table.resize(256, INT_MAX);
+        VEXHIP_TRY(hipMemcpyAsync(deltas, table.data(), sizeof(int) * 256, hipMemcpyHostToDevice, s));
+        VEXHIP_TRY(hipStreamSynchronize(s));
+        *ndeltas = hd[HASH_SLOTS];
+    }
+    if (*ndeltas > 0 && !(vi[1] != 0 || vi[0] > 255 || vi[0] < 1)) {
+        std::vector<B> table;
+        for (B b : hv) if (b != ~B(0)) table.push_back(b);
+        std::sort(table.begin(), table.end());
+        if ((int)table.size() != vi[0]) return fail(__FILE__, __LINE__, "value set is inconsistent");
+        std::vector<V> vals(256, V(0));
+        for (size_t k = 0; k < table.size(); ++k) __builtin_memcpy(&vals[k], &table[k], sizeof(B));
+        VEXHIP_TRY(hipMemcpyAsync(values, vals.data(), sizeof(V) * 256, hipMemcpyHostToDevice, s));
+        VEXHIP_TRY(hipStreamSynchronize(s));
+        *nvalues = vi[0];
+    }
+    return 0;
+}
+
 template <typename V, typename P>
 int sell8v_fill(int dev, void *stream, int64_t n, const P *ptr, const int *col, const V *val, int64_t w,
         const int *deltas, int ndeltas, const V *values, int nvalues, void *buf, vexhip_traversal *trav)
@@ -984,10 +1181,21 @@ int sell8v_fill(int dev, void *stream, int64_t n, const P *ptr, const int *col, 
     VEXHIP_TRY(hipMalloc(&dcounts, sizeof(unsigned long long) * 256 + 4 * sizeof(int)));
     int *dinfo = reinterpret_cast<int *>(dcounts + 256);                    // [0] unused, [1] error flag, [2] largest ELL column
     VEXHIP_TRY(hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256 + 2 * sizeof(int), s));
-    VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
-    ell_max_col_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
-    sell8v_fill_kernel<V, P><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, nvalues, ptr, col, val, deltas, values,
-            dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
+    if (g_max_col_hint >= 0 && g_hint_ptr == static_cast<const void *>(ptr) && g_hint_n == n) {   // the fused analysis of THIS matrix ran just before on this thread
+        const int known = (int)g_max_col_hint;
+        g_max_col_hint = -1;
+        VEXHIP_TRY(hipMemcpyAsync(dinfo + 2, &known, sizeof(int), hipMemcpyHostToDevice, s));
+        VEXHIP_TRY(hipStreamSynchronize(s));
+    } else {
+        VEXHIP_TRY(hipMemsetAsync(dinfo + 2, 0xff, sizeof(int), s));
+        ell_max_col_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, dinfo + 2);
+    }
+    if (w <= 8)
+        sell8v_fill_kernel<V, P, true><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, nvalues, ptr, col, val, deltas, values,
+                dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
+    else
+        sell8v_fill_kernel<V, P, false><<<grid_for(dev, ns * (S8_ROWS / 2)), 256, 0, s>>>(n, ns, (int)w, ndeltas, nvalues, ptr, col, val, deltas, values,
+                dinfo + 2, static_cast<char *>(buf), dcounts, dinfo);
     std::vector<unsigned long long> counts(256);
     std::vector<int> table(ndeltas);
     int hinfo[3] = {0, 0, -1};
@@ -1185,6 +1393,15 @@ int sell8_analyze(int dev, void *stream, int64_t n, const P *ptr, const int32_t 
 
 // ---- 64-bit row pointers (a device may hold 2^31 entries or more; columns stay 32-bit): internal entry points used by
 //      spmat.hip -- vexhip_spmat_create_*_p64 is the C-ABI door (reference: size_t row pointers, vexcl/spmat.hpp:56-57)
+int analyze_fused_p32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val, int64_t w, int32_t *deltas, int *ndeltas, double *values, int *nvalues)
+{ return analyze_fused<double, int32_t>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues); }
+int analyze_fused_p32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val, int64_t w, int32_t *deltas, int *ndeltas, float *values, int *nvalues)
+{ return analyze_fused<float, int32_t>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues); }
+int analyze_fused_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, int32_t *deltas, int *ndeltas, double *values, int *nvalues)
+{ return analyze_fused<double, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues); }
+int analyze_fused_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, int32_t *deltas, int *ndeltas, float *values, int *nvalues)
+{ return analyze_fused<float, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues); }
+void clear_max_col_hint() { g_max_col_hint = -1; g_hint_ptr = nullptr; g_hint_n = -1; }
 int sell8_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int64_t w, int32_t *deltas, int *ndeltas)
 { return sell8_analyze<long long>(dev, stream, n, ptr, col, w, deltas, ndeltas); }
 int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const double *val, int64_t w, double *values, int *nvalues)

@@ -21,6 +21,12 @@ int hell_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, int
 int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, int32_t *csr_ptr, int32_t *csr_col, double *csr_val);
 int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, int32_t *csr_ptr, int32_t *csr_col, float *csr_val);
 int sell8_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int64_t w, int32_t *deltas, int *ndeltas);
+void clear_max_col_hint();
+// diagonals + values + largest ELL column in one pass over the CSR arrays (the fill that follows skips its own column pass)
+int analyze_fused_p32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val, int64_t w, int32_t *deltas, int *ndeltas, double *values, int *nvalues);
+int analyze_fused_p32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val, int64_t w, int32_t *deltas, int *ndeltas, float *values, int *nvalues);
+int analyze_fused_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, int32_t *deltas, int *ndeltas, double *values, int *nvalues);
+int analyze_fused_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, int32_t *deltas, int *ndeltas, float *values, int *nvalues);
 int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const double *val, int64_t w, double *values, int *nvalues);
 int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const float *val, int64_t w, float *values, int *nvalues);
 int sell8v_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, const int32_t *deltas, int ndeltas, const double *values, int nvalues, void *buf, vexhip_traversal *trav);
@@ -183,6 +189,7 @@ template <typename V> struct setup32 {
     static int v_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, const V *vals, int nv, void *b, vexhip_traversal *t) { return F::v_fill(d, s, n, p, c, v, w, dl, nd, vals, nv, b, t); }
     static int d_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, void *b, vexhip_traversal *t) { return F::d_fill(d, s, n, p, c, v, w, dl, nd, b, t); }
     static int s_fill(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, void *b) { return F::s_fill(d, s, n, p, c, v, w, b); }
+    static int fused(int d, void *s, int64_t n, const int32_t *p, const int32_t *c, const V *v, int64_t w, int32_t *dl, int *nd, V *vals, int *nv) { return analyze_fused_p32(d, s, n, p, c, v, w, dl, nd, vals, nv); }
 };
 template <typename V> struct setup64 {
     static int analyze(int d, void *s, int64_t n, const long long *p, int64_t *w, int64_t *t) { return hell_analyze_p64(d, s, n, p, w, t); }
@@ -192,6 +199,7 @@ template <typename V> struct setup64 {
     static int v_fill(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, const V *vals, int nv, void *b, vexhip_traversal *t) { return sell8v_fill_p64(d, s, n, p, c, v, w, dl, nd, vals, nv, b, t); }
     static int d_fill(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, const int32_t *dl, int nd, void *b, vexhip_traversal *t) { return sell8_fill_p64(d, s, n, p, c, v, w, dl, nd, b, t); }
     static int s_fill(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, void *b) { return sell_fill_p64(d, s, n, p, c, v, w, b); }
+    static int fused(int d, void *s, int64_t n, const long long *p, const int32_t *c, const V *v, int64_t w, int32_t *dl, int *nd, V *vals, int *nv) { return analyze_fused_p64(d, s, n, p, c, v, w, dl, nd, vals, nv); }
 };
 
 // P = int32_t or long long (row pointers); columns are 32-bit either way
@@ -252,20 +260,20 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         A->csr_val = cv;
         if (int rc = S::tail(dev, stream, n, ptr, col, val, w, A->csr_ptr, A->csr_col, cv)) return rc;
     }
-    int nd = -1;
-    if (format != VEXHIP_SPMAT_SELL) {
+    int nd = -1, nv = -1;
+    if (format == VEXHIP_SPMAT_AUTO || format == VEXHIP_SPMAT_SELL8V) {
+        // both analyses are wanted: ONE pass over the CSR arrays finds the diagonals, the values and the largest ELL column
+        V *vals = nullptr;
+        if (int rc = dmalloc(&A->deltas, 256)) return rc;
+        if (int rc = dmalloc(&vals, 256)) return rc;
+        A->values = vals;
+        if (int rc = S::fused(dev, stream, n, ptr, col, val, w, A->deltas, &nd, vals, &nv)) return rc;
+    } else if (format != VEXHIP_SPMAT_SELL) {
         if (int rc = dmalloc(&A->deltas, 256)) return rc;
         if (int rc = S::d_analyze(dev, stream, n, ptr, col, w, A->deltas, &nd)) return rc;
     }
     if (nd > 0) {
         A->ndeltas = nd;
-        int nv = -1;
-        if (format != VEXHIP_SPMAT_SELL8) {
-            V *vals = nullptr;
-            if (int rc = dmalloc(&vals, 256)) return rc;
-            A->values = vals;
-            if (int rc = S::v_analyze(dev, stream, n, ptr, val, w, vals, &nv)) return rc;
-        }
         if (nv > 0) {
             A->nvalues = nv; A->format = VEXHIP_SPMAT_SELL8V;
             A->sell_bytes = vexhip_sell8v_bytes(n, w);
@@ -282,12 +290,14 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         }
     } else {
         if (A->deltas) { (void)hipFree(A->deltas); A->deltas = nullptr; }
+        if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
         A->format = VEXHIP_SPMAT_SELL;
         A->sell_bytes = vexhip_sell_bytes(n, w, (int)sizeof(V));
         VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
         if (int rc = S::s_fill(dev, stream, n, ptr, col, val, w, A->sell)) return rc;
         if (int rc = vexhip_sell_order_i32(dev, stream, n, w, (int)sizeof(V), A->sell, 0, nullptr, 0, &A->trav)) return rc;
     }
+    clear_max_col_hint();
     VEXHIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
