@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round-3 evidence in one gpurun call (outputs under gpurun_out/, copied to profiles/ afterwards):
+#   kernel trace + stats of the driver's bench command, the un-profiled bench line (with its in-run PMC traffic passes),
+#   the 2-rank front door on one device, the C++ roofline rows, the reference's own benchmark program.
+ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b --output-format csv -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/r03_bench_under_rocprof.log 2>&1
+cp /tmp/prof_b/b_kernel_stats.csv $OUT/r03_bench_kernel_stats.csv 2>/dev/null
+cd $ROOT
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r03_bench_n1.log 2> $OUT/r03_bench_n1.err
+timeout 600 python bench.py --gpus 2 --one-device --steps 20 --warmup 5 > $OUT/r03_bench_n2_one_device.log 2> $OUT/r03_bench_n2_one_device.err
+timeout 300 ./examples/build/roofline 1000000000 escpk > $OUT/r03_examples_roofline_cpp.log 2>&1
+timeout 300 ./oracle/_ref/example_benchmark > $OUT/r03_reference_examples_benchmark_cpp.log 2>&1
+tail -c 600 $OUT/r03_bench_n1.log; echo; tail -c 300 $OUT/r03_bench_n2_one_device.log; echo; grep -c row $OUT/r03_examples_roofline_cpp.log; tail -3 $OUT/r03_reference_examples_benchmark_cpp.log
