@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvexhip.so")
+LIB_PATH = os.environ.get("VEXHIP_LIBRARY") or os.path.join(_HERE, "lib", "libvexhip.so")   # VEXHIP_LIBRARY: A/B builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 

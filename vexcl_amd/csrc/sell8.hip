@@ -708,6 +708,289 @@ void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
     }
 }
 
+// ---------------------------------------------------------------------------
+// The march product, second form (round 3, v8).  The counters of the kernel above said: 150 vector + 91 scalar instructions
+// per wave and slice, the waves issue-bound.  Of those only 28 are arithmetic.  What this form removes:
+//   * the ring is no power of two but span + 2 slices (span = bytes the near diagonals cover, rounded to whole slices) and
+//     carries a MIRROR of its first `span` bytes behind its end: a column's pair sits at  window base + offset  without a
+//     wrap, the window base is one scalar per slice, a column address is ONE vector add (was: add, and, add);
+//   * masking only the HIGH word of a double an invalid lane "covers": (+0.0) * (a number whose exponent field is 0) is +0
+//     whatever the low word holds -- one v_cndmask per value instead of two;
+//   * slices whose loads lie inside x and whose rows lie inside y (all but the first / last plane's) take loads and the
+//     store without any per-lane bounds arithmetic: scalar base + lane offset;
+//   * the diagonal and value tables are read from global memory when a code block is decoded (rare) instead of being staged
+//     in LDS by every workgroup: 32 KiB of LDS per workgroup at 512^3 fp64 (ring 16 + mirror 8 + far slots 8) = 5 per CU.
+// Same products in the same order: bit-identical to the kernel above, the pair kernel and the CSR oracle.
+// ---------------------------------------------------------------------------
+struct march2_dev { int lo, hi, lo_e, span_b, cap_b, run, nfar, far0, far1; long long x_last; };
+
+template <typename V> __device__ __forceinline__ V masked_hi(V v, unsigned long long lanes);
+template <> __device__ __forceinline__ double masked_hi<double>(double v, unsigned long long lanes) {
+    unsigned hi = (unsigned)(__double_as_longlong(v) >> 32), rhi;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"(hi), "s"(lanes));
+    return __longlong_as_double((long long)(((unsigned long long)rhi << 32) | (unsigned)__double_as_longlong(v)));
+}
+template <> __device__ __forceinline__ float masked_hi<float>(float v, unsigned long long lanes) { return masked<float>(v, lanes); }
+
+// Arguments the hot loop does not touch.  The kernel reads them from its kernarg segment WHERE they are used, through a
+// pointer the optimiser cannot see through (cold()): hoisted to the top they would sit in ~25 scalar registers across the
+// hot loop, which needs 28 for the lane masks alone -- the first build of this kernel spilled 50 scalars into vector lanes.
+template <typename V>
+struct march_cold {
+    long long n, nslices;
+    const int *deltas; const V *values;
+    const int *csr_ptr, *csr_col; const V *csr_val;
+    const char *pool;
+    trav_dev trav;
+};
+#ifndef MARCH2_BOUNDS
+#define MARCH2_BOUNDS __launch_bounds__(256)
+#endif
+template <typename V, int W>
+__global__ MARCH2_BOUNDS
+void sell8_march2_kernel(march_cold<V> cold_args /* first: offset 0 of the kernarg segment; read through cold() only */, V alpha, int append,
+        const V *__restrict__ x, V *__restrict__ y, const int *__restrict__ blocks, march2_dev mp)
+{
+    constexpr int WP = (W + 1) / 2;
+    constexpr long long CODE_BYTES = (long long)WP * 2048;
+    constexpr int VB = (int)sizeof(V);
+    constexpr int SLB = S8_ROWS * VB;                          // bytes of x per slice
+    typedef typename vec2<V>::type V2;
+    typedef const __attribute__((address_space(4))) march_cold<V> *kernarg_ptr;
+    extern __shared__ __align__(16) unsigned char s_march[];  // [ring: cap_b][mirror of its first span_b bytes][far 0: SLB][far 1: SLB][diagonal table: 1 KiB][value table]
+
+    auto cold = [&]() -> const __attribute__((address_space(4))) march_cold<V> * {
+        unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        return (kernarg_ptr)ka;
+    };
+
+    const int t = threadIdx.x;
+    long long first; int count;
+    {
+        const auto *c = cold();
+        const trav_dev trav = {nullptr, c->trav.chunk, c->trav.planes, c->trav.plane_blocks};   // the plan declines explicit orders
+        march_run(trav, c->nslices, mp.run, blockIdx.x, first, count);
+    }
+    if (count <= 0) return;                                   // the whole workgroup: holes of the strip order
+
+    const int capb = mp.cap_b, spanb = mp.span_b, farb = capb + spanb;
+    const int hi2 = mp.lo_e + spanb / VB;                     // the window of a slice: x[i0 + lo_e .. i0 + 512 + hi2)
+    const long long i00 = first * S8_ROWS;
+    const unsigned lane_b = 2u * (unsigned)t * VB;
+    // Iteration k requests the 512 elements slice k + 2 adds to the window and the far diagonals of slice k + 1, and stores
+    // the rows of slice k.  [kA, kend): the iterations for which all of that lies inside x and y -- the hot loop.
+    int kA = 0, kend = count;
+    {
+        const auto *c = cold();
+        long long m = 2 * S8_ROWS + hi2, M = m;
+        if (mp.nfar > 0) { const long long f = S8_ROWS + (long long)mp.far0; m = f < m ? f : m; M = f > M ? f : M; }
+        if (mp.nfar > 1) { const long long f = S8_ROWS + (long long)mp.far1; m = f < m ? f : m; M = f > M ? f : M; }
+        const long long a = -(i00 + m);
+        if (a > 0) { const long long q = (a + S8_ROWS - 1) / S8_ROWS; kA = q > count ? count : (int)q; }
+        const long long bb = mp.x_last - (S8_ROWS - 1) - M - i00;
+        const long long kB = bb >= 0 ? bb / S8_ROWS + 1 : 0;
+        const long long kS = c->n / S8_ROWS - first;
+        if (kB < kend) kend = (int)kB;
+        if (kS < kend) kend = kS > 0 ? (int)kS : 0;
+        if (c->csr_ptr || (reinterpret_cast<unsigned long long>(y) & (2 * VB - 1)) != 0) kend = 0;
+    }
+    auto load512 = [&](long long gb) -> V2 {
+        if (gb >= 0 && gb + S8_ROWS - 1 <= mp.x_last) { V2 v; __builtin_memcpy(&v, x + gb + 2 * t, sizeof(V2)); return v; }
+        return load_pair_clamped<V>(x, gb + 2 * t, mp.x_last);
+    };
+    // The prologue of a run costs round trips, not bytes (the first build: three for the window, one for the registers, three
+    // for block number -> codes -> tables; 11 % of the product at 32 slices per run).  Now: the block number, then ONE batch
+    // of independent loads -- codes of the first block, the diagonal / value tables (into LDS, behind the far slots), the
+    // window of the first slice (ring position 0; <= 4 pairs per lane, the plan sees to that), the 512 elements the second
+    // slice adds and the far diagonals of the first slice -- then the decode from LDS.
+    int *s_delta = reinterpret_cast<int *>(s_march + farb + 2 * SLB);
+    V *s_value = reinterpret_cast<V *>(s_march + farb + 2 * SLB + 1024);
+    int cur = blocks[first];
+    unsigned cwv[2 * WP];
+    V2 chunk = {V(0), V(0)}, f0 = {V(0), V(0)}, f1 = {V(0), V(0)};
+    {
+        const auto *c = cold();
+        const int *deltas = c->deltas; const V *values = c->values;
+        const unsigned *cw = reinterpret_cast<const unsigned *>(c->pool + (long long)cur * CODE_BYTES) + t;
+#pragma unroll
+        for (int u = 0; u < 2 * WP; ++u) cwv[u] = cw[u * 256];
+        const int dl = deltas[t]; const V vl = values[t];
+        const long long g0 = i00 + mp.lo_e;
+        const int wpairs = (SLB + spanb) / (2 * VB);
+        V2 w[4];
+        const long long glo = g0 < i00 + mp.far0 ? g0 : i00 + mp.far0;
+        long long ghi = i00 + 2 * S8_ROWS + hi2;                     // one past the last element any of these loads touches
+        if (mp.nfar > 0 && i00 + S8_ROWS + mp.far0 > ghi) ghi = i00 + S8_ROWS + mp.far0;
+        if (mp.nfar > 1 && i00 + S8_ROWS + mp.far1 > ghi) ghi = i00 + S8_ROWS + mp.far1;
+        if (glo >= 0 && (mp.nfar < 2 || i00 + mp.far1 >= 0) && ghi - 1 <= mp.x_last) {      // uniform: nothing to clamp
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { w[u] = V2{V(0), V(0)}; if (t + u * 256 < wpairs) __builtin_memcpy(&w[u], x + g0 + 2 * (t + u * 256), sizeof(V2)); }
+            __builtin_memcpy(&chunk, x + i00 + S8_ROWS + hi2 + 2 * t, sizeof(V2));
+            if (mp.nfar > 0) __builtin_memcpy(&f0, x + i00 + mp.far0 + 2 * t, sizeof(V2));
+            if (mp.nfar > 1) __builtin_memcpy(&f1, x + i00 + mp.far1 + 2 * t, sizeof(V2));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { w[u] = V2{V(0), V(0)}; if (t + u * 256 < wpairs) w[u] = load_pair_clamped<V>(x, g0 + 2 * (t + u * 256), mp.x_last); }
+            if (count > 1) chunk = load512(i00 + S8_ROWS + hi2);
+            if (mp.nfar > 0) f0 = load512(i00 + mp.far0);
+            if (mp.nfar > 1) f1 = load512(i00 + mp.far1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (t + u * 256 < wpairs) *reinterpret_cast<V2 *>(s_march + 2 * (t + u * 256) * VB) = w[u];
+        s_delta[t] = dl; s_value[t] = vl;
+    }
+    __syncthreads();
+
+    bool slow = false;                                        // this wave, this block: per-entry loop
+    int um[W];                                                // uniform per column: -1 = the ring (its address moves with the window), 0 = a far slot
+    int cj[W];                                                // the lane's LDS byte address in column j relative to the window base (ring) / absolute (far slot)
+    V a0[W], a1[W];                                           // the matrix values of the lane's two rows (0 for padding)
+    unsigned long long v0[W], v1[W];                          // uniform: the lanes whose row 2t / 2t + 1 has an entry in column j
+    // code words of a block (cwv) -> the per-column state above
+    auto decode = [&]() {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned cword = cwv[j >> 1] >> (16 * (j & 1)), vword = cwv[WP + (j >> 1)] >> (16 * (j & 1));
+            const unsigned c0 = cword & 255u, c1 = (cword >> 8) & 255u;
+            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE, any = m0 || m1;
+            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+            const int d = any ? s_delta[m0 ? c0 : c1] : 0;
+            // the wave's diagonal in this column: that of its first lane with an entry
+            const unsigned long long have = __builtin_amdgcn_ballot_w64(any);
+            const int du = have ? __builtin_amdgcn_readlane(d, __ffsll((long long)have) - 1) : 0;
+            bad |= any && (!pair || d != du);
+            const bool nearcol = du >= mp.lo && du <= mp.hi;
+            const int slot = (mp.nfar > 0 && du == mp.far0) ? 0 : (mp.nfar > 1 && du == mp.far1) ? 1 : -1;
+            bad |= have && !nearcol && slot < 0;
+            um[j] = __builtin_amdgcn_readfirstlane(nearcol ? -1 : 0);   // an integer in one scalar register, not a condition the optimiser re-derives per slice
+            cj[j] = nearcol ? (int)lane_b + (du - mp.lo_e) * VB : farb + (slot > 0 ? SLB : 0) + (int)lane_b;
+            v0[j] = __builtin_amdgcn_ballot_w64(m0); v1[j] = __builtin_amdgcn_ballot_w64(m1);
+            a0[j] = s_value[m0 ? (vword & 255u) : 255u];           // entry 255 is 0.0
+            a1[j] = s_value[m1 ? ((vword >> 8) & 255u) : 255u];
+        }
+        slow = __builtin_amdgcn_ballot_w64(bad) != 0;
+    };
+    decode();
+    int b = 0;                                                // ring position of the window of slice k
+
+    // what arrived during slice k - 1 goes into the slot slice k - 1 has left (and into the mirror if that slot is mirrored);
+    // this slice's far elements go into the lane's own slots
+    auto park = [&](bool far) {
+        int wb = b + SLB + spanb; if (wb >= capb) wb -= capb;
+        *reinterpret_cast<V2 *>(s_march + wb + lane_b) = chunk;
+        if (wb < spanb) *reinterpret_cast<V2 *>(s_march + capb + wb + lane_b) = chunk;
+        if (far) {
+            *reinterpret_cast<V2 *>(s_march + farb + lane_b) = f0;
+            *reinterpret_cast<V2 *>(s_march + farb + SLB + lane_b) = f1;
+        }
+    };
+    auto body = [&](V (&sum)[2]) {
+        V2 p[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const V *q = reinterpret_cast<const V *>(s_march + (cj[j] + (b & um[j])));   // b & um: scalar -- the window base for ring columns, 0 for far slots
+            p[j].x = q[0]; p[j].y = q[1];                        // one ds_read2: the pair is adjacent, also across the end of the ring (mirror)
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            // what a padding entry "covers" is replaced by a number with a zero exponent field (its matrix value is +0):
+            // sum + (+0) == sum, whatever x holds there
+            sum[0] += a0[j] * masked_hi<V>(p[j].x, v0[j]);
+            sum[1] += a1[j] * masked_hi<V>(p[j].y, v1[j]);
+        }
+    };
+
+    // ---- the hot loop: code block unchanged, everything inside x and y -- straight-line slices.  With far diagonals it always
+    // carries two (a matrix with one: the second slot repeats the first) ----
+    int k = 0;
+    auto hot = [&](auto far_tag) {
+        constexpr bool FAR = decltype(far_tag)::value;
+        const char *xc = reinterpret_cast<const char *>(x + (i00 + (long long)(k + 2) * S8_ROWS + hi2));   // uniform running pointers
+        const char *xf0 = reinterpret_cast<const char *>(x + (i00 + (long long)(k + 1) * S8_ROWS + mp.far0));
+        const char *xf1 = reinterpret_cast<const char *>(x + (i00 + (long long)(k + 1) * S8_ROWS + (mp.nfar > 1 ? mp.far1 : mp.far0)));
+        char *ys = reinterpret_cast<char *>(y + (i00 + (long long)k * S8_ROWS));
+        // how many of the next slices keep this code block: one look at blocks[] per entry, no scalar load inside the loop
+        // (a scalar load in flight turns every partial wait for the LDS reads into a full one)
+        int kstop;
+        {
+            const int l = t & 63, left = kend - k;
+            const bool same = l < left && blocks[first + k + l] == cur;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(same);
+            const int len = ~m ? __builtin_ctzll(~m) : 64;           // >= 1: the caller has checked slice k
+            kstop = k + len;
+        }
+        do {
+            unsigned lb = lane_b;
+            asm volatile("" : "+v"(lb));                      // extended to 64 bits HERE: scalar base + lane offset addressing
+            park(FAR);
+            __builtin_memcpy(&chunk, xc + lb, sizeof(V2));
+            if (FAR) { __builtin_memcpy(&f0, xf0 + lb, sizeof(V2)); __builtin_memcpy(&f1, xf1 + lb, sizeof(V2)); }
+            V sum[2] = {V(0), V(0)};
+            body(sum);
+            V2 *yp = reinterpret_cast<V2 *>(ys + lb);
+            V2 o; o.x = alpha * sum[0]; o.y = alpha * sum[1];
+            if (append) { const V2 old = *yp; o.x = old.x + o.x; o.y = old.y + o.y; }
+            __builtin_nontemporal_store(o, yp);               // y is written once and not re-read by this kernel
+            b += SLB; if (b >= capb) b -= capb;
+            xc += SLB; xf0 += SLB; xf1 += SLB; ys += SLB; ++k;
+            __syncthreads();              // slice k is done with the ring: its oldest 512 elements may be overwritten
+        } while (k < kstop);
+    };
+    while (k < count) {
+        if (k >= kA && k < kend && !slow && blocks[first + k] == cur) {
+            if (mp.nfar > 0) hot(std::true_type{}); else hot(std::false_type{});
+            continue;
+        }
+        // ---- a general slice: clamped loads, rows checked against n, the code block decoded if it is a new one ----
+        const auto *c = cold();
+        const long long i0 = i00 + (long long)k * S8_ROWS;
+        park(mp.nfar > 0);
+        if (k + 2 < count) chunk = load512(i0 + 2 * S8_ROWS + hi2);
+        if (k + 1 < count) {
+            if (mp.nfar > 0) f0 = load512(i0 + S8_ROWS + mp.far0);
+            if (mp.nfar > 1) f1 = load512(i0 + S8_ROWS + mp.far1);
+        }
+        const int blk = blocks[first + k];
+        const char *pool = c->pool;
+        if (blk != cur) {                                        // uniform: a new code block -- load and decode it
+            cur = blk;
+            const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
+#pragma unroll
+            for (int u = 0; u < 2 * WP; ++u) cwv[u] = cw[u * 256];
+            decode();
+        }
+        V sum[2] = {V(0), V(0)};
+        const long long i = i0 + 2 * t;
+        if (!slow) body(sum);
+        else {
+            const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
+#pragma unroll 1
+            for (int j = 0; j < W; ++j) {
+                const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned code = (cword >> (8 * q)) & 255u;
+                    if (code < S8_PAD_UNSAFE) sum[q] += s_value[(vword >> (8 * q)) & 255u] * x[i + q + s_delta[code]];
+                }
+            }
+        }
+        const long long n = c->n;
+        if (const int *csr_ptr = c->csr_ptr) {
+            const int *csr_col = c->csr_col; const V *csr_val = c->csr_val;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (i + q < n)
+                    for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+        }
+        store_pair<V>(n, i, alpha, append, sum, y);
+        b += SLB; if (b >= capb) b -= capb;
+        ++k;
+        __syncthreads();
+    }
+}
+
 // distinct value bit patterns of the ELL part: gset = HASH_SLOTS words (all-ones = empty), info as delta_collect_kernel
 template <typename B>
 __device__ __forceinline__ bool vset_insert(B *set, int slots, B v, bool *is_new) {
@@ -944,24 +1227,54 @@ void csr_delta_count_kernel(long long n, int w, int ndeltas, const P *__restrict
     if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
+/// LDS of the march product: ring (span + 2 slices) + mirror (span) + one slice per far diagonal.
+inline long long march_span_bytes(int lo, int hi, int value_bytes) {
+    const long long slb = (long long)S8_ROWS * value_bytes;
+    const long long lo_e = (long long)lo & ~1ll, hi_e = ((long long)hi + 1) & ~1ll;
+    return ((hi_e - lo_e) * value_bytes + slb - 1) / slb * slb;
+}
+inline long long march_lds_bytes(int lo, int hi, int value_bytes) {
+    const long long slb = (long long)S8_ROWS * value_bytes;
+    return 2 * march_span_bytes(lo, hi, value_bytes) + 4 * slb + 1024 + 256 * value_bytes;      // ring + mirror, two far slots, diagonal and value tables
+}
+
 template <typename V>
 int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int append, int w, const int *deltas, const V *values,
         const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr, const char *pool, const int *blocks,
         const vexhip_march *m)
 {
-    const int lo_e = m->lo & ~1, hi_e = (m->hi + 1) & ~1;                 // window bounds on even elements (16-byte ring accesses)
-    int cap = 1024;
-    while (cap < S8_ROWS + hi_e - lo_e + S8_ROWS) cap <<= 1;
-    VEXHIP_REQUIRE(m->lo <= 0 && m->hi >= 0 && m->run >= 1 && m->nfar >= 0 && m->nfar <= 2 && (size_t)cap * sizeof(V) <= 64 * 1024, "bad march plan");
+    VEXHIP_REQUIRE(m->lo <= 0 && m->hi >= 0 && m->run >= 1 && m->nfar >= 0 && m->nfar <= 2, "bad march plan");
     const bool strips = tr && tr->grid_blocks > 0 && tr->chunk > 0;
     VEXHIP_REQUIRE(!strips || tr->chunk % m->run == 0, "march run does not divide the strip length");
     const long long grid = strips ? tr->grid_blocks / m->run : (ns + m->run - 1) / m->run;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
-    const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
-    const size_t lds = (size_t)cap * sizeof(V) + 16 + 2 * S8_ROWS * sizeof(V);       // ring + copy of its first element + two far slots
+    const int lo_e = m->lo & ~1;                                           // window bounds on even elements (16-byte ring accesses)
+    if (g_sell8_variant == 3) {                                            // the first form (power-of-two ring), kept for A/B runs
+        const int hi_e = (m->hi + 1) & ~1;
+        int cap = 1024;
+        while (cap < S8_ROWS + hi_e - lo_e + S8_ROWS) cap <<= 1;
+        VEXHIP_REQUIRE((size_t)cap * sizeof(V) <= 64 * 1024 - 16 - 2 * S8_ROWS * sizeof(V), "bad march plan");
+        const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
+        const size_t lds = (size_t)cap * sizeof(V) + 16 + 2 * S8_ROWS * sizeof(V);   // ring + copy of its first element + two far slots
 #define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
+        switch (w) {
+            MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
+            default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
+        }
+#undef MARCH
+        VEXHIP_LAUNCH_CHECK();
+        return 0;
+    }
+    const long long span_b = march_span_bytes(m->lo, m->hi, (int)sizeof(V));
+    long long lds = march_lds_bytes(m->lo, m->hi, (int)sizeof(V));
+    VEXHIP_REQUIRE(lds <= 64 * 1024, "bad march plan: window too large");
+    static const long long lds_floor = [] { const char *e = std::getenv("VEXHIP_MARCH_LDS"); return e ? std::atoll(e) : 0ll; }();   // experiments: fewer workgroups per CU
+    if (lds_floor > lds && lds_floor <= 64 * 1024) lds = lds_floor;
+    const march2_dev mp = {m->lo, m->hi, lo_e, (int)span_b, (int)(span_b + 2 * S8_ROWS * (long long)sizeof(V)), m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
+    const march_cold<V> cold = {(long long)n, ns, deltas, values, cp, cc, cv, pool, t8};
+#define MARCH(W) case W: sell8_march2_kernel<V, W><<<(unsigned)grid, 256, (size_t)lds, s>>>(cold, alpha, append, x, y, blocks, mp); break;
     switch (w) {
         MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
         default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
@@ -1225,7 +1538,7 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     const trav_dev t8 = make_traversal(tr, ns, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
-    if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
+    if (march && blocks && w <= 8 && (g_sell8_variant == 0 || g_sell8_variant == 3) && !(tr && tr->order))
         return march_launch<V>(dev, s, n, ns, alpha, append, (int)w, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);
 #define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, b, blocks)
 #define CASE(W) case W: if (g_sell8_variant != 1 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \
@@ -1500,16 +1813,15 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
     int64_t changes = 0;
     for (int64_t k = 1; k < nslices; ++k) changes += id[(size_t)k] != id[(size_t)k - 1];
     if (changes * 2 > nslices) return 0;
-    // near diagonals: as many as a ring of <= 32 KiB holds (two slices + the span of the diagonals), grown from 0 outwards
-    const int max_elems = (int)(32 * 1024 / value_bytes);
+    // near diagonals: as many as 48 KiB of LDS hold (ring + mirror + two far slots + tables: three workgroups per CU; the 512^3 Poisson
+    // matrix needs 35 KiB: four), grown from 0 outwards
     int lo = 0, hi = 0;
     std::vector<int> by_abs(table);
     std::sort(by_abs.begin(), by_abs.end(), [](int a, int b) { return std::llabs((long long)a) < std::llabs((long long)b); });
     for (int dlt : by_abs) {
         const int nlo = std::min(lo, dlt), nhi = std::max(hi, dlt);
-        const long long span = 2ll * S8_ROWS + (((long long)nhi + 1) & ~1ll) - ((long long)nlo & ~1ll);
-        long long cap = 1024; while (cap < span) cap <<= 1;
-        if (cap > max_elems) break;
+        if ((long long)nhi - nlo > (1 << 20) || march_lds_bytes(nlo, nhi, value_bytes) > 48 * 1024) break;
+        if (march_span_bytes(nlo, nhi, value_bytes) / value_bytes + S8_ROWS > 2048) break;       // the first window: <= 4 pairs per lane
         lo = nlo; hi = nhi;
     }
     int run = 32;                                       // 8 / 16 / 32 / 64: 0.69 / 0.63 / 0.59 / 0.61 ms (v4), 0.60 / 0.554 / 0.550 from 16 up (v6): the prologue of a run costs about a slice
