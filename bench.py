@@ -641,13 +641,31 @@ def main():
             out["setup"] = setup
         if storage == "sell8v" and dict_blocks and march:
             # the march product: the near diagonals' window of x comes once per slice (8 B/row + the overlap of a run's first
-            # window), the two far diagonals are gathered (16 B/row), y is stored (8 B/row); codes are decoded once per run
+            # window), the two far diagonals come as two more coalesced streams (16 B/row), y is stored (8 B/row); codes are
+            # decoded once per run.  HBM sees x and y once -- the traffic of a copy of x to y, timed here for comparison.
             l1_bytes = (8 + 16 + 8) * rows_rank
             out["roofline"]["on_chip"] = {
-                "what": "bytes through L1 per launch: window 8 B/row + far diagonals 16 B/row + y 8 B/row; HBM sees x and y once; the "
-                        "kernel is bound by instruction issue and LDS latency (profiles/r03_sq_summary_march_v6.txt), not by bytes",
+                "what": "bytes through L1 per launch: window 8 B/row + far diagonals 16 B/row + y 8 B/row; HBM sees x and y once; "
+                        "with four workgroups per CU the memory system is saturated (profiles/r03_sq_summary_march_v8.txt, DESIGN.md 3.0b)",
                 "bytes_per_launch": l1_bytes, "achieved": round(l1_bytes / kern_s / 1e9, 1), "peak_l2": 34500.0, "unit": "GB/s",
                 "frac_of_l2": round(l1_bytes / kern_s / 1e9 / 34500.0, 4)}
+            try:
+                yc = torch.empty_like(x)
+                for _ in range(10):
+                    yc.copy_(x)
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(20):
+                    yc.copy_(x)
+                c1.record(); torch.cuda.synchronize()
+                copy_s = c0.elapsed_time(c1) / 20 / 1e3
+                out["roofline"]["device_copy"] = {
+                    "what": "torch's copy of x to y on this device, same process: the same HBM traffic as the product (x once, y once)",
+                    "ms": round(copy_s * 1e3, 5), "gbps": round(2 * x.numel() * x.element_size() / copy_s / 1e9, 1),
+                    "copy_over_product": round(copy_s / kern_s, 4)}
+                del yc
+            except Exception as e:  # noqa: BLE001 -- a comparison, not the measurement
+                out["roofline"]["device_copy"] = {"error": str(e)[:200]}
         elif storage == "sell8v" and dict_blocks:
             # not HBM-bound any more: what the kernel pulls through L1 per product (ELL width 7: seven 16-byte x gathers per
             # lane and row pair = 56 B/row, 16 B/row of codes from the pooled blocks, 8 B/row stored), against the L2 rate

@@ -43,9 +43,9 @@ torch.cuda.empty_cache()
 out = {"grid": n, "library": os.environ.get("VEXHIP_LIBRARY", "default"), "march": A.march, "ms": {}}
 L.spmv_sell8_set_variant(2)
 A.apply(x, yref)
-names = {2: "pair", 3: "march_v7", 0: "march_v8"}
+names = {2: "pair", 0: "march"}
 for rnd in range(3):
-    for var in (2, 3, 0):
+    for var in (2, 0):
         L.spmv_sell8_set_variant(var)
         y.zero_()
         A.apply(x, y)

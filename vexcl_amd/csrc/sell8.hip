@@ -489,24 +489,38 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
 }
 
 // ---------------------------------------------------------------------------
-// MARCH kernels (round 3): the pair product with the x window of a slice staged in LDS and carried from slice to slice.
+// The MARCH product (round 3): the pair product with the x window of a slice staged in LDS and carried from slice to slice.
 //
 // With its codes on chip (slice dictionary) the pair kernel is bound by what it pulls through L1: seven 16-byte gathers
-// per lane and slice, 195 L1 accesses per wave, TA busy 70 % (profiles/r02_sq_summary.txt) -- 0.72 ms against 0.34 ms for
-// x and y alone.  But the NEAR diagonals of a banded matrix (|d| <= ~1000: the -n, -1, 0, +1, +n taps of a grid operator)
-// read one contiguous window of x per slice, x[i0 + lo .. i0 + 511 + hi], and the window of the NEXT slice is the same
-// window moved by 512 elements.  So a workgroup owns a RUN of consecutive slices and keeps that window in an LDS ring:
-//   per slice ONE coalesced 16-byte load per lane brings the 512 new elements (issued one slice ahead, written into the
-//   ring slot the previous slice has left), the near columns are served by ds_read_b128 / ds_read_b64, and only the FAR
-//   diagonals (+-n^2) still gather from global memory -- 4 vector-memory instructions per lane and slice instead of 18.
-//   The codes of a slice are decoded again only when its block number differs from the previous slice's.
-// Everything is still driven by the codes: a column is looked up in the diagonal table, near -> ring, far -> global, per
-// lane; same products, same order => bit-identical to the pair kernel (tests/test_gpu_spmv.py).  The host picks this
-// kernel when the matrix has a slice dictionary whose block numbers rarely change from slice to slice and the near
-// diagonals fit a ring of <= 32 KiB (vexhip_sell8_march_plan); otherwise the pair kernel runs as before.
+// per lane and slice, 195 L1 accesses per wave, TA busy 70 % (profiles/r02_sq_summary.txt) -- 0.70 ms against 0.42 ms for a
+// plain copy of x to y.  But the NEAR diagonals of a banded matrix (|d| <= ~1000: the -n, -1, 0, +1, +n taps of a grid
+// operator) read one contiguous window of x per slice, x[i0 + lo .. i0 + 511 + hi], and the window of the NEXT slice is the
+// same window moved by 512 elements.  So a workgroup owns a RUN of consecutive slices and keeps that window in an LDS ring:
+//   per slice ONE coalesced 16-byte load per lane brings the 512 new elements (requested one slice ahead, written into the
+//   ring slot the previous slice has left), the FAR diagonals (+-n^2: up to two) are requested one slice ahead the same way
+//   and parked in lane-private LDS slots, and every column of the slice is one LDS read at "base + position".
+//   The codes of a slice are decoded again only when its block number differs from the previous slice's: per lane the two
+//   matrix values, per wave the lane masks of the valid entries and where each column reads.
+// Everything is still driven by the codes; same products, same order => bit-identical to the pair kernel and to the host
+// loop over the CSR arrays (tests/test_gpu_spmv.py).  The host picks this kernel when the matrix has a slice dictionary whose block numbers
+// rarely change from slice to slice and the near diagonals fit the LDS budget (vexhip_sell8_march_plan); otherwise the pair
+// kernel runs as before.
+//
+// History at 512^3 (profiles/r03_march_ab_v*.json, r03_march2_*.json; pair kernel 0.69-0.72 ms, torch's copy of x to y 0.423 ms
+// on the same boxes):
+//   v1  decode per slice as the pair kernel does, far diagonals gathered                                    0.674 ms
+//   v2  + far diagonals one slice ahead into registers (114 registers)                                      0.84
+//   v3  + the frontier lines touched 1..16 slices ahead instead                                             0.78-0.86
+//   v4  decode hoisted out of the slice loop                                                                0.589
+//   v6  straight-line slice: one ds_read2 per column, far diagonals parked in LDS                           0.550
+//   v7  lane masks in scalar registers                                                                      0.547   (150 vector + 91 scalar instructions per wave and slice)
+//   v8  this kernel: mirrored ring (one add per column address), high-word masks, a hot loop without bounds arithmetic
+//       or scalar loads, arguments of the cold paths read from the kernarg segment where they are used              0.484   (83 + 43)
+//       + the prologue of a run as ONE batch of loads                                                       0.466
+// At 0.466 ms the memory system is saturated: requests two slices ahead change nothing with four workgroups per CU (0.465) and
+// help with three (0.493 -> 0.480) or two (0.605 -> 0.555); the product moves 2.37 GB (PMC; 2.15 priced) at 5.1 TB/s, the rate
+// at which the same box copies x to y.
 // ---------------------------------------------------------------------------
-struct march_dev { int lo, hi, lo_e, hi_e, mask, run, nfar, far0, far1; long long x_last; };
-
 __device__ __forceinline__ void march_run(const trav_dev &t, long long nblocks, int R, unsigned mb, long long &first, int &count) {
     long long c;
     if (t.chunk > 0) {       // strip order (traversal.hpp) in runs of R slices: R divides the strip length
@@ -536,201 +550,33 @@ __device__ __forceinline__ typename vec2<V>::type load_pair_clamped(const V *__r
     return v;
 }
 
-// v for the lanes of `lanes`, +0 elsewhere: v_cndmask with the lane mask taken straight from a scalar register pair (the
-// compiler, given a bool per lane, keeps it in a vector register and rebuilds the mask with two instructions per use)
-template <typename V> __device__ __forceinline__ V masked(V v, unsigned long long lanes);
-template <> __device__ __forceinline__ double masked<double>(double v, unsigned long long lanes) {
-    unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32), rlo, rhi;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rlo) : "v"(lo), "s"(lanes));
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"(hi), "s"(lanes));
-    return __longlong_as_double((long long)(((unsigned long long)rhi << 32) | rlo));
-}
-template <> __device__ __forceinline__ float masked<float>(float v, unsigned long long lanes) {
-    unsigned r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(__float_as_uint(v)), "s"(lanes));
-    return __uint_as_float(r);
-}
-
-// Value-coded storage with a slice dictionary only: with stored values the product is bound by the value stream and the
-// pair kernel already moves it at 0.9 of the copy rate (a first version of this kernel with stored values: 1.85 against
-// 1.69 ms, profiles/r03_march_ab.json).
-//
-// What bounds it (profiles/r03_sq_summary.txt, tools/r03_march_ablate.py): instruction issue and exposed LDS latency, not
-// bytes.  Version by version at 512^3, pair kernel 0.69 ms on the same box:
-//   decode per slice as the pair kernel does (extract two codes per column, compare, three table look-ups, select) 0.67 ms;
-//   + far diagonals requested one slice ahead into registers (114 registers, 4 workgroups per CU)                    0.84 ms;
-//   + the 32 frontier lines of slice k + 1..16 touched ahead of time instead                                          0.78-0.86 ms;
-//   decode hoisted out of the slice loop (per lane: the two values and validities per column; per column a branch on
-//   where x comes from)                                                                                               0.59 ms
-//     -- 161 vector + 140 scalar instructions per wave and slice, waves parked 60 % of their life: the per-column branches
-//     keep the seven LDS reads of a slice from being in flight together.
-// Hence the form below: when the code block of a slice equals the previous slice's, a slice is STRAIGHT-LINE code -- per
-// column one address (three vector instructions), ONE LDS read of the lane's pair (ds_read2: the two elements of a pair
-// are adjacent for either parity of the diagonal; the ring carries a copy of its first element behind its last), a masked
-// multiply-add per row.  Far diagonals go the same way: their elements for the next slice are requested one slice ahead
-// into registers and parked in a lane-private LDS slot, so that every column is "an LDS read at base + position".
-// That form needs every lane of the wave with an entry in column j to sit on the same diagonal (true wherever the rows of
-// a slice are rows of one stencil; lanes at the boundary hold padding there); a wave where that fails -- or that meets a
-// far diagonal beyond the two prefetched ones -- takes a compact per-entry loop for that code block.
-template <typename V, int W>
-__global__ __launch_bounds__(256)
-void sell8_march_kernel(long long n, long long nslices, V alpha, int append,
-        const int *__restrict__ deltas, const V *__restrict__ values,
-        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
-        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const char *__restrict__ pool, const int *__restrict__ blocks, march_dev mp)
-{
-    constexpr int WP = (W + 1) / 2;
-    constexpr long long CODE_BYTES = (long long)WP * 2048;
-    constexpr int VB = (int)sizeof(V);
-    constexpr int SLB = S8_ROWS * VB;                          // bytes of x per slice
-    typedef typename vec2<V>::type V2;
-    extern __shared__ __align__(16) unsigned char s_ring_raw[];
-    unsigned char *ringb = s_ring_raw;                        // [ring: cap elements][copy of element 0, padded to 16 B][far 0: 512][far 1: 512]
-    __shared__ int s_delta[256];
-    __shared__ V s_value[256];
-
-    const int t = threadIdx.x;
-    long long first; int count;
-    march_run(trav, nslices, mp.run, blockIdx.x, first, count);
-    if (count <= 0) return;                                   // the whole workgroup: holes of the strip order
-    s_delta[t] = deltas[t];
-    s_value[t] = values[t];
-
-    const int capb = (mp.mask + 1) * VB, maskb = capb - 1;    // ring size in bytes
-    const int farb = capb + 16;                               // where the far slots start
-    const long long i00 = first * S8_ROWS;
-    const long long g0 = i00 + mp.lo_e;                       // the element at ring position 0
-    const int lane_b = 2 * t * VB;
-    // one aligned pair per lane of the 512 elements starting at x[gb] (gb uniform): unconditional when they all exist
-    auto load512 = [&](long long gb) -> V2 {
-        if (gb >= 0 && gb + S8_ROWS - 1 <= mp.x_last) { V2 v; __builtin_memcpy(&v, x + gb + 2 * t, sizeof(V2)); return v; }
-        return load_pair_clamped<V>(x, gb + 2 * t, mp.x_last);
-    };
-    auto ring_put = [&](int pb, V2 v) {                       // pb: masked byte position of an aligned pair
-        *reinterpret_cast<V2 *>(ringb + pb) = v;
-        if (pb == 0) *reinterpret_cast<V *>(ringb + capb) = v.x;
-    };
-    // the window of the first slice, x[i00 + lo_e .. i00 + 512 + hi_e); in registers: the 512 elements the second slice adds
-    // and the far diagonals of the first slice
-    const int wpairs = (S8_ROWS + mp.hi_e - mp.lo_e) / 2;
-    for (int p = t; p < wpairs; p += 256) ring_put((2 * p * VB) & maskb, load_pair_clamped<V>(x, g0 + 2 * p, mp.x_last));
-    V2 chunk = {V(0), V(0)}, f0 = {V(0), V(0)}, f1 = {V(0), V(0)};
-    if (count > 1) chunk = load512(i00 + S8_ROWS + mp.hi_e);
-    if (mp.nfar > 0) f0 = load512(i00 + mp.far0);
-    if (mp.nfar > 1) f1 = load512(i00 + mp.far1);
-    __syncthreads();
-
-    int cur = -1;
-    bool slow = false;                                        // this wave, this block: per-entry loop
-    int ustep[W], umask[W];                                   // uniform per column: the ring (moves SLB per slice, wraps) or a far slot (fixed)
-    int pos[W];                                               // the lane's LDS byte address in column j for the slice at hand
-    V a0[W], a1[W];                                           // the matrix values of the lane's two rows (0 for padding)
-    unsigned long long v0[W], v1[W];                          // uniform: the lanes whose row 2t / 2t + 1 has an entry in column j (lane masks in scalar registers)
-    for (int k = 0; k < count; ++k) {
-        const long long s = first + k;
-        const long long i0 = s * S8_ROWS;
-        const int kb = k * SLB;
-        // Everything slice k + 1 reads from global memory is requested NOW: the 512 elements it adds to the window (kept in
-        // registers until the ring slot is free) and its far diagonals.  What arrived during slice k - 1 goes into the slot
-        // slice k - 1 has left; this slice's far elements go into the lane's own slots.
-        if (k + 1 < count) ring_put((kb + lane_b + (S8_ROWS + mp.hi_e - mp.lo_e) * VB) & maskb, chunk);
-        if (mp.nfar > 0) *reinterpret_cast<V2 *>(ringb + farb + lane_b) = f0;
-        if (mp.nfar > 1) *reinterpret_cast<V2 *>(ringb + farb + SLB + lane_b) = f1;
-        if (k + 2 < count) chunk = load512(i00 + (long long)(k + 2) * S8_ROWS + mp.hi_e);
-        if (k + 1 < count) {
-            if (mp.nfar > 0) f0 = load512(i0 + S8_ROWS + mp.far0);
-            if (mp.nfar > 1) f1 = load512(i0 + S8_ROWS + mp.far1);
-        }
-        const int blk = blocks[s];
-        if (blk != cur) {                                        // uniform: a new code block -- load and decode it
-            cur = blk;
-            const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-                const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
-                const unsigned c0 = cword & 255u, c1 = (cword >> 8) & 255u;
-                const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE, any = m0 || m1;
-                const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
-                const int d = any ? s_delta[m0 ? c0 : c1] : 0;
-                // the wave's diagonal in this column: that of its first lane with an entry
-                const unsigned long long have = __builtin_amdgcn_ballot_w64(any);
-                const int du = have ? __builtin_amdgcn_readlane(d, __ffsll((long long)have) - 1) : 0;
-                bad |= any && (!pair || d != du);
-                const bool nearcol = du >= mp.lo && du <= mp.hi;
-                const int slot = (mp.nfar > 0 && du == mp.far0) ? 0 : (mp.nfar > 1 && du == mp.far1) ? 1 : -1;
-                bad |= have && !nearcol && slot < 0;
-                ustep[j] = nearcol ? SLB : 0;
-                umask[j] = nearcol ? maskb : -1;
-                pos[j] = nearcol ? ((kb + lane_b + (du - mp.lo_e) * VB) & maskb) : farb + (slot > 0 ? SLB : 0) + lane_b;
-                v0[j] = __builtin_amdgcn_ballot_w64(m0); v1[j] = __builtin_amdgcn_ballot_w64(m1);
-                a0[j] = s_value[m0 ? (vword & 255u) : 255u];          // entry 255 is 0.0
-                a1[j] = s_value[m1 ? ((vword >> 8) & 255u) : 255u];
-            }
-            slow = __builtin_amdgcn_ballot_w64(bad) != 0;
-        }
-        const long long i = i0 + 2 * t;
-        V sum[2] = {V(0), V(0)};
-        if (!slow) {
-            V2 p[W];
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-                const V *q = reinterpret_cast<const V *>(ringb + pos[j]);
-                p[j].x = q[0]; p[j].y = q[1];                        // one ds_read2: the pair is adjacent, the ring's first element is repeated behind its last
-                pos[j] = (pos[j] + ustep[j]) & umask[j];             // where the column's pair sits for the next slice
-            }
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-                // what a padding entry "covers" is replaced by 0 (its matrix value is 0): sum + (+-0) == sum, whatever x holds there
-                sum[0] += a0[j] * masked<V>(p[j].x, v0[j]);
-                sum[1] += a1[j] * masked<V>(p[j].y, v1[j]);
-            }
-        } else {
-            const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * CODE_BYTES) + t;
-#pragma unroll 1
-            for (int j = 0; j < W; ++j) {
-                const unsigned cword = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = cw[(WP + (j >> 1)) * 256] >> (16 * (j & 1));
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const unsigned code = (cword >> (8 * q)) & 255u;
-                    if (code < S8_PAD_UNSAFE) sum[q] += s_value[(vword >> (8 * q)) & 255u] * x[i + q + s_delta[code]];
-                }
-            }
-        }
-        if (csr_ptr) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (i + q < n)
-                    for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
-        }
-        store_pair<V>(n, i, alpha, append, sum, y);
-        __syncthreads();          // slice k is done with the ring: its oldest 512 elements may be overwritten
-    }
-}
-
-// ---------------------------------------------------------------------------
-// The march product, second form (round 3, v8).  The counters of the kernel above said: 150 vector + 91 scalar instructions
-// per wave and slice, the waves issue-bound.  Of those only 28 are arithmetic.  What this form removes:
+// What keeps the instruction count of a slice down (the first seven versions were bound by instruction issue):
 //   * the ring is no power of two but span + 2 slices (span = bytes the near diagonals cover, rounded to whole slices) and
 //     carries a MIRROR of its first `span` bytes behind its end: a column's pair sits at  window base + offset  without a
-//     wrap, the window base is one scalar per slice, a column address is ONE vector add (was: add, and, add);
+//     wrap, the window base is one scalar per slice, a column address is ONE vector add;
 //   * masking only the HIGH word of a double an invalid lane "covers": (+0.0) * (a number whose exponent field is 0) is +0
-//     whatever the low word holds -- one v_cndmask per value instead of two;
+//     whatever the low word holds -- one v_cndmask per value, its lane mask taken straight from a scalar register pair;
 //   * slices whose loads lie inside x and whose rows lie inside y (all but the first / last plane's) take loads and the
-//     store without any per-lane bounds arithmetic: scalar base + lane offset;
-//   * the diagonal and value tables are read from global memory when a code block is decoded (rare) instead of being staged
-//     in LDS by every workgroup: 32 KiB of LDS per workgroup at 512^3 fp64 (ring 16 + mirror 8 + far slots 8) = 5 per CU.
-// Same products in the same order: bit-identical to the kernel above, the pair kernel and the CSR oracle.
-// ---------------------------------------------------------------------------
-struct march2_dev { int lo, hi, lo_e, span_b, cap_b, run, nfar, far0, far1; long long x_last; };
+//     store without any per-lane bounds arithmetic: scalar base + lane offset (the hot loop);
+//   * no scalar load inside the hot loop (one in flight turns every partial wait for the LDS reads into a full one): how
+//     many slices keep the code block is found once, on entry.
+// LDS per workgroup at 512^3 fp64: ring 16 + mirror 8 + far slots 8 + tables 3 = 35 KiB, four workgroups per CU.
+struct march_dev { int lo, hi, lo_e, span_b, cap_b, run, nfar, far0, far1; long long x_last; };
 
+// v for the lanes of `lanes`; elsewhere a number a (+0.0) matrix value multiplies to +0: v_cndmask with the lane mask taken
+// straight from a scalar register pair (the compiler, given a bool per lane, keeps it in a vector register and rebuilds the
+// mask with two instructions per use)
 template <typename V> __device__ __forceinline__ V masked_hi(V v, unsigned long long lanes);
 template <> __device__ __forceinline__ double masked_hi<double>(double v, unsigned long long lanes) {
     unsigned hi = (unsigned)(__double_as_longlong(v) >> 32), rhi;
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"(hi), "s"(lanes));
     return __longlong_as_double((long long)(((unsigned long long)rhi << 32) | (unsigned)__double_as_longlong(v)));
 }
-template <> __device__ __forceinline__ float masked_hi<float>(float v, unsigned long long lanes) { return masked<float>(v, lanes); }
+template <> __device__ __forceinline__ float masked_hi<float>(float v, unsigned long long lanes) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(__float_as_uint(v)), "s"(lanes));
+    return __uint_as_float(r);
+}
 
 // Arguments the hot loop does not touch.  The kernel reads them from its kernarg segment WHERE they are used, through a
 // pointer the optimiser cannot see through (cold()): hoisted to the top they would sit in ~25 scalar registers across the
@@ -743,13 +589,10 @@ struct march_cold {
     const char *pool;
     trav_dev trav;
 };
-#ifndef MARCH2_BOUNDS
-#define MARCH2_BOUNDS __launch_bounds__(256)
-#endif
 template <typename V, int W>
-__global__ MARCH2_BOUNDS
-void sell8_march2_kernel(march_cold<V> cold_args /* first: offset 0 of the kernarg segment; read through cold() only */, V alpha, int append,
-        const V *__restrict__ x, V *__restrict__ y, const int *__restrict__ blocks, march2_dev mp)
+__global__ __launch_bounds__(256)          // 120 registers, four workgroups per CU; (256, 5): 95 registers and 0.54 instead of 0.48 ms
+void sell8_march_kernel(march_cold<V> cold_args /* first: offset 0 of the kernarg segment; read through cold() only */, V alpha, int append,
+        const V *__restrict__ x, V *__restrict__ y, const int *__restrict__ blocks, march_dev mp)
 {
     constexpr int WP = (W + 1) / 2;
     constexpr long long CODE_BYTES = (long long)WP * 2048;
@@ -877,13 +720,13 @@ void sell8_march2_kernel(march_cold<V> cold_args /* first: offset 0 of the kerna
 
     // what arrived during slice k - 1 goes into the slot slice k - 1 has left (and into the mirror if that slot is mirrored);
     // this slice's far elements go into the lane's own slots
-    auto park = [&](bool far) {
+    auto park = [&](bool far, const V2 &c, const V2 &g0, const V2 &g1) {
         int wb = b + SLB + spanb; if (wb >= capb) wb -= capb;
-        *reinterpret_cast<V2 *>(s_march + wb + lane_b) = chunk;
-        if (wb < spanb) *reinterpret_cast<V2 *>(s_march + capb + wb + lane_b) = chunk;
+        *reinterpret_cast<V2 *>(s_march + wb + lane_b) = c;
+        if (wb < spanb) *reinterpret_cast<V2 *>(s_march + capb + wb + lane_b) = c;
         if (far) {
-            *reinterpret_cast<V2 *>(s_march + farb + lane_b) = f0;
-            *reinterpret_cast<V2 *>(s_march + farb + SLB + lane_b) = f1;
+            *reinterpret_cast<V2 *>(s_march + farb + lane_b) = g0;
+            *reinterpret_cast<V2 *>(s_march + farb + SLB + lane_b) = g1;
         }
     };
     auto body = [&](V (&sum)[2]) {
@@ -921,12 +764,13 @@ void sell8_march2_kernel(march_cold<V> cold_args /* first: offset 0 of the kerna
             const int len = ~m ? __builtin_ctzll(~m) : 64;           // >= 1: the caller has checked slice k
             kstop = k + len;
         }
-        do {
+        // one slice: park what was requested for it, request the same for a later slice into the same registers, multiply, store
+        auto slice = [&](V2 &c, V2 &g0, V2 &g1) {
             unsigned lb = lane_b;
             asm volatile("" : "+v"(lb));                      // extended to 64 bits HERE: scalar base + lane offset addressing
-            park(FAR);
-            __builtin_memcpy(&chunk, xc + lb, sizeof(V2));
-            if (FAR) { __builtin_memcpy(&f0, xf0 + lb, sizeof(V2)); __builtin_memcpy(&f1, xf1 + lb, sizeof(V2)); }
+            park(FAR, c, g0, g1);
+            __builtin_memcpy(&c, xc + lb, sizeof(V2));
+            if (FAR) { __builtin_memcpy(&g0, xf0 + lb, sizeof(V2)); __builtin_memcpy(&g1, xf1 + lb, sizeof(V2)); }
             V sum[2] = {V(0), V(0)};
             body(sum);
             V2 *yp = reinterpret_cast<V2 *>(ys + lb);
@@ -936,7 +780,10 @@ void sell8_march2_kernel(march_cold<V> cold_args /* first: offset 0 of the kerna
             b += SLB; if (b >= capb) b -= capb;
             xc += SLB; xf0 += SLB; xf1 += SLB; ys += SLB; ++k;
             __syncthreads();              // slice k is done with the ring: its oldest 512 elements may be overwritten
-        } while (k < kstop);
+        };
+        // (requests two slices ahead instead of one: 0.466 -> 0.465 ms with four workgroups per CU, 0.493 -> 0.480 with three --
+        // with four the memory system is saturated; far diagonals two ahead and the window one: 0.472.  Not built in.)
+        do slice(chunk, f0, f1); while (k < kstop);
     };
     while (k < count) {
         if (k >= kA && k < kend && !slow && blocks[first + k] == cur) {
@@ -946,7 +793,7 @@ void sell8_march2_kernel(march_cold<V> cold_args /* first: offset 0 of the kerna
         // ---- a general slice: clamped loads, rows checked against n, the code block decoded if it is a new one ----
         const auto *c = cold();
         const long long i0 = i00 + (long long)k * S8_ROWS;
-        park(mp.nfar > 0);
+        park(mp.nfar > 0, chunk, f0, f1);
         if (k + 2 < count) chunk = load512(i0 + 2 * S8_ROWS + hi2);
         if (k + 1 < count) {
             if (mp.nfar > 0) f0 = load512(i0 + S8_ROWS + mp.far0);
@@ -1251,30 +1098,14 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
     const int lo_e = m->lo & ~1;                                           // window bounds on even elements (16-byte ring accesses)
-    if (g_sell8_variant == 3) {                                            // the first form (power-of-two ring), kept for A/B runs
-        const int hi_e = (m->hi + 1) & ~1;
-        int cap = 1024;
-        while (cap < S8_ROWS + hi_e - lo_e + S8_ROWS) cap <<= 1;
-        VEXHIP_REQUIRE((size_t)cap * sizeof(V) <= 64 * 1024 - 16 - 2 * S8_ROWS * sizeof(V), "bad march plan");
-        const march_dev mp = {m->lo, m->hi, lo_e, hi_e, cap - 1, m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
-        const size_t lds = (size_t)cap * sizeof(V) + 16 + 2 * S8_ROWS * sizeof(V);   // ring + copy of its first element + two far slots
-#define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, lds, s>>>(n, ns, alpha, append, deltas, values, cp, cc, cv, x, y, t8, pool, blocks, mp); break;
-        switch (w) {
-            MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
-            default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
-        }
-#undef MARCH
-        VEXHIP_LAUNCH_CHECK();
-        return 0;
-    }
     const long long span_b = march_span_bytes(m->lo, m->hi, (int)sizeof(V));
     long long lds = march_lds_bytes(m->lo, m->hi, (int)sizeof(V));
     VEXHIP_REQUIRE(lds <= 64 * 1024, "bad march plan: window too large");
     static const long long lds_floor = [] { const char *e = std::getenv("VEXHIP_MARCH_LDS"); return e ? std::atoll(e) : 0ll; }();   // experiments: fewer workgroups per CU
     if (lds_floor > lds && lds_floor <= 64 * 1024) lds = lds_floor;
-    const march2_dev mp = {m->lo, m->hi, lo_e, (int)span_b, (int)(span_b + 2 * S8_ROWS * (long long)sizeof(V)), m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
+    const march_dev mp = {m->lo, m->hi, lo_e, (int)span_b, (int)(span_b + 2 * S8_ROWS * (long long)sizeof(V)), m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
     const march_cold<V> cold = {(long long)n, ns, deltas, values, cp, cc, cv, pool, t8};
-#define MARCH(W) case W: sell8_march2_kernel<V, W><<<(unsigned)grid, 256, (size_t)lds, s>>>(cold, alpha, append, x, y, blocks, mp); break;
+#define MARCH(W) case W: sell8_march_kernel<V, W><<<(unsigned)grid, 256, (size_t)lds, s>>>(cold, alpha, append, x, y, blocks, mp); break;
     switch (w) {
         MARCH(1) MARCH(2) MARCH(3) MARCH(4) MARCH(5) MARCH(6) MARCH(7) MARCH(8)
         default: return fail(__FILE__, __LINE__, "march kernels cover ELL widths 1..8");
@@ -1538,7 +1369,7 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     const trav_dev t8 = make_traversal(tr, ns, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
-    if (march && blocks && w <= 8 && (g_sell8_variant == 0 || g_sell8_variant == 3) && !(tr && tr->order))
+    if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
         return march_launch<V>(dev, s, n, ns, alpha, append, (int)w, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);
 #define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, b, blocks)
 #define CASE(W) case W: if (g_sell8_variant != 1 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \
