@@ -321,6 +321,28 @@ TEST_CASE(by_key_single_pass_against_three_phases) {
     vex::exclusive_scan_by_key(K, L, OL); vex::copy(OL, gl); CHECK(gl == le);
 }
 
+// reduce_by_key takes the size its outputs already have as the likely number of runs and does ONE pass (scan_by_key.hpp,
+// sbk::run); a wrong guess -- more runs than the outputs hold, or fewer -- must cost a second pass, never a wrong result
+TEST_CASE(reduce_by_key_reuses_outputs_of_any_size) {
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    const size_t n = 300007;
+    vex::vector<int> OK; vex::vector<double> OV;
+    const int run_lengths[] = {64, 64, 7, 7, 1000, 1, 64, 300007};
+    for (int len : run_lengths) {
+        std::vector<int> k(n); std::vector<double> v(n);
+        for (size_t i = 0; i < n; ++i) { k[i] = int(i / size_t(len)) * 3 - 11; v[i] = double(int(i % 23) - 11) * 0.25; }
+        std::vector<int> uk; std::vector<double> us;
+        for (size_t i = 0; i < n; ++i) { if (i == 0 || k[i - 1] != k[i]) { uk.push_back(k[i]); us.push_back(v[i]); } else us.back() += v[i]; }
+        vex::vector<int> K(queue, k); vex::vector<double> V(queue, v);
+        const int runs = vex::reduce_by_key(K, V, OK, OV);
+        CHECK_EQUAL(size_t(runs), uk.size());
+        CHECK_EQUAL(OK.size(), uk.size()); CHECK_EQUAL(OV.size(), uk.size());
+        std::vector<int> gk(uk.size()); std::vector<double> gs(uk.size());
+        vex::copy(OK, gk); vex::copy(OV, gs);
+        CHECK(gk == uk); CHECK(gs == us);
+    }
+}
+
 VEX_FUNCTION(bool, pair_equal, (int, a1)(int, a2)(int, b1)(int, b2), return a1 == b1 && a2 == b2;);
 VEX_FUNCTION(int, int_plus, (int, x)(int, y), return x + y;);
 VEX_FUNCTION(int, int_max, (int, x)(int, y), return x > y ? x : y;);

@@ -52,13 +52,18 @@ int reduce_by_key_sink(const IKTuple &ikeys, const vector<V> &ivals, const OKTup
         ovals.resize(queue, 0);
         return 0;
     }
+    // outputs that already have one common size on this queue: the likely number of runs (see sbk::run)
+    size_t guess = (ovals.nparts() == queue.size() && ovals.size() && ovals.queue_list()[0].id() == queue[0].id()) ? ovals.size() : 0;
+    sbk::for_each_key(okeys, [&](auto &o) {
+        if (o.size() != guess || o.nparts() != queue.size() || (guess && o.queue_list()[0].id() != queue[0].id())) guess = 0;
+    }, seq());
     return sbk::run<sbk::REDUCE>(ikeys, ivals, comp, oper,
             [&](backend::kernel &k, int count) {
                 resize_outputs(okeys, queue, count, seq());
                 size_output(ovals, queue, count);
                 sbk::for_each_key(okeys, [&](auto &o) { k.push_arg(o(0).raw()); }, seq());
                 k.push_arg(ovals(0).raw());
-            }, true);
+            }, true, false, guess);
 }
 
 } // namespace rbk

@@ -321,11 +321,14 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         // over them (aggregate before the look-back, results after it); keys are only needed for the head flags (one bit
         // per element) and, in reduce_by_key, re-read at the run heads.
         s << "#define LBR " << LB_ROWS << "\n"
+             // One 16-wave workgroup per CU: 52 vector registers would allow two, 96 + 6 scalar registers do not (gfx9-family
+             // SIMDs hold 800: seven waves each; 13.4 waves per CU measured, profiles/r03_sq_bykey.txt).  Forcing two with a
+             // second launch bound (8 waves per SIMD) made it slower: 0.61 -> 0.75 ms (scan), 0.46 -> 0.67 ms (reduce_by_key).
              "extern \"C\" __global__ void __launch_bounds__(" << LB_WAVES * 64 << ") vexcl_sbk_lookback(ulong n, " << key_params(true)
           << "const val_t *vals, sbk_word *ws, ";
         if (mode == REDUCE) {
             for (size_t k = 0; k < nk; ++k) s << K[k] << " *okey" << k << ", ";
-            s << "val_t *ovals) {\n";
+            s << "val_t *ovals, int cap) {\n";             // cap: the outputs hold that many runs (the true count goes to ws[1])
         } else {
             s << "val_t *ovals, val_t init) {\n";
         }
@@ -463,11 +466,11 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         } else if (mode == EXCLUSIVE) {
             s << "        ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
         } else {
-            s << "        if (head) {\n";
+            s << "        if (head && fin.c <= cap) {\n";
             for (size_t k = 0; k < nk; ++k) s << "          okey" << k << "[fin.c - 1] = key" << k << "[i];\n";
             s << "          if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
                  "        }\n"
-                 "        if (i == n - 1) ovals[fin.c - 1] = fin.v;\n";
+                 "        if (i == n - 1) { if (fin.c <= cap) ovals[fin.c - 1] = fin.v; ((int *)(ws + 1))[0] = fin.c; }\n";
         }
         s << "        prev = fin;\n"
              "      }\n"
@@ -526,7 +529,7 @@ void for_each_key(const Tuple &t, F &&f, std::index_sequence<I...>) {
 
 /// Runs phases 1 and 2; returns the number of segments.  `finish` then launches phase 3.
 template <scan_mode mode, class KTuple, class V, class Comp, class Oper, class PushOutputs>
-int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&push_outputs, bool need_count, bool three_phases = false) {
+int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&push_outputs, bool need_count, bool three_phases = false, size_t guess = 0) {
     constexpr size_t nk = std::tuple_size<KTuple>::value;
     typedef std::make_index_sequence<nk> seq;
     const auto &queue = ivals.queue_list();
@@ -564,23 +567,38 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
         unsigned long long *ws = reinterpret_cast<unsigned long long *>(wsb.raw());
         backend::check(vexhip_memset(q.device_ordinal(), ws, 0, words * 8, q.raw()));      // ticket, run count, tile states
         int count = 0;
+        int *total = reinterpret_cast<int *>(ws + 1);
+        auto read_total = [&]() { int c = 0; backend::device_vector<int> t = backend::device_vector<int>::wrap(total, 1); t.read(q, 0, 1, &c, true); return c; };
+        auto launch = [&](int cap) {
+            K.lookback.push_arg(n);
+            for_each_key(keys, [&](const auto &k) { K.lookback.push_arg(k(0).raw()); }, seq());
+            K.lookback.push_arg(ivals(0).raw());
+            K.lookback.push_arg(ws);
+            push_outputs(K.lookback, cap);
+            if (mode == REDUCE) K.lookback.push_arg(cap);
+            K.lookback.config(nt, LB_WAVES * 64);
+            K.lookback(q);
+        };
+        if (need_count && guess > 0 && guess < (size_t(1) << 31)) {
+            // The outputs already hold `guess` runs (the previous call on data of this shape): ONE pass that stores what fits
+            // and reports the true count.  Right guess (an iteration that calls this again and again): done -- no keys-only
+            // pass, no read-back between two kernels.  Wrong guess: the count is known now, the pass runs again.
+            launch(static_cast<int>(guess));
+            count = read_total();
+            if (static_cast<size_t>(count) == guess) return count;
+            backend::check(vexhip_memset(q.device_ordinal(), ws, 0, words * 8, q.raw()));
+            launch(count);
+            return count;
+        }
         if (need_count) {
-            int *total = reinterpret_cast<int *>(ws + 1);
             K.count.push_arg(n);
             for_each_key(keys, [&](const auto &k) { K.count.push_arg(k(0).raw()); }, seq());
             K.count.push_arg(total);
             K.count.config(std::min<size_t>((n + 256 * ITEMS - 1) / (256 * ITEMS), size_t(256) * 16), 256);
             K.count(q);
-            backend::device_vector<int> t = backend::device_vector<int>::wrap(total, 1);
-            t.read(q, 0, 1, &count, true);
+            count = read_total();
         }
-        K.lookback.push_arg(n);
-        for_each_key(keys, [&](const auto &k) { K.lookback.push_arg(k(0).raw()); }, seq());
-        K.lookback.push_arg(ivals(0).raw());
-        K.lookback.push_arg(ws);
-        push_outputs(K.lookback, count);
-        K.lookback.config(nt, LB_WAVES * 64);
-        K.lookback(q);
+        launch(count);
         return count;
     }
 
