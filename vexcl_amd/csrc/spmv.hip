@@ -285,6 +285,10 @@ void csr_scalar_kernel(long long n, V alpha, int append,
 // wave because adjacent rows of a banded matrix read adjacent columns.
 // W > 0: compile-time ELL width (fully unrolled, all loads issued before the
 // first dependent gather); W == 0: run-time width.
+// Round 3: pair gathers as in the SELL products (one 16-byte load of x where rows 2t and 2t + 1 hold columns c and c + 1)
+// were tried here and dropped -- 2.586 against 2.534 ms at 512^3 (profiles/r03_hell_ab.json): this layout is bound by its
+// 14 column-plane streams (13.4 GB at 5.3 TB/s), not by its gathers; the slice-local SELL layout moves the same bytes in
+// 2.2-2.3 ms, and no default path uses this kernel (vex::SpMat and vexhip_spmat pick SELL storages).
 // ---------------------------------------------------------------------------
 template <int RPT> struct colvec;
 template <> struct colvec<1> { typedef int   type; };
