@@ -1655,7 +1655,11 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
         if (march_span_bytes(nlo, nhi, value_bytes) / value_bytes + S8_ROWS > 2048) break;       // the first window: <= 4 pairs per lane
         lo = nlo; hi = nhi;
     }
-    int run = 32;                                       // 8 / 16 / 32 / 64: 0.69 / 0.63 / 0.59 / 0.61 ms (v4), 0.60 / 0.554 / 0.550 from 16 up (v6): the prologue of a run costs about a slice
+    // Slices per workgroup.  The prologue of a run costs about two slices (v8b), so long runs -- but a CU holds four workgroups
+    // and wants at least two rounds of them: 512^3 (262 144 slices) run 16 / 32 / 64 = 0.540 / 0.469 / 0.484 ms; 256^3 (32 768
+    // slices, the local matrix of one of eight ranks) run 8 / 16 / 32 = 0.068 / 0.057 / 0.075 ms, pair kernel 0.070.
+    int run = 32;
+    for (const long long want = nslices / (8ll * std::max(1, info(dev).cus)); run > 4 && run > want; ) run >>= 1;
     if (const char *e = std::getenv("VEXHIP_MARCH_RUN")) run = std::max(1, std::atoi(e));
     if (traversal && traversal->grid_blocks > 0 && traversal->chunk > 0) {
         while (run > 1 && traversal->chunk % run != 0) --run;
