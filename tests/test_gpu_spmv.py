@@ -325,6 +325,49 @@ def test_march_product_is_bit_identical(T, oracle, built_lib, run):
         os.environ.pop("VEXHIP_MARCH_RUN", None)
 
 
+def test_march_with_one_far_diagonal_and_narrow_widths(T, oracle, built_lib):
+    """The hot loop of the march product always carries two far slots (a matrix with ONE far diagonal: the second slot
+    repeats the first) or none.  (a) the five-point pattern of a 1024 x 1024 grid: the window takes -1024 .. 1 (three slices
+    of span), +1024 stays far; (b) ELL widths 1 .. 3 (diagonal only; two near; one near + one far); each against the pair
+    product and the CSR oracle bit for bit, '=' and '+= alpha', fp64 and fp32."""
+    torch = T.torch
+    cases = (((-1024, -1, 0, 1, 1024), 1024 * 1024 + 300, (-1024, 1), [1024]),
+             ((0,), 100 * 512 + 9, (0, 0), []),
+             ((-1, 2), 64 * 512, (-1, 2), []),
+             ((0, 40000), 150 * 512 + 100, (0, 0), [40000]))
+    for offs, m, near, far in cases:
+        ptr, col, val = _band(m, offs, 9, constant=True)
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+        assert A.storage == "sell8v" and A.march is not None and B.march is None, (offs, A.march)
+        assert (A.march["lo"], A.march["hi"]) == near and A.march["far"] == far, (offs, A.march)
+        xb = oracle.random_f64(12, m); y0 = oracle.random_f64(13, m)
+        want = oracle.spmv_csr(ptr, col, val, xb)
+        for alpha, append in ((1.0, False), (0.5, True)):
+            ya, yb = T.up(y0.copy()), T.up(y0.copy())
+            A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+            assert torch.equal(ya, yb), (offs, alpha)
+            assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (offs, alpha)
+        v32, x32 = val.astype(np.float32), xb.astype(np.float32)
+        F = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32)); Fp = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), march=False)
+        assert F.march is not None
+        yf = torch.empty(m, dtype=torch.float32, device=T.dev); yp = torch.empty_like(yf)
+        F.apply(T.up(x32), yf); Fp.apply(T.up(x32), yp)
+        assert torch.equal(yf, yp), offs
+    # x that holds NaN / Inf where padding entries "cover" it: rows at the ends of the band must not see them (the masks
+    # clear the high word only -- a product with +0.0 must still be +0.0)
+    offs, m = (-1024, -1, 0, 1, 1024), 200 * 512
+    ptr, col, val = _band(m, offs, 9, constant=True)
+    A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+    xb = oracle.random_f64(14, m)
+    xb[0] = np.inf; xb[1] = -np.inf; xb[m - 1] = np.nan          # rows 0 / 1 / m - 1 read them as real entries; padding must not
+    ya = torch.empty(m, dtype=torch.float64, device=T.dev); yb = torch.empty_like(ya)
+    A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
+    a, b = ya.cpu().numpy(), yb.cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(a, oracle.spmv_csr(ptr, col, val, xb), equal_nan=True)
+    assert np.isfinite(a[2048:m - 2048]).all()
+
+
 def test_march_needs_slices_that_repeat_in_runs(T, built_lib):
     """384^3: a grid line is 384 rows, a slice 512 -- the code blocks of consecutive slices cycle with period 3, every
     slice would decode anew, so the plan declines and the pair product runs (checked against an independent stencil
