@@ -249,13 +249,16 @@ int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha
         const float *x, float *y, const vexhip_traversal *traversal);
 /* March products (round 3): the _dict products with the x window of the NEAR diagonals staged in an LDS ring that a
  * workgroup carries along a run of consecutive slices -- one coalesced load of the 512 new elements per slice instead of
- * one gather per near column; far diagonals (+-n^2 of a 3-D grid operator) still gather.  Replaces, like every SELL
- * product, the per-row gathers of the reference's ELL kernel (vexcl/spmat/hybrid_ell.inl:238-269).  Bit-identical to
- * the _dict products.  vexhip_sell8_march_plan decides from the diagonal table and the slice numbers whether it applies
- * (usable = 0: call the _dict product; value-coded storage only -- with stored values the product is bound by the value
- * stream, which the pair kernel already moves at 0.9 of the copy rate): the code block must rarely change from slice to slice, and the near diagonals
- * (grown from 0 outwards) are those whose window fits a ring of <= 32 KiB.  x_last = largest valid index of x (the
- * fills report the largest ELL column through vexhip_sell8_last_fill_max_col, per thread).                            */
+ * one gather per near column; up to two far diagonals (+-n^2 of a 3-D grid operator) are requested one slice ahead as two
+ * more coalesced streams and parked in LDS, any further one is gathered.  Replaces, like every SELL product, the per-row
+ * gathers of the reference's ELL kernel (vexcl/spmat/hybrid_ell.inl:238-269).  Bit-identical to the _dict products.
+ * vexhip_sell8_march_plan decides from the diagonal table and the slice numbers whether it applies (usable = 0: call the
+ * _dict product; value-coded storage only -- with stored values the product is bound by the value stream, which the pair
+ * kernel already moves at 0.9 of the copy rate): the code block must rarely change from slice to slice, and the near
+ * diagonals (grown from 0 outwards) are those whose ring + mirror + far slots + tables fit 48 KiB of LDS and whose first
+ * window is at most 2048 elements.  run: from the slice count (32 for large matrices; shorter so that a CU sees at least
+ * two rounds of workgroups), VEXHIP_MARCH_RUN overrides.  x_last = largest valid index of x (the fills report the largest
+ * ELL column through vexhip_sell8_last_fill_max_col, per thread).                                                        */
 typedef struct vexhip_march { int32_t lo, hi;      /* smallest / largest NEAR diagonal (lo <= 0 <= hi)                */
                               int32_t run;         /* consecutive slices per workgroup (divides the strip length)     */
                               int32_t usable;
