@@ -321,9 +321,9 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         // over them (aggregate before the look-back, results after it); keys are only needed for the head flags (one bit
         // per element) and, in reduce_by_key, re-read at the run heads.
         s << "#define LBR " << LB_ROWS << "\n"
-             // One 16-wave workgroup per CU: 52 vector registers would allow two, 96 + 6 scalar registers do not (gfx9-family
-             // SIMDs hold 800: seven waves each; 13.4 waves per CU measured, profiles/r03_sq_bykey.txt).  Forcing two with a
-             // second launch bound (8 waves per SIMD) made it slower: 0.61 -> 0.75 ms (scan), 0.46 -> 0.67 ms (reduce_by_key).
+             // One 16-wave workgroup per CU: the kernel takes 104 vector registers (the lane's 16 values, the four row prefixes;
+             // rocprofv3 reports them in pairs: 52).  Forcing two workgroups with a second launch bound (8 waves per SIMD, 64
+             // registers) made it slower: 0.61 -> 0.75 ms (scan), 0.46 -> 0.67 ms (reduce_by_key).
              "extern \"C\" __global__ void __launch_bounds__(" << LB_WAVES * 64 << ") vexcl_sbk_lookback(ulong n, " << key_params(true)
           << "const val_t *vals, sbk_word *ws, ";
         if (mode == REDUCE) {
@@ -333,6 +333,7 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
             s << "val_t *ovals, val_t init) {\n";
         }
         s << "  __shared__ sbk_t agg[LBW];\n"
+             "  __shared__ val_t s_x[sizeof(val_t) == 8 ? LBW : 1][ITEMS * 64] __attribute__((aligned(16)));\n"    // per wave: one row of results on its way out
              "  __shared__ long s_tile;\n"
              "  __shared__ sbk_t s_pre;\n"
              "  sbk_word *status = ws + 2;\n"
@@ -452,9 +453,45 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              // second pass over the lane's values: prev = inclusive prefix of the element before, fin = of the element itself
              "  #pragma unroll\n"
              "  for (int r = 0; r < LBR; ++r) {\n"
-             "    const ulong i0 = wbase + (ulong)r * (64 * ITEMS) + (ulong)lane * ITEMS;\n"
-             "    sbk_t prev = sbk_combine(W, pre[r]);\n"
-             "    #pragma unroll\n"
+             "    const ulong row0 = wbase + (ulong)r * (64 * ITEMS), i0 = row0 + (ulong)lane * ITEMS;\n"
+             "    sbk_t prev = sbk_combine(W, pre[r]);\n";
+        if (mode != REDUCE) {
+            // Full rows: the lane's ITEMS results leave as 16-byte pieces, and for 8-byte values (32 bytes per lane) through a
+            // wave-private LDS row, so that every store instruction of the wave writes 1 KiB of consecutive bytes.  The guarded
+            // loop below stores element by element -- 8-byte pieces at a 32-byte lane stride, 16 store instructions per lane and
+            // tile: with it alone the scan took 0.60 ms per 1e8 (int, double) pairs; 16-byte pieces at a 32-byte stride 0.505;
+            // consecutive pieces 0.474.  (The same detour for the LOADS of the values changed nothing: 0.480.)
+            s << "    if (row0 + 64 * ITEMS <= n && ((ulong)ovals & 15) == 0) {\n"
+                 "      val_t out[ITEMS];\n"
+                 "      #pragma unroll\n"
+                 "      for (int j = 0; j < ITEMS; ++j) {\n"
+                 "        const bool head = (heads >> (r * ITEMS + j)) & 1u;\n"
+                 "        sbk_t x; x.c = head; x.f = 2 | (int)head; x.v = v[r][j];\n"
+                 "        const sbk_t fin = sbk_combine(prev, x);\n";
+            if (mode == INCLUSIVE) s << "        (void)init; out[j] = fin.v;\n";
+            else                   s << "        out[j] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+            s << "        prev = fin;\n"
+                 "      }\n"
+                 "      typedef val_t sbk_vec __attribute__((ext_vector_type(16 / sizeof(val_t))));\n"
+                 "      #define NQ ((int)(ITEMS * sizeof(val_t) / 16))\n"
+                 "      sbk_vec o[NQ];\n"
+                 "      #pragma unroll\n"
+                 "      for (int q = 0; q < NQ; ++q)\n"
+                 "        #pragma unroll\n"
+                 "        for (int e = 0; e < (int)(16 / sizeof(val_t)); ++e) o[q][e] = out[q * (16 / sizeof(val_t)) + e];\n"
+                 "      if (NQ == 1) { ((sbk_vec *)(ovals + row0))[lane] = o[0]; continue; }\n"
+                 "      sbk_vec *sx = (sbk_vec *)s_x[wave];\n"
+                 "      #pragma unroll\n"
+                 "      for (int q = 0; q < NQ; ++q) sx[lane * NQ + q] = o[q];\n"
+                 "      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n"
+                 "      #pragma unroll\n"
+                 "      for (int q = 0; q < NQ; ++q) ((sbk_vec *)(ovals + row0))[q * 64 + lane] = sx[q * 64 + lane];\n"
+                 "      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();\n"
+                 "      #undef NQ\n"
+                 "      continue;\n"
+                 "    }\n";
+        }
+        s << "    #pragma unroll\n"
              "    for (int j = 0; j < ITEMS; ++j) {\n"
              "      const ulong i = i0 + j;\n"
              "      if (i < n) {\n"
