@@ -782,7 +782,8 @@ void sell8_march_kernel(march_cold<V> cold_args /* first: offset 0 of the kernar
             __syncthreads();              // slice k is done with the ring: its oldest 512 elements may be overwritten
         };
         // (requests two slices ahead instead of one: 0.466 -> 0.465 ms with four workgroups per CU, 0.493 -> 0.480 with three --
-        // with four the memory system is saturated; far diagonals two ahead and the window one: 0.472.  Not built in.)
+        // with four the memory system is saturated; far diagonals two ahead and the window one: 0.472; far diagonals loaded
+        // non-temporally (their last use by this workgroup, but not by its neighbours): 0.491.  Not built in.)
         do slice(chunk, f0, f1); while (k < kstop);
     };
     while (k < count) {
