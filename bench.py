@@ -36,6 +36,14 @@ import subprocess
 import sys
 import time
 
+T_START = time.perf_counter()
+
+
+def progress(msg):
+    """rank 0, N > 1: where the run is (stderr) -- a multi-GPU run that stalls must say where"""
+    if os.environ.get("RANK", "0") == "0" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        print("[bench %7.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -345,6 +353,7 @@ def main():
     single = world == 1 and not args.dist
 
     # ---- inputs resident in HBM before the timed region
+    progress("process group up; generating rows [%d, %d) of the %d^3 matrix" % (r0, r1, n))
     ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
     # x is a function of the GLOBAL index, so the job computes the same product for every N
     x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev),
@@ -375,7 +384,9 @@ def main():
             A.ptr = A.col = A.val = None
         step = lambda: A.apply(x, y, 1.0, False)
     else:
+        progress("strip generated; splitting into local / remote parts and planning the exchange")
         A = DistSpMat(ptr, col, val, N, N, local_fmt=args.format)
+        progress("exchange planned; independent evaluation of this rank's rows")
         storage = A.loc.storage
         matrix_bytes = A.loc.matrix_bytes()
         dict_blocks = getattr(A.loc, "dictionary_blocks", 0)
@@ -399,7 +410,13 @@ def main():
                     A.apply(x, y, 1.0, False)
                     torch.cuda.synchronize()
                     d = (y - y_ind).abs()
-                    ok = ok and bool((d <= tol_ind).all())
+                    bad = d > tol_ind
+                    if bool(bad.any()):
+                        ok = False
+                        rows_bad = torch.nonzero(bad).flatten()
+                        print("[bench rank %d] product %d: %d rows outside the tolerance, first local row %d (global %d), last %d; error there %.3e"
+                              % (rank, k, rows_bad.numel(), int(rows_bad[0]), r0 + int(rows_bad[0]), int(rows_bad[-1]), float(d[rows_bad[0]])),
+                              file=sys.stderr, flush=True)
                     worst = max(worst, float(d.max()))
                 st = A.native_status()
                 if st and st["timed_out"]:
@@ -410,25 +427,34 @@ def main():
                 ok = False
             return A._agree(ok), worst
 
-        def trial(steps):
-            """ms per product over `steps` products between barriers (max over the ranks), after a settle run"""
-            for _ in range(50):
-                step()
+        def timed_products(k):
             torch.cuda.synchronize(); barrier()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for _ in range(k):
                 step()
             torch.cuda.synchronize(); barrier()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=A._coll_device())
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.cpu()[0]) / steps * 1e3
+            return float(t.cpu()[0]) / k
+
+        def trial(steps):
+            """ms per product over `steps` products between barriers (max over the ranks), after a settle run.  Both runs are
+            bounded in time by a three-product probe whose result every rank shares (a transport that takes 0.2 s per product
+            -- gloo with all ranks on one device -- must not cost minutes): settle <= 2 s, trial <= 5 s."""
+            probe = max(timed_products(3), 1e-6)
+            settle = int(min(50, 2.0 / probe))
+            steps = int(max(3, min(steps, 5.0 / probe)))
+            for _ in range(settle):
+                step()
+            return timed_products(steps) * 1e3
 
         def barrier():
             if world > 1:
                 dist.barrier()
 
         tried = {}
+        progress("matrix partitioned and converted on %d ranks; validating torch.distributed (%s)" % (world, args.backend))
         ok, worst = validate()
         tried["torch"] = {"valid": ok, "max_abs_err": worst, "what": "torch.distributed batch_isend_irecv (%s), pack and products launched from Python" % args.backend}
         candidates = []
@@ -442,6 +468,7 @@ def main():
                 tried["torch"]["trial_ms_per_step"] = round(trial(args.trial_steps), 5)
         for tr in candidates:
             torch.cuda.synchronize(); barrier()
+            progress("transports so far: %r; trying %s" % ({k: v.get("trial_ms_per_step", v.get("valid")) for k, v in tried.items()}, tr))
             rec = {"valid": False}
             if A.enable_native(transport=tr):
                 rec["valid"], rec["max_abs_err"] = validate()
@@ -461,6 +488,7 @@ def main():
         if not valid:
             raise SystemExit("no ghost-exchange transport reproduces the independent evaluation of the product: %r" % tried)
         chosen = min(valid, key=lambda k: tried[k].get("trial_ms_per_step", 1e30))
+        progress("transport chosen: %s of %r" % (chosen, {k: v.get("trial_ms_per_step", v.get("valid")) for k, v in tried.items()}))
         if chosen != "torch":
             assert A.enable_native(transport=chosen), A.native_error
             ok, _ = validate(1)
@@ -497,7 +525,8 @@ def main():
     # products on every rank bring the devices out of the post-idle transient before the W warm-ups (reported as settle_steps)
     settle_steps = 0
     if not single:
-        settle_steps = 200
+        per_step_ms = tried[chosen].get("trial_ms_per_step", 1.0)          # the same on every rank (all-reduced)
+        settle_steps = int(max(3, min(200, 2000.0 / max(per_step_ms, 1e-3))))
         for _ in range(settle_steps):
             step()
 

@@ -110,7 +110,8 @@ def _worker(rank, world, port, case, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "poisson"), (2, "random_square"), (3, "nonsquare"), (3, "poisson")])
+@pytest.mark.parametrize("world,case", [(2, "poisson"), (2, "random_square"), (3, "nonsquare"), (3, "poisson"), (4, "random_square"),
+                                        (8, "poisson")])
 def test_distributed_spmv_gloo(world, case, oracle):
     ctx = mp.get_context("spawn")
     out = ctx.Array("i", [0] * world)

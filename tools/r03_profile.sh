@@ -9,6 +9,7 @@ cp /tmp/prof_b/b_kernel_stats.csv $OUT/r03_bench_kernel_stats.csv 2>/dev/null
 cd $ROOT
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r03_bench_n1.log 2> $OUT/r03_bench_n1.err
 timeout 600 python bench.py --gpus 2 --one-device --steps 20 --warmup 5 > $OUT/r03_bench_n2_one_device.log 2> $OUT/r03_bench_n2_one_device.err
+timeout 600 python bench.py --gpus 8 --one-device --steps 10 --warmup 3 > $OUT/r03_bench_n8_one_device.log 2> $OUT/r03_bench_n8_one_device.err
 timeout 300 ./examples/build/roofline 1000000000 escpk > $OUT/r03_examples_roofline_cpp.log 2>&1
 timeout 300 ./oracle/_ref/example_benchmark > $OUT/r03_reference_examples_benchmark_cpp.log 2>&1
-tail -c 600 $OUT/r03_bench_n1.log; echo; tail -c 300 $OUT/r03_bench_n2_one_device.log; echo; grep -c row $OUT/r03_examples_roofline_cpp.log; tail -3 $OUT/r03_reference_examples_benchmark_cpp.log
+tail -c 600 $OUT/r03_bench_n1.log; echo; tail -c 300 $OUT/r03_bench_n2_one_device.log; echo; tail -c 300 $OUT/r03_bench_n8_one_device.log; echo; grep -c row $OUT/r03_examples_roofline_cpp.log; tail -3 $OUT/r03_reference_examples_benchmark_cpp.log
