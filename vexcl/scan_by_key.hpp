@@ -243,8 +243,31 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "    const sbk_t last = sbk_combine(W, y[r * ITEMS + ITEMS - 1]);\n"
              "    sbk_t prev = sbk_up(last, 1);\n"
              "    if (lane == 0) prev = before;\n"
-             "    before = sbk_from(last, 63);\n"
-             "    #pragma unroll\n"
+             "    before = sbk_from(last, 63);\n";
+        if (mode != REDUCE && (sizeof(V) == 4 || sizeof(V) == 8)) {
+            // full rows: the lane's ITEMS results leave as 16-byte pieces, not element by element (see vexcl_sbk_lookback)
+            o << "    if (wbase + (ulong)(r + 1) * (64 * ITEMS) <= n && ((ulong)ovals & 15) == 0) {\n"
+                 "      typedef val_t sbk_vec3 __attribute__((ext_vector_type(16 / sizeof(val_t))));\n"
+                 "      val_t out[ITEMS];\n"
+                 "      #pragma unroll\n"
+                 "      for (int j = 0; j < ITEMS; ++j) {\n"
+                 "        const sbk_t fin = sbk_combine(W, y[r * ITEMS + j]);\n"
+                 "        const bool head = fin.c != prev.c;\n";
+            if (mode == INCLUSIVE) o << "        (void)head; (void)init; out[j] = fin.v;\n";
+            else                   o << "        out[j] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+            o << "        prev = fin;\n"
+                 "      }\n"
+                 "      #pragma unroll\n"
+                 "      for (int q = 0; q < (int)(ITEMS * sizeof(val_t) / 16); ++q) {\n"
+                 "        sbk_vec3 t;\n"
+                 "        #pragma unroll\n"
+                 "        for (int e = 0; e < (int)(16 / sizeof(val_t)); ++e) t[e] = out[q * (16 / sizeof(val_t)) + e];\n"
+                 "        ((sbk_vec3 *)(ovals + i0))[q] = t;\n"
+                 "      }\n"
+                 "      continue;\n"
+                 "    }\n";
+        }
+        o << "    #pragma unroll\n"
              "    for (int j = 0; j < ITEMS; ++j) {\n"
              "      const ulong i = i0 + j;\n"
              "      const sbk_t fin = sbk_combine(W, y[r * ITEMS + j]);\n"
