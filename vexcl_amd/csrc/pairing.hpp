@@ -58,12 +58,12 @@ struct diag_global {
     const int *col; long long row, b[2];
     __device__ __forceinline__ long long operator()(int q, int k) const { return (long long)col[b[q] + k] - (row + q); }
 };
-// diagonals of a pair whose first <= 8 columns per row were staged in LDS, entry (q, k) of lane t at s[(q * 8 + k) * 256 + t]
-// (round 3: the fill kernels load a pair's entries with one batch of independent loads instead of walking the CSR arrays
-// entry by entry -- the merge is a chain of dependent look-ups: 23 ms of the 512^3 set-up)
-struct diag_staged {
-    const int *s; int t; long long row;
-    __device__ __forceinline__ long long operator()(int q, int k) const { return (long long)s[(q * 8 + k) * 256 + t] - (row + q); }
+// diagonals of a pair whose rows lie in a piece of the column array that its wave copied into LDS: entry k of row q at
+// s[off[q] + k] (round 3: the fill kernels copy the 128 rows of a wave with coalesced loads -- a lane reading ITS rows'
+// entries from global memory reads 4 bytes at a stride of 56, and the merge is a chain of dependent look-ups on top)
+struct diag_lds {
+    const int *s; int off[2]; long long row;
+    __device__ __forceinline__ long long operator()(int q, int k) const { return (long long)s[off[q] + k] - (row + q); }
 };
 
 struct pair_walk {

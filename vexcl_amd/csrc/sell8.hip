@@ -196,6 +196,43 @@ __device__ __forceinline__ unsigned pad_code(int partner_col, int partner_q, int
     return (first >= 0 && first + 1 <= max_col) ? (unsigned)S8_PAD : S8_PAD_UNSAFE;
 }
 
+// The entries of the 128 rows a wave fills (64 row pairs) are one contiguous piece of col / val: the wave copies it into its own
+// LDS region with coalesced loads -- no workgroup barrier, the waves keep their own pace -- and merge, code look-ups and
+// stores work from there.  (History at 512^3, sell8v fill: every lane loading its pair's entries itself, 4 / 8 bytes at a
+// stride of 56 / 112, 8.8 ms; the same with the 512 rows of a slice copied by the whole workgroup behind barriers, 56 KiB
+// of LDS: 10.9 ms; this: see DESIGN.md 6.)  A piece beyond WAVE_CAP entries (long rows) is walked in global memory.
+constexpr int WAVE_CAP = 1024;
+template <typename V>
+__device__ __forceinline__ bool wave_stage(const int *__restrict__ col, const V *__restrict__ val, long long b0_lane, long long e1_lane,
+        int *s_c, V *s_v, long long &e0)
+{
+    const int lane = threadIdx.x & 63;
+    // lanes past the end of the matrix hold b = e = 0: the piece is [first lane's begin, last REAL lane's end)
+    const unsigned long long real = __ballot(e1_lane > 0 || b0_lane > 0);
+    long long lo = b0_lane, hi = e1_lane;
+    e0 = __shfl(lo, 0, 64);                                         // lane 0 is real whenever any lane is
+    const int lastl = real ? 63 - __builtin_clzll(real) : 0;
+    const long long end = __shfl(hi, lastl, 64);
+    const long long cnt = end - e0;
+    if (cnt > WAVE_CAP || cnt < 0) return false;                     // uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();       // the previous trip's reads of this region are done
+    for (int k = lane; k < (int)cnt; k += 64) { s_c[k] = col[e0 + k]; s_v[k] = val[e0 + k]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return true;
+}
+
+// One LDS counter bump per entry -- but the lanes of a wave that walk the rows of one stencil hold the SAME code in the same
+// column, and 64 same-address LDS atomics serialise.  A wave whose active lanes agree adds their number once.
+__device__ __forceinline__ void count_code(unsigned *s_cnt, unsigned code) {
+    const unsigned long long act = __ballot(1);
+    const unsigned c0 = __builtin_amdgcn_readfirstlane(code);
+    if (__ballot(code == c0) == act) {
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&s_cnt[c0], (unsigned)__popcll(act));
+    } else {
+        atomicAdd(&s_cnt[code], 1u);
+    }
+}
+
 // table: sorted diagonals (ndeltas valid entries); counts[256]: entries per code; info[1]: set if a diagonal is missing;
 // max_col: largest column index of the ELL part (ell_max_col_kernel)
 template <typename V, typename P, bool STAGED>
@@ -206,8 +243,8 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
 {
     __shared__ int s_table[256];
     __shared__ unsigned s_cnt[256];
-    __shared__ int s_c[STAGED ? 16 * 256 : 1];          // STAGED (w <= 8): the pair's entries in lane-private LDS slots (sell8v_fill_kernel)
-    __shared__ V s_v[STAGED ? 16 * 256 : 1];
+    __shared__ int s_cw[STAGED ? 4 : 1][STAGED ? WAVE_CAP : 1];          // STAGED (w <= 8): the pair's entries in lane-private LDS slots (sell8v_fill_kernel)
+    __shared__ V s_vw[STAGED ? 4 : 1][STAGED ? WAVE_CAP : 1];
     s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -227,27 +264,37 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
         const int n0 = (int)min(e[0] - b[0], (long long)w), n1 = (int)min(e[1] - b[1], (long long)w);
         pair_walk pw;
-        pair_merge<diag_staged> pm;
+        pair_merge<diag_lds> pm;
+        bool staged = false, same = false;
+        int *s_c = s_cw[STAGED ? lt >> 6 : 0]; V *s_v = s_vw[STAGED ? lt >> 6 : 0];
         if constexpr (STAGED) {
+            long long e0;
+            // (the previous trip's reads of this wave's region are done: same wave, program order)
+            staged = wave_stage<V>(col, val, b[0], e[1] > 0 ? e[1] : e[0], s_c, s_v, e0);
+            if (staged) {
+                diag_lds g; g.s = s_c; g.off[0] = (int)(b[0] - e0); g.off[1] = (int)(b[1] - e0); g.row = i;
+                pm.d = g;
+                // the common pair: both rows hold the same diagonals in the same order (column of row 2t + 1 = column of
+                // row 2t, plus one) -- entry j of both goes to column j, no merge (a chain of dependent look-ups)
+                same = n0 == n1 && n0 <= 8;
+                if (same) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k < (q ? n1 : n0)) { s_c[(q * 8 + k) * 256 + lt] = col[b[q] + k]; s_v[(q * 8 + k) * 256 + lt] = val[b[q] + k]; }
-            diag_staged g; g.s = s_c; g.t = lt; g.row = i;
-            pm.init(g, n0, n1, w);
-        } else {
-            pw.init(col, i, b[0], n0, b[1], n1, w);
+                    for (int k = 0; k < 8; ++k) if (k < n0 && s_c[g.off[0] + k] + 1 != s_c[g.off[1] + k]) same = false;
+                }
+                if (!same) pm.init(g, n0, n1, w);
+            }
         }
+        if (!staged) pw.init(col, i, b[0], n0, b[1], n1, w);
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
                 int ec[2] = {-1, -1}; V ev[2] = {V(0), V(0)}; bool has[2] = {false, false};
                 if (j < w) {
-                    if constexpr (STAGED) {
-                        int k[2]; pm.next(k[0], k[1]);
-                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[(q * 8 + k[q]) * 256 + lt]; ev[q] = s_v[(q * 8 + k[q]) * 256 + lt]; }
+                    if (staged) {
+                        int k[2];
+                        if (same) k[0] = k[1] = j < n0 ? j : -1; else pm.next(k[0], k[1]);
+                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[pm.d.off[q] + k[q]]; ev[q] = s_v[pm.d.off[q] + k[q]]; }
                     } else {
                         long long en[2]; pw.next(en[0], en[1]);
                         for (int q = 0; q < 2; ++q) if (en[q] >= 0) { has[q] = true; ec[q] = col[en[q]]; ev[q] = val[en[q]]; }
@@ -256,8 +303,9 @@ void sell8_fill_kernel(long long n, long long nslices, int w, int ndeltas,
                 for (int q = 0; q < 2; ++q) {
                     unsigned code;
                     if (has[q]) {
-                        code = delta_code(s_table, ndeltas, (long long)ec[q] - (i + q));
-                        if (code != S8_PAD) atomicAdd(&s_cnt[code], 1u); else atomicExch(&info[1], 1);
+                        if (q == 1 && has[0] && ec[1] == ec[0] + 1) code = (word >> (8 * (jj * 2))) & 255u;     // the partner's diagonal: its code
+                        else code = delta_code(s_table, ndeltas, (long long)ec[q] - (i + q));
+                        if (code != S8_PAD) count_code(s_cnt, code); else atomicExch(&info[1], 1);
                     } else code = pad_code(has[1 - q] ? ec[1 - q] : -1, 1 - q, max_col);
                     word |= code << (8 * (jj * 2 + q));
                     if (j < w) vp[(long long)j * S8_ROWS + q] = ev[q];
@@ -897,7 +945,11 @@ void value_collect_kernel(long long n, int w, const P *__restrict__ ptr, const V
 // vtable: sorted value bit patterns (nvalues valid entries)
 // Diagonals, values and the largest column of the ELL part in ONE pass over the CSR arrays (round 3: delta_collect +
 // value_collect + ell_max_col read ptr / col / val three times, 12 ms of the 512^3 set-up).  Same sets, same overflow rules
-// as the two collect kernels; a lane loads its row's first <= 8 entries with one batch of independent loads.
+// as the two collect kernels.  A workgroup takes 256 consecutive rows at a time; their entries are one contiguous piece of
+// col / val, which the workgroup copies into LDS with coalesced loads (a lane reading ITS row's entries reads 4 / 8 bytes at
+// a stride of 28 / 56: 1.25 TB/s, 9.3 ms at 512^3) and every lane then walks its row there.  A piece that does not fit
+// (rows with long tails) is read from global memory as before.
+constexpr int ANALYZE_CAP = 2560;
 template <typename V, typename P>
 __global__ __launch_bounds__(256)
 void analyze_fused_kernel(long long n, int w, const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val,
@@ -907,38 +959,56 @@ void analyze_fused_kernel(long long n, int w, const P *__restrict__ ptr, const i
     __shared__ int s_set[LOCAL_SLOTS];
     __shared__ B s_vset[LOCAL_SLOTS];
     __shared__ int s_over, s_count, s_vover, s_vcount;
-    for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) { s_set[k] = EMPTY; s_vset[k] = ~B(0); }
-    if (threadIdx.x == 0) { s_over = *(volatile int *)&info_d[1]; s_count = 0; s_vover = *(volatile int *)&info_v[1]; s_vcount = 0; }
+    __shared__ long long s_ptr[257];
+    __shared__ int s_c[ANALYZE_CAP];
+    __shared__ V s_v[ANALYZE_CAP];
+    const int t = threadIdx.x;
+    for (int k = t; k < LOCAL_SLOTS; k += blockDim.x) { s_set[k] = EMPTY; s_vset[k] = ~B(0); }
+    if (t == 0) { s_over = *(volatile int *)&info_d[1]; s_count = 0; s_vover = *(volatile int *)&info_v[1]; s_vcount = 0; }
     __syncthreads();
     int m = -1;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const P b = ptr[i], e = ptr[i + 1];
-        const bool dstop = *(volatile int *)&s_over || *(volatile int *)&info_d[1];
-        const bool vstop = *(volatile int *)&s_vover || *(volatile int *)&info_v[1];
-        int last = EMPTY; B vlast = ~B(0);
-        for (int j0 = 0; j0 < w && b + j0 < e; j0 += 8) {
-            int c[8]; V v[8]; int cnt = 0;
+    int seen_d[8]; B seen_v[8];                                  // what this lane inserted last at entry position j (both sets only grow)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (j0 + u < w && b + j0 + u < e) { c[u] = col[b + j0 + u]; v[u] = val[b + j0 + u]; cnt = u + 1; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u >= cnt) break;
-                m = c[u] > m ? c[u] : m;
+    for (int j = 0; j < 8; ++j) { seen_d[j] = EMPTY; seen_v[j] = ~B(0); }
+    for (long long r0 = (long long)blockIdx.x * 256; r0 < n; r0 += (long long)gridDim.x * 256) {
+        const int rows = (int)(n - r0 < 256 ? n - r0 : 256);
+        for (int k = t; k <= rows; k += 256) s_ptr[k] = (long long)ptr[r0 + k];
+        __syncthreads();
+        const long long e0 = s_ptr[0], cnt = s_ptr[rows] - e0;
+        const bool staged = cnt <= ANALYZE_CAP;                       // uniform
+        if (staged)
+            for (int k = t; k < (int)cnt; k += 256) { s_c[k] = col[e0 + k]; s_v[k] = val[e0 + k]; }
+        __syncthreads();
+        if (t < rows) {
+            const long long i = r0 + t, b = s_ptr[t], e = s_ptr[t + 1];
+            const bool dstop = *(volatile int *)&s_over || *(volatile int *)&info_d[1];
+            const bool vstop = *(volatile int *)&s_vover || *(volatile int *)&info_v[1];
+            int last = EMPTY; B vlast = ~B(0);
+            const int nj = (int)(e - b < (long long)w ? e - b : (long long)w), off = (int)(b - e0);
+            for (int j = 0; j < nj; ++j) {
+                const int c = staged ? s_c[off + j] : col[b + j];
+                const V v = staged ? s_v[off + j] : val[b + j];
+                m = c > m ? c : m;
                 if (!dstop) {
-                    const long long dl = (long long)c[u] - i;
+                    const long long dl = (long long)c - i;
                     if (dl <= INT_MIN || dl > INT_MAX) s_over = 1;
-                    else if ((int)dl != last) {
+                    else if ((int)dl != last && !(j < 8 && (int)dl == seen_d[j])) {
+                        // (a lane of a structured matrix meets the same diagonal at the same place of every row: what it has
+                        // inserted once it does not insert again -- 64 lanes inserting the same 7 diagonals per row were
+                        // 64-way conflicts on the LDS set: the kernel was bound by them, not by its loads)
                         last = (int)dl;
+                        if (j < 8) seen_d[j] = last;
                         bool fresh = false;
                         if (!set_insert(s_set, LOCAL_SLOTS, last, &fresh)) s_over = 1;
                         else if (fresh && atomicAdd(&s_count, 1) >= 254) { s_over = 1; atomicExch(&info_d[1], 1); }
                     }
                 }
                 if (!vstop) {
-                    B bits; __builtin_memcpy(&bits, &v[u], sizeof(B));
+                    B bits; __builtin_memcpy(&bits, &v, sizeof(B));
                     if (bits == ~B(0)) s_vover = 1;
-                    else if (bits != vlast) {
+                    else if (bits != vlast && !(j < 8 && bits == seen_v[j])) {
                         vlast = bits;
+                        if (j < 8) seen_v[j] = bits;
                         bool fresh = false;
                         if (!vset_insert<B>(s_vset, LOCAL_SLOTS, bits, &fresh)) s_vover = 1;
                         else if (fresh && atomicAdd(&s_vcount, 1) >= 255) { s_vover = 1; atomicExch(&info_v[1], 1); }
@@ -946,21 +1016,22 @@ void analyze_fused_kernel(long long n, int w, const P *__restrict__ ptr, const i
                 }
             }
         }
+        __syncthreads();                                               // the next 256 rows overwrite s_ptr / s_c / s_v
     }
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_down(m, o, 64); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(max_col, m);
+    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_down(m, o, 64); m = u > m ? u : m; }
+    if ((t & 63) == 0 && m >= 0) atomicMax(max_col, m);
     __syncthreads();
-    if (s_over) { if (threadIdx.x == 0) atomicExch(&info_d[1], 1); }
+    if (s_over) { if (t == 0) atomicExch(&info_d[1], 1); }
     else
-        for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
+        for (int k = t; k < LOCAL_SLOTS; k += blockDim.x) {
             if (s_set[k] == EMPTY) continue;
             bool is_new = false;
             if (!set_insert(gset_d, HASH_SLOTS, s_set[k], &is_new)) atomicExch(&info_d[1], 1);
             else if (is_new) atomicAdd(&info_d[0], 1);
         }
-    if (s_vover) { if (threadIdx.x == 0) atomicExch(&info_v[1], 1); }
+    if (s_vover) { if (t == 0) atomicExch(&info_v[1], 1); }
     else
-        for (int k = threadIdx.x; k < LOCAL_SLOTS; k += blockDim.x) {
+        for (int k = t; k < LOCAL_SLOTS; k += blockDim.x) {
             if (s_vset[k] == ~B(0)) continue;
             bool is_new = false;
             if (!vset_insert<B>(gset_v, HASH_SLOTS, s_vset[k], &is_new)) atomicExch(&info_v[1], 1);
@@ -981,8 +1052,8 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
     __shared__ int s_table[256];
     __shared__ B s_vtable[256];
     __shared__ unsigned s_cnt[256];
-    __shared__ int s_c[STAGED ? 16 * 256 : 1];
-    __shared__ V s_v[STAGED ? 16 * 256 : 1];
+    __shared__ int s_cw[STAGED ? 4 : 1][STAGED ? WAVE_CAP : 1];
+    __shared__ V s_vw[STAGED ? 4 : 1][STAGED ? WAVE_CAP : 1];
     s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
     { V v = threadIdx.x < nvalues ? vtable[threadIdx.x] : V(0); B b; __builtin_memcpy(&b, &v, sizeof(B)); s_vtable[threadIdx.x] = threadIdx.x < nvalues ? b : ~B(0); }
     s_cnt[threadIdx.x] = 0;
@@ -1001,27 +1072,37 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
         for (int q = 0; q < 2; ++q) if (i + q < n) { b[q] = ptr[i + q]; e[q] = ptr[i + q + 1]; }
         const int n0 = (int)min(e[0] - b[0], (long long)w), n1 = (int)min(e[1] - b[1], (long long)w);
         pair_walk pw;
-        pair_merge<diag_staged> pm;
+        pair_merge<diag_lds> pm;
+        bool staged = false, same = false;
+        int *s_c = s_cw[STAGED ? lt >> 6 : 0]; V *s_v = s_vw[STAGED ? lt >> 6 : 0];
         if constexpr (STAGED) {
+            long long e0;
+            // (the previous trip's reads of this wave's region are done: same wave, program order)
+            staged = wave_stage<V>(col, val, b[0], e[1] > 0 ? e[1] : e[0], s_c, s_v, e0);
+            if (staged) {
+                diag_lds g; g.s = s_c; g.off[0] = (int)(b[0] - e0); g.off[1] = (int)(b[1] - e0); g.row = i;
+                pm.d = g;
+                // the common pair: both rows hold the same diagonals in the same order (column of row 2t + 1 = column of
+                // row 2t, plus one) -- entry j of both goes to column j, no merge (a chain of dependent look-ups)
+                same = n0 == n1 && n0 <= 8;
+                if (same) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k < (q ? n1 : n0)) { s_c[(q * 8 + k) * 256 + lt] = col[b[q] + k]; s_v[(q * 8 + k) * 256 + lt] = val[b[q] + k]; }
-            diag_staged g; g.s = s_c; g.t = lt; g.row = i;
-            pm.init(g, n0, n1, w);
-        } else {
-            pw.init(col, i, b[0], n0, b[1], n1, w);
+                    for (int k = 0; k < 8; ++k) if (k < n0 && s_c[g.off[0] + k] + 1 != s_c[g.off[1] + k]) same = false;
+                }
+                if (!same) pm.init(g, n0, n1, w);
+            }
         }
+        if (!staged) pw.init(col, i, b[0], n0, b[1], n1, w);
         for (int jp = 0; jp < wp; ++jp) {
             unsigned word = 0, vword = 0;
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
                 int ec[2] = {-1, -1}; V ev[2] = {V(0), V(0)}; bool has[2] = {false, false};      // the column's two entries: column index, value
                 if (j < w) {
-                    if constexpr (STAGED) {
-                        int k[2]; pm.next(k[0], k[1]);
-                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[(q * 8 + k[q]) * 256 + lt]; ev[q] = s_v[(q * 8 + k[q]) * 256 + lt]; }
+                    if (staged) {
+                        int k[2];
+                        if (same) k[0] = k[1] = j < n0 ? j : -1; else pm.next(k[0], k[1]);
+                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[pm.d.off[q] + k[q]]; ev[q] = s_v[pm.d.off[q] + k[q]]; }
                     } else {
                         long long en[2]; pw.next(en[0], en[1]);
                         for (int q = 0; q < 2; ++q) if (en[q] >= 0) { has[q] = true; ec[q] = col[en[q]]; ev[q] = val[en[q]]; }
@@ -1030,8 +1111,9 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
                 for (int q = 0; q < 2; ++q) {
                     unsigned code, vcode = 255;                     // value code of padding: table entry 255 = 0.0
                     if (has[q]) {
-                        code = delta_code(s_table, ndeltas, (long long)ec[q] - (i + q));
-                        if (code != S8_PAD) atomicAdd(&s_cnt[code], 1u); else atomicExch(&info[1], 1);
+                        if (q == 1 && has[0] && ec[1] == ec[0] + 1) code = (word >> (8 * (jj * 2))) & 255u;     // the partner's diagonal: its code
+                        else code = delta_code(s_table, ndeltas, (long long)ec[q] - (i + q));
+                        if (code != S8_PAD) count_code(s_cnt, code); else atomicExch(&info[1], 1);
                         B bits; V v = ev[q];
                         __builtin_memcpy(&bits, &v, sizeof(B));
                         int lo = 0, hi = nvalues;
