@@ -1039,8 +1039,38 @@ void analyze_fused_kernel(long long n, int w, const P *__restrict__ ptr, const i
         }
 }
 
-// STAGED (w <= 8): the pair's entries are loaded with one batch of independent loads into lane-private LDS slots and the
-// merge, the code look-ups and the stores work from there (48 KiB of LDS per workgroup for fp64).
+// The same for the value-coded storage, which does not need the values themselves: the lane that copies an entry looks its
+// value up in the sorted table there and then and leaves a 2-byte code (0xffff: not in the table) -- 6 instead of 12 bytes
+// of LDS per entry, 27 instead of 53 KiB per workgroup, twice the waves per CU for a kernel whose waves are parked 73 % of
+// their time (profiles/r03_sq_setup.txt).
+template <typename V>
+__device__ __forceinline__ bool wave_stage_codes(const int *__restrict__ col, const V *__restrict__ val, long long b0_lane, long long e1_lane,
+        int *s_c, unsigned short *s_vc, const typename bits_of<V>::type *s_vtable, int nvalues, long long &e0)
+{
+    typedef typename bits_of<V>::type B;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long real = __ballot(e1_lane > 0 || b0_lane > 0);
+    long long lo_ = b0_lane, hi_ = e1_lane;
+    e0 = __shfl(lo_, 0, 64);
+    const int lastl = real ? 63 - __builtin_clzll(real) : 0;
+    const long long end = __shfl(hi_, lastl, 64);
+    const long long cnt = end - e0;
+    if (cnt > WAVE_CAP || cnt < 0) return false;                     // uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();       // the previous trip's reads of this region are done
+    for (int k = lane; k < (int)cnt; k += 64) {
+        s_c[k] = col[e0 + k];
+        const V v = val[e0 + k];
+        B bits; __builtin_memcpy(&bits, &v, sizeof(B));
+        int lo = 0, hi = nvalues;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (s_vtable[mid] < bits) lo = mid + 1; else hi = mid; }
+        s_vc[k] = (lo < nvalues && s_vtable[lo] == bits) ? (unsigned short)lo : (unsigned short)0xffffu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return true;
+}
+
+// STAGED (w <= 8): the entries of a wave's 128 rows are copied into its LDS region with coalesced loads (wave_stage_codes);
+// the merge, the code look-ups and the stores work from there.
 template <typename V, typename P, bool STAGED>
 __global__ __launch_bounds__(256)
 void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int nvalues,
@@ -1053,7 +1083,7 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
     __shared__ B s_vtable[256];
     __shared__ unsigned s_cnt[256];
     __shared__ int s_cw[STAGED ? 4 : 1][STAGED ? WAVE_CAP : 1];
-    __shared__ V s_vw[STAGED ? 4 : 1][STAGED ? WAVE_CAP : 1];
+    __shared__ unsigned short s_vcw[STAGED ? 4 : 1][STAGED ? WAVE_CAP : 1];     // value CODES of the staged entries (wave_stage_codes)
     s_table[threadIdx.x] = threadIdx.x < ndeltas ? table[threadIdx.x] : INT_MAX;
     { V v = threadIdx.x < nvalues ? vtable[threadIdx.x] : V(0); B b; __builtin_memcpy(&b, &v, sizeof(B)); s_vtable[threadIdx.x] = threadIdx.x < nvalues ? b : ~B(0); }
     s_cnt[threadIdx.x] = 0;
@@ -1074,11 +1104,11 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
         pair_walk pw;
         pair_merge<diag_lds> pm;
         bool staged = false, same = false;
-        int *s_c = s_cw[STAGED ? lt >> 6 : 0]; V *s_v = s_vw[STAGED ? lt >> 6 : 0];
+        int *s_c = s_cw[STAGED ? lt >> 6 : 0]; unsigned short *s_vc = s_vcw[STAGED ? lt >> 6 : 0];
         if constexpr (STAGED) {
             long long e0;
             // (the previous trip's reads of this wave's region are done: same wave, program order)
-            staged = wave_stage<V>(col, val, b[0], e[1] > 0 ? e[1] : e[0], s_c, s_v, e0);
+            staged = wave_stage_codes<V>(col, val, b[0], e[1] > 0 ? e[1] : e[0], s_c, s_vc, s_vtable, nvalues, e0);
             if (staged) {
                 diag_lds g; g.s = s_c; g.off[0] = (int)(b[0] - e0); g.off[1] = (int)(b[1] - e0); g.row = i;
                 pm.d = g;
@@ -1098,11 +1128,12 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
                 int ec[2] = {-1, -1}; V ev[2] = {V(0), V(0)}; bool has[2] = {false, false};      // the column's two entries: column index, value
+                unsigned sc[2] = {0x10000u, 0x10000u};                                          // ... or (staged) the value's code: 0x10000 = look ev up
                 if (j < w) {
                     if (staged) {
                         int k[2];
                         if (same) k[0] = k[1] = j < n0 ? j : -1; else pm.next(k[0], k[1]);
-                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[pm.d.off[q] + k[q]]; ev[q] = s_v[pm.d.off[q] + k[q]]; }
+                        for (int q = 0; q < 2; ++q) if (k[q] >= 0) { has[q] = true; ec[q] = s_c[pm.d.off[q] + k[q]]; sc[q] = s_vc[pm.d.off[q] + k[q]]; }
                     } else {
                         long long en[2]; pw.next(en[0], en[1]);
                         for (int q = 0; q < 2; ++q) if (en[q] >= 0) { has[q] = true; ec[q] = col[en[q]]; ev[q] = val[en[q]]; }
@@ -1114,12 +1145,16 @@ void sell8v_fill_kernel(long long n, long long nslices, int w, int ndeltas, int 
                         if (q == 1 && has[0] && ec[1] == ec[0] + 1) code = (word >> (8 * (jj * 2))) & 255u;     // the partner's diagonal: its code
                         else code = delta_code(s_table, ndeltas, (long long)ec[q] - (i + q));
                         if (code != S8_PAD) count_code(s_cnt, code); else atomicExch(&info[1], 1);
-                        B bits; V v = ev[q];
-                        __builtin_memcpy(&bits, &v, sizeof(B));
-                        int lo = 0, hi = nvalues;
-                        while (lo < hi) { int mid = (lo + hi) >> 1; if (s_vtable[mid] < bits) lo = mid + 1; else hi = mid; }
-                        if (lo < nvalues && s_vtable[lo] == bits) vcode = (unsigned)lo;
-                        else atomicExch(&info[1], 1);
+                        if (sc[q] != 0x10000u) {                            // looked up when the entry was staged
+                            if (sc[q] != 0xffffu) vcode = sc[q]; else atomicExch(&info[1], 1);
+                        } else {
+                            B bits; V v = ev[q];
+                            __builtin_memcpy(&bits, &v, sizeof(B));
+                            int lo = 0, hi = nvalues;
+                            while (lo < hi) { int mid = (lo + hi) >> 1; if (s_vtable[mid] < bits) lo = mid + 1; else hi = mid; }
+                            if (lo < nvalues && s_vtable[lo] == bits) vcode = (unsigned)lo;
+                            else atomicExch(&info[1], 1);
+                        }
                     } else code = pad_code(has[1 - q] ? ec[1 - q] : -1, 1 - q, max_col);
                     word |= code << (8 * (jj * 2 + q));
                     vword |= vcode << (8 * (jj * 2 + q));
