@@ -20,7 +20,9 @@ What the line reports, and how to read it:
   roofline            the launched kernel against the HBM roofline by the bytes it REALLY moves: the stored matrix
                       (vexhip_spmat_get_info: matrix_bytes) + x once + y once.  frac <= 1 by construction.  `traffic`
                       = HBM bytes per launch measured in THIS run (rocprofv3 FETCH_SIZE / WRITE_SIZE passes over
-                      tools/pmc_headline.py, FETCH calibrated on a stream of known size), or null.
+                      tools/pmc_headline.py, FETCH calibrated on a stream of known size), or null.  `device_copy`
+                      (march product): torch's copy of x to y timed in the same process -- the same HBM traffic as the
+                      product (x once, y once): what the memory system gives a kernel with nothing else to do.
   roofline_csr        the same product by kernels that stream fp64 values + int32 columns (no compression), priced
                       with the CSR-algorithmic bytes: SELL-512 with 32-bit columns and the CSR arrays themselves.
   variable_coefficient  the same 7-point pattern with a coefficient per face (~4 N distinct values: no value coding
@@ -28,6 +30,8 @@ What the line reports, and how to read it:
   checksum            sum(y) asserted against an independent evaluation of the stencil (torch slicing, no matrix); for N > 1 every
                       rank checks its rows against x regenerated from the global index (no transport involved).
   setup               what building the storage from CSR arrays in HBM costs (ms, bytes, products to amortise it).
+N > 1: rank 0 says on stderr where the run is ("[bench  12.3 s] ..."); the trial and settle runs of a transport are bounded
+in time by a three-product probe whose result all ranks share.
 """
 import argparse
 import json
