@@ -267,6 +267,27 @@ typedef struct vexhip_march { int32_t lo, hi;      /* smallest / largest NEAR di
                             } vexhip_march;
 int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
         int value_bytes, const vexhip_traversal *traversal, int64_t x_last, vexhip_march *out);
+/* The PLANE product (plane.hip, round 4; same semantics, hybrid_ell.inl:238-269): value-coded storage with a slice dictionary
+ * whose diagonals are {0, +-1, +-512, +-P}, P = 512 * lines_per_plane -- a 7-point operator on a grid with 512-point lines.
+ * A workgroup owns two adjacent grid lines and walks through `depth` planes; the +-512 and +-P neighbours of a lane's rows
+ * are pairs the same lane loaded (registers), the +-1 neighbours come by DPP wave shifts: no LDS, every x line requested
+ * twice instead of three times.  The plan checks on the host that every dictionary block keeps its rows' diagonals in
+ * ascending order of position (position order = storage order), that at most 1/16 of the slices use another block than the
+ * most frequent one (hot_block), that there is no CSR tail and that x can be read in whole lines ((x_last + 1) % 512 == 0);
+ * usable = 0 otherwise and the march / pair products stay.  VEXHIP_PLANE_DEPTH overrides depth.  fp64 only.            */
+typedef struct vexhip_plane { int32_t usable;
+                              int32_t lines_per_plane;   /* the far diagonals are +-512 * lines_per_plane                     */
+                              int32_t planes;            /* ceil(slices / lines_per_plane)                                    */
+                              int32_t depth;             /* planes one workgroup walks through                                */
+                              int32_t hot_block;         /* dictionary block kept decoded in registers                        */
+                              int32_t reserved;
+                              int64_t x_last;
+                            } vexhip_plane;
+int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
+        const void *pool, int64_t dictionary_blocks, int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes,
+        int64_t x_last, vexhip_plane *out);
+int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
 int64_t vexhip_sell8_last_fill_max_col(void);
 int vexhip_spmv_sell8v_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
@@ -331,7 +352,8 @@ enum { VEXHIP_SPMAT_AUTO = 0,      /* create(): most compact storage; info: neve
        VEXHIP_SPMAT_CSR = 4 };     /* the CSR arrays themselves (csr_stream_kernel)                               */
 enum { VEXHIP_SPMAT_BORROW_CSR = 1,      /* format CSR: keep the caller's arrays instead of copying them (caller keeps them alive) */
        VEXHIP_SPMAT_NO_DICTIONARY = 2,   /* value-coded storage: keep one block per slice even if the slices repeat (A/B, tests)   */
-       VEXHIP_SPMAT_NO_MARCH = 4 };      /* keep the pair products where the march products would apply (A/B, tests)               */
+       VEXHIP_SPMAT_NO_MARCH = 4,        /* keep the pair products where the march / plane products would apply (A/B, tests)       */
+       VEXHIP_SPMAT_NO_PLANE = 8 };      /* keep the march product where the plane product would apply (A/B, tests)                */
 typedef struct vexhip_spmat_info {
     int32_t format, value_type, device, ndeltas, nvalues, reserved;
     int64_t rows, nnz, ell_width, tail_nnz, sell_bytes;
@@ -343,6 +365,7 @@ typedef struct vexhip_spmat_info {
     const void *code_pool;          /* code_pool, which holds dictionary_blocks distinct code blocks.  SELL8V: `sell` IS the   */
     int64_t dictionary_blocks;      /* pool (no per-slice storage left); SELL8: `sell` keeps the values, slice-major           */
     vexhip_march march;             /* march product (usable = 1: apply() runs it; see vexhip_sell8_march_plan)                */
+    vexhip_plane plane;             /* plane product (usable = 1: apply() prefers it to the march product; vexhip_sell8_plane_plan) */
 } vexhip_spmat_info;
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int format, int flags, vexhip_spmat **out);

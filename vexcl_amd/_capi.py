@@ -60,6 +60,12 @@ class March(ctypes.Structure):
                 ("nfar", ctypes.c_int32), ("far", ctypes.c_int32 * 3)]
 
 
+class Plane(ctypes.Structure):
+    """vexhip_plane (include/vexhip.h)."""
+    _fields_ = [("usable", ctypes.c_int32), ("lines_per_plane", ctypes.c_int32), ("planes", ctypes.c_int32), ("depth", ctypes.c_int32),
+                ("hot_block", ctypes.c_int32), ("reserved", ctypes.c_int32), ("x_last", ctypes.c_int64)]
+
+
 class SpMatInfo(ctypes.Structure):
     """vexhip_spmat_info (include/vexhip.h)."""
     _fields_ = [("format", ctypes.c_int32), ("value_type", ctypes.c_int32), ("device", ctypes.c_int32),
@@ -69,13 +75,14 @@ class SpMatInfo(ctypes.Structure):
                 ("sell", ctypes.c_void_p), ("deltas", ctypes.c_void_p), ("values", ctypes.c_void_p),
                 ("csr_ptr", ctypes.c_void_p), ("csr_col", ctypes.c_void_p), ("csr_val", ctypes.c_void_p),
                 ("traversal", Traversal), ("slice_blocks", ctypes.c_void_p), ("code_pool", ctypes.c_void_p),
-                ("dictionary_blocks", ctypes.c_int64), ("march", March)]
+                ("dictionary_blocks", ctypes.c_int64), ("march", March), ("plane", Plane)]
 
 
 SPMAT_AUTO, SPMAT_SELL8V, SPMAT_SELL8, SPMAT_SELL, SPMAT_CSR = range(5)
 SPMAT_BORROW_CSR = 1
 SPMAT_NO_DICTIONARY = 2
 SPMAT_NO_MARCH = 4
+SPMAT_NO_PLANE = 8
 SPMAT_NAMES = {SPMAT_SELL8V: "sell8v", SPMAT_SELL8: "sell8", SPMAT_SELL: "sell32", SPMAT_CSR: "csr"}
 
 # name -> (restype, argtypes); restype None means "int status, checked"
@@ -154,6 +161,8 @@ _PROTOS = {
     "vexhip_spmv_sell8_dict_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
     "vexhip_sell8_march_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_int, ctypes.POINTER(Traversal), c_i64, ctypes.POINTER(March)]),
     "vexhip_sell8_last_fill_max_col": (c_i64, []),
+    "vexhip_sell8_plane_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, ctypes.POINTER(Plane)]),
+    "vexhip_spmv_sell8v_plane_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Plane)]),
     "vexhip_spmv_sell8v_march_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),
     "vexhip_spmv_sell8v_march_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),
     "vexhip_spmm_sell8_dict_f64_i32": (None, [c_int, c_vp, c_i64, c_int, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),

@@ -1,0 +1,327 @@
+// The PLANE product (round 4): y (=|+=) alpha * A * x for value-coded SELL-512 storage with a slice dictionary whose diagonals
+// are those of a 7-point operator on a grid with 512-point lines -- {0, +-1, +-512, +-P}, P = 512 * (lines per plane).
+// This is the headline kernel of vex::SpMat on the 512^3 Poisson matrix; semantics are the reference's ELL product
+// (/root/reference/vexcl/spmat/hybrid_ell.inl:238-269: the row's entries in storage order, products rounded before they are
+// added, the scale applied to the sum), results bit-identical to the CSR loop (spmat/csr.inl:163-170).
+//
+// What it does differently from the march product (sell8.hip), and why (profiles/r04_pm_proto.json):
+//   * the march product walks a run of consecutive slices and keeps the +-512 window in an LDS ring; the +-P diagonals are
+//     two more 16-byte requests per lane and slice that other workgroups satisfy from HBM a second and third time whenever
+//     the three touches of a line do not meet in one L2 (1.21 x the read traffic, L2 hit 58 %), and every x element crosses
+//     the LDS (55 % busy, 39 % of it bank conflicts).
+//   * here a workgroup owns TWO adjacent grid lines and walks through the PLANES.  Lane t owns rows 2t, 2t + 1 of both lines in
+//     every plane, so the +-512 neighbours (the line above / below) and the +-P neighbours (the same line one plane back /
+//     ahead) of its rows are 16-byte pairs THE SAME LANE loaded itself: they stay in registers.  Only the +-1 neighbours
+//     belong to other lanes: one DPP wave shift each; the element beyond either end of a wave's 128 rows is a scalar load.
+//     No LDS, no barrier.  Per plane step a lane requests 4 pairs (two centre lines, the halo line above and below) and stores
+//     2: every x line is requested twice instead of three times, and the halo lines are the centre lines of the neighbouring
+//     tile, which the same XCD works on at the same plane (tiles are dealt to XCDs in contiguous ranges).
+//   * the matrix enters as it does in the march product: 4 bytes per slice (its dictionary block) + the pool of distinct code
+//     blocks.  A lane decodes a block into values and validity of its two rows at the seven diagonal positions; the block
+//     that most slices use (the plan's `hot` block) keeps them in registers with scalar lane masks, one other block sits
+//     next to it and is re-decoded when a line needs a third one (boundary planes / lines: < 1/16 of the slices, the plan
+//     checks).  Rows need not be pair-aligned: x comes by diagonal position, not by ELL column.
+// The plan (vexhip_sell8_plane_plan) validates every dictionary block on the host -- diagonals in the set, positions ascending
+// within a row (so that position order IS storage order) -- and declines otherwise; the march and pair products remain.
+// Compiled with -ffp-contract=off.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace vexhip {
+namespace {
+
+constexpr int PL_ROWS = 512;
+constexpr unsigned PL_PAD_FIRST = 254;      // codes 254 / 255 are padding (sell8.hip)
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct plane_dev {
+    long long nslices;       // 512-row lines of the matrix
+    long long xlines;        // lines of x that may be loaded whole: (x_last + 1) / 512
+    long long x_last;
+    int ny;                  // lines per plane
+    int nz;                  // planes: ceil(nslices / ny)
+    int depth;               // planes per workgroup
+    int tiles;               // ny / 2
+    int tpx;                 // tiles per XCD: ceil(tiles / 8)
+    int hot;                 // dictionary block decoded into registers with scalar masks
+    int w;                   // ELL width (<= 8)
+    int far;                 // 512 * ny
+};
+
+__device__ __forceinline__ double shift_from_lower_lane(double v, double edge) {       // lane i <- lane i - 1, lane 0 <- edge
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);   // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shift_from_upper_lane(double v, double edge) {       // lane i <- lane i + 1, lane 63 <- edge
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);   // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v for the lanes of `lanes`, elsewhere a number whose exponent field is 0: (+0.0) * that == +0.0 whatever x holds there
+// (the matrix value of a position without an entry is +0.0; x may hold Inf / NaN where CSR would never look)
+__device__ __forceinline__ double keep_lanes(double v, unsigned long long lanes) {
+    unsigned rhi;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"((unsigned)__double2hiint(v)), "s"(lanes));
+    return __hiloint2double((int)rhi, __double2loint(v));
+}
+__device__ __forceinline__ double keep_bit(double v, unsigned bits, int pos) {
+    const int m = (int)(bits << (31 - pos)) >> 31;                // -1 where the bit is set
+    return __hiloint2double(__double2hiint(v) & m, __double2loint(v));
+}
+
+// diagonal -> position 0..6 in {-far, -512, -1, 0, 1, 512, far} (the plan has checked that it is one of them)
+__device__ __forceinline__ int position_of(int d, int far) {
+    return d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -PL_ROWS ? 1 : d == PL_ROWS ? 5 : d == -far ? 0 : 6;
+}
+
+__global__ __launch_bounds__(256, 4)
+void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha, int append,
+        const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
+        plane_dev pd)
+{
+    // LDS: per diagonal code its position (x 2), the value table, and the decoded values of the OTHER block, lane-private
+    // ([position * 2 + row][lane]: consecutive lanes, consecutive 8-byte words -- conflict-free; row 14 takes what padding
+    // "writes").  33 KiB: four workgroups per CU.
+    __shared__ int s_slot[256];
+    __shared__ double s_value[256];
+    __shared__ double s_other[15][256];
+
+    const int t = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
+    const int zc = (int)(q / (unsigned)pd.tpx), tyl = (int)(q - (unsigned)zc * (unsigned)pd.tpx);
+    const int tile = (int)xcd * pd.tpx + tyl;
+    if (tile >= pd.tiles) return;                                   // the whole workgroup
+    const int y0 = 2 * tile;
+    int z = zc * pd.depth;
+    const int zend = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
+    if (z >= zend) return;
+    const int ny = pd.ny;
+    const int nslices = (int)pd.nslices, xlines = (int)pd.xlines;
+    const long long x_last = pd.x_last;
+    const unsigned lane_b = 16u * (unsigned)t;
+
+    s_slot[t] = 2 * position_of(deltas[t], pd.far); s_value[t] = values[t];
+    __syncthreads();
+
+    // ---- a dictionary block -> values (into s_other) and validity (returned) of this lane's rows at the seven positions ----
+    const int wp = (pd.w + 1) >> 1;
+    auto decode = [&](int blk) -> unsigned {
+        const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * ((long long)wp * 2048)) + t;
+        unsigned dcw[4], vcw[4];                // diagonal codes, value codes: one word per pair of ELL columns
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { dcw[u] = u < wp ? cw[u * 256] : 0xffffffffu; vcw[u] = u < wp ? cw[(wp + u) * 256] : 0u; }
+#pragma unroll
+        for (int p = 0; p < 14; ++p) s_other[p][t] = 0.0;
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned cword = dcw[j >> 1] >> (16 * (j & 1)), vword = vcw[j >> 1] >> (16 * (j & 1));
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned code = j < pd.w ? (cword >> (8 * r)) & 255u : 255u;
+                const bool real = code < PL_PAD_FIRST;
+                const int slot = real ? s_slot[code] + r : 14;
+                s_other[slot][t] = s_value[real ? (vword >> (8 * r)) & 255u : 255u];      // entry 255 of the table is 0.0
+                bits |= (real ? 1u : 0u) << slot;
+            }
+        }
+        return bits & 0x3fffu;
+    };
+
+    double aH[7][2];                            // the hot block: values ...
+    unsigned long long mH[7][2];                // ... and the lanes with an entry, per position and row
+    {
+        const unsigned bitsH = decode(pd.hot);
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            aH[p][0] = s_other[2 * p][t]; aH[p][1] = s_other[2 * p + 1][t];
+            mH[p][0] = __builtin_amdgcn_ballot_w64((bitsH >> (2 * p)) & 1u);
+            mH[p][1] = __builtin_amdgcn_ballot_w64((bitsH >> (2 * p + 1)) & 1u);
+        }
+    }
+    unsigned bitsO = 0;
+    int other = -1;                             // what s_other holds now is the hot block's: never asked for
+
+    // line `l` of the tile's window (0 = the line above the tile, 1, 2 = the tile, 3 = the line below) in plane zz; clamped:
+    // a line outside x is never referenced by an entry, what is loaded in its place is multiplied by +0.0 behind a mask
+    auto line_of = [&](int zz, int l) -> int {
+        int li = zz * ny + (y0 - 1 + l);
+        li = li < 0 ? 0 : li; li = li >= xlines ? xlines - 1 : li;
+        return li;
+    };
+    auto ld = [&](int zz, int l) -> d2 {
+        const char *p = reinterpret_cast<const char *>(x + (long long)line_of(zz, l) * PL_ROWS);
+        return *reinterpret_cast<const d2 *>(p + lane_b);
+    };
+    auto edge = [&](int zz, int l, int side) -> double {          // uniform address: a scalar load
+        long long i = (long long)line_of(zz, l) * PL_ROWS + wv * 128 + (side ? 128 : -1);
+        i = i < 0 ? 0 : i; i = i > x_last ? x_last : i;
+        return x[i];
+    };
+    auto block_of = [&](int zz, int l) -> int {
+        int li = zz * ny + (y0 + l);
+        li = li < 0 ? 0 : li; li = li >= nslices ? nslices - 1 : li;
+        return blocks[li];
+    };
+
+    d2 prev[2], cur[4], nxt[2], ph[2], pc[2];
+    double eL[2], eR[2], peL[2], peR[2];
+    int bl[2], pbl[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) { prev[l] = ld(z - 1, l + 1); nxt[l] = ld(z + 1, l + 1); pc[l] = ld(z + 2, l + 1); }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) cur[l] = ld(z, l);
+    ph[0] = ld(z + 1, 0); ph[1] = ld(z + 1, 3);
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        eL[l] = edge(z, l + 1, 0); eR[l] = edge(z, l + 1, 1); peL[l] = edge(z + 1, l + 1, 0); peR[l] = edge(z + 1, l + 1, 1);
+        bl[l] = block_of(z, l); pbl[l] = block_of(z + 1, l);
+    }
+
+    for (; z < zend; ++z) {
+        // ---- the two lines of plane z ----
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const int li = z * ny + (y0 + l);
+            if (li < nslices) {                                           // uniform (a ragged last plane)
+                const d2 c = cur[l + 1];
+                const double xs0[7] = {prev[l].x, cur[l].x, shift_from_lower_lane(c.y, eL[l]), c.x, c.y, cur[l + 2].x, nxt[l].x};
+                const double xs1[7] = {prev[l].y, cur[l].y, c.x, c.y, shift_from_upper_lane(c.x, eR[l]), cur[l + 2].y, nxt[l].y};
+                double s0 = 0.0, s1 = 0.0;
+                const int blk = __builtin_amdgcn_readfirstlane(bl[l]);
+                if (blk == pd.hot) {
+#pragma unroll
+                    for (int p = 0; p < 7; ++p) { s0 += aH[p][0] * keep_lanes(xs0[p], mH[p][0]); s1 += aH[p][1] * keep_lanes(xs1[p], mH[p][1]); }
+                } else {
+                    if (blk != other) { bitsO = decode(blk); other = blk; }
+#pragma unroll
+                    for (int p = 0; p < 7; ++p) {
+                        s0 += s_other[2 * p][t] * keep_bit(xs0[p], bitsO, 2 * p);
+                        s1 += s_other[2 * p + 1][t] * keep_bit(xs1[p], bitsO, 2 * p + 1);
+                    }
+                }
+                d2 o; o.x = alpha * s0; o.y = alpha * s1;
+                d2 *yp = reinterpret_cast<d2 *>(reinterpret_cast<char *>(y + (long long)li * PL_ROWS) + lane_b);
+                if (append) { const d2 old = *yp; o.x = old.x + o.x; o.y = old.y + o.y; }
+                __builtin_nontemporal_store(o, yp);                       // written once, not read again by this kernel
+            }
+        }
+        // ---- rotate; request the halo lines of plane z + 2 and the centre lines of plane z + 3 ----
+#pragma unroll
+        for (int l = 0; l < 2; ++l) { prev[l] = cur[l + 1]; cur[l + 1] = nxt[l]; nxt[l] = pc[l]; eL[l] = peL[l]; eR[l] = peR[l]; bl[l] = pbl[l]; }
+        cur[0] = ph[0]; cur[3] = ph[1];
+        if (z + 1 < zend) {
+            ph[0] = ld(z + 2, 0); ph[1] = ld(z + 2, 3);
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                pc[l] = ld(z + 3, l + 1);
+                peL[l] = edge(z + 2, l + 1, 0); peR[l] = edge(z + 2, l + 1, 1);
+                pbl[l] = block_of(z + 2, l);
+            }
+        }
+    }
+}
+
+} // namespace
+} // namespace vexhip
+
+using namespace vexhip;
+
+extern "C" {
+
+int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
+        const void *pool, int64_t dictionary_blocks, int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes,
+        int64_t x_last, vexhip_plane *out)
+{
+    VEXHIP_REQUIRE(out, "NULL output");
+    std::memset(out, 0, sizeof(*out));
+    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids, many blocks
+    if (value_bytes != 8 || !deltas || !blocks || !pool || ndeltas < 2 || ndeltas > 7 || dictionary_blocks < 1 || dictionary_blocks > 128) return 0;
+    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows != nslices * PL_ROWS || (nslices < 64 && !force)) return 0;
+    if (x_last < 0 || (x_last + 1) % PL_ROWS != 0) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const int wp = (int)((ell_width + 1) / 2);
+    const size_t code_bytes = (size_t)wp * 2048;
+    std::vector<int> table((size_t)ndeltas), id((size_t)nslices);
+    std::vector<unsigned> codes((size_t)dictionary_blocks * code_bytes / 4);
+    VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * (size_t)ndeltas, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(id.data(), blocks, sizeof(int) * (size_t)nslices, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(codes.data(), pool, (size_t)dictionary_blocks * code_bytes, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    // the diagonals: {0, +-1, +-512} and one far pair +-P, P a multiple of 1024 (two lines per workgroup)
+    long long far = 0;
+    for (int d : table) {
+        const long long a = std::llabs((long long)d);
+        if (a == 0 || a == 1 || a == PL_ROWS) continue;
+        if (far == 0) far = a;
+        if (a != far) return 0;
+    }
+    if (far < 4 * PL_ROWS || far % (2 * PL_ROWS) != 0 || far > (1ll << 30)) return 0;
+    const long long ny = far / PL_ROWS, nz = (nslices + ny - 1) / ny;
+    if (nz < 4 && !force) return 0;
+    auto position = [&](int d) { return d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -PL_ROWS ? 1 : d == PL_ROWS ? 5 : d == -far ? 0 : 6; };
+    // every row of every dictionary block: positions strictly ascending along the ELL columns (position order = storage order)
+    for (int64_t blk = 0; blk < dictionary_blocks; ++blk) {
+        const unsigned *cw = codes.data() + (size_t)blk * code_bytes / 4;
+        for (int t = 0; t < 256; ++t)
+            for (int r = 0; r < 2; ++r) {
+                int last = -1;
+                for (int j = 0; j < (int)ell_width; ++j) {
+                    const unsigned cword = cw[(size_t)(j >> 1) * 256 + t] >> (16 * (j & 1));
+                    const unsigned code = (cword >> (8 * r)) & 255u;
+                    if (code >= PL_PAD_FIRST) continue;
+                    if ((int)code >= ndeltas) return 0;
+                    const int p = position(table[code]);
+                    if (p <= last) return 0;
+                    last = p;
+                }
+            }
+    }
+    // the hot block; lines that use another one must be few (each change of the other block is a decode: two dependent loads)
+    std::vector<int64_t> uses((size_t)dictionary_blocks, 0);
+    for (int64_t k = 0; k < nslices; ++k) {
+        if (id[(size_t)k] < 0 || id[(size_t)k] >= dictionary_blocks) return 0;
+        ++uses[(size_t)id[(size_t)k]];
+    }
+    const int hot = (int)(std::max_element(uses.begin(), uses.end()) - uses.begin());
+    if ((nslices - uses[(size_t)hot]) * 16 > nslices && !force) return 0;
+    // planes per workgroup: about four workgroups per CU, all resident at once
+    const long long tiles = ny / 2, cus = std::max(1, info(dev).cus);
+    long long chunks = std::max(1ll, std::min(nz / 8, (4 * cus + tiles / 2) / tiles));
+    long long depth = (nz + chunks - 1) / chunks;
+    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
+    depth = std::min(depth, nz);
+    out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth; out->hot_block = hot;
+    out->x_last = x_last; out->usable = 1;
+    return 0;
+}
+
+int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane)
+{
+    VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
+    VEXHIP_REQUIRE(n > 0 && n % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
+    VEXHIP_REQUIRE(plane->lines_per_plane >= 4 && plane->lines_per_plane % 2 == 0 && plane->depth >= 1 && plane->planes >= 1
+                   && (plane->x_last + 1) % PL_ROWS == 0, "bad plane plan");
+    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "plane product: x and y must be 16-byte aligned");
+    VEXHIP_SET_DEVICE(dev);
+    plane_dev pd;
+    pd.nslices = n / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
+    pd.ny = plane->lines_per_plane; pd.nz = plane->planes; pd.depth = plane->depth;
+    pd.tiles = pd.ny / 2; pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
+    const long long chunks = (pd.nz + pd.depth - 1) / pd.depth;
+    const long long grid = 8ll * pd.tpx * chunks;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    sell8_plane_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(x, y, alpha, append, blocks, static_cast<const char *>(pool), deltas, values, pd);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+} // extern "C"

@@ -22,6 +22,7 @@ int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const 
 int hell_tail_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, int32_t *csr_ptr, int32_t *csr_col, float *csr_val);
 int sell8_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int64_t w, int32_t *deltas, int *ndeltas);
 void clear_max_col_hint();
+extern int g_sell8_variant;            // sell8.hip (vexhip_spmv_sell8_set_variant): 0 = default products
 // diagonals + values + largest ELL column in one pass over the CSR arrays (the fill that follows skips its own column pass)
 int analyze_fused_p32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val, int64_t w, int32_t *deltas, int *ndeltas, double *values, int *nvalues);
 int analyze_fused_p32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const float *val, int64_t w, int32_t *deltas, int *ndeltas, float *values, int *nvalues);
@@ -56,6 +57,7 @@ struct spmat {
     bool owns_csr = false;
     vexhip_traversal trav = {0, 0, 0, 0, nullptr};
     vexhip_march march = {0, 0, 0, 0, 0, 0, {0, 0, 0}};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
+    vexhip_plane plane = {0, 0, 0, 0, 0, 0, 0};              // plane product (plane.hip): 7-point pattern on 512-point lines; preferred to the march product
 };
 
 template <typename T> int dmalloc(T **p, size_t count) {
@@ -170,9 +172,14 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
         if (e != hipSuccess) return check(e, __FILE__, __LINE__);
         A->dict_blocks = nb; A->code_bytes = code_bytes;
         if (whole_slice) { (void)hipFree(A->sell); A->sell = nullptr; A->sell_bytes = 0; }
-        if (whole_slice && !(flags & VEXHIP_SPMAT_NO_MARCH))
-            if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, A->value_type == VEXHIP_F64 ? 8 : 4,
+        if (whole_slice && !(flags & VEXHIP_SPMAT_NO_MARCH)) {
+            const int vb = A->value_type == VEXHIP_F64 ? 8 : 4;
+            if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, vb,
                                                   &A->trav, vexhip_sell8_last_fill_max_col(), &A->march)) return rc2;
+            if (!(flags & VEXHIP_SPMAT_NO_PLANE))
+                if (int rc2 = vexhip_sell8_plane_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, A->pool, nb, A->ell_w, A->n, A->tail, vb,
+                                                      vexhip_sell8_last_fill_max_col(), &A->plane)) return rc2;
+        }
         return 0;
     }
     (void)hipFree(big); (void)hipFree(A->blocks); A->blocks = nullptr;
@@ -330,6 +337,10 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
     const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
     switch (A->format) {
         case VEXHIP_SPMAT_SELL8V:
+            if constexpr (std::is_same<V, double>::value)
+                if (A->blocks && A->plane.usable && g_sell8_variant == 0 && !A->tail)
+                    return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas,
+                                                            (const double *)A->values, x, y, &A->plane);
             if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
             return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL8:
@@ -413,6 +424,7 @@ int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
     o->traversal = A->trav;
     o->slice_blocks = A->blocks; o->code_pool = A->pool; o->dictionary_blocks = A->dict_blocks;
     o->march = A->march;
+    o->plane = A->plane;
     // bytes one product moves through HBM at least: the stored matrix + x once + y once (+ y read for "+=" not counted)
     const int64_t vb = A->value_type == VEXHIP_F64 ? 8 : 4;
     int64_t m = A->sell_bytes;

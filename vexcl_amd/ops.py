@@ -355,10 +355,12 @@ class SpMat:
 
     _FORMATS = {"sell": _capi.SPMAT_AUTO, "sell8": _capi.SPMAT_SELL8, "sell32": _capi.SPMAT_SELL, "csr": _capi.SPMAT_CSR}
 
-    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True, march=True):
+    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True, march=True, plane=True):
         """dictionary=False keeps one code block per slice even when the slices of a value-coded matrix repeat
         (VEXHIP_SPMAT_NO_DICTIONARY: A/B and tests); march=False keeps the pair product where the march product (x window
-        of the near diagonals in an LDS ring carried along a run of slices) would apply (VEXHIP_SPMAT_NO_MARCH)."""
+        of the near diagonals in an LDS ring carried along a run of slices) or the plane product would apply
+        (VEXHIP_SPMAT_NO_MARCH); plane=False keeps the march product where the plane product (round 4: two grid lines per
+        workgroup walked through the planes, neighbours in registers) would apply (VEXHIP_SPMAT_NO_PLANE)."""
         self.ptr, self.col, self.val = ptr, col, val
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
@@ -371,6 +373,7 @@ class SpMat:
         self.hell, self.handle, self.csr_trav = None, None, None
         self.dictionary_blocks = 0
         self.march = None
+        self.plane = None
         self.dtype = val.dtype
         if fmt == "hell":                        # the reference's column-major hybrid ELL (kept for A/B and sparse::ell)
             self.hell = HybridELL(ptr, col, val)
@@ -387,7 +390,8 @@ class SpMat:
                   (L.spmat_create_f64_i32 if f64 else L.spmat_create_f32_i32))
         create(
             _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
-            _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH), ctypes.byref(h))
+            _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH)
+            | (0 if plane else _capi.SPMAT_NO_PLANE), ctypes.byref(h))
         self.handle = h
         info = _capi.SpMatInfo()
         L.spmat_get_info(h, ctypes.byref(info))
@@ -397,6 +401,9 @@ class SpMat:
         self.march = ({"lo": int(info.march.lo), "hi": int(info.march.hi), "run": int(info.march.run), "x_last": int(info.march.x_last),
                        "far": [int(info.march.far[k]) for k in range(info.march.nfar)]}
                       if info.march.usable else None)              # not None: apply() runs the march product
+        self.plane = ({"lines_per_plane": int(info.plane.lines_per_plane), "planes": int(info.plane.planes), "depth": int(info.plane.depth),
+                       "hot_block": int(info.plane.hot_block), "x_last": int(info.plane.x_last)}
+                      if info.plane.usable else None)              # not None: apply() runs the plane product (fp64)
         self.fmt = "csr" if self.storage == "csr" else "sell"      # SELL without an ELL part degrades to CSR
         if self.fmt == "sell":
             self.hell = _SellInfo(info)
