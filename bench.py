@@ -15,14 +15,20 @@ evaluation of the stencil that involves no matrix and no transport (RCCL send/re
 windows, or torch.distributed requests; `distributed.transports_tried`).
 
 What the line reports, and how to read it:
-  value / hbm_gbps    2*nnz / t and CSR-ALGORITHMIC bytes / t (nnz*12 + (N+1)*4 + 16*N):
-                      the metric's own definition, independent of how the matrix is stored.
+  value / csr_algorithmic_gbps   2*nnz / t and CSR-ALGORITHMIC bytes / t (nnz*12 + (N+1)*4 + 16*N):
+                      the metric's own definition, independent of how the matrix is stored -- NOT an achieved HBM rate when the
+                      storage is smaller than CSR (it exceeds the 8 TB/s peak then); the achieved rate is roofline.achieved.
+  ms_per_step         the MEDIAN of five blocks of K steps (median-of-5 of total / M), each block bracketed by a
+                      barrier + synchronize on both sides; block 1 is the driver's "W warm-ups, then exactly K steps"; all five,
+                      their minimum and maximum are under `blocks`.
   roofline            the launched kernel against the HBM roofline by the bytes it REALLY moves: the stored matrix
                       (vexhip_spmat_get_info: matrix_bytes) + x once + y once.  frac <= 1 by construction.  `traffic`
                       = HBM bytes per launch measured in THIS run (rocprofv3 FETCH_SIZE / WRITE_SIZE passes over
-                      tools/pmc_headline.py, FETCH calibrated on a stream of known size), or null.  `device_copy`
-                      (march product): torch's copy of x to y timed in the same process -- the same HBM traffic as the
-                      product (x once, y once): what the memory system gives a kernel with nothing else to do.
+                      tools/pmc_headline.py, FETCH calibrated on a stream of known size), or null.  `device_copy_hand`
+                      (plane / march product): x copied to y by a hand kernel (vexhip_stream_copy_f64: one 16-byte pair per
+                      lane, non-temporal stores) in the same process -- the same HBM traffic as the product (x once, y once):
+                      what the memory system gives a kernel with nothing else to do; `device_copy`: torch's copy of the same;
+                      `frac_of_measured_copy` = hand copy time / product time.
   roofline_csr        the same product by kernels that stream fp64 values + int32 columns (no compression), priced
                       with the CSR-algorithmic bytes: SELL-512 with 32-bit columns and the CSR arrays themselves.
   variable_coefficient  the same 7-point pattern with a coefficient per face (~4 N distinct values: no value coding
@@ -52,7 +58,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
-KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true, false>", "sell8v_march": "sell8_march_kernel<double, 7>", "sell8": "sell8_pair_kernel<double, 7, false, false>",
+KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true, false>", "sell8v_march": "sell8_march_kernel<double, 7>", "sell8v_plane": "sell8_plane_kernel", "sell8": "sell8_pair_kernel<double, 7, false, false>",
              "sell32": "sell_pair_kernel<double, 7>", "csr": "csr_stream2_kernel<double, int, false>", "hell": "hell_kernel"}
 
 
@@ -206,7 +212,7 @@ def measure_traffic(grid, timeout=240):
                         continue
                     name = r["Kernel_Name"]
                     key = None
-                    for k in ("sell8_march_kernel", "sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
+                    for k in ("sell8_plane_kernel", "sell8_march_kernel", "sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
                         if k in name:
                             key = k
                             if k == "sell8_pair_kernel":
@@ -312,7 +318,9 @@ def main():
                          "(hipIpcGetMemHandle); torch = torch.distributed requests; auto = every one that validates, fastest wins")
     ap.add_argument("--trial-steps", type=int, default=100, help="N > 1, --transport auto: products timed per candidate transport")
     ap.add_argument("--no-dictionary", action="store_true", help="value-coded storage with one code block per slice (no slice dictionary)")
-    ap.add_argument("--no-march", action="store_true", help="keep the pair product where the march product (x window in an LDS ring, round 3) would apply")
+    ap.add_argument("--no-march", action="store_true", help="keep the pair product where the march / plane products would apply")
+    ap.add_argument("--no-plane", action="store_true", help="keep the march product (x window in an LDS ring, round 3) where the plane product (round 4) would apply")
+    ap.add_argument("--blocks", type=int, default=5, help="blocks of K steps; ms_per_step is their median (block 1 = the W warm-ups + exactly K steps of the contract)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the ~3 s back-to-back run of the product after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic = null)")
     args = ap.parse_args()
@@ -365,19 +373,21 @@ def main():
     y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
     setup = None
     march = None
+    plane = None
     if single:
         # set-up is timed (not part of `value`): CSR arrays in HBM -> the storage the product runs on.  A solver that rebuilds
         # its matrices (AMG set-up, a nonlinear iteration) pays this once per matrix.
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info(dev)[0]
         ts0 = time.perf_counter()
-        A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary, march=not args.no_march)
+        A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary, march=not args.no_march, plane=not args.no_plane)
         torch.cuda.synchronize()
         setup_ms = (time.perf_counter() - ts0) * 1e3
         storage = A.storage
         matrix_bytes = A.matrix_bytes()
         dict_blocks = A.dictionary_blocks
         march = A.march
+        plane = A.plane if x.dtype == torch.float64 else None
         setup = {"setup_ms": round(setup_ms, 3),
                  "what": "vexhip_spmat_create on CSR arrays resident in HBM: hybrid-ELL analysis, diagonal / value tables, fill, slice dictionary, march plan (host wall time, synchronised)",
                  "csr_input_bytes": int(ptr.numel() * ptr.element_size() + col.numel() * col.element_size() + val.numel() * val.element_size()),
@@ -395,6 +405,7 @@ def main():
         matrix_bytes = A.loc.matrix_bytes()
         dict_blocks = getattr(A.loc, "dictionary_blocks", 0)
         march = getattr(A.loc, "march", None)
+        plane = getattr(A.loc, "plane", None)
         step = lambda: A.apply(x, y, 1.0, False)
 
         # ---- every transport is validated against an evaluation that trusts NO transport: x is a hash of the global index,
@@ -543,27 +554,36 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    L.event_record(local_rank, e0, stream)
-    for _ in range(args.steps):
-        step()
-    L.event_record(local_rank, e1, stream)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    ms = ctypes.c_float()
-    L.event_elapsed_ms(local_rank, e0, e1, ctypes.byref(ms))
+    # Five blocks of exactly K steps, each bracketed by a barrier + torch.cuda.synchronize() on both sides and by HIP events on
+    # the launch stream; the wall time of a block is the MAX over the ranks.  Block 1 is the driver's contract (W warm-ups, then
+    # exactly K steps); the headline is the median block (median-of-5 of total / M).
+    block_wall, block_kern = [], []
+    for _blk in range(max(1, args.blocks)):
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        L.event_record(local_rank, e0, stream)
+        for _ in range(args.steps):
+            step()
+        L.event_record(local_rank, e1, stream)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        ms = ctypes.c_float()
+        L.event_elapsed_ms(local_rank, e0, e1, ctypes.byref(ms))
+        block_wall.append(t1 - t0); block_kern.append(ms.value)
+    if world > 1:
+        t = torch.tensor(block_wall, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        block_wall = [float(v) for v in t]
+    order = sorted(range(len(block_wall)), key=lambda i: block_wall[i])
+    mid = order[len(order) // 2]
 
     checksum = DistReductor("SUM_Kahan")(y)          # sum(y): the same for every N up to rounding
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = block_wall[mid]
     per_step = elapsed / args.steps
-    kern_s = ms.value / 1e3 / args.steps         # average launch duration of the product on this rank
+    kern_s = block_kern[mid] / 1e3 / args.steps   # average launch duration of the product on this rank in the median block (HIP events)
+    ms = ctypes.c_float(block_kern[mid])
 
     check = None
     dist_extra = None
@@ -646,16 +666,23 @@ def main():
             "data": "synthetic",
             "front_end": "vexcl_amd/ops.py SpMat -> vexhip_spmat_create / vexhip_spmat_apply_f64 (the C++ vex::SpMat calls the same two; "
                          "its own timing of this product is under secondary['C++ front end'])",
+            "blocks": {"what": "blocks of K steps, each between barrier + synchronize; ms_per_step is the median block; block 1 = W warm-ups then exactly K steps",
+                       "ms_per_step": [round(w / args.steps * 1e3, 5) for w in block_wall],
+                       "min": round(min(block_wall) / args.steps * 1e3, 5), "max": round(max(block_wall) / args.steps * 1e3, 5),
+                       "event_ms_per_step": [round(k / args.steps, 5) for k in block_kern]},
             "checksum": check if check else {"sum_y": checksum},
-            "hbm_gbps": round(gbps, 1),
-            "hbm_gbps_note": "CSR-algorithmic bytes / time (the metric's definition); the kernel's own traffic is under roofline",
+            "csr_algorithmic_gbps": round(gbps, 1),
+            "csr_algorithmic_gbps_note": "CSR-algorithmic bytes / time (the metric's definition, SURVEY 8(d)); NOT an HBM rate when the storage is "
+                                         "smaller than CSR -- the bytes the kernel moves and its achieved rate are under roofline",
             "config": {"workload": "configs[%d]: 7-point 3D Poisson %d^3, N=%d rows, nnz=%d, fp64 values, int32 indices"
                                    % (2 if world == 1 else 3, n, N, nnz_total),
                        "format": storage, "rows_per_gpu": rows_rank,
                        "parallelism": "row-partitioned x%d" % world},
             "roofline": {"bound": "hbm",
-                         "kernel": (KERNEL_OF["sell8v_march"] if (storage == "sell8v" and march) else
+                         "kernel": (("sell8_plane_kernel<%d, false, %d>" % (plane["tile"], {0: 2, 1: 18, 2: 17, 3: 0}[plane["store_policy"]])) if (storage == "sell8v" and plane) else
+                                    KERNEL_OF["sell8v_march"] if (storage == "sell8v" and march) else
                                     "sell8_pair_kernel<double, 7, true, true>" if (storage == "sell8v" and dict_blocks) else KERNEL_OF.get(storage, storage)),
+                         "plane": plane,
                          "march": march,
                          "achieved": round(moved_rank / kern_s / 1e9, 1),
                          "peak": HBM_PEAK_GBPS,
@@ -672,31 +699,45 @@ def main():
         }
         if setup is not None:
             out["setup"] = setup
-        if storage == "sell8v" and dict_blocks and march:
-            # the march product: the near diagonals' window of x comes once per slice (8 B/row + the overlap of a run's first
-            # window), the two far diagonals come as two more coalesced streams (16 B/row), y is stored (8 B/row); codes are
-            # decoded once per run.  HBM sees x and y once -- the traffic of a copy of x to y, timed here for comparison.
-            l1_bytes = (8 + 16 + 8) * rows_rank
-            out["roofline"]["on_chip"] = {
-                "what": "bytes through L1 per launch: window 8 B/row + far diagonals 16 B/row + y 8 B/row; HBM sees x and y once; "
-                        "with four workgroups per CU the memory system is saturated (profiles/r03_sq_summary_march_v8.txt, DESIGN.md 3.0b)",
-                "bytes_per_launch": l1_bytes, "achieved": round(l1_bytes / kern_s / 1e9, 1), "peak_l2": 34500.0, "unit": "GB/s",
-                "frac_of_l2": round(l1_bytes / kern_s / 1e9 / 34500.0, 4)}
+        if storage == "sell8v" and dict_blocks and (march or plane):
+            if plane:
+                # the plane product: per plane step a lane requests tile + 2 pairs of x for tile lines (centre lines + the two halo
+                # lines; +-512 / +-P neighbours are its own earlier loads), 8 B per wave end and line for the +-1 neighbours, and
+                # stores tile pairs.  HBM sees x and y once -- the traffic of a copy of x to y.
+                tl = plane["tile"]
+                l1_bytes = int((8 * (tl + 2) / tl + 8) * rows_rank)
+                out["roofline"]["on_chip"] = {
+                    "what": "bytes through L1 per launch: x %.0f B/row (tile %d: centre lines + 2 halo lines per %d) + y 8 B/row; HBM sees x and y once; "
+                            "no LDS in the fast loop (profiles/r04_sq_summary_plane.txt, DESIGN.md 3.0c)" % (8 * (tl + 2) / tl, tl, tl),
+                    "bytes_per_launch": l1_bytes, "achieved": round(l1_bytes / kern_s / 1e9, 1), "peak_l2": 34500.0, "unit": "GB/s",
+                    "frac_of_l2": round(l1_bytes / kern_s / 1e9 / 34500.0, 4)}
+            else:
+                # the march product: the near diagonals' window of x comes once per slice (8 B/row + the overlap of a run's first
+                # window), the two far diagonals come as two more coalesced streams (16 B/row), y is stored (8 B/row); codes are
+                # decoded once per run.  HBM sees x and y once -- the traffic of a copy of x to y, timed here for comparison.
+                l1_bytes = (8 + 16 + 8) * rows_rank
+                out["roofline"]["on_chip"] = {
+                    "what": "bytes through L1 per launch: window 8 B/row + far diagonals 16 B/row + y 8 B/row; HBM sees x and y once; "
+                            "with four workgroups per CU the memory system is saturated (profiles/r03_sq_summary_march_v8.txt, DESIGN.md 3.0b)",
+                    "bytes_per_launch": l1_bytes, "achieved": round(l1_bytes / kern_s / 1e9, 1), "peak_l2": 34500.0, "unit": "GB/s",
+                    "frac_of_l2": round(l1_bytes / kern_s / 1e9 / 34500.0, 4)}
             try:
                 yc = torch.empty_like(x)
-                for _ in range(10):
-                    yc.copy_(x)
-                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                c0.record()
-                for _ in range(20):
-                    yc.copy_(x)
-                c1.record(); torch.cuda.synchronize()
-                copy_s = c0.elapsed_time(c1) / 20 / 1e3
-                out["roofline"]["device_copy"] = {
-                    "what": "torch's copy of x to y on this device, same process: the same HBM traffic as the product (x once, y once)",
-                    "ms": round(copy_s * 1e3, 5), "gbps": round(2 * x.numel() * x.element_size() / copy_s / 1e9, 1),
-                    "copy_over_product": round(copy_s / kern_s, 4)}
+                copies = {"device_copy": ("torch's copy of x to y on this device, same process: the same HBM traffic as the product (x once, y once)",
+                                          lambda: yc.copy_(x)),
+                          "device_copy_hand": ("vexhip_stream_copy_f64: x copied to y with one 16-byte pair per lane and non-temporal stores, same process -- "
+                                               "the ceiling the memory system gives a kernel that moves these bytes and does nothing else",
+                                               lambda: L.stream_copy_f64(local_rank, stream, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(yc.data_ptr()), x.numel()))}
+                for name, (what, fn) in copies.items():
+                    copy_ms = min(timed_events(torch, fn, 20) for _ in range(3))
+                    out["roofline"][name] = {"what": what, "ms": round(copy_ms, 5), "gbps": round(2 * x.numel() * x.element_size() / copy_ms / 1e6, 1),
+                                             "frac_of_8TBps": round(2 * x.numel() * x.element_size() / copy_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                                             "copy_over_product": round(copy_ms / 1e3 / kern_s, 4)}
+                assert torch.equal(yc, x), "vexhip_stream_copy_f64 does not copy"
+                out["roofline"]["frac_of_measured_copy"] = out["roofline"]["device_copy_hand"]["copy_over_product"]
                 del yc
+            except AssertionError:
+                raise
             except Exception as e:  # noqa: BLE001 -- a comparison, not the measurement
                 out["roofline"]["device_copy"] = {"error": str(e)[:200]}
         elif storage == "sell8v" and dict_blocks:
@@ -725,8 +766,17 @@ def main():
                 torch.cuda.empty_cache()
                 p2, c2, v2 = ops.poisson3d(n, dev)
                 rcsr = []
+                if storage == "sell8v" and plane and march:
+                    # the march product of round 3 on the same storage (the plane product replaces it where it applies)
+                    B = ops.SpMat(p2, c2, v2, fmt=args.format, plane=False)
+                    tb = timed_events(torch, lambda: B.apply(x, y), 40)
+                    assert abs(DistReductor("SUM_Kahan")(y) - checksum) <= 1e-10 * abs(checksum) + 1e-300
+                    out["march_product"] = {"kernel": KERNEL_OF["sell8v_march"], "avg_launch_ms": round(tb, 5),
+                                            "gflops": round(2.0 * nnz_total / tb / 1e6, 1),
+                                            "what": "the same storage through the round-3 kernel (VEXHIP_SPMAT_NO_PLANE): x window in an LDS ring along runs of slices"}
+                    del B
                 if storage == "sell8v" and march:
-                    # the pair product of round 2 on the same storage (the march product replaces it where it applies)
+                    # the pair product of round 2 on the same storage (the march / plane products replace it where they apply)
                     B = ops.SpMat(p2, c2, v2, fmt=args.format, march=False)
                     tb = timed_events(torch, lambda: B.apply(x, y), 40)
                     assert abs(DistReductor("SUM_Kahan")(y) - checksum) <= 1e-10 * abs(checksum) + 1e-300
@@ -806,6 +856,8 @@ def main():
                 key = {"sell8v": "sell8_pair_kernel_vcoded", "sell8": "sell8_pair_kernel_values", "sell32": "sell_pair_kernel", "csr": "csr_stream2_kernel"}.get(storage)
                 if storage == "sell8v" and march:
                     key = "sell8_march_kernel"
+                if storage == "sell8v" and plane:
+                    key = "sell8_plane_kernel"
                 if key in tr:
                     out["roofline"]["traffic"] = tr[key]["total"]
                     out["roofline"]["traffic_read_written"] = [tr[key]["read"], tr[key]["written"]]

@@ -280,12 +280,18 @@ typedef struct vexhip_plane { int32_t usable;
                               int32_t planes;            /* ceil(slices / lines_per_plane)                                    */
                               int32_t depth;             /* planes one workgroup walks through                                */
                               int32_t hot_block;         /* dictionary block kept decoded in registers                        */
+                              int32_t tile;              /* grid lines per workgroup: 2 or 4 (divides lines_per_plane)        */
+                              int32_t store_policy;      /* y stores: 0 non-temporal, 1 non-temporal + sc1, 2 sc0 sc1, 3 plain  */
                               int32_t reserved;
                               int64_t x_last;
                             } vexhip_plane;
 int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
         const void *pool, int64_t dictionary_blocks, int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes,
         int64_t x_last, vexhip_plane *out);
+/* y = x with one 16-byte pair per lane and non-temporal stores: the measured ceiling for a product whose HBM traffic is x once
+ * + y once (bench.py roofline.device_copy_hand); the reference times its copies through clEnqueueCopyBuffer
+ * (vexcl/backend/opencl/device_vector.hpp) -- this is the device-side counterpart used as a yardstick only.             */
+int vexhip_stream_copy_f64(int dev, void *stream, const double *x, double *y, int64_t n);
 int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
 int64_t vexhip_sell8_last_fill_max_col(void);

@@ -368,6 +368,117 @@ def test_march_with_one_far_diagonal_and_narrow_widths(T, oracle, built_lib):
     assert np.isfinite(a[2048:m - 2048]).all()
 
 
+def _grid7(nx, ny, nz):
+    """7-point operator on an nx x ny x nz grid in the benchmark's form (examples/benchmark.cpp:364-415: boundary rows identity,
+    interior rows -h, -h, -h, 6h, -h, -h, -h in that order), CSR with int32 indices; three distinct values"""
+    N = nx * ny * nz
+    idx = np.arange(N, dtype=np.int64)
+    i, j, k = idx % nx, (idx // nx) % ny, idx // (nx * ny)
+    interior = (i > 0) & (i < nx - 1) & (j > 0) & (j < ny - 1) & (k > 0) & (k < nz - 1)
+    cnt = np.where(interior, 7, 1)
+    ptr = np.zeros(N + 1, dtype=np.int64); ptr[1:] = np.cumsum(cnt)
+    col = np.empty(ptr[-1], dtype=np.int32); val = np.empty(ptr[-1], dtype=np.float64)
+    b = ~interior
+    col[ptr[:-1][b]] = idx[b]; val[ptr[:-1][b]] = 1.0
+    h = float((nx - 1) ** 2)
+    base = ptr[:-1][interior]
+    for q, (off, v) in enumerate(((-nx * ny, -h), (-nx, -h), (-1, -h), (0, 6 * h), (1, -h), (nx, -h), (nx * ny, -h))):
+        col[base + q] = idx[interior] + off; val[base + q] = v
+    return ptr.astype(np.int32), col, val
+
+
+@pytest.mark.parametrize("tile", [2, 4])
+def test_plane_product_is_bit_identical(T, oracle, built_lib, tile):
+    """The plane product (round 4: a workgroup owns `tile` grid lines of 512 points and walks through the planes; the +-512 and
+    +-P neighbours of a lane's rows stay in registers, the +-1 neighbours come by DPP wave shifts) against the pair product AND
+    the CSR restatement, bit for bit.  (a) small banded matrices through the forced plan (VEXHIP_PLANE_FORCE: five dictionary
+    blocks, lines that change their block from plane to plane, a ragged last plane, walks shorter than a group of four
+    steps), '=' and '+= alpha'; (b) the plan as the library chooses it on a 512 x 64 x 80 band and on the benchmark's
+    operator on a 512 x 72 x 72 grid (identity rows on every face: the hot block + one other block per line and plane);
+    (c) x holding Inf / NaN where positions without an entry 'cover' it; (d) what the plan must decline."""
+    torch = T.torch
+    os.environ["VEXHIP_PLANE_TILE"] = str(tile)
+    try:
+        os.environ["VEXHIP_PLANE_FORCE"] = "1"
+        for ny, nz, extra, depth in ((8, 12, 0, None), (4, 40, 0, None), (16, 9, 3 * 512, None), (12, 33, 5 * 512, 7), (8, 21, 0, 3)):
+            if depth is None:
+                os.environ.pop("VEXHIP_PLANE_DEPTH", None)
+            else:
+                os.environ["VEXHIP_PLANE_DEPTH"] = str(depth)
+            P = 512 * ny
+            m = P * nz + extra
+            ptr, col, val = _band(m, (-P, -512, -1, 0, 1, 512, P), 5, constant=True)
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+            assert A.storage == "sell8v" and A.plane is not None and B.plane is None and B.march is None, (ny, nz, A.plane)
+            assert A.plane["lines_per_plane"] == ny and A.plane["tile"] == (tile if ny % tile == 0 else 2), A.plane
+            xb = oracle.random_f64(21, m); y0 = oracle.random_f64(22, m)
+            want = oracle.spmv_csr(ptr, col, val, xb)
+            for alpha, append in ((1.0, False), (-0.75, True)):
+                ya, yb = T.up(y0.copy()), T.up(y0.copy())
+                A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+                assert torch.equal(ya, yb), (ny, nz, alpha)
+                assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (ny, nz, alpha)
+        os.environ.pop("VEXHIP_PLANE_DEPTH", None)
+        # (c) Inf / NaN in x: only the rows that reference them may see them
+        ny, nz = 8, 12
+        P = 512 * ny; m = P * nz
+        ptr, col, val = _band(m, (-P, -512, -1, 0, 1, 512, P), 5, constant=True)
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        assert A.plane is not None
+        xb = oracle.random_f64(23, m)
+        xb[0] = np.inf; xb[1] = -np.inf; xb[m - 1] = np.nan; xb[5 * P + 3 * 512 + 255] = np.nan
+        ya = torch.empty(m, dtype=torch.float64, device=T.dev)
+        A.apply(T.up(xb), ya)
+        assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb), equal_nan=True)
+        os.environ.pop("VEXHIP_PLANE_FORCE")
+
+        # (b) the plan as the library chooses it
+        ny, nz = 64, 80
+        P = 512 * ny; m = P * nz
+        ptr, col, val = _band(m, (-P, -512, -1, 0, 1, 512, P), 6, constant=True)
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), plane=False)
+        assert A.plane is not None and A.plane["lines_per_plane"] == ny and A.plane["planes"] == nz and B.plane is None and B.march is not None
+        xb = oracle.random_f64(24, m)
+        ya = torch.empty(m, dtype=torch.float64, device=T.dev); yb = torch.empty_like(ya)
+        A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
+        assert torch.equal(ya, yb)
+        assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
+        ptr, col, val = _grid7(512, 72, 72)
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+        assert A.storage == "sell8v" and A.dictionary_blocks == 2 and A.plane is not None and A.plane["lines_per_plane"] == 72, (A.plane, A.dictionary_blocks)
+        m = 512 * 72 * 72
+        xb = oracle.random_f64(25, m); y0 = oracle.random_f64(26, m)
+        want = oracle.spmv_csr(ptr, col, val, xb)
+        for alpha, append in ((1.0, False), (2.5, True)):
+            ya, yb = T.up(y0.copy()), T.up(y0.copy())
+            A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+            assert torch.equal(ya, yb), alpha
+            assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), alpha
+
+        # (d) declined: an eighth diagonal; fp32; rows whose entries do not ascend by diagonal (storage order is not position
+        # order); a matrix whose rows do not fill whole lines; lines per plane not even
+        P = 512 * 64; m = P * 40
+        ptr, col, val = _band(m, (-P, -512, -2, -1, 0, 1, 512, P), 7, constant=True)
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)).plane is None
+        ptr, col, val = _band(m, (-P, -512, -1, 0, 1, 512, P), 7, constant=True)
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val.astype(np.float32))).plane is None
+        rcol, rval = col.copy(), val.copy()
+        for r in range(3 * P, 3 * P + 2048):                      # a few rows with their entries reversed
+            rcol[ptr[r]:ptr[r + 1]] = col[ptr[r]:ptr[r + 1]][::-1]; rval[ptr[r]:ptr[r + 1]] = val[ptr[r]:ptr[r + 1]][::-1]
+        R = T.ops.SpMat(T.up(ptr), T.up(rcol), T.up(rval))
+        assert R.plane is None
+        xb = oracle.random_f64(27, m)
+        assert np.array_equal((R @ T.up(xb)).cpu().numpy(), oracle.spmv_csr(ptr, rcol, rval, xb))
+        ptr, col, val = _band(m + 100, (-P, -512, -1, 0, 1, 512, P), 7, constant=True)
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)).plane is None
+        P = 512 * 63
+        ptr, col, val = _band(P * 40, (-P, -512, -1, 0, 1, 512, P), 7, constant=True)
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)).plane is None
+    finally:
+        for k in ("VEXHIP_PLANE_TILE", "VEXHIP_PLANE_FORCE", "VEXHIP_PLANE_DEPTH"):
+            os.environ.pop(k, None)
+
+
 def test_march_needs_slices_that_repeat_in_runs(T, built_lib):
     """384^3: a grid line is 384 rows, a slice 512 -- the code blocks of consecutive slices cycle with period 3, every
     slice would decode anew, so the plan declines and the pair product runs (checked against an independent stencil
@@ -477,8 +588,17 @@ def test_poisson512_properties(T):
     # the default product here is the march product on the XCD strip order (64 slices per strip, runs of 16); the pair product
     # of the same storage must give the same bits
     assert A_ell.march is not None and A_ell.march["far"] == [-262144, 262144] and A_ell.info.traversal.chunk % A_ell.march["run"] == 0
+    # round 4: the default product is the plane product (512 lines per plane); the march product of the same storage must give
+    # the same bits, also for '+= alpha'
+    assert A_ell.plane is not None and A_ell.plane["lines_per_plane"] == 512 and A_ell.plane["planes"] == 512, A_ell.plane
+    A_march = ops.SpMat(dp, dc, dv, plane=False)
+    assert A_march.plane is None and A_march.march is not None and torch.equal(A_march @ x, y2)
+    ya = y1.clone(); yb = y1.clone()
+    A_ell.apply(x, ya, -0.5, True); A_march.apply(x, yb, -0.5, True)
+    assert torch.equal(ya, yb)
+    del A_march, ya, yb
     A_pair = ops.SpMat(dp, dc, dv, march=False)
-    assert A_pair.march is None and torch.equal(A_pair @ x, y2)
+    assert A_pair.march is None and A_pair.plane is None and torch.equal(A_pair @ x, y2)
     del A_pair
     assert torch.equal(y1, A_hell @ x)
     y0 = torch.empty_like(y1)

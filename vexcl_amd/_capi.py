@@ -63,7 +63,8 @@ class March(ctypes.Structure):
 class Plane(ctypes.Structure):
     """vexhip_plane (include/vexhip.h)."""
     _fields_ = [("usable", ctypes.c_int32), ("lines_per_plane", ctypes.c_int32), ("planes", ctypes.c_int32), ("depth", ctypes.c_int32),
-                ("hot_block", ctypes.c_int32), ("reserved", ctypes.c_int32), ("x_last", ctypes.c_int64)]
+                ("hot_block", ctypes.c_int32), ("tile", ctypes.c_int32), ("store_policy", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("x_last", ctypes.c_int64)]
 
 
 class SpMatInfo(ctypes.Structure):
@@ -161,6 +162,7 @@ _PROTOS = {
     "vexhip_spmv_sell8_dict_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal)]),
     "vexhip_sell8_march_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_int, ctypes.POINTER(Traversal), c_i64, ctypes.POINTER(March)]),
     "vexhip_sell8_last_fill_max_col": (c_i64, []),
+    "vexhip_stream_copy_f64": (None, [c_int, c_vp, c_vp, c_vp, c_i64]),
     "vexhip_sell8_plane_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, ctypes.POINTER(Plane)]),
     "vexhip_spmv_sell8v_plane_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Plane)]),
     "vexhip_spmv_sell8v_march_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),

@@ -37,6 +37,7 @@ namespace {
 constexpr int PL_ROWS = 512;
 constexpr unsigned PL_PAD_FIRST = 254;      // codes 254 / 255 are padding (sell8.hip)
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 struct plane_dev {
     long long nslices;       // 512-row lines of the matrix
@@ -45,7 +46,7 @@ struct plane_dev {
     int ny;                  // lines per plane
     int nz;                  // planes: ceil(nslices / ny)
     int depth;               // planes per workgroup
-    int tiles;               // ny / 2
+    int tiles;               // ny / tile height
     int tpx;                 // tiles per XCD: ceil(tiles / 8)
     int hot;                 // dictionary block decoded into registers with scalar masks
     int w;                   // ELL width (<= 8)
@@ -79,8 +80,9 @@ __device__ __forceinline__ int position_of(int d, int far) {
     return d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -PL_ROWS ? 1 : d == PL_ROWS ? 5 : d == -far ? 0 : 6;
 }
 
-__global__ __launch_bounds__(256, 4)
-void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha, int append,
+template <int TY, bool APPEND, int STORE_AUX>
+__global__ __launch_bounds__(256, TY == 2 ? 4 : 2)
+void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
         plane_dev pd)
 {
@@ -92,12 +94,11 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     __shared__ double s_other[15][256];
 
     const int t = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
     const int zc = (int)(q / (unsigned)pd.tpx), tyl = (int)(q - (unsigned)zc * (unsigned)pd.tpx);
     const int tile = (int)xcd * pd.tpx + tyl;
     if (tile >= pd.tiles) return;                                   // the whole workgroup
-    const int y0 = 2 * tile;
+    const int y0 = TY * tile;
     int z = zc * pd.depth;
     const int zend = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
     if (z >= zend) return;
@@ -105,6 +106,9 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     const int nslices = (int)pd.nslices, xlines = (int)pd.xlines;
     const long long x_last = pd.x_last;
     const unsigned lane_b = 16u * (unsigned)t;
+    // the element beyond either end of the wave's 128 rows of a line: lane 63 reads the one behind them, every other lane the
+    // one in front (lane 0 uses it; one cache line for the rest) -- byte offset from the start of the line
+    const int edge_b = (t >> 6) * 1024 + ((t & 63) == 63 ? 1024 : -8);
 
     s_slot[t] = 2 * position_of(deltas[t], pd.far); s_value[t] = values[t];
     __syncthreads();
@@ -134,10 +138,11 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
         return bits & 0x3fffu;
     };
 
+    const int hot = pd.hot;
     double aH[7][2];                            // the hot block: values ...
     unsigned long long mH[7][2];                // ... and the lanes with an entry, per position and row
     {
-        const unsigned bitsH = decode(pd.hot);
+        const unsigned bitsH = decode(hot);
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
             aH[p][0] = s_other[2 * p][t]; aH[p][1] = s_other[2 * p + 1][t];
@@ -148,8 +153,9 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     unsigned bitsO = 0;
     int other = -1;                             // what s_other holds now is the hot block's: never asked for
 
-    // line `l` of the tile's window (0 = the line above the tile, 1, 2 = the tile, 3 = the line below) in plane zz; clamped:
-    // a line outside x is never referenced by an entry, what is loaded in its place is multiplied by +0.0 behind a mask
+    // clamped requests (prologue, slow steps): line `l` of the tile's window (0 = the line above the tile, 1 .. TY = the tile,
+    // TY + 1 = the line below) in plane zz.  A line outside x is never referenced by an entry; what is loaded in its place is
+    // multiplied by +0.0 behind a mask
     auto line_of = [&](int zz, int l) -> int {
         int li = zz * ny + (y0 - 1 + l);
         li = li < 0 ? 0 : li; li = li >= xlines ? xlines - 1 : li;
@@ -159,73 +165,165 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
         const char *p = reinterpret_cast<const char *>(x + (long long)line_of(zz, l) * PL_ROWS);
         return *reinterpret_cast<const d2 *>(p + lane_b);
     };
-    auto edge = [&](int zz, int l, int side) -> double {          // uniform address: a scalar load
-        long long i = (long long)line_of(zz, l) * PL_ROWS + wv * 128 + (side ? 128 : -1);
+    auto edge = [&](int zz, int l) -> double {
+        long long i = (long long)line_of(zz, l) * PL_ROWS + (edge_b >> 3);
         i = i < 0 ? 0 : i; i = i > x_last ? x_last : i;
         return x[i];
     };
-    auto block_of = [&](int zz, int l) -> int {
+    auto yold = [&](int zz, int l) -> d2 {
         int li = zz * ny + (y0 + l);
         li = li < 0 ? 0 : li; li = li >= nslices ? nslices - 1 : li;
-        return blocks[li];
+        return *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(y + (long long)li * PL_ROWS) + lane_b);
     };
 
-    d2 prev[2], cur[4], nxt[2], ph[2], pc[2];
-    double eL[2], eR[2], peL[2], peR[2];
-    int bl[2], pbl[2];
+    // ---- state at the top of the step for plane z (canonical naming) ----
+    // Cs[0..3]: the tile's two centre lines in planes z-1, z, z+1, z+2;  Hs[0..1]: the halo lines (above, below) in planes z, z+1;
+    // Es[0..1]: per centre line the edge element of this lane (lane 0: the one in front of the wave's rows, lane 63: the one behind)
+    // in planes z, z+1.  A step consumes plane z-1's centres and plane z's halos and edges and requests into the SAME registers
+    // what plays that role three (centres) or two planes later: every request has two steps to arrive.  The fast loop runs
+    // GROUPS of four steps with the names rotated: after four steps every name is back in place and no register is copied (a
+    // copy behind a request makes the step wait for it: the one-step form of this loop ran 8 % slower).  It contains no memory
+    // instruction other than these requests and the stores, so that the waits of a step count what the step before requested;
+    // which block a line uses is known for up to 64 planes ahead (one look at blocks[] per entry).
+    d2 Cs[4][TY], Hs[2][2], Yo[TY];
+    double Es[2][TY];
+    const unsigned plane_b32 = (unsigned)ny * (PL_ROWS * 8u);          // bytes from a line to the same line of the next plane (the plan: (depth + 4) of them < 2^32)
+    const int z_first = z;
+    // buffer resources of the fast loop: x from the line above the tile in the workgroup's first plane, y from the tile's first
+    // line in that plane (no range check: the fast loop only runs where every request lies inside the arrays)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(x + ((long long)z_first * ny + (y0 - 1)) * PL_ROWS), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + ((long long)z_first * ny + y0) * PL_ROWS, 0, -1, 0x00020000);
 #pragma unroll
-    for (int l = 0; l < 2; ++l) { prev[l] = ld(z - 1, l + 1); nxt[l] = ld(z + 1, l + 1); pc[l] = ld(z + 2, l + 1); }
+    for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
+    Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
 #pragma unroll
-    for (int l = 0; l < 4; ++l) cur[l] = ld(z, l);
-    ph[0] = ld(z + 1, 0); ph[1] = ld(z + 1, 3);
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        eL[l] = edge(z, l + 1, 0); eR[l] = edge(z, l + 1, 1); peL[l] = edge(z + 1, l + 1, 0); peR[l] = edge(z + 1, l + 1, 1);
-        bl[l] = block_of(z, l); pbl[l] = block_of(z + 1, l);
+    for (int l = 0; l < TY; ++l) {
+        Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
+        if (APPEND) Yo[l] = yold(z, l);
     }
 
-    for (; z < zend; ++z) {
-        // ---- the two lines of plane z ----
+    // the lane's sums for tile line l: x at the seven positions from the registers named above
+#define PLANE_XS(P, C, N, H, E, l)                                                                                                   \
+        const d2 c = C[l], up = (l) == 0 ? H[0] : C[(l) > 0 ? (l) - 1 : 0], dn = (l) == TY - 1 ? H[1] : C[(l) < TY - 1 ? (l) + 1 : 0];                                                  \
+        const double xs0[7] = {P[l].x, up.x, shift_from_lower_lane(c.y, E[l]), c.x, c.y, dn.x, N[l].x};                                \
+        const double xs1[7] = {P[l].y, up.y, c.x, c.y, shift_from_upper_lane(c.x, E[l]), dn.y, N[l].y};
+#define PLANE_HOT_SUMS(s0, s1)                                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) { s0 += aH[p][0] * keep_lanes(xs0[p], mH[p][0]); s1 += aH[p][1] * keep_lanes(xs1[p], mH[p][1]); }
+#define PLANE_OTHER_SUMS(s0, s1)                                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) {                                                                               \
+            s0 += s_other[2 * p][t] * keep_bit(xs0[p], bitsO, 2 * p); s1 += s_other[2 * p + 1][t] * keep_bit(xs1[p], bitsO, 2 * p + 1); }
+
+    // fast steps need nothing clamped: planes up to z + 3 inside x, both lines inside y
+    int zh = zend;
+    {
+        const int a = (xlines - 1 - TY - y0) / ny - 3, bb = (nslices - TY - y0) / ny;      // largest z with (z+3) ny + y0 + TY <= xlines - 1 / z ny + y0 + TY - 1 <= nslices - 1
+        if (xlines - 1 - TY - y0 < 0 || nslices - TY - y0 < 0) zh = 0;
+        else { zh = zh < a + 1 ? zh : a + 1; zh = zh < bb + 1 ? zh : bb + 1; }
+    }
+
+    while (z < zend) {
+        // ---- how many of the next planes (<= 64) can take fast steps: both lines use the hot block or the other block ----
+        unsigned long long use_hot[TY];          // bit k: line l of plane z + k uses the hot block (else: the other block)
+        int run;
+        {
+            const int k = t & 63, zz = z + k;
+            const bool in = zz < zh;
+            bool ok = in;
 #pragma unroll
-        for (int l = 0; l < 2; ++l) {
+            for (int l = 0; l < TY; ++l) {
+                const int bk = in ? blocks[(long long)zz * ny + (y0 + l)] : hot;
+                ok = ok && (bk == hot || bk == other);
+                use_hot[l] = __builtin_amdgcn_ballot_w64(bk == hot);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+            run = ~m ? __builtin_ctzll(~m) : 64;
+        }
+        if (run >= 4) {
+            // Buffer addressing: a resource per array (scalar), the lane's byte offset (ONE vector register for the whole
+            // kernel) and a scalar offset that moves with the planes -- no 64-bit vector address arithmetic, which cost a dozen
+            // registers and, re-using the registers of requests still in flight, forced early waits.  xo: plane z + 2, the
+            // line above the tile; yo: plane z, the tile's first line; both relative to the workgroup's first plane.
+            unsigned xo = (unsigned)((z + 2 - z_first) * plane_b32), yo = (unsigned)((z - z_first) * plane_b32);
+            auto fast_step = [&](d2 (&P)[TY], d2 (&C)[TY], d2 (&N)[TY], d2 (&H)[2], double (&E)[TY]) {
+                d2 o[TY];
+#pragma unroll
+                for (int l = 0; l < TY; ++l) {
+                    PLANE_XS(P, C, N, H, E, l)
+                    double s0 = 0.0, s1 = 0.0;
+                    if (use_hot[l] & 1ull) { PLANE_HOT_SUMS(s0, s1) } else { PLANE_OTHER_SUMS(s0, s1) }      // uniform
+                    o[l].x = alpha * s0; o[l].y = alpha * s1;
+                    if (APPEND) { o[l].x = Yo[l].x + o[l].x; o[l].y = Yo[l].y + o[l].y; }
+                }
+#pragma unroll
+                for (int l = 0; l < TY; ++l) use_hot[l] >>= 1;
+#pragma unroll
+                for (int l = 0; l < TY; ++l)       // written once, not read again by this kernel
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[l]), ry, (int)lane_b, (int)(yo + l * 4096u), STORE_AUX);
+                if (APPEND) {
+#pragma unroll
+                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)lane_b, (int)(yo + plane_b32 + l * 4096u), 0));
+                }
+                H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
+                H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * 4096u), 0));
+#pragma unroll
+                for (int l = 0; l < TY; ++l) {
+                    P[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + plane_b32 + (l + 1) * 4096u), 0));
+                    E[l] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, edge_b + 8, (int)(xo + (l + 1) * 4096u - 8u), 0));
+                }
+                xo += plane_b32; yo += plane_b32; ++z;
+            };
+            for (int g = run >> 2; g > 0; --g) {
+                fast_step(Cs[0], Cs[1], Cs[2], Hs[0], Es[0]);
+                fast_step(Cs[1], Cs[2], Cs[3], Hs[1], Es[1]);
+                fast_step(Cs[2], Cs[3], Cs[0], Hs[0], Es[0]);
+                fast_step(Cs[3], Cs[0], Cs[1], Hs[1], Es[1]);
+            }
+            if (run == 64) continue;                                      // look again: the run may go on
+        }
+        if (z >= zend) break;
+        // ---- a slow step: a line needs another block decoded, the last planes (clamped requests), the ragged last plane, what
+        // a run leaves over after its groups of four; names rotated by copies ----
+#pragma unroll
+        for (int l = 0; l < TY; ++l) {
             const int li = z * ny + (y0 + l);
-            if (li < nslices) {                                           // uniform (a ragged last plane)
-                const d2 c = cur[l + 1];
-                const double xs0[7] = {prev[l].x, cur[l].x, shift_from_lower_lane(c.y, eL[l]), c.x, c.y, cur[l + 2].x, nxt[l].x};
-                const double xs1[7] = {prev[l].y, cur[l].y, c.x, c.y, shift_from_upper_lane(c.x, eR[l]), cur[l + 2].y, nxt[l].y};
+            if (li < nslices) {                                           // uniform
+                PLANE_XS(Cs[0], Cs[1], Cs[2], Hs[0], Es[0], l)
                 double s0 = 0.0, s1 = 0.0;
-                const int blk = __builtin_amdgcn_readfirstlane(bl[l]);
-                if (blk == pd.hot) {
-#pragma unroll
-                    for (int p = 0; p < 7; ++p) { s0 += aH[p][0] * keep_lanes(xs0[p], mH[p][0]); s1 += aH[p][1] * keep_lanes(xs1[p], mH[p][1]); }
-                } else {
+                const int blk = __builtin_amdgcn_readfirstlane(blocks[li]);
+                if (blk == hot) { PLANE_HOT_SUMS(s0, s1) }
+                else {
                     if (blk != other) { bitsO = decode(blk); other = blk; }
-#pragma unroll
-                    for (int p = 0; p < 7; ++p) {
-                        s0 += s_other[2 * p][t] * keep_bit(xs0[p], bitsO, 2 * p);
-                        s1 += s_other[2 * p + 1][t] * keep_bit(xs1[p], bitsO, 2 * p + 1);
-                    }
+                    PLANE_OTHER_SUMS(s0, s1)
                 }
                 d2 o; o.x = alpha * s0; o.y = alpha * s1;
-                d2 *yp = reinterpret_cast<d2 *>(reinterpret_cast<char *>(y + (long long)li * PL_ROWS) + lane_b);
-                if (append) { const d2 old = *yp; o.x = old.x + o.x; o.y = old.y + o.y; }
-                __builtin_nontemporal_store(o, yp);                       // written once, not read again by this kernel
+                if (APPEND) { o.x = Yo[l].x + o.x; o.y = Yo[l].y + o.y; }
+                __builtin_nontemporal_store(o, reinterpret_cast<d2 *>(reinterpret_cast<char *>(y + (long long)li * PL_ROWS) + lane_b));
             }
         }
-        // ---- rotate; request the halo lines of plane z + 2 and the centre lines of plane z + 3 ----
 #pragma unroll
-        for (int l = 0; l < 2; ++l) { prev[l] = cur[l + 1]; cur[l + 1] = nxt[l]; nxt[l] = pc[l]; eL[l] = peL[l]; eR[l] = peR[l]; bl[l] = pbl[l]; }
-        cur[0] = ph[0]; cur[3] = ph[1];
-        if (z + 1 < zend) {
-            ph[0] = ld(z + 2, 0); ph[1] = ld(z + 2, 3);
-#pragma unroll
-            for (int l = 0; l < 2; ++l) {
-                pc[l] = ld(z + 3, l + 1);
-                peL[l] = edge(z + 2, l + 1, 0); peR[l] = edge(z + 2, l + 1, 1);
-                pbl[l] = block_of(z + 2, l);
-            }
+        for (int l = 0; l < TY; ++l) {
+            Cs[0][l] = Cs[1][l]; Cs[1][l] = Cs[2][l]; Cs[2][l] = Cs[3][l]; Cs[3][l] = ld(z + 3, l + 1);
+            Es[0][l] = Es[1][l]; Es[1][l] = edge(z + 2, l + 1);
+            if (APPEND) Yo[l] = yold(z + 1, l);
         }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
+        ++z;
     }
+#undef PLANE_XS
+#undef PLANE_HOT_SUMS
+#undef PLANE_OTHER_SUMS
+}
+
+// The yardstick of the plane / march products (bench.py roofline.device_copy_hand): x copied to y with one 16-byte pair per lane,
+// no loop, non-temporal stores -- the same HBM traffic as the product (x once, y once) and nothing else to do.  6.23 TB/s at
+// 512^3 elements on the box where the library's copy (torch) reaches 4.94 (profiles/r04_pm_proto.json).
+__global__ __launch_bounds__(256)
+void stream_copy_kernel(const double *__restrict__ x, double *__restrict__ y, long long npairs, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < npairs) __builtin_nontemporal_store(reinterpret_cast<const d2 *>(x)[i], reinterpret_cast<d2 *>(y) + i);
+    else if (i == npairs && (n & 1)) y[n - 1] = x[n - 1];
 }
 
 } // namespace
@@ -292,13 +390,30 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
     }
     const int hot = (int)(std::max_element(uses.begin(), uses.end()) - uses.begin());
     if ((nslices - uses[(size_t)hot]) * 16 > nslices && !force) return 0;
-    // planes per workgroup: about four workgroups per CU, all resident at once
-    const long long tiles = ny / 2, cus = std::max(1, info(dev).cus);
-    long long chunks = std::max(1ll, std::min(nz / 8, (4 * cus + tiles / 2) / tiles));
-    long long depth = (nz + chunks - 1) / chunks;
+    // Lines per workgroup (2 or 4) and planes per workgroup.  Measured at 512^3 (profiles/r04_plane_sweep_store*.json, one box,
+    // march product 0.466 ms beside them): FEW, LONG workgroups win -- with every request two steps ahead a wave hides the memory
+    // latency by itself, and every workgroup re-reads the 4 planes around its range -- tile 2 x depth 128 / 256 / 512 = 0.403 /
+    // 0.398 / 0.395 ms, tile 4 x depth 128 / 256 = 0.404 / 0.384 ms (tile 4 x 512: half the CUs idle, 0.57).  So: about one
+    // workgroup per CU; four lines (half the halo traffic of two) when that still leaves walks of 128 planes or more.
+    const long long cus = std::max(1, info(dev).cus);
+    auto depth_for = [&](long long tl) {
+        const long long tiles = ny / tl;
+        const long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
+        return (nz + chunks - 1) / chunks;
+    };
+    long long tile = (ny % 4 == 0 && depth_for(4) >= 128) ? 4 : 2;
+    if (const char *e = std::getenv("VEXHIP_PLANE_TILE")) tile = (std::atoi(e) == 4 && ny % 4 == 0) ? 4 : 2;
+    long long depth = depth_for(tile);
     if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
     depth = std::min(depth, nz);
-    out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth; out->hot_block = hot;
+    while ((depth + 4) * ny * 4096 >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;      // 32-bit byte offsets inside a workgroup's walk
+    if ((depth + 4) * ny * 4096 >= (1ll << 32)) return 0;
+    out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth; out->hot_block = hot; out->tile = (int32_t)tile;
+    // Cache policy of the y stores: 0 = non-temporal, 1 = non-temporal + sc1, 2 = sc0 sc1 (write-through, the line leaves the L2:
+    // more of it is left for the halo lines of x), 3 = plain.  Same sweep, tile 4 x 256: 0.395 / 0.393 / 0.384 / 0.387 ms;
+    // tile 2 x 512: 0.395 / 0.391 / 0.396 / 0.401.  VEXHIP_PLANE_STORE overrides.
+    out->store_policy = tile == 4 ? 2 : 1;
+    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
     out->x_last = x_last; out->usable = 1;
     return 0;
 }
@@ -308,18 +423,40 @@ int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double al
 {
     VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
     VEXHIP_REQUIRE(n > 0 && n % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
-    VEXHIP_REQUIRE(plane->lines_per_plane >= 4 && plane->lines_per_plane % 2 == 0 && plane->depth >= 1 && plane->planes >= 1
-                   && (plane->x_last + 1) % PL_ROWS == 0, "bad plane plan");
+    VEXHIP_REQUIRE((plane->tile == 2 || plane->tile == 4) && plane->lines_per_plane >= 4 && plane->lines_per_plane % plane->tile == 0 && plane->depth >= 1 && plane->planes >= 1
+                   && (plane->x_last + 1) % PL_ROWS == 0
+                   && ((long long)plane->depth + 4) * plane->lines_per_plane * 4096 < (1ll << 32), "bad plane plan");
     VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "plane product: x and y must be 16-byte aligned");
     VEXHIP_SET_DEVICE(dev);
     plane_dev pd;
     pd.nslices = n / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
     pd.ny = plane->lines_per_plane; pd.nz = plane->planes; pd.depth = plane->depth;
-    pd.tiles = pd.ny / 2; pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
+    pd.tiles = pd.ny / plane->tile; pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
     const long long chunks = (pd.nz + pd.depth - 1) / pd.depth;
     const long long grid = 8ll * pd.tpx * chunks;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
-    sell8_plane_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(x, y, alpha, append, blocks, static_cast<const char *>(pool), deltas, values, pd);
+    const int store_kind = plane->store_policy;
+    const char *cpool = static_cast<const char *>(pool);
+    hipStream_t s = as_stream(stream);
+#define PLANE_LAUNCH(TY, AP, AUX) sell8_plane_kernel<TY, AP, AUX><<<(unsigned)grid, 256, 0, s>>>(x, y, alpha, blocks, cpool, deltas, values, pd)
+#define PLANE_AUX(TY, AP) switch (store_kind) { case 1: PLANE_LAUNCH(TY, AP, 18); break; case 2: PLANE_LAUNCH(TY, AP, 17); break; case 3: PLANE_LAUNCH(TY, AP, 0); break; default: PLANE_LAUNCH(TY, AP, 2); }
+    if (plane->tile == 4) { if (append) { PLANE_AUX(4, true) } else { PLANE_AUX(4, false) } }
+    else { if (append) { PLANE_AUX(2, true) } else { PLANE_AUX(2, false) } }
+#undef PLANE_AUX
+#undef PLANE_LAUNCH
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int vexhip_stream_copy_f64(int dev, void *stream, const double *x, double *y, int64_t n)
+{
+    VEXHIP_REQUIRE(n >= 0 && (n == 0 || (x && y)), "bad copy arguments");
+    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "stream copy: x and y must be 16-byte aligned");
+    if (n == 0) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    const long long npairs = n / 2, grid = (npairs + 1 + 255) / 256;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "vector too large for one launch");
+    stream_copy_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(x, y, npairs, (long long)n);
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -57,7 +57,7 @@ struct spmat {
     bool owns_csr = false;
     vexhip_traversal trav = {0, 0, 0, 0, nullptr};
     vexhip_march march = {0, 0, 0, 0, 0, 0, {0, 0, 0}};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
-    vexhip_plane plane = {0, 0, 0, 0, 0, 0, 0};              // plane product (plane.hip): 7-point pattern on 512-point lines; preferred to the march product
+    vexhip_plane plane = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // plane product (plane.hip): 7-point pattern on 512-point lines; preferred to the march product
 };
 
 template <typename T> int dmalloc(T **p, size_t count) {

@@ -402,7 +402,7 @@ class SpMat:
                        "far": [int(info.march.far[k]) for k in range(info.march.nfar)]}
                       if info.march.usable else None)              # not None: apply() runs the march product
         self.plane = ({"lines_per_plane": int(info.plane.lines_per_plane), "planes": int(info.plane.planes), "depth": int(info.plane.depth),
-                       "hot_block": int(info.plane.hot_block), "x_last": int(info.plane.x_last)}
+                       "hot_block": int(info.plane.hot_block), "tile": int(info.plane.tile), "store_policy": int(info.plane.store_policy), "x_last": int(info.plane.x_last)}
                       if info.plane.usable else None)              # not None: apply() runs the plane product (fp64)
         self.fmt = "csr" if self.storage == "csr" else "sell"      # SELL without an ELL part degrades to CSR
         if self.fmt == "sell":
