@@ -30,7 +30,7 @@ torch.cuda.empty_cache()
 big = torch.empty(3 * N + (1 << 24), dtype=torch.float64, device=dev)
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 out = {"base_address_mod_2MiB": big.data_ptr() % (1 << 21), "rows": []}
-for gap in (0, 512, 4096, 1 << 15, 1 << 18, (1 << 18) + 512 * 3, 1 << 20, 3 << 19, 1 << 23, N // 2, N):
+for gap in [int(g) for g in os.environ.get('GAPS', '0,512,4096,32768,262144,263680,1048576,1572864,8388608,67108864,134217728').split(',')]:
     x = big[:N]; y = big[N + gap:2 * N + gap]
     ops.fill_hash(x, 42)
     row = {"gap_elements": gap, "y_minus_x_bytes": (N + gap) * 8}

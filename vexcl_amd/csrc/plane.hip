@@ -342,7 +342,7 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
     const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids, many blocks
     if (value_bytes != 8 || !deltas || !blocks || !pool || ndeltas < 2 || ndeltas > 7 || dictionary_blocks < 1 || dictionary_blocks > 128) return 0;
     if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows != nslices * PL_ROWS || (nslices < 64 && !force)) return 0;
-    if (x_last < 0 || (x_last + 1) % PL_ROWS != 0) return 0;
+    if (x_last < 0 || (x_last + 1) % PL_ROWS != 0 || x_last + 1 < rows) return 0;
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
     const int wp = (int)((ell_width + 1) / 2);
@@ -390,18 +390,20 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
     }
     const int hot = (int)(std::max_element(uses.begin(), uses.end()) - uses.begin());
     if ((nslices - uses[(size_t)hot]) * 16 > nslices && !force) return 0;
-    // Lines per workgroup (2 or 4) and planes per workgroup.  Measured at 512^3 (profiles/r04_plane_sweep_store*.json, one box,
+    // Lines per workgroup (2 or 4) and planes per workgroup.  Measured at 512^3 (profiles/r04_plane_sweep*.json, r04_plane_offsets.json;
     // march product 0.466 ms beside them): FEW, LONG workgroups win -- with every request two steps ahead a wave hides the memory
-    // latency by itself, and every workgroup re-reads the 4 planes around its range -- tile 2 x depth 128 / 256 / 512 = 0.403 /
-    // 0.398 / 0.395 ms, tile 4 x depth 128 / 256 = 0.404 / 0.384 ms (tile 4 x 512: half the CUs idle, 0.57).  So: about one
-    // workgroup per CU; four lines (half the halo traffic of two) when that still leaves walks of 128 planes or more.
+    // latency by itself, and every workgroup re-reads the 4 planes around its range: tile 2 x depth 128 / 256 / 512 = 0.393 /
+    // 0.389 / 0.381 ms, tile 4 x depth 128 / 256 = 0.409 / 0.388 ms (tile 4 x 512: half the CUs idle, 0.57).  Tile 4 halves the
+    // halo requests (HBM read 1.04 x instead of 1.14 x of x at depth 128) but needs 164 registers and is not faster.  So: two
+    // lines, about one workgroup per CU.  The time also depends on where x and y lie relative to each other (0.378 - 0.41 ms for
+    // the same kernel, r04_plane_offsets.json; the copy kernel and the march product do not show it).
     const long long cus = std::max(1, info(dev).cus);
     auto depth_for = [&](long long tl) {
         const long long tiles = ny / tl;
         const long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
         return (nz + chunks - 1) / chunks;
     };
-    long long tile = (ny % 4 == 0 && depth_for(4) >= 128) ? 4 : 2;
+    long long tile = 2;
     if (const char *e = std::getenv("VEXHIP_PLANE_TILE")) tile = (std::atoi(e) == 4 && ny % 4 == 0) ? 4 : 2;
     long long depth = depth_for(tile);
     if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
@@ -410,7 +412,7 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
     if ((depth + 4) * ny * 4096 >= (1ll << 32)) return 0;
     out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth; out->hot_block = hot; out->tile = (int32_t)tile;
     // Cache policy of the y stores: 0 = non-temporal, 1 = non-temporal + sc1, 2 = sc0 sc1 (write-through, the line leaves the L2:
-    // more of it is left for the halo lines of x), 3 = plain.  Same sweep, tile 4 x 256: 0.395 / 0.393 / 0.384 / 0.387 ms;
+    // more of it is left for the halo lines of x), 3 = plain.  Same sweeps, tile 4 x 256: 0.395 / 0.393 / 0.384 / 0.387 ms;
     // tile 2 x 512: 0.395 / 0.391 / 0.396 / 0.401.  VEXHIP_PLANE_STORE overrides.
     out->store_policy = tile == 4 ? 2 : 1;
     if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
