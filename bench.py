@@ -436,7 +436,7 @@ def main():
                 st = A.native_status()
                 if st and st["timed_out"]:
                     ok = False
-                    A.native_error = "a flag wait of the IPC transport ran into its 4 s bound"
+                    A.native_error = "a flag wait of the IPC transport ran into its bound (VEXHIP_IPC_TIMEOUT_MS)"
             except Exception as e:
                 A.native_error = repr(e)
                 ok = False

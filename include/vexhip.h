@@ -250,7 +250,7 @@ int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha
 /* March products (round 3): the _dict products with the x window of the NEAR diagonals staged in an LDS ring that a
  * workgroup carries along a run of consecutive slices -- one coalesced load of the 512 new elements per slice instead of
  * one gather per near column; up to two far diagonals (+-n^2 of a 3-D grid operator) are requested one slice ahead as two
- * more coalesced streams and parked in LDS, any further one is gathered.  Replaces, like every SELL product, the per-row
+ * more coalesced streams and parked in LDS; a matrix with a third far diagonal is declined (round 4).  Replaces, like every SELL product, the per-row
  * gathers of the reference's ELL kernel (vexcl/spmat/hybrid_ell.inl:238-269).  Bit-identical to the _dict products.
  * vexhip_sell8_march_plan decides from the diagonal table and the slice numbers whether it applies (usable = 0: call the
  * _dict product; value-coded storage only -- with stored values the product is bound by the value stream, which the pair
@@ -465,8 +465,11 @@ int vexhip_comm_rccl_info(const vexhip_comm *comm, int *nranks, int *device, int
  * with.  Per product ONE kernel per rank writes every neighbour's share straight into that neighbour's window over
  * xGMI and raises `arrive` there; the consumer's stream waits on its own flags with a one-wave kernel, runs the remote
  * part on the window and raises `consumed` at the owners, which gates their next write.  No pack buffer, no receive,
- * no collective kernel.  Spins are bounded (4 s): a missing peer sets a sticky flag (vexhip_dist_spmv_status) instead
- * of hanging the device.  dst_offsets[p] = element offset of this rank's share in rank p's ghost set.               */
+ * no collective kernel.  Spins are bounded (20 s; VEXHIP_IPC_TIMEOUT_MS): a wait that runs out is an ERROR -- the ghost
+ * values are overwritten with NaN (the remote part can not turn stale ghosts into plausible numbers), a flag in pinned
+ * host memory is set, and vexhip_dist_spmv_apply / _profile fail from then on (vexhip_dist_spmv_status reports it too).
+ * Several plans may share a window (each counts its own launches).  dst_offsets[p] = element offset of this rank's
+ * share in rank p's ghost set.                                                                                         */
 typedef struct vexhip_ipc_window vexhip_ipc_window;
 int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, vexhip_ipc_window **out);
 int vexhip_ipc_window_export(const vexhip_ipc_window *win, void *handle64);

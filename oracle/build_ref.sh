@@ -69,7 +69,18 @@ if [ $# -eq 0 ]; then
     printf '%s\n' $EXAMPLES | xargs -P "$jobs" -I{} bash -c 'build_example {}'
     printf '%s\n' $CHECKED | xargs -P "$jobs" -I{} bash -c 'build_checked {}'
 fi
-ls "$out" | grep -v '\.log$' | grep -v '^HEADERS_SHA256$' > "$out/MANIFEST" || true
+# Fixtures from reference-run code (the reference's generators + the host loop of tests/spmv.cpp:28-32): pins oracle/vex_oracle.c
+# directly (tests/test_oracle.py::test_oracle_against_reference_run_fixtures).  The .npz under tests/golden/ is committed; it is
+# rewritten here only when VEXCL_REF_FIXTURES=1 (std::default_random_engine is the same stream for one libstdc++).
+if [ $# -eq 0 ]; then
+    if g++ -std=c++17 -O1 -w -I "$ref/tests" -I "$repo" "$here/ref_fixture_driver.cpp" -o "$out/ref_fixture_driver" 2> "$out/ref_fixture_driver.build.log"; then
+        rm -f "$out/ref_fixture_driver.build.log"; echo "built   ref_fixture_driver"
+        "$out/ref_fixture_driver" "$out/ref_fixtures.bin" && [ "${VEXCL_REF_FIXTURES:-0}" = "1" ] && python3 "$here/ref_fixtures_to_npz.py"
+    else
+        echo "FAILED  ref_fixture_driver (see oracle/_ref/ref_fixture_driver.build.log)"
+    fi
+fi
+ls "$out" | grep -v '\.log$' | grep -v '^HEADERS_SHA256$' | grep -v '^ref_fixture' > "$out/MANIFEST" || true
 # the binaries embed the vexcl/ headers (code generators included): record what they were built from, so that
 # tests/test_reference_suite.py can refuse to run binaries that are older than the headers they claim to test
 python3 "$here/headers_hash.py" > "$out/HEADERS_SHA256"

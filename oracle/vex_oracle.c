@@ -4,12 +4,26 @@
  * product (vexcl_amd/, include/, vexcl/) may link, import or call this file;
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
  *
- * PARITY UNPINNED: the reference holds no golden vectors (every reference test
- * recomputes its expectation on the host from time(0)-seeded inputs,
- * tests/context_setup.hpp:19-22) and cannot be compiled here (Boost is a hard
- * dependency of every hot-path header and is absent; no CPU OpenCL device).
- * Each function below cites the reference file:line it restates; the checks it
- * mirrors are the host recomputation loops of the reference's own tests.
+ * HOW PARITY IS PINNED.  The reference holds no golden vectors (every reference
+ * test recomputes its expectation on the host from time(0)-seeded inputs,
+ * tests/context_setup.hpp:19-22) and its LIBRARY cannot be compiled here (Boost
+ * is a hard dependency of every hot-path header and is absent; no CPU OpenCL
+ * device).  What can be executed is the reference's TEST code, and that is what
+ * pins this file:
+ *   * SpMV (the headline path) -- directly: oracle/ref_fixture_driver.cpp runs
+ *     the reference's generators (tests/random_matrix.hpp, random_vector.hpp,
+ *     fixed srand) and the host loop its test asserts against
+ *     (tests/spmv.cpp:28-32); tests/golden/ref_fixtures.npz holds its output and
+ *     tests/test_oracle.py::test_oracle_against_reference_run_fixtures requires
+ *     vxo_spmv_csr_* (plain, alpha / append, OpenMP, through hybrid ELL) to
+ *     reproduce it BIT FOR BIT (round 4);
+ *   * everything else -- through the reference's own test programs: oracle/_ref
+ *     holds /root/reference/tests/*.cpp compiled where they lie against this
+ *     repository's vexcl/ headers (oracle/build_ref.sh), their host loops and
+ *     BOOST_CHECK_CLOSE assertions run against the HIP path on the GPU box
+ *     (tests/test_reference_suite.py), and the HIP path is compared with this
+ *     file bit for bit (integers, SpMV) or within the stated tolerance.
+ * Each function below cites the reference file:line it restates.
  *
  * Built with:  gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC  (oracle/Makefile)
  * -ffp-contract=off keeps "sum += val[j]*x[col[j]]" as a rounded multiply

@@ -33,6 +33,55 @@ def test_spmv_against_scipy_golden(oracle, name):
     assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(bound, 1e-300))
 
 
+REF = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_fixtures.npz"))
+REF_CASES = ("square", "nonsquare", "types", "emptyrows")
+
+
+@pytest.mark.parametrize("case", REF_CASES)
+@pytest.mark.parametrize("index_dtype", [np.int32, np.int64])
+def test_oracle_against_reference_run_fixtures(oracle, case, index_dtype):
+    """tests/golden/ref_fixtures.npz was written by oracle/ref_fixture_driver.cpp, which RUNS the reference's generators
+    (/root/reference/tests/random_matrix.hpp, random_vector.hpp, fixed srand) and the host loop the reference's test asserts
+    against (tests/spmv.cpp:28-32): the restatement must reproduce that loop's y bit for bit -- plain, '+= 42 *' on top of
+    y0 (spmv.cpp:44-52), through hybrid ELL (hybrid_ell.inl:254-267: ELL entries then the CSR tail, i.e. the same order); the
+    2- and 3-device split (spmat.hpp:120-185: local part, then remote part) within the reference's own tolerance.  A drift of vex_oracle.c from the reference's loop fails here."""
+    row, col, val, x, y0, y, y42 = (REF[case + "_" + k] for k in ("row", "col", "val", "x", "y0", "y", "y42"))
+    n, m = int(REF[case + "_shape"][0]), int(REF[case + "_shape"][1])
+    ptr, c = row.astype(index_dtype), col.astype(index_dtype)
+    assert np.array_equal(oracle.spmv_csr(ptr, c, val, x), y)
+    got = y0.copy(); oracle.spmv_csr(ptr, c, val, x, got, alpha=42.0, append=True)
+    assert np.array_equal(got, y42)
+    if index_dtype is np.int32:
+        assert np.array_equal(oracle.spmv_csr(ptr, c, val, x, omp=True), y)
+        assert np.array_equal(oracle.spmv_hell(oracle.hell_build(ptr, c, val), x), y)
+        bound = oracle.spmv_abs_bound(ptr, c, val, x)
+        for ndev in (2, 3):      # local part first, then the remote part: another summation order -- the reference's own 1e-8 %
+            got = oracle.spmv_split(oracle.split_rows(ptr, c, val, m, ndev), x)
+            assert np.all(np.abs(got - y) <= 1e-10 * np.maximum(bound, 1e-300)), ndev
+        if n == m:
+            yx = x.copy(); oracle.spmv_csr(ptr, c, val, x, yx, alpha=1.0, append=True)
+            assert np.array_equal(yx, REF[case + "_yx"])               # Y = X + A * X (spmv.cpp:54-58)
+
+
+@pytest.mark.parametrize("case", REF_CASES)
+def test_reference_generator_has_the_layout_the_restated_generator_promises(oracle, case):
+    """What oracle.random_matrix states about tests/random_matrix.hpp (width uniform in [0, nnz_per_row - 1], distinct ascending
+    columns in [0, m), values in [0, 1), trailing rows empty in the empty_rows case), checked on the output of the
+    REFERENCE's generator itself, next to the restated generator's output for the same shape."""
+    row, col, val = REF[case + "_row"], REF[case + "_col"], REF[case + "_val"]
+    n, m, filled = (int(v) for v in REF[case + "_shape"][:3])
+    mine = oracle.random_matrix(7, n, m, 16, empty_tail=n - filled)
+    for ptr, cc, vv in ((row, col, val), mine):
+        w = np.diff(ptr)
+        assert len(ptr) == n + 1 and ptr[0] == 0 and ptr[-1] == len(cc) == len(vv)
+        assert w.min() >= 0 and w.max() <= 15 and np.all(w[filled:] == 0) and w[:filled].max() >= 12
+        assert cc.min() >= 0 and cc.max() < m and vv.min() >= 0.0 and vv.max() < 1.0
+        for i in range(filled):
+            assert np.all(np.diff(cc[ptr[i]:ptr[i + 1]]) > 0)
+    # both generators draw the widths uniformly: about 7.5 entries per filled row
+    assert abs(len(col) / filled - 7.5) < 0.6 and abs(len(mine[1]) / filled - 7.5) < 0.6
+
+
 def test_spmv_alpha_append_semantics(oracle):
     # spmat.hpp:120-121 / tests/spmv.cpp:34-58
     ptr, col, val = oracle.random_matrix(1, 1024, 1024, 16)

@@ -15,6 +15,7 @@
 // dictionary -- 0.72 instead of 0.83 ms per product at 512^3, same summation order, same bits.
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <vector>
 #include "../operations.hpp"
 #include "../vector.hpp"
@@ -50,7 +51,13 @@ struct SpMatCCSR {
         expanded = 0;
         for (size_t i = 0; i < n; ++i) expanded += (unsigned long long)(row32[idx32[i] + 1] - row32[idx32[i]]);
         try { build_fast(); }
-        catch (const backend::error &) { fast.reset(); }     // out of memory, ...: the CCSR kernel needs none of it
+        catch (const backend::error &e) {
+            // only an allocation that did not fit keeps the CCSR kernel (it needs none of that memory); anything else -- a sticky
+            // device fault, a bad argument -- must not disappear here
+            const std::string what = e.what();
+            if (what.find("OutOfMemory") == std::string::npos && what.find("out of memory") == std::string::npos) throw;
+            fast.reset();
+        }
     }
 
     size_t rows() const { return n; }

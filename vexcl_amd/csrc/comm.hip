@@ -154,7 +154,19 @@ int nccl_type(int dtype, ncclDataType_t *t) {
 // consumed[p] (written by consumer p): number of the latest product for which p has finished reading what THIS rank
 //                                      wrote into p's window -- this rank may overwrite it then.
 // The flags are 64-bit step numbers that only grow: nothing is ever reset, a late reader can not miss an update.
-constexpr unsigned long long kSpinTicks = 400000000ull;        // wall_clock64() counts at 100 MHz: 4 s
+// How long a flag wait may last before the product is declared failed: wall_clock64() counts at 100 MHz.  20 s by default
+// (VEXHIP_IPC_TIMEOUT_MS): ranks of one job may be seconds apart (a JIT compile, I/O, an unbalanced phase between two
+// products), and a wait that gives up corrupts the product -- so a timeout is an ERROR, not a fallback: the waiting kernel
+// overwrites the ghost values with NaN (the remote part then produces NaN instead of numbers from stale ghosts), the error
+// flag lives in pinned host memory, and vexhip_dist_spmv_apply / _profile fail from then on.
+inline unsigned long long spin_ticks() {
+    static const unsigned long long t = [] {
+        const char *e = std::getenv("VEXHIP_IPC_TIMEOUT_MS");
+        const long long ms = e ? std::atoll(e) : 20000;
+        return (unsigned long long)(ms > 0 ? ms : 20000) * 100000ull;
+    }();
+    return t;
+}
 
 struct ipc_window {
     int dev = 0, rank = 0, world = 1;
@@ -179,13 +191,16 @@ struct push_peer {
 };
 constexpr int kPushPerBlock = 2048;
 
-__device__ inline void spin_until(const unsigned long long *flag, unsigned long long want, int *err) {
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // a peer is gone: do not wait again
+// returns false when the flag was not raised in time (err, in pinned host memory, is set then and stays set: the products that
+// are already queued fail fast instead of waiting `ticks` each; the host refuses further ones)
+__device__ inline bool spin_until(const unsigned long long *flag, unsigned long long want, int *err, unsigned long long ticks) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > kSpinTicks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
     }
+    return true;
 }
 
 // Every owner writes, per destination, exactly the values that destination needs straight into its window (idx: the
@@ -193,13 +208,15 @@ __device__ inline void spin_until(const unsigned long long *flag, unsigned long 
 template <typename T>
 __global__ __launch_bounds__(256)
 void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned long long step, const int32_t *__restrict__ idx,
-        const T *__restrict__ x, unsigned long long *done, unsigned long long step0, int *err)
+        const T *__restrict__ x, unsigned long long *done, unsigned long long launches, int *err, unsigned long long ticks)
 {
     int j = 0;
     while (j + 1 < npeers && (long long)blockIdx.x >= peers[j + 1].blk0) ++j;
     const push_peer P = peers[j];
-    if (threadIdx.x == 0) spin_until(P.consumed, step - 1, err);          // the destination has read the previous product's share
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_ok = spin_until(P.consumed, step - 1, err, ticks) ? 1 : 0;     // the destination has read the previous product's share
     __syncthreads();
+    if (!s_ok) return;                        // uniform: a destination that does not answer is not written to, and `arrive` is not raised
     T *dst = static_cast<T *>(P.dst);
     const long long i0 = ((long long)blockIdx.x - P.blk0) * kPushPerBlock;
 #pragma unroll
@@ -212,16 +229,24 @@ void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned l
     if (threadIdx.x == 0) {
         const unsigned long long nblk = (unsigned long long)((P.count + kPushPerBlock - 1) / kPushPerBlock);
         const unsigned long long old = __hip_atomic_fetch_add(&done[j], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == nblk * (step - step0)) {                                     // ... the last block of this destination raises the flag
+        // `done` counts THIS plan's blocks and `launches` this plan's products: several plans may share a window (the flags carry the
+        // window's step numbers), each sees its own launches only
+        if (old + 1 == nblk * launches) {                                           // ... the last block of this destination raises the flag
             __threadfence_system();
             __hip_atomic_store(P.arrive, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
+// one wave: lane k waits for owner k's share; if any wait fails, every ghost value becomes NaN (all bits set) -- the remote part
+// that follows must not turn stale ghosts into plausible numbers
 __global__ __launch_bounds__(64)
-void ipc_wait_kernel(const unsigned long long *const *flags, int n, unsigned long long step, int *err) {
-    if ((int)threadIdx.x < n) spin_until(flags[threadIdx.x], step, err);
+void ipc_wait_kernel(const unsigned long long *const *flags, int n, unsigned long long step, int *err, unsigned long long ticks,
+        unsigned long long *ghost_words, long long nwords) {
+    bool ok = true;
+    if ((int)threadIdx.x < n) ok = spin_until(flags[threadIdx.x], step, err, ticks);
+    if (__builtin_amdgcn_ballot_w64(!ok))
+        for (long long i = threadIdx.x; i < nwords; i += 64) ghost_words[i] = ~0ull;
 }
 
 __global__ __launch_bounds__(64)
@@ -252,10 +277,11 @@ struct dist_spmv {
     const void *gx = nullptr; void *gy = nullptr; double galpha = 0; int gappend = 0; hipStream_t gstream = nullptr;
     // IPC transport (peer-mapped ghost windows): the owners WRITE their shares into the consumer's window
     ipc_window *win = nullptr;
-    unsigned long long step0 = 0;              // the window's product count when this plan was made (the `done` counters start there)
+    unsigned long long step0 = 0;              // the window's product count when this plan was made
+    unsigned long long launches = 0;           // products issued through THIS plan (the `done` counters count its blocks)
     push_peer *d_push = nullptr; int npush = 0; int64_t push_blocks = 0;
     unsigned long long *d_done = nullptr;      // per destination: blocks of the push kernel that have finished (monotonic)
-    int *d_err = nullptr;                      // sticky: a flag was not raised within kSpinTicks
+    int *d_err = nullptr;                      // sticky, in pinned host memory mapped into the device: a flag was not raised in time
     const unsigned long long **d_arrive = nullptr; unsigned long long **d_consumed = nullptr; int nown = 0;
     hipEvent_t pushed = nullptr;
     // optional phase timing of one step (vexhip_dist_spmv_profile)
@@ -310,7 +336,12 @@ int local_part(dist_spmv *D, hipStream_t s, double alpha, int append, const void
 //   compute stream s:  [x ready] ...... local part ...... wait kernel (arrive flags) -> remote part -> signal kernel (consumed flags) -> wait(pushed)
 //   comm stream:       wait(x ready) -> push kernel: per destination wait for consumed >= step-1, write the share into ITS window, raise arrive = step
 int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
+    if (D->d_err && *static_cast<volatile int *>(D->d_err))
+        return fail(__FILE__, __LINE__, "an earlier product of this plan timed out waiting for a peer's ghost flag (IPC transport, VEXHIP_IPC_TIMEOUT_MS): "
+                                        "its result and every later one are invalid");
     const unsigned long long step = ++D->win->step;
+    const unsigned long long launches = ++D->launches;
+    const unsigned long long ticks = spin_ticks();
     PROF(0, s);
     if (D->npush) {
         VEXHIP_TRY(hipEventRecord(D->packed, s));
@@ -318,9 +349,9 @@ int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const 
         PROF(4, D->comm_stream); PROF(5, D->comm_stream);
         const int32_t *idx = D->direct ? nullptr : D->send_idx;
         if (D->dtype == VEXHIP_F64)
-            ipc_push_kernel<double><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const double *>(x), D->d_done, D->step0, D->d_err);
+            ipc_push_kernel<double><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const double *>(x), D->d_done, launches, D->d_err, ticks);
         else
-            ipc_push_kernel<float><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const float *>(x), D->d_done, D->step0, D->d_err);
+            ipc_push_kernel<float><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const float *>(x), D->d_done, launches, D->d_err, ticks);
         VEXHIP_LAUNCH_CHECK();
         PROF(6, D->comm_stream);
         VEXHIP_TRY(hipEventRecord(D->pushed, D->comm_stream));
@@ -328,7 +359,8 @@ int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const 
     if (int rc = local_part(D, s, alpha, append, x, y)) return rc;
     PROF(1, s);
     if (D->nown) {
-        ipc_wait_kernel<<<1, 64, 0, s>>>(D->d_arrive, D->nown, step, D->d_err);
+        ipc_wait_kernel<<<1, 64, 0, s>>>(D->d_arrive, D->nown, step, D->d_err, ticks, static_cast<unsigned long long *>(D->ghost_buf),
+                                         (long long)(D->nghost * (int64_t)type_bytes(D->dtype) / 8));
         VEXHIP_LAUNCH_CHECK();
     }
     PROF(2, s);
@@ -673,7 +705,7 @@ int vexhip_dist_spmv_destroy(vexhip_dist_spmv *h) {
     if (D->prof) { for (int k = 0; k < 7; ++k) if (D->prof[k]) (void)hipEventDestroy(D->prof[k]); delete[] D->prof; }
     if (D->d_push) (void)hipFree(D->d_push);
     if (D->d_done) (void)hipFree(D->d_done);
-    if (D->d_err) (void)hipFree(D->d_err);
+    if (D->d_err) (void)hipHostFree(D->d_err);
     if (D->d_arrive) (void)hipFree(D->d_arrive);
     if (D->d_consumed) (void)hipFree(D->d_consumed);
     delete D;
@@ -851,8 +883,8 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
             con.push_back(window_consumed(w->peer[o], w->world, w->rank));
         }
     D->nown = (int)arr.size();
-    e = hipMalloc(reinterpret_cast<void **>(&D->d_err), sizeof(int));
-    if (e == hipSuccess) e = hipMemset(D->d_err, 0, sizeof(int));
+    e = hipHostMalloc(reinterpret_cast<void **>(&D->d_err), sizeof(int), hipHostMallocMapped);       // host-visible without a copy
+    if (e == hipSuccess) *D->d_err = 0;
     if (e == hipSuccess && D->npush) {
         e = hipMalloc(reinterpret_cast<void **>(&D->d_push), sizeof(push_peer) * plan.size());
         if (e == hipSuccess) e = hipMemcpy(D->d_push, plan.data(), sizeof(push_peer) * plan.size(), hipMemcpyHostToDevice);
@@ -875,7 +907,7 @@ int vexhip_dist_spmv_status(vexhip_dist_spmv *h, int *timed_out, int *transport,
     VEXHIP_REQUIRE(D, "NULL argument");
     if (timed_out) {
         *timed_out = 0;
-        if (D->d_err) { VEXHIP_SET_DEVICE(D->dev); VEXHIP_TRY(hipMemcpy(timed_out, D->d_err, sizeof(int), hipMemcpyDeviceToHost)); }
+        if (D->d_err) *timed_out = *static_cast<volatile int *>(D->d_err);
     }
     if (transport) *transport = D->win ? VEXHIP_COMM_IPC : VEXHIP_COMM_RCCL;
     if (direct) *direct = D->direct ? 1 : 0;

@@ -1784,11 +1784,15 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
         while (run > 1 && traversal->chunk % run != 0) --run;
     }
     if (run < 2) return 0;
-    // the (up to two) far diagonals nearest to the window are requested one slice ahead; any other far diagonal is gathered
+    // the (up to two) far diagonals are requested one slice ahead
+    // A THIRD far diagonal has no slot: decode() would send every wave of every slice through the per-entry loop (the hot loop is
+    // never entered, the ring traffic is still paid) -- slower than the pair product such a matrix had before.  Decline.
     out->nfar = 0;
+    int nfar_all = 0;
     for (int dlt : by_abs)
-        if ((dlt < lo || dlt > hi) && out->nfar < 2) out->far[out->nfar++] = dlt;
+        if (dlt < lo || dlt > hi) { if (out->nfar < 2) out->far[out->nfar++] = dlt; ++nfar_all; }
     out->far[2] = 0;
+    if (nfar_all > 2) { std::memset(out, 0, sizeof(*out)); return 0; }
     out->lo = lo; out->hi = hi; out->run = run; out->x_last = x_last; out->usable = 1;
     return 0;
 }

@@ -218,6 +218,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     constexpr bool p64 = sizeof(P) == 8;
     const int dev = A->dev;
     A->n = n; A->value_type = F::type;
+    clear_max_col_hint();                      // a hint left by a build that failed half-way must not reach this matrix's fill
     if (n == 0) { A->format = VEXHIP_SPMAT_CSR; return 0; }
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
