@@ -101,6 +101,46 @@ for label, sidx in (("run", torch.arange(ng, device=dev) + 777), ("perm", torch.
     L.dist_spmv_profile(step, ctypes.c_void_p(s.cuda_stream), 1.0, 0, p(x), p(y), ms)
     assert ms[0] > 0 and all(v >= 0 for v in ms), list(ms)
     L.dist_spmv_destroy(step)
+# two LIVE plans on one window, used alternately (AMG levels, A and A^T): each plan counts its own launches, the flags carry
+# the window's step numbers (round 4; the round-3 form never raised `arrive` here and ran into its timeout)
+plans = []
+for sidx in (torch.arange(ng, device=dev) + 777, torch.randperm(rows, device=dev)[:ng]):
+    sidx = sidx.to(torch.int32).contiguous()
+    step = ctypes.c_void_p()
+    L.dist_spmv_create_ipc(win, _capi.F64, rows, loc.handle, ng, p(rw), p(cp), p(rc), p(rv), ng, p(sidx), cnts, zero, ng, cnts, ctypes.byref(step))
+    plans.append((step, sidx))
+y = torch.empty(rows, dtype=torch.float64, device=dev)
+for k in range(12):
+    step, sidx = plans[k %% 2] if k %% 5 else plans[0]
+    xk = x * (k + 1)
+    L.dist_spmv_apply(step, ctypes.c_void_p(s.cuda_stream), 1.0, 0, p(xk), p(y))
+    s.synchronize()
+    want = 2.0 * xk
+    want[rw.long()] += 3.0 * xk[sidx.long()]
+    assert torch.equal(y, want), ("two plans", k)
+# the IPC step replayed from a hipGraph (its step numbers live in device memory): x changes IN PLACE between the replays
+step, sidx = plans[1]
+L.dist_spmv_set_graph(step, 1)
+xg = x.clone()
+for k in range(25):
+    with torch.cuda.stream(s):
+        xg.mul_(1.0 + 1.0 / (k + 1))
+    L.dist_spmv_apply(step, ctypes.c_void_p(s.cuda_stream), 1.0, 0, p(xg), p(y))
+    s.synchronize()
+    want = 2.0 * xg
+    want[rw.long()] += 3.0 * xg[sidx.long()]
+    assert torch.equal(y, want), ("graph", k)
+L.dist_spmv_set_graph(step, 0)
+L.dist_spmv_apply(plans[0][0], ctypes.c_void_p(s.cuda_stream), 1.0, 0, p(x), p(y))      # and the other plan still works
+s.synchronize()
+want = 2.0 * x
+want[rw.long()] += 3.0 * x[plans[0][1].long()]
+assert torch.equal(y, want)
+for step, _ in plans:
+    to = ctypes.c_int()
+    L.dist_spmv_status(step, ctypes.byref(to), None, None)
+    assert to.value == 0
+    L.dist_spmv_destroy(step)
 L.ipc_window_destroy(win)
 print("rccl self ok")
 '''

@@ -175,9 +175,11 @@ struct ipc_window {
     char *base = nullptr;
     std::vector<char *> peer;                  // base address of every opened window (own pointer for this rank)
     std::vector<char> opened;                  // mapped with hipIpcOpenMemHandle (to be closed)
-    unsigned long long step = 0;               // products issued over this window so far: the flags carry these numbers, so a
-                                               // second vexhip_dist_spmv on the same windows continues the count (every rank
-                                               // issues the same products in the same order)
+    // products issued over this window so far, IN DEVICE MEMORY: the flags carry these numbers, so a second vexhip_dist_spmv on
+    // the same windows continues the count (every rank issues the same products in the same order).  The first kernel of a step
+    // increments it and the kernels of the step read it -- no kernel argument changes from one product to the next, which is
+    // what lets a whole step be captured in a hipGraph and replayed (round 4).
+    unsigned long long *d_step = nullptr;
 };
 inline size_t window_header(int world) { return ((size_t)world * 16 + 255) / 256 * 256; }
 inline unsigned long long *window_arrive(char *base, int o) { return reinterpret_cast<unsigned long long *>(base) + o; }
@@ -189,27 +191,40 @@ struct push_peer {
     const unsigned long long *consumed;        // my consumed[destination]
     long long first, count, direct_first, blk0;
 };
-constexpr int kPushPerBlock = 2048;
+// Elements one block of the push kernel writes (VEXHIP_IPC_PUSH_PER_BLOCK; a multiple of 256).  Stores into the uncached window
+// are slow (about 75 GB/s from a full grid on the one-GPU box, where the "peer" is the GPU itself) and a wide push kernel slows
+// the local part that runs beside it; at the 1/8 strip of the 512^3 problem (2 x 262 144 ghosts, tools/r04_dist_step.py) 2048 /
+// 16384 / 65536 / 262144 elements per block give 110 / 95 / 202 / 647 us per step (local + remote part alone: 64 us).
+inline int push_per_block() {
+    static const int v = [] { const char *e = std::getenv("VEXHIP_IPC_PUSH_PER_BLOCK"); int k = e ? std::atoi(e) : 16384; k = k < 256 ? 256 : k; return k / 256 * 256; }();
+    return v;
+}
 
 // returns false when the flag was not raised in time (err, in pinned host memory, is set then and stays set: the products that
 // are already queued fail fast instead of waiting `ticks` each; the host refuses further ones)
 __device__ inline bool spin_until(const unsigned long long *flag, unsigned long long want, int *err, unsigned long long ticks) {
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-        __builtin_amdgcn_s_sleep(16);
+    // relaxed polls (the flags are uncached: every poll reads memory), ONE acquire once the flag is there
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     return true;
 }
 
 // Every owner writes, per destination, exactly the values that destination needs straight into its window (idx: the
 // packed order; NULL: the share is one run of x starting at direct_first), then raises arrive[me] there.
+// first kernel of a step (compute stream): this product's number on the window, and this plan's launch count
+__global__ void ipc_begin_kernel(unsigned long long *step, unsigned long long *launches) { ++*step; ++*launches; }
+
 template <typename T>
 __global__ __launch_bounds__(256)
-void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned long long step, const int32_t *__restrict__ idx,
-        const T *__restrict__ x, unsigned long long *done, unsigned long long launches, int *err, unsigned long long ticks)
+void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, const unsigned long long *step_p, const int32_t *__restrict__ idx,
+        const T *__restrict__ x, unsigned long long *done, const unsigned long long *launches_p, int *err, unsigned long long ticks, int per_block)
 {
+    const unsigned long long step = *step_p, launches = *launches_p;
     int j = 0;
     while (j + 1 < npeers && (long long)blockIdx.x >= peers[j + 1].blk0) ++j;
     const push_peer P = peers[j];
@@ -218,16 +233,22 @@ void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned l
     __syncthreads();
     if (!s_ok) return;                        // uniform: a destination that does not answer is not written to, and `arrive` is not raised
     T *dst = static_cast<T *>(P.dst);
-    const long long i0 = ((long long)blockIdx.x - P.blk0) * kPushPerBlock;
-#pragma unroll
-    for (int k = 0; k < kPushPerBlock / 256; ++k) {
+    const long long i0 = ((long long)blockIdx.x - P.blk0) * per_block;
+#pragma unroll 4
+    for (int k = 0; k < per_block / 256; ++k) {
         const long long i = i0 + k * 256 + threadIdx.x;
         if (i < P.count) dst[i] = idx ? x[idx[P.first + i]] : x[P.direct_first + i];
     }
-    __threadfence_system();                                               // this lane's stores are performed before ...
+    // The window is UNCACHED memory: its stores bypass the L2, and a wave's stores have been performed at the destination once
+    // the wave's store counter is back at zero -- a workgroup-scope release (s_waitcnt vmcnt(0)) per lane, not the system-scope
+    // fence every lane used to execute here: that one writes back and invalidates the WHOLE L2 65 000 times per product, which
+    // doubled the time of the local part running beside it (profiles/r04_dist_step.json: 59 -> 129 us).  One system-scope
+    // release remains: by the lane that raises the flag.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long nblk = (unsigned long long)((P.count + kPushPerBlock - 1) / kPushPerBlock);
+        const unsigned long long nblk = (unsigned long long)((P.count + per_block - 1) / per_block);
         const unsigned long long old = __hip_atomic_fetch_add(&done[j], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         // `done` counts THIS plan's blocks and `launches` this plan's products: several plans may share a window (the flags carry the
         // window's step numbers), each sees its own launches only
@@ -241,8 +262,9 @@ void ipc_push_kernel(const push_peer *__restrict__ peers, int npeers, unsigned l
 // one wave: lane k waits for owner k's share; if any wait fails, every ghost value becomes NaN (all bits set) -- the remote part
 // that follows must not turn stale ghosts into plausible numbers
 __global__ __launch_bounds__(64)
-void ipc_wait_kernel(const unsigned long long *const *flags, int n, unsigned long long step, int *err, unsigned long long ticks,
+void ipc_wait_kernel(const unsigned long long *const *flags, int n, const unsigned long long *step_p, int *err, unsigned long long ticks,
         unsigned long long *ghost_words, long long nwords) {
+    const unsigned long long step = *step_p;
     bool ok = true;
     if ((int)threadIdx.x < n) ok = spin_until(flags[threadIdx.x], step, err, ticks);
     if (__builtin_amdgcn_ballot_w64(!ok))
@@ -250,7 +272,8 @@ void ipc_wait_kernel(const unsigned long long *const *flags, int n, unsigned lon
 }
 
 __global__ __launch_bounds__(64)
-void ipc_signal_kernel(unsigned long long *const *flags, int n, unsigned long long step) {
+void ipc_signal_kernel(unsigned long long *const *flags, int n, const unsigned long long *step_p) {
+    const unsigned long long step = *step_p;
     if ((int)threadIdx.x < n) __hip_atomic_store(flags[threadIdx.x], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -277,8 +300,7 @@ struct dist_spmv {
     const void *gx = nullptr; void *gy = nullptr; double galpha = 0; int gappend = 0; hipStream_t gstream = nullptr;
     // IPC transport (peer-mapped ghost windows): the owners WRITE their shares into the consumer's window
     ipc_window *win = nullptr;
-    unsigned long long step0 = 0;              // the window's product count when this plan was made
-    unsigned long long launches = 0;           // products issued through THIS plan (the `done` counters count its blocks)
+    unsigned long long *d_launches = nullptr;  // products issued through THIS plan, in device memory (the `done` counters count its blocks)
     push_peer *d_push = nullptr; int npush = 0; int64_t push_blocks = 0;
     unsigned long long *d_done = nullptr;      // per destination: blocks of the push kernel that have finished (monotonic)
     int *d_err = nullptr;                      // sticky, in pinned host memory mapped into the device: a flag was not raised in time
@@ -339,19 +361,20 @@ int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const 
     if (D->d_err && *static_cast<volatile int *>(D->d_err))
         return fail(__FILE__, __LINE__, "an earlier product of this plan timed out waiting for a peer's ghost flag (IPC transport, VEXHIP_IPC_TIMEOUT_MS): "
                                         "its result and every later one are invalid");
-    const unsigned long long step = ++D->win->step;
-    const unsigned long long launches = ++D->launches;
     const unsigned long long ticks = spin_ticks();
+    const unsigned long long *step = D->win->d_step, *launches = D->d_launches;
     PROF(0, s);
+    ipc_begin_kernel<<<1, 1, 0, s>>>(D->win->d_step, D->d_launches);
+    VEXHIP_LAUNCH_CHECK();
     if (D->npush) {
         VEXHIP_TRY(hipEventRecord(D->packed, s));
         VEXHIP_TRY(hipStreamWaitEvent(D->comm_stream, D->packed, 0));
         PROF(4, D->comm_stream); PROF(5, D->comm_stream);
         const int32_t *idx = D->direct ? nullptr : D->send_idx;
         if (D->dtype == VEXHIP_F64)
-            ipc_push_kernel<double><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const double *>(x), D->d_done, launches, D->d_err, ticks);
+            ipc_push_kernel<double><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const double *>(x), D->d_done, launches, D->d_err, ticks, push_per_block());
         else
-            ipc_push_kernel<float><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const float *>(x), D->d_done, launches, D->d_err, ticks);
+            ipc_push_kernel<float><<<(unsigned)D->push_blocks, 256, 0, D->comm_stream>>>(D->d_push, D->npush, step, idx, static_cast<const float *>(x), D->d_done, launches, D->d_err, ticks, push_per_block());
         VEXHIP_LAUNCH_CHECK();
         PROF(6, D->comm_stream);
         VEXHIP_TRY(hipEventRecord(D->pushed, D->comm_stream));
@@ -705,6 +728,7 @@ int vexhip_dist_spmv_destroy(vexhip_dist_spmv *h) {
     if (D->prof) { for (int k = 0; k < 7; ++k) if (D->prof[k]) (void)hipEventDestroy(D->prof[k]); delete[] D->prof; }
     if (D->d_push) (void)hipFree(D->d_push);
     if (D->d_done) (void)hipFree(D->d_done);
+    if (D->d_launches) (void)hipFree(D->d_launches);
     if (D->d_err) (void)hipHostFree(D->d_err);
     if (D->d_arrive) (void)hipFree(D->d_arrive);
     if (D->d_consumed) (void)hipFree(D->d_consumed);
@@ -726,11 +750,13 @@ int vexhip_dist_spmv_apply(vexhip_dist_spmv *h, void *stream, double alpha, int 
     if (!D->win && (D->nsend || D->nghost)) RCCL_READY();
     VEXHIP_SET_DEVICE(D->dev);
     hipStream_t s = as_stream(stream);
-    if (D->win) return issue_step(D, s, alpha, append, x, y);             // the flags carry step numbers: nothing to replay
-    // Steps with a ghost exchange are always issued directly: capturing ncclSend / ncclRecv into a hipGraph crashes in
-    // this RCCL (2.26.6, measured with tools/r02_dist_step.py), and the direct step costs ~50 us of host time against
-    // ~130 us on the device for a 1/8 strip of the 512^3 problem.
-    if (!D->use_graph || D->nsend || D->nghost) return issue_step(D, s, alpha, append, x, y);
+    // Steps with an RCCL exchange are always issued directly: capturing ncclSend / ncclRecv into a hipGraph crashes in this RCCL
+    // (2.26.6, measured with tools/r02_dist_step.py).  The IPC step is kernels and events only -- its step numbers live in
+    // device memory -- and replays like a step without an exchange (tools/r04_dist_step.py: host time per product).
+    if (!D->use_graph || (!D->win && (D->nsend || D->nghost))) return issue_step(D, s, alpha, append, x, y);
+    if (D->win && D->d_err && *static_cast<volatile int *>(D->d_err))
+        return fail(__FILE__, __LINE__, "an earlier product of this plan timed out waiting for a peer's ghost flag (IPC transport, VEXHIP_IPC_TIMEOUT_MS): "
+                                        "its result and every later one are invalid");
     // replay: the captured step is valid for exactly these operands
     if (D->exec && (D->gx != x || D->gy != y || D->galpha != alpha || D->gappend != append || D->gstream != s)) {
         (void)hipGraphExecDestroy(D->exec); D->exec = nullptr;
@@ -769,6 +795,10 @@ int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, v
     if (e != hipSuccess) { if (p) (void)hipFree(p); delete w; return check(e, __FILE__, __LINE__); }
     w->base = static_cast<char *>(p);
     w->peer[rank] = w->base;
+    e = hipMalloc(reinterpret_cast<void **>(&w->d_step), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(w->d_step, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); if (w->d_step) (void)hipFree(w->d_step); delete w; return check(e, __FILE__, __LINE__); }
     *out = reinterpret_cast<vexhip_ipc_window *>(w);
     return 0;
 }
@@ -811,6 +841,7 @@ int vexhip_ipc_window_destroy(vexhip_ipc_window *h) {
     (void)hipDeviceSynchronize();
     for (int p = 0; p < w->world; ++p) if (w->opened[p] && w->peer[p]) (void)hipIpcCloseMemHandle(w->peer[p]);
     if (w->base) (void)hipFree(w->base);
+    if (w->d_step) (void)hipFree(w->d_step);
     delete w;
     return 0;
 }
@@ -832,7 +863,7 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
     VEXHIP_REQUIRE(w->world <= 64, "more than 64 ranks");
     dist_spmv *D = new (std::nothrow) dist_spmv;
     VEXHIP_REQUIRE(D, "out of host memory");
-    D->win = w; D->step0 = w->step; D->dev = w->dev; D->dtype = dtype; D->loc = local; D->rows = rows;
+    D->win = w; D->dev = w->dev; D->dtype = dtype; D->loc = local; D->rows = rows;
     D->rem_rows = rem_rows; D->rows_idx = rows_idx; D->rem_ptr = rem_ptr; D->rem_col = rem_col; D->rem_val = rem_val;
     D->nsend = nsend; D->send_idx = send_idx; D->nghost = nghost;
     D->ghost_buf = w->base + window_header(w->world);
@@ -869,7 +900,7 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
             q.consumed = window_consumed(w->base, w->world, p);
             q.first = first; q.count = k; q.direct_first = D->direct ? D->send_first[p] : 0; q.blk0 = blk;
             plan.push_back(q);
-            blk += (k + kPushPerBlock - 1) / kPushPerBlock;
+            blk += (k + push_per_block() - 1) / push_per_block();
         }
         first += k;
     }
@@ -885,6 +916,8 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
     D->nown = (int)arr.size();
     e = hipHostMalloc(reinterpret_cast<void **>(&D->d_err), sizeof(int), hipHostMallocMapped);       // host-visible without a copy
     if (e == hipSuccess) *D->d_err = 0;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&D->d_launches), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(D->d_launches, 0, sizeof(unsigned long long));
     if (e == hipSuccess && D->npush) {
         e = hipMalloc(reinterpret_cast<void **>(&D->d_push), sizeof(push_peer) * plan.size());
         if (e == hipSuccess) e = hipMemcpy(D->d_push, plan.data(), sizeof(push_peer) * plan.size(), hipMemcpyHostToDevice);
