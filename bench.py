@@ -238,13 +238,13 @@ def measure_traffic(grid, timeout=240):
     return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run (tools/pmc_headline.py)"
 
 
-def cpp_rows(args_list, timeout=300):
+def cpp_rows(args_list, timeout=300, env=None):
     """Rows printed by a C++ example (JSON objects, one per line): the vex:: header API end to end."""
     exe = os.path.join(ROOT, "examples", "build", args_list[0])
     if not os.path.exists(exe):
         return [{"error": "%s is not built (python -c 'import __graft_entry__ as g; g.build()')" % args_list[0]}]
     p = subprocess.run([exe] + [str(a) for a in args_list[1:]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout,
-                       env=dict(os.environ, TMPDIR="/tmp"))
+                       env=dict(os.environ, TMPDIR="/tmp", **(env or {})))
     rows = []
     for line in p.stdout.decode(errors="replace").splitlines():
         line = line.strip()
@@ -865,6 +865,22 @@ def main():
                 out["roofline"]["traffic_all_kernels"] = tr
         if single and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_seconds)
+    # N > 1: north_star's own multi-GPU shape -- ONE vex::Context driving all N GPUs through the C++ headers (vexcl/spmat.hpp
+    # built from per-device strips, vexcl/exchange.hpp) -- timed by rank 0 in a child process while the ranks of this job wait
+    # at a barrier with their devices idle; reported next to the one-process-per-GPU figure, never part of it.
+    if world > 1 and not args.no_secondary:
+        torch.cuda.synchronize()
+        barrier()
+        if rank == 0:
+            progress("one vex::Context x%d through the C++ headers (examples/spmv_headline --devices %d)" % (world, world))
+            extra_env = {"VEXCL_LOGICAL_DEVICES": str(world)} if args.one_device else {}
+            try:
+                rows = cpp_rows(["spmv_headline", n, 50, "--devices", 1 if args.one_device else world], env=extra_env)
+            except Exception as e:  # noqa: BLE001 -- a comparison, not the measurement
+                rows = [{"error": repr(e)[:300]}]
+            out.setdefault("secondary", {})["C++ vex::Context x%d" % world] = rows
+        barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -3,13 +3,25 @@
 // on a 512^3 grid, and the same 7-point pattern with variable coefficients.  The reference harness
 // (examples/benchmark.cpp:353-477) assembles the matrix on the host and uploads it (12 GB of host
 // arrays at this size); here the CSR arrays are generated in HBM and handed to the device-array
-// constructor of vex::SpMat, which converts them on the device (vexhip_spmat_create).
-// Prints one JSON object per matrix: ms per product (HIP events on the compute queue, M products
-// then one synchronisation -- benchmark.cpp:426-433), GFLOP/s = 2 nnz / t, and the bytes the chosen
-// storage streams per product.   Usage: spmv_headline [grid = 512] [products = 100]
+// constructors of vex::SpMat, which convert them on the device (vexhip_spmat_create).
+// Prints one JSON object per matrix: ms per product (M products, then one synchronisation --
+// benchmark.cpp:426-433), GFLOP/s = 2 nnz / t, and the bytes the chosen storage streams per product.
+//
+//   spmv_headline [grid = 512] [products = 100]                 one device (Filter::Count(1))
+//   spmv_headline [grid] [products] --devices D|all             ONE vex::Context driving D GPUs (north_star's multi-GPU shape:
+//       VexCL's own multi-device partitioning, vector.hpp:131-167, spmat.hpp:74-106): every device generates ITS row strip in
+//       its own HBM, vex::SpMat is built from the per-device strips (all devices at once), the product runs the ghost
+//       exchange of vexcl/exchange.hpp (RCCL over xGMI between distinct GPUs).  Reported: wall time per product over the
+//       whole context (host clock around M products + ctx.finish()), the slowest device's event time, the per-device step
+//       phases (local part / wait for ghosts / remote part), and sum(y) -- the same for every D up to rounding.
+//   VEXCL_LOGICAL_DEVICES=k (tests) makes one GPU appear k times, as in the reference's test fixture.
+#include <array>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
+#include <memory>
 #include <vexcl/vexcl.hpp>
 
 static const char *storage_name(int f) {
@@ -22,9 +34,116 @@ static const char *storage_name(int f) {
     return "?";
 }
 
+static int multi_device(int64_t n, int M, int want) {
+    std::shared_ptr<vex::Context> context = want > 0 ? std::make_shared<vex::Context>(vex::Filter::Env && vex::Filter::Count(want))
+                                                     : std::make_shared<vex::Context>(vex::Filter::Env);
+    if (!*context) { std::cerr << "no device" << std::endl; return 1; }
+    if (const char *e = std::getenv("VEXCL_LOGICAL_DEVICES")) {
+        // one GPU appears k times (the reference's test fixture duplicates its queue the same way, tests/context_setup.hpp:24-38)
+        const int k = std::atoi(e);
+        std::vector<vex::backend::context> c = context->context();
+        std::vector<vex::backend::command_queue> qq = context->queue();
+        while ((int)qq.size() < k) {
+            vex::Context more(vex::Filter::Env && vex::Filter::Count(1));
+            c.push_back(more.context(0)); qq.push_back(more.queue(0));
+        }
+        context = std::make_shared<vex::Context>(c, qq);
+    }
+    vex::Context &ctx = *context;
+    const std::vector<vex::backend::command_queue> &q = ctx.queue();
+    const unsigned D = (unsigned)q.size();
+    const size_t N = (size_t)(n * n * n), nnz = (size_t)vexhip_poisson3d_nnz(n);
+    const std::vector<size_t> part = vex::partition(N, q);
+    const unsigned long long GOLD = 0x9E3779B97F4A7C15ull;
+
+    for (int variable = 0; variable < 2; ++variable) {
+        const auto t_setup0 = std::chrono::steady_clock::now();
+        vex::SpMat<double, int, int> A;
+        {
+            std::vector<vex::backend::device_vector<int>> ptr(D), col(D);
+            std::vector<vex::backend::device_vector<double>> val(D);
+            std::vector<size_t> strip_nnz(D);
+            for (unsigned d = 0; d < D; ++d) {       // every device generates its strip in its own HBM (global column ids)
+                const int dev = q[d].device_ordinal();
+                const int64_t r0 = (int64_t)part[d], r1 = (int64_t)part[d + 1];
+                strip_nnz[d] = (size_t)vexhip_poisson3d_strip_nnz(n, r0, r1);
+                ptr[d] = vex::backend::device_vector<int>(q[d], (size_t)(r1 - r0) + 1);
+                col[d] = vex::backend::device_vector<int>(q[d], std::max<size_t>(1, strip_nnz[d]));
+                val[d] = vex::backend::device_vector<double>(q[d], std::max<size_t>(1, strip_nnz[d]));
+                if (variable) vex::backend::check(vexhip_diffusion3d_strip_f64_i32(dev, q[d].raw(), n, r0, r1, 7, ptr[d].raw(), col[d].raw(), val[d].raw()));
+                else vex::backend::check(vexhip_poisson3d_strip_f64_i32(dev, q[d].raw(), n, r0, r1, ptr[d].raw(), col[d].raw(), val[d].raw()));
+            }
+            A = vex::SpMat<double, int, int>(q, N, N, ptr, col, val, strip_nnz);
+        }
+        ctx.finish();
+        const double setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_setup0).count();
+        vex::vector<double> x(ctx, N), y(ctx, N);
+        // x is a function of the GLOBAL index (bench.py's hash): the job computes the same product for every D
+        for (unsigned d = 0; d < D; ++d)
+            vex::backend::check(vexhip_fill_hash(q[d].device_ordinal(), q[d].raw(), VEXHIP_F64, 42ull + (unsigned long long)part[d] * GOLD,
+                        x(d).raw(), (int64_t)(part[d + 1] - part[d])));
+        for (int i = 0; i < 40; ++i) y = A * x;
+        ctx.finish();
+        std::vector<void *> e0(D, nullptr), e1(D, nullptr);
+        for (unsigned d = 0; d < D; ++d) {
+            vex::backend::check(vexhip_event_create(q[d].device_ordinal(), 1, &e0[d]));
+            vex::backend::check(vexhip_event_create(q[d].device_ordinal(), 1, &e1[d]));
+            vex::backend::check(vexhip_event_record(q[d].device_ordinal(), e0[d], q[d].raw()));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < M; ++i) y = A * x;
+        const auto t_issued = std::chrono::steady_clock::now();
+        for (unsigned d = 0; d < D; ++d) vex::backend::check(vexhip_event_record(q[d].device_ordinal(), e1[d], q[d].raw()));
+        ctx.finish();
+        const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / M;
+        const double host_issue_us = std::chrono::duration<double, std::micro>(t_issued - t0).count() / M;
+        double slowest = 0;
+        std::vector<float> dev_ms(D);
+        for (unsigned d = 0; d < D; ++d) {
+            vex::backend::check(vexhip_event_elapsed_ms(q[d].device_ordinal(), e0[d], e1[d], &dev_ms[d]));
+            dev_ms[d] /= M; slowest = std::max<double>(slowest, dev_ms[d]);
+            vexhip_event_destroy(q[d].device_ordinal(), e0[d]); vexhip_event_destroy(q[d].device_ordinal(), e1[d]);
+        }
+        // phases of one product per device: median of 7
+        std::vector<std::array<std::array<float, 4>, 7>> reps(D);
+        for (int r = 0; r < 7; ++r) {
+            std::vector<std::array<float, 4>> ms;
+            A.apply_timed(x, y, ms);
+            for (unsigned d = 0; d < D; ++d) reps[d][r] = ms[d];
+        }
+        vex::Reductor<double, vex::SUM_Kahan> sum(ctx);
+        const double checksum = sum(y);
+        std::printf("{\"row\": \"vex::SpMat<double,int,int> y = A*x, %s 7-point %lld^3, ONE vex::Context x%u\", \"front_end\": \"C++ vexcl/spmat.hpp + vexcl/exchange.hpp\", "
+                    "\"devices\": %u, \"rows\": %zu, \"nnz\": %zu, \"setup_ms\": %.2f, \"ms\": %.5f, \"gflops\": %.1f, \"slowest_device_event_ms\": %.5f, "
+                    "\"host_issue_us_per_product\": %.2f, \"csr_algorithmic_gbps\": %.1f, \"sum_y\": %.17g, \"per_device\": [",
+                variable ? "variable-coefficient" : "Poisson", (long long)n, D, D, N, nnz, setup_ms, wall_ms, 2.0 * nnz / wall_ms / 1e6, slowest,
+                host_issue_us, (12.0 * nnz + 4.0 * (N + 1) + 16.0 * N) / wall_ms / 1e6, checksum);
+        for (unsigned d = 0; d < D; ++d) {
+            std::array<float, 4> med;
+            for (int k = 0; k < 4; ++k) { float v[7]; for (int r = 0; r < 7; ++r) v[r] = reps[d][r][k]; std::sort(v, v + 7); med[k] = v[3]; }
+            const vexhip_spmat_info &info = A.storage_info(d);
+            std::printf("%s{\"device\": %d, \"rows\": %zu, \"storage\": \"%s\", \"plane_product\": %d, \"event_ms\": %.5f, "
+                        "\"step_ms\": {\"total\": %.5f, \"local\": %.5f, \"wait_for_ghosts\": %.5f, \"remote\": %.5f}}",
+                    d ? ", " : "", q[d].device_ordinal(), part[d + 1] - part[d], storage_name(info.format), (int)info.plane.usable, dev_ms[d],
+                    med[0], med[1], med[2], med[3]);
+        }
+        std::printf("]}\n");
+        std::fflush(stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    const int64_t n = argc > 1 ? std::atoll(argv[1]) : 512;
-    const int M = argc > 2 ? std::atoi(argv[2]) : 100;
+    int devices = -1;                       // -1: the single-device run
+    std::vector<char *> pos;
+    for (int i = 1; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) { ++i; devices = !std::strcmp(argv[i], "all") ? 0 : std::atoi(argv[i]); }
+        else pos.push_back(argv[i]);
+    }
+    const int64_t n = pos.size() > 0 ? std::atoll(pos[0]) : 512;
+    const int M = pos.size() > 1 ? std::atoi(pos[1]) : 100;
+    if (devices >= 0) return multi_device(n, M, devices);
+
     vex::Context ctx(vex::Filter::Env && vex::Filter::Count(1));
     if (!ctx) { std::cerr << "no device" << std::endl; return 1; }
     const vex::backend::command_queue &q = ctx.queue(0);
@@ -61,10 +180,10 @@ int main(int argc, char **argv) {
         const vexhip_spmat_info &info = A.storage_info();
         const double moved = (double)info.matrix_bytes + 16.0 * N;   // stored matrix + x once + y once
         std::printf("{\"row\": \"vex::SpMat<double,int,int> y = A*x, %s 7-point %lld^3\", \"front_end\": \"C++ vexcl/spmat.hpp\", "
-                    "\"storage\": \"%s\", \"rows\": %zu, \"nnz\": %zu, \"ms\": %.5f, \"gflops\": %.1f, "
+                    "\"storage\": \"%s\", \"plane_product\": %d, \"rows\": %zu, \"nnz\": %zu, \"ms\": %.5f, \"gflops\": %.1f, "
                     "\"bytes_streamed\": %.0f, \"streamed_gbps\": %.1f, \"streamed_frac_of_8TBps\": %.4f, "
                     "\"csr_algorithmic_gbps\": %.1f, \"sum_y\": %.17g}\n",
-                variable ? "variable-coefficient" : "Poisson", (long long)n, storage_name(info.format), N, nnz, ms, 2.0 * nnz / ms / 1e6,
+                variable ? "variable-coefficient" : "Poisson", (long long)n, storage_name(info.format), (int)info.plane.usable, N, nnz, ms, 2.0 * nnz / ms / 1e6,
                 moved, moved / ms / 1e6, moved / ms / 1e6 / 8000.0, (12.0 * nnz + 4.0 * (N + 1) + 16.0 * N) / ms / 1e6, checksum);
         std::fflush(stdout);
     }

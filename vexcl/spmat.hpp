@@ -15,7 +15,10 @@
 // consumer needs (gather kernel on the primary queue) and ONE vexhip_halo_exchange ships them on the
 // secondary queues -- grouped ncclSend / ncclRecv over xGMI between GPUs, event-ordered copies between
 // logical devices of one GPU -- while the local product runs; the remote product waits on an event.
+#include <array>
+#include <exception>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "operations.hpp"
@@ -44,16 +47,50 @@ class SpMat {
                     "SpMat value type must be float or double");
 
             std::vector<std::vector<col_t>> ghosts(queue.size());
-            for (unsigned d = 0; d < queue.size(); ++d)
+            // every device's strip is uploaded, split and converted by its own host thread (round 4: the set-up of D devices
+            // used to run one after the other)
+            per_device([&](unsigned d) {
                 mtx[d] = std::make_shared<device_part>(queue[d], row + part[d], row + part[d + 1], col, val,
                         col_part[d], col_part[d + 1], ghosts[d], queue.size() == 1);
+            });
             if (queue.size() > 1) exc.setup(queue, col_part, ghosts);
+        }
+
+        /// From per-device DEVICE strips (round 4): strip d holds rows part[d] .. part[d+1] of the matrix (part =
+        /// vex::partition(n, queue), the partition of a vex::vector on this context), resident on device d, with strip-local
+        /// row pointers (row[d][0] == 0), GLOBAL column ids and nonzeros[d] entries.  Nothing passes through the host: every
+        /// device splits its strip into the local and the remote part and converts the local part itself
+        /// (vexhip_csr_split_*, vexhip_spmat_create), all devices at the same time.  The reference builds from one host CSR
+        /// (spmat.hpp:71-106: 12 GB of host arrays at 512^3); this is the constructor the multi-device headline runs through
+        /// (examples/spmv_headline --devices).  Each strip must stay below 2^31 entries.
+        SpMat(const std::vector<backend::command_queue> &queue, size_t n, size_t m,
+              const std::vector<backend::device_vector<int>> &row, const std::vector<backend::device_vector<int>> &col,
+              const std::vector<backend::device_vector<val_t>> &val, const std::vector<size_t> &nonzeros)
+            : queue(queue), part(vex::partition(n, queue)), col_part(vex::partition(m, queue)),
+              nrows(n), ncols(m), nnz(0), mtx(queue.size())
+        {
+            static_assert(std::is_same<val_t, double>::value || std::is_same<val_t, float>::value,
+                    "SpMat value type must be float or double");
+            const size_t nd = queue.size();
+            precondition(row.size() == nd && col.size() == nd && val.size() == nd && nonzeros.size() == nd, "SpMat from device strips: one strip per device");
+            precondition(m < (size_t(1) << 31), "SpMat: more than 2^31 columns");
+            for (unsigned d = 0; d < nd; ++d) {
+                precondition(row[d].size() == part[d + 1] - part[d] + 1 && col[d].size() >= nonzeros[d] && val[d].size() >= nonzeros[d]
+                             && nonzeros[d] < (size_t(1) << 31), "SpMat from device strips: inconsistent strip");
+                nnz += nonzeros[d];
+            }
+            std::vector<std::vector<col_t>> ghosts(nd);
+            per_device([&](unsigned d) {
+                mtx[d] = std::make_shared<device_part>(queue[d], part[d + 1] - part[d], nonzeros[d], row[d], col[d], val[d],
+                        col_part[d], col_part[d + 1], ghosts[d], nd == 1);
+            });
+            if (nd > 1) exc.setup(queue, col_part, ghosts);
         }
 
         /// From DEVICE CSR arrays (int32 row pointers and columns, `nonzeros` entries): nothing is staged through the
         /// host -- the library converts on the device (vexhip_spmat_create).  The reference only builds from host
         /// arrays (spmat.hpp:71-106: 12 GB of host CSR at 512^3); this is the constructor the headline runs through.
-        /// Single-device contexts; a multi-device context partitions with the host-array constructor above.
+        /// Single-device contexts; a multi-device context takes one strip per device (the constructor below).
         SpMat(const std::vector<backend::command_queue> &queue, size_t n, size_t m, size_t nonzeros,
               const backend::device_vector<int> &row, const backend::device_vector<int> &col, const backend::device_vector<val_t> &val)
             : queue(queue), part(vex::partition(n, queue)), col_part(vex::partition(m, queue)),
@@ -101,6 +138,42 @@ class SpMat {
                     exc.finish(d);                        // queue[d] waits for its ghosts
                     mtx[d]->mul_remote(queue[d], exc.ghost_buffer(d), y(d), alpha);
                 }
+        }
+
+        /// The same product with its phases timed per device (HIP events on the primary queues; the call waits for them):
+        /// ms[d] = {whole step, local part, wait for the ghosts after the local part, remote part}.  What the multi-device
+        /// headline reports next to its wall time (examples/spmv_headline --devices).
+        template <class T>
+        void apply_timed(const vex::vector<T> &x, vex::vector<T> &y, std::vector<std::array<float, 4>> &ms, scalar_type alpha = 1, bool append = false) const {
+            static_assert(std::is_same<T, val_t>::value, "vector and matrix value types differ");
+            precondition(x.size() == ncols && y.size() == nrows, "SpMat::apply: incompatible sizes");
+            const unsigned nd = static_cast<unsigned>(queue.size());
+            std::vector<std::array<void *, 4>> ev(nd);
+            for (unsigned d = 0; d < nd; ++d)
+                for (int k = 0; k < 4; ++k) { ev[d][k] = nullptr; backend::check(vexhip_event_create(queue[d].device_ordinal(), 1, &ev[d][k])); }
+            auto mark = [&](unsigned d, int k) { backend::check(vexhip_event_record(queue[d].device_ordinal(), ev[d][k], queue[d].raw())); };
+            const bool exchange = nd > 1 && exc.active();
+            for (unsigned d = 0; d < nd; ++d) mark(d, 0);
+            if (exchange) exc.start(x);
+            for (unsigned d = 0; d < nd; ++d) {
+                if (part[d + 1] > part[d]) mtx[d]->mul_local(queue[d], x(d), y(d), alpha, append);
+                mark(d, 1);
+            }
+            for (unsigned d = 0; d < nd; ++d) {
+                const bool rem = exchange && exc.ghosts(d) && part[d + 1] > part[d];
+                if (rem) exc.finish(d);
+                mark(d, 2);
+                if (rem) mtx[d]->mul_remote(queue[d], exc.ghost_buffer(d), y(d), alpha);
+                mark(d, 3);
+            }
+            ms.assign(nd, std::array<float, 4>{{0, 0, 0, 0}});
+            for (unsigned d = 0; d < nd; ++d) {
+                const int dev = queue[d].device_ordinal();
+                backend::check(vexhip_event_sync(dev, ev[d][3]));
+                const int pair[4][2] = {{0, 3}, {0, 1}, {1, 2}, {2, 3}};
+                for (int k = 0; k < 4; ++k) backend::check(vexhip_event_elapsed_ms(dev, ev[d][pair[k][0]], ev[d][pair[k][1]], &ms[d][k]));
+                for (int k = 0; k < 4; ++k) vexhip_event_destroy(dev, ev[d][k]);
+            }
         }
 
         /// Y = alpha * A * X for a multivector (spmat.hpp:388-398).  Without a ghost exchange
@@ -190,10 +263,28 @@ class SpMat {
                     precondition(static_cast<size_t>(col[first + j]) < (1ull << 31), "SpMat: column index beyond 2^31");
                     scol[j] = static_cast<int>(col[first + j]);
                 }
-                const int dev = q.device_ordinal();
                 backend::device_vector<int> dptr(q, n + 1, sptr.data()), dcol(q, strip_nnz, scol.data());
                 backend::device_vector<val_t> dval(q, strip_nnz, val + first);
                 std::vector<int>().swap(sptr); std::vector<int>().swap(scol);
+                split_strip(q, dptr, dcol, dval, col_begin, col_end, ghost_cols);
+            }
+
+            /// One device's strip given as DEVICE CSR arrays (strip-local row pointers, global columns): split here.
+            device_part(const backend::command_queue &q, size_t rows, size_t nonzeros, const backend::device_vector<int> &dptr,
+                    const backend::device_vector<int> &dcol, const backend::device_vector<val_t> &dval,
+                    size_t col_begin, size_t col_end, std::vector<col_t> &ghost_cols, bool whole)
+                : n(rows)
+            {
+                if (whole && col_begin == 0) { set_local(q, dptr, dcol, dval, nonzeros); rem.n = n; rem.nnz = 0; return; }
+                precondition(col_end < (1ull << 31), "SpMat: more than 2^31 columns on one device");
+                split_strip(q, dptr, dcol, dval, col_begin, col_end, ghost_cols);
+            }
+
+            /// The strip on the device -> local part (a vexhip_spmat), row-subset remote part, sorted ghost set.
+            void split_strip(const backend::command_queue &q, const backend::device_vector<int> &dptr, const backend::device_vector<int> &dcol,
+                    const backend::device_vector<val_t> &dval, size_t col_begin, size_t col_end, std::vector<col_t> &ghost_cols)
+            {
+                const int dev = q.device_ordinal();
                 int64_t sz[4] = {0, 0, 0, 0};
                 backend::check(vexhip_csr_split_sizes_i32(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), (int64_t)col_begin, (int64_t)col_end, sz));
                 backend::device_vector<int> lptr(q, n + 1), lcol(q, (size_t)sz[0]);
@@ -310,6 +401,20 @@ class SpMat {
         };
 
     private:
+        /// f(d) for every device, each on its own host thread when there are several (the C ABI keeps its state per thread
+        /// and per device); the first exception is rethrown here.
+        template <class F>
+        void per_device(F f) const {
+            const unsigned nd = static_cast<unsigned>(queue.size());
+            if (nd <= 1 || std::getenv("VEXCL_SPMAT_SERIAL_SETUP")) { for (unsigned d = 0; d < nd; ++d) f(d); return; }
+            std::vector<std::exception_ptr> err(nd);
+            std::vector<std::thread> th;
+            for (unsigned d = 0; d < nd; ++d)
+                th.emplace_back([&, d]() { try { f(d); } catch (...) { err[d] = std::current_exception(); } });
+            for (auto &t : th) t.join();
+            for (unsigned d = 0; d < nd; ++d) if (err[d]) std::rethrow_exception(err[d]);
+        }
+
         std::vector<backend::command_queue> queue;
         std::vector<size_t> part, col_part;
         size_t nrows, ncols, nnz;
