@@ -58,7 +58,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
-KERNEL_OF = {"sell8v": "sell8_pair_kernel<double, 7, true, false>", "sell8v_march": "sell8_march_kernel<double, 7>", "sell8v_plane": "sell8_plane_kernel", "sell8": "sell8_pair_kernel<double, 7, false, false>",
+KERNEL_OF = {"sell8v_grid": "sell8_grid_kernel", "sell8v": "sell8_pair_kernel<double, 7, true, false>", "sell8v_march": "sell8_march_kernel<double, 7>", "sell8v_plane": "sell8_plane_kernel", "sell8": "sell8_pair_kernel<double, 7, false, false>",
              "sell32": "sell_pair_kernel<double, 7>", "csr": "csr_stream2_kernel<double, int, false>", "hell": "hell_kernel"}
 
 
@@ -836,6 +836,29 @@ def main():
                     "ms": round(t4, 4), "gflops": round(8.0 * nnz_total / t4 / 1e6, 1)}
                 del V, xs, ys
                 torch.cuda.empty_cache()
+                # ---- grids whose lines are not 512 points long (round 4, grid.hip): the same operator on 384^3 and 500^3
+                for g in (384, 500):
+                    Ng = g ** 3
+                    pg, cg, vg = ops.poisson3d(g, dev)
+                    G = ops.SpMat(pg, cg, vg)
+                    xg = ops.fill_hash(torch.empty(Ng, dtype=torch.float64, device=dev), 7)
+                    yg = torch.empty(Ng, dtype=torch.float64, device=dev)
+                    tg = min(timed_events(torch, lambda: G.apply(xg, yg), 20) for _ in range(3))
+                    row = {"storage": G.storage, "grid_plan": G.grid, "plane_plan": G.plane, "march_plan": G.march, "dictionary_blocks": G.dictionary_blocks,
+                           "kernel": "sell8_grid_kernel" if G.grid else ("sell8_plane_kernel" if G.plane else "sell8_march_kernel" if G.march else "sell8_pair_kernel"),
+                           "ms": round(tg, 5), "gflops": round(2.0 * cg.numel() / tg / 1e6, 1)}
+                    mg = G.matrix_bytes() + 16 * Ng
+                    row["roofline"] = {"bound": "hbm", "achieved": round(mg / tg / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": round(mg / tg / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": mg}
+                    Bg = ops.SpMat(pg, cg, vg, march=False)
+                    yb = torch.empty_like(yg)
+                    tb = min(timed_events(torch, lambda: Bg.apply(xg, yb), 20) for _ in range(2))
+                    row["pair_product_ms"] = round(tb, 5)
+                    row["bit_identical_to_pair_product"] = bool(torch.equal(yg, yb))
+                    assert row["bit_identical_to_pair_product"], "grid product differs from the pair product at %d^3" % g
+                    sec["SpMV Poisson 7-point %d^3 (y = A*x, vexhip_spmat)" % g] = row
+                    del G, Bg, pg, cg, vg, xg, yg, yb
+                    torch.cuda.empty_cache()
                 # ---- the C++ front end on the same two matrices (examples/spmv_headline.cpp)
                 sec["C++ front end"] = cpp_rows(["spmv_headline", n, 50])
                 sec.update(secondary_rows(torch, L, ops, dev, local_rank))

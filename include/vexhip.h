@@ -294,6 +294,37 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
 int vexhip_stream_copy_f64(int dev, void *stream, const double *x, double *y, int64_t n);
 int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
+/* The GRID product (grid.hip, round 4; same semantics, hybrid_ell.inl:238-269; the size-agnostic stencil form the reference
+ * reaches through SpMatCCSR, spmat/ccsr.hpp:55-113): the plane product for grids of any line length.  Value-coded storage
+ * (with or without a slice dictionary: `blocks` may be NULL, `codes` is then the per-slice buffer) whose diagonals are
+ * {0, +-1, +-nx, +-nx * lines_per_plane}, rows = a whole number of lines.  The plan re-expresses the matrix by grid line on the
+ * device: seven bytes per row (the value code per position, 255 = no entry), lines with equal rows form a class (<= 128), every
+ * line is verified against its class; it declines (usable = 0) when a row's entries do not ascend by position, when more
+ * than 1/4 of the lines use another class than the most frequent one, for fp32, a CSR tail, fewer than 32768 rows or 4 planes.
+ * The product owns two adjacent lines (one segment of <= 512 rows of them) per workgroup and walks through `depth` planes;
+ * lines need not be 16-byte aligned (odd nx), lines_per_plane may be odd.  line_class / table are device memory owned by the
+ * plan: vexhip_sell8_grid_release frees them.  VEXHIP_PLANE_DEPTH / VEXHIP_PLANE_STORE override, VEXHIP_NO_GRID declines.  */
+typedef struct vexhip_grid { int32_t usable;
+                             int32_t nx;                /* rows per grid line: the middle diagonals are +-nx                  */
+                             int32_t lines_per_plane;   /* the far diagonals are +-nx * lines_per_plane                       */
+                             int32_t planes;            /* ceil(lines / lines_per_plane)                                      */
+                             int32_t depth;             /* planes one workgroup walks through                                 */
+                             int32_t segments;          /* segments per line (nx > 512: more than one)                        */
+                             int32_t segment_rows;      /* rows per segment (even, <= 512)                                    */
+                             int32_t threads;           /* lanes per workgroup: 64 * ceil(segment_rows / 128)                 */
+                             int32_t hot_class;         /* line class kept decoded in registers                               */
+                             int32_t classes;           /* distinct line classes                                              */
+                             int32_t pitch;             /* bytes per position row of a class table                            */
+                             int32_t store_policy;      /* as vexhip_plane.store_policy                                       */
+                             int64_t x_last;
+                             const int32_t *line_class; /* device: class of every grid line                                   */
+                             const void *table;         /* device: classes x 7 positions x pitch value codes                  */
+                           } vexhip_grid;
+int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const void *codes, const int32_t *blocks,
+        int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes, int64_t x_last, vexhip_grid *out);
+int vexhip_sell8_grid_release(int dev, vexhip_grid *grid);
+int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, int append, const double *values,
+        const double *x, double *y, const vexhip_grid *grid);
 int64_t vexhip_sell8_last_fill_max_col(void);
 int vexhip_spmv_sell8v_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,
@@ -372,6 +403,7 @@ typedef struct vexhip_spmat_info {
     int64_t dictionary_blocks;      /* pool (no per-slice storage left); SELL8: `sell` keeps the values, slice-major           */
     vexhip_march march;             /* march product (usable = 1: apply() runs it; see vexhip_sell8_march_plan)                */
     vexhip_plane plane;             /* plane product (usable = 1: apply() prefers it to the march product; vexhip_sell8_plane_plan) */
+    vexhip_grid grid;               /* grid product (usable = 1: apply() runs it where the plane product does not apply; vexhip_sell8_grid_plan) */
 } vexhip_spmat_info;
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int format, int flags, vexhip_spmat **out);

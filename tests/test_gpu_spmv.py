@@ -407,6 +407,129 @@ def _grid7(nx, ny, nz):
     return ptr.astype(np.int32), col, val
 
 
+def _grid7_natural(nx, ny, nz, zero_face=False):
+    """7-point operator with natural boundaries: every row holds its diagonal (= the number of neighbours it has) and -1 for each
+    neighbour inside the grid, columns ascending -- nine kinds of grid lines.  zero_face: the +-1 entries of plane 1 are stored
+    as explicit 0.0 (an entry with value zero is not the same as no entry: 0 * Inf = NaN)."""
+    N = nx * ny * nz
+    idx = np.arange(N, dtype=np.int64)
+    i, j, k = idx % nx, (idx // nx) % ny, idx // (nx * ny)
+    has = np.stack([k > 0, j > 0, i > 0, np.ones(N, bool), i < nx - 1, j < ny - 1, k < nz - 1], axis=1)
+    offs = np.array([-nx * ny, -nx, -1, 0, 1, nx, nx * ny], dtype=np.int64)
+    cols = idx[:, None] + offs[None, :]
+    vals = np.where(np.arange(7)[None, :] == 3, (has.sum(axis=1) - 1).astype(np.float64)[:, None], -1.0)
+    if zero_face:
+        vals[(k == 1)[:, None] & ((np.arange(7) == 2) | (np.arange(7) == 4))[None, :]] = 0.0
+    ptr = np.zeros(N + 1, dtype=np.int64); ptr[1:] = np.cumsum(has.sum(axis=1))
+    return ptr.astype(np.int32), cols[has].astype(np.int32), vals[has]
+
+
+def test_grid_product_is_bit_identical(T, oracle, built_lib):
+    """The grid product (round 4, grid.hip: the plane walk for grid lines of ANY length -- the matrix re-expressed by grid line,
+    a class per line) against the pair / streamed products AND the CSR restatement, bit for bit: the benchmark's operator on
+    96^3 and 125^3 (odd line length: 16-byte requests at 8-byte addresses; odd lines per plane: the last tile stores one line),
+    lines longer than 512 (two segments), 384- and 500-point lines, natural boundaries (nine line classes, explicit zeros),
+    full bands whose +-1 diagonal crosses the line ends, a ragged last plane, several walk depths, '=' and '+= alpha',
+    Inf / NaN in x under absent entries; and what the plan declines."""
+    torch = T.torch
+    try:
+        def check(ptr, col, val, shape, seed, depth=None, expect=True, classes=None):
+            if depth is None:
+                os.environ.pop("VEXHIP_PLANE_DEPTH", None)
+            else:
+                os.environ["VEXHIP_PLANE_DEPTH"] = str(depth)
+            m = len(ptr) - 1
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+            assert A.storage == "sell8v" and B.grid is None and B.plane is None and B.march is None
+            if not expect:
+                assert A.grid is None, (shape, A.grid)
+                return
+            assert A.grid is not None and A.plane is None, (shape, A.storage, A.dictionary_blocks)
+            assert (A.grid["nx"], A.grid["lines_per_plane"]) == shape[:2] and A.grid["x_last"] == m - 1, (shape, A.grid)
+            assert A.grid["segments"] == (shape[0] + 511) // 512 and (depth is None or A.grid["depth"] == min(depth, A.grid["planes"])), (shape, A.grid)
+            if classes is not None:
+                assert A.grid["classes"] == classes, (shape, A.grid)
+            xb = oracle.random_f64(seed, m); y0 = oracle.random_f64(seed + 1, m)
+            want = oracle.spmv_csr(ptr, col, val, xb)
+            for alpha, append in ((1.0, False), (-0.75, True)):
+                ya, yb = T.up(y0.copy()), T.up(y0.copy())
+                A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+                assert torch.equal(ya, yb), (shape, alpha)
+                assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (shape, alpha)
+            return A
+
+        # the benchmark's operator (examples/benchmark.cpp:364-415): two line classes
+        for n in (96, 125):
+            ptr, col, val = oracle.poisson3d(n)
+            check(ptr, col, val, (n, n, n), 31, classes=2)
+        # small grids: most lines are boundary lines, the plan is forced (it declines when more than a quarter of the lines
+        # use another class than the most frequent one)
+        os.environ["VEXHIP_PLANE_FORCE"] = "1"
+        for shape, depth in (((70, 33, 20), None), ((70, 33, 20), 3), ((1030, 6, 8), None), ((1030, 6, 8), 5), ((384, 10, 12), None),
+                             ((500, 7, 11), 4), ((127, 17, 19), 7), ((514, 5, 13), None)):
+            ptr, col, val = _grid7(*shape)
+            check(ptr, col, val, shape, 33, depth, classes=2)
+        # natural boundaries: nine line classes, the other class changes along every walk; explicit zeros in plane 1
+        for shape, depth in (((96, 20, 21), None), ((125, 15, 18), 5), ((250, 9, 16), None)):
+            ptr, col, val = _grid7_natural(*shape, zero_face=True)
+            A = check(ptr, col, val, shape, 35, depth)
+            assert A.grid["classes"] >= 9, A.grid
+        # full bands: the +-1 diagonal crosses the line ends (lane 0 / the last lane of a line read the neighbouring line's
+        # element), a ragged last plane (lines not a multiple of the lines per plane)
+        for nx, ny, nz, extra_lines, depth in ((96, 12, 30, 0, None), (125, 9, 33, 4, 6), (300, 8, 14, 3, None)):
+            P = nx * ny; m = P * nz + extra_lines * nx
+            ptr, col, val = _band(m, (-P, -nx, -1, 0, 1, nx, P), 5, constant=True)
+            check(ptr, col, val, (nx, ny, nz), 37, depth)
+        os.environ.pop("VEXHIP_PLANE_DEPTH", None)
+        # Inf / NaN in x: only the rows that reference them may see them; a stored 0.0 times Inf is NaN as in the CSR loop
+        shape = (125, 15, 18)
+        ptr, col, val = _grid7_natural(*shape, zero_face=True)
+        m = len(ptr) - 1
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        assert A.grid is not None
+        xb = oracle.random_f64(39, m)
+        xb[0] = np.inf; xb[1] = -np.inf; xb[m - 1] = np.nan; xb[125 * 15 + 7 * 125 + 60] = np.inf; xb[5 * 125 * 15 + 124] = np.nan
+        ya = torch.empty(m, dtype=torch.float64, device=T.dev)
+        A.apply(T.up(xb), ya)
+        want = oracle.spmv_csr(ptr, col, val, xb)
+        assert np.isnan(want).sum() >= 8                      # the neighbours of the NaN and of the Inf under a stored zero
+        assert np.array_equal(ya.cpu().numpy(), want, equal_nan=True)
+        os.environ.pop("VEXHIP_PLANE_FORCE")
+        # the Poisson matrix bordered by Inf: the boundary rows are identity rows, their neighbours never look at them... but
+        # interior rows next to the boundary do: as the CSR loop
+        ptr, col, val = oracle.poisson3d(96)
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        xb = oracle.random_f64(40, 96 ** 3); xb[::97] = np.inf
+        ya = torch.empty(96 ** 3, dtype=torch.float64, device=T.dev)
+        A.apply(T.up(xb), ya)
+        assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb), equal_nan=True)
+
+        # declined: fp32; an eighth diagonal; a 2-D operator (no far pair); rows reversed (storage order is not position order);
+        # rows that do not fill whole lines; plane=False / dictionary=False keep the older products
+        ptr, col, val = _grid7(96, 20, 21)
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val.astype(np.float32))).grid is None
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), plane=False).grid is None
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), dictionary=False).grid is None
+        P = 96 * 20; m = P * 21
+        b8 = _band(m, (-P, -96, -2, -1, 0, 1, 96, P), 7, constant=True)
+        check(*b8, (96, 20, 21), 41, expect=False)
+        b5 = _band(m, (-96, -1, 0, 1, 96), 7, constant=True)
+        check(*b5, (96, 20, 21), 41, expect=False)
+        ptr, col, val = _band(m, (-P, -96, -1, 0, 1, 96, P), 7, constant=True)
+        rcol, rval = col.copy(), val.copy()
+        for r in range(3 * P, 3 * P + 200):                      # a few rows with their entries reversed
+            rcol[ptr[r]:ptr[r + 1]] = col[ptr[r]:ptr[r + 1]][::-1]; rval[ptr[r]:ptr[r + 1]] = val[ptr[r]:ptr[r + 1]][::-1]
+        R = T.ops.SpMat(T.up(ptr), T.up(rcol), T.up(rval))
+        assert R.grid is None
+        xb = oracle.random_f64(43, m)
+        assert np.array_equal((R @ T.up(xb)).cpu().numpy(), oracle.spmv_csr(ptr, rcol, rval, xb))
+        ptr, col, val = _band(m + 50, (-P, -96, -1, 0, 1, 96, P), 7, constant=True)
+        check(ptr, col, val, (96, 20, 21), 45, expect=False)
+    finally:
+        os.environ.pop("VEXHIP_PLANE_DEPTH", None)
+        os.environ.pop("VEXHIP_PLANE_FORCE", None)
+
+
 @pytest.mark.parametrize("tile", [2, 4])
 def test_plane_product_is_bit_identical(T, oracle, built_lib, tile):
     """The plane product (round 4: a workgroup owns `tile` grid lines of 512 points and walks through the planes; the +-512 and

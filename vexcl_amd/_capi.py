@@ -67,6 +67,14 @@ class Plane(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("x_last", ctypes.c_int64)]
 
 
+class Grid(ctypes.Structure):
+    """vexhip_grid (include/vexhip.h)."""
+    _fields_ = [("usable", ctypes.c_int32), ("nx", ctypes.c_int32), ("lines_per_plane", ctypes.c_int32), ("planes", ctypes.c_int32),
+                ("depth", ctypes.c_int32), ("segments", ctypes.c_int32), ("segment_rows", ctypes.c_int32), ("threads", ctypes.c_int32),
+                ("hot_class", ctypes.c_int32), ("classes", ctypes.c_int32), ("pitch", ctypes.c_int32), ("store_policy", ctypes.c_int32),
+                ("x_last", ctypes.c_int64), ("line_class", ctypes.c_void_p), ("table", ctypes.c_void_p)]
+
+
 class SpMatInfo(ctypes.Structure):
     """vexhip_spmat_info (include/vexhip.h)."""
     _fields_ = [("format", ctypes.c_int32), ("value_type", ctypes.c_int32), ("device", ctypes.c_int32),
@@ -76,7 +84,7 @@ class SpMatInfo(ctypes.Structure):
                 ("sell", ctypes.c_void_p), ("deltas", ctypes.c_void_p), ("values", ctypes.c_void_p),
                 ("csr_ptr", ctypes.c_void_p), ("csr_col", ctypes.c_void_p), ("csr_val", ctypes.c_void_p),
                 ("traversal", Traversal), ("slice_blocks", ctypes.c_void_p), ("code_pool", ctypes.c_void_p),
-                ("dictionary_blocks", ctypes.c_int64), ("march", March), ("plane", Plane)]
+                ("dictionary_blocks", ctypes.c_int64), ("march", March), ("plane", Plane), ("grid", Grid)]
 
 
 SPMAT_AUTO, SPMAT_SELL8V, SPMAT_SELL8, SPMAT_SELL, SPMAT_CSR = range(5)
@@ -164,6 +172,9 @@ _PROTOS = {
     "vexhip_sell8_last_fill_max_col": (c_i64, []),
     "vexhip_stream_copy_f64": (None, [c_int, c_vp, c_vp, c_vp, c_i64]),
     "vexhip_sell8_plane_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, ctypes.POINTER(Plane)]),
+    "vexhip_sell8_grid_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_i64, ctypes.POINTER(Grid)]),
+    "vexhip_sell8_grid_release": (None, [c_int, ctypes.POINTER(Grid)]),
+    "vexhip_spmv_sell8v_grid_f64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(Grid)]),
     "vexhip_spmv_sell8v_plane_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Plane)]),
     "vexhip_spmv_sell8v_march_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),
     "vexhip_spmv_sell8v_march_f32_i32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),

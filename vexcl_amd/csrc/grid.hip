@@ -1,0 +1,558 @@
+// The GRID product (round 4): the plane product (plane.hip) for grids of ANY line length.
+//
+// y (=|+=) alpha * A * x for value-coded SELL-512 storage whose diagonals are those of a 7-point operator on an nx x ny x nz
+// grid -- {0, +-1, +-nx, +-nx*ny} -- with nx, ny arbitrary (odd, not a divisor or multiple of 512: 384^3, 500^3, 127^3).
+// Semantics are the reference's ELL product (/root/reference/vexcl/spmat/hybrid_ell.inl:238-269: the row's entries in storage
+// order, products rounded before they are added, the scale applied to the sum), results bit-identical to the CSR loop
+// (spmat/csr.inl:163-170).  The reference's own size-agnostic answer to stencil matrices is SpMatCCSR (spmat/ccsr.hpp:55-113:
+// rows -> one of a few (offset, value) stencils); this is what the plan below recovers from the stored matrix.
+//
+// Why the plane product does not cover these grids: it reads the matrix from the slice dictionary of the SELL-512 storage -- a
+// slice IS a grid line when nx = 512.  For other nx the lines drift through the slices: 384^3 still has a dictionary, 500^3
+// has > 128 distinct slices and streams 14 bytes of codes per row next to the 16 bytes of x and y.  The grid does not care:
+//   * the plan re-expresses the matrix by GRID LINE.  A device pass turns every row's codes into seven bytes -- the value code
+//     at each of the positions {-P, -nx, -1, 0, +1, +nx, +P}, 255 where the row has no entry -- checks that every row keeps
+//     its entries in ascending position (position order = storage order) and hashes each line's rows.  Lines with equal rows
+//     form a CLASS (a handful: interior lines, boundary lines, lines of boundary planes); the matrix becomes 4 bytes per line
+//     (its class) + a table of 7 * nx bytes per class, and a second pass verifies every line against its class byte by byte.
+//   * the kernel is the plane kernel with the line length as a number: a workgroup owns TWO adjacent grid lines (one SEGMENT of
+//     <= 512 rows of them when nx > 512) and walks through the planes; lane t owns rows 2t, 2t + 1 of its segment in every
+//     plane, so the +-nx and +-P neighbours are pairs the same lane loaded (registers), the +-1 neighbours one DPP wave shift
+//     (the element beyond either end of a wave's 128 rows: a scalar-like 8-byte load).  All x addressing is LINEAR (line *
+//     nx + row), so lines need not be 16-byte aligned (odd nx: 16-byte requests at 8-byte addresses, which gfx950 serves),
+//     the last tile of a plane with an odd number of lines simply does not store its second line, and a lane beyond the end
+//     of its line computes on whatever lies there and stores nothing (the fast loop runs only where such a lane's requests
+//     still lie inside the arrays; the last planes take clamped, element-wise requests).
+// The 512-point kernel stays the default where it applies (the headline): same walk, fewer scalar operands.
+// Compiled with -ffp-contract=off.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace vexhip {
+namespace {
+
+constexpr unsigned GR_PAD_FIRST = 254;      // codes 254 / 255 are padding (sell8.hip)
+constexpr int GR_ABSENT = 255;              // table byte of a position without an entry (value codes are < 255)
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+struct grid_dev {
+    long long lines;         // grid lines of the matrix: rows / nx
+    long long x_last;        // largest valid index of x
+    long long n;             // rows
+    int nx, ny, nz;          // line length, lines per plane, planes: ceil(lines / ny)
+    int depth;               // planes per workgroup
+    int segs, seg_len;       // segments per line, rows per segment (even, <= 512)
+    int tiles, tpx;          // ceil(ny / 2) * segs, and per XCD: ceil(tiles / 8)
+    int hot;                 // line class decoded into registers with scalar masks
+    int pitch;               // bytes per position row of a class table (>= segs * 512, padded with 255)
+};
+
+struct codes_dev {           // where the value-coded slices are (sell8.hip: ceil(w/2) KiB diagonal codes, then as many value codes)
+    const char *buf; const int *blocks; int w, ndeltas;
+    signed char pos[8];      // diagonal code -> position 0..6
+};
+
+__device__ __forceinline__ double shift_from_lower_lane(double v, double edge) {       // lane i <- lane i - 1, lane 0 <- edge
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);   // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shift_from_upper_lane(double v, double edge) {       // lane i <- lane i + 1, lane 63 <- edge
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);   // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v for the lanes of `lanes`, elsewhere a number whose exponent field is 0: (+0.0) * that == +0.0 whatever x holds there
+__device__ __forceinline__ double keep_lanes(double v, unsigned long long lanes) {
+    unsigned rhi;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"((unsigned)__double2hiint(v)), "s"(lanes));
+    return __hiloint2double((int)rhi, __double2loint(v));
+}
+__device__ __forceinline__ double keep_bit(double v, unsigned bits, int pos) {
+    const int m = (int)(bits << (31 - pos)) >> 31;                // -1 where the bit is set
+    return __hiloint2double(__double2hiint(v) & m, __double2loint(v));
+}
+
+// ---- set-up: a row's codes -> seven bytes (value code per position, 255 = no entry); false: not a matrix for this product ----
+__device__ __forceinline__ bool row_signature(const codes_dev &cd, long long i, unsigned char (&sig)[7]) {
+    const long long s = i >> 9;
+    const int t2 = (int)(i & 511) >> 1, q = (int)(i & 1);
+    const int wp = (cd.w + 1) >> 1;
+    const long long sb = cd.blocks ? (long long)cd.blocks[s] : s;
+    const unsigned *cw = reinterpret_cast<const unsigned *>(cd.buf + sb * ((long long)wp * 2048)) + t2;
+    const unsigned *vw = cw + wp * 256;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) sig[p] = GR_ABSENT;
+    int last = -1; bool ok = true;
+    for (int j = 0; j < cd.w; ++j) {
+        const int sh = 8 * ((j & 1) * 2 + q);
+        const unsigned code = (cw[(j >> 1) * 256] >> sh) & 255u;
+        if (code >= GR_PAD_FIRST) continue;
+        if ((int)code >= cd.ndeltas) { ok = false; continue; }
+        const int p = cd.pos[code];
+        const unsigned vc = (vw[(j >> 1) * 256] >> sh) & 255u;
+        if (p <= last || vc >= (unsigned)GR_ABSENT) { ok = false; continue; }
+        last = p;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) if (k == p) sig[k] = (unsigned char)vc;
+    }
+    return ok;
+}
+__device__ __forceinline__ unsigned long long mix64(unsigned long long v) {           // splitmix64 finaliser
+    v ^= v >> 30; v *= 0xbf58476d1ce4e5b9ull; v ^= v >> 27; v *= 0x94d049bb133111ebull; v ^= v >> 31;
+    return v;
+}
+// one wave per grid line: hash[line] = sum over its rows of mix(signature, row) (commutative: any lane order)
+__global__ __launch_bounds__(256)
+void grid_line_hash_kernel(codes_dev cd, long long lines, int nx, unsigned long long *__restrict__ hash, int *__restrict__ bad)
+{
+    const long long line = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= lines) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long h = 0; bool ok = true;
+    for (int r = lane; r < nx; r += 64) {
+        unsigned char sig[7];
+        ok = row_signature(cd, line * nx + r, sig) && ok;
+        unsigned long long v = 0;
+#pragma unroll
+        for (int p = 0; p < 7; ++p) v |= (unsigned long long)sig[p] << (8 * p);
+        h += mix64(v + 0x9e3779b97f4a7c15ull * (unsigned long long)(r + 1));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    if (lane == 0) hash[line] = h;
+    if (!ok) atomicOr(bad, 1);
+}
+// table[c][p][r] of class c from its representative line (rows beyond nx: 255)
+__global__ __launch_bounds__(256)
+void grid_line_table_kernel(codes_dev cd, const long long *__restrict__ rep, int nx, int pitch, unsigned char *__restrict__ table)
+{
+    const int c = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= pitch) return;
+    unsigned char sig[7];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) sig[p] = GR_ABSENT;
+    if (r < nx) (void)row_signature(cd, rep[c] * nx + r, sig);
+#pragma unroll
+    for (int p = 0; p < 7; ++p) table[((long long)c * 7 + p) * pitch + r] = sig[p];
+}
+// every row of every line against the table of the line's class
+__global__ __launch_bounds__(256)
+void grid_line_verify_kernel(codes_dev cd, long long lines, int nx, int pitch, const int *__restrict__ line_class,
+        const unsigned char *__restrict__ table, int *__restrict__ bad)
+{
+    const long long line = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= lines) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned char *tb = table + (long long)line_class[line] * 7 * pitch;
+    bool ok = true;
+    for (int r = lane; r < nx; r += 64) {
+        unsigned char sig[7];
+        ok = row_signature(cd, line * nx + r, sig) && ok;
+#pragma unroll
+        for (int p = 0; p < 7; ++p) ok = ok && sig[p] == tb[(long long)p * pitch + r];
+    }
+    if (!ok) atomicOr(bad, 2);
+}
+
+// ---- the product ----
+template <bool APPEND, int STORE_AUX>
+__global__ __launch_bounds__(256, 4)
+void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
+        const int *__restrict__ line_class, const unsigned char *__restrict__ table, const double *__restrict__ values, grid_dev gd)
+{
+    constexpr int TY = 2;
+    // LDS: the value table and the decoded values of the OTHER class, lane-private ([position * 2 + row][lane]: conflict-free)
+    __shared__ double s_value[256];
+    __shared__ double s_other[14][256];
+
+    const int t = threadIdx.x;
+    const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
+    const int zc = (int)(q / (unsigned)gd.tpx), tyl = (int)(q - (unsigned)zc * (unsigned)gd.tpx);
+    const int tile = (int)xcd * gd.tpx + tyl;
+    if (tile >= gd.tiles) return;                                   // the whole workgroup
+    const int ytile = tile / gd.segs, seg = tile - ytile * gd.segs;
+    const int y0 = TY * ytile;
+    const int nl = gd.ny - y0 < TY ? gd.ny - y0 : TY;               // lines of the tile inside a plane (odd ny: the last tile has one)
+    const int row0 = seg * gd.seg_len;
+    const int len = gd.nx - row0 < gd.seg_len ? gd.nx - row0 : gd.seg_len;
+    int z = zc * gd.depth;
+    const int zend = z + gd.depth < gd.nz ? z + gd.depth : gd.nz;
+    if (z >= zend) return;
+    const int nx = gd.nx, ny = gd.ny;
+    const long long lines = gd.lines, x_last = gd.x_last, n = gd.n;
+    const unsigned lane_b = 16u * (unsigned)t;
+    const bool full = 2 * t + 1 < len, half = 2 * t + 1 == len;       // the lane stores a pair / its first row only / nothing
+    // the element beyond either end of the wave's 128 rows of a segment: lane 63 reads the one behind them, every other lane the
+    // one in front (lane 0 uses it; one cache line for the rest) -- byte offset from the start of the segment
+    const int edge_b = (t >> 6) * 1024 + ((t & 63) == 63 ? 1024 : -8);
+
+    for (int i = t; i < 256; i += (int)blockDim.x) s_value[i] = values[i];
+    __syncthreads();
+
+    // ---- a line class -> values (into s_other) and validity (returned) of this lane's rows at the seven positions ----
+    auto decode = [&](int cls) -> unsigned {
+        const unsigned char *tb = table + (long long)cls * 7 * gd.pitch + row0 + 2 * t;
+        unsigned bits = 0;
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            const unsigned c2 = *reinterpret_cast<const unsigned short *>(tb + (long long)p * gd.pitch);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned code = (c2 >> (8 * r)) & 255u;
+                s_other[2 * p + r][t] = s_value[code];            // entry 255 of the value table is 0.0
+                bits |= (code != (unsigned)GR_ABSENT ? 1u : 0u) << (2 * p + r);
+            }
+        }
+        return bits;
+    };
+
+    const int hot = gd.hot;
+    double aH[7][2];                            // the hot class: values ...
+    unsigned long long mH[7][2];                // ... and the lanes with an entry, per position and row
+    {
+        const unsigned bitsH = decode(hot);
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            aH[p][0] = s_other[2 * p][t]; aH[p][1] = s_other[2 * p + 1][t];
+            mH[p][0] = __builtin_amdgcn_ballot_w64((bitsH >> (2 * p)) & 1u);
+            mH[p][1] = __builtin_amdgcn_ballot_w64((bitsH >> (2 * p + 1)) & 1u);
+        }
+    }
+    unsigned bitsO = 0;
+    int other = -1;                             // what s_other holds now is the hot class's: never asked for
+
+    // clamped requests (prologue, slow steps): line `l` of the tile's window (0 = the line above the tile, 1 .. TY = the tile,
+    // TY + 1 = the line below) in plane zz, element by element.  What lies outside x is never referenced by an entry; what is
+    // loaded in its place is multiplied by +0.0 behind a mask
+    auto elem = [&](long long i) -> double { i = i < 0 ? 0 : i; i = i > x_last ? x_last : i; return x[i]; };
+    auto ld = [&](int zz, int l) -> d2 {
+        const long long i = ((long long)zz * ny + (y0 - 1 + l)) * nx + row0 + 2 * t;
+        d2 r; r.x = elem(i); r.y = elem(i + 1);
+        return r;
+    };
+    auto edge = [&](int zz, int l) -> double {
+        return elem(((long long)zz * ny + (y0 - 1 + l)) * nx + row0 + (edge_b >> 3));
+    };
+    auto yold = [&](int zz, int l) -> d2 {
+        long long i = ((long long)zz * ny + (y0 + l)) * nx + row0 + 2 * t, j = i + 1;
+        i = i < 0 ? 0 : i; i = i > n - 1 ? n - 1 : i; j = j < 0 ? 0 : j; j = j > n - 1 ? n - 1 : j;
+        d2 r; r.x = y[i]; r.y = y[j];
+        return r;
+    };
+
+    // ---- state at the top of the step for plane z: as in plane.hip ----
+    // Cs[0..3]: the tile's two centre lines in planes z-1, z, z+1, z+2;  Hs[0..1]: the halo lines (above, below) in planes z, z+1;
+    // Es[0..1]: per centre line the edge element of this lane in planes z, z+1.  The fast loop runs GROUPS of four steps with
+    // the names rotated; every request has two steps to arrive.
+    d2 Cs[4][TY], Hs[2][2], Yo[TY];
+    double Es[2][TY];
+    const unsigned line_b = (unsigned)nx * 8u;                        // bytes from a line to the next
+    const unsigned plane_b32 = (unsigned)ny * line_b;                 // ... to the same line of the next plane (the plan: (depth + 4) of them < 2^32)
+    const int z_first = z;
+    // buffer resources of the fast loop: x from the segment of the line above the tile in the workgroup's first plane, y from
+    // the tile's first line in that plane.  No range check (the scalar offset that moves with the planes takes no part in it):
+    // the fast loop only runs where every request of every lane lies inside the arrays (zh below)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(x + (((long long)z_first * ny + (y0 - 1)) * nx + row0)), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + (((long long)z_first * ny + y0) * nx + row0), 0, -1, 0x00020000);
+#pragma unroll
+    for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
+    Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
+#pragma unroll
+    for (int l = 0; l < TY; ++l) {
+        Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
+        if (APPEND) Yo[l] = yold(z, l);
+    }
+
+    // the lane's sums for tile line l: x at the seven positions from the registers named above
+#define GRID_XS(P, C, N, H, E, l)                                                                                                    \
+        const d2 c = C[l], up = (l) == 0 ? H[0] : C[(l) > 0 ? (l) - 1 : 0], dn = (l) == TY - 1 ? H[1] : C[(l) < TY - 1 ? (l) + 1 : 0];                                                  \
+        const double xs0[7] = {P[l].x, up.x, shift_from_lower_lane(c.y, E[l]), c.x, c.y, dn.x, N[l].x};                                \
+        const double xs1[7] = {P[l].y, up.y, c.x, c.y, shift_from_upper_lane(c.x, E[l]), dn.y, N[l].y};
+#define GRID_HOT_SUMS(s0, s1)                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) { s0 += aH[p][0] * keep_lanes(xs0[p], mH[p][0]); s1 += aH[p][1] * keep_lanes(xs1[p], mH[p][1]); }
+#define GRID_OTHER_SUMS(s0, s1)                                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) {                                                                               \
+            s0 += s_other[2 * p][t] * keep_bit(xs0[p], bitsO, 2 * p); s1 += s_other[2 * p + 1][t] * keep_bit(xs1[p], bitsO, 2 * p + 1); }
+
+    // fast steps: every request lies inside the arrays.  A lane may sit beyond the end of its line (it stores nothing, but it
+    // requests): `over` = the furthest element, from the start of a line, that a lane of this workgroup asks for
+    int zh = zend;
+    {
+        const long long over = row0 + 2 * (long long)blockDim.x + 1;
+        const long long xl_in = x_last - over >= 0 ? (x_last - over) / nx : -1;       // largest line all of whose requests are inside x
+        const long long yl_in = n - 1 - over >= 0 ? (n - 1 - over) / nx : -1;         // ... inside y ('+=' reads the old y one plane ahead)
+        // largest z with (z + ahead) * ny + y0 + line <= limit, + 1
+        auto end_for = [&](long long limit, int ahead, int line) -> long long { const long long v = limit - y0 - line; return v < 0 ? 0 : v / ny - ahead + 1; };
+        long long e = end_for(xl_in, 3, TY);                                           // x: planes up to z + 3, lines up to the one below the tile
+        e = std::min(e, end_for(lines - 1, 0, TY - 1));                               // y: both lines exist
+        if (APPEND) e = std::min(e, end_for(yl_in, 1, TY - 1));
+        zh = zh < e ? zh : (int)(e < 0 ? 0 : e);
+    }
+
+    while (z < zend) {
+        // ---- how many of the next planes (<= 64) can take fast steps: both lines use the hot class or the other class ----
+        unsigned long long use_hot[TY];          // bit k: line l of plane z + k uses the hot class (else: the other class)
+        int run;
+        {
+            const int k = t & 63, zz = z + k;
+            const bool in = zz < zh;
+            bool ok = in;
+#pragma unroll
+            for (int l = 0; l < TY; ++l) {
+                const int bk = (in && l < nl) ? line_class[(long long)zz * ny + (y0 + l)] : hot;
+                ok = ok && (bk == hot || bk == other);
+                use_hot[l] = __builtin_amdgcn_ballot_w64(bk == hot);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+            run = ~m ? __builtin_ctzll(~m) : 64;
+        }
+        if (run >= 4) {
+            // xo: plane z + 2, the line above the tile; yo: plane z, the tile's first line; both relative to the workgroup's first plane
+            unsigned xo = (unsigned)((z + 2 - z_first) * plane_b32), yo = (unsigned)((z - z_first) * plane_b32);
+            auto fast_step = [&](d2 (&P)[TY], d2 (&C)[TY], d2 (&N)[TY], d2 (&H)[2], double (&E)[TY]) {
+                d2 o[TY];
+#pragma unroll
+                for (int l = 0; l < TY; ++l) {
+                    GRID_XS(P, C, N, H, E, l)
+                    double s0 = 0.0, s1 = 0.0;
+                    if (use_hot[l] & 1ull) { GRID_HOT_SUMS(s0, s1) } else { GRID_OTHER_SUMS(s0, s1) }      // uniform
+                    o[l].x = alpha * s0; o[l].y = alpha * s1;
+                    if (APPEND) { o[l].x = Yo[l].x + o[l].x; o[l].y = Yo[l].y + o[l].y; }
+                }
+#pragma unroll
+                for (int l = 0; l < TY; ++l) use_hot[l] >>= 1;
+#pragma unroll
+                for (int l = 0; l < TY; ++l)
+                    if (l < nl) {                  // uniform; written once, not read again by this kernel
+                        if (full) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[l]), ry, (int)lane_b, (int)(yo + l * line_b), STORE_AUX);
+                        else if (half) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, o[l].x), ry, (int)lane_b, (int)(yo + l * line_b), STORE_AUX);
+                    }
+                if (APPEND) {
+#pragma unroll
+                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)lane_b, (int)(yo + plane_b32 + l * line_b), 0));
+                }
+                H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
+                H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * line_b), 0));
+#pragma unroll
+                for (int l = 0; l < TY; ++l) {
+                    P[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + plane_b32 + (l + 1) * line_b), 0));
+                    E[l] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, edge_b + 8, (int)(xo + (l + 1) * line_b - 8u), 0));
+                }
+                xo += plane_b32; yo += plane_b32; ++z;
+            };
+            for (int g = run >> 2; g > 0; --g) {
+                fast_step(Cs[0], Cs[1], Cs[2], Hs[0], Es[0]);
+                fast_step(Cs[1], Cs[2], Cs[3], Hs[1], Es[1]);
+                fast_step(Cs[2], Cs[3], Cs[0], Hs[0], Es[0]);
+                fast_step(Cs[3], Cs[0], Cs[1], Hs[1], Es[1]);
+            }
+            if (run == 64) continue;                                      // look again: the run may go on
+        }
+        if (z >= zend) break;
+        // ---- a slow step: a line needs another class decoded, the last planes (clamped requests), the ragged last plane, what
+        // a run leaves over after its groups of four; names rotated by copies ----
+#pragma unroll
+        for (int l = 0; l < TY; ++l) {
+            const long long li = (long long)z * ny + (y0 + l);
+            if (l < nl && li < lines) {                                   // uniform
+                GRID_XS(Cs[0], Cs[1], Cs[2], Hs[0], Es[0], l)
+                double s0 = 0.0, s1 = 0.0;
+                const int cls = __builtin_amdgcn_readfirstlane(line_class[li]);
+                if (cls == hot) { GRID_HOT_SUMS(s0, s1) }
+                else {
+                    if (cls != other) { bitsO = decode(cls); other = cls; }
+                    GRID_OTHER_SUMS(s0, s1)
+                }
+                d2 o; o.x = alpha * s0; o.y = alpha * s1;
+                if (APPEND) { o.x = Yo[l].x + o.x; o.y = Yo[l].y + o.y; }
+                double *yr = y + li * nx + row0 + 2 * t;
+                if (full || half) __builtin_nontemporal_store(o.x, yr);
+                if (full) __builtin_nontemporal_store(o.y, yr + 1);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < TY; ++l) {
+            Cs[0][l] = Cs[1][l]; Cs[1][l] = Cs[2][l]; Cs[2][l] = Cs[3][l]; Cs[3][l] = ld(z + 3, l + 1);
+            Es[0][l] = Es[1][l]; Es[1][l] = edge(z + 2, l + 1);
+            if (APPEND) Yo[l] = yold(z + 1, l);
+        }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
+        ++z;
+    }
+#undef GRID_XS
+#undef GRID_HOT_SUMS
+#undef GRID_OTHER_SUMS
+}
+
+template <typename T> struct dev_buf {       // device scratch of the plan, freed on every exit path
+    T *p = nullptr;
+    ~dev_buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)); }
+    T *release() { T *r = p; p = nullptr; return r; }
+};
+
+} // namespace
+} // namespace vexhip
+
+using namespace vexhip;
+
+extern "C" {
+
+int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const void *codes, const int32_t *blocks,
+        int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes, int64_t x_last, vexhip_grid *out)
+{
+    VEXHIP_REQUIRE(out, "NULL output");
+    std::memset(out, 0, sizeof(*out));
+    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
+    if (std::getenv("VEXHIP_NO_GRID")) return 0;
+    if (value_bytes != 8 || !deltas || !codes || ndeltas < 4 || ndeltas > 7) return 0;
+    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < 32768 && !force)) return 0;
+    if (x_last < 0 || x_last + 1 < rows || x_last >= (1ll << 31)) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    std::vector<int> table((size_t)ndeltas);
+    VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * (size_t)ndeltas, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    // the diagonals: a subset of {0, +-1, +-nx, +-P} that names 1 < nx < P, P a multiple of nx
+    std::vector<long long> mags;
+    for (int d : table) { const long long a = std::llabs((long long)d); if (a && std::find(mags.begin(), mags.end(), a) == mags.end()) mags.push_back(a); }
+    std::sort(mags.begin(), mags.end());
+    if (mags.size() != 3 || mags[0] != 1) return 0;
+    const long long nx = mags[1], far = mags[2];
+    if (nx < 8 || far % nx != 0 || far / nx < 2 || rows % nx != 0 || far > (1ll << 30)) return 0;
+    const long long ny = far / nx, lines = rows / nx, nz = (lines + ny - 1) / ny;
+    if (nz < 4 && !force) return 0;
+
+    codes_dev cd;
+    cd.buf = static_cast<const char *>(codes); cd.blocks = blocks; cd.w = (int)ell_width; cd.ndeltas = ndeltas;
+    std::memset(cd.pos, 0, sizeof(cd.pos));
+    for (int c = 0; c < ndeltas; ++c) {
+        const long long d = table[(size_t)c];
+        cd.pos[c] = (signed char)(d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -nx ? 1 : d == nx ? 5 : d == -far ? 0 : 6);
+    }
+    // pass 1: a hash per line, rows checked (codes in the table, positions ascending)
+    dev_buf<unsigned long long> d_hash; dev_buf<int> d_bad;
+    VEXHIP_TRY(d_hash.alloc((size_t)lines)); VEXHIP_TRY(d_bad.alloc(1));
+    VEXHIP_TRY(hipMemsetAsync(d_bad.p, 0, sizeof(int), s));
+    const unsigned wgs = (unsigned)((lines + 3) / 4);
+    grid_line_hash_kernel<<<wgs, 256, 0, s>>>(cd, lines, (int)nx, d_hash.p, d_bad.p);
+    VEXHIP_LAUNCH_CHECK();
+    std::vector<unsigned long long> hash((size_t)lines);
+    int bad = 0;
+    VEXHIP_TRY(hipMemcpyAsync(hash.data(), d_hash.p, sizeof(unsigned long long) * (size_t)lines, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    if (bad) return 0;
+    // classes: lines with equal hashes (a handful; the verify pass below compares the rows themselves)
+    constexpr size_t max_classes = 128;
+    std::vector<unsigned long long> seen; std::vector<long long> rep, uses;
+    std::vector<int> cls((size_t)lines);
+    size_t lastc = 0;
+    for (long long l = 0; l < lines; ++l) {
+        const unsigned long long h = hash[(size_t)l];
+        size_t c = seen.size();
+        if (!seen.empty() && seen[lastc] == h) c = lastc;
+        else for (size_t k = 0; k < seen.size(); ++k) if (seen[k] == h) { c = k; break; }
+        if (c == seen.size()) {
+            if (seen.size() == max_classes) return 0;
+            seen.push_back(h); rep.push_back(l); uses.push_back(0);
+        }
+        cls[(size_t)l] = (int)c; ++uses[c]; lastc = c;
+    }
+    const int nclasses = (int)seen.size();
+    const int hot = (int)(std::max_element(uses.begin(), uses.end()) - uses.begin());
+    if ((lines - uses[(size_t)hot]) * 4 > lines && !force) return 0;         // each change of the other class is a decode, a step with another class reads its values from LDS
+
+    // geometry: segments of <= 512 rows (even), lanes for one segment, planes per workgroup
+    const long long segs = (nx + 511) / 512;
+    long long seg_len = (nx + segs - 1) / segs; seg_len += seg_len & 1;
+    const int threads = (int)std::min<long long>(256, ((seg_len + 1) / 2 + 63) / 64 * 64);
+    const long long pitch = (segs * 512 + 2 + 15) / 16 * 16;
+    const long long tiles = (ny + 1) / 2 * segs;
+    const long long cus = std::max(1, info(dev).cus);
+    // few, long workgroups (plane.hip): about four waves per CU in all, at least 8 planes each
+    long long chunks = std::max(1ll, std::min(nz / 8, (4 * cus + tiles * (threads / 64) / 2) / (tiles * (threads / 64))));
+    long long depth = (nz + chunks - 1) / chunks;
+    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
+    depth = std::min(depth, nz);
+    const long long plane_bytes = ny * nx * 8;
+    while ((depth + 4) * plane_bytes >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;
+    if ((depth + 4) * plane_bytes >= (1ll << 32)) return 0;
+
+    // the table of every class from its representative line, then every line against it
+    dev_buf<long long> d_rep; dev_buf<int> d_cls; dev_buf<unsigned char> d_table;
+    VEXHIP_TRY(d_rep.alloc((size_t)nclasses)); VEXHIP_TRY(d_cls.alloc((size_t)lines)); VEXHIP_TRY(d_table.alloc((size_t)nclasses * 7 * (size_t)pitch));
+    VEXHIP_TRY(hipMemcpyAsync(d_rep.p, rep.data(), sizeof(long long) * (size_t)nclasses, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipMemcpyAsync(d_cls.p, cls.data(), sizeof(int) * (size_t)lines, hipMemcpyHostToDevice, s));
+    grid_line_table_kernel<<<dim3((unsigned)((pitch + 255) / 256), (unsigned)nclasses), 256, 0, s>>>(cd, d_rep.p, (int)nx, (int)pitch, d_table.p);
+    VEXHIP_LAUNCH_CHECK();
+    grid_line_verify_kernel<<<wgs, 256, 0, s>>>(cd, lines, (int)nx, (int)pitch, d_cls.p, d_table.p, d_bad.p);
+    VEXHIP_LAUNCH_CHECK();
+    VEXHIP_TRY(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    if (bad) return 0;                            // two different lines with one hash: not this product's matrix
+
+    out->nx = (int32_t)nx; out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth;
+    out->segments = (int32_t)segs; out->segment_rows = (int32_t)seg_len; out->threads = threads;
+    out->hot_class = hot; out->classes = nclasses; out->pitch = (int32_t)pitch;
+    out->store_policy = 1;
+    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
+    out->x_last = x_last;
+    out->line_class = d_cls.release(); out->table = d_table.release();
+    out->usable = 1;
+    return 0;
+}
+
+int vexhip_sell8_grid_release(int dev, vexhip_grid *g)
+{
+    if (!g) return 0;
+    if (g->line_class || g->table) {
+        VEXHIP_SET_DEVICE(dev);
+        if (g->line_class) (void)hipFree(const_cast<int32_t *>(g->line_class));
+        if (g->table) (void)hipFree(const_cast<void *>(g->table));
+    }
+    std::memset(g, 0, sizeof(*g));
+    return 0;
+}
+
+int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, int append, const double *values,
+        const double *x, double *y, const vexhip_grid *g)
+{
+    VEXHIP_REQUIRE(g && g->usable && g->line_class && g->table && values && x && y, "bad grid product arguments");
+    VEXHIP_REQUIRE(g->nx >= 8 && n > 0 && n % g->nx == 0 && g->lines_per_plane >= 2 && g->depth >= 1 && g->planes >= 1 && g->segments >= 1
+                   && g->segment_rows >= 2 && g->segment_rows <= 512 && g->segment_rows % 2 == 0 && (long long)g->segments * g->segment_rows >= g->nx
+                   && g->threads >= 64 && g->threads <= 256 && g->threads % 64 == 0 && 2 * g->threads >= g->segment_rows
+                   && g->pitch >= g->segments * 512 + 2 && g->x_last + 1 >= n
+                   && ((long long)g->depth + 4) * g->lines_per_plane * g->nx * 8 < (1ll << 32), "bad grid plan");
+    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "grid product: x and y must be 8-byte aligned");
+    VEXHIP_SET_DEVICE(dev);
+    grid_dev gd;
+    gd.lines = n / g->nx; gd.x_last = g->x_last; gd.n = n;
+    gd.nx = g->nx; gd.ny = g->lines_per_plane; gd.nz = g->planes; gd.depth = g->depth;
+    gd.segs = g->segments; gd.seg_len = g->segment_rows;
+    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch;
+    const long long chunks = (gd.nz + gd.depth - 1) / gd.depth;
+    const long long grid = 8ll * gd.tpx * chunks;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    const unsigned char *tb = static_cast<const unsigned char *>(g->table);
+    hipStream_t s = as_stream(stream);
+#define GRID_LAUNCH(AP, AUX) sell8_grid_kernel<AP, AUX><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd)
+#define GRID_AUX(AP) switch (g->store_policy) { case 1: GRID_LAUNCH(AP, 18); break; case 2: GRID_LAUNCH(AP, 17); break; case 3: GRID_LAUNCH(AP, 0); break; default: GRID_LAUNCH(AP, 2); }
+    if (append) { GRID_AUX(true) } else { GRID_AUX(false) }
+#undef GRID_AUX
+#undef GRID_LAUNCH
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+} // extern "C"

@@ -58,6 +58,7 @@ struct spmat {
     vexhip_traversal trav = {0, 0, 0, 0, nullptr};
     vexhip_march march = {0, 0, 0, 0, 0, 0, {0, 0, 0}};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
     vexhip_plane plane = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // plane product (plane.hip): 7-point pattern on 512-point lines; preferred to the march product
+    vexhip_grid grid = {};                                         // grid product (grid.hip): 7-point pattern on lines of any length, where the plane product does not apply
 };
 
 template <typename T> int dmalloc(T **p, size_t count) {
@@ -74,6 +75,7 @@ void release(spmat *A) {
     if (A->pool) (void)hipFree(A->pool);
     if (A->deltas) (void)hipFree(A->deltas);
     if (A->values) (void)hipFree(A->values);
+    (void)vexhip_sell8_grid_release(A->dev, &A->grid);
     if (A->owns_csr) {
         if (A->csr_ptr) (void)hipFree(A->csr_ptr);
         if (A->csr_ptr64) (void)hipFree(A->csr_ptr64);       // (both only when owned: a borrowed CSR matrix keeps the caller's arrays)
@@ -288,6 +290,12 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
             if (int rc = S::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
             if (int rc = make_dictionary(A, stream, flags, A->sell_bytes / ((n + 511) / 512), true)) return rc;
+            // a 7-point pattern on grid lines of another length than 512: the matrix by grid line (grid.hip), from the slices'
+            // codes wherever they are now (the pool of a dictionary, or the per-slice buffer)
+            if (std::is_same<V, double>::value && !A->plane.usable && !tail
+                && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE)))
+                if (int rc = vexhip_sell8_grid_plan(dev, stream, A->deltas, nd, A->blocks ? A->pool : A->sell, A->blocks, w, n, tail, 8,
+                                                    vexhip_sell8_last_fill_max_col(), &A->grid)) return rc;
         } else {
             if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
             A->format = VEXHIP_SPMAT_SELL8;
@@ -342,6 +350,9 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
                 if (A->blocks && A->plane.usable && g_sell8_variant == 0 && !A->tail)
                     return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas,
                                                             (const double *)A->values, x, y, &A->plane);
+            if constexpr (std::is_same<V, double>::value)
+                if (A->grid.usable && g_sell8_variant == 0 && !A->tail)
+                    return vexhip_spmv_sell8v_grid_f64(A->dev, stream, A->n, alpha, append, (const double *)A->values, x, y, &A->grid);
             if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
             return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL8:
@@ -426,6 +437,7 @@ int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
     o->slice_blocks = A->blocks; o->code_pool = A->pool; o->dictionary_blocks = A->dict_blocks;
     o->march = A->march;
     o->plane = A->plane;
+    o->grid = A->grid;
     // bytes one product moves through HBM at least: the stored matrix + x once + y once (+ y read for "+=" not counted)
     const int64_t vb = A->value_type == VEXHIP_F64 ? 8 : 4;
     int64_t m = A->sell_bytes;
@@ -435,6 +447,8 @@ int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
     }
     if (A->format == VEXHIP_SPMAT_CSR) m = A->nnz * (4 + vb) + (A->n + 1) * (A->csr_ptr64 ? 8 : 4);
     else if (A->tail) m += A->tail * (4 + vb) + (A->n + 1) * 4;
+    if (A->grid.usable)                     // the grid product reads the matrix by grid line: a class per line + the class tables
+        m = (A->n / A->grid.nx) * 4 + (int64_t)A->grid.classes * 7 * A->grid.pitch;
     o->matrix_bytes = m;
     return 0;
 }

@@ -360,7 +360,8 @@ class SpMat:
         (VEXHIP_SPMAT_NO_DICTIONARY: A/B and tests); march=False keeps the pair product where the march product (x window
         of the near diagonals in an LDS ring carried along a run of slices) or the plane product would apply
         (VEXHIP_SPMAT_NO_MARCH); plane=False keeps the march product where the plane product (round 4: two grid lines per
-        workgroup walked through the planes, neighbours in registers) would apply (VEXHIP_SPMAT_NO_PLANE)."""
+        workgroup walked through the planes, neighbours in registers) or the grid product (the same walk for lines of any
+        length) would apply (VEXHIP_SPMAT_NO_PLANE)."""
         self.ptr, self.col, self.val = ptr, col, val
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
@@ -374,6 +375,7 @@ class SpMat:
         self.dictionary_blocks = 0
         self.march = None
         self.plane = None
+        self.grid = None
         self.dtype = val.dtype
         if fmt == "hell":                        # the reference's column-major hybrid ELL (kept for A/B and sparse::ell)
             self.hell = HybridELL(ptr, col, val)
@@ -404,6 +406,11 @@ class SpMat:
         self.plane = ({"lines_per_plane": int(info.plane.lines_per_plane), "planes": int(info.plane.planes), "depth": int(info.plane.depth),
                        "hot_block": int(info.plane.hot_block), "tile": int(info.plane.tile), "store_policy": int(info.plane.store_policy), "x_last": int(info.plane.x_last)}
                       if info.plane.usable else None)              # not None: apply() runs the plane product (fp64)
+        g = info.grid
+        self.grid = ({"nx": int(g.nx), "lines_per_plane": int(g.lines_per_plane), "planes": int(g.planes), "depth": int(g.depth),
+                      "segments": int(g.segments), "segment_rows": int(g.segment_rows), "threads": int(g.threads), "hot_class": int(g.hot_class),
+                      "classes": int(g.classes), "store_policy": int(g.store_policy), "x_last": int(g.x_last)}
+                     if g.usable else None)                        # not None: apply() runs the grid product (fp64; grids of any line length)
         self.fmt = "csr" if self.storage == "csr" else "sell"      # SELL without an ELL part degrades to CSR
         if self.fmt == "sell":
             self.hell = _SellInfo(info)
