@@ -291,7 +291,25 @@ def secondary_rows(torch, L, ops, dev, local_rank):
         best = t if best is None else min(best, t)
     rows["sort u32 keys n=1e9 (stable LSD radix)"] = {"ms": round(best, 3), "gkeys_per_s": round(n / best / 1e6, 1),
                                                       "lower_bound_frac_of_8TBps": round(8.0 * n / best / 1e6 / HBM_PEAK_GBPS, 4)}
-    del k, ktmp, tmp
+    del ktmp, tmp
+    torch.cuda.empty_cache()
+    # yardstick, not the product: the library's sort (torch.sort = rocPRIM's radix sort) on the same keys, same box.  Its
+    # allocations (values + indices) are part of the call, so the time is an upper bound of rocPRIM's own kernel time.
+    try:
+        best = None
+        for _ in range(2):
+            ops.fill_hash(k, 42); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sk = torch.sort(k.view(torch.int32))
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1)
+            best = t if best is None else min(best, t)
+            del sk
+        rows["sort yardstick: torch.sort (rocPRIM) on the same 1e9 keys, int32, values + indices"] = {"ms": round(best, 3), "gkeys_per_s": round(n / best / 1e6, 1)}
+    except Exception as e:  # noqa: BLE001 -- a comparison, not the measurement
+        rows["sort yardstick: torch.sort"] = {"error": repr(e)[:200]}
+    del k
     torch.cuda.empty_cache()
     return rows
 

@@ -598,7 +598,11 @@ int vexhip_scan(int dev, void *stream, int dtype, int exclusive, const void *ini
  * ping-pong buffers; tmp holds vexhip_sort_tmp_bytes().  value_bytes in {0,4,8}. */
 size_t vexhip_sort_tmp_bytes(int key_dtype, int64_t n);
 /* How the scatter ranks the keys of a wave: -1 (default) = atomic ranks if the device passes the lane-order self-test of
- * LDS atomics (run once per device), else match words; 0 = match words; 1 = atomic ranks (A/B, tests).                 */
+ * LDS atomics (run once per device), else match words; 0 = match words (ordered by construction: no assumption about the
+ * order in which the LDS serves the lanes of one atomic); 1 = atomic ranks (A/B, tests).  With atomic ranks every sort
+ * ranks one complete tile in 16 BOTH ways inside the production launch (all twelve keys of every lane) and traps on the
+ * first difference (the error surfaces at the next synchronisation): a pass is never silently unstable on those tiles,
+ * and a part that served lanes in another order would be caught by the first sort of more than 16 tiles.            */
 int vexhip_sort_set_rank(int mode);
 int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
         void *keys, void *keys_tmp, int value_bytes, void *vals, void *vals_tmp,

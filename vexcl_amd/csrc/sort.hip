@@ -128,7 +128,11 @@ struct scatter_lds {
 };
 
 // FULL: every slot of the tile holds a key (all tiles but the last): no validity masks.
-template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOMIC_RANK>
+// VERIFY (with ATOMIC_RANK): the tile is ranked by the LDS atomics AND by the match words, which do not depend on the order in
+// which the LDS serves the lanes of one atomic; every key's two ranks must agree (trap otherwise).  One tile in SORT_VERIFY_EVERY
+// goes through this variant (sort_passes), in the production launch geometry: every sort checks the lane-order property on
+// ~6 % of its keys, all twelve keys of every lane of those tiles.
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOMIC_RANK, bool VERIFY = false>
 __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const unsigned tile,
         const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const typename valtype<VB>::type *__restrict__ vals_in, typename valtype<VB>::type *__restrict__ vals_out,
@@ -147,7 +151,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
 
     for (int i = t; i < RW * RADIX; i += RB) {
         (&L.hist[0][0])[i] = 0;
-        if constexpr (!ATOMIC_RANK) s_match[i] = 0ull;            // the match words are only used by the fallback ranking
+        if constexpr (!ATOMIC_RANK || VERIFY) s_match[i] = 0ull;  // the match words are only used by the fallback ranking (and the verified tiles)
     }
 
     K key[KPT];
@@ -184,6 +188,20 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
             // program order (k ascending = tile order).  The match-word scheme below needs five conflicting LDS operations
             // per key and left the kernel LDS-bound (500 of 838 LDS-active cycles per wave were bank conflicts).
             unsigned r;
+            unsigned expect = 0;                                     // VERIFY: the rank the match words give
+            if constexpr (VERIFY) {
+                if (!uniform) {
+                    unsigned long long *word = s_match + wave * RADIX + d;
+                    const unsigned prev = L.hist[wave][d];           // the counter before this key's atomic (a wave's LDS operations run in program order)
+                    if (valid) atomicOr(word, 1ull << lane);
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned long long m = valid ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0ull;
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid && (m & lt_mask) == 0) __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __builtin_amdgcn_wave_barrier();
+                    expect = prev + (unsigned)__popcll(m & lt_mask);
+                }
+            }
             if (uniform) {                                           // one counter bump instead of 64 same-address atomics
                 const unsigned prev = L.hist[wave][d0];
                 __builtin_amdgcn_wave_barrier();
@@ -192,6 +210,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
                 __builtin_amdgcn_wave_barrier();
             } else {
                 r = valid ? atomicAdd(&L.hist[wave][d], 1u) : 0u;
+                if constexpr (VERIFY) if (valid && r != expect) __builtin_trap();      // a lane was served out of lane order
             }
             rd[k] = valid ? (r | (d << 16)) : ~0u;
             // Tripwire (round 3): two NEIGHBOURING lanes with the same digit must have received consecutive ranks.  Lane order
@@ -302,7 +321,9 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
 // 8 waves per SIMD = two 1024-lane workgroups per CU (<= 64 VGPRs)
 // FULL = true: launched over the complete tiles (first_tile = their number); FULL = false: one
 // workgroup for the ragged last tile (first_tile = its index).
-template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOMIC_RANK>
+constexpr unsigned SORT_VERIFY_EVERY = 16;       // one complete tile in 16 is ranked twice (scatter_tile VERIFY)
+
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOMIC_RANK, bool VERIFY = false>
 __global__ __launch_bounds__(RB, 8)
 void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
@@ -320,10 +341,16 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
         // the array front to back together -- run 4 / 16 / 32 / 64 / 256: 10.71 / 10.21 / 10.15 / 10.10 / 10.05 ms against
         // 10.00 ms for the contiguous eighths on the same box (1e9 u32 keys).
         const unsigned per = (first_tile + 7) / 8;          // FULL launches pass the number of complete tiles here
-        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-        if (tile >= first_tile) return;
+        if constexpr (VERIFY) {
+            tile = blockIdx.x * SORT_VERIFY_EVERY + (SORT_VERIFY_EVERY - 1);       // compact launch: first_tile / 16 workgroups
+        } else {
+            tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+            if (tile >= first_tile) return;
+            // atomic ranks: every SORT_VERIFY_EVERY-th tile is left to the launch with VERIFY
+            if constexpr (ATOMIC_RANK) if (tile % SORT_VERIFY_EVERY == SORT_VERIFY_EVERY - 1) return;
+        }
     }
-    scatter_tile<K, MODE, DESC, VB, KPT, FULL, ATOMIC_RANK>(L, tile, keys_in, keys_out,
+    scatter_tile<K, MODE, DESC, VB, KPT, FULL, ATOMIC_RANK, VERIFY>(L, tile, keys_in, keys_out,
             reinterpret_cast<const VT *>(vals_in_), reinterpret_cast<VT *>(vals_out_), n, shift, nblocks, table);
 }
 
@@ -348,8 +375,11 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
         if (int rc = scan_exclusive_u32_tmp(s, table, table, tn, scan_tmp)) return rc;
         const unsigned nfull = (unsigned)(n / TILE);
         if (nfull) {
-            if (atomic_rank) radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
-            else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            if (atomic_rank) {
+                radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+                if (nfull >= SORT_VERIFY_EVERY)
+                    radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, true><<<nfull / SORT_VERIFY_EVERY, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            } else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
             VEXHIP_LAUNCH_CHECK();
         }
         if (nfull < nblocks) {
