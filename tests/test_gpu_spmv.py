@@ -676,6 +676,41 @@ def test_row_pointers_64bit(T, oracle, built_lib):
     assert torch.equal(yf, yg)
 
 
+def test_csr_row_pointers_beyond_2_31_on_a_small_matrix(T, oracle, built_lib):
+    """The staged CSR kernel with 64-bit row bounds (round 4: re-enabled).  Round 3 saw it fault on a small matrix whose row
+    pointer VALUES cross 2^31 and take 120 s at 700^3; the cause was the fold of lanes WITHOUT a row in the ragged last
+    workgroup ((int)(0 - tile_start) wraps to a large positive trip count once tile_start >= 2^31).  Here: 1000 and 1500 rows
+    (not multiples of 256), pointers offset so that they run from below 2^31 to above it / start above 2^32 -- the column and
+    value arrays are passed as base addresses that many entries BELOW the real arrays (the kernel only ever touches entries
+    [ptr[0] & ~3, ptr[n])) -- bit for bit against the CSR restatement, '=' and '+= alpha', and the plain loop (variant 8)."""
+    import ctypes
+    from vexcl_amd import lib, _capi
+    torch = T.torch
+    L = lib()
+    dev_index = T.dev.index or 0
+    stream = ctypes.c_void_p(torch.cuda.current_stream(T.dev).cuda_stream)
+    for n, m, off in ((1000, 3000, (1 << 31) - 2000), (1500, 1500, (1 << 32) + 4096), (777, 9000, (1 << 31) - 4)):
+        ptr, col, val = oracle.random_matrix(200 + n, n, m, 12)
+        x = oracle.random_f64(5, m); y0 = oracle.random_f64(6, n)
+        want = oracle.spmv_csr(ptr, col, val, x)
+        dptr = T.up(ptr.astype(np.int64) + off); dcol = T.up(col); dval = T.up(val); dx = T.up(x)
+        assert dcol.data_ptr() % 16 == 0 and dval.data_ptr() % 16 == 0 and off % 4 == 0
+        h = ctypes.c_void_p()
+        L.spmat_create_f64_p64(dev_index, stream, n, ctypes.c_void_p(dptr.data_ptr()), ctypes.c_void_p(dcol.data_ptr() - 4 * off),
+                               ctypes.c_void_p(dval.data_ptr() - 8 * off), _capi.SPMAT_CSR, _capi.SPMAT_BORROW_CSR, ctypes.byref(h))
+        try:
+            for variant in (-1, 8):
+                L.spmv_csr_set_variant(variant)
+                for alpha, append in ((1.0, False), (-0.75, True)):
+                    y = T.up(y0.copy())
+                    L.spmat_apply_f64(h, stream, alpha, int(append), ctypes.c_void_p(dx.data_ptr()), ctypes.c_void_p(y.data_ptr()))
+                    torch.cuda.synchronize()
+                    assert np.array_equal(y.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (n, off, variant, alpha)
+        finally:
+            L.spmv_csr_set_variant(-1)
+            L.spmat_destroy(h)
+
+
 def test_more_than_2_31_nonzeros(T, built_lib):
     """700^3 Poisson: 343 000 000 rows, 2 383 410 352 entries -- more than 2^31 on one device (the reference's default index
     type is size_t, vexcl/spmat.hpp:56-57).  Built in HBM with 64-bit row pointers, stored with diagonal and value codes,

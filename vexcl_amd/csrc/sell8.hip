@@ -1684,6 +1684,42 @@ int sell8_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const
         const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *trav)
 { return sell8_fill<float, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, buf, trav); }
 
+template <typename P>
+int csr_traversal_impl(int dev, void *stream, int64_t n, const P *ptr, const int32_t *col,
+        int rows_per_block, vexhip_traversal *traversal)
+{
+    VEXHIP_REQUIRE(traversal && rows_per_block > 0, "bad argument");
+    std::memset(traversal, 0, sizeof(*traversal));
+    if (n <= 0) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    int *deltas = nullptr;
+    VEXHIP_TRY(hipMalloc(&deltas, sizeof(int) * 256 + sizeof(unsigned long long) * 256));
+    unsigned long long *dcounts = reinterpret_cast<unsigned long long *>(deltas + 256);
+    int nd = -1;
+    const int w = 64;                                    // the first 64 entries of every row decide
+    int rc = sell8_analyze<P>(dev, stream, n, ptr, col, w, deltas, &nd);
+    if (rc == 0 && nd > 0) {
+        std::vector<unsigned long long> counts(256);
+        std::vector<int> table(nd);
+        hipError_t e = hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256, s);
+        if (e == hipSuccess) {
+            csr_delta_count_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, w, nd, ptr, col, deltas, dcounts);
+            e = hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(table.data(), deltas, sizeof(int) * nd, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { (void)hipFree(deltas); return check(e, __FILE__, __LINE__); }
+        strip_traversal(n, table, counts, traversal, rows_per_block);
+    }
+    VEXHIP_TRY(hipFree(deltas));
+    return rc;
+}
+
+// 64-bit row pointers: the strips of a CSR matrix kept in CSR with 2^31 entries or more (spmat.hip)
+int csr_traversal_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int rows_per_block, vexhip_traversal *traversal)
+{ return csr_traversal_impl<long long>(dev, stream, n, ptr, col, rows_per_block, traversal); }
+
 } // namespace vexhip
 
 using namespace vexhip;
@@ -1809,34 +1845,7 @@ int vexhip_spmv_sell8v_march_f32_i32(int dev, void *stream, int64_t n, float alp
 { return spmv_sell8v<float>(dev, stream, n, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks, (march && march->usable) ? march : nullptr); }
 int vexhip_csr_traversal_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
         int rows_per_block, vexhip_traversal *traversal)
-{
-    VEXHIP_REQUIRE(traversal && rows_per_block > 0, "bad argument");
-    std::memset(traversal, 0, sizeof(*traversal));
-    if (n <= 0) return 0;
-    VEXHIP_SET_DEVICE(dev);
-    hipStream_t s = as_stream(stream);
-    int *deltas = nullptr;
-    VEXHIP_TRY(hipMalloc(&deltas, sizeof(int) * 256 + sizeof(unsigned long long) * 256));
-    unsigned long long *dcounts = reinterpret_cast<unsigned long long *>(deltas + 256);
-    int nd = -1;
-    const int w = 64;                                    // the first 64 entries of every row decide
-    int rc = vexhip_sell8_analyze_i32(dev, stream, n, ptr, col, w, deltas, &nd);
-    if (rc == 0 && nd > 0) {
-        std::vector<unsigned long long> counts(256);
-        std::vector<int> table(nd);
-        hipError_t e = hipMemsetAsync(dcounts, 0, sizeof(unsigned long long) * 256, s);
-        if (e == hipSuccess) {
-            csr_delta_count_kernel<int32_t><<<grid_for(dev, n), 256, 0, s>>>(n, w, nd, ptr, col, deltas, dcounts);
-            e = hipMemcpyAsync(counts.data(), dcounts, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, s);
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(table.data(), deltas, sizeof(int) * nd, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { (void)hipFree(deltas); return check(e, __FILE__, __LINE__); }
-        strip_traversal(n, table, counts, traversal, rows_per_block);
-    }
-    VEXHIP_TRY(hipFree(deltas));
-    return rc;
-}
+{ return csr_traversal_impl<int32_t>(dev, stream, n, ptr, col, rows_per_block, traversal); }
 
 int vexhip_sell8_fill_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *traversal)

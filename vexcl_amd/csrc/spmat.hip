@@ -36,8 +36,9 @@ int sell8_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const
 int sell8_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, const int32_t *deltas, int ndeltas, void *buf, vexhip_traversal *trav);
 int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const double *val, int64_t w, void *sell);
 int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, void *sell);
-int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y);
-int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y);
+int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y, const vexhip_traversal *tr);
+int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y, const vexhip_traversal *tr);
+int csr_traversal_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int rows_per_block, vexhip_traversal *traversal);
 
 namespace {
 
@@ -253,8 +254,10 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
             }
         }
         if constexpr (p64) A->csr_ptr64 = own_ptr; else A->csr_ptr = own_ptr;
-        if constexpr (!p64)
-            if (A->nnz) (void)vexhip_csr_traversal_i32(dev, stream, n, A->csr_ptr, A->csr_col, 256, &A->trav);   // strips for banded matrices
+        if (A->nnz) {                             // strips for banded matrices
+            if constexpr (p64) (void)csr_traversal_p64(dev, stream, n, A->csr_ptr64, A->csr_col, 256, &A->trav);
+            else (void)vexhip_csr_traversal_i32(dev, stream, n, A->csr_ptr, A->csr_col, 256, &A->trav);
+        }
         VEXHIP_TRY(hipStreamSynchronize(s));
         return 0;
     }
@@ -360,7 +363,7 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
             return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL:   return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         default:
-            if (A->csr_ptr64) return spmv_csr_p64(A->dev, stream, A->n, alpha, append, A->csr_ptr64, A->csr_col, (const V *)A->csr_val, x, y);
+            if (A->csr_ptr64) return spmv_csr_p64(A->dev, stream, A->n, alpha, append, A->csr_ptr64, A->csr_col, (const V *)A->csr_val, x, y, &A->trav);
             return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
     }
 }

@@ -131,8 +131,9 @@ void csr_stream_kernel(long long n, long long nblocks, V alpha, int append,
             }
         }
         __syncthreads();
-        const int lo = (int)((my_lo > tb ? my_lo : tb) - tb);
-        const int hi = (int)((my_hi < te ? my_hi : te) - tb);
+        const long long lo64 = (my_lo > tb ? my_lo : tb) - tb, hi64 = (my_hi < te ? my_hi : te) - tb;       // in 64 bits: see csr_stream2_kernel
+        const int lo = (int)(lo64 < CSR_TILE ? lo64 : CSR_TILE);
+        const int hi = (int)(hi64 < 0 ? 0 : hi64);
         for (int j = lo; j < hi; ++j) sum += s_prod[j];
         if (te < end) __syncthreads();
     }
@@ -213,9 +214,14 @@ void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
         __syncthreads();
         // every lane folds the part of its row that lies in this tile, up to 8 entries in flight
         asm volatile("" : "+v"(raw_lo), "+v"(raw_hi));
-        const long long my_lo = t < rows_here ? (long long)raw_lo : 0, my_hi = t < rows_here ? (long long)raw_hi : 0;
-        const int lo = (int)((my_lo > tb ? my_lo : tb) - tb);
-        const int hi = (int)((my_hi < te ? my_hi : te) - tb);
+        // A lane without a row (ragged last workgroup) folds nothing: its bounds are the tile's start.  (Round 3 gave such lanes
+        // the bounds 0, 0: hi = (int)(0 - tb) -- negative, no trip, while tb < 2^31; with 64-bit row pointers and tb >= 2^31 the
+        // cast wraps to a large POSITIVE count: 2^28 trips through LDS far beyond the tile and gathers of x at whatever lies
+        // there -- the 120 s / the fault that round 3 recorded as "not understood" at 700^3 and on pointers offset past 2^31.)
+        const long long my_lo = t < rows_here ? (long long)raw_lo : tb, my_hi = t < rows_here ? (long long)raw_hi : tb;
+        const long long lo64 = (my_lo > tb ? my_lo : tb) - tb, hi64 = (my_hi < te ? my_hi : te) - tb;
+        const int lo = (int)(lo64 < CSR2_TILE ? lo64 : CSR2_TILE);
+        const int hi = (int)(hi64 < 0 ? 0 : hi64);
         for (int j = lo; j < hi; j += 8) {
             I c[8]; V v[8], xv[8];
 #pragma unroll
@@ -755,25 +761,39 @@ int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const 
 int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, void *sell)
 { return sell_fill<float, long long>(dev, stream, n, ptr, col, val, w, sell); }
 
-// The CSR arrays themselves with 64-bit row pointers: the reference's one-row-per-work-item loop (spmat/csr.inl:153-171).
-// The staged kernel above, instantiated with 64-bit row bounds, gave correct results but took 120 s at 700^3 and faulted on
-// a small matrix whose pointer VALUES crossed 2^31 (tools/r03_p64_debug.py) -- not understood (its machine code keeps every
-// entry offset in 64 bits); the plain loop is what a matrix kept in CSR with 2^31 entries or more runs until it is.
+// The CSR arrays themselves with 64-bit row pointers (2^31 entries or more kept in CSR): the staged kernel with 64-bit row
+// bounds, strips as for 32-bit pointers (spmat.hip passes the traversal).  Round 3 ran the reference's one-row-per-work-item
+// loop here (spmat/csr.inl:153-171; 30 ms at 700^3) because this instantiation took 120 s and faulted: lanes without a row in
+// the ragged last workgroup -- see the fold of csr_stream2_kernel.  Arrays that are not 16-byte aligned keep the plain loop.
 template <typename V>
-int spmv_csr_p64_impl(int dev, void *stream, int64_t n, V alpha, int append, const long long *ptr, const int32_t *col, const V *val, const V *x, V *y) {
+int spmv_csr_p64_impl(int dev, void *stream, int64_t n, V alpha, int append, const long long *ptr, const int32_t *col, const V *val, const V *x, V *y,
+        const vexhip_traversal *tr) {
     VEXHIP_REQUIRE(n >= 0, "negative row count");
     if (n == 0) return 0;
     VEXHIP_REQUIRE(ptr && x && y, "NULL argument");
     VEXHIP_SET_DEVICE(dev);
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 32);
-    csr_scalar_kernel<V, int, long long><<<grid, 256, 0, as_stream(stream)>>>(n, alpha, append, ptr, col, val, x, y);
+    hipStream_t s = as_stream(stream);
+    if (!aligned16(col) || !aligned16(val) || g_csr_variant == 8) {
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 32);
+        csr_scalar_kernel<V, int, long long><<<grid, 256, 0, s>>>(n, alpha, append, ptr, col, val, x, y);
+        VEXHIP_LAUNCH_CHECK();
+        return 0;
+    }
+    const long long nb = (n + CSR_BLOCK - 1) / CSR_BLOCK;
+    long long grid = ((nb + 7) / 8) * 8;                      // no strips: XCD-contiguous row blocks
+    trav_dev order = {nullptr, 0, 0, 0};
+    const bool strips = tr && tr->grid_blocks > 0;
+    if (strips) order = make_traversal(tr, nb, &grid);
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    if (strips) csr_stream2_kernel<V, int, false, 2048, long long><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
+    else csr_stream2_kernel<V, int, true, 2048, long long><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
-int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y)
-{ return spmv_csr_p64_impl<double>(dev, stream, n, alpha, append, ptr, col, val, x, y); }
-int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y)
-{ return spmv_csr_p64_impl<float>(dev, stream, n, alpha, append, ptr, col, val, x, y); }
+int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y, const vexhip_traversal *tr)
+{ return spmv_csr_p64_impl<double>(dev, stream, n, alpha, append, ptr, col, val, x, y, tr); }
+int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y, const vexhip_traversal *tr)
+{ return spmv_csr_p64_impl<float>(dev, stream, n, alpha, append, ptr, col, val, x, y, tr); }
 
 } // namespace vexhip
 
