@@ -83,10 +83,16 @@ def _worker(rank, world, port, n, out, ipc=True):
             ok = ok and st["timed_out"] == 0
             prof = A.profile_step(x, y)
             ok = ok and prof["total"] > 0
+            # the step over the IPC windows and the step over the torch.distributed transport (the one RCCL carries on a node
+            # with one GPU per rank) must give the SAME bits: same local and remote kernels, only the ghosts travel differently
+            y_ipc = torch.full((r1 - r0,), 7.0, dtype=torch.float64, device=dev)
+            A.apply(x, y_ipc, 1.5, True)
+            torch.cuda.synchronize()
             dist.barrier()
             A.disable_native()
             y.fill_(7.0)
             A.apply(x, y, 1.5, True)
+            ok = ok and bool(torch.equal(y, y_ipc))
             ref = torch.full((N,), 7.0, dtype=torch.float64, device=dev)
             ops.SpMat(fp, fc, fv).apply(fx, ref, 1.5, True)
             ok = ok and bool(((y - ref[r0:r1]).abs() <= 1e-12 * scale).all())

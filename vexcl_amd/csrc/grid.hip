@@ -480,8 +480,13 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     const long long pitch = (segs * 512 + 2 + 15) / 16 * 16;
     const long long tiles = (ny + 1) / 2 * segs;
     const long long cus = std::max(1, info(dev).cus);
-    // few, long workgroups (plane.hip): about four waves per CU in all, at least 8 planes each
-    long long chunks = std::max(1ll, std::min(nz / 8, (4 * cus + tiles * (threads / 64) / 2) / (tiles * (threads / 64))));
+    // Few, long workgroups (plane.hip) -- but lines that are not 512 points long want about EIGHT waves per CU in all (their
+    // requests straddle cache lines, a wave hides less of the latency by itself): 384^3 walks of 48 / 96 / 128 / 192 / 384
+    // planes = 0.202 / 0.184 / 0.217 / 0.227 / 0.349 ms (2304 waves at 96), 500^3 walks of 62 / 125 / 166 / 250 / 500 = 0.433 /
+    // 0.419 / 0.415 / 0.389 / 0.520 ms (2000 waves at 250); pair product 0.312 / 0.781 ms (profiles/r04_grid_sweep.json).
+    // At least 8 planes per walk.
+    const long long wpt = tiles * (threads / 64);                // waves of one layer of tiles
+    long long chunks = std::max(1ll, std::min(nz / 8, (8 * cus + wpt / 2) / wpt));
     long long depth = (nz + chunks - 1) / chunks;
     if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
     depth = std::min(depth, nz);

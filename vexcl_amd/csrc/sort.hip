@@ -327,7 +327,7 @@ template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOM
 __global__ __launch_bounds__(RB, 8)
 void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
-        long long n, int shift, unsigned nblocks, unsigned first_tile, const unsigned *__restrict__ table)
+        long long n, int shift, unsigned nblocks, unsigned first_tile, const unsigned *__restrict__ table, unsigned verify_every)
 {
     typedef typename valtype<VB>::type VT;
     __shared__ scatter_lds<K, VB, KPT> L;
@@ -342,22 +342,25 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
         // 10.00 ms for the contiguous eighths on the same box (1e9 u32 keys).
         const unsigned per = (first_tile + 7) / 8;          // FULL launches pass the number of complete tiles here
         if constexpr (VERIFY) {
-            tile = blockIdx.x * SORT_VERIFY_EVERY + (SORT_VERIFY_EVERY - 1);       // compact launch: first_tile / 16 workgroups
+            tile = blockIdx.x * verify_every + (verify_every - 1);                 // compact launch: first_tile / 16 workgroups
         } else {
             tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
             if (tile >= first_tile) return;
             // atomic ranks: every SORT_VERIFY_EVERY-th tile is left to the launch with VERIFY
-            if constexpr (ATOMIC_RANK) if (tile % SORT_VERIFY_EVERY == SORT_VERIFY_EVERY - 1) return;
+            if constexpr (ATOMIC_RANK) if (verify_every && tile % verify_every == verify_every - 1) return;
         }
     }
     scatter_tile<K, MODE, DESC, VB, KPT, FULL, ATOMIC_RANK, VERIFY>(L, tile, keys_in, keys_out,
             reinterpret_cast<const VT *>(vals_in_), reinterpret_cast<VT *>(vals_out_), n, shift, nblocks, table);
 }
 
+extern int g_sort_rank;
+
 template <typename K, int VB> constexpr int kpt_for() { return keys_per_lane((int)sizeof(K), VB); }
 
 template <typename K, int MODE, bool DESC, int VB>
 int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp, bool atomic_rank) {
+    const unsigned every = g_sort_rank != 2 ? SORT_VERIFY_EVERY : 0u;        // 2: A/B without the verified tiles
     constexpr int KPT = kpt_for<K, VB>();
     constexpr int TILE = RB * KPT;
     const unsigned nblocks = (unsigned)((n + TILE - 1) / TILE);
@@ -376,15 +379,16 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
         const unsigned nfull = (unsigned)(n / TILE);
         if (nfull) {
             if (atomic_rank) {
-                radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
-                if (nfull >= SORT_VERIFY_EVERY)
-                    radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, true><<<nfull / SORT_VERIFY_EVERY, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
-            } else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+                const unsigned ev = nfull >= SORT_VERIFY_EVERY ? every : 0u;
+                radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, ev);
+                if (ev)
+                    radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, true><<<nfull / ev, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, ev);
+            } else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
             VEXHIP_LAUNCH_CHECK();
         }
         if (nfull < nblocks) {
-            if (atomic_rank) radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, true><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
-            else radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, false><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+            if (atomic_rank) radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, true><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
+            else radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, false><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
             VEXHIP_LAUNCH_CHECK();
         }
         std::swap(src, dst);
@@ -426,7 +430,7 @@ void lds_atomic_order_kernel(unsigned seed, int rounds, unsigned *violations) {
     if (bad) atomicAdd(violations, bad);
 }
 
-int g_sort_rank = -1;               // -1: decide by the self-test; 0: match words; 1: atomic ranks (A/B)
+int g_sort_rank = -1;               // -1: decide by the self-test; 0: match words; 1: atomic ranks; 2: atomic ranks without the verified tiles (A/B)
 
 int atomic_rank_ok(int dev, hipStream_t s, bool *ok) {
     static std::atomic<int> verdict[64];          // 0 unknown, 1 in order, 2 not (two threads may both run the test: same answer)
@@ -473,7 +477,7 @@ int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
     VEXHIP_REQUIRE(value_bytes == 0 || (vals && vals_tmp), "NULL value buffers");
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
-    bool ar = g_sort_rank == 1;
+    bool ar = g_sort_rank >= 1;
     if (g_sort_rank < 0) if (int rc = atomic_rank_ok(dev, s, &ar)) return rc;
     switch (key_dtype) {
         case VEXHIP_U32: return sort_dispatch<unsigned, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
