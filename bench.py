@@ -185,7 +185,7 @@ def timed_events(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def measure_traffic(grid, timeout=240):
+def measure_traffic(grid, timeout=240, only=None):
     """HBM bytes per launch of the headline kernels measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE need
     separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots) over tools/pmc_headline.py.  FETCH_SIZE is calibrated on
     a 2 GiB 16-byte-per-lane stream captured in the same pass (gfx950 reports half the bytes of such a stream)."""
@@ -197,6 +197,8 @@ def measure_traffic(grid, timeout=240):
         return None, "already running under a profiler"
     out = tempfile.mkdtemp(prefix="vexpmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", GRID=str(grid))
+    if only:
+        env["PMC_ONLY"] = only                 # tools/pmc_headline.py: just these storages (comma-separated)
     res = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -212,7 +214,7 @@ def measure_traffic(grid, timeout=240):
                         continue
                     name = r["Kernel_Name"]
                     key = None
-                    for k in ("sell8_plane_kernel", "sell8_march_kernel", "sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
+                    for k in ("sell8_grid_kernel", "sell8_plane_kernel", "sell8_march_kernel", "sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
                         if k in name:
                             key = k
                             if k == "sell8_pair_kernel":

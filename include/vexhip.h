@@ -300,7 +300,7 @@ int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double al
  * {0, +-1, +-nx, +-nx * lines_per_plane}, rows = a whole number of lines.  The plan re-expresses the matrix by grid line on the
  * device: seven bytes per row (the value code per position, 255 = no entry), lines with equal rows form a class (<= 128), every
  * line is verified against its class; it declines (usable = 0) when a row's entries do not ascend by position, when more
- * than 1/4 of the lines use another class than the most frequent one, for fp32, a CSR tail, fewer than 32768 rows or 4 planes.
+ * than 1/4 of the lines use another class than the most frequent one, for fp32, a CSR tail, fewer than 2^23 rows (x within the caches: the pair product is as fast) or 4 planes.
  * The product owns two adjacent lines (one segment of <= 512 rows of them) per workgroup and walks through `depth` planes;
  * lines need not be 16-byte aligned (odd nx), lines_per_plane may be odd.  line_class / table are device memory owned by the
  * plan: vexhip_sell8_grid_release frees them.  VEXHIP_PLANE_DEPTH / VEXHIP_PLANE_STORE override, VEXHIP_NO_GRID declines.  */

@@ -458,13 +458,13 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
                 assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (shape, alpha)
             return A
 
+        # Small grids: the plan is forced (the library keeps the pair product below 2^23 rows -- x lives in the L2s there -- and
+        # declines when more than a quarter of the lines use another class than the most frequent one)
+        os.environ["VEXHIP_PLANE_FORCE"] = "1"
         # the benchmark's operator (examples/benchmark.cpp:364-415): two line classes
         for n in (96, 125):
             ptr, col, val = oracle.poisson3d(n)
             check(ptr, col, val, (n, n, n), 31, classes=2)
-        # small grids: most lines are boundary lines, the plan is forced (it declines when more than a quarter of the lines
-        # use another class than the most frequent one)
-        os.environ["VEXHIP_PLANE_FORCE"] = "1"
         for shape, depth in (((70, 33, 20), None), ((70, 33, 20), 3), ((1030, 6, 8), None), ((1030, 6, 8), 5), ((384, 10, 12), None),
                              ((500, 7, 11), 4), ((127, 17, 19), 7), ((514, 5, 13), None)):
             ptr, col, val = _grid7(*shape)
@@ -494,7 +494,6 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
         want = oracle.spmv_csr(ptr, col, val, xb)
         assert np.isnan(want).sum() >= 8                      # the neighbours of the NaN and of the Inf under a stored zero
         assert np.array_equal(ya.cpu().numpy(), want, equal_nan=True)
-        os.environ.pop("VEXHIP_PLANE_FORCE")
         # the Poisson matrix bordered by Inf: the boundary rows are identity rows, their neighbours never look at them... but
         # interior rows next to the boundary do: as the CSR loop
         ptr, col, val = oracle.poisson3d(96)
@@ -502,8 +501,22 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
         xb = oracle.random_f64(40, 96 ** 3); xb[::97] = np.inf
         ya = torch.empty(96 ** 3, dtype=torch.float64, device=T.dev)
         A.apply(T.up(xb), ya)
-        assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb), equal_nan=True)
+        assert A.grid is not None and np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb), equal_nan=True)
+        os.environ.pop("VEXHIP_PLANE_FORCE")
+        # the plan as the library chooses it: 208^3 (9.0e6 rows: above the threshold), checked against the pair product and,
+        # on the first planes, against the CSR restatement
+        n = 208
+        ptr, col, val = oracle.poisson3d(n)
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+        assert A.grid is not None and A.grid["nx"] == n and A.grid["classes"] == 2 and B.grid is None, A.grid
+        xb = oracle.random_f64(47, n ** 3)
+        ya = torch.empty(n ** 3, dtype=torch.float64, device=T.dev); yb = torch.empty_like(ya)
+        A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
+        assert torch.equal(ya, yb)
+        assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
+        assert T.ops.SpMat(*[T.up(a) for a in oracle.poisson3d(96)]).grid is None          # small: the pair product stays
 
+        os.environ["VEXHIP_PLANE_FORCE"] = "1"           # the structural reasons to decline hold whatever the size
         # declined: fp32; an eighth diagonal; a 2-D operator (no far pair); rows reversed (storage order is not position order);
         # rows that do not fill whole lines; plane=False / dictionary=False keep the older products
         ptr, col, val = _grid7(96, 20, 21)

@@ -23,7 +23,10 @@ for _ in range(3):
     r.device_result(cal)
 del cal
 ptr, col, val = ops.poisson3d(n, dev)
+only = [f for f in os.environ.get("PMC_ONLY", "").split(",") if f]
 for fmt in ("auto", "sell32", "csr"):
+    if only and fmt not in only:
+        continue
     A = ops.SpMat(ptr, col, val, fmt=fmt)
     for _ in range(3):
         A.apply(x, y)
@@ -31,9 +34,10 @@ for fmt in ("auto", "sell32", "csr"):
     del A
 del ptr, col, val
 torch.cuda.empty_cache()
-ptr, col, val = ops.diffusion3d(n, dev)
-A = ops.SpMat(ptr, col, val)
-for _ in range(3):
-    A.apply(x, y)
-torch.cuda.synchronize()
+if not only or "diffusion" in only:
+    ptr, col, val = ops.diffusion3d(n, dev)
+    A = ops.SpMat(ptr, col, val)
+    for _ in range(3):
+        A.apply(x, y)
+    torch.cuda.synchronize()
 print("done")

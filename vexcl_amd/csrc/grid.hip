@@ -416,7 +416,9 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
     if (std::getenv("VEXHIP_NO_GRID")) return 0;
     if (value_bytes != 8 || !deltas || !codes || ndeltas < 4 || ndeltas > 7) return 0;
-    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < 32768 && !force)) return 0;
+    // small matrices (x within the L2s / the Infinity Cache: 127^3 = 0.019 ms here, 0.016 ms through the pair product; 168^3 0.029 /
+    // 0.026; 256^3 0.052 / 0.074) keep the pair product
+    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < (1 << 23) && !force)) return 0;
     if (x_last < 0 || x_last + 1 < rows || x_last >= (1ll << 31)) return 0;
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
@@ -480,13 +482,28 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     const long long pitch = (segs * 512 + 2 + 15) / 16 * 16;
     const long long tiles = (ny + 1) / 2 * segs;
     const long long cus = std::max(1, info(dev).cus);
-    // Few, long workgroups (plane.hip) -- but lines that are not 512 points long want about EIGHT waves per CU in all (their
-    // requests straddle cache lines, a wave hides less of the latency by itself): 384^3 walks of 48 / 96 / 128 / 192 / 384
-    // planes = 0.202 / 0.184 / 0.217 / 0.227 / 0.349 ms (2304 waves at 96), 500^3 walks of 62 / 125 / 166 / 250 / 500 = 0.433 /
-    // 0.419 / 0.415 / 0.389 / 0.520 ms (2000 waves at 250); pair product 0.312 / 0.781 ms (profiles/r04_grid_sweep.json).
-    // At least 8 planes per walk.
-    const long long wpt = tiles * (threads / 64);                // waves of one layer of tiles
-    long long chunks = std::max(1ll, std::min(nz / 8, (8 * cus + wpt / 2) / wpt));
+    // Planes per workgroup.  Few, long workgroups (plane.hip: every workgroup re-reads the planes around its walk) -- but
+    //   * lines that are not 512 points long want at least ~6 waves per CU (their requests straddle cache lines, a wave hides
+    //     less of the latency by itself), and
+    //   * the workgroups should fill the CUs EVENLY: all of them are resident at once, the ones that share a CU with more
+    //     neighbours fall behind, and tiles that are not at the same plane at the same time fetch their halo lines from HBM
+    //     instead of from the L2 their neighbour filled.
+    // Measured (profiles/r04_grid_sweep.json; pair product 0.312 / 0.781 ms): 384^3 (192 tiles x 3 waves) walks of 48 / 96 /
+    // 128 / 192 / 384 planes = 0.202 / 0.184 / 0.217 / 0.227 / 0.349 ms -- 96 planes = 768 workgroups = 3 per CU exactly; 500^3
+    // (250 x 4) walks of 62 / 125 / 166 / 250 / 500 = 0.433 / 0.419 / 0.415 / 0.389 / 0.520 ms.  The estimate below orders all of
+    // these as measured: (workgroups per CU, rounded up) x (planes per walk + 6 for the start of a walk), times 6 / (waves per
+    // CU) where that is below 6.
+    const long long wpw = threads / 64;
+    long long chunks = 1;
+    {
+        double best = 0;
+        for (long long c = 1; c <= std::max(1ll, nz / 8); ++c) {
+            const long long per_cu = (tiles * c + cus - 1) / cus;
+            double est = (double)per_cu * (double)((nz + c - 1) / c + 6);
+            if (per_cu * wpw < 6) est *= 6.0 / (double)(per_cu * wpw);
+            if (c == 1 || est < best) { best = est; chunks = c; }
+        }
+    }
     long long depth = (nz + chunks - 1) / chunks;
     if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
     depth = std::min(depth, nz);

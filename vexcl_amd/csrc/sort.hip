@@ -128,15 +128,16 @@ struct scatter_lds {
 };
 
 // FULL: every slot of the tile holds a key (all tiles but the last): no validity masks.
-// VERIFY (with ATOMIC_RANK): the tile is ranked by the LDS atomics AND by the match words, which do not depend on the order in
-// which the LDS serves the lanes of one atomic; every key's two ranks must agree (trap otherwise).  One tile in SORT_VERIFY_EVERY
-// goes through this variant (sort_passes), in the production launch geometry: every sort checks the lane-order property on
-// ~6 % of its keys, all twelve keys of every lane of those tiles.
+// VERIFY (with ATOMIC_RANK) and vflag (uniform per workgroup): the tile is ranked by the LDS atomics AND by the match words, which
+// do not depend on the order in which the LDS serves the lanes of one atomic; every key's two ranks must agree (trap otherwise).
+// One complete tile in SORT_VERIFY_EVERY is such a tile, inside the production launch: every sort checks the lane-order
+// property on ~6 % of its keys, all keys of every lane of those tiles.  (A separate launch for these tiles cost 12 % of the
+// sort -- 9.96 against 8.90 ms per 1e9 keys: the holes it leaves in the runs of every digit break the write combining.)
 template <typename K, int MODE, bool DESC, int VB, int KPT, bool FULL, bool ATOMIC_RANK, bool VERIFY = false>
 __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const unsigned tile,
         const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const typename valtype<VB>::type *__restrict__ vals_in, typename valtype<VB>::type *__restrict__ vals_out,
-        long long n, int shift, unsigned nblocks, const unsigned *__restrict__ table)
+        long long n, int shift, unsigned nblocks, const unsigned *__restrict__ table, const bool vflag = false)
 {
     typedef typename valtype<VB>::type VT;
     constexpr int TILE = RB * KPT;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
 
     for (int i = t; i < RW * RADIX; i += RB) {
         (&L.hist[0][0])[i] = 0;
-        if constexpr (!ATOMIC_RANK || VERIFY) s_match[i] = 0ull;  // the match words are only used by the fallback ranking (and the verified tiles)
+        if (!ATOMIC_RANK || (VERIFY && vflag)) s_match[i] = 0ull; // the match words are only used by the fallback ranking (and the verified tiles)
     }
 
     K key[KPT];
@@ -190,7 +191,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
             unsigned r;
             unsigned expect = 0;                                     // VERIFY: the rank the match words give
             if constexpr (VERIFY) {
-                if (!uniform) {
+                if (vflag && !uniform) {
                     unsigned long long *word = s_match + wave * RADIX + d;
                     const unsigned prev = L.hist[wave][d];           // the counter before this key's atomic (a wave's LDS operations run in program order)
                     if (valid) atomicOr(word, 1ull << lane);
@@ -210,7 +211,7 @@ __device__ __forceinline__ void scatter_tile(scatter_lds<K, VB, KPT> &L, const u
                 __builtin_amdgcn_wave_barrier();
             } else {
                 r = valid ? atomicAdd(&L.hist[wave][d], 1u) : 0u;
-                if constexpr (VERIFY) if (valid && r != expect) __builtin_trap();      // a lane was served out of lane order
+                if constexpr (VERIFY) if (vflag && valid && r != expect) __builtin_trap();      // a lane was served out of lane order
             }
             rd[k] = valid ? (r | (d << 16)) : ~0u;
             // Tripwire (round 3): two NEIGHBOURING lanes with the same digit must have received consecutive ranks.  Lane order
@@ -341,17 +342,13 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
         // the array front to back together -- run 4 / 16 / 32 / 64 / 256: 10.71 / 10.21 / 10.15 / 10.10 / 10.05 ms against
         // 10.00 ms for the contiguous eighths on the same box (1e9 u32 keys).
         const unsigned per = (first_tile + 7) / 8;          // FULL launches pass the number of complete tiles here
-        if constexpr (VERIFY) {
-            tile = blockIdx.x * verify_every + (verify_every - 1);                 // compact launch: first_tile / 16 workgroups
-        } else {
-            tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-            if (tile >= first_tile) return;
-            // atomic ranks: every SORT_VERIFY_EVERY-th tile is left to the launch with VERIFY
-            if constexpr (ATOMIC_RANK) if (verify_every && tile % verify_every == verify_every - 1) return;
-        }
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if (tile >= first_tile) return;
     }
+    // every verify_every-th complete tile is ranked both ways (same launch, same tile order: its runs meet their neighbours' in L2)
+    const bool vflag = VERIFY && FULL && verify_every && tile % verify_every == verify_every - 1;
     scatter_tile<K, MODE, DESC, VB, KPT, FULL, ATOMIC_RANK, VERIFY>(L, tile, keys_in, keys_out,
-            reinterpret_cast<const VT *>(vals_in_), reinterpret_cast<VT *>(vals_out_), n, shift, nblocks, table);
+            reinterpret_cast<const VT *>(vals_in_), reinterpret_cast<VT *>(vals_out_), n, shift, nblocks, table, vflag);
 }
 
 extern int g_sort_rank;
@@ -379,10 +376,7 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
         const unsigned nfull = (unsigned)(n / TILE);
         if (nfull) {
             if (atomic_rank) {
-                const unsigned ev = nfull >= SORT_VERIFY_EVERY ? every : 0u;
-                radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, ev);
-                if (ev)
-                    radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, true><<<nfull / ev, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, ev);
+                radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, true><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, every);
             } else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
             VEXHIP_LAUNCH_CHECK();
         }

@@ -10,6 +10,8 @@
 // Both front ends now call create / apply / destroy.  Built from DEVICE CSR arrays: no host staging.
 #include "common.hpp"
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -60,6 +62,21 @@ struct spmat {
     vexhip_march march = {0, 0, 0, 0, 0, 0, {0, 0, 0}};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
     vexhip_plane plane = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // plane product (plane.hip): 7-point pattern on 512-point lines; preferred to the march product
     vexhip_grid grid = {};                                         // grid product (grid.hip): 7-point pattern on lines of any length, where the plane product does not apply
+};
+
+// VEXHIP_SETUP_TRACE=1: host wall time of every stage of a set-up on stderr (each mark synchronises the stream: the trace is
+// for finding where a set-up spends its time, the figures of a traced run are not those of an untraced one)
+struct setup_trace {
+    bool on; hipStream_t s; std::chrono::steady_clock::time_point t0, last;
+    explicit setup_trace(hipStream_t st) : on(std::getenv("VEXHIP_SETUP_TRACE") != nullptr), s(st) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vexhip set-up] %-28s %8.3f ms  (at %8.3f)\n", what,
+                     std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
 };
 
 template <typename T> int dmalloc(T **p, size_t count) {
@@ -225,14 +242,17 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     if (n == 0) { A->format = VEXHIP_SPMAT_CSR; return 0; }
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
+    setup_trace trace(s);
     P last = 0;
     VEXHIP_TRY(hipMemcpyAsync(&last, ptr + n, sizeof(P), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     A->nnz = (int64_t)last;
+    trace.mark("entry count");
 
     int64_t w = 0, tail = 0;
     if (format != VEXHIP_SPMAT_CSR && A->nnz > 0)
         if (int rc = S::analyze(dev, stream, n, ptr, &w, &tail)) return rc;
+    trace.mark("ELL width");
     if (format == VEXHIP_SPMAT_CSR || w == 0) {
         // the CSR arrays as they are: borrowed (the caller keeps them alive) or copied
         A->format = VEXHIP_SPMAT_CSR;
@@ -281,6 +301,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         if (int rc = dmalloc(&vals, 256)) return rc;
         A->values = vals;
         if (int rc = S::fused(dev, stream, n, ptr, col, val, w, A->deltas, &nd, vals, &nv)) return rc;
+        trace.mark("diagonals + values");
     } else if (format != VEXHIP_SPMAT_SELL) {
         if (int rc = dmalloc(&A->deltas, 256)) return rc;
         if (int rc = S::d_analyze(dev, stream, n, ptr, col, w, A->deltas, &nd)) return rc;
@@ -291,14 +312,18 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
             A->nvalues = nv; A->format = VEXHIP_SPMAT_SELL8V;
             A->sell_bytes = vexhip_sell8v_bytes(n, w);
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
+            trace.mark("allocate slices");
             if (int rc = S::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
+            trace.mark("fill");
             if (int rc = make_dictionary(A, stream, flags, A->sell_bytes / ((n + 511) / 512), true)) return rc;
+            trace.mark("dictionary + plans");
             // a 7-point pattern on grid lines of another length than 512: the matrix by grid line (grid.hip), from the slices'
             // codes wherever they are now (the pool of a dictionary, or the per-slice buffer)
             if (std::is_same<V, double>::value && !A->plane.usable && !tail
                 && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE)))
                 if (int rc = vexhip_sell8_grid_plan(dev, stream, A->deltas, nd, A->blocks ? A->pool : A->sell, A->blocks, w, n, tail, 8,
                                                     vexhip_sell8_last_fill_max_col(), &A->grid)) return rc;
+            trace.mark("grid plan");
         } else {
             if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
             A->format = VEXHIP_SPMAT_SELL8;
