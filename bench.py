@@ -339,6 +339,7 @@ def main():
     ap.add_argument("--trial-steps", type=int, default=100, help="N > 1, --transport auto: products timed per candidate transport")
     ap.add_argument("--no-dictionary", action="store_true", help="value-coded storage with one code block per slice (no slice dictionary)")
     ap.add_argument("--no-march", action="store_true", help="keep the pair product where the march / plane products would apply")
+    ap.add_argument("--no-direct", action="store_true", help="build the SELL-512 storage (slices, dictionary, plans) where the default set-up stores the matrix by grid line (round 4)")
     ap.add_argument("--no-plane", action="store_true", help="keep the march product (x window in an LDS ring, round 3) where the plane product (round 4) would apply")
     ap.add_argument("--blocks", type=int, default=5, help="blocks of K steps; ms_per_step is their median (block 1 = the W warm-ups + exactly K steps of the contract)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the ~3 s back-to-back run of the product after the timed region")
@@ -394,13 +395,20 @@ def main():
     setup = None
     march = None
     plane = None
+    grid_plan = None
+    direct = False
     if single:
         # set-up is timed (not part of `value`): CSR arrays in HBM -> the storage the product runs on.  A solver that rebuilds
         # its matrices (AMG set-up, a nonlinear iteration) pays this once per matrix.
+        # The device is brought out of idle first (30 copies of x, ~12 ms): a set-up that follows a pause is clocked up to 5 ms slower
+        # in its first kernel than one in the middle of a computation, which is where a solver rebuilds a matrix.
+        for _ in range(30):
+            y.copy_(x)
+        y.zero_()
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info(dev)[0]
         ts0 = time.perf_counter()
-        A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary, march=not args.no_march, plane=not args.no_plane)
+        A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary, march=not args.no_march, plane=not args.no_plane, direct=not args.no_direct)
         torch.cuda.synchronize()
         setup_ms = (time.perf_counter() - ts0) * 1e3
         storage = A.storage
@@ -408,8 +416,13 @@ def main():
         dict_blocks = A.dictionary_blocks
         march = A.march
         plane = A.plane if x.dtype == torch.float64 else None
+        grid_plan = A.grid if x.dtype == torch.float64 else None
+        direct = bool(A.direct)
         setup = {"setup_ms": round(setup_ms, 3),
-                 "what": "vexhip_spmat_create on CSR arrays resident in HBM: hybrid-ELL analysis, diagonal / value tables, fill, slice dictionary, march plan (host wall time, synchronised)",
+                 "what": ("vexhip_spmat_create on CSR arrays resident in HBM (host wall time, synchronised; the first creation in this process, after 30 copies of x "
+                          "that bring the device out of idle): " + ("ELL width, diagonal / value tables, then ONE pass that stores the matrix by grid line (classes of lines)"
+                          if direct else "hybrid-ELL analysis, diagonal / value tables, fill, slice dictionary, march / plane plans")),
+                 "stored_by_grid_line": direct,
                  "csr_input_bytes": int(ptr.numel() * ptr.element_size() + col.numel() * col.element_size() + val.numel() * val.element_size()),
                  "stored_bytes": int(matrix_bytes),
                  "held_after_setup_bytes": int(free0 - torch.cuda.mem_get_info(dev)[0])}
@@ -426,6 +439,8 @@ def main():
         dict_blocks = getattr(A.loc, "dictionary_blocks", 0)
         march = getattr(A.loc, "march", None)
         plane = getattr(A.loc, "plane", None)
+        grid_plan = getattr(A.loc, "grid", None)
+        direct = bool(getattr(A.loc, "direct", False))
         step = lambda: A.apply(x, y, 1.0, False)
 
         # ---- every transport is validated against an evaluation that trusts NO transport: x is a hash of the global index,
@@ -700,9 +715,12 @@ def main():
                        "parallelism": "row-partitioned x%d" % world},
             "roofline": {"bound": "hbm",
                          "kernel": (("sell8_plane_kernel<%d, false, %d>" % (plane["tile"], {0: 2, 1: 18, 2: 17, 3: 0}[plane["store_policy"]])) if (storage == "sell8v" and plane) else
+                                    KERNEL_OF["sell8v_grid"] if (storage == "sell8v" and grid_plan) else
                                     KERNEL_OF["sell8v_march"] if (storage == "sell8v" and march) else
                                     "sell8_pair_kernel<double, 7, true, true>" if (storage == "sell8v" and dict_blocks) else KERNEL_OF.get(storage, storage)),
                          "plane": plane,
+                         "grid": grid_plan,
+                         "stored_by_grid_line": direct,
                          "march": march,
                          "achieved": round(moved_rank / kern_s / 1e9, 1),
                          "peak": HBM_PEAK_GBPS,
@@ -711,7 +729,8 @@ def main():
                          "dictionary_blocks": dict_blocks,
                          "bytes_per_launch": moved_rank,
                          "bytes_per_launch_what": "stored matrix (%d B: %s%s) + x once + y once" % (
-                             matrix_bytes, storage, (", %d distinct 512-row code blocks + 4 B per slice" % dict_blocks) if dict_blocks else ""),
+                             matrix_bytes, storage, (", %d distinct 512-row code blocks + 4 B per slice" % dict_blocks) if dict_blocks else
+                             (", by grid line: %d classes x 7 positions x %d value codes + 4 B per line" % (grid_plan["classes"], grid_plan["nx"])) if (direct and grid_plan) else ""),
                          "algorithmic_bytes_per_launch": alg_rank,
                          "algorithmic_gbps": round(alg_rank / kern_s / 1e9, 1),
                          "traffic": None,
@@ -719,12 +738,12 @@ def main():
         }
         if setup is not None:
             out["setup"] = setup
-        if storage == "sell8v" and dict_blocks and (march or plane):
-            if plane:
+        if storage == "sell8v" and (march or plane or grid_plan):
+            if plane or grid_plan:
                 # the plane product: per plane step a lane requests tile + 2 pairs of x for tile lines (centre lines + the two halo
                 # lines; +-512 / +-P neighbours are its own earlier loads), 8 B per wave end and line for the +-1 neighbours, and
                 # stores tile pairs.  HBM sees x and y once -- the traffic of a copy of x to y.
-                tl = plane["tile"]
+                tl = plane["tile"] if plane else 2
                 l1_bytes = int((8 * (tl + 2) / tl + 8) * rows_rank)
                 out["roofline"]["on_chip"] = {
                     "what": "bytes through L1 per launch: x %.0f B/row (tile %d: centre lines + 2 halo lines per %d) + y 8 B/row; HBM sees x and y once; "
@@ -786,16 +805,21 @@ def main():
                 torch.cuda.empty_cache()
                 p2, c2, v2 = ops.poisson3d(n, dev)
                 rcsr = []
-                if storage == "sell8v" and plane and march:
-                    # the march product of round 3 on the same storage (the plane product replaces it where it applies)
+                if storage == "sell8v" and plane:
+                    # the SELL-512 storage with its slice dictionary (the set-up of rounds 2-3) and the march product of round 3 on it
+                    torch.cuda.synchronize(); tc0 = time.perf_counter()
                     B = ops.SpMat(p2, c2, v2, fmt=args.format, plane=False)
+                    torch.cuda.synchronize()
+                    out["setup"]["sell512_setup_ms"] = round((time.perf_counter() - tc0) * 1e3, 3)
+                    out["setup"]["sell512_setup_what"] = "the set-up of rounds 2-3 on the same arrays (VEXHIP_SPMAT_NO_PLANE: analysis, fill of 2.1 GB of per-slice codes, slice dictionary, march plan), second creation in this process"
+                if storage == "sell8v" and plane and B.march:
                     tb = timed_events(torch, lambda: B.apply(x, y), 40)
                     assert abs(DistReductor("SUM_Kahan")(y) - checksum) <= 1e-10 * abs(checksum) + 1e-300
                     out["march_product"] = {"kernel": KERNEL_OF["sell8v_march"], "avg_launch_ms": round(tb, 5),
                                             "gflops": round(2.0 * nnz_total / tb / 1e6, 1),
                                             "what": "the same storage through the round-3 kernel (VEXHIP_SPMAT_NO_PLANE): x window in an LDS ring along runs of slices"}
                     del B
-                if storage == "sell8v" and march:
+                if storage == "sell8v" and (march or plane):
                     # the pair product of round 2 on the same storage (the march / plane products replace it where they apply)
                     B = ops.SpMat(p2, c2, v2, fmt=args.format, march=False)
                     tb = timed_events(torch, lambda: B.apply(x, y), 40)
@@ -804,7 +828,7 @@ def main():
                                            "gflops": round(2.0 * nnz_total / tb / 1e6, 1),
                                            "what": "the same storage through the round-2 kernel (VEXHIP_SPMAT_NO_MARCH): seven 16-byte gathers per lane and slice"}
                     del B
-                if storage == "sell8v" and dict_blocks:
+                if storage == "sell8v" and (dict_blocks or direct):
                     # the value-coded storage WITHOUT the slice dictionary: one code block per slice, streamed from HBM
                     B = ops.SpMat(p2, c2, v2, fmt=args.format, dictionary=False)
                     tb = timed_events(torch, lambda: B.apply(x, y), 40)
@@ -899,6 +923,8 @@ def main():
                 key = {"sell8v": "sell8_pair_kernel_vcoded", "sell8": "sell8_pair_kernel_values", "sell32": "sell_pair_kernel", "csr": "csr_stream2_kernel"}.get(storage)
                 if storage == "sell8v" and march:
                     key = "sell8_march_kernel"
+                if storage == "sell8v" and grid_plan:
+                    key = "sell8_grid_kernel"
                 if storage == "sell8v" and plane:
                     key = "sell8_plane_kernel"
                 if key in tr:

@@ -282,7 +282,7 @@ typedef struct vexhip_plane { int32_t usable;
                               int32_t hot_block;         /* dictionary block kept decoded in registers                        */
                               int32_t tile;              /* grid lines per workgroup: 2 or 4 (divides lines_per_plane)        */
                               int32_t store_policy;      /* y stores: 0 non-temporal, 1 non-temporal + sc1, 2 sc0 sc1, 3 plain  */
-                              int32_t reserved;
+                              int32_t table_pitch;       /* 0: `pool` holds SELL-512 code blocks; > 0: class tables of the grid storage (vexhip_grid.pitch) */
                               int64_t x_last;
                             } vexhip_plane;
 int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
@@ -390,7 +390,8 @@ enum { VEXHIP_SPMAT_AUTO = 0,      /* create(): most compact storage; info: neve
 enum { VEXHIP_SPMAT_BORROW_CSR = 1,      /* format CSR: keep the caller's arrays instead of copying them (caller keeps them alive) */
        VEXHIP_SPMAT_NO_DICTIONARY = 2,   /* value-coded storage: keep one block per slice even if the slices repeat (A/B, tests)   */
        VEXHIP_SPMAT_NO_MARCH = 4,        /* keep the pair products where the march / plane products would apply (A/B, tests)       */
-       VEXHIP_SPMAT_NO_PLANE = 8 };      /* keep the march product where the plane product would apply (A/B, tests)                */
+       VEXHIP_SPMAT_NO_PLANE = 8,        /* keep the march product where the plane product would apply (A/B, tests)                */
+       VEXHIP_SPMAT_NO_GRID_BUILD = 16 };/* build the SELL-512 storage even where the matrix could be stored by grid line (A/B, tests) */
 typedef struct vexhip_spmat_info {
     int32_t format, value_type, device, ndeltas, nvalues, reserved;
     int64_t rows, nnz, ell_width, tail_nnz, sell_bytes;

@@ -439,23 +439,28 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
             else:
                 os.environ["VEXHIP_PLANE_DEPTH"] = str(depth)
             m = len(ptr) - 1
-            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
-            assert A.storage == "sell8v" and B.grid is None and B.plane is None and B.march is None
+            B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
+            assert B.storage == "sell8v" and B.grid is None and B.plane is None and B.march is None
             if not expect:
-                assert A.grid is None, (shape, A.grid)
+                for direct in (True, False):
+                    assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct).grid is None, (shape, direct)
                 return
-            assert A.grid is not None and A.plane is None, (shape, A.storage, A.dictionary_blocks)
-            assert (A.grid["nx"], A.grid["lines_per_plane"]) == shape[:2] and A.grid["x_last"] == m - 1, (shape, A.grid)
-            assert A.grid["segments"] == (shape[0] + 511) // 512 and (depth is None or A.grid["depth"] == min(depth, A.grid["planes"])), (shape, A.grid)
-            if classes is not None:
-                assert A.grid["classes"] == classes, (shape, A.grid)
             xb = oracle.random_f64(seed, m); y0 = oracle.random_f64(seed + 1, m)
             want = oracle.spmv_csr(ptr, col, val, xb)
-            for alpha, append in ((1.0, False), (-0.75, True)):
-                ya, yb = T.up(y0.copy()), T.up(y0.copy())
-                A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
-                assert torch.equal(ya, yb), (shape, alpha)
-                assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (shape, alpha)
+            # direct: the matrix by grid line straight from the CSR arrays (grid_build, the default); not direct: the SELL-512
+            # storage first, the grid plan from its slices' codes
+            for direct in (True, False):
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct)
+                assert A.storage == "sell8v" and A.grid is not None and A.plane is None and A.direct == direct, (shape, direct, A.storage, A.dictionary_blocks)
+                assert (A.grid["nx"], A.grid["lines_per_plane"]) == shape[:2] and A.grid["x_last"] == m - 1, (shape, A.grid)
+                assert A.grid["segments"] == (shape[0] + 511) // 512 and (depth is None or A.grid["depth"] == min(depth, A.grid["planes"])), (shape, A.grid)
+                if classes is not None:
+                    assert A.grid["classes"] == classes, (shape, A.grid)
+                for alpha, append in ((1.0, False), (-0.75, True)):
+                    ya, yb = T.up(y0.copy()), T.up(y0.copy())
+                    A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+                    assert torch.equal(ya, yb), (shape, alpha, direct)
+                    assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (shape, alpha, direct)
             return A
 
         # Small grids: the plan is forced (the library keeps the pair product below 2^23 rows -- x lives in the L2s there -- and
@@ -508,11 +513,20 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
         n = 208
         ptr, col, val = oracle.poisson3d(n)
         A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
-        assert A.grid is not None and A.grid["nx"] == n and A.grid["classes"] == 2 and B.grid is None, A.grid
+        assert A.direct and A.grid is not None and A.grid["nx"] == n and A.grid["classes"] == 2 and B.grid is None, A.grid
+        C = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=False)
+        assert not C.direct and C.grid is not None and C.grid["classes"] == 2
         xb = oracle.random_f64(47, n ** 3)
         ya = torch.empty(n ** 3, dtype=torch.float64, device=T.dev); yb = torch.empty_like(ya)
         A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
-        assert torch.equal(ya, yb)
+        assert torch.equal(ya, yb) and torch.equal(C @ T.up(xb), yb)
+        # four right-hand sides through the storage by grid line: one product per component
+        xs = [T.up(oracle.random_f64(50 + k, n ** 3)) for k in range(3)]
+        ys = [torch.empty_like(ya) for _ in range(3)]
+        A.apply_multi(xs, ys)
+        for k in range(3):
+            assert torch.equal(ys[k], B @ xs[k])
+        del C
         assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
         assert T.ops.SpMat(*[T.up(a) for a in oracle.poisson3d(96)]).grid is None          # small: the pair product stays
 
@@ -564,16 +578,19 @@ def test_plane_product_is_bit_identical(T, oracle, built_lib, tile):
             P = 512 * ny
             m = P * nz + extra
             ptr, col, val = _band(m, (-P, -512, -1, 0, 1, 512, P), 5, constant=True)
-            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
-            assert A.storage == "sell8v" and A.plane is not None and B.plane is None and B.march is None, (ny, nz, A.plane)
-            assert A.plane["lines_per_plane"] == ny and A.plane["tile"] == (tile if ny % tile == 0 else 2), A.plane
+            B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), march=False)
             xb = oracle.random_f64(21, m); y0 = oracle.random_f64(22, m)
             want = oracle.spmv_csr(ptr, col, val, xb)
-            for alpha, append in ((1.0, False), (-0.75, True)):
-                ya, yb = T.up(y0.copy()), T.up(y0.copy())
-                A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
-                assert torch.equal(ya, yb), (ny, nz, alpha)
-                assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (ny, nz, alpha)
+            for direct in (False, True):       # the plane kernel on dictionary blocks of the SELL-512 storage / on the class tables of the storage by grid line
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct)
+                assert A.storage == "sell8v" and A.plane is not None and B.plane is None and B.march is None and A.direct == direct, (ny, nz, A.plane)
+                assert A.plane["lines_per_plane"] == ny and A.plane["tile"] == (tile if ny % tile == 0 else 2), A.plane
+                assert (A.plane["table_pitch"] > 0) == direct
+                for alpha, append in ((1.0, False), (-0.75, True)):
+                    ya, yb = T.up(y0.copy()), T.up(y0.copy())
+                    A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+                    assert torch.equal(ya, yb), (ny, nz, alpha, direct)
+                    assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (ny, nz, alpha, direct)
         os.environ.pop("VEXHIP_PLANE_DEPTH", None)
         # (c) Inf / NaN in x: only the rows that reference them may see them
         ny, nz = 8, 12
@@ -643,9 +660,17 @@ def test_march_needs_slices_that_repeat_in_runs(T, built_lib):
     n = 384
     N = n ** 3
     dp, dc, dv = ops.poisson3d(n, T.dev)
-    A = ops.SpMat(dp, dc, dv)
-    assert A.march is None and A.dictionary_blocks > 0
+    A = ops.SpMat(dp, dc, dv, direct=False)
+    assert A.march is None and A.dictionary_blocks > 0 and not A.direct
+    # round 4: the SELL-512 storage gets the grid plan (the matrix re-expressed by grid line from the slices' codes); the default
+    # set-up stores the matrix by grid line straight from the CSR arrays -- same classes, same product
+    assert A.grid is not None and A.grid["nx"] == 384 and A.grid["classes"] == 2, A.grid
+    D = ops.SpMat(dp, dc, dv)
+    assert D.direct and D.grid is not None and D.plane is None and D.dictionary_blocks == 0, (D.grid, D.plane)
+    assert {k: v for k, v in D.grid.items() if k != "hot_class"} == {k: v for k, v in A.grid.items() if k != "hot_class"}, (D.grid, A.grid)
     x = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=T.dev), 7)
+    assert torch.equal(D @ x, A @ x) and torch.equal(A @ x, ops.SpMat(dp, dc, dv, march=False) @ x)
+    del D
     ya = torch.full((N,), 3.0, dtype=torch.float64, device=T.dev)
     A.apply(x, ya, 0.5, True)
     h2i = float((n - 1) ** 2)
@@ -767,8 +792,8 @@ def test_poisson512_properties(T):
     dp, dc, dv = ops.poisson3d(n, T.dev)
     assert dc.numel() == 930123728 and int(dp[-1]) == 930123728
     A_csr = ops.SpMat(dp, dc, dv, fmt="csr")
-    A_ell = ops.SpMat(dp, dc, dv)                       # default format: SELL-512
-    assert A_ell.fmt == "sell" and A_ell.hell.width == 7 and A_ell.hell.tail_nnz == 0
+    A_ell = ops.SpMat(dp, dc, dv, direct=False)         # the SELL-512 storage (slices, dictionary, march / plane plans)
+    assert A_ell.fmt == "sell" and A_ell.hell.width == 7 and A_ell.hell.tail_nnz == 0 and not A_ell.direct
     A_hell = ops.SpMat(dp, dc, dv, fmt="hell")          # reference layout + L2-tiled traversal order
     assert A_hell.hell.order_grid >= N // 512 and A_ell.hell.order_grid >= N // 512
 
@@ -787,7 +812,19 @@ def test_poisson512_properties(T):
     ya = y1.clone(); yb = y1.clone()
     A_ell.apply(x, ya, -0.5, True); A_march.apply(x, yb, -0.5, True)
     assert torch.equal(ya, yb)
-    del A_march, ya, yb
+    del A_march
+    # round 4: the default set-up stores the matrix by grid line straight from the CSR arrays (two classes: interior lines,
+    # boundary lines); the plane kernel reads those tables -- same bits, '=' and '+= alpha'
+    A_line = ops.SpMat(dp, dc, dv)
+    assert A_line.direct and A_line.storage == "sell8v" and A_line.dictionary_blocks == 0 and A_line.march is None
+    assert A_line.grid is not None and A_line.grid["nx"] == 512 and A_line.grid["classes"] == 2, A_line.grid
+    assert A_line.plane is not None and A_line.plane["table_pitch"] >= 514 and A_ell.plane["table_pitch"] == 0, (A_line.plane, A_ell.plane)
+    assert A_line.plane["lines_per_plane"] == 512 and A_line.plane["planes"] == 512 and A_line.matrix_bytes() < (1 << 21)
+    assert torch.equal(A_line @ x, y2)
+    yc = y1.clone()
+    A_line.apply(x, yc, -0.5, True)
+    assert torch.equal(yc, ya)
+    del A_line, ya, yb, yc
     A_pair = ops.SpMat(dp, dc, dv, march=False)
     assert A_pair.march is None and A_pair.plane is None and torch.equal(A_pair @ x, y2)
     del A_pair

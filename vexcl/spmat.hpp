@@ -480,10 +480,23 @@ struct inline_spmv : expression_base {
         c.src.parameter("const " + V + " *", "values"); c.src.parameter("const int *", "blocks"); c.src.parameter("const char *", "pool");
         c.src.parameter("const int *", "csr_row"); c.src.parameter("const int *", "csr_col");
         c.src.parameter("const " + V + " *", "csr_val"); c.src.parameter("const " + V + " *", "in");
+        c.src.parameter("long", "grid_nx"); c.src.parameter("long", "grid_far"); c.src.parameter("long", "grid_pitch");
+        c.src.parameter("const int *", "line_class"); c.src.parameter("const uchar *", "grid_table");
         c.src.parameter("ulong", "i");
         c.src.end_function_parameters();
         c.src.new_line() << V << " sum = 0;";
-        c.src.new_line() << "if (values)";            // SELL8V: diagonal codes and value codes (include/vexhip.h)
+        c.src.new_line() << "if (line_class)";        // stored by grid line (grid.hip): a class per line, a value code per position and row
+        c.src.open("{");
+        c.src.new_line() << "const long line = (long)i / grid_nx, r = (long)i - line * grid_nx;";
+        c.src.new_line() << "const uchar *tb = grid_table + (long)line_class[line] * 7 * grid_pitch + r;";
+        c.src.new_line() << "const long off[7] = {-grid_far, -grid_nx, -1, 0, 1, grid_nx, grid_far};";
+        c.src.new_line() << "for(int p = 0; p < 7; ++p)";
+        c.src.open("{");
+        c.src.new_line() << "const uint code = tb[p * grid_pitch];";
+        c.src.new_line() << "if (code != 255u) sum += values[code] * in[(long)i + off[p]];";
+        c.src.close("}");
+        c.src.close("}");
+        c.src.new_line() << "else if (values)";       // SELL8V: diagonal codes and value codes (include/vexhip.h)
         c.src.open("{");
         c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
         c.src.new_line() << "const long slice = blocks ? (long)blocks[i >> 9] : (long)(i >> 9);";   // slice dictionary (include/vexhip.h)
@@ -535,12 +548,15 @@ struct inline_spmv : expression_base {
         c.src.parameter("const char *", name + "_pool");
         c.src.parameter("const int *", name + "_csr_row"); c.src.parameter("const int *", name + "_csr_col");
         c.src.parameter("const " + V + " *", name + "_csr_val"); c.src.parameter("const " + V + " *", name + "_vec");
+        c.src.parameter("long", name + "_grid_nx"); c.src.parameter("long", name + "_grid_far"); c.src.parameter("long", name + "_grid_pitch");
+        c.src.parameter("const int *", name + "_line_class"); c.src.parameter("const uchar *", name + "_grid_table");
     }
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
         c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, " << n << "_blocks, " << n << "_pool, "
-              << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, idx)";
+              << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, "
+              << n << "_grid_nx, " << n << "_grid_far, " << n << "_grid_pitch, " << n << "_line_class, " << n << "_grid_table, idx)";
     }
     void set_args(arg_context &a) const {
         a.next();
@@ -557,6 +573,11 @@ struct inline_spmv : expression_base {
         a.krn.push_arg(static_cast<const int *>(csr_rows ? L.csr_ptr : nullptr));
         a.krn.push_arg(static_cast<const int *>(L.csr_col)); a.krn.push_arg(static_cast<const T *>(L.csr_val));
         a.krn.push_arg(static_cast<const T *>(x(a.device).raw()));
+        // stored by grid line (no SELL-512 slices at all): the class of every line and the class tables
+        const bool by_line = L.grid.usable && !L.sell && !L.code_pool;
+        a.krn.push_arg((long)L.grid.nx); a.krn.push_arg((long)L.grid.nx * (long)L.grid.lines_per_plane); a.krn.push_arg((long)L.grid.pitch);
+        a.krn.push_arg(static_cast<const int *>(by_line ? L.grid.line_class : nullptr));
+        a.krn.push_arg(static_cast<const unsigned char *>(by_line ? L.grid.table : nullptr));
     }
     void get_props(prop_context &p) const {
         if (p.empty()) { p.queue = A.queue_list(); p.part = A.row_partition(); p.size = A.rows(); }

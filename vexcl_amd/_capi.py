@@ -64,7 +64,7 @@ class Plane(ctypes.Structure):
     """vexhip_plane (include/vexhip.h)."""
     _fields_ = [("usable", ctypes.c_int32), ("lines_per_plane", ctypes.c_int32), ("planes", ctypes.c_int32), ("depth", ctypes.c_int32),
                 ("hot_block", ctypes.c_int32), ("tile", ctypes.c_int32), ("store_policy", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("x_last", ctypes.c_int64)]
+                ("table_pitch", ctypes.c_int32), ("x_last", ctypes.c_int64)]
 
 
 class Grid(ctypes.Structure):
@@ -92,6 +92,7 @@ SPMAT_BORROW_CSR = 1
 SPMAT_NO_DICTIONARY = 2
 SPMAT_NO_MARCH = 4
 SPMAT_NO_PLANE = 8
+SPMAT_NO_GRID_BUILD = 16
 SPMAT_NAMES = {SPMAT_SELL8V: "sell8v", SPMAT_SELL8: "sell8", SPMAT_SELL: "sell32", SPMAT_CSR: "csr"}
 
 # name -> (restype, argtypes); restype None means "int status, checked"

@@ -1,8 +1,10 @@
 // Shared host-side helpers for libvexhip.so (error capture, device guard).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/vexhip.h"
@@ -29,6 +31,21 @@ struct device_info {
     bool ok = false;
 };
 const device_info &info(int dev);
+
+// VEXHIP_SETUP_TRACE=1: host wall time of every stage of a set-up on stderr (each mark synchronises the stream: the trace is
+// for finding where a set-up spends its time, the figures of a traced run are not those of an untraced one)
+struct setup_trace {
+    bool on; hipStream_t s; std::chrono::steady_clock::time_point t0, last;
+    explicit setup_trace(hipStream_t st) : on(std::getenv("VEXHIP_SETUP_TRACE") != nullptr), s(st) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vexhip set-up] %-28s %8.3f ms  (at %8.3f)\n", what,
+                     std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
 
 } // namespace vexhip
 

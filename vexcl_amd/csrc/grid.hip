@@ -162,6 +162,185 @@ void grid_line_verify_kernel(codes_dev cd, long long lines, int nx, int pitch, c
     if (!ok) atomicOr(bad, 2);
 }
 
+
+// ---- the matrix by grid line straight from the CSR arrays (round 4: the set-up of grid matrices without the SELL-512 detour) ----
+// Once the analysis has named the diagonals {0, +-1, +-nx, +-P} and the (<= 255) values, ONE pass over the CSR arrays builds
+// what the grid / plane products read: a workgroup takes one grid line, stages the entries of 512 rows at a time in LDS with
+// coalesced loads (the value -> code look-up happens there, through a hash of the value table), every lane turns its two rows
+// into seven bytes each (code per position, 255 = no entry; the entries must ascend by position), the line's rows are hashed
+// and the line is looked up in a device-wide table of classes: the first workgroup to bring a hash writes the class table and
+// publishes its number, every later one compares its rows with that table byte by byte (a different line with the same hash
+// ends the build: the classic set-up takes over).  No per-slice codes are written (2.1 GB at 512^3) and nothing but a few
+// counters returns to the host.
+constexpr int GB_PIECE = 512;                 // rows staged at a time
+constexpr int GB_CAP = 8 * GB_PIECE;          // entries of a piece (rows with more than 8 entries have no place in this storage)
+constexpr int GB_VSLOTS = 512;                // LDS hash of the value table
+constexpr int GB_KEYS = 1024;                 // device-wide table of line hashes
+constexpr int GB_KNOWN = 128;                 // classes a workgroup remembers
+constexpr int GB_MAX_CLASSES = 128;
+enum { GB_BAD_ROW = 1, GB_OVERFLOW = 2, GB_COLLISION = 4, GB_TIMEOUT = 8 };
+
+struct gb_dev {
+    long long n, lines, far;
+    int nx, nvalues, pitch, cap;
+    unsigned long long *keys; int *ids; int *count; int *uses; int *flags;
+    unsigned char *table; int *line_class;
+};
+
+template <typename P>
+__global__ __launch_bounds__(256)
+void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
+        const double *__restrict__ vtable, gb_dev g)
+{
+    extern __shared__ unsigned char gb_lds[];
+    // [value hash keys 512 x 8][value hash codes 512][row bounds 513 x 8][staged columns GB_CAP x 4][staged value codes GB_CAP][line 7 x pitch][scratch]
+    unsigned long long *s_vkey = reinterpret_cast<unsigned long long *>(gb_lds);
+    unsigned char *s_vcode = gb_lds + GB_VSLOTS * 8;
+    long long *s_ptr = reinterpret_cast<long long *>(s_vcode + GB_VSLOTS);
+    int *s_c = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(s_ptr) + 520 * 8);
+    unsigned char *s_vc = reinterpret_cast<unsigned char *>(s_c + GB_CAP);
+    unsigned char *s_sig = s_vc + GB_CAP;
+    unsigned long long *s_red = reinterpret_cast<unsigned long long *>(s_sig + ((7 * g.pitch + 15) / 16) * 16);     // [0..3] wave sums, [4] id, [5] winner, [6] slot, [8..11] bad rows
+    __shared__ unsigned long long s_kkey[GB_KNOWN];
+    __shared__ int s_kid[GB_KNOWN];
+    __shared__ int s_uses[GB_MAX_CLASSES];
+    int known = 0;                                       // (lane 0's)
+    const int t = threadIdx.x;
+    if (t < GB_MAX_CLASSES) s_uses[t] = 0;
+
+    // the value table as an LDS hash: bits -> code (255 = not a value of the table)
+    for (int i = t; i < GB_VSLOTS; i += 256) { s_vkey[i] = ~0ull; s_vcode[i] = 255; }
+    __syncthreads();
+    if (t < g.nvalues) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vtable[t]);
+        unsigned h = (unsigned)((bits * 0x9e3779b97f4a7c15ull) >> 55) & (GB_VSLOTS - 1);
+        for (int probe = 0; probe < GB_VSLOTS; ++probe) {
+            const unsigned long long old = atomicCAS(&s_vkey[h], ~0ull, bits);
+            if (old == ~0ull || old == bits) { s_vcode[h] = (unsigned char)t; break; }
+            h = (h + 1) & (GB_VSLOTS - 1);
+        }
+    }
+    __syncthreads();
+    // (a table value whose bits are all ones -- a NaN -- cannot be told from an empty slot: the analysis never codes such a matrix
+    //  with fewer than 2 values... it simply is not found and the build declines)
+
+    for (long long line = blockIdx.x; line < g.lines; line += gridDim.x) {
+        if (__hip_atomic_load(g.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;       // uniform: another workgroup gave up
+        for (int i = t; i < 7 * g.pitch; i += 256) s_sig[i] = GR_ABSENT;
+        unsigned long long hsum = 0;
+        bool bad = false;
+        const long long row_l = line * g.nx;
+        for (int r0 = 0; r0 < g.nx; r0 += GB_PIECE) {
+            const int rows = g.nx - r0 < GB_PIECE ? g.nx - r0 : GB_PIECE;
+            __syncthreads();                                    // the previous piece's staging is consumed, s_sig is initialised
+            for (int i = t; i <= rows; i += 256) s_ptr[i] = (long long)ptr[row_l + r0 + i];
+            __syncthreads();
+            const long long e0 = s_ptr[0];
+            const long long cnt = s_ptr[rows] - e0;
+            if (cnt < 0 || cnt > GB_CAP) { bad = true; break; }                         // uniform
+            for (int k = t; k < (int)cnt; k += 256) {
+                s_c[k] = col[e0 + k];
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(val[e0 + k]);
+                unsigned h = (unsigned)((bits * 0x9e3779b97f4a7c15ull) >> 55) & (GB_VSLOTS - 1);
+                unsigned code = 255;
+                for (int probe = 0; probe < GB_VSLOTS; ++probe) {
+                    const unsigned long long key = s_vkey[h];
+                    if (key == bits) { code = s_vcode[h]; break; }
+                    if (key == ~0ull) break;
+                    h = (h + 1) & (GB_VSLOTS - 1);
+                }
+                s_vc[k] = (unsigned char)code;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * t + q;
+                if (r >= rows) continue;
+                const long long i = row_l + r0 + r;
+                const int b = (int)(s_ptr[r] - e0), e = (int)(s_ptr[r + 1] - e0);
+                unsigned long long sig = 0x00ffffffffffffffull;           // seven bytes of 255
+                int last = -1;
+                if (e - b > 8 || e < b) bad = true;
+                else for (int j = b; j < e; ++j) {
+                    const long long d = (long long)s_c[j] - i;
+                    const int p = d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -g.nx ? 1 : d == g.nx ? 5 : d == -g.far ? 0 : d == g.far ? 6 : -1;
+                    const unsigned vc = s_vc[j];
+                    if (p <= last || vc == 255u) { bad = true; break; }
+                    last = p;
+                    sig = (sig & ~(0xffull << (8 * p))) | ((unsigned long long)vc << (8 * p));
+                }
+#pragma unroll
+                for (int p = 0; p < 7; ++p) s_sig[p * g.pitch + r0 + r] = (unsigned char)(sig >> (8 * p));
+                hsum += mix64(sig + 0x9e3779b97f4a7c15ull * (unsigned long long)(r0 + r + 1));
+            }
+        }
+        // the line's hash and whether any lane met a row that does not fit
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o, 64);
+        const unsigned long long anybad = __ballot(bad);
+        __syncthreads();
+        if ((t & 63) == 0) { s_red[t >> 6] = hsum; s_red[8 + (t >> 6)] = anybad ? 1 : 0; }
+        __syncthreads();
+        if (t == 0) {
+            int id = -2; int winner = 0; unsigned slot = 0;
+            if (s_red[8] | s_red[9] | s_red[10] | s_red[11]) atomicOr(g.flags, GB_BAD_ROW);
+            else {
+                const unsigned long long key = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) | 1ull;      // never 0 (= empty)
+                // the classes this workgroup has met before (a handful): no device-wide traffic for them
+                for (int k = 0; k < known; ++k) if (s_kkey[k] == key) { id = s_kid[k]; break; }
+                if (id < 0) {
+                    slot = (unsigned)(key >> 20) & (GB_KEYS - 1);
+                    for (int probe = 0; probe < GB_KEYS; ++probe) {
+                        unsigned long long old = __hip_atomic_load(&g.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old == 0ull) old = atomicCAS(&g.keys[slot], 0ull, key);
+                        if (old == 0ull) {                                 // a new class: number it, write its table, publish
+                            id = atomicAdd(g.count, 1);
+                            if (id >= g.cap) { atomicOr(g.flags, GB_OVERFLOW); __hip_atomic_store(&g.ids[slot], -2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); id = -2; }
+                            else winner = 1;
+                            break;
+                        }
+                        if (old == key) {                                  // known: wait for its number (the writer is running)
+                            int v = -1;
+                            for (int spin = 0; spin < (1 << 22); ++spin) {
+                                v = __hip_atomic_load(&g.ids[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                                if (v != -1) break;
+                                __builtin_amdgcn_s_sleep(4);
+                            }
+                            if (v == -1) atomicOr(g.flags, GB_TIMEOUT);
+                            id = v < 0 ? -2 : v;
+                            break;
+                        }
+                        slot = (slot + 1) & (GB_KEYS - 1);
+                    }
+                    if (id >= 0 && known < GB_KNOWN) { s_kkey[known] = key; s_kid[known] = id; }
+                    if (id >= 0 && known < GB_KNOWN) ++known;
+                }
+            }
+            s_red[4] = (unsigned long long)(long long)id; s_red[5] = (unsigned long long)winner; s_red[6] = slot;
+        }
+        __syncthreads();
+        const int id = (int)(long long)s_red[4];
+        const bool winner = s_red[5] != 0;
+        if (id < 0) return;                                                              // the build is over (a flag is set); uniform
+        unsigned *tb = reinterpret_cast<unsigned *>(g.table + (long long)id * 7 * g.pitch);
+        const unsigned *mine = reinterpret_cast<const unsigned *>(s_sig);
+        const int words = 7 * g.pitch / 4;                                              // pitch is a multiple of 16
+        if (winner) {
+            for (int i = t; i < words; i += 256) __hip_atomic_store(tb + i, mine[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();                                    // every lane's part of the table is visible device-wide ...
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(&g.ids[(unsigned)s_red[6]], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);    // ... before its number is
+        } else {
+            bool differ = false;
+            for (int i = t; i < words; i += 256) differ = differ || __hip_atomic_load(tb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine[i];
+            if (__ballot(differ) && (t & 63) == 0) atomicOr(g.flags, GB_COLLISION);
+        }
+        if (t == 0) { g.line_class[line] = id; ++s_uses[id]; }
+    }
+    __syncthreads();
+    for (int i = t; i < g.cap; i += 256) if (s_uses[i]) atomicAdd(&g.uses[i], s_uses[i]);
+}
+
 // ---- the product ----
 template <bool APPEND, int STORE_AUX>
 __global__ __launch_bounds__(256, 4)
@@ -394,6 +573,75 @@ void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, dou
 #undef GRID_OTHER_SUMS
 }
 
+
+// segments of <= 512 rows (even), lanes for one segment, bytes per position row of a class table, planes per workgroup
+struct grid_geometry { long long segs, seg_len, pitch, depth; int threads; };
+inline long long grid_pitch(long long nx) { return (((nx + 511) / 512) * 512 + 2 + 15) / 16 * 16; }
+
+bool grid_geometry_for(int dev, long long nx, long long ny, long long nz, grid_geometry *geo)
+{
+    const long long segs = (nx + 511) / 512;
+    long long seg_len = (nx + segs - 1) / segs; seg_len += seg_len & 1;
+    const int threads = (int)std::min<long long>(256, ((seg_len + 1) / 2 + 63) / 64 * 64);
+    const long long pitch = grid_pitch(nx);
+    const long long tiles = (ny + 1) / 2 * segs;
+    const long long cus = std::max(1, info(dev).cus);
+    // Planes per workgroup.  Few, long workgroups (plane.hip: every workgroup re-reads the planes around its walk) -- but
+    //   * lines that are not 512 points long want at least ~6 waves per CU (their requests straddle cache lines, a wave hides
+    //     less of the latency by itself), and
+    //   * the workgroups should fill the CUs EVENLY: all of them are resident at once, the ones that share a CU with more
+    //     neighbours fall behind, and tiles that are not at the same plane at the same time fetch their halo lines from HBM
+    //     instead of from the L2 their neighbour filled.
+    // Measured (profiles/r04_grid_sweep.json; pair product 0.312 / 0.781 ms): 384^3 (192 tiles x 3 waves) walks of 48 / 96 /
+    // 128 / 192 / 384 planes = 0.202 / 0.184 / 0.217 / 0.227 / 0.349 ms -- 96 planes = 768 workgroups = 3 per CU exactly; 500^3
+    // (250 x 4) walks of 62 / 125 / 166 / 250 / 500 = 0.433 / 0.419 / 0.415 / 0.389 / 0.520 ms.  The estimate below orders all of
+    // these as measured: (workgroups per CU, rounded up) x (planes per walk + 6 for the start of a walk), times 6 / (waves per
+    // CU) where that is below 6.
+    const long long wpw = threads / 64;
+    long long chunks = 1;
+    {
+        double best = 0;
+        for (long long c = 1; c <= std::max(1ll, nz / 8); ++c) {
+            const long long per_cu = (tiles * c + cus - 1) / cus;
+            double est = (double)per_cu * (double)((nz + c - 1) / c + 6);
+            if (per_cu * wpw < 6) est *= 6.0 / (double)(per_cu * wpw);
+            if (c == 1 || est < best) { best = est; chunks = c; }
+        }
+    }
+    long long depth = (nz + chunks - 1) / chunks;
+    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
+    depth = std::min(depth, nz);
+    const long long plane_bytes = ny * nx * 8;
+    while ((depth + 4) * plane_bytes >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;
+    if ((depth + 4) * plane_bytes >= (1ll << 32)) return false;
+
+    geo->segs = segs; geo->seg_len = seg_len; geo->pitch = pitch; geo->depth = depth; geo->threads = threads;
+    return true;
+}
+
+void grid_fill_plan(vexhip_grid *out, long long nx, long long ny, long long nz, const grid_geometry &geo, int hot, int nclasses, long long x_last)
+{
+    out->nx = (int32_t)nx; out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)geo.depth;
+    out->segments = (int32_t)geo.segs; out->segment_rows = (int32_t)geo.seg_len; out->threads = geo.threads;
+    out->hot_class = hot; out->classes = nclasses; out->pitch = (int32_t)geo.pitch;
+    out->store_policy = 1;
+    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
+    out->x_last = x_last;
+}
+
+// the diagonals: {0, +-1, +-nx, +-P} with 1 < nx < P, P a multiple of nx (a subset that names both); false: not a grid matrix
+bool grid_diagonals(const std::vector<int> &table, long long rows, long long *nx_out, long long *far_out)
+{
+    std::vector<long long> mags;
+    for (int d : table) { const long long a = std::llabs((long long)d); if (a && std::find(mags.begin(), mags.end(), a) == mags.end()) mags.push_back(a); }
+    std::sort(mags.begin(), mags.end());
+    if (mags.size() != 3 || mags[0] != 1) return false;
+    const long long nx = mags[1], far = mags[2];
+    if (nx < 8 || far % nx != 0 || far / nx < 2 || rows % nx != 0 || far > (1ll << 30)) return false;
+    *nx_out = nx; *far_out = far;
+    return true;
+}
+
 template <typename T> struct dev_buf {       // device scratch of the plan, freed on every exit path
     T *p = nullptr;
     ~dev_buf() { if (p) (void)hipFree(p); }
@@ -401,7 +649,73 @@ template <typename T> struct dev_buf {       // device scratch of the plan, free
     T *release() { T *r = p; p = nullptr; return r; }
 };
 
+
+// ---- host side of the direct build ----
+template <typename P>
+int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t *col, const double *val, int64_t ell_width, int64_t tail_nnz,
+        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out)
+{
+    VEXHIP_REQUIRE(out, "NULL output");
+    std::memset(out, 0, sizeof(*out));
+    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
+    if (std::getenv("VEXHIP_NO_GRID") || std::getenv("VEXHIP_NO_GRID_BUILD")) return 0;
+    if (!ptr || !col || !val || !deltas || !values || ndeltas < 4 || ndeltas > 7 || nvalues < 1 || nvalues > 255) return 0;
+    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < (1 << 23) && !force)) return 0;
+    if (x_last < 0 || x_last + 1 < rows || x_last >= (1ll << 31)) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    std::vector<int> table((size_t)ndeltas);
+    VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * (size_t)ndeltas, hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    long long nx = 0, far = 0;
+    if (!grid_diagonals(table, rows, &nx, &far) || nx > 4096) return 0;         // (the line's seven position rows live in LDS)
+    const long long ny = far / nx, lines = rows / nx, nz = (lines + ny - 1) / ny;
+    if (nz < 4 && !force) return 0;
+    grid_geometry geo;
+    if (!grid_geometry_for(dev, nx, ny, nz, &geo)) return 0;
+
+    // control block: [keys GB_KEYS x 8][ids GB_KEYS x 4][count][flags][uses GB_MAX_CLASSES x 4]
+    const size_t ctl_bytes = GB_KEYS * 8 + GB_KEYS * 4 + 8 + GB_MAX_CLASSES * 4;
+    dev_buf<unsigned char> d_ctl, d_table; dev_buf<int> d_cls;
+    VEXHIP_TRY(d_ctl.alloc(ctl_bytes)); VEXHIP_TRY(d_cls.alloc((size_t)lines)); VEXHIP_TRY(d_table.alloc((size_t)GB_MAX_CLASSES * 7 * (size_t)geo.pitch));
+    gb_dev g;
+    g.n = rows; g.lines = lines; g.far = far; g.nx = (int)nx; g.nvalues = nvalues; g.pitch = (int)geo.pitch; g.cap = GB_MAX_CLASSES;
+    g.keys = reinterpret_cast<unsigned long long *>(d_ctl.p);
+    g.ids = reinterpret_cast<int *>(d_ctl.p + GB_KEYS * 8);
+    g.count = g.ids + GB_KEYS; g.flags = g.count + 1; g.uses = g.flags + 1;
+    g.table = d_table.p; g.line_class = d_cls.p;
+    VEXHIP_TRY(hipMemsetAsync(d_ctl.p, 0, ctl_bytes, s));
+    VEXHIP_TRY(hipMemsetAsync(g.ids, 0xff, GB_KEYS * 4, s));                     // -1: no number yet
+    const size_t lds = GB_VSLOTS * 8 + GB_VSLOTS + 520 * 8 + GB_CAP * 4 + GB_CAP + ((7 * (size_t)geo.pitch + 15) / 16) * 16 + 16 * 8;
+    const long long cus = std::max(1, info(dev).cus);
+    const unsigned wgs = (unsigned)std::min<long long>(lines, cus * std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)(lds + 2048))));
+    grid_build_kernel<P><<<wgs, 256, lds, s>>>(ptr, col, val, values, g);
+    VEXHIP_LAUNCH_CHECK();
+    int res[2 + GB_MAX_CLASSES];
+    VEXHIP_TRY(hipMemcpyAsync(res, g.count, sizeof(res), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    if (std::getenv("VEXHIP_DEBUG")) std::fprintf(stderr, "grid build: nx %lld ny %lld lines %lld classes %d flags %d\n", nx, ny, lines, res[0], res[1]);
+    if (res[1] != 0 || res[0] < 1 || res[0] > GB_MAX_CLASSES) return 0;         // not a matrix for this storage: the classic set-up takes over
+    const int nclasses = res[0];
+    const int *uses = res + 2;
+    const int hot = (int)(std::max_element(uses, uses + nclasses) - uses);
+    if ((lines - uses[hot]) * 4 > lines && !force) return 0;
+    grid_fill_plan(out, nx, ny, nz, geo, hot, nclasses, x_last);
+    out->line_class = d_cls.release(); out->table = d_table.release();
+    out->usable = 1;
+    return 0;
+}
+
 } // namespace
+
+// internal entry points of the direct build (spmat.hip)
+int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
+        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out)
+{ return grid_build<int32_t>(dev, stream, rows, ptr, col, val, w, tail, deltas, ndeltas, values, nvalues, x_last, out); }
+int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
+        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out)
+{ return grid_build<long long>(dev, stream, rows, ptr, col, val, w, tail, deltas, ndeltas, values, nvalues, x_last, out); }
+
 } // namespace vexhip
 
 using namespace vexhip;
@@ -425,13 +739,8 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     std::vector<int> table((size_t)ndeltas);
     VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * (size_t)ndeltas, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
-    // the diagonals: a subset of {0, +-1, +-nx, +-P} that names 1 < nx < P, P a multiple of nx
-    std::vector<long long> mags;
-    for (int d : table) { const long long a = std::llabs((long long)d); if (a && std::find(mags.begin(), mags.end(), a) == mags.end()) mags.push_back(a); }
-    std::sort(mags.begin(), mags.end());
-    if (mags.size() != 3 || mags[0] != 1) return 0;
-    const long long nx = mags[1], far = mags[2];
-    if (nx < 8 || far % nx != 0 || far / nx < 2 || rows % nx != 0 || far > (1ll << 30)) return 0;
+    long long nx = 0, far = 0;
+    if (!grid_diagonals(table, rows, &nx, &far)) return 0;
     const long long ny = far / nx, lines = rows / nx, nz = (lines + ny - 1) / ny;
     if (nz < 4 && !force) return 0;
 
@@ -475,42 +784,9 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     const int hot = (int)(std::max_element(uses.begin(), uses.end()) - uses.begin());
     if ((lines - uses[(size_t)hot]) * 4 > lines && !force) return 0;         // each change of the other class is a decode, a step with another class reads its values from LDS
 
-    // geometry: segments of <= 512 rows (even), lanes for one segment, planes per workgroup
-    const long long segs = (nx + 511) / 512;
-    long long seg_len = (nx + segs - 1) / segs; seg_len += seg_len & 1;
-    const int threads = (int)std::min<long long>(256, ((seg_len + 1) / 2 + 63) / 64 * 64);
-    const long long pitch = (segs * 512 + 2 + 15) / 16 * 16;
-    const long long tiles = (ny + 1) / 2 * segs;
-    const long long cus = std::max(1, info(dev).cus);
-    // Planes per workgroup.  Few, long workgroups (plane.hip: every workgroup re-reads the planes around its walk) -- but
-    //   * lines that are not 512 points long want at least ~6 waves per CU (their requests straddle cache lines, a wave hides
-    //     less of the latency by itself), and
-    //   * the workgroups should fill the CUs EVENLY: all of them are resident at once, the ones that share a CU with more
-    //     neighbours fall behind, and tiles that are not at the same plane at the same time fetch their halo lines from HBM
-    //     instead of from the L2 their neighbour filled.
-    // Measured (profiles/r04_grid_sweep.json; pair product 0.312 / 0.781 ms): 384^3 (192 tiles x 3 waves) walks of 48 / 96 /
-    // 128 / 192 / 384 planes = 0.202 / 0.184 / 0.217 / 0.227 / 0.349 ms -- 96 planes = 768 workgroups = 3 per CU exactly; 500^3
-    // (250 x 4) walks of 62 / 125 / 166 / 250 / 500 = 0.433 / 0.419 / 0.415 / 0.389 / 0.520 ms.  The estimate below orders all of
-    // these as measured: (workgroups per CU, rounded up) x (planes per walk + 6 for the start of a walk), times 6 / (waves per
-    // CU) where that is below 6.
-    const long long wpw = threads / 64;
-    long long chunks = 1;
-    {
-        double best = 0;
-        for (long long c = 1; c <= std::max(1ll, nz / 8); ++c) {
-            const long long per_cu = (tiles * c + cus - 1) / cus;
-            double est = (double)per_cu * (double)((nz + c - 1) / c + 6);
-            if (per_cu * wpw < 6) est *= 6.0 / (double)(per_cu * wpw);
-            if (c == 1 || est < best) { best = est; chunks = c; }
-        }
-    }
-    long long depth = (nz + chunks - 1) / chunks;
-    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
-    depth = std::min(depth, nz);
-    const long long plane_bytes = ny * nx * 8;
-    while ((depth + 4) * plane_bytes >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;
-    if ((depth + 4) * plane_bytes >= (1ll << 32)) return 0;
-
+    grid_geometry geo;
+    if (!grid_geometry_for(dev, nx, ny, nz, &geo)) return 0;
+    const long long pitch = geo.pitch;
     // the table of every class from its representative line, then every line against it
     dev_buf<long long> d_rep; dev_buf<int> d_cls; dev_buf<unsigned char> d_table;
     VEXHIP_TRY(d_rep.alloc((size_t)nclasses)); VEXHIP_TRY(d_cls.alloc((size_t)lines)); VEXHIP_TRY(d_table.alloc((size_t)nclasses * 7 * (size_t)pitch));
@@ -524,12 +800,7 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     VEXHIP_TRY(hipStreamSynchronize(s));
     if (bad) return 0;                            // two different lines with one hash: not this product's matrix
 
-    out->nx = (int32_t)nx; out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth;
-    out->segments = (int32_t)segs; out->segment_rows = (int32_t)seg_len; out->threads = threads;
-    out->hot_class = hot; out->classes = nclasses; out->pitch = (int32_t)pitch;
-    out->store_policy = 1;
-    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
-    out->x_last = x_last;
+    grid_fill_plan(out, nx, ny, nz, geo, hot, nclasses, x_last);
     out->line_class = d_cls.release(); out->table = d_table.release();
     out->usable = 1;
     return 0;

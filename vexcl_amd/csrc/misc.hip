@@ -245,13 +245,19 @@ int hell_analyze(int dev, void *stream, int64_t n, const P *ptr,
     const int cap = 4096;                      // widths above this share one bucket
     unsigned long long *d = nullptr;           // [0] max (as int), [1] tail total, [2..] histogram
     size_t bytes = sizeof(unsigned long long) * (size_t)(cap + 3);
+    setup_trace trace(s);
     VEXHIP_TRY(hipMalloc(&d, bytes));
+    trace.mark("  width: hipMalloc");
     VEXHIP_TRY(hipMemsetAsync(d, 0, bytes, s));
+    trace.mark("  width: memset");
     width_max_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, ptr, reinterpret_cast<int *>(d));
+    trace.mark("  width: max kernel");
     width_hist_kernel<P><<<grid_for(dev, n), 256, 0, s>>>(n, ptr, cap, d + 2);
+    trace.mark("  width: hist kernel");
     std::vector<unsigned long long> h(cap + 3);
     VEXHIP_TRY(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
+    trace.mark("  width: D2H");
     int64_t maxw = (int64_t)(int)(h[0] & 0xffffffffu);
     // hybrid_ell.inl:103-110: smallest i with 3 * (#rows wider than i) < n
     const double ell_vs_csr = 3.0;
@@ -268,6 +274,7 @@ int hell_analyze(int dev, void *stream, int64_t n, const P *ptr,
         *tail_nnz = (int64_t)t;
     }
     VEXHIP_TRY(hipFree(d));
+    trace.mark("  width: hipFree");
     *ell_width = w;
     return 0;
 }

@@ -51,6 +51,7 @@ struct plane_dev {
     int hot;                 // dictionary block decoded into registers with scalar masks
     int w;                   // ELL width (<= 8)
     int far;                 // 512 * ny
+    int pitch;               // 0: `pool` holds SELL-512 code blocks; > 0: class tables of the grid storage ([class][7 positions][pitch] value codes, grid.hip)
 };
 
 __device__ __forceinline__ double shift_from_lower_lane(double v, double edge) {       // lane i <- lane i - 1, lane 0 <- edge
@@ -116,6 +117,21 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     // ---- a dictionary block -> values (into s_other) and validity (returned) of this lane's rows at the seven positions ----
     const int wp = (pd.w + 1) >> 1;
     auto decode = [&](int blk) -> unsigned {
+        if (pd.pitch > 0) {                      // the matrix stored by grid line (grid.hip): a value code per position and row, 255 = no entry
+            const char *tb = pool + (long long)blk * 7 * pd.pitch + 2 * t;
+            unsigned bits = 0;
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const unsigned c2 = *reinterpret_cast<const unsigned short *>(tb + (long long)p * pd.pitch);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned code = (c2 >> (8 * r)) & 255u;
+                    s_other[2 * p + r][t] = s_value[code];            // entry 255 of the value table is 0.0
+                    bits |= (code != 255u ? 1u : 0u) << (2 * p + r);
+                }
+            }
+            return bits;
+        }
         const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * ((long long)wp * 2048)) + t;
         unsigned dcw[4], vcw[4];                // diagonal codes, value codes: one word per pair of ELL columns
 #pragma unroll
@@ -331,6 +347,51 @@ void stream_copy_kernel(const double *__restrict__ x, double *__restrict__ y, lo
 
 using namespace vexhip;
 
+// lines per workgroup (2 or 4), planes per workgroup, store policy of a plane plan; false: the walk does not fit 32-bit offsets
+static bool plane_geometry(int dev, long long ny, long long nz, int hot, vexhip_plane *out)
+{
+    const long long cus = std::max(1, info(dev).cus);
+    auto depth_for = [&](long long tl) {
+        const long long tiles = ny / tl;
+        const long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
+        return (nz + chunks - 1) / chunks;
+    };
+    long long tile = 2;
+    if (const char *e = std::getenv("VEXHIP_PLANE_TILE")) tile = (std::atoi(e) == 4 && ny % 4 == 0) ? 4 : 2;
+    long long depth = depth_for(tile);
+    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
+    depth = std::min(depth, nz);
+    while ((depth + 4) * ny * 4096 >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;      // 32-bit byte offsets inside a workgroup's walk
+    if ((depth + 4) * ny * 4096 >= (1ll << 32)) return false;
+    out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth; out->hot_block = hot; out->tile = (int32_t)tile;
+    // Cache policy of the y stores: 0 = non-temporal, 1 = non-temporal + sc1, 2 = sc0 sc1 (write-through, the line leaves the L2:
+    // more of it is left for the halo lines of x), 3 = plain.  Same sweeps, tile 4 x 256: 0.395 / 0.393 / 0.384 / 0.387 ms;
+    // tile 2 x 512: 0.395 / 0.391 / 0.396 / 0.401.  VEXHIP_PLANE_STORE overrides.
+    out->store_policy = tile == 4 ? 2 : 1;
+    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
+    return true;
+}
+
+namespace vexhip {
+// The plane plan of a matrix stored by grid line (grid.hip grid_build) whose lines are 512 points long: the plane kernel reads the
+// class tables instead of SELL-512 code blocks (table_pitch > 0); a line IS a slice, its class takes the place of its block.
+// The build has checked what the plan checks on dictionary blocks (diagonals, positions ascending, few lines off the hot class).
+int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_plane *out)
+{
+    VEXHIP_REQUIRE(grid && out, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;
+    if (!grid->usable || grid->nx != PL_ROWS || grid->segments != 1 || rows % PL_ROWS != 0) return 0;
+    const long long ny = grid->lines_per_plane, nz = grid->planes;
+    if (ny < 4 || ny % 2 != 0 || (nz < 4 && !force) || (rows / PL_ROWS < 64 && !force)) return 0;
+    if ((grid->x_last + 1) % PL_ROWS != 0 || grid->x_last + 1 < rows) return 0;
+    if (!plane_geometry(dev, ny, nz, grid->hot_class, out)) return 0;
+    out->table_pitch = grid->pitch;
+    out->x_last = grid->x_last; out->usable = 1;
+    return 0;
+}
+} // namespace vexhip
+
 extern "C" {
 
 int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
@@ -397,25 +458,7 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
     // halo requests (HBM read 1.04 x instead of 1.14 x of x at depth 128) but needs 164 registers and is not faster.  So: two
     // lines, about one workgroup per CU.  The time also depends on where x and y lie relative to each other (0.378 - 0.41 ms for
     // the same kernel, r04_plane_offsets.json; the copy kernel and the march product do not show it).
-    const long long cus = std::max(1, info(dev).cus);
-    auto depth_for = [&](long long tl) {
-        const long long tiles = ny / tl;
-        const long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
-        return (nz + chunks - 1) / chunks;
-    };
-    long long tile = 2;
-    if (const char *e = std::getenv("VEXHIP_PLANE_TILE")) tile = (std::atoi(e) == 4 && ny % 4 == 0) ? 4 : 2;
-    long long depth = depth_for(tile);
-    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
-    depth = std::min(depth, nz);
-    while ((depth + 4) * ny * 4096 >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;      // 32-bit byte offsets inside a workgroup's walk
-    if ((depth + 4) * ny * 4096 >= (1ll << 32)) return 0;
-    out->lines_per_plane = (int32_t)ny; out->planes = (int32_t)nz; out->depth = (int32_t)depth; out->hot_block = hot; out->tile = (int32_t)tile;
-    // Cache policy of the y stores: 0 = non-temporal, 1 = non-temporal + sc1, 2 = sc0 sc1 (write-through, the line leaves the L2:
-    // more of it is left for the halo lines of x), 3 = plain.  Same sweeps, tile 4 x 256: 0.395 / 0.393 / 0.384 / 0.387 ms;
-    // tile 2 x 512: 0.395 / 0.391 / 0.396 / 0.401.  VEXHIP_PLANE_STORE overrides.
-    out->store_policy = tile == 4 ? 2 : 1;
-    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
+    if (!plane_geometry(dev, ny, nz, hot, out)) return 0;
     out->x_last = x_last; out->usable = 1;
     return 0;
 }
@@ -425,6 +468,7 @@ int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double al
 {
     VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
     VEXHIP_REQUIRE(n > 0 && n % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
+    VEXHIP_REQUIRE(plane->table_pitch == 0 || plane->table_pitch >= PL_ROWS + 2, "bad plane plan (table pitch)");
     VEXHIP_REQUIRE((plane->tile == 2 || plane->tile == 4) && plane->lines_per_plane >= 4 && plane->lines_per_plane % plane->tile == 0 && plane->depth >= 1 && plane->planes >= 1
                    && (plane->x_last + 1) % PL_ROWS == 0
                    && ((long long)plane->depth + 4) * plane->lines_per_plane * 4096 < (1ll << 32), "bad plane plan");
@@ -434,6 +478,7 @@ int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double al
     pd.nslices = n / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
     pd.ny = plane->lines_per_plane; pd.nz = plane->planes; pd.depth = plane->depth;
     pd.tiles = pd.ny / plane->tile; pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
+    pd.pitch = plane->table_pitch;
     const long long chunks = (pd.nz + pd.depth - 1) / pd.depth;
     const long long grid = 8ll * pd.tpx * chunks;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");

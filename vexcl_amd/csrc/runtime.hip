@@ -42,6 +42,21 @@ const device_info &info(int dev) {
         if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
             cache[dev].cus = p.multiProcessorCount;
             cache[dev].ok = true;
+            // HIP sets up its staging path for pageable host memory at the first copy that needs it: 6.7 ms for a 32 KiB
+            // read-back, measured inside the first matrix set-up of a process (VEXHIP_SETUP_TRACE).  Pay it here, when the
+            // library first meets the device (context creation), not in the first set-up.
+            int cur = -1;
+            if (hipGetDevice(&cur) == hipSuccess && hipSetDevice(dev) == hipSuccess) {
+                void *d = nullptr;
+                if (hipMalloc(&d, 1 << 16) == hipSuccess) {
+                    std::vector<char> h(1 << 16);
+                    (void)hipMemcpy(h.data(), d, h.size(), hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
+                    (void)hipFree(d);
+                }
+                (void)hipGetLastError();
+                (void)hipSetDevice(cur);
+            }
         } else {
             cache[dev].cus = 256;
         }

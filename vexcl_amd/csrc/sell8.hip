@@ -1380,7 +1380,9 @@ int analyze_fused(int dev, void *stream, int64_t n, const P *ptr, const int *col
     // [int set: HASH_SLOTS + 2 info][value set: HASH_SLOTS B + 2 int info][max col]
     const size_t dbytes = sizeof(int) * (HASH_SLOTS + 2), vbytes = sizeof(B) * HASH_SLOTS + 2 * sizeof(int);
     char *d = nullptr;
+    setup_trace trace(s);
     VEXHIP_TRY(hipMalloc(&d, dbytes + vbytes + sizeof(int) + 64));
+    trace.mark("  fused: hipMalloc");
     int *dset = reinterpret_cast<int *>(d);
     B *vset = reinterpret_cast<B *>(d + ((dbytes + 15) / 16) * 16);
     int *vinfo = reinterpret_cast<int *>(vset + HASH_SLOTS);
@@ -1393,16 +1395,20 @@ int analyze_fused(int dev, void *stream, int64_t n, const P *ptr, const int *col
     if (e == hipSuccess) e = hipMemsetAsync(dmax, 0xff, sizeof(int), s);
     std::vector<B> hv(HASH_SLOTS);
     int vi[2] = {0, 0}, hmax = -1;
+    trace.mark("  fused: H2D + memsets");
     if (e == hipSuccess) {
         analyze_fused_kernel<V, P><<<grid_for(dev, n), 256, 0, s>>>(n, (int)std::min<int64_t>(w, INT_MAX), ptr, col, val, dset, dset + HASH_SLOTS, vset, vinfo, dmax);
         e = hipGetLastError();
     }
+    trace.mark("  fused: kernel");
     if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), dset, dbytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(hv.data(), vset, sizeof(B) * HASH_SLOTS, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(vi, vinfo, sizeof(vi), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    trace.mark("  fused: D2H");
     (void)hipFree(d);
+    trace.mark("  fused: hipFree");
     VEXHIP_TRY(e);
     g_max_col_hint = hmax; g_hint_ptr = ptr; g_hint_n = n;
     if (!(hd[HASH_SLOTS + 1] != 0 || hd[HASH_SLOTS] > 254 || hd[HASH_SLOTS] < 1)) {
@@ -1665,6 +1671,8 @@ int analyze_fused_p64(int dev, void *stream, int64_t n, const long long *ptr, co
 int analyze_fused_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, const float *val, int64_t w, int32_t *deltas, int *ndeltas, float *values, int *nvalues)
 { return analyze_fused<float, long long>(dev, stream, n, ptr, col, val, w, deltas, ndeltas, values, nvalues); }
 void clear_max_col_hint() { g_max_col_hint = -1; g_hint_ptr = nullptr; g_hint_n = -1; }
+// the largest ELL column the fused analysis of THIS matrix saw on this thread (-1: no such analysis): the direct grid build (grid.hip)
+long long analysis_max_col(const void *ptr, long long n) { return (g_max_col_hint >= 0 && g_hint_ptr == ptr && g_hint_n == n) ? g_max_col_hint : -1; }
 int sell8_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int64_t w, int32_t *deltas, int *ndeltas)
 { return sell8_analyze<long long>(dev, stream, n, ptr, col, w, deltas, ndeltas); }
 int sell8v_analyze_p64(int dev, void *stream, int64_t n, const long long *ptr, const double *val, int64_t w, double *values, int *nvalues)

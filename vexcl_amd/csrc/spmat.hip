@@ -10,7 +10,6 @@
 // Both front ends now call create / apply / destroy.  Built from DEVICE CSR arrays: no host staging.
 #include "common.hpp"
 
-#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -41,6 +40,12 @@ int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const 
 int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y, const vexhip_traversal *tr);
 int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y, const vexhip_traversal *tr);
 int csr_traversal_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int rows_per_block, vexhip_traversal *traversal);
+long long analysis_max_col(const void *ptr, long long n);
+int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
+        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out);
+int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
+        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out);
+int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_plane *out);
 
 namespace {
 
@@ -62,21 +67,7 @@ struct spmat {
     vexhip_march march = {0, 0, 0, 0, 0, 0, {0, 0, 0}};      // march product (sell8.hip): usable when the slices repeat in runs and the near diagonals fit a ring
     vexhip_plane plane = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // plane product (plane.hip): 7-point pattern on 512-point lines; preferred to the march product
     vexhip_grid grid = {};                                         // grid product (grid.hip): 7-point pattern on lines of any length, where the plane product does not apply
-};
-
-// VEXHIP_SETUP_TRACE=1: host wall time of every stage of a set-up on stderr (each mark synchronises the stream: the trace is
-// for finding where a set-up spends its time, the figures of a traced run are not those of an untraced one)
-struct setup_trace {
-    bool on; hipStream_t s; std::chrono::steady_clock::time_point t0, last;
-    explicit setup_trace(hipStream_t st) : on(std::getenv("VEXHIP_SETUP_TRACE") != nullptr), s(st) { t0 = last = std::chrono::steady_clock::now(); }
-    void mark(const char *what) {
-        if (!on) return;
-        (void)hipStreamSynchronize(s);
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[vexhip set-up] %-28s %8.3f ms  (at %8.3f)\n", what,
-                     std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
-        last = now;
-    }
+    bool direct = false;                                           // stored by grid line straight from the CSR arrays (grid.hip grid_build): no SELL-512 slices, no dictionary
 };
 
 template <typename T> int dmalloc(T **p, size_t count) {
@@ -196,7 +187,7 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
             const int vb = A->value_type == VEXHIP_F64 ? 8 : 4;
             if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, vb,
                                                   &A->trav, vexhip_sell8_last_fill_max_col(), &A->march)) return rc2;
-            if (!(flags & VEXHIP_SPMAT_NO_PLANE))
+            if (!(flags & VEXHIP_SPMAT_NO_PLANE) && !std::getenv("VEXHIP_NO_PLANE512"))      // (A/B: the grid product on 512-point lines)
                 if (int rc2 = vexhip_sell8_plane_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, A->pool, nb, A->ell_w, A->n, A->tail, vb,
                                                       vexhip_sell8_last_fill_max_col(), &A->plane)) return rc2;
         }
@@ -306,6 +297,27 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         if (int rc = dmalloc(&A->deltas, 256)) return rc;
         if (int rc = S::d_analyze(dev, stream, n, ptr, col, w, A->deltas, &nd)) return rc;
     }
+    if (nd > 0 && nv > 0 && !tail) {
+        // A 7-point pattern on a grid, a handful of distinct values: stored by grid line straight from the CSR arrays (one more pass
+        // over them, no per-slice codes, no dictionary, no plans from read-backs).  Declined (usable = 0): the SELL-512 set-up below.
+        if constexpr (std::is_same<V, double>::value) {
+            const long long x_last = analysis_max_col(ptr, n);
+            if (x_last >= 0 && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE | VEXHIP_SPMAT_NO_GRID_BUILD))) {
+                int rc;
+                if constexpr (p64) rc = grid_build_p64(dev, stream, n, ptr, col, val, w, tail, A->deltas, nd, (const double *)A->values, nv, x_last, &A->grid);
+                else rc = grid_build_p32(dev, stream, n, ptr, col, val, w, tail, A->deltas, nd, (const double *)A->values, nv, x_last, &A->grid);
+                if (rc) return rc;
+                trace.mark("grid build");
+                if (A->grid.usable) {
+                    A->ndeltas = nd; A->nvalues = nv; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
+                    if (!std::getenv("VEXHIP_NO_PLANE512"))
+                        if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
+                    clear_max_col_hint();
+                    return 0;
+                }
+            }
+        }
+    }
     if (nd > 0) {
         A->ndeltas = nd;
         if (nv > 0) {
@@ -375,11 +387,11 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
     switch (A->format) {
         case VEXHIP_SPMAT_SELL8V:
             if constexpr (std::is_same<V, double>::value)
-                if (A->blocks && A->plane.usable && g_sell8_variant == 0 && !A->tail)
-                    return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas,
-                                                            (const double *)A->values, x, y, &A->plane);
+                if ((A->blocks || A->direct) && A->plane.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
+                    return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
+                                                            A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
             if constexpr (std::is_same<V, double>::value)
-                if (A->grid.usable && g_sell8_variant == 0 && !A->tail)
+                if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
                     return vexhip_spmv_sell8v_grid_f64(A->dev, stream, A->n, alpha, append, (const double *)A->values, x, y, &A->grid);
             if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
             return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
@@ -400,7 +412,7 @@ int apply_multi(const spmat *A, void *stream, int k, V alpha, int append, const 
     VEXHIP_REQUIRE(A && A->value_type == F::type, "matrix and vector value types differ");
     VEXHIP_REQUIRE(k >= 1 && x && y, "bad argument");
     if (A->n == 0) return 0;
-    if (A->nnz == 0 || A->format == VEXHIP_SPMAT_CSR) {          // no multi-vector kernel: one product per component
+    if (A->nnz == 0 || A->format == VEXHIP_SPMAT_CSR || A->direct) {          // no multi-vector kernel (stored by grid line: k plane / grid products beat it): one product per component
         for (int c = 0; c < k; ++c) if (int rc = apply<V>(A, stream, alpha, append, x[c], y[c])) return rc;
         return 0;
     }

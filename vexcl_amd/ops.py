@@ -355,13 +355,14 @@ class SpMat:
 
     _FORMATS = {"sell": _capi.SPMAT_AUTO, "sell8": _capi.SPMAT_SELL8, "sell32": _capi.SPMAT_SELL, "csr": _capi.SPMAT_CSR}
 
-    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True, march=True, plane=True):
+    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True, march=True, plane=True, direct=True):
         """dictionary=False keeps one code block per slice even when the slices of a value-coded matrix repeat
         (VEXHIP_SPMAT_NO_DICTIONARY: A/B and tests); march=False keeps the pair product where the march product (x window
         of the near diagonals in an LDS ring carried along a run of slices) or the plane product would apply
         (VEXHIP_SPMAT_NO_MARCH); plane=False keeps the march product where the plane product (round 4: two grid lines per
         workgroup walked through the planes, neighbours in registers) or the grid product (the same walk for lines of any
-        length) would apply (VEXHIP_SPMAT_NO_PLANE)."""
+        length) would apply (VEXHIP_SPMAT_NO_PLANE); direct=False builds the SELL-512 storage (slices, dictionary, plans) even where
+        the matrix could be stored by grid line straight from the CSR arrays (VEXHIP_SPMAT_NO_GRID_BUILD)."""
         self.ptr, self.col, self.val = ptr, col, val
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
@@ -376,6 +377,7 @@ class SpMat:
         self.march = None
         self.plane = None
         self.grid = None
+        self.direct = False
         self.dtype = val.dtype
         if fmt == "hell":                        # the reference's column-major hybrid ELL (kept for A/B and sparse::ell)
             self.hell = HybridELL(ptr, col, val)
@@ -393,7 +395,7 @@ class SpMat:
         create(
             _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
             _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH)
-            | (0 if plane else _capi.SPMAT_NO_PLANE), ctypes.byref(h))
+            | (0 if plane else _capi.SPMAT_NO_PLANE) | (0 if direct else _capi.SPMAT_NO_GRID_BUILD), ctypes.byref(h))
         self.handle = h
         info = _capi.SpMatInfo()
         L.spmat_get_info(h, ctypes.byref(info))
@@ -404,13 +406,16 @@ class SpMat:
                        "far": [int(info.march.far[k]) for k in range(info.march.nfar)]}
                       if info.march.usable else None)              # not None: apply() runs the march product
         self.plane = ({"lines_per_plane": int(info.plane.lines_per_plane), "planes": int(info.plane.planes), "depth": int(info.plane.depth),
-                       "hot_block": int(info.plane.hot_block), "tile": int(info.plane.tile), "store_policy": int(info.plane.store_policy), "x_last": int(info.plane.x_last)}
+                       "hot_block": int(info.plane.hot_block), "tile": int(info.plane.tile), "store_policy": int(info.plane.store_policy), "x_last": int(info.plane.x_last),
+                       "table_pitch": int(info.plane.table_pitch)}
                       if info.plane.usable else None)              # not None: apply() runs the plane product (fp64)
         g = info.grid
         self.grid = ({"nx": int(g.nx), "lines_per_plane": int(g.lines_per_plane), "planes": int(g.planes), "depth": int(g.depth),
                       "segments": int(g.segments), "segment_rows": int(g.segment_rows), "threads": int(g.threads), "hot_class": int(g.hot_class),
                       "classes": int(g.classes), "store_policy": int(g.store_policy), "x_last": int(g.x_last)}
-                     if g.usable else None)                        # not None: apply() runs the grid product (fp64; grids of any line length)
+                     if g.usable else None)                        # not None: the matrix is stored by grid line; apply() runs the grid product (fp64; grids of
+                                                                   # any line length) unless `plane` is set too (512-point lines: the plane kernel reads the same tables)
+        self.direct = bool(g.usable and not info.sell and not info.code_pool)      # stored by grid line straight from the CSR arrays: no SELL-512 slices
         self.fmt = "csr" if self.storage == "csr" else "sell"      # SELL without an ELL part degrades to CSR
         if self.fmt == "sell":
             self.hell = _SellInfo(info)
