@@ -1,6 +1,7 @@
 // GPU: vex::SpMat and vex::sparse::* against a host recomputation, as the
 // reference's tests/spmv.cpp:10-260 and tests/sparse_matrices.cpp:66-237 do,
 // on the 2-"device" context (partitioning + ghost exchange are exercised).
+#include <cstdlib>
 #include <array>
 #include "vex_test.hpp"
 
@@ -351,6 +352,24 @@ TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp
             CHECK_SMALL(a[i] - want3[i], 1e-10 * 13 * h2);
             CHECK_SMALL(b[i] - want3[i], 1e-10 * 13 * h2);
         }
+        // round 4: the matrix stored by grid line straight from the CSR arrays (the default above 2^23 rows; forced here on the
+        // 64 x 64 x 64 grid): no slices, no dictionary -- the inline terminal reads the class of the row's line and the class table
+        setenv("VEXHIP_PLANE_FORCE", "1", 1);
+        poisson(g2, row2, col2, val2);
+        vex::SpMat<double, unsigned> G(queue, N2, N2, row2.data(), col2.data(), val2.data());
+        unsetenv("VEXHIP_PLANE_FORCE");
+        CHECK(G.storage_info(0).grid.usable && G.storage_info(0).grid.nx == 64 && G.storage_info(0).grid.classes == 2
+              && G.storage_info(0).sell == nullptr && G.storage_info(0).code_pool == nullptr && G.storage_info(0).dictionary_blocks == 0);
+        DY = G * DX;
+        DZ = vex::make_inline(G * DX);
+        vex::copy(DY, a); vex::copy(DZ, b);
+        for (size_t i = 0; i < N2; ++i) {
+            CHECK_SMALL(a[i] - want2[i], 1e-10 * 12 * h2);
+            CHECK_SMALL(b[i] - want2[i], 1e-10 * 12 * h2);
+        }
+        DY = DX - 0.5 * (G * DX);
+        vex::copy(DY, a);
+        for (size_t i = 0; i < N2; i += 7) CHECK_SMALL(a[i] - (x2[i] - 0.5 * want2[i]), 1e-10 * 12 * h2);
     }
 }
 

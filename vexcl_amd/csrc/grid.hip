@@ -336,6 +336,7 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
             if (__ballot(differ) && (t & 63) == 0) atomicOr(g.flags, GB_COLLISION);
         }
         if (t == 0) { g.line_class[line] = id; ++s_uses[id]; }
+        __syncthreads();                                        // the line's rows (s_sig) are compared / copied before the next line overwrites them
     }
     __syncthreads();
     for (int i = t; i < g.cap; i += 256) if (s_uses[i]) atomicAdd(&g.uses[i], s_uses[i]);
