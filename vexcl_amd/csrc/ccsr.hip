@@ -358,3 +358,5 @@ int vexhip_ccsr_to_csr_f32_i32(int dev, void *stream, int64_t n, const uint32_t 
 int vexhip_spmv_ccsr_set_rows_per_lane(int rpl) { g_ccsr_rpl = rpl; return 0; }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(ccsr)

@@ -991,3 +991,5 @@ int vexhip_comm_rccl_info(const vexhip_comm *h, int *nranks, int *device, int *u
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(comm)

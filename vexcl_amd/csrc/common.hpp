@@ -61,5 +61,15 @@ struct setup_trace {
 
 #define VEXHIP_SET_DEVICE(dev) VEXHIP_TRY(hipSetDevice(dev))
 
+// Every .hip file of the library is its own code object, and HIP loads a code object when the first kernel of it is launched on
+// a device: 4.8 ms for sell8.hip's, measured inside the first matrix set-up of a process (VEXHIP_SETUP_TRACE: the first launch
+// of the analysis kernel took 9.4 ms, every later one 4.9).  Each file defines an empty kernel; info(dev) launches them all when
+// the library first meets a device (context creation), so that no set-up or product pays for the loading.
+#define VEXHIP_WARM_TU(name)                                                   \
+    namespace vexhip {                                                         \
+    namespace { __global__ void warm_##name##_kernel() {} }                    \
+    void warm_##name() { warm_##name##_kernel<<<1, 64>>>(); }                  \
+    }
+
 // launch check: hipGetLastError right after a <<<>>> launch
 #define VEXHIP_LAUNCH_CHECK() VEXHIP_TRY(hipGetLastError())

@@ -910,3 +910,5 @@ int vexhip_fft_exec(void *plan, void *stream, const void *in, void *out) {
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(fft)

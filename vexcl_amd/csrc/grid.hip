@@ -331,9 +331,17 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
             __syncthreads();
             if (t == 0) __hip_atomic_store(&g.ids[(unsigned)s_red[6]], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);    // ... before its number is
         } else {
-            bool differ = false;
-            for (int i = t; i < words; i += 256) differ = differ || __hip_atomic_load(tb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine[i];
-            if (__ballot(differ) && (t & 63) == 0) atomicOr(g.flags, GB_COLLISION);
+            // (plain loads: lane 0's acquire of the class number -- when this workgroup first met the class -- has invalidated what this
+            //  CU and its L2 held; the table does not change after it is published.  All loads of a trip are issued before the
+            //  first comparison: a chain of dependent loads here was a fifth of the kernel.)
+            unsigned diff = 0;
+            int i = t;
+            for (; i + 3 * 256 < words; i += 4 * 256) {
+                const unsigned a0 = tb[i], a1 = tb[i + 256], a2 = tb[i + 512], a3 = tb[i + 768];
+                diff |= (a0 ^ mine[i]) | (a1 ^ mine[i + 256]) | (a2 ^ mine[i + 512]) | (a3 ^ mine[i + 768]);
+            }
+            for (; i < words; i += 256) diff |= tb[i] ^ mine[i];
+            if (__ballot(diff != 0) && (t & 63) == 0) atomicOr(g.flags, GB_COLLISION);
         }
         if (t == 0) { g.line_class[line] = id; ++s_uses[id]; }
         __syncthreads();                                        // the line's rows (s_sig) are compared / copied before the next line overwrites them
@@ -850,3 +858,5 @@ int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, 
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(grid)

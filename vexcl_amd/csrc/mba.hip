@@ -289,3 +289,5 @@ extern "C" int vexhip_mba_fit(int dev, void *stream, int dtype, int ndim, const 
         return fit_dim<double>(dev, as_stream(stream), ndim, cmin, cmax, coo, val, npts, grid, levels, tol, xmin, hinv, n, stride, phi, phi_elems);
     return fit_dim<float>(dev, as_stream(stream), ndim, cmin, cmax, coo, val, npts, grid, levels, tol, xmin, hinv, n, stride, phi, phi_elems);
 }
+
+VEXHIP_WARM_TU(mba)

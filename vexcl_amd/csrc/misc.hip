@@ -397,3 +397,5 @@ int vexhip_hell_fill_f32_i32(int dev, void *stream, int64_t n,
 { return hell_fill<float, int32_t>(dev, stream, n, ptr, col, val, w, pitch, ell_col, ell_val, csr_ptr, csr_col, csr_val); }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(misc)

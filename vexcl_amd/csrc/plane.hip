@@ -509,3 +509,5 @@ int vexhip_stream_copy_f64(int dev, void *stream, const double *x, double *y, in
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(plane)

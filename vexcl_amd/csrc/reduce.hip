@@ -255,3 +255,5 @@ int vexhip_reduce_finish(int dev, void *stream, int op, int dtype, const void *p
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(reduce)

@@ -31,6 +31,22 @@ int fail(const char *file, int line, const std::string &what) {
     return 1;
 }
 
+void warm_misc();
+void warm_reduce();
+void warm_scan();
+void warm_sort();
+void warm_stencil();
+void warm_ccsr();
+void warm_sell8();
+void warm_plane();
+void warm_grid();
+void warm_spmm();
+void warm_spmv();
+void warm_split();
+void warm_comm();
+void warm_fft();
+void warm_mba();
+
 const device_info &info(int dev) {
     static std::mutex mx;
     static device_info cache[64];              // fixed storage: references stay valid across threads
@@ -54,6 +70,9 @@ const device_info &info(int dev) {
                     (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
                     (void)hipFree(d);
                 }
+                // ... and the code objects of the library's files (see VEXHIP_WARM_TU)
+                warm_misc(); warm_reduce(); warm_scan(); warm_sort(); warm_stencil(); warm_ccsr(); warm_sell8(); warm_plane(); warm_grid(); warm_spmm(); warm_spmv(); warm_split(); warm_comm(); warm_fft(); warm_mba();
+                (void)hipDeviceSynchronize();
                 (void)hipGetLastError();
                 (void)hipSetDevice(cur);
             }

@@ -425,3 +425,5 @@ int vexhip_scan(int dev, void *stream, int dtype, int exclusive, const void *ini
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(scan)

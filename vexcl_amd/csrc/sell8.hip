@@ -1874,3 +1874,5 @@ int vexhip_spmv_sell8_f32_i32(int dev, void *stream, int64_t n, float alpha, int
 { return spmv_sell8<float>(dev, stream, n, alpha, append, w, buf, deltas, cp, cc, cv, x, y, traversal); }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(sell8)

@@ -485,3 +485,5 @@ int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(sort)

@@ -202,3 +202,5 @@ int vexhip_csr_split_f32_i32(int dev, void *stream, int64_t n, const int32_t *pt
 { return split<float>(dev, stream, n, ptr, col, val, col_begin, col_end, 1, sizes, lptr, lcol, lval, rem_rows, rem_ptr, rem_col, rem_val, ghosts); }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(split)

@@ -397,3 +397,5 @@ int vexhip_spmm_sell8v_dict_f32_i32(int dev, void *stream, int64_t n, int nrhs, 
 { return spmm<float, 2>(dev, stream, n, nrhs, alpha, append, w, pool, deltas, values, cp, cc, cv, x, y, traversal, blocks); }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(spmm)

@@ -1046,3 +1046,5 @@ int vexhip_gather_f32_i32(int dev, void *stream, int64_t n, const int32_t *idx, 
 }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(spmv)

@@ -147,3 +147,5 @@ int vexhip_stencil_conv_f32(int dev, void *stream, int64_t n, int has_left, int 
 { return conv<float>(dev, stream, n, has_left, has_right, lhalo, rhalo, s, x, xrem, y, beta, alpha); }
 
 } // extern "C"
+
+VEXHIP_WARM_TU(stencil)
