@@ -28,6 +28,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -163,37 +164,76 @@ void grid_line_verify_kernel(codes_dev cd, long long lines, int nx, int pitch, c
 }
 
 
-// ---- the matrix by grid line straight from the CSR arrays (round 4: the set-up of grid matrices without the SELL-512 detour) ----
-// Once the analysis has named the diagonals {0, +-1, +-nx, +-P} and the (<= 255) values, ONE pass over the CSR arrays builds
-// what the grid / plane products read: a workgroup takes one grid line, stages the entries of 512 rows at a time in LDS with
-// coalesced loads (the value -> code look-up happens there, through a hash of the value table), every lane turns its two rows
-// into seven bytes each (code per position, 255 = no entry; the entries must ascend by position), the line's rows are hashed
-// and the line is looked up in a device-wide table of classes: the first workgroup to bring a hash writes the class table and
-// publishes its number, every later one compares its rows with that table byte by byte (a different line with the same hash
-// ends the build: the classic set-up takes over).  No per-slice codes are written (2.1 GB at 512^3) and nothing but a few
-// counters returns to the host.
+// ---- the matrix by grid line straight from the CSR arrays (round 4: the set-up of grid matrices in ONE pass over them) ----
+// A probe of a few thousand rows in the middle of the matrix names the diagonals; if they are {0, +-1, +-nx, +-P}, one kernel
+// reads the CSR arrays once and leaves what the grid / plane products read.  A workgroup takes one grid line at a time, 512 rows
+// of it at a time: the rows' entries are staged in LDS with coalesced loads -- a value becomes its code there: an LDS hash per workgroup in front of a device-wide
+// table that numbers the distinct values in the order they are first met -- every lane turns its two rows into seven bytes
+// each (code per position, 255 = no entry; the entries must ascend by position), the line's rows are hashed and the line is
+// looked up in a device-wide table of classes: the first workgroup to bring a hash writes the class table and publishes its
+// number, every later one compares its rows with that table byte by byte (a different line with the same hash ends the build:
+// the classic set-up takes over, as it does for rows that do not fit -- a diagonal outside the set, descending positions, more
+// than 254 values, more than 128 classes).  No per-slice codes are written (2.1 GB at 512^3), no second pass over the arrays
+// (the analysis of the classic set-up reads them once to find the tables, the fill a second time), nothing but a few counters
+// and the value table returns to the host.
 constexpr int GB_PIECE = 512;                 // rows staged at a time
 constexpr int GB_CAP = 8 * GB_PIECE;          // entries of a piece (rows with more than 8 entries have no place in this storage)
-constexpr int GB_VSLOTS = 512;                // LDS hash of the value table
+constexpr int GB_CHUNK = 8;                   // entries a lane requests together while staging a piece
+constexpr int GB_VSLOTS = 512;                // hash of the values: LDS per workgroup, and the device-wide table behind it
 constexpr int GB_KEYS = 1024;                 // device-wide table of line hashes
 constexpr int GB_KNOWN = 128;                 // classes a workgroup remembers
 constexpr int GB_MAX_CLASSES = 128;
+constexpr int GB_MAX_VALUES = 255;            // codes 0 .. 254 (255 = no entry)
 enum { GB_BAD_ROW = 1, GB_OVERFLOW = 2, GB_COLLISION = 4, GB_TIMEOUT = 8 };
+enum { GBI_COUNT = 0, GBI_FLAGS, GBI_VCOUNT, GBI_POSMASK, GBI_MAXCOL, GBI_MAXLEN, GBI_USES = 8, GBI_INTS = 8 + GB_MAX_CLASSES };
 
 struct gb_dev {
     long long n, lines, far;
-    int nx, nvalues, pitch, cap;
-    unsigned long long *keys; int *ids; int *count; int *uses; int *flags;
+    int nx, pitch, pieces;
+    unsigned long long *keys; int *ids;                              // classes: hash of a line -> number
+    unsigned long long *vkeys; int *vstate; int *vcodes;             // values: bits -> code (vstate 0 empty, 1 being written, 2 ready)
+    int *ints;                                                       // GBI_*
     unsigned char *table; int *line_class;
 };
 
+__device__ __forceinline__ unsigned gb_vhash(unsigned long long bits) { return (unsigned)((bits * 0x9e3779b97f4a7c15ull) >> 55) & (GB_VSLOTS - 1); }
+
+// the device-wide code of a value: found, or numbered now (-1: the table is full / a writer never finished)
+__device__ int gb_global_value_code(unsigned long long bits, const gb_dev &g)
+{
+    unsigned h = gb_vhash(bits);
+    for (int probe = 0; probe < GB_VSLOTS; ++probe) {
+        int st = __hip_atomic_load(&g.vstate[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == 0) {
+            st = atomicCAS(&g.vstate[h], 0, 1);
+            if (st == 0) {                                           // this slot is ours: number the value, publish
+                int c = atomicAdd(&g.ints[GBI_VCOUNT], 1);
+                if (c >= GB_MAX_VALUES) { atomicOr(&g.ints[GBI_FLAGS], GB_OVERFLOW); c = -1; }
+                __hip_atomic_store(&g.vkeys[h], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g.vcodes[h], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g.vstate[h], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return c;
+            }
+        }
+        for (int spin = 0; st != 2 && spin < (1 << 22); ++spin) {    // the writer is running: a few hundred cycles
+            __builtin_amdgcn_s_sleep(2);
+            st = __hip_atomic_load(&g.vstate[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (st != 2) { atomicOr(&g.ints[GBI_FLAGS], GB_TIMEOUT); return -1; }
+        if (__hip_atomic_load(&g.vkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bits)
+            return __hip_atomic_load(&g.vcodes[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h = (h + 1) & (GB_VSLOTS - 1);
+    }
+    atomicOr(&g.ints[GBI_FLAGS], GB_OVERFLOW);
+    return -1;
+}
+
 template <typename P>
 __global__ __launch_bounds__(256)
-void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
-        const double *__restrict__ vtable, gb_dev g)
+void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val, gb_dev g)
 {
     extern __shared__ unsigned char gb_lds[];
-    // [value hash keys 512 x 8][value hash codes 512][row bounds 513 x 8][staged columns GB_CAP x 4][staged value codes GB_CAP][line 7 x pitch][scratch]
+    // [value hash keys 512 x 8][value hash codes 512][row bounds 520 x 8][staged columns GB_CAP x 4][staged value codes GB_CAP][line 7 x pitch][scratch]
     unsigned long long *s_vkey = reinterpret_cast<unsigned long long *>(gb_lds);
     unsigned char *s_vcode = gb_lds + GB_VSLOTS * 8;
     long long *s_ptr = reinterpret_cast<long long *>(s_vcode + GB_VSLOTS);
@@ -205,53 +245,91 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
     __shared__ int s_kid[GB_KNOWN];
     __shared__ int s_uses[GB_MAX_CLASSES];
     int known = 0;                                       // (lane 0's)
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
     if (t < GB_MAX_CLASSES) s_uses[t] = 0;
-
-    // the value table as an LDS hash: bits -> code (255 = not a value of the table)
+    // the workgroup's view of the value table: bits -> code (all ones = empty slot: a value with those bits -- a NaN -- declines)
     for (int i = t; i < GB_VSLOTS; i += 256) { s_vkey[i] = ~0ull; s_vcode[i] = 255; }
     __syncthreads();
-    if (t < g.nvalues) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(vtable[t]);
-        unsigned h = (unsigned)((bits * 0x9e3779b97f4a7c15ull) >> 55) & (GB_VSLOTS - 1);
-        for (int probe = 0; probe < GB_VSLOTS; ++probe) {
-            const unsigned long long old = atomicCAS(&s_vkey[h], ~0ull, bits);
-            if (old == ~0ull || old == bits) { s_vcode[h] = (unsigned char)t; break; }
-            h = (h + 1) & (GB_VSLOTS - 1);
-        }
-    }
-    __syncthreads();
-    // (a table value whose bits are all ones -- a NaN -- cannot be told from an empty slot: the analysis never codes such a matrix
-    //  with fewer than 2 values... it simply is not found and the build declines)
 
-    for (long long line = blockIdx.x; line < g.lines; line += gridDim.x) {
-        if (__hip_atomic_load(g.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;       // uniform: another workgroup gave up
-        for (int i = t; i < 7 * g.pitch; i += 256) s_sig[i] = GR_ABSENT;
-        unsigned long long hsum = 0;
-        bool bad = false;
+    unsigned posmask = 0; int maxcol = -1, maxlen = 0;
+    long long line = blockIdx.x; int pc = 0;
+    unsigned long long hsum = 0;
+    bool bad = false;
+    while (line < g.lines) {
+        const int r0 = pc * GB_PIECE;
+        const int rows = g.nx - r0 < GB_PIECE ? g.nx - r0 : GB_PIECE;
         const long long row_l = line * g.nx;
-        for (int r0 = 0; r0 < g.nx; r0 += GB_PIECE) {
-            const int rows = g.nx - r0 < GB_PIECE ? g.nx - r0 : GB_PIECE;
-            __syncthreads();                                    // the previous piece's staging is consumed, s_sig is initialised
-            for (int i = t; i <= rows; i += 256) s_ptr[i] = (long long)ptr[row_l + r0 + i];
-            __syncthreads();
-            const long long e0 = s_ptr[0];
-            const long long cnt = s_ptr[rows] - e0;
-            if (cnt < 0 || cnt > GB_CAP) { bad = true; break; }                         // uniform
-            for (int k = t; k < (int)cnt; k += 256) {
-                s_c[k] = col[e0 + k];
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(val[e0 + k]);
-                unsigned h = (unsigned)((bits * 0x9e3779b97f4a7c15ull) >> 55) & (GB_VSLOTS - 1);
-                unsigned code = 255;
+        long long nline = line; int npc = pc + 1;
+        if (npc == g.pieces) { nline = line + gridDim.x; npc = 0; }
+        // the piece's bounds (uniform) and its rows' (one or two per lane); requested before the barrier, used behind it
+        const long long e0 = (long long)ptr[row_l + r0];
+        const long long cnt64 = (long long)ptr[row_l + r0 + rows] - e0;
+        const int cnt = (cnt64 < 0 || cnt64 > GB_CAP) ? -1 : (int)cnt64;
+        long long my_ptr[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = t + 256 * u; my_ptr[u] = i <= rows ? (long long)ptr[row_l + r0 + i] : 0; }
+
+        if (pc == 0 && __hip_atomic_load(&g.ints[GBI_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;       // uniform: another workgroup gave up
+        __syncthreads();                                        // the previous trip is done with the staged entries and with the line's rows (compared / copied)
+        if (pc == 0) {
+            for (int i = t; i < 7 * g.pitch; i += 256) s_sig[i] = GR_ABSENT;       // (the rows below write into it behind the next barrier)
+            hsum = 0; bad = false;
+        }
+        if (cnt < 0) bad = true;                                // uniform
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = t + 256 * u; if (i <= rows) s_ptr[i] = my_ptr[u]; }
+        // GB_CHUNK entries per lane are requested together (14 dependent round trips per piece otherwise), then coded and staged
+        for (int base = 0; base < cnt; base += GB_CHUNK * 256) {
+            int n_c[GB_CHUNK]; double n_v[GB_CHUNK];
+#pragma unroll
+            for (int u = 0; u < GB_CHUNK; ++u) {
+                const int k = base + t + 256 * u;
+                n_c[u] = 0; n_v[u] = 0.0;
+                if (k < cnt) { n_c[u] = col[e0 + k]; n_v[u] = val[e0 + k]; }
+            }
+#pragma unroll
+        for (int u = 0; u < GB_CHUNK; ++u) {
+            const int k = base + t + 256 * u;
+            const bool active = k < cnt;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(n_v[u]);
+            unsigned code = 255;
+            if (active) {
+                unsigned h = gb_vhash(bits);
                 for (int probe = 0; probe < GB_VSLOTS; ++probe) {
                     const unsigned long long key = s_vkey[h];
                     if (key == bits) { code = s_vcode[h]; break; }
                     if (key == ~0ull) break;
                     h = (h + 1) & (GB_VSLOTS - 1);
                 }
-                s_vc[k] = (unsigned char)code;
+                if (bits == ~0ull) { bad = true; code = 254; }
+                maxcol = n_c[u] > maxcol ? n_c[u] : maxcol;
             }
-            __syncthreads();
+            // values this workgroup has not met: one look-up in the device-wide table per distinct value and wave
+            unsigned long long miss = __ballot(active && code == 255);
+            while (miss) {
+                const int leader = __ffsll((long long)miss) - 1;
+                const unsigned long long lb = __shfl(bits, leader, 64);
+                int cglob = 0;
+                if (lane == leader) {
+                    cglob = gb_global_value_code(lb, g);
+                    if (cglob >= 0) {                           // into the workgroup's hash
+                        unsigned h = gb_vhash(lb);
+                        for (int probe = 0; probe < GB_VSLOTS; ++probe) {
+                            const unsigned long long old = atomicCAS(&s_vkey[h], ~0ull, lb);
+                            if (old == ~0ull || old == lb) { s_vcode[h] = (unsigned char)cglob; break; }
+                            h = (h + 1) & (GB_VSLOTS - 1);
+                        }
+                    }
+                }
+                cglob = __shfl(cglob, leader, 64);
+                if (active && code == 255 && bits == lb) { if (cglob < 0) { bad = true; code = 254; } else code = (unsigned)cglob; }
+                miss = __ballot(active && code == 255);
+            }
+            if (active) { s_c[k] = n_c[u]; s_vc[k] = (unsigned char)code; }
+        }
+        }
+        __syncthreads();
+        if (cnt >= 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = 2 * t + q;
@@ -260,30 +338,37 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                 const int b = (int)(s_ptr[r] - e0), e = (int)(s_ptr[r + 1] - e0);
                 unsigned long long sig = 0x00ffffffffffffffull;           // seven bytes of 255
                 int last = -1;
-                if (e - b > 8 || e < b) bad = true;
-                else for (int j = b; j < e; ++j) {
-                    const long long d = (long long)s_c[j] - i;
-                    const int p = d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -g.nx ? 1 : d == g.nx ? 5 : d == -g.far ? 0 : d == g.far ? 6 : -1;
-                    const unsigned vc = s_vc[j];
-                    if (p <= last || vc == 255u) { bad = true; break; }
-                    last = p;
-                    sig = (sig & ~(0xffull << (8 * p))) | ((unsigned long long)vc << (8 * p));
+                if (e - b > 8 || e < b || b < 0 || e > cnt) bad = true;
+                else {
+                    maxlen = e - b > maxlen ? e - b : maxlen;
+                    for (int j = b; j < e; ++j) {
+                        const long long d = (long long)s_c[j] - i;
+                        const int p = d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -g.nx ? 1 : d == g.nx ? 5 : d == -g.far ? 0 : d == g.far ? 6 : -1;
+                        const unsigned vc = s_vc[j];
+                        if (p <= last || vc >= 254u) { bad = true; break; }
+                        last = p;
+                        posmask |= 1u << p;
+                        sig = (sig & ~(0xffull << (8 * p))) | ((unsigned long long)vc << (8 * p));
+                    }
                 }
 #pragma unroll
                 for (int p = 0; p < 7; ++p) s_sig[p * g.pitch + r0 + r] = (unsigned char)(sig >> (8 * p));
                 hsum += mix64(sig + 0x9e3779b97f4a7c15ull * (unsigned long long)(r0 + r + 1));
             }
         }
-        // the line's hash and whether any lane met a row that does not fit
+        if (pc + 1 < g.pieces) { line = nline; pc = npc; continue; }        // (same line, next piece)
+
+        // ---- the line is complete: its hash, whether any lane met a row that does not fit, its class ----
+        unsigned long long hs = hsum;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o, 64);
+        for (int o = 32; o > 0; o >>= 1) hs += __shfl_xor(hs, o, 64);
         const unsigned long long anybad = __ballot(bad);
         __syncthreads();
-        if ((t & 63) == 0) { s_red[t >> 6] = hsum; s_red[8 + (t >> 6)] = anybad ? 1 : 0; }
+        if (lane == 0) { s_red[t >> 6] = hs; s_red[8 + (t >> 6)] = anybad ? 1 : 0; }
         __syncthreads();
         if (t == 0) {
             int id = -2; int winner = 0; unsigned slot = 0;
-            if (s_red[8] | s_red[9] | s_red[10] | s_red[11]) atomicOr(g.flags, GB_BAD_ROW);
+            if (s_red[8] | s_red[9] | s_red[10] | s_red[11]) atomicOr(&g.ints[GBI_FLAGS], GB_BAD_ROW);
             else {
                 const unsigned long long key = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) | 1ull;      // never 0 (= empty)
                 // the classes this workgroup has met before (a handful): no device-wide traffic for them
@@ -294,8 +379,8 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                         unsigned long long old = __hip_atomic_load(&g.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (old == 0ull) old = atomicCAS(&g.keys[slot], 0ull, key);
                         if (old == 0ull) {                                 // a new class: number it, write its table, publish
-                            id = atomicAdd(g.count, 1);
-                            if (id >= g.cap) { atomicOr(g.flags, GB_OVERFLOW); __hip_atomic_store(&g.ids[slot], -2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); id = -2; }
+                            id = atomicAdd(&g.ints[GBI_COUNT], 1);
+                            if (id >= GB_MAX_CLASSES) { atomicOr(&g.ints[GBI_FLAGS], GB_OVERFLOW); __hip_atomic_store(&g.ids[slot], -2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); id = -2; }
                             else winner = 1;
                             break;
                         }
@@ -306,14 +391,13 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                                 if (v != -1) break;
                                 __builtin_amdgcn_s_sleep(4);
                             }
-                            if (v == -1) atomicOr(g.flags, GB_TIMEOUT);
+                            if (v == -1) atomicOr(&g.ints[GBI_FLAGS], GB_TIMEOUT);
                             id = v < 0 ? -2 : v;
                             break;
                         }
                         slot = (slot + 1) & (GB_KEYS - 1);
                     }
-                    if (id >= 0 && known < GB_KNOWN) { s_kkey[known] = key; s_kid[known] = id; }
-                    if (id >= 0 && known < GB_KNOWN) ++known;
+                    if (id >= 0 && known < GB_KNOWN) { s_kkey[known] = key; s_kid[known] = id; ++known; }
                 }
             }
             s_red[4] = (unsigned long long)(long long)id; s_red[5] = (unsigned long long)winner; s_red[6] = slot;
@@ -333,7 +417,7 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
         } else {
             // (plain loads: lane 0's acquire of the class number -- when this workgroup first met the class -- has invalidated what this
             //  CU and its L2 held; the table does not change after it is published.  All loads of a trip are issued before the
-            //  first comparison: a chain of dependent loads here was a fifth of the kernel.)
+            //  first comparison.)
             unsigned diff = 0;
             int i = t;
             for (; i + 3 * 256 < words; i += 4 * 256) {
@@ -341,13 +425,39 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                 diff |= (a0 ^ mine[i]) | (a1 ^ mine[i + 256]) | (a2 ^ mine[i + 512]) | (a3 ^ mine[i + 768]);
             }
             for (; i < words; i += 256) diff |= tb[i] ^ mine[i];
-            if (__ballot(diff != 0) && (t & 63) == 0) atomicOr(g.flags, GB_COLLISION);
+            if (__ballot(diff != 0) && lane == 0) atomicOr(&g.ints[GBI_FLAGS], GB_COLLISION);
         }
         if (t == 0) { g.line_class[line] = id; ++s_uses[id]; }
-        __syncthreads();                                        // the line's rows (s_sig) are compared / copied before the next line overwrites them
+        line = nline; pc = npc;
     }
     __syncthreads();
-    for (int i = t; i < g.cap; i += 256) if (s_uses[i]) atomicAdd(&g.uses[i], s_uses[i]);
+    for (int i = t; i < GB_MAX_CLASSES; i += 256) if (s_uses[i]) atomicAdd(&g.ints[GBI_USES + i], s_uses[i]);
+    // what the product and the storage selection need to know about the matrix as a whole
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { posmask |= (unsigned)__shfl_xor((int)posmask, o, 64); const int mc = __shfl_xor(maxcol, o, 64), ml = __shfl_xor(maxlen, o, 64); maxcol = mc > maxcol ? mc : maxcol; maxlen = ml > maxlen ? ml : maxlen; }
+    if (lane == 0) { atomicOr(&g.ints[GBI_POSMASK], (int)posmask); atomicMax(&g.ints[GBI_MAXCOL], maxcol); atomicMax(&g.ints[GBI_MAXLEN], maxlen); }
+}
+
+// the diagonals of a few thousand rows (the probe in front of the one-pass build): a set of at most 15, overflow flag in [15]
+template <typename P>
+__global__ __launch_bounds__(256)
+void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, long long first, long long rows, int *__restrict__ set /* 16, INT_MIN = empty */)
+{
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+        const long long i = first + r;
+        const long long b = (long long)ptr[i], e = (long long)ptr[i + 1];
+        for (long long j = b; j < e && j < b + 16; ++j) {
+            const long long d64 = (long long)col[j] - i;
+            const int d = (int)d64;
+            bool placed = false;
+            for (int k = 0; k < 15 && !placed; ++k) {
+                int old = __hip_atomic_load(&set[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (int)0x80000000) old = atomicCAS(&set[k], (int)0x80000000, d);
+                placed = old == (int)0x80000000 || old == d;
+            }
+            if (!placed || d64 != (long long)d) atomicExch(&set[15], 1);
+        }
+    }
 }
 
 // ---- the product ----
@@ -660,70 +770,116 @@ template <typename T> struct dev_buf {       // device scratch of the plan, free
 
 
 // ---- host side of the direct build ----
+// rows x rows-or-more matrix in CSR on the device -> vexhip_grid (usable = 1), the diagonal table (sorted, 256 ints on the device,
+// INT_MAX behind the last) and the value table (256 values on the device, 0.0 behind the last), ELL width and largest column;
+// usable = 0: not a matrix for this storage, nothing was written that the classic set-up would read.
 template <typename P>
-int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t *col, const double *val, int64_t ell_width, int64_t tail_nnz,
-        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out)
+int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t *col, const double *val,
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last_out, vexhip_grid *out)
 {
-    VEXHIP_REQUIRE(out, "NULL output");
+    VEXHIP_REQUIRE(out && ndeltas && nvalues && ell_width && x_last_out, "NULL output");
     std::memset(out, 0, sizeof(*out));
+    *ndeltas = -1; *nvalues = -1; *ell_width = 0; *x_last_out = -1;
     const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
     if (std::getenv("VEXHIP_NO_GRID") || std::getenv("VEXHIP_NO_GRID_BUILD")) return 0;
-    if (!ptr || !col || !val || !deltas || !values || ndeltas < 4 || ndeltas > 7 || nvalues < 1 || nvalues > 255) return 0;
-    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < (1 << 23) && !force)) return 0;
-    if (x_last < 0 || x_last + 1 < rows || x_last >= (1ll << 31)) return 0;
+    // small matrices (x within the L2s / the Infinity Cache) keep the pair product of the SELL-512 storage
+    if (!ptr || !col || !val || !deltas || !values || rows < 64 || (rows < (1 << 23) && !force) || rows >= (1ll << 31)) return 0;
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
-    std::vector<int> table((size_t)ndeltas);
-    VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * (size_t)ndeltas, hipMemcpyDeviceToHost, s));
+    setup_trace trace(s);
+
+    // ---- probe: the diagonals of (up to) 8192 rows in the middle of the matrix ----
+    dev_buf<int> d_set;
+    VEXHIP_TRY(d_set.alloc(16));
+    VEXHIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_set.p), (int)0x80000000, 15, s));
+    VEXHIP_TRY(hipMemsetAsync(d_set.p + 15, 0, sizeof(int), s));
+    const long long probe_rows = std::min<long long>(rows, 8192), probe_first = (rows - probe_rows) / 2;
+    grid_probe_kernel<P><<<(unsigned)((probe_rows + 255) / 256), 256, 0, s>>>(ptr, col, probe_first, probe_rows, d_set.p);
+    VEXHIP_LAUNCH_CHECK();
+    int set[16];
+    VEXHIP_TRY(hipMemcpyAsync(set, d_set.p, sizeof(set), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
+    if (set[15]) return 0;
+    std::vector<int> table;
+    for (int k = 0; k < 15; ++k) if (set[k] != (int)0x80000000) table.push_back(set[k]);
+    if (table.size() < 4 || table.size() > 7) return 0;
     long long nx = 0, far = 0;
     if (!grid_diagonals(table, rows, &nx, &far) || nx > 4096) return 0;         // (the line's seven position rows live in LDS)
     const long long ny = far / nx, lines = rows / nx, nz = (lines + ny - 1) / ny;
     if (nz < 4 && !force) return 0;
     grid_geometry geo;
     if (!grid_geometry_for(dev, nx, ny, nz, &geo)) return 0;
+    trace.mark("  grid: probe");
 
-    // control block: [keys GB_KEYS x 8][ids GB_KEYS x 4][count][flags][uses GB_MAX_CLASSES x 4]
-    const size_t ctl_bytes = GB_KEYS * 8 + GB_KEYS * 4 + 8 + GB_MAX_CLASSES * 4;
+    // ---- the pass ----
+    // control block: [keys GB_KEYS x 8][vkeys GB_VSLOTS x 8][ids GB_KEYS x 4][vstate GB_VSLOTS x 4][vcodes GB_VSLOTS x 4][ints GBI_INTS x 4]
+    const size_t ctl_bytes = GB_KEYS * 8 + GB_VSLOTS * 8 + GB_KEYS * 4 + GB_VSLOTS * 4 + GB_VSLOTS * 4 + GBI_INTS * 4;
     dev_buf<unsigned char> d_ctl, d_table; dev_buf<int> d_cls;
     VEXHIP_TRY(d_ctl.alloc(ctl_bytes)); VEXHIP_TRY(d_cls.alloc((size_t)lines)); VEXHIP_TRY(d_table.alloc((size_t)GB_MAX_CLASSES * 7 * (size_t)geo.pitch));
     gb_dev g;
-    g.n = rows; g.lines = lines; g.far = far; g.nx = (int)nx; g.nvalues = nvalues; g.pitch = (int)geo.pitch; g.cap = GB_MAX_CLASSES;
+    g.n = rows; g.lines = lines; g.far = far; g.nx = (int)nx; g.pitch = (int)geo.pitch; g.pieces = (int)((nx + GB_PIECE - 1) / GB_PIECE);
     g.keys = reinterpret_cast<unsigned long long *>(d_ctl.p);
-    g.ids = reinterpret_cast<int *>(d_ctl.p + GB_KEYS * 8);
-    g.count = g.ids + GB_KEYS; g.flags = g.count + 1; g.uses = g.flags + 1;
+    g.vkeys = g.keys + GB_KEYS;
+    g.ids = reinterpret_cast<int *>(g.vkeys + GB_VSLOTS);
+    g.vstate = g.ids + GB_KEYS; g.vcodes = g.vstate + GB_VSLOTS; g.ints = g.vcodes + GB_VSLOTS;
     g.table = d_table.p; g.line_class = d_cls.p;
     VEXHIP_TRY(hipMemsetAsync(d_ctl.p, 0, ctl_bytes, s));
     VEXHIP_TRY(hipMemsetAsync(g.ids, 0xff, GB_KEYS * 4, s));                     // -1: no number yet
+    VEXHIP_TRY(hipMemsetAsync(g.ints + GBI_MAXCOL, 0xff, sizeof(int), s));        // -1
     const size_t lds = GB_VSLOTS * 8 + GB_VSLOTS + 520 * 8 + GB_CAP * 4 + GB_CAP + ((7 * (size_t)geo.pitch + 15) / 16) * 16 + 16 * 8;
     const long long cus = std::max(1, info(dev).cus);
-    const unsigned wgs = (unsigned)std::min<long long>(lines, cus * std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)(lds + 2048))));
-    grid_build_kernel<P><<<wgs, 256, lds, s>>>(ptr, col, val, values, g);
+    long long per_cu = std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)(lds + 2048)));
+    if (const char *e = std::getenv("VEXHIP_GRID_BUILD_WGS")) per_cu = std::max(1, std::atoi(e));
+    const unsigned wgs = (unsigned)std::min<long long>(lines, cus * per_cu);
+    grid_build_kernel<P><<<wgs, 256, lds, s>>>(ptr, col, val, g);
     VEXHIP_LAUNCH_CHECK();
-    int res[2 + GB_MAX_CLASSES];
-    VEXHIP_TRY(hipMemcpyAsync(res, g.count, sizeof(res), hipMemcpyDeviceToHost, s));
+    std::vector<unsigned char> ctl(ctl_bytes);
+    VEXHIP_TRY(hipMemcpyAsync(ctl.data(), d_ctl.p, ctl_bytes, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
-    if (std::getenv("VEXHIP_DEBUG")) std::fprintf(stderr, "grid build: nx %lld ny %lld lines %lld classes %d flags %d\n", nx, ny, lines, res[0], res[1]);
-    if (res[1] != 0 || res[0] < 1 || res[0] > GB_MAX_CLASSES) return 0;         // not a matrix for this storage: the classic set-up takes over
-    const int nclasses = res[0];
-    const int *uses = res + 2;
+    trace.mark("  grid: pass");
+    const unsigned long long *h_vkeys = reinterpret_cast<const unsigned long long *>(ctl.data()) + GB_KEYS;
+    const int *h_ids = reinterpret_cast<const int *>(h_vkeys + GB_VSLOTS);
+    const int *h_vstate = h_ids + GB_KEYS, *h_vcodes = h_vstate + GB_VSLOTS, *h_ints = h_vcodes + GB_VSLOTS;
+    if (std::getenv("VEXHIP_DEBUG"))
+        std::fprintf(stderr, "grid build: nx %lld ny %lld lines %lld classes %d values %d flags %d positions %#x max column %d widest row %d\n",
+                     nx, ny, lines, h_ints[GBI_COUNT], h_ints[GBI_VCOUNT], h_ints[GBI_FLAGS], h_ints[GBI_POSMASK], h_ints[GBI_MAXCOL], h_ints[GBI_MAXLEN]);
+    const int nclasses = h_ints[GBI_COUNT], nv = h_ints[GBI_VCOUNT];
+    if (h_ints[GBI_FLAGS] != 0 || nclasses < 1 || nclasses > GB_MAX_CLASSES || nv < 1 || nv > GB_MAX_VALUES) return 0;   // the classic set-up takes over
+    const long long x_last = h_ints[GBI_MAXCOL];
+    if (x_last < 0 || x_last + 1 < rows) return 0;
+    const int *uses = h_ints + GBI_USES;
     const int hot = (int)(std::max_element(uses, uses + nclasses) - uses);
     if ((lines - uses[hot]) * 4 > lines && !force) return 0;
+    // the tables the products read: values by code (0.0 behind the last: code 255 reads it), diagonals sorted
+    std::vector<double> vals(256, 0.0);
+    for (int k = 0; k < GB_VSLOTS; ++k)
+        if (h_vstate[k] == 2 && h_vcodes[k] >= 0 && h_vcodes[k] < nv) std::memcpy(&vals[(size_t)h_vcodes[k]], &h_vkeys[k], sizeof(double));
+    const long long by_pos[7] = {-far, -nx, -1, 0, 1, nx, far};
+    std::vector<int> dl;
+    for (int p = 0; p < 7; ++p) if (h_ints[GBI_POSMASK] & (1 << p)) dl.push_back((int)by_pos[p]);
+    const int nd = (int)dl.size();
+    if (nd < 1) return 0;
+    dl.resize(256, INT_MAX);
+    VEXHIP_TRY(hipMemcpyAsync(values, vals.data(), sizeof(double) * 256, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipMemcpyAsync(deltas, dl.data(), sizeof(int) * 256, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
     grid_fill_plan(out, nx, ny, nz, geo, hot, nclasses, x_last);
     out->line_class = d_cls.release(); out->table = d_table.release();
     out->usable = 1;
+    *ndeltas = nd; *nvalues = nv; *ell_width = h_ints[GBI_MAXLEN]; *x_last_out = x_last;
+    trace.mark("  grid: tables");
     return 0;
 }
 
 } // namespace
 
 // internal entry points of the direct build (spmat.hip)
-int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
-        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out)
-{ return grid_build<int32_t>(dev, stream, rows, ptr, col, val, w, tail, deltas, ndeltas, values, nvalues, x_last, out); }
-int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
-        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out)
-{ return grid_build<long long>(dev, stream, rows, ptr, col, val, w, tail, deltas, ndeltas, values, nvalues, x_last, out); }
+int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val,
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out)
+{ return grid_build<int32_t>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out); }
+int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val,
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out)
+{ return grid_build<long long>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out); }
 
 } // namespace vexhip
 

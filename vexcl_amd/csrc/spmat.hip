@@ -40,11 +40,10 @@ int sell_fill_p64(int dev, void *stream, int64_t n, const long long *ptr, const 
 int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, const long long *ptr, const int32_t *col, const double *val, const double *x, double *y, const vexhip_traversal *tr);
 int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y, const vexhip_traversal *tr);
 int csr_traversal_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int rows_per_block, vexhip_traversal *traversal);
-long long analysis_max_col(const void *ptr, long long n);
-int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
-        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out);
-int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val, int64_t w, int64_t tail,
-        const int32_t *deltas, int ndeltas, const double *values, int nvalues, int64_t x_last, vexhip_grid *out);
+int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val,
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out);
+int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val,
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out);
 int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_plane *out);
 
 namespace {
@@ -240,6 +239,32 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     A->nnz = (int64_t)last;
     trace.mark("entry count");
 
+    // A 7-point pattern on a grid with a handful of distinct values: stored by grid line in ONE pass over the CSR arrays (grid.hip
+    // grid_build: no ELL analysis, no table pass, no per-slice codes, no dictionary, no plans from read-backs).  Declined
+    // (usable = 0, after a probe of a few thousand rows in most cases): the SELL-512 set-up below.
+    if constexpr (std::is_same<V, double>::value) {
+        if ((format == VEXHIP_SPMAT_AUTO || format == VEXHIP_SPMAT_SELL8V) && A->nnz > 0
+            && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE | VEXHIP_SPMAT_NO_GRID_BUILD))) {
+            V *vals = nullptr;
+            if (int rc = dmalloc(&A->deltas, 256)) return rc;
+            if (int rc = dmalloc(&vals, 256)) return rc;
+            A->values = vals;
+            int nd = -1, nv = -1; int64_t gw = 0, x_last = -1;
+            int rc;
+            if constexpr (p64) rc = grid_build_p64(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid);
+            else rc = grid_build_p32(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid);
+            if (rc) return rc;
+            trace.mark("grid build");
+            if (A->grid.usable) {
+                A->ndeltas = nd; A->nvalues = nv; A->ell_w = gw; A->tail = 0; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
+                if (!std::getenv("VEXHIP_NO_PLANE512"))
+                    if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
+                return 0;
+            }
+            (void)hipFree(A->deltas); A->deltas = nullptr;
+            (void)hipFree(A->values); A->values = nullptr;
+        }
+    }
     int64_t w = 0, tail = 0;
     if (format != VEXHIP_SPMAT_CSR && A->nnz > 0)
         if (int rc = S::analyze(dev, stream, n, ptr, &w, &tail)) return rc;
@@ -296,27 +321,6 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     } else if (format != VEXHIP_SPMAT_SELL) {
         if (int rc = dmalloc(&A->deltas, 256)) return rc;
         if (int rc = S::d_analyze(dev, stream, n, ptr, col, w, A->deltas, &nd)) return rc;
-    }
-    if (nd > 0 && nv > 0 && !tail) {
-        // A 7-point pattern on a grid, a handful of distinct values: stored by grid line straight from the CSR arrays (one more pass
-        // over them, no per-slice codes, no dictionary, no plans from read-backs).  Declined (usable = 0): the SELL-512 set-up below.
-        if constexpr (std::is_same<V, double>::value) {
-            const long long x_last = analysis_max_col(ptr, n);
-            if (x_last >= 0 && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE | VEXHIP_SPMAT_NO_GRID_BUILD))) {
-                int rc;
-                if constexpr (p64) rc = grid_build_p64(dev, stream, n, ptr, col, val, w, tail, A->deltas, nd, (const double *)A->values, nv, x_last, &A->grid);
-                else rc = grid_build_p32(dev, stream, n, ptr, col, val, w, tail, A->deltas, nd, (const double *)A->values, nv, x_last, &A->grid);
-                if (rc) return rc;
-                trace.mark("grid build");
-                if (A->grid.usable) {
-                    A->ndeltas = nd; A->nvalues = nv; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
-                    if (!std::getenv("VEXHIP_NO_PLANE512"))
-                        if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
-                    clear_max_col_hint();
-                    return 0;
-                }
-            }
-        }
     }
     if (nd > 0) {
         A->ndeltas = nd;
