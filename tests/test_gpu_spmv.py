@@ -453,7 +453,7 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
                 A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct)
                 assert A.storage == "sell8v" and A.grid is not None and A.plane is None and A.direct == direct, (shape, direct, A.storage, A.dictionary_blocks)
                 assert (A.grid["nx"], A.grid["lines_per_plane"]) == shape[:2] and A.grid["x_last"] == m - 1, (shape, A.grid)
-                assert A.grid["segments"] == (shape[0] + 511) // 512 and (depth is None or A.grid["depth"] == min(depth, A.grid["planes"])), (shape, A.grid)
+                assert A.grid["segments"] == ((shape[0] + 511) // 512 if shape[0] <= 768 else (shape[0] + 1023) // 1024) and (depth is None or A.grid["depth"] == min(depth, A.grid["planes"])), (shape, A.grid)
                 if classes is not None:
                     assert A.grid["classes"] == classes, (shape, A.grid)
                 for alpha, append in ((1.0, False), (-0.75, True)):

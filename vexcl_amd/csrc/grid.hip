@@ -461,15 +461,17 @@ void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, l
 }
 
 // ---- the product ----
-template <bool APPEND, int STORE_AUX>
-__global__ __launch_bounds__(256, 4)
+// MAXT: 256 lanes (segments of <= 512 rows, four workgroups per CU) or 512 (segments of <= 1024 rows, two per CU: lines of 513 ..
+// 1024 points stay in one piece -- two 320-row segments of a 640-point line read x 1.87 times, profiles/r04_grid_pmc.json)
+template <bool APPEND, int STORE_AUX, int MAXT>
+__global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 2)
 void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
         const int *__restrict__ line_class, const unsigned char *__restrict__ table, const double *__restrict__ values, grid_dev gd)
 {
     constexpr int TY = 2;
     // LDS: the value table and the decoded values of the OTHER class, lane-private ([position * 2 + row][lane]: conflict-free)
     __shared__ double s_value[256];
-    __shared__ double s_other[14][256];
+    __shared__ double s_other[14][MAXT];
 
     const int t = threadIdx.x;
     const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
@@ -699,9 +701,14 @@ inline long long grid_pitch(long long nx) { return (((nx + 511) / 512) * 512 + 2
 
 bool grid_geometry_for(int dev, long long nx, long long ny, long long nz, grid_geometry *geo)
 {
-    const long long segs = (nx + 511) / 512;
+    // lines of up to 1024 points in one segment (workgroups of up to 512 lanes), longer ones in segments of <= 1024 rows
+    // (640^3 / 700^3: one 640- / 700-row segment = 1.26 / 1.55 ms -- few waves per CU -- against 0.97 / 1.37 ms in two segments;
+    //  1024^3 in one segment: 3.31 ms, 0.65 of 8 TB/s.  VEXHIP_GRID_SEGMENT = 512 | 1024 overrides.)
+    long long max_seg = nx > 768 ? 1024 : 512;
+    if (const char *e = std::getenv("VEXHIP_GRID_SEGMENT")) max_seg = std::atoi(e) == 1024 ? 1024 : 512;
+    const long long segs = (nx + max_seg - 1) / max_seg;
     long long seg_len = (nx + segs - 1) / segs; seg_len += seg_len & 1;
-    const int threads = (int)std::min<long long>(256, ((seg_len + 1) / 2 + 63) / 64 * 64);
+    const int threads = (int)std::min<long long>(max_seg / 2, ((seg_len + 1) / 2 + 63) / 64 * 64);
     const long long pitch = grid_pitch(nx);
     const long long tiles = (ny + 1) / 2 * segs;
     const long long cus = std::max(1, info(dev).cus);
@@ -720,8 +727,10 @@ bool grid_geometry_for(int dev, long long nx, long long ny, long long nz, grid_g
     long long chunks = 1;
     {
         double best = 0;
+        const long long resident = std::max(1ll, (threads > 256 ? 12 : 16) / wpw);       // workgroups a CU holds at once (138 / 128 registers per lane)
         for (long long c = 1; c <= std::max(1ll, nz / 8); ++c) {
             const long long per_cu = (tiles * c + cus - 1) / cus;
+            if (c > 1 && per_cu > resident) break;              // a second round of workgroups walks out of step with the first
             double est = (double)per_cu * (double)((nz + c - 1) / c + 6);
             if (per_cu * wpw < 6) est *= 6.0 / (double)(per_cu * wpw);
             if (c == 1 || est < best) { best = est; chunks = c; }
@@ -988,9 +997,9 @@ int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, 
 {
     VEXHIP_REQUIRE(g && g->usable && g->line_class && g->table && values && x && y, "bad grid product arguments");
     VEXHIP_REQUIRE(g->nx >= 8 && n > 0 && n % g->nx == 0 && g->lines_per_plane >= 2 && g->depth >= 1 && g->planes >= 1 && g->segments >= 1
-                   && g->segment_rows >= 2 && g->segment_rows <= 512 && g->segment_rows % 2 == 0 && (long long)g->segments * g->segment_rows >= g->nx
-                   && g->threads >= 64 && g->threads <= 256 && g->threads % 64 == 0 && 2 * g->threads >= g->segment_rows
-                   && g->pitch >= g->segments * 512 + 2 && g->x_last + 1 >= n
+                   && g->segment_rows >= 2 && g->segment_rows <= 1024 && g->segment_rows % 2 == 0 && (long long)g->segments * g->segment_rows >= g->nx
+                   && g->threads >= 64 && g->threads <= 512 && g->threads % 64 == 0 && 2 * g->threads >= g->segment_rows
+                   && (long long)(g->segments - 1) * g->segment_rows + 2 * g->threads <= g->pitch && g->x_last + 1 >= n
                    && ((long long)g->depth + 4) * g->lines_per_plane * g->nx * 8 < (1ll << 32), "bad grid plan");
     VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "grid product: x and y must be 8-byte aligned");
     VEXHIP_SET_DEVICE(dev);
@@ -1004,7 +1013,8 @@ int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, 
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const unsigned char *tb = static_cast<const unsigned char *>(g->table);
     hipStream_t s = as_stream(stream);
-#define GRID_LAUNCH(AP, AUX) sell8_grid_kernel<AP, AUX><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd)
+#define GRID_LAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd); \
+                               else sell8_grid_kernel<AP, AUX, 256><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd); }
 #define GRID_AUX(AP) switch (g->store_policy) { case 1: GRID_LAUNCH(AP, 18); break; case 2: GRID_LAUNCH(AP, 17); break; case 3: GRID_LAUNCH(AP, 0); break; default: GRID_LAUNCH(AP, 2); }
     if (append) { GRID_AUX(true) } else { GRID_AUX(false) }
 #undef GRID_AUX
