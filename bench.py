@@ -317,6 +317,9 @@ def secondary_rows(torch, L, ops, dev, local_rank):
 
 
 def main():
+    if os.environ.get("BENCH_DUMP_AFTER"):            # diagnostics: where is every rank after that many seconds?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_AFTER"]), exit=False)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
