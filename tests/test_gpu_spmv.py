@@ -552,6 +552,24 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
         assert np.array_equal((R @ T.up(xb)).cpu().numpy(), oracle.spmv_csr(ptr, rcol, rval, xb))
         ptr, col, val = _band(m + 50, (-P, -96, -1, 0, 1, 96, P), 7, constant=True)
         check(ptr, col, val, (96, 20, 21), 45, expect=False)
+        # grid matrices that the one-pass set-up starts on and gives up: more than 254 values (a coefficient per face: the device-wide
+        # value table fills up) and more than 128 classes of lines (a value that depends on the line) -- the SELL-512 set-up takes
+        # over and the products equal the CSR restatement
+        ptr, col, val = oracle.diffusion3d(48, 3)
+        D = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        assert D.grid is None and not D.direct and D.storage == "sell8", (D.storage, D.grid)
+        xb = oracle.random_f64(49, 48 ** 3)
+        assert np.array_equal((D @ T.up(xb)).cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
+        ptr, col, val = _grid7(96, 20, 21)
+        val = val.copy()
+        line_of_row = np.arange(96 * 20 * 21) // 96
+        centre = (np.arange(96 * 20 * 21) % 96) == 40
+        rows_c = np.nonzero(centre & (np.diff(ptr) == 7))[0]
+        val[ptr[rows_c] + 3] = 1000.0 + (line_of_row[rows_c] % 200)              # the diagonal of one row per interior line: 200 values, > 128 classes
+        C = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        assert C.grid is None and not C.direct and C.storage == "sell8v", (C.storage, C.grid)
+        xb = oracle.random_f64(51, len(ptr) - 1)
+        assert np.array_equal((C @ T.up(xb)).cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb))
     finally:
         os.environ.pop("VEXHIP_PLANE_DEPTH", None)
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
