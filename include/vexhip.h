@@ -379,6 +379,12 @@ int vexhip_spmv_sell8_set_variant(int variant);
  * nothing is staged through the host.  create() decides, in this order: hybrid-ELL width and CSR tail
  * (hybrid_ell.inl:103-110) -> 1-byte diagonal codes if the ELL part uses <= 254 diagonals -> 1-byte value codes if
  * it holds <= 255 distinct values -> otherwise 32-bit columns; plain CSR when the ELL part would be empty.
+ * Round 4, in front of all that (fp64, format AUTO / SELL8V, >= 2^23 rows): a probe of 8192 rows names the diagonals; if they
+ * are {0, +-1, +-nx, +-nx * ny} -- a 7-point operator on a grid -- ONE pass over the CSR arrays stores the matrix BY GRID LINE
+ * (vexhip_grid: a class per line, a table of value codes per class; values numbered on the device in the order they are met,
+ * <= 254 of them, <= 128 classes) and the plane / grid products run on it; info then reports format SELL8V, grid.usable,
+ * sell = code_pool = NULL.  Anything that does not fit gives the pass up and the selection above takes over
+ * (VEXHIP_SPMAT_NO_GRID_BUILD skips the attempt).
  * `format` pins a less compact storage (tests, A/B): AUTO = most compact the matrix allows.
  * apply: y (=|+=) alpha * A * x, bit-identical for every storage (products rounded, rows folded in CSR order).   */
 typedef struct vexhip_spmat vexhip_spmat;
