@@ -8,6 +8,9 @@
 // Stage 2 runs on the device too (libvexhip: vexhip_reduce_finish), so each GPU
 // hands back one scalar; the host only combines one value per GPU
 // (the reference folds 8 x CU partials per device on the host, :412-436).
+#include <cstring>
+#include <chrono>
+#include <atomic>
 #include <limits>
 #include <map>
 #include <memory>
@@ -75,11 +78,12 @@ namespace detail {
     }
 
     struct reductor_buffers {
-        backend::device_vector<char> partials, result;
+        backend::device_vector<char> partials, result, counter;      // counter: how many workgroups of the running reduction have stored their partial (round 4)
         // Round 3: stage 2 stores the scalar straight into host memory the GPU can write (pinned, mapped): the host only
         // waits for the queue -- no copy command between the kernel and the value (the 8-byte read-back was a third of a
         // 2^24-element reduction: 0.066 ms).  The device-side `result` stays for the RCCL combine, which works in place.
         void *pinned = nullptr;
+        unsigned long long seq = 0;          // reductions issued on this device (the kernel stores it behind the result)
         reductor_buffers() {}
         reductor_buffers(const reductor_buffers &) = delete;
         reductor_buffers &operator=(const reductor_buffers &) = delete;
@@ -99,7 +103,13 @@ class Reductor {
                 auto b = std::make_shared<detail::reductor_buffers>();
                 b->partials = backend::device_vector<char>(q, (size_t)groups * 2 * sizeof(ScalarType));
                 b->result = backend::device_vector<char>(q, 2 * sizeof(ScalarType));
-                backend::check(vexhip_host_alloc(2 * sizeof(ScalarType), &b->pinned));
+                // arrival counters of the single-launch reduction: [0] the top one, [32 * (1 + k)] one per residue of the workgroup
+                // number mod 32, 128 bytes apart (2048 same-address atomics at the end of the kernel took 40 us; 64 do not)
+                const std::vector<unsigned> zeros(33 * 32, 0u);
+                b->counter = backend::device_vector<char>(q, zeros.size() * sizeof(unsigned));
+                b->counter.write(q, 0, zeros.size() * sizeof(unsigned), reinterpret_cast<const char *>(zeros.data()), true);
+                backend::check(vexhip_host_alloc(128, &b->pinned));          // [0..1] the scalar(s); byte 64: the number of the reduction that stored them
+                std::memset(b->pinned, 0, 128);
                 bufs.push_back(b);
                 ngroups.push_back(groups);
             }
@@ -140,12 +150,18 @@ class Reductor {
                 arg_context a(krn, d, part[d]);
                 expr.set_args(a);
                 krn.push_arg(bufs[d]->partials.raw());
+                // Round 4: ONE launch.  The workgroup that stores its partial last (a counter in device memory tells) folds all of
+                // them -- in the order of libvexhip's stage-2 kernel, so the bits are those of the two-launch form -- and stores the
+                // scalar (pinned host memory, or the device word the RCCL combine works on): the second launch and the gap in
+                // front of it were 5-7 us of a 53 us reduction at 2^24 elements.
+                krn.push_arg(reinterpret_cast<unsigned *>(bufs[d]->counter.raw()));
+                krn.push_arg(static_cast<ScalarType *>(rccl_combine(minmax) ? static_cast<void *>(bufs[d]->result.raw()) : bufs[d]->pinned));
+                krn.push_arg(reinterpret_cast<unsigned long long *>(static_cast<char *>(bufs[d]->pinned) + 64));
+                krn.push_arg((unsigned long long)++bufs[d]->seq);
                 krn.config(ngroups[d], 256);
                 krn(queue[d]);
-                backend::check(vexhip_reduce_finish(queue[d].device_ordinal(), queue[d].raw(), op,
-                            reduce_dtype<ScalarType>::value, bufs[d]->partials.raw(), ngroups[d],
-                            rccl_combine(minmax) ? static_cast<void *>(bufs[d]->result.raw()) : bufs[d]->pinned));
             }
+            (void)op;
             if (rccl_combine(minmax)) {
                 // VEXCL_REDUCTOR_COMBINE=rccl: the D per-device scalars are combined by ONE all-reduce over xGMI
                 // (vexhip_allreduce_scalar) and a single 8-byte read-back, instead of D read-backs and a host fold
@@ -164,6 +180,20 @@ class Reductor {
                 for (unsigned d = 0; d < queue.size(); ++d)
                     if (active[d]) bufs[d]->result.read(queue[d], 0, nout * sizeof(ScalarType), reinterpret_cast<char *>(&host[2 * d]), false);
             }
+            if (!rccl_combine(minmax)) {
+                // the kernel stores the scalar in pinned host memory and, behind it (system-scope release), the number of this
+                // reduction: the host watches that word instead of waiting for the queue to drain (the wake-up of a blocked
+                // hipStreamSynchronize is several microseconds of a 50 us reduction); a second of silence falls back to the wait
+                for (unsigned d = 0; d < queue.size(); ++d) if (active[d]) {
+                    const volatile unsigned long long *seen = reinterpret_cast<const volatile unsigned long long *>(static_cast<char *>(bufs[d]->pinned) + 64);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    unsigned spins = 0;
+                    while (*seen != bufs[d]->seq) {
+                        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) { queue[d].finish(); break; }
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
+            } else
             for (unsigned d = 0; d < queue.size(); ++d) if (active[d]) queue[d].finish();
             if (!rccl_combine(minmax))
                 for (unsigned d = 0; d < queue.size(); ++d)
@@ -233,6 +263,10 @@ class Reductor {
             src.template parameter<size_t>("n");
             { gen_context c(src, q); expr.params(c); }
             src.template parameter<global_ptr<ScalarType>>("g_odata");
+            src.template parameter<global_ptr<unsigned>>("g_counter");
+            src.template parameter<global_ptr<ScalarType>>("g_result");
+            src.template parameter<global_ptr<cl_ulong>>("g_seen");
+            src.template parameter<cl_ulong>("seq");
             src.end_kernel_parameters();
 
             auto fold = [&](const std::string &a, const std::string &b) -> std::string {
@@ -295,7 +329,9 @@ class Reductor {
                 src.new_line() << "myMin = sdata[2 * w] < myMin ? sdata[2 * w] : myMin;";
                 src.new_line() << "myMax = sdata[2 * w + 1] > myMax ? sdata[2 * w + 1] : myMax;";
                 src.close("}");
-                src.new_line() << "g_odata[2 * blockIdx.x] = myMin; g_odata[2 * blockIdx.x + 1] = myMax;";
+                src.new_line() << T << " prev0 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x], myMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                src.new_line() << T << " prev1 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x + 1], myMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                src.new_line() << "asm volatile(\"\" :: \"v\"(prev0), \"v\"(prev1) : \"memory\");";
                 src.close("}");
             } else {
                 wave_fold("mySum", "fold");
@@ -304,9 +340,64 @@ class Reductor {
                 src.new_line() << "if (threadIdx.x == 0)";
                 src.open("{");
                 src.new_line() << "for (int w = 1; w < nwaves; ++w) mySum = " << fold("mySum", "sdata[w]") << ";";
-                src.new_line() << "g_odata[blockIdx.x] = mySum;";
+                // (an atomic exchange at agent scope: performed where every XCD sees it, and its return tells when -- no fence, which
+                //  would write back and invalidate a whole L2 per workgroup: 0.26 -> 0.33 ms at 1e8 elements)
+                src.new_line() << T << " prev = __hip_atomic_exchange(&g_odata[blockIdx.x], mySum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                src.new_line() << "asm volatile(\"\" :: \"v\"(prev) : \"memory\");";
                 src.close("}");
             }
+            // ---- stage 2 inside the same launch: the workgroup that arrives last folds the partials (order of reduce_stage2 in
+            // libvexhip: lane t takes partials t, t + 256, ...; wave fold; waves in order) ----
+            src.new_line() << "__shared__ int s_last;";
+            src.new_line() << "if (threadIdx.x == 0)";
+            src.open("{");
+            src.new_line() << "const unsigned sub = blockIdx.x & 31u, members = (gridDim.x - sub + 31u) >> 5, groups = gridDim.x < 32u ? gridDim.x : 32u;";
+            src.new_line() << "int last = 0;";
+            src.new_line() << "if (atomicAdd(g_counter + 32u * (1u + sub), 1u) == members - 1u)";      // the last of its residue class ...
+            src.open("{");
+            src.new_line() << "g_counter[32u * (1u + sub)] = 0u;";
+            src.new_line() << "last = atomicAdd(g_counter, 1u) == groups - 1u;";                       // ... counts for the class; the last class closes the reduction
+            src.close("}");
+            src.new_line() << "s_last = last;";
+            src.close("}");
+            src.new_line() << "__syncthreads();";
+            src.new_line() << "if (s_last)";
+            src.open("{");
+            if (minmax) {
+                src.new_line() << "myMin = " << literal(std::numeric_limits<ScalarType>::max()) << "; myMax = " << literal(std::numeric_limits<ScalarType>::lowest()) << ";";
+                src.new_line() << "for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)";
+                src.open("{");
+                src.new_line() << T << " a = __hip_atomic_load(&g_odata[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(&g_odata[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                src.new_line() << "myMin = a < myMin ? a : myMin; myMax = b > myMax ? b : myMax;";
+                src.close("}");
+                wave_fold("myMin", "min"); wave_fold("myMax", "max");
+                src.new_line() << "if (lane == 0) { sdata[2 * wave] = myMin; sdata[2 * wave + 1] = myMax; }";
+                src.new_line() << "__syncthreads();";
+                src.new_line() << "if (threadIdx.x == 0)";
+                src.open("{");
+                src.new_line() << "for (int w = 1; w < nwaves; ++w)";
+                src.open("{");
+                src.new_line() << "myMin = sdata[2 * w] < myMin ? sdata[2 * w] : myMin;";
+                src.new_line() << "myMax = sdata[2 * w + 1] > myMax ? sdata[2 * w + 1] : myMax;";
+                src.close("}");
+                src.new_line() << "g_result[0] = myMin; g_result[1] = myMax; *g_counter = 0u;";
+                src.new_line() << "__hip_atomic_store(g_seen, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);";
+                src.close("}");
+            } else {
+                typedef typename std::conditional<minmax || kahan, SUM, RDC>::type R2;
+                src.new_line() << "mySum = " << literal(R2::template impl<ScalarType>::initial()) << ";";
+                src.new_line() << "for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) mySum = " << fold("mySum", "__hip_atomic_load(&g_odata[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)") << ";";
+                wave_fold("mySum", "fold");
+                src.new_line() << "if (lane == 0) sdata[wave] = mySum;";
+                src.new_line() << "__syncthreads();";
+                src.new_line() << "if (threadIdx.x == 0)";
+                src.open("{");
+                src.new_line() << "for (int w = 1; w < nwaves; ++w) mySum = " << fold("mySum", "sdata[w]") << ";";
+                src.new_line() << "g_result[0] = mySum; *g_counter = 0u;";
+                src.new_line() << "__hip_atomic_store(g_seen, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);";
+                src.close("}");
+            }
+            src.close("}");
             src.end_kernel();
             return src.str();
         }
