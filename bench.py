@@ -410,10 +410,21 @@ def main():
         y.zero_()
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info(dev)[0]
+        # (Python's cyclic collector is run NOW: a full collection over what `import torch` leaves behind takes ~40 ms, and whether
+        #  the allocation counter trips inside the creation, inside the synchronisation that follows it or nowhere near depended on
+        #  how many objects the prelude had made -- the first `setup_ms` of round 4 read 5, 41 and 54 ms for the same 5 ms of work)
+        import gc
+        gc.collect()
         ts0 = time.perf_counter()
         A = ops.SpMat(ptr, col, val, fmt=args.format, dictionary=not args.no_dictionary, march=not args.no_march, plane=not args.no_plane, direct=not args.no_direct)
+        create_ms = (time.perf_counter() - ts0) * 1e3
         torch.cuda.synchronize()
         setup_ms = (time.perf_counter() - ts0) * 1e3
+        if os.environ.get("BENCH_STOP_AFTER_SETUP"):      # diagnostics
+            print("setup_ms %.3f returned_after_ms %.3f" % (setup_ms, create_ms), flush=True)
+            if os.environ["BENCH_STOP_AFTER_SETUP"] == "2":
+                os._exit(0)
+            return
         storage = A.storage
         matrix_bytes = A.matrix_bytes()
         dict_blocks = A.dictionary_blocks
@@ -421,7 +432,7 @@ def main():
         plane = A.plane if x.dtype == torch.float64 else None
         grid_plan = A.grid if x.dtype == torch.float64 else None
         direct = bool(A.direct)
-        setup = {"setup_ms": round(setup_ms, 3),
+        setup = {"setup_ms": round(setup_ms, 3), "returned_after_ms": round(create_ms, 3),
                  "what": ("vexhip_spmat_create on CSR arrays resident in HBM (host wall time, synchronised; the first creation in this process, after 30 copies of x "
                           "that bring the device out of idle): " + ("ELL width, diagonal / value tables, then ONE pass that stores the matrix by grid line (classes of lines)"
                           if direct else "hybrid-ELL analysis, diagonal / value tables, fill, slice dictionary, march / plane plans")),

@@ -201,6 +201,10 @@ __device__ __forceinline__ unsigned gb_vhash(unsigned long long bits) { return (
 // the device-wide code of a value: found, or numbered now (-1: the table is full / a writer never finished)
 __device__ int gb_global_value_code(unsigned long long bits, const gb_dev &g)
 {
+    // the build is over (a flag is set) or the table is full: no walk through 512 device-wide slots per value -- a matrix with a
+    // coefficient per face kept every wave of the kernel in such walks for seconds before this check (5.7 s at 512^3)
+    if (__hip_atomic_load(&g.ints[GBI_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
+    if (__hip_atomic_load(&g.ints[GBI_VCOUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= GB_MAX_VALUES) { atomicOr(&g.ints[GBI_FLAGS], GB_OVERFLOW); return -1; }
     unsigned h = gb_vhash(bits);
     for (int probe = 0; probe < GB_VSLOTS; ++probe) {
         int st = __hip_atomic_load(&g.vstate[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -322,7 +326,8 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                     }
                 }
                 cglob = __shfl(cglob, leader, 64);
-                if (active && code == 255 && bits == lb) { if (cglob < 0) { bad = true; code = 254; } else code = (unsigned)cglob; }
+                if (cglob < 0) { if (active && code == 255) { bad = true; code = 254; } }              // the build is over: no further look-ups
+                else if (active && code == 255 && bits == lb) code = (unsigned)cglob;
                 miss = __ballot(active && code == 255);
             }
             if (active) { s_c[k] = n_c[u]; s_vc[k] = (unsigned char)code; }
@@ -441,11 +446,27 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
 // the diagonals of a few thousand rows (the probe in front of the one-pass build): a set of at most 15, overflow flag in [15]
 template <typename P>
 __global__ __launch_bounds__(256)
-void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, long long first, long long rows, int *__restrict__ set /* 16, INT_MIN = empty */)
+void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val, long long first, long long rows,
+        int *__restrict__ set /* 16, INT_MIN = empty */, unsigned long long *__restrict__ vset /* 512 slots, all ones = empty */, int *__restrict__ vinfo /* [0] distinct values, [1] more than 254 */)
 {
     for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
         const long long i = first + r;
         const long long b = (long long)ptr[i], e = (long long)ptr[i + 1];
+        // the values of these rows: a matrix with more than 254 of them in 8192 rows (a coefficient per face) is not one for this storage
+        for (long long j = b; j < e && j < b + 16; ++j) {
+            if (__hip_atomic_load(&vinfo[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(val[j]);
+            unsigned h = gb_vhash(bits);
+            for (int probe = 0; probe < GB_VSLOTS; ++probe) {
+                unsigned long long old = __hip_atomic_load(&vset[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == ~0ull) {
+                    old = atomicCAS(&vset[h], ~0ull, bits);
+                    if (old == ~0ull && atomicAdd(&vinfo[0], 1) >= GB_MAX_VALUES) atomicExch(&vinfo[1], 1);
+                }
+                if (old == ~0ull || old == bits) break;
+                h = (h + 1) & (GB_VSLOTS - 1);
+            }
+        }
         for (long long j = b; j < e && j < b + 16; ++j) {
             const long long d64 = (long long)col[j] - i;
             const int d = (int)d64;
@@ -774,6 +795,7 @@ template <typename T> struct dev_buf {       // device scratch of the plan, free
     T *p = nullptr;
     ~dev_buf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)); }
+    void free_now() { if (p) (void)hipFree(p); p = nullptr; }
     T *release() { T *r = p; p = nullptr; return r; }
 };
 
@@ -798,17 +820,21 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     setup_trace trace(s);
 
     // ---- probe: the diagonals of (up to) 8192 rows in the middle of the matrix ----
-    dev_buf<int> d_set;
-    VEXHIP_TRY(d_set.alloc(16));
-    VEXHIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_set.p), (int)0x80000000, 15, s));
-    VEXHIP_TRY(hipMemsetAsync(d_set.p + 15, 0, sizeof(int), s));
+    // [diagonal set 16 ints][value info 2 ints][pad][value set GB_VSLOTS x 8]
+    dev_buf<unsigned long long> d_probe;
+    VEXHIP_TRY(d_probe.alloc(16 + GB_VSLOTS));
+    int *d_set = reinterpret_cast<int *>(d_probe.p), *d_vinfo = d_set + 16;
+    unsigned long long *d_vset = d_probe.p + 16;
+    VEXHIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_set), (int)0x80000000, 15, s));
+    VEXHIP_TRY(hipMemsetAsync(d_set + 15, 0, sizeof(int) * 3, s));
+    VEXHIP_TRY(hipMemsetAsync(d_vset, 0xff, sizeof(unsigned long long) * GB_VSLOTS, s));
     const long long probe_rows = std::min<long long>(rows, 8192), probe_first = (rows - probe_rows) / 2;
-    grid_probe_kernel<P><<<(unsigned)((probe_rows + 255) / 256), 256, 0, s>>>(ptr, col, probe_first, probe_rows, d_set.p);
+    grid_probe_kernel<P><<<(unsigned)((probe_rows + 255) / 256), 256, 0, s>>>(ptr, col, val, probe_first, probe_rows, d_set, d_vset, d_vinfo);
     VEXHIP_LAUNCH_CHECK();
-    int set[16];
-    VEXHIP_TRY(hipMemcpyAsync(set, d_set.p, sizeof(set), hipMemcpyDeviceToHost, s));
+    int set[18];
+    VEXHIP_TRY(hipMemcpyAsync(set, d_set, sizeof(set), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
-    if (set[15]) return 0;
+    if (set[15] || set[17]) return 0;              // a diagonal set that is not a grid's, or more values than codes: the classic set-up
     std::vector<int> table;
     for (int k = 0; k < 15; ++k) if (set[k] != (int)0x80000000) table.push_back(set[k]);
     if (table.size() < 4 || table.size() > 7) return 0;
@@ -877,6 +903,8 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     out->usable = 1;
     *ndeltas = nd; *nvalues = nv; *ell_width = h_ints[GBI_MAXLEN]; *x_last_out = x_last;
     trace.mark("  grid: tables");
+    d_probe.free_now(); d_ctl.free_now();
+    trace.mark("  grid: scratch freed");
     return 0;
 }
 

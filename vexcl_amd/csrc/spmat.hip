@@ -259,6 +259,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
                 A->ndeltas = nd; A->nvalues = nv; A->ell_w = gw; A->tail = 0; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
                 if (!std::getenv("VEXHIP_NO_PLANE512"))
                     if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
+                trace.mark("plane plan");
                 return 0;
             }
             (void)hipFree(A->deltas); A->deltas = nullptr;

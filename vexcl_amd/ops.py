@@ -9,6 +9,9 @@ The C++ header API (``vexcl/*.hpp``) is the primary host side; this module is
 what the Python parity tests and ``bench.py`` drive.
 """
 import ctypes
+import os
+import sys
+import time
 
 import torch
 
@@ -392,11 +395,14 @@ class SpMat:
         h = ctypes.c_void_p()
         create = ((L.spmat_create_f64_p64 if f64 else L.spmat_create_f32_p64) if p64 else
                   (L.spmat_create_f64_i32 if f64 else L.spmat_create_f32_i32))
+        _t0 = time.perf_counter() if os.environ.get("VEXHIP_SETUP_TRACE") else None
         create(
             _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
             _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH)
             | (0 if plane else _capi.SPMAT_NO_PLANE) | (0 if direct else _capi.SPMAT_NO_GRID_BUILD), ctypes.byref(h))
         self.handle = h
+        if _t0 is not None:
+            sys.stderr.write("[vexhip set-up] python: create() returned after %.3f ms\n" % ((time.perf_counter() - _t0) * 1e3))
         info = _capi.SpMatInfo()
         L.spmat_get_info(h, ctypes.byref(info))
         self.info = info
