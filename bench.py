@@ -613,6 +613,9 @@ def main():
     # the launch stream; the wall time of a block is the MAX over the ranks.  Block 1 is the driver's contract (W warm-ups, then
     # exactly K steps); the headline is the median block (median-of-5 of total / M).
     block_wall, block_kern = [], []
+    import gc
+    gc.collect()                       # (a full collection takes ~40 ms in this process: not inside a block of K x 0.37 ms; see the set-up above)
+    gc.disable()
     for _blk in range(max(1, args.blocks)):
         torch.cuda.synchronize()
         barrier()
@@ -627,6 +630,7 @@ def main():
         ms = ctypes.c_float()
         L.event_elapsed_ms(local_rank, e0, e1, ctypes.byref(ms))
         block_wall.append(t1 - t0); block_kern.append(ms.value)
+    gc.enable()
     if world > 1:
         t = torch.tensor(block_wall, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
