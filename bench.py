@@ -607,15 +607,15 @@ def main():
     L.event_create(local_rank, 1, ctypes.byref(e0))
     L.event_create(local_rank, 1, ctypes.byref(e1))
 
+    import gc
+    gc.collect()                       # a full collection takes ~40 ms in this process (see the set-up above): now, in front of the warm-ups,
+    gc.disable()                       # and none inside the blocks of K x 0.37 ms
     for _ in range(args.warmup):
         step()
     # Five blocks of exactly K steps, each bracketed by a barrier + torch.cuda.synchronize() on both sides and by HIP events on
     # the launch stream; the wall time of a block is the MAX over the ranks.  Block 1 is the driver's contract (W warm-ups, then
     # exactly K steps); the headline is the median block (median-of-5 of total / M).
     block_wall, block_kern = [], []
-    import gc
-    gc.collect()                       # (a full collection takes ~40 ms in this process: not inside a block of K x 0.37 ms; see the set-up above)
-    gc.disable()
     for _blk in range(max(1, args.blocks)):
         torch.cuda.synchronize()
         barrier()
