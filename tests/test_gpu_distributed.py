@@ -22,8 +22,10 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, out, ipc=True):
+def _worker(rank, world, port, n, out, ipc=True, by_line=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if by_line:            # the ranks' local parts stored by grid line (the default above 2^23 rows per rank; forced at this size)
+        os.environ["VEXHIP_PLANE_FORCE"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vexcl_amd import ops, lib
@@ -51,6 +53,7 @@ def _worker(rank, world, port, n, out, ipc=True):
         ok = ok and bool(((y - fy[r0:r1]).abs() <= 1e-12 * scale).all())
         ok = ok and A.loc is not None and (world == 1 or A.rem is not None)
         ok = ok and A.loc.fmt == "sell" and A.loc.hell.deltas is not None      # banded local part: 1-byte diagonal codes
+        ok = ok and bool(A.loc.direct) == bool(by_line) and (not by_line or A.loc.grid is not None)
         tot = DistReductor("SUM")(y)
         ok = ok and abs(tot - float(fy.sum())) <= 1e-9 * float(fy.abs().sum())
         mx = DistReductor("MAX")(y)
@@ -101,12 +104,12 @@ def _worker(rank, world, port, n, out, ipc=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 64), (3, 48)])
-def test_two_ranks_share_one_gpu(world, n, built_lib):
+@pytest.mark.parametrize("world,n,by_line", [(2, 64, False), (3, 48, False), (2, 64, True)])
+def test_two_ranks_share_one_gpu(world, n, by_line, built_lib):
     ctx = mp.get_context("spawn")
     out = ctx.Array("i", [0] * world)
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, out, True, by_line)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
