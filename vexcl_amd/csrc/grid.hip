@@ -219,7 +219,7 @@ __device__ int gb_global_value_code(unsigned long long bits, const gb_dev &g)
                 return c;
             }
         }
-        for (int spin = 0; st != 2 && spin < (1 << 22); ++spin) {    // the writer is running: a few hundred cycles
+        for (int spin = 0; st != 2 && spin < (1 << 18); ++spin) {    // the writer is running: a few hundred cycles
             __builtin_amdgcn_s_sleep(2);
             st = __hip_atomic_load(&g.vstate[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -391,7 +391,7 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                         }
                         if (old == key) {                                  // known: wait for its number (the writer is running)
                             int v = -1;
-                            for (int spin = 0; spin < (1 << 22); ++spin) {
+                            for (int spin = 0; spin < (1 << 18); ++spin) {
                                 v = __hip_atomic_load(&g.ids[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                                 if (v != -1) break;
                                 __builtin_amdgcn_s_sleep(4);
