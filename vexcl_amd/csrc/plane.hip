@@ -233,7 +233,7 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     // fast steps need nothing clamped: planes up to z + 3 inside x, both lines inside y
     int zh = zend;
     {
-        const int a = (xlines - 1 - TY - y0) / ny - 3, bb = (nslices - TY - y0) / ny;      // largest z with (z+3) ny + y0 + TY <= xlines - 1 / z ny + y0 + TY - 1 <= nslices - 1
+        const int a = (xlines - 1 - TY - y0) / ny - 3, bb = (nslices - TY - y0) / ny - (APPEND ? 1 : 0);      // largest z with (z+3) ny + y0 + TY <= xlines - 1 / z ny + y0 + TY - 1 <= nslices - 1 ('+=': the old y is requested one plane ahead -- inside y also when x is longer than y)
         if (xlines - 1 - TY - y0 < 0 || nslices - TY - y0 < 0) zh = 0;
         else { zh = zh < a + 1 ? zh : a + 1; zh = zh < bb + 1 ? zh : bb + 1; }
     }
