@@ -1,5 +1,6 @@
-"""The plane product at 512^3: requests two steps ahead (default) against three (VEXHIP_PLANE_DEEP=1, read once per process): time
-of 5 x 40 products, bit-identity with the pair product, walk depths."""
+"""The plane product at 512^3: time of 5 x 40 products, bit-identity with the pair product ('=' and '+= alpha'), walk depths.
+Written for the A/B of a variant that requested every line one more step ahead (VEXHIP_PLANE_DEEP=1 selected it; DESIGN.md 3.0c:
+bit-identical, 0.423 against 0.397 ms) -- the variant was removed after the measurement, the switch no longer exists."""
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vexcl_amd import ops
