@@ -46,6 +46,30 @@ def test_abi_version_and_sizes(built_lib):
     assert built_lib.scan_tmp_bytes(3, 10 ** 9) > 0 and built_lib.sort_tmp_bytes(3, 10 ** 9) > 0
 
 
+def test_ctypes_mirrors_have_the_size_of_the_c_structs(tmp_path):
+    """The structs that cross the C ABI by value or by pointer (vexhip_spmat_info and what it embeds): a C program compiled
+    against include/vexhip.h prints sizeof / offsetof, the ctypes mirrors of vexcl_amd/_capi.py must agree -- a field added on
+    one side only would shift every field behind it."""
+    import subprocess
+    from vexcl_amd import _capi
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "vexhip.h"\n'
+        'int main(void) {\n'
+        '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(vexhip_traversal), sizeof(vexhip_march), sizeof(vexhip_plane), sizeof(vexhip_grid),\n'
+        '         sizeof(vexhip_spmat_info), sizeof(vexhip_device_props));\n'
+        '  printf("%zu %zu %zu %zu %zu\\n", offsetof(vexhip_spmat_info, march), offsetof(vexhip_spmat_info, plane), offsetof(vexhip_spmat_info, grid),\n'
+        '         offsetof(vexhip_grid, x_last), offsetof(vexhip_grid, table));\n'
+        '  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    want = [ctypes.sizeof(_capi.Traversal), ctypes.sizeof(_capi.March), ctypes.sizeof(_capi.Plane), ctypes.sizeof(_capi.Grid),
+            ctypes.sizeof(_capi.SpMatInfo), ctypes.sizeof(_capi.DeviceProps),
+            _capi.SpMatInfo.march.offset, _capi.SpMatInfo.plane.offset, _capi.SpMatInfo.grid.offset, _capi.Grid.x_last.offset, _capi.Grid.table.offset]
+    assert [int(v) for v in out] == want, (out, want)
+
+
 def test_no_device_reports_zero_or_error(built_lib):
     # without a GPU the runtime must answer, not crash
     n = ctypes.c_int(-1)
