@@ -575,6 +575,47 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
 
 
+def test_storage_by_grid_line_holds_the_matrix(T, oracle, built_lib):
+    """The storage by grid line read back and decoded on the host: line_class[rows / nx], one table of 7 x pitch value codes per
+    class (255 = no entry), the value table and the diagonal table reproduce every row of the CSR matrix -- columns, values and
+    their ORDER (position order is storage order) -- for a matrix with natural boundaries (nine line classes, explicit zeros) and
+    for the benchmark's operator; the value table holds exactly the distinct values, the diagonal table is sorted."""
+    import ctypes
+    os.environ["VEXHIP_PLANE_FORCE"] = "1"
+    try:
+        for (ptr, col, val), shape in ((_grid7_natural(70, 11, 13, zero_face=True), (70, 11, 13)), (oracle.poisson3d(40), (40, 40, 40))):
+            nx, ny, nz = shape
+            m = len(ptr) - 1
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+            assert A.direct and A.grid is not None and A.grid["nx"] == nx and A.grid["lines_per_plane"] == ny, A.grid
+            g = A.info.grid
+            lines, classes, pitch = m // nx, int(g.classes), int(g.pitch)
+
+            def read(ptr_, nbytes, dtype):
+                host = np.empty(nbytes, dtype=np.uint8)
+                built_lib.memcpy_d2h(0, ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr_), nbytes, None, 1)
+                return host.view(dtype)
+            line_class = read(g.line_class, 4 * lines, np.int32)
+            table = read(g.table, classes * 7 * pitch, np.uint8).reshape(classes, 7, pitch)
+            values = read(A.info.values, 8 * 256, np.float64)
+            deltas = read(A.info.deltas, 4 * 256, np.int32)
+            nd, nv = int(A.info.ndeltas), int(A.info.nvalues)
+            assert sorted(set(val.tolist())) == sorted(values[:nv].tolist()) and values[255] == 0.0
+            by_pos = [-nx * ny, -nx, -1, 0, 1, nx, nx * ny]
+            assert deltas[:nd].tolist() == sorted(deltas[:nd].tolist()) and set(deltas[:nd].tolist()) <= set(by_pos)
+            assert set(deltas[:nd].tolist()) == set((col - np.repeat(np.arange(m), np.diff(ptr))).tolist())
+            assert line_class.min() >= 0 and line_class.max() < classes and (table[:, :, nx:] == 255).all()
+            rng = np.random.default_rng(5)
+            rows = np.unique(np.concatenate([rng.integers(0, m, 4000), np.arange(0, 3 * nx), np.arange(m - 3 * nx, m)]))
+            for i in rows:
+                codes = table[line_class[i // nx], :, i % nx]
+                got_cols = [i + by_pos[p] for p in range(7) if codes[p] != 255]
+                got_vals = [values[codes[p]] for p in range(7) if codes[p] != 255]
+                assert got_cols == col[ptr[i]:ptr[i + 1]].tolist() and got_vals == val[ptr[i]:ptr[i + 1]].tolist(), (shape, i)
+    finally:
+        os.environ.pop("VEXHIP_PLANE_FORCE", None)
+
+
 @pytest.mark.parametrize("tile", [2, 4])
 def test_plane_product_is_bit_identical(T, oracle, built_lib, tile):
     """The plane product (round 4: a workgroup owns `tile` grid lines of 512 points and walks through the planes; the +-512 and
