@@ -24,12 +24,14 @@
 #include <memory>
 #include <vexcl/vexcl.hpp>
 
-static const char *storage_name(int f) {
-    switch (f) {
+static const char *storage_name(const vexhip_spmat_info &info) {
+    if (info.format == VEXHIP_SPMAT_SELL8V && info.grid.usable && !info.sell && !info.code_pool)
+        return "by grid line (a class per line, 7 x nx value codes per class)";
+    switch (info.format) {
         case VEXHIP_SPMAT_SELL8V: return "sell8v (1-byte diagonal codes + 1-byte value codes)";
-        case VEXHIP_SPMAT_SELL8:  return "sell8 (1-byte diagonal codes, fp64 values)";
-        case VEXHIP_SPMAT_SELL:   return "sell32 (32-bit columns, fp64 values)";
-        case VEXHIP_SPMAT_CSR:    return "csr";
+        case VEXHIP_SPMAT_SELL8: return "sell8 (1-byte diagonal codes, fp64 values)";
+        case VEXHIP_SPMAT_SELL: return "sell32 (32-bit columns, fp64 values)";
+        case VEXHIP_SPMAT_CSR: return "csr";
     }
     return "?";
 }
@@ -124,7 +126,7 @@ static int multi_device(int64_t n, int M, int want) {
             const vexhip_spmat_info &info = A.storage_info(d);
             std::printf("%s{\"device\": %d, \"rows\": %zu, \"storage\": \"%s\", \"plane_product\": %d, \"event_ms\": %.5f, "
                         "\"step_ms\": {\"total\": %.5f, \"local\": %.5f, \"wait_for_ghosts\": %.5f, \"remote\": %.5f}}",
-                    d ? ", " : "", q[d].device_ordinal(), part[d + 1] - part[d], storage_name(info.format), (int)info.plane.usable, dev_ms[d],
+                    d ? ", " : "", q[d].device_ordinal(), part[d + 1] - part[d], storage_name(info), (int)info.plane.usable, dev_ms[d],
                     med[0], med[1], med[2], med[3]);
         }
         std::printf("]}\n");
@@ -183,7 +185,7 @@ int main(int argc, char **argv) {
                     "\"storage\": \"%s\", \"plane_product\": %d, \"rows\": %zu, \"nnz\": %zu, \"ms\": %.5f, \"gflops\": %.1f, "
                     "\"bytes_streamed\": %.0f, \"streamed_gbps\": %.1f, \"streamed_frac_of_8TBps\": %.4f, "
                     "\"csr_algorithmic_gbps\": %.1f, \"sum_y\": %.17g}\n",
-                variable ? "variable-coefficient" : "Poisson", (long long)n, storage_name(info.format), (int)info.plane.usable, N, nnz, ms, 2.0 * nnz / ms / 1e6,
+                variable ? "variable-coefficient" : "Poisson", (long long)n, storage_name(info), (int)info.plane.usable, N, nnz, ms, 2.0 * nnz / ms / 1e6,
                 moved, moved / ms / 1e6, moved / ms / 1e6 / 8000.0, (12.0 * nnz + 4.0 * (N + 1) + 16.0 * N) / ms / 1e6, checksum);
         std::fflush(stdout);
     }
