@@ -608,9 +608,8 @@ def main():
     L.event_create(local_rank, 1, ctypes.byref(e1))
 
     import gc
-    gc.collect()                       # a full collection takes ~40 ms in this process (see the set-up above): now, in front of the warm-ups,
-    gc.disable()                       # and none inside the blocks of K x 0.37 ms
-    for _ in range(args.warmup):
+    gc.disable()                       # a full collection takes ~40 ms in this process (see the set-up above): none inside the blocks of K x 0.37 ms
+    for _ in range(args.warmup):       # (and none right in front of them either: the device would idle and clock the first block down)
         step()
     # Five blocks of exactly K steps, each bracketed by a barrier + torch.cuda.synchronize() on both sides and by HIP events on
     # the launch stream; the wall time of a block is the MAX over the ranks.  Block 1 is the driver's contract (W warm-ups, then
