@@ -196,7 +196,8 @@ struct gb_dev {
     unsigned char *table; int *line_class;
 };
 
-__device__ __forceinline__ unsigned gb_vhash(unsigned long long bits) { return (unsigned)((bits * 0x9e3779b97f4a7c15ull) >> 55) & (GB_VSLOTS - 1); }
+// (two 32-bit multiplies: the 64-bit golden-ratio multiply was a dozen instructions per entry in a kernel bound by instruction issue)
+__device__ __forceinline__ unsigned gb_vhash(unsigned long long bits) { return ((((unsigned)bits ^ ((unsigned)(bits >> 32) * 0x9e3779b9u)) * 0x85ebca6bu) >> 23) & (GB_VSLOTS - 1); }
 
 // the device-wide code of a value: found, or numbered now (-1: the table is full / a writer never finished)
 __device__ int gb_global_value_code(unsigned long long bits, const gb_dev &g)
@@ -298,12 +299,17 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
             const unsigned long long bits = (unsigned long long)__double_as_longlong(n_v[u]);
             unsigned code = 255;
             if (active) {
+                // (the first probe almost always decides: straight-line code for it, the walk only behind a collision)
                 unsigned h = gb_vhash(bits);
-                for (int probe = 0; probe < GB_VSLOTS; ++probe) {
-                    const unsigned long long key = s_vkey[h];
-                    if (key == bits) { code = s_vcode[h]; break; }
-                    if (key == ~0ull) break;
-                    h = (h + 1) & (GB_VSLOTS - 1);
+                unsigned long long key = s_vkey[h];
+                if (key == bits) code = s_vcode[h];
+                else if (key != ~0ull) {
+                    for (int probe = 1; probe < GB_VSLOTS; ++probe) {
+                        h = (h + 1) & (GB_VSLOTS - 1);
+                        key = s_vkey[h];
+                        if (key == bits) { code = s_vcode[h]; break; }
+                        if (key == ~0ull) break;
+                    }
                 }
                 if (bits == ~0ull) { bad = true; code = 254; }
                 maxcol = n_c[u] > maxcol ? n_c[u] : maxcol;
@@ -346,14 +352,21 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                 if (e - b > 8 || e < b || b < 0 || e > cnt) bad = true;
                 else {
                     maxlen = e - b > maxlen ? e - b : maxlen;
-                    for (int j = b; j < e; ++j) {
-                        const long long d = (long long)s_c[j] - i;
-                        const int p = d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -g.nx ? 1 : d == g.nx ? 5 : d == -g.far ? 0 : d == g.far ? 6 : -1;
-                        const unsigned vc = s_vc[j];
-                        if (p <= last || vc >= 254u) { bad = true; break; }
-                        last = p;
-                        posmask |= 1u << p;
-                        sig = (sig & ~(0xffull << (8 * p))) | ((unsigned long long)vc << (8 * p));
+                    // eight predicated trips instead of a loop of e - b (per-lane trip counts: a scalar instruction per vector one)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = b + u;
+                        if (j < e) {
+                            const int d = s_c[j] - (int)i;                       // (rows and columns are below 2^31; a difference that wraps is no diagonal of the set)
+                            const int p = d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -g.nx ? 1 : d == g.nx ? 5 : d == -(int)g.far ? 0 : d == (int)g.far ? 6 : -1;
+                            const unsigned vc = s_vc[j];
+                            if (p <= last || vc >= 254u) bad = true;
+                            else {
+                                last = p;
+                                posmask |= 1u << p;
+                                sig ^= (unsigned long long)(255u ^ vc) << (8 * p);          // (the byte at p still holds 255: positions ascend)
+                            }
+                        }
                     }
                 }
 #pragma unroll
