@@ -301,7 +301,7 @@ int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double al
  * device: seven bytes per row (the value code per position, 255 = no entry), lines with equal rows form a class (<= 128), every
  * line is verified against its class; it declines (usable = 0) when a row's entries do not ascend by position, when more
  * than 1/4 of the lines use another class than the most frequent one, for fp32, a CSR tail, fewer than 2^23 rows (x within the caches: the pair product is as fast) or 4 planes.
- * The product owns two adjacent lines (one segment of <= 512 rows of them) per workgroup and walks through `depth` planes;
+ * The product owns two adjacent lines (one segment of <= 512 rows of them, <= 1024 for nx > 768) per workgroup and walks through `depth` planes;
  * lines need not be 16-byte aligned (odd nx), lines_per_plane may be odd.  line_class / table are device memory owned by the
  * plan: vexhip_sell8_grid_release frees them.  VEXHIP_PLANE_DEPTH / VEXHIP_PLANE_STORE override, VEXHIP_NO_GRID declines.  */
 typedef struct vexhip_grid { int32_t usable;
@@ -309,12 +309,12 @@ typedef struct vexhip_grid { int32_t usable;
                              int32_t lines_per_plane;   /* the far diagonals are +-nx * lines_per_plane                       */
                              int32_t planes;            /* ceil(lines / lines_per_plane)                                      */
                              int32_t depth;             /* planes one workgroup walks through                                 */
-                             int32_t segments;          /* segments per line (nx > 512: more than one)                        */
-                             int32_t segment_rows;      /* rows per segment (even, <= 512)                                    */
-                             int32_t threads;           /* lanes per workgroup: 64 * ceil(segment_rows / 128)                 */
+                             int32_t segments;          /* segments per line: ceil(nx / 512), ceil(nx / 1024) for nx > 768    */
+                             int32_t segment_rows;      /* rows per segment (even, <= 512; <= 1024 for nx > 768)              */
+                             int32_t threads;           /* lanes per workgroup: 64 * ceil(segment_rows / 128), <= 512         */
                              int32_t hot_class;         /* line class kept decoded in registers                               */
                              int32_t classes;           /* distinct line classes                                              */
-                             int32_t pitch;             /* bytes per position row of a class table                            */
+                             int32_t pitch;             /* bytes per position row of a class table (>= what the lanes read)   */
                              int32_t store_policy;      /* as vexhip_plane.store_policy                                       */
                              int64_t x_last;
                              const int32_t *line_class; /* device: class of every grid line                                   */
@@ -323,6 +323,13 @@ typedef struct vexhip_grid { int32_t usable;
 int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const void *codes, const int32_t *blocks,
         int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes, int64_t x_last, vexhip_grid *out);
 int vexhip_sell8_grid_release(int dev, vexhip_grid *grid);
+/* The geometry the two set-ups choose for an nx x lines_per_plane x planes grid on a device with `cus` compute units -- host
+ * arithmetic only, no device is touched: nx .. threads, pitch and store_policy are filled, usable = 0, no tables (depth = 0: no
+ * geometry, a plane too large for 32-bit offsets).  vexhip_sell8_grid_check returns 0 when the product accepts the plan's geometry
+ * for a matrix of n rows (the same test the product runs before every launch).  Both exist so that the plan of EVERY line length
+ * can be checked where there is no GPU (tests/test_capi_exports.py).                                                            */
+int vexhip_sell8_grid_geometry(int cus, int64_t nx, int64_t lines_per_plane, int64_t planes, vexhip_grid *out);
+int vexhip_sell8_grid_check(const vexhip_grid *grid, int64_t n);
 int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, int append, const double *values,
         const double *x, double *y, const vexhip_grid *grid);
 int64_t vexhip_sell8_last_fill_max_col(void);

@@ -97,3 +97,27 @@ def test_missing_library_fails_loudly(tmp_path):
     from vexcl_amd import _capi
     with pytest.raises(_capi.Error):
         _capi._Lib(str(tmp_path / "nope.so"))
+
+
+def test_grid_plan_of_every_line_length_is_one_the_product_accepts(built_lib):
+    """The by-grid-line storage (grid.hip) is the ONLY storage of a matrix the one-pass set-up has built, so a plan the product
+    refuses ("bad grid plan") leaves that matrix without a product.  Host arithmetic only (no device): for every line length the
+    set-up accepts (8 .. 4096), flat and tall grids, devices of 64 and 256 CUs, the geometry must pass the product's own check.
+    (Round 4: lines of 2521 .. 2560 points got three segments whose last lanes read 4 .. 28 bytes beyond the rounded line length.)"""
+    from vexcl_amd import _capi
+    L = _capi.lib()
+    refused = []
+    for cus in (64, 256):
+        for nx in range(8, 4097):
+            for ny, nz in ((2, 4), (3, 1000), (nx, nx), (5, 70001)):
+                g = _capi.Grid()
+                L.sell8_grid_geometry(cus, nx, ny, nz, ctypes.byref(g))
+                if g.depth == 0:                      # no geometry: the set-ups keep the SELL-512 storage (a plane of 2^32 bytes or more)
+                    assert (4 + 8) * ny * nx * 8 >= (1 << 32), (nx, ny, nz)
+                    continue
+                assert g.nx == nx and g.lines_per_plane == ny and g.planes == nz and 1 <= g.depth <= nz
+                try:
+                    L.sell8_grid_check(ctypes.byref(g), nx * ny * nz)
+                except _capi.Error:
+                    refused.append((cus, nx, ny, nz, g.segments, g.segment_rows, g.threads, g.pitch))
+    assert not refused, refused[:10]

@@ -733,7 +733,13 @@ void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, dou
 struct grid_geometry { long long segs, seg_len, pitch, depth; int threads; };
 inline long long grid_pitch(long long nx) { return (((nx + 511) / 512) * 512 + 2 + 15) / 16 * 16; }
 
+bool grid_geometry_with(long long cus, long long nx, long long ny, long long nz, grid_geometry *geo);
 bool grid_geometry_for(int dev, long long nx, long long ny, long long nz, grid_geometry *geo)
+{
+    return grid_geometry_with(std::max(1, info(dev).cus), nx, ny, nz, geo);
+}
+// (host arithmetic only: vexhip_sell8_grid_geometry exposes it so that the plans of every line length can be checked without a device)
+bool grid_geometry_with(long long cus, long long nx, long long ny, long long nz, grid_geometry *geo)
 {
     // lines of up to 1024 points in one segment (workgroups of up to 512 lanes), longer ones in segments of <= 1024 rows
     // (640^3 / 700^3: one 640- / 700-row segment = 1.26 / 1.55 ms -- few waves per CU -- against 0.97 / 1.37 ms in two segments;
@@ -743,9 +749,12 @@ bool grid_geometry_for(int dev, long long nx, long long ny, long long nz, grid_g
     const long long segs = (nx + max_seg - 1) / max_seg;
     long long seg_len = (nx + segs - 1) / segs; seg_len += seg_len & 1;
     const int threads = (int)std::min<long long>(max_seg / 2, ((seg_len + 1) / 2 + 63) / 64 * 64);
-    const long long pitch = grid_pitch(nx);
+    // a position row of a class table covers what the lanes of the LAST segment read: lanes beyond the end of the line read
+    // (and ignore) two bytes each.  Lines of 2521 .. 2560 points -- three segments of 842 .. 854 rows, 448 lanes -- reach up to
+    // 28 bytes beyond the rounded line length: the plan of such a matrix was refused by the product ("bad grid plan")
+    const long long pitch = (std::max(grid_pitch(nx), (segs - 1) * seg_len + 2 * (long long)threads) + 15) / 16 * 16;
     const long long tiles = (ny + 1) / 2 * segs;
-    const long long cus = std::max(1, info(dev).cus);
+    cus = std::max(1ll, cus);
     // Planes per workgroup.  Few, long workgroups (plane.hip: every workgroup re-reads the planes around its walk) -- but
     //   * lines that are not 512 points long want at least ~6 waves per CU (their requests straddle cache lines, a wave hides
     //     less of the latency by itself), and
@@ -1033,15 +1042,35 @@ int vexhip_sell8_grid_release(int dev, vexhip_grid *g)
     return 0;
 }
 
+int vexhip_sell8_grid_geometry(int cus, int64_t nx, int64_t lines_per_plane, int64_t planes, vexhip_grid *out)
+{
+    VEXHIP_REQUIRE(out, "NULL output");
+    std::memset(out, 0, sizeof(*out));
+    VEXHIP_REQUIRE(nx >= 8 && nx < (1ll << 30) && lines_per_plane >= 2 && lines_per_plane < (1ll << 30) && planes >= 1 && planes < (1ll << 30), "bad grid");
+    grid_geometry geo;
+    if (!grid_geometry_with(cus, nx, lines_per_plane, planes, &geo)) return 0;          // depth = 0: no geometry (a plane too large for 32-bit offsets)
+    grid_fill_plan(out, nx, lines_per_plane, planes, geo, 0, 0, -1);
+    return 0;
+}
+
+int vexhip_sell8_grid_check(const vexhip_grid *g, int64_t n)
+{
+    VEXHIP_REQUIRE(g, "NULL plan");
+    VEXHIP_REQUIRE(g->nx >= 8 && n > 0 && n % g->nx == 0 && g->lines_per_plane >= 2 && g->depth >= 1 && g->planes >= 1 && g->segments >= 1
+                   && g->segment_rows >= 2 && g->segment_rows <= 1024 && g->segment_rows % 2 == 0 && (long long)g->segments * g->segment_rows >= g->nx
+                   && g->threads >= 64 && g->threads <= 512 && g->threads % 64 == 0 && 2 * g->threads >= g->segment_rows
+                   && (long long)(g->segments - 1) * g->segment_rows + 2 * g->threads <= g->pitch && g->pitch % 16 == 0
+                   && ((n / g->nx + g->lines_per_plane - 1) / g->lines_per_plane) == g->planes
+                   && ((long long)g->depth + 4) * g->lines_per_plane * g->nx * 8 < (1ll << 32), "bad grid plan");
+    return 0;
+}
+
 int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, int append, const double *values,
         const double *x, double *y, const vexhip_grid *g)
 {
     VEXHIP_REQUIRE(g && g->usable && g->line_class && g->table && values && x && y, "bad grid product arguments");
-    VEXHIP_REQUIRE(g->nx >= 8 && n > 0 && n % g->nx == 0 && g->lines_per_plane >= 2 && g->depth >= 1 && g->planes >= 1 && g->segments >= 1
-                   && g->segment_rows >= 2 && g->segment_rows <= 1024 && g->segment_rows % 2 == 0 && (long long)g->segments * g->segment_rows >= g->nx
-                   && g->threads >= 64 && g->threads <= 512 && g->threads % 64 == 0 && 2 * g->threads >= g->segment_rows
-                   && (long long)(g->segments - 1) * g->segment_rows + 2 * g->threads <= g->pitch && g->x_last + 1 >= n
-                   && ((long long)g->depth + 4) * g->lines_per_plane * g->nx * 8 < (1ll << 32), "bad grid plan");
+    if (int rc = vexhip_sell8_grid_check(g, n)) return rc;
+    VEXHIP_REQUIRE(g->x_last + 1 >= n, "bad grid plan");
     VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "grid product: x and y must be 8-byte aligned");
     VEXHIP_SET_DEVICE(dev);
     grid_dev gd;
