@@ -662,6 +662,22 @@ def test_plane_product_is_bit_identical(T, oracle, built_lib, tile):
         ya = torch.empty(m, dtype=torch.float64, device=T.dev)
         A.apply(T.up(xb), ya)
         assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xb), equal_nan=True)
+        # vectors that start at an odd element (views into larger vectors: 8-byte, not 16-byte addresses).  The plane product moves
+        # 16-byte pieces at 16-byte addresses and is not launched on them: the grid product (matrix stored by grid line -- it has
+        # no other storage) or the march / pair products take the call, same bits
+        xb = oracle.random_f64(27, m); y0 = oracle.random_f64(28, m)
+        want = oracle.spmv_csr(ptr, col, val, xb)
+        for direct in (True, False):
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct)
+            assert A.plane is not None and A.direct == direct
+            for alpha, append in ((1.0, False), (-0.75, True)):
+                xbig = torch.zeros(m + 3, dtype=torch.float64, device=T.dev); ybig = torch.zeros(m + 3, dtype=torch.float64, device=T.dev)
+                for xo, yo in ((1, 1), (1, 0), (0, 1)):
+                    xv, yv = xbig[xo:xo + m], ybig[yo:yo + m]
+                    assert (xv.data_ptr() % 16 != 0) == (xo == 1) and (yv.data_ptr() % 16 != 0) == (yo == 1)
+                    xv.copy_(T.up(xb)); yv.copy_(T.up(y0))
+                    A.apply(xv, yv, alpha, append)
+                    assert np.array_equal(yv.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (direct, alpha, xo, yo)
         os.environ.pop("VEXHIP_PLANE_FORCE")
 
         # (b) the plan as the library chooses it

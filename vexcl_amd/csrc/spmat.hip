@@ -391,8 +391,11 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
     const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
     switch (A->format) {
         case VEXHIP_SPMAT_SELL8V:
+            // (the plane product moves x and y in 16-byte pieces at 16-byte addresses; vectors that start at an odd element -- a view
+            //  into a larger vector -- take the grid product, which addresses by element, or the older products)
             if constexpr (std::is_same<V, double>::value)
-                if ((A->blocks || A->direct) && A->plane.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
+                if ((A->blocks || A->direct) && A->plane.usable && (g_sell8_variant == 0 || A->direct) && !A->tail
+                    && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
                     return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
                                                             A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
             if constexpr (std::is_same<V, double>::value)
