@@ -213,7 +213,17 @@ TEST_CASE(by_key_kernels_compile) {                                   // scan_by
     }
     std::string s = source<int, equal_fn<unsigned>, plus_fn<int>>(q, {"uint"}, EXCLUSIVE);
     CHECK(has(s, "sbk_plus(init, prev.v)"));
+    CHECK(!has(s, "vexcl_sbk_pipe"));                                  // the pipelined single pass is not part of the default source
     backend::check_sources(s);
+    // VEXCL_SBK_PIPELINE=1 (round 4, experimental): the same single pass with the next tile's elements in flight; every mode compiles
+    setenv("VEXCL_SBK_PIPELINE", "1", 1);
+    for (scan_mode m : {INCLUSIVE, EXCLUSIVE, REDUCE}) {
+        std::string p = source<double, decltype(keys_equal), decltype(dplus)>(q, {"int", "long"}, m);
+        CHECK(has(p, "vexcl_sbk_pipe") && has(p, "sbk_fetch_ragged") && has(p, "#define PW 7"));
+        backend::check_sources(p);
+    }
+    backend::check_sources(source<float, equal_fn<int>, plus_fn<float>>(q, {"int"}, INCLUSIVE));
+    unsetenv("VEXCL_SBK_PIPELINE");
 }
 
 namespace {

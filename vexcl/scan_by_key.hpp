@@ -75,7 +75,8 @@ std::vector<std::string> key_types(std::index_sequence<I...>) {
 struct kernels {
     backend::kernel reduce, carry_local, carry, scan;
     backend::kernel lookback, count;       // single-pass form (valid when has_lookback)
-    bool has_lookback = false;
+    backend::kernel pipe;                  // pipelined single pass (valid when has_pipe: VEXCL_SBK_PIPELINE=1)
+    bool has_lookback = false, has_pipe = false;
 };
 
 // geometry of the single-pass kernel: waves per workgroup, rows of 64 x ITEMS elements per wave (tuning: VEXCL_SBK_WAVES / _ROWS)
@@ -83,7 +84,248 @@ inline int lb_env(const char *name, int def) { const char *e = std::getenv(name)
 static const int LB_WAVES = lb_env("VEXCL_SBK_WAVES", 16);
 static const int LB_ROWS = lb_env("VEXCL_SBK_ROWS", 4);
 template <class V> struct lookback_value { static const bool value = std::is_arithmetic<V>::value && (sizeof(V) == 4 || sizeof(V) == 8); };
+// Round 4, not the default yet (VEXCL_SBK_PIPELINE=1): the single pass as a PIPELINE.  A workgroup keeps taking tiles; its worker
+// waves hold the elements of the NEXT tile in flight while they work on this one, and one extra wave that holds no elements does
+// the look-back (its polls are not queued behind a tile's worth of loads).  See vexcl_sbk_pipe in source().
+inline bool pipe_enabled() { const char *e = std::getenv("VEXCL_SBK_PIPELINE"); return e && std::atoi(e) != 0; }
+inline int pipe_waves() { const int w = lb_env("VEXCL_SBK_PIPE_WAVES", 7); return w < 1 ? 1 : (w > 15 ? 15 : w); }
+inline int pipe_rows() { const int r = lb_env("VEXCL_SBK_PIPE_ROWS", 4); return r < 1 ? 1 : (r > 8 ? 8 : r); }
 inline bool lookback_enabled() { const char *e = std::getenv("VEXCL_SCAN_BY_KEY"); return !(e && std::string(e) == "tree"); }
+
+/// vexcl_sbk_pipe: the single pass of vexcl_sbk_lookback as a pipeline (uses the helpers that kernel's text defines).
+/// The one-tile kernel spends a tile's time twice: ~9 us streaming its 196 KB, then as long again in wave scans, two barriers, the
+/// look-back and the second pass, with nothing else resident on the CU (104 registers x 16 waves).  Here a workgroup of PW worker
+/// waves + one scan wave takes tile after tile (tickets, two ahead):
+///   step:  workers: rows of THIS tile (elements requested one step ago) -> aggregates -> request the NEXT tile's elements
+///          barrier;  scan wave: fold the aggregates, publish, look back, publish the inclusive prefix;  barrier
+///          workers: second pass over this tile's values, stores;  barrier
+/// The next tile's loads stay in flight through all of it: the barriers are bare s_barrier behind an LDS-only wait (a fence at
+/// workgroup scope would drain vmcnt, i.e. wait for the loads), and the wave that polls the predecessors' status words holds no
+/// elements -- on gfx950 loads return in order, a poll behind 12 KB of requests would wait for all of them.
+template <class V, class Comp, class Oper>
+void pipe_source(std::ostringstream &s, const std::vector<std::string> &K, scan_mode mode) {
+    const size_t nk = K.size();
+    const int PW = pipe_waves();
+    auto key_params = [&]() { std::ostringstream p; for (size_t k = 0; k < nk; ++k) p << "const " << K[k] << " *key" << k << ", "; return p.str(); };
+    auto key_args = [&]() { std::ostringstream p; for (size_t k = 0; k < nk; ++k) p << "key" << k << ", "; return p.str(); };
+    s << "\n#define PW " << PW << "\n#define PLBR " << pipe_rows() << "\n"
+         "#define SBK_BAR() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
+         "struct sbk_in {\n";
+    for (size_t k = 0; k < nk; ++k) s << "  " << K[k] << " k" << k << "[PLBR][ITEMS], e" << k << "[PLBR];\n";      // e: lane 0's key before the row's first element
+    s << "  val_t v[PLBR][ITEMS];\n"
+         "};\n"
+         // complete rows only (a scalar test: no divergent arms whose merge would wait for the loads just issued); the rows of the
+         // ragged last tile are loaded where they are used (sbk_fetch_ragged)
+         "__device__ inline void sbk_fetch(sbk_in &x, ulong n, ulong wbase, int lane, " << key_params() << "const val_t *vals) {\n"
+         "  #pragma unroll\n"
+         "  for (int r = 0; r < PLBR; ++r) {\n"
+         "    const ulong row0 = wbase + (ulong)r * (64 * ITEMS), i0 = row0 + (ulong)lane * ITEMS;\n"
+         "    if (row0 + 64 * ITEMS <= n) {\n"
+         "      #pragma unroll\n"
+         "      for (int j = 0; j < ITEMS; ++j) {\n";
+    for (size_t k = 0; k < nk; ++k) s << "        x.k" << k << "[r][j] = key" << k << "[i0 + j];\n";
+    s << "        x.v[r][j] = vals[i0 + j];\n"
+         "      }\n"
+         "    }\n";
+    for (size_t k = 0; k < nk; ++k)
+        s << "    x.e" << k << "[r] = (" << K[k] << ")0;\n"
+             "    if (lane == 0 && i0 > 0 && i0 < n) x.e" << k << "[r] = key" << k << "[i0 - 1];\n";
+    s << "  }\n"
+         "}\n"
+         "__device__ inline void sbk_fetch_ragged(sbk_in &x, int r, ulong n, ulong i0, " << key_params() << "const val_t *vals) {\n"
+         "  #pragma unroll\n"
+         "  for (int j = 0; j < ITEMS; ++j) {\n"
+         "    const bool in = i0 + j < n;\n";
+    for (size_t k = 0; k < nk; ++k) s << "    x.k" << k << "[r][j] = in ? key" << k << "[i0 + j] : (" << K[k] << ")0;\n";
+    s << "    x.v[r][j] = in ? vals[i0 + j] : val_t();\n"
+         "  }\n"
+         "}\n"
+         "extern \"C\" __global__ void __launch_bounds__(" << (PW + 1) * 64 << ") vexcl_sbk_pipe(ulong n, long nt, " << key_params()
+      << "const val_t *vals, sbk_word *ws, ";
+    if (mode == REDUCE) {
+        for (size_t k = 0; k < nk; ++k) s << K[k] << " *okey" << k << ", ";
+        s << "val_t *ovals, int cap) {\n";
+    } else {
+        s << "val_t *ovals, val_t init) {\n";
+    }
+    s << "  __shared__ sbk_t agg[PW];\n"
+         "  __shared__ val_t s_x[sizeof(val_t) == 8 ? PW : 1][ITEMS * 64] __attribute__((aligned(16)));\n"
+         "  __shared__ long s_tile[4];\n"           // ring: s_tile[i & 3] = ticket of this workgroup's i-th tile
+         "  __shared__ sbk_t s_pre;\n"
+         "  sbk_word *status = ws + 2;\n"
+         "  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"      // (a scalar: the tests on a wave's rows are scalar branches)
+         "  const bool scanner = wave == PW;\n"
+         "  const unsigned long long below = (1ull << lane) - 1ull;\n"
+         "  if (threadIdx.x == PW * 64) { s_tile[0] = (long)atomicAdd(&ws[0], 1ull); s_tile[1] = (long)atomicAdd(&ws[0], 1ull); }\n"
+         "  SBK_BAR();\n"
+         "  if (s_tile[0] >= nt) return;\n"
+         "  sbk_in A, B;\n"
+         "  if (!scanner) sbk_fetch(A, n, ((ulong)s_tile[0] * PW + wave) * (PLBR * ITEMS * 64), lane, " << key_args() << "vals);\n"
+         // one step: `cur` holds this tile's elements (requested a step ago), `nxt` receives the next tile's; false: that was the last tile
+         "  auto step = [&](sbk_in &cur, sbk_in &nxt, long it) -> bool {\n"
+         "    const long tile = s_tile[it & 3], next = s_tile[(it + 1) & 3];\n"
+         "    const ulong wbase = ((ulong)tile * PW + (scanner ? 0 : wave)) * (PLBR * ITEMS * 64);\n"
+         "    sbk_t pre[PLBR];\n"
+         "    unsigned heads = 0;\n"
+         "    if (scanner) {\n"
+         "      if (lane == 0) s_tile[(it + 2) & 3] = (long)atomicAdd(&ws[0], 1ull);\n"      // the ticket after next: read two barriers later
+         "    } else {\n"
+         "      sbk_t carry = sbk_empty();\n"
+         "      #pragma unroll\n"
+         "      for (int r = 0; r < PLBR; ++r) {\n"
+         "        const ulong row0 = wbase + (ulong)r * (64 * ITEMS), i0 = row0 + (ulong)lane * ITEMS;\n"
+         "        unsigned h = 0, ok = 0;\n"
+         "        if (row0 + 64 * ITEMS <= n) ok = (1u << ITEMS) - 1u;\n"
+         "        else {\n"
+         "          sbk_fetch_ragged(cur, r, n, i0, " << key_args() << "vals);\n"
+         "          #pragma unroll\n"
+         "          for (int j = 0; j < ITEMS; ++j) ok |= (unsigned)(i0 + j < n) << j;\n"
+         "        }\n";
+    for (size_t k = 0; k < nk; ++k)
+        s << "        " << K[k] << " p" << k << " = __shfl_up(cur.k" << k << "[r][ITEMS - 1], 1, 64);\n"
+          << "        if (lane == 0) p" << k << " = cur.e" << k << "[r];\n";
+    s << "        val_t tail = val_t();\n"
+         "        #pragma unroll\n"
+         "        for (int j = 0; j < ITEMS; ++j) {\n";
+    for (size_t k = 0; k < nk; ++k)
+        s << "          const " << K[k] << " pk" << k << " = j ? cur.k" << k << "[r][j ? j - 1 : 0] : p" << k << ";\n";
+    s << "          const bool hd = ((ok >> j) & 1u) && ((i0 + j == 0) || !" << Comp::name() << "(";
+    for (size_t k = 0; k < nk; ++k) s << "pk" << k << ", ";
+    for (size_t k = 0; k < nk; ++k) s << "cur.k" << k << "[r][j]" << (k + 1 < nk ? ", " : "");
+    s << "));\n"
+         "          h |= (unsigned)hd << j;\n"
+         "          if ((ok >> j) & 1u) tail = (hd || j == 0) ? cur.v[r][j] : " << Oper::name() << "(tail, cur.v[r][j]);\n"
+         "        }\n"
+         "        heads |= h << (r * ITEMS);\n"
+         "        const unsigned long long H = __ballot(h != 0u), any = __ballot(ok != 0u);\n"
+         "        const unsigned long long upto = H & (below | (1ull << lane));\n"
+         "        const int hl = upto ? 63 - __builtin_clzll(upto) : 0;\n"
+         "        val_t T = tail;\n"
+         "        #pragma unroll\n"
+         "        for (int o = 1; o < 64; o <<= 1) {\n"
+         "          const val_t u = __shfl_up(T, o, 64);\n"
+         "          if (lane - o >= hl && ((any >> lane) & 1ull)) T = " << Oper::name() << "(u, T);\n"
+         "        }\n"
+         "        int cb = 0;\n"
+         "        #pragma unroll\n"
+         "        for (int j = 0; j < ITEMS; ++j) cb += __popcll(__ballot((h >> j) & 1u) & below);\n"
+         "        sbk_t p; p.c = cb; p.f = ((any & below) ? 2 : 0) | ((H & below) ? 1 : 0); p.v = __shfl_up(T, 1, 64);\n"
+         "        if (lane == 0) p = sbk_empty();\n"
+         "        pre[r] = sbk_combine(carry, p);\n"
+         "        sbk_t ra; ra.c = 0;\n"
+         "        #pragma unroll\n"
+         "        for (int j = 0; j < ITEMS; ++j) ra.c += __popcll(__ballot((h >> j) & 1u));\n"
+         "        ra.f = (any ? 2 : 0) | (H ? 1 : 0);\n"
+         "        ra.v = __shfl(T, any ? 63 - __builtin_clzll(any) : 0, 64);\n"
+         "        carry = sbk_combine(carry, ra);\n"
+         "      }\n"
+         "      if (lane == 0) agg[wave] = carry;\n"
+         "      if (next < nt) sbk_fetch(nxt, n, ((ulong)next * PW + wave) * (PLBR * ITEMS * 64), lane, " << key_args() << "vals);\n"
+         "    }\n"
+         "    SBK_BAR();\n"
+         "    if (scanner) {\n"
+         "      sbk_t t = agg[0];\n"
+         "      for (int w = 1; w < PW; ++w) t = sbk_combine(t, agg[w]);\n"
+         "      if (lane == 0) sbk_publish(status, tile, t, tile == 0 ? 2u : 1u);\n"
+         "      sbk_t excl = sbk_empty();\n"
+         "      long base = tile - 1, spins = 0;\n"
+         "      while (base >= 0) {\n"
+         "        const long idx = base - lane;\n"
+         "        sbk_t q = sbk_empty();\n"
+         "        unsigned st = 2u;\n"
+         "        if (idx >= 0) st = sbk_read(status, idx, q);\n"
+         "        while (__any(st == 0u)) {\n"
+         "          __builtin_amdgcn_s_sleep(8);\n"
+         "          if (idx >= 0 && st == 0u) st = sbk_read(status, idx, q);\n"
+         "          if (++spins > (1l << 30)) __builtin_trap();\n"
+         "        }\n"
+         "        const unsigned long long incl = __ballot(st == 2u);\n"
+         "        const int first = incl ? __builtin_ctzll(incl) : 63;\n"
+         "        if (lane > first) q = sbk_empty();\n"
+         "        for (int o = 1; o < 64; o <<= 1) {\n"
+         "          sbk_t u = sbk_down(q, o);\n"
+         "          if (lane + o < 64) q = sbk_combine(u, q);\n"
+         "        }\n"
+         "        excl = sbk_combine(sbk_from(q, 0), excl);\n"
+         "        if (incl) break;\n"
+         "        base -= 64;\n"
+         "      }\n"
+         "      if (lane == 0) {\n"
+         "        if (tile > 0) sbk_publish(status, tile, sbk_combine(excl, t), 2u);\n"
+         "        s_pre = excl;\n"
+         "      }\n"
+         "    }\n"
+         "    SBK_BAR();\n"
+         "    if (!scanner) {\n"
+         "      sbk_t W = s_pre;\n"
+         "      for (int w = 0; w < wave; ++w) W = sbk_combine(W, agg[w]);\n"
+         "      #pragma unroll\n"
+         "      for (int r = 0; r < PLBR; ++r) {\n"
+         "        const ulong row0 = wbase + (ulong)r * (64 * ITEMS), i0 = row0 + (ulong)lane * ITEMS;\n"
+         "        sbk_t prev = sbk_combine(W, pre[r]);\n";
+    if (mode != REDUCE) {
+        s << "        if (row0 + 64 * ITEMS <= n && ((ulong)ovals & 15) == 0) {\n"
+             "          val_t out[ITEMS];\n"
+             "          #pragma unroll\n"
+             "          for (int j = 0; j < ITEMS; ++j) {\n"
+             "            const bool head = (heads >> (r * ITEMS + j)) & 1u;\n"
+             "            sbk_t x; x.c = head; x.f = 2 | (int)head; x.v = cur.v[r][j];\n"
+             "            const sbk_t fin = sbk_combine(prev, x);\n";
+        if (mode == INCLUSIVE) s << "            (void)init; out[j] = fin.v;\n";
+        else                   s << "            out[j] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+        s << "            prev = fin;\n"
+             "          }\n"
+             "          typedef val_t sbk_vecp __attribute__((ext_vector_type(16 / sizeof(val_t))));\n"
+             "          #define NQ ((int)(ITEMS * sizeof(val_t) / 16))\n"
+             "          sbk_vecp o[NQ];\n"
+             "          #pragma unroll\n"
+             "          for (int q = 0; q < NQ; ++q)\n"
+             "            #pragma unroll\n"
+             "            for (int e = 0; e < (int)(16 / sizeof(val_t)); ++e) o[q][e] = out[q * (16 / sizeof(val_t)) + e];\n"
+             "          if (NQ == 1) { ((sbk_vecp *)(ovals + row0))[lane] = o[0]; continue; }\n"
+             "          sbk_vecp *sx = (sbk_vecp *)s_x[wave];\n"
+             "          #pragma unroll\n"
+             "          for (int q = 0; q < NQ; ++q) sx[lane * NQ + q] = o[q];\n"
+             "          __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n"
+             "          #pragma unroll\n"
+             "          for (int q = 0; q < NQ; ++q) ((sbk_vecp *)(ovals + row0))[q * 64 + lane] = sx[q * 64 + lane];\n"
+             "          __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();\n"
+             "          #undef NQ\n"
+             "          continue;\n"
+             "        }\n";
+    }
+    s << "        #pragma unroll\n"
+         "        for (int j = 0; j < ITEMS; ++j) {\n"
+         "          const ulong i = i0 + j;\n"
+         "          if (i < n) {\n"
+         "            const bool head = (heads >> (r * ITEMS + j)) & 1u;\n"
+         "            sbk_t x; x.c = head; x.f = 2 | (int)head; x.v = cur.v[r][j];\n"
+         "            const sbk_t fin = sbk_combine(prev, x);\n";
+    if (mode == INCLUSIVE) {
+        s << "            (void)init; ovals[i] = fin.v;\n";
+    } else if (mode == EXCLUSIVE) {
+        s << "            ovals[i] = head ? init : " << Oper::name() << "(init, prev.v);\n";
+    } else {
+        s << "            if (head && fin.c <= cap) {\n";
+        for (size_t k = 0; k < nk; ++k) s << "              okey" << k << "[fin.c - 1] = cur.k" << k << "[r][j];\n";       // (the key is in a register: no second read)
+        s << "              if (fin.c > 1) ovals[fin.c - 2] = prev.v;\n"
+             "            }\n"
+             "            if (i == n - 1) { if (fin.c <= cap) ovals[fin.c - 1] = fin.v; ((int *)(ws + 1))[0] = fin.c; }\n";
+    }
+    s << "            prev = fin;\n"
+         "          }\n"
+         "        }\n"
+         "      }\n"
+         "    }\n"
+         "    SBK_BAR();\n"                        // agg, s_pre and the ticket slots are free for the next step
+         "    return next < nt;\n"
+         "  };\n"
+         "  for (long it = 0;; it += 2) {\n"
+         "    if (!step(A, B, it)) break;\n"
+         "    if (!step(B, A, it + 1)) break;\n"
+         "  }\n"
+         "}\n";
+}
 
 /// Source of the three kernels for the given key types, value type, functions and mode.
 template <class V, class Comp, class Oper>
@@ -577,6 +819,7 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "  __syncthreads();\n"
              "  if (threadIdx.x == 0 && (wc[0] + wc[1] + wc[2] + wc[3])) atomicAdd(total, wc[0] + wc[1] + wc[2] + wc[3]);\n"
              "}\n";
+        if (pipe_enabled()) pipe_source<V, Comp, Oper>(s, K, mode);
     }
     return src.str() + s.str();
 }
@@ -612,6 +855,7 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
             k.lookback = backend::kernel(q, prog, "vexcl_sbk_lookback");
             k.count = backend::kernel(q, prog, "vexcl_sbk_count");
             k.has_lookback = true;
+            if (pipe_enabled()) { k.pipe = backend::kernel(q, prog, "vexcl_sbk_pipe"); k.has_pipe = true; }
         }
         it = cache.insert(q, std::move(k));
     }
@@ -619,7 +863,8 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
 
     if (K.has_lookback && !three_phases && lookback_enabled()) {
         // ---- single pass: [count the run heads (keys only) -> size the outputs] -> decoupled look-back over the tiles
-        const size_t LT = size_t(LB_ROWS) * ITEMS * LB_WAVES * 64;
+        const bool piped = K.has_pipe;
+        const size_t LT = size_t(piped ? pipe_rows() : LB_ROWS) * ITEMS * (piped ? pipe_waves() : LB_WAVES) * 64;
         const size_t nt = (n + LT - 1) / LT;
         precondition(nt < (size_t(1) << 31), "input too large");
         const size_t words = 2 + (sizeof(V) == 8 ? 3 : 2) * nt;
@@ -630,6 +875,19 @@ int run(const KTuple &keys, const vector<V> &ivals, Comp, Oper, PushOutputs &&pu
         int *total = reinterpret_cast<int *>(ws + 1);
         auto read_total = [&]() { int c = 0; backend::device_vector<int> t = backend::device_vector<int>::wrap(total, 1); t.read(q, 0, 1, &c, true); return c; };
         auto launch = [&](int cap) {
+            if (piped) {
+                // as many workgroups as can be resident at once (one per CU: ~170 registers x 12 waves), each takes tiles until none is left
+                K.pipe.push_arg(n);
+                K.pipe.push_arg(static_cast<long>(nt));
+                for_each_key(keys, [&](const auto &k) { K.pipe.push_arg(k(0).raw()); }, seq());
+                K.pipe.push_arg(ivals(0).raw());
+                K.pipe.push_arg(ws);
+                push_outputs(K.pipe, cap);
+                if (mode == REDUCE) K.pipe.push_arg(cap);
+                K.pipe.config(std::min<size_t>(nt, static_cast<size_t>(lb_env("VEXCL_SBK_PIPE_GROUPS", 256))), (pipe_waves() + 1) * 64);
+                K.pipe(q);
+                return;
+            }
             K.lookback.push_arg(n);
             for_each_key(keys, [&](const auto &k) { K.lookback.push_arg(k(0).raw()); }, seq());
             K.lookback.push_arg(ivals(0).raw());
