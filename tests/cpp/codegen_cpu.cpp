@@ -224,6 +224,15 @@ TEST_CASE(by_key_kernels_compile) {                                   // scan_by
     }
     backend::check_sources(source<float, equal_fn<int>, plus_fn<float>>(q, {"int"}, INCLUSIVE));
     unsetenv("VEXCL_SBK_PIPELINE");
+    // VEXCL_SBK_DPP=1 (round 4, opt-in): the wave scan of the single pass on DPP (row_shr, row_bcast:15 / 31) for 4- and 8-byte values
+    setenv("VEXCL_SBK_DPP", "1", 1);
+    for (scan_mode m : {INCLUSIVE, EXCLUSIVE, REDUCE}) {
+        std::string d = source<double, decltype(keys_equal), decltype(dplus)>(q, {"int", "long"}, m);
+        CHECK(has(d, "sbk_dpp<0x142>(T)") && has(d, "sbk_dpp<0x138>(T)") && !has(d, "__shfl_up(T, o, 64)"));
+        backend::check_sources(d);
+    }
+    backend::check_sources(source<float, equal_fn<int>, plus_fn<float>>(q, {"int"}, EXCLUSIVE));
+    unsetenv("VEXCL_SBK_DPP");
 }
 
 namespace {

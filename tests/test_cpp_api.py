@@ -100,3 +100,13 @@ def test_cpp_reductor_combine_through_the_comm_layer(name):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-3000:]
     assert "0 failures" in out.stdout
+
+
+def test_by_key_wave_scan_on_dpp_matches_the_shuffle_form():
+    """Host model of the by-key wave scan (vexcl/scan_by_key.hpp): the DPP steps (VEXCL_SBK_DPP=1: row_shr 1/2/4/8, row_bcast:15,
+    row_bcast:31) give every live lane the sum the six shuffle steps give it, on random head / live patterns (tools/r04_sbk_dpp_sim.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sbk_dpp_sim", os.path.join(ROOT, "tools", "r04_sbk_dpp_sim.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(4000, seed=7)

@@ -47,6 +47,7 @@ namespace sbk {
 
 enum scan_mode { INCLUSIVE = 0, EXCLUSIVE = 1, REDUCE = 2 };
 
+static const bool SBK_DPP_DEFAULT = false;
 static const int ITEMS = 4;         // consecutive elements per lane
 static const int ROWS = 2;          // rows of 64 x ITEMS elements per wave
 static const int WAVES = 4;         // waves per workgroup
@@ -90,6 +91,9 @@ template <class V> struct lookback_value { static const bool value = std::is_ari
 inline bool pipe_enabled() { const char *e = std::getenv("VEXCL_SBK_PIPELINE"); return e && std::atoi(e) != 0; }
 inline int pipe_waves() { const int w = lb_env("VEXCL_SBK_PIPE_WAVES", 7); return w < 1 ? 1 : (w > 15 ? 15 : w); }
 inline int pipe_rows() { const int r = lb_env("VEXCL_SBK_PIPE_ROWS", 4); return r < 1 ? 1 : (r > 8 ? 8 : r); }
+// VEXCL_SBK_DPP=1 (round 4): the wave-level segmented scan of the single pass moves its values with DPP (row_shr 1/2/4/8, then
+// row_bcast:15 and row_bcast:31) instead of six ds_bpermute round trips through the LDS per row
+inline bool dpp_enabled() { const char *e = std::getenv("VEXCL_SBK_DPP"); return e ? std::atoi(e) != 0 : SBK_DPP_DEFAULT; }
 inline bool lookback_enabled() { const char *e = std::getenv("VEXCL_SCAN_BY_KEY"); return !(e && std::string(e) == "tree"); }
 
 /// vexcl_sbk_pipe: the single pass of vexcl_sbk_lookback as a pipeline (uses the helpers that kernel's text defines).
@@ -575,6 +579,17 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         s << "  return s0 == s1 ? s0 : 0u;\n"
              "}\n"
              "__device__ inline sbk_t sbk_down(sbk_t x, int o) { sbk_t r; r.c = __shfl_down(x.c, o, 64); r.f = __shfl_down(x.f, o, 64); r.v = __shfl_down(x.v, o, 64); return r; }\n";
+        if (dpp_enabled())
+            // a value moved between lanes by DPP (CTRL: 0x110 + n = row_shr:n, 0x138 = wave_shr:1, 0x142 / 0x143 = row_bcast:15 / 31);
+            // a lane without a source keeps its own value (the callers do not use it there)
+            s << "template <int CTRL> __device__ inline val_t sbk_dpp(val_t v) {\n"
+                 "  int b[sizeof(val_t) / 4];\n"
+                 "  __builtin_memcpy(b, &v, sizeof(val_t));\n"
+                 "  #pragma unroll\n"
+                 "  for (int i = 0; i < (int)(sizeof(val_t) / 4); ++i) b[i] = __builtin_amdgcn_update_dpp(b[i], b[i], CTRL, 0xf, 0xf, false);\n"
+                 "  __builtin_memcpy(&v, b, sizeof(val_t));\n"
+                 "  return v;\n"
+                 "}\n";
         // ws[0] = ticket counter, ws[1] = run count (reduce_by_key), ws + 2 = tile status words (all zero before launch).
         // Tile = 16 waves x LBR rows x 64 lanes x ITEMS consecutive elements = 16 Ki elements: a first version with 4 Ki
         // elements per tile (what the three phases use) took 0.85 ms per 1e8 (int, double) pairs against 0.77 ms for the
@@ -657,16 +672,29 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "    const unsigned long long H = __ballot(h != 0u), any = __ballot(ok != 0u);\n"
              "    const unsigned long long upto = H & (below | (1ull << lane));\n"
              "    const int hl = upto ? 63 - __builtin_clzll(upto) : 0;\n"
-             "    val_t T = tail;\n"
-             "    #pragma unroll\n"
+             "    val_t T = tail;\n";
+        if (dpp_enabled()) {
+            // rows of 16 lanes by row_shr, then lane 15 / 47 into the row behind it, then lane 31 into the upper half: the same
+            // rule at every step -- a lane adds what it is handed exactly when the lane that value comes from is not below the
+            // nearest head lane at or before it (the value then is the sum of that lane's stretch of the SAME run)
+            s << "    const bool live = (any >> lane) & 1ull;\n"
+                 "    { const val_t u = sbk_dpp<0x111>(T); if ((lane & 15) >= 1 && lane - 1 >= hl && live) T = " << Oper::name() << "(u, T); }\n"
+                 "    { const val_t u = sbk_dpp<0x112>(T); if ((lane & 15) >= 2 && lane - 2 >= hl && live) T = " << Oper::name() << "(u, T); }\n"
+                 "    { const val_t u = sbk_dpp<0x114>(T); if ((lane & 15) >= 4 && lane - 4 >= hl && live) T = " << Oper::name() << "(u, T); }\n"
+                 "    { const val_t u = sbk_dpp<0x118>(T); if ((lane & 15) >= 8 && lane - 8 >= hl && live) T = " << Oper::name() << "(u, T); }\n"
+                 "    { const val_t u = sbk_dpp<0x142>(T); if ((lane & 16) && (lane & 48) - 1 >= hl && live) T = " << Oper::name() << "(u, T); }\n"
+                 "    { const val_t u = sbk_dpp<0x143>(T); if (lane >= 32 && 31 >= hl && live) T = " << Oper::name() << "(u, T); }\n";
+        } else {
+        s << "    #pragma unroll\n"
              "    for (int o = 1; o < 64; o <<= 1) {\n"
              "      const val_t u = __shfl_up(T, o, 64);\n"
              "      if (lane - o >= hl && ((any >> lane) & 1ull)) T = " << Oper::name() << "(u, T);\n"
-             "    }\n"
-             "    int cb = 0;\n"
+             "    }\n";
+        }
+        s << "    int cb = 0;\n"
              "    #pragma unroll\n"
              "    for (int j = 0; j < ITEMS; ++j) cb += __popcll(__ballot((h >> j) & 1u) & below);\n"
-             "    sbk_t p; p.c = cb; p.f = ((any & below) ? 2 : 0) | ((H & below) ? 1 : 0); p.v = __shfl_up(T, 1, 64);\n"
+             "    sbk_t p; p.c = cb; p.f = ((any & below) ? 2 : 0) | ((H & below) ? 1 : 0); p.v = " << (dpp_enabled() ? "sbk_dpp<0x138>(T)" : "__shfl_up(T, 1, 64)") << ";\n"
              "    if (lane == 0) p = sbk_empty();\n"
              "    pre[r] = sbk_combine(carry, p);\n"
              // the row's aggregate: all its heads, the value of the run that is open at its end
