@@ -189,6 +189,30 @@ TEST_CASE(multivector_kernel_shape) {
     static_assert(std::is_same<AX::value_type, double>::value, "");
 }
 
+TEST_CASE(reductor_kernels_compile_in_every_order_mode) {             // reductor.hpp:302-439; VEXCL_REDUCTOR_ORDER
+    using namespace detail;
+    backend::command_queue q;
+    vector<double> a, b;
+    auto e = a * b;
+    for (int mode : {order_release, order_relaxed, order_two_launch}) {
+        reductor_order_override() = mode;
+        for (int r = 0; r < 3; ++r) {
+            std::string s = r == 0 ? Reductor<double, SUM>::source(as_expr<decltype(e)>::get(e), q)
+                          : r == 1 ? Reductor<double, SUM_Kahan>::source(as_expr<decltype(e)>::get(e), q)
+                                   : Reductor<double, MIN_MAX>::source(as_expr<decltype(e)>::get(e), q);
+            CHECK(has(s, "vexcl_reductor_kernel"));
+            // the default publishes a partial with a RELEASE arrival and the closing workgroup acquires; round 4's exchange form
+            // only on request; the two-launch form has no device-side hand-over at all
+            CHECK_EQUAL(has(s, "__ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT"), mode == order_release);
+            CHECK_EQUAL(count(s, "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\")"), size_t(mode == order_release ? 2 : 0));
+            CHECK_EQUAL(has(s, "__hip_atomic_exchange"), mode == order_relaxed);
+            CHECK_EQUAL(has(s, "s_last"), mode != order_two_launch);
+            backend::check_sources(s);
+        }
+    }
+    reductor_order_override() = -1;
+}
+
 VEX_FUNCTION(bool, keys_equal, (int, a1)(long, a2)(int, b1)(long, b2), return a1 == b1 && a2 == b2;);
 VEX_FUNCTION(double, dplus, (double, x)(double, y), return x + y;);
 

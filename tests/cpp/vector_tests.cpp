@@ -140,6 +140,41 @@ TEST_CASE(reductions) {                                              // :66-99
     CHECK_EQUAL(ksumi(k * 2), 6000);
 }
 
+TEST_CASE(reductions_back_to_back_never_fold_a_stale_partial) {
+    // The single-launch reduction (reductor.hpp:302-439 in one kernel): a workgroup's partial must be visible to the workgroup
+    // that arrives last -- ordered by RELEASE arrivals / ACQUIRE in the closing workgroup (VEXCL_REDUCTOR_ORDER=release, the
+    // default; `relaxed` and `two_launch` run the same test through tests/test_cpp_api.py).  Every reduction here changes EVERY
+    // workgroup's partial (the multiplier changes), lengths alternate so the number of arrivals changes too, and each result
+    // is compared exactly (integers): a fold that picked up one partial of the previous reduction gives a different number.
+    const size_t N = (1 << 20) + 77;
+    std::vector<long> h(N);
+    for (size_t i = 0; i < N; ++i) h[i] = (long)((i * 2654435761ull) % 2003) - 1001;
+    vex::vector<long> x(ctx, h);
+    vex::Reductor<long, vex::SUM> sum(ctx);
+    vex::Reductor<long, vex::MIN_MAX> minmax(ctx);
+    const size_t lens[3] = {N, N / 3 + 5, 70001};
+    long S[3] = {0, 0, 0}, lo[3], hi[3];
+    for (int l = 0; l < 3; ++l) {
+        lo[l] = h[0]; hi[l] = h[0];
+        for (size_t i = 0; i < lens[l]; ++i) { S[l] += h[i]; lo[l] = std::min(lo[l], h[i]); hi[l] = std::max(hi[l], h[i]); }
+    }
+    const char *e = std::getenv("VEX_TEST_REDUCE_STRESS");
+    const long rounds = e ? std::atol(e) : 20000;
+    long wrong = 0;
+    std::vector<std::unique_ptr<vex::vector<long>>> xs;
+    for (int l = 0; l < 3; ++l) xs.emplace_back(new vex::vector<long>(ctx, std::vector<long>(h.begin(), h.begin() + lens[l])));
+    for (long k = 1; k <= rounds; ++k) {
+        const int l = (int)(k % 3);
+        const long got = sum(*xs[l] * k + 1);
+        if (got != S[l] * k + (long)lens[l]) ++wrong;
+        if (k % 16 == 0) {
+            auto mm = minmax(*xs[l] + k);
+            if (mm.s[0] != lo[l] + k || mm.s[1] != hi[l] + k) ++wrong;
+        }
+    }
+    CHECK_EQUAL(wrong, 0L);
+}
+
 TEST_CASE(custom_kernel) {                                           // custom_kernel.cpp:7-91
     const cl_ulong n = 1024;
     std::vector<vex::command_queue> queue(1, ctx.queue(0));

@@ -102,6 +102,20 @@ def test_cpp_reductor_combine_through_the_comm_layer(name):
     assert "0 failures" in out.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["relaxed", "two_launch"])
+def test_cpp_reductor_order_modes(order):
+    """VEXCL_REDUCTOR_ORDER: the default (`release`: partial published by a RELEASE arrival, ACQUIRE in the closing workgroup --
+    ordered by the HIP memory model) runs in test_cpp_api_on_gpu; round 4's exchange form and the two-launch form
+    (vexhip_reduce_finish as stage 2) must pass the same assertions, the back-to-back stress included: all three fold in the
+    same order (reference: vexcl/reductor.hpp:412-436, a host fold that has no such hazard)."""
+    exe = _build("vector_tests")
+    env = dict(os.environ, VEXCL_REDUCTOR_ORDER=order)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-3000:]
+    assert "0 failures" in out.stdout
+
+
 def test_by_key_wave_scan_on_dpp_matches_the_shuffle_form():
     """Host model of the by-key wave scan (vexcl/scan_by_key.hpp): the DPP steps (VEXCL_SBK_DPP=1: row_shr 1/2/4/8, row_bcast:15,
     row_bcast:31) give every live lane the sum the six shuffle steps give it, on random head / live patterns (tools/r04_sbk_dpp_sim.py)."""

@@ -77,6 +77,27 @@ namespace detail {
         return "(" + type_name<T>() + ")(" + s.str() + ")";
     }
 
+    // How the single-launch reduction orders a workgroup's partial against its arrival count (VEXCL_REDUCTOR_ORDER):
+    //   release (default) -- by the HIP/LLVM memory model: relaxed agent-scope store of the partial, RELEASE arrival, ACQUIRE
+    //                        in the workgroups that pass counts on and in the one that folds;
+    //   relaxed           -- round 4's form (atomic exchange + compiler barrier; relies on where gfx942/gfx950 perform sc1 atomics);
+    //   two_launch        -- no device-side hand-over at all: stage 2 is libvexhip's vexhip_reduce_finish on the same queue
+    //                        (kernel boundary orders it).  All three fold in the same order: the bits are the same.
+    enum reduction_order { order_release = 0, order_relaxed = 1, order_two_launch = 2 };
+    inline int &reductor_order_override() { static int o = -1; return o; }      // tests: a mode per generated source (-1: the environment's)
+    inline reduction_order reductor_order() {
+        if (reductor_order_override() >= 0) return static_cast<reduction_order>(reductor_order_override());
+        static const reduction_order m = [] {
+            const char *e = std::getenv("VEXCL_REDUCTOR_ORDER");
+            const std::string v = e ? e : "";
+            if (v == "relaxed") return order_relaxed;
+            if (v == "two_launch") return order_two_launch;
+            precondition(v.empty() || v == "release", "VEXCL_REDUCTOR_ORDER: release | relaxed | two_launch");
+            return order_release;
+        }();
+        return m;
+    }
+
     struct reductor_buffers {
         backend::device_vector<char> partials, result, counter;      // counter: how many workgroups of the running reduction have stored their partial (round 4)
         // Round 3: stage 2 stores the scalar straight into host memory the GPU can write (pinned, mapped): the host only
@@ -135,6 +156,7 @@ class Reductor {
             constexpr bool minmax = std::is_same<RDC, MIN_MAX>::value;
             constexpr int nout = minmax ? 2 : 1;
             const int op = op_code();
+            const bool two_launch = reductor_order() == order_two_launch;
 
             std::vector<char> active(queue.size(), 0);
             std::vector<ScalarType> host(queue.size() * 2);
@@ -160,6 +182,10 @@ class Reductor {
                 krn.push_arg((unsigned long long)++bufs[d]->seq);
                 krn.config(ngroups[d], 256);
                 krn(queue[d]);
+                if (two_launch)
+                    backend::check(vexhip_reduce_finish(queue[d].device_ordinal(), queue[d].raw(), op, reduce_dtype<ScalarType>::value,
+                                bufs[d]->partials.raw(), ngroups[d],
+                                rccl_combine(minmax) ? static_cast<void *>(bufs[d]->result.raw()) : bufs[d]->pinned));
             }
             (void)op;
             if (rccl_combine(minmax)) {
@@ -185,10 +211,12 @@ class Reductor {
                 // reduction: the host watches that word instead of waiting for the queue to drain (the wake-up of a blocked
                 // hipStreamSynchronize is several microseconds of a 50 us reduction); a second of silence falls back to the wait
                 for (unsigned d = 0; d < queue.size(); ++d) if (active[d]) {
+                    if (two_launch) { queue[d].finish(); continue; }
                     const volatile unsigned long long *seen = reinterpret_cast<const volatile unsigned long long *>(static_cast<char *>(bufs[d]->pinned) + 64);
                     const auto t0 = std::chrono::steady_clock::now();
                     unsigned spins = 0;
                     while (*seen != bufs[d]->seq) {
+                        __builtin_ia32_pause();
                         if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) { queue[d].finish(); break; }
                     }
                     std::atomic_thread_fence(std::memory_order_acquire);
@@ -250,6 +278,8 @@ class Reductor {
             return r;
         }
 
+    public:
+        /// Text of the reduction kernel of one expression type (stage 1, and stage 2 unless VEXCL_REDUCTOR_ORDER=two_launch).
         template <class E>
         static std::string source(const E &expr, const backend::command_queue &q) {
             using namespace detail;
@@ -268,6 +298,7 @@ class Reductor {
             src.template parameter<global_ptr<cl_ulong>>("g_seen");
             src.template parameter<cl_ulong>("seq");
             src.end_kernel_parameters();
+            const reduction_order order = reductor_order();
 
             auto fold = [&](const std::string &a, const std::string &b) -> std::string {
                 if (std::is_same<RDC, MAX>::value) return MAX::impl<ScalarType>::device(a, b);
@@ -329,9 +360,14 @@ class Reductor {
                 src.new_line() << "myMin = sdata[2 * w] < myMin ? sdata[2 * w] : myMin;";
                 src.new_line() << "myMax = sdata[2 * w + 1] > myMax ? sdata[2 * w + 1] : myMax;";
                 src.close("}");
-                src.new_line() << T << " prev0 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x], myMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
-                src.new_line() << T << " prev1 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x + 1], myMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
-                src.new_line() << "asm volatile(\"\" :: \"v\"(prev0), \"v\"(prev1) : \"memory\");";
+                if (order == order_relaxed) {
+                    src.new_line() << T << " prev0 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x], myMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                    src.new_line() << T << " prev1 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x + 1], myMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                    src.new_line() << "asm volatile(\"\" :: \"v\"(prev0), \"v\"(prev1) : \"memory\");";
+                } else {
+                    src.new_line() << "__hip_atomic_store(&g_odata[2 * blockIdx.x], myMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                    src.new_line() << "__hip_atomic_store(&g_odata[2 * blockIdx.x + 1], myMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                }
                 src.close("}");
             } else {
                 wave_fold("mySum", "fold");
@@ -340,12 +376,21 @@ class Reductor {
                 src.new_line() << "if (threadIdx.x == 0)";
                 src.open("{");
                 src.new_line() << "for (int w = 1; w < nwaves; ++w) mySum = " << fold("mySum", "sdata[w]") << ";";
-                // (an atomic exchange at agent scope: performed where every XCD sees it, and its return tells when -- no fence, which
-                //  would write back and invalidate a whole L2 per workgroup: 0.26 -> 0.33 ms at 1e8 elements)
-                src.new_line() << T << " prev = __hip_atomic_exchange(&g_odata[blockIdx.x], mySum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
-                src.new_line() << "asm volatile(\"\" :: \"v\"(prev) : \"memory\");";
+                if (order == order_relaxed) {
+                    // (round 4's form, VEXCL_REDUCTOR_ORDER=relaxed: an atomic exchange at agent scope is performed where every XCD
+                    //  sees it and its return tells when; no fence.  Relies on gfx942/gfx950 behaviour -- a returning sc1 atomic has
+                    //  been performed at the memory side -- that the HIP memory model does not promise: kept for A/B only)
+                    src.new_line() << T << " prev = __hip_atomic_exchange(&g_odata[blockIdx.x], mySum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                    src.new_line() << "asm volatile(\"\" :: \"v\"(prev) : \"memory\");";
+                } else {
+                    // the partial is ordered before the arrival count by the RELEASE on that count (below): one write-back of this
+                    // workgroup's dirty lines (the partial itself) -- not the acq_rel fence of round 3 (0.26 -> 0.33 ms), which
+                    // also invalidated the L2 under the workgroups still streaming
+                    src.new_line() << "__hip_atomic_store(&g_odata[blockIdx.x], mySum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                }
                 src.close("}");
             }
+            if (order == order_two_launch) { src.end_kernel(); return src.str(); }
             // ---- stage 2 inside the same launch: the workgroup that arrives last folds the partials (order of reduce_stage2 in
             // libvexhip: lane t takes partials t, t + 256, ...; wave fold; waves in order) ----
             src.new_line() << "__shared__ int s_last;";
@@ -353,16 +398,30 @@ class Reductor {
             src.open("{");
             src.new_line() << "const unsigned sub = blockIdx.x & 31u, members = (gridDim.x - sub + 31u) >> 5, groups = gridDim.x < 32u ? gridDim.x : 32u;";
             src.new_line() << "int last = 0;";
-            src.new_line() << "if (atomicAdd(g_counter + 32u * (1u + sub), 1u) == members - 1u)";      // the last of its residue class ...
-            src.open("{");
-            src.new_line() << "g_counter[32u * (1u + sub)] = 0u;";
-            src.new_line() << "last = atomicAdd(g_counter, 1u) == groups - 1u;";                       // ... counts for the class; the last class closes the reduction
-            src.close("}");
+            if (order == order_relaxed) {
+                src.new_line() << "if (atomicAdd(g_counter + 32u * (1u + sub), 1u) == members - 1u)";      // the last of its residue class ...
+                src.open("{");
+                src.new_line() << "g_counter[32u * (1u + sub)] = 0u;";
+                src.new_line() << "last = atomicAdd(g_counter, 1u) == groups - 1u;";                       // ... counts for the class; the last class closes the reduction
+                src.close("}");
+            } else {
+                // Ordered by the memory model (round 5): every arrival RELEASEs its partial on the class counter; the last of a
+                // class ACQUIREs the others' (fence, executed by 32 workgroups per launch) and passes everything on with an
+                // ACQ_REL arrival on the top counter; the last of all has thereby acquired every partial.
+                src.new_line() << "if (__hip_atomic_fetch_add(g_counter + 32u * (1u + sub), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == members - 1u)";
+                src.open("{");
+                src.new_line() << "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");";
+                src.new_line() << "__hip_atomic_store(g_counter + 32u * (1u + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                src.new_line() << "last = __hip_atomic_fetch_add(g_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;";
+                src.close("}");
+            }
             src.new_line() << "s_last = last;";
             src.close("}");
             src.new_line() << "__syncthreads();";
             src.new_line() << "if (s_last)";
             src.open("{");
+            // every lane of the closing workgroup reads partials: each acquires for itself (once per launch, one workgroup)
+            if (order != order_relaxed) src.new_line() << "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");";
             if (minmax) {
                 src.new_line() << "myMin = " << literal(std::numeric_limits<ScalarType>::max()) << "; myMax = " << literal(std::numeric_limits<ScalarType>::lowest()) << ";";
                 src.new_line() << "for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)";
