@@ -135,17 +135,18 @@ def test_sort_by_key_is_stable(T, oracle, n):
     assert np.array_equal(di.cpu().numpy(), np.argsort(k, kind="stable"))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3, 4, 5])
 def test_sort_rank_schemes_give_the_stable_permutation(T, oracle, mode):
-    """Both ranking schemes of the scatter kernel -- match words (0) and one returning LDS atomic per key (1: relies on
-    gfx950 serving same-address lanes of one LDS atomic in lane order; the library checks that on the device before it
-    picks the scheme) -- must produce std::stable_sort's permutation (sort.cpp:22-45), for few and for many distinct
-    keys, ragged sizes, 4- and 8-byte keys and payloads."""
+    """Every ranking scheme of the scatter kernels -- match words (0); round 4's returning counter atomic with one verified
+    tile in 16 (1); the lean scatter of round 5 with unchecked counter atomics (3, A/B only), counter atomics checked by the
+    order words of the same wave round (4), ranks TAKEN from the order words, every key of every tile checked (5, the
+    default) -- must produce std::stable_sort's permutation (sort.cpp:22-45), for few and for many distinct keys, keys whose
+    upper digits are constant (tiles copied as blocks), ragged sizes, 4- and 8-byte keys and payloads."""
     from vexcl_amd import lib
     L = lib()
     L.sort_set_rank(mode)
     try:
-        for n, hi in ((12288 * 3 + 17, 3), (1 << 20, 100), (777777, 1 << 30), (1 << 22, 255)):
+        for n, hi in ((12288 * 3 + 17, 3), (1 << 20, 100), (777777, 1 << 30), (1 << 22, 255), (12288 * 40 + 5, 0), (12288 * 9, 70000)):
             k = oracle.random_i32(n, n, 0, hi)
             idx = np.arange(n, dtype=np.int64)
             dk, di = T.up(k), T.up(idx)

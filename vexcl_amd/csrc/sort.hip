@@ -351,13 +351,244 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
             reinterpret_cast<const VT *>(vals_in_), reinterpret_cast<VT *>(vals_out_), n, shift, nblocks, table, vflag);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the lean scatter.  Round 4's kernel issued 39 VALU and 55 SALU instructions per key round (the uniform-digit
+// branches, the verified-tile branches, 64-bit address arithmetic); profiles/r04_bench_kernel_stats.csv: 1.79 ms per pass at
+// 1e9 keys = 0.56 of HBM, bound by instruction issue.  Here:
+//   * the tile's digit counts come from the scanned table (entry [d][tile + 1] - entry [d][tile]) BEFORE the keys arrive, so
+//     the tile-local digit starts are computed beside the key loads, and a tile whose keys all share the digit (constant upper
+//     digits of a small key range) is copied straight from registers -- no per-round uniformity test;
+//   * ranks with a COMPLETE check of the property they rest on, on every key of every tile (CHECK 1 / 2): each lane ORs its lane
+//     bit into a 64-bit word of its (wave, digit) and gets the bits of the lanes that were served before it; a lane that sees
+//     the bit of a HIGHER lane was served out of lane order -> trap.  If no lane of a group sees a higher bit, the group was
+//     served in lane order (of two lanes a < b one is served first; b first would show b's bit to a).
+//       CHECK 2 (default): the rank itself is popcount(returned bits) + the counter read before the round: nothing depends on
+//                the order in which any OTHER instruction serves its lanes (the counter is bumped by non-returning adds);
+//       CHECK 1: the rank is the return of the counter atomic (round 4), the OR word checks the same wave round beside it;
+//       CHECK 0: the counter atomic alone (A/B only).
+//   * no branches in the rank loop (violations are OR-ed into two registers and tested once), byte offsets with a scalar base
+//     per key round in the write-out (one add per key).
+template <typename T>
+__device__ __forceinline__ void store_elem(T v, __amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned scalar_bytes) {
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)lane_bytes, (int)scalar_bytes, 0);
+    else {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (int)lane_bytes, (int)scalar_bytes, 0);
+    }
+}
+
+template <typename K, int VB, int KPT>
+struct lean_lds {
+    static constexpr int TILE = RB * KPT;
+    static constexpr int TILE_BYTES = TILE * ((int)sizeof(K) + VB);
+    static constexpr int CHK_BYTES = RW * RADIX * 8;
+    static constexpr int RAW_WORDS = ((TILE_BYTES > CHK_BYTES ? TILE_BYTES : CHK_BYTES) + 15) / 16 * 2;
+    unsigned long long raw[RAW_WORDS];      // the order words while the keys are ranked, then the re-ordered tile
+    unsigned hist[RW][RADIX];               // per (wave, digit): count, then tile position of the wave's first key of that digit
+    unsigned gbase[RADIX];                  // global index of the tile's first key of a digit, minus its tile position
+    unsigned dstart[RADIX];
+    unsigned cnt[RADIX];
+    unsigned wtot[RADIX / kWave];
+    int uni;
+};
+
+template <typename K, int MODE, bool DESC, int VB, int KPT, int CHECK, bool WIDE>
+__global__ __launch_bounds__(RB, 8)
+void radix_scatter_lean_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+        const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
+        long long n, int shift, unsigned nblocks, unsigned nfull, const unsigned *__restrict__ table)
+{
+    typedef typename valtype<VB>::type VT;
+    constexpr int TILE = RB * KPT;
+    __shared__ __attribute__((aligned(16))) lean_lds<K, VB, KPT> L;
+    const VT *__restrict__ vals_in = reinterpret_cast<const VT *>(vals_in_);
+    VT *__restrict__ vals_out = reinterpret_cast<VT *>(vals_out_);
+    K *s_keys = reinterpret_cast<K *>(L.raw);
+    VT *s_vals = reinterpret_cast<VT *>(reinterpret_cast<char *>(L.raw) + (size_t)TILE * sizeof(K));
+    unsigned long long *s_chk = L.raw;
+
+    // XCD-contiguous tile order, as the histogram kernel (see radix_scatter_kernel)
+    const unsigned per = (nfull + 7) / 8;
+    const unsigned tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (tile >= nfull) return;
+
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+    const long long wbase = (long long)tile * TILE + (long long)wave * (kWave * KPT);
+
+    K key[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) key[k] = __builtin_nontemporal_load(keys_in + wbase + k * kWave + lane);
+    VT val[VB ? KPT : 1];
+    if constexpr (VB != 0) {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) val[k] = __builtin_nontemporal_load(vals_in + wbase + k * kWave + lane);
+    }
+    // the tile's count and global base of digit t, straight from the scanned table (independent of the keys: in flight with them)
+    unsigned b0 = 0, cnt = 0;
+    if (t < RADIX) {
+        const size_t idx = (size_t)t * nblocks + tile;
+        b0 = table[idx];
+        const unsigned b1 = (idx + 1 < (size_t)RADIX * nblocks) ? table[idx + 1] : (unsigned)n;
+        cnt = b1 - b0;
+    }
+    {   // zero the counters and the order words: 4 + 8 words per lane
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 z = {0u, 0u, 0u, 0u};
+        reinterpret_cast<u4 *>(&L.hist[0][0])[t] = z;
+        if constexpr (CHECK != 0) {
+            reinterpret_cast<u4 *>(s_chk)[t] = z;
+            reinterpret_cast<u4 *>(s_chk)[t + RB] = z;
+        }
+        if (t == 0) L.uni = 0;
+    }
+    unsigned inc = 0;
+    if (t < RADIX) {
+        inc = cnt;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == kWave - 1) L.wtot[wave] = inc;
+    }
+    __syncthreads();
+    if (t < RADIX) {
+        unsigned woff = 0;
+#pragma unroll
+        for (int w = 0; w < RADIX / kWave; ++w) if (w < wave) woff += L.wtot[w];
+        const unsigned ds = woff + inc - cnt;
+        L.dstart[t] = ds;
+        L.cnt[t] = cnt;
+        L.gbase[t] = b0 - ds + (unsigned)TILE;               // biased by TILE: never negative, so that base + position stays a plain 32-bit sum
+        if (cnt == (unsigned)TILE) L.uni = t + 1;
+    }
+    __syncthreads();
+    if (L.uni) {
+        // every key of the tile has digit uni - 1: the tile keeps its order (a stable pass moves it as a block)
+        const unsigned g = L.gbase[L.uni - 1] - (unsigned)TILE + (unsigned)(wave * (kWave * KPT) + lane);
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            keys_out[(size_t)g + k * kWave] = key[k];
+            if constexpr (VB != 0) vals_out[(size_t)g + k * kWave] = val[k];
+        }
+        return;
+    }
+
+    unsigned rr[KPT];
+    {
+        unsigned *hw = L.hist[wave];
+        unsigned long long *cw = s_chk + wave * RADIX;
+        const unsigned long long lanebit = 1ull << lane;
+        const unsigned long long ge = ~(lanebit - 1ull);        // this lane and the higher ones (its own bit is never in a returned word)
+        unsigned long long bad = 0ull;
+        // rounds in groups of GR: the LDS operations of a group are issued back to back, then their returns are folded into
+        // ranks (all KPT returned pairs held back until the end cost 3-5 spilled registers at 64 per lane)
+        constexpr int GR = CHECK == 2 ? (KPT % 4 == 0 ? 4 : (KPT % 3 == 0 ? 3 : 1)) : KPT;
+#pragma unroll
+        for (int k0 = 0; k0 < KPT; k0 += GR) {
+            unsigned prev[GR];
+            unsigned long long old[GR];
+#pragma unroll
+            for (int j = 0; j < GR; ++j) {
+                const int k = k0 + j;
+                const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(key[k]) >> shift) & (RADIX - 1);
+                if constexpr (CHECK == 0) {
+                    rr[k] = atomicAdd(&hw[d], 1u);
+                } else if constexpr (CHECK == 1) {
+                    rr[k] = atomicAdd(&hw[d], 1u);
+                    old[j] = atomicOr(&cw[d], lanebit);
+                    atomicXor(&cw[d], lanebit);                 // back to zero for the next round (no return: any order)
+                } else {
+                    prev[j] = hw[d];                             // a wave's LDS operations execute in program order: before this round's adds
+                    __builtin_amdgcn_wave_barrier();
+                    old[j] = atomicOr(&cw[d], lanebit);
+                    atomicXor(&cw[d], lanebit);
+                    atomicAdd(&hw[d], 1u);                      // no return: only the sum matters
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if constexpr (CHECK == 2) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CHECK != 0) {
+#pragma unroll
+                for (int j = 0; j < GR; ++j) {
+                    bad |= old[j] & ge;
+                    if constexpr (CHECK == 2) {
+                        rr[k0 + j] = prev[j] + (unsigned)__popcll(old[j]);
+                        asm volatile("" : "+v"(rr[k0 + j]));     // computed HERE: the optimiser otherwise sinks the sum to its use and keeps three registers alive for one
+                    }
+                }
+            }
+            if constexpr (CHECK == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (bad) __builtin_trap();                               // a lane of one LDS atomic was served before a lower lane with the same address
+    }
+    __syncthreads();
+
+    if (t < RADIX) {
+        unsigned run = L.dstart[t];
+#pragma unroll
+        for (int w = 0; w < RW; ++w) { const unsigned c = L.hist[w][t]; L.hist[w][t] = run; run += c; }
+        if (run - L.dstart[t] != L.cnt[t]) __builtin_trap();     // the table and the keys disagree (the input changed between the passes' kernels)
+    }
+    __syncthreads();
+
+    // all offsets first, then all stores: a store into the tile may alias the offset table as far as the compiler knows, and
+    // read -> wait -> write per key serialises twelve LDS round trips
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(key[k]) >> shift) & (RADIX - 1);      // recomputed: one operation against a register per key
+        rr[k] += L.hist[wave][d];
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        s_keys[rr[k]] = key[k];
+        if constexpr (VB != 0) s_vals[rr[k]] = val[k];
+    }
+    __syncthreads();
+
+    // descriptors that start TILE elements in front of the outputs: with the biased bases every lane offset is a plain unsigned number
+    __amdgpu_buffer_rsrc_t rk, rv;
+    if constexpr (!WIDE) {
+        rk = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(keys_out) - (long long)TILE * (long long)sizeof(K), 0, -1, 0x00020000);
+        if constexpr (VB != 0) rv = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(vals_out) - (long long)TILE * (long long)VB, 0, -1, 0x00020000);
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const K kk = s_keys[t + k * RB];
+        const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(kk) >> shift) & (RADIX - 1);
+        const unsigned e = L.gbase[d] + (unsigned)t;            // + k * RB - TILE: the scalar offset and the descriptor base
+        if constexpr (WIDE) {
+            const unsigned g = e + (unsigned)(k * RB) - (unsigned)TILE;
+            keys_out[(size_t)g] = kk;
+            if constexpr (VB != 0) vals_out[(size_t)g] = s_vals[t + k * RB];
+        } else {
+            // (n + 2 TILE) x element bytes fits 32 bits (checked by the host).  Buffer stores: descriptor base + 32-bit lane offset
+            // + scalar offset of the key round -- one add and one shift per key, no 64-bit address per lane
+            store_elem<K>(kk, rk, e * (unsigned)sizeof(K), (unsigned)(k * RB) * (unsigned)sizeof(K));
+            if constexpr (VB != 0) store_elem<VT>(s_vals[t + k * RB], rv, e * (unsigned)VB, (unsigned)(k * RB) * (unsigned)VB);
+        }
+    }
+}
+
 extern int g_sort_rank;
 
 template <typename K, int VB> constexpr int kpt_for() { return keys_per_lane((int)sizeof(K), VB); }
 
+template <typename K, int MODE, bool DESC, int VB, int CHECK>
+void launch_lean(hipStream_t s, bool wide, unsigned nfull, const K *src, K *dst, const void *vsrc, void *vdst,
+        int64_t n, int shift, unsigned nblocks, const unsigned *table) {
+    constexpr int KPT = kpt_for<K, VB>();
+    const unsigned grid = (nfull + 7) / 8 * 8;
+    if (wide) radix_scatter_lean_kernel<K, MODE, DESC, VB, KPT, CHECK, true><<<grid, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+    else      radix_scatter_lean_kernel<K, MODE, DESC, VB, KPT, CHECK, false><<<grid, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+}
+
+// rank: 0 match words (round 2), 1 counter atomics with one verified tile in 16 (round 4), 2 the same without verified tiles,
+//       3 / 4 / 5 the lean scatter with CHECK 0 / 1 / 2 (5 is the default)
 template <typename K, int MODE, bool DESC, int VB>
-int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp, bool atomic_rank) {
-    const unsigned every = g_sort_rank != 2 ? SORT_VERIFY_EVERY : 0u;        // 2: A/B without the verified tiles
+int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp, int rank) {
+    const bool atomic_rank = rank == 1 || rank == 2;
+    const unsigned every = rank == 1 ? SORT_VERIFY_EVERY : 0u;
     constexpr int KPT = kpt_for<K, VB>();
     constexpr int TILE = RB * KPT;
     const unsigned nblocks = (unsigned)((n + TILE - 1) / TILE);
@@ -368,6 +599,8 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
     void *vsrc = vals, *vdst = vals_tmp;
     constexpr int passes = (int)sizeof(K);
     const int vec_ok = ((reinterpret_cast<uintptr_t>(keys) & 15) == 0) && ((reinterpret_cast<uintptr_t>(keys_tmp) & 15) == 0);
+    constexpr int64_t widest = (int64_t)sizeof(K) > VB ? (int64_t)sizeof(K) : VB;
+    const bool wide = (n + 2 * TILE) * widest >= (1ll << 32) - 16;  // byte offsets of the write-out (lane + scalar part, range-checked together) beyond 32 bits
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         radix_hist_kernel<K, MODE, DESC, KPT><<<(nblocks + 7) / 8 * 8, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
@@ -375,12 +608,16 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
         if (int rc = scan_exclusive_u32_tmp(s, table, table, tn, scan_tmp)) return rc;
         const unsigned nfull = (unsigned)(n / TILE);
         if (nfull) {
-            if (atomic_rank) {
+            if (rank == 3) launch_lean<K, MODE, DESC, VB, 0>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);
+            else if (rank == 4) launch_lean<K, MODE, DESC, VB, 1>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);
+            else if (rank == 5) launch_lean<K, MODE, DESC, VB, 2>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);
+            else if (atomic_rank) {
                 radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, true><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, every);
             } else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
             VEXHIP_LAUNCH_CHECK();
         }
         if (nfull < nblocks) {
+            // the ragged last tile: one workgroup; ranked by the match words (order-independent) unless the round 4 forms are asked for
             if (atomic_rank) radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, true><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
             else radix_scatter_kernel<K, MODE, DESC, VB, KPT, false, false><<<1, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
             VEXHIP_LAUNCH_CHECK();
@@ -394,8 +631,8 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
 }
 
 template <typename K, int MODE>
-int sort_dispatch(hipStream_t s, int desc, int vb, void *keys, void *keys_tmp, void *vals, void *vals_tmp, int64_t n, void *tmp, bool atomic_rank) {
-#define GO(DESC, VB) return sort_passes<K, MODE, DESC, VB>(s, (K *)keys, (K *)keys_tmp, vals, vals_tmp, n, (unsigned *)tmp, atomic_rank)
+int sort_dispatch(hipStream_t s, int desc, int vb, void *keys, void *keys_tmp, void *vals, void *vals_tmp, int64_t n, void *tmp, int rank) {
+#define GO(DESC, VB) return sort_passes<K, MODE, DESC, VB>(s, (K *)keys, (K *)keys_tmp, vals, vals_tmp, n, (unsigned *)tmp, rank)
     if (desc) { if (vb == 0) GO(true, 0); if (vb == 4) GO(true, 4); if (vb == 8) GO(true, 8); }
     else      { if (vb == 0) GO(false, 0); if (vb == 4) GO(false, 4); if (vb == 8) GO(false, 8); }
 #undef GO
@@ -424,7 +661,8 @@ void lds_atomic_order_kernel(unsigned seed, int rounds, unsigned *violations) {
     if (bad) atomicAdd(violations, bad);
 }
 
-int g_sort_rank = -1;               // -1: decide by the self-test; 0: match words; 1: atomic ranks; 2: atomic ranks without the verified tiles (A/B)
+int g_sort_rank = -1;               // -1: the default (5); 0: match words; 1 / 2: round 4's counter-atomic ranks with / without verified tiles (1 only if the
+                                    // device self-test agrees); 3 / 4 / 5: the lean scatter, ranks unchecked / checked beside / taken from the checked words
 
 int atomic_rank_ok(int dev, hipStream_t s, bool *ok) {
     static std::atomic<int> verdict[64];          // 0 unknown, 1 in order, 2 not (two threads may both run the test: same answer)
@@ -471,8 +709,8 @@ int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
     VEXHIP_REQUIRE(value_bytes == 0 || (vals && vals_tmp), "NULL value buffers");
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
-    bool ar = g_sort_rank >= 1;
-    if (g_sort_rank < 0) if (int rc = atomic_rank_ok(dev, s, &ar)) return rc;
+    int ar = g_sort_rank < 0 ? 5 : g_sort_rank;
+    if (ar == 1) { bool ok = false; if (int rc = atomic_rank_ok(dev, s, &ok)) return rc; if (!ok) ar = 0; }
     switch (key_dtype) {
         case VEXHIP_U32: return sort_dispatch<unsigned, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
         case VEXHIP_I32: return sort_dispatch<unsigned, KEY_SIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
