@@ -194,7 +194,7 @@ TEST_CASE(reductor_kernels_compile_in_every_order_mode) {             // reducto
     backend::command_queue q;
     vector<double> a, b;
     auto e = a * b;
-    for (int mode : {order_release, order_relaxed, order_two_launch}) {
+    for (int mode : {order_tagged, order_release, order_relaxed, order_two_launch}) {
         reductor_order_override() = mode;
         for (int r = 0; r < 3; ++r) {
             std::string s = r == 0 ? Reductor<double, SUM>::source(as_expr<decltype(e)>::get(e), q)
@@ -207,6 +207,9 @@ TEST_CASE(reductor_kernels_compile_in_every_order_mode) {             // reducto
             CHECK_EQUAL(count(s, "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\")"), size_t(mode == order_release ? 3 : 0));
             CHECK_EQUAL(has(s, "__hip_atomic_exchange"), mode == order_relaxed);
             CHECK_EQUAL(has(s, "s_last"), mode != order_two_launch);
+            // the default: partials as tagged words, no fence anywhere but the system-scope release of the result
+            CHECK_EQUAL(has(s, "vex_publish(g_words") && has(s, "vex_collect(g_words"), mode == order_tagged);
+            if (mode == order_tagged) CHECK(!has(s, "__builtin_amdgcn_fence"));
             backend::check_sources(s);
         }
     }

@@ -103,12 +103,13 @@ def test_cpp_reductor_combine_through_the_comm_layer(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("order", ["relaxed", "two_launch"])
+@pytest.mark.parametrize("order", ["release", "relaxed", "two_launch"])
 def test_cpp_reductor_order_modes(order):
-    """VEXCL_REDUCTOR_ORDER: the default (`release`: partial published by a RELEASE arrival, ACQUIRE in the closing workgroup --
-    ordered by the HIP memory model) runs in test_cpp_api_on_gpu; round 4's exchange form and the two-launch form
-    (vexhip_reduce_finish as stage 2) must pass the same assertions, the back-to-back stress included: all three fold in the
-    same order (reference: vexcl/reductor.hpp:412-436, a host fold that has no such hazard)."""
+    """VEXCL_REDUCTOR_ORDER: the default (`tagged`: every partial travels as 8-byte words that carry the number of the reduction,
+    the folding workgroup re-reads a word until it does -- single-object coherence only, correct by the HIP memory model without
+    a fence) runs in test_cpp_api_on_gpu; the fence form (`release`), round 4's exchange form and the two-launch form
+    (vexhip_reduce_finish as stage 2) must pass the same assertions, the back-to-back stress included: all fold in the same
+    order (reference: vexcl/reductor.hpp:412-436, a host fold that has no such hazard)."""
     exe = _build("vector_tests")
     env = dict(os.environ, VEXCL_REDUCTOR_ORDER=order)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)

@@ -77,13 +77,20 @@ namespace detail {
         return "(" + type_name<T>() + ")(" + s.str() + ")";
     }
 
-    // How the single-launch reduction orders a workgroup's partial against its arrival count (VEXCL_REDUCTOR_ORDER):
-    //   release (default) -- by the HIP/LLVM memory model: relaxed agent-scope store of the partial, RELEASE arrival, ACQUIRE
-    //                        in the workgroups that pass counts on and in the one that folds;
-    //   relaxed           -- round 4's form (atomic exchange + compiler barrier; relies on where gfx942/gfx950 perform sc1 atomics);
-    //   two_launch        -- no device-side hand-over at all: stage 2 is libvexhip's vexhip_reduce_finish on the same queue
-    //                        (kernel boundary orders it).  All three fold in the same order: the bits are the same.
-    enum reduction_order { order_release = 0, order_relaxed = 1, order_two_launch = 2 };
+    // How the workgroup that folds the partials of a single-launch reduction gets to see them (VEXCL_REDUCTOR_ORDER):
+    //   tagged (default) -- every partial travels as 8-byte words {32 bits of the value | number of this reduction}, written
+    //                       and read with relaxed agent-scope atomics (a 4-byte value is one word, an 8-byte value two).  The
+    //                       folding workgroup re-reads a word until it carries this reduction's number: coherence of ONE atomic
+    //                       object is all that is used -- no ordering between different locations, hence no fence, and nothing
+    //                       is inferred from the arrival counter but who folds.  Correct by the HIP / LLVM memory model.
+    //   release          -- relaxed store of the partial, release fence, arrival; acquire fences in the workgroups that pass
+    //                       counts on and in the one that folds.  Correct by the model, and slow: 2048 L2 write-backs per
+    //                       launch (0.263 -> 0.31 ms at 1e8, 0.049 -> 0.066 ms at 2^24: profiles/r05_reduce_order.log).
+    //   relaxed          -- round 4's form (atomic exchange + compiler barrier): relies on gfx942 / gfx950 performing a returning
+    //                       sc1 atomic at the memory side before it returns; NOT ordered by the model.  A/B only.
+    //   two_launch       -- stage 2 is libvexhip's vexhip_reduce_finish on the same queue (kernel boundary).
+    // All four fold in the same order: the bits are the same.
+    enum reduction_order { order_release = 0, order_relaxed = 1, order_two_launch = 2, order_tagged = 3 };
     inline int &reductor_order_override() { static int o = -1; return o; }      // tests: a mode per generated source (-1: the environment's)
     inline reduction_order reductor_order() {
         if (reductor_order_override() >= 0) return static_cast<reduction_order>(reductor_order_override());
@@ -92,8 +99,9 @@ namespace detail {
             const std::string v = e ? e : "";
             if (v == "relaxed") return order_relaxed;
             if (v == "two_launch") return order_two_launch;
-            precondition(v.empty() || v == "release", "VEXCL_REDUCTOR_ORDER: release | relaxed | two_launch");
-            return order_release;
+            if (v == "release") return order_release;
+            precondition(v.empty() || v == "tagged", "VEXCL_REDUCTOR_ORDER: tagged | release | relaxed | two_launch");
+            return order_tagged;
         }();
         return m;
     }
@@ -122,7 +130,10 @@ class Reductor {
                 int groups = 0, block = 0;
                 backend::check(vexhip_reduce_num_groups(q.device_ordinal(), &groups, &block));
                 auto b = std::make_shared<detail::reductor_buffers>();
-                b->partials = backend::device_vector<char>(q, (size_t)groups * 2 * sizeof(ScalarType));
+                // per workgroup: two outputs x two tagged 8-byte words (order `tagged`; the other orders use the front as a plain
+                // array of partials).  Zeroed: no word carries the number of a reduction yet (they start at 1)
+                b->partials = backend::device_vector<char>(q, (size_t)groups * 32);
+                { const std::vector<char> z((size_t)groups * 32, 0); b->partials.write(q, 0, z.size(), z.data(), true); }
                 b->result = backend::device_vector<char>(q, 2 * sizeof(ScalarType));
                 // arrival counters of the single-launch reduction: [0] the top one, [32 * (1 + k)] one per residue of the workgroup
                 // number mod 32, 128 bytes apart (2048 same-address atomics at the end of the kernel took 40 us; 64 do not)
@@ -288,6 +299,34 @@ class Reductor {
             constexpr bool kahan = std::is_same<RDC, SUM_Kahan>::value;
             backend::source_generator src(q);
             { gen_context c(src, q); expr.preamble(c); }
+            const reduction_order order = reductor_order();
+            if (order == order_tagged) {
+                // a partial as tagged words: W = 1 (4-byte value) or 2 (8-byte value) words per value
+                constexpr int W = sizeof(ScalarType) == 8 ? 2 : 1;
+                static_assert(sizeof(ScalarType) == 4 || sizeof(ScalarType) == 8, "Reductor: 4- or 8-byte scalars");
+                const std::string B = W == 2 ? "unsigned long long" : "unsigned";
+                src.new_line() << "__device__ __forceinline__ void vex_publish(unsigned long long *w, " << T << " v, unsigned long long tag)";
+                src.open("{");
+                src.new_line() << B << " b; __builtin_memcpy(&b, &v, sizeof(b));";
+                src.new_line() << "__hip_atomic_store(w, (unsigned long long)(unsigned)b | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                if (W == 2) src.new_line() << "__hip_atomic_store(w + 1, (b >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                src.close("}");
+                src.new_line() << "__device__ __forceinline__ " << T << " vex_collect(const unsigned long long *w, unsigned long long tag)";
+                src.open("{");
+                // a word that does not carry this reduction's number yet has not arrived: read it again (the workgroup that owns it
+                // has stored it before it was counted; a relaxed atomic load of the same object must return it eventually)
+                src.new_line() << "unsigned long long w0 = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                src.new_line() << "while ((w0 >> 32 << 32) != tag) { __builtin_amdgcn_s_sleep(1); w0 = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }";
+                if (W == 2) {
+                    src.new_line() << "unsigned long long w1 = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
+                    src.new_line() << "while ((w1 >> 32 << 32) != tag) { __builtin_amdgcn_s_sleep(1); w1 = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }";
+                    src.new_line() << B << " b = (w0 & 0xffffffffull) | (w1 << 32);";
+                } else {
+                    src.new_line() << B << " b = (unsigned)w0;";
+                }
+                src.new_line() << T << " v; __builtin_memcpy(&v, &b, sizeof(b)); return v;";
+                src.close("}");
+            }
             src.begin_kernel("vexcl_reductor_kernel");
             src.begin_kernel_parameters();
             src.template parameter<size_t>("n");
@@ -298,7 +337,11 @@ class Reductor {
             src.template parameter<global_ptr<cl_ulong>>("g_seen");
             src.template parameter<cl_ulong>("seq");
             src.end_kernel_parameters();
-            const reduction_order order = reductor_order();
+            constexpr int TW = sizeof(ScalarType) == 8 ? 2 : 1;                 // tagged words per value
+            if (order == order_tagged) {
+                src.new_line() << "unsigned long long *g_words = (unsigned long long *)g_odata;";
+                src.new_line() << "const unsigned long long vex_tag = seq << 32;";
+            }
 
             auto fold = [&](const std::string &a, const std::string &b) -> std::string {
                 if (std::is_same<RDC, MAX>::value) return MAX::impl<ScalarType>::device(a, b);
@@ -364,6 +407,9 @@ class Reductor {
                     src.new_line() << T << " prev0 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x], myMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
                     src.new_line() << T << " prev1 = __hip_atomic_exchange(&g_odata[2 * blockIdx.x + 1], myMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
                     src.new_line() << "asm volatile(\"\" :: \"v\"(prev0), \"v\"(prev1) : \"memory\");";
+                } else if (order == order_tagged) {
+                    src.new_line() << "vex_publish(g_words + " << 2 * TW << " * blockIdx.x, myMin, vex_tag);";
+                    src.new_line() << "vex_publish(g_words + " << 2 * TW << " * blockIdx.x + " << TW << ", myMax, vex_tag);";
                 } else {
                     src.new_line() << "__hip_atomic_store(&g_odata[2 * blockIdx.x], myMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
                     src.new_line() << "__hip_atomic_store(&g_odata[2 * blockIdx.x + 1], myMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
@@ -382,10 +428,10 @@ class Reductor {
                     //  been performed at the memory side -- that the HIP memory model does not promise: kept for A/B only)
                     src.new_line() << T << " prev = __hip_atomic_exchange(&g_odata[blockIdx.x], mySum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
                     src.new_line() << "asm volatile(\"\" :: \"v\"(prev) : \"memory\");";
+                } else if (order == order_tagged) {
+                    src.new_line() << "vex_publish(g_words + " << TW << " * blockIdx.x, mySum, vex_tag);";
                 } else {
-                    // the partial is ordered before the arrival count by the RELEASE on that count (below): one write-back of this
-                    // workgroup's dirty lines (the partial itself) -- not the acq_rel fence of round 3 (0.26 -> 0.33 ms), which
-                    // also invalidated the L2 under the workgroups still streaming
+                    // (order release: the partial is ordered before the arrival count by the release fence in front of that count)
                     src.new_line() << "__hip_atomic_store(&g_odata[blockIdx.x], mySum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
                 }
                 src.close("}");
@@ -398,7 +444,8 @@ class Reductor {
             src.open("{");
             src.new_line() << "const unsigned sub = blockIdx.x & 31u, members = (gridDim.x - sub + 31u) >> 5, groups = gridDim.x < 32u ? gridDim.x : 32u;";
             src.new_line() << "int last = 0;";
-            if (order == order_relaxed) {
+            if (order == order_relaxed || order == order_tagged) {
+                // (order tagged: the counters only elect the workgroup that folds; nothing about the partials is inferred from them)
                 src.new_line() << "if (atomicAdd(g_counter + 32u * (1u + sub), 1u) == members - 1u)";      // the last of its residue class ...
                 src.open("{");
                 src.new_line() << "g_counter[32u * (1u + sub)] = 0u;";
@@ -429,11 +476,14 @@ class Reductor {
             src.new_line() << "if (s_last)";
             src.open("{");
             // every lane of the closing workgroup reads partials: each acquires for itself (once per launch, one workgroup)
-            if (order != order_relaxed) src.new_line() << "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");";
+            if (order == order_release) src.new_line() << "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");";
             if (minmax) {
                 src.new_line() << "myMin = " << literal(std::numeric_limits<ScalarType>::max()) << "; myMax = " << literal(std::numeric_limits<ScalarType>::lowest()) << ";";
                 src.new_line() << "for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)";
                 src.open("{");
+                if (order == order_tagged)
+                    src.new_line() << T << " a = vex_collect(g_words + " << 2 * TW << " * i, vex_tag), b = vex_collect(g_words + " << 2 * TW << " * i + " << TW << ", vex_tag);";
+                else
                 src.new_line() << T << " a = __hip_atomic_load(&g_odata[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(&g_odata[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);";
                 src.new_line() << "myMin = a < myMin ? a : myMin; myMax = b > myMax ? b : myMax;";
                 src.close("}");
@@ -453,6 +503,9 @@ class Reductor {
             } else {
                 typedef typename std::conditional<minmax || kahan, SUM, RDC>::type R2;
                 src.new_line() << "mySum = " << literal(R2::template impl<ScalarType>::initial()) << ";";
+                if (order == order_tagged)
+                    src.new_line() << "for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) mySum = " << fold("mySum", "vex_collect(g_words + " + std::to_string(TW) + " * i, vex_tag)") << ";";
+                else
                 src.new_line() << "for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) mySum = " << fold("mySum", "__hip_atomic_load(&g_odata[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)") << ";";
                 wave_fold("mySum", "fold");
                 src.new_line() << "if (lane == 0) sdata[wave] = mySum;";
