@@ -185,7 +185,7 @@ def timed_events(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def measure_traffic(grid, timeout=240, only=None):
+def measure_traffic(grid, timeout=240, only=None, names=None, extra_env=None):
     """HBM bytes per launch of the headline kernels measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE need
     separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots) over tools/pmc_headline.py.  FETCH_SIZE is calibrated on
     a 2 GiB 16-byte-per-lane stream captured in the same pass (gfx950 reports half the bytes of such a stream)."""
@@ -199,6 +199,9 @@ def measure_traffic(grid, timeout=240, only=None):
     env = dict(os.environ, TMPDIR="/tmp", GRID=str(grid))
     if only:
         env["PMC_ONLY"] = only                 # tools/pmc_headline.py: just these storages (comma-separated)
+    if extra_env:
+        env.update(extra_env)
+    wanted = tuple(names) if names else ("sell8_grid_kernel", "sell8_plane_kernel", "sell8_march_kernel", "sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel")
     res = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -214,8 +217,8 @@ def measure_traffic(grid, timeout=240, only=None):
                         continue
                     name = r["Kernel_Name"]
                     key = None
-                    for k in ("sell8_grid_kernel", "sell8_plane_kernel", "sell8_march_kernel", "sell8_pair_kernel", "sell_pair_kernel", "csr_stream2_kernel", "reduce_stage1"):
-                        if k in name:
+                    for k in wanted + ("reduce_stage1",):
+                        if k + "<" in name or k + "(" in name:
                             key = k
                             if k == "sell8_pair_kernel":
                                 targs = [a.strip() for a in name.split("sell8_pair_kernel<")[1].split(">")[0].split(",")]   # <V, W, VCODED, DICT>
@@ -257,6 +260,58 @@ def cpp_rows(args_list, timeout=300, env=None):
                 pass
     if p.returncode != 0:
         rows.append({"error": "%s exited %d" % (args_list[0], p.returncode)})
+    return rows
+
+
+def unstructured_rows(torch, ops, dev, args):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import unstructured as U
+    rows = {}
+    m = int(float(os.environ.get("UNSTRUCTURED_ROWS", "2e7")))
+    x = ops.fill_hash(torch.empty(m, dtype=torch.float64, device=dev), 42)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    what = {"random16": "16 entries per row, columns uniform in [0, n), sorted (the shape of tests/random_matrix.hpp)",
+            "powerlaw": "row lengths floor(6 / sqrt(u)) capped at 4096 (mean ~12), columns uniform, sorted"}
+    for name in ("random16", "powerlaw"):
+        try:
+            ptr, col, val = U.MAKERS[name](m, dev)
+            nnz = int(col.numel())
+            yr, mag = U.reference_product(ptr, col, val, x)
+            A = ops.SpMat(ptr, col, val)
+            A.apply(x, y)
+            bad = int(((y - yr).abs() > 1e-10 * mag).sum())
+            assert bad == 0, "%s: %d rows outside 1e-10 * sum|terms| of the row" % (name, bad)
+            del yr, mag
+            t = min(timed_events(torch, lambda: A.apply(x, y), 10) for _ in range(3))
+            stored = A.matrix_bytes() + 16 * m            # what the product must move at least: the stored matrix + x once + y once
+            alg = algorithmic_bytes(m, nnz)
+            row = {"what": what[name], "rows": m, "nnz": nnz, "storage": A.storage, "ell_width": getattr(A, "width", None), "tail_nnz": getattr(A, "tail_nnz", None),
+                   "ms": round(t, 5), "gflops": round(2.0 * nnz / t / 1e6, 1), "rows_outside_tolerance": bad,
+                   "roofline": {"bound": "hbm", "bytes_per_launch": stored, "achieved": round(stored / t / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(stored / t / 1e6 / HBM_PEAK_GBPS, 4),
+                                "algorithmic_bytes_per_launch": alg, "algorithmic_gbps": round(alg / t / 1e6, 1),
+                                "frac_of_algorithmic_bytes": round(alg / t / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None,
+                                "what": "x is gathered 8 bytes at a time from lines nobody else in the wave uses: the memory system moves a whole "
+                                        "sector per entry (traffic below), the bytes priced here are the floor (matrix + x once + y once)"}}
+            del A, ptr, col, val
+            torch.cuda.empty_cache()
+            if not args.no_pmc:
+                tr, how = measure_traffic(8, only=name, names=U.PRODUCT_KERNELS, extra_env={"UNSTRUCTURED_ROWS": str(m), "GRID": "8"})
+                row["roofline"]["traffic_source"] = how
+                if tr:
+                    ks = {k: v for k, v in tr.items() if isinstance(v, dict)}
+                    total = sum(v["total"] for v in ks.values())
+                    row["roofline"]["traffic"] = total
+                    row["roofline"]["traffic_kernels"] = ks
+                    row["roofline"]["traffic_over_bytes_per_launch"] = round(total / float(stored), 3)
+                    row["roofline"]["traffic_over_algorithmic_bytes"] = round(total / float(alg), 3)
+                    row["roofline"]["traffic_gbps"] = round(total / t / 1e6, 1)
+            rows["SpMV unstructured: %s, %d rows (y = A*x, default vexhip_spmat)" % (name, m)] = row
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001 -- a secondary row
+            rows["SpMV unstructured: %s" % name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
     return rows
 
 
@@ -308,7 +363,7 @@ def secondary_rows(torch, L, ops, dev, local_rank):
             t = e0.elapsed_time(e1)
             best = t if best is None else min(best, t)
             del sk
-        rows["sort yardstick: torch.sort (rocPRIM) on the same 1e9 keys, int32, values + indices"] = {"ms": round(best, 3), "gkeys_per_s": round(n / best / 1e6, 1)}
+        rows["torch.sort = rocPRIM PAIRS sort on the same 1e9 keys (int32 keys + int64 indices: 12 B per element and pass, NOT a like-for-like keys-only sort)"] = {"ms": round(best, 3), "gpairs_per_s": round(n / best / 1e6, 1)}
     except Exception as e:  # noqa: BLE001 -- a comparison, not the measurement
         rows["sort yardstick: torch.sort"] = {"error": repr(e)[:200]}
     del k
@@ -895,6 +950,17 @@ def main():
                                  "frac": round(mv / tv / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": mv,
                                  "algorithmic_bytes_per_launch": alg_total, "algorithmic_gbps": round(alg_total / tv / 1e6, 1)},
                     "sum_y": DistReductor("SUM_Kahan")(y)}
+                # the general-matrix figure next to the headline (inside `roofline`, which the driver's summary keeps): the headline
+                # product runs on a lossless re-coding of a constant-coefficient stencil; a matrix with a coefficient per face
+                # streams diagonal codes + fp64 values, and the CSR-sized storages stream what the metric's name says
+                out["value_general"] = out["variable_coefficient"]["gflops"]
+                out["roofline"]["general_matrix"] = {
+                    "what": "same 7-point pattern with a coefficient per face (%d^3): 1-byte diagonal codes + fp64 values streamed, default vex::SpMat" % n,
+                    "gflops": out["variable_coefficient"]["gflops"], "avg_launch_ms": round(tv, 5),
+                    "bytes_per_launch": mv, "achieved": round(mv / tv / 1e6, 1), "frac": round(mv / tv / 1e6 / HBM_PEAK_GBPS, 4)}
+                out["roofline"]["frac_csr_bytes_kernel"] = max(r["frac"] for r in rcsr) if rcsr else None
+                out["roofline"]["frac_csr_bytes_kernel_what"] = ("the kernels that stream CSR-sized bytes on the headline matrix (32-bit columns + fp64 values): "
+                                                                 + "; ".join("%s %.5f ms = %.4f" % (r["kernel"].split("<")[0], r["avg_launch_ms"], r["frac"]) for r in rcsr))
                 # multi-right-hand-side product on the general matrix
                 xs = [ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 100 + k) for k in range(4)]
                 ys = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(4)]
@@ -926,6 +992,9 @@ def main():
                     sec["SpMV Poisson 7-point %d^3 (y = A*x, vexhip_spmat)" % g] = row
                     del G, Bg, pg, cg, vg, xg, yg, yb
                     torch.cuda.empty_cache()
+                # ---- matrices WITHOUT structure at size (round 5; the reference's tests are built on tests/random_matrix.hpp, its
+                #      real-world caller feeds irregular matrices): default SpMat, checked against a gather + segmented sum in torch
+                sec.update(unstructured_rows(torch, ops, dev, args))
                 # ---- the C++ front end on the same two matrices (examples/spmv_headline.cpp)
                 sec["C++ front end"] = cpp_rows(["spmv_headline", n, 50])
                 sec.update(secondary_rows(torch, L, ops, dev, local_rank))

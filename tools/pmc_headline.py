@@ -22,8 +22,28 @@ torch.cuda.synchronize()
 for _ in range(3):
     r.device_result(cal)
 del cal
-ptr, col, val = ops.poisson3d(n, dev)
 only = [f for f in os.environ.get("PMC_ONLY", "").split(",") if f]
+unstructured = [f for f in only if f in ("random16", "powerlaw")]
+if unstructured:
+    # round 5: the unstructured rows of bench.py (tools/unstructured.py); UNSTRUCTURED_ROWS rows
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import unstructured as U
+    del x, y
+    m = int(float(os.environ.get("UNSTRUCTURED_ROWS", "2e7")))
+    xu = ops.fill_hash(torch.empty(m, dtype=torch.float64, device=dev), 42)
+    yu = torch.zeros(m, dtype=torch.float64, device=dev)
+    for name in unstructured:
+        p_, c_, v_ = U.MAKERS[name](m, dev)
+        A = ops.SpMat(p_, c_, v_)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            A.apply(xu, yu)
+        torch.cuda.synchronize()
+        del A, p_, c_, v_
+        torch.cuda.empty_cache()
+    print("done")
+    sys.exit(0)
+ptr, col, val = ops.poisson3d(n, dev)
 for fmt in ("auto", "sell32", "csr"):
     if only and fmt not in only:
         continue
