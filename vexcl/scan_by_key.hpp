@@ -47,7 +47,7 @@ namespace sbk {
 
 enum scan_mode { INCLUSIVE = 0, EXCLUSIVE = 1, REDUCE = 2 };
 
-static const bool SBK_DPP_DEFAULT = false;
+static const bool SBK_DPP_DEFAULT = true;        // round 5: the wave scan on DPP is the default (VEXCL_SBK_DPP=0: six shuffles per row) -- profiles/r05_sbk_sweep.log
 static const int ITEMS = 4;         // consecutive elements per lane
 static const int ROWS = 2;          // rows of 64 x ITEMS elements per wave
 static const int WAVES = 4;         // waves per workgroup
