@@ -285,7 +285,7 @@ def unstructured_rows(torch, ops, dev, args):
             t = min(timed_events(torch, lambda: A.apply(x, y), 10) for _ in range(3))
             stored = A.matrix_bytes() + 16 * m            # what the product must move at least: the stored matrix + x once + y once
             alg = algorithmic_bytes(m, nnz)
-            row = {"what": what[name], "rows": m, "nnz": nnz, "storage": A.storage, "ell_width": getattr(A, "width", None), "tail_nnz": getattr(A, "tail_nnz", None),
+            row = {"what": what[name], "rows": m, "nnz": nnz, "storage": A.storage, "ell_width": getattr(getattr(A, "hell", None), "width", None), "tail_nnz": getattr(getattr(A, "hell", None), "tail_nnz", None),
                    "ms": round(t, 5), "gflops": round(2.0 * nnz / t / 1e6, 1), "rows_outside_tolerance": bad,
                    "roofline": {"bound": "hbm", "bytes_per_launch": stored, "achieved": round(stored / t / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(stored / t / 1e6 / HBM_PEAK_GBPS, 4),
@@ -792,7 +792,7 @@ def main():
                        "format": storage, "rows_per_gpu": rows_rank,
                        "parallelism": "row-partitioned x%d" % world},
             "roofline": {"bound": "hbm",
-                         "kernel": (("sell8_plane_kernel<%d, false, %d>" % (plane["tile"], {0: 2, 1: 18, 2: 17, 3: 0}[plane["store_policy"]])) if (storage == "sell8v" and plane) else
+                         "kernel": (("sell8_plane_kernel<%d, false, %d, false>" % (plane["tile"], {0: 2, 1: 18, 2: 17, 3: 0}[plane["store_policy"]])) if (storage == "sell8v" and plane) else
                                     KERNEL_OF["sell8v_grid"] if (storage == "sell8v" and grid_plan) else
                                     KERNEL_OF["sell8v_march"] if (storage == "sell8v" and march) else
                                     "sell8_pair_kernel<double, 7, true, true>" if (storage == "sell8v" and dict_blocks) else KERNEL_OF.get(storage, storage)),

@@ -11,6 +11,7 @@
 //                            handful of launches instead of a Python loop over torch.distributed requests.
 // librccl is loaded on first use (dlopen): a single-GPU user of libvexhip.so never pays for it.
 #include "common.hpp"
+#include "halo.hpp"
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -198,20 +199,6 @@ struct push_peer {
 inline int push_per_block() {
     static const int v = [] { const char *e = std::getenv("VEXHIP_IPC_PUSH_PER_BLOCK"); int k = e ? std::atoi(e) : 16384; k = k < 256 ? 256 : k; return k / 256 * 256; }();
     return v;
-}
-
-// returns false when the flag was not raised in time (err, in pinned host memory, is set then and stays set: the products that
-// are already queued fail fast instead of waiting `ticks` each; the host refuses further ones)
-__device__ inline bool spin_until(const unsigned long long *flag, unsigned long long want, int *err, unsigned long long ticks) {
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
-    const unsigned long long t0 = wall_clock64();
-    // relaxed polls (the flags are uncached: every poll reads memory), ONE acquire once the flag is there
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    return true;
 }
 
 // Every owner writes, per destination, exactly the values that destination needs straight into its window (idx: the

@@ -1,0 +1,48 @@
+// The product step of one rank in ONE launch (round 5; reference: the five phases of vexcl/spmat.hpp:120-185 -- gather the
+// boundary values, ship them, local part, wait, remote part).  For a matrix whose remote columns are the plane below the rank's
+// first plane and the plane above its last one (a plane partition of a 7-point operator), the rank's strip is stored as ONE grid
+// matrix that includes the entries reaching into the neighbours' planes, and the plane product (plane.hip) reads those two ghost
+// planes straight from the rank's peer-mapped window (comm.hip) -- no remote part, no wait kernel, no second stream:
+//   workgroups 0 .. 2 * push_blocks - 1 : copy the rank's first / last plane of x into the neighbours' windows and raise
+//                                         `arrive` there (dispatched first: the shares are on their way before the product starts);
+//   the other workgroups                : the plane product; a workgroup checks `arrive` when its walk first needs a line of a
+//                                         ghost plane -- the chunk next to the lower ghost plane is short and dispatched last, every
+//                                         other chunk walks upwards and meets the upper ghost plane at the end of its walk;
+//   the workgroup that finishes last    : raises `consumed` at the owners of the ghost planes and advances the step number.
+#pragma once
+#include "common.hpp"
+
+namespace vexhip {
+
+struct halo_dev {
+    const double *lo, *hi;                              // this rank's ghost planes (in its window); NULL: no neighbour on that side
+    const unsigned long long *arrive_lo, *arrive_hi;    // in this rank's window: the owner has written the share of product s
+    unsigned long long *consumed_lo, *consumed_hi;      // in the owners' windows: this rank has read the share of product s
+    double *dst_lo, *dst_hi;                            // where this rank's first / last plane goes: the lower neighbour's upper ghost plane, the upper neighbour's lower one
+    unsigned long long *peer_arrive_lo, *peer_arrive_hi;
+    const unsigned long long *sent_lo, *sent_hi;        // in this rank's window: the neighbour has read this rank's previous share
+    unsigned long long *step;                           // device word: the number of the product this launch computes (advanced by its last workgroup)
+    unsigned *done;                                     // [0]: workgroups of the launch that have finished; [1], [2]: push workgroups per side
+    int *err;                                           // sticky, pinned host memory: a flag was not raised in time
+    unsigned long long ticks;                           // bound of a flag wait (100 MHz ticks)
+    int push_blocks;                                    // workgroups per side that copy a plane
+    int halo;                                           // elements of a ghost plane
+    int z0, z1;                                         // planes of the stored grid this launch computes: [z0, z1)
+    int lo_planes;                                      // planes of the short chunk next to the lower ghost plane (0: none)
+};
+
+// returns false when the flag was not raised in time (err, in pinned host memory, is set then and stays set: the products that
+// are already queued fail fast instead of waiting `ticks` each; the host refuses further ones)
+__device__ inline bool spin_until(const unsigned long long *flag, unsigned long long want, int *err, unsigned long long ticks) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
+    const unsigned long long t0 = wall_clock64();
+    // relaxed polls (the flags are uncached: every poll reads memory), ONE acquire once the flag is there
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    return true;
+}
+
+} // namespace vexhip

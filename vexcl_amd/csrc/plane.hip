@@ -25,6 +25,7 @@
 // within a row (so that position order IS storage order) -- and declines otherwise; the march and pair products remain.
 // Compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "halo.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -81,11 +82,16 @@ __device__ __forceinline__ int position_of(int d, int far) {
     return d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -PL_ROWS ? 1 : d == PL_ROWS ? 5 : d == -far ? 0 : 6;
 }
 
-template <int TY, bool APPEND, int STORE_AUX>
+// HALO (round 5, halo.hpp): the launch is one rank's whole product step.  x and y are addressed in the numbering of the STORED
+// grid, whose plane z0 - 1 / z1 (if the rank has a neighbour there) is a ghost plane: its lines are read from the rank's window
+// (H.lo / H.hi) behind the owner's `arrive` flag; the first workgroups of the launch copy the rank's own boundary planes to the
+// neighbours.  (`consumed` is raised and the step number advanced by halo_signal_kernel behind this launch: a kernel boundary
+// orders every workgroup's reads of the ghost planes before the owners may overwrite them.)
+template <int TY, bool APPEND, int STORE_AUX, bool HALO = false>
 __global__ __launch_bounds__(256, TY == 2 ? 4 : 2)
 void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
-        plane_dev pd)
+        plane_dev pd, halo_dev H)
 {
     // LDS: per diagonal code its position (x 2), the value table, and the decoded values of the OTHER block, lane-private
     // ([position * 2 + row][lane]: consecutive lanes, consecutive 8-byte words -- conflict-free; row 14 takes what padding
@@ -95,13 +101,64 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     __shared__ double s_other[15][256];
 
     const int t = threadIdx.x;
-    const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
+    unsigned b = blockIdx.x;
+    [[maybe_unused]] unsigned long long step = 0;
+    [[maybe_unused]] __shared__ int s_flag[2];
+    if constexpr (HALO) {
+        step = *H.step;
+        const unsigned npush = (H.dst_lo ? (unsigned)H.push_blocks : 0u) + (H.dst_hi ? (unsigned)H.push_blocks : 0u);
+        if (b < npush) {
+            // ---- copy one of the rank's boundary planes into the neighbour's window (16-byte pieces), raise `arrive` there ----
+            const bool down = H.dst_lo && b < (unsigned)H.push_blocks;           // the FIRST plane goes to the lower neighbour
+            const unsigned j = down ? b : b - (H.dst_lo ? (unsigned)H.push_blocks : 0u);
+            if (t == 0) s_flag[0] = spin_until(down ? H.sent_lo : H.sent_hi, step - 1ull, H.err, H.ticks) ? 1 : 0;   // the neighbour has read the previous share
+            __syncthreads();
+            if (s_flag[0]) {                                                     // uniform; a neighbour that does not answer is not written to
+                const double *src = x + (down ? (long long)H.z0 * pd.far : (long long)(H.z1 - 1) * pd.far);
+                double *dst = down ? H.dst_lo : H.dst_hi;
+                const int per = ((H.halo + H.push_blocks - 1) / H.push_blocks + 511) / 512 * 512;
+                const int i0 = (int)j * per, i1 = i0 + per < H.halo ? i0 + per : H.halo;
+                for (int i = i0 + 2 * t; i < i1; i += 512)
+                    *reinterpret_cast<d2 *>(dst + i) = *reinterpret_cast<const d2 *>(src + i);
+                // the window is uncached memory: a wave's stores have been performed at the destination once its store counter is
+                // back at zero (comm.hip, ipc_push_kernel); ONE system-scope release by the lane that raises the flag
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t == 0) {
+                    unsigned *cnt = H.done + (down ? 1 : 2);
+                    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old + 1u == (unsigned)H.push_blocks) {
+                        *cnt = 0u;
+                        __threadfence_system();
+                        __hip_atomic_store(down ? H.peer_arrive_lo : H.peer_arrive_hi, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+            return;
+        }
+        b -= npush;
+    }
+    const unsigned xcd = b & 7u, q = b >> 3;
     const int zc = (int)(q / (unsigned)pd.tpx), tyl = (int)(q - (unsigned)zc * (unsigned)pd.tpx);
     const int tile = (int)xcd * pd.tpx + tyl;
     if (tile >= pd.tiles) return;                                   // the whole workgroup
     const int y0 = TY * tile;
-    int z = zc * pd.depth;
-    const int zend = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
+    int z, zend;
+    if constexpr (HALO) {
+        // chunks of the planes [z0, z1): a short one next to the lower ghost plane (it needs that plane at its first step: it is
+        // dispatched LAST), then chunks of `depth` planes that walk upwards
+        const int rest = H.z1 - H.z0 - H.lo_planes, nch = (H.lo_planes ? 1 : 0) + (rest + pd.depth - 1) / pd.depth;
+        const int cid = H.lo_planes ? (zc + 1) % nch : zc;
+        if (H.lo_planes && cid == 0) { z = H.z0; zend = H.z0 + H.lo_planes; }
+        else {
+            z = H.z0 + H.lo_planes + (cid - (H.lo_planes ? 1 : 0)) * pd.depth;
+            zend = z + pd.depth < H.z1 ? z + pd.depth : H.z1;
+        }
+    } else {
+        z = zc * pd.depth;
+        zend = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
+    }
     if (z >= zend) return;
     const int ny = pd.ny;
     const int nslices = (int)pd.nslices, xlines = (int)pd.xlines;
@@ -172,23 +229,56 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     // clamped requests (prologue, slow steps): line `l` of the tile's window (0 = the line above the tile, 1 .. TY = the tile,
     // TY + 1 = the line below) in plane zz.  A line outside x is never referenced by an entry; what is loaded in its place is
     // multiplied by +0.0 behind a mask
+    // HALO: the lines of x and y that exist are those of the planes [z0, z1); the plane below / above them is the ghost plane
+    const int line_lo = HALO ? H.z0 * ny : 0, line_hi = HALO ? H.z1 * ny : xlines;       // x: [line_lo, line_hi)
+    const int yline_hi = HALO ? H.z1 * ny : nslices;
+    [[maybe_unused]] bool got_lo = false, got_hi = false, ghost_bad = false;
     auto line_of = [&](int zz, int l) -> int {
         int li = zz * ny + (y0 - 1 + l);
-        li = li < 0 ? 0 : li; li = li >= xlines ? xlines - 1 : li;
+        li = li < line_lo ? line_lo : li; li = li >= line_hi ? line_hi - 1 : li;
         return li;
     };
     auto ld = [&](int zz, int l) -> d2 {
+        if constexpr (HALO) {
+            const int li = zz * ny + (y0 - 1 + l);                                   // uniform
+            if (li < line_lo || li >= line_hi) {
+                const bool below = li < line_lo;
+                const int gl = below ? li - (line_lo - ny) : li - line_hi;           // line of the ghost plane
+                const double *g = below ? H.lo : H.hi;
+                d2 r = {0.0, 0.0};
+                if (!g || gl < 0 || gl >= ny) return r;                              // no neighbour there / not the adjacent plane: never referenced by an entry
+                bool &got = below ? got_lo : got_hi;
+                if (!got) {
+                    // the first line of this ghost plane the workgroup needs: has the owner's share of THIS product arrived?
+                    if (t == 0) s_flag[below ? 0 : 1] = spin_until(below ? H.arrive_lo : H.arrive_hi, step, H.err, H.ticks) ? 1 : 0;
+                    __syncthreads();
+                    if (!s_flag[below ? 0 : 1]) ghost_bad = true;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                    got = true;
+                }
+                if (ghost_bad) { r.x = r.y = __builtin_nan(""); return r; }         // never numbers from stale ghosts (comm.hip)
+                return *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(g + (long long)gl * PL_ROWS) + lane_b);
+            }
+        }
         const char *p = reinterpret_cast<const char *>(x + (long long)line_of(zz, l) * PL_ROWS);
         return *reinterpret_cast<const d2 *>(p + lane_b);
     };
     auto edge = [&](int zz, int l) -> double {
+        if constexpr (HALO) {
+            const int li = zz * ny + (y0 - 1 + l);
+            if (li < line_lo || li >= line_hi) return 0.0;                           // the +-1 neighbours inside a ghost line: no row of this rank has them
+            long long i = (long long)li * PL_ROWS + (edge_b >> 3);
+            const long long a = (long long)line_lo * PL_ROWS, e = (long long)line_hi * PL_ROWS - 1;
+            i = i < a ? a : i; i = i > e ? e : i;
+            return x[i];
+        }
         long long i = (long long)line_of(zz, l) * PL_ROWS + (edge_b >> 3);
         i = i < 0 ? 0 : i; i = i > x_last ? x_last : i;
         return x[i];
     };
     auto yold = [&](int zz, int l) -> d2 {
         int li = zz * ny + (y0 + l);
-        li = li < 0 ? 0 : li; li = li >= nslices ? nslices - 1 : li;
+        li = li < line_lo ? line_lo : li; li = li >= yline_hi ? yline_hi - 1 : li;
         return *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(y + (long long)li * PL_ROWS) + lane_b);
     };
 
@@ -233,8 +323,8 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     // fast steps need nothing clamped: planes up to z + 3 inside x, both lines inside y
     int zh = zend;
     {
-        const int a = (xlines - 1 - TY - y0) / ny - 3, bb = (nslices - TY - y0) / ny - (APPEND ? 1 : 0);      // largest z with (z+3) ny + y0 + TY <= xlines - 1 / z ny + y0 + TY - 1 <= nslices - 1 ('+=': the old y is requested one plane ahead -- inside y also when x is longer than y)
-        if (xlines - 1 - TY - y0 < 0 || nslices - TY - y0 < 0) zh = 0;
+        const int a = (line_hi - 1 - TY - y0) / ny - 3, bb = (yline_hi - TY - y0) / ny - (APPEND ? 1 : 0);      // largest z with (z+3) ny + y0 + TY <= xlines - 1 / z ny + y0 + TY - 1 <= nslices - 1 ('+=': the old y is requested one plane ahead -- inside y also when x is longer than y)
+        if (line_hi - 1 - TY - y0 < 0 || yline_hi - TY - y0 < 0) zh = 0;
         else { zh = zh < a + 1 ? zh : a + 1; zh = zh < bb + 1 ? zh : bb + 1; }
     }
 
@@ -303,7 +393,7 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
 #pragma unroll
         for (int l = 0; l < TY; ++l) {
             const int li = z * ny + (y0 + l);
-            if (li < nslices) {                                           // uniform
+            if (li < yline_hi) {                                          // uniform
                 PLANE_XS(Cs[0], Cs[1], Cs[2], Hs[0], Es[0], l)
                 double s0 = 0.0, s1 = 0.0;
                 const int blk = __builtin_amdgcn_readfirstlane(blocks[li]);
@@ -340,6 +430,14 @@ void stream_copy_kernel(const double *__restrict__ x, double *__restrict__ y, lo
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < npairs) __builtin_nontemporal_store(reinterpret_cast<const d2 *>(x)[i], reinterpret_cast<d2 *>(y) + i);
     else if (i == npairs && (n & 1)) y[n - 1] = x[n - 1];
+}
+
+// behind a HALO launch: the ghost planes of product `step` have been read -- the owners may write the next ones
+__global__ void halo_signal_kernel(halo_dev H) {
+    const unsigned long long step = *H.step;
+    if (H.consumed_lo) __hip_atomic_store(H.consumed_lo, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (H.consumed_hi) __hip_atomic_store(H.consumed_hi, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    *H.step = step + 1ull;
 }
 
 } // namespace
