@@ -404,7 +404,9 @@ enum { VEXHIP_SPMAT_BORROW_CSR = 1,      /* format CSR: keep the caller's arrays
        VEXHIP_SPMAT_NO_DICTIONARY = 2,   /* value-coded storage: keep one block per slice even if the slices repeat (A/B, tests)   */
        VEXHIP_SPMAT_NO_MARCH = 4,        /* keep the pair products where the march / plane products would apply (A/B, tests)       */
        VEXHIP_SPMAT_NO_PLANE = 8,        /* keep the march product where the plane product would apply (A/B, tests)                */
-       VEXHIP_SPMAT_NO_GRID_BUILD = 16 };/* build the SELL-512 storage even where the matrix could be stored by grid line (A/B, tests) */
+       VEXHIP_SPMAT_NO_GRID_BUILD = 16,  /* build the SELL-512 storage even where the matrix could be stored by grid line (A/B, tests) */
+       VEXHIP_SPMAT_SQUARE = 32 };       /* x has at least `rows` elements whatever the largest column that occurs (the set-up assumes     *
+                                          * only max column + 1 otherwise: vex::SpMat takes n AND m, spmat.hpp:56-60)                     */
 typedef struct vexhip_spmat_info {
     int32_t format, value_type, device, ndeltas, nvalues, reserved;
     int64_t rows, nnz, ell_width, tail_nnz, sell_bytes;
@@ -468,8 +470,9 @@ enum { VEXHIP_COMM_AUTO = 0,   /* RCCL when the devices are distinct GPUs and th
        VEXHIP_COMM_PEER = 2,   /* single process only: event-ordered device-to-device copies (no communicator; the only  *
                                 * option when logical devices share one GPU -- the reference's own test fixture,           *
                                 * tests/context_setup.hpp:24-39 -- and the host fold of the reference for reductions)      */
-       VEXHIP_COMM_IPC = 3 };  /* one process per GPU: peer-mapped ghost windows (vexhip_ipc_window_*), reported by       *
+       VEXHIP_COMM_IPC = 3,    /* one process per GPU: peer-mapped ghost windows (vexhip_ipc_window_*), reported by       *
                                 * vexhip_dist_spmv_status; not a value for vexhip_comm_init                               */
+       VEXHIP_COMM_HALO = 4 }; /* the same windows, the whole step in ONE product launch (vexhip_dist_spmv_create_halo)   */
 int vexhip_comm_init(int ndev, const int *devs, int transport, vexhip_comm **out);
 int vexhip_comm_init_rank(int dev, int rank, int world, const void *id128, vexhip_comm **out);
 int vexhip_comm_destroy(vexhip_comm *comm);
@@ -526,7 +529,19 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *win, int dtype, int64_t rows,
         int64_t rem_rows, const int32_t *rows_idx, const int32_t *rem_ptr, const int32_t *rem_col, const void *rem_val,
         int64_t nsend, const int32_t *send_idx, const int64_t *send_counts, const int64_t *dst_offsets,
         int64_t nghost, const int64_t *recv_counts, vexhip_dist_spmv **out);
-/* timed_out: a flag wait ran into its bound; transport: VEXHIP_COMM_RCCL or VEXHIP_COMM_IPC; direct: the shares are
+/* Round 5 -- the step as ONE launch (replaces all five phases of vexcl/spmat.hpp:120-185 for plane partitions of a 7-point
+ * operator on 512-point lines): `ext` is the rank's strip stored as ONE grid matrix that keeps the entries reaching into the
+ * neighbours' planes -- (has lower neighbour ? `halo` empty rows : none) + the rank's rows + (has upper ? `halo` empty rows :
+ * none), columns counted from the first element of the lower ghost plane -- and must have come out of vexhip_spmat_create_*
+ * with a plane plan.  The window holds [lower ghost plane | upper ghost plane] (2 * halo * 8 bytes); lower / upper are the
+ * neighbours' ranks (-1: none; their windows opened).  vexhip_dist_spmv_apply then issues the plane product whose first
+ * workgroups copy the rank's first / last plane of x into the neighbours' windows and whose other workgroups read the ghost
+ * planes from the rank's own window behind the owners' `arrive` flags, followed by one single-thread kernel that raises
+ * `consumed`: no second stream, no event, no remote part, two launches per product.  x and y are the rank's own segments.
+ * The plan owns the window (no other plan on it).  Timeouts as above (NaN ghosts, sticky error).                          */
+int vexhip_dist_spmv_create_halo(vexhip_ipc_window *win, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
+        vexhip_dist_spmv **out);
+/* timed_out: a flag wait ran into its bound; transport: VEXHIP_COMM_RCCL, VEXHIP_COMM_IPC or VEXHIP_COMM_HALO; direct: the shares are
  * runs of x and no pack kernel / index list is used.                                                                 */
 int vexhip_dist_spmv_status(vexhip_dist_spmv *step, int *timed_out, int *transport, int *direct);
 /* One product with its phases timed (HIP events on both streams; synchronises): ms6 = total, local part, wait for the

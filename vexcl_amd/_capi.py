@@ -93,6 +93,7 @@ SPMAT_NO_DICTIONARY = 2
 SPMAT_NO_MARCH = 4
 SPMAT_NO_PLANE = 8
 SPMAT_NO_GRID_BUILD = 16
+SPMAT_SQUARE = 32
 SPMAT_NAMES = {SPMAT_SELL8V: "sell8v", SPMAT_SELL8: "sell8", SPMAT_SELL: "sell32", SPMAT_CSR: "csr"}
 
 # name -> (restype, argtypes); restype None means "int status, checked"
@@ -216,6 +217,7 @@ _PROTOS = {
     "vexhip_ipc_window_open": (None, [c_vp, c_int, c_vp]),
     "vexhip_ipc_window_data": (None, [c_vp, ctypes.POINTER(c_vp)]),
     "vexhip_ipc_window_destroy": (None, [c_vp]),
+    "vexhip_dist_spmv_create_halo": (None, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, ctypes.POINTER(c_vp)]),
     "vexhip_dist_spmv_create_ipc": (None, [c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64),
                                            ctypes.POINTER(c_i64), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_vp)]),
     "vexhip_dist_spmv_status": (None, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

@@ -23,6 +23,11 @@
 #include <vector>
 
 namespace vexhip {
+// spmat.hip: the stored strip of a rank as the operand of the one-launch step (halo.hpp)
+int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane);
+int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const double *x, double *y, const halo_dev &H);
+}
+namespace vexhip {
 namespace {
 
 struct rccl_api {
@@ -307,6 +312,11 @@ struct dist_spmv {
     int *d_err = nullptr;                      // sticky, in pinned host memory mapped into the device: a flag was not raised in time
     const unsigned long long **d_arrive = nullptr; unsigned long long **d_consumed = nullptr; int nown = 0;
     hipEvent_t pushed = nullptr;
+    // one-launch step (halo.hpp): the stored strip with its ghost planes, the kernel's view of the windows
+    bool halo = false;
+    const vexhip_spmat *ext = nullptr;
+    halo_dev hd;
+    unsigned *d_halo_done = nullptr;
     // optional phase timing of one step (vexhip_dist_spmv_profile)
     hipEvent_t *prof = nullptr;                // [0..3] compute stream: start, local done, ghosts here, end; [4..6] comm stream: start, packed, exchanged
 };
@@ -398,7 +408,20 @@ int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const 
     return 0;
 }
 
+// The whole step as ONE product launch (+ the one-thread kernel that raises `consumed`): push workgroups, ghost planes read by the
+// plane product itself (halo.hpp, plane.hip).  No second stream, no event, nothing to capture: two launches per product.
+int issue_step_halo(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
+    if (D->d_err && *static_cast<volatile int *>(D->d_err))
+        return fail(__FILE__, __LINE__, "an earlier product of this plan timed out waiting for a peer's ghost flag (IPC transport, VEXHIP_IPC_TIMEOUT_MS): "
+                                        "its result and every later one are invalid");
+    PROF(0, s); PROF(4, s); PROF(5, s); PROF(6, s);
+    if (int rc = spmat_apply_halo(D->ext, s, alpha, append, static_cast<const double *>(x), static_cast<double *>(y), D->hd)) return rc;
+    PROF(1, s); PROF(2, s); PROF(3, s);
+    return 0;
+}
+
 int issue_step(dist_spmv *D, hipStream_t s, double alpha, int append, const void *x, void *y) {
+    if (D->halo) return issue_step_halo(D, s, alpha, append, x, y);
     if (D->win) return issue_step_ipc(D, s, alpha, append, x, y);
     const bool f64 = D->dtype == VEXHIP_F64;
     const bool exch = D->nsend > 0 || D->nghost > 0;
@@ -733,6 +756,7 @@ int vexhip_dist_spmv_destroy(vexhip_dist_spmv *h) {
     if (D->d_err) (void)hipHostFree(D->d_err);
     if (D->d_arrive) (void)hipFree(D->d_arrive);
     if (D->d_consumed) (void)hipFree(D->d_consumed);
+    if (D->d_halo_done) (void)hipFree(D->d_halo_done);
     delete D;
     return 0;
 }
@@ -790,7 +814,14 @@ int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, v
     w->bytes = window_header(world) + (((size_t)data_bytes + 255) / 256 * 256) + 256;
     w->peer.assign(world, nullptr); w->opened.assign(world, 0);
     void *p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, w->bytes, hipDeviceMallocUncached);
+    // (VEXHIP_IPC_WINDOW_MEM=finegrained | default: diagnostics on ONE device only -- tools/r05_dist_step.py measures what the
+    //  uncached mapping costs the reader; between two devices only the uncached window is known to show a peer's writes)
+    unsigned kind = hipDeviceMallocUncached;
+    if (const char *m = std::getenv("VEXHIP_IPC_WINDOW_MEM")) {
+        if (std::string(m) == "finegrained") kind = hipDeviceMallocFinegrained;
+        else if (std::string(m) == "default") kind = hipDeviceMallocDefault;
+    }
+    hipError_t e = hipExtMallocWithFlags(&p, w->bytes, kind);
     if (e == hipSuccess) e = hipMemset(p, 0, w->bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { if (p) (void)hipFree(p); delete w; return check(e, __FILE__, __LINE__); }
@@ -936,6 +967,91 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
     return 0;
 }
 
+// The one-launch step.  `ext` is the rank's strip stored as a grid matrix of (has_lower + planes + has_upper) planes: `halo`
+// empty rows (one plane) in front of the rank's rows when it has a lower neighbour, one plane of empty rows behind them when it
+// has an upper one, columns counted from the first element of the lower ghost plane.  The window holds [lower ghost plane | upper
+// ghost plane]; the neighbours' windows must have been opened.  The plan owns the window's step counter (no other plan on it).
+int vexhip_dist_spmv_create_halo(vexhip_ipc_window *hw, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
+        vexhip_dist_spmv **out)
+{
+    ipc_window *w = reinterpret_cast<ipc_window *>(hw);
+    VEXHIP_REQUIRE(out, "NULL output");
+    *out = nullptr;
+    VEXHIP_REQUIRE(w && ext, "NULL argument");
+    VEXHIP_REQUIRE(rows > 0 && halo > 0 && halo < (1ll << 31) && rows % halo == 0, "the rank's rows must be whole planes of `halo` elements");
+    VEXHIP_REQUIRE(lower >= -1 && lower < w->world && upper >= -1 && upper < w->world, "bad neighbour");
+    VEXHIP_REQUIRE(2 * halo * 8 <= w->data_bytes, "the window is smaller than two ghost planes");
+    int planes = 0, ny = 0;
+    if (int rc = spmat_halo_geometry(ext, &planes, &ny)) return rc;
+    const int has_lo = lower >= 0 ? 1 : 0, has_hi = upper >= 0 ? 1 : 0;
+    VEXHIP_REQUIRE(planes > 0 && (int64_t)ny * 512 == halo && planes == has_lo + rows / halo + has_hi,
+                   "the stored strip is not a plane-product matrix of (lower ghost plane +) the rank's planes (+ upper ghost plane)");
+    VEXHIP_REQUIRE((lower < 0 || w->peer[lower]) && (upper < 0 || w->peer[upper]), "a neighbour's window has not been opened (vexhip_ipc_window_open)");
+    dist_spmv *D = new (std::nothrow) dist_spmv;
+    VEXHIP_REQUIRE(D, "out of host memory");
+    D->win = w; D->dev = w->dev; D->dtype = VEXHIP_F64; D->rows = rows; D->halo = true; D->ext = ext; D->direct = true;
+    D->nsend = (has_lo + has_hi) * halo; D->nghost = (has_lo + has_hi) * halo;
+    D->send_counts.assign(w->world, 0); D->recv_counts.assign(w->world, 0);
+    if (has_lo) { D->send_counts[lower] += halo; D->recv_counts[lower] += halo; }
+    if (has_hi) { D->send_counts[upper] += halo; D->recv_counts[upper] += halo; }
+    auto bail = [&](int rc) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return rc; };
+    hipError_t e = hipSetDevice(D->dev);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&D->d_err), sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) *D->d_err = 0;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&D->d_halo_done), 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(D->d_halo_done, 0, 4 * sizeof(unsigned));
+    const unsigned long long one = 1ull;                       // products are numbered from 1; the flags start at 0
+    if (e == hipSuccess) e = hipMemcpy(w->d_step, &one, sizeof(one), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(check(e, __FILE__, __LINE__));
+    const size_t hdr = window_header(w->world);
+    halo_dev &H = D->hd;
+    H = halo_dev();
+    double *mine = reinterpret_cast<double *>(w->base + hdr);
+    // window layout: [lower ghost plane | upper ghost plane]
+    if (has_lo) {
+        H.lo = mine;
+        H.arrive_lo = window_arrive(w->base, lower);
+        H.consumed_lo = window_consumed(w->peer[lower], w->world, w->rank);
+        H.dst_lo = reinterpret_cast<double *>(w->peer[lower] + hdr) + halo;          // my first plane is the lower neighbour's UPPER ghost plane
+        H.peer_arrive_lo = window_arrive(w->peer[lower], w->rank);
+        H.sent_lo = window_consumed(w->base, w->world, lower);
+    }
+    if (has_hi) {
+        H.hi = mine + halo;
+        H.arrive_hi = window_arrive(w->base, upper);
+        H.consumed_hi = window_consumed(w->peer[upper], w->world, w->rank);
+        H.dst_hi = reinterpret_cast<double *>(w->peer[upper] + hdr);                 // my last plane is the upper neighbour's LOWER ghost plane
+        H.peer_arrive_hi = window_arrive(w->peer[upper], w->rank);
+        H.sent_hi = window_consumed(w->base, w->world, upper);
+        if (upper == lower) {
+            // one rank exchanging with itself (tools/r05_dist_step.py: the cost of a step on the one-GPU box): both sides would
+            // share arrive[rank] / consumed[rank]; the upper side takes two spare words of the window's header
+            if (upper != w->rank || 2 * (size_t)w->world + 2 > hdr / 8) return bail(fail(__FILE__, __LINE__, "lower and upper neighbour are the same rank"));
+            unsigned long long *spare = reinterpret_cast<unsigned long long *>(w->base) + 2 * w->world;
+            H.arrive_hi = spare; H.peer_arrive_hi = spare; H.consumed_hi = spare + 1; H.sent_hi = spare + 1;
+        }
+    }
+    H.step = w->d_step; H.done = D->d_halo_done; H.err = D->d_err; H.ticks = spin_ticks();
+    H.push_blocks = 16;
+    if (const char *pb = std::getenv("VEXHIP_HALO_PUSH_BLOCKS")) H.push_blocks = std::max(1, std::min(1024, std::atoi(pb)));
+    H.halo = (int)halo; H.z0 = has_lo; H.z1 = has_lo + (int)(rows / halo); H.lo_planes = 0; H.hi_planes = 0;
+    if (std::getenv("VEXHIP_HALO_NO_PUSH")) {
+        // diagnostics (tools/r05_dist_step.py): nobody pushes, the flags this rank waits for are raised once and for all -- what the
+        // product with ghost planes costs when the exchange costs nothing
+        const unsigned long long big = ~0ull >> 2;
+        if (H.arrive_lo) (void)hipMemcpy(const_cast<unsigned long long *>(H.arrive_lo), &big, 8, hipMemcpyHostToDevice);
+        if (H.arrive_hi) (void)hipMemcpy(const_cast<unsigned long long *>(H.arrive_hi), &big, 8, hipMemcpyHostToDevice);
+        H.dst_lo = H.dst_hi = nullptr; H.consumed_lo = H.consumed_hi = nullptr;
+        if (const char *g = std::getenv("VEXHIP_HALO_NO_GHOST")) {          // ... and nobody reads a ghost plane either (wrong numbers: the cost of the chunking alone); 1 both, 2 lower only, 3 upper only
+            const int k = std::atoi(g);
+            if (k == 1 || k == 2) H.lo = nullptr;
+            if (k == 1 || k == 3) H.hi = nullptr;
+        }
+    }
+    *out = reinterpret_cast<vexhip_dist_spmv *>(D);
+    return 0;
+}
+
 int vexhip_dist_spmv_status(vexhip_dist_spmv *h, int *timed_out, int *transport, int *direct) {
     dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
     VEXHIP_REQUIRE(D, "NULL argument");
@@ -943,7 +1059,7 @@ int vexhip_dist_spmv_status(vexhip_dist_spmv *h, int *timed_out, int *transport,
         *timed_out = 0;
         if (D->d_err) *timed_out = *static_cast<volatile int *>(D->d_err);
     }
-    if (transport) *transport = D->win ? VEXHIP_COMM_IPC : VEXHIP_COMM_RCCL;
+    if (transport) *transport = D->halo ? VEXHIP_COMM_HALO : D->win ? VEXHIP_COMM_IPC : VEXHIP_COMM_RCCL;
     if (direct) *direct = D->direct ? 1 : 0;
     return 0;
 }

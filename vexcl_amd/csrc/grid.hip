@@ -828,7 +828,7 @@ template <typename T> struct dev_buf {       // device scratch of the plan, free
 // usable = 0: not a matrix for this storage, nothing was written that the classic set-up would read.
 template <typename P>
 int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t *col, const double *val,
-        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last_out, vexhip_grid *out)
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last_out, vexhip_grid *out, int64_t min_cols)
 {
     VEXHIP_REQUIRE(out && ndeltas && nvalues && ell_width && x_last_out, "NULL output");
     std::memset(out, 0, sizeof(*out));
@@ -902,7 +902,7 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
                      nx, ny, lines, h_ints[GBI_COUNT], h_ints[GBI_VCOUNT], h_ints[GBI_FLAGS], h_ints[GBI_POSMASK], h_ints[GBI_MAXCOL], h_ints[GBI_MAXLEN]);
     const int nclasses = h_ints[GBI_COUNT], nv = h_ints[GBI_VCOUNT];
     if (h_ints[GBI_FLAGS] != 0 || nclasses < 1 || nclasses > GB_MAX_CLASSES || nv < 1 || nv > GB_MAX_VALUES) return 0;   // the classic set-up takes over
-    const long long x_last = h_ints[GBI_MAXCOL];
+    const long long x_last = std::max<long long>(h_ints[GBI_MAXCOL], min_cols - 1);      // min_cols: the caller vouches for that many elements of x (VEXHIP_SPMAT_SQUARE)
     if (x_last < 0 || x_last + 1 < rows) return 0;
     const int *uses = h_ints + GBI_USES;
     const int hot = (int)(std::max_element(uses, uses + nclasses) - uses);
@@ -934,11 +934,11 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
 
 // internal entry points of the direct build (spmat.hip)
 int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val,
-        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out)
-{ return grid_build<int32_t>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out); }
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols)
+{ return grid_build<int32_t>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
 int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val,
-        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out)
-{ return grid_build<long long>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out); }
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols)
+{ return grid_build<long long>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
 
 } // namespace vexhip
 

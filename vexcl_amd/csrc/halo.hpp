@@ -6,9 +6,9 @@
 //   workgroups 0 .. 2 * push_blocks - 1 : copy the rank's first / last plane of x into the neighbours' windows and raise
 //                                         `arrive` there (dispatched first: the shares are on their way before the product starts);
 //   the other workgroups                : the plane product; a workgroup checks `arrive` when its walk first needs a line of a
-//                                         ghost plane -- the chunk next to the lower ghost plane is short and dispatched last, every
-//                                         other chunk walks upwards and meets the upper ghost plane at the end of its walk;
-//   the workgroup that finishes last    : raises `consumed` at the owners of the ghost planes and advances the step number.
+//                                         ghost plane -- only the SHORT chunks next to the two ghost planes ever do (dispatched
+//                                         behind the main chunks, which stream the bulk of the strip meanwhile);
+//   a one-thread kernel behind it       : raises `consumed` at the owners of the ghost planes and advances the step number.
 #pragma once
 #include "common.hpp"
 
@@ -28,7 +28,7 @@ struct halo_dev {
     int push_blocks;                                    // workgroups per side that copy a plane
     int halo;                                           // elements of a ghost plane
     int z0, z1;                                         // planes of the stored grid this launch computes: [z0, z1)
-    int lo_planes;                                      // planes of the short chunk next to the lower ghost plane (0: none)
+    int lo_planes, hi_planes;                           // planes of the short chunks next to the lower / upper ghost plane (0: none)
 };
 
 // returns false when the flag was not raised in time (err, in pinned host memory, is set then and stays set: the products that

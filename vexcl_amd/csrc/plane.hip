@@ -88,7 +88,7 @@ __device__ __forceinline__ int position_of(int d, int far) {
 // neighbours.  (`consumed` is raised and the step number advanced by halo_signal_kernel behind this launch: a kernel boundary
 // orders every workgroup's reads of the ghost planes before the owners may overwrite them.)
 template <int TY, bool APPEND, int STORE_AUX, bool HALO = false>
-__global__ __launch_bounds__(256, TY == 2 ? 4 : 2)
+__global__ __launch_bounds__(256, (TY == 2 && !HALO) ? 4 : 2)       // (HALO: a few registers more than 128, and one product workgroup per CU anyway)
 void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
         plane_dev pd, halo_dev H)
@@ -120,18 +120,21 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
                 const int i0 = (int)j * per, i1 = i0 + per < H.halo ? i0 + per : H.halo;
                 for (int i = i0 + 2 * t; i < i1; i += 512)
                     *reinterpret_cast<d2 *>(dst + i) = *reinterpret_cast<const d2 *>(src + i);
-                // the window is uncached memory: a wave's stores have been performed at the destination once its store counter is
-                // back at zero (comm.hip, ipc_push_kernel); ONE system-scope release by the lane that raises the flag
+                // The window is UNCACHED memory (here and through the peer mapping): its stores go past every cache, and a wave's
+                // stores have been performed at the destination once its store counter is back at zero -- so the flag may follow
+                // behind `s_waitcnt vmcnt(0)` + a barrier + a relaxed count of the workgroups, with NO release fence.  A fence at
+                // agent or system scope writes back the XCD's L2, which at this moment is full of the product's freshly stored y:
+                // with ACQ_REL counts and a system fence in front of the flag the push of 4 MB took ~50 us of a 120 us step
+                // (tools/r05_dist_step.py, VEXHIP_HALO_NO_PUSH against the default; profiles/r05_dist_step_*.json).
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (t == 0) {
                     unsigned *cnt = H.done + (down ? 1 : 2);
-                    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (old + 1u == (unsigned)H.push_blocks) {
-                        *cnt = 0u;
-                        __threadfence_system();
-                        __hip_atomic_store(down ? H.peer_arrive_lo : H.peer_arrive_hi, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(down ? H.peer_arrive_lo : H.peer_arrive_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 }
             }
@@ -146,15 +149,14 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     const int y0 = TY * tile;
     int z, zend;
     if constexpr (HALO) {
-        // chunks of the planes [z0, z1): a short one next to the lower ghost plane (it needs that plane at its first step: it is
-        // dispatched LAST), then chunks of `depth` planes that walk upwards
-        const int rest = H.z1 - H.z0 - H.lo_planes, nch = (H.lo_planes ? 1 : 0) + (rest + pd.depth - 1) / pd.depth;
-        const int cid = H.lo_planes ? (zc + 1) % nch : zc;
-        if (H.lo_planes && cid == 0) { z = H.z0; zend = H.z0 + H.lo_planes; }
-        else {
-            z = H.z0 + H.lo_planes + (cid - (H.lo_planes ? 1 : 0)) * pd.depth;
-            zend = z + pd.depth < H.z1 ? z + pd.depth : H.z1;
-        }
+        // chunks of the planes [z0, z1): the planes next to a ghost plane form SHORT chunks of their own, dispatched behind the
+        // main chunks -- they wait for the neighbour's share and read it from uncached memory (slow: few requests in flight)
+        // while the main chunks, which never touch a ghost plane, stream the bulk of the strip
+        const int mid0 = H.z0 + H.lo_planes, mid1 = H.z1 - H.hi_planes;
+        const int nmain = (mid1 - mid0 + pd.depth - 1) / pd.depth;
+        if (zc < nmain) { z = mid0 + zc * pd.depth; zend = z + pd.depth < mid1 ? z + pd.depth : mid1; }
+        else if (H.hi_planes && zc == nmain) { z = mid1; zend = H.z1; }
+        else { z = H.z0; zend = mid0; }
     } else {
         z = zc * pd.depth;
         zend = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
@@ -246,14 +248,16 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
                 const int gl = below ? li - (line_lo - ny) : li - line_hi;           // line of the ghost plane
                 const double *g = below ? H.lo : H.hi;
                 d2 r = {0.0, 0.0};
-                if (!g || gl < 0 || gl >= ny) return r;                              // no neighbour there / not the adjacent plane: never referenced by an entry
+                if (!g || gl < 0 || gl >= ny || l == 0 || l == TY + 1) return r;     // no neighbour there / not the adjacent plane / the line above or below the tile IN a ghost plane: never referenced by an entry
                 bool &got = below ? got_lo : got_hi;
                 if (!got) {
                     // the first line of this ghost plane the workgroup needs: has the owner's share of THIS product arrived?
                     if (t == 0) s_flag[below ? 0 : 1] = spin_until(below ? H.arrive_lo : H.arrive_hi, step, H.err, H.ticks) ? 1 : 0;
                     __syncthreads();
                     if (!s_flag[below ? 0 : 1]) ghost_bad = true;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                    // (no fence per lane: the ghost planes are UNCACHED memory -- nothing of them is ever held in a cache -- and
+                    //  lane 0 has acquired at system scope inside spin_until in front of the barrier; a system-scope acquire by
+                    //  every lane of every workgroup doubled the time of the whole product: 55 -> 119 us)
                     got = true;
                 }
                 if (ghost_bad) { r.x = r.y = __builtin_nan(""); return r; }         // never numbers from stale ghosts (comm.hip)
@@ -490,6 +494,51 @@ int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_
 }
 } // namespace vexhip
 
+namespace vexhip {
+// One rank's product step in one launch (halo.hpp): the plane product over the planes [H.z0, H.z1) of the stored grid of n_ext
+// rows, x and y being the rank's own segments (their element 0 is row H.z0 * far of the stored grid); ghost planes from the
+// window, boundary planes pushed by the first workgroups; then the kernel that raises `consumed` and advances the step number.
+int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
+        const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane, halo_dev H)
+{
+    VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
+    VEXHIP_REQUIRE(n_ext > 0 && n_ext % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
+    VEXHIP_REQUIRE(plane->lines_per_plane >= 4 && plane->lines_per_plane % 2 == 0 && plane->depth >= 1 && plane->planes >= 1
+                   && ((long long)plane->depth + 4) * plane->lines_per_plane * 4096 < (1ll << 32), "bad plane plan");
+    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "plane product: x and y must be 16-byte aligned");
+    VEXHIP_REQUIRE(H.z0 >= 0 && H.z1 > H.z0 && H.z1 <= plane->planes && H.step && H.done && H.err && H.push_blocks >= 1, "bad halo step");
+    VEXHIP_REQUIRE(H.halo == plane->lines_per_plane * PL_ROWS, "the ghost planes must be planes of the stored grid");
+    VEXHIP_REQUIRE((!H.lo || H.z0 >= 1) && (!H.hi || H.z1 < plane->planes), "a ghost plane outside the stored grid");
+    VEXHIP_SET_DEVICE(dev);
+    plane_dev pd;
+    pd.nslices = n_ext / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
+    pd.ny = plane->lines_per_plane; pd.nz = plane->planes; pd.depth = plane->depth;
+    pd.tiles = pd.ny / 2; pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
+    pd.pitch = plane->table_pitch;
+    const int nzr = H.z1 - H.z0;
+    int edge_planes = 8;
+    if (const char *e = std::getenv("VEXHIP_HALO_EDGE_PLANES")) edge_planes = std::max(1, std::atoi(e));
+    H.lo_planes = H.lo ? std::min(edge_planes, nzr) : 0;
+    H.hi_planes = H.hi ? std::min(edge_planes, nzr - H.lo_planes) : 0;
+    const int mid = nzr - H.lo_planes - H.hi_planes;
+    if (const char *e = std::getenv("VEXHIP_HALO_DEPTH")) pd.depth = std::max(1, std::atoi(e));
+    const long long chunks = (H.lo_planes ? 1 : 0) + (H.hi_planes ? 1 : 0) + (mid + pd.depth - 1) / pd.depth;
+    const long long npush = (H.dst_lo ? H.push_blocks : 0) + (H.dst_hi ? H.push_blocks : 0);
+    const long long grid = npush + 8ll * pd.tpx * chunks;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    // the kernel addresses x and y in the numbering of the stored grid
+    const double *xe = x - (long long)H.z0 * pd.far;
+    double *ye = y - (long long)H.z0 * pd.far;
+    const char *cpool = static_cast<const char *>(pool);
+    if (append) sell8_plane_kernel<2, true, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
+    else        sell8_plane_kernel<2, false, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
+    VEXHIP_LAUNCH_CHECK();
+    halo_signal_kernel<<<1, 1, 0, s>>>(H);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+} // namespace vexhip
+
 extern "C" {
 
 int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
@@ -583,7 +632,8 @@ int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double al
     const int store_kind = plane->store_policy;
     const char *cpool = static_cast<const char *>(pool);
     hipStream_t s = as_stream(stream);
-#define PLANE_LAUNCH(TY, AP, AUX) sell8_plane_kernel<TY, AP, AUX><<<(unsigned)grid, 256, 0, s>>>(x, y, alpha, blocks, cpool, deltas, values, pd)
+    const halo_dev none = halo_dev();
+#define PLANE_LAUNCH(TY, AP, AUX) sell8_plane_kernel<TY, AP, AUX><<<(unsigned)grid, 256, 0, s>>>(x, y, alpha, blocks, cpool, deltas, values, pd, none)
 #define PLANE_AUX(TY, AP) switch (store_kind) { case 1: PLANE_LAUNCH(TY, AP, 18); break; case 2: PLANE_LAUNCH(TY, AP, 17); break; case 3: PLANE_LAUNCH(TY, AP, 0); break; default: PLANE_LAUNCH(TY, AP, 2); }
     if (plane->tile == 4) { if (append) { PLANE_AUX(4, true) } else { PLANE_AUX(4, false) } }
     else { if (append) { PLANE_AUX(2, true) } else { PLANE_AUX(2, false) } }

@@ -9,7 +9,9 @@
 // lives in this file once, instead of once in vexcl/spmat.hpp and once in vexcl_amd/ops.py (round 1).
 // Both front ends now call create / apply / destroy.  Built from DEVICE CSR arrays: no host staging.
 #include "common.hpp"
+#include "halo.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -41,10 +43,12 @@ int spmv_csr_p64(int dev, void *stream, int64_t n, double alpha, int append, con
 int spmv_csr_p64(int dev, void *stream, int64_t n, float alpha, int append, const long long *ptr, const int32_t *col, const float *val, const float *x, float *y, const vexhip_traversal *tr);
 int csr_traversal_p64(int dev, void *stream, int64_t n, const long long *ptr, const int32_t *col, int rows_per_block, vexhip_traversal *traversal);
 int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val,
-        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out);
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols);
 int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val,
-        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out);
+        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols);
 int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_plane *out);
+int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
+        const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane, halo_dev H);
 
 namespace {
 
@@ -185,10 +189,10 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
         if (whole_slice && !(flags & VEXHIP_SPMAT_NO_MARCH)) {
             const int vb = A->value_type == VEXHIP_F64 ? 8 : 4;
             if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, vb,
-                                                  &A->trav, vexhip_sell8_last_fill_max_col(), &A->march)) return rc2;
+                                                  &A->trav, std::max<int64_t>(vexhip_sell8_last_fill_max_col(), ((flags & VEXHIP_SPMAT_SQUARE) ? A->n : 0) - 1), &A->march)) return rc2;
             if (!(flags & VEXHIP_SPMAT_NO_PLANE) && !std::getenv("VEXHIP_NO_PLANE512"))      // (A/B: the grid product on 512-point lines)
                 if (int rc2 = vexhip_sell8_plane_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, A->pool, nb, A->ell_w, A->n, A->tail, vb,
-                                                      vexhip_sell8_last_fill_max_col(), &A->plane)) return rc2;
+                                                      std::max<int64_t>(vexhip_sell8_last_fill_max_col(), ((flags & VEXHIP_SPMAT_SQUARE) ? A->n : 0) - 1), &A->plane)) return rc2;
         }
         return 0;
     }
@@ -238,6 +242,8 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     VEXHIP_TRY(hipStreamSynchronize(s));
     A->nnz = (int64_t)last;
     trace.mark("entry count");
+    // VEXHIP_SPMAT_SQUARE: x has at least as many elements as the matrix has rows, whatever the largest column that occurs
+    const int64_t min_cols = (flags & VEXHIP_SPMAT_SQUARE) ? n : 0;
 
     // A 7-point pattern on a grid with a handful of distinct values: stored by grid line in ONE pass over the CSR arrays (grid.hip
     // grid_build: no ELL analysis, no table pass, no per-slice codes, no dictionary, no plans from read-backs).  Declined
@@ -251,8 +257,8 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
             A->values = vals;
             int nd = -1, nv = -1; int64_t gw = 0, x_last = -1;
             int rc;
-            if constexpr (p64) rc = grid_build_p64(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid);
-            else rc = grid_build_p32(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid);
+            if constexpr (p64) rc = grid_build_p64(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid, min_cols);
+            else rc = grid_build_p32(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid, min_cols);
             if (rc) return rc;
             trace.mark("grid build");
             if (A->grid.usable) {
@@ -339,7 +345,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
             if (std::is_same<V, double>::value && !A->plane.usable && !tail
                 && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE)))
                 if (int rc = vexhip_sell8_grid_plan(dev, stream, A->deltas, nd, A->blocks ? A->pool : A->sell, A->blocks, w, n, tail, 8,
-                                                    vexhip_sell8_last_fill_max_col(), &A->grid)) return rc;
+                                                    std::max<int64_t>(vexhip_sell8_last_fill_max_col(), min_cols - 1), &A->grid)) return rc;
             trace.mark("grid plan");
         } else {
             if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
@@ -437,6 +443,24 @@ int apply_multi(const spmat *A, void *stream, int k, V alpha, int append, const 
 }
 
 } // namespace
+
+// The stored strip of one rank (its rows, plus an empty ghost plane in front of / behind them where it has a neighbour) as the
+// operand of the one-launch product step (halo.hpp, comm.hip): must be stored for the plane product.  planes / lines_per_plane
+// tell the caller the geometry it has to match (ghost plane = one plane of the stored grid).
+int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane) {
+    const spmat *A = reinterpret_cast<const spmat *>(h);
+    VEXHIP_REQUIRE(A && planes && lines_per_plane, "NULL argument");
+    const bool ok = A->value_type == VEXHIP_F64 && A->format == VEXHIP_SPMAT_SELL8V && (A->blocks || A->direct) && A->plane.usable && !A->tail;
+    *planes = ok ? A->plane.planes : 0; *lines_per_plane = ok ? A->plane.lines_per_plane : 0;
+    return 0;
+}
+int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const double *x, double *y, const halo_dev &H) {
+    const spmat *A = reinterpret_cast<const spmat *>(h);
+    VEXHIP_REQUIRE(A && A->value_type == VEXHIP_F64 && A->format == VEXHIP_SPMAT_SELL8V && (A->blocks || A->direct) && A->plane.usable && !A->tail,
+                   "the one-launch step needs a matrix stored for the plane product");
+    return plane_apply_halo(A->dev, s, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
+                            A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane, H);
+}
 } // namespace vexhip
 
 using namespace vexhip;

@@ -76,6 +76,10 @@ class DistSpMat:
         dev = val.device
         self.dev = dev
 
+        # the strip as it was handed over (GLOBAL columns): transport "halo" stores it once more, ghost planes included
+        # (enable_native); drop_strip() releases the references
+        self._strip = (ptr, col, val)
+        self._ext = None
         # ---- split into local / remote parts (setup; not on the timed path)
         is_loc = (col >= c0) & (col < c1)
         rem_mask = ~is_loc
@@ -177,7 +181,7 @@ class DistSpMat:
 
         def pre():
             nonlocal L
-            if transport not in ("rccl", "ipc"):
+            if transport not in ("rccl", "ipc", "halo"):
                 raise ValueError("unknown transport %r" % (transport,))
             if self.dev.type != "cuda" or not hasattr(self.k, "make_remote"):
                 raise RuntimeError("native step needs the device kernels")
@@ -221,6 +225,48 @@ class DistSpMat:
                     L.dist_spmv_create(comm, dt, self.rows, self.loc.handle if self.loc is not None else None, *rem_args,
                                        self.send_idx.numel(), p(self.send_idx), p(self.send_buf), sc,
                                        self.ghost_buf.numel(), p(self.ghost_buf), rc, ctypes.byref(step))
+                    st["step"] = step
+                if not self._stage(make_step):
+                    self._drop_native(st.get("step"))
+                    return False
+            elif transport == "halo":
+                # ---- the whole step in ONE launch (include/vexhip.h vexhip_dist_spmv_create_halo; csrc/halo.hpp): every remote
+                #      column of this rank lies in the plane below its first row or the plane above its last one, the strip is
+                #      stored as one grid matrix with those two ghost planes, and the plane product reads them from the window
+                def make_ext():
+                    st["halo"] = self._halo_plan()
+                if not self._stage(make_ext):
+                    return False
+                H, lower, upper = st["halo"]
+
+                def make_window():
+                    win = ctypes.c_void_p()
+                    L.ipc_window_create(self.dev.index or 0, self.rank, self.world, 2 * H * 8, ctypes.byref(win))
+                    self._window = win
+                    raw = (ctypes.c_char * 64)()
+                    L.ipc_window_export(win, ctypes.cast(raw, ctypes.c_void_p))
+                    st["handle"] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+                if not self._stage(make_window):
+                    self._drop_native(None)
+                    return False
+                handles = [st["handle"]]
+                geo = [torch.tensor([H, self.rows], dtype=torch.int64)]
+                if self.world > 1:
+                    hs = [torch.empty(64, dtype=torch.uint8, device=cdev) for _ in range(self.world)]
+                    dist.all_gather(hs, st["handle"].to(cdev), group=self.group)
+                    gs = [torch.empty(2, dtype=torch.int64, device=cdev) for _ in range(self.world)]
+                    dist.all_gather(gs, geo[0].to(cdev), group=self.group)
+                    handles, geo = [h.cpu() for h in hs], [g.cpu() for g in gs]
+
+                def make_step():
+                    for peer in (lower, upper):
+                        if peer >= 0 and peer != self.rank:
+                            if int(geo[peer][0]) != H or int(geo[peer][1]) < H:
+                                raise RuntimeError("the neighbours' strips do not have planes of the same size")
+                            hb = (ctypes.c_char * 64).from_buffer_copy(bytes(handles[peer].numpy().tobytes()))
+                            L.ipc_window_open(self._window, peer, ctypes.cast(hb, ctypes.c_void_p))
+                    step = ctypes.c_void_p()
+                    L.dist_spmv_create_halo(self._window, self._ext.handle, self.rows, H, lower, upper, ctypes.byref(step))
                     st["step"] = step
                 if not self._stage(make_step):
                     self._drop_native(st.get("step"))
@@ -273,6 +319,56 @@ class DistSpMat:
         self.native_transport = transport
         return True
 
+    def drop_strip(self):
+        """release the references to the strip the constructor was given (only transport "halo" needs them)"""
+        self._strip = None
+
+    def _halo_plan(self, self_exchange=False):
+        """Transport "halo": (H, lower, upper) and self._ext = the strip stored with its ghost planes, or an exception that says
+        why this matrix / partition does not qualify.  H = elements of a ghost plane; lower / upper = the neighbours (-1: none).
+        self_exchange (one rank, tools/r05_dist_step.py): the rank is its own lower and upper neighbour."""
+        from . import ops
+        if self._strip is None:
+            raise RuntimeError("the strip has been dropped")
+        ptr, col, val = self._strip
+        if val.dtype != torch.float64:
+            raise RuntimeError("transport halo: fp64 only")
+        if self.part != self.col_part:
+            raise RuntimeError("transport halo: rows and columns must be partitioned alike")
+        c0, c1 = self.col_part[self.rank], self.col_part[self.rank + 1]
+        g = self.ghosts
+        below, above = g[g < c0], g[g >= c1]
+        has_lo, has_hi = below.numel() > 0, above.numel() > 0
+        if self_exchange:
+            lower = upper = self.rank
+            has_lo = has_hi = True
+        else:
+            lower = self.rank - 1 if has_lo else -1
+            upper = self.rank + 1 if has_hi else -1
+            owners = [o for o in range(self.world) if self.recv_counts[o]]
+            if any(o not in (lower, upper) for o in owners):
+                raise RuntimeError("transport halo: ghosts come from other ranks than the two neighbours")
+        reach = max(int(c0 - below.min()) if below.numel() else 0, int(above.max()) + 1 - c1 if above.numel() else 0)
+        H = (reach + 1023) // 1024 * 1024
+        if H <= 0 or self.rows % H or H % 1024:
+            raise RuntimeError("transport halo: the strip is not a whole number of planes of %d elements" % H)
+        lo, hi = (H if has_lo else 0), (H if has_hi else 0)
+        dev = val.device
+        last = ptr[-1:].to(torch.int32)
+        ptr_ext = torch.cat([torch.zeros(lo, dtype=torch.int32, device=dev), ptr.to(torch.int32), last.expand(hi)]).contiguous()
+        if self_exchange:
+            col_ext = col.to(torch.int64) + lo               # a one-rank strip already counts from its own first element
+        else:
+            col_ext = col.to(torch.int64) - (c0 - lo)
+        if int(col_ext.min()) < 0 or int(col_ext.max()) >= lo + self.rows + hi:
+            raise RuntimeError("transport halo: a column outside the two ghost planes")
+        ext = ops.SpMat(ptr_ext, col_ext.to(torch.int32).contiguous(), val, n_cols=lo + self.rows + hi)
+        if not getattr(ext, "handle", None) or not getattr(ext, "plane", None):
+            raise RuntimeError("transport halo: the stored strip did not get a plane plan (storage %s)" % getattr(ext, "storage", "?"))
+        ext.ptr = ext.col = ext.val = None
+        self._ext = ext
+        return H, lower, upper
+
     def _drop_native(self, step):
         from . import _capi
         L = _capi.lib()
@@ -302,7 +398,7 @@ class DistSpMat:
             return None
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _capi.lib().dist_spmv_status(self._native, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
-        return {"timed_out": a.value, "transport": {1: "rccl", 3: "ipc"}.get(b.value, b.value), "direct": bool(c.value)}
+        return {"timed_out": a.value, "transport": {1: "rccl", 3: "ipc", 4: "halo"}.get(b.value, b.value), "direct": bool(c.value)}
 
     def rccl_info(self):
         import ctypes

@@ -399,7 +399,8 @@ class SpMat:
         create(
             _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
             _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH)
-            | (0 if plane else _capi.SPMAT_NO_PLANE) | (0 if direct else _capi.SPMAT_NO_GRID_BUILD), ctypes.byref(h))
+            | (0 if plane else _capi.SPMAT_NO_PLANE) | (0 if direct else _capi.SPMAT_NO_GRID_BUILD)
+            | (_capi.SPMAT_SQUARE if self.m >= self.n else 0), ctypes.byref(h))      # x has m >= n elements (vex::SpMat is told n and m: spmat.hpp:56-60)
         self.handle = h
         if _t0 is not None:
             sys.stderr.write("[vexhip set-up] python: create() returned after %.3f ms\n" % ((time.perf_counter() - _t0) * 1e3))
