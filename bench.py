@@ -391,7 +391,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (debug: exercises the N>1 path on a 1-GPU box; needs --backend gloo)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (CSR-bytes kernels, variable coefficients, C++ front end, elementwise, reduce, scan, sort)")
     ap.add_argument("--no-native", action="store_true", help="N > 1: keep the torch.distributed transport (do not try the C++ product step)")
-    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "ipc", "torch"],
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "ipc", "halo", "torch"],
                     help="N > 1 ghost exchange: rccl = grouped ncclSend/ncclRecv issued from C++; ipc = peer-mapped ghost windows "
                          "(hipIpcGetMemHandle); torch = torch.distributed requests; auto = every one that validates, fastest wins")
     ap.add_argument("--trial-steps", type=int, default=100, help="N > 1, --transport auto: products timed per candidate transport")
@@ -584,6 +584,8 @@ def main():
         tried["torch"] = {"valid": ok, "max_abs_err": worst, "what": "torch.distributed batch_isend_irecv (%s), pack and products launched from Python" % args.backend}
         candidates = []
         if not args.no_native and args.transport != "torch":
+            if args.transport in ("auto", "halo"):
+                candidates.append("halo")           # round 5: the whole step in one launch (ghost planes read by the plane product itself)
             if args.transport in ("auto", "ipc"):
                 candidates.append("ipc")
             if args.transport in ("auto", "rccl") and (args.backend == "nccl" or world == 1):
@@ -621,7 +623,10 @@ def main():
         transport = {"torch": "torch.distributed batch_isend_irecv (%s)" % args.backend,
                      "rccl": "vexhip_dist_spmv_apply: pack + grouped ncclSend/ncclRecv + local + remote part issued from C++ (own RCCL communicator)",
                      "ipc": "vexhip_dist_spmv_apply over peer-mapped ghost windows (hipIpcGetMemHandle): owners write their neighbours' shares "
-                            "into the consumers' windows, step-numbered flags, no communicator"}[chosen]
+                            "into the consumers' windows, step-numbered flags, no communicator",
+                     "halo": "vexhip_dist_spmv_apply, ONE product launch per step (vexhip_dist_spmv_create_halo): the strip stored with its two ghost "
+                             "planes, the plane product reads them from the peer-mapped window behind the owners' flags and its first workgroups "
+                             "push the rank's boundary planes; no second stream, no remote part"}[chosen]
     torch.cuda.synchronize()
 
     def barrier():
@@ -816,6 +821,15 @@ def main():
         }
         if setup is not None:
             out["setup"] = setup
+        if world > 1:
+            # north_star's second number: the fraction of HBM peak per GPU and over the N GPUs, by the bytes the ranks' kernels move
+            # (stored matrix + x once + y once per rank; the ghost planes add 2 x 2 MB per rank and product) in the wall time of a step
+            moved_all = world * matrix_bytes + 16 * N
+            out["roofline"]["per_gpu"] = {"bytes_per_step": moved_rank, "achieved": round(moved_rank / per_step / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                          "frac": round(moved_rank / per_step / 1e9 / HBM_PEAK_GBPS, 4), "what": "rank 0's bytes / wall time of a step (max over ranks)"}
+            out["roofline"]["aggregate"] = {"bytes_per_step": moved_all, "achieved": round(moved_all / per_step / 1e9, 1), "peak": HBM_PEAK_GBPS * world,
+                                            "frac": round(moved_all / per_step / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                                            "what": "all ranks' bytes / wall time of a step / (N x 8 TB/s): north_star's >= 0.50 at N = 8"}
         if storage == "sell8v" and (march or plane or grid_plan):
             if plane or grid_plan:
                 # the plane product: per plane step a lane requests tile + 2 pairs of x for tile lines (centre lines + the two halo

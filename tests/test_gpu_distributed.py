@@ -116,3 +116,101 @@ def test_two_ranks_share_one_gpu(world, n, by_line, built_lib):
         p.join(600)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert list(out) == [1] * world
+
+
+def _stencil_strip(torch, nx, ny, nz, r0, r1, dev):
+    """Rows [r0, r1) of the 7-point operator on an nx x ny x nz grid (identity rows on the boundary, as the generator of
+    examples/benchmark.cpp:364-415 writes them), GLOBAL columns, int32 CSR on the device."""
+    r = torch.arange(r0, r1, device=dev, dtype=torch.int64)
+    P = nx * ny
+    ix, iy, iz = r % nx, (r // nx) % ny, r // P
+    inner = (ix > 0) & (ix < nx - 1) & (iy > 0) & (iy < ny - 1) & (iz > 0) & (iz < nz - 1)
+    cnt = torch.where(inner, 7, 1)
+    ptr = torch.zeros(r1 - r0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(cnt, 0, out=ptr[1:])
+    nnz = int(ptr[-1])
+    col = torch.empty(nnz, dtype=torch.int64, device=dev)
+    val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    h2i = float((nx - 1) ** 2)
+    b = ptr[:-1]
+    bi, ri = b[inner], r[inner]
+    for k, (d, v) in enumerate(((-P, -h2i), (-nx, -h2i), (-1, -h2i), (0, 6 * h2i), (1, -h2i), (nx, -h2i), (P, -h2i))):
+        col[bi + k] = ri + d
+        val[bi + k] = v
+    bo, ro = b[~inner], r[~inner]
+    col[bo] = ro
+    val[bo] = 1.0
+    return ptr.to(torch.int32), col.to(torch.int32), val
+
+
+def _halo_worker(rank, world, port, planes_per_rank, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VEXHIP_PLANE_FORCE="1", VEXHIP_IPC_TIMEOUT_MS="20000")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vexcl_amd import ops
+        from vexcl_amd.distributed import DistSpMat, partition
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        nx = ny = 512
+        nz = planes_per_rank * world
+        N = nx * ny * nz
+        part = partition(N, world)
+        r0, r1 = part[rank], part[rank + 1]
+        assert (r1 - r0) == planes_per_rank * nx * ny
+        ptr, col, val = _stencil_strip(torch, nx, ny, nz, r0, r1, dev)
+        A = DistSpMat(ptr, col, val, N, N)
+        # the whole matrix on one "device": the bits the N-rank product must reproduce (the stored strip keeps a row's entries in
+        # column order, ghost columns included -- unlike the split step, which adds the remote entries last)
+        fp, fc, fv = _stencil_strip(torch, nx, ny, nz, 0, N, dev)
+        F = ops.SpMat(fp, fc, fv)
+        fx = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
+        x = fx[r0:r1].clone()
+        ok = A.enable_native(transport="halo")
+        assert ok, A.native_error
+        st = A.native_status()
+        ok = ok and st["transport"] == "halo"
+        y = torch.empty(r1 - r0, dtype=torch.float64, device=dev)
+        fy = torch.empty(N, dtype=torch.float64, device=dev)
+        for k in range(40):                                  # back to back, x changing: flags, ghost planes and step numbers are reused
+            xk = x * (1.0 + k)
+            y.fill_(-3.0)
+            A.apply(xk, y, 1.0, False)
+            if k % 13 == 0:
+                F.apply(fx * (1.0 + k), fy, 1.0, False)
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.equal(y, fy[r0:r1]))
+        # y += alpha A x
+        y.fill_(7.0); fy.fill_(7.0)
+        A.apply(x, y, 1.5, True)
+        F.apply(fx, fy, 1.5, True)
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(y, fy[r0:r1]))
+        ok = ok and A.native_status()["timed_out"] == 0
+        # against the split step over the torch.distributed transport: the same numbers up to the order of a boundary row's sum
+        dist.barrier()
+        A.disable_native()
+        y2 = torch.full((r1 - r0,), 7.0, dtype=torch.float64, device=dev)
+        A.apply(x, y2, 1.5, True)
+        scale = float(fv.abs().max()) * 8
+        ok = ok and bool(((y - y2).abs() <= 1e-12 * scale).all())
+        out[rank] = 1 if ok else 0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,planes", [(2, 8), (3, 8)])
+def test_one_launch_step_reads_ghost_planes_from_the_window(world, planes, built_lib):
+    """Transport "halo" (round 5, csrc/halo.hpp; reference: the five phases of vexcl/spmat.hpp:120-185): every rank stores its strip
+    with the two ghost planes, ONE plane-product launch pushes the boundary planes and reads the neighbours' from the peer-mapped
+    window.  Ranks share the GPU; 512 x 512 x (8 per rank) grid; 40 products back to back.  The result must have the BITS of the
+    one-device product of the whole matrix."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Array("i", [0] * world)
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, planes, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert list(out) == [1] * world
