@@ -28,6 +28,10 @@ extern "C" {
 
 /* ---- errors (backend/cuda/error.hpp:119-156, util.hpp:67-77) ------------ */
 const char *vexhip_last_error(void);
+/* the hipError_t behind the last failure on the calling thread (0: a check of the library's own), so that callers can tell an
+ * allocation that did not fit (VEXHIP_ERROR_OUT_OF_MEMORY) from a fault without parsing the text                              */
+int vexhip_last_error_code(void);
+enum { VEXHIP_ERROR_OUT_OF_MEMORY = 2 };   /* hipErrorOutOfMemory */
 int vexhip_abi_version(void);
 
 /* ---- devices (backend/cuda/context.hpp:96-203,383-413; devlist.hpp) ----- */

@@ -31,11 +31,16 @@ namespace backend {
 // ---- errors (backend/cuda/error.hpp:119-156) --------------------------------
 class error : public std::runtime_error {
     public:
-        explicit error(const std::string &msg) : std::runtime_error(msg) {}
+        explicit error(const std::string &msg, int hip_code = 0) : std::runtime_error(msg), code_(hip_code) {}
+        /// the hipError_t behind the failure (0: a check of the library's own)
+        int code() const { return code_; }
+        bool out_of_memory() const { return code_ == VEXHIP_ERROR_OUT_OF_MEMORY; }
+    private:
+        int code_;
 };
 
 inline void check(int rc) {
-    if (rc != 0) throw error(vexhip_last_error());
+    if (rc != 0) throw error(vexhip_last_error(), vexhip_last_error_code());
 }
 
 inline std::ostream &operator<<(std::ostream &os, const error &e) {

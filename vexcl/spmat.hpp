@@ -148,9 +148,15 @@ class SpMat {
             static_assert(std::is_same<T, val_t>::value, "vector and matrix value types differ");
             precondition(x.size() == ncols && y.size() == nrows, "SpMat::apply: incompatible sizes");
             const unsigned nd = static_cast<unsigned>(queue.size());
-            std::vector<std::array<void *, 4>> ev(nd);
+            struct events {                        // released on every way out (a failing launch throws past the loop below)
+                std::vector<std::array<void *, 4>> e; std::vector<int> dev;
+                ~events() { for (size_t d = 0; d < e.size(); ++d) for (void *x : e[d]) if (x) (void)vexhip_event_destroy(dev[d], x); }
+                std::array<void *, 4> &operator[](size_t d) { return e[d]; }
+            } ev;
+            ev.e.assign(nd, std::array<void *, 4>{{nullptr, nullptr, nullptr, nullptr}});
+            for (unsigned d = 0; d < nd; ++d) ev.dev.push_back(queue[d].device_ordinal());
             for (unsigned d = 0; d < nd; ++d)
-                for (int k = 0; k < 4; ++k) { ev[d][k] = nullptr; backend::check(vexhip_event_create(queue[d].device_ordinal(), 1, &ev[d][k])); }
+                for (int k = 0; k < 4; ++k) backend::check(vexhip_event_create(queue[d].device_ordinal(), 1, &ev[d][k]));
             auto mark = [&](unsigned d, int k) { backend::check(vexhip_event_record(queue[d].device_ordinal(), ev[d][k], queue[d].raw())); };
             const bool exchange = nd > 1 && exc.active();
             for (unsigned d = 0; d < nd; ++d) mark(d, 0);
@@ -172,7 +178,6 @@ class SpMat {
                 backend::check(vexhip_event_sync(dev, ev[d][3]));
                 const int pair[4][2] = {{0, 3}, {0, 1}, {1, 2}, {2, 3}};
                 for (int k = 0; k < 4; ++k) backend::check(vexhip_event_elapsed_ms(dev, ev[d][pair[k][0]], ev[d][pair[k][1]], &ms[d][k]));
-                for (int k = 0; k < 4; ++k) vexhip_event_destroy(dev, ev[d][k]);
             }
         }
 
@@ -409,8 +414,20 @@ class SpMat {
             if (nd <= 1 || std::getenv("VEXCL_SPMAT_SERIAL_SETUP")) { for (unsigned d = 0; d < nd; ++d) f(d); return; }
             std::vector<std::exception_ptr> err(nd);
             std::vector<std::thread> th;
-            for (unsigned d = 0; d < nd; ++d)
-                th.emplace_back([&, d]() { try { f(d); } catch (...) { err[d] = std::current_exception(); } });
+            th.reserve(nd);
+            struct joiner {                        // a thread that could not be started (resource limit) must not leave joinable ones behind: std::terminate
+                std::vector<std::thread> &t;
+                ~joiner() { for (auto &x : t) if (x.joinable()) x.join(); }
+            } join_all{th};
+            unsigned started = 0;
+            try {
+                for (; started < nd; ++started) {
+                    const unsigned d = started;
+                    th.emplace_back([&, d]() { try { f(d); } catch (...) { err[d] = std::current_exception(); } });
+                }
+            } catch (...) {
+                for (unsigned d = started; d < nd; ++d) { try { f(d); } catch (...) { err[d] = std::current_exception(); } }     // the rest on this thread
+            }
             for (auto &t : th) t.join();
             for (unsigned d = 0; d < nd; ++d) if (err[d]) std::rethrow_exception(err[d]);
         }

@@ -54,8 +54,7 @@ struct SpMatCCSR {
         catch (const backend::error &e) {
             // only an allocation that did not fit keeps the CCSR kernel (it needs none of that memory); anything else -- a sticky
             // device fault, a bad argument -- must not disappear here
-            const std::string what = e.what();
-            if (what.find("OutOfMemory") == std::string::npos && what.find("out of memory") == std::string::npos) throw;
+            if (!e.out_of_memory()) throw;                 // the hipError_t of the failure (vexhip_last_error_code), not a search in its text
             fast.reset();
         }
     }

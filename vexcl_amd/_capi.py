@@ -99,6 +99,7 @@ SPMAT_NAMES = {SPMAT_SELL8V: "sell8v", SPMAT_SELL8: "sell8", SPMAT_SELL: "sell32
 # name -> (restype, argtypes); restype None means "int status, checked"
 _PROTOS = {
     "vexhip_last_error": (ctypes.c_char_p, []),
+    "vexhip_last_error_code": (ctypes.c_int, []),
     "vexhip_abi_version": (c_int, []),
     "vexhip_device_count": (None, [ctypes.POINTER(c_int)]),
     "vexhip_device_get_props": (None, [c_int, ctypes.POINTER(DeviceProps)]),

@@ -394,7 +394,7 @@ int issue_step_ipc(dist_spmv *D, hipStream_t s, double alpha, int append, const 
     PROF(1, s);
     if (D->nown) {
         ipc_wait_kernel<<<1, 64, 0, s>>>(D->d_arrive, D->nown, step, D->d_err, ticks, static_cast<unsigned long long *>(D->ghost_buf),
-                                         (long long)(D->nghost * (int64_t)type_bytes(D->dtype) / 8));
+                                         (long long)((D->nghost * (int64_t)type_bytes(D->dtype) + 7) / 8));      // rounded UP: an odd number of fp32 ghosts ends half-way into a word (the window is padded)
         VEXHIP_LAUNCH_CHECK();
     }
     PROF(2, s);

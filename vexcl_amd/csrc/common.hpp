@@ -14,12 +14,15 @@ namespace vexhip {
 // Thread-local last-error text, in the reference's "file:line\n\t<code text>"
 // shape (backend/cuda/error.hpp:119-145).
 std::string &last_error();
+int &last_error_code();          // the hipError_t behind the last failure on this thread (0: none of HIP's -- a check of the library's own)
 int fail(const char *file, int line, const std::string &what);
 
 inline int check(hipError_t e, const char *file, int line) {
     if (e == hipSuccess) return 0;
     (void)hipGetLastError();      // HIP's last-error slot is sticky: clear it so a later launch check does not report this failure again
-    return fail(file, line, std::string(hipGetErrorName(e)) + ": " + hipGetErrorString(e));
+    const int rc = fail(file, line, std::string(hipGetErrorName(e)) + ": " + hipGetErrorString(e));
+    last_error_code() = (int)e;
+    return rc;
 }
 
 constexpr int kWave = 64;   // gfx950 wavefront

@@ -26,6 +26,7 @@
 // The 512-point kernel stays the default where it applies (the headline): same walk, fewer scalar operands.
 // Compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "lanes.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -38,9 +39,6 @@ namespace {
 
 constexpr unsigned GR_PAD_FIRST = 254;      // codes 254 / 255 are padding (sell8.hip)
 constexpr int GR_ABSENT = 255;              // table byte of a position without an entry (value codes are < 255)
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 struct grid_dev {
     long long lines;         // grid lines of the matrix: rows / nx
@@ -59,26 +57,6 @@ struct codes_dev {           // where the value-coded slices are (sell8.hip: cei
     signed char pos[8];      // diagonal code -> position 0..6
 };
 
-__device__ __forceinline__ double shift_from_lower_lane(double v, double edge) {       // lane i <- lane i - 1, lane 0 <- edge
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);   // wave_shr:1
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double shift_from_upper_lane(double v, double edge) {       // lane i <- lane i + 1, lane 63 <- edge
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);   // wave_shl:1
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// v for the lanes of `lanes`, elsewhere a number whose exponent field is 0: (+0.0) * that == +0.0 whatever x holds there
-__device__ __forceinline__ double keep_lanes(double v, unsigned long long lanes) {
-    unsigned rhi;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"((unsigned)__double2hiint(v)), "s"(lanes));
-    return __hiloint2double((int)rhi, __double2loint(v));
-}
-__device__ __forceinline__ double keep_bit(double v, unsigned bits, int pos) {
-    const int m = (int)(bits << (31 - pos)) >> 31;                // -1 where the bit is set
-    return __hiloint2double(__double2hiint(v) & m, __double2loint(v));
-}
 
 // ---- set-up: a row's codes -> seven bytes (value code per position, 255 = no entry); false: not a matrix for this product ----
 __device__ __forceinline__ bool row_signature(const codes_dev &cd, long long i, unsigned char (&sig)[7]) {
@@ -274,8 +252,11 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
 #pragma unroll
         for (int u = 0; u < 3; ++u) { const int i = t + 256 * u; my_ptr[u] = i <= rows ? (long long)ptr[row_l + r0 + i] : 0; }
 
-        if (pc == 0 && __hip_atomic_load(&g.ints[GBI_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;       // uniform: another workgroup gave up
+        // another workgroup gave up?  ONE lane looks and the workgroup leaves together (every lane loading the flag for itself could
+        // split the workgroup: lanes that leave while the others wait at the barrier below and go on with a stale s_red)
+        if (pc == 0 && t == 0) s_red[7] = __hip_atomic_load(&g.ints[GBI_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1ull : 0ull;
         __syncthreads();                                        // the previous trip is done with the staged entries and with the line's rows (compared / copied)
+        if (pc == 0 && s_red[7]) return;                        // uniform
         if (pc == 0) {
             for (int i = t; i < 7 * g.pitch; i += 256) s_sig[i] = GR_ABSENT;       // (the rows below write into it behind the next barrier)
             hsum = 0; bad = false;

@@ -12,6 +12,12 @@
 #pragma once
 #include "common.hpp"
 
+// The flag hand-offs of comm.hip and plane.hip wait for a wave's STORES with `s_waitcnt vmcnt(0)`: on the gfx9 family (gfx90a,
+// gfx942, gfx950) vmcnt counts loads and stores alike; gfx10 and later count stores in vscnt and would need `s_waitcnt_vscnt`.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "libvexhip's inter-GPU flag protocol waits for stores with s_waitcnt vmcnt(0): gfx9-family targets only (ARCH in csrc/Makefile)"
+#endif
+
 namespace vexhip {
 
 struct halo_dev {

@@ -25,6 +25,7 @@
 // within a row (so that position order IS storage order) -- and declines otherwise; the march and pair products remain.
 // Compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "lanes.hpp"
 #include "halo.hpp"
 
 #include <algorithm>
@@ -37,8 +38,6 @@ namespace {
 
 constexpr int PL_ROWS = 512;
 constexpr unsigned PL_PAD_FIRST = 254;      // codes 254 / 255 are padding (sell8.hip)
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 struct plane_dev {
     long long nslices;       // 512-row lines of the matrix
@@ -55,27 +54,6 @@ struct plane_dev {
     int pitch;               // 0: `pool` holds SELL-512 code blocks; > 0: class tables of the grid storage ([class][7 positions][pitch] value codes, grid.hip)
 };
 
-__device__ __forceinline__ double shift_from_lower_lane(double v, double edge) {       // lane i <- lane i - 1, lane 0 <- edge
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);   // wave_shr:1
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double shift_from_upper_lane(double v, double edge) {       // lane i <- lane i + 1, lane 63 <- edge
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);   // wave_shl:1
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// v for the lanes of `lanes`, elsewhere a number whose exponent field is 0: (+0.0) * that == +0.0 whatever x holds there
-// (the matrix value of a position without an entry is +0.0; x may hold Inf / NaN where CSR would never look)
-__device__ __forceinline__ double keep_lanes(double v, unsigned long long lanes) {
-    unsigned rhi;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(rhi) : "v"((unsigned)__double2hiint(v)), "s"(lanes));
-    return __hiloint2double((int)rhi, __double2loint(v));
-}
-__device__ __forceinline__ double keep_bit(double v, unsigned bits, int pos) {
-    const int m = (int)(bits << (31 - pos)) >> 31;                // -1 where the bit is set
-    return __hiloint2double(__double2hiint(v) & m, __double2loint(v));
-}
 
 // diagonal -> position 0..6 in {-far, -512, -1, 0, 1, 512, far} (the plan has checked that it is one of them)
 __device__ __forceinline__ int position_of(int d, int far) {

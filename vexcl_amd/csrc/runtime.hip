@@ -24,10 +24,16 @@ std::string &last_error() {
     return s;
 }
 
+int &last_error_code() {
+    static thread_local int c = 0;
+    return c;
+}
+
 int fail(const char *file, int line, const std::string &what) {
     std::ostringstream o;
     o << file << ":" << line << "\n\t" << what;
     last_error() = o.str();
+    last_error_code() = 0;                     // a failure of the library's own checks; check() below overwrites it for a HIP error
     return 1;
 }
 
@@ -61,6 +67,10 @@ const device_info &info(int dev) {
             // HIP sets up its staging path for pageable host memory at the first copy that needs it: 6.7 ms for a 32 KiB
             // read-back, measured inside the first matrix set-up of a process (VEXHIP_SETUP_TRACE).  Pay it here, when the
             // library first meets the device (context creation), not in the first set-up.
+            // (if the calling thread is capturing a stream into a hipGraph -- a step object meeting a device for the first time
+            //  inside a capture -- the synchronous calls below must not invalidate that capture: relaxed mode for their duration)
+            hipStreamCaptureMode cmode = hipStreamCaptureModeRelaxed;
+            const bool swapped = hipThreadExchangeStreamCaptureMode(&cmode) == hipSuccess;
             int cur = -1;
             if (hipGetDevice(&cur) == hipSuccess && hipSetDevice(dev) == hipSuccess) {
                 void *d = nullptr;
@@ -76,6 +86,7 @@ const device_info &info(int dev) {
                 (void)hipGetLastError();
                 (void)hipSetDevice(cur);
             }
+            if (swapped) (void)hipThreadExchangeStreamCaptureMode(&cmode);
         } else {
             cache[dev].cus = 256;
         }
@@ -159,6 +170,7 @@ int rtc_fail(const char *file, int line, hiprtcResult r, const std::string &log)
 extern "C" {
 
 const char *vexhip_last_error(void) { return last_error().c_str(); }
+int vexhip_last_error_code(void) { return last_error_code(); }
 int vexhip_abi_version(void) { return VEXHIP_ABI_VERSION; }
 
 // ---------------------------------------------------------------- devices
