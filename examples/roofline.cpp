@@ -2,7 +2,7 @@
 // HIP events on the compute queue:  C2 elementwise a = b*c + sin(d) (n = 1e8),
 // reduce sum(a*b) (n = 2^24 and 1e8), inclusive scan and sort of 1e9 uint32
 // keys.  Prints one JSON object per row: algorithmic GB/s and fraction of 8 TB/s.
-// Usage: roofline [n_big = 1e9] [sections = "escpk"]   (e elementwise + reduce, s stencil, c SpMatCCSR,
+// Usage: roofline [n_big = 1e9] [sections = "escpk"]   (e elementwise + reduce, s stencil, c SpMatCCSR, i inline SpMV terminals at 512^3,
 // p scan + sort, k by-key primitives); bench.py runs section "e" for its elementwise / reduce rows, so that
 // those rows come from the kernels the expression engine itself generates.
 #include <algorithm>
@@ -113,6 +113,61 @@ int main(int argc, char **argv) {
                (double)N, own ? 20 : 16, ms, ", \"equiv_csr_gflops\": 0");
         std::printf("{\"row\": \"SpMatCCSR vs CSR-algorithmic\", \"gflops\": %.1f, \"csr_equiv_gbps\": %.1f}\n",
                 2.0 * 930123728.0 / ms / 1e6, 13845839300.0 / ms / 1e6);
+    }
+    if (on('i')) {   // SpMV fused INTO an expression kernel (spmat/inline_spmv.hpp:142-198, sparse/ell.hpp:207-267) at 512^3
+        const long long n = 512;
+        const size_t N = (size_t)(n * n * n), nnz = (size_t)vexhip_poisson3d_nnz(n);
+        const int dev = q.device_ordinal();
+        std::vector<vex::command_queue> q1(1, q);
+        for (int variable = 0; variable < 2; ++variable) {
+            vex::SpMat<double, int, int> A;
+            {
+                vex::backend::device_vector<int> ptr(q, N + 1), col(q, nnz);
+                vex::backend::device_vector<double> val(q, nnz);
+                if (variable) vex::backend::check(vexhip_diffusion3d_strip_f64_i32(dev, q.raw(), n, 0, (int64_t)N, 7, ptr.raw(), col.raw(), val.raw()));
+                else vex::backend::check(vexhip_poisson3d_csr_f64_i32(dev, q.raw(), n, ptr.raw(), col.raw(), val.raw()));
+                A = vex::SpMat<double, int, int>(q1, N, N, nnz, ptr, col, val);
+            }
+            vex::vector<double> x(q1, N), y(q1, N);
+            vex::backend::check(vexhip_fill_hash(dev, q.raw(), VEXHIP_F64, 42, x(0).raw(), (int64_t)N));
+            const vexhip_spmat_info &info = A.storage_info();
+            const double moved = (double)info.matrix_bytes + 16.0 * N;            // stored matrix + x once + y once: what a product kernel moves
+            char extra[512];
+            // the product as its own kernel, then the same product as a terminal of a generated kernel (one row per lane, entries
+            // looked up in the stored form -- class tables, code blocks or columns -- by the generated device function)
+            warm(t, [&] { y = A * x; });
+            t.start(); for (int i = 0; i < reps; ++i) y = A * x; double ms = t.stop_ms() / reps;
+            std::snprintf(extra, sizeof extra, ", \"kernel\": \"%s\", \"gflops\": %.1f", info.plane.usable ? "sell8_plane_kernel" : "sell8_pair_kernel", 2.0 * nnz / ms / 1e6);
+            report(variable ? "SpMat y = A*x, variable-coefficient 512^3 (library product)" : "SpMat y = A*x, Poisson 512^3 (library product)", 1.0, moved, ms, extra);
+            warm(t, [&] { y = x + 2 * vex::make_inline(A * x); });
+            t.start(); for (int i = 0; i < reps; ++i) y = x + 2 * vex::make_inline(A * x); ms = t.stop_ms() / reps;
+            std::snprintf(extra, sizeof extra, ", \"kernel\": \"vexcl_vector_kernel (hiprtc; the product is a __device__ function of the expression, one row per lane)\", \"gflops\": %.1f", 2.0 * nnz / ms / 1e6);
+            report(variable ? "y = x + 2 * make_inline(A*x), variable-coefficient 512^3 (SpMV inside the expression kernel)"
+                            : "y = x + 2 * make_inline(A*x), Poisson 512^3 (SpMV inside the expression kernel)", 1.0, moved, ms, extra);
+        }
+    }
+    if (on('i')) {   // sparse::ell (sparse/ell.hpp:207-267): its product IS an inline terminal of the expression kernel; built from host arrays, 256^3
+        const size_t g = 256, N = g * g * g;
+        std::vector<int> row(1, 0), col; std::vector<double> val;
+        col.reserve(7 * N); val.reserve(7 * N); row.reserve(N + 1);
+        const double h2i = (g - 1.0) * (g - 1.0);
+        for (size_t k = 0, p = 0; k < g; ++k) for (size_t j = 0; j < g; ++j) for (size_t i = 0; i < g; ++i, ++p) {
+            if (i == 0 || i == g - 1 || j == 0 || j == g - 1 || k == 0 || k == g - 1) { col.push_back((int)p); val.push_back(1.0); }
+            else {
+                const long off[7] = {-(long)(g * g), -(long)g, -1, 0, 1, (long)g, (long)(g * g)};
+                for (int e = 0; e < 7; ++e) { col.push_back((int)((long)p + off[e])); val.push_back(e == 3 ? 6 * h2i : -h2i); }
+            }
+            row.push_back((int)col.size());
+        }
+        std::vector<vex::command_queue> q1(1, q);
+        vex::sparse::ell<double> E(q1, N, N, row, col, val);
+        vex::vector<double> x(q1, N), y(q1, N);
+        x = 1e-2 + 1e-9 * vex::element_index();
+        warm(t, [&] { y = E * x; });
+        t.start(); for (int i = 0; i < reps; ++i) y = E * x; const double ms = t.stop_ms() / reps;
+        char extra[256];
+        std::snprintf(extra, sizeof extra, ", \"kernel\": \"vexcl_vector_kernel (hiprtc; ELL columns + values read by the generated device function)\", \"gflops\": %.1f", 2.0 * col.size() / ms / 1e6);
+        report("y = E * x, sparse::ell<double> Poisson 256^3 (inline terminal; ELL width 7: 12 B per slot + x + y)", (double)N, 7 * 12 + 16, ms, extra);
     }
     if (on('p')) {   // C5 scan
         const size_t n = big;
