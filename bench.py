@@ -272,6 +272,36 @@ def unstructured_rows(torch, ops, dev, args):
     y = torch.empty(m, dtype=torch.float64, device=dev)
     what = {"random16": "16 entries per row, columns uniform in [0, n), sorted (the shape of tests/random_matrix.hpp)",
             "powerlaw": "row lengths floor(6 / sqrt(u)) capped at 4096 (mean ~12), columns uniform, sorted"}
+    # ---- round 5: a structured operator in TWO dimensions (5-point, 16384^2): walked along virtual 512-point lines by the plane product
+    try:
+        W = H = int(os.environ.get("BENCH_2D_SIDE", "16384"))
+        ptr, col, val, h2i = U.stencil2d(W, H, dev)
+        n2, nnz2 = W * H, int(col.numel())
+        x2 = ops.fill_hash(torch.empty(n2, dtype=torch.float64, device=dev), 42)
+        y2 = torch.empty_like(x2)
+        A = ops.SpMat(ptr, col, val)
+        del ptr, col, val
+        A.ptr = A.col = A.val = None
+        torch.cuda.empty_cache()
+        A.apply(x2, y2)
+        yr, mag = U.stencil2d_reference(x2, W, H, h2i)
+        bad = int(((y2 - yr).abs() > 1e-10 * mag).sum())
+        assert bad == 0, "2-D 5-point: %d rows outside 1e-10 * sum|terms|" % bad
+        del yr, mag
+        t = min(timed_events(torch, lambda: A.apply(x2, y2), 20) for _ in range(3))
+        moved = A.matrix_bytes() + 16 * n2
+        rows["SpMV 5-point 2-D %d^2 (y = A*x, default vexhip_spmat)" % W] = {
+            "rows": n2, "nnz": nnz2, "storage": A.storage, "plane_plan": A.plane, "grid_plan": A.grid, "ms": round(t, 5), "gflops": round(2.0 * nnz2 / t / 1e6, 1),
+            "rows_outside_tolerance": bad,
+            "roofline": {"bound": "hbm", "bytes_per_launch": moved, "achieved": round(moved / t / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(moved / t / 1e6 / HBM_PEAK_GBPS, 4), "what": "stored matrix (class tables + 4 B per virtual line) + x once + y once"}}
+        del A, x2, y2
+        torch.cuda.empty_cache()
+    except AssertionError:
+        raise
+    except Exception as e:  # noqa: BLE001 -- a secondary row
+        rows["SpMV 5-point 2-D"] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
     for name in ("random16", "powerlaw"):
         try:
             ptr, col, val = U.MAKERS[name](m, dev)

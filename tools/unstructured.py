@@ -51,3 +51,41 @@ MAKERS = {"random16": random16, "powerlaw": powerlaw}
 # kernels a product of such a matrix may launch (the ELL part, the CSR arrays); names as rocprofv3 prints them
 PRODUCT_KERNELS = ("sell_kernel", "sell_pair_kernel", "sell8_pair_kernel", "hell_kernel", "csr_stream2_kernel", "csr_stream_kernel",
                    "csr_scalar_kernel", "csr_rows_kernel", "sellu_kernel")
+
+
+def stencil2d(W, H, dev):
+    """The benchmark's operator (examples/benchmark.cpp:364-415) in TWO dimensions: 5-point Laplacian on a W x H grid, identity rows
+    on the boundary; int32 CSR on the device.  -> (ptr, col, val, h2i)"""
+    N = W * H
+    r = torch.arange(N, device=dev, dtype=torch.int32)
+    ix, iy = r % W, r // W
+    inner = (ix > 0) & (ix < W - 1) & (iy > 0) & (iy < H - 1)
+    del ix, iy
+    ptr64 = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.where(inner, 5, 1), 0, out=ptr64[1:])
+    nnz = int(ptr64[-1])
+    assert nnz < 2 ** 31
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    h2i = float((W - 1) ** 2)
+    b = ptr64[:-1]
+    bi, ri = b[inner], r[inner]
+    for k, (d, v) in enumerate(((-W, -h2i), (-1, -h2i), (0, 4 * h2i), (1, -h2i), (W, -h2i))):
+        col[bi + k] = ri + d
+        val[bi + k] = v
+    del bi, ri
+    bo, ro = b[~inner], r[~inner]
+    col[bo] = ro
+    val[bo] = 1.0
+    return ptr64.to(torch.int32), col, val, h2i
+
+
+def stencil2d_reference(x, W, H, h2i):
+    """(y, sum |terms| per row) of that operator without a matrix: torch slicing on the grid."""
+    X = x.view(H, W)
+    y = X.clone(); mag = X.abs().clone()
+    c = X[1:-1, 1:-1]
+    nb = X[:-2, 1:-1], X[1:-1, :-2], X[1:-1, 2:], X[2:, 1:-1]
+    y[1:-1, 1:-1] = h2i * (4 * c) - h2i * (nb[0] + nb[1] + nb[2] + nb[3])
+    mag[1:-1, 1:-1] = h2i * (4 * c.abs() + nb[0].abs() + nb[1].abs() + nb[2].abs() + nb[3].abs())
+    return y.view(-1), mag.view(-1)

@@ -787,6 +787,21 @@ bool grid_diagonals(const std::vector<int> &table, long long rows, long long *nx
     std::vector<long long> mags;
     for (int d : table) { const long long a = std::llabs((long long)d); if (a && std::find(mags.begin(), mags.end(), a) == mags.end()) mags.push_back(a); }
     std::sort(mags.begin(), mags.end());
+    if (mags.size() == 2 && mags[0] == 1) {
+        // Round 5 -- a 5-point operator on a 2-D grid (or any band matrix {0, +-1, +-W}): no line-above / line-below pair.  Its rows
+        // of W points are cut into VIRTUAL lines of nx points (W / nx of them make a "plane"), so that +-W is the far pair of the
+        // walk and positions +-nx simply never occur; the +-1 entries that join two virtual lines of one row are ordinary entries of
+        // the class tables (all x addressing is linear).  The reference's SpMatCCSR has no notion of dimension either
+        // (spmat/ccsr.hpp:55-113).  512-point lines where they fit (the plane product), else the largest divisor of W up to 1024.
+        const long long W = mags[1];
+        if (W < 16 || rows % W != 0 || W > (1ll << 30)) return false;
+        long long nx = 0;
+        if (W % 512 == 0 && (W / 512) % 2 == 0 && W / 512 >= 4) nx = 512;
+        else for (long long d = std::min<long long>(1024, W / 2); d >= 8; --d) if (W % d == 0) { nx = d; break; }
+        if (nx < 8) return false;
+        *nx_out = nx; *far_out = W;
+        return true;
+    }
     if (mags.size() != 3 || mags[0] != 1) return false;
     const long long nx = mags[1], far = mags[2];
     if (nx < 8 || far % nx != 0 || far / nx < 2 || rows % nx != 0 || far > (1ll << 30)) return false;
