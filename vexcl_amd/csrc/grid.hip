@@ -792,12 +792,15 @@ bool grid_diagonals(const std::vector<int> &table, long long rows, long long *nx
         // of W points are cut into VIRTUAL lines of nx points (W / nx of them make a "plane"), so that +-W is the far pair of the
         // walk and positions +-nx simply never occur; the +-1 entries that join two virtual lines of one row are ordinary entries of
         // the class tables (all x addressing is linear).  The reference's SpMatCCSR has no notion of dimension either
-        // (spmat/ccsr.hpp:55-113).  512-point lines where they fit (the plane product), else the largest divisor of W up to 1024.
+        // (spmat/ccsr.hpp:55-113).  Taken where 512-point lines fit (an even number of them, four or more): the plane product.
         const long long W = mags[1];
         if (W < 16 || rows % W != 0 || W > (1ll << 30)) return false;
         long long nx = 0;
         if (W % 512 == 0 && (W / 512) % 2 == 0 && W / 512 >= 4) nx = 512;
-        else for (long long d = std::min<long long>(1024, W / 2); d >= 8; --d) if (W % d == 0) { nx = d; break; }
+        // (other row lengths walked along a divisor of W -- 10000^2 as 20 lines of 500 points, 12000 x 9000, 7000 x 20000 -- ran level
+        //  with the pair product of the SELL-512 storage or behind it, 0.528 / 0.462 / 0.656 ms against 0.493 / 0.467 / 0.678: few
+        //  lines per "plane", and the walk still requests the line above and below, which a 2-D operator never uses.  They keep the
+        //  pair product; tools/r05_2d.py, profiles/r05_2d.json)
         if (nx < 8) return false;
         *nx_out = nx; *far_out = W;
         return true;
