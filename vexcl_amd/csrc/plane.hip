@@ -433,7 +433,12 @@ static bool plane_geometry(int dev, long long ny, long long nz, int hot, vexhip_
     const long long cus = std::max(1, info(dev).cus);
     auto depth_for = [&](long long tl) {
         const long long tiles = ny / tl;
-        const long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
+        long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
+        // SHORT walks (a rank's strip of a partitioned grid: 64 planes at 512^3 / 8) want two workgroups per CU: the start and the
+        // end of a walk -- four planes requested before the first row is stored, the last planes clamped -- are a tenth of a
+        // 64-plane walk and overlap with the other workgroup's steady state: 56.6 -> 47.0 us for 16.8 M rows (depth 22 / 16 / 11:
+        // 50.0 / 50.8 / 52.4; tools/r05_dist_step.py, "local part alone").  Long walks lose 2 % that way (512 planes, round 4).
+        if (chunks == 1 && nz >= 32 && nz <= 192 && tiles * 2 <= 2 * cus) chunks = 2;
         return (nz + chunks - 1) / chunks;
     };
     long long tile = 2;
@@ -499,6 +504,7 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
     H.lo_planes = H.lo ? std::min(edge_planes, nzr) : 0;
     H.hi_planes = H.hi ? std::min(edge_planes, nzr - H.lo_planes) : 0;
     const int mid = nzr - H.lo_planes - H.hi_planes;
+    pd.depth = std::max(1, mid);          // ONE main chunk (two of 25 planes beside the short chunks: 88-90 us against 76 for the step)
     if (const char *e = std::getenv("VEXHIP_HALO_DEPTH")) pd.depth = std::max(1, std::atoi(e));
     const long long chunks = (H.lo_planes ? 1 : 0) + (H.hi_planes ? 1 : 0) + (mid + pd.depth - 1) / pd.depth;
     const long long npush = (H.dst_lo ? H.push_blocks : 0) + (H.dst_hi ? H.push_blocks : 0);
