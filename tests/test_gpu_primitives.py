@@ -135,12 +135,13 @@ def test_sort_by_key_is_stable(T, oracle, n):
     assert np.array_equal(di.cpu().numpy(), np.argsort(k, kind="stable"))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 1, 3, 4, 5, 6])
 def test_sort_rank_schemes_give_the_stable_permutation(T, oracle, mode):
     """Every ranking scheme of the scatter kernels -- match words (0); round 4's returning counter atomic with one verified
     tile in 16 (1); the lean scatter of round 5 with unchecked counter atomics (3, A/B only), counter atomics checked by the
-    order words of the same wave round (4), ranks TAKEN from the order words, every key of every tile checked (5, the
-    default) -- must produce std::stable_sort's permutation (sort.cpp:22-45), for few and for many distinct keys, keys whose
+    order words of the same wave round (4), ranks TAKEN from the order words, every key of every tile checked (5), and the
+    default (6): half-wave units whose 64-bit counter words return the rank AND the lanes served before, one returning atomic
+    per key -- must produce std::stable_sort's permutation (sort.cpp:22-45), for few and for many distinct keys, keys whose
     upper digits are constant (tiles copied as blocks), ragged sizes, 4- and 8-byte keys and payloads."""
     from vexcl_amd import lib
     L = lib()

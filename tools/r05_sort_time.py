@@ -1,4 +1,5 @@
-"""1e9 u32 keys: vexhip_sort per rank scheme.  -1 default (= 5); 5 lean scatter, ranks taken from the order words (every key of every
+"""1e9 u32 keys: vexhip_sort per rank scheme.  -1 default (= 6: half-wave units, one returning 64-bit atomic per key that proves its own
+order); 5 lean scatter, ranks taken from the order words (every key of every
 tile checked); 4 lean, counter atomics checked by the order words; 3 lean, unchecked counter atomics (A/B only); 1 round 4's
 kernel (counter atomics, one verified tile in 16); 0 match words.  Every scheme must give the bits of the first.  Also: keys whose
 two upper digits are constant (tiles copied as blocks), and sort_by_key u32 -> u32 at 2.5e8.
@@ -9,7 +10,7 @@ import torch
 from vexcl_amd import ops, lib
 dev = torch.device("cuda:0"); L = lib()
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10 ** 9
-modes = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 5, 4, 3, 1, 0]
+modes = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 6, 5, 4, 3, 1, 0]
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 k = torch.empty(n, dtype=torch.int32, device=dev); ktmp = torch.empty_like(k)
 tmp = torch.empty(L.sort_tmp_bytes(3, n), dtype=torch.uint8, device=dev)

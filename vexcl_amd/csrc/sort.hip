@@ -570,6 +570,180 @@ void radix_scatter_lean_kernel(const K *__restrict__ keys_in, K *__restrict__ ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5, the default: ranks from ONE returning LDS atomic per key whose own return proves the order it was served in.
+// A ranking UNIT is a half wave (32 lanes); its counter of digit d is a 64-bit word [ keys so far : 32 | lane bits : 32 ].  A lane
+// adds (1 << 32) | (1 << (lane & 31)): the word it gets back holds, in its upper half, the number of the unit's keys with this digit
+// that were counted before it -- earlier rounds AND the lanes of this round that were served first -- and in its lower half the
+// bits of exactly those lanes of this round.  A lane that finds the bit of a HIGHER lane there was served out of lane order:
+// trap.  If no lane does, the upper half IS the stable rank (of two lanes a < b with one digit, b first would show b's bit to a).
+// A second, non-returning atomic takes the lane's bit out again.  Two LDS operations per key -- round 4's unchecked rank took
+// one, the forms above three (CHECK 1) and four (CHECK 2) -- and nothing is assumed about any instruction but the one that
+// delivers the rank.  768 lanes x 16 keys (4-byte keys): 24 units x 256 words = 48 KiB, which the re-ordered tile then reuses;
+// the units' tile offsets live on as 16-bit numbers (12 KiB): two workgroups per CU.
+constexpr int UB = 768, UW = UB / kWave, UU = 2 * UW;
+template <typename K, int VB> constexpr int unit_kpt() { return keys_per_lane((int)sizeof(K), VB) * RB / UB; }
+template <typename K, int VB> constexpr bool unit_ok() { return keys_per_lane((int)sizeof(K), VB) * RB % UB == 0; }
+
+template <typename K, int VB, int KPT>
+struct unit_lds {
+    static constexpr int TILE = UB * KPT;
+    static constexpr int TILE_BYTES = TILE * ((int)sizeof(K) + VB);
+    static constexpr int WORD_BYTES = UU * RADIX * 8;
+    static constexpr int RAW_WORDS = ((TILE_BYTES > WORD_BYTES ? TILE_BYTES : WORD_BYTES) + 15) / 16 * 2;
+    unsigned long long raw[RAW_WORDS];      // the units' counter words while the keys are ranked, then the re-ordered tile
+    unsigned short off[UU][RADIX];          // tile position of a unit's first key of a digit
+    unsigned gbase[RADIX];
+    unsigned dstart[RADIX];
+    unsigned wtot[RADIX / kWave];
+    int uni;
+};
+
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool WIDE>
+__global__ __launch_bounds__(UB, 6)
+void radix_scatter_unit_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+        const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
+        long long n, int shift, unsigned nblocks, unsigned nfull, const unsigned *__restrict__ table)
+{
+    typedef typename valtype<VB>::type VT;
+    constexpr int TILE = UB * KPT;
+    static_assert(TILE == RB * keys_per_lane((int)sizeof(K), VB), "the tile of the histogram kernel");
+    __shared__ __attribute__((aligned(16))) unit_lds<K, VB, KPT> L;
+    const VT *__restrict__ vals_in = reinterpret_cast<const VT *>(vals_in_);
+    VT *__restrict__ vals_out = reinterpret_cast<VT *>(vals_out_);
+    K *s_keys = reinterpret_cast<K *>(L.raw);
+    VT *s_vals = reinterpret_cast<VT *>(reinterpret_cast<char *>(L.raw) + (size_t)TILE * sizeof(K));
+    unsigned long long *s_word = L.raw;
+
+    const unsigned per = (nfull + 7) / 8;                       // XCD-contiguous tile order (radix_scatter_kernel)
+    const unsigned tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (tile >= nfull) return;
+
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+    // a UNIT's keys are consecutive in the tile (32 * KPT of them, round k = the next 32): the units' keys then follow each other
+    // in tile order, which is what a stable pass ranks by.  (A wave's load covers two 128-byte pieces 32 * KPT elements apart.)
+    const int unit = 2 * wave + (lane >> 5);
+    const int upos = unit * (32 * KPT) + (lane & 31);           // tile position of the lane's first key
+    const long long ubase = (long long)tile * TILE + upos;
+
+    K key[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) key[k] = __builtin_nontemporal_load(keys_in + ubase + k * 32);
+    VT val[VB ? KPT : 1];
+    if constexpr (VB != 0) {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) val[k] = __builtin_nontemporal_load(vals_in + ubase + k * 32);
+    }
+    unsigned b0 = 0, cnt = 0;                                   // the tile's count and global base of digit t, from the scanned table
+    if (t < RADIX) {
+        const size_t idx = (size_t)t * nblocks + tile;
+        b0 = table[idx];
+        const unsigned b1 = (idx + 1 < (size_t)RADIX * nblocks) ? table[idx + 1] : (unsigned)n;
+        cnt = b1 - b0;
+    }
+    {   // zero the counter words: UU * 256 * 8 bytes = 4 x 16 bytes per lane
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < UU * RADIX * 8 / 16 / UB; ++q) reinterpret_cast<u4 *>(s_word)[t + q * UB] = z;
+        static_assert(UU * RADIX * 8 / 16 % UB == 0, "whole rounds");
+        if (t == 0) L.uni = 0;
+    }
+    unsigned inc = 0;
+    if (t < RADIX) {
+        inc = cnt;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        if (lane == kWave - 1) L.wtot[wave] = inc;
+    }
+    __syncthreads();
+    if (t < RADIX) {
+        unsigned woff = 0;
+#pragma unroll
+        for (int w = 0; w < RADIX / kWave; ++w) if (w < wave) woff += L.wtot[w];
+        const unsigned ds = woff + inc - cnt;
+        L.dstart[t] = ds;
+        L.gbase[t] = b0 - ds + (unsigned)TILE;               // biased by TILE (see the lean kernel)
+        if (cnt == (unsigned)TILE) L.uni = t + 1;
+    }
+    __syncthreads();
+    if (L.uni) {                                              // every key of the tile has one digit: moved as a block
+        const unsigned g = L.gbase[L.uni - 1] - (unsigned)TILE + (unsigned)upos;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            keys_out[(size_t)g + k * 32] = key[k];
+            if constexpr (VB != 0) vals_out[(size_t)g + k * 32] = val[k];
+        }
+        return;
+    }
+
+    unsigned rr[KPT];
+    {
+        unsigned long long *uw = s_word + unit * RADIX;
+        const unsigned mybit = 1u << (lane & 31);
+        const unsigned long long add = (1ull << 32) | mybit;
+        unsigned seen = 0;                                     // lane bits returned over all rounds
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(key[k]) >> shift) & (RADIX - 1);
+            const unsigned long long old = atomicAdd(&uw[d], add);
+            atomicAdd(&uw[d], (unsigned long long)(0ull - (unsigned long long)mybit));       // the lane's bit out again (no return: any order)
+            rr[k] = (unsigned)(old >> 32);
+            seen |= (unsigned)old;
+        }
+        if (seen >> (lane & 31)) __builtin_trap();             // a lane was served before a lower lane of its unit that hit the same word
+    }
+    __syncthreads();
+
+    if (t < RADIX) {
+        unsigned run = L.dstart[t];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            const unsigned c = (unsigned)(s_word[u * RADIX + t] >> 32);
+            L.off[u][t] = (unsigned short)run;
+            run += c;
+        }
+        if (run - L.dstart[t] != cnt) __builtin_trap();       // the table and the keys disagree
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(key[k]) >> shift) & (RADIX - 1);
+        rr[k] += L.off[unit][d];
+    }
+    __syncthreads();                                          // (the tile goes where the counter words are)
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        s_keys[rr[k]] = key[k];
+        if constexpr (VB != 0) s_vals[rr[k]] = val[k];
+    }
+    __syncthreads();
+
+    __amdgpu_buffer_rsrc_t rk, rv;
+    if constexpr (!WIDE) {
+        rk = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(keys_out) - (long long)TILE * (long long)sizeof(K), 0, -1, 0x00020000);
+        if constexpr (VB != 0) rv = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(vals_out) - (long long)TILE * (long long)VB, 0, -1, 0x00020000);
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const K kk = s_keys[t + k * UB];
+        const unsigned d = (unsigned)(to_ordered<K, MODE, DESC>(kk) >> shift) & (RADIX - 1);
+        const unsigned e = L.gbase[d] + (unsigned)t;
+        if constexpr (WIDE) {
+            const unsigned g = e + (unsigned)(k * UB) - (unsigned)TILE;
+            keys_out[(size_t)g] = kk;
+            if constexpr (VB != 0) vals_out[(size_t)g] = s_vals[t + k * UB];
+        } else {
+            store_elem<K>(kk, rk, e * (unsigned)sizeof(K), (unsigned)(k * UB) * (unsigned)sizeof(K));
+            if constexpr (VB != 0) store_elem<VT>(s_vals[t + k * UB], rv, e * (unsigned)VB, (unsigned)(k * UB) * (unsigned)VB);
+        }
+    }
+}
+
 extern int g_sort_rank;
 
 template <typename K, int VB> constexpr int kpt_for() { return keys_per_lane((int)sizeof(K), VB); }
@@ -583,8 +757,19 @@ void launch_lean(hipStream_t s, bool wide, unsigned nfull, const K *src, K *dst,
     else      radix_scatter_lean_kernel<K, MODE, DESC, VB, KPT, CHECK, false><<<grid, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
 }
 
+template <typename K, int MODE, bool DESC, int VB>
+void launch_unit(hipStream_t s, bool wide, unsigned nfull, const K *src, K *dst, const void *vsrc, void *vdst,
+        int64_t n, int shift, unsigned nblocks, const unsigned *table) {
+    if constexpr (unit_ok<K, VB>()) {
+        constexpr int KPT = unit_kpt<K, VB>();
+        const unsigned grid = (nfull + 7) / 8 * 8;
+        if (wide) radix_scatter_unit_kernel<K, MODE, DESC, VB, KPT, true><<<grid, UB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+        else      radix_scatter_unit_kernel<K, MODE, DESC, VB, KPT, false><<<grid, UB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+    } else launch_lean<K, MODE, DESC, VB, 2>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);      // (4-byte keys with 8-byte values: 4096 pairs per tile do not split over 768 lanes)
+}
+
 // rank: 0 match words (round 2), 1 counter atomics with one verified tile in 16 (round 4), 2 the same without verified tiles,
-//       3 / 4 / 5 the lean scatter with CHECK 0 / 1 / 2 (5 is the default)
+//       3 / 4 / 5 the lean scatter with CHECK 0 / 1 / 2, 6 the unit scatter (one returning atomic per key that proves its own order: the default)
 template <typename K, int MODE, bool DESC, int VB>
 int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp, int64_t n, unsigned *tmp, int rank) {
     const bool atomic_rank = rank == 1 || rank == 2;
@@ -611,6 +796,7 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
             if (rank == 3) launch_lean<K, MODE, DESC, VB, 0>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);
             else if (rank == 4) launch_lean<K, MODE, DESC, VB, 1>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);
             else if (rank == 5) launch_lean<K, MODE, DESC, VB, 2>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);
+            else if (rank == 6) launch_unit<K, MODE, DESC, VB>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);
             else if (atomic_rank) {
                 radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, true, true><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, every);
             } else radix_scatter_kernel<K, MODE, DESC, VB, KPT, true, false><<<(nfull + 7) / 8 * 8, RB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table, 0u);
@@ -661,7 +847,7 @@ void lds_atomic_order_kernel(unsigned seed, int rounds, unsigned *violations) {
     if (bad) atomicAdd(violations, bad);
 }
 
-int g_sort_rank = -1;               // -1: the default (5); 0: match words; 1 / 2: round 4's counter-atomic ranks with / without verified tiles (1 only if the
+int g_sort_rank = -1;               // -1: the default (6: the unit scatter); 0: match words; 1 / 2: round 4's counter-atomic ranks with / without verified tiles (1 only if the
                                     // device self-test agrees); 3 / 4 / 5: the lean scatter, ranks unchecked / checked beside / taken from the checked words
 
 int atomic_rank_ok(int dev, hipStream_t s, bool *ok) {
@@ -709,7 +895,7 @@ int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
     VEXHIP_REQUIRE(value_bytes == 0 || (vals && vals_tmp), "NULL value buffers");
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
-    int ar = g_sort_rank < 0 ? 5 : g_sort_rank;
+    int ar = g_sort_rank < 0 ? 6 : g_sort_rank;
     if (ar == 1) { bool ok = false; if (int rc = atomic_rank_ok(dev, s, &ok)) return rc; if (!ok) ar = 0; }
     switch (key_dtype) {
         case VEXHIP_U32: return sort_dispatch<unsigned, KEY_UNSIGNED>(s, descending, value_bytes, keys, keys_tmp, vals, vals_tmp, n, tmp, ar);
