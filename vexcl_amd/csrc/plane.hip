@@ -66,7 +66,10 @@ __device__ __forceinline__ int position_of(int d, int far) {
 // neighbours.  (`consumed` is raised and the step number advanced by halo_signal_kernel behind this launch: a kernel boundary
 // orders every workgroup's reads of the ghost planes before the owners may overwrite them.)
 template <int TY, bool APPEND, int STORE_AUX, bool HALO = false>
-__global__ __launch_bounds__(256, (TY == 2 && !HALO) ? 4 : 2)       // (HALO: a few registers more than 128, and one product workgroup per CU anyway)
+#ifndef VEXHIP_HALO_WAVES
+#define VEXHIP_HALO_WAVES 2
+#endif
+__global__ __launch_bounds__(256, (TY == 2 && !HALO) ? 4 : (HALO ? VEXHIP_HALO_WAVES : 2))       // (HALO: a few registers more than 128)
 void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
         plane_dev pd, halo_dev H)
