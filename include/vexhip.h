@@ -545,6 +545,10 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *win, int dtype, int64_t rows,
  * The plan owns the window (no other plan on it).  Timeouts as above (NaN ghosts, sticky error).                          */
 int vexhip_dist_spmv_create_halo(vexhip_ipc_window *win, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
         vexhip_dist_spmv **out);
+/* Diagnostics of the one-launch step (VEXHIP_HALO_DEBUG=1 in the environment when the plan is created): six 64-bit words per
+ * workgroup of the last launch -- start, ghost flag seen, first ghost line in registers, end (100 MHz ticks), first plane, end
+ * plane (push workgroups: ~0, side) -- copied to `out` (at most 4096 workgroups).  tools/r05_halo_timeline.py.                    */
+int vexhip_dist_spmv_debug(vexhip_dist_spmv *step, void *out, int64_t bytes);
 /* timed_out: a flag wait ran into its bound; transport: VEXHIP_COMM_RCCL, VEXHIP_COMM_IPC or VEXHIP_COMM_HALO; direct: the shares are
  * runs of x and no pack kernel / index list is used.                                                                 */
 int vexhip_dist_spmv_status(vexhip_dist_spmv *step, int *timed_out, int *transport, int *direct);

@@ -1,9 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-run() { echo "== $*"; env "$@" VEXHIP_IPC_TIMEOUT_MS=5000 timeout 600 python tools/r05_dist_step.py 2>&1 | grep -E "^halo: |^local part alone|Traceback|Error" | cut -c1-300; }
+run() { echo "== $*"; env "$@" VEXHIP_IPC_TIMEOUT_MS=5000 timeout 300 python tools/r05_halo_timeline.py 2>&1 | grep -E "^device|lower|main" | cut -c1-330; }
 run A=1
-run VEXHIP_LIBRARY=$PWD/vexcl_amd/lib/libvexhip_halo4.so
-run VEXHIP_LIBRARY=$PWD/vexcl_amd/lib/libvexhip_halo4.so VEXHIP_HALO_DEPTH=24
-run VEXHIP_LIBRARY=$PWD/vexcl_amd/lib/libvexhip_halo4.so VEXHIP_HALO_DEPTH=24 VEXHIP_HALO_EDGE_PLANES=4
-run VEXHIP_LIBRARY=$PWD/vexcl_amd/lib/libvexhip_halo4.so VEXHIP_HALO_DEPTH=16
+run VEXHIP_HALO_TWO_PASS=1
 run A=1
+run VEXHIP_HALO_TWO_PASS=1

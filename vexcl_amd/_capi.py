@@ -218,6 +218,7 @@ _PROTOS = {
     "vexhip_ipc_window_open": (None, [c_vp, c_int, c_vp]),
     "vexhip_ipc_window_data": (None, [c_vp, ctypes.POINTER(c_vp)]),
     "vexhip_ipc_window_destroy": (None, [c_vp]),
+    "vexhip_dist_spmv_debug": (None, [c_vp, c_vp, c_i64]),
     "vexhip_dist_spmv_create_halo": (None, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, ctypes.POINTER(c_vp)]),
     "vexhip_dist_spmv_create_ipc": (None, [c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64),
                                            ctypes.POINTER(c_i64), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_vp)]),

@@ -317,6 +317,7 @@ struct dist_spmv {
     const vexhip_spmat *ext = nullptr;
     halo_dev hd;
     unsigned *d_halo_done = nullptr;
+    unsigned long long *d_halo_debug = nullptr;
     // optional phase timing of one step (vexhip_dist_spmv_profile)
     hipEvent_t *prof = nullptr;                // [0..3] compute stream: start, local done, ghosts here, end; [4..6] comm stream: start, packed, exchanged
 };
@@ -757,6 +758,7 @@ int vexhip_dist_spmv_destroy(vexhip_dist_spmv *h) {
     if (D->d_arrive) (void)hipFree(D->d_arrive);
     if (D->d_consumed) (void)hipFree(D->d_consumed);
     if (D->d_halo_done) (void)hipFree(D->d_halo_done);
+    if (D->d_halo_debug) (void)hipFree(D->d_halo_debug);
     delete D;
     return 0;
 }
@@ -1033,8 +1035,16 @@ int vexhip_dist_spmv_create_halo(vexhip_ipc_window *hw, const vexhip_spmat *ext,
     }
     H.step = w->d_step; H.done = D->d_halo_done; H.err = D->d_err; H.ticks = spin_ticks();
     H.push_blocks = 16;
-    if (const char *pb = std::getenv("VEXHIP_HALO_PUSH_BLOCKS")) H.push_blocks = std::max(1, std::min(1024, std::atoi(pb)));
+    if (const char *pb = std::getenv("VEXHIP_HALO_PUSH_BLOCKS")) H.push_blocks = std::max(0, std::min(1024, std::atoi(pb)));       // 0: the product workgroups push (plane.hip)
     H.halo = (int)halo; H.z0 = has_lo; H.z1 = has_lo + (int)(rows / halo); H.lo_planes = 0; H.hi_planes = 0;
+    H.debug = nullptr;
+    if (std::getenv("VEXHIP_HALO_DEBUG")) {                  // diagnostics: 6 words per workgroup of the LAST launch (tools/r05_halo_timeline.py reads them through vexhip_dist_spmv_debug)
+        if (hipMalloc(reinterpret_cast<void **>(&D->d_halo_debug), 6 * 8 * 4096) == hipSuccess) { (void)hipMemset(D->d_halo_debug, 0, 6 * 8 * 4096); H.debug = D->d_halo_debug; }
+    }
+    H.lo_two_pass = 0;
+    if (const char *tp = std::getenv("VEXHIP_HALO_TWO_PASS")) H.lo_two_pass = std::atoi(tp) != 0;
+    H.acquire = 0;                                           // the ghost planes live in uncached memory (halo.hpp, spin_until)
+    if (const char *aq = std::getenv("VEXHIP_HALO_ACQUIRE")) H.acquire = std::max(0, std::min(2, std::atoi(aq)));
     if (std::getenv("VEXHIP_HALO_NO_PUSH")) {
         // diagnostics (tools/r05_dist_step.py): nobody pushes, the flags this rank waits for are raised once and for all -- what the
         // product with ghost planes costs when the exchange costs nothing
@@ -1049,6 +1059,19 @@ int vexhip_dist_spmv_create_halo(vexhip_ipc_window *hw, const vexhip_spmat *ext,
         }
     }
     *out = reinterpret_cast<vexhip_dist_spmv *>(D);
+    return 0;
+}
+
+/* diagnostics (VEXHIP_HALO_DEBUG=1 at creation): 6 x 64-bit words per workgroup of the last one-launch step -- start, ghost flag seen,
+ * first ghost line in registers, end (100 MHz ticks), first plane, end plane (push workgroups: ~0, side) -- copied to `out` (up to
+ * 4096 workgroups = 196 608 bytes); returns the number of workgroups' records the plan holds, 0 without the switch.                 */
+int vexhip_dist_spmv_debug(vexhip_dist_spmv *h, void *out, int64_t bytes) {
+    dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
+    VEXHIP_REQUIRE(D && out, "NULL argument");
+    if (!D->d_halo_debug) return 0;
+    VEXHIP_SET_DEVICE(D->dev);
+    VEXHIP_TRY(hipDeviceSynchronize());
+    VEXHIP_TRY(hipMemcpy(out, D->d_halo_debug, (size_t)std::min<int64_t>(bytes, 6 * 8 * 4096), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -35,11 +35,18 @@ struct halo_dev {
     int halo;                                           // elements of a ghost plane
     int z0, z1;                                         // planes of the stored grid this launch computes: [z0, z1)
     int lo_planes, hi_planes;                           // planes of the short chunks next to the lower / upper ghost plane (0: none)
+    unsigned long long *debug;                          // diagnostics (VEXHIP_HALO_DEBUG): per workgroup {start, ghost flag seen, first ghost line in registers, end} in 100 MHz ticks
+    int lo_two_pass;                                    // the lower chunk walks its planes above the first one first and its first plane (the one that needs the ghost plane) last
+    int acquire;                                        // behind a ghost flag: 0 no cache invalidate (the window is uncached), 1 agent scope, 2 system scope
 };
 
 // returns false when the flag was not raised in time (err, in pinned host memory, is set then and stays set: the products that
 // are already queued fail fast instead of waiting `ticks` each; the host refuses further ones)
-__device__ inline bool spin_until(const unsigned long long *flag, unsigned long long want, int *err, unsigned long long ticks) {
+// acquire: 2 = system-scope acquire once the flag is there (invalidates this CU's L1 AND the XCD's L2 lines that are not kept coherent:
+// the right thing in front of loads from CACHED memory another device wrote), 1 = agent scope, 0 = none -- for loads from the UNCACHED
+// window, which no cache ever holds: the flag's value has returned before the first data load is issued, and that is all the order
+// an uncached read needs.
+__device__ inline bool spin_until(const unsigned long long *flag, unsigned long long want, int *err, unsigned long long ticks, int acquire = 2) {
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
     const unsigned long long t0 = wall_clock64();
     // relaxed polls (the flags are uncached: every poll reads memory), ONE acquire once the flag is there
@@ -47,7 +54,9 @@ __device__ inline bool spin_until(const unsigned long long *flag, unsigned long 
         __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (acquire == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else if (acquire == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return true;
 }
 

@@ -85,14 +85,16 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     unsigned b = blockIdx.x;
     [[maybe_unused]] unsigned long long step = 0;
     [[maybe_unused]] __shared__ int s_flag[2];
+    [[maybe_unused]] unsigned long long dbg_t0 = 0, dbg_flag = 0, dbg_data = 0;
     if constexpr (HALO) {
+        if (H.debug) dbg_t0 = wall_clock64();
         step = *H.step;
         const unsigned npush = (H.dst_lo ? (unsigned)H.push_blocks : 0u) + (H.dst_hi ? (unsigned)H.push_blocks : 0u);
         if (b < npush) {
             // ---- copy one of the rank's boundary planes into the neighbour's window (16-byte pieces), raise `arrive` there ----
             const bool down = H.dst_lo && b < (unsigned)H.push_blocks;           // the FIRST plane goes to the lower neighbour
             const unsigned j = down ? b : b - (H.dst_lo ? (unsigned)H.push_blocks : 0u);
-            if (t == 0) s_flag[0] = spin_until(down ? H.sent_lo : H.sent_hi, step - 1ull, H.err, H.ticks) ? 1 : 0;   // the neighbour has read the previous share
+            if (t == 0) s_flag[0] = spin_until(down ? H.sent_lo : H.sent_hi, step - 1ull, H.err, H.ticks, 0) ? 1 : 0;   // the neighbour has read the previous share
             __syncthreads();
             if (s_flag[0]) {                                                     // uniform; a neighbour that does not answer is not written to
                 const double *src = x + (down ? (long long)H.z0 * pd.far : (long long)(H.z1 - 1) * pd.far);
@@ -119,6 +121,7 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
                     }
                 }
             }
+            if (H.debug && t == 0) { unsigned long long *d = H.debug + 6ull * blockIdx.x; d[0] = dbg_t0; d[1] = 0; d[2] = 0; d[3] = wall_clock64(); d[4] = ~0ull; d[5] = down ? 0ull : 1ull; }
             return;
         }
         b -= npush;
@@ -129,6 +132,8 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     if (tile >= pd.tiles) return;                                   // the whole workgroup
     const int y0 = TY * tile;
     int z, zend;
+    [[maybe_unused]] bool second = false;
+    [[maybe_unused]] int z2 = 0, zend2 = 0;
     if constexpr (HALO) {
         // chunks of the planes [z0, z1): the planes next to a ghost plane form SHORT chunks of their own, dispatched behind the
         // main chunks -- they wait for the neighbour's share and read it from uncached memory (slow: few requests in flight)
@@ -137,12 +142,55 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
         const int nmain = (mid1 - mid0 + pd.depth - 1) / pd.depth;
         if (zc < nmain) { z = mid0 + zc * pd.depth; zend = z + pd.depth < mid1 ? z + pd.depth : mid1; }
         else if (H.hi_planes && zc == nmain) { z = mid1; zend = H.z1; }
-        else { z = H.z0; zend = mid0; }
+        else if (H.lo_two_pass && mid0 - H.z0 >= 2) {
+            // the chunk next to the LOWER ghost plane needs that plane for its FIRST plane: it walks the planes above it first and
+            // comes back for plane z0 in a second pass, when the neighbour's share has arrived (the push of a plane takes 45 us and
+            // more: tools/r05_halo_timeline.py) -- one plane of work behind the flag instead of the whole chunk
+            z = H.z0 + 1; zend = mid0; second = true; z2 = H.z0; zend2 = H.z0 + 1;
+        } else { z = H.z0; zend = mid0; }
     } else {
         z = zc * pd.depth;
         zend = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
     }
     if (z >= zend) return;
+    [[maybe_unused]] const int z_first0 = z, mid_end = zend;
+    if constexpr (HALO) {
+        // push_blocks == 0: NO dedicated push workgroups -- the first 2 x 256 product workgroups each copy 1024 elements of a
+        // boundary plane before they start their walk.  Stores into the uncached window complete one after the other per wave
+        // (32 of them per lane took the 32 dedicated workgroups 45 us on some boxes and 84 us on others: tools/r05_halo_timeline.py);
+        // two per lane from 2048 waves at once are done in a few microseconds, and the neighbours' ghost flags rise that early.
+        if (H.push_blocks == 0 && b < 512u) {
+            const bool down = b < 256u;
+            double *dst = down ? H.dst_lo : H.dst_hi;
+            if (dst) {                                                           // uniform
+                if (t == 0) s_flag[0] = spin_until(down ? H.sent_lo : H.sent_hi, step - 1ull, H.err, H.ticks, 0) ? 1 : 0;
+                __syncthreads();
+                if (s_flag[0]) {
+                    const double *src = x + (down ? (long long)H.z0 * pd.far : (long long)(H.z1 - 1) * pd.far);
+                    const int per = ((H.halo + 255) / 256 + 511) / 512 * 512;
+                    const int i0 = (int)(b & 255u) * per, i1 = i0 + per < H.halo ? i0 + per : H.halo;
+                    for (int i = i0 + 2 * t; i < i1; i += 512)
+                        *reinterpret_cast<d2 *>(dst + i) = *reinterpret_cast<const d2 *>(src + i);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (t == 0) {
+                        unsigned *cnt = H.done + (down ? 1 : 2);
+                        const unsigned npieces = (unsigned)((H.halo + per - 1) / per);
+                        const bool mine = i0 < H.halo;
+                        if (mine) {
+                            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (old + 1u == npieces) {
+                                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(down ? H.peer_arrive_lo : H.peer_arrive_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();                                                 // s_flag is used again by the ghost waits
+            }
+        }
+    }
     const int ny = pd.ny;
     const int nslices = (int)pd.nslices, xlines = (int)pd.xlines;
     const long long x_last = pd.x_last;
@@ -233,15 +281,22 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
                 bool &got = below ? got_lo : got_hi;
                 if (!got) {
                     // the first line of this ghost plane the workgroup needs: has the owner's share of THIS product arrived?
-                    if (t == 0) s_flag[below ? 0 : 1] = spin_until(below ? H.arrive_lo : H.arrive_hi, step, H.err, H.ticks) ? 1 : 0;
+                    if (t == 0) s_flag[below ? 0 : 1] = spin_until(below ? H.arrive_lo : H.arrive_hi, step, H.err, H.ticks, H.acquire) ? 1 : 0;
                     __syncthreads();
                     if (!s_flag[below ? 0 : 1]) ghost_bad = true;
                     // (no fence per lane: the ghost planes are UNCACHED memory -- nothing of them is ever held in a cache -- and
                     //  lane 0 has acquired at system scope inside spin_until in front of the barrier; a system-scope acquire by
                     //  every lane of every workgroup doubled the time of the whole product: 55 -> 119 us)
                     got = true;
+                    if (H.debug && !dbg_flag) dbg_flag = wall_clock64();
                 }
                 if (ghost_bad) { r.x = r.y = __builtin_nan(""); return r; }         // never numbers from stale ghosts (comm.hip)
+                if (H.debug && !dbg_data) {                                          // diagnostics: how long the first ghost line takes to arrive
+                    const d2 v = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(g + (long long)gl * PL_ROWS) + lane_b);
+                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(v.x), "v"(v.y) : "memory");
+                    dbg_data = wall_clock64();
+                    return v;
+                }
                 return *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(g + (long long)gl * PL_ROWS) + lane_b);
             }
         }
@@ -276,6 +331,9 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     // copy behind a request makes the step wait for it: the one-step form of this loop ran 8 % slower).  It contains no memory
     // instruction other than these requests and the stores, so that the waits of a step count what the step before requested;
     // which block a line uses is known for up to 64 planes ahead (one look at blocks[] per entry).
+    constexpr int NPASS = HALO ? 2 : 1;
+    for (int pass = 0; pass < NPASS; ++pass) {
+    if constexpr (HALO) if (pass == 1) { if (!second) break; z = z2; zend = zend2; }
     d2 Cs[4][TY], Hs[2][2], Yo[TY];
     double Es[2][TY];
     const unsigned plane_b32 = (unsigned)ny * (PL_ROWS * 8u);          // bytes from a line to the same line of the next plane (the plan: (depth + 4) of them < 2^32)
@@ -402,6 +460,13 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
         for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
         ++z;
     }
+    }       // pass
+    if constexpr (HALO) {
+        if (H.debug && t == 0) {
+            unsigned long long *d = H.debug + 6ull * blockIdx.x;
+            d[0] = dbg_t0; d[1] = dbg_flag; d[2] = dbg_data; d[3] = wall_clock64(); d[4] = (unsigned long long)(second ? z2 : z_first0); d[5] = (unsigned long long)(second ? mid_end : zend);
+        }
+    }
 #undef PLANE_XS
 #undef PLANE_HOT_SUMS
 #undef PLANE_OTHER_SUMS
@@ -492,7 +557,7 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
     VEXHIP_REQUIRE(plane->lines_per_plane >= 4 && plane->lines_per_plane % 2 == 0 && plane->depth >= 1 && plane->planes >= 1
                    && ((long long)plane->depth + 4) * plane->lines_per_plane * 4096 < (1ll << 32), "bad plane plan");
     VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "plane product: x and y must be 16-byte aligned");
-    VEXHIP_REQUIRE(H.z0 >= 0 && H.z1 > H.z0 && H.z1 <= plane->planes && H.step && H.done && H.err && H.push_blocks >= 1, "bad halo step");
+    VEXHIP_REQUIRE(H.z0 >= 0 && H.z1 > H.z0 && H.z1 <= plane->planes && H.step && H.done && H.err && H.push_blocks >= 0, "bad halo step");
     VEXHIP_REQUIRE(H.halo == plane->lines_per_plane * PL_ROWS, "the ghost planes must be planes of the stored grid");
     VEXHIP_REQUIRE((!H.lo || H.z0 >= 1) && (!H.hi || H.z1 < plane->planes), "a ghost plane outside the stored grid");
     VEXHIP_SET_DEVICE(dev);
@@ -504,14 +569,18 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
     const int nzr = H.z1 - H.z0;
     int edge_planes = 8;
     if (const char *e = std::getenv("VEXHIP_HALO_EDGE_PLANES")) edge_planes = std::max(1, std::atoi(e));
-    H.lo_planes = H.lo ? std::min(edge_planes, nzr) : 0;
-    H.hi_planes = H.hi ? std::min(edge_planes, nzr - H.lo_planes) : 0;
+    int lo_planes = edge_planes, hi_planes = edge_planes;
+    if (const char *e = std::getenv("VEXHIP_HALO_LO_PLANES")) lo_planes = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("VEXHIP_HALO_HI_PLANES")) hi_planes = std::max(1, std::atoi(e));
+    H.lo_planes = H.lo ? std::min(lo_planes, nzr) : 0;
+    H.hi_planes = H.hi ? std::min(hi_planes, nzr - H.lo_planes) : 0;
     const int mid = nzr - H.lo_planes - H.hi_planes;
     pd.depth = std::max(1, mid);          // ONE main chunk (two of 25 planes beside the short chunks: 88-90 us against 76 for the step)
     if (const char *e = std::getenv("VEXHIP_HALO_DEPTH")) pd.depth = std::max(1, std::atoi(e));
     const long long chunks = (H.lo_planes ? 1 : 0) + (H.hi_planes ? 1 : 0) + (mid + pd.depth - 1) / pd.depth;
     const long long npush = (H.dst_lo ? H.push_blocks : 0) + (H.dst_hi ? H.push_blocks : 0);
     const long long grid = npush + 8ll * pd.tpx * chunks;
+    VEXHIP_REQUIRE(H.push_blocks > 0 || 8ll * pd.tpx * chunks >= 512 || !(H.dst_lo || H.dst_hi), "too few workgroups to push the boundary planes");
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     // the kernel addresses x and y in the numbering of the stored grid
     const double *xe = x - (long long)H.z0 * pd.far;
