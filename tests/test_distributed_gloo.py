@@ -105,6 +105,26 @@ def _worker(rank, world, port, case, out):
         ys2 = torch.full_like(ys, 123.0)                # SET semantics overwrite
         A.apply(xs, ys2, 1.0, False)
         ok = ok and bool(np.allclose(ys2.numpy(), oracle.spmv_csr(ptr, col, val, x)[r0:r1], rtol=1e-12, atol=1e-12))
+        # the C++ steps need the device kernels: on CPU every transport must decline ON EVERY RANK, together (each stage of
+        # enable_native ends in an all-reduce), and leave the torch.distributed step working
+        for tr in ("halo", "ipc"):
+            ok = ok and A.enable_native(transport=tr) is False and A.native_error is not None and A.native_status() is None
+        ys3 = torch.full_like(ys, -5.0)
+        A.apply(xs, ys3, 1.0, False)
+        ok = ok and bool(torch.equal(ys3, ys2))
+        if case == "poisson":
+            # the strip stored WITH its ghost planes (transport "halo", distributed.halo_extended_csr): its product with
+            # [lower ghost plane | x | upper ghost plane] gives this rank's rows of the global product, for every rank of every world
+            from vexcl_amd.distributed import halo_extended_csr
+            P = n * n
+            has_lo, has_hi = rank > 0, rank < world - 1
+            lo, hi = (P if has_lo else 0), (P if has_hi else 0)
+            if (r1 - r0) % P == 0:
+                pe, ce = halo_extended_csr(torch.from_numpy((ptr[r0:r1 + 1] - ptr[r0]).astype(np.int32)), torch.from_numpy(col[j0:j1].copy()), r0, r1 - r0, lo, hi)
+                xe = x[r0 - lo:r1 + hi]
+                ye = oracle.spmv_csr(pe.numpy(), ce.numpy(), val[j0:j1].copy(), np.ascontiguousarray(xe))
+                ok = ok and len(ye) == lo + (r1 - r0) + hi and np.array_equal(ye[lo:lo + r1 - r0], oracle.spmv_csr(ptr, col, val, x)[r0:r1])
+                ok = ok and not ye[:lo].any() and not ye[lo + r1 - r0:].any()
         out[rank] = 1 if (ok and ok_red) else 0
     finally:
         dist.destroy_process_group()

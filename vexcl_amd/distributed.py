@@ -35,6 +35,21 @@ def partition(n, nparts):
     return part
 
 
+def halo_extended_csr(ptr, col, col_begin, rows, lo, hi):
+    """A rank's strip (CSR, GLOBAL columns, first owned column `col_begin`) as ONE square matrix that includes its ghost planes
+    (transport "halo"): `lo` empty rows in front of the rank's rows and `hi` empty rows behind them, columns counted from the first
+    element of the lower ghost plane -- so that x of that matrix is [lower ghost plane | the rank's segment | upper ghost plane] and
+    its rows lo .. lo + rows are the rank's rows of the global product, entries in their global column order.
+    -> (ptr_ext, col_ext) as int32 tensors; raises if a column lies outside the two ghost planes."""
+    dev = col.device
+    last = ptr[-1:].to(torch.int32)
+    ptr_ext = torch.cat([torch.zeros(lo, dtype=torch.int32, device=dev), ptr.to(torch.int32), last.expand(hi)]).contiguous()
+    col_ext = col.to(torch.int64) - (col_begin - lo)
+    if col_ext.numel() and (int(col_ext.min()) < 0 or int(col_ext.max()) >= lo + rows + hi):
+        raise RuntimeError("transport halo: a column outside the two ghost planes")
+    return ptr_ext, col_ext.to(torch.int32).contiguous()
+
+
 class DeviceKernels:
     """The HIP kernels behind the distributed product (no CPU stand-in here)."""
 
@@ -353,16 +368,8 @@ class DistSpMat:
         if H <= 0 or self.rows % H or H % 1024:
             raise RuntimeError("transport halo: the strip is not a whole number of planes of %d elements" % H)
         lo, hi = (H if has_lo else 0), (H if has_hi else 0)
-        dev = val.device
-        last = ptr[-1:].to(torch.int32)
-        ptr_ext = torch.cat([torch.zeros(lo, dtype=torch.int32, device=dev), ptr.to(torch.int32), last.expand(hi)]).contiguous()
-        if self_exchange:
-            col_ext = col.to(torch.int64) + lo               # a one-rank strip already counts from its own first element
-        else:
-            col_ext = col.to(torch.int64) - (c0 - lo)
-        if int(col_ext.min()) < 0 or int(col_ext.max()) >= lo + self.rows + hi:
-            raise RuntimeError("transport halo: a column outside the two ghost planes")
-        ext = ops.SpMat(ptr_ext, col_ext.to(torch.int32).contiguous(), val, n_cols=lo + self.rows + hi)
+        ptr_ext, col_ext = halo_extended_csr(ptr, col, 0 if self_exchange else c0, self.rows, lo, hi)
+        ext = ops.SpMat(ptr_ext, col_ext, val, n_cols=lo + self.rows + hi)
         if not getattr(ext, "handle", None) or not getattr(ext, "plane", None):
             raise RuntimeError("transport halo: the stored strip did not get a plane plan (storage %s)" % getattr(ext, "storage", "?"))
         ext.ptr = ext.col = ext.val = None
