@@ -302,6 +302,38 @@ def unstructured_rows(torch, ops, dev, args):
     except Exception as e:  # noqa: BLE001 -- a secondary row
         rows["SpMV 5-point 2-D"] = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
+    # ---- round 5: the headline operator in fp32 (plane32.hip: the plane walk with four rows per lane; the march product took
+    # float matrices until then) -- bit-compared with the library's CSR loop on the same arrays
+    try:
+        g = int(os.environ.get("BENCH_FP32_GRID", "512"))
+        ptr, col, val = ops.poisson3d(g, dev)
+        v32 = val.to(torch.float32)
+        del val
+        n3, nnz3 = g ** 3, int(col.numel())
+        x3 = ops.fill_hash(torch.empty(n3, dtype=torch.float64, device=dev), 42).to(torch.float32)
+        y3 = torch.empty_like(x3); yc = torch.empty_like(x3)
+        A = ops.SpMat(ptr, col, v32)
+        C = ops.SpMat(ptr, col, v32, fmt="csr")
+        A.apply(x3, y3); C.apply(x3, yc)
+        same = bool(torch.equal(y3, yc))
+        assert same, "fp32 product differs from the CSR loop"
+        del C, yc, ptr, col, v32
+        A.ptr = A.col = A.val = None
+        torch.cuda.empty_cache()
+        t = min(timed_events(torch, lambda: A.apply(x3, y3), 20) for _ in range(3))
+        moved = A.matrix_bytes() + 8 * n3
+        rows["SpMV fp32 Poisson %d^3 (y = A*x, default vexhip_spmat)" % g] = {
+            "rows": n3, "nnz": nnz3, "storage": A.storage, "plane_plan": A.plane, "ms": round(t, 5), "gflops": round(2.0 * nnz3 / t / 1e6, 1),
+            "bit_identical_to_csr_loop": same,
+            "roofline": {"bound": "hbm", "bytes_per_launch": moved, "achieved": round(moved / t / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(moved / t / 1e6 / HBM_PEAK_GBPS, 4), "what": "stored matrix (4 B per line + the dictionary) + x once + y once, 4-byte elements"}}
+        del A, x3, y3
+        torch.cuda.empty_cache()
+    except AssertionError:
+        raise
+    except Exception as e:  # noqa: BLE001 -- a secondary row
+        rows["SpMV fp32 Poisson"] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
     for name in ("random16", "powerlaw"):
         try:
             ptr, col, val = U.MAKERS[name](m, dev)

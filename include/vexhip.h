@@ -278,7 +278,9 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
  * twice instead of three times.  The plan checks on the host that every dictionary block keeps its rows' diagonals in
  * ascending order of position (position order = storage order), that at most 1/16 of the slices use another block than the
  * most frequent one (hot_block), that there is no CSR tail and that x can be read in whole lines ((x_last + 1) % 512 == 0);
- * usable = 0 otherwise and the march / pair products stay.  VEXHIP_PLANE_DEPTH overrides depth.  fp64 only.            */
+ * usable = 0 otherwise and the march / pair products stay.  VEXHIP_PLANE_DEPTH overrides depth.  value_bytes 8 or 4: the
+ * fp32 product (plane32.hip, round 5) reads the same storage with FOUR rows per lane -- a 512-point line of floats is 128
+ * lanes x 16 bytes, a workgroup is two waves and walks half of `depth` (VEXHIP_PLANE32_DEPTH overrides).               */
 typedef struct vexhip_plane { int32_t usable;
                               int32_t lines_per_plane;   /* the far diagonals are +-512 * lines_per_plane                     */
                               int32_t planes;            /* ceil(slices / lines_per_plane)                                    */
@@ -298,6 +300,8 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
 int vexhip_stream_copy_f64(int dev, void *stream, const double *x, double *y, int64_t n);
 int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
+int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane);
 /* The GRID product (grid.hip, round 4; same semantics, hybrid_ell.inl:238-269; the size-agnostic stencil form the reference
  * reaches through SpMatCCSR, spmat/ccsr.hpp:55-113): the plane product for grids of any line length.  Value-coded storage
  * (with or without a slice dictionary: `blocks` may be NULL, `codes` is then the per-slice buffer) whose diagonals are

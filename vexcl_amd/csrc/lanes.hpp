@@ -33,5 +33,23 @@ __device__ __forceinline__ double keep_bit(double v, unsigned bits, int pos) {
     return __hiloint2double(__double2hiint(v) & m, __double2loint(v));
 }
 
+// fp32 (plane32.hip): a lane owns FOUR adjacent rows as one 16-byte quad
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float shift_from_lower_lane(float v, float edge) {          // lane i <- lane i - 1, lane 0 <- edge
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float shift_from_upper_lane(float v, float edge) {          // lane i <- lane i + 1, lane 63 <- edge
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float keep_lanes(float v, unsigned long long lanes) {       // +0.0 outside `lanes`
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(__float_as_uint(v)), "s"(lanes));
+    return __uint_as_float(r);
+}
+__device__ __forceinline__ float keep_bit(float v, unsigned bits, int pos) {
+    const int m = (int)(bits << (31 - pos)) >> 31;                // -1 where the bit is set
+    return __int_as_float(__float_as_int(v) & m);
+}
+
 } // namespace
 } // namespace vexhip

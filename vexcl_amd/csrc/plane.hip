@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "lanes.hpp"
 #include "halo.hpp"
+#include "plane.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -35,30 +36,6 @@
 
 namespace vexhip {
 namespace {
-
-constexpr int PL_ROWS = 512;
-constexpr unsigned PL_PAD_FIRST = 254;      // codes 254 / 255 are padding (sell8.hip)
-
-struct plane_dev {
-    long long nslices;       // 512-row lines of the matrix
-    long long xlines;        // lines of x that may be loaded whole: (x_last + 1) / 512
-    long long x_last;
-    int ny;                  // lines per plane
-    int nz;                  // planes: ceil(nslices / ny)
-    int depth;               // planes per workgroup
-    int tiles;               // ny / tile height
-    int tpx;                 // tiles per XCD: ceil(tiles / 8)
-    int hot;                 // dictionary block decoded into registers with scalar masks
-    int w;                   // ELL width (<= 8)
-    int far;                 // 512 * ny
-    int pitch;               // 0: `pool` holds SELL-512 code blocks; > 0: class tables of the grid storage ([class][7 positions][pitch] value codes, grid.hip)
-};
-
-
-// diagonal -> position 0..6 in {-far, -512, -1, 0, 1, 512, far} (the plan has checked that it is one of them)
-__device__ __forceinline__ int position_of(int d, int far) {
-    return d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -PL_ROWS ? 1 : d == PL_ROWS ? 5 : d == -far ? 0 : 6;
-}
 
 // HALO (round 5, halo.hpp): the launch is one rank's whole product step.  x and y are addressed in the numbering of the STORED
 // grid, whose plane z0 - 1 / z1 (if the rank has a neighbour there) is a ghost plane: its lines are read from the rank's window
@@ -604,7 +581,7 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
     VEXHIP_REQUIRE(out, "NULL output");
     std::memset(out, 0, sizeof(*out));
     const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids, many blocks
-    if (value_bytes != 8 || !deltas || !blocks || !pool || ndeltas < 2 || ndeltas > 7 || dictionary_blocks < 1 || dictionary_blocks > 128) return 0;
+    if ((value_bytes != 8 && value_bytes != 4) || !deltas || !blocks || !pool || ndeltas < 2 || ndeltas > 7 || dictionary_blocks < 1 || dictionary_blocks > 128) return 0;
     if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows != nslices * PL_ROWS || (nslices < 64 && !force)) return 0;
     if (x_last < 0 || (x_last + 1) % PL_ROWS != 0 || x_last + 1 < rows) return 0;
     VEXHIP_SET_DEVICE(dev);

@@ -404,6 +404,10 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
                     && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
                     return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
                                                             A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
+            if constexpr (std::is_same<V, float>::value)       // fp32: the same storage, four rows per lane (plane32.hip)
+                if (A->blocks && !A->direct && A->plane.usable && A->plane.table_pitch == 0 && g_sell8_variant == 0 && !A->tail
+                    && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+                    return vexhip_spmv_sell8v_plane_f32_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, (const float *)A->values, x, y, &A->plane);
             if constexpr (std::is_same<V, double>::value)
                 if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
                     return vexhip_spmv_sell8v_grid_f64(A->dev, stream, A->n, alpha, append, (const double *)A->values, x, y, &A->grid);

@@ -415,7 +415,7 @@ class SpMat:
         self.plane = ({"lines_per_plane": int(info.plane.lines_per_plane), "planes": int(info.plane.planes), "depth": int(info.plane.depth),
                        "hot_block": int(info.plane.hot_block), "tile": int(info.plane.tile), "store_policy": int(info.plane.store_policy), "x_last": int(info.plane.x_last),
                        "table_pitch": int(info.plane.table_pitch)}
-                      if info.plane.usable else None)              # not None: apply() runs the plane product (fp64)
+                      if info.plane.usable else None)              # not None: apply() runs the plane product (fp64: plane.hip; fp32: plane32.hip)
         g = info.grid
         self.grid = ({"nx": int(g.nx), "lines_per_plane": int(g.lines_per_plane), "planes": int(g.planes), "depth": int(g.depth),
                       "segments": int(g.segments), "segment_rows": int(g.segment_rows), "threads": int(g.threads), "hot_class": int(g.hot_class),
