@@ -655,8 +655,9 @@ def test_plane_product_fp32_is_bit_identical(T, oracle, built_lib):
     banded matrices through the forced plan (five dictionary blocks, lines that change their block from plane to plane, a
     ragged last plane, walks shorter than a group of four steps, several walk depths), '=' and '+= alpha'; the plan as the
     library chooses it (a 512 x 64 x 80 band, the benchmark's operator on 512 x 72 x 72 with identity rows on every face);
-    Inf / NaN in x where positions without an entry 'cover' it; vectors at addresses that are not multiples of 16 bytes
-    (the march / pair products take those calls)."""
+    Inf / NaN in x where positions without an entry 'cover' it; vectors at addresses that are not multiples of 16 bytes;
+    both stored forms (dictionary blocks of the SELL-512 storage, class tables of the storage by grid line -- grid.hip's
+    one-pass build, which takes float values where this product applies)."""
     torch = T.torch
     f32 = np.float32
     try:
@@ -670,40 +671,47 @@ def test_plane_product_fp32_is_bit_identical(T, oracle, built_lib):
             m = P * nz + extra
             ptr, col, val = _band(m, (-P, -512, -1, 0, 1, 512, P), 5, constant=True)
             v32 = val.astype(f32)
-            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), march=False)
-            assert A.storage == "sell8v" and A.plane is not None and A.plane["table_pitch"] == 0 and not A.direct and B.plane is None and B.march is None, (ny, nz, A.plane)
-            assert A.plane["lines_per_plane"] == ny
+            B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), march=False)
+            assert B.plane is None and B.march is None
             xb = oracle.random_f64(21, m).astype(f32); y0 = oracle.random_f64(22, m).astype(f32)
             want = oracle.spmv_csr(ptr, col, v32, xb)
             assert want.dtype == f32
-            for alpha, append in ((1.0, False), (-0.75, True)):
-                ya, yb = T.up(y0.copy()), T.up(y0.copy())
-                A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
-                assert torch.equal(ya, yb), (ny, nz, alpha)
-                assert np.array_equal(ya.cpu().numpy(), (y0 + f32(alpha) * want) if append else f32(alpha) * want), (ny, nz, alpha)
+            for direct in (False, True):       # dictionary blocks of the SELL-512 storage / class tables of the storage by grid line
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), direct=direct)
+                assert A.storage == "sell8v" and A.plane is not None and (A.plane["table_pitch"] > 0) == direct and A.direct == direct, (ny, nz, direct, A.plane)
+                assert A.plane["lines_per_plane"] == ny
+                for alpha, append in ((1.0, False), (-0.75, True)):
+                    ya, yb = T.up(y0.copy()), T.up(y0.copy())
+                    A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+                    assert torch.equal(ya, yb), (ny, nz, alpha, direct)
+                    assert np.array_equal(ya.cpu().numpy(), (y0 + f32(alpha) * want) if append else f32(alpha) * want), (ny, nz, alpha, direct)
         os.environ.pop("VEXHIP_PLANE32_DEPTH", None)
         # Inf / NaN in x: only the rows that reference them may see them
         ny, nz = 8, 12
         P = 512 * ny; m = P * nz
         ptr, col, val = _band(m, (-P, -512, -1, 0, 1, 512, P), 5, constant=True)
         v32 = val.astype(f32)
-        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32))
-        assert A.plane is not None
         xb = oracle.random_f64(23, m).astype(f32)
         xb[0] = np.inf; xb[1] = -np.inf; xb[m - 1] = np.nan; xb[5 * P + 3 * 512 + 255] = np.nan; xb[7 * P + 2 * 512 + 256] = np.inf
-        ya = torch.empty(m, dtype=torch.float32, device=T.dev)
-        A.apply(T.up(xb), ya)
-        assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, xb), equal_nan=True)
-        # vectors that do not start at a 16-byte address: the march / pair products take the call, same bits
+        for direct in (False, True):
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), direct=direct)
+            assert A.plane is not None and A.direct == direct
+            ya = torch.empty(m, dtype=torch.float32, device=T.dev)
+            A.apply(T.up(xb), ya)
+            assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, xb), equal_nan=True), direct
+        # vectors that start at any element (views into larger vectors): the fp32 plane product issues its 16-byte requests at
+        # 4-byte addresses -- a matrix stored by grid line has no other product
         xb = oracle.random_f64(27, m).astype(f32); y0 = oracle.random_f64(28, m).astype(f32)
         want = oracle.spmv_csr(ptr, col, v32, xb)
-        for alpha, append in ((1.0, False), (-0.75, True)):
-            xbig = torch.zeros(m + 7, dtype=torch.float32, device=T.dev); ybig = torch.zeros(m + 7, dtype=torch.float32, device=T.dev)
-            for xo, yo in ((1, 1), (2, 0), (0, 3), (4, 4)):
-                xv, yv = xbig[xo:xo + m], ybig[yo:yo + m]
-                xv.copy_(T.up(xb)); yv.copy_(T.up(y0))
-                A.apply(xv, yv, alpha, append)
-                assert np.array_equal(yv.cpu().numpy(), (y0 + f32(alpha) * want) if append else f32(alpha) * want), (alpha, xo, yo)
+        for direct in (False, True):
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), direct=direct)
+            for alpha, append in ((1.0, False), (-0.75, True)):
+                xbig = torch.zeros(m + 7, dtype=torch.float32, device=T.dev); ybig = torch.zeros(m + 7, dtype=torch.float32, device=T.dev)
+                for xo, yo in ((1, 1), (2, 0), (0, 3), (4, 4)):
+                    xv, yv = xbig[xo:xo + m], ybig[yo:yo + m]
+                    xv.copy_(T.up(xb)); yv.copy_(T.up(y0))
+                    A.apply(xv, yv, alpha, append)
+                    assert np.array_equal(yv.cpu().numpy(), (y0 + f32(alpha) * want) if append else f32(alpha) * want), (direct, alpha, xo, yo)
         os.environ.pop("VEXHIP_PLANE_FORCE")
 
         # the plan as the library chooses it

@@ -154,7 +154,10 @@ void grid_line_verify_kernel(codes_dev cd, long long lines, int nx, int pitch, c
 // than 254 values, more than 128 classes).  No per-slice codes are written (2.1 GB at 512^3), no second pass over the arrays
 // (the analysis of the classic set-up reads them once to find the tables, the fill a second time), nothing but a few counters
 // and the value table returns to the host.
-constexpr int GB_PIECE = 512;                 // rows staged at a time
+#ifndef VEXHIP_GB_PIECE
+#define VEXHIP_GB_PIECE 512
+#endif
+constexpr int GB_PIECE = VEXHIP_GB_PIECE;     // rows staged at a time
 constexpr int GB_CAP = 8 * GB_PIECE;          // entries of a piece (rows with more than 8 entries have no place in this storage)
 constexpr int GB_CHUNK = 8;                   // entries a lane requests together while staging a piece
 constexpr int GB_VSLOTS = 512;                // hash of the values: LDS per workgroup, and the device-wide table behind it
@@ -211,9 +214,10 @@ __device__ int gb_global_value_code(unsigned long long bits, const gb_dev &g)
     return -1;
 }
 
-template <typename P>
+// V: the matrix values (double / float; a float is coded by the bits of the double it converts to -- exactly, both ways)
+template <typename P, typename V>
 __global__ __launch_bounds__(256)
-void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val, gb_dev g)
+void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val, gb_dev g)
 {
     extern __shared__ unsigned char gb_lds[];
     // [value hash keys 512 x 8][value hash codes 512][row bounds 520 x 8][staged columns GB_CAP x 4][staged value codes GB_CAP][line 7 x pitch][scratch]
@@ -271,7 +275,7 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
             for (int u = 0; u < GB_CHUNK; ++u) {
                 const int k = base + t + 256 * u;
                 n_c[u] = 0; n_v[u] = 0.0;
-                if (k < cnt) { n_c[u] = col[e0 + k]; n_v[u] = val[e0 + k]; }
+                if (k < cnt) { n_c[u] = col[e0 + k]; n_v[u] = (double)val[e0 + k]; }
             }
 #pragma unroll
         for (int u = 0; u < GB_CHUNK; ++u) {
@@ -438,9 +442,9 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
 }
 
 // the diagonals of a few thousand rows (the probe in front of the one-pass build): a set of at most 15, overflow flag in [15]
-template <typename P>
+template <typename P, typename V>
 __global__ __launch_bounds__(256)
-void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val, long long first, long long rows,
+void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val, long long first, long long rows,
         int *__restrict__ set /* 16, INT_MIN = empty */, unsigned long long *__restrict__ vset /* 512 slots, all ones = empty */, int *__restrict__ vinfo /* [0] distinct values, [1] more than 254 */)
 {
     for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
@@ -449,7 +453,7 @@ void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
         // the values of these rows: a matrix with more than 254 of them in 8192 rows (a coefficient per face) is not one for this storage
         for (long long j = b; j < e && j < b + 16; ++j) {
             if (__hip_atomic_load(&vinfo[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(val[j]);
+            const unsigned long long bits = (unsigned long long)__double_as_longlong((double)val[j]);
             unsigned h = gb_vhash(bits);
             for (int probe = 0; probe < GB_VSLOTS; ++probe) {
                 unsigned long long old = __hip_atomic_load(&vset[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -825,9 +829,11 @@ template <typename T> struct dev_buf {       // device scratch of the plan, free
 // rows x rows-or-more matrix in CSR on the device -> vexhip_grid (usable = 1), the diagonal table (sorted, 256 ints on the device,
 // INT_MAX behind the last) and the value table (256 values on the device, 0.0 behind the last), ELL width and largest column;
 // usable = 0: not a matrix for this storage, nothing was written that the classic set-up would read.
-template <typename P>
-int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t *col, const double *val,
-        int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last_out, vexhip_grid *out, int64_t min_cols)
+// fp32 (V = float): only where the fp32 plane product applies (512-point lines, an even number of them per plane) -- there is no
+// fp32 grid product for other line lengths; declined right behind the probe otherwise.
+template <typename P, typename V>
+int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t *col, const V *val,
+        int32_t *deltas, V *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last_out, vexhip_grid *out, int64_t min_cols)
 {
     VEXHIP_REQUIRE(out && ndeltas && nvalues && ell_width && x_last_out, "NULL output");
     std::memset(out, 0, sizeof(*out));
@@ -850,7 +856,7 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     VEXHIP_TRY(hipMemsetAsync(d_set + 15, 0, sizeof(int) * 3, s));
     VEXHIP_TRY(hipMemsetAsync(d_vset, 0xff, sizeof(unsigned long long) * GB_VSLOTS, s));
     const long long probe_rows = std::min<long long>(rows, 8192), probe_first = (rows - probe_rows) / 2;
-    grid_probe_kernel<P><<<(unsigned)((probe_rows + 255) / 256), 256, 0, s>>>(ptr, col, val, probe_first, probe_rows, d_set, d_vset, d_vinfo);
+    grid_probe_kernel<P, V><<<(unsigned)((probe_rows + 255) / 256), 256, 0, s>>>(ptr, col, val, probe_first, probe_rows, d_set, d_vset, d_vinfo);
     VEXHIP_LAUNCH_CHECK();
     int set[18];
     VEXHIP_TRY(hipMemcpyAsync(set, d_set, sizeof(set), hipMemcpyDeviceToHost, s));
@@ -865,6 +871,7 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     if (nz < 4 && !force) return 0;
     grid_geometry geo;
     if (!grid_geometry_for(dev, nx, ny, nz, &geo)) return 0;
+    if (!std::is_same<V, double>::value && (nx != 512 || geo.segs != 1 || ny < 4 || ny % 2 != 0 || rows % 512 != 0 || (lines < 64 && !force))) return 0;
     trace.mark("  grid: probe");
 
     // ---- the pass ----
@@ -887,7 +894,7 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     long long per_cu = std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)(lds + 2048)));
     if (const char *e = std::getenv("VEXHIP_GRID_BUILD_WGS")) per_cu = std::max(1, std::atoi(e));
     const unsigned wgs = (unsigned)std::min<long long>(lines, cus * per_cu);
-    grid_build_kernel<P><<<wgs, 256, lds, s>>>(ptr, col, val, g);
+    grid_build_kernel<P, V><<<wgs, 256, lds, s>>>(ptr, col, val, g);
     VEXHIP_LAUNCH_CHECK();
     std::vector<unsigned char> ctl(ctl_bytes);
     VEXHIP_TRY(hipMemcpyAsync(ctl.data(), d_ctl.p, ctl_bytes, hipMemcpyDeviceToHost, s));
@@ -907,16 +914,16 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     const int hot = (int)(std::max_element(uses, uses + nclasses) - uses);
     if ((lines - uses[hot]) * 4 > lines && !force) return 0;
     // the tables the products read: values by code (0.0 behind the last: code 255 reads it), diagonals sorted
-    std::vector<double> vals(256, 0.0);
+    std::vector<V> vals(256, V(0));
     for (int k = 0; k < GB_VSLOTS; ++k)
-        if (h_vstate[k] == 2 && h_vcodes[k] >= 0 && h_vcodes[k] < nv) std::memcpy(&vals[(size_t)h_vcodes[k]], &h_vkeys[k], sizeof(double));
+        if (h_vstate[k] == 2 && h_vcodes[k] >= 0 && h_vcodes[k] < nv) { double v; std::memcpy(&v, &h_vkeys[k], sizeof(double)); vals[(size_t)h_vcodes[k]] = (V)v; }
     const long long by_pos[7] = {-far, -nx, -1, 0, 1, nx, far};
     std::vector<int> dl;
     for (int p = 0; p < 7; ++p) if (h_ints[GBI_POSMASK] & (1 << p)) dl.push_back((int)by_pos[p]);
     const int nd = (int)dl.size();
     if (nd < 1) return 0;
     dl.resize(256, INT_MAX);
-    VEXHIP_TRY(hipMemcpyAsync(values, vals.data(), sizeof(double) * 256, hipMemcpyHostToDevice, s));
+    VEXHIP_TRY(hipMemcpyAsync(values, vals.data(), sizeof(V) * 256, hipMemcpyHostToDevice, s));
     VEXHIP_TRY(hipMemcpyAsync(deltas, dl.data(), sizeof(int) * 256, hipMemcpyHostToDevice, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     grid_fill_plan(out, nx, ny, nz, geo, hot, nclasses, x_last);
@@ -934,10 +941,16 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
 // internal entry points of the direct build (spmat.hip)
 int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const double *val,
         int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols)
-{ return grid_build<int32_t>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
+{ return grid_build<int32_t, double>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
 int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val,
         int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols)
-{ return grid_build<long long>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
+{ return grid_build<long long, double>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
+int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const float *val,
+        int32_t *deltas, float *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols)
+{ return grid_build<int32_t, float>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
+int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const float *val,
+        int32_t *deltas, float *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols)
+{ return grid_build<long long, float>(dev, stream, rows, ptr, col, val, deltas, values, ndeltas, nvalues, ell_width, x_last, out, min_cols); }
 
 } // namespace vexhip
 

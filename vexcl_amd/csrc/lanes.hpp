@@ -35,6 +35,7 @@ __device__ __forceinline__ double keep_bit(double v, unsigned bits, int pos) {
 
 // fp32 (plane32.hip): a lane owns FOUR adjacent rows as one 16-byte quad
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));    // a quad at any element (16-byte requests at 4-byte addresses)
 __device__ __forceinline__ float shift_from_lower_lane(float v, float edge) {          // lane i <- lane i - 1, lane 0 <- edge
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }

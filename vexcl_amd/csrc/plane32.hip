@@ -59,6 +59,21 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
     // ---- a dictionary block -> values (into s_other) and validity (returned) of this lane's four rows at the seven positions ----
     const int wp = (pd.w + 1) >> 1;
     auto decode = [&](int blk) -> unsigned {
+        if (pd.pitch > 0) {                      // the matrix stored by grid line (grid.hip): a value code per position and row, 255 = no entry
+            const char *tb = pool + (long long)blk * 7 * pd.pitch + 4 * t;
+            unsigned bits = 0;
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const unsigned c4 = *reinterpret_cast<const unsigned *>(tb + (long long)p * pd.pitch);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned code = (c4 >> (8 * r)) & 255u;
+                    s_other[4 * p + r][t] = s_value[code];            // entry 255 of the value table is 0.0
+                    bits |= (code != 255u ? 1u : 0u) << (4 * p + r);
+                }
+            }
+            return bits;
+        }
         // a code block: per pair of ELL columns 256 words of diagonal codes, then as many of value codes; word i holds rows 2i, 2i + 1
         const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blk * ((long long)wp * 2048)) + 2 * t;
         unsigned dcw[4][2], vcw[4][2];
@@ -115,7 +130,7 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
     };
     auto ld = [&](int zz, int l) -> f4 {
         const char *p = reinterpret_cast<const char *>(x + (long long)line_of(zz, l) * PL_ROWS);
-        return *reinterpret_cast<const f4 *>(p + lane_b);
+        return *reinterpret_cast<const f4u *>(p + lane_b);
     };
     auto edge = [&](int zz, int l) -> float {
         long long i = (long long)line_of(zz, l) * PL_ROWS + (edge_b >> 2);
@@ -125,7 +140,7 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
     auto yold = [&](int zz, int l) -> f4 {
         int li = zz * ny + (y0 + l);
         li = li < 0 ? 0 : li; li = li >= nslices ? nslices - 1 : li;
-        return *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(y + (long long)li * PL_ROWS) + lane_b);
+        return *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(y + (long long)li * PL_ROWS) + lane_b);
     };
 
     // ---- state at the top of the step for plane z: as in plane.hip ----
@@ -242,7 +257,7 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
                 }
                 f4 o; o.x = alpha * s[0]; o.y = alpha * s[1]; o.z = alpha * s[2]; o.w = alpha * s[3];
                 if (APPEND) o = Yo[l] + o;
-                __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(reinterpret_cast<char *>(y + (long long)li * PL_ROWS) + lane_b));
+                *reinterpret_cast<f4u *>(reinterpret_cast<char *>(y + (long long)li * PL_ROWS) + lane_b) = o;
             }
         }
 #pragma unroll
@@ -272,11 +287,12 @@ int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alp
 {
     VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
     VEXHIP_REQUIRE(n > 0 && n % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
-    VEXHIP_REQUIRE(plane->table_pitch == 0, "the fp32 plane product reads SELL-512 code blocks");
+    VEXHIP_REQUIRE(plane->table_pitch == 0 || plane->table_pitch >= PL_ROWS + 2, "bad plane plan (table pitch)");
     VEXHIP_REQUIRE(plane->lines_per_plane >= 4 && plane->lines_per_plane % 2 == 0 && plane->depth >= 1 && plane->planes >= 1
                    && (plane->x_last + 1) % PL_ROWS == 0
                    && ((long long)plane->depth + 4) * plane->lines_per_plane * P32_LINE_B < (1ll << 32), "bad plane plan");
-    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "plane product: x and y must be 16-byte aligned");
+    // (x and y may start at any element: 16-byte requests at 4-byte addresses are served, a matrix stored by grid line has no
+    //  other product to fall back on)
     VEXHIP_SET_DEVICE(dev);
     plane_dev pd;
     pd.nslices = n / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
@@ -291,7 +307,7 @@ int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alp
     }
     if (const char *e = std::getenv("VEXHIP_PLANE32_DEPTH")) if (std::atoi(e) > 0) pd.depth = std::min(std::atoi(e), (int)plane->planes);
     pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
-    pd.pitch = 0;
+    pd.pitch = plane->table_pitch;
     const long long chunks = (pd.nz + pd.depth - 1) / pd.depth;
     const long long grid = 8ll * pd.tpx * chunks;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");

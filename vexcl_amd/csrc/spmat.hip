@@ -46,6 +46,10 @@ int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, cons
         int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols);
 int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const double *val,
         int32_t *deltas, double *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols);
+int grid_build_p32(int dev, void *stream, int64_t rows, const int32_t *ptr, const int32_t *col, const float *val,
+        int32_t *deltas, float *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols);
+int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, const int32_t *col, const float *val,
+        int32_t *deltas, float *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last, vexhip_grid *out, int64_t min_cols);
 int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_plane *out);
 int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
         const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane, halo_dev H);
@@ -248,29 +252,34 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     // A 7-point pattern on a grid with a handful of distinct values: stored by grid line in ONE pass over the CSR arrays (grid.hip
     // grid_build: no ELL analysis, no table pass, no per-slice codes, no dictionary, no plans from read-backs).  Declined
     // (usable = 0, after a probe of a few thousand rows in most cases): the SELL-512 set-up below.
-    if constexpr (std::is_same<V, double>::value) {
-        if ((format == VEXHIP_SPMAT_AUTO || format == VEXHIP_SPMAT_SELL8V) && A->nnz > 0
-            && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE | VEXHIP_SPMAT_NO_GRID_BUILD))) {
-            V *vals = nullptr;
-            if (int rc = dmalloc(&A->deltas, 256)) return rc;
-            if (int rc = dmalloc(&vals, 256)) return rc;
-            A->values = vals;
-            int nd = -1, nv = -1; int64_t gw = 0, x_last = -1;
-            int rc;
-            if constexpr (p64) rc = grid_build_p64(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid, min_cols);
-            else rc = grid_build_p32(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid, min_cols);
-            if (rc) return rc;
-            trace.mark("grid build");
-            if (A->grid.usable) {
+    // (fp32, round 5: where the fp32 plane product applies -- 512-point lines; the build declines other line lengths behind its probe)
+    if ((format == VEXHIP_SPMAT_AUTO || format == VEXHIP_SPMAT_SELL8V) && A->nnz > 0
+        && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE | VEXHIP_SPMAT_NO_GRID_BUILD))
+        && (std::is_same<V, double>::value || !std::getenv("VEXHIP_NO_PLANE512"))) {
+        V *vals = nullptr;
+        if (int rc = dmalloc(&A->deltas, 256)) return rc;
+        if (int rc = dmalloc(&vals, 256)) return rc;
+        A->values = vals;
+        int nd = -1, nv = -1; int64_t gw = 0, x_last = -1;
+        int rc;
+        if constexpr (p64) rc = grid_build_p64(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid, min_cols);
+        else rc = grid_build_p32(dev, stream, n, ptr, col, val, A->deltas, vals, &nd, &nv, &gw, &x_last, &A->grid, min_cols);
+        if (rc) return rc;
+        trace.mark("grid build");
+        if (A->grid.usable) {
+            if (!std::getenv("VEXHIP_NO_PLANE512"))
+                if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
+            trace.mark("plane plan");
+            if (std::is_same<V, double>::value || A->plane.usable) {
                 A->ndeltas = nd; A->nvalues = nv; A->ell_w = gw; A->tail = 0; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
-                if (!std::getenv("VEXHIP_NO_PLANE512"))
-                    if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
-                trace.mark("plane plan");
                 return 0;
             }
-            (void)hipFree(A->deltas); A->deltas = nullptr;
-            (void)hipFree(A->values); A->values = nullptr;
+            // fp32 without a plane plan (x shorter than whole lines, ...): no product reads these tables -- the SELL-512 set-up
+            (void)vexhip_sell8_grid_release(dev, &A->grid);
+            std::memset(&A->grid, 0, sizeof(A->grid)); std::memset(&A->plane, 0, sizeof(A->plane));
         }
+        (void)hipFree(A->deltas); A->deltas = nullptr;
+        (void)hipFree(A->values); A->values = nullptr;
     }
     int64_t w = 0, tail = 0;
     if (format != VEXHIP_SPMAT_CSR && A->nnz > 0)
@@ -404,10 +413,10 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
                     && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
                     return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
                                                             A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
-            if constexpr (std::is_same<V, float>::value)       // fp32: the same storage, four rows per lane (plane32.hip)
-                if (A->blocks && !A->direct && A->plane.usable && A->plane.table_pitch == 0 && g_sell8_variant == 0 && !A->tail
-                    && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
-                    return vexhip_spmv_sell8v_plane_f32_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, (const float *)A->values, x, y, &A->plane);
+            if constexpr (std::is_same<V, float>::value)       // fp32: the same storage, four rows per lane (plane32.hip); x and y may start at any element
+                if ((A->blocks || A->direct) && A->plane.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
+                    return vexhip_spmv_sell8v_plane_f32_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
+                                                            A->direct ? A->grid.line_class : A->blocks, A->deltas, (const float *)A->values, x, y, &A->plane);
             if constexpr (std::is_same<V, double>::value)
                 if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
                     return vexhip_spmv_sell8v_grid_f64(A->dev, stream, A->n, alpha, append, (const double *)A->values, x, y, &A->grid);
