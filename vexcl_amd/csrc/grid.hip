@@ -159,7 +159,7 @@ void grid_line_verify_kernel(codes_dev cd, long long lines, int nx, int pitch, c
 #endif
 constexpr int GB_PIECE = VEXHIP_GB_PIECE;     // rows staged at a time
 constexpr int GB_CAP = 8 * GB_PIECE;          // entries of a piece (rows with more than 8 entries have no place in this storage)
-constexpr int GB_CHUNK = 8;                   // entries a lane requests together while staging a piece
+constexpr int GB_CHUNK = GB_CAP / 256;        // entries a lane requests together: a whole piece in one round (16)
 constexpr int GB_VSLOTS = 512;                // hash of the values: LDS per workgroup, and the device-wide table behind it
 constexpr int GB_KEYS = 1024;                 // device-wide table of line hashes
 constexpr int GB_KNOWN = 128;                 // classes a workgroup remembers
@@ -216,7 +216,7 @@ __device__ int gb_global_value_code(unsigned long long bits, const gb_dev &g)
 
 // V: the matrix values (double / float; a float is coded by the bits of the double it converts to -- exactly, both ways)
 template <typename P, typename V>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 4)                // four workgroups per CU (the LDS allows no fifth): 128 registers
 void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, const V *__restrict__ val, gb_dev g)
 {
     extern __shared__ unsigned char gb_lds[];
@@ -242,24 +242,61 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
     long long line = blockIdx.x; int pc = 0;
     unsigned long long hsum = 0;
     bool bad = false;
+
+    // Round 5: the pass is bound by the LATENCY of its dependent steps per line (row bounds -> entries -> codes -> rows -> class ->
+    // table), four workgroups per CU to hide it (2 / 3 / 4 per CU: 6.3 / 4.6 / 4.0 ms at 512^3; the float arrays, a third fewer
+    // bytes, take no less).  So the entries of the NEXT piece are requested as soon as the staging has emptied the registers of
+    // this one -- all of a piece in one round, GB_CHUNK = 16 entries per lane -- and its row bounds one step earlier; they arrive
+    // while the rows of this piece are coded and the line is classed.  The barriers in between order LDS traffic only (gb_barrier):
+    // a __syncthreads() waits for every outstanding load of the wave.
+    auto gb_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto load_bounds = [&](long long ln, int p, long long &e0_, long long &cnt64_, long long (&mp)[3]) {
+        const int r0_ = p * GB_PIECE;
+        const int rows_ = g.nx - r0_ < GB_PIECE ? g.nx - r0_ : GB_PIECE;
+        const long long at = ln * g.nx + r0_;
+        e0_ = (long long)ptr[at];
+        cnt64_ = (long long)ptr[at + rows_] - e0_;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = t + 256 * u; mp[u] = i <= rows_ ? (long long)ptr[at + i] : 0; }
+    };
+    int n_c[GB_CHUNK]; V n_v[GB_CHUNK];
+    // (buffer requests: the piece's first entry is the base -- scalar --, the lane's offset ONE register for all sixteen requests,
+    //  the range check gives the lanes beyond the piece's last entry zeros.  Flat addressing took two registers per request: 160
+    //  in all, one workgroup per CU fewer.)
+    auto load_entries = [&](long long e0_, int cnt_) {
+        const long long eu = ((long long)__builtin_amdgcn_readfirstlane((int)(e0_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)e0_);
+        const int cu = __builtin_amdgcn_readfirstlane(cnt_ > 0 ? cnt_ : 0);
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(col + eu), 0, cu * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(val + eu), 0, cu * (int)sizeof(V), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < GB_CHUNK; ++u) {
+            n_c[u] = __builtin_amdgcn_raw_buffer_load_b32(rc, 4 * t, 1024 * u, 0);
+            if constexpr (sizeof(V) == 8) n_v[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(rv, 8 * t, 2048 * u, 0));
+            else n_v[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(rv, 4 * t, 1024 * u, 0));
+        }
+    };
+    long long e0 = 0, cnt64 = 0, my_ptr[3] = {0, 0, 0};
+    int cnt = 0;
+    if (line < g.lines) {
+        load_bounds(line, pc, e0, cnt64, my_ptr);
+        cnt = (cnt64 < 0 || cnt64 > GB_CAP) ? -1 : (int)cnt64;
+        load_entries(e0, cnt);
+    }
     while (line < g.lines) {
         const int r0 = pc * GB_PIECE;
         const int rows = g.nx - r0 < GB_PIECE ? g.nx - r0 : GB_PIECE;
         const long long row_l = line * g.nx;
         long long nline = line; int npc = pc + 1;
         if (npc == g.pieces) { nline = line + gridDim.x; npc = 0; }
-        // the piece's bounds (uniform) and its rows' (one or two per lane); requested before the barrier, used behind it
-        const long long e0 = (long long)ptr[row_l + r0];
-        const long long cnt64 = (long long)ptr[row_l + r0 + rows] - e0;
-        const int cnt = (cnt64 < 0 || cnt64 > GB_CAP) ? -1 : (int)cnt64;
-        long long my_ptr[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) { const int i = t + 256 * u; my_ptr[u] = i <= rows ? (long long)ptr[row_l + r0 + i] : 0; }
+        // the NEXT piece's bounds (uniform) and its rows' (one to three per lane): requested now, used behind the staging
+        long long e0n = 0, cnt64n = 0, my_ptr_n[3] = {0, 0, 0};
+        const bool more = nline < g.lines;
+        if (more) load_bounds(nline, npc, e0n, cnt64n, my_ptr_n);
 
         // another workgroup gave up?  ONE lane looks and the workgroup leaves together (every lane loading the flag for itself could
         // split the workgroup: lanes that leave while the others wait at the barrier below and go on with a stale s_red)
         if (pc == 0 && t == 0) s_red[7] = __hip_atomic_load(&g.ints[GBI_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1ull : 0ull;
-        __syncthreads();                                        // the previous trip is done with the staged entries and with the line's rows (compared / copied)
+        gb_barrier();                                           // the previous trip is done with the staged entries and with the line's rows (compared / copied)
         if (pc == 0 && s_red[7]) return;                        // uniform
         if (pc == 0) {
             for (int i = t; i < 7 * g.pitch; i += 256) s_sig[i] = GR_ABSENT;       // (the rows below write into it behind the next barrier)
@@ -268,115 +305,136 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
         if (cnt < 0) bad = true;                                // uniform
 #pragma unroll
         for (int u = 0; u < 3; ++u) { const int i = t + 256 * u; if (i <= rows) s_ptr[i] = my_ptr[u]; }
-        // GB_CHUNK entries per lane are requested together (14 dependent round trips per piece otherwise), then coded and staged
-        for (int base = 0; base < cnt; base += GB_CHUNK * 256) {
-            int n_c[GB_CHUNK]; double n_v[GB_CHUNK];
-#pragma unroll
-            for (int u = 0; u < GB_CHUNK; ++u) {
-                const int k = base + t + 256 * u;
-                n_c[u] = 0; n_v[u] = 0.0;
-                if (k < cnt) { n_c[u] = col[e0 + k]; n_v[u] = (double)val[e0 + k]; }
-            }
+        // the piece's entries (requested one trip ago): coded and staged.  The first probe of the workgroup's value hash almost
+        // always decides: that much is straight-line code for all sixteen entries (an empty slot holds code 255, so does a slot with
+        // another value's bits); whatever is still uncoded -- a collision in the hash, a value this workgroup has not met, the
+        // bits that mean "empty" -- is settled behind ONE vote per piece.
+        bool open_ = false;
 #pragma unroll
         for (int u = 0; u < GB_CHUNK; ++u) {
-            const int k = base + t + 256 * u;
-            const bool active = k < cnt;
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(n_v[u]);
-            unsigned code = 255;
-            if (active) {
-                // (the first probe almost always decides: straight-line code for it, the walk only behind a collision)
-                unsigned h = gb_vhash(bits);
-                unsigned long long key = s_vkey[h];
-                if (key == bits) code = s_vcode[h];
-                else if (key != ~0ull) {
-                    for (int probe = 1; probe < GB_VSLOTS; ++probe) {
-                        h = (h + 1) & (GB_VSLOTS - 1);
-                        key = s_vkey[h];
-                        if (key == bits) { code = s_vcode[h]; break; }
-                        if (key == ~0ull) break;
-                    }
-                }
-                if (bits == ~0ull) { bad = true; code = 254; }
+            const int k = t + 256 * u;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong((double)n_v[u]);
+            const unsigned h = gb_vhash(bits);
+            const unsigned code = s_vkey[h] == bits ? (unsigned)s_vcode[h] : 255u;
+            if (k < cnt) {
+                s_c[k] = n_c[u]; s_vc[k] = (unsigned char)code;      // (255: settled below, the lane re-reads its own byte)
+                open_ = open_ || code == 255u;
                 maxcol = n_c[u] > maxcol ? n_c[u] : maxcol;
             }
-            // values this workgroup has not met: one look-up in the device-wide table per distinct value and wave
-            unsigned long long miss = __ballot(active && code == 255);
-            while (miss) {
-                const int leader = __ffsll((long long)miss) - 1;
-                const unsigned long long lb = __shfl(bits, leader, 64);
-                int cglob = 0;
-                if (lane == leader) {
-                    cglob = gb_global_value_code(lb, g);
-                    if (cglob >= 0) {                           // into the workgroup's hash
-                        unsigned h = gb_vhash(lb);
+        }
+        if (__ballot(open_)) {                                  // (per wave)
+#pragma unroll 1
+            for (int u = 0; u < GB_CHUNK; ++u) {
+                const int k = t + 256 * u;
+                const bool active = k < cnt;
+                // (dynamic index into the register array: a select chain, this path runs a few times per workgroup)
+                unsigned long long bits = 0;
+#pragma unroll
+                for (int v = 0; v < GB_CHUNK; ++v) if (v == u) bits = (unsigned long long)__double_as_longlong((double)n_v[v]);
+                unsigned cd = active ? (unsigned)s_vc[k] : 0u;
+                if (active && cd == 255u) {
+                    if (bits == ~0ull) { bad = true; cd = 254; }
+                    else {
+                        unsigned h = gb_vhash(bits);
                         for (int probe = 0; probe < GB_VSLOTS; ++probe) {
-                            const unsigned long long old = atomicCAS(&s_vkey[h], ~0ull, lb);
-                            if (old == ~0ull || old == lb) { s_vcode[h] = (unsigned char)cglob; break; }
+                            const unsigned long long key = s_vkey[h];
+                            if (key == bits) { cd = s_vcode[h]; break; }
+                            if (key == ~0ull) break;
                             h = (h + 1) & (GB_VSLOTS - 1);
                         }
                     }
                 }
-                cglob = __shfl(cglob, leader, 64);
-                if (cglob < 0) { if (active && code == 255) { bad = true; code = 254; } }              // the build is over: no further look-ups
-                else if (active && code == 255 && bits == lb) code = (unsigned)cglob;
-                miss = __ballot(active && code == 255);
-            }
-            if (active) { s_c[k] = n_c[u]; s_vc[k] = (unsigned char)code; }
-        }
-        }
-        __syncthreads();
-        if (cnt >= 0) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r = 2 * t + q;
-                if (r >= rows) continue;
-                const long long i = row_l + r0 + r;
-                const int b = (int)(s_ptr[r] - e0), e = (int)(s_ptr[r + 1] - e0);
-                unsigned long long sig = 0x00ffffffffffffffull;           // seven bytes of 255
-                int last = -1;
-                if (e - b > 8 || e < b || b < 0 || e > cnt) bad = true;
-                else {
-                    maxlen = e - b > maxlen ? e - b : maxlen;
-                    // eight predicated trips instead of a loop of e - b (per-lane trip counts: a scalar instruction per vector one)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = b + u;
-                        if (j < e) {
-                            const int d = s_c[j] - (int)i;                       // (rows and columns are below 2^31; a difference that wraps is no diagonal of the set)
-                            const int p = d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -g.nx ? 1 : d == g.nx ? 5 : d == -(int)g.far ? 0 : d == (int)g.far ? 6 : -1;
-                            const unsigned vc = s_vc[j];
-                            if (p <= last || vc >= 254u) bad = true;
-                            else {
-                                last = p;
-                                posmask |= 1u << p;
-                                sig ^= (unsigned long long)(255u ^ vc) << (8 * p);          // (the byte at p still holds 255: positions ascend)
+                // values this workgroup has not met: one look-up in the device-wide table per distinct value and wave
+                unsigned long long miss = __ballot(active && cd == 255u);
+                while (miss) {
+                    const int leader = __ffsll((long long)miss) - 1;
+                    const unsigned long long lb = __shfl(bits, leader, 64);
+                    int cglob = 0;
+                    if (lane == leader) {
+                        cglob = gb_global_value_code(lb, g);
+                        if (cglob >= 0) {                           // into the workgroup's hash
+                            unsigned h = gb_vhash(lb);
+                            for (int probe = 0; probe < GB_VSLOTS; ++probe) {
+                                const unsigned long long old = atomicCAS(&s_vkey[h], ~0ull, lb);
+                                if (old == ~0ull || old == lb) { s_vcode[h] = (unsigned char)cglob; break; }
+                                h = (h + 1) & (GB_VSLOTS - 1);
                             }
                         }
                     }
+                    cglob = __shfl(cglob, leader, 64);
+                    if (cglob < 0) { if (active && cd == 255u) { bad = true; cd = 254; } }              // the build is over: no further look-ups
+                    else if (active && cd == 255u && bits == lb) cd = (unsigned)cglob;
+                    miss = __ballot(active && cd == 255u);
                 }
-#pragma unroll
-                for (int p = 0; p < 7; ++p) s_sig[p * g.pitch + r0 + r] = (unsigned char)(sig >> (8 * p));
-                hsum += mix64(sig + 0x9e3779b97f4a7c15ull * (unsigned long long)(r0 + r + 1));
+                if (active) s_vc[k] = (unsigned char)cd;
             }
         }
-        if (pc + 1 < g.pieces) { line = nline; pc = npc; continue; }        // (same line, next piece)
+        // the next piece's entries, into the registers just emptied
+        const int cntn = (cnt64n < 0 || cnt64n > GB_CAP) ? -1 : (int)cnt64n;
+        if (more) load_entries(e0n, cntn);
+        gb_barrier();
+        if (cnt >= 0) {
+            // the lane's two rows, straight-line (selects instead of branches: per-lane trip counts cost a scalar instruction per
+            // vector one); the eighth trip only where a row of the wave has eight entries (a 7-point operator never does)
+            int rb[2], rl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * t + q;
+                const bool in = r < rows;
+                const int b = in ? (int)(s_ptr[r] - e0) : 0, e = in ? (int)(s_ptr[r + 1] - e0) : 0;
+                const bool fits = !(e - b > 8 || e < b || b < 0 || e > cnt);
+                if (!fits) bad = true;
+                rb[q] = fits ? b : 0; rl[q] = fits ? e - b : 0;
+                maxlen = rl[q] > maxlen ? rl[q] : maxlen;
+            }
+            const bool eighth = __ballot(rl[0] > 7 || rl[1] > 7) != 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * t + q;
+                const int i = (int)(row_l + r0 + r);                                   // (rows are below 2^31)
+                unsigned long long sig = 0x00ffffffffffffffull;           // seven bytes of 255
+                int last = -1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u == 7 && !eighth) break;                        // uniform
+                    const bool valid = u < rl[q];
+                    const int j = valid ? rb[q] + u : 0;
+                    const int d = s_c[j] - i;                            // (a difference that wraps is no diagonal of the set)
+                    const unsigned vc = s_vc[j];
+                    const int p = d == 0 ? 3 : d == -1 ? 2 : d == 1 ? 4 : d == -g.nx ? 1 : d == g.nx ? 5 : d == -(int)g.far ? 0 : d == (int)g.far ? 6 : -1;
+                    const bool ok = valid && p > last && vc < 254u;
+                    if (valid && !ok) bad = true;
+                    last = ok ? p : last;
+                    posmask |= ok ? 1u << (p & 7) : 0u;
+                    sig ^= ok ? (unsigned long long)(255u ^ vc) << (8 * (p & 7)) : 0ull;          // (the byte at p still holds 255: positions ascend)
+                }
+                if (r < rows) {
+#pragma unroll
+                    for (int p = 0; p < 7; ++p) s_sig[p * g.pitch + r0 + r] = (unsigned char)(sig >> (8 * p));
+                    hsum += mix64(sig + 0x9e3779b97f4a7c15ull * (unsigned long long)(r0 + r + 1));
+                }
+            }
+        }
+        if (pc + 1 < g.pieces) { e0 = e0n; cnt64 = cnt64n; cnt = cntn; my_ptr[0] = my_ptr_n[0]; my_ptr[1] = my_ptr_n[1]; my_ptr[2] = my_ptr_n[2]; line = nline; pc = npc; continue; }        // (same line, next piece)
 
         // ---- the line is complete: its hash, whether any lane met a row that does not fit, its class ----
         unsigned long long hs = hsum;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) hs += __shfl_xor(hs, o, 64);
         const unsigned long long anybad = __ballot(bad);
-        __syncthreads();
+        gb_barrier();
         if (lane == 0) { s_red[t >> 6] = hs; s_red[8 + (t >> 6)] = anybad ? 1 : 0; }
-        __syncthreads();
+        gb_barrier();
         if (t == 0) {
             int id = -2; int winner = 0; unsigned slot = 0;
+            int asked = 0;                                      // the device-wide table was consulted (first meeting of a class: a handful per workgroup)
             if (s_red[8] | s_red[9] | s_red[10] | s_red[11]) atomicOr(&g.ints[GBI_FLAGS], GB_BAD_ROW);
             else {
                 const unsigned long long key = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) | 1ull;      // never 0 (= empty)
                 // the classes this workgroup has met before (a handful): no device-wide traffic for them
                 for (int k = 0; k < known; ++k) if (s_kkey[k] == key) { id = s_kid[k]; break; }
                 if (id < 0) {
+                    asked = 1;
                     slot = (unsigned)(key >> 20) & (GB_KEYS - 1);
                     for (int probe = 0; probe < GB_KEYS; ++probe) {
                         unsigned long long old = __hip_atomic_load(&g.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -403,9 +461,11 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
                     if (id >= 0 && known < GB_KNOWN) { s_kkey[known] = key; s_kid[known] = id; ++known; }
                 }
             }
-            s_red[4] = (unsigned long long)(long long)id; s_red[5] = (unsigned long long)winner; s_red[6] = slot;
+            s_red[4] = (unsigned long long)(long long)id; s_red[5] = (unsigned long long)winner; s_red[6] = slot; s_red[12] = (unsigned long long)asked;
         }
-        __syncthreads();
+        gb_barrier();
+        // lane 0 has acquired a class number at agent scope: every wave orders its own loads of the class table behind that (rare)
+        if (s_red[12]) __syncthreads();                                                 // uniform
         const int id = (int)(long long)s_red[4];
         const bool winner = s_red[5] != 0;
         if (id < 0) return;                                                              // the build is over (a flag is set); uniform
@@ -431,7 +491,7 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
             if (__ballot(diff != 0) && lane == 0) atomicOr(&g.ints[GBI_FLAGS], GB_COLLISION);
         }
         if (t == 0) { g.line_class[line] = id; ++s_uses[id]; }
-        line = nline; pc = npc;
+        e0 = e0n; cnt64 = cnt64n; cnt = cntn; my_ptr[0] = my_ptr_n[0]; my_ptr[1] = my_ptr_n[1]; my_ptr[2] = my_ptr_n[2]; line = nline; pc = npc;
     }
     __syncthreads();
     for (int i = t; i < GB_MAX_CLASSES; i += 256) if (s_uses[i]) atomicAdd(&g.ints[GBI_USES + i], s_uses[i]);
