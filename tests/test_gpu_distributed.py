@@ -143,7 +143,7 @@ def _stencil_strip(torch, nx, ny, nz, r0, r1, dev):
     return ptr.to(torch.int32), col.to(torch.int32), val
 
 
-def _halo_worker(rank, world, port, planes_per_rank, out):
+def _halo_worker(rank, world, port, planes_per_rank, ny, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VEXHIP_PLANE_FORCE="1", VEXHIP_IPC_TIMEOUT_MS="20000")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -151,7 +151,7 @@ def _halo_worker(rank, world, port, planes_per_rank, out):
         from vexcl_amd.distributed import DistSpMat, partition
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        nx = ny = 512
+        nx = 512
         nz = planes_per_rank * world
         N = nx * ny * nz
         part = partition(N, world)
@@ -198,16 +198,21 @@ def _halo_worker(rank, world, port, planes_per_rank, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,planes", [(2, 8), (3, 8)])
-def test_one_launch_step_reads_ghost_planes_from_the_window(world, planes, built_lib):
+@pytest.mark.parametrize("world,planes,ny", [(2, 8, 512), (3, 8, 128)])
+def test_one_launch_step_reads_ghost_planes_from_the_window(world, planes, ny, built_lib):
     """Transport "halo" (round 5, csrc/halo.hpp; reference: the five phases of vexcl/spmat.hpp:120-185): every rank stores its strip
     with the two ghost planes, ONE plane-product launch pushes the boundary planes and reads the neighbours' from the peer-mapped
-    window.  Ranks share the GPU; 512 x 512 x (8 per rank) grid; 40 products back to back.  The result must have the BITS of the
-    one-device product of the whole matrix."""
+    window.  Ranks share the GPU; 512 x ny x (8 per rank) grid; 40 products back to back.  The result must have the BITS of the
+    one-device product of the whole matrix.
+    (Three ranks on ONE GPU run 128 lines per plane: the workgroups next to a ghost plane wait for the neighbour's launch while they
+    hold their CU slots -- 256 of them per ghost plane at 512 lines -- and the launches of three processes share the 768 slots of
+    the one device: a middle rank's 512 waiting workgroups and 256 of a neighbour that is one product ahead can leave no slot for
+    the third rank's push, and all of them sit there until the time-out.  With a GPU per rank a launch only ever waits for
+    launches on OTHER devices; the stand-in is kept below the device's capacity.)"""
     ctx = mp.get_context("spawn")
     out = ctx.Array("i", [0] * world)
     port = _free_port()
-    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, planes, out)) for r in range(world)]
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, planes, ny, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -9,6 +9,10 @@
 //                                         ghost plane -- only the SHORT chunks next to the two ghost planes ever do (dispatched
 //                                         behind the main chunks, which stream the bulk of the strip meanwhile);
 //   a one-thread kernel behind it       : raises `consumed` at the owners of the ghost planes and advances the step number.
+// A launch waits only for launches of OTHER ranks, and a rank runs its products one after the other: with a GPU per rank nothing
+// a launch waits for competes with it for CUs.  Ranks that SHARE a GPU (the one-device stand-ins of the tests and of
+// `bench.py --one-device`) do: the waiting workgroups of all ranks must leave room for the pushes they wait for -- up to 256 per
+// ghost plane at 512 lines per plane against 768 resident workgroups; two ranks always fit, three only with shorter planes.
 #pragma once
 #include "common.hpp"
 
