@@ -645,6 +645,19 @@ def test_two_dimensional_five_point_operators(T, oracle, built_lib):
                     A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
                     assert torch.equal(ya, yb), (W, H, alpha, direct)
                     assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (W, H, alpha, direct)
+            # the same operator in fp32: the fp32 plane product where rows are virtual 512-point lines, the pair product elsewhere
+            f32 = np.float32
+            v32, x32, y32 = val.astype(f32), xb.astype(f32), y0.astype(f32)
+            want32 = oracle.spmv_csr(ptr, col, v32, x32)
+            for direct in (True, False):
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), direct=direct)
+                assert (A.plane is not None) == plane, (W, H, direct, A.plane, A.grid)
+                if plane:
+                    assert A.direct == direct and A.plane["lines_per_plane"] == W // 512 and A.plane["planes"] == H, (W, H, direct, A.plane)
+                for alpha, append in ((1.0, False), (-0.75, True)):
+                    ya = T.up(y32.copy())
+                    A.apply(T.up(x32), ya, alpha, append)
+                    assert np.array_equal(ya.cpu().numpy(), (y32 + f32(alpha) * want32) if append else f32(alpha) * want32), (W, H, alpha, direct, "fp32")
     finally:
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
 
