@@ -326,9 +326,20 @@ def unstructured_rows(torch, ops, dev, args):
             "rows": n3, "nnz": nnz3, "storage": A.storage, "plane_plan": A.plane, "ms": round(t, 5), "gflops": round(2.0 * nnz3 / t / 1e6, 1),
             "bit_identical_to_csr_loop": same,
             "roofline": {"bound": "hbm", "bytes_per_launch": moved, "achieved": round(moved / t / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(moved / t / 1e6 / HBM_PEAK_GBPS, 4), "what": "stored matrix (4 B per line + the dictionary) + x once + y once, 4-byte elements"}}
+                         "frac": round(moved / t / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "what": "stored matrix (4 B per line + the class tables) + x once + y once, 4-byte elements"}}
         del A, x3, y3
         torch.cuda.empty_cache()
+        if not args.no_pmc:
+            tr, how = measure_traffic(g, only="fp32", names=("sell8_plane_f32_kernel", "sell8_march_kernel", "sell8_pair_kernel"))
+            rf = rows["SpMV fp32 Poisson %d^3 (y = A*x, default vexhip_spmat)" % g]["roofline"]
+            rf["traffic_source"] = how
+            if tr:
+                ks = {k: v for k, v in tr.items() if isinstance(v, dict)}
+                total = sum(v["total"] for v in ks.values())
+                rf["traffic"] = total
+                rf["traffic_kernels"] = ks
+                rf["traffic_over_bytes_per_launch"] = round(total / float(moved), 3)
     except AssertionError:
         raise
     except Exception as e:  # noqa: BLE001 -- a secondary row

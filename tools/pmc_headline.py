@@ -2,7 +2,7 @@
 """Workload of bench.py's counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): a calibration stream of known
 size (2 GiB read with 16-byte loads by the reduction kernel), then three products with each storage of the 512^3
 matrices bench.py times -- the default SpMat on the Poisson matrix (value codes), on the variable-coefficient matrix
-(diagonal codes + fp64 values), 32-bit columns, and the CSR arrays.  Counter values are read per dispatch from
+(diagonal codes + fp64 values), 32-bit columns, and the CSR arrays; PMC_ONLY=fp32: the Poisson matrix in float.  Counter values are read per dispatch from
 rocprofv3's CSV by bench.py (measure_traffic)."""
 import os
 import sys
@@ -41,6 +41,21 @@ if unstructured:
         torch.cuda.synchronize()
         del A, p_, c_, v_
         torch.cuda.empty_cache()
+    print("done")
+    sys.exit(0)
+if "fp32" in only:
+    # round 5: the headline operator in float (bench.py's fp32 row): three products with the default storage
+    del x, y
+    ptr, col, val = ops.poisson3d(n, dev)
+    v32 = val.to(torch.float32)
+    del val
+    xf = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42).to(torch.float32)
+    yf = torch.zeros(N, dtype=torch.float32, device=dev)
+    A = ops.SpMat(ptr, col, v32)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        A.apply(xf, yf)
+    torch.cuda.synchronize()
     print("done")
     sys.exit(0)
 ptr, col, val = ops.poisson3d(n, dev)
