@@ -428,7 +428,7 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
     """The grid product (round 4, grid.hip: the plane walk for grid lines of ANY length -- the matrix re-expressed by grid line,
     a class per line) against the pair / streamed products AND the CSR restatement, bit for bit: the benchmark's operator on
     96^3 and 125^3 (odd line length: 16-byte requests at 8-byte addresses; odd lines per plane: the last tile stores one line),
-    lines longer than 512 (two segments), 384- and 500-point lines, natural boundaries (nine line classes, explicit zeros),
+    lines longer than 512 (one segment up to 1024 points, two beyond), 384- and 500-point lines, natural boundaries (nine line classes, explicit zeros),
     full bands whose +-1 diagonal crosses the line ends, a ragged last plane, several walk depths, '=' and '+= alpha',
     Inf / NaN in x under absent entries; and what the plan declines."""
     torch = T.torch
@@ -453,7 +453,7 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
                 A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct)
                 assert A.storage == "sell8v" and A.grid is not None and A.plane is None and A.direct == direct, (shape, direct, A.storage, A.dictionary_blocks)
                 assert (A.grid["nx"], A.grid["lines_per_plane"]) == shape[:2] and A.grid["x_last"] == m - 1, (shape, A.grid)
-                assert A.grid["segments"] == ((shape[0] + 511) // 512 if shape[0] <= 768 else (shape[0] + 1023) // 1024) and (depth is None or A.grid["depth"] == min(depth, A.grid["planes"])), (shape, A.grid)
+                assert A.grid["segments"] == (shape[0] + 1023) // 1024 and (depth is None or A.grid["depth"] == min(depth, A.grid["planes"])), (shape, A.grid)
                 if classes is not None:
                     assert A.grid["classes"] == classes, (shape, A.grid)
                 for alpha, append in ((1.0, False), (-0.75, True)):
@@ -471,7 +471,9 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
             ptr, col, val = oracle.poisson3d(n)
             check(ptr, col, val, (n, n, n), 31, classes=2)
         for shape, depth in (((70, 33, 20), None), ((70, 33, 20), 3), ((1030, 6, 8), None), ((1030, 6, 8), 5), ((384, 10, 12), None),
-                             ((500, 7, 11), 4), ((127, 17, 19), 7), ((514, 5, 13), None)):
+                             ((500, 7, 11), 4), ((127, 17, 19), 7), ((514, 5, 13), None),
+                             # (round 5: 513 .. 1024 points in ONE segment -- workgroups of 5 .. 8 waves)
+                             ((640, 6, 9), None), ((700, 5, 8), 3), ((1000, 4, 7), 2), ((1024, 6, 6), None)):
             ptr, col, val = _grid7(*shape)
             check(ptr, col, val, shape, 33, depth, classes=2)
         # natural boundaries: nine line classes, the other class changes along every walk; explicit zeros in plane 1

@@ -786,10 +786,11 @@ bool grid_geometry_for(int dev, long long nx, long long ny, long long nz, grid_g
 // (host arithmetic only: vexhip_sell8_grid_geometry exposes it so that the plans of every line length can be checked without a device)
 bool grid_geometry_with(long long cus, long long nx, long long ny, long long nz, grid_geometry *geo)
 {
-    // lines of up to 1024 points in one segment (workgroups of up to 512 lanes), longer ones in segments of <= 1024 rows
-    // (640^3 / 700^3: one 640- / 700-row segment = 1.26 / 1.55 ms -- few waves per CU -- against 0.97 / 1.37 ms in two segments;
-    //  1024^3 in one segment: 3.31 ms, 0.65 of 8 TB/s.  VEXHIP_GRID_SEGMENT = 512 | 1024 overrides.)
-    long long max_seg = nx > 768 ? 1024 : 512;
+    // lines of up to 1024 points in ONE segment (workgroups of up to 512 lanes), longer ones in segments of <= 1024 rows.
+    // (Round 4 cut 513 .. 768-point lines in two: 640^3 / 700^3 in one segment took 1.26 / 1.63 ms against 0.98 / 1.51 ms in two --
+    //  but only because one segment was given ONE walk per tile; with the walks chosen below it takes 0.874 / 1.27 ms,
+    //  profiles/r05_grid_long_lines.json.  VEXHIP_GRID_SEGMENT = 512 | 1024 overrides.)
+    long long max_seg = nx > 512 ? 1024 : 512;
     if (const char *e = std::getenv("VEXHIP_GRID_SEGMENT")) max_seg = std::atoi(e) == 1024 ? 1024 : 512;
     const long long segs = (nx + max_seg - 1) / max_seg;
     long long seg_len = (nx + segs - 1) / segs; seg_len += seg_len & 1;
@@ -813,15 +814,32 @@ bool grid_geometry_with(long long cus, long long nx, long long ny, long long nz,
     // CU) where that is below 6.
     const long long wpw = threads / 64;
     long long chunks = 1;
-    {
+    if (threads <= 256) {
         double best = 0;
-        const long long resident = std::max(1ll, (threads > 256 ? 12 : 16) / wpw);       // workgroups a CU holds at once (138 / 128 registers per lane)
+        const long long resident = std::max(1ll, 16 / wpw);       // workgroups a CU holds at once (128 registers per lane)
         for (long long c = 1; c <= std::max(1ll, nz / 8); ++c) {
             const long long per_cu = (tiles * c + cus - 1) / cus;
             if (c > 1 && per_cu > resident) break;              // a second round of workgroups walks out of step with the first
             double est = (double)per_cu * (double)((nz + c - 1) / c + 6);
             if (per_cu * wpw < 6) est *= 6.0 / (double)(per_cu * wpw);
             if (c == 1 || est < best) { best = est; chunks = c; }
+        }
+    } else {
+        // Round 5 -- workgroups of 5 .. 8 waves (lines of 513 .. 1024 points): a CU holds two or three of them and a plane has
+        // 1.25 .. 2 tiles per CU, so ONE walk per tile leaves half of the CUs with twice the work of the others (640^3: 1.25 ms).
+        // Many short walks even that out through the dispatcher: at least six workgroups per CU, then the same estimate (rounds x
+        // (planes per walk + 6)), ties to the shorter walk.  Measured (profiles/r05_grid_long_lines.json, ms by walk depth):
+        //   640^3  640 / 160 / 80 / 40    1.252 / 0.875 / 0.874 / 0.891        768^3  768 / 192 / 96 / 48     1.728 / 1.408 / 1.425 / 1.429
+        //   700^3  700 / 175 / 88 / 44    1.628 / 1.316 / 1.270 / 1.277        800^3  800 / 200 / 80 / 40     2.049 / 1.814 / 1.694 / 1.701
+        //   900^3  450 / 150 / 90 / 45    2.704 / 2.572 / 2.546 / 2.537        1024^3 256 / 171 / 128 / 64    3.317 / 3.359 / 3.365 / 3.523
+        double best = 0;
+        const long long cmax = std::max(1ll, nz / 16);
+        for (long long c = 1; c <= cmax; ++c) {
+            const long long per_cu = (tiles * c + cus - 1) / cus;
+            if (per_cu < 6 && c < cmax) continue;
+            const double est = (double)per_cu * (double)((nz + c - 1) / c + 6);
+            if (best == 0 || est <= best * 1.01) { if (best == 0 || est < best) best = est; chunks = c; }
+            if (per_cu > 24) break;
         }
     }
     long long depth = (nz + chunks - 1) / chunks;
@@ -1018,27 +1036,28 @@ using namespace vexhip;
 
 extern "C" {
 
+#define GP_DECLINE(k) do { if (std::getenv("VEXHIP_DEBUG")) std::fprintf(stderr, "grid plan from the SELL-512 storage: declined at check %d (grid.hip:%d)\n", (k), __LINE__); return 0; } while (0)
 int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const void *codes, const int32_t *blocks,
         int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes, int64_t x_last, vexhip_grid *out)
 {
     VEXHIP_REQUIRE(out, "NULL output");
     std::memset(out, 0, sizeof(*out));
     const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
-    if (std::getenv("VEXHIP_NO_GRID")) return 0;
-    if (value_bytes != 8 || !deltas || !codes || ndeltas < 4 || ndeltas > 7) return 0;
+    if (std::getenv("VEXHIP_NO_GRID")) GP_DECLINE(1);
+    if (value_bytes != 8 || !deltas || !codes || ndeltas < 4 || ndeltas > 7) GP_DECLINE(2);
     // small matrices (x within the L2s / the Infinity Cache: 127^3 = 0.019 ms here, 0.016 ms through the pair product; 168^3 0.029 /
     // 0.026; 256^3 0.052 / 0.074) keep the pair product
-    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < (1 << 23) && !force)) return 0;
-    if (x_last < 0 || x_last + 1 < rows || x_last >= (1ll << 31)) return 0;
+    if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < (1 << 23) && !force)) GP_DECLINE(3);
+    if (x_last < 0 || x_last + 1 < rows || x_last >= (1ll << 31)) GP_DECLINE(4);
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
     std::vector<int> table((size_t)ndeltas);
     VEXHIP_TRY(hipMemcpyAsync(table.data(), deltas, sizeof(int) * (size_t)ndeltas, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     long long nx = 0, far = 0;
-    if (!grid_diagonals(table, rows, &nx, &far)) return 0;
+    if (!grid_diagonals(table, rows, &nx, &far)) GP_DECLINE(5);
     const long long ny = far / nx, lines = rows / nx, nz = (lines + ny - 1) / ny;
-    if (nz < 4 && !force) return 0;
+    if (nz < 4 && !force) GP_DECLINE(6);
 
     codes_dev cd;
     cd.buf = static_cast<const char *>(codes); cd.blocks = blocks; cd.w = (int)ell_width; cd.ndeltas = ndeltas;
@@ -1059,7 +1078,7 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     VEXHIP_TRY(hipMemcpyAsync(hash.data(), d_hash.p, sizeof(unsigned long long) * (size_t)lines, hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
-    if (bad) return 0;
+    if (bad) GP_DECLINE(7);
     // classes: lines with equal hashes (a handful; the verify pass below compares the rows themselves)
     constexpr size_t max_classes = 128;
     std::vector<unsigned long long> seen; std::vector<long long> rep, uses;
@@ -1071,17 +1090,17 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
         if (!seen.empty() && seen[lastc] == h) c = lastc;
         else for (size_t k = 0; k < seen.size(); ++k) if (seen[k] == h) { c = k; break; }
         if (c == seen.size()) {
-            if (seen.size() == max_classes) return 0;
+            if (seen.size() == max_classes) GP_DECLINE(8);
             seen.push_back(h); rep.push_back(l); uses.push_back(0);
         }
         cls[(size_t)l] = (int)c; ++uses[c]; lastc = c;
     }
     const int nclasses = (int)seen.size();
     const int hot = (int)(std::max_element(uses.begin(), uses.end()) - uses.begin());
-    if ((lines - uses[(size_t)hot]) * 4 > lines && !force) return 0;         // each change of the other class is a decode, a step with another class reads its values from LDS
+    if ((lines - uses[(size_t)hot]) * 4 > lines && !force) GP_DECLINE(9);         // each change of the other class is a decode, a step with another class reads its values from LDS
 
     grid_geometry geo;
-    if (!grid_geometry_for(dev, nx, ny, nz, &geo)) return 0;
+    if (!grid_geometry_for(dev, nx, ny, nz, &geo)) GP_DECLINE(10);
     const long long pitch = geo.pitch;
     // the table of every class from its representative line, then every line against it
     dev_buf<long long> d_rep; dev_buf<int> d_cls; dev_buf<unsigned char> d_table;
@@ -1094,7 +1113,7 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     VEXHIP_LAUNCH_CHECK();
     VEXHIP_TRY(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
-    if (bad) return 0;                            // two different lines with one hash: not this product's matrix
+    if (bad) GP_DECLINE(11);                      // two different lines with one hash: not this product's matrix
 
     grid_fill_plan(out, nx, ny, nz, geo, hot, nclasses, x_last);
     out->line_class = d_cls.release(); out->table = d_table.release();
@@ -1102,6 +1121,7 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     return 0;
 }
 
+#undef GP_DECLINE
 int vexhip_sell8_grid_release(int dev, vexhip_grid *g)
 {
     if (!g) return 0;
