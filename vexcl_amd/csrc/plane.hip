@@ -479,6 +479,25 @@ static bool plane_geometry(int dev, long long ny, long long nz, int hot, vexhip_
     auto depth_for = [&](long long tl) {
         const long long tiles = ny / tl;
         long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
+        // Round 5 -- ONE workgroup per CU, all of them resident and in step, is the best a launch can do (512 lines per plane:
+        // walks of 512 / 256 / 128 / 64 / 43 planes = 0.377 / 0.385 / 0.387 / 0.387 / 0.385 ms) -- but only where the tiles come out
+        // as one per CU.  Planes of 640 lines are 1.25 tiles per CU: with one walk per tile a quarter of the CUs do twice the work
+        // of the others (0.850 ms for 512 x 640 x 640; walks of 80 planes: 0.621).  So unless the workgroups above number
+        // 0.95 .. 1 per CU: many short walks, at least six per CU for the dispatcher to even out, the fewest rounds of
+        // (planes per walk + 6) -- the rule of the grid product (grid.hip).  Measured, plan before -> after
+        // (profiles/r05_plane_shapes.json): 512 x 640 x 640 0.850 -> 0.621 ms, 512 x 768 x 512 0.768 -> 0.626, 512 x 384 x 768
+        // 0.492 -> 0.431, 512 x 320 x 1024 0.702 -> 0.52, 512 x 1024 x 256 0.434 -> 0.428.
+        if (tiles * chunks > cus || tiles * chunks * 20 < cus * 19) {
+            double best = 0;
+            const long long cmax = std::max(1ll, nz / 16);
+            for (long long c = 1; c <= cmax; ++c) {
+                const long long per_cu = (tiles * c + cus - 1) / cus;
+                if (per_cu < 6 && c < cmax) continue;
+                const double est = (double)per_cu * (double)((nz + c - 1) / c + 6);
+                if (best == 0 || est <= best * 1.01) { if (best == 0 || est < best) best = est; chunks = c; }
+                if (per_cu > 24) break;
+            }
+        }
         // SHORT walks (a rank's strip of a partitioned grid: 64 planes at 512^3 / 8) want two workgroups per CU: the start and the
         // end of a walk -- four planes requested before the first row is stored, the last planes clamped -- are a tenth of a
         // 64-plane walk and overlap with the other workgroup's steady state: 56.6 -> 47.0 us for 16.8 M rows (depth 22 / 16 / 11:
