@@ -504,7 +504,11 @@ struct inline_spmv : expression_base {
         c.src.new_line() << V << " sum = 0;";
         c.src.new_line() << "if (line_class)";        // stored by grid line (grid.hip): a class per line, a value code per position and row
         c.src.open("{");
-        c.src.new_line() << "const long line = (long)i / grid_nx, r = (long)i - line * grid_nx;";
+        // (the row's line and place in it: a 32-bit division where the row number allows it -- the 64-bit one by a run-time
+        //  divisor is a hundred instructions per row in a kernel that does little else)
+        c.src.new_line() << "long line, r;";
+        c.src.new_line() << "if (i < 0x100000000ul) { const uint l32 = (uint)i / (uint)grid_nx; line = l32; r = (uint)i - l32 * (uint)grid_nx; }";
+        c.src.new_line() << "else { line = (long)i / grid_nx; r = (long)i - line * grid_nx; }";
         c.src.new_line() << "const uchar *tb = grid_table + (long)line_class[line] * 7 * grid_pitch + r;";
         c.src.new_line() << "const long off[7] = {-grid_far, -grid_nx, -1, 0, 1, grid_nx, grid_far};";
         c.src.new_line() << "for(int p = 0; p < 7; ++p)";
