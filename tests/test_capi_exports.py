@@ -121,3 +121,25 @@ def test_grid_plan_of_every_line_length_is_one_the_product_accepts(built_lib):
                 except _capi.Error:
                     refused.append((cus, nx, ny, nz, g.segments, g.segment_rows, g.threads, g.pitch))
     assert not refused, refused[:10]
+
+
+def test_long_grid_lines_get_one_segment_and_enough_walks_to_balance_the_cus(built_lib):
+    """Round 5 (grid.hip grid_geometry_with): lines of 513 .. 1024 points are ONE segment (workgroups of 5 .. 8 waves), and a
+    cube of such lines -- 1.25 .. 2 tiles per CU and plane -- is cut into walks so that every CU sees at least six workgroups
+    (one walk per tile left half of the CUs with twice the work: 640^3 1.25 ms against 0.87).  Lines of up to 512 points keep the
+    plan of round 4 (384^3: 96 planes per walk, 500^3: 250).  Host arithmetic only."""
+    from vexcl_amd import _capi
+    L = _capi.lib()
+    def geo(n, cus=256):
+        g = _capi.Grid()
+        L.sell8_grid_geometry(cus, n, n, n, ctypes.byref(g))
+        return g
+    for n in (513, 576, 640, 700, 768, 800, 900, 1000, 1024):
+        g = geo(n)
+        assert g.segments == 1 and g.segment_rows == n + (n & 1) and g.threads == min(512, (((n + 1) // 2) + 63) // 64 * 64), (n, g.segments, g.segment_rows, g.threads)
+        tiles = (n + 1) // 2
+        walks = (n + g.depth - 1) // g.depth
+        assert tiles * walks >= 6 * 256 and g.depth >= 16, (n, g.depth, walks)
+        L.sell8_grid_check(ctypes.byref(g), n ** 3)
+    assert geo(1030).segments == 2 and geo(2048).segments == 2 and geo(2049).segments == 3
+    assert (geo(384).depth, geo(500).depth) == (96, 250)
