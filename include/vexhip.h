@@ -340,6 +340,10 @@ int vexhip_sell8_grid_geometry(int cus, int64_t nx, int64_t lines_per_plane, int
 int vexhip_sell8_grid_check(const vexhip_grid *grid, int64_t n);
 int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, int append, const double *values,
         const double *x, double *y, const vexhip_grid *grid);
+/* the same product for float matrices (grid32.hip, round 5): four rows per lane, 16-byte requests at 4-byte addresses; the plan
+ * (vexhip_grid) is the fp64 one, the walk is cut shorter at launch (VEXHIP_GRID32_DEPTH overrides)                      */
+int vexhip_spmv_sell8v_grid_f32(int dev, void *stream, int64_t n, float alpha, int append, const float *values,
+        const float *x, float *y, const vexhip_grid *grid);
 int64_t vexhip_sell8_last_fill_max_col(void);
 int vexhip_spmv_sell8v_march_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const int32_t *csr_ptr, const int32_t *csr_col, const double *csr_val,

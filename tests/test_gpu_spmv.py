@@ -533,10 +533,10 @@ def test_grid_product_is_bit_identical(T, oracle, built_lib):
         assert T.ops.SpMat(*[T.up(a) for a in oracle.poisson3d(96)]).grid is None          # small: the pair product stays
 
         os.environ["VEXHIP_PLANE_FORCE"] = "1"           # the structural reasons to decline hold whatever the size
-        # declined: fp32; an eighth diagonal; a 2-D operator whose rows are no multiple of 1024 points; rows reversed (storage order is not position order);
+        # declined: an eighth diagonal; a 2-D operator whose rows are no multiple of 1024 points; rows reversed (storage order is not position order);
         # rows that do not fill whole lines; plane=False / dictionary=False keep the older products
         ptr, col, val = _grid7(96, 20, 21)
-        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val.astype(np.float32))).grid is None
+        assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val.astype(np.float32))).grid is not None       # (fp32: test_grid_product_fp32_is_bit_identical)
         assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), plane=False).grid is None
         assert T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), dictionary=False).grid is None
         P = 96 * 20; m = P * 21
@@ -616,6 +616,99 @@ def test_storage_by_grid_line_holds_the_matrix(T, oracle, built_lib):
                 assert got_cols == col[ptr[i]:ptr[i + 1]].tolist() and got_vals == val[ptr[i]:ptr[i + 1]].tolist(), (shape, i)
     finally:
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
+
+
+def test_grid_product_fp32_is_bit_identical(T, oracle, built_lib):
+    """The fp32 grid product (round 5, grid32.hip: the walk of the fp64 grid product with FOUR rows per lane -- 16-byte requests at
+    4-byte addresses, the lane at the end of a line stores 1 .. 3 rows) against the pair product and the fp32 CSR restatement,
+    bit for bit: the benchmark's operator on 96^3 and 125^3, line lengths that are no multiple of four (70, 125, 127, 250, 514,
+    700, 1030 -- two segments), odd lines per plane, natural boundaries (nine classes, explicit zeros), full bands whose +-1
+    diagonal crosses the line ends, a ragged last plane, walk depths, '=' and '+= alpha', Inf / NaN in x, vectors that start at
+    any element; both set-ups (one pass over the CSR arrays, from the SELL-512 storage); the plan as the library chooses it (208^3)."""
+    torch = T.torch
+    f32 = np.float32
+    try:
+        def check(ptr, col, val, shape, seed, depth=None, classes=None):
+            if depth is None:
+                os.environ.pop("VEXHIP_GRID32_DEPTH", None)
+            else:
+                os.environ["VEXHIP_GRID32_DEPTH"] = str(depth)
+            m = len(ptr) - 1
+            v32 = val.astype(f32)
+            B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), march=False)
+            assert B.grid is None and B.plane is None and B.march is None
+            xb = oracle.random_f64(seed, m).astype(f32); y0 = oracle.random_f64(seed + 1, m).astype(f32)
+            want = oracle.spmv_csr(ptr, col, v32, xb)
+            for direct in (True, False):
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), direct=direct)
+                assert A.storage == "sell8v" and A.grid is not None and A.plane is None and A.direct == direct, (shape, direct, A.storage)
+                assert (A.grid["nx"], A.grid["lines_per_plane"]) == shape[:2] and A.grid["x_last"] == m - 1, (shape, A.grid)
+                if classes is not None:
+                    assert A.grid["classes"] == classes, (shape, A.grid)
+                for alpha, append in ((1.0, False), (-0.75, True)):
+                    ya, yb = T.up(y0.copy()), T.up(y0.copy())
+                    A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
+                    assert torch.equal(ya, yb), (shape, alpha, direct)
+                    assert np.array_equal(ya.cpu().numpy(), (y0 + f32(alpha) * want) if append else f32(alpha) * want), (shape, alpha, direct)
+            return A
+
+        os.environ["VEXHIP_PLANE_FORCE"] = "1"
+        for n in (96, 125):
+            ptr, col, val = oracle.poisson3d(n)
+            check(ptr, col, val, (n, n, n), 31, classes=2)
+        for shape, depth in (((70, 33, 20), None), ((70, 33, 20), 3), ((1030, 6, 8), None), ((1030, 6, 8), 5), ((384, 10, 12), None),
+                             ((500, 7, 11), 4), ((127, 17, 19), 7), ((514, 5, 13), None), ((640, 6, 9), None), ((700, 5, 8), 3),
+                             ((1000, 4, 7), 2), ((1024, 6, 6), None), ((258, 6, 40), 16), ((9, 40, 41), None)):
+            ptr, col, val = _grid7(*shape)
+            check(ptr, col, val, shape, 33, depth, classes=2)
+        for shape, depth in (((96, 20, 21), None), ((125, 15, 18), 5), ((250, 9, 16), None)):
+            ptr, col, val = _grid7_natural(*shape, zero_face=True)
+            A = check(ptr, col, val, shape, 35, depth)
+            assert A.grid["classes"] >= 9, A.grid
+        for nx, ny, nz, extra_lines, depth in ((96, 12, 30, 0, None), (125, 9, 33, 4, 6), (300, 8, 14, 3, None), (1021, 4, 9, 2, None)):
+            P = nx * ny; m = P * nz + extra_lines * nx
+            ptr, col, val = _band(m, (-P, -nx, -1, 0, 1, nx, P), 5, constant=True)
+            check(ptr, col, val, (nx, ny, nz), 37, depth)
+        os.environ.pop("VEXHIP_GRID32_DEPTH", None)
+        # Inf / NaN in x: only the rows that reference them may see them; a stored 0.0 times Inf is NaN as in the CSR loop
+        shape = (125, 15, 18)
+        ptr, col, val = _grid7_natural(*shape, zero_face=True)
+        v32 = val.astype(f32)
+        m = len(ptr) - 1
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32))
+        assert A.grid is not None
+        xb = oracle.random_f64(39, m).astype(f32)
+        xb[0] = np.inf; xb[1] = -np.inf; xb[m - 1] = np.nan; xb[125 * 15 + 7 * 125 + 60] = np.inf; xb[5 * 125 * 15 + 124] = np.nan
+        ya = torch.empty(m, dtype=torch.float32, device=T.dev)
+        A.apply(T.up(xb), ya)
+        want = oracle.spmv_csr(ptr, col, v32, xb)
+        assert np.isnan(want).sum() >= 8
+        assert np.array_equal(ya.cpu().numpy(), want, equal_nan=True)
+        # vectors that start at any element
+        xb = oracle.random_f64(27, m).astype(f32); y0 = oracle.random_f64(28, m).astype(f32)
+        want = oracle.spmv_csr(ptr, col, v32, xb)
+        for alpha, append in ((1.0, False), (-0.75, True)):
+            xbig = torch.zeros(m + 7, dtype=torch.float32, device=T.dev); ybig = torch.zeros(m + 7, dtype=torch.float32, device=T.dev)
+            for xo, yo in ((1, 1), (2, 0), (0, 3)):
+                xv, yv = xbig[xo:xo + m], ybig[yo:yo + m]
+                xv.copy_(T.up(xb)); yv.copy_(T.up(y0))
+                A.apply(xv, yv, alpha, append)
+                assert np.array_equal(yv.cpu().numpy(), (y0 + f32(alpha) * want) if append else f32(alpha) * want), (alpha, xo, yo)
+        os.environ.pop("VEXHIP_PLANE_FORCE")
+        # the plan as the library chooses it: 208^3
+        n = 208
+        ptr, col, val = oracle.poisson3d(n)
+        v32 = val.astype(f32)
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32)); B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32), march=False)
+        assert A.direct and A.grid is not None and A.grid["nx"] == n and A.grid["classes"] == 2 and B.grid is None, A.grid
+        xb = oracle.random_f64(47, n ** 3).astype(f32)
+        ya = torch.empty(n ** 3, dtype=torch.float32, device=T.dev); yb = torch.empty_like(ya)
+        A.apply(T.up(xb), ya); B.apply(T.up(xb), yb)
+        assert torch.equal(ya, yb)
+        assert np.array_equal(ya.cpu().numpy(), oracle.spmv_csr(ptr, col, v32, xb))
+    finally:
+        for k in ("VEXHIP_PLANE_FORCE", "VEXHIP_GRID32_DEPTH"):
+            os.environ.pop(k, None)
 
 
 def test_two_dimensional_five_point_operators(T, oracle, built_lib):

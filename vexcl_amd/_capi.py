@@ -180,6 +180,7 @@ _PROTOS = {
     "vexhip_sell8_grid_geometry": (None, [c_int, c_i64, c_i64, c_i64, ctypes.POINTER(Grid)]),
     "vexhip_sell8_grid_check": (None, [ctypes.POINTER(Grid), c_i64]),
     "vexhip_spmv_sell8v_grid_f64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(Grid)]),
+    "vexhip_spmv_sell8v_grid_f32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(Grid)]),
     "vexhip_spmv_sell8v_plane_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Plane)]),
     "vexhip_spmv_sell8v_plane_f32_i32": (None, [c_int, c_vp, c_i64, ctypes.c_float, c_int, c_i64] + [c_vp] * 6 + [ctypes.POINTER(Plane)]),
     "vexhip_spmv_sell8v_march_f64_i32": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_i64] + [c_vp] * 9 + [ctypes.POINTER(Traversal), ctypes.POINTER(March)]),

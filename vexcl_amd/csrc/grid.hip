@@ -27,6 +27,7 @@
 // Compiled with -ffp-contract=off.
 #include "common.hpp"
 #include "lanes.hpp"
+#include "grid.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -39,18 +40,6 @@ namespace {
 
 constexpr unsigned GR_PAD_FIRST = 254;      // codes 254 / 255 are padding (sell8.hip)
 constexpr int GR_ABSENT = 255;              // table byte of a position without an entry (value codes are < 255)
-
-struct grid_dev {
-    long long lines;         // grid lines of the matrix: rows / nx
-    long long x_last;        // largest valid index of x
-    long long n;             // rows
-    int nx, ny, nz;          // line length, lines per plane, planes: ceil(lines / ny)
-    int depth;               // planes per workgroup
-    int segs, seg_len;       // segments per line, rows per segment (even, <= 512)
-    int tiles, tpx;          // ceil(ny / 2) * segs, and per XCD: ceil(tiles / 8)
-    int hot;                 // line class decoded into registers with scalar masks
-    int pitch;               // bytes per position row of a class table (>= segs * 512, padded with 255)
-};
 
 struct codes_dev {           // where the value-coded slices are (sell8.hip: ceil(w/2) KiB diagonal codes, then as many value codes)
     const char *buf; const int *blocks; int w, ndeltas;
@@ -907,8 +896,7 @@ template <typename T> struct dev_buf {       // device scratch of the plan, free
 // rows x rows-or-more matrix in CSR on the device -> vexhip_grid (usable = 1), the diagonal table (sorted, 256 ints on the device,
 // INT_MAX behind the last) and the value table (256 values on the device, 0.0 behind the last), ELL width and largest column;
 // usable = 0: not a matrix for this storage, nothing was written that the classic set-up would read.
-// fp32 (V = float): only where the fp32 plane product applies (512-point lines, an even number of them per plane) -- there is no
-// fp32 grid product for other line lengths; declined right behind the probe otherwise.
+// fp32 (V = float): the same tables; the products are plane32.hip (512-point lines) and grid32.hip (any line length).
 template <typename P, typename V>
 int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t *col, const V *val,
         int32_t *deltas, V *values, int *ndeltas, int *nvalues, int64_t *ell_width, int64_t *x_last_out, vexhip_grid *out, int64_t min_cols)
@@ -949,7 +937,6 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     if (nz < 4 && !force) return 0;
     grid_geometry geo;
     if (!grid_geometry_for(dev, nx, ny, nz, &geo)) return 0;
-    if (!std::is_same<V, double>::value && (nx != 512 || geo.segs != 1 || ny < 4 || ny % 2 != 0 || rows % 512 != 0 || (lines < 64 && !force))) return 0;
     trace.mark("  grid: probe");
 
     // ---- the pass ----
@@ -1044,7 +1031,7 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     std::memset(out, 0, sizeof(*out));
     const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
     if (std::getenv("VEXHIP_NO_GRID")) GP_DECLINE(1);
-    if (value_bytes != 8 || !deltas || !codes || ndeltas < 4 || ndeltas > 7) GP_DECLINE(2);
+    if ((value_bytes != 8 && value_bytes != 4) || !deltas || !codes || ndeltas < 4 || ndeltas > 7) GP_DECLINE(2);
     // small matrices (x within the L2s / the Infinity Cache: 127^3 = 0.019 ms here, 0.016 ms through the pair product; 168^3 0.029 /
     // 0.026; 256^3 0.052 / 0.074) keep the pair product
     if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows < 8 || (rows < (1 << 23) && !force)) GP_DECLINE(3);

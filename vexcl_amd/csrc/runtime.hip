@@ -47,6 +47,7 @@ void warm_sell8();
 void warm_plane();
 void warm_plane32();
 void warm_grid();
+void warm_grid32();
 void warm_spmm();
 void warm_spmv();
 void warm_split();
@@ -82,7 +83,7 @@ const device_info &info(int dev) {
                     (void)hipFree(d);
                 }
                 // ... and the code objects of the library's files (see VEXHIP_WARM_TU)
-                warm_misc(); warm_reduce(); warm_scan(); warm_sort(); warm_stencil(); warm_ccsr(); warm_sell8(); warm_plane(); warm_plane32(); warm_grid(); warm_spmm(); warm_spmv(); warm_split(); warm_comm(); warm_fft(); warm_mba();
+                warm_misc(); warm_reduce(); warm_scan(); warm_sort(); warm_stencil(); warm_ccsr(); warm_sell8(); warm_plane(); warm_plane32(); warm_grid(); warm_grid32(); warm_spmm(); warm_spmv(); warm_split(); warm_comm(); warm_fft(); warm_mba();
                 (void)hipDeviceSynchronize();
                 (void)hipGetLastError();
                 (void)hipSetDevice(cur);

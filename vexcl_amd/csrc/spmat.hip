@@ -252,10 +252,9 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     // A 7-point pattern on a grid with a handful of distinct values: stored by grid line in ONE pass over the CSR arrays (grid.hip
     // grid_build: no ELL analysis, no table pass, no per-slice codes, no dictionary, no plans from read-backs).  Declined
     // (usable = 0, after a probe of a few thousand rows in most cases): the SELL-512 set-up below.
-    // (fp32, round 5: where the fp32 plane product applies -- 512-point lines; the build declines other line lengths behind its probe)
+    // (fp32, round 5: the same storage; its products are plane32.hip on 512-point lines and grid32.hip on lines of any length)
     if ((format == VEXHIP_SPMAT_AUTO || format == VEXHIP_SPMAT_SELL8V) && A->nnz > 0
-        && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE | VEXHIP_SPMAT_NO_GRID_BUILD))
-        && (std::is_same<V, double>::value || !std::getenv("VEXHIP_NO_PLANE512"))) {
+        && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE | VEXHIP_SPMAT_NO_GRID_BUILD))) {
         V *vals = nullptr;
         if (int rc = dmalloc(&A->deltas, 256)) return rc;
         if (int rc = dmalloc(&vals, 256)) return rc;
@@ -267,16 +266,11 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         if (rc) return rc;
         trace.mark("grid build");
         if (A->grid.usable) {
+            A->ndeltas = nd; A->nvalues = nv; A->ell_w = gw; A->tail = 0; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
             if (!std::getenv("VEXHIP_NO_PLANE512"))
                 if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
             trace.mark("plane plan");
-            if (std::is_same<V, double>::value || A->plane.usable) {
-                A->ndeltas = nd; A->nvalues = nv; A->ell_w = gw; A->tail = 0; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
-                return 0;
-            }
-            // fp32 without a plane plan (x shorter than whole lines, ...): no product reads these tables -- the SELL-512 set-up
-            (void)vexhip_sell8_grid_release(dev, &A->grid);
-            std::memset(&A->grid, 0, sizeof(A->grid)); std::memset(&A->plane, 0, sizeof(A->plane));
+            return 0;
         }
         (void)hipFree(A->deltas); A->deltas = nullptr;
         (void)hipFree(A->values); A->values = nullptr;
@@ -351,9 +345,9 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
             trace.mark("dictionary + plans");
             // a 7-point pattern on grid lines of another length than 512: the matrix by grid line (grid.hip), from the slices'
             // codes wherever they are now (the pool of a dictionary, or the per-slice buffer)
-            if (std::is_same<V, double>::value && !A->plane.usable && !tail
+            if (!A->plane.usable && !tail
                 && !(flags & (VEXHIP_SPMAT_NO_DICTIONARY | VEXHIP_SPMAT_NO_MARCH | VEXHIP_SPMAT_NO_PLANE)))
-                if (int rc = vexhip_sell8_grid_plan(dev, stream, A->deltas, nd, A->blocks ? A->pool : A->sell, A->blocks, w, n, tail, 8,
+                if (int rc = vexhip_sell8_grid_plan(dev, stream, A->deltas, nd, A->blocks ? A->pool : A->sell, A->blocks, w, n, tail, (int)sizeof(V),
                                                     std::max<int64_t>(vexhip_sell8_last_fill_max_col(), min_cols - 1), &A->grid)) return rc;
             trace.mark("grid plan");
         } else {
@@ -420,6 +414,9 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
             if constexpr (std::is_same<V, double>::value)
                 if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
                     return vexhip_spmv_sell8v_grid_f64(A->dev, stream, A->n, alpha, append, (const double *)A->values, x, y, &A->grid);
+            if constexpr (std::is_same<V, float>::value)
+                if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
+                    return vexhip_spmv_sell8v_grid_f32(A->dev, stream, A->n, alpha, append, (const float *)A->values, x, y, &A->grid);
             if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
             return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case VEXHIP_SPMAT_SELL8:
