@@ -3,7 +3,9 @@
 // per lane, as plane32.hip does it for 512-point lines: every request is 16 bytes per lane (at 4-byte addresses: lines start
 // at any element), a wave covers 256 rows of a segment, workgroups are 1 .. 4 waves.  Until this kernel float matrices on
 // grids other than 512-point lines took the pair product of the SELL-512 storage and ran SLOWER than the same matrix in
-// double (384^3: 0.248 ms against 0.183; 640^3: 1.39 against 0.87 -- profiles/r05_fp32_sizes.json).
+// double (384^3: 0.248 ms against 0.183; 640^3: 1.39 against 0.87).  Now 384^3 0.12 ms, 500^3 0.26, 640^3 0.53, 700^3 0.75
+// (profiles/r05_fp32_sizes.json): 0.46 - 0.50 of the HBM peak by the bytes that must move -- a line of 384 floats fills 96 of
+// the 128 lanes of its two waves, one of 640 fills 160 of 192: the lanes beyond the line still request.
 // Semantics: the reference's ELL product (/root/reference/vexcl/spmat/hybrid_ell.inl:238-269: entries in storage order,
 // products rounded before they are added, the scale applied to the sum); bit-identical to the fp32 CSR loop
 // (spmat/csr.inl:163-170).  Compiled with -ffp-contract=off.
@@ -21,7 +23,7 @@ constexpr int G32_MAXT = 256;              // lanes of a workgroup at most: 1024
 constexpr unsigned G32_ABSENT = 255;       // table byte of a position without an entry (grid.hip)
 
 template <bool APPEND, int STORE_AUX>
-__global__ __launch_bounds__(G32_MAXT, 3)          // three waves per SIMD: 168 registers (199 unconstrained)
+__global__ __launch_bounds__(G32_MAXT)             // 199 registers, two waves per SIMD (capped at 168 for three, with 15 spilled: the same times)
 void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, float alpha,
         const int *__restrict__ line_class, const unsigned char *__restrict__ table, const float *__restrict__ values, grid_dev gd)
 {
