@@ -1078,6 +1078,25 @@ def main():
                     row["pair_product_ms"] = round(tb, 5)
                     row["bit_identical_to_pair_product"] = bool(torch.equal(yg, yb))
                     assert row["bit_identical_to_pair_product"], "grid product differs from the pair product at %d^3" % g
+                    # the same matrix in float (round 5, grid32.hip): bit-compared with the library's CSR loop
+                    try:
+                        v32 = vg.to(torch.float32); x32 = xg.to(torch.float32)
+                        y32 = torch.empty_like(x32); yc32 = torch.empty_like(x32)
+                        F = ops.SpMat(pg, cg, v32); C = ops.SpMat(pg, cg, v32, fmt="csr")
+                        F.apply(x32, y32); C.apply(x32, yc32)
+                        same32 = bool(torch.equal(y32, yc32))
+                        assert same32, "fp32 grid product differs from the CSR loop at %d^3" % g
+                        del C, yc32
+                        tf = min(timed_events(torch, lambda: F.apply(x32, y32), 20) for _ in range(3))
+                        mf = F.matrix_bytes() + 8 * Ng
+                        row["fp32"] = {"ms": round(tf, 5), "gflops": round(2.0 * cg.numel() / tf / 1e6, 1), "grid_plan": F.grid is not None, "bit_identical_to_csr_loop": same32,
+                                       "roofline": {"bound": "hbm", "achieved": round(mf / tf / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                    "frac": round(mf / tf / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": mf}}
+                        del F, v32, x32, y32
+                    except AssertionError:
+                        raise
+                    except Exception as e:  # noqa: BLE001 -- a secondary figure
+                        row["fp32"] = {"error": repr(e)[:200]}
                     sec["SpMV Poisson 7-point %d^3 (y = A*x, vexhip_spmat)" % g] = row
                     del G, Bg, pg, cg, vg, xg, yg, yb
                     torch.cuda.empty_cache()
