@@ -657,7 +657,9 @@ def main():
         tried["torch"] = {"valid": ok, "max_abs_err": worst, "what": "torch.distributed batch_isend_irecv (%s), pack and products launched from Python" % args.backend}
         candidates = []
         if not args.no_native and args.transport != "torch":
-            if args.transport in ("auto", "halo"):
+            # (three or more ranks SHARING one device can starve each other in the one-launch step: the workgroups that wait for a
+            #  ghost plane hold their CU slots, csrc/halo.hpp -- with a GPU per rank a launch only waits for other devices)
+            if args.transport == "halo" or (args.transport == "auto" and not (args.one_device and world > 2)):
                 candidates.append("halo")           # round 5: the whole step in one launch (ghost planes read by the plane product itself)
             if args.transport in ("auto", "ipc"):
                 candidates.append("ipc")
