@@ -711,6 +711,56 @@ def test_grid_product_fp32_is_bit_identical(T, oracle, built_lib):
             os.environ.pop(k, None)
 
 
+def test_structured_products_on_random_shapes(T, oracle, built_lib):
+    """Round 5: the four products of matrices stored by grid line -- plane / grid in fp64, plane32 / grid32 in fp32 -- on sixty
+    seeded random grids (line lengths 8 .. 1100 incl. 512 and lengths that are no multiple of four, 2 .. 13 lines per plane, 4 .. 26
+    planes, a ragged last plane now and then, random walk depths, natural or Dirichlet boundaries or full bands), '=' and
+    '+= alpha', against the CSR restatement bit for bit.  What the hand-picked shapes of the tests above may have missed: a chunk
+    boundary next to a class change, the last lane of a line with 1 .. 3 rows, odd lines per plane with short walks."""
+    torch = T.torch
+    rng = np.random.default_rng(int(os.environ.get("VEXHIP_TEST_SEED", "20250925")))      # (another seed: another sixty grids)
+    keys = ("VEXHIP_PLANE_DEPTH", "VEXHIP_PLANE32_DEPTH", "VEXHIP_GRID32_DEPTH")
+    os.environ["VEXHIP_PLANE_FORCE"] = "1"
+    seen = set()
+    try:
+        for case in range(60):
+            nx = int(rng.choice([512, 512, int(rng.integers(8, 1101)), int(rng.integers(8, 300)), 4 * int(rng.integers(3, 260)) + int(rng.integers(1, 4))]))
+            ny = int(rng.integers(2, 14)); nz = int(rng.integers(4, 27))
+            kind = int(rng.integers(0, 3))
+            extra = int(rng.integers(0, ny)) if kind == 2 and rng.random() < 0.5 else 0
+            if kind == 0:
+                ptr, col, val = _grid7(nx, ny, nz)
+            elif kind == 1:
+                ptr, col, val = _grid7_natural(nx, ny, nz, zero_face=bool(rng.integers(0, 2)))
+            else:
+                P = nx * ny
+                ptr, col, val = _band(P * nz + extra * nx, (-P, -nx, -1, 0, 1, nx, P), int(rng.integers(1, 100)), constant=True)
+            m = len(ptr) - 1
+            depth = None if rng.random() < 0.4 else int(rng.integers(1, nz + 1))
+            for k in keys:
+                if depth is None: os.environ.pop(k, None)
+                else: os.environ[k] = str(depth)
+            for dt in (np.float64, np.float32):
+                v = val.astype(dt)
+                xb = oracle.random_f64(100 + case, m).astype(dt); y0 = oracle.random_f64(200 + case, m).astype(dt)
+                want = oracle.spmv_csr(ptr, col, v, xb)
+                direct = bool(rng.integers(0, 2))
+                A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v), direct=direct)
+                if A.grid is None and A.plane is None:       # (hybrid-ELL width 1 on grids that are mostly boundary: a CSR tail, no grid plan)
+                    seen.add("none")
+                else:
+                    seen.add(("plane" if A.plane else "grid") + ("32" if dt == np.float32 else "64"))
+                for alpha, append in ((1.0, False), (-1.25, True)):
+                    ya = T.up(y0.copy())
+                    A.apply(T.up(xb), ya, alpha, append)
+                    ref = (y0 + dt(alpha) * want) if append else dt(alpha) * want
+                    assert np.array_equal(ya.cpu().numpy(), ref), (case, nx, ny, nz, kind, extra, depth, dt.__name__, direct, alpha, A.grid, A.plane)
+        assert {"plane64", "plane32", "grid64", "grid32"} <= seen, seen
+    finally:
+        for k in keys + ("VEXHIP_PLANE_FORCE",):
+            os.environ.pop(k, None)
+
+
 def test_two_dimensional_five_point_operators(T, oracle, built_lib):
     """Round 5: 5-point operators on 2-D grids -- diagonals {0, +-1, +-W}, no line-above / line-below pair -- take the grid or the
     plane product along VIRTUAL 512-point lines where the rows are an even number (>= 4) of them (grid.hip grid_diagonals: +-W as
