@@ -1073,6 +1073,21 @@ def test_row_pointers_64bit(T, oracle, built_lib):
     yf = torch.empty(N, dtype=torch.float32, device=T.dev); yg = torch.empty_like(yf)
     F.apply(T.up(x.astype(np.float32)), yf); G.apply(T.up(x.astype(np.float32)), yg)
     assert torch.equal(yf, yg)
+    # the one-pass build by grid line from 64-bit row pointers, both value types (forced: the grids are small)
+    os.environ["VEXHIP_PLANE_FORCE"] = "1"
+    try:
+        for shape in ((96, 20, 21), (512, 6, 9), (125, 9, 12)):
+            ptr, col, val = _grid7(*shape)
+            m = len(ptr) - 1
+            for dt in (np.float64, np.float32):
+                v = val.astype(dt); xb = oracle.random_f64(11, m).astype(dt)
+                A = T.ops.SpMat(T.up(ptr.astype(np.int64)), T.up(col), T.up(v))
+                assert A.direct and A.grid is not None and (A.plane is not None) == (shape[0] == 512), (shape, dt.__name__, A.grid, A.plane)
+                y = torch.empty(m, dtype=torch.float64 if dt == np.float64 else torch.float32, device=T.dev)
+                A.apply(T.up(xb), y)
+                assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, v, xb)), (shape, dt.__name__)
+    finally:
+        os.environ.pop("VEXHIP_PLANE_FORCE", None)
 
 
 def test_csr_row_pointers_beyond_2_31_on_a_small_matrix(T, oracle, built_lib):
