@@ -3,8 +3,8 @@
 // per lane, as plane32.hip does it for 512-point lines: every request is 16 bytes per lane (at 4-byte addresses: lines start
 // at any element), a wave covers 256 rows of a segment, workgroups are 1 .. 4 waves.  Until this kernel float matrices on
 // grids other than 512-point lines took the pair product of the SELL-512 storage and ran SLOWER than the same matrix in
-// double (384^3: 0.248 ms against 0.183; 640^3: 1.39 against 0.87).  Now 384^3 0.12 ms, 500^3 0.26, 640^3 0.53, 700^3 0.75
-// (profiles/r05_fp32_sizes.json): 0.46 - 0.50 of the HBM peak by the bytes that must move -- a line of 384 floats fills 96 of
+// double (384^3: 0.248 ms against 0.183; 640^3: 1.39 against 0.87).  Now 384^3 0.10 ms, 500^3 0.23, 640^3 0.54, 700^3 0.69 - 0.73
+// (profiles/r05_fp32_sizes.json): 0.47 - 0.56 of the HBM peak by the bytes that must move -- a line of 384 floats fills 96 of
 // the 128 lanes of its two waves, one of 640 fills 160 of 192: the lanes beyond the line still request.
 // Semantics: the reference's ELL product (/root/reference/vexcl/spmat/hybrid_ell.inl:238-269: entries in storage order,
 // products rounded before they are added, the scale applied to the sum); bit-identical to the fp32 CSR loop
@@ -281,14 +281,29 @@ int vexhip_spmv_sell8v_grid_f32(int dev, void *stream, int64_t n, float alpha, i
     gd.nx = g->nx; gd.ny = g->lines_per_plane; gd.nz = g->planes;
     gd.segs = g->segments; gd.seg_len = g->segment_rows;
     gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch;
-    // a workgroup is 1 .. 4 waves (four rows per lane): half the waves of the fp64 product's workgroups -- as many short walks as
-    // give every CU a dozen of them (plane32.hip), none shorter than 16 planes; never fewer walks than the fp64 plan
+    // A workgroup is 1 .. 4 waves (four rows per lane) and a CU holds eight waves of this kernel.  Measured (ms by walk depth,
+    // profiles/r05_fp32_sizes.json): the best launch is ONE round of workgroups that just fills the CUs -- 384^3 (192 tiles x 2 waves)
+    // 96 / 77 / 64 / 48 planes = 0.120 / 0.103 / 0.136 / 0.115 (3 / 3.75 / 4.5 / 6 workgroups per CU), 500^3 125 / 100 / 63 = 0.217 /
+    // 0.304 / 0.228 (3.9 / 4.9 / 7.8), 512^3 128 / 86 / 64 = 0.214 / 0.244 / 0.259 (4 / 6 / 8) -- a little more than one round is the
+    // worst.  Workgroups of three and four waves (two per CU, 1.25 .. 2 tiles per CU) cannot do that: many short walks, at least
+    // eight per CU, as the fp64 grid product does it (640^3: 320 / 160 / 80 planes = 0.697 / 0.595 / 0.524).
     const int threads = std::max(64, std::min(G32_MAXT, ((g->segment_rows + 3) / 4 + 63) / 64 * 64));
     {
         const long long cus = std::max(1, info(dev).cus);
-        const long long per_wg = threads / 64;
-        const long long want = (12 * cus * 2 / per_wg + gd.tiles - 1) / gd.tiles;              // 24 waves per CU in flight or queued
-        const long long chunks = std::max<long long>((gd.nz + g->depth - 1) / g->depth, std::max(1ll, std::min<long long>(gd.nz / 16, want)));
+        const long long resident = std::max(1, 8 / (threads / 64));
+        const long long cmax = std::max(1ll, (long long)gd.nz / 16);
+        long long chunks = std::min(cmax, resident * cus / gd.tiles);
+        if (resident < 3 || chunks < 1 || gd.tiles * chunks * 20 < resident * cus * 17) {
+            double best = 0;
+            chunks = 1;
+            for (long long c = 1; c <= cmax; ++c) {
+                const long long per_cu = (gd.tiles * c + cus - 1) / cus;
+                if (per_cu < 8 && c < cmax) continue;
+                const double est = (double)per_cu * (double)((gd.nz + c - 1) / c + 6);
+                if (best == 0 || est < best) { best = est; chunks = c; }
+                if (per_cu > 24) break;
+            }
+        }
         gd.depth = (int)((gd.nz + chunks - 1) / chunks);
     }
     if (const char *e = std::getenv("VEXHIP_GRID32_DEPTH")) if (std::atoi(e) > 0) gd.depth = std::min(std::atoi(e), (int)gd.nz);
