@@ -238,6 +238,9 @@ void grid_build_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
     // this one -- all of a piece in one round, GB_CHUNK = 16 entries per lane -- and its row bounds one step earlier; they arrive
     // while the rows of this piece are coded and the line is classed.  The barriers in between order LDS traffic only (gb_barrier):
     // a __syncthreads() waits for every outstanding load of the wave.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "grid_build_kernel orders its LDS traffic with `s_waitcnt lgkmcnt(0)` + `s_barrier`: gfx9-family targets only (ARCH in csrc/Makefile)"
+#endif
     auto gb_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto load_bounds = [&](long long ln, int p, long long &e0_, long long &cnt64_, long long (&mp)[3]) {
         const int r0_ = p * GB_PIECE;
