@@ -294,6 +294,9 @@ typedef struct vexhip_plane { int32_t usable;
 int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
         const void *pool, int64_t dictionary_blocks, int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes,
         int64_t x_last, vexhip_plane *out);
+/* the plan's choice of walks by itself (host arithmetic, no device; usable stays 0): ONE workgroup per CU where the tiles come
+ * out that way, else at least six short walks per CU (round 5) -- so that the rule can be checked for any device size     */
+int vexhip_sell8_plane_geometry(int cus, int64_t lines_per_plane, int64_t planes, vexhip_plane *out);
 /* y = x with one 16-byte pair per lane and non-temporal stores: the measured ceiling for a product whose HBM traffic is x once
  * + y once (bench.py roofline.device_copy_hand); the reference times its copies through clEnqueueCopyBuffer
  * (vexcl/backend/opencl/device_vector.hpp) -- this is the device-side counterpart used as a yardstick only.             */

@@ -143,3 +143,24 @@ def test_long_grid_lines_get_one_segment_and_enough_walks_to_balance_the_cus(bui
         L.sell8_grid_check(ctypes.byref(g), n ** 3)
     assert geo(1030).segments == 2 and geo(2048).segments == 2 and geo(2049).segments == 3
     assert (geo(384).depth, geo(500).depth) == (96, 250)
+
+
+def test_plane_walks_are_one_per_cu_or_many(built_lib):
+    """Round 5 (plane.hip plane_geometry_with): planes of 512 / 256 / 128 lines come out as ONE workgroup per CU on a 256-CU device
+    (the whole launch resident and in step: the headline's plan must not change); planes whose tiles do not -- 640, 768, 384, 320,
+    1024 lines -- are cut into at least six walks per CU, none shorter than 16 planes; short strips of a partitioned grid (64
+    planes) take two workgroups per CU.  Host arithmetic only."""
+    from vexcl_amd import _capi
+    L = _capi.lib()
+    def depth(ny, nz, cus=256):
+        p = _capi.Plane()
+        L.sell8_plane_geometry(cus, ny, nz, ctypes.byref(p))
+        assert p.tile == 2 and p.lines_per_plane == ny and p.planes == nz and 1 <= p.depth <= nz
+        return p.depth
+    assert depth(512, 512) == 512 and depth(256, 1024) == 512 and depth(128, 2048) == 512 and depth(512, 256) == 256
+    assert depth(512, 64) == 32                                   # a rank's strip: two workgroups per CU
+    for ny, nz in ((640, 640), (768, 512), (384, 768), (320, 1024), (1024, 256), (700, 700)):
+        d = depth(ny, nz)
+        walks = (nz + d - 1) // d
+        assert (ny // 2) * walks >= 6 * 256 and d >= 16, (ny, nz, d)
+    assert depth(640, 640) == 80 and depth(384, 768) == 96

@@ -178,6 +178,7 @@ _PROTOS = {
     "vexhip_sell8_grid_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_i64, ctypes.POINTER(Grid)]),
     "vexhip_sell8_grid_release": (None, [c_int, ctypes.POINTER(Grid)]),
     "vexhip_sell8_grid_geometry": (None, [c_int, c_i64, c_i64, c_i64, ctypes.POINTER(Grid)]),
+    "vexhip_sell8_plane_geometry": (None, [c_int, c_i64, c_i64, ctypes.POINTER(Plane)]),
     "vexhip_sell8_grid_check": (None, [ctypes.POINTER(Grid), c_i64]),
     "vexhip_spmv_sell8v_grid_f64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(Grid)]),
     "vexhip_spmv_sell8v_grid_f32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(Grid)]),

@@ -473,9 +473,15 @@ __global__ void halo_signal_kernel(halo_dev H) {
 using namespace vexhip;
 
 // lines per workgroup (2 or 4), planes per workgroup, store policy of a plane plan; false: the walk does not fit 32-bit offsets
+static bool plane_geometry_with(long long cus, long long ny, long long nz, int hot, vexhip_plane *out);
 static bool plane_geometry(int dev, long long ny, long long nz, int hot, vexhip_plane *out)
 {
-    const long long cus = std::max(1, info(dev).cus);
+    return plane_geometry_with(std::max(1, info(dev).cus), ny, nz, hot, out);
+}
+// (host arithmetic only: vexhip_sell8_plane_geometry exposes it so that the choice of walks can be checked without a device)
+static bool plane_geometry_with(long long cus, long long ny, long long nz, int hot, vexhip_plane *out)
+{
+    cus = std::max(1ll, cus);
     auto depth_for = [&](long long tl) {
         const long long tiles = ny / tl;
         long long chunks = std::max(1ll, std::min(nz / 8, (cus + tiles / 2) / tiles));
@@ -592,6 +598,15 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
 } // namespace vexhip
 
 extern "C" {
+
+int vexhip_sell8_plane_geometry(int cus, int64_t lines_per_plane, int64_t planes, vexhip_plane *out)
+{
+    VEXHIP_REQUIRE(out, "NULL output");
+    std::memset(out, 0, sizeof(*out));
+    VEXHIP_REQUIRE(lines_per_plane >= 4 && lines_per_plane % 2 == 0 && lines_per_plane < (1ll << 30) && planes >= 1 && planes < (1ll << 30), "bad grid");
+    if (!plane_geometry_with(cus, lines_per_plane, planes, 0, out)) { std::memset(out, 0, sizeof(*out)); return 0; }      // depth = 0: no geometry
+    return 0;
+}
 
 int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
         const void *pool, int64_t dictionary_blocks, int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes,
