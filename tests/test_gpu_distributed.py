@@ -198,7 +198,7 @@ def _halo_worker(rank, world, port, planes_per_rank, ny, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,planes,ny", [(2, 8, 512), (3, 8, 128)])
+@pytest.mark.parametrize("world,planes,ny", [(2, 8, 512), (3, 8, 128), (2, 3, 128), (3, 5, 64), (2, 21, 64)])
 def test_one_launch_step_reads_ghost_planes_from_the_window(world, planes, ny, built_lib):
     """Transport "halo" (round 5, csrc/halo.hpp; reference: the five phases of vexcl/spmat.hpp:120-185): every rank stores its strip
     with the two ghost planes, ONE plane-product launch pushes the boundary planes and reads the neighbours' from the peer-mapped
@@ -208,7 +208,9 @@ def test_one_launch_step_reads_ghost_planes_from_the_window(world, planes, ny, b
     hold their CU slots -- 256 of them per ghost plane at 512 lines -- and the launches of three processes share the 768 slots of
     the one device: a middle rank's 512 waiting workgroups and 256 of a neighbour that is one product ahead can leave no slot for
     the third rank's push, and all of them sit there until the time-out.  With a GPU per rank a launch only ever waits for
-    launches on OTHER devices; the stand-in is kept below the device's capacity.)"""
+    launches on OTHER devices; the stand-in is kept below the device's capacity.)
+    Strips of 3 and 5 planes are shorter than the chunks next to the ghost planes (a middle rank reads BOTH ghost planes from
+    one chunk); 21 planes leave a main chunk of five between them."""
     ctx = mp.get_context("spawn")
     out = ctx.Array("i", [0] * world)
     port = _free_port()
