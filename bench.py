@@ -580,7 +580,7 @@ def main():
         step = lambda: A.apply(x, y, 1.0, False)
     else:
         progress("strip generated; splitting into local / remote parts and planning the exchange")
-        A = DistSpMat(ptr, col, val, N, N, local_fmt=args.format)
+        A = DistSpMat(ptr, col, val, N, N, local_fmt=args.format, keep_strip=True)      # (transport "halo" stores the strip once more with its ghost planes; dropped below)
         progress("exchange planned; independent evaluation of this rank's rows")
         storage = A.loc.storage
         matrix_bytes = A.loc.matrix_bytes()
@@ -1015,11 +1015,13 @@ def main():
                     B = ops.SpMat(p2, c2, v2, fmt=f2)
                     tb = timed_events(torch, lambda: B.apply(x, y), 20)
                     assert abs(DistReductor("SUM_Kahan")(y) - checksum) <= 1e-10 * abs(checksum) + 1e-300
+                    moved = B.matrix_bytes() + 16 * N          # what THIS kernel streams (sell_pair_kernel reads no row pointers: 13.45 GB, not the 13.85 GB of the CSR arrays)
                     rcsr.append({"kernel": KERNEL_OF[B.storage], "what": label, "avg_launch_ms": round(tb, 5),
                                  "gflops": round(2.0 * nnz_total / tb / 1e6, 1),
-                                 "achieved": round(alg_total / tb / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                 "frac": round(alg_total / tb / 1e6 / HBM_PEAK_GBPS, 4),
-                                 "bytes_per_launch": B.matrix_bytes() + 16 * N, "algorithmic_bytes_per_launch": alg_total})
+                                 "achieved": round(moved / tb / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": round(moved / tb / 1e6 / HBM_PEAK_GBPS, 4),
+                                 "frac_of_algorithmic_bytes": round(alg_total / tb / 1e6 / HBM_PEAK_GBPS, 4),
+                                 "bytes_per_launch": moved, "algorithmic_bytes_per_launch": alg_total})
                     del B
                 out["roofline_csr"] = rcsr
                 del p2, c2, v2
@@ -1050,8 +1052,16 @@ def main():
                     "gflops": out["variable_coefficient"]["gflops"], "avg_launch_ms": round(tv, 5),
                     "bytes_per_launch": mv, "achieved": round(mv / tv / 1e6, 1), "frac": round(mv / tv / 1e6 / HBM_PEAK_GBPS, 4)}
                 out["roofline"]["frac_csr_bytes_kernel"] = max(r["frac"] for r in rcsr) if rcsr else None
-                out["roofline"]["frac_csr_bytes_kernel_what"] = ("the kernels that stream CSR-sized bytes on the headline matrix (32-bit columns + fp64 values): "
-                                                                 + "; ".join("%s %.5f ms = %.4f" % (r["kernel"].split("<")[0], r["avg_launch_ms"], r["frac"]) for r in rcsr))
+                out["roofline"]["frac_csr_bytes_kernel_what"] = ("the kernels that stream CSR-sized bytes on the headline matrix (32-bit columns + fp64 values), each priced "
+                                                                 "by the bytes IT moves: "
+                                                                 + "; ".join("%s %.5f ms x %.3f GB = %.4f" % (r["kernel"].split("<")[0], r["avg_launch_ms"], r["bytes_per_launch"] / 1e9, r["frac"]) for r in rcsr))
+                # the metric under its own name: GFLOP/s of the product that streams the CSR arrays themselves (row pointers +
+                # 32-bit columns + fp64 values) on the headline matrix, beside `value` (the re-coded stencil) and `value_general`
+                csr_row = [r for r in rcsr if r["kernel"].startswith("csr_stream2_kernel")]
+                if csr_row:
+                    out["value_csr_stream"] = csr_row[0]["gflops"]
+                    out["roofline"]["csr_stream"] = {"kernel": csr_row[0]["kernel"], "avg_launch_ms": csr_row[0]["avg_launch_ms"], "gflops": csr_row[0]["gflops"],
+                                                     "bytes_per_launch": csr_row[0]["bytes_per_launch"], "achieved": csr_row[0]["achieved"], "frac": csr_row[0]["frac"]}
                 # multi-right-hand-side product on the general matrix
                 xs = [ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 100 + k) for k in range(4)]
                 ys = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(4)]

@@ -14,6 +14,9 @@
 //       exchange of vexcl/exchange.hpp (RCCL over xGMI between distinct GPUs).  Reported: wall time per product over the
 //       whole context (host clock around M products + ctx.finish()), the slowest device's event time, the per-device step
 //       phases (local part / wait for ghosts / remote part), and sum(y) -- the same for every D up to rounding.
+//       Round 6: where every device's remote columns are its two neighbouring planes (this workload), the product of a device is
+//       ONE launch that reads the neighbours' boundary planes of x in place ("step" in the output; VEXCL_HALO=off keeps the exchange);
+//       --check compares y bit for bit with the product of the same matrix on one device.
 //   VEXCL_LOGICAL_DEVICES=k (tests) makes one GPU appear k times, as in the reference's test fixture.
 #include <array>
 #include <chrono>
@@ -36,7 +39,7 @@ static const char *storage_name(const vexhip_spmat_info &info) {
     return "?";
 }
 
-static int multi_device(int64_t n, int M, int want) {
+static int multi_device(int64_t n, int M, int want, bool check_bits) {
     std::shared_ptr<vex::Context> context = want > 0 ? std::make_shared<vex::Context>(vex::Filter::Env && vex::Filter::Count(want))
                                                      : std::make_shared<vex::Context>(vex::Filter::Env);
     if (!*context) { std::cerr << "no device" << std::endl; return 1; }
@@ -114,11 +117,36 @@ static int multi_device(int64_t n, int M, int want) {
             for (unsigned d = 0; d < D; ++d) reps[d][r] = ms[d];
         }
         vex::Reductor<double, vex::SUM_Kahan> sum(ctx);
+        y = A * x;
         const double checksum = sum(y);
-        std::printf("{\"row\": \"vex::SpMat<double,int,int> y = A*x, %s 7-point %lld^3, ONE vex::Context x%u\", \"front_end\": \"C++ vexcl/spmat.hpp + vexcl/exchange.hpp\", "
+        // --check: the same matrix on ONE device (device 0 of the context), the same x: how many elements of y differ in their BITS
+        // (the one-launch step keeps a row's entries in column order: 0; the split step adds the remote entries last: not 0)
+        long long differing = -1;
+        if (check_bits) {
+            std::vector<double> ym(N), y1(N);
+            vex::copy(y, ym);
+            std::vector<vex::backend::context> c1(1, ctx.context(0));
+            std::vector<vex::backend::command_queue> q1(1, q[0]);
+            vex::Context one(c1, q1);
+            const int dev = q[0].device_ordinal();
+            vex::backend::device_vector<int> ptr(q[0], N + 1), col(q[0], nnz);
+            vex::backend::device_vector<double> val(q[0], nnz);
+            if (variable) vex::backend::check(vexhip_diffusion3d_strip_f64_i32(dev, q[0].raw(), n, 0, (int64_t)N, 7, ptr.raw(), col.raw(), val.raw()));
+            else vex::backend::check(vexhip_poisson3d_csr_f64_i32(dev, q[0].raw(), n, ptr.raw(), col.raw(), val.raw()));
+            vex::SpMat<double, int, int> A1(one.queue(), N, N, nnz, ptr, col, val);
+            vex::vector<double> x1(one, N), yy(one, N);
+            vex::backend::check(vexhip_fill_hash(dev, q[0].raw(), VEXHIP_F64, 42ull, x1(0).raw(), (int64_t)N));
+            yy = A1 * x1;
+            vex::copy(yy, y1);
+            differing = 0;
+            for (size_t i = 0; i < N; ++i) differing += std::memcmp(&ym[i], &y1[i], 8) != 0;
+        }
+        std::printf("{\"row\": \"vex::SpMat<double,int,int> y = A*x, %s 7-point %lld^3, ONE vex::Context x%u\", \"front_end\": \"C++ vexcl/spmat.hpp\", "
+                    "\"step\": \"%s\", \"one_launch_step_declined\": \"%s\", \"elements_differing_from_one_device_product\": %lld, "
                     "\"devices\": %u, \"rows\": %zu, \"nnz\": %zu, \"setup_ms\": %.2f, \"ms\": %.5f, \"gflops\": %.1f, \"slowest_device_event_ms\": %.5f, "
                     "\"host_issue_us_per_product\": %.2f, \"csr_algorithmic_gbps\": %.1f, \"sum_y\": %.17g, \"per_device\": [",
-                variable ? "variable-coefficient" : "Poisson", (long long)n, D, D, N, nnz, setup_ms, wall_ms, 2.0 * nnz / wall_ms / 1e6, slowest,
+                variable ? "variable-coefficient" : "Poisson", (long long)n, D, A.step_kind(), A.halo_declined().c_str(), differing,
+                D, N, nnz, setup_ms, wall_ms, 2.0 * nnz / wall_ms / 1e6, slowest,
                 host_issue_us, (12.0 * nnz + 4.0 * (N + 1) + 16.0 * N) / wall_ms / 1e6, checksum);
         for (unsigned d = 0; d < D; ++d) {
             std::array<float, 4> med;
@@ -137,14 +165,16 @@ static int multi_device(int64_t n, int M, int want) {
 
 int main(int argc, char **argv) {
     int devices = -1;                       // -1: the single-device run
+    bool check_bits = false;
     std::vector<char *> pos;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) { ++i; devices = !std::strcmp(argv[i], "all") ? 0 : std::atoi(argv[i]); }
+        else if (!std::strcmp(argv[i], "--check")) check_bits = true;
         else pos.push_back(argv[i]);
     }
     const int64_t n = pos.size() > 0 ? std::atoll(pos[0]) : 512;
     const int M = pos.size() > 1 ? std::atoi(pos[1]) : 100;
-    if (devices >= 0) return multi_device(n, M, devices);
+    if (devices >= 0) return multi_device(n, M, devices, check_bits);
 
     vex::Context ctx(vex::Filter::Env && vex::Filter::Count(1));
     if (!ctx) { std::cerr << "no device" << std::endl; return 1; }

@@ -305,6 +305,9 @@ int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double al
         const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
 int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t ell_width, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane);
+/* planes per workgroup the fp32 plane product takes for this grid on a device of `cus` CUs (host arithmetic, no device): its walks
+ * are chosen per launch and must keep (depth + 4) planes of 2048-byte lines below 2^32 bytes; 0 = no depth fits (the launch fails) */
+int64_t vexhip_sell8_plane_f32_depth(int cus, int64_t lines_per_plane, int64_t planes);
 /* The GRID product (grid.hip, round 4; same semantics, hybrid_ell.inl:238-269; the size-agnostic stencil form the reference
  * reaches through SpMatCCSR, spmat/ccsr.hpp:55-113): the plane product for grids of any line length.  Value-coded storage
  * (with or without a slice dictionary: `blocks` may be NULL, `codes` is then the per-slice buffer) whose diagonals are
@@ -471,6 +474,13 @@ int vexhip_csr_split_f32_i32(int dev, void *stream, int64_t n, const int32_t *pt
         int64_t col_begin, int64_t col_end, int64_t *sizes, int32_t *lptr, int32_t *lcol, float *lval,
         int32_t *rem_rows, int32_t *rem_ptr, int32_t *rem_col, float *rem_val, int32_t *ghosts);
 
+/* The strip of one device WITH its ghost planes as one square matrix -- the operand of the one-launch step below (the reference keeps
+ * the remote columns in a second matrix, vexcl/spmat.hpp:291-378): `lo` empty rows, the strip's n rows, `hi` empty rows; columns
+ * col - (col_begin - lo), i.e. counted from the first element of the lower ghost plane.  ptr_ext[lo + n + hi + 1], col_ext[nnz]
+ * (values are shared with the strip).  *out_of_range = entries whose column lies outside the two ghost planes (the caller declines). */
+int vexhip_csr_extend_halo_i32(int dev, void *stream, int64_t n, int64_t nnz, const int32_t *ptr, const int32_t *col, int64_t col_begin,
+        int64_t lo, int64_t hi, int32_t *ptr_ext, int32_t *col_ext, int64_t *out_of_range);
+
 /* ---- RCCL transport over xGMI -------------------------------------------------------------
  * Replaces the host-staged ghost exchange of vexcl/spmat.hpp:125-183 / sparse/distributed.hpp:347-428 (device ->
  * host -> device, four finish() fences), the host fold of the Reductor partials (reductor.hpp:412-436) and the host
@@ -538,6 +548,10 @@ typedef struct vexhip_ipc_window vexhip_ipc_window;
 int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, vexhip_ipc_window **out);
 int vexhip_ipc_window_export(const vexhip_ipc_window *win, void *handle64);
 int vexhip_ipc_window_open(vexhip_ipc_window *win, int peer, const void *handle64);
+/* ONE process driving every GPU (vex::Context; the reference's model, vexcl/spmat.hpp:120-185): the peer's window is an address
+ * this process already holds -- no handle; distinct GPUs get hipDeviceEnablePeerAccess (which also covers the vectors a pull
+ * step reads in place).  `peer_win` must be rank `peer` of the same world.                                                       */
+int vexhip_ipc_window_attach(vexhip_ipc_window *win, int peer, const vexhip_ipc_window *peer_win);
 int vexhip_ipc_window_data(const vexhip_ipc_window *win, void **data);
 int vexhip_ipc_window_destroy(vexhip_ipc_window *win);
 int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *win, int dtype, int64_t rows, const vexhip_spmat *local,
@@ -556,6 +570,20 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *win, int dtype, int64_t rows,
  * The plan owns the window (no other plan on it).  Timeouts as above (NaN ghosts, sticky error).                          */
 int vexhip_dist_spmv_create_halo(vexhip_ipc_window *win, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
         vexhip_dist_spmv **out);
+/* Round 6 -- the PULL form of the one-launch step, for ONE process that drives every GPU (vex::SpMat on a multi-GPU vex::Context,
+ * vexcl/spmat.hpp; replaces the five phases of /root/reference/vexcl/spmat.hpp:120-185 and the set-up of :291-378): nothing is
+ * copied -- the planes next to a ghost plane read the NEIGHBOURS' boundary planes of x where they lie (peer access), passed with
+ * every product: x_below = the lower neighbour's LAST `halo` elements of its segment, x_above = the upper neighbour's FIRST ones
+ * (NULL where the plan has no neighbour).  order = VEXHIP_PULL_FLAGS: the windows (data_bytes 0, vexhip_ipc_window_attach) carry
+ * "x is final" (raised by the first workgroup of the owner's launch) and `consumed` (raised behind the launch; the same kernel
+ * waits for the neighbours' `consumed`, so that nothing behind it in the stream overwrites a plane still being read).
+ * order = VEXHIP_PULL_EVENTS: no flag, `win` may be NULL -- the CALLER orders the devices' streams with events (logical devices
+ * sharing one GPU may share a hardware queue, where a launch that waits for a later launch would never end).  Time-outs as above. */
+enum { VEXHIP_PULL_FLAGS = 1, VEXHIP_PULL_EVENTS = 2 };
+int vexhip_dist_spmv_create_halo_pull(vexhip_ipc_window *win, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
+        int order, vexhip_dist_spmv **out);
+int vexhip_dist_spmv_apply_pull(vexhip_dist_spmv *step, void *stream, double alpha, int append, const void *x, void *y,
+        const void *x_below, const void *x_above);
 /* Diagnostics of the one-launch step (VEXHIP_HALO_DEBUG=1 in the environment when the plan is created): six 64-bit words per
  * workgroup of the last launch -- start, ghost flag seen, first ghost line in registers, end (100 MHz ticks), first plane, end
  * plane (push workgroups: ~0, side) -- copied to `out` (at most 4096 workgroups).  tools/r05_halo_timeline.py.                    */

@@ -164,3 +164,10 @@ def test_plane_walks_are_one_per_cu_or_many(built_lib):
         walks = (nz + d - 1) // d
         assert (ny // 2) * walks >= 6 * 256 and d >= 16, (ny, nz, d)
     assert depth(640, 640) == 80 and depth(384, 768) == 96
+    # round 6 (advisor): the fp32 product chooses its own walks; (depth + 4) planes of 2048-byte lines must stay below 2^32 bytes
+    # for THAT depth -- ny = 8192, nz = 256 passed the fp64 plan's check at depth 64 and then walked all 256 planes in one workgroup
+    for ny, nz in ((8192, 256), (4096, 1024), (512, 512), (512, 64), (16384, 128), (1 << 20, 8)):
+        d = L.sell8_plane_f32_depth(256, ny, nz)
+        assert d == 0 or (1 <= d <= nz and (d + 4) * ny * 2048 < 2 ** 32), (ny, nz, d)
+    assert L.sell8_plane_f32_depth(256, 8192, 256) in range(1, 253) and L.sell8_plane_f32_depth(256, 512, 512) == 43
+    assert L.sell8_plane_f32_depth(256, 1 << 20, 8) == 0          # twelve planes of 2 GiB: no walk fits

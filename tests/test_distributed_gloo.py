@@ -57,6 +57,18 @@ def _worker(rank, world, port, case, out):
             n = 12
             ptr, col, val = oracle.poisson3d(n)
             N = M = n ** 3
+        elif case == "upwind":
+            # a ONE-SIDED coupling: the lower triangle of the Poisson matrix (entries at -n^2, -n, -1, 0 only).  Rank r has ghosts
+            # from r - 1 and nobody has ghosts from r - 1's upper neighbour: the one-launch step's push / `sent` protocol would wait
+            # for a flag nobody raises (advisor, round 5) -- _halo_plan must decline it on EVERY rank, by name
+            n = 12
+            ptr, col, val = oracle.poisson3d(n)
+            N = M = n ** 3
+            rows = np.repeat(np.arange(N), np.diff(ptr))
+            keep = col <= rows
+            cnt = np.bincount(rows[keep], minlength=N)
+            ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(ptr.dtype)
+            col, val = col[keep].copy(), val[keep].copy()
         elif case == "random_square":
             N = M = 1024
             ptr, col, val = oracle.random_matrix(7, N, M, 16)
@@ -75,7 +87,15 @@ def _worker(rank, world, port, case, out):
         j0, j1 = int(ptr[r0]), int(ptr[r1])
         A = DistSpMat(torch.from_numpy((ptr[r0:r1 + 1] - ptr[r0]).astype(np.int32)),
                       torch.from_numpy(col[j0:j1].copy()), torch.from_numpy(val[j0:j1].copy()),
-                      N, M, kernels=OracleKernels())
+                      N, M, kernels=OracleKernels(), keep_strip=(case == "upwind"))
+        if case == "upwind":
+            try:
+                A._halo_plan()
+                declined = False
+            except RuntimeError as e:
+                declined = "not symmetric" in str(e)
+            assert declined, "a one-sided coupling must be declined by the one-launch step's plan"
+            assert A.enable_native(transport="halo") is False and A.native_error is not None
         # the split must agree with the oracle's restatement of spmat.hpp:291-378
         S = oracle.split_rows(ptr, col, val, M, world)["devs"][rank]
         assert np.array_equal(A.ghosts.numpy(), S["ghosts"])
@@ -131,7 +151,7 @@ def _worker(rank, world, port, case, out):
 
 
 @pytest.mark.parametrize("world,case", [(2, "poisson"), (2, "random_square"), (3, "nonsquare"), (3, "poisson"), (4, "random_square"),
-                                        (8, "poisson")])
+                                        (8, "poisson"), (3, "upwind")])
 def test_distributed_spmv_gloo(world, case, oracle):
     ctx = mp.get_context("spawn")
     out = ctx.Array("i", [0] * world)

@@ -158,7 +158,7 @@ def _halo_worker(rank, world, port, planes_per_rank, ny, out):
         r0, r1 = part[rank], part[rank + 1]
         assert (r1 - r0) == planes_per_rank * nx * ny
         ptr, col, val = _stencil_strip(torch, nx, ny, nz, r0, r1, dev)
-        A = DistSpMat(ptr, col, val, N, N)
+        A = DistSpMat(ptr, col, val, N, N, keep_strip=True)
         # the whole matrix on one "device": the bits the N-rank product must reproduce (the stored strip keeps a row's entries in
         # column order, ghost columns included -- unlike the split step, which adds the remote entries last)
         fp, fc, fv = _stencil_strip(torch, nx, ny, nz, 0, N, dev)

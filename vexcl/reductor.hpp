@@ -227,7 +227,11 @@ class Reductor {
                     const auto t0 = std::chrono::steady_clock::now();
                     unsigned spins = 0;
                     while (*seen != bufs[d]->seq) {
+#if defined(__x86_64__) || defined(__i386__)
                         __builtin_ia32_pause();
+#elif defined(__aarch64__)
+                        asm volatile("yield" ::: "memory");
+#endif
                         if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) { queue[d].finish(); break; }
                     }
                     std::atomic_thread_fence(std::memory_order_acquire);

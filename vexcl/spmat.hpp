@@ -16,8 +16,10 @@
 // secondary queues -- grouped ncclSend / ncclRecv over xGMI between GPUs, event-ordered copies between
 // logical devices of one GPU -- while the local product runs; the remote product waits on an event.
 #include <array>
+#include <cstring>
 #include <exception>
 #include <memory>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -53,7 +55,8 @@ class SpMat {
                 mtx[d] = std::make_shared<device_part>(queue[d], row + part[d], row + part[d + 1], col, val,
                         col_part[d], col_part[d + 1], ghosts[d], queue.size() == 1);
             });
-            if (queue.size() > 1) exc.setup(queue, col_part, ghosts);
+            if (queue.size() > 1) { exc.setup(queue, col_part, ghosts); setup_halo(ghosts); }
+            for (auto &m : mtx) m->release_strip();
         }
 
         /// From per-device DEVICE strips (round 4): strip d holds rows part[d] .. part[d+1] of the matrix (part =
@@ -84,7 +87,8 @@ class SpMat {
                 mtx[d] = std::make_shared<device_part>(queue[d], part[d + 1] - part[d], nonzeros[d], row[d], col[d], val[d],
                         col_part[d], col_part[d + 1], ghosts[d], nd == 1);
             });
-            if (nd > 1) exc.setup(queue, col_part, ghosts);
+            if (nd > 1) { exc.setup(queue, col_part, ghosts); setup_halo(ghosts); }
+            for (auto &m : mtx) m->release_strip();
         }
 
         /// From DEVICE CSR arrays (int32 row pointers and columns, `nonzeros` entries): nothing is staged through the
@@ -121,13 +125,24 @@ class SpMat {
         size_t cols() const { return ncols; }
         size_t nonzeros() const { return nnz; }
         /// Storage the library chose for device d's local part (VEXHIP_SPMAT_*; info.matrix_bytes = bytes a product streams).
-        const vexhip_spmat_info &storage_info(unsigned d = 0) const { return mtx[d]->loc.info; }
+        const vexhip_spmat_info &storage_info(unsigned d = 0) const { return halo.active() ? halo.info(d) : mtx[d]->loc.info; }
+        /// How a product on a multi-device context runs: "one launch per device (...)" -- the strip of every device stored with its
+        /// two ghost planes, the neighbours' boundary planes of x read in place (vexhip_dist_spmv_create_halo_pull) -- or
+        /// "pack / exchange / local / remote" (vexcl/exchange.hpp), or "one device".
+        const char *step_kind() const {
+            if (halo.active()) return halo.order == VEXHIP_PULL_FLAGS ? "one launch per device (ghost planes read in place behind flags)"
+                                                                      : "one launch per device (ghost planes read in place, streams ordered by events)";
+            return queue.size() > 1 && exc.active() ? "pack / exchange / local / remote" : (queue.size() > 1 ? "block-diagonal: local parts only" : "one device");
+        }
+        /// Why the one-launch step was not taken on this multi-device context ("" if it was, or on one device).
+        const std::string &halo_declined() const { return halo.why; }
 
         /// y = alpha * A * x  or  y += alpha * A * x  (spmat.hpp:120-185).
         template <class T>
         void apply(const vex::vector<T> &x, vex::vector<T> &y, scalar_type alpha = 1, bool append = false) const {
             static_assert(std::is_same<T, val_t>::value, "vector and matrix value types differ");
             precondition(x.size() == ncols && y.size() == nrows, "SpMat::apply: incompatible sizes");
+            if (halo.active()) { halo.apply(queue, x, y, alpha, append); return; }      // the whole step of a device in ONE launch (below)
             const bool exchange = queue.size() > 1 && exc.active();
             if (exchange) exc.start(x);                  // pack + ship on the secondary queues
             for (unsigned d = 0; d < queue.size(); ++d)   // local part, overlapped with the exchange
@@ -158,8 +173,12 @@ class SpMat {
             for (unsigned d = 0; d < nd; ++d)
                 for (int k = 0; k < 4; ++k) backend::check(vexhip_event_create(queue[d].device_ordinal(), 1, &ev[d][k]));
             auto mark = [&](unsigned d, int k) { backend::check(vexhip_event_record(queue[d].device_ordinal(), ev[d][k], queue[d].raw())); };
-            const bool exchange = nd > 1 && exc.active();
+            const bool exchange = nd > 1 && exc.active() && !halo.active();
             for (unsigned d = 0; d < nd; ++d) mark(d, 0);
+            if (halo.active()) {         // one launch per device: there are no phases to tell apart -- {step, step, 0, 0}
+                halo.apply(queue, x, y, alpha, append);
+                for (unsigned d = 0; d < nd; ++d) { mark(d, 1); mark(d, 2); mark(d, 3); }
+            } else {
             if (exchange) exc.start(x);
             for (unsigned d = 0; d < nd; ++d) {
                 if (part[d + 1] > part[d]) mtx[d]->mul_local(queue[d], x(d), y(d), alpha, append);
@@ -171,6 +190,7 @@ class SpMat {
                 mark(d, 2);
                 if (rem) mtx[d]->mul_remote(queue[d], exc.ghost_buffer(d), y(d), alpha);
                 mark(d, 3);
+            }
             }
             ms.assign(nd, std::array<float, 4>{{0, 0, 0, 0}});
             for (unsigned d = 0; d < nd; ++d) {
@@ -290,6 +310,7 @@ class SpMat {
                     const backend::device_vector<val_t> &dval, size_t col_begin, size_t col_end, std::vector<col_t> &ghost_cols)
             {
                 const int dev = q.device_ordinal();
+                strip_ptr = dptr; strip_col = dcol; strip_val = dval;
                 int64_t sz[4] = {0, 0, 0, 0};
                 backend::check(vexhip_csr_split_sizes_i32(dev, q.raw(), (int64_t)n, dptr.raw(), dcol.raw(), (int64_t)col_begin, (int64_t)col_end, sz));
                 backend::device_vector<int> lptr(q, n + 1), lcol(q, (size_t)sz[0]);
@@ -334,6 +355,10 @@ class SpMat {
             }
 
             backend::device_vector<int> rem_rows;
+
+            // the strip as it came (device arrays, GLOBAL columns), kept while the constructor decides how the product runs
+            backend::device_vector<int> strip_ptr, strip_col; backend::device_vector<val_t> strip_val;
+            void release_strip() { strip_ptr = backend::device_vector<int>(); strip_col = backend::device_vector<int>(); strip_val = backend::device_vector<val_t>(); }
 
             static bool use_ell() {
 #ifdef VEXCL_SPMAT_CSR
@@ -406,6 +431,149 @@ class SpMat {
         };
 
     private:
+        // ---- the product step of a device in ONE launch (round 6; csrc/halo.hpp, plane.hip) -------------------------------------
+        // Where every device's remote columns are the plane below its first row and the plane above its last one (a plane partition
+        // of a 7-point operator on 512-point grid lines: the headline), the strip is stored ONCE, as a grid matrix that includes its
+        // two ghost planes, and the plane product reads those planes from the NEIGHBOURS' segments of x where they lie (peer access)
+        // -- no pack, no exchange, no remote part (the five phases of /root/reference/vexcl/spmat.hpp:120-185 and the set-up of
+        // :291-378).  The bits are those of the one-device product (a row's entries stay in column order).
+        // Distinct GPUs: flags in small uncached windows order the launches (VEXHIP_PULL_FLAGS).  Logical devices that share a GPU
+        // (the reference's test fixture): events between the queues (VEXHIP_PULL_EVENTS).  VEXCL_HALO=off|flags|events overrides.
+        // Anything else -- general matrices, other grids, float -- keeps the exchange of vexcl/exchange.hpp; halo_declined() says why.
+        struct halo_steps {
+            struct dev_t {
+                std::shared_ptr<vexhip_spmat> ext; std::shared_ptr<vexhip_ipc_window> win; std::shared_ptr<vexhip_dist_spmv> step;
+                vexhip_spmat_info info = vexhip_spmat_info();
+                bool lo = false, hi = false;
+                void *ready = nullptr, *done = nullptr; int ordinal = 0;
+                ~dev_t() { step.reset(); win.reset(); ext.reset(); if (ready) vexhip_event_destroy(ordinal, ready); if (done) vexhip_event_destroy(ordinal, done); }
+            };
+            std::vector<std::shared_ptr<dev_t>> dev;
+            size_t H = 0; int order = 0; bool on = false;
+            std::string why;
+            bool active() const { return on; }
+            const vexhip_spmat_info &info(unsigned d) const { return dev[d]->info; }
+
+            template <class T>
+            void apply(const std::vector<backend::command_queue> &q, const vex::vector<T> &x, vex::vector<T> &y, val_t alpha, bool append) const {
+                const unsigned nd = static_cast<unsigned>(q.size());
+                auto below = [&](unsigned d) -> const void * { return dev[d]->lo ? static_cast<const void *>(x(d - 1).raw() + (x.part_size(d - 1) - H)) : nullptr; };
+                auto above = [&](unsigned d) -> const void * { return dev[d]->hi ? static_cast<const void *>(x(d + 1).raw()) : nullptr; };
+                if (order == VEXHIP_PULL_FLAGS) {
+                    for (unsigned d = 0; d < nd; ++d)
+                        backend::check(vexhip_dist_spmv_apply_pull(dev[d]->step.get(), q[d].raw(), (double)alpha, append ? 1 : 0, x(d).raw(), y(d).raw(), below(d), above(d)));
+                    return;
+                }
+                // events: x of the neighbours is final before a launch reads it; the launch has finished before they go on
+                auto record = [&](unsigned d, void *e) { backend::check(vexhip_event_record(q[d].device_ordinal(), e, q[d].raw())); };
+                auto wait = [&](unsigned d, void *e) { backend::check(vexhip_stream_wait_event(q[d].device_ordinal(), q[d].raw(), e)); };
+                for (unsigned d = 0; d < nd; ++d) record(d, dev[d]->ready);
+                for (unsigned d = 0; d < nd; ++d) {
+                    if (dev[d]->lo) wait(d, dev[d - 1]->ready);
+                    if (dev[d]->hi) wait(d, dev[d + 1]->ready);
+                    backend::check(vexhip_dist_spmv_apply_pull(dev[d]->step.get(), q[d].raw(), (double)alpha, append ? 1 : 0, x(d).raw(), y(d).raw(), below(d), above(d)));
+                    record(d, dev[d]->done);
+                }
+                for (unsigned d = 0; d < nd; ++d) {
+                    if (dev[d]->lo) wait(d, dev[d - 1]->done);
+                    if (dev[d]->hi) wait(d, dev[d + 1]->done);
+                }
+            }
+        };
+        halo_steps halo;
+
+        template <class V> static typename std::enable_if<!std::is_same<V, double>::value, bool>::type is_double() { return false; }
+        template <class V> static typename std::enable_if<std::is_same<V, double>::value, bool>::type is_double() { return true; }
+
+        /// Decides whether this matrix on this context takes the one-launch step, and builds it (all devices at once).
+        void setup_halo(const std::vector<std::vector<col_t>> &ghosts) {
+            const unsigned nd = static_cast<unsigned>(queue.size());
+            halo = halo_steps();
+            int order = 0;
+            {
+                bool shared = false;
+                for (unsigned a = 0; a < nd; ++a) for (unsigned b = a + 1; b < nd; ++b) shared = shared || queue[a].device_ordinal() == queue[b].device_ordinal();
+                order = shared ? VEXHIP_PULL_EVENTS : VEXHIP_PULL_FLAGS;
+                if (const char *e = std::getenv("VEXCL_HALO")) {
+                    if (!std::strcmp(e, "off")) { halo.why = "VEXCL_HALO=off"; return; }
+                    if (!std::strcmp(e, "events")) order = VEXHIP_PULL_EVENTS;
+                    if (!std::strcmp(e, "flags") && !shared) order = VEXHIP_PULL_FLAGS;
+                }
+            }
+            if (!exc.active()) { halo.why = "no ghost columns"; return; }
+            if (!is_double<val_t>()) { halo.why = "value type is not double"; return; }
+            if (nrows != ncols || part != col_part) { halo.why = "rows and columns are partitioned differently"; return; }
+            // H = elements of a ghost plane: every device's remote columns lie within H of its own (rounded to whole pairs of 512-point lines)
+            size_t reach = 0;
+            std::vector<char> lo(nd, 0), hi(nd, 0);
+            for (unsigned d = 0; d < nd; ++d) {
+                if (part[d + 1] == part[d]) { halo.why = "a device owns no rows"; return; }
+                for (const col_t &g : ghosts[d]) {
+                    const size_t c = static_cast<size_t>(g);
+                    if (c < col_part[d]) { lo[d] = 1; reach = std::max(reach, col_part[d] - c); }
+                    else { hi[d] = 1; reach = std::max(reach, c + 1 - col_part[d + 1]); }
+                }
+            }
+            const size_t Hh = (reach + 1023) / 1024 * 1024;
+            if (!Hh) { halo.why = "no ghost columns"; return; }
+            for (unsigned d = 0; d < nd; ++d) {
+                const size_t rows = part[d + 1] - part[d];
+                if (rows % Hh || rows < Hh) { halo.why = "a strip is not a whole number of planes of " + std::to_string(Hh) + " elements"; return; }
+                if ((lo[d] && d == 0) || (hi[d] && d + 1 == nd)) { halo.why = "ghost columns outside the matrix"; return; }
+                // symmetric coupling: the flag protocol hands `consumed` back to exactly the neighbours it reads from
+                if (d + 1 < nd && hi[d] != lo[d + 1]) { halo.why = "the coupling between neighbouring strips is not symmetric"; return; }
+            }
+            std::vector<std::shared_ptr<typename halo_steps::dev_t>> dev(nd);
+            std::vector<std::string> declined(nd);
+            try {
+                per_device([&](unsigned d) {
+                    auto D = std::make_shared<typename halo_steps::dev_t>();
+                    const backend::command_queue &q = queue[d];
+                    const int ord = q.device_ordinal();
+                    D->ordinal = ord; D->lo = lo[d]; D->hi = hi[d];
+                    const device_part &P = *mtx[d];
+                    const size_t rows = part[d + 1] - part[d], l = lo[d] ? Hh : 0, h = hi[d] ? Hh : 0, snnz = P.loc.nnz + P.rem.nnz;
+                    if (P.strip_ptr.size() != rows + 1) { declined[d] = "the strip is not on the device any more"; return; }
+                    backend::device_vector<int> eptr(q, l + rows + h + 1), ecol(q, std::max<size_t>(1, snnz));
+                    int64_t bad = 0;
+                    backend::check(vexhip_csr_extend_halo_i32(ord, q.raw(), (int64_t)rows, (int64_t)snnz, P.strip_ptr.raw(), P.strip_col.raw(), (int64_t)col_part[d],
+                                (int64_t)l, (int64_t)h, eptr.raw(), ecol.raw(), &bad));
+                    if (bad) { declined[d] = "columns outside the two ghost planes"; return; }
+                    vexhip_spmat *e = nullptr;
+                    backend::check(spmat_create(ord, q.raw(), (int64_t)(l + rows + h), eptr.raw(), ecol.raw(), reinterpret_cast<const double *>(P.strip_val.raw()), VEXHIP_SPMAT_AUTO, VEXHIP_SPMAT_SQUARE, &e));
+                    D->ext = std::shared_ptr<vexhip_spmat>(e, [](vexhip_spmat *p) { vexhip_spmat_destroy(p); });
+                    backend::check(vexhip_spmat_get_info(e, &D->info));
+                    const auto &pl = D->info.plane;
+                    if (!pl.usable || (size_t)pl.lines_per_plane * 512 != Hh || (size_t)pl.planes * Hh != l + rows + h) { declined[d] = "the strip with its ghost planes is not stored for the plane product"; return; }
+                    if (order == VEXHIP_PULL_FLAGS) {
+                        vexhip_ipc_window *w = nullptr;
+                        backend::check(vexhip_ipc_window_create(ord, (int)d, (int)nd, 0, &w));
+                        D->win = std::shared_ptr<vexhip_ipc_window>(w, [](vexhip_ipc_window *p) { vexhip_ipc_window_destroy(p); });
+                    } else {
+                        backend::check(vexhip_event_create(ord, 0, &D->ready));
+                        backend::check(vexhip_event_create(ord, 0, &D->done));
+                    }
+                    dev[d] = D;
+                });
+            } catch (const std::exception &e) { halo.why = std::string("set-up failed: ") + e.what(); return; }
+            for (unsigned d = 0; d < nd; ++d) if (!dev[d]) { halo.why = "device " + std::to_string(d) + ": " + declined[d]; return; }
+            try {
+                for (unsigned d = 0; d < nd; ++d) {        // the windows exist on every device: attach the neighbours', then the steps
+                    if (order == VEXHIP_PULL_FLAGS) {
+                        if (lo[d]) backend::check(vexhip_ipc_window_attach(dev[d]->win.get(), (int)d - 1, dev[d - 1]->win.get()));
+                        if (hi[d]) backend::check(vexhip_ipc_window_attach(dev[d]->win.get(), (int)d + 1, dev[d + 1]->win.get()));
+                    }
+                    vexhip_dist_spmv *st = nullptr;
+                    backend::check(vexhip_dist_spmv_create_halo_pull(dev[d]->win.get(), dev[d]->ext.get(), (int64_t)(part[d + 1] - part[d]), (int64_t)Hh,
+                                lo[d] ? (int)d - 1 : -1, hi[d] ? (int)d + 1 : -1, order, &st));
+                    dev[d]->step = std::shared_ptr<vexhip_dist_spmv>(st, [](vexhip_dist_spmv *p) { vexhip_dist_spmv_destroy(p); });
+                }
+            } catch (const std::exception &e) { halo.why = std::string("set-up failed: ") + e.what(); return; }
+            halo.dev = dev; halo.H = Hh; halo.order = order; halo.on = true;
+            // the split parts are not needed any more: the stored strips hold every entry
+            for (unsigned d = 0; d < nd; ++d) { mtx[d]->loc = matrix_arrays(); mtx[d]->rem = matrix_arrays(); mtx[d]->rem_rows = backend::device_vector<int>(); }
+        }
+
         /// f(d) for every device, each on its own host thread when there are several (the C ABI keeps its state per thread
         /// and per device); the first exception is rethrown here.
         template <class F>

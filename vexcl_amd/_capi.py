@@ -179,6 +179,7 @@ _PROTOS = {
     "vexhip_sell8_grid_release": (None, [c_int, ctypes.POINTER(Grid)]),
     "vexhip_sell8_grid_geometry": (None, [c_int, c_i64, c_i64, c_i64, ctypes.POINTER(Grid)]),
     "vexhip_sell8_plane_geometry": (None, [c_int, c_i64, c_i64, ctypes.POINTER(Plane)]),
+    "vexhip_sell8_plane_f32_depth": (c_i64, [c_int, c_i64, c_i64]),
     "vexhip_sell8_grid_check": (None, [ctypes.POINTER(Grid), c_i64]),
     "vexhip_spmv_sell8v_grid_f64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(Grid)]),
     "vexhip_spmv_sell8v_grid_f32": (None, [c_int, c_vp, c_i64, c_f32, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(Grid)]),
@@ -223,6 +224,10 @@ _PROTOS = {
     "vexhip_ipc_window_destroy": (None, [c_vp]),
     "vexhip_dist_spmv_debug": (None, [c_vp, c_vp, c_i64]),
     "vexhip_dist_spmv_create_halo": (None, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_dist_spmv_create_halo_pull": (None, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "vexhip_dist_spmv_apply_pull": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "vexhip_ipc_window_attach": (None, [c_vp, c_int, c_vp]),
+    "vexhip_csr_extend_halo_i32": (None, [c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64)]),
     "vexhip_dist_spmv_create_ipc": (None, [c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64),
                                            ctypes.POINTER(c_i64), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_vp)]),
     "vexhip_dist_spmv_status": (None, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

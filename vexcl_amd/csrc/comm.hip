@@ -25,6 +25,7 @@
 namespace vexhip {
 // spmat.hip: the stored strip of a rank as the operand of the one-launch step (halo.hpp)
 int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane);
+int spmat_device(const vexhip_spmat *h, int *dev);
 int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const double *x, double *y, const halo_dev &H);
 }
 namespace vexhip {
@@ -178,6 +179,7 @@ struct ipc_window {
     int dev = 0, rank = 0, world = 1;
     int64_t data_bytes = 0;
     size_t bytes = 0;
+    bool uncached = true;                      // hipDeviceMallocUncached (the default): no cache ever holds a line of the window
     char *base = nullptr;
     std::vector<char *> peer;                  // base address of every opened window (own pointer for this rank)
     std::vector<char> opened;                  // mapped with hipIpcOpenMemHandle (to be closed)
@@ -318,6 +320,10 @@ struct dist_spmv {
     halo_dev hd;
     unsigned *d_halo_done = nullptr;
     unsigned long long *d_halo_debug = nullptr;
+    int pull = 0;                              // 0 pushed shares; 1 the neighbours' planes of x read in place behind flags; 2 ... ordered by the host's events
+    bool has_lo = false, has_hi = false;
+    unsigned long long *d_own_step = nullptr;  // pull == 2 without a window: the (unused) step word
+    const void *glo = nullptr, *ghi = nullptr; // pull: the ghost planes of the captured step
     // optional phase timing of one step (vexhip_dist_spmv_profile)
     hipEvent_t *prof = nullptr;                // [0..3] compute stream: start, local done, ghosts here, end; [4..6] comm stream: start, packed, exchanged
 };
@@ -759,6 +765,7 @@ int vexhip_dist_spmv_destroy(vexhip_dist_spmv *h) {
     if (D->d_consumed) (void)hipFree(D->d_consumed);
     if (D->d_halo_done) (void)hipFree(D->d_halo_done);
     if (D->d_halo_debug) (void)hipFree(D->d_halo_debug);
+    if (D->d_own_step) (void)hipFree(D->d_own_step);
     delete D;
     return 0;
 }
@@ -771,17 +778,39 @@ int vexhip_dist_spmv_set_graph(vexhip_dist_spmv *h, int enable) {
     return 0;
 }
 
+static int dist_spmv_apply_impl(dist_spmv *D, void *stream, double alpha, int append, const void *x, void *y);
+
 int vexhip_dist_spmv_apply(vexhip_dist_spmv *h, void *stream, double alpha, int append, const void *x, void *y) {
     dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
     VEXHIP_REQUIRE(D && (x || !D->rows) && (y || !D->rows), "NULL argument");
-    if (!D->win && (D->nsend || D->nghost)) RCCL_READY();
+    VEXHIP_REQUIRE(!D->pull, "a pull plan takes the neighbours' planes with every product: vexhip_dist_spmv_apply_pull");
+    return dist_spmv_apply_impl(D, stream, alpha, append, x, y);
+}
+
+// PULL (round 6): x_below / x_above = the lower neighbour's LAST plane and the upper neighbour's FIRST plane of ITS segment of the
+// same vector (`halo` elements each, readable from this device: peer access), NULL where the plan has no neighbour.
+int vexhip_dist_spmv_apply_pull(vexhip_dist_spmv *h, void *stream, double alpha, int append, const void *x, void *y,
+        const void *x_below, const void *x_above) {
+    dist_spmv *D = reinterpret_cast<dist_spmv *>(h);
+    VEXHIP_REQUIRE(D && x && y, "NULL argument");
+    VEXHIP_REQUIRE(D->halo && D->pull, "not a pull plan (vexhip_dist_spmv_create_halo_pull)");
+    VEXHIP_REQUIRE((x_below != nullptr) == D->has_lo && (x_above != nullptr) == D->has_hi, "the neighbours' planes do not match the plan's neighbours");
+    VEXHIP_REQUIRE(((reinterpret_cast<uintptr_t>(x_below) | reinterpret_cast<uintptr_t>(x_above)) & 15) == 0, "the neighbours' planes must be 16-byte aligned");
+    if (D->exec && (D->glo != x_below || D->ghi != x_above)) { (void)hipGraphExecDestroy(D->exec); D->exec = nullptr; }
+    D->glo = x_below; D->ghi = x_above;
+    D->hd.lo = static_cast<const double *>(x_below); D->hd.hi = static_cast<const double *>(x_above);
+    return dist_spmv_apply_impl(D, stream, alpha, append, x, y);
+}
+
+static int dist_spmv_apply_impl(dist_spmv *D, void *stream, double alpha, int append, const void *x, void *y) {
+    if (!D->win && !D->halo && (D->nsend || D->nghost)) RCCL_READY();
     VEXHIP_SET_DEVICE(D->dev);
     hipStream_t s = as_stream(stream);
     // Steps with an RCCL exchange are always issued directly: capturing ncclSend / ncclRecv into a hipGraph crashes in this RCCL
     // (2.26.6, measured with tools/r02_dist_step.py).  The IPC step is kernels and events only -- its step numbers live in
     // device memory -- and replays like a step without an exchange (tools/r04_dist_step.py: host time per product).
-    if (!D->use_graph || (!D->win && (D->nsend || D->nghost))) return issue_step(D, s, alpha, append, x, y);
-    if (D->win && D->d_err && *static_cast<volatile int *>(D->d_err))
+    if (!D->use_graph || (!D->win && !D->halo && (D->nsend || D->nghost))) return issue_step(D, s, alpha, append, x, y);
+    if (D->d_err && *static_cast<volatile int *>(D->d_err))
         return fail(__FILE__, __LINE__, "an earlier product of this plan timed out waiting for a peer's ghost flag (IPC transport, VEXHIP_IPC_TIMEOUT_MS): "
                                         "its result and every later one are invalid");
     // replay: the captured step is valid for exactly these operands
@@ -823,6 +852,7 @@ int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, v
         if (std::string(m) == "finegrained") kind = hipDeviceMallocFinegrained;
         else if (std::string(m) == "default") kind = hipDeviceMallocDefault;
     }
+    w->uncached = kind == hipDeviceMallocUncached;
     hipError_t e = hipExtMallocWithFlags(&p, w->bytes, kind);
     if (e == hipSuccess) e = hipMemset(p, 0, w->bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -858,6 +888,26 @@ int vexhip_ipc_window_open(vexhip_ipc_window *h, int peer, const void *handle64)
     void *p = nullptr;
     VEXHIP_TRY(hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
     w->peer[peer] = static_cast<char *>(p); w->opened[peer] = 1;
+    return 0;
+}
+
+// One process driving several devices (vex::Context): the peer's window is an address this process already has -- no handle to
+// export or open; distinct GPUs get peer access in both directions (which covers every allocation of the peer, the vectors the
+// pull step reads in place included).
+int vexhip_ipc_window_attach(vexhip_ipc_window *h, int peer, const vexhip_ipc_window *hp) {
+    ipc_window *w = reinterpret_cast<ipc_window *>(h);
+    const ipc_window *pw = reinterpret_cast<const ipc_window *>(hp);
+    VEXHIP_REQUIRE(w && pw && peer >= 0 && peer < w->world && pw->rank == peer && pw->world == w->world, "bad argument");
+    if (w->dev != pw->dev) {
+        int can = 0;
+        VEXHIP_TRY(hipDeviceCanAccessPeer(&can, w->dev, pw->dev));
+        VEXHIP_REQUIRE(can, "the devices cannot access each other's memory (no peer access)");
+        VEXHIP_SET_DEVICE(w->dev);
+        hipError_t e = hipDeviceEnablePeerAccess(pw->dev, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+        VEXHIP_TRY(e);
+    }
+    w->peer[peer] = pw->base; w->opened[peer] = 0;
     return 0;
 }
 
@@ -973,41 +1023,79 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
 // empty rows (one plane) in front of the rank's rows when it has a lower neighbour, one plane of empty rows behind them when it
 // has an upper one, columns counted from the first element of the lower ghost plane.  The window holds [lower ghost plane | upper
 // ghost plane]; the neighbours' windows must have been opened.  The plan owns the window's step counter (no other plan on it).
+static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper, int pull, vexhip_dist_spmv **out);
+
 int vexhip_dist_spmv_create_halo(vexhip_ipc_window *hw, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
         vexhip_dist_spmv **out)
 {
-    ipc_window *w = reinterpret_cast<ipc_window *>(hw);
+    return create_halo_impl(reinterpret_cast<ipc_window *>(hw), ext, rows, halo, lower, upper, 0, out);
+}
+
+// The PULL form of the one-launch step (round 6; one process drives every GPU): no share is copied -- the planes next to a ghost plane
+// read the neighbours' boundary planes of x where they lie (vexhip_dist_spmv_apply_pull passes them with every product).
+// order = VEXHIP_PULL_FLAGS: the windows (vexhip_ipc_window_create with data_bytes 0 + vexhip_ipc_window_attach) carry the flags
+// ("x is final" at launch start, `consumed` behind the launch; the kernel behind the launch also waits for the neighbours'
+// `consumed`).  order = VEXHIP_PULL_EVENTS: no flag is raised or waited for (`win` may be NULL): the CALLER orders the devices'
+// streams with events -- x of the neighbours final before this launch, this launch finished before they overwrite x.
+int vexhip_dist_spmv_create_halo_pull(vexhip_ipc_window *hw, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
+        int order, vexhip_dist_spmv **out)
+{
+    VEXHIP_REQUIRE(order == VEXHIP_PULL_FLAGS || order == VEXHIP_PULL_EVENTS, "order must be VEXHIP_PULL_FLAGS or VEXHIP_PULL_EVENTS");
+    return create_halo_impl(reinterpret_cast<ipc_window *>(hw), ext, rows, halo, lower, upper, order, out);
+}
+
+static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper, int pull, vexhip_dist_spmv **out)
+{
     VEXHIP_REQUIRE(out, "NULL output");
     *out = nullptr;
-    VEXHIP_REQUIRE(w && ext, "NULL argument");
+    VEXHIP_REQUIRE((w || pull == 2) && ext, "NULL argument");
     VEXHIP_REQUIRE(rows > 0 && halo > 0 && halo < (1ll << 31) && rows % halo == 0, "the rank's rows must be whole planes of `halo` elements");
-    VEXHIP_REQUIRE(lower >= -1 && lower < w->world && upper >= -1 && upper < w->world, "bad neighbour");
-    VEXHIP_REQUIRE(2 * halo * 8 <= w->data_bytes, "the window is smaller than two ghost planes");
+    const int world = w ? w->world : (1 << 30);
+    VEXHIP_REQUIRE(lower >= -1 && lower < world && upper >= -1 && upper < world, "bad neighbour");
+    VEXHIP_REQUIRE(pull || 2 * halo * 8 <= w->data_bytes, "the window is smaller than two ghost planes");
     int planes = 0, ny = 0;
     if (int rc = spmat_halo_geometry(ext, &planes, &ny)) return rc;
     const int has_lo = lower >= 0 ? 1 : 0, has_hi = upper >= 0 ? 1 : 0;
     VEXHIP_REQUIRE(planes > 0 && (int64_t)ny * 512 == halo && planes == has_lo + rows / halo + has_hi,
                    "the stored strip is not a plane-product matrix of (lower ghost plane +) the rank's planes (+ upper ghost plane)");
-    VEXHIP_REQUIRE((lower < 0 || w->peer[lower]) && (upper < 0 || w->peer[upper]), "a neighbour's window has not been opened (vexhip_ipc_window_open)");
+    VEXHIP_REQUIRE(!w || ((lower < 0 || w->peer[lower]) && (upper < 0 || w->peer[upper])), "a neighbour's window has not been opened (vexhip_ipc_window_open / _attach)");
+    int ext_dev = 0;
+    if (int rc = spmat_device(ext, &ext_dev)) return rc;
+    VEXHIP_REQUIRE(!w || w->dev == ext_dev, "the window and the stored strip live on different devices");
     dist_spmv *D = new (std::nothrow) dist_spmv;
     VEXHIP_REQUIRE(D, "out of host memory");
-    D->win = w; D->dev = w->dev; D->dtype = VEXHIP_F64; D->rows = rows; D->halo = true; D->ext = ext; D->direct = true;
+    D->win = w; D->dev = ext_dev; D->dtype = VEXHIP_F64; D->rows = rows; D->halo = true; D->ext = ext; D->direct = true;
+    D->pull = pull; D->has_lo = has_lo != 0; D->has_hi = has_hi != 0;
     D->nsend = (has_lo + has_hi) * halo; D->nghost = (has_lo + has_hi) * halo;
-    D->send_counts.assign(w->world, 0); D->recv_counts.assign(w->world, 0);
-    if (has_lo) { D->send_counts[lower] += halo; D->recv_counts[lower] += halo; }
-    if (has_hi) { D->send_counts[upper] += halo; D->recv_counts[upper] += halo; }
+    if (w) {
+        D->send_counts.assign(w->world, 0); D->recv_counts.assign(w->world, 0);
+        if (has_lo) { D->send_counts[lower] += halo; D->recv_counts[lower] += halo; }
+        if (has_hi) { D->send_counts[upper] += halo; D->recv_counts[upper] += halo; }
+    }
     auto bail = [&](int rc) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return rc; };
     hipError_t e = hipSetDevice(D->dev);
+    if (e == hipSuccess && !w) {
+        e = hipMalloc(reinterpret_cast<void **>(&D->d_own_step), sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(D->d_own_step, 0, sizeof(unsigned long long));
+    }
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&D->d_err), sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) *D->d_err = 0;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&D->d_halo_done), 4 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(D->d_halo_done, 0, 4 * sizeof(unsigned));
     const unsigned long long one = 1ull;                       // products are numbered from 1; the flags start at 0
-    if (e == hipSuccess) e = hipMemcpy(w->d_step, &one, sizeof(one), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(w ? w->d_step : D->d_own_step, &one, sizeof(one), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(check(e, __FILE__, __LINE__));
-    const size_t hdr = window_header(w->world);
     halo_dev &H = D->hd;
     H = halo_dev();
+    H.pull = pull;
+    if (!w) {
+        // ordered by the caller's events: no window, no flag; the ghost planes come with every product
+        H.step = D->d_own_step; H.done = D->d_halo_done; H.err = D->d_err; H.ticks = spin_ticks(); H.push_blocks = 0;
+        H.halo = (int)halo; H.z0 = has_lo; H.z1 = has_lo + (int)(rows / halo);
+        *out = reinterpret_cast<vexhip_dist_spmv *>(D);
+        return 0;
+    }
+    const size_t hdr = window_header(w->world);
     double *mine = reinterpret_cast<double *>(w->base + hdr);
     // window layout: [lower ghost plane | upper ghost plane]
     if (has_lo) {
@@ -1034,6 +1122,7 @@ int vexhip_dist_spmv_create_halo(vexhip_ipc_window *hw, const vexhip_spmat *ext,
         }
     }
     H.step = w->d_step; H.done = D->d_halo_done; H.err = D->d_err; H.ticks = spin_ticks();
+    if (pull) { H.lo = H.hi = nullptr; H.dst_lo = H.dst_hi = nullptr; }       // nothing is copied: lo / hi arrive with every product
     H.push_blocks = 16;
     if (const char *pb = std::getenv("VEXHIP_HALO_PUSH_BLOCKS")) H.push_blocks = std::max(0, std::min(1024, std::atoi(pb)));       // 0: the product workgroups push (plane.hip)
     H.halo = (int)halo; H.z0 = has_lo; H.z1 = has_lo + (int)(rows / halo); H.lo_planes = 0; H.hi_planes = 0;
@@ -1045,6 +1134,16 @@ int vexhip_dist_spmv_create_halo(vexhip_ipc_window *hw, const vexhip_spmat *ext,
     if (const char *tp = std::getenv("VEXHIP_HALO_TWO_PASS")) H.lo_two_pass = std::atoi(tp) != 0;
     H.acquire = 0;                                           // the ghost planes live in uncached memory (halo.hpp, spin_until)
     if (const char *aq = std::getenv("VEXHIP_HALO_ACQUIRE")) H.acquire = std::max(0, std::min(2, std::atoi(aq)));
+    // A window in CACHED memory (VEXHIP_IPC_WINDOW_MEM=finegrained | default: a one-device diagnostic) gets the model-correct form
+    // whatever was asked for: the reader invalidates at system scope behind the flag, the writers release at system scope in front of
+    // it (H.release, plane.hip) -- the waitcnt-only hand-off rests on stores that go past every cache (advisor, round 5)
+    H.release = 0;
+    if (!w->uncached) { H.acquire = 2; H.release = 1; }
+    // PULL reads the neighbours' x itself -- ordinary cached memory: behind the flag the workgroup's first lane invalidates what this
+    // device may still hold of it (system scope: the planes may lie on another GPU)
+    if (pull && !std::getenv("VEXHIP_HALO_ACQUIRE")) H.acquire = 2;
+    H.one_launch = 1;
+    if (const char *ol = std::getenv("VEXHIP_HALO_TWO_LAUNCHES")) H.one_launch = std::atoi(ol) ? 0 : 1;      // (A/B: the one-thread kernel behind the launch, round 5)
     if (std::getenv("VEXHIP_HALO_NO_PUSH")) {
         // diagnostics (tools/r05_dist_step.py): nobody pushes, the flags this rank waits for are raised once and for all -- what the
         // product with ghost planes costs when the exchange costs nothing

@@ -42,6 +42,16 @@ struct halo_dev {
     unsigned long long *debug;                          // diagnostics (VEXHIP_HALO_DEBUG): per workgroup {start, ghost flag seen, first ghost line in registers, end} in 100 MHz ticks
     int lo_two_pass;                                    // the lower chunk walks its planes above the first one first and its first plane (the one that needs the ghost plane) last
     int acquire;                                        // behind a ghost flag: 0 no cache invalidate (the window is uncached), 1 agent scope, 2 system scope
+    int release;                                        // in front of a raised flag: 0 s_waitcnt only (uncached window: the stores go past every cache), 1 system-scope release fence
+    // PULL (round 6; one process drives every GPU -- vex::Context, vexcl/spmat.hpp): lo / hi point at the NEIGHBOURS' boundary planes
+    // of x themselves (peer access: hipDeviceEnablePeerAccess), nothing is copied.  1 = flags: the launch's first workgroup raises
+    // `arrive` at the neighbours ("my x is final": everything in front of this launch in the stream has finished), the workgroups
+    // next to a ghost plane wait for the neighbours' flags, and the kernel behind the launch raises `consumed` AND waits for the
+    // neighbours' `consumed` before the stream goes on (a later kernel may overwrite the plane they read).  2 = no flags at all:
+    // the host orders the streams with events (logical devices sharing one GPU may share a hardware queue, where a launch that
+    // waits for a LATER launch never ends).
+    int pull;
+    int one_launch;                                     // round 6: the launch's LAST workgroup raises `consumed` and advances the step number (no second launch)
 };
 
 // returns false when the flag was not raised in time (err, in pinned host memory, is set then and stays set: the products that
@@ -51,12 +61,16 @@ struct halo_dev {
 // window, which no cache ever holds: the flag's value has returned before the first data load is issued, and that is all the order
 // an uncached read needs.
 __device__ inline bool spin_until(const unsigned long long *flag, unsigned long long want, int *err, unsigned long long ticks, int acquire = 2) {
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
-    const unsigned long long t0 = wall_clock64();
-    // relaxed polls (the flags are uncached: every poll reads memory), ONE acquire once the flag is there
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+    // relaxed polls (the flags are uncached: every poll reads memory), ONE acquire once the flag is there.  The common case -- the flag
+    // is already up -- costs one read: the sticky error word (pinned HOST memory: a trip over PCIe) and the clock are looked at only
+    // once a poll has missed
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+        }
     }
     if (acquire == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     else if (acquire == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -42,14 +42,12 @@ namespace {
 // (H.lo / H.hi) behind the owner's `arrive` flag; the first workgroups of the launch copy the rank's own boundary planes to the
 // neighbours.  (`consumed` is raised and the step number advanced by halo_signal_kernel behind this launch: a kernel boundary
 // orders every workgroup's reads of the ghost planes before the owners may overwrite them.)
-template <int TY, bool APPEND, int STORE_AUX, bool HALO = false>
-#ifndef VEXHIP_HALO_WAVES
-#define VEXHIP_HALO_WAVES 2
-#endif
-__global__ __launch_bounds__(256, (TY == 2 && !HALO) ? 4 : (HALO ? VEXHIP_HALO_WAVES : 2))       // (HALO: a few registers more than 128)
-void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
+// (the walk of one workgroup; the kernel below adds what follows it in a HALO launch)
+template <int TY, bool APPEND, int STORE_AUX, bool HALO>
+__device__ __forceinline__
+void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alpha,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
-        plane_dev pd, halo_dev H)
+        const plane_dev &pd, const halo_dev &H, [[maybe_unused]] const unsigned long long step_in)
 {
     // LDS: per diagonal code its position (x 2), the value table, and the decoded values of the OTHER block, lane-private
     // ([position * 2 + row][lane]: consecutive lanes, consecutive 8-byte words -- conflict-free; row 14 takes what padding
@@ -65,8 +63,17 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     [[maybe_unused]] unsigned long long dbg_t0 = 0, dbg_flag = 0, dbg_data = 0;
     if constexpr (HALO) {
         if (H.debug) dbg_t0 = wall_clock64();
-        step = *H.step;
-        const unsigned npush = (H.dst_lo ? (unsigned)H.push_blocks : 0u) + (H.dst_hi ? (unsigned)H.push_blocks : 0u);
+        step = step_in;
+        if (H.pull == 1 && b == 0 && t == 0) {
+            // PULL: this rank's x is final (stream order: its writers were earlier KERNELS, whose end wrote the caches back) -- tell the
+            // neighbours, who read its boundary planes in place.  A RELAXED store: nothing of THIS launch is published, and a release
+            // fence here writes back an L2 that the launch's other workgroups keep filling with y -- the flag left 65 us late
+            // (profiles/r06_dist_step_first.json: 117 us a step against 49 without flags); H.release asks for the fence anyway.
+            if (H.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (H.peer_arrive_lo) __hip_atomic_store(H.peer_arrive_lo, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (H.peer_arrive_hi) __hip_atomic_store(H.peer_arrive_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const unsigned npush = H.pull ? 0u : (H.dst_lo ? (unsigned)H.push_blocks : 0u) + (H.dst_hi ? (unsigned)H.push_blocks : 0u);
         if (b < npush) {
             // ---- copy one of the rank's boundary planes into the neighbour's window (16-byte pieces), raise `arrive` there ----
             const bool down = H.dst_lo && b < (unsigned)H.push_blocks;           // the FIRST plane goes to the lower neighbour
@@ -94,6 +101,7 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
                     const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (old + 1u == (unsigned)H.push_blocks) {
                         __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (H.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // a window in cached memory (diagnostic): the model-correct hand-off
                         __hip_atomic_store(down ? H.peer_arrive_lo : H.peer_arrive_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 }
@@ -136,7 +144,7 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
         // boundary plane before they start their walk.  Stores into the uncached window complete one after the other per wave
         // (32 of them per lane took the 32 dedicated workgroups 45 us on some boxes and 84 us on others: tools/r05_halo_timeline.py);
         // two per lane from 2048 waves at once are done in a few microseconds, and the neighbours' ghost flags rise that early.
-        if (H.push_blocks == 0 && b < 512u) {
+        if (!H.pull && H.push_blocks == 0 && b < 512u) {
             const bool down = b < 256u;
             double *dst = down ? H.dst_lo : H.dst_hi;
             if (dst) {                                                           // uniform
@@ -159,6 +167,7 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
                             const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (old + 1u == npieces) {
                                 __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (H.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
                                 __hip_atomic_store(down ? H.peer_arrive_lo : H.peer_arrive_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             }
                         }
@@ -256,8 +265,9 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
                 d2 r = {0.0, 0.0};
                 if (!g || gl < 0 || gl >= ny || l == 0 || l == TY + 1) return r;     // no neighbour there / not the adjacent plane / the line above or below the tile IN a ghost plane: never referenced by an entry
                 bool &got = below ? got_lo : got_hi;
-                if (!got) {
+                if (!got && H.pull != 2) {
                     // the first line of this ghost plane the workgroup needs: has the owner's share of THIS product arrived?
+                    // (PULL: is the owner's x final?  pull == 2: the host has ordered the streams, there is nothing to wait for)
                     if (t == 0) s_flag[below ? 0 : 1] = spin_until(below ? H.arrive_lo : H.arrive_hi, step, H.err, H.ticks, H.acquire) ? 1 : 0;
                     __syncthreads();
                     if (!s_flag[below ? 0 : 1]) ghost_bad = true;
@@ -449,6 +459,45 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
 #undef PLANE_OTHER_SUMS
 }
 
+#ifndef VEXHIP_HALO_WAVES
+#define VEXHIP_HALO_WAVES 2
+#endif
+template <int TY, bool APPEND, int STORE_AUX, bool HALO = false>
+__global__ __launch_bounds__(256, (TY == 2 && !HALO) ? 4 : (HALO ? VEXHIP_HALO_WAVES : 2))       // (HALO: a few registers more than 128)
+void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
+        const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
+        plane_dev pd, halo_dev H)
+{
+    if constexpr (!HALO) {
+        plane_walk<TY, APPEND, STORE_AUX, false>(x, y, alpha, blocks, pool, deltas, values, pd, H, 0ull);
+    } else {
+        const unsigned long long step = *H.step;
+        plane_walk<TY, APPEND, STORE_AUX, true>(x, y, alpha, blocks, pool, deltas, values, pd, H, step);
+        // ---- round 6: what used to be a second launch (halo_signal_kernel) is done by the workgroup that finishes LAST: every
+        // workgroup's reads of the ghost planes have returned before it is counted (s_waitcnt + barrier; a relaxed count: an agent-scope
+        // release here would write back an L2 full of this launch's y, 768 times), so the last one may tell the owners that their
+        // planes have been read, wait -- PULL: the planes are the owners' x itself -- until the neighbours say the same of this rank's,
+        // and advance the step number.  The next launch of the stream starts behind this one: it reads the new number.
+        if (H.one_launch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned old = __hip_atomic_fetch_add(H.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + 1u == gridDim.x) {
+                    __hip_atomic_store(H.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (H.consumed_lo) __hip_atomic_store(H.consumed_lo, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (H.consumed_hi) __hip_atomic_store(H.consumed_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (H.pull == 1) {
+                        if (H.sent_lo) (void)spin_until(H.sent_lo, step, H.err, H.ticks, 0);
+                        if (H.sent_hi) (void)spin_until(H.sent_hi, step, H.err, H.ticks, 0);
+                    }
+                    *H.step = step + 1ull;
+                }
+            }
+        }
+    }
+}
+
 // The yardstick of the plane / march products (bench.py roofline.device_copy_hand): x copied to y with one 16-byte pair per lane,
 // no loop, non-temporal stores -- the same HBM traffic as the product (x once, y once) and nothing else to do.  6.23 TB/s at
 // 512^3 elements on the box where the library's copy (torch) reaches 4.94 (profiles/r04_pm_proto.json).
@@ -464,6 +513,12 @@ __global__ void halo_signal_kernel(halo_dev H) {
     const unsigned long long step = *H.step;
     if (H.consumed_lo) __hip_atomic_store(H.consumed_lo, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (H.consumed_hi) __hip_atomic_store(H.consumed_hi, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (H.pull == 1) {
+        // PULL: the neighbours read this rank's boundary planes of x IN PLACE -- the stream must not go on (to a kernel that may
+        // overwrite x) before they say they have (a pushed share is a copy: there the next push waits instead)
+        if (H.sent_lo) (void)spin_until(H.sent_lo, step, H.err, H.ticks, 0);
+        if (H.sent_hi) (void)spin_until(H.sent_hi, step, H.err, H.ticks, 0);
+    }
     *H.step = step + 1ull;
 }
 
@@ -580,9 +635,9 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
     pd.depth = std::max(1, mid);          // ONE main chunk (two of 25 planes beside the short chunks: 88-90 us against 76 for the step)
     if (const char *e = std::getenv("VEXHIP_HALO_DEPTH")) pd.depth = std::max(1, std::atoi(e));
     const long long chunks = (H.lo_planes ? 1 : 0) + (H.hi_planes ? 1 : 0) + (mid + pd.depth - 1) / pd.depth;
-    const long long npush = (H.dst_lo ? H.push_blocks : 0) + (H.dst_hi ? H.push_blocks : 0);
+    const long long npush = H.pull ? 0 : (H.dst_lo ? H.push_blocks : 0) + (H.dst_hi ? H.push_blocks : 0);
     const long long grid = npush + 8ll * pd.tpx * chunks;
-    VEXHIP_REQUIRE(H.push_blocks > 0 || 8ll * pd.tpx * chunks >= 512 || !(H.dst_lo || H.dst_hi), "too few workgroups to push the boundary planes");
+    VEXHIP_REQUIRE(H.pull || H.push_blocks > 0 || 8ll * pd.tpx * chunks >= 512 || !(H.dst_lo || H.dst_hi), "too few workgroups to push the boundary planes");
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     // the kernel addresses x and y in the numbering of the stored grid
     const double *xe = x - (long long)H.z0 * pd.far;
@@ -591,8 +646,10 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
     if (append) sell8_plane_kernel<2, true, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
     else        sell8_plane_kernel<2, false, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
     VEXHIP_LAUNCH_CHECK();
-    halo_signal_kernel<<<1, 1, 0, s>>>(H);
-    VEXHIP_LAUNCH_CHECK();
+    if (H.pull != 2 && !H.one_launch) {   // (events: the host advances nothing on the device -- there are no flags to number; one_launch: the last workgroup has done it)
+        halo_signal_kernel<<<1, 1, 0, s>>>(H);
+        VEXHIP_LAUNCH_CHECK();
+    }
     return 0;
 }
 } // namespace vexhip

@@ -282,6 +282,23 @@ using namespace vexhip;
 
 extern "C" {
 
+// Planes per workgroup of the fp32 plane product (host arithmetic only, exported so that the choice can be checked without a device):
+// a workgroup is two waves and six of them fit a CU: about two rounds of workgroups (512^3: depth 512 / 256 / 128 / 64 / 43 / 32 / 16 =
+// 0.315 / 0.239 / 0.214 / 0.213 / 0.207 / 0.214 / 0.221 ms, profiles/r05_fp32_plane.txt); no walk shorter than 8 planes.  The kernel
+// forms byte offsets inside a walk in 32 bits: the depth is halved until (depth + 4) planes of 2048-byte lines fit -- checked on the
+// depth chosen HERE, not on the fp64 plan's (round 6: ny = 8192, nz = 256 passed the fp64 check at depth 64 and walked 256 planes).
+// 0: no depth fits.
+int64_t vexhip_sell8_plane_f32_depth(int cus, int64_t lines_per_plane, int64_t planes)
+{
+    if (lines_per_plane < 2 || planes < 1) return 0;
+    const long long c = std::max(1, cus), tiles = lines_per_plane / 2;
+    const long long chunks = std::max(1ll, std::min<long long>(planes / 8, (12 * c + tiles / 2) / tiles));
+    long long depth = (planes + chunks - 1) / chunks;
+    if (const char *e = std::getenv("VEXHIP_PLANE32_DEPTH")) if (std::atoi(e) > 0) depth = std::min<long long>(std::atoi(e), planes);
+    while ((depth + 4) * lines_per_plane * P32_LINE_B >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;
+    return (depth + 4) * lines_per_plane * P32_LINE_B < (1ll << 32) ? depth : 0;
+}
+
 int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane)
 {
@@ -289,8 +306,7 @@ int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alp
     VEXHIP_REQUIRE(n > 0 && n % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
     VEXHIP_REQUIRE(plane->table_pitch == 0 || plane->table_pitch >= PL_ROWS + 2, "bad plane plan (table pitch)");
     VEXHIP_REQUIRE(plane->lines_per_plane >= 4 && plane->lines_per_plane % 2 == 0 && plane->depth >= 1 && plane->planes >= 1
-                   && (plane->x_last + 1) % PL_ROWS == 0
-                   && ((long long)plane->depth + 4) * plane->lines_per_plane * P32_LINE_B < (1ll << 32), "bad plane plan");
+                   && (plane->x_last + 1) % PL_ROWS == 0, "bad plane plan");
     // (x and y may start at any element: 16-byte requests at 4-byte addresses are served, a matrix stored by grid line has no
     //  other product to fall back on)
     VEXHIP_SET_DEVICE(dev);
@@ -298,14 +314,8 @@ int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alp
     pd.nslices = n / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
     pd.ny = plane->lines_per_plane; pd.nz = plane->planes;
     pd.tiles = pd.ny / 2;
-    {
-        // a workgroup is two waves and six of them fit a CU: about two rounds of workgroups (512^3: depth 512 / 256 / 128 / 64 / 43 /
-        // 32 / 16 = 0.315 / 0.239 / 0.214 / 0.213 / 0.207 / 0.214 / 0.221 ms, profiles/r05_fp32_plane.txt); no walk shorter than 8 planes
-        const long long cus = std::max(1, info(dev).cus);
-        const long long chunks = std::max(1ll, std::min<long long>(pd.nz / 8, (12 * cus + pd.tiles / 2) / pd.tiles));
-        pd.depth = (int)((pd.nz + chunks - 1) / chunks);
-    }
-    if (const char *e = std::getenv("VEXHIP_PLANE32_DEPTH")) if (std::atoi(e) > 0) pd.depth = std::min(std::atoi(e), (int)plane->planes);
+    pd.depth = (int)vexhip_sell8_plane_f32_depth(std::max(1, info(dev).cus), pd.ny, pd.nz);
+    VEXHIP_REQUIRE(pd.depth > 0, "fp32 plane product: a walk of this grid does not fit 32-bit byte offsets");
     pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
     pd.pitch = plane->table_pitch;
     const long long chunks = (pd.nz + pd.depth - 1) / pd.depth;

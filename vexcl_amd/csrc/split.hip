@@ -80,6 +80,25 @@ void rank_kernel(long long n, int *__restrict__ c, const int *__restrict__ g, in
     }
 }
 
+// The strip with its ghost planes as ONE square matrix (transport "halo"): lo empty rows, the strip's rows, hi empty rows; columns
+// counted from the first element of the lower ghost plane.  out_of_range counts the columns outside [0, lo + n + hi).
+__global__ __launch_bounds__(256)
+void extend_ptr_kernel(long long n, long long lo, long long hi, const int *__restrict__ ptr, int *__restrict__ ptr_ext) {
+    const long long total = lo + n + hi + 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        ptr_ext[i] = i < lo ? 0 : (i <= lo + n ? ptr[i - lo] : ptr[n]);
+}
+__global__ __launch_bounds__(256)
+void extend_col_kernel(long long nnz, const int *__restrict__ col, long long shift, long long ncols, int *__restrict__ col_ext, unsigned long long *out_of_range) {
+    unsigned long long bad = 0;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (long long)gridDim.x * blockDim.x) {
+        const long long c = (long long)col[j] - shift;
+        if (c < 0 || c >= ncols) ++bad;
+        col_ext[j] = (int)c;
+    }
+    if (bad) atomicAdd(out_of_range, bad);
+}
+
 inline int grid_for(int dev, int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16)); }
 
 struct scratch {
@@ -186,6 +205,29 @@ int split(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *c
 using namespace vexhip;
 
 extern "C" {
+
+int vexhip_csr_extend_halo_i32(int dev, void *stream, int64_t n, int64_t nnz, const int32_t *ptr, const int32_t *col, int64_t col_begin,
+        int64_t lo, int64_t hi, int32_t *ptr_ext, int32_t *col_ext, int64_t *out_of_range)
+{
+    VEXHIP_REQUIRE(n >= 0 && nnz >= 0 && lo >= 0 && hi >= 0 && col_begin >= 0 && lo + n + hi < (1ll << 31), "bad argument");
+    VEXHIP_REQUIRE(ptr && ptr_ext && out_of_range && (nnz == 0 || (col && col_ext)), "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    scratch S;
+    unsigned long long *bad = nullptr, hbad = 0;
+    if (int rc = S.get(&bad, 1)) return rc;
+    VEXHIP_TRY(hipMemsetAsync(bad, 0, sizeof(*bad), s));
+    extend_ptr_kernel<<<grid_for(dev, lo + n + hi + 1), 256, 0, s>>>(n, lo, hi, ptr, ptr_ext);
+    VEXHIP_LAUNCH_CHECK();
+    if (nnz) {
+        extend_col_kernel<<<grid_for(dev, nnz), 256, 0, s>>>(nnz, col, col_begin - lo, lo + n + hi, col_ext, bad);
+        VEXHIP_LAUNCH_CHECK();
+    }
+    VEXHIP_TRY(hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, s));
+    VEXHIP_TRY(hipStreamSynchronize(s));
+    *out_of_range = (int64_t)hbad;
+    return 0;
+}
 
 int vexhip_csr_split_sizes_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col,
         int64_t col_begin, int64_t col_end, int64_t *sizes)

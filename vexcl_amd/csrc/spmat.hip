@@ -464,6 +464,11 @@ int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane
     *planes = ok ? A->plane.planes : 0; *lines_per_plane = ok ? A->plane.lines_per_plane : 0;
     return 0;
 }
+int spmat_device(const vexhip_spmat *h, int *dev) {
+    VEXHIP_REQUIRE(h && dev, "NULL argument");
+    *dev = reinterpret_cast<const spmat *>(h)->dev;
+    return 0;
+}
 int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const double *x, double *y, const halo_dev &H) {
     const spmat *A = reinterpret_cast<const spmat *>(h);
     VEXHIP_REQUIRE(A && A->value_type == VEXHIP_F64 && A->format == VEXHIP_SPMAT_SELL8V && (A->blocks || A->direct) && A->plane.usable && !A->tail,

@@ -74,7 +74,7 @@ class DistSpMat:
     (int32), on this rank's device.  x and y passed to ``apply`` are this
     rank's segments of the partitioned vectors (vex::vector's x(d), y(d))."""
 
-    def __init__(self, ptr, col, val, n_rows, n_cols, group=None, local_fmt="auto", kernels=None):
+    def __init__(self, ptr, col, val, n_rows, n_cols, group=None, local_fmt="auto", kernels=None, keep_strip=False):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -92,8 +92,9 @@ class DistSpMat:
         self.dev = dev
 
         # the strip as it was handed over (GLOBAL columns): transport "halo" stores it once more, ghost planes included
-        # (enable_native); drop_strip() releases the references
-        self._strip = (ptr, col, val)
+        # (enable_native).  Kept only on request (keep_strip=True, or enable_native(..., strip=(ptr, col, val))): the references
+        # would otherwise hold several GB per rank beside the local / remote split built below; drop_strip() releases them
+        self._strip = (ptr, col, val) if keep_strip else None
         self._ext = None
         # ---- split into local / remote parts (setup; not on the timed path)
         is_loc = (col >= c0) & (col < c1)
@@ -180,7 +181,7 @@ class DistSpMat:
             return False
         return True
 
-    def enable_native(self, graph=False, transport="rccl"):
+    def enable_native(self, graph=False, transport="rccl", strip=None):
         """Replace the per-product Python step (gather launch, torch.distributed request objects, two ctypes launches)
         by ONE call into libvexhip.  transport "rccl": pack -> grouped ncclSend/ncclRecv on a second stream -> local
         part -> remote part, over its own RCCL communicator (the unique id travels over this process group);
@@ -190,6 +191,8 @@ class DistSpMat:
         import ctypes
         from . import _capi
         self.disable_native()
+        if strip is not None:
+            self._strip = tuple(strip)
         self.native_error = None
         L = None
         st = {}
@@ -265,11 +268,11 @@ class DistSpMat:
                     self._drop_native(None)
                     return False
                 handles = [st["handle"]]
-                geo = [torch.tensor([H, self.rows], dtype=torch.int64)]
+                geo = [torch.tensor([H, self.rows, lower, upper], dtype=torch.int64)]
                 if self.world > 1:
                     hs = [torch.empty(64, dtype=torch.uint8, device=cdev) for _ in range(self.world)]
                     dist.all_gather(hs, st["handle"].to(cdev), group=self.group)
-                    gs = [torch.empty(2, dtype=torch.int64, device=cdev) for _ in range(self.world)]
+                    gs = [torch.empty(4, dtype=torch.int64, device=cdev) for _ in range(self.world)]
                     dist.all_gather(gs, geo[0].to(cdev), group=self.group)
                     handles, geo = [h.cpu() for h in hs], [g.cpu() for g in gs]
 
@@ -278,6 +281,9 @@ class DistSpMat:
                         if peer >= 0 and peer != self.rank:
                             if int(geo[peer][0]) != H or int(geo[peer][1]) < H:
                                 raise RuntimeError("the neighbours' strips do not have planes of the same size")
+                            # the neighbour must point back at this rank (its own plan was made from ITS ghosts)
+                            if int(geo[peer][3 if peer == lower else 2]) != self.rank:
+                                raise RuntimeError("rank %d does not exchange with this rank: the neighbour relation is not symmetric" % peer)
                             hb = (ctypes.c_char * 64).from_buffer_copy(bytes(handles[peer].numpy().tobytes()))
                             L.ipc_window_open(self._window, peer, ctypes.cast(hb, ctypes.c_void_p))
                     step = ctypes.c_void_p()
@@ -363,6 +369,14 @@ class DistSpMat:
             owners = [o for o in range(self.world) if self.recv_counts[o]]
             if any(o not in (lower, upper) for o in owners):
                 raise RuntimeError("transport halo: ghosts come from other ranks than the two neighbours")
+            # the protocol is symmetric: a rank pushes its boundary plane to exactly the neighbours it has ghosts from, and its push
+            # workgroups wait for `sent` flags only such a neighbour raises.  A one-sided coupling (an upwind stencil: entries at
+            # -far / -nx / -1 only) would leave rank r waiting for a share rank r - 1 never sends -- decline here, on every rank
+            # (the staging all-reduce makes the ranks decline together), instead of running into the flag time-out
+            takers = {o for o in range(self.world) if self.send_counts[o]}
+            if takers != {o for o in (lower, upper) if o >= 0}:
+                raise RuntimeError("transport halo: the coupling between neighbouring strips is not symmetric "
+                                   "(this rank receives from %s and sends to %s)" % (sorted(o for o in (lower, upper) if o >= 0), sorted(takers)))
         reach = max(int(c0 - below.min()) if below.numel() else 0, int(above.max()) + 1 - c1 if above.numel() else 0)
         H = (reach + 1023) // 1024 * 1024
         if H <= 0 or self.rows % H or H % 1024:
@@ -387,6 +401,7 @@ class DistSpMat:
         if getattr(self, "_window", None):
             L.ipc_window_destroy(self._window)
             self._window = None
+        self._ext = None            # the strip stored with its ghost planes belongs to the step that has just gone
 
     def disable_native(self):
         step, self._native = getattr(self, "_native", None), None
