@@ -271,7 +271,9 @@ def unstructured_rows(torch, ops, dev, args):
     x = ops.fill_hash(torch.empty(m, dtype=torch.float64, device=dev), 42)
     y = torch.empty(m, dtype=torch.float64, device=dev)
     what = {"random16": "16 entries per row, columns uniform in [0, n), sorted (the shape of tests/random_matrix.hpp)",
-            "powerlaw": "row lengths floor(6 / sqrt(u)) capped at 4096 (mean ~12), columns uniform, sorted"}
+            "powerlaw": "row lengths floor(6 / sqrt(u)) capped at 4096 (mean ~12), columns uniform, sorted",
+            "banded16": "round 6, WITH locality: 16 entries per row, columns uniform within +-100 000 of the diagonal, sorted (a mesh-ordered operator as the memory system sees it)",
+            "stencil27": "round 6, WITH locality: 27-point operator on 256^3, a different value in every entry (nothing to compress)"}
     # ---- round 5: a structured operator in TWO dimensions (5-point, 16384^2): walked along virtual 512-point lines by the plane product
     try:
         W = H = int(os.environ.get("BENCH_2D_SIDE", "16384"))
@@ -345,8 +347,13 @@ def unstructured_rows(torch, ops, dev, args):
     except Exception as e:  # noqa: BLE001 -- a secondary row
         rows["SpMV fp32 Poisson"] = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
-    for name in ("random16", "powerlaw"):
+    m0, x0, y0 = m, x, y
+    for name in ("random16", "powerlaw", "banded16", "stencil27"):
         try:
+            m, x, y = m0, x0, y0
+            if U.ROWS_OF.get(name, m0) != m0:
+                m = U.ROWS_OF[name]
+                x = ops.fill_hash(torch.empty(m, dtype=torch.float64, device=dev), 42); y = torch.empty(m, dtype=torch.float64, device=dev)
             ptr, col, val = U.MAKERS[name](m, dev)
             nnz = int(col.numel())
             yr, mag = U.reference_product(ptr, col, val, x)
@@ -364,8 +371,17 @@ def unstructured_rows(torch, ops, dev, args):
                                 "frac": round(stored / t / 1e6 / HBM_PEAK_GBPS, 4),
                                 "algorithmic_bytes_per_launch": alg, "algorithmic_gbps": round(alg / t / 1e6, 1),
                                 "frac_of_algorithmic_bytes": round(alg / t / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None,
-                                "what": "x is gathered 8 bytes at a time from lines nobody else in the wave uses: the memory system moves a whole "
-                                        "sector per entry (traffic below), the bytes priced here are the floor (matrix + x once + y once)"}}
+                                "what": ("the columns of a row lie close to its own: the lines of x a wave gathers from are shared with its neighbours and stay in the caches; "
+                                         "traffic / bytes_per_launch says how much of x is fetched more than once") if name in ("banded16", "stencil27") else
+                                        ("x is gathered 8 bytes at a time from lines nobody else in the wave uses: the memory system moves a whole "
+                                         "sector per entry (traffic below), the bytes priced here are the floor (matrix + x once + y once)")}}
+            if name == "random16":
+                # the bound this access pattern has: every entry pulls its own 128-byte line of x through the fabric (x, 160 MB, lies
+                # under the 256 MiB Infinity Cache: FETCH_SIZE counts those lines) -- nnz lines at the rate the fetch path sustains
+                # (the read kernel of tools/r06_mall_probe.hip on a working set of that size, non-temporal loads: 7.2 TB/s, profiles/r06_mall_probe.json)
+                row["roofline"]["bound_ms"] = round((nnz * 128.0 + A.matrix_bytes()) / 7.2e12 * 1e3, 3)
+                row["roofline"]["bound_what"] = ("nnz x 128-byte lines of x + the stored matrix at 7.2 TB/s, the rate at which a read-only kernel re-reads a 192 MiB "
+                                                 "working set on this part (profiles/r06_mall_probe.json): the wall of this access pattern, not of the kernel")
             del A, ptr, col, val
             torch.cuda.empty_cache()
             if not args.no_pmc:
@@ -520,9 +536,11 @@ def main():
     progress("process group up; generating rows [%d, %d) of the %d^3 matrix" % (r0, r1, n))
     ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
     # x is a function of the GLOBAL index, so the job computes the same product for every N
-    x = ops.fill_hash(torch.empty(r1 - r0, dtype=torch.float64, device=dev),
+    # (x and y placed as the library places every vex::vector -- vexhip_malloc, round 6: at a multiple of 64 MiB plus a small stagger;
+    #  where y lies relative to x is worth up to 11 % of this product: profiles/r06_xy_gap.json)
+    x = ops.fill_hash(ops.device_vector(r1 - r0, torch.float64, dev),
                       (42 + r0 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
-    y = torch.zeros(r1 - r0, dtype=torch.float64, device=dev)
+    y = ops.device_vector(r1 - r0, torch.float64, dev, zero=True)
     setup = None
     march = None
     plane = None
@@ -872,7 +890,9 @@ def main():
             "config": {"workload": "configs[%d]: 7-point 3D Poisson %d^3, N=%d rows, nnz=%d, fp64 values, int32 indices"
                                    % (2 if world == 1 else 3, n, N, nnz_total),
                        "format": storage, "rows_per_gpu": rows_rank,
-                       "parallelism": "row-partitioned x%d" % world},
+                       "parallelism": "row-partitioned x%d" % world,
+                       "vector_placement": {"y_minus_x_mod_64MiB_in_MiB": round(((y.data_ptr() - x.data_ptr()) % (64 << 20)) / float(1 << 20), 3),
+                                            "rule": "vexhip_malloc: multiples of 64 MiB + 0 / 2 / 4 / 6 / 8 MiB (ops.device_vector)"}},
             "roofline": {"bound": "hbm",
                          "kernel": (("sell8_plane_kernel<%d, false, %d, false>" % (plane["tile"], {0: 2, 1: 18, 2: 17, 3: 0}[plane["store_policy"]])) if (storage == "sell8v" and plane) else
                                     KERNEL_OF["sell8v_grid"] if (storage == "sell8v" and grid_plan) else

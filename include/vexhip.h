@@ -70,6 +70,13 @@ int vexhip_event_elapsed_ms(int dev, void *start, void *stop, float *ms);
 /* ---- device_vector<T> storage (backend/cuda/device_vector.hpp:66-214) --- */
 int vexhip_malloc(int dev, size_t bytes, void **ptr);
 int vexhip_free(int dev, void *ptr);
+/* Where vexhip_malloc places an allocation of 64 MiB or more (round 6; host arithmetic, no device): bytes to skip from the raw
+ * address hipMalloc returned so that the vector starts at a multiple of 64 MiB plus a stagger of 0 / 2 / 4 / 6 / 8 MiB (by the
+ * allocation's ordinal) -- vectors a product reads and writes in lockstep then differ by less than 10 MiB mod 64 MiB, where the
+ * headline product runs at its fast end (profiles/r06_xy_gap.json).  Smaller allocations: 0.  VEXHIP_MALLOC_STAGGER=0 turns it off.
+ * (vexhip_free takes the pointer vexhip_malloc returned.)                                                                        */
+size_t vexhip_malloc_placement(size_t bytes, uint64_t raw_address, unsigned ordinal);
+size_t vexhip_malloc_stagger(size_t bytes, unsigned ordinal);
 /* svm_vector<T> storage (backend/cuda/svm_vector.hpp:57-62: cuMemAllocManaged): memory addressable by the host and
  * the device alike (hipMallocManaged); released with vexhip_free. */
 int vexhip_malloc_managed(int dev, size_t bytes, void **ptr);

@@ -171,3 +171,28 @@ def test_plane_walks_are_one_per_cu_or_many(built_lib):
         assert d == 0 or (1 <= d <= nz and (d + 4) * ny * 2048 < 2 ** 32), (ny, nz, d)
     assert L.sell8_plane_f32_depth(256, 8192, 256) in range(1, 253) and L.sell8_plane_f32_depth(256, 512, 512) == 43
     assert L.sell8_plane_f32_depth(256, 1 << 20, 8) == 0          # twelve planes of 2 GiB: no walk fits
+
+
+def test_large_allocations_are_placed_within_ten_mib_of_each_other_mod_64_mib(built_lib):
+    """Round 6 (runtime.hip vexhip_malloc): the headline product's time depends on (y - x) mod 64 MiB -- fast within +-10 MiB of a
+    multiple of 64 MiB, up to 11 % slow between 12 and 32 MiB (profiles/r06_xy_gap.json).  The library places every allocation of
+    64 MiB or more at a multiple of 64 MiB plus 0 / 2 / 4 / 6 / 8 MiB: any two then differ by less than 10 MiB mod 64 MiB, and five
+    consecutive ones all start at different offsets.  Host arithmetic only."""
+    from vexcl_amd import _capi
+    L = _capi.lib()
+    MiB = 1 << 20
+    import random
+    rnd = random.Random(7)
+    starts = []
+    for k in range(40):
+        raw = rnd.randrange(1 << 44) // (2 * MiB) * (2 * MiB)          # what an allocator hands out: 2 MiB multiples
+        size = rnd.choice([64 * MiB, 800 * 10 ** 6, 1 << 30, 5 << 30])
+        skip = L.malloc_placement(size, raw, k)
+        assert 0 <= skip < 64 * MiB + 8 * MiB + 1 and skip == ((-raw) % (64 * MiB)) + (k % 5) * 2 * MiB
+        starts.append((raw + skip) % (64 * MiB))
+    assert set(starts) == {0, 2 * MiB, 4 * MiB, 6 * MiB, 8 * MiB}
+    for a in starts:
+        for b in starts:
+            d = (a - b) % (64 * MiB)
+            assert d < 10 * MiB or d > 54 * MiB
+    assert L.malloc_placement(64 * MiB - 1, 12345 * 4096, 3) == 0 and L.malloc_stagger(1 << 20, 3) == 0       # small allocations are left alone

@@ -23,7 +23,7 @@ for _ in range(3):
     r.device_result(cal)
 del cal
 only = [f for f in os.environ.get("PMC_ONLY", "").split(",") if f]
-unstructured = [f for f in only if f in ("random16", "powerlaw")]
+unstructured = [f for f in only if f in ("random16", "powerlaw", "banded16", "stencil27")]
 if unstructured:
     # round 5: the unstructured rows of bench.py (tools/unstructured.py); UNSTRUCTURED_ROWS rows
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +33,10 @@ if unstructured:
     xu = ops.fill_hash(torch.empty(m, dtype=torch.float64, device=dev), 42)
     yu = torch.zeros(m, dtype=torch.float64, device=dev)
     for name in unstructured:
-        p_, c_, v_ = U.MAKERS[name](m, dev)
+        mm = U.ROWS_OF.get(name, m)
+        if mm != m:
+            xu = ops.fill_hash(torch.empty(mm, dtype=torch.float64, device=dev), 42); yu = torch.zeros(mm, dtype=torch.float64, device=dev)
+        p_, c_, v_ = U.MAKERS[name](mm, dev)
         A = ops.SpMat(p_, c_, v_)
         torch.cuda.synchronize()
         for _ in range(3):

@@ -36,6 +36,50 @@ def powerlaw(n, dev, seed=2, cap=4096):
     return ptr64.to(torch.int32), col, val
 
 
+def banded16(n, dev, seed=3, per_row=16, half_band=100000):
+    """round 6: an unstructured matrix WITH locality -- 16 entries per row, columns uniform within +-half_band of the diagonal (clamped
+    to the matrix), sorted within the row: what a mesh-ordered operator looks like to the memory system (x is re-used from the caches)."""
+    from vexcl_amd import ops
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    off = torch.randint(-half_band, half_band + 1, (n, per_row), device=dev, dtype=torch.int64, generator=g)
+    col = (torch.arange(n, device=dev, dtype=torch.int64).view(-1, 1) + off).clamp_(0, n - 1)
+    del off
+    col = torch.sort(col, dim=1).values.to(torch.int32).contiguous().view(-1)
+    ptr = (torch.arange(n + 1, device=dev, dtype=torch.int64) * per_row).to(torch.int32)
+    val = ops.fill_hash(torch.empty(n * per_row, dtype=torch.float64, device=dev), seed + 100)
+    return ptr, col, val
+
+
+def stencil27(n, dev, seed=4):
+    """round 6: a 27-point operator with a DIFFERENT value in every entry (a hash of the entry number) on a g^3 grid, g = round(n^(1/3)),
+    identity rows on the boundary: the widest stencil an AMG hierarchy over a structured mesh produces; nothing to compress."""
+    from vexcl_amd import ops
+    g = int(round(n ** (1.0 / 3.0)))
+    N = g ** 3
+    assert N == n, "stencil27 wants a cube number of rows"
+    r = torch.arange(N, device=dev, dtype=torch.int32)
+    ix, iy, iz = r % g, (r // g) % g, r // (g * g)
+    inner = (ix > 0) & (ix < g - 1) & (iy > 0) & (iy < g - 1) & (iz > 0) & (iz < g - 1)
+    del ix, iy, iz
+    ptr64 = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.where(inner, 27, 1), 0, out=ptr64[1:])
+    nnz = int(ptr64[-1])
+    assert nnz < 2 ** 31
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    b = ptr64[:-1]
+    bi, ri = b[inner], r[inner]
+    k = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                col[bi + k] = ri + (dz * g * g + dy * g + dx)
+                k += 1
+    del bi, ri
+    col[b[~inner]] = r[~inner]
+    val = ops.fill_hash(torch.empty(nnz, dtype=torch.float64, device=dev), seed + 100)
+    return ptr64.to(torch.int32), col, val
+
+
 def reference_product(ptr, col, val, x):
     """(y, sum |terms| per row) without a matrix kernel."""
     n = ptr.numel() - 1
@@ -47,10 +91,11 @@ def reference_product(ptr, col, val, x):
     return y, mag
 
 
-MAKERS = {"random16": random16, "powerlaw": powerlaw}
+MAKERS = {"random16": random16, "powerlaw": powerlaw, "banded16": banded16, "stencil27": stencil27}
+ROWS_OF = {"stencil27": 256 ** 3}          # rows of a maker that does not take the bench's UNSTRUCTURED_ROWS
 # kernels a product of such a matrix may launch (the ELL part, the CSR arrays); names as rocprofv3 prints them
 PRODUCT_KERNELS = ("sell_kernel", "sell_pair_kernel", "sell8_pair_kernel", "hell_kernel", "csr_stream2_kernel", "csr_stream_kernel",
-                   "csr_scalar_kernel", "csr_rows_kernel", "sellu_kernel")
+                   "csr_scalar_kernel", "csr_rows_kernel", "sellu_kernel", "sell8_march_kernel", "sell8_grid_kernel", "sell8_plane_kernel")
 
 
 def stencil2d(W, H, dev):

@@ -667,8 +667,15 @@ struct inline_spmv : expression_base {
         c.src.parameter("const " + V + " *", "csr_val"); c.src.parameter("const " + V + " *", "in");
         c.src.parameter("long", "grid_nx"); c.src.parameter("long", "grid_far"); c.src.parameter("long", "grid_pitch");
         c.src.parameter("const int *", "line_class"); c.src.parameter("const uchar *", "grid_table");
+        c.src.parameter("long", "x_last");
         c.src.parameter("ulong", "i");
         c.src.end_function_parameters();
+        // Round 6: every branch below is straight-line code -- ALL requests of a row (codes, values, x) are issued before the first sum
+        // needs one.  Until then a missing entry was skipped by a branch around its two loads, and a row's seven entries cost seven
+        // round trips to memory one after the other (1.97 ms for the 512^3 Poisson product inside an expression kernel, where the
+        // library product takes 0.38: profiles/r05_examples_roofline_cpp.log).  Now the index of a missing entry is clamped into x
+        // and the term is dropped by a select (never multiplied: x may hold Inf / NaN there); the sums are formed in storage order,
+        // as before (hybrid_ell.inl:322-351).
         c.src.new_line() << V << " sum = 0;";
         c.src.new_line() << "if (line_class)";        // stored by grid line (grid.hip): a class per line, a value code per position and row
         c.src.open("{");
@@ -679,16 +686,34 @@ struct inline_spmv : expression_base {
         c.src.new_line() << "else { line = (long)i / grid_nx; r = (long)i - line * grid_nx; }";
         c.src.new_line() << "const uchar *tb = grid_table + (long)line_class[line] * 7 * grid_pitch + r;";
         c.src.new_line() << "const long off[7] = {-grid_far, -grid_nx, -1, 0, 1, grid_nx, grid_far};";
-        c.src.new_line() << "for(int p = 0; p < 7; ++p)";
-        c.src.open("{");
-        c.src.new_line() << "const uint code = tb[p * grid_pitch];";
-        c.src.new_line() << "if (code != 255u) sum += values[code] * in[(long)i + off[p]];";
+        c.src.new_line() << "uint code[7]; " << V << " xv[7], av[7];";
+        c.src.new_line() << "for(int p = 0; p < 7; ++p) code[p] = tb[p * grid_pitch];";
+        c.src.new_line() << "for(int p = 0; p < 7; ++p) { long j = (long)i + off[p]; j = j < 0 ? 0 : j; j = j > x_last ? x_last : j; xv[p] = in[j]; }";
+        c.src.new_line() << "for(int p = 0; p < 7; ++p) av[p] = values[code[p]];";
+        c.src.new_line() << "for(int p = 0; p < 7; ++p) sum = code[p] != 255u ? sum + av[p] * xv[p] : sum;";
         c.src.close("}");
-        c.src.close("}");
-        c.src.new_line() << "else if (values)";       // SELL8V: diagonal codes and value codes (include/vexhip.h)
+        c.src.new_line() << "else if (values && ell_w <= 8)";       // SELL8V: diagonal codes and value codes (include/vexhip.h)
         c.src.open("{");
         c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
         c.src.new_line() << "const long slice = blocks ? (long)blocks[i >> 9] : (long)(i >> 9);";   // slice dictionary (include/vexhip.h)
+        c.src.new_line() << "const uint *cw = (const uint *)(sell + slice * (wp * 2048)) + ((i & 511) >> 1);";
+        c.src.new_line() << "const uint *vw = cw + wp * 256;";
+        c.src.new_line() << "uint cword[4], vword[4]; " << V << " xv[8], av[8]; uint real[8];";
+        c.src.new_line() << "for(int u = 0; u < 4; ++u) { const long uu = u < wp ? u : wp - 1; cword[u] = cw[uu * 256]; vword[u] = vw[uu * 256]; }";
+        c.src.new_line() << "for(int j = 0; j < 8; ++j)";
+        c.src.open("{");
+        c.src.new_line() << "const int sh = 8 * ((j & 1) * 2 + (int)(i & 1));";
+        c.src.new_line() << "const uint code = (cword[j >> 1] >> sh) & 255u;";
+        c.src.new_line() << "real[j] = (j < ell_w && code < 254u) ? 1u : 0u;";
+        c.src.new_line() << "long jx = (long)i + deltas[real[j] ? code : 0u]; jx = jx < 0 ? 0 : jx; jx = jx > x_last ? x_last : jx;";
+        c.src.new_line() << "xv[j] = in[jx]; av[j] = values[(vword[j >> 1] >> sh) & 255u];";
+        c.src.close("}");
+        c.src.new_line() << "for(int j = 0; j < 8; ++j) sum = real[j] ? sum + av[j] * xv[j] : sum;";
+        c.src.close("}");
+        c.src.new_line() << "else if (values)";       // ... wider than eight columns: the loop
+        c.src.open("{");
+        c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
+        c.src.new_line() << "const long slice = blocks ? (long)blocks[i >> 9] : (long)(i >> 9);";
         c.src.new_line() << "const uint *cw = (const uint *)(sell + slice * (wp * 2048)) + ((i & 511) >> 1);";
         c.src.new_line() << "const uint *vw = cw + wp * 256;";
         c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
@@ -698,7 +723,24 @@ struct inline_spmv : expression_base {
         c.src.new_line() << "if (code < 254u) sum += values[(vw[(j >> 1) * 256] >> sh) & 255u] * in[(long)i + deltas[code]];";
         c.src.close("}");
         c.src.close("}");
-        c.src.new_line() << "else if (deltas)";       // SELL8: 1-byte diagonal codes
+        c.src.new_line() << "else if (deltas && ell_w <= 8)";       // SELL8: 1-byte diagonal codes
+        c.src.open("{");
+        c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
+        c.src.new_line() << "const char *slice = sell + (i >> 9) * (wp * 1024 + ell_w * 512 * sizeof(" << V << "));";
+        c.src.new_line() << "const uint *cw = (const uint *)(blocks ? pool + (long)blocks[i >> 9] * (wp * 1024) : slice) + ((i & 511) >> 1);";
+        c.src.new_line() << "const " << V << " *ell_val = (const " << V << " *)(slice + wp * 1024) + (i & 511);";
+        c.src.new_line() << "uint cword[4]; " << V << " xv[8], av[8]; uint real[8];";
+        c.src.new_line() << "for(int u = 0; u < 4; ++u) { const long uu = u < wp ? u : wp - 1; cword[u] = cw[uu * 256]; }";
+        c.src.new_line() << "for(int j = 0; j < 8; ++j)";
+        c.src.open("{");
+        c.src.new_line() << "const uint code = (cword[j >> 1] >> (8 * ((j & 1) * 2 + (int)(i & 1)))) & 255u;";
+        c.src.new_line() << "real[j] = (j < ell_w && code < 254u) ? 1u : 0u;";
+        c.src.new_line() << "long jx = (long)i + deltas[real[j] ? code : 0u]; jx = jx < 0 ? 0 : jx; jx = jx > x_last ? x_last : jx;";
+        c.src.new_line() << "xv[j] = in[jx]; av[j] = ell_val[(j < ell_w ? j : ell_w - 1) * 512];";
+        c.src.close("}");
+        c.src.new_line() << "for(int j = 0; j < 8; ++j) sum = real[j] ? sum + av[j] * xv[j] : sum;";
+        c.src.close("}");
+        c.src.new_line() << "else if (deltas)";
         c.src.open("{");
         c.src.new_line() << "const long wp = (ell_w + 1) / 2;";
         c.src.new_line() << "const char *slice = sell + (i >> 9) * (wp * 1024 + ell_w * 512 * sizeof(" << V << "));";
@@ -710,12 +752,20 @@ struct inline_spmv : expression_base {
         c.src.new_line() << "if (code < 254u) sum += ell_val[j * 512] * in[(long)i + deltas[code]];";
         c.src.close("}");
         c.src.close("}");
-        c.src.new_line() << "else";                   // SELL-512 with 32-bit columns
+        c.src.new_line() << "else";                   // SELL-512 with 32-bit columns: groups of four entries, their requests issued together
         c.src.open("{");
         c.src.new_line() << "const char *slice = sell + (i >> 9) * (ell_w * 512 * (4 + sizeof(" << V << ")));";
         c.src.new_line() << "const int *ell_col = (const int *)slice + (i & 511);";
         c.src.new_line() << "const " << V << " *ell_val = (const " << V << " *)(slice + ell_w * 2048) + (i & 511);";
-        c.src.new_line() << "for(long j = 0; j < ell_w; ++j)";
+        c.src.new_line() << "long j = 0;";
+        c.src.new_line() << "for(; j + 4 <= ell_w; j += 4)";
+        c.src.open("{");
+        c.src.new_line() << "int cc[4]; " << V << " av[4], xv[4];";
+        c.src.new_line() << "for(int u = 0; u < 4; ++u) { cc[u] = ell_col[(j + u) * 512]; av[u] = ell_val[(j + u) * 512]; }";
+        c.src.new_line() << "for(int u = 0; u < 4; ++u) xv[u] = in[cc[u] < 0 ? 0 : cc[u]];";
+        c.src.new_line() << "for(int u = 0; u < 4; ++u) sum = cc[u] >= 0 ? sum + av[u] * xv[u] : sum;";
+        c.src.close("}");
+        c.src.new_line() << "for(; j < ell_w; ++j)";
         c.src.open("{");
         c.src.new_line() << "int c = ell_col[j * 512];";
         c.src.new_line() << "if (c >= 0) sum += ell_val[j * 512] * in[c];";
@@ -739,13 +789,14 @@ struct inline_spmv : expression_base {
         c.src.parameter("const " + V + " *", name + "_csr_val"); c.src.parameter("const " + V + " *", name + "_vec");
         c.src.parameter("long", name + "_grid_nx"); c.src.parameter("long", name + "_grid_far"); c.src.parameter("long", name + "_grid_pitch");
         c.src.parameter("const int *", name + "_line_class"); c.src.parameter("const uchar *", name + "_grid_table");
+        c.src.parameter("long", name + "_x_last");
     }
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
         c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, " << n << "_blocks, " << n << "_pool, "
               << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, "
-              << n << "_grid_nx, " << n << "_grid_far, " << n << "_grid_pitch, " << n << "_line_class, " << n << "_grid_table, idx)";
+              << n << "_grid_nx, " << n << "_grid_far, " << n << "_grid_pitch, " << n << "_line_class, " << n << "_grid_table, " << n << "_x_last, idx)";
     }
     void set_args(arg_context &a) const {
         a.next();
@@ -767,6 +818,7 @@ struct inline_spmv : expression_base {
         a.krn.push_arg((long)L.grid.nx); a.krn.push_arg((long)L.grid.nx * (long)L.grid.lines_per_plane); a.krn.push_arg((long)L.grid.pitch);
         a.krn.push_arg(static_cast<const int *>(by_line ? L.grid.line_class : nullptr));
         a.krn.push_arg(static_cast<const unsigned char *>(by_line ? L.grid.table : nullptr));
+        a.krn.push_arg((long)x(a.device).size() - 1);        // the last element of x: clamped requests stay inside the vector
     }
     void get_props(prop_context &p) const {
         if (p.empty()) { p.queue = A.queue_list(); p.part = A.row_partition(); p.size = A.rows(); }

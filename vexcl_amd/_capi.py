@@ -115,6 +115,8 @@ _PROTOS = {
     "vexhip_stream_wait_event": (None, [c_int, c_vp, c_vp]),
     "vexhip_event_elapsed_ms": (None, [c_int, c_vp, c_vp, ctypes.POINTER(c_f32)]),
     "vexhip_malloc": (None, [c_int, c_size, ctypes.POINTER(c_vp)]),
+    "vexhip_malloc_placement": (c_size, [c_size, ctypes.c_uint64, ctypes.c_uint]),
+    "vexhip_malloc_stagger": (c_size, [c_size, ctypes.c_uint]),
     "vexhip_malloc_managed": (None, [c_int, c_size, ctypes.POINTER(c_vp)]),
     "vexhip_free": (None, [c_int, c_vp]),
     "vexhip_memcpy_h2d": (None, [c_int, c_vp, c_vp, c_size, c_vp, c_int]),

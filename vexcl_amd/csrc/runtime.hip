@@ -13,6 +13,7 @@
 #include <fstream>
 #include <mutex>
 #include <sstream>
+#include <unordered_map>
 #include <vector>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -280,12 +281,46 @@ int vexhip_event_elapsed_ms(int dev, void *start, void *stop, float *ms) {
 }
 
 // ---------------------------------------------------------------- memory
+// Where a large allocation starts (round 6).  The headline product reads x a few planes ahead of where it writes y; its time
+// depends on (y - x) mod 64 MiB and on nothing else of the placement (profiles/r06_xy_gap.json: two sweeps of 257 gaps correlate
+// at 0.994): 0.375 - 0.382 ms where the difference lies within +-10 MiB of a multiple of 64 MiB, up to 0.417 ms between 12 and
+// 32 MiB (bases at 2 MiB multiples -- what any allocator hands out; a third of all placements).  The library owns the allocation of
+// every vex::vector, so it places them: allocations of 64 MiB and more start at a multiple of 64 MiB plus a stagger of 0, 2, 4, 6,
+// 8 MiB in turn (any two of them then differ by less than 10 MiB mod 64 MiB, and vectors that are walked in lockstep -- a = b * c +
+// sin(d) -- do not all start on the same channel).  Costs up to 72 MiB of address space per large allocation.
+static constexpr size_t kStaggerAlign = size_t(64) << 20, kStaggerStep = size_t(2) << 20, kStaggerSlots = 5, kStaggerFrom = size_t(64) << 20;
+
+extern "C" size_t vexhip_malloc_stagger(size_t bytes, unsigned ordinal) {
+    if (bytes < kStaggerFrom) return 0;
+    static const bool off = std::getenv("VEXHIP_MALLOC_STAGGER") && std::atoi(std::getenv("VEXHIP_MALLOC_STAGGER")) == 0;
+    if (off) return 0;
+    return (ordinal % kStaggerSlots) * kStaggerStep;
+}
+extern "C" size_t vexhip_malloc_placement(size_t bytes, uint64_t raw_address, unsigned ordinal) {
+    if (bytes < kStaggerFrom) return 0;
+    const uint64_t aligned = (raw_address + kStaggerAlign - 1) / kStaggerAlign * kStaggerAlign;
+    return (size_t)(aligned - raw_address) + vexhip_malloc_stagger(bytes, ordinal);
+}
+
+namespace {
+std::mutex g_alloc_mx;
+std::unordered_map<void *, void *> g_alloc_base;       // what the caller holds -> what hipFree takes
+std::atomic<unsigned> g_alloc_ordinal{0};
+}
+
 int vexhip_malloc(int dev, size_t bytes, void **ptr) {
     VEXHIP_REQUIRE(ptr, "ptr is NULL");
     VEXHIP_SET_DEVICE(dev);
     *ptr = nullptr;
     if (bytes == 0) return 0;
-    VEXHIP_TRY(hipMalloc(ptr, bytes));
+    static const bool off = std::getenv("VEXHIP_MALLOC_STAGGER") && std::atoi(std::getenv("VEXHIP_MALLOC_STAGGER")) == 0;
+    if (bytes < kStaggerFrom || off) { VEXHIP_TRY(hipMalloc(ptr, bytes)); return 0; }
+    void *raw = nullptr;
+    VEXHIP_TRY(hipMalloc(&raw, bytes + kStaggerAlign + (kStaggerSlots - 1) * kStaggerStep));
+    const size_t shift = vexhip_malloc_placement(bytes, (uint64_t)reinterpret_cast<uintptr_t>(raw), g_alloc_ordinal.fetch_add(1));
+    void *p = static_cast<char *>(raw) + shift;
+    if (p != raw) { std::lock_guard<std::mutex> lock(g_alloc_mx); g_alloc_base[p] = raw; }
+    *ptr = p;
     return 0;
 }
 
@@ -301,6 +336,11 @@ int vexhip_malloc_managed(int dev, size_t bytes, void **ptr) {
 int vexhip_free(int dev, void *ptr) {
     if (!ptr) return 0;
     VEXHIP_SET_DEVICE(dev);
+    {
+        std::lock_guard<std::mutex> lock(g_alloc_mx);
+        auto it = g_alloc_base.find(ptr);
+        if (it != g_alloc_base.end()) { ptr = it->second; g_alloc_base.erase(it); }
+    }
     VEXHIP_TRY(hipFree(ptr));
     return 0;
 }

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 namespace vexhip {
 
@@ -56,7 +57,7 @@ __device__ __forceinline__ void count_digit(unsigned *s_h, unsigned d) {
     }
 }
 
-template <typename K, int MODE, bool DESC, int KPT>
+template <typename K, int MODE, bool DESC, int KPT, int UNROLL = 6>
 __global__ __launch_bounds__(HB)
 void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsigned nblocks, unsigned *__restrict__ table, int vec_ok)
 {
@@ -80,7 +81,7 @@ void radix_hist_kernel(const K *__restrict__ keys, long long n, int shift, unsig
         const vtype *kv = reinterpret_cast<const vtype *>(keys + base);
         // six 16-byte loads in flight per lane before the first counter bump: with one load per trip the kernel sat
         // at 4.3 TB/s with its waves parked 89 % of the time (profiles/r02_sort_sq.txt) -- latency, not HBM
-        constexpr int UN = 6;
+        constexpr int UN = UNROLL;
         int v = threadIdx.x;
         for (; v + (UN - 1) * HB < nv; v += UN * HB) {
             vtype q[UN];
@@ -368,12 +369,12 @@ void radix_scatter_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_ou
 //       CHECK 0: the counter atomic alone (A/B only).
 //   * no branches in the rank loop (violations are OR-ed into two registers and tested once), byte offsets with a scalar base
 //     per key round in the write-out (one add per key).
-template <typename T>
+template <typename T, int AUX = 0>
 __device__ __forceinline__ void store_elem(T v, __amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned scalar_bytes) {
-    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)lane_bytes, (int)scalar_bytes, 0);
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)lane_bytes, (int)scalar_bytes, AUX);
     else {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (int)lane_bytes, (int)scalar_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (int)lane_bytes, (int)scalar_bytes, AUX);
     }
 }
 
@@ -599,7 +600,7 @@ struct unit_lds {
     int uni;
 };
 
-template <typename K, int MODE, bool DESC, int VB, int KPT, bool WIDE>
+template <typename K, int MODE, bool DESC, int VB, int KPT, bool WIDE, int AUX = 0>
 __global__ __launch_bounds__(UB, 6)
 void radix_scatter_unit_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
         const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
@@ -738,8 +739,8 @@ void radix_scatter_unit_kernel(const K *__restrict__ keys_in, K *__restrict__ ke
             keys_out[(size_t)g] = kk;
             if constexpr (VB != 0) vals_out[(size_t)g] = s_vals[t + k * UB];
         } else {
-            store_elem<K>(kk, rk, e * (unsigned)sizeof(K), (unsigned)(k * UB) * (unsigned)sizeof(K));
-            if constexpr (VB != 0) store_elem<VT>(s_vals[t + k * UB], rv, e * (unsigned)VB, (unsigned)(k * UB) * (unsigned)VB);
+            store_elem<K, AUX>(kk, rk, e * (unsigned)sizeof(K), (unsigned)(k * UB) * (unsigned)sizeof(K));
+            if constexpr (VB != 0) store_elem<VT, AUX>(s_vals[t + k * UB], rv, e * (unsigned)VB, (unsigned)(k * UB) * (unsigned)VB);
         }
     }
 }
@@ -763,7 +764,11 @@ void launch_unit(hipStream_t s, bool wide, unsigned nfull, const K *src, K *dst,
     if constexpr (unit_ok<K, VB>()) {
         constexpr int KPT = unit_kpt<K, VB>();
         const unsigned grid = (nfull + 7) / 8 * 8;
+        static const int aux = std::getenv("VEXHIP_SORT_STORE_AUX") ? std::atoi(std::getenv("VEXHIP_SORT_STORE_AUX")) : 0;     // (A/B, round 6: 2 = nt, 18 = nt sc1, 17 = sc0 sc1)
         if (wide) radix_scatter_unit_kernel<K, MODE, DESC, VB, KPT, true><<<grid, UB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+        else if (aux == 2)  radix_scatter_unit_kernel<K, MODE, DESC, VB, KPT, false, 2><<<grid, UB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+        else if (aux == 18) radix_scatter_unit_kernel<K, MODE, DESC, VB, KPT, false, 18><<<grid, UB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
+        else if (aux == 17) radix_scatter_unit_kernel<K, MODE, DESC, VB, KPT, false, 17><<<grid, UB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
         else      radix_scatter_unit_kernel<K, MODE, DESC, VB, KPT, false><<<grid, UB, 0, s>>>(src, dst, vsrc, vdst, n, shift, nblocks, nfull, table);
     } else launch_lean<K, MODE, DESC, VB, 2>(s, wide, nfull, src, dst, vsrc, vdst, n, shift, nblocks, table);      // (4-byte keys with 8-byte values: 4096 pairs per tile do not split over 768 lanes)
 }
@@ -788,7 +793,10 @@ int sort_passes(hipStream_t s, K *keys, K *keys_tmp, void *vals, void *vals_tmp,
     const bool wide = (n + 2 * TILE) * widest >= (1ll << 32) - 16;  // byte offsets of the write-out (lane + scalar part, range-checked together) beyond 32 bits
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        radix_hist_kernel<K, MODE, DESC, KPT><<<(nblocks + 7) / 8 * 8, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
+        static const int hun = std::getenv("VEXHIP_SORT_HIST_UNROLL") ? std::atoi(std::getenv("VEXHIP_SORT_HIST_UNROLL")) : 6;     // (A/B, round 6)
+        if (hun == 12) radix_hist_kernel<K, MODE, DESC, KPT, 12><<<(nblocks + 7) / 8 * 8, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
+        else if (hun == 3) radix_hist_kernel<K, MODE, DESC, KPT, 3><<<(nblocks + 7) / 8 * 8, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
+        else radix_hist_kernel<K, MODE, DESC, KPT><<<(nblocks + 7) / 8 * 8, HB, 0, s>>>(src, n, shift, nblocks, table, vec_ok);
         VEXHIP_LAUNCH_CHECK();
         if (int rc = scan_exclusive_u32_tmp(s, table, table, tn, scan_tmp)) return rc;
         const unsigned nfull = (unsigned)(n / TILE);

@@ -160,6 +160,28 @@ def diffusion3d(n, device="cuda", rows=None, seed=7):
     return ptr, col, val
 
 
+_vector_ordinal = [0]
+
+
+def device_vector(n, dtype=torch.float64, device="cuda", zero=False):
+    """A vector placed as the library places a vex::vector (csrc/runtime.hip vexhip_malloc, round 6): allocations of 64 MiB and more
+    start at a multiple of 64 MiB plus a stagger of 0 / 2 / 4 / 6 / 8 MiB -- where x and y of a product lie relative to each other is
+    worth up to 11 % of the headline (profiles/r06_xy_gap.json).  The memory is torch's (a view into a larger allocation, which the
+    view keeps alive); the offset is the library's rule (vexhip_malloc_placement), not a copy of it."""
+    dev = torch.device(device)
+    item = torch.empty(0, dtype=dtype).element_size()
+    nbytes = n * item
+    slack = (64 << 20) + (8 << 20) if nbytes >= (64 << 20) else 0
+    raw = torch.empty(nbytes + slack, dtype=torch.uint8, device=dev)
+    skip = lib().malloc_placement(nbytes, raw.data_ptr(), _vector_ordinal[0]) if slack else 0
+    if slack:
+        _vector_ordinal[0] += 1
+    v = raw[skip:skip + nbytes].view(dtype)
+    if zero:
+        v.zero_()
+    return v
+
+
 def fill_hash(t, seed):
     lib().fill_hash(_dev(t), _stream(t), _dtype_code(t), ctypes.c_uint64(seed), _p(t), t.numel())
     return t
