@@ -375,6 +375,12 @@ def unstructured_rows(torch, ops, dev, args):
                                          "traffic / bytes_per_launch says how much of x is fetched more than once") if name in ("banded16", "stencil27") else
                                         ("x is gathered 8 bytes at a time from lines nobody else in the wave uses: the memory system moves a whole "
                                          "sector per entry (traffic below), the bytes priced here are the floor (matrix + x once + y once)")}}
+            if name in ("banded16", "random16"):
+                # A/B: the same matrix with its slices dealt round-robin to the XCDs (every XCD's L2 then sees every eighth slice)
+                B = ops.SpMat(ptr, col, val, plain_order=True)
+                tb = min(timed_events(torch, lambda: B.apply(x, y), 10) for _ in range(2))
+                row["slices_dealt_round_robin_ms"] = round(tb, 5)
+                del B
             if name == "random16":
                 # the bound this access pattern has: every entry pulls its own 128-byte line of x through the fabric (x, 160 MB, lies
                 # under the 256 MiB Infinity Cache: FETCH_SIZE counts those lines) -- nnz lines at the rate the fetch path sustains

@@ -68,6 +68,10 @@ int vexhip_stream_wait_event(int dev, void *stream, void *event); /* enqueue_bar
 int vexhip_event_elapsed_ms(int dev, void *start, void *stop, float *ms);
 
 /* ---- device_vector<T> storage (backend/cuda/device_vector.hpp:66-214) --- */
+/* The library's switches (VEXHIP_* / VEXCL_* environment variables: A/B experiments, diagnostics, test hooks -- none is needed in
+ * normal use) are looked up in a snapshot of the environment taken at first use and again whenever an object is created (a matrix,
+ * a plan, a window, a step, a communicator); products never read the environment.  This call takes the snapshot NOW.           */
+int vexhip_reload_env(void);
 int vexhip_malloc(int dev, size_t bytes, void **ptr);
 int vexhip_free(int dev, void *ptr);
 /* Where vexhip_malloc places an allocation of 64 MiB or more (round 6; host arithmetic, no device): bytes to skip from the raw
@@ -430,6 +434,7 @@ enum { VEXHIP_SPMAT_BORROW_CSR = 1,      /* format CSR: keep the caller's arrays
        VEXHIP_SPMAT_NO_MARCH = 4,        /* keep the pair products where the march / plane products would apply (A/B, tests)       */
        VEXHIP_SPMAT_NO_PLANE = 8,        /* keep the march product where the plane product would apply (A/B, tests)                */
        VEXHIP_SPMAT_NO_GRID_BUILD = 16,  /* build the SELL-512 storage even where the matrix could be stored by grid line (A/B, tests) */
+       VEXHIP_SPMAT_PLAIN_ORDER = 64,    /* 32-bit-column storage: slices dealt to the XCDs round-robin even where the default gives every XCD a contiguous eighth (A/B) */
        VEXHIP_SPMAT_SQUARE = 32 };       /* x has at least `rows` elements whatever the largest column that occurs (the set-up assumes     *
                                           * only max column + 1 otherwise: vex::SpMat takes n AND m, spmat.hpp:56-60)                     */
 typedef struct vexhip_spmat_info {
@@ -680,16 +685,19 @@ int vexhip_scan(int dev, void *stream, int dtype, int exclusive, const void *ini
  * keys are sorted in place; keys_tmp (n keys) and, for pairs, vals_tmp are
  * ping-pong buffers; tmp holds vexhip_sort_tmp_bytes().  value_bytes in {0,4,8}. */
 size_t vexhip_sort_tmp_bytes(int key_dtype, int64_t n);
-/* How the scatter ranks the keys of a wave: -1 (default) = atomic ranks if the device passes the lane-order self-test of
- * LDS atomics (run once per device), else match words; 0 = match words (ordered by construction: no assumption about the
- * order in which the LDS serves the lanes of one atomic); 1 = atomic ranks (A/B, tests).  With atomic ranks every sort
- * ranks one complete tile in 16 BOTH ways inside the production launch (all twelve keys of every lane) and traps on the
- * first difference (the error surfaces at the next synchronisation): a pass is never silently unstable on those tiles,
- * and a part that served lanes in another order would be caught by the first sort of more than 16 tiles.            */
+/* How the scatter ranks the keys of a tile: -1 / 6 (default) = half-wave ranking units, one returning 64-bit LDS atomic per key whose
+ * return carries the rank AND the lanes served before it -- a lane served out of lane order is SEEN, and the tile is then ranked again
+ * by ballots inside the same launch (counted: vexhip_sort_status); 0 = ranks from match words in every tile (ordered by construction:
+ * no assumption about the order in which the LDS serves the lanes of one atomic; 25 % slower; A/B, tests); 7 = the default with
+ * every tile taking the ballot path (tests of that path).                                                                          */
 int vexhip_sort_set_rank(int mode);
 int vexhip_sort(int dev, void *stream, int key_dtype, int descending,
         void *keys, void *keys_tmp, int value_bytes, void *vals, void *vals_tmp,
         int64_t n, void *tmp);
+/* What the last vexhip_sort of n keys on the workspace `tmp` met (waits for the stream): tiles ranked a second time because the LDS
+ * served a lane out of lane order (the result is correct all the same), tiles dropped because their keys no longer matched the
+ * pass's histogram -- the caller changed the input while the sort ran; then the call FAILS (vexhip_last_error).  Neither traps. */
+int vexhip_sort_status(int dev, void *stream, int64_t n, const void *tmp, int64_t *reranked_tiles, int64_t *dropped_tiles);
 
 /* ---- compressed-stencil SpMV (spmat/ccsr.hpp:40-53,184-200; vex::SpMatCCSR) ----
  * y[i] (=|+=) alpha * sum_{j in [row[idx[i]], row[idx[i]+1])} val[j] * x[i + col[j]];

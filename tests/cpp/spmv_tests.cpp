@@ -216,6 +216,45 @@ TEST_CASE(spmv_one_launch_step_multi_device) {
     D.apply_timed(X, Y, ms);
     CHECK(ms.size() == q.size());
     CHECK(same_bits());
+    // float on 512-point lines (plane32.hip) and double on lines of another length (the grid product): the same step
+    {
+        std::vector<float> valf(val.begin(), val.end()), xf(x.begin(), x.end()), yf(N), yf1(N);
+        vex::SpMat<float, int, int> F(q, N, N, row.data(), col.data(), valf.data()), F1(q1, N, N, row.data(), col.data(), valf.data());
+        CHECK(std::string(F.step_kind()).find("one launch per device") == 0);
+        if (std::string(F.step_kind()).find("one launch per device") != 0) std::cerr << "float: one-launch step declined: " << F.halo_declined() << std::endl;
+        vex::vector<float> XF(ctx, xf), YF(ctx, N), XF1(q1, xf), YF1(q1, N);
+        YF = F * XF; YF1 = F1 * XF1;
+        YF += 0.5f * (F * XF); YF1 += 0.5f * (F1 * XF1);
+        vex::copy(YF, yf); vex::copy(YF1, yf1);
+        bool same = true;
+        for (size_t i = 0; i < N; ++i) same = same && std::memcmp(&yf[i], &yf1[i], 4) == 0;
+        CHECK(same);
+    }
+    {
+        const size_t gx = 96, gy = 12, gz = 8 * q.size(), GN = gx * gy * gz, GP = gx * gy;
+        std::vector<int> grow(1, 0), gcol; std::vector<double> gval;
+        for (size_t k = 0, idx = 0; k < gz; ++k) for (size_t j = 0; j < gy; ++j) for (size_t i = 0; i < gx; ++i, ++idx) {
+            if (i == 0 || i == gx - 1 || j == 0 || j == gy - 1 || k == 0 || k == gz - 1) { gcol.push_back((int)idx); gval.push_back(1); }
+            else for (long d : {-(long)GP, -(long)gx, -1l, 0l, 1l, (long)gx, (long)GP}) { gcol.push_back((int)(idx + d)); gval.push_back(d ? -0.5 * (d > 0 ? 3 : 1) : 7.5); }
+            grow.push_back((int)gcol.size());
+        }
+        const std::vector<size_t> gpart = vex::partition(GN, q);
+        bool whole = true;
+        for (unsigned d = 0; d < q.size(); ++d) whole = whole && (gpart[d + 1] - gpart[d]) % GP == 0;
+        if (whole) {
+            vex::SpMat<double, int, int> G(q, GN, GN, grow.data(), gcol.data(), gval.data()), G1(q1, GN, GN, grow.data(), gcol.data(), gval.data());
+            CHECK(std::string(G.step_kind()).find("one launch per device") == 0);
+            if (std::string(G.step_kind()).find("one launch per device") != 0) std::cerr << "96-point lines: one-launch step declined: " << G.halo_declined() << std::endl;
+            std::vector<double> gx0 = random_vector<double>(GN), ga(GN), gb(GN);
+            vex::vector<double> GX(ctx, gx0), GY(ctx, GN), GX1(q1, gx0), GY1(q1, GN);
+            GY = G * GX; GY1 = G1 * GX1;
+            for (int rep = 0; rep < 5; ++rep) { GX = 0.5 * GX + 0.25; GY += 1.5 * (G * GX); GX1 = 0.5 * GX1 + 0.25; GY1 += 1.5 * (G1 * GX1); }
+            vex::copy(GY, ga); vex::copy(GY1, gb);
+            bool same = true;
+            for (size_t i = 0; i < GN; ++i) same = same && std::memcmp(&ga[i], &gb[i], 8) == 0;
+            CHECK(same);
+        }
+    }
     // a general matrix on the same context keeps the exchange, and says why
     {
         const size_t n = 1024;

@@ -20,6 +20,8 @@ P = n * n
 r0, r1 = rank * N // world, (rank + 1) * N // world
 rows = r1 - r0
 ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
+DT = torch.float32 if os.environ.get("DIST_DTYPE", "f64") == "f32" else torch.float64      # DIST_DTYPE=f32: the float step (plane32.hip; pull only)
+val = val.to(DT)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 # the strip stored WITH its ghost planes, built by the library (what vexcl/spmat.hpp calls)
 nnz = int(col.numel())
@@ -29,15 +31,15 @@ L.csr_extend_halo_i32(0, None, rows, nnz, p(ptr), p(col), r0, P, P, p(ptr_ext), 
 assert bad.value == 0, bad.value
 torch.cuda.synchronize()
 ext = ops.SpMat(ptr_ext, col_ext, val, n_cols=rows + 2 * P)
-assert ext.plane, "the stored strip did not get a plane plan"
+assert ext.plane or ext.grid, "the stored strip did not get a plane or grid plan"
 loc_only = None
-x = ops.fill_hash(torch.empty(rows, dtype=torch.float64, device=dev), 42); y = torch.empty_like(x)
+x = ops.fill_hash(torch.empty(rows, dtype=torch.float64, device=dev), 42).to(DT); y = torch.empty_like(x)
 s = torch.cuda.Stream(); sp = ctypes.c_void_p(s.cuda_stream)
 out = {"grid": n, "strip_rows": rows, "stored_strip": {"rows": rows + 2 * P, "storage": ext.storage, "plane_plan": ext.plane},
        "env": {k: v for k, v in os.environ.items() if k.startswith("VEXHIP_HALO")}}
 # the bits of the ONE-device product: the same stored strip through the CSR kernel on x with its ghost planes attached
 x_ext = torch.cat([x[rows - P:], x, x[:P]]).contiguous()
-y_ext = torch.empty(rows + 2 * P, dtype=torch.float64, device=dev)
+y_ext = torch.empty(rows + 2 * P, dtype=DT, device=dev)
 ref = ops.SpMat(ptr_ext, col_ext, val, n_cols=rows + 2 * P, fmt="csr")
 ref.apply(x_ext, y_ext); torch.cuda.synchronize()
 y_one = y_ext[P:P + rows].clone()
@@ -74,7 +76,7 @@ def status(step):
 
 
 which = os.environ.get("DIST_ONLY", "push,pull,events,parts").split(",")
-if "push" in which:
+if "push" in which and ext.plane and DT == torch.float64:
     win = ctypes.c_void_p(); L.ipc_window_create(0, 0, 1, 2 * P * 8, ctypes.byref(win))
     step = ctypes.c_void_p()
     L.dist_spmv_create_halo(win, ext.handle, rows, P, 0, 0, ctypes.byref(step))
@@ -84,7 +86,7 @@ if "push" in which:
     out["push_equals_one_device_csr_order"] = bool(torch.equal(y, y_one))
     L.dist_spmv_destroy(step); L.ipc_window_destroy(win)
 
-xb, xa = ctypes.c_void_p(x.data_ptr() + (rows - P) * 8), ctypes.c_void_p(x.data_ptr())      # own last plane below, own first plane above
+xb, xa = ctypes.c_void_p(x.data_ptr() + (rows - P) * x.element_size()), ctypes.c_void_p(x.data_ptr())      # own last plane below, own first plane above
 if "pull" in which:
     win = ctypes.c_void_p(); L.ipc_window_create(0, 0, 1, 0, ctypes.byref(win))
     step = ctypes.c_void_p()

@@ -95,7 +95,7 @@ MAKERS = {"random16": random16, "powerlaw": powerlaw, "banded16": banded16, "ste
 ROWS_OF = {"stencil27": 256 ** 3}          # rows of a maker that does not take the bench's UNSTRUCTURED_ROWS
 # kernels a product of such a matrix may launch (the ELL part, the CSR arrays); names as rocprofv3 prints them
 PRODUCT_KERNELS = ("sell_kernel", "sell_pair_kernel", "sell8_pair_kernel", "hell_kernel", "csr_stream2_kernel", "csr_stream_kernel",
-                   "csr_scalar_kernel", "csr_rows_kernel", "sellu_kernel", "sell8_march_kernel", "sell8_grid_kernel", "sell8_plane_kernel")
+                   "csr_scalar_kernel", "csr_rows_kernel", "sellu_kernel", "sell8_march_kernel", "sell8_grid_kernel", "sell8_plane_kernel", "sell8_kernel", "sell8v_kernel")
 
 
 def stencil2d(W, H, dev):

@@ -18,6 +18,7 @@
 #include <array>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -217,6 +218,16 @@ class SpMat {
         }
 
         // ---- pieces used by make_inline (spmat.hpp:195-230) -------------------------
+        /// A vector of this matrix's rows on device d that holds A * x for ONE make_inline terminal (keyed by the terminal's place in
+        /// its expression): where the library's product is a hand-written kernel that a generated row function cannot match, the
+        /// terminal is evaluated by that kernel into this vector and read back by the expression kernel (round 6).  Kernels of one
+        /// queue run in order: the vector is free again when the next expression needs it.
+        backend::device_vector<val_t> &inline_temporary(const std::string &key, unsigned d) const {
+            auto &v = inline_tmp[key + "/" + std::to_string(d)];
+            const size_t rows = part[d + 1] - part[d];
+            if (v.size() != rows) v = backend::device_vector<val_t>(queue[d], rows);
+            return v;
+        }
         struct device_part;
         const device_part &part_of(unsigned d) const { return *mtx[d]; }
         const std::vector<backend::command_queue> &queue_list() const { return queue; }
@@ -439,7 +450,8 @@ class SpMat {
         // :291-378).  The bits are those of the one-device product (a row's entries stay in column order).
         // Distinct GPUs: flags in small uncached windows order the launches (VEXHIP_PULL_FLAGS).  Logical devices that share a GPU
         // (the reference's test fixture): events between the queues (VEXHIP_PULL_EVENTS).  VEXCL_HALO=off|flags|events overrides.
-        // Anything else -- general matrices, other grids, float -- keeps the exchange of vexcl/exchange.hpp; halo_declined() says why.
+        // Double: 512-point lines through the plane product, lines of any other length through the grid product; float: 512-point lines
+        // (plane32.hip).  Anything else -- general matrices, float on other grids -- keeps the exchange of vexcl/exchange.hpp; halo_declined() says why.
         struct halo_steps {
             struct dev_t {
                 std::shared_ptr<vexhip_spmat> ext; std::shared_ptr<vexhip_ipc_window> win; std::shared_ptr<vexhip_dist_spmv> step;
@@ -501,7 +513,6 @@ class SpMat {
                 }
             }
             if (!exc.active()) { halo.why = "no ghost columns"; return; }
-            if (!is_double<val_t>()) { halo.why = "value type is not double"; return; }
             if (nrows != ncols || part != col_part) { halo.why = "rows and columns are partitioned differently"; return; }
             // H = elements of a ghost plane: every device's remote columns lie within H of its own (rounded to whole pairs of 512-point lines)
             size_t reach = 0;
@@ -514,8 +525,21 @@ class SpMat {
                     else { hi[d] = 1; reach = std::max(reach, c + 1 - col_part[d + 1]); }
                 }
             }
-            const size_t Hh = (reach + 1023) / 1024 * 1024;
-            if (!Hh) { halo.why = "no ghost columns"; return; }
+            // (a plane of the grid is at least `reach` long -- the first and the last points of a plane are boundary rows without
+            //  neighbours -- and every strip is a whole number of planes: the smallest such divisor of the first strip; the plan of the
+            //  stored strip decides below whether that IS the grid's plane)
+            size_t Hh = 0;
+            if (reach) {
+                const size_t rows0 = part[1] - part[0];
+                for (size_t k = std::min<size_t>(rows0 / reach, 65536); k >= 1 && !Hh; --k) {       // (planes per strip; thinner planes than a 65536th of a strip keep the exchange)
+                    if (rows0 % k) continue;
+                    const size_t h = rows0 / k;
+                    bool whole = h >= reach;
+                    for (unsigned d = 0; d < nd && whole; ++d) whole = (part[d + 1] - part[d]) % h == 0;
+                    if (whole) Hh = h;
+                }
+            }
+            if (!Hh) { halo.why = reach ? "the strips are not whole numbers of planes" : "no ghost columns"; return; }
             for (unsigned d = 0; d < nd; ++d) {
                 const size_t rows = part[d + 1] - part[d];
                 if (rows % Hh || rows < Hh) { halo.why = "a strip is not a whole number of planes of " + std::to_string(Hh) + " elements"; return; }
@@ -540,11 +564,14 @@ class SpMat {
                                 (int64_t)l, (int64_t)h, eptr.raw(), ecol.raw(), &bad));
                     if (bad) { declined[d] = "columns outside the two ghost planes"; return; }
                     vexhip_spmat *e = nullptr;
-                    backend::check(spmat_create(ord, q.raw(), (int64_t)(l + rows + h), eptr.raw(), ecol.raw(), reinterpret_cast<const double *>(P.strip_val.raw()), VEXHIP_SPMAT_AUTO, VEXHIP_SPMAT_SQUARE, &e));
+                    backend::check(spmat_create(ord, q.raw(), (int64_t)(l + rows + h), eptr.raw(), ecol.raw(), P.strip_val.raw(), VEXHIP_SPMAT_AUTO, VEXHIP_SPMAT_SQUARE, &e));
                     D->ext = std::shared_ptr<vexhip_spmat>(e, [](vexhip_spmat *p) { vexhip_spmat_destroy(p); });
                     backend::check(vexhip_spmat_get_info(e, &D->info));
-                    const auto &pl = D->info.plane;
-                    if (!pl.usable || (size_t)pl.lines_per_plane * 512 != Hh || (size_t)pl.planes * Hh != l + rows + h) { declined[d] = "the strip with its ghost planes is not stored for the plane product"; return; }
+                    const auto &pl = D->info.plane; const auto &gr = D->info.grid;
+                    const bool by_plane = pl.usable && (size_t)pl.lines_per_plane * 512 == Hh && (size_t)pl.planes * Hh == l + rows + h;
+                    const bool by_grid = is_double<val_t>() && !pl.usable && gr.usable && D->info.format == VEXHIP_SPMAT_SELL8V && !D->info.tail_nnz
+                                         && (size_t)gr.lines_per_plane * (size_t)gr.nx == Hh && (size_t)gr.planes * Hh == l + rows + h;
+                    if (!by_plane && !by_grid) { declined[d] = "the strip with its ghost planes is not stored for the plane or the grid product (a 7-point operator on a grid, few distinct values)"; return; }
                     if (order == VEXHIP_PULL_FLAGS) {
                         vexhip_ipc_window *w = nullptr;
                         backend::check(vexhip_ipc_window_create(ord, (int)d, (int)nd, 0, &w));
@@ -604,6 +631,7 @@ class SpMat {
         std::vector<size_t> part, col_part;
         size_t nrows, ncols, nnz;
         std::vector<std::shared_ptr<device_part>> mtx;
+        mutable std::map<std::string, backend::device_vector<val_t>> inline_tmp;
 
         template <class T, size_t N, class... Ts, size_t... I>
         void apply_components(const multivector<T, N> &x, detail::multi_target<Ts...> &y, scalar_type alpha, bool append,
@@ -790,16 +818,28 @@ struct inline_spmv : expression_base {
         c.src.parameter("long", name + "_grid_nx"); c.src.parameter("long", name + "_grid_far"); c.src.parameter("long", name + "_grid_pitch");
         c.src.parameter("const int *", name + "_line_class"); c.src.parameter("const uchar *", name + "_grid_table");
         c.src.parameter("long", name + "_x_last");
+        c.src.parameter("const " + V + " *", name + "_product");       // != NULL: A * x, evaluated by the library's kernel in front of this one
     }
     void local_init(gen_context &c) const { c.next(); }
     void emit(gen_context &c) const {
         std::string n = c.next();
-        c.src << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, " << n << "_blocks, " << n << "_pool, "
+        c.src << "(" << n << "_product ? " << n << "_product[idx] : " << n << "_hell_spmv(" << n << "_ell_w, " << n << "_sell, " << n << "_deltas, " << n << "_values, " << n << "_blocks, " << n << "_pool, "
               << n << "_csr_row, " << n << "_csr_col, " << n << "_csr_val, " << n << "_vec, "
-              << n << "_grid_nx, " << n << "_grid_far, " << n << "_grid_pitch, " << n << "_line_class, " << n << "_grid_table, " << n << "_x_last, idx)";
+              << n << "_grid_nx, " << n << "_grid_far, " << n << "_grid_pitch, " << n << "_line_class, " << n << "_grid_table, " << n << "_x_last, idx))";
+    }
+    /// Where the product comes from (round 6).  The generated row function issues 22 requests per row of a matrix stored by grid line --
+    /// class, seven codes, seven values, seven elements of x -- and runs at a fifth of the library's plane product (1.76 against 0.38 ms
+    /// at 512^3 even as straight-line code, profiles/r06_roofline_inline.log); the coded storages (SELL8V / SELL8: grid, plane, march,
+    /// pair products) therefore evaluate A * x with THEIR kernel into a vector the matrix keeps for this terminal, and the expression
+    /// kernel reads that vector -- two launches, 16 bytes per row more, still 2 x faster.  Matrices kept with 32-bit columns or in CSR
+    /// (no hand-written product that beats a row function by much) stay fused.  VEXCL_INLINE_SPMV=fused | product overrides.
+    bool through_product(const vexhip_spmat_info &L) const {
+        static const int forced = [] { const char *e = std::getenv("VEXCL_INLINE_SPMV"); return !e ? 0 : !std::strcmp(e, "fused") ? 1 : !std::strcmp(e, "product") ? 2 : 0; }();
+        if (forced) return forced == 2 && L.nnz > 0;
+        return L.nnz > 0 && (L.format == VEXHIP_SPMAT_SELL8V || L.format == VEXHIP_SPMAT_SELL8);
     }
     void set_args(arg_context &a) const {
-        a.next();
+        const std::string key = a.next();
         const auto &L = A.part_of(a.device).loc.info;      // zero-initialised when the local part is empty
         const bool csr_rows = L.format == VEXHIP_SPMAT_CSR || L.tail_nnz > 0;
         // (a matrix kept in CSR with 64-bit row pointers has no 32-bit pointer array for the generated terminal)
@@ -819,6 +859,13 @@ struct inline_spmv : expression_base {
         a.krn.push_arg(static_cast<const int *>(by_line ? L.grid.line_class : nullptr));
         a.krn.push_arg(static_cast<const unsigned char *>(by_line ? L.grid.table : nullptr));
         a.krn.push_arg((long)x(a.device).size() - 1);        // the last element of x: clamped requests stay inside the vector
+        const T *product = nullptr;
+        if (through_product(L)) {
+            backend::device_vector<T> &tmp = A.inline_temporary(key, a.device);
+            A.part_of(a.device).mul_local(A.queue_list()[a.device], x(a.device), tmp, T(1), false);
+            product = tmp.raw();
+        }
+        a.krn.push_arg(product);
     }
     void get_props(prop_context &p) const {
         if (p.empty()) { p.queue = A.queue_list(); p.part = A.row_partition(); p.size = A.rows(); }

@@ -94,6 +94,7 @@ SPMAT_NO_MARCH = 4
 SPMAT_NO_PLANE = 8
 SPMAT_NO_GRID_BUILD = 16
 SPMAT_SQUARE = 32
+SPMAT_PLAIN_ORDER = 64
 SPMAT_NAMES = {SPMAT_SELL8V: "sell8v", SPMAT_SELL8: "sell8", SPMAT_SELL: "sell32", SPMAT_CSR: "csr"}
 
 # name -> (restype, argtypes); restype None means "int status, checked"
@@ -114,6 +115,7 @@ _PROTOS = {
     "vexhip_event_sync": (None, [c_int, c_vp]),
     "vexhip_stream_wait_event": (None, [c_int, c_vp, c_vp]),
     "vexhip_event_elapsed_ms": (None, [c_int, c_vp, c_vp, ctypes.POINTER(c_f32)]),
+    "vexhip_reload_env": (None, []),
     "vexhip_malloc": (None, [c_int, c_size, ctypes.POINTER(c_vp)]),
     "vexhip_malloc_placement": (c_size, [c_size, ctypes.c_uint64, ctypes.c_uint]),
     "vexhip_malloc_stagger": (c_size, [c_size, ctypes.c_uint]),
@@ -257,6 +259,7 @@ _PROTOS = {
     "vexhip_scan": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vexhip_sort_tmp_bytes": (c_size, [c_int, c_i64]),
     "vexhip_sort_set_rank": (None, [c_int]),
+    "vexhip_sort_status": (None, [c_int, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "vexhip_sort": (None, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp]),
     "vexhip_spmv_ccsr_f64": (None, [c_int, c_vp, c_i64, c_f64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "vexhip_spmv_ccsr_set_rows_per_lane": (None, [c_int]),

@@ -24,9 +24,9 @@
 
 namespace vexhip {
 // spmat.hip: the stored strip of a rank as the operand of the one-launch step (halo.hpp)
-int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane);
+int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane, int *line_length, int *value_type);
 int spmat_device(const vexhip_spmat *h, int *dev);
-int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const double *x, double *y, const halo_dev &H);
+int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const void *x, void *y, const halo_dev &H);
 }
 namespace vexhip {
 namespace {
@@ -168,7 +168,7 @@ int nccl_type(int dtype, ncclDataType_t *t) {
 // flag lives in pinned host memory, and vexhip_dist_spmv_apply / _profile fail from then on.
 inline unsigned long long spin_ticks() {
     static const unsigned long long t = [] {
-        const char *e = std::getenv("VEXHIP_IPC_TIMEOUT_MS");
+        const char *e = env(ENV_VEXHIP_IPC_TIMEOUT_MS);
         const long long ms = e ? std::atoll(e) : 20000;
         return (unsigned long long)(ms > 0 ? ms : 20000) * 100000ull;
     }();
@@ -204,7 +204,7 @@ struct push_peer {
 // the local part that runs beside it; at the 1/8 strip of the 512^3 problem (2 x 262 144 ghosts, tools/r04_dist_step.py) 2048 /
 // 16384 / 65536 / 262144 elements per block give 110 / 95 / 202 / 647 us per step (local + remote part alone: 64 us).
 inline int push_per_block() {
-    static const int v = [] { const char *e = std::getenv("VEXHIP_IPC_PUSH_PER_BLOCK"); int k = e ? std::atoi(e) : 16384; k = k < 256 ? 256 : k; return k / 256 * 256; }();
+    static const int v = [] { const char *e = env(ENV_VEXHIP_IPC_PUSH_PER_BLOCK); int k = e ? std::atoi(e) : 16384; k = k < 256 ? 256 : k; return k / 256 * 256; }();
     return v;
 }
 
@@ -338,7 +338,7 @@ int exchange_one(comm *c, int slot, int dtype, const void *send, const int64_t *
     int64_t so = 0, ro = 0;
     for (int peer = 0; peer < c->world; ++peer) {
         const int64_t ns = scount[peer], nr = rcount[peer];
-        static const bool self_over_rccl = std::getenv("VEXHIP_RCCL_SELF") != nullptr;      // tests: force ncclSend/ncclRecv to self
+        static const bool self_over_rccl = env(ENV_VEXHIP_RCCL_SELF) != nullptr;      // tests: force ncclSend/ncclRecv to self
         // send_first: `send` is the vector itself and this peer's share starts at element send_first[peer] (no packed buffer)
         const char *src = static_cast<const char *>(send) + (send_first ? send_first[peer] : so) * (int64_t)b;
         if (peer == me && ns == nr && ns > 0 && !self_over_rccl) {
@@ -422,7 +422,7 @@ int issue_step_halo(dist_spmv *D, hipStream_t s, double alpha, int append, const
         return fail(__FILE__, __LINE__, "an earlier product of this plan timed out waiting for a peer's ghost flag (IPC transport, VEXHIP_IPC_TIMEOUT_MS): "
                                         "its result and every later one are invalid");
     PROF(0, s); PROF(4, s); PROF(5, s); PROF(6, s);
-    if (int rc = spmat_apply_halo(D->ext, s, alpha, append, static_cast<const double *>(x), static_cast<double *>(y), D->hd)) return rc;
+    if (int rc = spmat_apply_halo(D->ext, s, alpha, append, x, y, D->hd)) return rc;
     PROF(1, s); PROF(2, s); PROF(3, s);
     return 0;
 }
@@ -520,6 +520,7 @@ int vexhip_comm_unique_id(void *id128) {
 }
 
 int vexhip_comm_init(int ndev, const int *devs, int transport, vexhip_comm **out) {
+    reload_env();
     VEXHIP_REQUIRE(out && ndev >= 1 && devs, "bad argument");
     VEXHIP_REQUIRE(transport >= VEXHIP_COMM_AUTO && transport <= VEXHIP_COMM_PEER, "unknown transport");
     *out = nullptr;
@@ -531,7 +532,7 @@ int vexhip_comm_init(int ndev, const int *devs, int transport, vexhip_comm **out
     for (int d = 0; d < ndev; ++d) c->ranks[d] = d;
     // RCCL needs one GPU per rank; one device, or logical devices that share a GPU, exchange by copies
     bool want_rccl = transport == VEXHIP_COMM_RCCL || (transport == VEXHIP_COMM_AUTO && ndev > 1 && distinct(c->devs));
-    if (transport == VEXHIP_COMM_AUTO && std::getenv("VEXHIP_COMM_PEER")) want_rccl = false;
+    if (transport == VEXHIP_COMM_AUTO && env(ENV_VEXHIP_COMM_PEER)) want_rccl = false;
     if (want_rccl) {
         if (!rccl().error.empty()) {
             if (transport == VEXHIP_COMM_RCCL) { delete c; return fail(__FILE__, __LINE__, rccl().error); }
@@ -560,6 +561,7 @@ int vexhip_comm_init(int ndev, const int *devs, int transport, vexhip_comm **out
 }
 
 int vexhip_comm_init_rank(int dev, int rank, int world, const void *id128, vexhip_comm **out) {
+    reload_env();
     VEXHIP_REQUIRE(out && id128 && world >= 1 && rank >= 0 && rank < world, "bad argument");
     *out = nullptr;
     RCCL_READY();
@@ -710,6 +712,7 @@ int vexhip_dist_spmv_create(vexhip_comm *hc, int dtype, int64_t rows, const vexh
         int64_t nsend, const int32_t *send_idx, void *send_buf, const int64_t *send_counts,
         int64_t nghost, void *ghost_buf, const int64_t *recv_counts, vexhip_dist_spmv **out)
 {
+    reload_env();
     comm *c = reinterpret_cast<comm *>(hc);
     VEXHIP_REQUIRE(out, "NULL output");
     *out = nullptr;
@@ -741,7 +744,7 @@ int vexhip_dist_spmv_create(vexhip_comm *hc, int dtype, int64_t rows, const vexh
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->packed, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->received, hipEventDisableTiming);
-    if (e == hipSuccess && nsend > 0 && !std::getenv("VEXHIP_DIST_PACK")) e = detect_runs(D, send_idx, c->world);
+    if (e == hipSuccess && nsend > 0 && !env(ENV_VEXHIP_DIST_PACK)) e = detect_runs(D, send_idx, c->world);
     if (e != hipSuccess) { vexhip_dist_spmv_destroy(reinterpret_cast<vexhip_dist_spmv *>(D)); return check(e, __FILE__, __LINE__); }
     *out = reinterpret_cast<vexhip_dist_spmv *>(D);
     return 0;
@@ -836,6 +839,7 @@ static int dist_spmv_apply_impl(dist_spmv *D, void *stream, double alpha, int ap
 
 // ---- IPC windows + the product step over them --------------------------------------------------------------------
 int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, vexhip_ipc_window **out) {
+    reload_env();
     VEXHIP_REQUIRE(out && world >= 1 && rank >= 0 && rank < world && data_bytes >= 0, "bad argument");
     *out = nullptr;
     VEXHIP_SET_DEVICE(dev);
@@ -848,7 +852,7 @@ int vexhip_ipc_window_create(int dev, int rank, int world, int64_t data_bytes, v
     // (VEXHIP_IPC_WINDOW_MEM=finegrained | default: diagnostics on ONE device only -- tools/r05_dist_step.py measures what the
     //  uncached mapping costs the reader; between two devices only the uncached window is known to show a peer's writes)
     unsigned kind = hipDeviceMallocUncached;
-    if (const char *m = std::getenv("VEXHIP_IPC_WINDOW_MEM")) {
+    if (const char *m = env(ENV_VEXHIP_IPC_WINDOW_MEM)) {
         if (std::string(m) == "finegrained") kind = hipDeviceMallocFinegrained;
         else if (std::string(m) == "default") kind = hipDeviceMallocDefault;
     }
@@ -935,6 +939,7 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
         int64_t nsend, const int32_t *send_idx, const int64_t *send_counts, const int64_t *dst_offsets,
         int64_t nghost, const int64_t *recv_counts, vexhip_dist_spmv **out)
 {
+    reload_env();
     ipc_window *w = reinterpret_cast<ipc_window *>(hw);
     VEXHIP_REQUIRE(out, "NULL output");
     *out = nullptr;
@@ -968,7 +973,7 @@ int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *hw, int dtype, int64_t rows, 
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->packed, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&D->pushed, hipEventDisableTiming);
-    if (e == hipSuccess && nsend > 0 && !std::getenv("VEXHIP_DIST_PACK")) e = detect_runs(D, send_idx, w->world);
+    if (e == hipSuccess && nsend > 0 && !env(ENV_VEXHIP_DIST_PACK)) e = detect_runs(D, send_idx, w->world);
     if (e != hipSuccess) return bail(check(e, __FILE__, __LINE__));
     // the push plan: one entry per destination with a share, blocks of kPushPerBlock elements
     std::vector<push_peer> plan;
@@ -1046,6 +1051,7 @@ int vexhip_dist_spmv_create_halo_pull(vexhip_ipc_window *hw, const vexhip_spmat 
 
 static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper, int pull, vexhip_dist_spmv **out)
 {
+    reload_env();
     VEXHIP_REQUIRE(out, "NULL output");
     *out = nullptr;
     VEXHIP_REQUIRE((w || pull == 2) && ext, "NULL argument");
@@ -1053,18 +1059,18 @@ static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows
     const int world = w ? w->world : (1 << 30);
     VEXHIP_REQUIRE(lower >= -1 && lower < world && upper >= -1 && upper < world, "bad neighbour");
     VEXHIP_REQUIRE(pull || 2 * halo * 8 <= w->data_bytes, "the window is smaller than two ghost planes");
-    int planes = 0, ny = 0;
-    if (int rc = spmat_halo_geometry(ext, &planes, &ny)) return rc;
+    int planes = 0, ny = 0, nx = 0, vtype = VEXHIP_F64;
+    if (int rc = spmat_halo_geometry(ext, &planes, &ny, &nx, &vtype)) return rc;
     const int has_lo = lower >= 0 ? 1 : 0, has_hi = upper >= 0 ? 1 : 0;
-    VEXHIP_REQUIRE(planes > 0 && (int64_t)ny * 512 == halo && planes == has_lo + rows / halo + has_hi,
-                   "the stored strip is not a plane-product matrix of (lower ghost plane +) the rank's planes (+ upper ghost plane)");
+    VEXHIP_REQUIRE(planes > 0 && (int64_t)ny * nx == halo && planes == has_lo + rows / halo + has_hi && (pull || (nx == 512 && vtype == VEXHIP_F64)),
+                   "the stored strip is not a plane-product matrix (pull: or a grid-product matrix) of (lower ghost plane +) the rank's planes (+ upper ghost plane)");
     VEXHIP_REQUIRE(!w || ((lower < 0 || w->peer[lower]) && (upper < 0 || w->peer[upper])), "a neighbour's window has not been opened (vexhip_ipc_window_open / _attach)");
     int ext_dev = 0;
     if (int rc = spmat_device(ext, &ext_dev)) return rc;
     VEXHIP_REQUIRE(!w || w->dev == ext_dev, "the window and the stored strip live on different devices");
     dist_spmv *D = new (std::nothrow) dist_spmv;
     VEXHIP_REQUIRE(D, "out of host memory");
-    D->win = w; D->dev = ext_dev; D->dtype = VEXHIP_F64; D->rows = rows; D->halo = true; D->ext = ext; D->direct = true;
+    D->win = w; D->dev = ext_dev; D->dtype = vtype; D->rows = rows; D->halo = true; D->ext = ext; D->direct = true;
     D->pull = pull; D->has_lo = has_lo != 0; D->has_hi = has_hi != 0;
     D->nsend = (has_lo + has_hi) * halo; D->nghost = (has_lo + has_hi) * halo;
     if (w) {
@@ -1124,16 +1130,16 @@ static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows
     H.step = w->d_step; H.done = D->d_halo_done; H.err = D->d_err; H.ticks = spin_ticks();
     if (pull) { H.lo = H.hi = nullptr; H.dst_lo = H.dst_hi = nullptr; }       // nothing is copied: lo / hi arrive with every product
     H.push_blocks = 16;
-    if (const char *pb = std::getenv("VEXHIP_HALO_PUSH_BLOCKS")) H.push_blocks = std::max(0, std::min(1024, std::atoi(pb)));       // 0: the product workgroups push (plane.hip)
+    if (const char *pb = env(ENV_VEXHIP_HALO_PUSH_BLOCKS)) H.push_blocks = std::max(0, std::min(1024, std::atoi(pb)));       // 0: the product workgroups push (plane.hip)
     H.halo = (int)halo; H.z0 = has_lo; H.z1 = has_lo + (int)(rows / halo); H.lo_planes = 0; H.hi_planes = 0;
     H.debug = nullptr;
-    if (std::getenv("VEXHIP_HALO_DEBUG")) {                  // diagnostics: 6 words per workgroup of the LAST launch (tools/r05_halo_timeline.py reads them through vexhip_dist_spmv_debug)
+    if (env(ENV_VEXHIP_HALO_DEBUG)) {                  // diagnostics: 6 words per workgroup of the LAST launch (tools/r05_halo_timeline.py reads them through vexhip_dist_spmv_debug)
         if (hipMalloc(reinterpret_cast<void **>(&D->d_halo_debug), 6 * 8 * 4096) == hipSuccess) { (void)hipMemset(D->d_halo_debug, 0, 6 * 8 * 4096); H.debug = D->d_halo_debug; }
     }
     H.lo_two_pass = 0;
-    if (const char *tp = std::getenv("VEXHIP_HALO_TWO_PASS")) H.lo_two_pass = std::atoi(tp) != 0;
+    if (const char *tp = env(ENV_VEXHIP_HALO_TWO_PASS)) H.lo_two_pass = std::atoi(tp) != 0;
     H.acquire = 0;                                           // the ghost planes live in uncached memory (halo.hpp, spin_until)
-    if (const char *aq = std::getenv("VEXHIP_HALO_ACQUIRE")) H.acquire = std::max(0, std::min(2, std::atoi(aq)));
+    if (const char *aq = env(ENV_VEXHIP_HALO_ACQUIRE)) H.acquire = std::max(0, std::min(2, std::atoi(aq)));
     // A window in CACHED memory (VEXHIP_IPC_WINDOW_MEM=finegrained | default: a one-device diagnostic) gets the model-correct form
     // whatever was asked for: the reader invalidates at system scope behind the flag, the writers release at system scope in front of
     // it (H.release, plane.hip) -- the waitcnt-only hand-off rests on stores that go past every cache (advisor, round 5)
@@ -1141,17 +1147,17 @@ static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows
     if (!w->uncached) { H.acquire = 2; H.release = 1; }
     // PULL reads the neighbours' x itself -- ordinary cached memory: behind the flag the workgroup's first lane invalidates what this
     // device may still hold of it (system scope: the planes may lie on another GPU)
-    if (pull && !std::getenv("VEXHIP_HALO_ACQUIRE")) H.acquire = 2;
+    if (pull && !env(ENV_VEXHIP_HALO_ACQUIRE)) H.acquire = 2;
     H.one_launch = 1;
-    if (const char *ol = std::getenv("VEXHIP_HALO_TWO_LAUNCHES")) H.one_launch = std::atoi(ol) ? 0 : 1;      // (A/B: the one-thread kernel behind the launch, round 5)
-    if (std::getenv("VEXHIP_HALO_NO_PUSH")) {
+    if (const char *ol = env(ENV_VEXHIP_HALO_TWO_LAUNCHES)) H.one_launch = std::atoi(ol) ? 0 : 1;      // (A/B: the one-thread kernel behind the launch, round 5)
+    if (env(ENV_VEXHIP_HALO_NO_PUSH)) {
         // diagnostics (tools/r05_dist_step.py): nobody pushes, the flags this rank waits for are raised once and for all -- what the
         // product with ghost planes costs when the exchange costs nothing
         const unsigned long long big = ~0ull >> 2;
         if (H.arrive_lo) (void)hipMemcpy(const_cast<unsigned long long *>(H.arrive_lo), &big, 8, hipMemcpyHostToDevice);
         if (H.arrive_hi) (void)hipMemcpy(const_cast<unsigned long long *>(H.arrive_hi), &big, 8, hipMemcpyHostToDevice);
         H.dst_lo = H.dst_hi = nullptr; H.consumed_lo = H.consumed_hi = nullptr;
-        if (const char *g = std::getenv("VEXHIP_HALO_NO_GHOST")) {          // ... and nobody reads a ghost plane either (wrong numbers: the cost of the chunking alone); 1 both, 2 lower only, 3 upper only
+        if (const char *g = env(ENV_VEXHIP_HALO_NO_GHOST)) {          // ... and nobody reads a ghost plane either (wrong numbers: the cost of the chunking alone); 1 both, 2 lower only, 3 upper only
             const int k = std::atoi(g);
             if (k == 1 || k == 2) H.lo = nullptr;
             if (k == 1 || k == 3) H.hi = nullptr;

@@ -569,11 +569,11 @@ struct plan_t {
         while (L > 1 && L * ((long long)n + 1) > lds_elems<T>() + MAX_LINES) --L;
         if (!(map.in_es == 1 && map.out_es == 1)) {                    // strided passes: tiles of 2048 elements measured best for
             long long cap = 2048;                                      // both types (tools/fft_strided_experiment.py)
-            if (const char *e = getenv("VEXHIP_FFT_STRIDED_ELEMS")) cap = std::max(1, atoi(e));
+            if (const char *e = env(ENV_VEXHIP_FFT_STRIDED_ELEMS)) cap = std::max(1, atoi(e));
             if (cap >= (long long)n) L = std::max<long long>(1, std::min<long long>(L, cap / (long long)n));
         }
         long long row_elems = lds_elems<T>() / 2;                     // contiguous lines: <= 16 KiB per buffer
-        if (const char *e = getenv("VEXHIP_FFT_ROW_ELEMS")) row_elems = std::max(1, atoi(e));      // tuning knob (tools/fft_bench.py)
+        if (const char *e = env(ENV_VEXHIP_FFT_ROW_ELEMS)) row_elems = std::max(1, atoi(e));      // tuning knob (tools/fft_bench.py)
         if (map.in_es == 1 && map.out_es == 1) {
             L = std::max<long long>(1, std::min(L, row_elems / (long long)n));
             L = std::max<long long>(1, std::min(L, (lines + 2047) / 2048));
@@ -585,12 +585,12 @@ struct plan_t {
         int min_radix = s.st.radix[0];
         for (int i = 1; i < s.st.count; ++i) min_radix = std::min(min_radix, s.st.radix[i]);
         long long want = L * ((long long)n / min_radix);
-        if (const char *e = getenv("VEXHIP_FFT_LANES_DIV")) want /= std::max(1, atoi(e));
+        if (const char *e = env(ENV_VEXHIP_FFT_LANES_DIV)) want /= std::max(1, atoi(e));
         s.threads = (int)std::min<long long>(FB, std::max<long long>(kWave, (want + kWave - 1) / kWave * kWave));
         // register-resident stages in place in one LDS buffer: one lane per 8 (16, 32) elements of the tile
         const long long E = L * (long long)n;
         const bool pow2 = (n & (n - 1)) == 0, plain = !map.pre && !map.pre_n && !map.post && !map.post_n;
-        if ((plain || pow2) && !getenv("VEXHIP_FFT_NO_SINGLE")) {
+        if ((plain || pow2) && !env(ENV_VEXHIP_FFT_NO_SINGLE)) {
             for (int ept : {8, 16, 32}) {
                 const long long lanes = ((E + ept - 1) / ept + kWave - 1) / kWave * kWave;
                 const bool allowed = ept == 8 || (ept == 16 && (sizeof(T) == 4 || (pow2 && E > 2048))) || (ept == 32 && sizeof(T) == 4 && pow2);
@@ -624,7 +624,7 @@ struct plan_t {
         // one pass when a useful tile of lines fits LDS: any contiguous row that fits; strided lines need >= 4 per tile
         size_t cap = s == 1 ? (size_t)lds_elems<T>() : (size_t)lds_elems<T>() / 4;
         // a contiguous power-of-two row of twice that length still fits the single-buffer organisation (64 KiB of LDS)
-        if (s == 1 && (w & (w - 1)) == 0 && !getenv("VEXHIP_FFT_NO_SINGLE")) cap = 2 * (size_t)lds_elems<T>();
+        if (s == 1 && (w & (w - 1)) == 0 && !env(ENV_VEXHIP_FFT_NO_SINGLE)) cap = 2 * (size_t)lds_elems<T>();
         if (w <= cap) {
             line_map m{};
             m.in_es = m.out_es = S;
@@ -694,7 +694,7 @@ struct plan_t {
         if (int rc = upload(chirp, chirp_id)) return rc;
         if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), ba)) return rc;
         bb = ba;
-        const bool fused = m <= (size_t)lds_elems<T>() || (m <= 2 * (size_t)lds_elems<T>() && (m & (m - 1)) == 0 && !getenv("VEXHIP_FFT_NO_SINGLE"));
+        const bool fused = m <= (size_t)lds_elems<T>() || (m <= 2 * (size_t)lds_elems<T>() && (m & (m - 1)) == 0 && !env(ENV_VEXHIP_FFT_NO_SINGLE));
         if (!fused)                                // multi-pass convolution transforms alternate between two buffers
             if (int rc = alloc((size_t)rows * m * sizeof(cx<T>), bb)) return rc;
         {   // bhat = FFT_m(b), computed once with a plan of its own
@@ -709,7 +709,7 @@ struct plan_t {
             if (r == B_WORK) VEXHIP_TRY(hipMemcpyAsync(dst, sub.owned[w1 - B_FIRST_OWNED], m * sizeof(cx<T>), hipMemcpyDeviceToDevice, nullptr));
             VEXHIP_TRY(hipDeviceSynchronize());
         }
-        if (m <= (size_t)lds_elems<T>() || (m <= 2 * (size_t)lds_elems<T>() && (m & (m - 1)) == 0 && !getenv("VEXHIP_FFT_NO_SINGLE"))) {
+        if (m <= (size_t)lds_elems<T>() || (m <= 2 * (size_t)lds_elems<T>() && (m & (m - 1)) == 0 && !env(ENV_VEXHIP_FFT_NO_SINGLE))) {
             // two row passes carry all the pointwise work: chirp + zero padding on the way in and the product with
             // FFT(b) on the way out of the forward transform; chirp, 1/m and the cut to n on the way out of the inverse
             const int final_dst = writable(cur) ? cur : a;
@@ -768,7 +768,7 @@ struct plan_t {
                 case step::LINES: {
                     const long long grid = (s.lines + s.lines_per_wg - 1) / s.lines_per_wg;
                     size_t lds = (s.ept ? 1 : 2) * (size_t)s.lines_per_wg * s.pitch * sizeof(cx<T>);
-                    if (const char *e = getenv("VEXHIP_FFT_EXTRA_LDS")) lds += (size_t)atoi(e);       // occupancy experiments
+                    if (const char *e = env(ENV_VEXHIP_FFT_EXTRA_LDS)) lds += (size_t)atoi(e);       // occupancy experiments
                     const bool pow2 = (s.n & (s.n - 1)) == 0;
                     const bool fused = s.map.pre || s.map.pre_n || s.map.post || s.map.post_n;
                     auto kernel = fused ? (pow2 ? (s.ept == 8 ? &fft_lines_kernel<T, false, true, 8> : s.ept == 16 ? &fft_lines_kernel<T, false, true, 16>

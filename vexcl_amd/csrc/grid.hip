@@ -26,6 +26,7 @@
 // The 512-point kernel stays the default where it applies (the headline): same walk, fewer scalar operands.
 // Compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "halo.hpp"
 #include "lanes.hpp"
 #include "grid.hpp"
 
@@ -534,10 +535,15 @@ void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
 // ---- the product ----
 // MAXT: 256 lanes (segments of <= 512 rows, four workgroups per CU) or 512 (segments of <= 1024 rows, two per CU: lines of 513 ..
 // 1024 points stay in one piece -- two 320-row segments of a 640-point line read x 1.87 times, profiles/r04_grid_pmc.json)
-template <bool APPEND, int STORE_AUX, int MAXT>
-__global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 2)
-void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
-        const int *__restrict__ line_class, const unsigned char *__restrict__ table, const double *__restrict__ values, grid_dev gd)
+// HALO (round 6; halo.hpp, the PULL form only): the launch is one device's whole product step.  x and y are addressed in the numbering of
+// the STORED grid, whose plane z0 - 1 / z1 (where the device has a neighbour) is a ghost plane: read from the neighbour's x in place
+// (H.lo / H.hi), behind its "x is final" flag where flags order the launches.  The walks are the plan's; the two that touch a ghost
+// plane are dispatched last and wait before they start.
+template <bool APPEND, int STORE_AUX, int MAXT, bool HALO>
+__device__ __forceinline__
+void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alpha,
+        const int *__restrict__ line_class, const unsigned char *__restrict__ table, const double *__restrict__ values, const grid_dev &gd,
+        const halo_dev &H, [[maybe_unused]] const unsigned long long step)
 {
     constexpr int TY = 2;
     // LDS: the value table and the decoded values of the OTHER class, lane-private ([position * 2 + row][lane]: conflict-free)
@@ -554,11 +560,26 @@ void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, dou
     const int nl = gd.ny - y0 < TY ? gd.ny - y0 : TY;               // lines of the tile inside a plane (odd ny: the last tile has one)
     const int row0 = seg * gd.seg_len;
     const int len = gd.nx - row0 < gd.seg_len ? gd.nx - row0 : gd.seg_len;
-    int z = zc * gd.depth;
-    const int zend = z + gd.depth < gd.nz ? z + gd.depth : gd.nz;
-    if (z >= zend) return;
+    int z, zend_;
+    [[maybe_unused]] bool ghost_bad = false;
+    [[maybe_unused]] __shared__ int s_flag;
+    if constexpr (HALO) {
+        // the walks of the planes [z0, z1), the first and the last of them -- which touch a ghost plane -- dispatched behind the others
+        const int nch = (H.z1 - H.z0 + gd.depth - 1) / gd.depth;
+        const int c = nch > 1 ? (zc + 1) % nch : 0;
+        z = H.z0 + c * gd.depth; zend_ = z + gd.depth < H.z1 ? z + gd.depth : H.z1;
+        if (zc >= nch || z >= zend_) return;
+        ghost_bad = !halo_wait(H, step, H.lo && z == H.z0, H.hi && zend_ == H.z1, &s_flag);
+    } else {
+        z = zc * gd.depth;
+        zend_ = z + gd.depth < gd.nz ? z + gd.depth : gd.nz;
+        if (z >= zend_) return;
+    }
+    const int zend = zend_;
     const int nx = gd.nx, ny = gd.ny;
-    const long long lines = gd.lines, x_last = gd.x_last, n = gd.n;
+    // HALO: the elements of x and y that exist are those of the planes [z0, z1)
+    const long long own_lo = HALO ? (long long)H.z0 * ny * nx : 0;
+    const long long lines = HALO ? (long long)H.z1 * ny : gd.lines, x_last = HALO ? (long long)H.z1 * ny * nx - 1 : gd.x_last, n = HALO ? (long long)H.z1 * ny * nx : gd.n;
     const unsigned lane_b = 16u * (unsigned)t;
     const bool full = 2 * t + 1 < len, half = 2 * t + 1 == len;       // the lane stores a pair / its first row only / nothing
     // the element beyond either end of the wave's 128 rows of a segment: lane 63 reads the one behind them, every other lane the
@@ -603,7 +624,16 @@ void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, dou
     // clamped requests (prologue, slow steps): line `l` of the tile's window (0 = the line above the tile, 1 .. TY = the tile,
     // TY + 1 = the line below) in plane zz, element by element.  What lies outside x is never referenced by an entry; what is
     // loaded in its place is multiplied by +0.0 behind a mask
-    auto elem = [&](long long i) -> double { i = i < 0 ? 0 : i; i = i > x_last ? x_last : i; return x[i]; };
+    auto elem = [&](long long i) -> double {
+        if constexpr (HALO) {
+            // an element of the plane below / above the device's planes: the neighbour's boundary plane of x, where it lies
+            const long long plane = (long long)ny * nx;
+            if (i < own_lo) { const long long j = i - (own_lo - plane); if (H.lo && j >= 0) return ghost_bad ? __builtin_nan("") : H.lo[j]; }
+            else if (i > x_last) { const long long j = i - (x_last + 1); if (H.hi && j < plane) return ghost_bad ? __builtin_nan("") : H.hi[j]; }
+            i = i < own_lo ? own_lo : i;
+        }
+        i = i < 0 ? 0 : i; i = i > x_last ? x_last : i; return x[i];
+    };
     auto ld = [&](int zz, int l) -> d2 {
         const long long i = ((long long)zz * ny + (y0 - 1 + l)) * nx + row0 + 2 * t;
         d2 r; r.x = elem(i); r.y = elem(i + 1);
@@ -614,7 +644,7 @@ void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, dou
     };
     auto yold = [&](int zz, int l) -> d2 {
         long long i = ((long long)zz * ny + (y0 + l)) * nx + row0 + 2 * t, j = i + 1;
-        i = i < 0 ? 0 : i; i = i > n - 1 ? n - 1 : i; j = j < 0 ? 0 : j; j = j > n - 1 ? n - 1 : j;
+        i = i < own_lo ? own_lo : i; i = i > n - 1 ? n - 1 : i; j = j < own_lo ? own_lo : j; j = j > n - 1 ? n - 1 : j;
         d2 r; r.x = y[i]; r.y = y[j];
         return r;
     };
@@ -765,6 +795,21 @@ void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, dou
 #undef GRID_OTHER_SUMS
 }
 
+template <bool APPEND, int STORE_AUX, int MAXT, bool HALO = false>
+__global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 2)
+void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
+        const int *__restrict__ line_class, const unsigned char *__restrict__ table, const double *__restrict__ values, grid_dev gd, halo_dev H)
+{
+    if constexpr (!HALO) {
+        grid_walk<APPEND, STORE_AUX, MAXT, false>(x, y, alpha, line_class, table, values, gd, H, 0ull);
+    } else {
+        const unsigned long long step = *H.step;
+        halo_announce(H, step);
+        grid_walk<APPEND, STORE_AUX, MAXT, true>(x, y, alpha, line_class, table, values, gd, H, step);
+        halo_finish(H, step);
+    }
+}
+
 
 // segments of <= 512 rows (even), lanes for one segment, bytes per position row of a class table, planes per workgroup
 struct grid_geometry { long long segs, seg_len, pitch, depth; int threads; };
@@ -783,7 +828,7 @@ bool grid_geometry_with(long long cus, long long nx, long long ny, long long nz,
     //  but only because one segment was given ONE walk per tile; with the walks chosen below it takes 0.874 / 1.27 ms,
     //  profiles/r05_grid_long_lines.json.  VEXHIP_GRID_SEGMENT = 512 | 1024 overrides.)
     long long max_seg = nx > 512 ? 1024 : 512;
-    if (const char *e = std::getenv("VEXHIP_GRID_SEGMENT")) max_seg = std::atoi(e) == 1024 ? 1024 : 512;
+    if (const char *e = env(ENV_VEXHIP_GRID_SEGMENT)) max_seg = std::atoi(e) == 1024 ? 1024 : 512;
     const long long segs = (nx + max_seg - 1) / max_seg;
     long long seg_len = (nx + segs - 1) / segs; seg_len += seg_len & 1;
     const int threads = (int)std::min<long long>(max_seg / 2, ((seg_len + 1) / 2 + 63) / 64 * 64);
@@ -835,7 +880,7 @@ bool grid_geometry_with(long long cus, long long nx, long long ny, long long nz,
         }
     }
     long long depth = (nz + chunks - 1) / chunks;
-    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_PLANE_DEPTH)) depth = std::max(1, std::atoi(e));
     depth = std::min(depth, nz);
     const long long plane_bytes = ny * nx * 8;
     while ((depth + 4) * plane_bytes >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;
@@ -851,7 +896,7 @@ void grid_fill_plan(vexhip_grid *out, long long nx, long long ny, long long nz, 
     out->segments = (int32_t)geo.segs; out->segment_rows = (int32_t)geo.seg_len; out->threads = geo.threads;
     out->hot_class = hot; out->classes = nclasses; out->pitch = (int32_t)geo.pitch;
     out->store_policy = 1;
-    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
+    if (const char *e = env(ENV_VEXHIP_PLANE_STORE)) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
     out->x_last = x_last;
 }
 
@@ -907,8 +952,8 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     VEXHIP_REQUIRE(out && ndeltas && nvalues && ell_width && x_last_out, "NULL output");
     std::memset(out, 0, sizeof(*out));
     *ndeltas = -1; *nvalues = -1; *ell_width = 0; *x_last_out = -1;
-    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
-    if (std::getenv("VEXHIP_NO_GRID") || std::getenv("VEXHIP_NO_GRID_BUILD")) return 0;
+    const bool force = env(ENV_VEXHIP_PLANE_FORCE) != nullptr;          // tests: small grids
+    if (env(ENV_VEXHIP_NO_GRID) || env(ENV_VEXHIP_NO_GRID_BUILD)) return 0;
     // small matrices (x within the L2s / the Infinity Cache) keep the pair product of the SELL-512 storage
     if (!ptr || !col || !val || !deltas || !values || rows < 64 || (rows < (1 << 23) && !force) || rows >= (1ll << 31)) return 0;
     VEXHIP_SET_DEVICE(dev);
@@ -960,7 +1005,7 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     const size_t lds = GB_VSLOTS * 8 + GB_VSLOTS + 520 * 8 + GB_CAP * 4 + GB_CAP + ((7 * (size_t)geo.pitch + 15) / 16) * 16 + 16 * 8;
     const long long cus = std::max(1, info(dev).cus);
     long long per_cu = std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)(lds + 2048)));
-    if (const char *e = std::getenv("VEXHIP_GRID_BUILD_WGS")) per_cu = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_GRID_BUILD_WGS)) per_cu = std::max(1, std::atoi(e));
     const unsigned wgs = (unsigned)std::min<long long>(lines, cus * per_cu);
     grid_build_kernel<P, V><<<wgs, 256, lds, s>>>(ptr, col, val, g);
     VEXHIP_LAUNCH_CHECK();
@@ -971,7 +1016,7 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     const unsigned long long *h_vkeys = reinterpret_cast<const unsigned long long *>(ctl.data()) + GB_KEYS;
     const int *h_ids = reinterpret_cast<const int *>(h_vkeys + GB_VSLOTS);
     const int *h_vstate = h_ids + GB_KEYS, *h_vcodes = h_vstate + GB_VSLOTS, *h_ints = h_vcodes + GB_VSLOTS;
-    if (std::getenv("VEXHIP_DEBUG"))
+    if (env(ENV_VEXHIP_DEBUG))
         std::fprintf(stderr, "grid build: nx %lld ny %lld lines %lld classes %d values %d flags %d positions %#x max column %d widest row %d\n",
                      nx, ny, lines, h_ints[GBI_COUNT], h_ints[GBI_VCOUNT], h_ints[GBI_FLAGS], h_ints[GBI_POSMASK], h_ints[GBI_MAXCOL], h_ints[GBI_MAXLEN]);
     const int nclasses = h_ints[GBI_COUNT], nv = h_ints[GBI_VCOUNT];
@@ -1026,14 +1071,15 @@ using namespace vexhip;
 
 extern "C" {
 
-#define GP_DECLINE(k) do { if (std::getenv("VEXHIP_DEBUG")) std::fprintf(stderr, "grid plan from the SELL-512 storage: declined at check %d (grid.hip:%d)\n", (k), __LINE__); return 0; } while (0)
+#define GP_DECLINE(k) do { if (env(ENV_VEXHIP_DEBUG)) std::fprintf(stderr, "grid plan from the SELL-512 storage: declined at check %d (grid.hip:%d)\n", (k), __LINE__); return 0; } while (0)
 int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const void *codes, const int32_t *blocks,
         int64_t ell_width, int64_t rows, int64_t tail_nnz, int value_bytes, int64_t x_last, vexhip_grid *out)
 {
+    reload_env();
     VEXHIP_REQUIRE(out, "NULL output");
     std::memset(out, 0, sizeof(*out));
-    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids
-    if (std::getenv("VEXHIP_NO_GRID")) GP_DECLINE(1);
+    const bool force = env(ENV_VEXHIP_PLANE_FORCE) != nullptr;          // tests: small grids
+    if (env(ENV_VEXHIP_NO_GRID)) GP_DECLINE(1);
     if ((value_bytes != 8 && value_bytes != 4) || !deltas || !codes || ndeltas < 4 || ndeltas > 7) GP_DECLINE(2);
     // small matrices (x within the L2s / the Infinity Cache: 127^3 = 0.019 ms here, 0.016 ms through the pair product; 168^3 0.029 /
     // 0.026; 256^3 0.052 / 0.074) keep the pair product
@@ -1128,6 +1174,7 @@ int vexhip_sell8_grid_geometry(int cus, int64_t nx, int64_t lines_per_plane, int
 {
     VEXHIP_REQUIRE(out, "NULL output");
     std::memset(out, 0, sizeof(*out));
+    reload_env();
     VEXHIP_REQUIRE(nx >= 8 && nx < (1ll << 30) && lines_per_plane >= 2 && lines_per_plane < (1ll << 30) && planes >= 1 && planes < (1ll << 30), "bad grid");
     grid_geometry geo;
     if (!grid_geometry_with(cus, nx, lines_per_plane, planes, &geo)) return 0;          // depth = 0: no geometry (a plane too large for 32-bit offsets)
@@ -1165,8 +1212,9 @@ int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, 
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const unsigned char *tb = static_cast<const unsigned char *>(g->table);
     hipStream_t s = as_stream(stream);
-#define GRID_LAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd); \
-                               else sell8_grid_kernel<AP, AUX, 256><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd); }
+    const halo_dev none = halo_dev();
+#define GRID_LAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd, none); \
+                               else sell8_grid_kernel<AP, AUX, 256><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd, none); }
 #define GRID_AUX(AP) switch (g->store_policy) { case 1: GRID_LAUNCH(AP, 18); break; case 2: GRID_LAUNCH(AP, 17); break; case 3: GRID_LAUNCH(AP, 0); break; default: GRID_LAUNCH(AP, 2); }
     if (append) { GRID_AUX(true) } else { GRID_AUX(false) }
 #undef GRID_AUX
@@ -1176,5 +1224,45 @@ int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, 
 }
 
 } // extern "C"
+
+namespace vexhip {
+// One device's product step in one launch on a matrix stored by grid line with lines of ANY length (halo.hpp, the pull form): the
+// grid product over the planes [H.z0, H.z1) of the stored grid of n_ext rows; x and y are the device's own segments.
+int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
+        const vexhip_grid *g, halo_dev H)
+{
+    VEXHIP_REQUIRE(g && g->usable && g->line_class && g->table && values && x && y, "bad grid product arguments");
+    if (int rc = vexhip_sell8_grid_check(g, n_ext)) return rc;
+    VEXHIP_REQUIRE(H.pull && H.z0 >= 0 && H.z1 > H.z0 && H.z1 <= g->planes && H.step && H.done && H.err, "bad halo step");
+    VEXHIP_REQUIRE((long long)H.halo == (long long)g->lines_per_plane * g->nx, "the ghost planes must be planes of the stored grid");
+    VEXHIP_REQUIRE((!H.lo || H.z0 >= 1) && (!H.hi || H.z1 < g->planes), "a ghost plane outside the stored grid");
+    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "grid product: x and y must be 8-byte aligned");
+    VEXHIP_SET_DEVICE(dev);
+    grid_dev gd;
+    gd.lines = n_ext / g->nx; gd.x_last = g->x_last; gd.n = n_ext;
+    gd.nx = g->nx; gd.ny = g->lines_per_plane; gd.nz = g->planes; gd.depth = g->depth;
+    gd.segs = g->segments; gd.seg_len = g->segment_rows;
+    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch;
+    // the walks are the plan's (chosen for the balance of the CUs, grid_geometry_with: shorter ones cost more than the wait they would
+    // save -- a strip of 640^3 / 8 in walks of 20 planes took 170 us against 125 us in the plan's, profiles/r06_dist_step_f64_640_first.json)
+    const int nzr = H.z1 - H.z0;
+    gd.depth = std::min(gd.depth, nzr);
+    const long long chunks = (nzr + gd.depth - 1) / gd.depth;
+    const long long grid = 8ll * gd.tpx * chunks;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    const long long plane = (long long)gd.ny * gd.nx;
+    const double *xe = x - (long long)H.z0 * plane;            // the kernel addresses x and y in the numbering of the stored grid
+    double *ye = y - (long long)H.z0 * plane;
+    const unsigned char *tb = static_cast<const unsigned char *>(g->table);
+#define GRID_HLAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512, true><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(xe, ye, alpha, g->line_class, tb, values, gd, H); \
+                                else sell8_grid_kernel<AP, AUX, 256, true><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(xe, ye, alpha, g->line_class, tb, values, gd, H); }
+#define GRID_HAUX(AP) switch (g->store_policy) { case 1: GRID_HLAUNCH(AP, 18); break; case 2: GRID_HLAUNCH(AP, 17); break; case 3: GRID_HLAUNCH(AP, 0); break; default: GRID_HLAUNCH(AP, 2); }
+    if (append) { GRID_HAUX(true) } else { GRID_HAUX(false) }
+#undef GRID_HAUX
+#undef GRID_HLAUNCH
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+} // namespace vexhip
 
 VEXHIP_WARM_TU(grid)

@@ -306,7 +306,7 @@ int vexhip_spmv_sell8v_grid_f32(int dev, void *stream, int64_t n, float alpha, i
         }
         gd.depth = (int)((gd.nz + chunks - 1) / chunks);
     }
-    if (const char *e = std::getenv("VEXHIP_GRID32_DEPTH")) if (std::atoi(e) > 0) gd.depth = std::min(std::atoi(e), (int)gd.nz);
+    if (const char *e = env(ENV_VEXHIP_GRID32_DEPTH)) if (std::atoi(e) > 0) gd.depth = std::min(std::atoi(e), (int)gd.nz);
     VEXHIP_REQUIRE(((long long)gd.depth + 4) * gd.ny * gd.nx * 4 < (1ll << 32), "bad grid plan");
     const long long chunks = (gd.nz + gd.depth - 1) / gd.depth;
     const long long grid = 8ll * gd.tpx * chunks;

@@ -78,4 +78,57 @@ __device__ inline bool spin_until(const unsigned long long *flag, unsigned long 
     return true;
 }
 
+// PULL, order flags: the launch's first workgroup tells the neighbours that this rank's x is final (stream order: its writers were
+// earlier KERNELS, whose end wrote the caches back).  A RELAXED store: nothing of THIS launch is published, and a release fence here
+// writes back an L2 that the launch's other workgroups keep filling with y -- the flag left 65 us late (profiles/r06_dist_step_first.json:
+// 117 us a step against 49 without flags); H.release asks for the fence anyway.
+__device__ inline void halo_announce(const halo_dev &H, unsigned long long step) {
+    if (H.pull == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (H.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (H.peer_arrive_lo) __hip_atomic_store(H.peer_arrive_lo, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (H.peer_arrive_hi) __hip_atomic_store(H.peer_arrive_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// What used to be a second launch (halo_signal_kernel, round 5) is done by the workgroup that finishes LAST: every workgroup's reads of the
+// ghost planes have returned before it is counted (s_waitcnt + barrier; a relaxed count: an agent-scope release here would write back an
+// L2 full of this launch's y, once per workgroup), so the last one may tell the owners that their planes have been read, wait -- PULL: the
+// planes are the owners' x itself -- until the neighbours say the same of this rank's, and advance the step number.  The next launch
+// of the stream starts behind this one: it reads the new number.  Called by EVERY workgroup of the launch, idle ones included.
+__device__ inline void halo_finish(const halo_dev &H, unsigned long long step) {
+    if (!H.one_launch) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(H.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == gridDim.x) {
+            __hip_atomic_store(H.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (H.consumed_lo) __hip_atomic_store(H.consumed_lo, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (H.consumed_hi) __hip_atomic_store(H.consumed_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (H.pull == 1) {
+                if (H.sent_lo) (void)spin_until(H.sent_lo, step, H.err, H.ticks, 0);
+                if (H.sent_hi) (void)spin_until(H.sent_hi, step, H.err, H.ticks, 0);
+            }
+            *H.step = step + 1ull;
+        }
+    }
+}
+
+// A workgroup that will read a ghost plane waits here, once, before its walk (the walks of grid.hip / plane32.hip / grid32.hip that
+// touch a ghost plane are short and dispatched last; plane.hip waits when the walk first needs a ghost line).  false: the owner's flag
+// did not come (the sticky error is set; the caller fills its ghost values with NaN).  flag: one LDS word of the caller.
+__device__ inline bool halo_wait(const halo_dev &H, unsigned long long step, bool need_lo, bool need_hi, int *flag) {
+    if (H.pull == 2 || !(need_lo || need_hi)) return true;         // (uniform)
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        if (need_lo) ok = spin_until(H.arrive_lo, step, H.err, H.ticks, H.acquire) && ok;
+        if (need_hi) ok = spin_until(H.arrive_hi, step, H.err, H.ticks, H.acquire) && ok;
+        *flag = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
+}
+
 } // namespace vexhip

@@ -64,15 +64,7 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
     if constexpr (HALO) {
         if (H.debug) dbg_t0 = wall_clock64();
         step = step_in;
-        if (H.pull == 1 && b == 0 && t == 0) {
-            // PULL: this rank's x is final (stream order: its writers were earlier KERNELS, whose end wrote the caches back) -- tell the
-            // neighbours, who read its boundary planes in place.  A RELAXED store: nothing of THIS launch is published, and a release
-            // fence here writes back an L2 that the launch's other workgroups keep filling with y -- the flag left 65 us late
-            // (profiles/r06_dist_step_first.json: 117 us a step against 49 without flags); H.release asks for the fence anyway.
-            if (H.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            if (H.peer_arrive_lo) __hip_atomic_store(H.peer_arrive_lo, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (H.peer_arrive_hi) __hip_atomic_store(H.peer_arrive_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        halo_announce(H, step);
         const unsigned npush = H.pull ? 0u : (H.dst_lo ? (unsigned)H.push_blocks : 0u) + (H.dst_hi ? (unsigned)H.push_blocks : 0u);
         if (b < npush) {
             // ---- copy one of the rank's boundary planes into the neighbour's window (16-byte pieces), raise `arrive` there ----
@@ -473,28 +465,7 @@ void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, do
     } else {
         const unsigned long long step = *H.step;
         plane_walk<TY, APPEND, STORE_AUX, true>(x, y, alpha, blocks, pool, deltas, values, pd, H, step);
-        // ---- round 6: what used to be a second launch (halo_signal_kernel) is done by the workgroup that finishes LAST: every
-        // workgroup's reads of the ghost planes have returned before it is counted (s_waitcnt + barrier; a relaxed count: an agent-scope
-        // release here would write back an L2 full of this launch's y, 768 times), so the last one may tell the owners that their
-        // planes have been read, wait -- PULL: the planes are the owners' x itself -- until the neighbours say the same of this rank's,
-        // and advance the step number.  The next launch of the stream starts behind this one: it reads the new number.
-        if (H.one_launch) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const unsigned old = __hip_atomic_fetch_add(H.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old + 1u == gridDim.x) {
-                    __hip_atomic_store(H.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (H.consumed_lo) __hip_atomic_store(H.consumed_lo, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (H.consumed_hi) __hip_atomic_store(H.consumed_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (H.pull == 1) {
-                        if (H.sent_lo) (void)spin_until(H.sent_lo, step, H.err, H.ticks, 0);
-                        if (H.sent_hi) (void)spin_until(H.sent_hi, step, H.err, H.ticks, 0);
-                    }
-                    *H.step = step + 1ull;
-                }
-            }
-        }
+        halo_finish(H, step);          // the launch's last workgroup raises `consumed` and advances the step number (halo.hpp)
     }
 }
 
@@ -567,9 +538,9 @@ static bool plane_geometry_with(long long cus, long long ny, long long nz, int h
         return (nz + chunks - 1) / chunks;
     };
     long long tile = 2;
-    if (const char *e = std::getenv("VEXHIP_PLANE_TILE")) tile = (std::atoi(e) == 4 && ny % 4 == 0) ? 4 : 2;
+    if (const char *e = env(ENV_VEXHIP_PLANE_TILE)) tile = (std::atoi(e) == 4 && ny % 4 == 0) ? 4 : 2;
     long long depth = depth_for(tile);
-    if (const char *e = std::getenv("VEXHIP_PLANE_DEPTH")) depth = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_PLANE_DEPTH)) depth = std::max(1, std::atoi(e));
     depth = std::min(depth, nz);
     while ((depth + 4) * ny * 4096 >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;      // 32-bit byte offsets inside a workgroup's walk
     if ((depth + 4) * ny * 4096 >= (1ll << 32)) return false;
@@ -578,7 +549,7 @@ static bool plane_geometry_with(long long cus, long long ny, long long nz, int h
     // more of it is left for the halo lines of x), 3 = plain.  Same sweeps, tile 4 x 256: 0.395 / 0.393 / 0.384 / 0.387 ms;
     // tile 2 x 512: 0.395 / 0.391 / 0.396 / 0.401.  VEXHIP_PLANE_STORE overrides.
     out->store_policy = tile == 4 ? 2 : 1;
-    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
+    if (const char *e = env(ENV_VEXHIP_PLANE_STORE)) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
     return true;
 }
 
@@ -590,7 +561,7 @@ int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_
 {
     VEXHIP_REQUIRE(grid && out, "NULL argument");
     std::memset(out, 0, sizeof(*out));
-    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;
+    const bool force = env(ENV_VEXHIP_PLANE_FORCE) != nullptr;
     if (!grid->usable || grid->nx != PL_ROWS || grid->segments != 1 || rows % PL_ROWS != 0) return 0;
     const long long ny = grid->lines_per_plane, nz = grid->planes;
     if (ny < 4 || ny % 2 != 0 || (nz < 4 && !force) || (rows / PL_ROWS < 64 && !force)) return 0;
@@ -625,15 +596,15 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
     pd.pitch = plane->table_pitch;
     const int nzr = H.z1 - H.z0;
     int edge_planes = 8;
-    if (const char *e = std::getenv("VEXHIP_HALO_EDGE_PLANES")) edge_planes = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_HALO_EDGE_PLANES)) edge_planes = std::max(1, std::atoi(e));
     int lo_planes = edge_planes, hi_planes = edge_planes;
-    if (const char *e = std::getenv("VEXHIP_HALO_LO_PLANES")) lo_planes = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("VEXHIP_HALO_HI_PLANES")) hi_planes = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_HALO_LO_PLANES)) lo_planes = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_HALO_HI_PLANES)) hi_planes = std::max(1, std::atoi(e));
     H.lo_planes = H.lo ? std::min(lo_planes, nzr) : 0;
     H.hi_planes = H.hi ? std::min(hi_planes, nzr - H.lo_planes) : 0;
     const int mid = nzr - H.lo_planes - H.hi_planes;
     pd.depth = std::max(1, mid);          // ONE main chunk (two of 25 planes beside the short chunks: 88-90 us against 76 for the step)
-    if (const char *e = std::getenv("VEXHIP_HALO_DEPTH")) pd.depth = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_HALO_DEPTH)) pd.depth = std::max(1, std::atoi(e));
     const long long chunks = (H.lo_planes ? 1 : 0) + (H.hi_planes ? 1 : 0) + (mid + pd.depth - 1) / pd.depth;
     const long long npush = H.pull ? 0 : (H.dst_lo ? H.push_blocks : 0) + (H.dst_hi ? H.push_blocks : 0);
     const long long grid = npush + 8ll * pd.tpx * chunks;
@@ -660,6 +631,7 @@ int vexhip_sell8_plane_geometry(int cus, int64_t lines_per_plane, int64_t planes
 {
     VEXHIP_REQUIRE(out, "NULL output");
     std::memset(out, 0, sizeof(*out));
+    reload_env();
     VEXHIP_REQUIRE(lines_per_plane >= 4 && lines_per_plane % 2 == 0 && lines_per_plane < (1ll << 30) && planes >= 1 && planes < (1ll << 30), "bad grid");
     if (!plane_geometry_with(cus, lines_per_plane, planes, 0, out)) { std::memset(out, 0, sizeof(*out)); return 0; }      // depth = 0: no geometry
     return 0;
@@ -671,7 +643,8 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
 {
     VEXHIP_REQUIRE(out, "NULL output");
     std::memset(out, 0, sizeof(*out));
-    const bool force = std::getenv("VEXHIP_PLANE_FORCE") != nullptr;          // tests: small grids, many blocks
+    reload_env();
+    const bool force = env(ENV_VEXHIP_PLANE_FORCE) != nullptr;          // tests: small grids, many blocks
     if ((value_bytes != 8 && value_bytes != 4) || !deltas || !blocks || !pool || ndeltas < 2 || ndeltas > 7 || dictionary_blocks < 1 || dictionary_blocks > 128) return 0;
     if (ell_width < 1 || ell_width > 8 || tail_nnz != 0 || rows != nslices * PL_ROWS || (nslices < 64 && !force)) return 0;
     if (x_last < 0 || (x_last + 1) % PL_ROWS != 0 || x_last + 1 < rows) return 0;

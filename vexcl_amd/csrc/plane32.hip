@@ -10,6 +10,7 @@
 // order, products rounded before they are added, the scale applied to the sum); results bit-identical to the CSR loop
 // (spmat/csr.inl:163-170) in fp32.  Compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "halo.hpp"
 #include "lanes.hpp"
 #include "plane.hpp"
 
@@ -22,11 +23,14 @@ namespace {
 constexpr int P32_LANES = 128;             // lanes of a workgroup: 4 rows each
 constexpr int P32_LINE_B = PL_ROWS * 4;    // bytes of a line
 
-template <bool APPEND, int STORE_AUX>
-__global__ __launch_bounds__(P32_LANES)
-void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, float alpha,
+// HALO (round 6; halo.hpp, the PULL form only): the launch is one device's whole product step, as in grid.hip -- x and y addressed in
+// the numbering of the STORED grid, the plane below z0 / above z1 - 1 read from the neighbour's x in place (H.lo / H.hi point at
+// floats here), the two walks that touch a ghost plane dispatched last.
+template <bool APPEND, int STORE_AUX, bool HALO>
+__device__ __forceinline__
+void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alpha,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const float *__restrict__ values,
-        plane_dev pd)
+        const plane_dev &pd, const halo_dev &H, [[maybe_unused]] const unsigned long long step)
 {
     constexpr int TY = 2;
     // LDS: per diagonal code its position (x 4), the value table, and the decoded values of the OTHER block, lane-private
@@ -42,12 +46,26 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
     const int tile = (int)xcd * pd.tpx + tyl;
     if (tile >= pd.tiles) return;                                   // the whole workgroup
     const int y0 = TY * tile;
-    int z = zc * pd.depth;
-    const int zend = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
-    if (z >= zend) return;
+    int z, zend_;
+    [[maybe_unused]] bool ghost_bad = false;
+    [[maybe_unused]] __shared__ int s_flag;
+    if constexpr (HALO) {
+        const int nch = (H.z1 - H.z0 + pd.depth - 1) / pd.depth;
+        const int c = nch > 1 ? (zc + 1) % nch : 0;               // the first and the last walk touch a ghost plane: dispatched behind the others
+        z = H.z0 + c * pd.depth; zend_ = z + pd.depth < H.z1 ? z + pd.depth : H.z1;
+        if (zc >= nch || z >= zend_) return;
+        ghost_bad = !halo_wait(H, step, H.lo && z == H.z0, H.hi && zend_ == H.z1, &s_flag);
+    } else {
+        z = zc * pd.depth;
+        zend_ = z + pd.depth < pd.nz ? z + pd.depth : pd.nz;
+        if (z >= zend_) return;
+    }
+    const int zend = zend_;
     const int ny = pd.ny;
-    const int nslices = (int)pd.nslices, xlines = (int)pd.xlines;
-    const long long x_last = pd.x_last;
+    // HALO: the lines of x and y that exist are those of the planes [z0, z1)
+    const int line_lo = HALO ? H.z0 * ny : 0;
+    const int nslices = HALO ? H.z1 * ny : (int)pd.nslices, xlines = HALO ? H.z1 * ny : (int)pd.xlines;
+    const long long x_last = HALO ? (long long)H.z1 * ny * PL_ROWS - 1 : pd.x_last;
     const unsigned lane_b = 16u * (unsigned)t;
     // the element beyond either end of the wave's 256 rows of a line: lane 63 reads the one behind them, every other lane the
     // one in front (lane 0 uses it) -- byte offset from the start of the line
@@ -125,21 +143,38 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
     // multiplied by +0.0 behind a mask
     auto line_of = [&](int zz, int l) -> int {
         int li = zz * ny + (y0 - 1 + l);
-        li = li < 0 ? 0 : li; li = li >= xlines ? xlines - 1 : li;
+        li = li < line_lo ? line_lo : li; li = li >= xlines ? xlines - 1 : li;
         return li;
     };
     auto ld = [&](int zz, int l) -> f4 {
+        if constexpr (HALO) {
+            const int li = zz * ny + (y0 - 1 + l);                                   // uniform
+            if (li < line_lo || li >= xlines) {
+                const bool below = li < line_lo;
+                const int gl = below ? li - (line_lo - ny) : li - xlines;            // line of the ghost plane
+                const float *g = reinterpret_cast<const float *>(below ? H.lo : H.hi);
+                f4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (!g || gl < 0 || gl >= ny || l == 0 || l == TY + 1) return r;     // no neighbour there / not the adjacent plane / the line above or below the tile IN a ghost plane: never referenced
+                if (ghost_bad) { r.x = r.y = r.z = r.w = __builtin_nanf(""); return r; }
+                return *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(g + (long long)gl * PL_ROWS) + lane_b);
+            }
+        }
         const char *p = reinterpret_cast<const char *>(x + (long long)line_of(zz, l) * PL_ROWS);
         return *reinterpret_cast<const f4u *>(p + lane_b);
     };
     auto edge = [&](int zz, int l) -> float {
+        if constexpr (HALO) {
+            const int li = zz * ny + (y0 - 1 + l);
+            if (li < line_lo || li >= xlines) return 0.0f;                           // the +-1 neighbours inside a ghost line: no row of this device has them
+        }
         long long i = (long long)line_of(zz, l) * PL_ROWS + (edge_b >> 2);
-        i = i < 0 ? 0 : i; i = i > x_last ? x_last : i;
+        const long long a = (long long)line_lo * PL_ROWS;
+        i = i < a ? a : i; i = i > x_last ? x_last : i;
         return x[i];
     };
     auto yold = [&](int zz, int l) -> f4 {
         int li = zz * ny + (y0 + l);
-        li = li < 0 ? 0 : li; li = li >= nslices ? nslices - 1 : li;
+        li = li < line_lo ? line_lo : li; li = li >= nslices ? nslices - 1 : li;
         return *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(y + (long long)li * PL_ROWS) + lane_b);
     };
 
@@ -275,6 +310,22 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
 #undef P32_OTHER_SUMS
 }
 
+template <bool APPEND, int STORE_AUX, bool HALO = false>
+__global__ __launch_bounds__(P32_LANES)
+void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, float alpha,
+        const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const float *__restrict__ values,
+        plane_dev pd, halo_dev H)
+{
+    if constexpr (!HALO) {
+        plane32_walk<APPEND, STORE_AUX, false>(x, y, alpha, blocks, pool, deltas, values, pd, H, 0ull);
+    } else {
+        const unsigned long long step = *H.step;
+        halo_announce(H, step);
+        plane32_walk<APPEND, STORE_AUX, true>(x, y, alpha, blocks, pool, deltas, values, pd, H, step);
+        halo_finish(H, step);
+    }
+}
+
 } // namespace
 } // namespace vexhip
 
@@ -294,7 +345,7 @@ int64_t vexhip_sell8_plane_f32_depth(int cus, int64_t lines_per_plane, int64_t p
     const long long c = std::max(1, cus), tiles = lines_per_plane / 2;
     const long long chunks = std::max(1ll, std::min<long long>(planes / 8, (12 * c + tiles / 2) / tiles));
     long long depth = (planes + chunks - 1) / chunks;
-    if (const char *e = std::getenv("VEXHIP_PLANE32_DEPTH")) if (std::atoi(e) > 0) depth = std::min<long long>(std::atoi(e), planes);
+    if (const char *e = env(ENV_VEXHIP_PLANE32_DEPTH)) if (std::atoi(e) > 0) depth = std::min<long long>(std::atoi(e), planes);
     while ((depth + 4) * lines_per_plane * P32_LINE_B >= (1ll << 32) && depth > 8) depth = (depth + 1) / 2;
     return (depth + 4) * lines_per_plane * P32_LINE_B < (1ll << 32) ? depth : 0;
 }
@@ -324,8 +375,9 @@ int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alp
     const char *cpool = static_cast<const char *>(pool);
     hipStream_t s = as_stream(stream);
     int store_kind = 1;
-    if (const char *e = std::getenv("VEXHIP_PLANE_STORE")) store_kind = std::max(0, std::min(3, std::atoi(e)));
-#define P32_LAUNCH(AP, AUX) sell8_plane_f32_kernel<AP, AUX><<<(unsigned)grid, P32_LANES, 0, s>>>(x, y, alpha, blocks, cpool, deltas, values, pd)
+    if (const char *e = env(ENV_VEXHIP_PLANE_STORE)) store_kind = std::max(0, std::min(3, std::atoi(e)));
+    const halo_dev none = halo_dev();
+#define P32_LAUNCH(AP, AUX) sell8_plane_f32_kernel<AP, AUX><<<(unsigned)grid, P32_LANES, 0, s>>>(x, y, alpha, blocks, cpool, deltas, values, pd, none)
 #define P32_AUX(AP) switch (store_kind) { case 1: P32_LAUNCH(AP, 18); break; case 2: P32_LAUNCH(AP, 17); break; case 3: P32_LAUNCH(AP, 0); break; default: P32_LAUNCH(AP, 2); }
     if (append) { P32_AUX(true) } else { P32_AUX(false) }
 #undef P32_AUX
@@ -335,5 +387,40 @@ int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alp
 }
 
 } // extern "C"
+
+namespace vexhip {
+// One device's product step in one launch for a float matrix on 512-point lines (halo.hpp, the pull form): the fp32 plane product over
+// the planes [H.z0, H.z1) of the stored grid of n_ext rows; x and y are the device's own segments.
+int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
+        const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane, halo_dev H)
+{
+    VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
+    VEXHIP_REQUIRE(n_ext > 0 && n_ext % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
+    VEXHIP_REQUIRE(plane->lines_per_plane >= 4 && plane->lines_per_plane % 2 == 0 && plane->planes >= 1, "bad plane plan");
+    VEXHIP_REQUIRE(H.pull && H.z0 >= 0 && H.z1 > H.z0 && H.z1 <= plane->planes && H.step && H.done && H.err, "bad halo step");
+    VEXHIP_REQUIRE(H.halo == plane->lines_per_plane * PL_ROWS, "the ghost planes must be planes of the stored grid");
+    VEXHIP_REQUIRE((!H.lo || H.z0 >= 1) && (!H.hi || H.z1 < plane->planes), "a ghost plane outside the stored grid");
+    VEXHIP_SET_DEVICE(dev);
+    plane_dev pd;
+    pd.nslices = n_ext / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
+    pd.ny = plane->lines_per_plane; pd.nz = plane->planes;
+    pd.tiles = pd.ny / 2;
+    const int nzr = H.z1 - H.z0;
+    pd.depth = (int)vexhip_sell8_plane_f32_depth(std::max(1, info(dev).cus), pd.ny, nzr);
+    VEXHIP_REQUIRE(pd.depth > 0, "fp32 plane product: a walk of this grid does not fit 32-bit byte offsets");
+    pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
+    pd.pitch = plane->table_pitch;
+    const long long chunks = (nzr + pd.depth - 1) / pd.depth;
+    const long long grid = 8ll * pd.tpx * chunks;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    const float *xe = x - (long long)H.z0 * pd.far;            // the kernel addresses x and y in the numbering of the stored grid
+    float *ye = y - (long long)H.z0 * pd.far;
+    const char *cpool = static_cast<const char *>(pool);
+    if (append) sell8_plane_f32_kernel<true, 18, true><<<(unsigned)grid, P32_LANES, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
+    else        sell8_plane_f32_kernel<false, 18, true><<<(unsigned)grid, P32_LANES, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+} // namespace vexhip
 
 VEXHIP_WARM_TU(plane32)

@@ -121,13 +121,13 @@ std::string digest(const std::string &s) {
 }
 
 std::string cache_root() {
-    if (const char *e = std::getenv("VEXCL_CACHE_DIR")) return e;
+    if (const char *e = env(ENV_VEXCL_CACHE_DIR)) return e;
     const char *home = std::getenv("HOME");
     return std::string(home ? home : "/tmp") + "/.vexcl_amd";
 }
 
 bool cache_enabled() {
-    const char *e = std::getenv("VEXCL_CACHE_KERNELS");
+    const char *e = env(ENV_VEXCL_CACHE_KERNELS);
     return !(e && e[0] == '0');
 }
 
@@ -169,6 +169,81 @@ int rtc_fail(const char *file, int line, hiprtcResult r, const std::string &log)
 }
 
 } // namespace
+
+// ---------------------------------------------------------------- the environment (common.hpp)
+namespace vexhip {
+namespace {
+const char *const kEnvNames[ENV_COUNT] = {
+    "VEXCL_CACHE_DIR",
+    "VEXCL_CACHE_KERNELS",
+    "VEXCL_SHOW_KERNELS",
+    "VEXCL_SHOW_SCRATCH",
+    "VEXHIP_COMM_PEER",
+    "VEXHIP_DEBUG",
+    "VEXHIP_DIST_PACK",
+    "VEXHIP_FFT_EXTRA_LDS",
+    "VEXHIP_FFT_LANES_DIV",
+    "VEXHIP_FFT_NO_SINGLE",
+    "VEXHIP_FFT_ROW_ELEMS",
+    "VEXHIP_FFT_STRIDED_ELEMS",
+    "VEXHIP_GRID32_DEPTH",
+    "VEXHIP_GRID_BUILD_WGS",
+    "VEXHIP_GRID_SEGMENT",
+    "VEXHIP_HALO_ACQUIRE",
+    "VEXHIP_HALO_DEBUG",
+    "VEXHIP_HALO_DEPTH",
+    "VEXHIP_HALO_EDGE_PLANES",
+    "VEXHIP_HALO_HI_PLANES",
+    "VEXHIP_HALO_LO_PLANES",
+    "VEXHIP_HALO_NO_GHOST",
+    "VEXHIP_HALO_NO_PUSH",
+    "VEXHIP_HALO_PUSH_BLOCKS",
+    "VEXHIP_HALO_TWO_LAUNCHES",
+    "VEXHIP_HALO_TWO_PASS",
+    "VEXHIP_IPC_PUSH_PER_BLOCK",
+    "VEXHIP_IPC_TIMEOUT_MS",
+    "VEXHIP_IPC_WINDOW_MEM",
+    "VEXHIP_MALLOC_STAGGER",
+    "VEXHIP_MARCH_LDS",
+    "VEXHIP_MARCH_RUN",
+    "VEXHIP_NO_GRID",
+    "VEXHIP_NO_GRID_BUILD",
+    "VEXHIP_NO_PLANE512",
+    "VEXHIP_PLANE32_DEPTH",
+    "VEXHIP_PLANE_DEPTH",
+    "VEXHIP_PLANE_FORCE",
+    "VEXHIP_PLANE_STORE",
+    "VEXHIP_PLANE_TILE",
+    "VEXHIP_RCCL_SELF",
+    "VEXHIP_SELL_XLOAD",
+    "VEXHIP_SETUP_TRACE",
+};
+struct env_snapshot { bool set[ENV_COUNT]; char text[ENV_COUNT][96]; };
+env_snapshot g_env;
+std::mutex g_env_mx;
+std::once_flag g_env_once;
+void read_env() {
+    std::lock_guard<std::mutex> lock(g_env_mx);
+    for (int i = 0; i < ENV_COUNT; ++i) {
+        const char *v = std::getenv(kEnvNames[i]);          // THE place where the library reads its switches
+        const bool set = v != nullptr;
+        // entries that did not change are not touched: a reader on another thread never sees a half-written one of those
+        if (set == g_env.set[i] && (!set || std::strncmp(g_env.text[i], v, sizeof(g_env.text[i]) - 1) == 0)) continue;
+        if (set) { std::strncpy(g_env.text[i], v, sizeof(g_env.text[i]) - 1); g_env.text[i][sizeof(g_env.text[i]) - 1] = 0; }
+        g_env.set[i] = set;
+    }
+}
+}
+const char *env(env_id id) {
+    std::call_once(g_env_once, read_env);
+    return g_env.set[id] ? g_env.text[id] : nullptr;
+}
+void reload_env() {
+    std::call_once(g_env_once, read_env);
+    read_env();
+}
+}
+
 
 extern "C" {
 
@@ -280,6 +355,7 @@ int vexhip_event_elapsed_ms(int dev, void *start, void *stop, float *ms) {
     return 0;
 }
 
+
 // ---------------------------------------------------------------- memory
 // Where a large allocation starts (round 6).  The headline product reads x a few planes ahead of where it writes y; its time
 // depends on (y - x) mod 64 MiB and on nothing else of the placement (profiles/r06_xy_gap.json: two sweeps of 257 gaps correlate
@@ -292,7 +368,7 @@ static constexpr size_t kStaggerAlign = size_t(64) << 20, kStaggerStep = size_t(
 
 extern "C" size_t vexhip_malloc_stagger(size_t bytes, unsigned ordinal) {
     if (bytes < kStaggerFrom) return 0;
-    static const bool off = std::getenv("VEXHIP_MALLOC_STAGGER") && std::atoi(std::getenv("VEXHIP_MALLOC_STAGGER")) == 0;
+    static const bool off = env(ENV_VEXHIP_MALLOC_STAGGER) && std::atoi(env(ENV_VEXHIP_MALLOC_STAGGER)) == 0;
     if (off) return 0;
     return (ordinal % kStaggerSlots) * kStaggerStep;
 }
@@ -308,12 +384,14 @@ std::unordered_map<void *, void *> g_alloc_base;       // what the caller holds 
 std::atomic<unsigned> g_alloc_ordinal{0};
 }
 
+int vexhip_reload_env(void) { reload_env(); return 0; }
+
 int vexhip_malloc(int dev, size_t bytes, void **ptr) {
     VEXHIP_REQUIRE(ptr, "ptr is NULL");
     VEXHIP_SET_DEVICE(dev);
     *ptr = nullptr;
     if (bytes == 0) return 0;
-    static const bool off = std::getenv("VEXHIP_MALLOC_STAGGER") && std::atoi(std::getenv("VEXHIP_MALLOC_STAGGER")) == 0;
+    static const bool off = env(ENV_VEXHIP_MALLOC_STAGGER) && std::atoi(env(ENV_VEXHIP_MALLOC_STAGGER)) == 0;
     if (bytes < kStaggerFrom || off) { VEXHIP_TRY(hipMalloc(ptr, bytes)); return 0; }
     void *raw = nullptr;
     VEXHIP_TRY(hipMalloc(&raw, bytes + kStaggerAlign + (kStaggerSlots - 1) * kStaggerStep));
@@ -407,7 +485,7 @@ int vexhip_module_compile(int dev, const char *source, const char *options, void
     std::string arch = prop.gcnArchName;
     std::string opts = options ? options : "";
 
-    if (const char *show = std::getenv("VEXCL_SHOW_KERNELS"))
+    if (const char *show = env(ENV_VEXCL_SHOW_KERNELS))
         if (show[0] != '0') std::printf("%s\n", source);
 
     int rtc_major = 0, rtc_minor = 0;
@@ -511,7 +589,7 @@ int vexhip_module_get_function(int dev, void *module, const char *name, void **f
     *function = f;
     // VEXCL_SHOW_SCRATCH: report generated kernels whose private arrays ended up in scratch memory (a performance trap
     // of generated code: an array indexed by a loop the compiler did not unroll)
-    if (std::getenv("VEXCL_SHOW_SCRATCH")) {
+    if (env(ENV_VEXCL_SHOW_SCRATCH)) {
         int local = 0, regs = 0;
         if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) == hipSuccess && local > 0) {
             (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, f);

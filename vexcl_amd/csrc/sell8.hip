@@ -1227,7 +1227,7 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     const long long span_b = march_span_bytes(m->lo, m->hi, (int)sizeof(V));
     long long lds = march_lds_bytes(m->lo, m->hi, (int)sizeof(V));
     VEXHIP_REQUIRE(lds <= 64 * 1024, "bad march plan: window too large");
-    static const long long lds_floor = [] { const char *e = std::getenv("VEXHIP_MARCH_LDS"); return e ? std::atoll(e) : 0ll; }();   // experiments: fewer workgroups per CU
+    static const long long lds_floor = [] { const char *e = env(ENV_VEXHIP_MARCH_LDS); return e ? std::atoll(e) : 0ll; }();   // experiments: fewer workgroups per CU
     if (lds_floor > lds && lds_floor <= 64 * 1024) lds = lds_floor;
     const march_dev mp = {m->lo, m->hi, lo_e, (int)span_b, (int)(span_b + 2 * S8_ROWS * (long long)sizeof(V)), m->run, m->nfar, m->far[0], m->far[1], (long long)m->x_last};
     const march_cold<V> cold = {(long long)n, ns, deltas, values, cp, cc, cv, pool, t8};
@@ -1651,7 +1651,7 @@ int sell8_analyze(int dev, void *stream, int64_t n, const P *ptr, const int32_t 
     VEXHIP_TRY(hipMemcpyAsync(host.data(), d, sizeof(int) * host.size(), hipMemcpyDeviceToHost, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     VEXHIP_TRY(hipFree(d));
-    if (std::getenv("VEXHIP_DEBUG")) std::fprintf(stderr, "sell8 analyze: count %d overflow %d\n", host[HASH_SLOTS], host[HASH_SLOTS + 1]);
+    if (env(ENV_VEXHIP_DEBUG)) std::fprintf(stderr, "sell8 analyze: count %d overflow %d\n", host[HASH_SLOTS], host[HASH_SLOTS + 1]);
     if (host[HASH_SLOTS + 1] != 0 || host[HASH_SLOTS] > 254 || host[HASH_SLOTS] < 1) return 0;   // not a banded matrix (codes 254 and 255 are padding)
     std::vector<int> table;
     for (int k = 0; k < HASH_SLOTS; ++k) if (host[k] != EMPTY) table.push_back(host[k]);
@@ -1800,6 +1800,7 @@ int vexhip_spmv_sell8_dict_f32_i32(int dev, void *stream, int64_t n, float alpha
 int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,
         int value_bytes, const vexhip_traversal *traversal, int64_t x_last, vexhip_march *out)
 {
+    reload_env();
     VEXHIP_REQUIRE(out, "NULL output");
     std::memset(out, 0, sizeof(*out));
     if (ndeltas < 1 || ndeltas > 254 || !deltas || !blocks || nslices < 8 || x_last < 0) return 0;
@@ -1830,7 +1831,7 @@ int vexhip_sell8_march_plan(int dev, void *stream, const int32_t *deltas, int nd
     // slices, the local matrix of one of eight ranks) run 8 / 16 / 32 = 0.068 / 0.057 / 0.075 ms, pair kernel 0.070.
     int run = 32;
     for (const long long want = nslices / (8ll * std::max(1, info(dev).cus)); run > 4 && run > want; ) run >>= 1;
-    if (const char *e = std::getenv("VEXHIP_MARCH_RUN")) run = std::max(1, std::atoi(e));
+    if (const char *e = env(ENV_VEXHIP_MARCH_RUN)) run = std::max(1, std::atoi(e));
     if (traversal && traversal->grid_blocks > 0 && traversal->chunk > 0) {
         while (run > 1 && traversal->chunk % run != 0) --run;
     }

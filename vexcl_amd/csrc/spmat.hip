@@ -53,6 +53,10 @@ int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, co
 int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_plane *out);
 int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
         const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane, halo_dev H);
+int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
+        const vexhip_grid *g, halo_dev H);
+int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
+        const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane, halo_dev H);
 
 namespace {
 
@@ -194,7 +198,7 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
             const int vb = A->value_type == VEXHIP_F64 ? 8 : 4;
             if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, vb,
                                                   &A->trav, std::max<int64_t>(vexhip_sell8_last_fill_max_col(), ((flags & VEXHIP_SPMAT_SQUARE) ? A->n : 0) - 1), &A->march)) return rc2;
-            if (!(flags & VEXHIP_SPMAT_NO_PLANE) && !std::getenv("VEXHIP_NO_PLANE512"))      // (A/B: the grid product on 512-point lines)
+            if (!(flags & VEXHIP_SPMAT_NO_PLANE) && !env(ENV_VEXHIP_NO_PLANE512))      // (A/B: the grid product on 512-point lines)
                 if (int rc2 = vexhip_sell8_plane_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, A->pool, nb, A->ell_w, A->n, A->tail, vb,
                                                       std::max<int64_t>(vexhip_sell8_last_fill_max_col(), ((flags & VEXHIP_SPMAT_SQUARE) ? A->n : 0) - 1), &A->plane)) return rc2;
         }
@@ -267,7 +271,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         trace.mark("grid build");
         if (A->grid.usable) {
             A->ndeltas = nd; A->nvalues = nv; A->ell_w = gw; A->tail = 0; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
-            if (!std::getenv("VEXHIP_NO_PLANE512"))
+            if (!env(ENV_VEXHIP_NO_PLANE512))
                 if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
             trace.mark("plane plan");
             return 0;
@@ -366,6 +370,16 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
         if (int rc = S::s_fill(dev, stream, n, ptr, col, val, w, A->sell)) return rc;
         if (int rc = vexhip_sell_order_i32(dev, stream, n, w, (int)sizeof(V), A->sell, 0, nullptr, 0, &A->trav)) return rc;
+        // Round 6 -- no constant bands (an unstructured matrix): every XCD walks ONE contiguous eighth of the slices instead of every
+        // eighth slice.  Where the columns of a row lie near the row (a mesh-ordered operator) the lines of x a slice gathers from are
+        // the ones its neighbours use: walked in order by one XCD they stay in ITS L2; dealt round-robin, all eight L2s fetch all of
+        // them (banded16 of bench.py: x traffic 39 x its size).  Matrices without locality lose nothing; a large CSR tail (rows of very
+        // different cost) keeps the plain order, which the dispatcher balances.
+        const int64_t ns = (n + 511) / 512;
+        if (A->trav.grid_blocks == 0 && ns >= 4096 && tail * 8 <= A->nnz && !(flags & VEXHIP_SPMAT_PLAIN_ORDER)) {
+            const int64_t per = (ns + 7) / 8;
+            A->trav.grid_blocks = 8 * per; A->trav.chunk = per; A->trav.planes = 1; A->trav.plane_blocks = ns; A->trav.order = nullptr;
+        }
     }
     clear_max_col_hint();
     VEXHIP_TRY(hipStreamSynchronize(s));
@@ -377,6 +391,7 @@ int create(int dev, void *stream, int64_t n, const P *ptr, const int32_t *col, c
 {
     VEXHIP_REQUIRE(out, "NULL output");
     *out = nullptr;
+    reload_env();                              // an object is created: the switches are read now (common.hpp)
     VEXHIP_REQUIRE(n >= 0 && format >= VEXHIP_SPMAT_AUTO && format <= VEXHIP_SPMAT_CSR, "bad argument");
     VEXHIP_REQUIRE(n == 0 || ptr, "NULL row pointers");
     spmat *A = new (std::nothrow) spmat;
@@ -457,11 +472,13 @@ int apply_multi(const spmat *A, void *stream, int k, V alpha, int append, const 
 // The stored strip of one rank (its rows, plus an empty ghost plane in front of / behind them where it has a neighbour) as the
 // operand of the one-launch product step (halo.hpp, comm.hip): must be stored for the plane product.  planes / lines_per_plane
 // tell the caller the geometry it has to match (ghost plane = one plane of the stored grid).
-int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane) {
+int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane, int *line_length, int *value_type) {
     const spmat *A = reinterpret_cast<const spmat *>(h);
-    VEXHIP_REQUIRE(A && planes && lines_per_plane, "NULL argument");
-    const bool ok = A->value_type == VEXHIP_F64 && A->format == VEXHIP_SPMAT_SELL8V && (A->blocks || A->direct) && A->plane.usable && !A->tail;
-    *planes = ok ? A->plane.planes : 0; *lines_per_plane = ok ? A->plane.lines_per_plane : 0;
+    VEXHIP_REQUIRE(A && planes && lines_per_plane && line_length && value_type, "NULL argument");
+    *planes = 0; *lines_per_plane = 0; *line_length = 0; *value_type = A->value_type;
+    if (A->format != VEXHIP_SPMAT_SELL8V || A->tail) return 0;
+    if ((A->blocks || A->direct) && A->plane.usable) { *planes = A->plane.planes; *lines_per_plane = A->plane.lines_per_plane; *line_length = 512; }
+    else if (A->grid.usable && A->value_type == VEXHIP_F64) { *planes = A->grid.planes; *lines_per_plane = A->grid.lines_per_plane; *line_length = A->grid.nx; }      // lines of any length: the pull form, fp64
     return 0;
 }
 int spmat_device(const vexhip_spmat *h, int *dev) {
@@ -469,12 +486,19 @@ int spmat_device(const vexhip_spmat *h, int *dev) {
     *dev = reinterpret_cast<const spmat *>(h)->dev;
     return 0;
 }
-int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const double *x, double *y, const halo_dev &H) {
+int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const void *x, void *y, const halo_dev &H) {
     const spmat *A = reinterpret_cast<const spmat *>(h);
-    VEXHIP_REQUIRE(A && A->value_type == VEXHIP_F64 && A->format == VEXHIP_SPMAT_SELL8V && (A->blocks || A->direct) && A->plane.usable && !A->tail,
-                   "the one-launch step needs a matrix stored for the plane product");
-    return plane_apply_halo(A->dev, s, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
-                            A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane, H);
+    VEXHIP_REQUIRE(A && A->format == VEXHIP_SPMAT_SELL8V && !A->tail, "the one-launch step needs a matrix stored for the plane or the grid product");
+    if (A->value_type == VEXHIP_F32) {
+        VEXHIP_REQUIRE((A->blocks || A->direct) && A->plane.usable && H.pull, "the one-launch step of a float matrix needs the plane product and shares read in place");
+        return plane32_apply_halo(A->dev, s, A->n, (float)alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
+                                  A->direct ? A->grid.line_class : A->blocks, A->deltas, (const float *)A->values, static_cast<const float *>(x), static_cast<float *>(y), &A->plane, H);
+    }
+    if ((A->blocks || A->direct) && A->plane.usable)
+        return plane_apply_halo(A->dev, s, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
+                                A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, static_cast<const double *>(x), static_cast<double *>(y), &A->plane, H);
+    VEXHIP_REQUIRE(A->grid.usable && H.pull, "the one-launch step needs a matrix stored for the plane product (pushed shares) or the grid product (shares read in place)");
+    return grid_apply_halo(A->dev, s, A->n, alpha, append, (const double *)A->values, static_cast<const double *>(x), static_cast<double *>(y), &A->grid, H);
 }
 } // namespace vexhip
 

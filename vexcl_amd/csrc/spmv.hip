@@ -392,7 +392,9 @@ void hell_kernel(long long n, long long nblocks, V alpha, int append,
 // ---------------------------------------------------------------------------
 constexpr int SELL_ROWS = 512;
 
-template <typename V, int W, bool NT>
+// XNT (A/B, round 6, VEXHIP_SELL_XLOAD=nt): the gathers of x as non-temporal loads -- does the memory system move less than a whole line
+// per 8-byte gather then?  (profiles/r06_unstructured_counters.log: it does not; TCC_EA0_RDREQ_32B stays 0)
+template <typename V, int W, bool NT, bool XNT = false>
 __global__ __launch_bounds__(256)
 void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
         const char *__restrict__ sell,
@@ -428,7 +430,7 @@ void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
             int c[2]; V v[2];
             ell_load<V, 2, NT>(cp + j * SELL_ROWS, vp + j * SELL_ROWS, c, v);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) if (c[q] >= 0) sum[q] += v[q] * x[c[q]];
+            for (int q = 0; q < 2; ++q) if (c[q] >= 0) sum[q] += v[q] * (XNT ? __builtin_nontemporal_load(x + c[q]) : x[c[q]]);
         }
     }
     if (csr_ptr) {
@@ -704,7 +706,9 @@ int spmv_sell(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
         else sell_kernel<V, W, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order); break;
     switch (w) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
-        default: sell_kernel<V, 0, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order);
+        default:
+            if (env(ENV_VEXHIP_SELL_XLOAD)) sell_kernel<V, 0, true, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order);
+            else sell_kernel<V, 0, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order);
     }
 #undef CASE
     VEXHIP_LAUNCH_CHECK();

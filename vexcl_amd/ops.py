@@ -380,14 +380,15 @@ class SpMat:
 
     _FORMATS = {"sell": _capi.SPMAT_AUTO, "sell8": _capi.SPMAT_SELL8, "sell32": _capi.SPMAT_SELL, "csr": _capi.SPMAT_CSR}
 
-    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True, march=True, plane=True, direct=True):
+    def __init__(self, ptr, col, val, n_cols=None, fmt="auto", dictionary=True, march=True, plane=True, direct=True, plain_order=False):
         """dictionary=False keeps one code block per slice even when the slices of a value-coded matrix repeat
         (VEXHIP_SPMAT_NO_DICTIONARY: A/B and tests); march=False keeps the pair product where the march product (x window
         of the near diagonals in an LDS ring carried along a run of slices) or the plane product would apply
         (VEXHIP_SPMAT_NO_MARCH); plane=False keeps the march product where the plane product (round 4: two grid lines per
         workgroup walked through the planes, neighbours in registers) or the grid product (the same walk for lines of any
         length) would apply (VEXHIP_SPMAT_NO_PLANE); direct=False builds the SELL-512 storage (slices, dictionary, plans) even where
-        the matrix could be stored by grid line straight from the CSR arrays (VEXHIP_SPMAT_NO_GRID_BUILD)."""
+        the matrix could be stored by grid line straight from the CSR arrays (VEXHIP_SPMAT_NO_GRID_BUILD); plain_order=True deals the
+        slices of an unstructured matrix to the XCDs round-robin instead of giving every XCD a contiguous eighth (VEXHIP_SPMAT_PLAIN_ORDER, A/B)."""
         self.ptr, self.col, self.val = ptr, col, val
         self.n = ptr.numel() - 1
         self.m = self.n if n_cols is None else n_cols
@@ -422,6 +423,7 @@ class SpMat:
             _dev(val), _stream(val), self.n, _p(ptr), _p(col), _p(val), self._FORMATS[fmt],
             _capi.SPMAT_BORROW_CSR | (0 if dictionary else _capi.SPMAT_NO_DICTIONARY) | (0 if march else _capi.SPMAT_NO_MARCH)
             | (0 if plane else _capi.SPMAT_NO_PLANE) | (0 if direct else _capi.SPMAT_NO_GRID_BUILD)
+            | (_capi.SPMAT_PLAIN_ORDER if plain_order else 0)
             | (_capi.SPMAT_SQUARE if self.m >= self.n else 0), ctypes.byref(h))      # x has m >= n elements (vex::SpMat is told n and m: spmat.hpp:56-60)
         self.handle = h
         if _t0 is not None:
@@ -615,7 +617,22 @@ def _sort(keys, vals, descending, unsigned):
     tmp = torch.empty(max(1, L.sort_tmp_bytes(code, n)), dtype=torch.uint8, device=keys.device)
     L.sort(_dev(keys), _stream(keys), code, int(bool(descending)), _p(keys), _p(ktmp), vb, _p(vals), _p(vtmp),
            n, _p(tmp))
+    _last_sort_status[:] = [keys, tmp, n]
     return keys if vals is None else (keys, vals)
+
+
+_last_sort_status = [None, None, 0]
+
+
+def sort_status():
+    """(tiles ranked a second time, tiles dropped) of the last sort / sort_by_key (include/vexhip.h vexhip_sort_status; waits for it).
+    A dropped tile -- the input changed while the sort ran -- raises."""
+    keys, tmp, n = _last_sort_status
+    if keys is None:
+        return 0, 0
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    lib().sort_status(_dev(keys), _stream(keys), n, _p(tmp), ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def sort(keys, descending=False, unsigned=False):
