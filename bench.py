@@ -171,6 +171,42 @@ def self_launch(args, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def try_transports(names, enable, validate, trial, disable, error_of, settle=lambda: None):
+    """`--transport auto`: every candidate is enabled, validated against the independent evaluation and timed; a transport that raises,
+    times out or disagrees at ANY of these stages is recorded as invalid and skipped -- never fatal (a first run on real multi-GPU
+    hardware meets transports this project could only exercise on one device).  -> {name: record}.  The callables agree across the
+    ranks themselves (enable / validate end in an all-reduce); an exception on one rank must not leave the others waiting: the record
+    is made invalid on every rank by the next agreeing call of the caller."""
+    tried = {}
+    for tr in names:
+        rec = {"valid": False}
+        try:
+            settle()
+            if enable(tr):
+                rec["valid"], rec["max_abs_err"] = validate()
+                if rec["valid"]:
+                    rec["trial_ms_per_step"] = round(trial(), 5)
+        except BaseException as e:          # noqa: BLE001 -- SystemExit / KeyboardInterrupt are re-raised below
+            if isinstance(e, (SystemExit, KeyboardInterrupt)):
+                raise
+            rec = {"valid": False, "error": repr(e)[:300]}
+        if not rec["valid"] and "error" not in rec:
+            rec["error"] = error_of() or "results differ from the independent evaluation on some rank"
+        tried[tr] = rec
+        try:
+            settle()
+            disable()
+        except Exception as e:              # noqa: BLE001
+            rec.setdefault("disable_error", repr(e)[:200])
+    return tried
+
+
+def transports_by_time(tried):
+    """valid transports, fastest first (timed ones before merely valid ones)"""
+    timed = sorted((k for k in tried if tried[k].get("valid") and "trial_ms_per_step" in tried[k]), key=lambda k: tried[k]["trial_ms_per_step"])
+    return timed + [k for k in tried if tried[k].get("valid") and k not in timed]
+
+
 def timed_events(torch, fn, reps):
     """Average duration of fn over `reps` launches, after ~30 ms of the same launches: these rows run after host-side work
     (matrix set-up, subprocesses), and after >= 5 ms without work the first ~16 ms of launches are up to 12 % slow."""
@@ -683,6 +719,8 @@ def main():
         if not args.no_native and args.transport != "torch":
             # (three or more ranks SHARING one device can starve each other in the one-launch step: the workgroups that wait for a
             #  ghost plane hold their CU slots, csrc/halo.hpp -- with a GPU per rank a launch only waits for other devices)
+            if args.transport == "pull" or (args.transport == "auto" and not (args.one_device and world > 2)):
+                candidates.append("pull")           # round 6: one launch, the neighbours' boundary planes of x read in place (their allocations mapped through IPC handles)
             if args.transport == "halo" or (args.transport == "auto" and not (args.one_device and world > 2)):
                 candidates.append("halo")           # round 5: the whole step in one launch (ghost planes read by the plane product itself)
             if args.transport in ("auto", "ipc"):
@@ -692,35 +730,44 @@ def main():
         if args.transport == "auto" or not candidates:
             if tried["torch"]["valid"]:
                 tried["torch"]["trial_ms_per_step"] = round(trial(args.trial_steps), 5)
-        for tr in candidates:
+        def settle():
             torch.cuda.synchronize(); barrier()
+
+        def enable(tr):
             progress("transports so far: %r; trying %s" % ({k: v.get("trial_ms_per_step", v.get("valid")) for k, v in tried.items()}, tr))
-            rec = {"valid": False}
-            if A.enable_native(transport=tr):
-                rec["valid"], rec["max_abs_err"] = validate()
-                if rec["valid"]:
-                    rec["trial_ms_per_step"] = round(trial(args.trial_steps), 5)
-                    rec["status"] = A.native_status()
-                    if tr == "rccl":
-                        rec["rccl"] = A.rccl_info()
-            if not rec["valid"]:
-                rec["error"] = A.native_error or "results differ from the independent evaluation on some rank"
+            return A.enable_native(transport=tr)
+
+        native = try_transports(candidates, enable, validate, lambda: trial(args.trial_steps), A.disable_native, lambda: A.native_error, settle)
+        for tr, rec in native.items():
+            if rec.get("valid"):
+                rec["status"] = None
             tried[tr] = rec
-            torch.cuda.synchronize(); barrier()
-            A.disable_native()
-        valid = [k for k in tried if tried[k]["valid"] and "trial_ms_per_step" in tried[k]]
-        if not valid:
-            valid = [k for k in tried if tried[k]["valid"]]
-        if not valid:
+        order = transports_by_time(tried)
+        if not order:
             raise SystemExit("no ghost-exchange transport reproduces the independent evaluation of the product: %r" % tried)
-        chosen = min(valid, key=lambda k: tried[k].get("trial_ms_per_step", 1e30))
-        progress("transport chosen: %s of %r" % (chosen, {k: v.get("trial_ms_per_step", v.get("valid")) for k, v in tried.items()}))
-        if chosen != "torch":
-            assert A.enable_native(transport=chosen), A.native_error
+        progress("transports, fastest first: %r of %r" % (order, {k: v.get("trial_ms_per_step", v.get("valid")) for k, v in tried.items()}))
+        # the fastest one that comes up AGAIN and still validates is used (one that fails now is skipped like one that failed above)
+        chosen = None
+        for k in order:
+            if k == "torch":
+                chosen = k
+                break
+            try:
+                if A.enable_native(transport=k):
+                    ok, _ = validate(1)
+                    if ok:
+                        tried[k]["status"] = A.native_status()
+                        if k == "rccl":
+                            tried[k]["rccl"] = A.rccl_info()
+                        chosen = k
+                        break
+                tried[k]["second_enable_error"] = A.native_error or "did not validate after it was re-enabled"
+            except Exception as e:          # noqa: BLE001
+                tried[k]["second_enable_error"] = repr(e)[:300]
+            A.disable_native()
+        if chosen is None:
+            raise SystemExit("no ghost-exchange transport could be enabled a second time: %r" % tried)
         A.drop_strip()                 # (kept by DistSpMat for transport "halo", which stores the strip once more with its ghost planes)
-        if chosen != "torch":
-            ok, _ = validate(1)
-            assert ok, "transport %s does not validate after it was re-enabled: %s" % (chosen, A.native_error)
         transport = {"torch": "torch.distributed batch_isend_irecv (%s)" % args.backend,
                      "rccl": "vexhip_dist_spmv_apply: pack + grouped ncclSend/ncclRecv + local + remote part issued from C++ (own RCCL communicator)",
                      "ipc": "vexhip_dist_spmv_apply over peer-mapped ghost windows (hipIpcGetMemHandle): owners write their neighbours' shares "

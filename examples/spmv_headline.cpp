@@ -212,10 +212,10 @@ int main(int argc, char **argv) {
         const vexhip_spmat_info &info = A.storage_info();
         const double moved = (double)info.matrix_bytes + 16.0 * N;   // stored matrix + x once + y once
         std::printf("{\"row\": \"vex::SpMat<double,int,int> y = A*x, %s 7-point %lld^3\", \"front_end\": \"C++ vexcl/spmat.hpp\", "
-                    "\"storage\": \"%s\", \"plane_product\": %d, \"rows\": %zu, \"nnz\": %zu, \"ms\": %.5f, \"gflops\": %.1f, "
+                    "\"storage\": \"%s\", \"kernel\": \"%s\", \"selection\": \"%s\", \"plane_product\": %d, \"rows\": %zu, \"nnz\": %zu, \"ms\": %.5f, \"gflops\": %.1f, "
                     "\"bytes_streamed\": %.0f, \"streamed_gbps\": %.1f, \"streamed_frac_of_8TBps\": %.4f, "
                     "\"csr_algorithmic_gbps\": %.1f, \"sum_y\": %.17g}\n",
-                variable ? "variable-coefficient" : "Poisson", (long long)n, storage_name(info), (int)info.plane.usable, N, nnz, ms, 2.0 * nnz / ms / 1e6,
+                variable ? "variable-coefficient" : "Poisson", (long long)n, storage_name(info), info.product, info.reason, (int)info.plane.usable, N, nnz, ms, 2.0 * nnz / ms / 1e6,
                 moved, moved / ms / 1e6, moved / ms / 1e6 / 8000.0, (12.0 * nnz + 4.0 * (N + 1) + 16.0 * N) / ms / 1e6, checksum);
         std::fflush(stdout);
     }

@@ -450,6 +450,8 @@ typedef struct vexhip_spmat_info {
     vexhip_march march;             /* march product (usable = 1: apply() runs it; see vexhip_sell8_march_plan)                */
     vexhip_plane plane;             /* plane product (usable = 1: apply() prefers it to the march product; vexhip_sell8_plane_plan) */
     vexhip_grid grid;               /* grid product (usable = 1: apply() runs it where the plane product does not apply; vexhip_sell8_grid_plan) */
+    char product[64];               /* round 6: the kernel a product of this matrix launches (spmat.hip select_product: ONE table) ...          */
+    char reason[320];               /* ... why this storage was chosen and why that product; also printed under VEXHIP_DEBUG                    */
 } vexhip_spmat_info;
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
         int format, int flags, vexhip_spmat **out);
@@ -564,6 +566,11 @@ int vexhip_ipc_window_open(vexhip_ipc_window *win, int peer, const void *handle6
  * this process already holds -- no handle; distinct GPUs get hipDeviceEnablePeerAccess (which also covers the vectors a pull
  * step reads in place).  `peer_win` must be rank `peer` of the same world.                                                       */
 int vexhip_ipc_window_attach(vexhip_ipc_window *win, int peer, const vexhip_ipc_window *peer_win);
+/* Any device allocation shown to another process (the pull step BETWEEN processes reads the neighbours' x in place): the 64-byte handle of
+ * the allocation that holds `ptr` and ptr's offset in it; the peer opens the handle (base of the mapping) and closes it when done.   */
+int vexhip_ipc_export(int dev, const void *ptr, void *handle64, int64_t *offset);
+int vexhip_ipc_open(int dev, const void *handle64, void **base);
+int vexhip_ipc_close(int dev, void *base);
 int vexhip_ipc_window_data(const vexhip_ipc_window *win, void **data);
 int vexhip_ipc_window_destroy(vexhip_ipc_window *win);
 int vexhip_dist_spmv_create_ipc(vexhip_ipc_window *win, int dtype, int64_t rows, const vexhip_spmat *local,

@@ -111,6 +111,12 @@ if "events" in which:
     y.fill_(float("nan"))
     bench(lambda: L.dist_spmv_apply_pull(step, sp, 1.0, 0, p(x), p(y), xb, xa), "halo PULL, no flags (the host's events order the streams): one launch")
     out["pull_events_equals_one_device_csr_order"] = bool(torch.equal(y, y_one))
+    # the same launch on the vectors the ORDINARY product of the stored strip uses below (x_ext with its ghost planes in place, y_ext):
+    # same kernel body, same memory -- what the one-launch form of the kernel itself costs
+    xm = x_ext[P:P + rows]; ym = y_ext[P:P + rows]
+    bench(lambda: L.dist_spmv_apply_pull(step, sp, 1.0, 0, p(xm), p(ym), p(x_ext), ctypes.c_void_p(x_ext.data_ptr() + (P + rows) * x_ext.element_size())),
+          "halo PULL, no flags, on the vectors of the ordinary product (x with its ghost planes in place)")
+    out["pull_events_in_place_equals_one_device"] = bool(torch.equal(ym, y_one))
     L.dist_spmv_destroy(step)
 if "parts" in which:
     lp, lc, lv = None, None, None

@@ -84,7 +84,8 @@ class SpMatInfo(ctypes.Structure):
                 ("sell", ctypes.c_void_p), ("deltas", ctypes.c_void_p), ("values", ctypes.c_void_p),
                 ("csr_ptr", ctypes.c_void_p), ("csr_col", ctypes.c_void_p), ("csr_val", ctypes.c_void_p),
                 ("traversal", Traversal), ("slice_blocks", ctypes.c_void_p), ("code_pool", ctypes.c_void_p),
-                ("dictionary_blocks", ctypes.c_int64), ("march", March), ("plane", Plane), ("grid", Grid)]
+                ("dictionary_blocks", ctypes.c_int64), ("march", March), ("plane", Plane), ("grid", Grid),
+                ("product", ctypes.c_char * 64), ("reason", ctypes.c_char * 320)]
 
 
 SPMAT_AUTO, SPMAT_SELL8V, SPMAT_SELL8, SPMAT_SELL, SPMAT_CSR = range(5)
@@ -231,6 +232,9 @@ _PROTOS = {
     "vexhip_dist_spmv_create_halo_pull": (None, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
     "vexhip_dist_spmv_apply_pull": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp, c_vp, c_vp]),
     "vexhip_ipc_window_attach": (None, [c_vp, c_int, c_vp]),
+    "vexhip_ipc_export": (None, [c_int, c_vp, c_vp, ctypes.POINTER(c_i64)]),
+    "vexhip_ipc_open": (None, [c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "vexhip_ipc_close": (None, [c_int, c_vp]),
     "vexhip_csr_extend_halo_i32": (None, [c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64)]),
     "vexhip_dist_spmv_create_ipc": (None, [c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64),
                                            ctypes.POINTER(c_i64), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_vp)]),

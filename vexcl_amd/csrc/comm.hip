@@ -915,6 +915,35 @@ int vexhip_ipc_window_attach(vexhip_ipc_window *h, int peer, const vexhip_ipc_wi
     return 0;
 }
 
+// Any device allocation made visible to another process (the pull step between processes reads the neighbours' x in place): the handle of
+// the ALLOCATION that holds ptr and ptr's offset in it (what torch does for tensors shared between processes).
+int vexhip_ipc_export(int dev, const void *ptr, void *handle64, int64_t *offset) {
+    VEXHIP_REQUIRE(ptr && handle64 && offset, "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    VEXHIP_TRY(hipMemGetAddressRange(&base, &size, const_cast<void *>(ptr)));
+    hipIpcMemHandle_t mh;
+    VEXHIP_TRY(hipIpcGetMemHandle(&mh, base));
+    std::memcpy(handle64, &mh, sizeof(mh));
+    *offset = (int64_t)(static_cast<const char *>(ptr) - static_cast<const char *>(base));
+    return 0;
+}
+int vexhip_ipc_open(int dev, const void *handle64, void **base) {
+    VEXHIP_REQUIRE(handle64 && base, "NULL argument");
+    *base = nullptr;
+    VEXHIP_SET_DEVICE(dev);
+    hipIpcMemHandle_t mh;
+    std::memcpy(&mh, handle64, sizeof(mh));
+    VEXHIP_TRY(hipIpcOpenMemHandle(base, mh, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+int vexhip_ipc_close(int dev, void *base) {
+    if (!base) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    VEXHIP_TRY(hipIpcCloseMemHandle(base));
+    return 0;
+}
+
 int vexhip_ipc_window_data(const vexhip_ipc_window *h, void **data) {
     const ipc_window *w = reinterpret_cast<const ipc_window *>(h);
     VEXHIP_REQUIRE(w && data, "NULL argument");

@@ -478,6 +478,7 @@ int vexhip_host_free(void *ptr) {
 // ---------------------------------------------------------------- JIT
 
 int vexhip_module_compile(int dev, const char *source, const char *options, void **module) {
+    reload_env();                              // a module is created: VEXCL_CACHE_DIR / _CACHE_KERNELS / _SHOW_KERNELS are read now
     VEXHIP_REQUIRE(source && module, "source/module is NULL");
     VEXHIP_SET_DEVICE(dev);
     hipDeviceProp_t prop;

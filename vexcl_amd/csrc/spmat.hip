@@ -12,6 +12,7 @@
 #include "halo.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -79,6 +80,7 @@ struct spmat {
     vexhip_plane plane = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // plane product (plane.hip): 7-point pattern on 512-point lines; preferred to the march product
     vexhip_grid grid = {};                                         // grid product (grid.hip): 7-point pattern on lines of any length, where the plane product does not apply
     bool direct = false;                                           // stored by grid line straight from the CSR arrays (grid.hip grid_build): no SELL-512 slices, no dictionary
+    char why[200] = {0};                                           // why this storage (the branch of build() that was taken)
 };
 
 template <typename T> int dmalloc(T **p, size_t count) {
@@ -103,6 +105,45 @@ void release(spmat *A) {
         if (A->csr_val) (void)hipFree(A->csr_val);
     }
     delete A;
+}
+
+// ---- THE selection of the product (round 6: one table instead of conditions spread over apply / get_info / the front ends) ----
+// What a matrix's product launches, by storage and plan, first match wins:
+//   value codes (SELL8V)   plane product      a plane plan: 7-point pattern on 512-point lines (fp64: x and y 16-byte aligned; fp32: any)
+//                          grid product       a grid plan: the same pattern on lines of any length
+//                          march product      a slice dictionary (the x window of the near diagonals in an LDS ring along runs of slices)
+//                          pair product       otherwise
+//   diagonal codes (SELL8) pair product       with or without a slice dictionary
+//   32-bit columns (SELL)  pair / row kernel  (the slices dealt by XCD for unstructured matrices)
+//   CSR                    row-block streaming kernel (32- or 64-bit row pointers)
+enum product_kind { P_NONE, P_ZERO_FILL, P_PLANE64, P_PLANE32, P_GRID64, P_GRID32, P_MARCH, P_PAIR_CODES, P_PAIR_DICT_VALUES, P_PAIR_VALUES, P_SELL32, P_CSR32, P_CSR64 };
+struct product_choice { product_kind kind; const char *kernel; const char *reason; };
+
+inline product_choice select_product(const spmat *A, const void *x, const void *y)
+{
+    if (A->n == 0) return {P_NONE, "none", "no rows"};
+    if (A->nnz == 0) return {P_ZERO_FILL, "hipMemsetAsync", "no entries: '=' zero-fills y (csr.inl:186-200)"};
+    const bool f64 = A->value_type == VEXHIP_F64;
+    const bool coded_by_line = (A->blocks || A->direct) && (g_sell8_variant == 0 || A->direct) && !A->tail;
+    switch (A->format) {
+        case VEXHIP_SPMAT_SELL8V:
+            if (coded_by_line && A->plane.usable) {
+                if (!f64) return {P_PLANE32, "sell8_plane_f32_kernel", "plane plan (512-point lines), float: four rows per lane"};
+                if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) return {P_PLANE64, "sell8_plane_kernel", "plane plan (512-point lines)"};
+            }
+            if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
+                return f64 ? product_choice{P_GRID64, "sell8_grid_kernel", A->plane.usable ? "plane plan, but x or y is not 16-byte aligned: the grid product addresses by element" : "grid plan (lines of any length)"}
+                           : product_choice{P_GRID32, "sell8_grid_f32_kernel", "grid plan (lines of any length), float"};
+            if (A->blocks) return {P_MARCH, A->march.usable ? "sell8_march_kernel" : "sell8_pair_kernel", A->march.usable ? "slice dictionary + march plan" : "slice dictionary, no march plan: pair product on dictionary blocks"};
+            return {P_PAIR_CODES, "sell8_pair_kernel", "value codes, one code block per slice"};
+        case VEXHIP_SPMAT_SELL8:
+            if (A->blocks) return {P_PAIR_DICT_VALUES, "sell8_pair_kernel", "diagonal codes from the slice dictionary, values streamed"};
+            return {P_PAIR_VALUES, A->ell_w <= 8 ? "sell8_pair_kernel" : "sell8_kernel", "diagonal codes + values streamed per slice"};
+        case VEXHIP_SPMAT_SELL:
+            return {P_SELL32, A->ell_w <= 8 ? "sell_pair_kernel" : "sell_kernel", A->trav.grid_blocks ? "32-bit columns, slices in the plan's order (strips of a banded matrix / an eighth per XCD)" : "32-bit columns, slices in storage order"};
+        default:
+            return A->csr_ptr64 ? product_choice{P_CSR64, "csr_stream2_kernel", "CSR arrays, 64-bit row pointers"} : product_choice{P_CSR32, "csr_stream2_kernel", "CSR arrays"};
+    }
 }
 
 template <typename V> struct api;
@@ -241,7 +282,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     const int dev = A->dev;
     A->n = n; A->value_type = F::type;
     clear_max_col_hint();                      // a hint left by a build that failed half-way must not reach this matrix's fill
-    if (n == 0) { A->format = VEXHIP_SPMAT_CSR; return 0; }
+    if (n == 0) { A->format = VEXHIP_SPMAT_CSR; std::snprintf(A->why, sizeof A->why, "no rows"); return 0; }
     VEXHIP_SET_DEVICE(dev);
     hipStream_t s = as_stream(stream);
     setup_trace trace(s);
@@ -271,6 +312,8 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         trace.mark("grid build");
         if (A->grid.usable) {
             A->ndeltas = nd; A->nvalues = nv; A->ell_w = gw; A->tail = 0; A->format = VEXHIP_SPMAT_SELL8V; A->direct = true;
+            std::snprintf(A->why, sizeof A->why, "stored by grid line in one pass over the CSR arrays: a 7-point pattern on %d-point lines (%d lines per plane), %d distinct values, %d classes of lines",
+                          (int)A->grid.nx, (int)A->grid.lines_per_plane, nv, (int)A->grid.classes);
             if (!env(ENV_VEXHIP_NO_PLANE512))
                 if (int rc2 = plane_plan_from_grid(dev, &A->grid, n, &A->plane)) return rc2;       // 512-point lines: the plane kernel reads the same tables
             trace.mark("plane plan");
@@ -286,6 +329,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     if (format == VEXHIP_SPMAT_CSR || w == 0) {
         // the CSR arrays as they are: borrowed (the caller keeps them alive) or copied
         A->format = VEXHIP_SPMAT_CSR;
+        std::snprintf(A->why, sizeof A->why, format == VEXHIP_SPMAT_CSR ? "CSR was asked for" : "the hybrid-ELL rule (hybrid_ell.inl:103-110) gives width 0: every row goes to the CSR part");
         P *own_ptr = nullptr;
         if (flags & VEXHIP_SPMAT_BORROW_CSR) {
             own_ptr = const_cast<P *>(ptr); A->csr_col = const_cast<int32_t *>(col); A->csr_val = const_cast<V *>(val);
@@ -340,6 +384,8 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         A->ndeltas = nd;
         if (nv > 0) {
             A->nvalues = nv; A->format = VEXHIP_SPMAT_SELL8V;
+            std::snprintf(A->why, sizeof A->why, "SELL-512 with 1-byte diagonal and value codes: ELL width %lld, %d diagonals (<= 254), %d distinct values (<= 255), %lld entries in the CSR tail",
+                          (long long)w, nd, nv, (long long)tail);
             A->sell_bytes = vexhip_sell8v_bytes(n, w);
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
             trace.mark("allocate slices");
@@ -357,6 +403,8 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         } else {
             if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
             A->format = VEXHIP_SPMAT_SELL8;
+            std::snprintf(A->why, sizeof A->why, "SELL-512 with 1-byte diagonal codes and stored values: ELL width %lld, %d diagonals (<= 254), more than 255 distinct values%s, %lld entries in the CSR tail",
+                          (long long)w, nd, format == VEXHIP_SPMAT_SELL8 ? " (or format SELL8 asked for)" : "", (long long)tail);
             A->sell_bytes = vexhip_sell8_bytes(n, w, (int)sizeof(V));
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
             if (int rc = S::d_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, A->sell, &A->trav)) return rc;
@@ -366,6 +414,8 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
         if (A->deltas) { (void)hipFree(A->deltas); A->deltas = nullptr; }
         if (A->values) { (void)hipFree(A->values); A->values = nullptr; }
         A->format = VEXHIP_SPMAT_SELL;
+        std::snprintf(A->why, sizeof A->why, "SELL-512 with 32-bit columns: ELL width %lld, %s, %lld entries in the CSR tail", (long long)w,
+                      format == VEXHIP_SPMAT_SELL ? "format SELL asked for" : "more than 254 distinct diagonals (an unstructured matrix)", (long long)tail);
         A->sell_bytes = vexhip_sell_bytes(n, w, (int)sizeof(V));
         VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
         if (int rc = S::s_fill(dev, stream, n, ptr, col, val, w, A->sell)) return rc;
@@ -398,6 +448,10 @@ int create(int dev, void *stream, int64_t n, const P *ptr, const int32_t *col, c
     VEXHIP_REQUIRE(A, "out of host memory");
     A->dev = dev;
     if (int rc = build<V, P>(A, stream, n, ptr, col, val, format, flags)) { release(A); return rc; }
+    if (env(ENV_VEXHIP_DEBUG)) {
+        const product_choice pc = select_product(A, nullptr, nullptr);
+        std::fprintf(stderr, "[vexhip] matrix of %lld rows, %lld entries: %s; product: %s (%s)\n", (long long)A->n, (long long)A->nnz, A->why, pc.kernel, pc.reason);
+    }
     *out = reinterpret_cast<vexhip_spmat *>(A);
     return 0;
 }
@@ -407,41 +461,38 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
 {
     typedef api<V> F;
     VEXHIP_REQUIRE(A && A->value_type == F::type, "matrix and vector value types differ");
-    if (A->n == 0) return 0;
-    if (A->nnz == 0) {          // csr.inl:186-200: an empty matrix zero-fills y on "="
-        if (!append) { VEXHIP_SET_DEVICE(A->dev); VEXHIP_TRY(hipMemsetAsync(y, 0, sizeof(V) * (size_t)A->n, as_stream(stream))); }
-        return 0;
-    }
+    const product_choice pc = select_product(A, x, y);
     const int32_t *cp = A->tail ? A->csr_ptr : nullptr;
-    switch (A->format) {
-        case VEXHIP_SPMAT_SELL8V:
-            // (the plane product moves x and y in 16-byte pieces at 16-byte addresses; vectors that start at an odd element -- a view
-            //  into a larger vector -- take the grid product, which addresses by element, or the older products)
+    const void *tables = A->direct ? A->grid.table : A->pool;
+    const int32_t *classes = A->direct ? A->grid.line_class : A->blocks;
+    switch (pc.kind) {
+        case P_NONE: return 0;
+        case P_ZERO_FILL:
+            if (!append) { VEXHIP_SET_DEVICE(A->dev); VEXHIP_TRY(hipMemsetAsync(y, 0, sizeof(V) * (size_t)A->n, as_stream(stream))); }
+            return 0;
+        case P_PLANE64:
             if constexpr (std::is_same<V, double>::value)
-                if ((A->blocks || A->direct) && A->plane.usable && (g_sell8_variant == 0 || A->direct) && !A->tail
-                    && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
-                    return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
-                                                            A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
-            if constexpr (std::is_same<V, float>::value)       // fp32: the same storage, four rows per lane (plane32.hip); x and y may start at any element
-                if ((A->blocks || A->direct) && A->plane.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
-                    return vexhip_spmv_sell8v_plane_f32_i32(A->dev, stream, A->n, alpha, append, A->ell_w, A->direct ? A->grid.table : A->pool,
-                                                            A->direct ? A->grid.line_class : A->blocks, A->deltas, (const float *)A->values, x, y, &A->plane);
-            if constexpr (std::is_same<V, double>::value)
-                if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
-                    return vexhip_spmv_sell8v_grid_f64(A->dev, stream, A->n, alpha, append, (const double *)A->values, x, y, &A->grid);
+                return vexhip_spmv_sell8v_plane_f64_i32(A->dev, stream, A->n, alpha, append, A->ell_w, tables, classes, A->deltas, (const double *)A->values, x, y, &A->plane);
+            break;
+        case P_PLANE32:
             if constexpr (std::is_same<V, float>::value)
-                if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
-                    return vexhip_spmv_sell8v_grid_f32(A->dev, stream, A->n, alpha, append, (const float *)A->values, x, y, &A->grid);
-            if (A->blocks) return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
-            return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
-        case VEXHIP_SPMAT_SELL8:
-            if (A->blocks) return F::mul_dd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
-            return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
-        case VEXHIP_SPMAT_SELL:   return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
-        default:
-            if (A->csr_ptr64) return spmv_csr_p64(A->dev, stream, A->n, alpha, append, A->csr_ptr64, A->csr_col, (const V *)A->csr_val, x, y, &A->trav);
-            return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
+                return vexhip_spmv_sell8v_plane_f32_i32(A->dev, stream, A->n, alpha, append, A->ell_w, tables, classes, A->deltas, (const float *)A->values, x, y, &A->plane);
+            break;
+        case P_GRID64:
+            if constexpr (std::is_same<V, double>::value) return vexhip_spmv_sell8v_grid_f64(A->dev, stream, A->n, alpha, append, (const double *)A->values, x, y, &A->grid);
+            break;
+        case P_GRID32:
+            if constexpr (std::is_same<V, float>::value) return vexhip_spmv_sell8v_grid_f32(A->dev, stream, A->n, alpha, append, (const float *)A->values, x, y, &A->grid);
+            break;
+        case P_MARCH: return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
+        case P_PAIR_CODES: return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case P_PAIR_DICT_VALUES: return F::mul_dd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case P_PAIR_VALUES: return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case P_SELL32: return F::mul_s(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, cp, A->csr_col, A->csr_val, x, y, &A->trav);
+        case P_CSR64: return spmv_csr_p64(A->dev, stream, A->n, alpha, append, A->csr_ptr64, A->csr_col, (const V *)A->csr_val, x, y, &A->trav);
+        case P_CSR32: return F::mul_c(A->dev, stream, A->n, alpha, append, A->csr_ptr, A->csr_col, A->csr_val, x, y, &A->trav);
     }
+    return fail(__FILE__, __LINE__, "the selected product does not exist for this value type");
 }
 
 template <typename V>
@@ -561,6 +612,10 @@ int vexhip_spmat_get_info(const vexhip_spmat *h, vexhip_spmat_info *o) {
     if (A->grid.usable)                     // the grid product reads the matrix by grid line: a class per line + the class tables
         m = (A->n / A->grid.nx) * 4 + (int64_t)A->grid.classes * 7 * A->grid.pitch;
     o->matrix_bytes = m;
+    // what a product of this matrix launches and why (the table above; for vectors at 16-byte addresses), and why this storage
+    const product_choice pc = select_product(A, nullptr, nullptr);
+    std::snprintf(o->product, sizeof o->product, "%s", pc.kernel);
+    std::snprintf(o->reason, sizeof o->reason, "%s; product: %s", A->why, pc.reason);
     return 0;
 }
 

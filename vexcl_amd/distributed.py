@@ -199,7 +199,7 @@ class DistSpMat:
 
         def pre():
             nonlocal L
-            if transport not in ("rccl", "ipc", "halo"):
+            if transport not in ("rccl", "ipc", "halo", "pull"):
                 raise ValueError("unknown transport %r" % (transport,))
             if self.dev.type != "cuda" or not hasattr(self.k, "make_remote"):
                 raise RuntimeError("native step needs the device kernels")
@@ -247,7 +247,7 @@ class DistSpMat:
                 if not self._stage(make_step):
                     self._drop_native(st.get("step"))
                     return False
-            elif transport == "halo":
+            elif transport in ("halo", "pull"):
                 # ---- the whole step in ONE launch (include/vexhip.h vexhip_dist_spmv_create_halo; csrc/halo.hpp): every remote
                 #      column of this rank lies in the plane below its first row or the plane above its last one, the strip is
                 #      stored as one grid matrix with those two ghost planes, and the plane product reads them from the window
@@ -259,7 +259,8 @@ class DistSpMat:
 
                 def make_window():
                     win = ctypes.c_void_p()
-                    L.ipc_window_create(self.dev.index or 0, self.rank, self.world, 2 * H * 8, ctypes.byref(win))
+                    # (pull, round 6: the window carries flags only -- the ghost planes are read from the neighbours' x where it lies)
+                    L.ipc_window_create(self.dev.index or 0, self.rank, self.world, 0 if transport == "pull" else 2 * H * 8, ctypes.byref(win))
                     self._window = win
                     raw = (ctypes.c_char * 64)()
                     L.ipc_window_export(win, ctypes.cast(raw, ctypes.c_void_p))
@@ -287,7 +288,11 @@ class DistSpMat:
                             hb = (ctypes.c_char * 64).from_buffer_copy(bytes(handles[peer].numpy().tobytes()))
                             L.ipc_window_open(self._window, peer, ctypes.cast(hb, ctypes.c_void_p))
                     step = ctypes.c_void_p()
-                    L.dist_spmv_create_halo(self._window, self._ext.handle, self.rows, H, lower, upper, ctypes.byref(step))
+                    if transport == "pull":
+                        L.dist_spmv_create_halo_pull(self._window, self._ext.handle, self.rows, H, lower, upper, 1, ctypes.byref(step))
+                        self._pull = {"H": H, "lower": lower, "upper": upper, "vectors": {}, "opened": {}}
+                    else:
+                        L.dist_spmv_create_halo(self._window, self._ext.handle, self.rows, H, lower, upper, ctypes.byref(step))
                     st["step"] = step
                 if not self._stage(make_step):
                     self._drop_native(st.get("step"))
@@ -340,6 +345,47 @@ class DistSpMat:
         self.native_transport = transport
         return True
 
+    def register_vector(self, x):
+        """Transport "pull" (COLLECTIVE: every rank calls it with its segment of the same vector): the neighbours learn where this rank's
+        x lies -- the IPC handle of its allocation and x's offset in it travel over the process group -- and map it; products with
+        this x then read its boundary planes in place.  apply() calls it for an x it has not seen (all ranks must then see a new x in
+        the same product).  The mapping stays until disable_native()."""
+        import ctypes
+        from . import _capi
+        L = _capi.lib()
+        P = self._pull
+        raw = (ctypes.c_char * 64)(); off = ctypes.c_int64()
+        L.ipc_export(self.dev.index or 0, ctypes.c_void_p(x.data_ptr()), ctypes.cast(raw, ctypes.c_void_p), ctypes.byref(off))
+        mine = torch.cat([torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone(),
+                          torch.tensor([off.value, x.numel()], dtype=torch.int64).view(torch.uint8)])
+        everyone = [mine]
+        if self.world > 1:
+            cdev = self._coll_device()
+            got = [torch.empty(80, dtype=torch.uint8, device=cdev) for _ in range(self.world)]
+            dist.all_gather(got, mine.to(cdev), group=self.group)
+            everyone = [g.cpu() for g in got]
+        item = x.element_size()
+        ptrs = {}
+        for side, peer in (("lower", P["lower"]), ("upper", P["upper"])):
+            if peer < 0:
+                ptrs[side] = None
+                continue
+            rec = everyone[peer if self.world > 1 else 0]
+            hbytes = bytes(rec[:64].numpy().tobytes())
+            poff, pn = [int(v) for v in rec[64:].view(torch.int64)]
+            if peer == self.rank:
+                base = x.data_ptr() - off.value                      # (one rank exchanging with itself: tools/r06_dist_step.py)
+            else:
+                base = P["opened"].get(hbytes)
+                if base is None:
+                    hb = (ctypes.c_char * 64).from_buffer_copy(hbytes); b = ctypes.c_void_p()
+                    L.ipc_open(self.dev.index or 0, ctypes.cast(hb, ctypes.c_void_p), ctypes.byref(b))
+                    base = b.value; P["opened"][hbytes] = base
+            # the lower neighbour's LAST plane, the upper neighbour's FIRST plane
+            ptrs[side] = base + poff + ((pn - P["H"]) * item if side == "lower" else 0)
+        P["vectors"][x.data_ptr()] = (ptrs["lower"], ptrs["upper"])
+        return P["vectors"][x.data_ptr()]
+
     def drop_strip(self):
         """release the references to the strip the constructor was given (only transport "halo" needs them)"""
         self._strip = None
@@ -391,6 +437,7 @@ class DistSpMat:
         return H, lower, upper
 
     def _drop_native(self, step):
+        import ctypes
         from . import _capi
         L = _capi.lib()
         if step:
@@ -402,6 +449,13 @@ class DistSpMat:
             L.ipc_window_destroy(self._window)
             self._window = None
         self._ext = None            # the strip stored with its ghost planes belongs to the step that has just gone
+        P, self._pull = getattr(self, "_pull", None), None
+        if P:
+            for base in P["opened"].values():
+                try:
+                    L.ipc_close(self.dev.index or 0, ctypes.c_void_p(base))
+                except Exception:           # noqa: BLE001 -- the owner may be gone already
+                    pass
 
     def disable_native(self):
         step, self._native = getattr(self, "_native", None), None
@@ -420,7 +474,7 @@ class DistSpMat:
             return None
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _capi.lib().dist_spmv_status(self._native, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
-        return {"timed_out": a.value, "transport": {1: "rccl", 3: "ipc", 4: "halo"}.get(b.value, b.value), "direct": bool(c.value)}
+        return {"timed_out": a.value, "transport": "pull" if getattr(self, "_pull", None) else {1: "rccl", 3: "ipc", 4: "halo"}.get(b.value, b.value), "direct": bool(c.value)}
 
     def rccl_info(self):
         import ctypes
@@ -508,7 +562,13 @@ class DistSpMat:
         if self._native:
             import ctypes
             from . import _capi
-            _capi.lib().dist_spmv_apply(self._native, ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream),
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            if getattr(self, "_pull", None):
+                peers = self._pull["vectors"].get(x.data_ptr()) or self.register_vector(x)
+                _capi.lib().dist_spmv_apply_pull(self._native, stream, float(alpha), int(bool(append)), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                                 ctypes.c_void_p(peers[0]) if peers[0] else None, ctypes.c_void_p(peers[1]) if peers[1] else None)
+                return y
+            _capi.lib().dist_spmv_apply(self._native, stream,
                                         float(alpha), int(bool(append)), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()))
             return y
         reqs = ()

@@ -432,6 +432,8 @@ class SpMat:
         L.spmat_get_info(h, ctypes.byref(info))
         self.info = info
         self.storage = _capi.SPMAT_NAMES[info.format]              # sell8v | sell8 | sell32 | csr
+        self.product = info.product.decode()                       # the kernel a product launches ...
+        self.reason = info.reason.decode()                         # ... and why this storage and that product (csrc/spmat.hip select_product)
         self.dictionary_blocks = int(info.dictionary_blocks)       # > 0: the value-coded slices are stored once per DISTINCT slice
         self.march = ({"lo": int(info.march.lo), "hi": int(info.march.hi), "run": int(info.march.run), "x_last": int(info.march.x_last),
                        "far": [int(info.march.far[k]) for k in range(info.march.nfar)]}
