@@ -466,6 +466,11 @@ int vexhip_spmat_create_f32_p64(int dev, void *stream, int64_t n, const int64_t 
         int format, int flags, vexhip_spmat **out);
 int vexhip_spmat_destroy(vexhip_spmat *A);
 int vexhip_spmat_apply_f64(const vexhip_spmat *A, void *stream, double alpha, int append, const double *x, double *y);
+/* round 6: y = alpha A x + beta z (z != NULL; z may be x or y; x != y) -- what the reference's additive expressions amount to when their vector
+ * part is one vector (vector.hpp:698-801: `y = z - A * x`, a residual, is "y = z" then "y -= A * x": two passes over y; spmat.hpp:120-185).  One
+ * pass where the product takes the addend (the plane product; z == x costs no byte more than y = A x), otherwise y = beta z, then
+ * y += alpha A x.  Per element: round(beta z) + round(alpha (A x)_i), one addition -- the bits of the two-pass form.                       */
+int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *A, void *stream, double alpha, const double *x, double beta, const double *z, double *y);
 int vexhip_spmat_apply_f32(const vexhip_spmat *A, void *stream, float alpha, int append, const float *x, float *y);
 /* Y[k] (=|+=) alpha * A * X[k], k < nrhs, reading the matrix once per group of four (x, y: HOST arrays of device pointers) */
 int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, double alpha, int append, const double *const *x, double *const *y);

@@ -486,6 +486,70 @@ TEST_CASE(spmv_inline_single_queue) {                                // spmv.cpp
     }
 }
 
+// Round 6: `y = z - A * x` and its relatives -- one vector, one product term -- are handed to the product whole
+// (operations.hpp axpby_shape -> SpMat::apply_axpby -> vexhip_spmat_apply_axpby_f64): the plane product adds the vector in its own pass.
+// The reference's two passes ("y = z", then "y -= A * x": vector.hpp:698-801) give the same bits: round(beta z) + round(alpha (A x)_i).
+TEST_CASE(spmv_one_vector_one_product_single_queue) {
+    std::vector<vex::command_queue> queue(1, ctx.queue(0));
+    auto same_bits = [](const std::vector<double> &a, const std::vector<double> &b) { return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) == 0; };
+    // (a) 7-point operator on a 512 x 6 x 8 box: stored by grid line, 512-point lines -> the plane product
+    const size_t nx = 512, ny = 6, nz = 8, N = nx * ny * nz;
+    std::vector<size_t> row(1, 0); std::vector<unsigned> col; std::vector<double> val;
+    for (size_t k = 0; k < nz; ++k) for (size_t j = 0; j < ny; ++j) for (size_t i = 0; i < nx; ++i) {
+        const size_t r = (k * ny + j) * nx + i;
+        const bool inner = i > 0 && i + 1 < nx && j > 0 && j + 1 < ny && k > 0 && k + 1 < nz;
+        if (!inner) { col.push_back((unsigned)r); val.push_back(1.0); }
+        else {
+            const long off[7] = {-(long)(nx * ny), -(long)nx, -1, 0, 1, (long)nx, (long)(nx * ny)};
+            for (int p = 0; p < 7; ++p) { col.push_back((unsigned)((long)r + off[p])); val.push_back(p == 3 ? 6.5 : -1.25); }
+        }
+        row.push_back(col.size());
+    }
+    std::vector<double> x = random_vector<double>(N), z = random_vector<double>(N);
+    auto want = host_spmv(row, col, val, x);
+    setenv("VEXHIP_PLANE_FORCE", "1", 1);
+    vex::SpMat<double, unsigned> A(queue, N, N, row.data(), col.data(), val.data());
+    unsetenv("VEXHIP_PLANE_FORCE");
+    CHECK(A.storage_info(0).plane.usable && std::string(A.storage_info(0).product) == "sell8_plane_kernel");
+    vex::vector<double> X(queue, x), Z(queue, z), Y(queue, N), T(queue, N);
+    std::vector<double> a(N), b(N);
+    Y = Z - A * X;                       T = Z; T -= A * X;
+    vex::copy(Y, a); vex::copy(T, b); CHECK(same_bits(a, b));
+    for (size_t i = 0; i < N; i += 3) CHECK_SMALL(a[i] - (z[i] - want[i]), 1e-12 * 20);
+    Y = X + 2 * vex::make_inline(A * X); T = X; T += 2 * (A * X);
+    vex::copy(Y, a); vex::copy(T, b); CHECK(same_bits(a, b));
+    for (size_t i = 0; i < N; i += 3) CHECK_SMALL(a[i] - (x[i] + 2 * want[i]), 1e-12 * 40);
+    Y = 3 * Z + A * X;                   T = 3 * Z; T += A * X;
+    vex::copy(Y, a); vex::copy(T, b); CHECK(same_bits(a, b));
+    Y = -Z - 2 * (A * X);                T = -Z; T -= 2 * (A * X);
+    vex::copy(Y, a); vex::copy(T, b); CHECK(same_bits(a, b));
+    Y = 0.5 * (A * X) - Z * 0.25;        T = -0.25 * Z; T += 0.5 * (A * X);
+    vex::copy(Y, a); vex::copy(T, b); CHECK(same_bits(a, b));
+    Y = Z; T = Z;
+    Y = Y - A * X;                       T -= A * X;                     // the vector is the target itself
+    vex::copy(Y, a); vex::copy(T, b); CHECK(same_bits(a, b));
+    Y = X - vex::make_inline(A * X);     T = X; T -= A * X;              // the vector is x itself: taken from the registers that hold it
+    vex::copy(Y, a); vex::copy(T, b); CHECK(same_bits(a, b));
+    // views into larger vectors start at odd elements: the product that wants 16-byte addresses declines, the general route runs
+    // (b) an unstructured matrix (32-bit columns): no product that adds a vector -- y = beta z, then y += alpha A x inside the call
+    const size_t n = 4096;
+    std::vector<size_t> r2, c2; std::vector<double> v2;
+    random_matrix(n, n, 16, r2, c2, v2);
+    std::vector<double> x2 = random_vector<double>(n), z2 = random_vector<double>(n);
+    vex::SpMat<double> R(queue, n, n, r2.data(), c2.data(), v2.data());
+    vex::vector<double> X2(queue, x2), Z2(queue, z2), Y2(queue, n), T2(queue, n);
+    std::vector<double> a2(n), b2(n);
+    Y2 = Z2 - R * X2;                    T2 = Z2; T2 -= R * X2;
+    vex::copy(Y2, a2); vex::copy(T2, b2); CHECK(same_bits(a2, b2));
+    Y2 = X2 + 2 * vex::make_inline(R * X2); T2 = X2; T2 += 2 * (R * X2);
+    vex::copy(Y2, a2); vex::copy(T2, b2); CHECK(same_bits(a2, b2));
+    auto w2 = host_spmv(r2, c2, v2, x2);
+    for (size_t i = 0; i < n; ++i) CHECK_CLOSE(a2[i], x2[i] + 2 * w2[i], 1e-8);
+    // float matrices and expressions of any other shape keep the general route
+    Y2 = sin(Z2) - R * X2;               T2 = sin(Z2); T2 -= R * X2;
+    vex::copy(Y2, a2); vex::copy(T2, b2); CHECK(same_bits(a2, b2));
+}
+
 TEST_CASE(sparse_csr_ell_matrix_single_queue) {                      // sparse_matrices.cpp:66-151
     const size_t n = 1024;
     std::vector<vex::command_queue> queue(1, ctx.queue(0));

@@ -618,6 +618,44 @@ def test_storage_by_grid_line_holds_the_matrix(T, oracle, built_lib):
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
 
 
+def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
+    """Round 6, vexhip_spmat_apply_axpby_f64: y = alpha A x + beta z in one call.  The plane product adds the vector in its own pass
+    (z an array of its own, z = y, z = x taken from the registers that hold the centre lines), every other storage runs y = beta z and
+    then y += alpha A x inside the call; both are round(beta z_i) + round(alpha (A x)_i) with (A x)_i summed in CSR order: compared bit
+    for bit with that evaluation on the host (the CSR restatement of spmat/csr.inl:163-170)."""
+    torch = T.torch
+    nx, ny, nz = 512, 6, 8
+    ptr, col, val = _grid7_natural(nx, ny, nz, zero_face=False)
+    m = len(ptr) - 1
+    x = oracle.random_f64(11, m); z = oracle.random_f64(12, m); y0 = oracle.random_f64(13, m)
+    for fmt, force in ((None, True), ("csr", False), ("sell32", False), ("sell8", False)):
+        if force:
+            os.environ["VEXHIP_PLANE_FORCE"] = "1"
+        try:
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)) if fmt is None else T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt=fmt)
+        finally:
+            os.environ.pop("VEXHIP_PLANE_FORCE", None)
+        if force:
+            assert A.plane is not None and A.product == "sell8_plane_kernel", (A.product, A.reason)
+        dx = T.up(x)
+        for alpha, beta in ((1.0, 1.0), (-1.0, 1.0), (2.0, 1.0), (0.5, -0.25), (-3.0, 0.0)):
+            ax = oracle.spmv_csr(ptr, col, val, x, alpha=alpha)
+            # z an array of its own
+            dz, dy = T.up(z), T.up(np.full(m, np.nan))
+            A.apply_axpby(dx, dy, alpha, dz, beta)
+            assert np.array_equal(dy.cpu().numpy(), beta * z + ax), (fmt, alpha, beta, "z")
+            # z = x
+            dy = T.up(np.full(m, np.nan))
+            A.apply_axpby(dx, dy, alpha, dx, beta)
+            assert np.array_equal(dy.cpu().numpy(), beta * x + ax), (fmt, alpha, beta, "z = x")
+            # z = y
+            dy = T.up(y0)
+            A.apply_axpby(dx, dy, alpha, dy, beta)
+            assert np.array_equal(dy.cpu().numpy(), beta * y0 + ax), (fmt, alpha, beta, "z = y")
+    with pytest.raises(Exception):
+        A.apply_axpby(dx, dx, 1.0, dz, 1.0)          # y = x: refused
+
+
 def test_grid_product_fp32_is_bit_identical(T, oracle, built_lib):
     """The fp32 grid product (round 5, grid32.hip: the walk of the fp64 grid product with FOUR rows per lane -- 16-byte requests at
     4-byte addresses, the lane at the end of a line stores 1 .. 3 rows) against the pair product and the fp32 CSR restatement,

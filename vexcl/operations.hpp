@@ -12,6 +12,7 @@
 // Terminals are numbered in traversal order, lhs first, exactly as the
 // reference does (prm_1, prm_2, ...), so generated kernels have the shape of
 // SURVEY appendix A.1 and are cached per expression TYPE per context.
+#include <functional>
 #include <limits>
 #include <set>
 #include <sstream>
@@ -564,6 +565,62 @@ void assign_expression(const LHS &lhs, const RHS &rhs,
     }
 }
 
+// ---- y = [c1 *] z +- [c2 *] (A * x): one vector and one product term (round 6) ---------------------------------------
+// The reference evaluates `y = z - A * x` as "y = z", then "y -= A * x" (vector.hpp:698-801): two passes over y.  Products that can add
+// a vector in the same pass (SpMat::apply_axpby -> include/vexhip.h vexhip_spmat_apply_axpby_f64) take such an expression whole; the
+// same shape with make_inline(A * x) in place of A * x lands there too.  SHAPE is decided at compile time (axpby_shape), the scales and
+// operands are read off at run time (axpby_collect); anything else, or a product that declines, takes the general route below.
+/// A leaf of such an expression: kind 1 = a vector of the target's type (get), kind 2 = a product term (apply), 0 = neither.
+template <class E, class Enable = void> struct axpby_leaf : std::integral_constant<int, 0> {};
+template <class M, class = void> struct has_apply_axpby : std::false_type {};
+template <class M> struct has_apply_axpby<M, typename std::enable_if<M::has_axpby_product>::type> : std::true_type {};
+template <class T> class plain_vector_of { public: typedef void type; };        // vector.hpp: plain_vector_of<vector<T>>::type = T
+
+template <class E, class Enable = void> struct axpby_shape { static constexpr int vectors = 0, terms = 0; static constexpr bool ok = false; };
+template <class E> struct axpby_shape<E, typename std::enable_if<axpby_leaf<E>::value == 1>::type> { static constexpr int vectors = 1, terms = 0; static constexpr bool ok = true; };
+template <class E> struct axpby_shape<E, typename std::enable_if<axpby_leaf<E>::value == 2>::type> { static constexpr int vectors = 0, terms = 1; static constexpr bool ok = true; };
+template <class L, class R> struct axpby_shape<binary_expr<tag::plus, L, R>, void> {
+    static constexpr int vectors = axpby_shape<L>::vectors + axpby_shape<R>::vectors, terms = axpby_shape<L>::terms + axpby_shape<R>::terms;
+    static constexpr bool ok = axpby_shape<L>::ok && axpby_shape<R>::ok; };
+template <class L, class R> struct axpby_shape<binary_expr<tag::minus, L, R>, void> : axpby_shape<binary_expr<tag::plus, L, R>, void> {};
+template <class S, class R> struct axpby_shape<binary_expr<tag::multiplies, scalar_terminal<S>, R>, void> : axpby_shape<R> {};
+template <class L, class S> struct axpby_shape<binary_expr<tag::multiplies, L, scalar_terminal<S>>, typename std::enable_if<!is_scalar_terminal<L>::value>::type> : axpby_shape<L> {};
+template <class A> struct axpby_shape<unary_expr<tag::negate, A>, void> : axpby_shape<A> {};
+
+template <class T> struct axpby_form {
+    const void *z = nullptr; double beta = 0, alpha = 0;
+    std::function<bool(double, double)> term;          // (alpha, beta) -> the product took the expression
+};
+template <class T, class Y, class E> void axpby_collect(axpby_form<T> &f, Y &y, const E &e, double scale);
+template <class T, class Y, class E> struct axpby_visit {
+    static void go(axpby_form<T> &f, Y &y, const E &e, double scale) {
+        if constexpr (axpby_leaf<E>::value == 1) {
+            (void)y;
+            if constexpr (std::is_same<typename E::value_type, T>::value) { f.z = axpby_leaf<E>::get(e); f.beta = scale; } else { (void)e; (void)scale; }
+        }
+        else { f.alpha = scale; f.term = [&f, &y, &e](double a, double b) { return axpby_leaf<E>::apply(e, y, a, f.z, b); }; }
+    }
+};
+template <class T, class Y, class L, class R> struct axpby_visit<T, Y, binary_expr<tag::plus, L, R>> {
+    static void go(axpby_form<T> &f, Y &y, const binary_expr<tag::plus, L, R> &e, double s) { axpby_collect(f, y, e.l, s); axpby_collect(f, y, e.r, s); } };
+template <class T, class Y, class L, class R> struct axpby_visit<T, Y, binary_expr<tag::minus, L, R>> {
+    static void go(axpby_form<T> &f, Y &y, const binary_expr<tag::minus, L, R> &e, double s) { axpby_collect(f, y, e.l, s); axpby_collect(f, y, e.r, -s); } };
+template <class T, class Y, class S, class R> struct axpby_visit<T, Y, binary_expr<tag::multiplies, scalar_terminal<S>, R>> {
+    static void go(axpby_form<T> &f, Y &y, const binary_expr<tag::multiplies, scalar_terminal<S>, R> &e, double s) { axpby_collect(f, y, e.r, s * static_cast<double>(e.l.v)); } };
+template <class T, class Y, class L, class S> struct axpby_visit<T, Y, binary_expr<tag::multiplies, L, scalar_terminal<S>>> {
+    static void go(axpby_form<T> &f, Y &y, const binary_expr<tag::multiplies, L, scalar_terminal<S>> &e, double s) { axpby_collect(f, y, e.l, s * static_cast<double>(e.r.v)); } };
+template <class T, class Y, class A> struct axpby_visit<T, Y, unary_expr<tag::negate, A>> {
+    static void go(axpby_form<T> &f, Y &y, const unary_expr<tag::negate, A> &e, double s) { axpby_collect(f, y, e.a, -s); } };
+template <class T, class Y, class E> void axpby_collect(axpby_form<T> &f, Y &y, const E &e, double scale) { axpby_visit<T, Y, E>::go(f, y, e, scale); }
+
+template <class M, class V> struct axpby_leaf<additive_operator<M, V>, typename std::enable_if<has_apply_axpby<M>::value && !std::is_void<typename plain_vector_of<V>::type>::value>::type>
+    : std::integral_constant<int, 2> {
+    template <class Y> static bool apply(const additive_operator<M, V> &e, Y &y, double alpha, const void *z, double beta) {
+        if constexpr (std::is_same<Y, V>::value) return e.A.apply_axpby(e.x, y, alpha, *static_cast<const Y *>(z), beta);
+        else { (void)e; (void)y; (void)alpha; (void)z; (void)beta; return false; }
+    }
+};
+
 /// Assignment of any assignable expression to an lvalue terminal:
 /// fused kernel for the vector part, SpMat::apply for every A*x term
 /// (vector.hpp:698-801).
@@ -573,6 +630,14 @@ void assign_any(const LHS &lhs, W &target, const Expr &expr,
 {
     constexpr int kind = expr_kind<Expr>::value;
     static_assert(kind >= 0, "this expression cannot be assigned: A*x terms may only be added, subtracted or scaled");
+    typedef typename plain_vector_of<W>::type target_value;
+    if constexpr (std::is_same<OP, assign::SET>::value && !std::is_void<target_value>::value && axpby_shape<Expr>::ok
+                  && axpby_shape<Expr>::vectors == 1 && axpby_shape<Expr>::terms == 1) {
+        // one vector and one product term: the product adds the vector in its own pass, if it can
+        axpby_form<target_value> f;
+        axpby_collect(f, target, expr, 1.0);
+        if (f.z && f.term && f.term(f.alpha, f.beta)) return;
+    }
     if constexpr (kind == 0) {
         constexpr bool lin = std::is_same<OP, assign::SET>::value || std::is_same<OP, assign::ADD>::value || std::is_same<OP, assign::SUB>::value;
         if constexpr (direct_assign<Expr>::value && lin) {

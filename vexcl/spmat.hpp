@@ -156,6 +156,25 @@ class SpMat {
                 }
         }
 
+        static constexpr bool has_axpby_product = true;      // (operations.hpp: `y = z - A * x` is offered to apply_axpby)
+        /// y = alpha * A * x + beta * z in ONE pass, if this matrix can: one device (no ghost exchange), double values, x, y and z three
+        /// vectors of one partition with y != x (round 6: include/vexhip.h vexhip_spmat_apply_axpby_f64 -- the plane product takes the addend;
+        /// other storages run y = beta z, y += alpha A x inside the call).  false: nothing was done, the caller takes the general route.
+        /// What ends up here: `y = z - A * x` (a residual), `y = x + 2 * make_inline(A * x)` (detail::assign_any).
+        template <class T>
+        bool apply_axpby(const vex::vector<T> &x, vex::vector<T> &y, double alpha, const vex::vector<T> &z, double beta) const {
+            if constexpr (!std::is_same<T, double>::value || !std::is_same<val_t, double>::value) { (void)x; (void)y; (void)alpha; (void)z; (void)beta; return false; }
+            else {
+                if (queue.size() != 1 || halo.active() || x.size() != ncols || y.size() != nrows || z.size() != nrows || part[1] == part[0]) return false;
+                const device_part &P = *mtx[0];
+                if (P.loc.empty() || !P.loc.handle || x(0).raw() == y(0).raw()) return false;
+                static const bool off = [] { const char *e = std::getenv("VEXCL_AXPBY"); return e && !std::strcmp(e, "off"); }();
+                if (off) return false;
+                backend::check(vexhip_spmat_apply_axpby_f64(P.loc.handle.get(), queue[0].raw(), alpha, x(0).raw(), beta, z(0).raw(), y(0).raw()));
+                return true;
+            }
+        }
+
         /// The same product with its phases timed per device (HIP events on the primary queues; the call waits for them):
         /// ms[d] = {whole step, local part, wait for the ghosts after the local part, remote part}.  What the multi-device
         /// headline reports next to its wall time (examples/spmv_headline --devices).
@@ -869,6 +888,16 @@ struct inline_spmv : expression_base {
     }
     void get_props(prop_context &p) const {
         if (p.empty()) { p.queue = A.queue_list(); p.part = A.row_partition(); p.size = A.rows(); }
+    }
+};
+} // namespace detail
+
+namespace detail {
+// (operations.hpp: `y = z + c * make_inline(A * x)` is the shape y = beta z + alpha A x as well)
+template <class M, class T> struct axpby_leaf<inline_spmv<M, T>, typename std::enable_if<has_apply_axpby<M>::value>::type> : std::integral_constant<int, 2> {
+    template <class Y> static bool apply(const inline_spmv<M, T> &e, Y &y, double alpha, const void *z, double beta) {
+        if constexpr (std::is_same<Y, vector<T>>::value) return e.A.apply_axpby(e.x, y, alpha, *static_cast<const Y *>(z), beta);
+        else { (void)e; (void)y; (void)alpha; (void)z; (void)beta; return false; }
     }
 };
 } // namespace detail

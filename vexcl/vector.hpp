@@ -392,6 +392,9 @@ struct vector_address : expression_base {
     }
 };
 template <class T> struct expr_kind<vector_address<T>> : std::integral_constant<int, 0> {};
+// (operations.hpp, y = z +- A * x in one pass: a vector terminal is the z of such an expression; the target must be a plain vector)
+template <class T> struct axpby_leaf<vector_ref<T>, void> : std::integral_constant<int, 1> { static const void *get(const vector_ref<T> &e) { return e.v; } };
+template <class T> class plain_vector_of<vector<T>> { public: typedef T type; };
 template <class T> struct is_extra_operand<vector<T> *> : std::true_type {};
 template <class T> struct as_expr<vector<T> *, void> {
     typedef vector_address<T> type;

@@ -43,9 +43,12 @@ namespace {
 // neighbours.  (`consumed` is raised and the step number advanced by halo_signal_kernel behind this launch: a kernel boundary
 // orders every workgroup's reads of the ghost planes before the owners may overwrite them.)
 // (the walk of one workgroup; the kernel below adds what follows it in a HALO launch)
-template <int TY, bool APPEND, int STORE_AUX, bool HALO>
+// ZM, the addend of the result (round 6): 0 none (y = alpha A x); 1 an array `zs` scaled by beta (y = alpha A x + beta zs: '+=' is zs = y,
+// beta = 1; a residual b - A x is zs = b, alpha = -1); 2 beta times x ITSELF, taken from the registers that hold the centre lines (y = x + 2 A x
+// moves not a byte more than y = A x).
+template <int TY, int ZM, int STORE_AUX, bool HALO>
 __device__ __forceinline__
-void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alpha,
+void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alpha, const double *__restrict__ zs, double beta,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
         const plane_dev &pd, const halo_dev &H, [[maybe_unused]] const unsigned long long step_in)
 {
@@ -298,7 +301,7 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
     auto yold = [&](int zz, int l) -> d2 {
         int li = zz * ny + (y0 + l);
         li = li < line_lo ? line_lo : li; li = li >= yline_hi ? yline_hi - 1 : li;
-        return *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(y + (long long)li * PL_ROWS) + lane_b);
+        return *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(zs + (long long)li * PL_ROWS) + lane_b);
     };
 
     // ---- state at the top of the step for plane z (canonical naming) ----
@@ -322,13 +325,14 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(x + ((long long)z_first * ny + (y0 - 1)) * PL_ROWS), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + ((long long)z_first * ny + y0) * PL_ROWS, 0, -1, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(ZM == 1 ? zs : x) + ((long long)z_first * ny + y0) * PL_ROWS, 0, -1, 0x00020000);
 #pragma unroll
     for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
     Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
 #pragma unroll
     for (int l = 0; l < TY; ++l) {
         Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
-        if (APPEND) Yo[l] = yold(z, l);
+        if (ZM == 1) Yo[l] = yold(z, l);
     }
 
     // the lane's sums for tile line l: x at the seven positions from the registers named above
@@ -345,7 +349,7 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
     // fast steps need nothing clamped: planes up to z + 3 inside x, both lines inside y
     int zh = zend;
     {
-        const int a = (line_hi - 1 - TY - y0) / ny - 3, bb = (yline_hi - TY - y0) / ny - (APPEND ? 1 : 0);      // largest z with (z+3) ny + y0 + TY <= xlines - 1 / z ny + y0 + TY - 1 <= nslices - 1 ('+=': the old y is requested one plane ahead -- inside y also when x is longer than y)
+        const int a = (line_hi - 1 - TY - y0) / ny - 3, bb = (yline_hi - TY - y0) / ny - (ZM == 1 ? 1 : 0);      // largest z with (z+3) ny + y0 + TY <= xlines - 1 / z ny + y0 + TY - 1 <= nslices - 1 ('+=': the old y is requested one plane ahead -- inside y also when x is longer than y)
         if (line_hi - 1 - TY - y0 < 0 || yline_hi - TY - y0 < 0) zh = 0;
         else { zh = zh < a + 1 ? zh : a + 1; zh = zh < bb + 1 ? zh : bb + 1; }
     }
@@ -381,16 +385,17 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
                     double s0 = 0.0, s1 = 0.0;
                     if (use_hot[l] & 1ull) { PLANE_HOT_SUMS(s0, s1) } else { PLANE_OTHER_SUMS(s0, s1) }      // uniform
                     o[l].x = alpha * s0; o[l].y = alpha * s1;
-                    if (APPEND) { o[l].x = Yo[l].x + o[l].x; o[l].y = Yo[l].y + o[l].y; }
+                    if (ZM == 1) { o[l].x = beta * Yo[l].x + o[l].x; o[l].y = beta * Yo[l].y + o[l].y; }
+                    if (ZM == 2) { o[l].x = beta * c.x + o[l].x; o[l].y = beta * c.y + o[l].y; }
                 }
 #pragma unroll
                 for (int l = 0; l < TY; ++l) use_hot[l] >>= 1;
 #pragma unroll
                 for (int l = 0; l < TY; ++l)       // written once, not read again by this kernel
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[l]), ry, (int)lane_b, (int)(yo + l * 4096u), STORE_AUX);
-                if (APPEND) {
+                if (ZM == 1) {
 #pragma unroll
-                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)lane_b, (int)(yo + plane_b32 + l * 4096u), 0));
+                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)lane_b, (int)(yo + plane_b32 + l * 4096u), 0));
                 }
                 H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
                 H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * 4096u), 0));
@@ -425,7 +430,8 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
                     PLANE_OTHER_SUMS(s0, s1)
                 }
                 d2 o; o.x = alpha * s0; o.y = alpha * s1;
-                if (APPEND) { o.x = Yo[l].x + o.x; o.y = Yo[l].y + o.y; }
+                if (ZM == 1) { o.x = beta * Yo[l].x + o.x; o.y = beta * Yo[l].y + o.y; }
+                if (ZM == 2) { o.x = beta * c.x + o.x; o.y = beta * c.y + o.y; }
                 __builtin_nontemporal_store(o, reinterpret_cast<d2 *>(reinterpret_cast<char *>(y + (long long)li * PL_ROWS) + lane_b));
             }
         }
@@ -433,7 +439,7 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
         for (int l = 0; l < TY; ++l) {
             Cs[0][l] = Cs[1][l]; Cs[1][l] = Cs[2][l]; Cs[2][l] = Cs[3][l]; Cs[3][l] = ld(z + 3, l + 1);
             Es[0][l] = Es[1][l]; Es[1][l] = edge(z + 2, l + 1);
-            if (APPEND) Yo[l] = yold(z + 1, l);
+            if (ZM == 1) Yo[l] = yold(z + 1, l);
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
@@ -454,17 +460,17 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
 #ifndef VEXHIP_HALO_WAVES
 #define VEXHIP_HALO_WAVES 2
 #endif
-template <int TY, bool APPEND, int STORE_AUX, bool HALO = false>
+template <int TY, int ZM, int STORE_AUX, bool HALO = false>
 __global__ __launch_bounds__(256, (TY == 2 && !HALO) ? 4 : (HALO ? VEXHIP_HALO_WAVES : 2))       // (HALO: a few registers more than 128)
-void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
+void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha, const double *__restrict__ zs, double beta,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
         plane_dev pd, halo_dev H)
 {
     if constexpr (!HALO) {
-        plane_walk<TY, APPEND, STORE_AUX, false>(x, y, alpha, blocks, pool, deltas, values, pd, H, 0ull);
+        plane_walk<TY, ZM, STORE_AUX, false>(x, y, alpha, zs, beta, blocks, pool, deltas, values, pd, H, 0ull);
     } else {
         const unsigned long long step = *H.step;
-        plane_walk<TY, APPEND, STORE_AUX, true>(x, y, alpha, blocks, pool, deltas, values, pd, H, step);
+        plane_walk<TY, ZM, STORE_AUX, true>(x, y, alpha, zs, beta, blocks, pool, deltas, values, pd, H, step);
         halo_finish(H, step);          // the launch's last workgroup raises `consumed` and advances the step number (halo.hpp)
     }
 }
@@ -494,6 +500,45 @@ __global__ void halo_signal_kernel(halo_dev H) {
 }
 
 } // namespace
+} // namespace vexhip
+
+namespace vexhip {
+// y = alpha A x + [zm 1: beta zs | zm 2: beta x] through the plane product (spmat.hip vexhip_spmat_apply_axpby_f64; the exported
+// vexhip_spmv_sell8v_plane_f64_i32 is zm = append, zs = y, beta = 1)
+int plane_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, const double *zs, double beta, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane)
+{
+    VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
+    VEXHIP_REQUIRE(n > 0 && n % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
+    VEXHIP_REQUIRE(plane->table_pitch == 0 || plane->table_pitch >= PL_ROWS + 2, "bad plane plan (table pitch)");
+    VEXHIP_REQUIRE((plane->tile == 2 || plane->tile == 4) && plane->lines_per_plane >= 4 && plane->lines_per_plane % plane->tile == 0 && plane->depth >= 1 && plane->planes >= 1
+                   && (plane->x_last + 1) % PL_ROWS == 0
+                   && ((long long)plane->depth + 4) * plane->lines_per_plane * 4096 < (1ll << 32), "bad plane plan");
+    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "plane product: x and y must be 16-byte aligned");
+    VEXHIP_REQUIRE(zm == 0 || zm == 2 || (zm == 1 && zs && (reinterpret_cast<uintptr_t>(zs) & 15) == 0), "plane product: the addend must be a 16-byte aligned vector");
+    VEXHIP_SET_DEVICE(dev);
+    plane_dev pd;
+    pd.nslices = n / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
+    pd.ny = plane->lines_per_plane; pd.nz = plane->planes; pd.depth = plane->depth;
+    pd.tiles = pd.ny / plane->tile; pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
+    pd.pitch = plane->table_pitch;
+    const long long chunks = (pd.nz + pd.depth - 1) / pd.depth;
+    const long long grid = 8ll * pd.tpx * chunks;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    const int store_kind = plane->store_policy;
+    const char *cpool = static_cast<const char *>(pool);
+    hipStream_t s = as_stream(stream);
+    const halo_dev none = halo_dev();
+#define PLANE_LAUNCH(TY, ZM, AUX) sell8_plane_kernel<TY, ZM, AUX><<<(unsigned)grid, 256, 0, s>>>(x, y, alpha, zs, beta, blocks, cpool, deltas, values, pd, none)
+#define PLANE_AUX(TY, AP) switch (store_kind) { case 1: PLANE_LAUNCH(TY, AP, 18); break; case 2: PLANE_LAUNCH(TY, AP, 17); break; case 3: PLANE_LAUNCH(TY, AP, 0); break; default: PLANE_LAUNCH(TY, AP, 2); }
+    if (plane->tile == 4) { if (zm == 1) { PLANE_AUX(4, 1) } else if (zm == 2) { PLANE_AUX(4, 2) } else { PLANE_AUX(4, 0) } }
+    else { if (zm == 1) { PLANE_AUX(2, 1) } else if (zm == 2) { PLANE_AUX(2, 2) } else { PLANE_AUX(2, 0) } }
+#undef PLANE_AUX
+#undef PLANE_LAUNCH
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 } // namespace vexhip
 
 using namespace vexhip;
@@ -614,8 +659,8 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
     const double *xe = x - (long long)H.z0 * pd.far;
     double *ye = y - (long long)H.z0 * pd.far;
     const char *cpool = static_cast<const char *>(pool);
-    if (append) sell8_plane_kernel<2, true, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
-    else        sell8_plane_kernel<2, false, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
+    if (append) sell8_plane_kernel<2, 1, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, ye, 1.0, blocks, cpool, deltas, values, pd, H);
+    else        sell8_plane_kernel<2, 0, 18, true><<<(unsigned)grid, 256, 0, s>>>(xe, ye, alpha, nullptr, 0.0, blocks, cpool, deltas, values, pd, H);
     VEXHIP_LAUNCH_CHECK();
     if (H.pull != 2 && !H.one_launch) {   // (events: the host advances nothing on the device -- there are no flags to number; one_launch: the last workgroup has done it)
         halo_signal_kernel<<<1, 1, 0, s>>>(H);
@@ -710,34 +755,7 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
 int vexhip_spmv_sell8v_plane_f64_i32(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane)
 {
-    VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
-    VEXHIP_REQUIRE(n > 0 && n % PL_ROWS == 0 && w >= 1 && w <= 8, "bad plane product geometry");
-    VEXHIP_REQUIRE(plane->table_pitch == 0 || plane->table_pitch >= PL_ROWS + 2, "bad plane plan (table pitch)");
-    VEXHIP_REQUIRE((plane->tile == 2 || plane->tile == 4) && plane->lines_per_plane >= 4 && plane->lines_per_plane % plane->tile == 0 && plane->depth >= 1 && plane->planes >= 1
-                   && (plane->x_last + 1) % PL_ROWS == 0
-                   && ((long long)plane->depth + 4) * plane->lines_per_plane * 4096 < (1ll << 32), "bad plane plan");
-    VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "plane product: x and y must be 16-byte aligned");
-    VEXHIP_SET_DEVICE(dev);
-    plane_dev pd;
-    pd.nslices = n / PL_ROWS; pd.xlines = (plane->x_last + 1) / PL_ROWS; pd.x_last = plane->x_last;
-    pd.ny = plane->lines_per_plane; pd.nz = plane->planes; pd.depth = plane->depth;
-    pd.tiles = pd.ny / plane->tile; pd.tpx = (pd.tiles + 7) / 8; pd.hot = plane->hot_block; pd.w = (int)w; pd.far = pd.ny * PL_ROWS;
-    pd.pitch = plane->table_pitch;
-    const long long chunks = (pd.nz + pd.depth - 1) / pd.depth;
-    const long long grid = 8ll * pd.tpx * chunks;
-    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
-    const int store_kind = plane->store_policy;
-    const char *cpool = static_cast<const char *>(pool);
-    hipStream_t s = as_stream(stream);
-    const halo_dev none = halo_dev();
-#define PLANE_LAUNCH(TY, AP, AUX) sell8_plane_kernel<TY, AP, AUX><<<(unsigned)grid, 256, 0, s>>>(x, y, alpha, blocks, cpool, deltas, values, pd, none)
-#define PLANE_AUX(TY, AP) switch (store_kind) { case 1: PLANE_LAUNCH(TY, AP, 18); break; case 2: PLANE_LAUNCH(TY, AP, 17); break; case 3: PLANE_LAUNCH(TY, AP, 0); break; default: PLANE_LAUNCH(TY, AP, 2); }
-    if (plane->tile == 4) { if (append) { PLANE_AUX(4, true) } else { PLANE_AUX(4, false) } }
-    else { if (append) { PLANE_AUX(2, true) } else { PLANE_AUX(2, false) } }
-#undef PLANE_AUX
-#undef PLANE_LAUNCH
-    VEXHIP_LAUNCH_CHECK();
-    return 0;
+    return plane_apply_axpby(dev, stream, n, alpha, append ? 1 : 0, y, 1.0, w, pool, blocks, deltas, values, x, y, plane);
 }
 
 int vexhip_stream_copy_f64(int dev, void *stream, const double *x, double *y, int64_t n)

@@ -54,6 +54,8 @@ int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, co
 int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_plane *out);
 int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
         const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane, halo_dev H);
+int plane_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, const double *zs, double beta, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
 int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
         const vexhip_grid *g, halo_dev H);
 int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
@@ -144,6 +146,11 @@ inline product_choice select_product(const spmat *A, const void *x, const void *
         default:
             return A->csr_ptr64 ? product_choice{P_CSR64, "csr_stream2_kernel", "CSR arrays, 64-bit row pointers"} : product_choice{P_CSR32, "csr_stream2_kernel", "CSR arrays"};
     }
+}
+
+__global__ __launch_bounds__(256) void scale_into_kernel(double *__restrict__ y, const double *z, double beta, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = beta * z[i];                 // (z may be y itself)
 }
 
 template <typename V> struct api;
@@ -579,6 +586,29 @@ int vexhip_spmat_apply_f64(const vexhip_spmat *A, void *stream, double alpha, in
 { return apply<double>(reinterpret_cast<const spmat *>(A), stream, alpha, append, x, y); }
 int vexhip_spmat_apply_f32(const vexhip_spmat *A, void *stream, float alpha, int append, const float *x, float *y)
 { return apply<float>(reinterpret_cast<const spmat *>(A), stream, alpha, append, x, y); }
+
+// y = alpha A x + beta z in ONE pass where the matrix's product can take the addend (the plane product: from z, or -- z == x -- from the
+// registers that hold x anyway), else as y = beta z followed by y += alpha A x: the same two roundings and one addition per element either way.
+int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *h, void *stream, double alpha, const double *x, double beta, const double *z, double *y)
+{
+    const spmat *A = reinterpret_cast<const spmat *>(h);
+    VEXHIP_REQUIRE(A && A->value_type == VEXHIP_F64, "matrix and vector value types differ");
+    VEXHIP_REQUIRE(x && y && z, "NULL argument");
+    VEXHIP_REQUIRE(static_cast<const void *>(x) != static_cast<const void *>(y), "y = alpha A x + beta z: x and y are the same vector");
+    if (A->n == 0) return 0;
+    const product_choice pc = select_product(A, x, y);
+    if (pc.kind == P_PLANE64 && (z == x || (reinterpret_cast<uintptr_t>(z) & 15) == 0))
+        return plane_apply_axpby(A->dev, stream, A->n, alpha, z == x ? 2 : 1, z, beta, A->ell_w, A->direct ? A->grid.table : A->pool,
+                                 A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
+    if (!(z == y && beta == 1.0)) {
+        VEXHIP_SET_DEVICE(A->dev);
+        const long long grid = (A->n + 255) / 256;
+        VEXHIP_REQUIRE(grid < (1ll << 31), "vector too large for one launch");
+        scale_into_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(y, z, beta, (long long)A->n);
+        VEXHIP_LAUNCH_CHECK();
+    }
+    return apply<double>(A, stream, alpha, 1, x, y);
+}
 
 int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, double alpha, int append, const double *const *x, double *const *y)
 { return apply_multi<double>(reinterpret_cast<const spmat *>(A), stream, nrhs, alpha, append, x, y); }
