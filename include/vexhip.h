@@ -471,6 +471,8 @@ int vexhip_spmat_apply_f64(const vexhip_spmat *A, void *stream, double alpha, in
  * pass where the product takes the addend (the plane product; z == x costs no byte more than y = A x), otherwise y = beta z, then
  * y += alpha A x.  Per element: round(beta z) + round(alpha (A x)_i), one addition -- the bits of the two-pass form.                       */
 int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *A, void *stream, double alpha, const double *x, double beta, const double *z, double *y);
+/* 1: that call runs as ONE pass on these vectors; 0: as two (vex::SpMat then keeps its own general route: vexcl/spmat.hpp apply_axpby) */
+int vexhip_spmat_axpby_fused(const vexhip_spmat *A, const void *x, const void *z, const void *y);
 int vexhip_spmat_apply_f32(const vexhip_spmat *A, void *stream, float alpha, int append, const float *x, float *y);
 /* Y[k] (=|+=) alpha * A * X[k], k < nrhs, reading the matrix once per group of four (x, y: HOST arrays of device pointers) */
 int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, double alpha, int append, const double *const *x, double *const *y);

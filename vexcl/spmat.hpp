@@ -159,7 +159,7 @@ class SpMat {
         static constexpr bool has_axpby_product = true;      // (operations.hpp: `y = z - A * x` is offered to apply_axpby)
         /// y = alpha * A * x + beta * z in ONE pass, if this matrix can: one device (no ghost exchange), double values, x, y and z three
         /// vectors of one partition with y != x (round 6: include/vexhip.h vexhip_spmat_apply_axpby_f64 -- the plane product takes the addend;
-        /// other storages run y = beta z, y += alpha A x inside the call).  false: nothing was done, the caller takes the general route.
+        /// other storages decline).  false: nothing was done, the caller takes the general route.
         /// What ends up here: `y = z - A * x` (a residual), `y = x + 2 * make_inline(A * x)` (detail::assign_any).
         template <class T>
         bool apply_axpby(const vex::vector<T> &x, vex::vector<T> &y, double alpha, const vex::vector<T> &z, double beta) const {
@@ -170,6 +170,9 @@ class SpMat {
                 if (P.loc.empty() || !P.loc.handle || x(0).raw() == y(0).raw()) return false;
                 static const bool off = [] { const char *e = std::getenv("VEXCL_AXPBY"); return e && !std::strcmp(e, "off"); }();
                 if (off) return false;
+                // (only where the product takes the addend: elsewhere the general route costs the same or less -- a make_inline terminal keeps
+                //  its product-into-a-vector form, 2.20 against 2.30 ms on the variable-coefficient 512^3 operator)
+                if (!vexhip_spmat_axpby_fused(P.loc.handle.get(), x(0).raw(), z(0).raw(), y(0).raw())) return false;
                 backend::check(vexhip_spmat_apply_axpby_f64(P.loc.handle.get(), queue[0].raw(), alpha, x(0).raw(), beta, z(0).raw(), y(0).raw()));
                 return true;
             }

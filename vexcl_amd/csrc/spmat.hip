@@ -610,6 +610,14 @@ int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *h, void *stream, double alp
     return apply<double>(A, stream, alpha, 1, x, y);
 }
 
+// 1: vexhip_spmat_apply_axpby_f64 on these vectors runs as ONE pass (the product takes the addend); 0: as y = beta z, y += alpha A x
+int vexhip_spmat_axpby_fused(const vexhip_spmat *h, const void *x, const void *z, const void *y)
+{
+    const spmat *A = reinterpret_cast<const spmat *>(h);
+    if (!A || A->value_type != VEXHIP_F64 || !x || !y || !z || x == y || A->n == 0) return 0;
+    return select_product(A, x, y).kind == P_PLANE64 && (z == x || (reinterpret_cast<uintptr_t>(z) & 15) == 0) ? 1 : 0;
+}
+
 int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, double alpha, int append, const double *const *x, double *const *y)
 { return apply_multi<double>(reinterpret_cast<const spmat *>(A), stream, nrhs, alpha, append, x, y); }
 int vexhip_spmat_apply_multi_f32(const vexhip_spmat *A, void *stream, int nrhs, float alpha, int append, const float *const *x, float *const *y)
