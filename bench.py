@@ -1042,6 +1042,26 @@ def main():
         if single and not args.no_secondary:
             sec = {}
             try:
+                # ---- round 6: the product with a vector added in the same pass (vexhip_spmat_apply_axpby_f64): y = x + 2 A x takes x from the
+                # registers that hold it (the bytes of y = A x), a residual r = b - A x reads b as well; both checked against the product
+                if hasattr(A, "apply_axpby") and getattr(A, "handle", None) and A.dtype == torch.float64:
+                    bvec = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 43)
+                    r1 = torch.empty_like(y)
+                    A.apply(x, y)
+                    A.apply_axpby(x, r1, -1.0, bvec, 1.0)
+                    same = bool(torch.equal(r1, bvec - y))
+                    t_res = min(timed_events(torch, lambda: A.apply_axpby(x, r1, -1.0, bvec, 1.0), 40) for _ in range(2))
+                    t_self = min(timed_events(torch, lambda: A.apply_axpby(x, r1, 2.0, x, 1.0), 40) for _ in range(2))
+                    mb = int(A.info.matrix_bytes)
+                    fused = bool(lib().spmat_axpby_fused(A.handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(bvec.data_ptr()), ctypes.c_void_p(r1.data_ptr())))
+                    sec["SpMV + vector in one pass: r = b - A*x, Poisson %d^3 (vexhip_spmat_apply_axpby_f64)" % n] = {
+                        "ms": round(t_res, 5), "one_pass": fused, "bits_equal_b_minus_product": same, "bytes_per_launch": mb + 24 * N,
+                        "frac": round((mb + 24 * N) / t_res / 1e6 / HBM_PEAK_GBPS, 4),
+                        "what": "x once + b once + r once + the stored matrix; the reference's two passes (r = b, then r -= A*x: vector.hpp:698-801) move 40 B per row"}
+                    sec["SpMV + vector in one pass: y = x + 2 A*x, Poisson %d^3 (vexhip_spmat_apply_axpby_f64, the addend is x itself)" % n] = {
+                        "ms": round(t_self, 5), "one_pass": fused, "bytes_per_launch": mb + 16 * N, "frac": round((mb + 16 * N) / t_self / 1e6 / HBM_PEAK_GBPS, 4),
+                        "what": "x once + y once + the stored matrix: the addend comes from the registers that hold the centre lines"}
+                    del bvec, r1
                 # ---- kernels that stream what the metric counts: fp64 values + 32-bit columns, no compression
                 del A
                 torch.cuda.empty_cache()

@@ -624,20 +624,22 @@ def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
     then y += alpha A x inside the call; both are round(beta z_i) + round(alpha (A x)_i) with (A x)_i summed in CSR order: compared bit
     for bit with that evaluation on the host (the CSR restatement of spmat/csr.inl:163-170)."""
     torch = T.torch
-    nx, ny, nz = 512, 6, 8
-    ptr, col, val = _grid7_natural(nx, ny, nz, zero_face=False)
-    m = len(ptr) - 1
-    x = oracle.random_f64(11, m); z = oracle.random_f64(12, m); y0 = oracle.random_f64(13, m)
-    for fmt, force in ((None, True), ("csr", False), ("sell32", False), ("sell8", False)):
+    for (nx, ny, nz), fmt, force, product in (((512, 6, 8), None, True, "sell8_plane_kernel"), ((70, 11, 13), None, True, "sell8_grid_kernel"), ((1030, 5, 9), None, True, "sell8_grid_kernel"),
+                                              ((512, 6, 8), "csr", False, None), ((512, 6, 8), "sell32", False, None), ((512, 6, 8), "sell8", False, None)):
+        ptr, col, val = _grid7_natural(nx, ny, nz, zero_face=False)
+        m = len(ptr) - 1
+        x = oracle.random_f64(11, m); z = oracle.random_f64(12, m); y0 = oracle.random_f64(13, m)
         if force:
             os.environ["VEXHIP_PLANE_FORCE"] = "1"
         try:
             A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)) if fmt is None else T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt=fmt)
         finally:
             os.environ.pop("VEXHIP_PLANE_FORCE", None)
-        if force:
-            assert A.plane is not None and A.product == "sell8_plane_kernel", (A.product, A.reason)
+        if product:
+            assert A.product == product, (A.product, A.reason)
         dx = T.up(x)
+        fused = built_lib.spmat_axpby_fused(A.handle, T.ops._p(dx), T.ops._p(dx), T.ops._p(T.up(y0)))
+        assert bool(fused) == bool(product), (fmt, product, fused)
         for alpha, beta in ((1.0, 1.0), (-1.0, 1.0), (2.0, 1.0), (0.5, -0.25), (-3.0, 0.0)):
             ax = oracle.spmv_csr(ptr, col, val, x, alpha=alpha)
             # z an array of its own

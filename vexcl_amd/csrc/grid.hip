@@ -539,9 +539,10 @@ void grid_probe_kernel(const P *__restrict__ ptr, const int *__restrict__ col, c
 // the STORED grid, whose plane z0 - 1 / z1 (where the device has a neighbour) is a ghost plane: read from the neighbour's x in place
 // (H.lo / H.hi), behind its "x is final" flag where flags order the launches.  The walks are the plan's; the two that touch a ghost
 // plane are dispatched last and wait before they start.
-template <bool APPEND, int STORE_AUX, int MAXT, bool HALO>
+// ZM: the addend of the result (plane.hip): 0 none, 1 beta times the array zs ('+=': zs = y, beta = 1), 2 beta times x itself (from the registers)
+template <int ZM, int STORE_AUX, int MAXT, bool HALO>
 __device__ __forceinline__
-void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alpha,
+void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alpha, const double *__restrict__ zs, double beta,
         const int *__restrict__ line_class, const unsigned char *__restrict__ table, const double *__restrict__ values, const grid_dev &gd,
         const halo_dev &H, [[maybe_unused]] const unsigned long long step)
 {
@@ -645,7 +646,7 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
     auto yold = [&](int zz, int l) -> d2 {
         long long i = ((long long)zz * ny + (y0 + l)) * nx + row0 + 2 * t, j = i + 1;
         i = i < own_lo ? own_lo : i; i = i > n - 1 ? n - 1 : i; j = j < own_lo ? own_lo : j; j = j > n - 1 ? n - 1 : j;
-        d2 r; r.x = y[i]; r.y = y[j];
+        d2 r; r.x = zs[i]; r.y = zs[j];
         return r;
     };
 
@@ -664,13 +665,14 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(x + (((long long)z_first * ny + (y0 - 1)) * nx + row0)), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + (((long long)z_first * ny + y0) * nx + row0), 0, -1, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(ZM == 1 ? zs : x) + (((long long)z_first * ny + y0) * nx + row0), 0, -1, 0x00020000);
 #pragma unroll
     for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
     Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
 #pragma unroll
     for (int l = 0; l < TY; ++l) {
         Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
-        if (APPEND) Yo[l] = yold(z, l);
+        if (ZM == 1) Yo[l] = yold(z, l);
     }
 
     // the lane's sums for tile line l: x at the seven positions from the registers named above
@@ -695,7 +697,7 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
         auto end_for = [&](long long limit, int ahead, int line) -> long long { const long long v = limit - y0 - line; return v < 0 ? 0 : v / ny - ahead + 1; };
         long long e = end_for(xl_in, 3, TY);                                           // x: planes up to z + 3, lines up to the one below the tile
         e = std::min(e, end_for(lines - 1, 0, TY - 1));                               // y: both lines exist
-        if (APPEND) e = std::min(e, end_for(yl_in, 1, TY - 1));
+        if (ZM == 1) e = std::min(e, end_for(yl_in, 1, TY - 1));
         zh = zh < e ? zh : (int)(e < 0 ? 0 : e);
     }
 
@@ -727,7 +729,8 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
                     double s0 = 0.0, s1 = 0.0;
                     if (use_hot[l] & 1ull) { GRID_HOT_SUMS(s0, s1) } else { GRID_OTHER_SUMS(s0, s1) }      // uniform
                     o[l].x = alpha * s0; o[l].y = alpha * s1;
-                    if (APPEND) { o[l].x = Yo[l].x + o[l].x; o[l].y = Yo[l].y + o[l].y; }
+                    if (ZM == 1) { o[l].x = beta * Yo[l].x + o[l].x; o[l].y = beta * Yo[l].y + o[l].y; }
+                    if (ZM == 2) { o[l].x = beta * c.x + o[l].x; o[l].y = beta * c.y + o[l].y; }
                 }
 #pragma unroll
                 for (int l = 0; l < TY; ++l) use_hot[l] >>= 1;
@@ -737,9 +740,9 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
                         if (full) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[l]), ry, (int)lane_b, (int)(yo + l * line_b), STORE_AUX);
                         else if (half) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, o[l].x), ry, (int)lane_b, (int)(yo + l * line_b), STORE_AUX);
                     }
-                if (APPEND) {
+                if (ZM == 1) {
 #pragma unroll
-                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)lane_b, (int)(yo + plane_b32 + l * line_b), 0));
+                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)lane_b, (int)(yo + plane_b32 + l * line_b), 0));
                 }
                 H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
                 H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * line_b), 0));
@@ -774,7 +777,8 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
                     GRID_OTHER_SUMS(s0, s1)
                 }
                 d2 o; o.x = alpha * s0; o.y = alpha * s1;
-                if (APPEND) { o.x = Yo[l].x + o.x; o.y = Yo[l].y + o.y; }
+                if (ZM == 1) { o.x = beta * Yo[l].x + o.x; o.y = beta * Yo[l].y + o.y; }
+                if (ZM == 2) { o.x = beta * c.x + o.x; o.y = beta * c.y + o.y; }
                 double *yr = y + li * nx + row0 + 2 * t;
                 if (full || half) __builtin_nontemporal_store(o.x, yr);
                 if (full) __builtin_nontemporal_store(o.y, yr + 1);
@@ -784,7 +788,7 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
         for (int l = 0; l < TY; ++l) {
             Cs[0][l] = Cs[1][l]; Cs[1][l] = Cs[2][l]; Cs[2][l] = Cs[3][l]; Cs[3][l] = ld(z + 3, l + 1);
             Es[0][l] = Es[1][l]; Es[1][l] = edge(z + 2, l + 1);
-            if (APPEND) Yo[l] = yold(z + 1, l);
+            if (ZM == 1) Yo[l] = yold(z + 1, l);
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
@@ -795,17 +799,17 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
 #undef GRID_OTHER_SUMS
 }
 
-template <bool APPEND, int STORE_AUX, int MAXT, bool HALO = false>
+template <int ZM, int STORE_AUX, int MAXT, bool HALO = false>
 __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 2)
-void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha,
+void sell8_grid_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha, const double *__restrict__ zs, double beta,
         const int *__restrict__ line_class, const unsigned char *__restrict__ table, const double *__restrict__ values, grid_dev gd, halo_dev H)
 {
     if constexpr (!HALO) {
-        grid_walk<APPEND, STORE_AUX, MAXT, false>(x, y, alpha, line_class, table, values, gd, H, 0ull);
+        grid_walk<ZM, STORE_AUX, MAXT, false>(x, y, alpha, zs, beta, line_class, table, values, gd, H, 0ull);
     } else {
         const unsigned long long step = *H.step;
         halo_announce(H, step);
-        grid_walk<APPEND, STORE_AUX, MAXT, true>(x, y, alpha, line_class, table, values, gd, H, step);
+        grid_walk<ZM, STORE_AUX, MAXT, true>(x, y, alpha, zs, beta, line_class, table, values, gd, H, step);
         halo_finish(H, step);
     }
 }
@@ -1069,6 +1073,11 @@ int grid_build_p64(int dev, void *stream, int64_t rows, const long long *ptr, co
 
 using namespace vexhip;
 
+namespace vexhip {
+int grid_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, const double *zs, double beta, const double *values,
+        const double *x, double *y, const vexhip_grid *g);
+}
+
 extern "C" {
 
 #define GP_DECLINE(k) do { if (env(ENV_VEXHIP_DEBUG)) std::fprintf(stderr, "grid plan from the SELL-512 storage: declined at check %d (grid.hip:%d)\n", (k), __LINE__); return 0; } while (0)
@@ -1197,10 +1206,21 @@ int vexhip_sell8_grid_check(const vexhip_grid *g, int64_t n)
 int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, int append, const double *values,
         const double *x, double *y, const vexhip_grid *g)
 {
+    return grid_apply_axpby(dev, stream, n, alpha, append ? 1 : 0, y, 1.0, values, x, y, g);
+}
+
+} // extern "C"
+
+namespace vexhip {
+// y = alpha A x + [zm 1: beta zs | zm 2: beta x] through the grid product (spmat.hip vexhip_spmat_apply_axpby_f64)
+int grid_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, const double *zs, double beta, const double *values,
+        const double *x, double *y, const vexhip_grid *g)
+{
     VEXHIP_REQUIRE(g && g->usable && g->line_class && g->table && values && x && y, "bad grid product arguments");
     if (int rc = vexhip_sell8_grid_check(g, n)) return rc;
     VEXHIP_REQUIRE(g->x_last + 1 >= n, "bad grid plan");
     VEXHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "grid product: x and y must be 8-byte aligned");
+    VEXHIP_REQUIRE(zm == 0 || zm == 2 || (zm == 1 && zs && (reinterpret_cast<uintptr_t>(zs) & 7) == 0), "grid product: the addend must be an 8-byte aligned vector");
     VEXHIP_SET_DEVICE(dev);
     grid_dev gd;
     gd.lines = n / g->nx; gd.x_last = g->x_last; gd.n = n;
@@ -1213,19 +1233,17 @@ int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, 
     const unsigned char *tb = static_cast<const unsigned char *>(g->table);
     hipStream_t s = as_stream(stream);
     const halo_dev none = halo_dev();
-#define GRID_LAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd, none); \
-                               else sell8_grid_kernel<AP, AUX, 256><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd, none); }
+#define GRID_LAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, zs, beta, g->line_class, tb, values, gd, none); \
+                               else sell8_grid_kernel<AP, AUX, 256><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(x, y, alpha, zs, beta, g->line_class, tb, values, gd, none); }
 #define GRID_AUX(AP) switch (g->store_policy) { case 1: GRID_LAUNCH(AP, 18); break; case 2: GRID_LAUNCH(AP, 17); break; case 3: GRID_LAUNCH(AP, 0); break; default: GRID_LAUNCH(AP, 2); }
-    if (append) { GRID_AUX(true) } else { GRID_AUX(false) }
+    if (zm == 1) { GRID_AUX(1) } else if (zm == 2) { GRID_AUX(2) } else { GRID_AUX(0) }
 #undef GRID_AUX
 #undef GRID_LAUNCH
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
 
-} // extern "C"
 
-namespace vexhip {
 // One device's product step in one launch on a matrix stored by grid line with lines of ANY length (halo.hpp, the pull form): the
 // grid product over the planes [H.z0, H.z1) of the stored grid of n_ext rows; x and y are the device's own segments.
 int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
@@ -1254,10 +1272,10 @@ int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int app
     const double *xe = x - (long long)H.z0 * plane;            // the kernel addresses x and y in the numbering of the stored grid
     double *ye = y - (long long)H.z0 * plane;
     const unsigned char *tb = static_cast<const unsigned char *>(g->table);
-#define GRID_HLAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512, true><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(xe, ye, alpha, g->line_class, tb, values, gd, H); \
-                                else sell8_grid_kernel<AP, AUX, 256, true><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(xe, ye, alpha, g->line_class, tb, values, gd, H); }
+#define GRID_HLAUNCH(AP, AUX) { if (g->threads > 256) sell8_grid_kernel<AP, AUX, 512, true><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(xe, ye, alpha, ye, 1.0, g->line_class, tb, values, gd, H); \
+                                else sell8_grid_kernel<AP, AUX, 256, true><<<(unsigned)grid, (unsigned)g->threads, 0, s>>>(xe, ye, alpha, ye, 1.0, g->line_class, tb, values, gd, H); }
 #define GRID_HAUX(AP) switch (g->store_policy) { case 1: GRID_HLAUNCH(AP, 18); break; case 2: GRID_HLAUNCH(AP, 17); break; case 3: GRID_HLAUNCH(AP, 0); break; default: GRID_HLAUNCH(AP, 2); }
-    if (append) { GRID_HAUX(true) } else { GRID_HAUX(false) }
+    if (append) { GRID_HAUX(1) } else { GRID_HAUX(0) }
 #undef GRID_HAUX
 #undef GRID_HLAUNCH
     VEXHIP_LAUNCH_CHECK();

@@ -56,6 +56,8 @@ int plane_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int ap
         const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane, halo_dev H);
 int plane_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, const double *zs, double beta, int64_t w, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
+int grid_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, const double *zs, double beta, const double *values,
+        const double *x, double *y, const vexhip_grid *g);
 int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
         const vexhip_grid *g, halo_dev H);
 int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
@@ -137,7 +139,7 @@ inline product_choice select_product(const spmat *A, const void *x, const void *
                 return f64 ? product_choice{P_GRID64, "sell8_grid_kernel", A->plane.usable ? "plane plan, but x or y is not 16-byte aligned: the grid product addresses by element" : "grid plan (lines of any length)"}
                            : product_choice{P_GRID32, "sell8_grid_f32_kernel", "grid plan (lines of any length), float"};
             if (A->blocks) return {P_MARCH, A->march.usable ? "sell8_march_kernel" : "sell8_pair_kernel", A->march.usable ? "slice dictionary + march plan" : "slice dictionary, no march plan: pair product on dictionary blocks"};
-            return {P_PAIR_CODES, "sell8_pair_kernel", "value codes, one code block per slice"};
+            return {P_PAIR_CODES, A->ell_w <= 8 ? "sell8_pair_kernel" : "sell8v_kernel", "value codes, one code block per slice"};
         case VEXHIP_SPMAT_SELL8:
             if (A->blocks) return {P_PAIR_DICT_VALUES, "sell8_pair_kernel", "diagonal codes from the slice dictionary, values streamed"};
             return {P_PAIR_VALUES, A->ell_w <= 8 ? "sell8_pair_kernel" : "sell8_kernel", "diagonal codes + values streamed per slice"};
@@ -600,6 +602,8 @@ int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *h, void *stream, double alp
     if (pc.kind == P_PLANE64 && (z == x || (reinterpret_cast<uintptr_t>(z) & 15) == 0))
         return plane_apply_axpby(A->dev, stream, A->n, alpha, z == x ? 2 : 1, z, beta, A->ell_w, A->direct ? A->grid.table : A->pool,
                                  A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
+    if (pc.kind == P_GRID64 && (reinterpret_cast<uintptr_t>(z) & 7) == 0)
+        return grid_apply_axpby(A->dev, stream, A->n, alpha, z == x ? 2 : 1, z, beta, (const double *)A->values, x, y, &A->grid);
     if (!(z == y && beta == 1.0)) {
         VEXHIP_SET_DEVICE(A->dev);
         const long long grid = (A->n + 255) / 256;
@@ -615,7 +619,8 @@ int vexhip_spmat_axpby_fused(const vexhip_spmat *h, const void *x, const void *z
 {
     const spmat *A = reinterpret_cast<const spmat *>(h);
     if (!A || A->value_type != VEXHIP_F64 || !x || !y || !z || x == y || A->n == 0) return 0;
-    return select_product(A, x, y).kind == P_PLANE64 && (z == x || (reinterpret_cast<uintptr_t>(z) & 15) == 0) ? 1 : 0;
+    const product_kind k = select_product(A, x, y).kind;
+    return (k == P_PLANE64 && (z == x || (reinterpret_cast<uintptr_t>(z) & 15) == 0)) || (k == P_GRID64 && (reinterpret_cast<uintptr_t>(z) & 7) == 0) ? 1 : 0;
 }
 
 int vexhip_spmat_apply_multi_f64(const vexhip_spmat *A, void *stream, int nrhs, double alpha, int append, const double *const *x, double *const *y)
