@@ -774,7 +774,10 @@ def main():
                             "into the consumers' windows, step-numbered flags, no communicator",
                      "halo": "vexhip_dist_spmv_apply, ONE product launch per step (vexhip_dist_spmv_create_halo): the strip stored with its two ghost "
                              "planes, the plane product reads them from the peer-mapped window behind the owners' flags and its first workgroups "
-                             "push the rank's boundary planes; no second stream, no remote part"}[chosen]
+                             "push the rank's boundary planes; no second stream, no remote part",
+                     "pull": "vexhip_dist_spmv_apply_pull, ONE product launch per step (vexhip_dist_spmv_create_halo_pull): the strip stored with its two "
+                             "ghost planes, read IN PLACE from the neighbours' x (their allocations mapped through IPC handles) behind 'x is final' flags; "
+                             "nothing is pushed"}.get(chosen, chosen)
     torch.cuda.synchronize()
 
     def barrier():
