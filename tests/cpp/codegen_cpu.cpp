@@ -2,6 +2,7 @@
 //  and compiled for gfx950 with hiprtc (no GPU needed).
 #define VEX_TEST_CPU_ONLY
 #include "vex_test.hpp"
+#include <tuple>
 #undef ctx
 
 using namespace vex;
@@ -361,6 +362,29 @@ TEST_CASE(short_vector_types_compile) {                              // types.hp
     CHECK(has(s, "threefry_ulong_4_20") && has(s, "typedef T T##8 __attribute__((ext_vector_type(8)))"));
     backend::check_sources(s);
     backend::check_sources(src_of<assign::SET>(d2, d2 * x + d2));               // short vector with scalar operands
+}
+
+// Round 6: which right-hand sides are handed to a product whole (operations.hpp axpby_shape: one vector + one product term, plus / minus /
+// negation / scalar factors only) -- decided at compile time, checked here without a device.
+TEST_CASE(one_vector_one_product_shapes) {
+    using detail::axpby_shape;
+    vector<double> x, z; SpMat<double> A;
+    // (the expressions are only NAMED -- decltype --, never built: make_inline wants a vector that lives on a device)
+#define SHAPE(...) std::make_tuple(axpby_shape<typename std::decay<decltype(__VA_ARGS__)>::type>::ok, axpby_shape<typename std::decay<decltype(__VA_ARGS__)>::type>::vectors, axpby_shape<typename std::decay<decltype(__VA_ARGS__)>::type>::terms)
+    CHECK(SHAPE(z - A * x) == std::make_tuple(true, 1, 1));
+    CHECK(SHAPE(3 * z + A * x) == std::make_tuple(true, 1, 1));
+    CHECK(SHAPE(-z - 2 * (A * x)) == std::make_tuple(true, 1, 1));
+    CHECK(SHAPE(0.5 * (A * x) - z * 0.25) == std::make_tuple(true, 1, 1));
+    CHECK(SHAPE(x + 2 * make_inline(A * x)) == std::make_tuple(true, 1, 1));
+    CHECK(SHAPE(z + x - A * x) == std::make_tuple(true, 2, 1));                 // two vectors: the general route
+    CHECK(SHAPE(z - A * x - A * z) == std::make_tuple(true, 1, 2));             // two products
+    CHECK(!std::get<0>(SHAPE(sin(z) - A * x)));                                 // a function of a vector
+    CHECK(!std::get<0>(SHAPE(z * x + make_inline(A * x))));                     // a product of vectors
+    CHECK(!std::get<0>(SHAPE(x * make_inline(A * x))));
+    vector<float> xf; SpMat<float> Af;                                          // float matrices: the shape matches, SpMat::apply_axpby declines at run time
+    CHECK(SHAPE(xf - Af * xf) == std::make_tuple(true, 1, 1));
+#undef SHAPE
+    (void)x; (void)z; (void)A; (void)xf; (void)Af;
 }
 
 TEST_CASE(partition_and_util) {
