@@ -138,7 +138,7 @@ inline product_choice select_product(const spmat *A, const void *x, const void *
             if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
                 return f64 ? product_choice{P_GRID64, "sell8_grid_kernel", A->plane.usable ? "plane plan, but x or y is not 16-byte aligned: the grid product addresses by element" : "grid plan (lines of any length)"}
                            : product_choice{P_GRID32, "sell8_grid_f32_kernel", "grid plan (lines of any length), float"};
-            if (A->blocks) return {P_MARCH, A->march.usable ? "sell8_march_kernel" : "sell8_pair_kernel", A->march.usable ? "slice dictionary + march plan" : "slice dictionary, no march plan: pair product on dictionary blocks"};
+            if (A->blocks) return {P_MARCH, A->march.usable ? "sell8_march_kernel" : (A->ell_w <= 8 ? "sell8_pair_kernel" : "sell8v_kernel"), A->march.usable ? "slice dictionary + march plan" : "slice dictionary, no march plan: the codes of the distinct slices from the pool"};
             return {P_PAIR_CODES, A->ell_w <= 8 ? "sell8_pair_kernel" : "sell8v_kernel", "value codes, one code block per slice"};
         case VEXHIP_SPMAT_SELL8:
             if (A->blocks) return {P_PAIR_DICT_VALUES, "sell8_pair_kernel", "diagonal codes from the slice dictionary, values streamed"};
@@ -229,7 +229,9 @@ template <> struct api<float> {
 int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool whole_slice)
 {
     const int64_t ns = (A->n + 511) / 512, stride = A->sell_bytes / ns;
-    if ((flags & VEXHIP_SPMAT_NO_DICTIONARY) || ns < 64 || A->ell_w > 8) return 0;
+    // (round 6: also wider than eight columns -- a constant-coefficient 27-point operator keeps 28 KiB of codes per DISTINCT slice instead of
+    //  54 bytes per row; the march and plane plans are for the 7-point pattern)
+    if ((flags & VEXHIP_SPMAT_NO_DICTIONARY) || ns < 64 || A->ell_w > 32 || (A->ell_w > 8 && !whole_slice)) return 0;
     hipStream_t s = as_stream(stream);
     const int64_t cap = 128;
     void *big = nullptr; int64_t nb = -1;
@@ -244,7 +246,7 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
         if (e != hipSuccess) return check(e, __FILE__, __LINE__);
         A->dict_blocks = nb; A->code_bytes = code_bytes;
         if (whole_slice) { (void)hipFree(A->sell); A->sell = nullptr; A->sell_bytes = 0; }
-        if (whole_slice && !(flags & VEXHIP_SPMAT_NO_MARCH)) {
+        if (whole_slice && A->ell_w <= 8 && !(flags & VEXHIP_SPMAT_NO_MARCH)) {
             const int vb = A->value_type == VEXHIP_F64 ? 8 : 4;
             if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, vb,
                                                   &A->trav, std::max<int64_t>(vexhip_sell8_last_fill_max_col(), ((flags & VEXHIP_SPMAT_SQUARE) ? A->n : 0) - 1), &A->march)) return rc2;
