@@ -618,6 +618,51 @@ def test_storage_by_grid_line_holds_the_matrix(T, oracle, built_lib):
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
 
 
+def _stencil27_const(g):
+    """constant-coefficient 27-point operator on g^3, identity rows on the boundary, columns ascending"""
+    N = g ** 3
+    idx = np.arange(N, dtype=np.int64)
+    i, j, k = idx % g, (idx // g) % g, idx // (g * g)
+    inner = (i > 0) & (i < g - 1) & (j > 0) & (j < g - 1) & (k > 0) & (k < g - 1)
+    ptr = np.zeros(N + 1, dtype=np.int64); ptr[1:] = np.cumsum(np.where(inner, 27, 1))
+    col = np.empty(ptr[-1], dtype=np.int32); val = np.empty(ptr[-1], dtype=np.float64)
+    b = ptr[:-1][inner]; e = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                col[b + e] = (idx[inner] + dz * g * g + dy * g + dx).astype(np.int32)
+                val[b + e] = 26.0 if (dx, dy, dz) == (0, 0, 0) else -1.0 - 0.125 * (dx == 0) - 0.25 * (dy == 0)
+                e += 1
+    col[ptr[:-1][~inner]] = idx[~inner].astype(np.int32); val[ptr[:-1][~inner]] = 1.0
+    return ptr.astype(np.int32), col, val
+
+
+def test_wide_value_coded_slices_share_a_dictionary(T, oracle, built_lib):
+    """Round 6: value-coded SELL-512 slices WIDER than eight columns (a constant-coefficient 27-point operator: 27 diagonals, a handful of
+    values) are pooled in the slice dictionary too -- 28 KiB of codes per distinct slice instead of 54 bytes per row (320^3: 1.06 -> 0.60 ms,
+    profiles/r06_widen_probe.json).  Product, '+=', the multi-vector product: bit for bit the CSR loop."""
+    for g in (64, 40):
+        ptr, col, val = _stencil27_const(g)
+        m = len(ptr) - 1
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        assert A.storage == "sell8v" and int(A.info.ell_width) == 27, (A.storage, A.reason)
+        assert A.dictionary_blocks > 0 and A.product == "sell8v_kernel", (A.dictionary_blocks, A.product, A.reason)
+        x = oracle.random_f64(21, m); y0 = oracle.random_f64(22, m)
+        y = T.up(np.full(m, np.nan)); A.apply(T.up(x), y)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
+        y = T.up(y0); A.apply(T.up(x), y, -0.5, True)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x, y=y0.copy(), alpha=-0.5, append=True))
+        xs = [oracle.random_f64(30 + k, m) for k in range(3)]
+        ys = [T.up(np.full(m, np.nan)) for _ in range(3)]
+        A.apply_multi([T.up(v) for v in xs], ys)
+        for v, w in zip(xs, ys):
+            assert np.array_equal(w.cpu().numpy(), oracle.spmv_csr(ptr, col, val, v))
+        B = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), dictionary=False)          # one code block per slice: the same bits
+        assert B.dictionary_blocks == 0
+        y = T.up(np.full(m, np.nan)); B.apply(T.up(x), y)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
+
+
 def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
     """Round 6, vexhip_spmat_apply_axpby_f64: y = alpha A x + beta z in one call.  The plane product adds the vector in its own pass
     (z an array of its own, z = y, z = x taken from the registers that hold the centre lines), every other storage runs y = beta z and
