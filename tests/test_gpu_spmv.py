@@ -639,7 +639,7 @@ def _stencil27_const(g):
 
 def test_wide_value_coded_slices_share_a_dictionary(T, oracle, built_lib):
     """Round 6: value-coded SELL-512 slices WIDER than eight columns (a constant-coefficient 27-point operator: 27 diagonals, a handful of
-    values) are pooled in the slice dictionary too -- 28 KiB of codes per distinct slice instead of 54 bytes per row (320^3: 1.06 -> 0.60 ms,
+    values) are pooled in the slice dictionary too -- 28 KiB of codes per distinct slice instead of 54 bytes per row (320^3: 1.06 -> 0.52 ms with the eight-column trips of the any-width kernel,
     profiles/r06_widen_probe.json).  Product, '+=', the multi-vector product: bit for bit the CSR loop."""
     for g in (64, 40):
         ptr, col, val = _stencil27_const(g)

@@ -380,7 +380,32 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
                 if (code < S8_FIRST_PAD) sum[q] += s_value[(vc[j >> 1] >> sh) & 255u] * xv[j][q];
             }
     } else {
-        for (int j = 0; j < w; ++j) {
+        // any width (round 6: eight columns per trip -- their four code words, then their sixteen elements of x, are requested before the
+        // first product; with one column per trip a 27-point row waited for memory 27 times: 0.60 -> see profiles/r06_widen_probe_unrolled.json).
+        // Sums in column order, as before.
+        int j = 0;
+        for (; j + 8 <= w; j += 8) {
+            unsigned c[4], vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c[u] = cw[((j >> 1) + u) * 256]; vc[u] = vw[((j >> 1) + u) * 256]; }
+            V xv[8][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned code = (c[u >> 1] >> (8 * ((u & 1) * 2 + q))) & 255u;
+                    xv[u][q] = (code < S8_FIRST_PAD) ? x[i + q + s_delta[code]] : V(0);
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int sh = 8 * ((u & 1) * 2 + q);
+                    const unsigned code = (c[u >> 1] >> sh) & 255u;
+                    if (code < S8_FIRST_PAD) sum[q] += s_value[(vc[u >> 1] >> sh) & 255u] * xv[u][q];
+                }
+        }
+        for (; j < w; ++j) {
             const unsigned cword = cw[(j >> 1) * 256], vword = vw[(j >> 1) * 256];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
