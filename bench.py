@@ -340,6 +340,39 @@ def unstructured_rows(torch, ops, dev, args):
     except Exception as e:  # noqa: BLE001 -- a secondary row
         rows["SpMV 5-point 2-D"] = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
+    # ---- round 6: structured operators OUTSIDE the grid storage's pattern -- 2-D rows that are not whole 512-point lines (march product of
+    # the SELL-512 storage) and a constant-coefficient 27-point operator (value-coded slices of width 27, pooled in the slice dictionary)
+    for name, make in (("SpMV 5-point 2-D 12000^2 (y = A*x, default vexhip_spmat)", lambda: U.stencil2d(12000, 12000, dev)[:3]),
+                       ("SpMV 27-point constant coefficients 320^3 (y = A*x, default vexhip_spmat)", lambda: U.stencil27_const(320, dev))):
+        try:
+            ptr, col, val = make()
+            nr, nz_ = ptr.numel() - 1, int(col.numel())
+            xs = ops.fill_hash(torch.empty(nr, dtype=torch.float64, device=dev), 42)
+            ys = torch.empty_like(xs)
+            A = ops.SpMat(ptr, col, val)
+            A.apply(xs, ys)
+            yr, mag = U.reference_product(ptr, col, val, xs)
+            bad = int(((ys - yr).abs() > 1e-10 * mag).sum())
+            assert bad == 0, "%s: %d rows outside 1e-10 * sum|terms|" % (name, bad)
+            del yr, mag, ptr, col, val
+            A.ptr = A.col = A.val = None
+            torch.cuda.empty_cache()
+            t = min(timed_events(torch, lambda: A.apply(xs, ys), 20) for _ in range(3))
+            moved = A.matrix_bytes() + 16 * nr
+            alg = 12 * nz_ + 4 * (nr + 1) + 16 * nr
+            rows[name] = {"rows": nr, "nnz": nz_, "storage": A.storage, "kernel": A.product, "selection": A.reason, "dictionary_blocks": A.dictionary_blocks,
+                          "ms": round(t, 5), "gflops": round(2.0 * nz_ / t / 1e6, 1), "rows_outside_tolerance": bad,
+                          "roofline": {"bound": "hbm", "bytes_per_launch": moved, "achieved": round(moved / t / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": round(moved / t / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": alg, "algorithmic_gbps": round(alg / t / 1e6, 1),
+                                       "what": "stored matrix (pooled code blocks + 4 B per slice) + x once + y once; the kernel gathers x per entry through the L1 (5 / 27 "
+                                               "16-byte requests per row pair): bound there, not by these bytes"}}
+            del A, xs, ys
+            torch.cuda.empty_cache()
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001 -- a secondary row
+            rows[name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
     # ---- round 5: the headline operator in fp32 (plane32.hip: the plane walk with four rows per lane; the march product took
     # float matrices until then) -- bit-compared with the library's CSR loop on the same arrays
     try:

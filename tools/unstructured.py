@@ -80,6 +80,33 @@ def stencil27(n, dev, seed=4):
     return ptr64.to(torch.int32), col, val
 
 
+def stencil27_const(g, dev):
+    """round 6: a CONSTANT-coefficient 27-point operator on g^3 (centre 26, the 26 neighbours -1; identity rows on the boundary): 27 diagonals,
+    three values -- the slices repeat, so the value-coded SELL-512 storage pools them in its dictionary."""
+    N = g ** 3
+    r = torch.arange(N, device=dev, dtype=torch.int32)
+    ix, iy, iz = r % g, (r // g) % g, r // (g * g)
+    inner = (ix > 0) & (ix < g - 1) & (iy > 0) & (iy < g - 1) & (iz > 0) & (iz < g - 1)
+    del ix, iy, iz
+    ptr64 = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.where(inner, 27, 1), 0, out=ptr64[1:])
+    nnz = int(ptr64[-1])
+    assert nnz < 2 ** 31
+    col = torch.empty(nnz, dtype=torch.int32, device=dev); val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    b = ptr64[:-1]
+    bi, ri = b[inner], r[inner]
+    k = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                col[bi + k] = ri + (dz * g * g + dy * g + dx)
+                val[bi + k] = 26.0 if (dx, dy, dz) == (0, 0, 0) else -1.0
+                k += 1
+    del bi, ri
+    col[b[~inner]] = r[~inner]; val[b[~inner]] = 1.0
+    return ptr64.to(torch.int32), col, val
+
+
 def reference_product(ptr, col, val, x):
     """(y, sum |terms| per row) without a matrix kernel."""
     n = ptr.numel() - 1
