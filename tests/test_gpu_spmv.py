@@ -661,6 +661,10 @@ def test_wide_value_coded_slices_share_a_dictionary(T, oracle, built_lib):
         assert B.dictionary_blocks == 0
         y = T.up(np.full(m, np.nan)); B.apply(T.up(x), y)
         assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
+        # Inf / NaN in x where no entry of a row looks: never multiplied
+        xi = x.copy(); xi[0] = np.inf; xi[m - 1] = np.nan
+        y = T.up(np.full(m, np.nan)); A.apply(T.up(xi), y)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xi), equal_nan=True)
 
 
 def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
