@@ -471,6 +471,7 @@ int vexhip_spmat_apply_f64(const vexhip_spmat *A, void *stream, double alpha, in
  * pass where the product takes the addend (the plane product; z == x costs no byte more than y = A x), otherwise y = beta z, then
  * y += alpha A x.  Per element: round(beta z) + round(alpha (A x)_i), one addition -- the bits of the two-pass form.                       */
 int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *A, void *stream, double alpha, const double *x, double beta, const double *z, double *y);
+int vexhip_spmat_apply_axpby_f32(const vexhip_spmat *A, void *stream, float alpha, const float *x, float beta, const float *z, float *y);
 /* 1: that call runs as ONE pass on these vectors; 0: as two (vex::SpMat then keeps its own general route: vexcl/spmat.hpp apply_axpby) */
 int vexhip_spmat_axpby_fused(const vexhip_spmat *A, const void *x, const void *z, const void *y);
 int vexhip_spmat_apply_f32(const vexhip_spmat *A, void *stream, float alpha, int append, const float *x, float *y);

@@ -381,7 +381,7 @@ TEST_CASE(one_vector_one_product_shapes) {
     CHECK(!std::get<0>(SHAPE(sin(z) - A * x)));                                 // a function of a vector
     CHECK(!std::get<0>(SHAPE(z * x + make_inline(A * x))));                     // a product of vectors
     CHECK(!std::get<0>(SHAPE(x * make_inline(A * x))));
-    vector<float> xf; SpMat<float> Af;                                          // float matrices: the shape matches, SpMat::apply_axpby declines at run time
+    vector<float> xf; SpMat<float> Af;                                          // float matrices: the same shape (the fp32 plane / grid products take the addend too)
     CHECK(SHAPE(xf - Af * xf) == std::make_tuple(true, 1, 1));
 #undef SHAPE
     (void)x; (void)z; (void)A; (void)xf; (void)Af;

@@ -545,7 +545,21 @@ TEST_CASE(spmv_one_vector_one_product_single_queue) {
     vex::copy(Y2, a2);
     auto w2 = host_spmv(r2, c2, v2, x2);
     for (size_t i = 0; i < n; ++i) CHECK_CLOSE(a2[i], x2[i] + 2 * w2[i], 1e-8);
-    // float matrices and expressions of any other shape keep the general route
+    // float matrices: the fp32 plane product takes the addend too
+    {
+        std::vector<float> vf(val.begin(), val.end()), xf(x.begin(), x.end()), zf(z.begin(), z.end());
+        setenv("VEXHIP_PLANE_FORCE", "1", 1);
+        vex::SpMat<float, unsigned> F(queue, N, N, row.data(), col.data(), vf.data());
+        unsetenv("VEXHIP_PLANE_FORCE");
+        CHECK(std::string(F.storage_info(0).product) == "sell8_plane_f32_kernel");
+        vex::vector<float> XF(queue, xf), ZF(queue, zf), YF(queue, N), TF(queue, N);
+        std::vector<float> af(N), bf(N);
+        YF = ZF - F * XF;                TF = ZF; TF -= F * XF;
+        vex::copy(YF, af); vex::copy(TF, bf); CHECK(std::memcmp(af.data(), bf.data(), N * sizeof(float)) == 0);
+        YF = XF + 2 * vex::make_inline(F * XF); TF = XF; TF += 2 * (F * XF);
+        vex::copy(YF, af); vex::copy(TF, bf); CHECK(std::memcmp(af.data(), bf.data(), N * sizeof(float)) == 0);
+    }
+    // expressions of any other shape keep the general route
     Y2 = sin(Z2) - R * X2;               T2 = sin(Z2); T2 -= R * X2;
     vex::copy(Y2, a2); vex::copy(T2, b2); CHECK(same_bits(a2, b2));
 }

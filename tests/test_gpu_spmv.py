@@ -705,6 +705,29 @@ def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
             assert np.array_equal(dy.cpu().numpy(), beta * y0 + ax), (fmt, alpha, beta, "z = y")
     with pytest.raises(Exception):
         A.apply_axpby(dx, dx, 1.0, dz, 1.0)          # y = x: refused
+    # float matrices: the fp32 plane and grid products take the addend as well; every rounding is a float's
+    f32 = np.float32
+    for (nx, ny, nz), product in (((512, 6, 8), "sell8_plane_f32_kernel"), ((70, 11, 13), "sell8_grid_f32_kernel"), ((1030, 5, 9), "sell8_grid_f32_kernel")):
+        ptr, col, val = _grid7_natural(nx, ny, nz, zero_face=False)
+        m = len(ptr) - 1
+        v32 = val.astype(f32)
+        x = oracle.random_f64(11, m).astype(f32); z = oracle.random_f64(12, m).astype(f32); y0 = oracle.random_f64(13, m).astype(f32)
+        os.environ["VEXHIP_PLANE_FORCE"] = "1"
+        try:
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(v32))
+        finally:
+            os.environ.pop("VEXHIP_PLANE_FORCE", None)
+        assert A.product == product, (A.product, A.reason)
+        dx = T.up(x)
+        assert built_lib.spmat_axpby_fused(A.handle, T.ops._p(dx), T.ops._p(dx), T.ops._p(T.up(y0)))
+        for alpha, beta in ((1.0, 1.0), (-1.0, 1.0), (0.5, -0.25)):
+            ax = oracle.spmv_csr(ptr, col, v32, x, alpha=alpha)
+            dy = T.up(np.full(m, np.nan, dtype=f32)); A.apply_axpby(dx, dy, alpha, T.up(z), beta)
+            assert np.array_equal(dy.cpu().numpy(), f32(beta) * z + ax), (product, alpha, beta, "z")
+            dy = T.up(np.full(m, np.nan, dtype=f32)); A.apply_axpby(dx, dy, alpha, dx, beta)
+            assert np.array_equal(dy.cpu().numpy(), f32(beta) * x + ax), (product, alpha, beta, "z = x")
+            dy = T.up(y0); A.apply_axpby(dx, dy, alpha, dy, beta)
+            assert np.array_equal(dy.cpu().numpy(), f32(beta) * y0 + ax), (product, alpha, beta, "z = y")
 
 
 def test_grid_product_fp32_is_bit_identical(T, oracle, built_lib):

@@ -157,13 +157,13 @@ class SpMat {
         }
 
         static constexpr bool has_axpby_product = true;      // (operations.hpp: `y = z - A * x` is offered to apply_axpby)
-        /// y = alpha * A * x + beta * z in ONE pass, if this matrix can: one device (no ghost exchange), double values, x, y and z three
+        /// y = alpha * A * x + beta * z in ONE pass, if this matrix can: one device (no ghost exchange), double or float values, x, y and z three
         /// vectors of one partition with y != x (round 6: include/vexhip.h vexhip_spmat_apply_axpby_f64 -- the plane product takes the addend;
         /// other storages decline).  false: nothing was done, the caller takes the general route.
         /// What ends up here: `y = z - A * x` (a residual), `y = x + 2 * make_inline(A * x)` (detail::assign_any).
         template <class T>
         bool apply_axpby(const vex::vector<T> &x, vex::vector<T> &y, double alpha, const vex::vector<T> &z, double beta) const {
-            if constexpr (!std::is_same<T, double>::value || !std::is_same<val_t, double>::value) { (void)x; (void)y; (void)alpha; (void)z; (void)beta; return false; }
+            if constexpr (!std::is_same<T, val_t>::value || !(std::is_same<T, double>::value || std::is_same<T, float>::value)) { (void)x; (void)y; (void)alpha; (void)z; (void)beta; return false; }
             else {
                 if (queue.size() != 1 || halo.active() || x.size() != ncols || y.size() != nrows || z.size() != nrows || part[1] == part[0]) return false;
                 const device_part &P = *mtx[0];
@@ -173,7 +173,10 @@ class SpMat {
                 // (only where the product takes the addend: elsewhere the general route costs the same or less -- a make_inline terminal keeps
                 //  its product-into-a-vector form, 2.20 against 2.30 ms on the variable-coefficient 512^3 operator)
                 if (!vexhip_spmat_axpby_fused(P.loc.handle.get(), x(0).raw(), z(0).raw(), y(0).raw())) return false;
-                backend::check(vexhip_spmat_apply_axpby_f64(P.loc.handle.get(), queue[0].raw(), alpha, x(0).raw(), beta, z(0).raw(), y(0).raw()));
+                if constexpr (std::is_same<T, double>::value)
+                    backend::check(vexhip_spmat_apply_axpby_f64(P.loc.handle.get(), queue[0].raw(), alpha, x(0).raw(), beta, z(0).raw(), y(0).raw()));
+                else
+                    backend::check(vexhip_spmat_apply_axpby_f32(P.loc.handle.get(), queue[0].raw(), (float)alpha, x(0).raw(), (float)beta, z(0).raw(), y(0).raw()));
                 return true;
             }
         }

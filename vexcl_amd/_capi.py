@@ -203,6 +203,7 @@ _PROTOS = {
     "vexhip_spmat_apply_f64": (None, [c_vp, c_vp, c_f64, c_int, c_vp, c_vp]),
     "vexhip_spmat_apply_axpby_f64": (None, [c_vp, c_vp, c_f64, c_vp, c_f64, c_vp, c_vp]),
     "vexhip_spmat_axpby_fused": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "vexhip_spmat_apply_axpby_f32": (None, [c_vp, c_vp, c_f32, c_vp, c_f32, c_vp, c_vp]),
     "vexhip_spmat_apply_f32": (None, [c_vp, c_vp, c_f32, c_int, c_vp, c_vp]),
     "vexhip_spmat_apply_multi_f64": (None, [c_vp, c_vp, c_int, c_f64, c_int, c_vp, c_vp]),
     "vexhip_spmat_apply_multi_f32": (None, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp]),

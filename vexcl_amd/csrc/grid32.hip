@@ -22,9 +22,10 @@ namespace {
 constexpr int G32_MAXT = 256;              // lanes of a workgroup at most: 1024 rows of a segment
 constexpr unsigned G32_ABSENT = 255;       // table byte of a position without an entry (grid.hip)
 
-template <bool APPEND, int STORE_AUX>
+// ZM: the addend of the result (plane.hip): 0 none, 1 beta times the array zs ('+=': zs = y, beta = 1), 2 beta times x itself (from the registers)
+template <int ZM, int STORE_AUX>
 __global__ __launch_bounds__(G32_MAXT)             // 199 registers, two waves per SIMD (capped at 168 for three, with 15 spilled: the same times)
-void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, float alpha,
+void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, float alpha, const float *__restrict__ zs, float beta,
         const int *__restrict__ line_class, const unsigned char *__restrict__ table, const float *__restrict__ values, grid_dev gd)
 {
     constexpr int TY = 2;
@@ -104,7 +105,7 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
     auto edge = [&](int zz, int l) -> float {
         return elem(((long long)zz * ny + (y0 - 1 + l)) * nx + row0 + (edge_b >> 2));
     };
-    auto yelem = [&](long long i) -> float { i = i < 0 ? 0 : i; i = i > n - 1 ? n - 1 : i; return y[i]; };
+    auto yelem = [&](long long i) -> float { i = i < 0 ? 0 : i; i = i > n - 1 ? n - 1 : i; return zs[i]; };
     auto yold = [&](int zz, int l) -> f4 {
         const long long i = ((long long)zz * ny + (y0 + l)) * nx + row0 + 4 * t;
         f4 r; r.x = yelem(i); r.y = yelem(i + 1); r.z = yelem(i + 2); r.w = yelem(i + 3);
@@ -123,13 +124,14 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(x + (((long long)z_first * ny + (y0 - 1)) * nx + row0)), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + (((long long)z_first * ny + y0) * nx + row0), 0, -1, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZM == 1 ? zs : x) + (((long long)z_first * ny + y0) * nx + row0), 0, -1, 0x00020000);
 #pragma unroll
     for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
     Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
 #pragma unroll
     for (int l = 0; l < TY; ++l) {
         Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
-        if (APPEND) Yo[l] = yold(z, l);
+        if (ZM == 1) Yo[l] = yold(z, l);
     }
 
     // x at the seven positions {-far, -nx, -1, 0, +1, +nx, +far} of the lane's four rows of tile line l
@@ -155,7 +157,7 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
         auto end_for = [&](long long limit, int ahead, int line) -> long long { const long long v = limit - y0 - line; return v < 0 ? 0 : v / ny - ahead + 1; };
         long long e = end_for(xl_in, 3, TY);                                           // x: planes up to z + 3, lines up to the one below the tile
         e = std::min(e, end_for(lines - 1, 0, TY - 1));                               // y: both lines exist
-        if (APPEND) e = std::min(e, end_for(yl_in, 1, TY - 1));
+        if (ZM == 1) e = std::min(e, end_for(yl_in, 1, TY - 1));
         zh = zh < e ? zh : (int)(e < 0 ? 0 : e);
     }
 
@@ -187,7 +189,8 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
                     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (use_hot[l] & 1ull) { G32_HOT_SUMS(s) } else { G32_OTHER_SUMS(s) }      // uniform
                     o[l].x = alpha * s[0]; o[l].y = alpha * s[1]; o[l].z = alpha * s[2]; o[l].w = alpha * s[3];
-                    if (APPEND) o[l] = Yo[l] + o[l];
+                    if (ZM == 1) o[l] = beta * Yo[l] + o[l];
+                    if (ZM == 2) o[l] = beta * c + o[l];
                 }
 #pragma unroll
                 for (int l = 0; l < TY; ++l) use_hot[l] >>= 1;
@@ -202,9 +205,9 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
                             if (nv > 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[l].z), ry, (int)lane_b + 8, at, STORE_AUX);
                         }
                     }
-                if (APPEND) {
+                if (ZM == 1) {
 #pragma unroll
-                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)lane_b, (int)(yo + plane_b32 + l * line_b), 0));
+                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)lane_b, (int)(yo + plane_b32 + l * line_b), 0));
                 }
                 H[0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
                 H[1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * line_b), 0));
@@ -241,7 +244,8 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = alpha * s[r];
-                if (APPEND) { o[0] = Yo[l].x + o[0]; o[1] = Yo[l].y + o[1]; o[2] = Yo[l].z + o[2]; o[3] = Yo[l].w + o[3]; }
+                if (ZM == 1) { o[0] = beta * Yo[l].x + o[0]; o[1] = beta * Yo[l].y + o[1]; o[2] = beta * Yo[l].z + o[2]; o[3] = beta * Yo[l].w + o[3]; }
+                if (ZM == 2) { o[0] = beta * c.x + o[0]; o[1] = beta * c.y + o[1]; o[2] = beta * c.z + o[2]; o[3] = beta * c.w + o[3]; }
                 float *yr = y + li * nx + row0 + 4 * t;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (r < nv) __builtin_nontemporal_store(o[r], yr + r);
@@ -251,7 +255,7 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
         for (int l = 0; l < TY; ++l) {
             Cs[0][l] = Cs[1][l]; Cs[1][l] = Cs[2][l]; Cs[2][l] = Cs[3][l]; Cs[3][l] = ld(z + 3, l + 1);
             Es[0][l] = Es[1][l]; Es[1][l] = edge(z + 2, l + 1);
-            if (APPEND) Yo[l] = yold(z + 1, l);
+            if (ZM == 1) Yo[l] = yold(z + 1, l);
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
@@ -267,9 +271,24 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
 
 using namespace vexhip;
 
+namespace vexhip {
+int grid32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, const float *zs, float beta, const float *values,
+        const float *x, float *y, const vexhip_grid *g);
+}
+
 extern "C" {
 
 int vexhip_spmv_sell8v_grid_f32(int dev, void *stream, int64_t n, float alpha, int append, const float *values,
+        const float *x, float *y, const vexhip_grid *g)
+{
+    return grid32_apply_axpby(dev, stream, n, alpha, append ? 1 : 0, y, 1.0f, values, x, y, g);
+}
+
+} // extern "C"
+
+namespace vexhip {
+// y = alpha A x + [zm 1: beta zs | zm 2: beta x] through the fp32 grid product (spmat.hip vexhip_spmat_apply_axpby_f32)
+int grid32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, const float *zs, float beta, const float *values,
         const float *x, float *y, const vexhip_grid *g)
 {
     VEXHIP_REQUIRE(g && g->usable && g->line_class && g->table && values && x && y, "bad grid product arguments");
@@ -313,15 +332,17 @@ int vexhip_spmv_sell8v_grid_f32(int dev, void *stream, int64_t n, float alpha, i
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const unsigned char *tb = static_cast<const unsigned char *>(g->table);
     hipStream_t s = as_stream(stream);
-#define G32_LAUNCH(AP, AUX) sell8_grid_f32_kernel<AP, AUX><<<(unsigned)grid, (unsigned)threads, 0, s>>>(x, y, alpha, g->line_class, tb, values, gd)
+#define G32_LAUNCH(AP, AUX) sell8_grid_f32_kernel<AP, AUX><<<(unsigned)grid, (unsigned)threads, 0, s>>>(x, y, alpha, zs, beta, g->line_class, tb, values, gd)
 #define G32_AUX(AP) switch (g->store_policy) { case 1: G32_LAUNCH(AP, 18); break; case 2: G32_LAUNCH(AP, 17); break; case 3: G32_LAUNCH(AP, 0); break; default: G32_LAUNCH(AP, 2); }
-    if (append) { G32_AUX(true) } else { G32_AUX(false) }
+    VEXHIP_REQUIRE(zm == 0 || zm == 2 || (zm == 1 && zs), "grid product: the addend must be a vector");
+    if (zm == 1) { G32_AUX(1) } else if (zm == 2) { G32_AUX(2) } else { G32_AUX(0) }
 #undef G32_AUX
 #undef G32_LAUNCH
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
 
-} // extern "C"
+} // namespace vexhip
+
 
 VEXHIP_WARM_TU(grid32)

@@ -26,9 +26,10 @@ constexpr int P32_LINE_B = PL_ROWS * 4;    // bytes of a line
 // HALO (round 6; halo.hpp, the PULL form only): the launch is one device's whole product step, as in grid.hip -- x and y addressed in
 // the numbering of the STORED grid, the plane below z0 / above z1 - 1 read from the neighbour's x in place (H.lo / H.hi point at
 // floats here), the two walks that touch a ghost plane dispatched last.
-template <bool APPEND, int STORE_AUX, bool HALO>
+// ZM: the addend of the result (plane.hip): 0 none, 1 beta times the array zs ('+=': zs = y, beta = 1), 2 beta times x itself (from the registers)
+template <int ZM, int STORE_AUX, bool HALO>
 __device__ __forceinline__
-void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alpha,
+void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alpha, const float *__restrict__ zs, float beta,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const float *__restrict__ values,
         const plane_dev &pd, const halo_dev &H, [[maybe_unused]] const unsigned long long step)
 {
@@ -175,7 +176,7 @@ void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alph
     auto yold = [&](int zz, int l) -> f4 {
         int li = zz * ny + (y0 + l);
         li = li < line_lo ? line_lo : li; li = li >= nslices ? nslices - 1 : li;
-        return *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(y + (long long)li * PL_ROWS) + lane_b);
+        return *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(zs + (long long)li * PL_ROWS) + lane_b);
     };
 
     // ---- state at the top of the step for plane z: as in plane.hip ----
@@ -190,13 +191,14 @@ void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alph
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(x + ((long long)z_first * ny + (y0 - 1)) * PL_ROWS), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + ((long long)z_first * ny + y0) * PL_ROWS, 0, -1, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZM == 1 ? zs : x) + ((long long)z_first * ny + y0) * PL_ROWS, 0, -1, 0x00020000);
 #pragma unroll
     for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
     Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
 #pragma unroll
     for (int l = 0; l < TY; ++l) {
         Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
-        if (APPEND) Yo[l] = yold(z, l);
+        if (ZM == 1) Yo[l] = yold(z, l);
     }
 
     // x at the seven positions {-far, -512, -1, 0, +1, +512, +far} of the lane's four rows of tile line l
@@ -214,7 +216,7 @@ void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alph
     // fast steps need nothing clamped: planes up to z + 3 inside x, both lines inside y
     int zh = zend;
     {
-        const int a = (xlines - 1 - TY - y0) / ny - 3, bb = (nslices - TY - y0) / ny - (APPEND ? 1 : 0);
+        const int a = (xlines - 1 - TY - y0) / ny - 3, bb = (nslices - TY - y0) / ny - (ZM == 1 ? 1 : 0);
         if (xlines - 1 - TY - y0 < 0 || nslices - TY - y0 < 0) zh = 0;
         else { zh = zh < a + 1 ? zh : a + 1; zh = zh < bb + 1 ? zh : bb + 1; }
     }
@@ -247,16 +249,17 @@ void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alph
                     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (use_hot[l] & 1ull) { P32_HOT_SUMS(s) } else { P32_OTHER_SUMS(s) }      // uniform
                     o[l].x = alpha * s[0]; o[l].y = alpha * s[1]; o[l].z = alpha * s[2]; o[l].w = alpha * s[3];
-                    if (APPEND) o[l] = Yo[l] + o[l];
+                    if (ZM == 1) o[l] = beta * Yo[l] + o[l];
+                    if (ZM == 2) o[l] = beta * c + o[l];
                 }
 #pragma unroll
                 for (int l = 0; l < TY; ++l) use_hot[l] >>= 1;
 #pragma unroll
                 for (int l = 0; l < TY; ++l)       // written once, not read again by this kernel
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[l]), ry, (int)lane_b, (int)(yo + l * (unsigned)P32_LINE_B), STORE_AUX);
-                if (APPEND) {
+                if (ZM == 1) {
 #pragma unroll
-                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)lane_b, (int)(yo + plane_b32 + l * (unsigned)P32_LINE_B), 0));
+                    for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)lane_b, (int)(yo + plane_b32 + l * (unsigned)P32_LINE_B), 0));
                 }
                 H[0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
                 H[1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * (unsigned)P32_LINE_B), 0));
@@ -291,7 +294,8 @@ void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alph
                     P32_OTHER_SUMS(s)
                 }
                 f4 o; o.x = alpha * s[0]; o.y = alpha * s[1]; o.z = alpha * s[2]; o.w = alpha * s[3];
-                if (APPEND) o = Yo[l] + o;
+                if (ZM == 1) o = beta * Yo[l] + o;
+                if (ZM == 2) o = beta * c + o;
                 *reinterpret_cast<f4u *>(reinterpret_cast<char *>(y + (long long)li * PL_ROWS) + lane_b) = o;
             }
         }
@@ -299,7 +303,7 @@ void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alph
         for (int l = 0; l < TY; ++l) {
             Cs[0][l] = Cs[1][l]; Cs[1][l] = Cs[2][l]; Cs[2][l] = Cs[3][l]; Cs[3][l] = ld(z + 3, l + 1);
             Es[0][l] = Es[1][l]; Es[1][l] = edge(z + 2, l + 1);
-            if (APPEND) Yo[l] = yold(z + 1, l);
+            if (ZM == 1) Yo[l] = yold(z + 1, l);
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
@@ -310,18 +314,18 @@ void plane32_walk(const float *__restrict__ x, float *__restrict__ y, float alph
 #undef P32_OTHER_SUMS
 }
 
-template <bool APPEND, int STORE_AUX, bool HALO = false>
+template <int ZM, int STORE_AUX, bool HALO = false>
 __global__ __launch_bounds__(P32_LANES)
-void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, float alpha,
+void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, float alpha, const float *__restrict__ zs, float beta,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const float *__restrict__ values,
         plane_dev pd, halo_dev H)
 {
     if constexpr (!HALO) {
-        plane32_walk<APPEND, STORE_AUX, false>(x, y, alpha, blocks, pool, deltas, values, pd, H, 0ull);
+        plane32_walk<ZM, STORE_AUX, false>(x, y, alpha, zs, beta, blocks, pool, deltas, values, pd, H, 0ull);
     } else {
         const unsigned long long step = *H.step;
         halo_announce(H, step);
-        plane32_walk<APPEND, STORE_AUX, true>(x, y, alpha, blocks, pool, deltas, values, pd, H, step);
+        plane32_walk<ZM, STORE_AUX, true>(x, y, alpha, zs, beta, blocks, pool, deltas, values, pd, H, step);
         halo_finish(H, step);
     }
 }
@@ -330,6 +334,11 @@ void sell8_plane_f32_kernel(const float *__restrict__ x, float *__restrict__ y, 
 } // namespace vexhip
 
 using namespace vexhip;
+
+namespace vexhip {
+int plane32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, const float *zs, float beta, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane);
+}
 
 extern "C" {
 
@@ -351,6 +360,16 @@ int64_t vexhip_sell8_plane_f32_depth(int cus, int64_t lines_per_plane, int64_t p
 }
 
 int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane)
+{
+    return plane32_apply_axpby(dev, stream, n, alpha, append ? 1 : 0, y, 1.0f, w, pool, blocks, deltas, values, x, y, plane);
+}
+
+} // extern "C"
+
+namespace vexhip {
+// y = alpha A x + [zm 1: beta zs | zm 2: beta x] through the fp32 plane product (spmat.hip vexhip_spmat_apply_axpby_f32)
+int plane32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, const float *zs, float beta, int64_t w, const void *pool,
         const int32_t *blocks, const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane)
 {
     VEXHIP_REQUIRE(plane && plane->usable && pool && blocks && deltas && values && x && y, "bad plane product arguments");
@@ -377,18 +396,17 @@ int vexhip_spmv_sell8v_plane_f32_i32(int dev, void *stream, int64_t n, float alp
     int store_kind = 1;
     if (const char *e = env(ENV_VEXHIP_PLANE_STORE)) store_kind = std::max(0, std::min(3, std::atoi(e)));
     const halo_dev none = halo_dev();
-#define P32_LAUNCH(AP, AUX) sell8_plane_f32_kernel<AP, AUX><<<(unsigned)grid, P32_LANES, 0, s>>>(x, y, alpha, blocks, cpool, deltas, values, pd, none)
+#define P32_LAUNCH(AP, AUX) sell8_plane_f32_kernel<AP, AUX><<<(unsigned)grid, P32_LANES, 0, s>>>(x, y, alpha, zs, beta, blocks, cpool, deltas, values, pd, none)
 #define P32_AUX(AP) switch (store_kind) { case 1: P32_LAUNCH(AP, 18); break; case 2: P32_LAUNCH(AP, 17); break; case 3: P32_LAUNCH(AP, 0); break; default: P32_LAUNCH(AP, 2); }
-    if (append) { P32_AUX(true) } else { P32_AUX(false) }
+    VEXHIP_REQUIRE(zm == 0 || zm == 2 || (zm == 1 && zs), "plane product: the addend must be a vector");
+    if (zm == 1) { P32_AUX(1) } else if (zm == 2) { P32_AUX(2) } else { P32_AUX(0) }
 #undef P32_AUX
 #undef P32_LAUNCH
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }
 
-} // extern "C"
 
-namespace vexhip {
 // One device's product step in one launch for a float matrix on 512-point lines (halo.hpp, the pull form): the fp32 plane product over
 // the planes [H.z0, H.z1) of the stored grid of n_ext rows; x and y are the device's own segments.
 int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
@@ -416,8 +434,8 @@ int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int a
     const float *xe = x - (long long)H.z0 * pd.far;            // the kernel addresses x and y in the numbering of the stored grid
     float *ye = y - (long long)H.z0 * pd.far;
     const char *cpool = static_cast<const char *>(pool);
-    if (append) sell8_plane_f32_kernel<true, 18, true><<<(unsigned)grid, P32_LANES, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
-    else        sell8_plane_f32_kernel<false, 18, true><<<(unsigned)grid, P32_LANES, 0, s>>>(xe, ye, alpha, blocks, cpool, deltas, values, pd, H);
+    if (append) sell8_plane_f32_kernel<1, 18, true><<<(unsigned)grid, P32_LANES, 0, s>>>(xe, ye, alpha, ye, 1.0f, blocks, cpool, deltas, values, pd, H);
+    else        sell8_plane_f32_kernel<0, 18, true><<<(unsigned)grid, P32_LANES, 0, s>>>(xe, ye, alpha, nullptr, 0.0f, blocks, cpool, deltas, values, pd, H);
     VEXHIP_LAUNCH_CHECK();
     return 0;
 }

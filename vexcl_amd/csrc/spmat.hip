@@ -58,6 +58,10 @@ int plane_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, co
         const int32_t *blocks, const int32_t *deltas, const double *values, const double *x, double *y, const vexhip_plane *plane);
 int grid_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, const double *zs, double beta, const double *values,
         const double *x, double *y, const vexhip_grid *g);
+int plane32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, const float *zs, float beta, int64_t w, const void *pool,
+        const int32_t *blocks, const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane);
+int grid32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, const float *zs, float beta, const float *values,
+        const float *x, float *y, const vexhip_grid *g);
 int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
         const vexhip_grid *g, halo_dev H);
 int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
@@ -150,7 +154,8 @@ inline product_choice select_product(const spmat *A, const void *x, const void *
     }
 }
 
-__global__ __launch_bounds__(256) void scale_into_kernel(double *__restrict__ y, const double *z, double beta, long long n) {
+template <typename V>
+__global__ __launch_bounds__(256) void scale_into_kernel(V *__restrict__ y, const V *z, V beta, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = beta * z[i];                 // (z may be y itself)
 }
@@ -610,18 +615,42 @@ int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *h, void *stream, double alp
         VEXHIP_SET_DEVICE(A->dev);
         const long long grid = (A->n + 255) / 256;
         VEXHIP_REQUIRE(grid < (1ll << 31), "vector too large for one launch");
-        scale_into_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(y, z, beta, (long long)A->n);
+        scale_into_kernel<double><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(y, z, beta, (long long)A->n);
         VEXHIP_LAUNCH_CHECK();
     }
     return apply<double>(A, stream, alpha, 1, x, y);
+}
+
+int vexhip_spmat_apply_axpby_f32(const vexhip_spmat *h, void *stream, float alpha, const float *x, float beta, const float *z, float *y)
+{
+    const spmat *A = reinterpret_cast<const spmat *>(h);
+    VEXHIP_REQUIRE(A && A->value_type == VEXHIP_F32, "matrix and vector value types differ");
+    VEXHIP_REQUIRE(x && y && z, "NULL argument");
+    VEXHIP_REQUIRE(static_cast<const void *>(x) != static_cast<const void *>(y), "y = alpha A x + beta z: x and y are the same vector");
+    if (A->n == 0) return 0;
+    const product_choice pc = select_product(A, x, y);
+    if (pc.kind == P_PLANE32)
+        return plane32_apply_axpby(A->dev, stream, A->n, alpha, z == x ? 2 : 1, z, beta, A->ell_w, A->direct ? A->grid.table : A->pool,
+                                   A->direct ? A->grid.line_class : A->blocks, A->deltas, (const float *)A->values, x, y, &A->plane);
+    if (pc.kind == P_GRID32)
+        return grid32_apply_axpby(A->dev, stream, A->n, alpha, z == x ? 2 : 1, z, beta, (const float *)A->values, x, y, &A->grid);
+    if (!(z == y && beta == 1.0f)) {
+        VEXHIP_SET_DEVICE(A->dev);
+        const long long grid = (A->n + 255) / 256;
+        VEXHIP_REQUIRE(grid < (1ll << 31), "vector too large for one launch");
+        scale_into_kernel<float><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(y, z, beta, (long long)A->n);
+        VEXHIP_LAUNCH_CHECK();
+    }
+    return apply<float>(A, stream, alpha, 1, x, y);
 }
 
 // 1: vexhip_spmat_apply_axpby_f64 on these vectors runs as ONE pass (the product takes the addend); 0: as y = beta z, y += alpha A x
 int vexhip_spmat_axpby_fused(const vexhip_spmat *h, const void *x, const void *z, const void *y)
 {
     const spmat *A = reinterpret_cast<const spmat *>(h);
-    if (!A || A->value_type != VEXHIP_F64 || !x || !y || !z || x == y || A->n == 0) return 0;
+    if (!A || !x || !y || !z || x == y || A->n == 0) return 0;
     const product_kind k = select_product(A, x, y).kind;
+    if (A->value_type == VEXHIP_F32) return k == P_PLANE32 || k == P_GRID32 ? 1 : 0;
     return (k == P_PLANE64 && (z == x || (reinterpret_cast<uintptr_t>(z) & 15) == 0)) || (k == P_GRID64 && (reinterpret_cast<uintptr_t>(z) & 7) == 0) ? 1 : 0;
 }
 

@@ -492,12 +492,15 @@ class SpMat:
 
     def apply_axpby(self, x, y, alpha, z, beta):
         """y = alpha * A * x + beta * z in one call (vexhip_spmat_apply_axpby_f64: one pass where the product takes the addend);
-        z may be x or y, y must not be x.  fp64 matrices behind the library object only."""
-        if not self.handle or self.dtype != torch.float64:
-            raise Error("apply_axpby: an fp64 matrix behind vexhip_spmat only")
+        z may be x or y, y must not be x."""
+        if not self.handle:
+            raise Error("apply_axpby: a matrix behind vexhip_spmat only")
         if x.numel() != self.m:
             raise Error("x has %d elements, matrix has %d columns" % (x.numel(), self.m))
-        lib().spmat_apply_axpby_f64(self.handle, _stream(y), ctypes.c_double(alpha), _p(x), ctypes.c_double(beta), _p(z), _p(y))
+        if self.dtype == torch.float64:
+            lib().spmat_apply_axpby_f64(self.handle, _stream(y), ctypes.c_double(alpha), _p(x), ctypes.c_double(beta), _p(z), _p(y))
+        else:
+            lib().spmat_apply_axpby_f32(self.handle, _stream(y), ctypes.c_float(alpha), _p(x), ctypes.c_float(beta), _p(z), _p(y))
         return y
 
     def apply_multi(self, xs, ys, alpha=1.0, append=False):
