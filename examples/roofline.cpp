@@ -142,7 +142,9 @@ int main(int argc, char **argv) {
             // round 6: one vector + one product term is handed to the product whole (SpMat::apply_axpby: the plane product adds the vector in
             // its own pass; x itself costs no byte more than y = A*x); a residual reads b as well; any other expression around make_inline
             // runs the library product into a vector the matrix keeps, then the fused kernel
-            const char *pk = info.plane.usable ? "sell8_plane_kernel, the vector added in the same pass" : "this product takes no addend: the general route (y = z, y -= A*x; make_inline: the product into a kept vector + vexcl_vector_kernel)";
+            const bool one_pass = vexhip_spmat_axpby_fused(A.storage_handle(), x(0).raw(), x(0).raw(), y(0).raw()) != 0;
+            const std::string pks = std::string(info.product) + (one_pass ? ", the vector added in the same pass" : ": takes no addend -- the general route (y = z, y -= A*x; make_inline: the product into a kept vector + vexcl_vector_kernel)");
+            const char *pk = pks.c_str();
             warm(t, [&] { y = x + 2 * vex::make_inline(A * x); });
             t.start(); for (int i = 0; i < reps; ++i) y = x + 2 * vex::make_inline(A * x); ms = t.stop_ms() / reps;
             std::snprintf(extra, sizeof extra, ", \"kernel\": \"%s\", \"gflops\": %.1f", pk, 2.0 * nnz / ms / 1e6);

@@ -673,28 +673,36 @@ def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
     then y += alpha A x inside the call; both are round(beta z_i) + round(alpha (A x)_i) with (A x)_i summed in CSR order: compared bit
     for bit with that evaluation on the host (the CSR restatement of spmat/csr.inl:163-170)."""
     torch = T.torch
-    for (nx, ny, nz), fmt, force, product in (((512, 6, 8), None, True, "sell8_plane_kernel"), ((70, 11, 13), None, True, "sell8_grid_kernel"), ((1030, 5, 9), None, True, "sell8_grid_kernel"),
-                                              ((512, 6, 8), "csr", False, None), ((512, 6, 8), "sell32", False, None), ((512, 6, 8), "sell8", False, None)):
-        ptr, col, val = _grid7_natural(nx, ny, nz, zero_face=False)
+    # (geometry, format, storage by grid line forced, keyword arguments, the product expected, one pass expected)
+    cases = (((512, 6, 8), None, True, {}, "sell8_plane_kernel", True), ((70, 11, 13), None, True, {}, "sell8_grid_kernel", True), ((1030, 5, 9), None, True, {}, "sell8_grid_kernel", True),
+             ((512, 6, 8), "csr", False, {}, "csr_stream2_kernel", False),                  # the CSR kernels take no addend: y = beta z, then y += alpha A x inside the call
+             ((512, 6, 8), "sell32", False, {}, "sell_pair_kernel", True),                  # the SELL-family kernels add it in store_pair
+             ((512, 6, 8), "sell8", False, {}, "sell8_pair_kernel", True),
+             ((512, 6, 8), "sell8", False, {"dictionary": False}, "sell8_pair_kernel", True),
+             ((64, 16, 16), None, False, {"march": False}, "sell8_pair_kernel", True),       # value codes from the slice dictionary, pair product
+             ((64, 16, 16), None, False, {"dictionary": False}, "sell8_pair_kernel", True),  # value codes, one block per slice
+             ((64, 64, 64), None, False, {"march": False}, "sell8_pair_kernel", True),       # the benchmark's operator: slice dictionary, pair product
+             ((64, 64, 64), None, False, {}, "sell8_march_kernel", False))                  # the march product has its own epilogue: two passes
+    for (nx, ny, nz), fmt, force, kw, product, one_pass in cases:
+        ptr, col, val = oracle.poisson3d(nx) if (nx, ny, nz) == (64, 64, 64) else _grid7_natural(nx, ny, nz, zero_face=False)
         m = len(ptr) - 1
         x = oracle.random_f64(11, m); z = oracle.random_f64(12, m); y0 = oracle.random_f64(13, m)
         if force:
             os.environ["VEXHIP_PLANE_FORCE"] = "1"
         try:
-            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val)) if fmt is None else T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt=fmt)
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), **kw) if fmt is None else T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), fmt=fmt, **kw)
         finally:
             os.environ.pop("VEXHIP_PLANE_FORCE", None)
-        if product:
-            assert A.product == product, (A.product, A.reason)
+        assert A.product == product, (fmt, kw, A.product, A.reason)
         dx = T.up(x)
         fused = built_lib.spmat_axpby_fused(A.handle, T.ops._p(dx), T.ops._p(dx), T.ops._p(T.up(y0)))
-        assert bool(fused) == bool(product), (fmt, product, fused)
+        assert bool(fused) == one_pass, (fmt, kw, product, fused)
         for alpha, beta in ((1.0, 1.0), (-1.0, 1.0), (2.0, 1.0), (0.5, -0.25), (-3.0, 0.0)):
             ax = oracle.spmv_csr(ptr, col, val, x, alpha=alpha)
             # z an array of its own
             dz, dy = T.up(z), T.up(np.full(m, np.nan))
             A.apply_axpby(dx, dy, alpha, dz, beta)
-            assert np.array_equal(dy.cpu().numpy(), beta * z + ax), (fmt, alpha, beta, "z")
+            assert np.array_equal(dy.cpu().numpy(), beta * z + ax), (fmt, kw, alpha, beta, "z")
             # z = x
             dy = T.up(np.full(m, np.nan))
             A.apply_axpby(dx, dy, alpha, dx, beta)

@@ -127,6 +127,8 @@ class SpMat {
         size_t nonzeros() const { return nnz; }
         /// Storage the library chose for device d's local part (VEXHIP_SPMAT_*; info.matrix_bytes = bytes a product streams).
         const vexhip_spmat_info &storage_info(unsigned d = 0) const { return halo.active() ? halo.info(d) : mtx[d]->loc.info; }
+        /// The library object behind device d's local part (NULL: empty) -- for the C ABI's queries (vexhip_spmat_axpby_fused, ...).
+        const vexhip_spmat *storage_handle(unsigned d = 0) const { return mtx[d]->loc.handle.get(); }
         /// How a product on a multi-device context runs: "one launch per device (...)" -- the strip of every device stored with its
         /// two ghost planes, the neighbours' boundary planes of x read in place (vexhip_dist_spmv_create_halo_pull) -- or
         /// "pack / exchange / local / remote" (vexcl/exchange.hpp), or "one device".

@@ -125,7 +125,7 @@ void sell8_kernel(long long n, long long nslices, V alpha, int append, int ell_w
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-    store_pair<V>(n, i, alpha, append, sum, y);
+    store_pair<V>(n, i, alpha, append, sum, y, trav);
 }
 
 // ---- set-up: which diagonals does the ELL part use? ------------------------------------
@@ -421,7 +421,7 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-    store_pair<V>(n, i, alpha, append, sum, y);
+    store_pair<V>(n, i, alpha, append, sum, y, trav);
 }
 
 // ---------------------------------------------------------------------------
@@ -558,7 +558,7 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-    store_pair<V>(n, i, alpha, append, sum, y);
+    store_pair<V>(n, i, alpha, append, sum, y, trav);
 }
 
 // ---------------------------------------------------------------------------
@@ -905,7 +905,7 @@ void sell8_march_kernel(march_cold<V> cold_args /* first: offset 0 of the kernar
                 if (i + q < n)
                     for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
         }
-        store_pair<V>(n, i, alpha, append, sum, y);
+        store_pair<V>(n, i, alpha, append, sum, y);          // (the march product takes no addend: spmat.hip does not offer it one)
         b += SLB; if (b >= capb) b -= capb;
         ++k;
         __syncthreads();
@@ -1350,6 +1350,7 @@ int spmv_sell8(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     const long long grid = ordered ? tr->grid_blocks : ns;
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (ordered) t8 = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
+    t8 = with_addend(t8);                                          // y = alpha A x + beta z (vexhip_spmat_apply_axpby_*): the kernels' store_pair adds it
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf), *pool = static_cast<const char *>(pool_);
 #define PAIR(W, DICT) sell8_pair_kernel<V, W, false, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, (const V *)nullptr, cp, cc, cv, x, y, t8, pool, blocks)
@@ -1523,11 +1524,12 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     hipStream_t s = as_stream(stream);
     const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
     long long grid = 0;
-    const trav_dev t8 = make_traversal(tr, ns, &grid);
+    trav_dev t8 = make_traversal(tr, ns, &grid);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
     if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
-        return march_launch<V>(dev, s, n, ns, alpha, append, (int)w, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);
+        return march_launch<V>(dev, s, n, ns, alpha, append, (int)w, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);      // (takes no addend: spmat.hip does not offer it one)
+    t8 = with_addend(t8);
 #define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, b, blocks)
 #define CASE(W) case W: if (g_sell8_variant != 1 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \
         else sell8v_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, b, deltas, values, cp, cc, cv, x, y, t8, blocks); break;

@@ -10,6 +10,7 @@
 // Both front ends now call create / apply / destroy.  Built from DEVICE CSR arrays: no host staging.
 #include "common.hpp"
 #include "halo.hpp"
+#include "traversal.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -571,6 +572,26 @@ int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int app
 
 using namespace vexhip;
 
+namespace {
+// products whose launcher hands the addend to its kernels' store_pair (traversal.hpp): the pair / any-width products of the coded storages
+// and of the 32-bit columns; not the march product (its hot loop has its own epilogue), not the CSR kernels
+inline bool addend_by_store_pair(const spmat *A, product_kind k) {
+    return k == P_PAIR_CODES || k == P_PAIR_DICT_VALUES || k == P_PAIR_VALUES || k == P_SELL32 || (k == P_MARCH && !A->march.usable);
+}
+template <typename V>
+int apply_with_addend(const spmat *A, void *stream, V alpha, const V *x, V beta, const V *z, V *y) {
+    pending_addend &a = next_addend();
+    a.z = z; a.beta = (double)beta; a.taken = false;
+    const int rc = apply<V>(A, stream, alpha, 0, x, y);
+    const bool taken = a.taken;
+    a = pending_addend();
+    if (rc) return rc;
+    if (!taken) return fail(__FILE__, __LINE__, "y = alpha A x + beta z: the product that ran took no addend (select_product and the launchers disagree)");
+    return 0;
+}
+
+} // namespace
+
 extern "C" {
 
 int vexhip_spmat_create_f64_i32(int dev, void *stream, int64_t n, const int32_t *ptr, const int32_t *col, const double *val,
@@ -611,6 +632,7 @@ int vexhip_spmat_apply_axpby_f64(const vexhip_spmat *h, void *stream, double alp
                                  A->direct ? A->grid.line_class : A->blocks, A->deltas, (const double *)A->values, x, y, &A->plane);
     if (pc.kind == P_GRID64 && (reinterpret_cast<uintptr_t>(z) & 7) == 0)
         return grid_apply_axpby(A->dev, stream, A->n, alpha, z == x ? 2 : 1, z, beta, (const double *)A->values, x, y, &A->grid);
+    if (addend_by_store_pair(A, pc.kind)) return apply_with_addend<double>(A, stream, alpha, x, beta, z, y);
     if (!(z == y && beta == 1.0)) {
         VEXHIP_SET_DEVICE(A->dev);
         const long long grid = (A->n + 255) / 256;
@@ -634,6 +656,7 @@ int vexhip_spmat_apply_axpby_f32(const vexhip_spmat *h, void *stream, float alph
                                    A->direct ? A->grid.line_class : A->blocks, A->deltas, (const float *)A->values, x, y, &A->plane);
     if (pc.kind == P_GRID32)
         return grid32_apply_axpby(A->dev, stream, A->n, alpha, z == x ? 2 : 1, z, beta, (const float *)A->values, x, y, &A->grid);
+    if (addend_by_store_pair(A, pc.kind)) return apply_with_addend<float>(A, stream, alpha, x, beta, z, y);
     if (!(z == y && beta == 1.0f)) {
         VEXHIP_SET_DEVICE(A->dev);
         const long long grid = (A->n + 255) / 256;
@@ -650,6 +673,7 @@ int vexhip_spmat_axpby_fused(const vexhip_spmat *h, const void *x, const void *z
     const spmat *A = reinterpret_cast<const spmat *>(h);
     if (!A || !x || !y || !z || x == y || A->n == 0) return 0;
     const product_kind k = select_product(A, x, y).kind;
+    if (addend_by_store_pair(A, k)) return 1;
     if (A->value_type == VEXHIP_F32) return k == P_PLANE32 || k == P_GRID32 ? 1 : 0;
     return (k == P_PLANE64 && (z == x || (reinterpret_cast<uintptr_t>(z) & 15) == 0)) || (k == P_GRID64 && (reinterpret_cast<uintptr_t>(z) & 7) == 0) ? 1 : 0;
 }

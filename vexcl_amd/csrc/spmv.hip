@@ -439,7 +439,7 @@ void sell_kernel(long long n, long long nslices, V alpha, int append, int ell_w,
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-    store_pair<V>(n, i, alpha, append, sum, y);
+    store_pair<V>(n, i, alpha, append, sum, y, trav);
 }
 
 // Pair form of sell_kernel (the default for W <= 8; reasoning and measurements: sell8.hip, "PAIR kernels").
@@ -499,7 +499,7 @@ void sell_pair_kernel(long long n, long long nslices, V alpha, int append,
             if (i + q < n)
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
-    store_pair<V>(n, i, alpha, append, sum, y);
+    store_pair<V>(n, i, alpha, append, sum, y, trav);
 }
 
 // One lane per row PAIR: the entries of rows 2t and 2t+1 are aligned by diagonal (pairing.hpp); the empty half of
@@ -701,6 +701,7 @@ int spmv_sell(int dev, void *stream, int64_t n, V alpha, int append, int64_t w,
     long long grid = ordered ? tr->grid_blocks : ns;
     trav_dev order = {nullptr, 0, 0, 0};
     if (ordered) order = trav_dev{tr->order, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
+    order = with_addend(order);                                    // y = alpha A x + beta z (vexhip_spmat_apply_axpby_*): the kernels' store_pair adds it
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
 #define CASE(W) case W: if (g_sell8_variant == 0) sell_pair_kernel<V, W><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, sc, cp, cc, cv, x, y, order); \
         else sell_kernel<V, W, true><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, sc, cp, cc, cv, x, y, order); break;
