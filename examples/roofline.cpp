@@ -230,6 +230,11 @@ int main(int argc, char **argv) {
         t.start(); for (int i = 0; i < 5; ++i) runs = vex::reduce_by_key(keys, vals, okeys, ovals); ms = t.stop_ms() / 5;
         report("reduce_by_key (int, f64) n=1e8: one pass into the outputs of the previous call + 4-byte run count read back (first call: keys-only count first)", (double)n, 12, ms);
         std::printf("{\"row\": \"reduce_by_key runs\", \"runs\": %d}\n", runs);
+        setenv("VEXCL_SCAN_BY_KEY", "tree", 1);
+        runs = vex::reduce_by_key(keys, vals, okeys, ovals); q.finish();
+        t.start(); for (int i = 0; i < 5; ++i) runs = vex::reduce_by_key(keys, vals, okeys, ovals); ms = t.stop_ms() / 5;
+        report("reduce_by_key (int, f64) n=1e8, VEXCL_SCAN_BY_KEY=tree: three phases", (double)n, 12, ms);
+        unsetenv("VEXCL_SCAN_BY_KEY");
     }
     return 0;
 }
