@@ -675,7 +675,7 @@ def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
     torch = T.torch
     # (geometry, format, storage by grid line forced, keyword arguments, the product expected, one pass expected)
     cases = (((512, 6, 8), None, True, {}, "sell8_plane_kernel", True), ((70, 11, 13), None, True, {}, "sell8_grid_kernel", True), ((1030, 5, 9), None, True, {}, "sell8_grid_kernel", True),
-             ((512, 6, 8), "csr", False, {}, "csr_stream2_kernel", False),                  # the CSR kernels take no addend: y = beta z, then y += alpha A x inside the call
+             ((512, 6, 8), "csr", False, {}, "csr_stream2_kernel", True),                   # the CSR kernels add it in their own epilogue
              ((512, 6, 8), "sell32", False, {}, "sell_pair_kernel", True),                  # the SELL-family kernels add it in store_pair
              ((512, 6, 8), "sell8", False, {}, "sell8_pair_kernel", True),
              ((512, 6, 8), "sell8", False, {"dictionary": False}, "sell8_pair_kernel", True),

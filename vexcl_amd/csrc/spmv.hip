@@ -140,9 +140,11 @@ void csr_stream_kernel(long long n, long long nblocks, V alpha, int append,
 
     // "+=" on an empty row leaves y untouched: no read-modify-write traffic for
     // the mostly-empty remote part of a partitioned matrix
-    if (t < rows_here && !(append && my_lo == my_hi)) {
+    const V *zs = static_cast<const V *>(trav.z);             // != NULL: y = alpha A x + beta zs (round 6; every row is written)
+    if (t < rows_here && !(append && !zs && my_lo == my_hi)) {
         V r = alpha * sum;
-        if (append) r = y[r0 + t] + r;
+        if (zs) r = (V)trav.beta * zs[r0 + t] + r;
+        else if (append) r = y[r0 + t] + r;
         y[r0 + t] = r;
     }
 }
@@ -241,9 +243,11 @@ void csr_stream2_kernel(long long n, long long nblocks, V alpha, int append,
         }
         if (te < end) __syncthreads();
     }
-    if (t < rows_here && !(append && raw_lo == raw_hi)) {
+    const V *zs = static_cast<const V *>(trav.z);             // != NULL: y = alpha A x + beta zs (round 6; every row is written)
+    if (t < rows_here && !(append && !zs && raw_lo == raw_hi)) {
         V r = alpha * sum;
-        if (append) r = y[r0 + t] + r;
+        if (zs) r = (V)trav.beta * zs[r0 + t] + r;
+        else if (append) r = y[r0 + t] + r;
         y[r0 + t] = r;
     }
 }
@@ -271,14 +275,15 @@ template <typename V, typename I, typename P = I>
 __global__ __launch_bounds__(256)
 void csr_scalar_kernel(long long n, V alpha, int append,
         const P *__restrict__ ptr, const I *__restrict__ col, const V *__restrict__ val,
-        const V *__restrict__ x, V *__restrict__ y)
+        const V *__restrict__ x, V *__restrict__ y, const V *zs = nullptr, V beta = V(0))
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         V sum = 0;
         for (P j = ptr[i], e = ptr[i + 1]; j < e; ++j) sum += val[j] * x[col[j]];
         V r = alpha * sum;
-        if (append) r = y[i] + r;
+        if (zs) r = beta * zs[i] + r;
+        else if (append) r = y[i] + r;
         y[i] = r;
     }
 }
@@ -574,7 +579,8 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
     hipStream_t s = as_stream(stream);
     if (!aligned16(col) || !aligned16(val)) {
         int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 32);
-        csr_scalar_kernel<V, I><<<grid, 256, 0, s>>>(n, alpha, append, ptr, col, val, x, y);
+        const trav_dev ad = with_addend(trav_dev{nullptr, 0, 0, 0});
+        csr_scalar_kernel<V, I><<<grid, 256, 0, s>>>(n, alpha, append, ptr, col, val, x, y, static_cast<const V *>(ad.z), (V)ad.beta);
         VEXHIP_LAUNCH_CHECK();
         return 0;
     }
@@ -584,6 +590,7 @@ int spmv_csr(int dev, void *stream, int64_t n, V alpha, int append,
     long long grid = swz ? ((nb + 7) / 8) * 8 : nb;
     trav_dev order = {nullptr, 0, 0, 0};
     if (tr && tr->grid_blocks > 0) order = make_traversal(tr, nb, &grid);
+    order = with_addend(order);                                    // y = alpha A x + beta z (vexhip_spmat_apply_axpby_*)
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
 #define LAUNCH(NT, SWZ) csr_stream_kernel<V, I, NT, SWZ><<<(unsigned)grid, CSR_BLOCK, 0, s>>>( \
         n, nb, alpha, append, ptr, col, val, x, y, order)
@@ -780,7 +787,8 @@ int spmv_csr_p64_impl(int dev, void *stream, int64_t n, V alpha, int append, con
     hipStream_t s = as_stream(stream);
     if (!aligned16(col) || !aligned16(val) || g_csr_variant == 8) {
         const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 32);
-        csr_scalar_kernel<V, int, long long><<<grid, 256, 0, s>>>(n, alpha, append, ptr, col, val, x, y);
+        const trav_dev ad = with_addend(trav_dev{nullptr, 0, 0, 0});
+        csr_scalar_kernel<V, int, long long><<<grid, 256, 0, s>>>(n, alpha, append, ptr, col, val, x, y, static_cast<const V *>(ad.z), (V)ad.beta);
         VEXHIP_LAUNCH_CHECK();
         return 0;
     }
@@ -789,6 +797,7 @@ int spmv_csr_p64_impl(int dev, void *stream, int64_t n, V alpha, int append, con
     trav_dev order = {nullptr, 0, 0, 0};
     const bool strips = tr && tr->grid_blocks > 0;
     if (strips) order = make_traversal(tr, nb, &grid);
+    order = with_addend(order);
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     if (strips) csr_stream2_kernel<V, int, false, 2048, long long><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
     else csr_stream2_kernel<V, int, true, 2048, long long><<<(unsigned)grid, CSR_BLOCK, 0, s>>>(n, nb, alpha, append, ptr, col, val, x, y, order);
