@@ -1,4 +1,5 @@
-"""Round 6: the chained scatter (vexhip_sort_set_rank(8)...) against the default on hashed u32 keys: same result (keys and, for pairs, the
+"""Round 6 EXPERIMENT (not the product): needs tools/r06_sort_onesweep_experiment.hip built in place of vexcl_amd/csrc/sort.hip -- rank modes 8 / 9
+exist only there (profiles/r06_sort_chain_experiments.md).  The chained scatter (vexhip_sort_set_rank(8)...) against the default on hashed u32 keys: same result (keys and, for pairs, the
 permutation), time per sort; SORT_MODES = comma list of rank modes, SORT_N = keys."""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
