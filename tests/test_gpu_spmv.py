@@ -713,6 +713,25 @@ def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
             assert np.array_equal(dy.cpu().numpy(), beta * y0 + ax), (fmt, alpha, beta, "z = y")
     with pytest.raises(Exception):
         A.apply_axpby(dx, dx, 1.0, dz, 1.0)          # y = x: refused
+    # vectors that start at an odd element (views): the plane product wants 16-byte addresses -- x or y odd: the grid product takes the
+    # addend; only z odd: two passes inside the call; the same bits every time
+    ptr, col, val = _grid7_natural(512, 6, 8, zero_face=False)
+    m = len(ptr) - 1
+    os.environ["VEXHIP_PLANE_FORCE"] = "1"
+    try:
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+    finally:
+        os.environ.pop("VEXHIP_PLANE_FORCE", None)
+    x = oracle.random_f64(31, m); z = oracle.random_f64(32, m)
+    ax = oracle.spmv_csr(ptr, col, val, x, alpha=-1.0)
+    for ox, oz, oy in ((0, 1, 0), (1, 0, 0), (0, 0, 1), (1, 1, 1)):
+        bx = T.up(np.concatenate([np.zeros(ox), x])); bz = T.up(np.concatenate([np.zeros(oz), z])); by = T.up(np.full(m + oy, np.nan))
+        A.apply_axpby(bx[ox:], by[oy:], -1.0, bz[oz:], 0.5)
+        assert np.array_equal(by[oy:].cpu().numpy(), 0.5 * z + ax), (ox, oz, oy)
+    # a matrix without entries: y = beta z
+    E0 = T.ops.SpMat(T.up(np.zeros(m + 1, dtype=np.int32)), T.up(np.zeros(0, dtype=np.int32)), T.up(np.zeros(0)), n_cols=m)
+    dy = T.up(np.full(m, np.nan)); E0.apply_axpby(T.up(x), dy, 3.0, T.up(z), -2.0)
+    assert np.array_equal(dy.cpu().numpy(), -2.0 * z)
     # float matrices: the fp32 plane and grid products take the addend as well; every rounding is a float's
     f32 = np.float32
     for (nx, ny, nz), product in (((512, 6, 8), "sell8_plane_f32_kernel"), ((70, 11, 13), "sell8_grid_f32_kernel"), ((1030, 5, 9), "sell8_grid_f32_kernel")):
