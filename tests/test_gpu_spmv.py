@@ -682,7 +682,7 @@ def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):
              ((64, 16, 16), None, False, {"march": False}, "sell8_pair_kernel", True),       # value codes from the slice dictionary, pair product
              ((64, 16, 16), None, False, {"dictionary": False}, "sell8_pair_kernel", True),  # value codes, one block per slice
              ((64, 64, 64), None, False, {"march": False}, "sell8_pair_kernel", True),       # the benchmark's operator: slice dictionary, pair product
-             ((64, 64, 64), None, False, {}, "sell8_march_kernel", False))                  # the march product has its own epilogue: two passes
+             ((64, 64, 64), None, False, {}, "sell8_march_kernel", True))                   # the march product: in its hot loop's epilogue (z and beta from the cold arguments)
     for (nx, ny, nz), fmt, force, kw, product, one_pass in cases:
         ptr, col, val = oracle.poisson3d(nx) if (nx, ny, nz) == (64, 64, 64) else _grid7_natural(nx, ny, nz, zero_face=False)
         m = len(ptr) - 1

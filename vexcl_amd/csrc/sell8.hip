@@ -848,7 +848,12 @@ void sell8_march_kernel(march_cold<V> cold_args /* first: offset 0 of the kernar
             body(sum);
             V2 *yp = reinterpret_cast<V2 *>(ys + lb);
             V2 o; o.x = alpha * sum[0]; o.y = alpha * sum[1];
-            if (append) { const V2 old = *yp; o.x = old.x + o.x; o.y = old.y + o.y; }
+            if (append == 2) {                                // y = alpha A x + beta z (round 6): z and beta from the cold arguments, where y's element lies in z
+                const auto *ca = cold();
+                const V bz = (V)ca->trav.beta;
+                const V2 old = *reinterpret_cast<const V2 *>(static_cast<const char *>(ca->trav.z) + (reinterpret_cast<const char *>(yp) - reinterpret_cast<const char *>(y)));
+                o.x = bz * old.x + o.x; o.y = bz * old.y + o.y;
+            } else if (append) { const V2 old = *yp; o.x = old.x + o.x; o.y = old.y + o.y; }
             __builtin_nontemporal_store(o, yp);               // y is written once and not re-read by this kernel
             b += SLB; if (b >= capb) b -= capb;
             xc += SLB; xf0 += SLB; xf1 += SLB; ys += SLB; ++k;
@@ -905,7 +910,10 @@ void sell8_march_kernel(march_cold<V> cold_args /* first: offset 0 of the kernar
                 if (i + q < n)
                     for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
         }
-        store_pair<V>(n, i, alpha, append, sum, y);          // (the march product takes no addend: spmat.hip does not offer it one)
+        {
+            const trav_dev tz = {nullptr, 0, 0, 0, append == 2 ? c->trav.z : nullptr, append == 2 ? c->trav.beta : 0.0};
+            store_pair<V>(n, i, alpha, append == 1, sum, y, tz);
+        }
         b += SLB; if (b >= capb) b -= capb;
         ++k;
         __syncthreads();
@@ -1248,6 +1256,8 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     trav_dev t8 = {nullptr, 0, 0, 0};
     if (strips) t8 = trav_dev{nullptr, (int)tr->chunk, (int)tr->planes, (int)tr->plane_blocks};
+    t8 = with_addend(t8);                                                  // y = alpha A x + beta z: the kernel is told by append == 2
+    if (t8.z) append = 2;
     const int lo_e = m->lo & ~1;                                           // window bounds on even elements (16-byte ring accesses)
     const long long span_b = march_span_bytes(m->lo, m->hi, (int)sizeof(V));
     long long lds = march_lds_bytes(m->lo, m->hi, (int)sizeof(V));
@@ -1528,7 +1538,7 @@ int spmv_sell8v(int dev, void *stream, int64_t n, V alpha, int append, int64_t w
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const char *b = static_cast<const char *>(buf);
     if (march && blocks && w <= 8 && g_sell8_variant == 0 && !(tr && tr->order))
-        return march_launch<V>(dev, s, n, ns, alpha, append, (int)w, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);      // (takes no addend: spmat.hip does not offer it one)
+        return march_launch<V>(dev, s, n, ns, alpha, append, (int)w, deltas, values, cp, cc, cv, x, y, tr, b, blocks, march);
     t8 = with_addend(t8);
 #define PAIRV(W, DICT) sell8_pair_kernel<V, (W <= 8 ? W : 8), true, DICT><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, b, deltas, values, cp, cc, cv, x, y, t8, b, blocks)
 #define CASE(W) case W: if (g_sell8_variant != 1 && W <= 8) { if (blocks) PAIRV(W, true); else PAIRV(W, false); } \

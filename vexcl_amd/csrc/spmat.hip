@@ -574,9 +574,9 @@ using namespace vexhip;
 
 namespace {
 // products whose launcher hands the addend to its kernels' store_pair (traversal.hpp): the pair / any-width products of the coded storages
-// and of the 32-bit columns, the CSR kernels in their own epilogues; not the march product (its hot loop has its own epilogue)
+// and of the 32-bit columns, the CSR kernels and the march product in their own epilogues
 inline bool addend_by_store_pair(const spmat *A, product_kind k) {
-    return k == P_PAIR_CODES || k == P_PAIR_DICT_VALUES || k == P_PAIR_VALUES || k == P_SELL32 || (k == P_MARCH && !A->march.usable) || k == P_CSR32 || k == P_CSR64;
+    return k == P_PAIR_CODES || k == P_PAIR_DICT_VALUES || k == P_PAIR_VALUES || k == P_SELL32 || k == P_MARCH || k == P_CSR32 || k == P_CSR64;
 }
 template <typename V>
 int apply_with_addend(const spmat *A, void *stream, V alpha, const V *x, V beta, const V *z, V *y) {
