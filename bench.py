@@ -536,6 +536,10 @@ def secondary_rows(torch, L, ops, dev, local_rank):
 
 
 def main():
+    # a flag wait of the peer-window transports gives up after 20 s by default (ranks of a job may be seconds apart); inside this bench every
+    # product stands between barriers, so a flag that does not come within 5 s never comes: a transport that does not work on this
+    # machine then costs --transport auto seconds, not minutes (read once, when the library first waits)
+    os.environ.setdefault("VEXHIP_IPC_TIMEOUT_MS", "5000")
     if os.environ.get("BENCH_DUMP_AFTER"):            # diagnostics: where is every rank after that many seconds?
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_AFTER"]), exit=False)
