@@ -605,7 +605,12 @@ int vexhip_dist_spmv_create_halo(vexhip_ipc_window *win, const vexhip_spmat *ext
  * "x is final" (raised by the first workgroup of the owner's launch) and `consumed` (raised behind the launch; the same kernel
  * waits for the neighbours' `consumed`, so that nothing behind it in the stream overwrites a plane still being read).
  * order = VEXHIP_PULL_EVENTS: no flag, `win` may be NULL -- the CALLER orders the devices' streams with events (logical devices
- * sharing one GPU may share a hardware queue, where a launch that waits for a later launch would never end).  Time-outs as above. */
+ * sharing one GPU may share a hardware queue, where a launch that waits for a later launch would never end).  Time-outs as above.
+ * `ext` may have a plane plan, a grid plan (any line length, fp64 or fp32) or -- no geometry at all -- be stored as SELL-512 with
+ * diagonal codes (storage "sell8" / "sell8v": a value per entry or value codes), provided no diagonal reaches further than `halo`
+ * elements beyond the rank's rows: any banded operator whose band fits one ghost range, e.g. the variable-coefficient 7-point
+ * problem.  The launch is then the pair product in its HALO role (csrc/sell8.hip: the slices that touch a ghost range run last and
+ * translate a column into [x_below | x | x_above]).  Anything else: a non-zero return with the reason in vexhip_last_error(); the caller keeps the five-phase step.    */
 enum { VEXHIP_PULL_FLAGS = 1, VEXHIP_PULL_EVENTS = 2 };
 int vexhip_dist_spmv_create_halo_pull(vexhip_ipc_window *win, const vexhip_spmat *ext, int64_t rows, int64_t halo, int lower, int upper,
         int order, vexhip_dist_spmv **out);

@@ -265,6 +265,48 @@ TEST_CASE(spmv_one_launch_step_multi_device) {
     }
 }
 
+TEST_CASE(spmv_one_launch_step_general_matrix_multi_device) {
+    // round 6: the one-launch step for ANY strip stored with diagonal codes (csrc/sell8.hip, the pair product's role): a 7-point pattern with a
+    // different value in every entry (nothing to code: SELL8, values in the slices) and a banded matrix with an odd diagonal whose pairs
+    // straddle the seam between a ghost range and the device's rows.  Bits of the same matrix on one device; '=', '+=', scaled, x rewritten.
+    const std::vector<vex::backend::command_queue> &q = ctx.queue();
+    if (q.size() < 2) return;
+    const size_t nx = 64, ny = 32, nz = 16 * q.size(), N = nx * ny * nz, P = nx * ny;      // a plane = 2048 rows = 4 slices; strips of 16 planes
+    for (int kind = 0; kind < 2; ++kind) {
+        std::vector<int> row(1, 0), col; std::vector<double> val;
+        for (size_t k = 0, idx = 0; k < nz; ++k) for (size_t j = 0; j < ny; ++j) for (size_t i = 0; i < nx; ++i, ++idx) {
+            const bool inner = i > 0 && i + 1 < nx && j > 0 && j + 1 < ny && k > 0 && k + 1 < nz;
+            if (!inner) { col.push_back((int)idx); val.push_back(1); }
+            else if (kind == 0) for (long d : {-(long)P, -(long)nx, -1l, 0l, 1l, (long)nx, (long)P}) { col.push_back((int)(idx + d)); val.push_back(1.0 + 1e-3 * (double)((idx * 7 + (size_t)(d + (long)P)) % 9973)); }
+            else for (long d : {-(long)P + 1, -3l, 0l, 5l, (long)P - 1}) { col.push_back((int)(idx + d)); val.push_back(0.5 + 1e-3 * (double)((idx * 5 + (size_t)(d + (long)P)) % 7919)); }
+            row.push_back((int)col.size());
+        }
+        const std::vector<size_t> part = vex::partition(N, q);
+        for (unsigned d = 0; d < q.size(); ++d) CHECK((part[d + 1] - part[d]) % P == 0);
+        vex::SpMat<double, int, int> A(q, N, N, row.data(), col.data(), val.data());
+        CHECK(std::string(A.step_kind()).find("one launch per device") == 0);
+        if (std::string(A.step_kind()).find("one launch per device") != 0) std::cerr << "one-launch step declined: " << A.halo_declined() << std::endl;
+        for (unsigned d = 0; d < q.size(); ++d) CHECK(A.storage_info(d).format == VEXHIP_SPMAT_SELL8 && !A.storage_info(d).plane.usable && !A.storage_info(d).grid.usable);
+        std::vector<vex::backend::command_queue> q1(1, q[0]);
+        vex::SpMat<double, int, int> A1(q1, N, N, row.data(), col.data(), val.data());
+        std::vector<double> x = random_vector<double>(N), y1(N), ym(N);
+        vex::vector<double> X(ctx, x), Y(ctx, N), X1(q1, x), Y1(q1, N);
+        auto same_bits = [&]() { vex::copy(Y, ym); vex::copy(Y1, y1); for (size_t i = 0; i < N; ++i) if (std::memcmp(&ym[i], &y1[i], 8)) return false; return true; };
+        Y = A * X; Y1 = A1 * X1;
+        CHECK(same_bits());
+        for (int rep = 0; rep < 20; ++rep) { Y = A * X; X = 0.5 * X + 0.25; Y += 1.5 * (A * X); X1 = 0.5 * X1 + 0.25; }
+        Y1 = A1 * X1; Y = A * X;
+        CHECK(same_bits());
+        Y = X; Y += 2.5 * (A * X); Y -= A * X; Y1 = X1; Y1 += 2.5 * (A1 * X1); Y1 -= A1 * X1;
+        CHECK(same_bits());
+        std::vector<size_t> r2(row.begin(), row.end()), c2(col.begin(), col.end());
+        vex::copy(X, x);
+        auto want = host_spmv(r2, c2, val, x);
+        Y = A * X; vex::copy(Y, ym);
+        for (size_t i = 0; i < N; i += 53) CHECK_CLOSE(ym[i], want[i], 1e-8);
+    }
+}
+
 TEST_CASE(spmv_nonsquare_and_index_types) {                          // spmv.cpp:61-114
     const size_t n = 1024, m = 2 * n;
     std::vector<size_t> row; std::vector<int> col; std::vector<double> val;

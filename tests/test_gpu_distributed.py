@@ -143,7 +143,7 @@ def _stencil_strip(torch, nx, ny, nz, r0, r1, dev):
     return ptr.to(torch.int32), col.to(torch.int32), val
 
 
-def _halo_worker(rank, world, port, planes_per_rank, ny, out):
+def _halo_worker(rank, world, port, planes_per_rank, ny, out, transport="halo", variable=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VEXHIP_PLANE_FORCE="1", VEXHIP_IPC_TIMEOUT_MS="20000")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -158,21 +158,27 @@ def _halo_worker(rank, world, port, planes_per_rank, ny, out):
         r0, r1 = part[rank], part[rank + 1]
         assert (r1 - r0) == planes_per_rank * nx * ny
         ptr, col, val = _stencil_strip(torch, nx, ny, nz, r0, r1, dev)
+        fp, fc, fv = _stencil_strip(torch, nx, ny, nz, 0, N, dev)
+        if variable:           # a different value in every entry: nothing to code -- SELL-512 with diagonal codes and stored values (the pair product's role)
+            fv = fv * (1.0 + 1e-3 * ops.fill_hash(torch.empty_like(fv), 5))
+            val = fv[int(fp[r0]):int(fp[r1])].clone()
         A = DistSpMat(ptr, col, val, N, N, keep_strip=True)
         # the whole matrix on one "device": the bits the N-rank product must reproduce (the stored strip keeps a row's entries in
         # column order, ghost columns included -- unlike the split step, which adds the remote entries last)
-        fp, fc, fv = _stencil_strip(torch, nx, ny, nz, 0, N, dev)
         F = ops.SpMat(fp, fc, fv)
         fx = ops.fill_hash(torch.empty(N, dtype=torch.float64, device=dev), 42)
         x = fx[r0:r1].clone()
-        ok = A.enable_native(transport="halo")
+        ok = A.enable_native(transport=transport)
         assert ok, A.native_error
         st = A.native_status()
-        ok = ok and st["transport"] == "halo"
+        ok = ok and st["transport"] == transport
+        if variable:
+            ok = ok and A._ext.storage == "sell8" and A._ext.plane is None and A._ext.grid is None
         y = torch.empty(r1 - r0, dtype=torch.float64, device=dev)
         fy = torch.empty(N, dtype=torch.float64, device=dev)
+        xk = torch.empty_like(x)                             # ONE vector rewritten between products (pull: mapped by the neighbours once)
         for k in range(40):                                  # back to back, x changing: flags, ghost planes and step numbers are reused
-            xk = x * (1.0 + k)
+            torch.mul(x, 1.0 + k, out=xk)
             y.fill_(-3.0)
             A.apply(xk, y, 1.0, False)
             if k % 13 == 0:
@@ -215,6 +221,24 @@ def test_one_launch_step_reads_ghost_planes_from_the_window(world, planes, ny, b
     out = ctx.Array("i", [0] * world)
     port = _free_port()
     procs = [ctx.Process(target=_halo_worker, args=(r, world, port, planes, ny, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert list(out) == [1] * world
+
+
+@pytest.mark.parametrize("world,planes,ny,variable", [(2, 8, 128, False), (2, 8, 128, True), (2, 3, 64, True)])
+def test_one_launch_step_reads_the_neighbours_x_in_place(world, planes, ny, variable, built_lib):
+    """Transport "pull" (round 6) BETWEEN PROCESSES: nothing is pushed -- every rank maps the allocation that holds its neighbours' x
+    (vexhip_ipc_export / _open) and the product launch reads their boundary planes where they lie, behind "x is final" flags.  For the
+    plane product and -- variable -- for a strip stored with diagonal codes and a value per entry (the pair product's role,
+    csrc/sell8.hip): any banded operator.  40 products back to back with x rewritten in between; the BITS of the one-device product."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Array("i", [0] * world)
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, planes, ny, out, "pull", variable)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -22,6 +22,8 @@ rows = r1 - r0
 ptr, col, val = ops.poisson3d(n, dev, rows=(r0, r1))
 DT = torch.float32 if os.environ.get("DIST_DTYPE", "f64") == "f32" else torch.float64      # DIST_DTYPE=f32: the float step (plane32.hip; pull only)
 val = val.to(DT)
+if os.environ.get("DIST_VARIABLE"):       # a value per entry (the variable-coefficient problem): no geometry plan -- SELL-512 with diagonal codes, the pair product's HALO role
+    val = val * (1.0 + 1e-3 * ops.fill_hash(torch.empty(val.numel(), dtype=torch.float64, device=dev), 7).to(DT))
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 # the strip stored WITH its ghost planes, built by the library (what vexcl/spmat.hpp calls)
 nnz = int(col.numel())
@@ -31,11 +33,11 @@ L.csr_extend_halo_i32(0, None, rows, nnz, p(ptr), p(col), r0, P, P, p(ptr_ext), 
 assert bad.value == 0, bad.value
 torch.cuda.synchronize()
 ext = ops.SpMat(ptr_ext, col_ext, val, n_cols=rows + 2 * P)
-assert ext.plane or ext.grid, "the stored strip did not get a plane or grid plan"
+assert ext.plane or ext.grid or ext.storage in ("sell8", "sell8v"), "the stored strip did not get a plane or grid plan nor diagonal codes"
 loc_only = None
 x = ops.fill_hash(torch.empty(rows, dtype=torch.float64, device=dev), 42).to(DT); y = torch.empty_like(x)
 s = torch.cuda.Stream(); sp = ctypes.c_void_p(s.cuda_stream)
-out = {"grid": n, "strip_rows": rows, "stored_strip": {"rows": rows + 2 * P, "storage": ext.storage, "plane_plan": ext.plane},
+out = {"grid": n, "strip_rows": rows, "stored_strip": {"rows": rows + 2 * P, "storage": ext.storage, "product": ext.product, "plane_plan": ext.plane},
        "env": {k: v for k, v in os.environ.items() if k.startswith("VEXHIP_HALO")}}
 # the bits of the ONE-device product: the same stored strip through the CSR kernel on x with its ghost planes attached
 x_ext = torch.cat([x[rows - P:], x, x[:P]]).contiguous()

@@ -598,7 +598,12 @@ class SpMat {
                     const bool by_plane = pl.usable && (size_t)pl.lines_per_plane * 512 == Hh && (size_t)pl.planes * Hh == l + rows + h;
                     const bool by_grid = is_double<val_t>() && !pl.usable && gr.usable && D->info.format == VEXHIP_SPMAT_SELL8V && !D->info.tail_nnz
                                          && (size_t)gr.lines_per_plane * (size_t)gr.nx == Hh && (size_t)gr.planes * Hh == l + rows + h;
-                    if (!by_plane && !by_grid) { declined[d] = "the strip with its ghost planes is not stored for the plane or the grid product (a 7-point operator on a grid, few distinct values)"; return; }
+                    // round 6: or ANY strip stored with diagonal codes (a general banded operator, a coefficient per face) whose diagonals stay
+                    // within one ghost range: the pair product's role (csrc/sell8.hip); the library checks the reach when the step is made
+                    const bool by_codes = is_double<val_t>() && !by_plane && !by_grid
+                                          && (D->info.format == VEXHIP_SPMAT_SELL8 || D->info.format == VEXHIP_SPMAT_SELL8V) && !D->info.tail_nnz && D->info.ell_width <= 8
+                                          && Hh % 512 == 0 && rows % 512 == 0;
+                    if (!by_plane && !by_grid && !by_codes) { declined[d] = "the strip with its ghost planes is stored neither for the plane / grid product nor with diagonal codes (ELL width <= 8, no CSR tail, whole 512-row slices)"; return; }
                     if (order == VEXHIP_PULL_FLAGS) {
                         vexhip_ipc_window *w = nullptr;
                         backend::check(vexhip_ipc_window_create(ord, (int)d, (int)nd, 0, &w));

@@ -25,6 +25,7 @@
 namespace vexhip {
 // spmat.hip: the stored strip of a rank as the operand of the one-launch step (halo.hpp)
 int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane, int *line_length, int *value_type);
+int spmat_halo_general(const vexhip_spmat *h, int64_t halo, int64_t rows_ext, int *reach, int *value_type);
 int spmat_device(const vexhip_spmat *h, int *dev);
 int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const void *x, void *y, const halo_dev &H);
 }
@@ -1091,8 +1092,13 @@ static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows
     int planes = 0, ny = 0, nx = 0, vtype = VEXHIP_F64;
     if (int rc = spmat_halo_geometry(ext, &planes, &ny, &nx, &vtype)) return rc;
     const int has_lo = lower >= 0 ? 1 : 0, has_hi = upper >= 0 ? 1 : 0;
-    VEXHIP_REQUIRE(planes > 0 && (int64_t)ny * nx == halo && planes == has_lo + rows / halo + has_hi && (pull || (nx == 512 && vtype == VEXHIP_F64)),
-                   "the stored strip is not a plane-product matrix (pull: or a grid-product matrix) of (lower ghost plane +) the rank's planes (+ upper ghost plane)");
+    // round 6: not a grid matrix, but stored with diagonal codes (a general banded operator) whose diagonals stay within one ghost range:
+    // the pair product's role (sell8.hip), pull form only
+    int reach = 0;
+    if (planes == 0 && pull) { if (int rc = spmat_halo_general(ext, halo, (int64_t)(has_lo + has_hi) * halo + rows, &reach, &vtype)) return rc; }
+    VEXHIP_REQUIRE(reach > 0 || (planes > 0 && (int64_t)ny * nx == halo && planes == has_lo + rows / halo + has_hi && (pull || (nx == 512 && vtype == VEXHIP_F64))),
+                   "the stored strip is not a plane-product matrix (pull: or a grid-product matrix, or a matrix with diagonal codes whose diagonals stay within one ghost range) "
+                   "of (lower ghost plane +) the rank's planes (+ upper ghost plane)");
     VEXHIP_REQUIRE(!w || ((lower < 0 || w->peer[lower]) && (upper < 0 || w->peer[upper])), "a neighbour's window has not been opened (vexhip_ipc_window_open / _attach)");
     int ext_dev = 0;
     if (int rc = spmat_device(ext, &ext_dev)) return rc;
@@ -1127,6 +1133,7 @@ static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows
         // ordered by the caller's events: no window, no flag; the ghost planes come with every product
         H.step = D->d_own_step; H.done = D->d_halo_done; H.err = D->d_err; H.ticks = spin_ticks(); H.push_blocks = 0;
         H.halo = (int)halo; H.z0 = has_lo; H.z1 = has_lo + (int)(rows / halo);
+        if (reach > 0) { H.lo_planes = reach; H.hi_planes = -1; }       // the pair product's role (spmat.hip spmat_apply_halo)
         *out = reinterpret_cast<vexhip_dist_spmv *>(D);
         return 0;
     }
@@ -1161,6 +1168,7 @@ static int create_halo_impl(ipc_window *w, const vexhip_spmat *ext, int64_t rows
     H.push_blocks = 16;
     if (const char *pb = env(ENV_VEXHIP_HALO_PUSH_BLOCKS)) H.push_blocks = std::max(0, std::min(1024, std::atoi(pb)));       // 0: the product workgroups push (plane.hip)
     H.halo = (int)halo; H.z0 = has_lo; H.z1 = has_lo + (int)(rows / halo); H.lo_planes = 0; H.hi_planes = 0;
+    if (reach > 0) { H.lo_planes = reach; H.hi_planes = -1; }           // the pair product's role (spmat.hip spmat_apply_halo)
     H.debug = nullptr;
     if (env(ENV_VEXHIP_HALO_DEBUG)) {                  // diagnostics: 6 words per workgroup of the LAST launch (tools/r05_halo_timeline.py reads them through vexhip_dist_spmv_debug)
         if (hipMalloc(reinterpret_cast<void **>(&D->d_halo_debug), 6 * 8 * 4096) == hipSuccess) { (void)hipMemset(D->d_halo_debug, 0, 6 * 8 * 4096); H.debug = D->d_halo_debug; }

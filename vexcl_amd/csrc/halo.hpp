@@ -38,7 +38,7 @@ struct halo_dev {
     int push_blocks;                                    // workgroups per side that copy a plane
     int halo;                                           // elements of a ghost plane
     int z0, z1;                                         // planes of the stored grid this launch computes: [z0, z1)
-    int lo_planes, hi_planes;                           // planes of the short chunks next to the lower / upper ghost plane (0: none)
+    int lo_planes, hi_planes;                           // planes of the short chunks next to the lower / upper ghost plane (0: none); the pair product's role (sell8.hip): lo_planes = reach of the diagonals in rows
     unsigned long long *debug;                          // diagnostics (VEXHIP_HALO_DEBUG): per workgroup {start, ghost flag seen, first ghost line in registers, end} in 100 MHz ticks
     int lo_two_pass;                                    // the lower chunk walks its planes above the first one first and its first plane (the one that needs the ghost plane) last
     int acquire;                                        // behind a ghost flag: 0 no cache invalidate (the window is uncached), 1 agent scope, 2 system scope
@@ -95,13 +95,16 @@ __device__ inline void halo_announce(const halo_dev &H, unsigned long long step)
 // L2 full of this launch's y, once per workgroup), so the last one may tell the owners that their planes have been read, wait -- PULL: the
 // planes are the owners' x itself -- until the neighbours say the same of this rank's, and advance the step number.  The next launch
 // of the stream starts behind this one: it reads the new number.  Called by EVERY workgroup of the launch, idle ones included.
-__device__ inline void halo_finish(const halo_dev &H, unsigned long long step) {
-    if (!H.one_launch) return;
+// (`counted`, `target`: a launch of MANY short workgroups of which few read a ghost range -- the pair product's role, sell8.hip --
+// counts only those and workgroup 0, which has raised the flags: the wait for the stores' acknowledgements in front of the count
+// costs a workgroup that lives 12 us a quarter of its life, and the others have nothing the neighbours wait for.)
+__device__ inline void halo_finish(const halo_dev &H, unsigned long long step, bool counted = true, unsigned target = 0) {
+    if (!H.one_launch || !counted) return;                                // (uniform)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned old = __hip_atomic_fetch_add(H.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == gridDim.x) {
+        if (old + 1u == (target ? target : gridDim.x)) {
             __hip_atomic_store(H.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (H.consumed_lo) __hip_atomic_store(H.consumed_lo, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (H.consumed_hi) __hip_atomic_store(H.consumed_hi, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

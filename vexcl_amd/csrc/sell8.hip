@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "traversal.hpp"
 #include "pairing.hpp"
+#include "halo.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -559,6 +560,127 @@ void sell8_pair_kernel(long long n, long long nslices, V alpha, int append,
                 for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
     }
     store_pair<V>(n, i, alpha, append, sum, y, trav);
+}
+
+// ---------------------------------------------------------------------------
+// HALO role of the pair product (round 6; halo.hpp, the PULL form): one device's whole product step in ONE launch for ANY matrix stored
+// with diagonal codes (a general banded operator: a coefficient per face), not only the grid storages.  The stored strip has an empty
+// ghost range of H.halo rows in front of / behind the device's rows where it has a neighbour; rows and columns are numbered in that
+// stored form.  Slices whose diagonals stay inside the device's own rows run the pair product as it is (x and y moved by the ghost
+// range); the slices within `reach` of an end -- dispatched LAST -- wait for the neighbour's "x is final" flag and take every element
+// of x through a translation ghost-below / own / ghost-above (two 8-byte requests per column instead of one 16-byte pair: a pair may
+// straddle the seam).  Same codes, same order of the sums: the BITS of the one-device product.
+template <typename V, int W, bool VCODED, bool DICT>
+__global__ __launch_bounds__(256)
+void sell8_pair_halo_kernel(long long own_rows, V alpha, int append,
+        const char *__restrict__ buf, const int *__restrict__ deltas, const V *__restrict__ values,
+        const V *__restrict__ x, V *__restrict__ y, const char *__restrict__ pool, const int *__restrict__ blocks, halo_dev H)
+{
+    constexpr int WP = (W + 1) / 2;
+    constexpr long long SLICE = VCODED ? (long long)WP * 2048 : ((long long)WP * 1024 + (long long)W * S8_ROWS * (long long)sizeof(V));
+    constexpr long long CODE_BYTES = VCODED ? (long long)WP * 2048 : (long long)WP * 1024;
+    typedef typename vec2<V>::type V2;
+    __shared__ int s_delta[256];
+    __shared__ V s_value[VCODED ? 256 : 1];
+    __shared__ int s_flag;
+    const int t = threadIdx.x;
+    // own slices [0, ns); the first / last `edge` of them reach into a ghost range.  Dispatch order: the inner ones, then the lower
+    // edge, then the upper edge (a workgroup that waits for a flag holds its CU slot: it must not start before the ones that do not)
+    const long long hlo = (long long)H.z0 * H.halo;                       // rows of the lower ghost range (0: no neighbour below)
+    const long long ns = (own_rows + S8_ROWS - 1) / S8_ROWS;
+    const long long edge = ((long long)H.lo_planes + S8_ROWS - 1) / S8_ROWS;      // H.lo_planes: the reach of the diagonals in rows (comm.hip)
+    const long long elo = H.lo ? (edge < ns ? edge : ns) : 0, ehi = H.hi ? (edge < ns - elo ? edge : ns - elo) : 0;
+    const long long inner = ns - elo - ehi;
+    long long so = blockIdx.x;                                            // -> own slice
+    bool need_lo = false, need_hi = false;
+    if (so < inner) so += elo;
+    else if (so < inner + elo) { so -= inner; need_lo = true; }
+    else { so = ns - ehi + (so - inner - elo); need_hi = true; }
+    if (H.lo && H.hi && ns < 2 * edge) { need_lo = need_lo || so < edge; need_hi = need_hi || so >= ns - edge; }      // (strips shorter than two reaches)
+    // the step number (uncached: the neighbours' flags are compared with it) is read by the workgroups that need it only -- the ones
+    // that read a ghost range and workgroup 0, which raises "x is final": loads return in order, and the other 32 000 workgroups of a
+    // 16 Mi-row strip would wait for that word before their first code arrives.  The same workgroups are the ones halo_finish counts.
+    const bool edge_wg = need_lo || need_hi;                              // uniform
+    const bool counted = edge_wg || blockIdx.x == 0;
+    const unsigned n_counted = (unsigned)(elo + ehi) + (inner > 0 ? 1u : 0u);
+    const unsigned long long step = counted ? *H.step : 0ull;
+    halo_announce(H, step);
+    const long long sl = so + hlo / S8_ROWS;                              // slice of the stored strip
+    const long long i = sl * S8_ROWS + 2 * t;                             // row, stored numbering
+    const unsigned *cw = reinterpret_cast<const unsigned *>(DICT ? pool + (long long)blocks[sl] * CODE_BYTES : buf + sl * SLICE) + t;
+    unsigned c[WP], vc[VCODED ? WP : 1];
+#pragma unroll
+    for (int jp = 0; jp < WP; ++jp) {
+        if constexpr (DICT) { c[jp] = cw[jp * 256]; if constexpr (VCODED) vc[jp] = cw[(WP + jp) * 256]; }
+        else { c[jp] = __builtin_nontemporal_load(cw + jp * 256); if constexpr (VCODED) vc[jp] = __builtin_nontemporal_load(cw + (WP + jp) * 256); }
+    }
+    V2 v[VCODED ? 1 : W];
+    if constexpr (!VCODED) {
+        const V *vp = reinterpret_cast<const V *>(buf + sl * SLICE + (long long)WP * 1024) + 2 * t;
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(vp + j * S8_ROWS));
+    }
+    s_delta[t] = deltas[t];
+    if constexpr (VCODED) s_value[t] = values[t];
+    __syncthreads();
+    bool ghosts_ok = true;
+    if (edge_wg) ghosts_ok = halo_wait(H, step, need_lo && H.lo, need_hi && H.hi, &s_flag);
+    const V *xe = x - hlo;                                                // x in stored numbering (own range only)
+    V xv[W][2];
+    if (!edge_wg) {
+        int d[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            d[j] = s_delta[c0 < S8_PAD_UNSAFE ? c0 : c1];
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            const bool m0 = c0 < S8_PAD_UNSAFE, m1 = c1 < S8_PAD_UNSAFE;
+            const bool pair = (c0 == c1) || (c0 == S8_PAD && m1) || (c1 == S8_PAD && m0);
+            const bool use16 = pair && (m0 || m1);
+            V2 p = {V(0), V(0)};
+            if (__builtin_amdgcn_ballot_w64(use16) != 0) {
+                const V *px = use16 ? xe + (i + d[j]) : reinterpret_cast<const V *>(deltas);
+                __builtin_memcpy(&p, px, sizeof(V2));
+            }
+            xv[j][0] = p.x; xv[j][1] = p.y;
+            if (!pair) {
+                if (m0) xv[j][0] = xe[i + s_delta[c0]];
+                if (m1) xv[j][1] = xe[i + 1 + s_delta[c1]];
+            }
+            xv[j][0] = m0 ? xv[j][0] : V(0);
+            xv[j][1] = m1 ? xv[j][1] : V(0);
+        }
+    } else {
+        const long long own_end = hlo + own_rows;
+        const V *glo = reinterpret_cast<const V *>(H.lo), *ghi = reinterpret_cast<const V *>(H.hi);
+        auto at = [&](long long k) -> V {                                 // element k of x in stored numbering
+            if (k < hlo) return (glo && ghosts_ok && k >= 0) ? glo[k] : V(__builtin_nan(""));
+            if (k >= own_end) return (ghi && ghosts_ok && k - own_end < (long long)H.halo) ? ghi[k - own_end] : V(__builtin_nan(""));
+            return xe[k];
+        };
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned c0 = (c[j >> 1] >> (16 * (j & 1))) & 255u, c1 = (c[j >> 1] >> (16 * (j & 1) + 8)) & 255u;
+            xv[j][0] = c0 < S8_PAD_UNSAFE ? at(i + s_delta[c0]) : V(0);
+            xv[j][1] = c1 < S8_PAD_UNSAFE ? at(i + 1 + s_delta[c1]) : V(0);
+        }
+    }
+    V sum[2] = {V(0), V(0)};
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int sh = 16 * (j & 1) + 8 * q;
+            V a;
+            if constexpr (VCODED) a = s_value[((c[j >> 1] >> sh) & 255u) < S8_PAD_UNSAFE ? (vc[j >> 1] >> sh) & 255u : 255u];
+            else a = v[j][q];
+            sum[q] += a * xv[j][q];
+        }
+    store_pair<V>(hlo + own_rows, i, alpha, append, sum, y - hlo);
+    halo_finish(H, step, counted, n_counted);
 }
 
 // ---------------------------------------------------------------------------
@@ -1276,6 +1398,26 @@ int march_launch(int dev, hipStream_t s, int64_t n, long long ns, V alpha, int a
     return 0;
 }
 
+// One device's product step in one launch on a strip stored with diagonal codes (SELL8: values in the slices; SELL8V: value codes),
+// with or without a slice dictionary; x and y are the device's own segments (halo.hpp, the pull form; spmat.hip spmat_apply_halo).
+template <typename V>
+int sell8_apply_halo_impl(int dev, hipStream_t s, long long own_rows, V alpha, int append, int w, bool vcoded, const void *buf, const void *pool_,
+        const int *blocks, const int *deltas, const V *values, const V *x, V *y, halo_dev H)
+{
+    VEXHIP_REQUIRE(H.pull && own_rows > 0 && own_rows % S8_ROWS == 0 && H.halo % S8_ROWS == 0 && w >= 1 && w <= 8, "the one-launch step of a matrix with diagonal codes: whole slices, ELL width <= 8");
+    VEXHIP_REQUIRE(deltas && x && y && (buf || pool_) && (!vcoded || values), "NULL argument");
+    VEXHIP_SET_DEVICE(dev);
+    const long long grid = own_rows / S8_ROWS;
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    const char *b = static_cast<const char *>(buf), *pool = static_cast<const char *>(pool_);
+#define HP(W, VC, DICT) sell8_pair_halo_kernel<V, W, VC, DICT><<<(unsigned)grid, 256, 0, s>>>(own_rows, alpha, append, b, deltas, values, x, y, pool, blocks, H)
+#define HCASE(W) case W: if (vcoded) { if (blocks) HP(W, true, true); else HP(W, true, false); } else { if (blocks) HP(W, false, true); else HP(W, false, false); } break;
+    switch (w) { HCASE(1) HCASE(2) HCASE(3) HCASE(4) HCASE(5) HCASE(6) HCASE(7) HCASE(8) }
+#undef HCASE
+#undef HP
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
 inline int grid_for(int dev, int64_t n) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)info(dev).cus * 16));
 }
@@ -1703,6 +1845,11 @@ int sell8_analyze(int dev, void *stream, int64_t n, const P *ptr, const int32_t 
 
 
 } // namespace
+
+int sell8_apply_halo(int dev, hipStream_t s, long long own_rows, double alpha, int append, int w, bool vcoded, const void *buf, const void *pool,
+        const int *blocks, const int *deltas, const double *values, const double *x, double *y, halo_dev H)
+{ return sell8_apply_halo_impl<double>(dev, s, own_rows, alpha, append, w, vcoded, buf, pool, blocks, deltas, values, x, y, H); }
+
 
 // ---- 64-bit row pointers (a device may hold 2^31 entries or more; columns stay 32-bit): internal entry points used by
 //      spmat.hip -- vexhip_spmat_create_*_p64 is the C-ABI door (reference: size_t row pointers, vexcl/spmat.hpp:56-57)

@@ -65,6 +65,8 @@ int grid32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, co
         const float *x, float *y, const vexhip_grid *g);
 int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
         const vexhip_grid *g, halo_dev H);
+int sell8_apply_halo(int dev, hipStream_t s, long long own_rows, double alpha, int append, int w, bool vcoded, const void *buf, const void *pool,
+        const int *blocks, const int *deltas, const double *values, const double *x, double *y, halo_dev H);
 int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
         const int32_t *deltas, const float *values, const float *x, float *y, const vexhip_plane *plane, halo_dev H);
 
@@ -549,6 +551,24 @@ int spmat_halo_geometry(const vexhip_spmat *h, int *planes, int *lines_per_plane
     else if (A->grid.usable && A->value_type == VEXHIP_F64) { *planes = A->grid.planes; *lines_per_plane = A->grid.lines_per_plane; *line_length = A->grid.nx; }      // lines of any length: the pull form, fp64
     return 0;
 }
+// ... or ANY matrix stored with diagonal codes (round 6; the pair product's role, sell8.hip): fp64, ELL width <= 8, no CSR tail, whole slices,
+// every diagonal within one ghost range.  *reach = the largest |diagonal| (0: not such a matrix).
+int spmat_halo_general(const vexhip_spmat *h, int64_t halo, int64_t rows_ext, int *reach, int *value_type) {
+    const spmat *A = reinterpret_cast<const spmat *>(h);
+    VEXHIP_REQUIRE(A && reach && value_type, "NULL argument");
+    *reach = 0; *value_type = A->value_type;
+    if (!(A->format == VEXHIP_SPMAT_SELL8 || A->format == VEXHIP_SPMAT_SELL8V) || A->tail || A->value_type != VEXHIP_F64 || A->ell_w > 8 || A->ndeltas < 1) return 0;
+    if (A->n != rows_ext || halo % 512 || A->n % 512 || !A->deltas) return 0;
+    if (A->format == VEXHIP_SPMAT_SELL8V ? !(A->sell || (A->blocks && A->pool)) : !A->sell) return 0;
+    VEXHIP_SET_DEVICE(A->dev);
+    int table[256];
+    VEXHIP_TRY(hipMemcpy(table, A->deltas, sizeof(int) * (size_t)A->ndeltas, hipMemcpyDeviceToHost));
+    long long far = 0;
+    for (int k = 0; k < A->ndeltas; ++k) far = std::max<long long>(far, std::llabs((long long)table[k]));
+    if (far == 0 || far > halo) return 0;
+    *reach = (int)far;
+    return 0;
+}
 int spmat_device(const vexhip_spmat *h, int *dev) {
     VEXHIP_REQUIRE(h && dev, "NULL argument");
     *dev = reinterpret_cast<const spmat *>(h)->dev;
@@ -556,6 +576,13 @@ int spmat_device(const vexhip_spmat *h, int *dev) {
 }
 int spmat_apply_halo(const vexhip_spmat *h, hipStream_t s, double alpha, int append, const void *x, void *y, const halo_dev &H) {
     const spmat *A = reinterpret_cast<const spmat *>(h);
+    if (A && H.lo_planes > 0 && H.hi_planes == -1) {           // the pair product's role (comm.hip marks it: hi_planes = -1, lo_planes = reach)
+        VEXHIP_REQUIRE(A->value_type == VEXHIP_F64 && !A->tail && H.pull, "the one-launch step of a matrix with diagonal codes: fp64, no CSR tail, shares read in place");
+        halo_dev G = H; G.hi_planes = 0;
+        const bool vcoded = A->format == VEXHIP_SPMAT_SELL8V;
+        return sell8_apply_halo(A->dev, s, (long long)(H.z1 - H.z0) * H.halo, alpha, append, (int)A->ell_w, vcoded, A->sell, A->pool, A->blocks, A->deltas,
+                                (const double *)A->values, static_cast<const double *>(x), static_cast<double *>(y), G);
+    }
     VEXHIP_REQUIRE(A && A->format == VEXHIP_SPMAT_SELL8V && !A->tail, "the one-launch step needs a matrix stored for the plane or the grid product");
     if (A->value_type == VEXHIP_F32) {
         VEXHIP_REQUIRE((A->blocks || A->direct) && A->plane.usable && H.pull, "the one-launch step of a float matrix needs the plane product and shares read in place");

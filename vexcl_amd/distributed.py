@@ -252,7 +252,7 @@ class DistSpMat:
                 #      column of this rank lies in the plane below its first row or the plane above its last one, the strip is
                 #      stored as one grid matrix with those two ghost planes, and the plane product reads them from the window
                 def make_ext():
-                    st["halo"] = self._halo_plan()
+                    st["halo"] = self._halo_plan(pull=(transport == "pull"))
                 if not self._stage(make_ext):
                     return False
                 H, lower, upper = st["halo"]
@@ -390,7 +390,7 @@ class DistSpMat:
         """release the references to the strip the constructor was given (only transport "halo" needs them)"""
         self._strip = None
 
-    def _halo_plan(self, self_exchange=False):
+    def _halo_plan(self, self_exchange=False, pull=False):
         """Transport "halo": (H, lower, upper) and self._ext = the strip stored with its ghost planes, or an exception that says
         why this matrix / partition does not qualify.  H = elements of a ghost plane; lower / upper = the neighbours (-1: none).
         self_exchange (one rank, tools/r05_dist_step.py): the rank is its own lower and upper neighbour."""
@@ -430,8 +430,11 @@ class DistSpMat:
         lo, hi = (H if has_lo else 0), (H if has_hi else 0)
         ptr_ext, col_ext = halo_extended_csr(ptr, col, 0 if self_exchange else c0, self.rows, lo, hi)
         ext = ops.SpMat(ptr_ext, col_ext, val, n_cols=lo + self.rows + hi)
-        if not getattr(ext, "handle", None) or not getattr(ext, "plane", None):
-            raise RuntimeError("transport halo: the stored strip did not get a plane plan (storage %s)" % getattr(ext, "storage", "?"))
+        # pushed shares (halo): the plane product only; shares read in place (pull): also the grid product and -- round 6 -- any strip stored
+        # with diagonal codes whose diagonals stay within one ghost range (the library checks: vexhip_dist_spmv_create_halo_pull)
+        ok = getattr(ext, "handle", None) and (getattr(ext, "plane", None) or (pull and (getattr(ext, "grid", None) or getattr(ext, "storage", "") in ("sell8", "sell8v"))))
+        if not ok:
+            raise RuntimeError("transport %s: the stored strip did not get a plan for the one-launch step (storage %s)" % ("pull" if pull else "halo", getattr(ext, "storage", "?")))
         ext.ptr = ext.col = ext.val = None
         self._ext = ext
         return H, lower, upper
