@@ -235,6 +235,15 @@ int main(int argc, char **argv) {
         t.start(); for (int i = 0; i < 5; ++i) runs = vex::reduce_by_key(keys, vals, okeys, ovals); ms = t.stop_ms() / 5;
         report("reduce_by_key (int, f64) n=1e8, VEXCL_SCAN_BY_KEY=tree: three phases", (double)n, 12, ms);
         unsetenv("VEXCL_SCAN_BY_KEY");
+        // runs whose carries cross many tiles of 16 Ki elements: the value of the look-back is folded serially from the nearest tile
+        // with a run head (scan_by_key.hpp sbk_look_back: reproducible bits) -- what that costs where it has work to do
+        for (size_t len : {size_t(1) << 20, n}) {
+            keys = vex::element_index() / len;
+            vex::inclusive_scan_by_key(keys, vals, out); q.finish();
+            t.start(); for (int i = 0; i < 5; ++i) vex::inclusive_scan_by_key(keys, vals, out); ms = t.stop_ms() / 5;
+            report(len == n ? "inclusive_scan_by_key (int, f64) n=1e8, ONE run (every carry crosses every tile in front of it)"
+                            : "inclusive_scan_by_key (int, f64) n=1e8, runs of 2^20 elements (a carry crosses 64 tiles)", (double)n, 20, ms);
+        }
     }
     return 0;
 }

@@ -3,6 +3,8 @@
 // 2-"device" context (cross-device carry and merge are exercised).
 #include "vex_test.hpp"
 #include <numeric>
+#include <cstring>
+#include <cmath>
 
 TEST_CASE(scan_inclusive_ints_in_place) {                            // scan.cpp:9-24
     const size_t n = 1 << 20;
@@ -319,6 +321,54 @@ TEST_CASE(by_key_single_pass_against_three_phases) {
     serial_scan_by_key(k, f, fi, fe, 0.f); serial_scan_by_key(k, l, li, le, cl_long(0));
     vex::inclusive_scan_by_key(K, F, OF); vex::copy(OF, gf); CHECK(gf == fi);
     vex::exclusive_scan_by_key(K, L, OL); vex::copy(OL, gl); CHECK(gl == le);
+}
+
+// Round 6: a floating-point carry that crosses SEVERAL tiles is folded serially from the nearest tile that holds a run head (or an
+// inclusive prefix, which is such a fold itself): the bits no longer depend on how far the predecessors of a tile happened to be
+// (scan_by_key.hpp sbk_look_back).  Values whose sums round at every step, runs from one element to 300 tiles of 16 Ki, the whole
+// vector one run: twelve repetitions of the scan and of reduce_by_key must give the same bits, and they must be the serial
+// loop's values up to rounding.
+TEST_CASE(by_key_floating_point_carries_are_reproducible) {
+    std::vector<vex::backend::command_queue> queue(1, ctx.queue(0));
+    std::mt19937_64 rng(2026);
+    for (int shape = 0; shape < 3; ++shape) {
+        const size_t n = shape == 2 ? size_t(12) * 1024 * 1024 + 77 : size_t(20) * 1024 * 1024 + 5;
+        std::vector<int> k(n); std::vector<double> v(n); std::vector<float> f(n);
+        int key = 0;
+        for (size_t i = 0; i < n;) {
+            const size_t choices[] = {1, 5, 4096, 16384, 16385, 40000, 3 * 16384 + 1, 70 * 16384, 300 * 16384 + 3, 1000};
+            size_t len = shape == 2 ? n : shape == 1 ? size_t(200) * 16384 + 11 : choices[rng() % 10];
+            for (size_t j = 0; j < len && i < n; ++j, ++i) { k[i] = key; v[i] = std::ldexp(double(rng() >> 11), -53) - 0.25; f[i] = float(v[i]); }
+            ++key;
+        }
+        vex::vector<int> K(queue, k); vex::vector<double> V(queue, v), O(queue, n); vex::vector<float> F(queue, f), OF(queue, n);
+        std::vector<double> first(n), got(n), incl, excl;
+        std::vector<float> ffirst(n), fgot(n);
+        serial_scan_by_key(k, v, incl, excl, 0.0);
+        vex::vector<int> OK; vex::vector<double> OV;
+        std::vector<double> rfirst, rgot;
+        size_t differing = 0, fdiffering = 0, rdiffering = 0;
+        for (int rep = 0; rep < 12; ++rep) {
+            vex::inclusive_scan_by_key(K, V, O); vex::copy(O, rep ? got : first);
+            vex::inclusive_scan_by_key(K, F, OF); vex::copy(OF, rep ? fgot : ffirst);
+            const int runs = vex::reduce_by_key(K, V, OK, OV);
+            CHECK_EQUAL(runs, key);
+            (rep ? rgot : rfirst).resize(runs); vex::copy(OV, rep ? rgot : rfirst);
+            if (rep) {
+                for (size_t i = 0; i < n; ++i) { differing += std::memcmp(&got[i], &first[i], 8) != 0; fdiffering += std::memcmp(&fgot[i], &ffirst[i], 4) != 0; }
+                for (size_t i = 0; i < rfirst.size(); ++i) rdiffering += std::memcmp(&rgot[i], &rfirst[i], 8) != 0;
+            }
+        }
+        CHECK_EQUAL(differing, size_t(0)); CHECK_EQUAL(fdiffering, size_t(0)); CHECK_EQUAL(rdiffering, size_t(0));
+        double worst = 0;
+        for (size_t i = 0; i < n; ++i) worst = std::max(worst, std::fabs(first[i] - incl[i]) / (1.0 + std::fabs(incl[i])));
+        CHECK(worst < 1e-9);
+        // the run's entry of reduce_by_key against the last element of the run in the scan (the two modes fold a lane's elements
+        // differently: equal up to rounding, not bit for bit)
+        size_t r = 0; double rworst = 0;
+        for (size_t i = 0; i < n; ++i) if (i + 1 == n || k[i + 1] != k[i]) { rworst = std::max(rworst, std::fabs(first[i] - rfirst[r]) / (1.0 + std::fabs(first[i]))); ++r; }
+        CHECK(rworst < 1e-9);
+    }
 }
 
 // reduce_by_key takes the size its outputs already have as the likely number of runs and does ONE pass (scan_by_key.hpp,

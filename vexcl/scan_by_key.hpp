@@ -20,10 +20,12 @@
 // publishes its aggregate and later its inclusive prefix in 8-byte words that carry their state, predecessors are read
 // 64 at a time by the tile's first wave and folded IN ORDER with wave shuffles): inputs are read once (12 + 8 instead of
 // 24 + 8 bytes per (int, double) element).  reduce_by_key counts the run heads first (keys only) so that the outputs can
-// be sized, then runs the same single pass.  Floating point: the carried value of a run that spans SEVERAL tiles is
-// associated as the look-back happened to find its predecessors (aggregate or inclusive), i.e. it can differ in the last
-// bits from run to run; runs inside one tile -- and integer values -- do not depend on it.  VEXCL_SCAN_BY_KEY=tree keeps
-// the three deterministic phases (and vex::inclusive_scan / exclusive_scan with a user operator always use them).
+// be sized, then runs the same single pass.  Floating point (round 6): the carried value of a run that spans SEVERAL tiles
+// is folded serially, oldest tile first, from the nearest tile that holds a run head (sbk_look_back below) -- the same
+// association whichever predecessors happened to have published an inclusive prefix, so the bits are the same from run to run
+// (until round 5 they were not: 60 of 100 million elements differed between two calls on runs that cross tiles,
+// profiles/r06_bykey_reproducible.log).  VEXCL_SCAN_BY_KEY=tree keeps the three phases, with their own fixed association
+// (vex::inclusive_scan / exclusive_scan with a user operator always use them).
 // A lane owns FOUR CONSECUTIVE elements: it folds them serially (head flags come
 // from its own previous element, the first one from the neighbour lane -- one
 // extra load per row for lane 0), and the wave scans ONE aggregate per lane with
@@ -231,29 +233,7 @@ void pipe_source(std::ostringstream &s, const std::vector<std::string> &K, scan_
          "      sbk_t t = agg[0];\n"
          "      for (int w = 1; w < PW; ++w) t = sbk_combine(t, agg[w]);\n"
          "      if (lane == 0) sbk_publish(status, tile, t, tile == 0 ? 2u : 1u);\n"
-         "      sbk_t excl = sbk_empty();\n"
-         "      long base = tile - 1, spins = 0;\n"
-         "      while (base >= 0) {\n"
-         "        const long idx = base - lane;\n"
-         "        sbk_t q = sbk_empty();\n"
-         "        unsigned st = 2u;\n"
-         "        if (idx >= 0) st = sbk_read(status, idx, q);\n"
-         "        while (__any(st == 0u)) {\n"
-         "          __builtin_amdgcn_s_sleep(8);\n"
-         "          if (idx >= 0 && st == 0u) st = sbk_read(status, idx, q);\n"
-         "          if (++spins > (1l << 30)) __builtin_trap();\n"
-         "        }\n"
-         "        const unsigned long long incl = __ballot(st == 2u);\n"
-         "        const int first = incl ? __builtin_ctzll(incl) : 63;\n"
-         "        if (lane > first) q = sbk_empty();\n"
-         "        for (int o = 1; o < 64; o <<= 1) {\n"
-         "          sbk_t u = sbk_down(q, o);\n"
-         "          if (lane + o < 64) q = sbk_combine(u, q);\n"
-         "        }\n"
-         "        excl = sbk_combine(sbk_from(q, 0), excl);\n"
-         "        if (incl) break;\n"
-         "        base -= 64;\n"
-         "      }\n"
+         "      const sbk_t excl = sbk_look_back(status, tile, lane);\n"
          "      if (lane == 0) {\n"
          "        if (tile > 0) sbk_publish(status, tile, sbk_combine(excl, t), 2u);\n"
          "        s_pre = excl;\n"
@@ -579,6 +559,86 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
         s << "  return s0 == s1 ? s0 : 0u;\n"
              "}\n"
              "__device__ inline sbk_t sbk_down(sbk_t x, int o) { sbk_t r; r.c = __shfl_down(x.c, o, 64); r.f = __shfl_down(x.f, o, 64); r.v = __shfl_down(x.v, o, 64); return r; }\n";
+        // The look-back of a tile, by ONE wave: the prefix of everything in front of the tile.
+        // Counts and flags are integers: the window of 64 predecessors is folded by a shuffle tree, cut at the nearest one that has
+        // published its inclusive prefix.  The VALUE (round 6) is not folded by that tree: where the tree is cut depends on how far the
+        // predecessors happened to be, and with it the association of a floating-point carry that crosses several tiles -- the
+        // last bits used to differ from run to run.  It is folded SERIALLY, oldest first, from the ANCHOR -- the nearest predecessor
+        // whose value stands for everything in front of it: a tile that holds a run head (its aggregate's value is the open run's,
+        // whatever came before) or one with an inclusive prefix.  An inclusive prefix is itself such a left fold (induction over
+        // the tiles), so every choice of anchor continues the same chain: carry(k) = ((v(h) + v(h+1)) + ...) + v(k-1) from the
+        // nearest head tile h, a function of the data alone.  Keys that change every few elements anchor at the nearest
+        // predecessor: one step.  A run that spans hundreds of tiles folds up to 63 aggregates per window with readlane (about a
+        // microsecond), and re-reads the windows between the anchor's and the nearest one (their words only ever advance from
+        // aggregate to inclusive, which restarts the fold with the same value).
+        s << "__device__ inline val_t sbk_lane(val_t v, int l) {\n"
+             "  int b[sizeof(val_t) / 4];\n"
+             "  __builtin_memcpy(b, &v, sizeof(val_t));\n"
+             "  #pragma unroll\n"
+             "  for (int i = 0; i < (int)(sizeof(val_t) / 4); ++i) b[i] = __builtin_amdgcn_readlane(b[i], l);\n"
+             "  __builtin_memcpy(&v, b, sizeof(val_t));\n"
+             "  return v;\n"
+             "}\n"
+             "__device__ inline sbk_t sbk_look_back(const sbk_word *status, long tile, int lane) {\n"
+             "  sbk_t excl = sbk_empty();\n"
+             "  if (tile == 0) return excl;\n"
+             "  long base = tile - 1, spins = 0, abase = -1;\n"
+             "  int alane = 0, q0f = 0;\n"
+             "  val_t q0v = val_t();\n"                                                // the nearest window stays in registers
+             "  while (base >= 0) {\n"
+             "    const long idx = base - lane;\n"                                     // lane 0 = the nearest predecessor
+             "    sbk_t q = sbk_empty();\n"
+             "    unsigned st = 2u;\n"                                                 // lanes before tile 0 end the walk with the identity
+             "    if (idx >= 0) st = sbk_read(status, idx, q);\n"
+             "    while (__any(st == 0u)) {\n"
+             "      __builtin_amdgcn_s_sleep(8);\n"
+             "      if (idx >= 0 && st == 0u) st = sbk_read(status, idx, q);\n"
+             "      if (++spins > (1l << 30)) __builtin_trap();\n"                    // a bug, never a truncated prefix (scan.hip)
+             "    }\n"
+             "    const unsigned long long incl = __ballot(st == 2u);\n"
+             "    const int first = incl ? __builtin_ctzll(incl) : 63;\n"            // nearest predecessor with a complete prefix
+             "    if (lane > first) q = sbk_empty();\n"
+             "    if (base == tile - 1) { q0v = q.v; q0f = q.f; }\n"
+             "    if (abase < 0) {\n"
+             "      const unsigned long long R = __ballot(lane <= first && ((q.f & 1) || (incl && lane == first)));\n"
+             "      if (R) { abase = base; alane = __builtin_ctzll(R); }\n"
+             "    }\n"
+             "    for (int o = 1; o < 64; o <<= 1) {\n"                                // counts and flags: older tiles (higher lanes) on the left
+             "      sbk_t u = sbk_down(q, o);\n"
+             "      if (lane + o < 64) q = sbk_combine(u, q);\n"
+             "    }\n"
+             "    excl = sbk_combine(sbk_from(q, 0), excl);\n"
+             "    if (incl) break;\n"
+             "    base -= 64;\n"
+             "  }\n"
+             "  sbk_t a = sbk_empty();\n"                                              // the value: from the anchor to the nearest predecessor, one tile after the other
+             "  for (long b = abase; b <= tile - 1; b += 64) {\n"
+             "    val_t wv = q0v; int wf = q0f;\n"
+             "    if (b != tile - 1) {\n"
+             "      const long idx = b - lane;\n"
+             "      sbk_t q = sbk_empty();\n"
+             "      unsigned st = 2u;\n"
+             "      if (idx >= 0) {\n"
+             "        st = sbk_read(status, idx, q);\n"
+             "        while (st == 0u) {\n"                                            // (published long ago: only a reader that met the words half way from aggregate to inclusive)
+             "          __builtin_amdgcn_s_sleep(1);\n"
+             "          st = sbk_read(status, idx, q);\n"
+             "          if (++spins > (1l << 30)) __builtin_trap();\n"
+             "        }\n"
+             "      }\n"
+             "      wv = q.v; wf = q.f | (st == 2u ? 1 : 0);\n"                        // an inclusive prefix stands for everything in front of it, like a head
+             "    }\n"
+             "    int hi = b == abase ? alane : 63;\n"
+             "    const unsigned long long Rw = __ballot((wf & 1) != 0 && lane <= hi);\n"
+             "    if (Rw) hi = __builtin_ctzll(Rw);\n"                                 // (a nearer tile that has become inclusive since)
+             "    for (int l = hi; l >= 0; --l) {\n"
+             "      sbk_t x; x.c = 0; x.f = __builtin_amdgcn_readlane(wf, l); x.v = sbk_lane(wv, l);\n"
+             "      a = sbk_combine(a, x);\n"
+             "    }\n"
+             "  }\n"
+             "  excl.v = a.v;\n"
+             "  return excl;\n"
+             "}\n";
         if (dpp_enabled())
             // a value moved between lanes by DPP (CTRL: 0x110 + n = row_shr:n, 0x138 = wave_shr:1, 0x142 / 0x143 = row_bcast:15 / 31);
             // a lane without a source keeps its own value (the callers do not use it there)
@@ -711,30 +771,7 @@ std::string source(const backend::command_queue &q, const std::vector<std::strin
              "    sbk_t t = agg[0];\n"
              "    for (int w = 1; w < LBW; ++w) t = sbk_combine(t, agg[w]);\n"
              "    if (lane == 0) sbk_publish(status, tile, t, tile == 0 ? 2u : 1u);\n"
-             "    sbk_t excl = sbk_empty();\n"
-             "    long base = tile - 1, spins = 0;\n"
-          <<
-             "    while (base >= 0) {\n"
-             "      const long idx = base - lane;\n"                                    // lane 0 = the nearest predecessor
-             "      sbk_t q = sbk_empty();\n"
-             "      unsigned st = 2u;\n"                                                // lanes before tile 0 end the walk with the identity
-             "      if (idx >= 0) st = sbk_read(status, idx, q);\n"
-             "      while (__any(st == 0u)) {\n"
-             "        __builtin_amdgcn_s_sleep(8);\n"
-             "        if (idx >= 0 && st == 0u) st = sbk_read(status, idx, q);\n"
-             "        if (++spins > (1l << 30)) __builtin_trap();\n"                   // a bug, never a truncated prefix (scan.hip)
-             "      }\n"
-             "      const unsigned long long incl = __ballot(st == 2u);\n"
-             "      const int first = incl ? __builtin_ctzll(incl) : 63;\n"           // nearest predecessor with a complete prefix
-             "      if (lane > first) q = sbk_empty();\n"
-             "      for (int o = 1; o < 64; o <<= 1) {\n"                               // ordered fold: older tiles (higher lanes) on the left
-             "        sbk_t u = sbk_down(q, o);\n"
-             "        if (lane + o < 64) q = sbk_combine(u, q);\n"
-             "      }\n"
-             "      excl = sbk_combine(sbk_from(q, 0), excl);\n"
-             "      if (incl) break;\n"
-             "      base -= 64;\n"
-             "    }\n"
+             "    const sbk_t excl = sbk_look_back(status, tile, lane);\n"
              "    if (lane == 0) {\n"
              "      if (tile > 0) sbk_publish(status, tile, sbk_combine(excl, t), 2u);\n"
              "      s_pre = excl;\n"
