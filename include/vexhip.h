@@ -328,7 +328,11 @@ int64_t vexhip_sell8_plane_f32_depth(int cus, int64_t lines_per_plane, int64_t p
  * than 1/4 of the lines use another class than the most frequent one, for fp32, a CSR tail, fewer than 2^23 rows (x within the caches: the pair product is as fast) or 4 planes.
  * The product owns two adjacent lines (one segment of <= 512 rows of them, <= 1024 for nx > 768) per workgroup and walks through `depth` planes;
  * lines need not be 16-byte aligned (odd nx), lines_per_plane may be odd.  line_class / table are device memory owned by the
- * plan: vexhip_sell8_grid_release frees them.  VEXHIP_PLANE_DEPTH / VEXHIP_PLANE_STORE override, VEXHIP_NO_GRID declines.  */
+ * plan: vexhip_sell8_grid_release frees them.  VEXHIP_PLANE_DEPTH / VEXHIP_PLANE_STORE override, VEXHIP_NO_GRID declines.
+ * Round 6: a matrix with the diagonals {0, +-1, +-W} only (a 5-point operator on a 2-D grid; the reference's SpMatCCSR has no notion
+ * of dimension either, spmat/ccsr.hpp:55-113) is stored the same way with its rows cut into VIRTUAL lines -- nx = 512 where an even
+ * number >= 4 of them make a row (the plane product), else the longest even divisor of W in [128, min(1024, W / 10)] --,
+ * lines_per_plane = W / nx, +-W as the far pair, flat = 1; rows without such a divisor keep the SELL-512 products.               */
 typedef struct vexhip_grid { int32_t usable;
                              int32_t nx;                /* rows per grid line: the middle diagonals are +-nx                  */
                              int32_t lines_per_plane;   /* the far diagonals are +-nx * lines_per_plane                       */
@@ -341,6 +345,9 @@ typedef struct vexhip_grid { int32_t usable;
                              int32_t classes;           /* distinct line classes                                              */
                              int32_t pitch;             /* bytes per position row of a class table (>= what the lanes read)   */
                              int32_t store_policy;      /* as vexhip_plane.store_policy                                       */
+                             int32_t flat;              /* 1: no line has an entry at +-nx (a 5-point operator on a 2-D grid whose rows are cut into
+                                                           virtual lines, +-row length = the far pair): the walk requests no neighbour lines */
+                             int32_t reserved;
                              int64_t x_last;
                              const int32_t *line_class; /* device: class of every grid line                                   */
                              const void *table;         /* device: classes x 7 positions x pitch value codes                  */

@@ -143,6 +143,29 @@ def _stencil_strip(torch, nx, ny, nz, r0, r1, dev):
     return ptr.to(torch.int32), col.to(torch.int32), val
 
 
+def _stencil_strip_2d(torch, W, Hrows, r0, r1, dev):
+    """Rows [r0, r1) of the 5-point operator on a W x Hrows grid (identity rows on the boundary), GLOBAL columns, int32 CSR on the device."""
+    r = torch.arange(r0, r1, device=dev, dtype=torch.int64)
+    ix, iz = r % W, r // W
+    inner = (ix > 0) & (ix < W - 1) & (iz > 0) & (iz < Hrows - 1)
+    cnt = torch.where(inner, 5, 1)
+    ptr = torch.zeros(r1 - r0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(cnt, 0, out=ptr[1:])
+    nnz = int(ptr[-1])
+    col = torch.empty(nnz, dtype=torch.int64, device=dev)
+    val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    h2i = float((W - 1) ** 2)
+    b = ptr[:-1]
+    bi, ri = b[inner], r[inner]
+    for k, (d, v) in enumerate(((-W, -h2i), (-1, -h2i), (0, 4 * h2i), (1, -h2i), (W, -h2i))):
+        col[bi + k] = ri + d
+        val[bi + k] = v
+    bo, ro = b[~inner], r[~inner]
+    col[bo] = ro
+    val[bo] = 1.0
+    return ptr.to(torch.int32), col.to(torch.int32), val
+
+
 def _halo_worker(rank, world, port, planes_per_rank, ny, out, transport="halo", variable=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VEXHIP_PLANE_FORCE="1", VEXHIP_IPC_TIMEOUT_MS="20000")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -153,12 +176,19 @@ def _halo_worker(rank, world, port, planes_per_rank, ny, out, transport="halo", 
         torch.cuda.set_device(dev)
         nx = 512
         nz = planes_per_rank * world
+        two_d = ny < 0                 # ny = -W: a 5-point operator on a 2-D grid with rows of W points, `planes_per_rank` rows each
+        if two_d:
+            nx, ny = -ny, 1
         N = nx * ny * nz
         part = partition(N, world)
         r0, r1 = part[rank], part[rank + 1]
         assert (r1 - r0) == planes_per_rank * nx * ny
-        ptr, col, val = _stencil_strip(torch, nx, ny, nz, r0, r1, dev)
-        fp, fc, fv = _stencil_strip(torch, nx, ny, nz, 0, N, dev)
+        if two_d:
+            ptr, col, val = _stencil_strip_2d(torch, nx, nz, r0, r1, dev)
+            fp, fc, fv = _stencil_strip_2d(torch, nx, nz, 0, N, dev)
+        else:
+            ptr, col, val = _stencil_strip(torch, nx, ny, nz, r0, r1, dev)
+            fp, fc, fv = _stencil_strip(torch, nx, ny, nz, 0, N, dev)
         if variable:           # a different value in every entry: nothing to code -- SELL-512 with diagonal codes and stored values (the pair product's role)
             fv = fv * (1.0 + 1e-3 * ops.fill_hash(torch.empty_like(fv), 5))
             val = fv[int(fp[r0]):int(fp[r1])].clone()
@@ -174,6 +204,8 @@ def _halo_worker(rank, world, port, planes_per_rank, ny, out, transport="halo", 
         ok = ok and st["transport"] == transport
         if variable:
             ok = ok and A._ext.storage == "sell8" and A._ext.plane is None and A._ext.grid is None
+        if two_d:                      # the rows cut into virtual lines, a flat plan (grid.hip): the ghost range is one row of the grid
+            ok = ok and A._ext.grid is not None and A._ext.grid["flat"] == 1 and A._ext.grid["nx"] * A._ext.grid["lines_per_plane"] == nx
         y = torch.empty(r1 - r0, dtype=torch.float64, device=dev)
         fy = torch.empty(N, dtype=torch.float64, device=dev)
         xk = torch.empty_like(x)                             # ONE vector rewritten between products (pull: mapped by the neighbours once)
@@ -229,12 +261,13 @@ def test_one_launch_step_reads_ghost_planes_from_the_window(world, planes, ny, b
     assert list(out) == [1] * world
 
 
-@pytest.mark.parametrize("world,planes,ny,variable", [(2, 8, 128, False), (2, 8, 128, True), (2, 3, 64, True)])
+@pytest.mark.parametrize("world,planes,ny,variable", [(2, 8, 128, False), (2, 8, 128, True), (2, 3, 64, True), (2, 40, -2000, False), (2, 8, -3000, False)])
 def test_one_launch_step_reads_the_neighbours_x_in_place(world, planes, ny, variable, built_lib):
     """Transport "pull" (round 6) BETWEEN PROCESSES: nothing is pushed -- every rank maps the allocation that holds its neighbours' x
     (vexhip_ipc_export / _open) and the product launch reads their boundary planes where they lie, behind "x is final" flags.  For the
-    plane product and -- variable -- for a strip stored with diagonal codes and a value per entry (the pair product's role,
-    csrc/sell8.hip): any banded operator.  40 products back to back with x rewritten in between; the BITS of the one-device product."""
+    plane product, -- variable -- for a strip stored with diagonal codes and a value per entry (the pair product's role,
+    csrc/sell8.hip): any banded operator, and -- ny = -W -- for the 5-point operator on a 2-D grid with rows of W points (virtual lines,
+    a flat grid plan: the ghost range is ONE row).  40 products back to back with x rewritten in between; the BITS of the one-device product."""
     ctx = mp.get_context("spawn")
     out = ctx.Array("i", [0] * world)
     port = _free_port()

@@ -900,16 +900,33 @@ def test_structured_products_on_random_shapes(T, oracle, built_lib):
             os.environ.pop(k, None)
 
 
+def _virtual_line(W):
+    """grid.hip grid_diagonals: the virtual line a 2-D row of W points is cut into -- 512 where an even number (>= 4) of them fit (the
+    plane product), else the longest even divisor of W in [128, min(1024, W / 10)] (a flat grid plan), else 0 (the pair product)"""
+    if W % 512 == 0 and (W // 512) % 2 == 0 and W // 512 >= 4:
+        return 512
+    for d in range(min(1024, W // 10), 127, -1):
+        if W % d == 0 and d % 2 == 0:
+            return d
+    return 0
+
+
 def test_two_dimensional_five_point_operators(T, oracle, built_lib):
-    """Round 5: 5-point operators on 2-D grids -- diagonals {0, +-1, +-W}, no line-above / line-below pair -- take the grid or the
+    """Round 5: 5-point operators on 2-D grids -- diagonals {0, +-1, +-W}, no line-above / line-below pair -- take the
     plane product along VIRTUAL 512-point lines where the rows are an even number (>= 4) of them (grid.hip grid_diagonals: +-W as
-    the far pair; the reference's SpMatCCSR covers such operators without a notion of dimension, spmat/ccsr.hpp:55-113); other
-    row lengths keep the pair product (measured level with it).  Bit for bit against the pair product and the CSR restatement:
-    natural boundaries (rows of 3, 4 and 5 entries), '=' and '+= alpha', through the one-pass set-up and the SELL-512 storage."""
+    the far pair; the reference's SpMatCCSR covers such operators without a notion of dimension, spmat/ccsr.hpp:55-113).  Round 6:
+    rows of any other length are cut into virtual lines of their longest even divisor up to 1024 points (ten or more per row) and
+    take the grid product with a FLAT plan -- the walk requests no lines above / below a tile, an XCD owns walks instead of tiles
+    (12 000^2: 0.46 ms against 0.68 through the march product, profiles/r06_2d.json); rows without such a divisor keep the pair
+    product.  Bit for bit against the pair product and the CSR restatement: natural boundaries (rows of 3, 4 and 5 entries), an odd
+    number of lines per row, '=' and '+= alpha', y = alpha A x + beta z in one pass, through the one-pass set-up and the SELL-512
+    storage, fp64 and fp32."""
     torch = T.torch
     os.environ["VEXHIP_PLANE_FORCE"] = "1"
     try:
-        for W, H, nx, plane in ((1000, 300, 0, False), (96, 700, 0, False), (2048, 120, 512, True), (4096, 64, 512, True), (1536, 90, 0, False), (3072, 40, 512, True)):
+        for W, H, nx, plane in ((1000, 300, 0, False), (96, 700, 0, False), (2048, 120, 512, True), (4096, 64, 512, True), (1536, 90, 128, False), (3072, 40, 512, True),
+                                (2000, 150, 200, False), (12000, 24, 1000, False), (9000, 37, 900, False), (1400, 100, 140, False), (5632, 41, 512, False)):
+            assert _virtual_line(W) == nx, (W, nx, _virtual_line(W))
             ptr, col, val = _grid7_natural(W, H, 1)
             m = len(ptr) - 1
             assert set((col - np.repeat(np.arange(m), np.diff(ptr))).tolist()) == {-W, -1, 0, 1, W}
@@ -922,13 +939,22 @@ def test_two_dimensional_five_point_operators(T, oracle, built_lib):
                 assert A.storage == "sell8v", (W, H, A.storage)
                 if plane:
                     assert A.plane is not None and A.plane["lines_per_plane"] == W // 512 and A.plane["planes"] == H, (W, H, direct, A.plane, A.grid)
-                else:              # rows that are not an even number (>= 4) of 512-point lines keep the pair product
+                elif nx:           # virtual lines of a divisor of W: the grid product, flat
+                    assert A.plane is None and A.grid is not None and A.grid["nx"] == nx and A.grid["lines_per_plane"] == W // nx and A.grid["planes"] == H \
+                        and A.grid["flat"] == 1 and A.product == "sell8_grid_kernel", (W, H, direct, A.grid, A.product)
+                else:              # no such divisor: the pair product
                     assert A.grid is None and A.plane is None, (W, H, direct, A.grid)
                 for alpha, append in ((1.0, False), (-0.75, True)):
                     ya, yb = T.up(y0.copy()), T.up(y0.copy())
                     A.apply(T.up(xb), ya, alpha, append); B.apply(T.up(xb), yb, alpha, append)
                     assert torch.equal(ya, yb), (W, H, alpha, direct)
                     assert np.array_equal(ya.cpu().numpy(), (y0 + alpha * want) if append else alpha * want), (W, H, alpha, direct)
+                # y = alpha A x + beta z in one pass (z an array / x itself): round(beta z) + round(alpha (A x)_i), as the host forms it
+                xd, zd = T.up(xb), T.up(y0.copy())
+                for z, zh in ((zd, y0), (xd, xb)):
+                    ya = torch.empty_like(xd)
+                    A.apply_axpby(xd, ya, -0.75, z, 2.5)
+                    assert np.array_equal(ya.cpu().numpy(), 2.5 * zh + (-0.75) * want), (W, H, direct, "axpby")
             # the same operator in fp32: the fp32 plane product where rows are virtual 512-point lines, the pair product elsewhere
             f32 = np.float32
             v32, x32, y32 = val.astype(f32), xb.astype(f32), y0.astype(f32)
@@ -938,6 +964,8 @@ def test_two_dimensional_five_point_operators(T, oracle, built_lib):
                 assert (A.plane is not None) == plane, (W, H, direct, A.plane, A.grid)
                 if plane:
                     assert A.direct == direct and A.plane["lines_per_plane"] == W // 512 and A.plane["planes"] == H, (W, H, direct, A.plane)
+                elif nx:
+                    assert A.grid is not None and A.grid["nx"] == nx and A.grid["flat"] == 1 and A.product == "sell8_grid_f32_kernel", (W, H, direct, A.grid, A.product)
                 for alpha, append in ((1.0, False), (-0.75, True)):
                     ya = T.up(y32.copy())
                     A.apply(T.up(x32), ya, alpha, append)

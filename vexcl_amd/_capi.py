@@ -72,6 +72,7 @@ class Grid(ctypes.Structure):
     _fields_ = [("usable", ctypes.c_int32), ("nx", ctypes.c_int32), ("lines_per_plane", ctypes.c_int32), ("planes", ctypes.c_int32),
                 ("depth", ctypes.c_int32), ("segments", ctypes.c_int32), ("segment_rows", ctypes.c_int32), ("threads", ctypes.c_int32),
                 ("hot_class", ctypes.c_int32), ("classes", ctypes.c_int32), ("pitch", ctypes.c_int32), ("store_policy", ctypes.c_int32),
+                ("flat", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("x_last", ctypes.c_int64), ("line_class", ctypes.c_void_p), ("table", ctypes.c_void_p)]
 
 

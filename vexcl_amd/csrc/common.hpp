@@ -58,6 +58,7 @@ enum env_id {
     ENV_VEXHIP_FFT_ROW_ELEMS,
     ENV_VEXHIP_FFT_STRIDED_ELEMS,
     ENV_VEXHIP_GRID32_DEPTH,
+    ENV_VEXHIP_GRID_2D_LINE,
     ENV_VEXHIP_GRID_BUILD_WGS,
     ENV_VEXHIP_GRID_SEGMENT,
     ENV_VEXHIP_HALO_ACQUIRE,

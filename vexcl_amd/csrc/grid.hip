@@ -553,8 +553,9 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
 
     const int t = threadIdx.x;
     const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
-    const int zc = (int)(q / (unsigned)gd.tpx), tyl = (int)(q - (unsigned)zc * (unsigned)gd.tpx);
-    const int tile = (int)xcd * gd.tpx + tyl;
+    int zc = (int)(q / (unsigned)gd.tpx);
+    int tile = (int)xcd * gd.tpx + (int)(q - (unsigned)zc * (unsigned)gd.tpx);
+    if (gd.cpx) { const int w = (int)(q / (unsigned)gd.tiles); tile = (int)(q - (unsigned)w * (unsigned)gd.tiles); zc = (int)xcd * gd.cpx + w; }      // (grid.hpp)
     if (tile >= gd.tiles) return;                                   // the whole workgroup
     const int ytile = tile / gd.segs, seg = tile - ytile * gd.segs;
     const int y0 = TY * ytile;
@@ -668,7 +669,12 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(ZM == 1 ? zs : x) + (((long long)z_first * ny + y0) * nx + row0), 0, -1, 0x00020000);
 #pragma unroll
     for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
-    Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
+    // gd.flat (round 6): no entry at +-nx anywhere -- a 5-point operator on a 2-D grid, its rows cut into virtual lines: the lines above
+    // and below the tile are never requested (two of the six 16-byte requests of a step)
+    const bool flat = gd.flat != 0;                                   // uniform
+    const d2 dzero = {0.0, 0.0};
+    Hs[0][0] = Hs[0][1] = Hs[1][0] = Hs[1][1] = dzero;
+    if (!flat) { Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1); }
 #pragma unroll
     for (int l = 0; l < TY; ++l) {
         Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
@@ -744,8 +750,10 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
 #pragma unroll
                     for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)lane_b, (int)(yo + plane_b32 + l * line_b), 0));
                 }
-                H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
-                H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * line_b), 0));
+                if (!flat) {
+                    H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
+                    H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * line_b), 0));
+                }
 #pragma unroll
                 for (int l = 0; l < TY; ++l) {
                     P[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + plane_b32 + (l + 1) * line_b), 0));
@@ -791,7 +799,7 @@ void grid_walk(const double *__restrict__ x, double *__restrict__ y, double alph
             if (ZM == 1) Yo[l] = yold(z + 1, l);
         }
 #pragma unroll
-        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
+        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; if (!flat) Hs[1][l] = ld(z + 2, (TY + 1) * l); }
         ++z;
     }
 #undef GRID_XS
@@ -902,6 +910,7 @@ void grid_fill_plan(vexhip_grid *out, long long nx, long long ny, long long nz, 
     out->store_policy = 1;
     if (const char *e = env(ENV_VEXHIP_PLANE_STORE)) out->store_policy = std::max(0, std::min(3, std::atoi(e)));
     out->x_last = x_last;
+    out->flat = 0; out->reserved = 0;
 }
 
 // the diagonals: {0, +-1, +-nx, +-P} with 1 < nx < P, P a multiple of nx (a subset that names both); false: not a grid matrix
@@ -920,6 +929,19 @@ bool grid_diagonals(const std::vector<int> &table, long long rows, long long *nx
         if (W < 16 || rows % W != 0 || W > (1ll << 30)) return false;
         long long nx = 0;
         if (W % 512 == 0 && (W / 512) % 2 == 0 && W / 512 >= 4) nx = 512;
+        // Round 6: any other row length -- the walk of a FLAT plan (vexhip_grid.flat) no longer requests the lines above and below a
+        // tile, which is what kept these rows behind the pair product in round 5 (below).  Virtual lines of the longest even divisor of
+        // W up to 1024 points, ten or more of them per row (the first and the last line of a row are classes of their own, so are the
+        // lines of the first and the last row: the hot class must keep three lines in four).  VEXHIP_GRID_2D_LINE = points per virtual
+        // line (a divisor of W), 0: as in round 5.
+        if (nx == 0) {
+            long long want = -1;
+            if (const char *e = env(ENV_VEXHIP_GRID_2D_LINE)) want = std::atoll(e);
+            if (want > 0) { if (W % want == 0 && want >= 8) nx = want; }
+            else if (want < 0)
+                for (long long d = std::min<long long>(1024, W / 10); d >= 128; --d)
+                    if (W % d == 0 && d % 2 == 0) { nx = d; break; }
+        }
         // (other row lengths walked along a divisor of W -- 10000^2 as 20 lines of 500 points, 12000 x 9000, 7000 x 20000 -- ran level
         //  with the pair product of the SELL-512 storage or behind it, 0.528 / 0.462 / 0.656 ms against 0.493 / 0.467 / 0.678: few
         //  lines per "plane", and the walk still requests the line above and below, which a 2-D operator never uses.  They keep the
@@ -1044,6 +1066,7 @@ int grid_build(int dev, void *stream, int64_t rows, const P *ptr, const int32_t 
     VEXHIP_TRY(hipMemcpyAsync(deltas, dl.data(), sizeof(int) * 256, hipMemcpyHostToDevice, s));
     VEXHIP_TRY(hipStreamSynchronize(s));
     grid_fill_plan(out, nx, ny, nz, geo, hot, nclasses, x_last);
+    out->flat = (h_ints[GBI_POSMASK] & ((1 << 1) | (1 << 5))) == 0;
     out->line_class = d_cls.release(); out->table = d_table.release();
     out->usable = 1;
     *ndeltas = nd; *nvalues = nv; *ell_width = h_ints[GBI_MAXLEN]; *x_last_out = x_last;
@@ -1161,6 +1184,8 @@ int vexhip_sell8_grid_plan(int dev, void *stream, const int32_t *deltas, int nde
     if (bad) GP_DECLINE(11);                      // two different lines with one hash: not this product's matrix
 
     grid_fill_plan(out, nx, ny, nz, geo, hot, nclasses, x_last);
+    out->flat = 1;
+    for (int c = 0; c < ndeltas; ++c) if (cd.pos[c] == 1 || cd.pos[c] == 5) out->flat = 0;
     out->line_class = d_cls.release(); out->table = d_table.release();
     out->usable = 1;
     return 0;
@@ -1226,9 +1251,10 @@ int grid_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, con
     gd.lines = n / g->nx; gd.x_last = g->x_last; gd.n = n;
     gd.nx = g->nx; gd.ny = g->lines_per_plane; gd.nz = g->planes; gd.depth = g->depth;
     gd.segs = g->segments; gd.seg_len = g->segment_rows;
-    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch;
+    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch; gd.flat = g->flat;
     const long long chunks = (gd.nz + gd.depth - 1) / gd.depth;
-    const long long grid = 8ll * gd.tpx * chunks;
+    gd.cpx = gd.flat ? (int)((chunks + 7) / 8) : 0;
+    const long long grid = gd.cpx ? 8ll * gd.cpx * gd.tiles : 8ll * gd.tpx * chunks;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const unsigned char *tb = static_cast<const unsigned char *>(g->table);
     hipStream_t s = as_stream(stream);
@@ -1260,13 +1286,14 @@ int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int app
     gd.lines = n_ext / g->nx; gd.x_last = g->x_last; gd.n = n_ext;
     gd.nx = g->nx; gd.ny = g->lines_per_plane; gd.nz = g->planes; gd.depth = g->depth;
     gd.segs = g->segments; gd.seg_len = g->segment_rows;
-    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch;
+    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch; gd.flat = g->flat;
     // the walks are the plan's (chosen for the balance of the CUs, grid_geometry_with: shorter ones cost more than the wait they would
     // save -- a strip of 640^3 / 8 in walks of 20 planes took 170 us against 125 us in the plan's, profiles/r06_dist_step_f64_640_first.json)
     const int nzr = H.z1 - H.z0;
     gd.depth = std::min(gd.depth, nzr);
     const long long chunks = (nzr + gd.depth - 1) / gd.depth;
-    const long long grid = 8ll * gd.tpx * chunks;
+    gd.cpx = gd.flat ? (int)((chunks + 7) / 8) : 0;
+    const long long grid = gd.cpx ? 8ll * gd.cpx * gd.tiles : 8ll * gd.tpx * chunks;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const long long plane = (long long)gd.ny * gd.nx;
     const double *xe = x - (long long)H.z0 * plane;            // the kernel addresses x and y in the numbering of the stored grid

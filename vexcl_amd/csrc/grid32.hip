@@ -35,8 +35,9 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
 
     const int t = threadIdx.x;
     const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
-    const int zc = (int)(q / (unsigned)gd.tpx), tyl = (int)(q - (unsigned)zc * (unsigned)gd.tpx);
-    const int tile = (int)xcd * gd.tpx + tyl;
+    int zc = (int)(q / (unsigned)gd.tpx);
+    int tile = (int)xcd * gd.tpx + (int)(q - (unsigned)zc * (unsigned)gd.tpx);
+    if (gd.cpx) { const int w = (int)(q / (unsigned)gd.tiles); tile = (int)(q - (unsigned)w * (unsigned)gd.tiles); zc = (int)xcd * gd.cpx + w; }      // (grid.hpp)
     if (tile >= gd.tiles) return;                                   // the whole workgroup
     const int ytile = tile / gd.segs, seg = tile - ytile * gd.segs;
     const int y0 = TY * ytile;
@@ -127,7 +128,10 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZM == 1 ? zs : x) + (((long long)z_first * ny + y0) * nx + row0), 0, -1, 0x00020000);
 #pragma unroll
     for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
-    Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
+    const bool flat = gd.flat != 0;                                   // uniform (grid.hip: a 2-D operator on virtual lines never reads the lines above / below a tile)
+    const f4 fzero = {0.f, 0.f, 0.f, 0.f};
+    Hs[0][0] = Hs[0][1] = Hs[1][0] = Hs[1][1] = fzero;
+    if (!flat) { Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1); }
 #pragma unroll
     for (int l = 0; l < TY; ++l) {
         Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
@@ -209,8 +213,10 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
 #pragma unroll
                     for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)lane_b, (int)(yo + plane_b32 + l * line_b), 0));
                 }
-                H[0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
-                H[1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * line_b), 0));
+                if (!flat) {
+                    H[0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
+                    H[1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * line_b), 0));
+                }
 #pragma unroll
                 for (int l = 0; l < TY; ++l) {
                     P[l] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + plane_b32 + (l + 1) * line_b), 0));
@@ -258,7 +264,7 @@ void sell8_grid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, f
             if (ZM == 1) Yo[l] = yold(z + 1, l);
         }
 #pragma unroll
-        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
+        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; if (!flat) Hs[1][l] = ld(z + 2, (TY + 1) * l); }
         ++z;
     }
 #undef G32_XS
@@ -299,7 +305,7 @@ int grid32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, co
     gd.lines = n / g->nx; gd.x_last = g->x_last; gd.n = n;
     gd.nx = g->nx; gd.ny = g->lines_per_plane; gd.nz = g->planes;
     gd.segs = g->segments; gd.seg_len = g->segment_rows;
-    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch;
+    gd.tiles = (gd.ny + 1) / 2 * gd.segs; gd.tpx = (gd.tiles + 7) / 8; gd.hot = g->hot_class; gd.pitch = g->pitch; gd.flat = g->flat;
     // A workgroup is 1 .. 4 waves (four rows per lane) and a CU holds eight waves of this kernel.  Measured (ms by walk depth,
     // profiles/r05_fp32_sizes.json): the best launch is ONE round of workgroups that just fills the CUs -- 384^3 (192 tiles x 2 waves)
     // 96 / 77 / 64 / 48 planes = 0.120 / 0.103 / 0.136 / 0.115 (3 / 3.75 / 4.5 / 6 workgroups per CU), 500^3 125 / 100 / 63 = 0.217 /
@@ -328,7 +334,8 @@ int grid32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, co
     if (const char *e = env(ENV_VEXHIP_GRID32_DEPTH)) if (std::atoi(e) > 0) gd.depth = std::min(std::atoi(e), (int)gd.nz);
     VEXHIP_REQUIRE(((long long)gd.depth + 4) * gd.ny * gd.nx * 4 < (1ll << 32), "bad grid plan");
     const long long chunks = (gd.nz + gd.depth - 1) / gd.depth;
-    const long long grid = 8ll * gd.tpx * chunks;
+    gd.cpx = gd.flat ? (int)((chunks + 7) / 8) : 0;
+    const long long grid = gd.cpx ? 8ll * gd.cpx * gd.tiles : 8ll * gd.tpx * chunks;
     VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
     const unsigned char *tb = static_cast<const unsigned char *>(g->table);
     hipStream_t s = as_stream(stream);

@@ -187,6 +187,7 @@ const char *const kEnvNames[ENV_COUNT] = {
     "VEXHIP_FFT_ROW_ELEMS",
     "VEXHIP_FFT_STRIDED_ELEMS",
     "VEXHIP_GRID32_DEPTH",
+    "VEXHIP_GRID_2D_LINE",
     "VEXHIP_GRID_BUILD_WGS",
     "VEXHIP_GRID_SEGMENT",
     "VEXHIP_HALO_ACQUIRE",

@@ -424,17 +424,37 @@ class DistSpMat:
                 raise RuntimeError("transport halo: the coupling between neighbouring strips is not symmetric "
                                    "(this rank receives from %s and sends to %s)" % (sorted(o for o in (lower, upper) if o >= 0), sorted(takers)))
         reach = max(int(c0 - below.min()) if below.numel() else 0, int(above.max()) + 1 - c1 if above.numel() else 0)
-        H = (reach + 1023) // 1024 * 1024
-        if H <= 0 or self.rows % H or H % 1024:
-            raise RuntimeError("transport halo: the strip is not a whole number of planes of %d elements" % H)
-        lo, hi = (H if has_lo else 0), (H if has_hi else 0)
-        ptr_ext, col_ext = halo_extended_csr(ptr, col, 0 if self_exchange else c0, self.rows, lo, hi)
-        ext = ops.SpMat(ptr_ext, col_ext, val, n_cols=lo + self.rows + hi)
-        # pushed shares (halo): the plane product only; shares read in place (pull): also the grid product and -- round 6 -- any strip stored
-        # with diagonal codes whose diagonals stay within one ghost range (the library checks: vexhip_dist_spmv_create_halo_pull)
-        ok = getattr(ext, "handle", None) and (getattr(ext, "plane", None) or (pull and (getattr(ext, "grid", None) or getattr(ext, "storage", "") in ("sell8", "sell8v"))))
-        if not ok:
-            raise RuntimeError("transport %s: the stored strip did not get a plan for the one-launch step (storage %s)" % ("pull" if pull else "halo", getattr(ext, "storage", "?")))
+        # the ghost range: a plane of the stored grid.  Planes of 512-point lines and slices of the SELL-512 storage are multiples of 1024
+        # / 512 elements; a grid with other lines (500^3; round 6: the rows of a 2-D grid, cut into virtual lines) has planes of
+        # exactly `reach` elements -- tried first where the two differ (pull only: the grid product has no push form)
+        rounded = (reach + 1023) // 1024 * 1024
+        why = "transport halo: the strip is not a whole number of planes of %d elements" % rounded
+        exact = 0                      # the shortest plane the strip is a whole number of (the first and the last point of a plane are boundary rows: reach <= plane)
+        if pull and reach > 0:
+            for k in range(self.rows // reach, max(self.rows // reach - 4096, 0), -1):
+                if self.rows % k == 0:
+                    exact = self.rows // k
+                    break
+        for H in ([exact] if exact and exact != rounded and exact % 2 == 0 else []) + [rounded]:
+            if H <= 0 or self.rows % H:
+                continue
+            lo, hi = (H if has_lo else 0), (H if has_hi else 0)
+            ptr_ext, col_ext = halo_extended_csr(ptr, col, 0 if self_exchange else c0, self.rows, lo, hi)
+            ext = ops.SpMat(ptr_ext, col_ext, val, n_cols=lo + self.rows + hi)
+            # pushed shares (halo): the plane product only; shares read in place (pull): also the grid product and -- round 6 -- any strip
+            # stored with diagonal codes whose diagonals stay within one ghost range (the library checks: vexhip_dist_spmv_create_halo_pull)
+            plane, grid = getattr(ext, "plane", None), getattr(ext, "grid", None)
+            if getattr(ext, "handle", None):
+                if plane and H == plane["lines_per_plane"] * 512:
+                    break
+                if pull and grid and not plane and H == grid["nx"] * grid["lines_per_plane"]:
+                    break
+                if pull and not plane and not grid and H % 512 == 0 and getattr(ext, "storage", "") in ("sell8", "sell8v"):
+                    break
+            why = "transport %s: the stored strip did not get a plan for the one-launch step with ghost ranges of %d elements (storage %s)" % ("pull" if pull else "halo", H, getattr(ext, "storage", "?"))
+            del ext
+        else:
+            raise RuntimeError(why)
         ext.ptr = ext.col = ext.val = None
         self._ext = ext
         return H, lower, upper

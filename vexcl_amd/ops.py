@@ -445,7 +445,7 @@ class SpMat:
         g = info.grid
         self.grid = ({"nx": int(g.nx), "lines_per_plane": int(g.lines_per_plane), "planes": int(g.planes), "depth": int(g.depth),
                       "segments": int(g.segments), "segment_rows": int(g.segment_rows), "threads": int(g.threads), "hot_class": int(g.hot_class),
-                      "classes": int(g.classes), "store_policy": int(g.store_policy), "x_last": int(g.x_last)}
+                      "classes": int(g.classes), "store_policy": int(g.store_policy), "flat": int(g.flat), "x_last": int(g.x_last)}
                      if g.usable else None)                        # not None: the matrix is stored by grid line; apply() runs the grid product (fp64; grids of
                                                                    # any line length) unless `plane` is set too (512-point lines: the plane kernel reads the same tables)
         self.direct = bool(g.usable and not info.sell and not info.code_pool)      # stored by grid line straight from the CSR arrays: no SELL-512 slices
