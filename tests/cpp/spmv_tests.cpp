@@ -307,6 +307,45 @@ TEST_CASE(spmv_one_launch_step_general_matrix_multi_device) {
     }
 }
 
+TEST_CASE(spmv_one_launch_step_two_dimensional_multi_device) {
+    // round 6: a 5-point operator on a 2-D grid whose rows (2000 points) are no multiple of 512 -- stored by VIRTUAL grid lines (200 points,
+    // a flat plan: csrc/grid.hip) -- on a multi-device context: the ghost range of a device is ONE row of the grid.  Bits of one device.
+    const std::vector<vex::backend::command_queue> &q = ctx.queue();
+    if (q.size() < 2) return;
+    const size_t W = 2000, Hr = 64 * q.size(), N = W * Hr;
+    std::vector<int> row(1, 0), col; std::vector<double> val;
+    for (size_t k = 0, idx = 0; k < Hr; ++k) for (size_t i = 0; i < W; ++i, ++idx) {
+        if (i == 0 || i == W - 1 || k == 0 || k == Hr - 1) { col.push_back((int)idx); val.push_back(1); }
+        else for (long d : {-(long)W, -1l, 0l, 1l, (long)W}) { col.push_back((int)(idx + d)); val.push_back(d ? -0.25 * (d > 0 ? 3 : 1) : 4.5); }
+        row.push_back((int)col.size());
+    }
+    const std::vector<size_t> part = vex::partition(N, q);
+    for (unsigned d = 0; d < q.size(); ++d) CHECK((part[d + 1] - part[d]) % W == 0);
+    setenv("VEXHIP_PLANE_FORCE", "1", 1);
+    struct unforce { ~unforce() { unsetenv("VEXHIP_PLANE_FORCE"); } } unforce_at_exit;
+    vex::SpMat<double, int, int> A(q, N, N, row.data(), col.data(), val.data());
+    CHECK(std::string(A.step_kind()).find("one launch per device") == 0);
+    if (std::string(A.step_kind()).find("one launch per device") != 0) std::cerr << "2-D: one-launch step declined: " << A.halo_declined() << std::endl;
+    for (unsigned d = 0; d < q.size(); ++d) CHECK(A.storage_info(d).grid.usable == 1 && A.storage_info(d).grid.flat == 1 && A.storage_info(d).grid.nx == 200);
+    std::vector<vex::backend::command_queue> q1(1, q[0]);
+    vex::SpMat<double, int, int> A1(q1, N, N, row.data(), col.data(), val.data());
+    std::vector<double> x = random_vector<double>(N), y1(N), ym(N);
+    vex::vector<double> X(ctx, x), Y(ctx, N), X1(q1, x), Y1(q1, N);
+    auto same_bits = [&]() { vex::copy(Y, ym); vex::copy(Y1, y1); for (size_t i = 0; i < N; ++i) if (std::memcmp(&ym[i], &y1[i], 8)) return false; return true; };
+    Y = A * X; Y1 = A1 * X1;
+    CHECK(same_bits());
+    for (int rep = 0; rep < 20; ++rep) { Y = A * X; X = 0.5 * X + 0.25; Y += 1.5 * (A * X); X1 = 0.5 * X1 + 0.25; }
+    Y1 = A1 * X1; Y = A * X;
+    CHECK(same_bits());
+    Y = X; Y += 2.5 * (A * X); Y -= A * X; Y1 = X1; Y1 += 2.5 * (A1 * X1); Y1 -= A1 * X1;
+    CHECK(same_bits());
+    std::vector<size_t> r2(row.begin(), row.end()), c2(col.begin(), col.end());
+    vex::copy(X, x);
+    auto want = host_spmv(r2, c2, val, x);
+    Y = A * X; vex::copy(Y, ym);
+    for (size_t i = 0; i < N; i += 53) CHECK_CLOSE(ym[i], want[i], 1e-8);
+}
+
 TEST_CASE(spmv_nonsquare_and_index_types) {                          // spmv.cpp:61-114
     const size_t n = 1024, m = 2 * n;
     std::vector<size_t> row; std::vector<int> col; std::vector<double> val;

@@ -970,6 +970,16 @@ def test_two_dimensional_five_point_operators(T, oracle, built_lib):
                     ya = T.up(y32.copy())
                     A.apply(T.up(x32), ya, alpha, append)
                     assert np.array_equal(ya.cpu().numpy(), (y32 + f32(alpha) * want32) if append else f32(alpha) * want32), (W, H, alpha, direct, "fp32")
+        # a full band {0, +-1, +-W} (no boundary rows: the +-1 diagonal crosses the ends of the rows and of the virtual lines, the first
+        # and the last rows lack their far entries), a ragged number of rows per walk, Inf in x under a position without an entry
+        W, m = 2000, 2000 * 37
+        ptr, col, val = _band(m, (-W, -1, 0, 1, W), 11, constant=True)
+        xb = oracle.random_f64(5, m); xb[0] = np.inf
+        want = oracle.spmv_csr(ptr, col, val, xb)
+        for direct in (True, False):
+            A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct)
+            assert A.grid is not None and A.grid["flat"] == 1 and A.grid["nx"] == 200 and A.grid["planes"] == 37, (direct, A.grid)
+            assert np.array_equal((A @ T.up(xb)).cpu().numpy(), want, equal_nan=True), direct
     finally:
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
 
