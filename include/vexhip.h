@@ -300,6 +300,8 @@ typedef struct vexhip_plane { int32_t usable;
                               int32_t tile;              /* grid lines per workgroup: 2 or 4 (divides lines_per_plane)        */
                               int32_t store_policy;      /* y stores: 0 non-temporal, 1 non-temporal + sc1, 2 sc0 sc1, 3 plain  */
                               int32_t table_pitch;       /* 0: `pool` holds SELL-512 code blocks; > 0: class tables of the grid storage (vexhip_grid.pitch) */
+                              int32_t flat;              /* 1: no entry at +-512 anywhere (vexhip_grid.flat: a 2-D operator on virtual lines): the walk requests no neighbour lines */
+                              int32_t reserved;
                               int64_t x_last;
                             } vexhip_plane;
 int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int ndeltas, const int32_t *blocks, int64_t nslices,

@@ -938,7 +938,7 @@ def test_two_dimensional_five_point_operators(T, oracle, built_lib):
                 A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val), direct=direct)
                 assert A.storage == "sell8v", (W, H, A.storage)
                 if plane:
-                    assert A.plane is not None and A.plane["lines_per_plane"] == W // 512 and A.plane["planes"] == H, (W, H, direct, A.plane, A.grid)
+                    assert A.plane is not None and A.plane["lines_per_plane"] == W // 512 and A.plane["planes"] == H and A.plane["flat"] == 1, (W, H, direct, A.plane, A.grid)
                 elif nx:           # virtual lines of a divisor of W: the grid product, flat
                     assert A.plane is None and A.grid is not None and A.grid["nx"] == nx and A.grid["lines_per_plane"] == W // nx and A.grid["planes"] == H \
                         and A.grid["flat"] == 1 and A.product == "sell8_grid_kernel", (W, H, direct, A.grid, A.product)

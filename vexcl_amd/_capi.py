@@ -64,7 +64,7 @@ class Plane(ctypes.Structure):
     """vexhip_plane (include/vexhip.h)."""
     _fields_ = [("usable", ctypes.c_int32), ("lines_per_plane", ctypes.c_int32), ("planes", ctypes.c_int32), ("depth", ctypes.c_int32),
                 ("hot_block", ctypes.c_int32), ("tile", ctypes.c_int32), ("store_policy", ctypes.c_int32),
-                ("table_pitch", ctypes.c_int32), ("x_last", ctypes.c_int64)]
+                ("table_pitch", ctypes.c_int32), ("flat", ctypes.c_int32), ("reserved", ctypes.c_int32), ("x_last", ctypes.c_int64)]
 
 
 class Grid(ctypes.Structure):

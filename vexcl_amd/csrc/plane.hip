@@ -46,7 +46,10 @@ namespace {
 // ZM, the addend of the result (round 6): 0 none (y = alpha A x); 1 an array `zs` scaled by beta (y = alpha A x + beta zs: '+=' is zs = y,
 // beta = 1; a residual b - A x is zs = b, alpha = -1); 2 beta times x ITSELF, taken from the registers that hold the centre lines (y = x + 2 A x
 // moves not a byte more than y = A x).
-template <int TY, int ZM, int STORE_AUX, bool HALO>
+// FLAT (round 6): no block has an entry at +-512 -- a 5-point operator on a 2-D grid whose rows are virtual 512-point lines (grid.hip
+// grid_diagonals): the lines above / below the tile are never requested (two of a step's six 16-byte requests).  A template flag: the
+// instantiations of the 3-D operators -- the headline's -- are what they were.
+template <int TY, int ZM, int STORE_AUX, bool HALO, bool FLAT = false>
 __device__ __forceinline__
 void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alpha, const double *__restrict__ zs, double beta,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
@@ -328,7 +331,8 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(ZM == 1 ? zs : x) + ((long long)z_first * ny + y0) * PL_ROWS, 0, -1, 0x00020000);
 #pragma unroll
     for (int l = 0; l < TY; ++l) { Cs[0][l] = ld(z - 1, l + 1); Cs[1][l] = ld(z, l + 1); Cs[2][l] = ld(z + 1, l + 1); Cs[3][l] = ld(z + 2, l + 1); }
-    Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1);
+    if constexpr (FLAT) { const d2 dzero = {0.0, 0.0}; Hs[0][0] = Hs[0][1] = Hs[1][0] = Hs[1][1] = dzero; }
+    else { Hs[0][0] = ld(z, 0); Hs[0][1] = ld(z, TY + 1); Hs[1][0] = ld(z + 1, 0); Hs[1][1] = ld(z + 1, TY + 1); }
 #pragma unroll
     for (int l = 0; l < TY; ++l) {
         Es[0][l] = edge(z, l + 1); Es[1][l] = edge(z + 1, l + 1);
@@ -397,8 +401,10 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
 #pragma unroll
                     for (int l = 0; l < TY; ++l) Yo[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)lane_b, (int)(yo + plane_b32 + l * 4096u), 0));
                 }
-                H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
-                H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * 4096u), 0));
+                if constexpr (!FLAT) {
+                    H[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)xo, 0));
+                    H[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + (TY + 1) * 4096u), 0));
+                }
 #pragma unroll
                 for (int l = 0; l < TY; ++l) {
                     P[l] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)lane_b, (int)(xo + plane_b32 + (l + 1) * 4096u), 0));
@@ -442,7 +448,7 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
             if (ZM == 1) Yo[l] = yold(z + 1, l);
         }
 #pragma unroll
-        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; Hs[1][l] = ld(z + 2, (TY + 1) * l); }
+        for (int l = 0; l < 2; ++l) { Hs[0][l] = Hs[1][l]; if constexpr (!FLAT) Hs[1][l] = ld(z + 2, (TY + 1) * l); }
         ++z;
     }
     }       // pass
@@ -460,14 +466,14 @@ void plane_walk(const double *__restrict__ x, double *__restrict__ y, double alp
 #ifndef VEXHIP_HALO_WAVES
 #define VEXHIP_HALO_WAVES 2
 #endif
-template <int TY, int ZM, int STORE_AUX, bool HALO = false>
+template <int TY, int ZM, int STORE_AUX, bool HALO = false, bool FLAT = false>
 __global__ __launch_bounds__(256, (TY == 2 && !HALO) ? 4 : (HALO ? VEXHIP_HALO_WAVES : 2))       // (HALO: a few registers more than 128)
 void sell8_plane_kernel(const double *__restrict__ x, double *__restrict__ y, double alpha, const double *__restrict__ zs, double beta,
         const int *__restrict__ blocks, const char *__restrict__ pool, const int *__restrict__ deltas, const double *__restrict__ values,
         plane_dev pd, halo_dev H)
 {
     if constexpr (!HALO) {
-        plane_walk<TY, ZM, STORE_AUX, false>(x, y, alpha, zs, beta, blocks, pool, deltas, values, pd, H, 0ull);
+        plane_walk<TY, ZM, STORE_AUX, false, FLAT>(x, y, alpha, zs, beta, blocks, pool, deltas, values, pd, H, 0ull);
     } else {
         const unsigned long long step = *H.step;
         plane_walk<TY, ZM, STORE_AUX, true>(x, y, alpha, zs, beta, blocks, pool, deltas, values, pd, H, step);
@@ -531,8 +537,13 @@ int plane_apply_axpby(int dev, void *stream, int64_t n, double alpha, int zm, co
     const halo_dev none = halo_dev();
 #define PLANE_LAUNCH(TY, ZM, AUX) sell8_plane_kernel<TY, ZM, AUX><<<(unsigned)grid, 256, 0, s>>>(x, y, alpha, zs, beta, blocks, cpool, deltas, values, pd, none)
 #define PLANE_AUX(TY, AP) switch (store_kind) { case 1: PLANE_LAUNCH(TY, AP, 18); break; case 2: PLANE_LAUNCH(TY, AP, 17); break; case 3: PLANE_LAUNCH(TY, AP, 0); break; default: PLANE_LAUNCH(TY, AP, 2); }
+#define PLANE_FLAT(ZM, AUX) sell8_plane_kernel<2, ZM, AUX, false, true><<<(unsigned)grid, 256, 0, s>>>(x, y, alpha, zs, beta, blocks, cpool, deltas, values, pd, none)
+#define PLANE_FAUX(AP) switch (store_kind) { case 1: PLANE_FLAT(AP, 18); break; case 2: PLANE_FLAT(AP, 17); break; case 3: PLANE_FLAT(AP, 0); break; default: PLANE_FLAT(AP, 2); }
     if (plane->tile == 4) { if (zm == 1) { PLANE_AUX(4, 1) } else if (zm == 2) { PLANE_AUX(4, 2) } else { PLANE_AUX(4, 0) } }
+    else if (plane->flat) { if (zm == 1) { PLANE_FAUX(1) } else if (zm == 2) { PLANE_FAUX(2) } else { PLANE_FAUX(0) } }
     else { if (zm == 1) { PLANE_AUX(2, 1) } else if (zm == 2) { PLANE_AUX(2, 2) } else { PLANE_AUX(2, 0) } }
+#undef PLANE_FAUX
+#undef PLANE_FLAT
 #undef PLANE_AUX
 #undef PLANE_LAUNCH
     VEXHIP_LAUNCH_CHECK();
@@ -613,6 +624,7 @@ int plane_plan_from_grid(int dev, const vexhip_grid *grid, int64_t rows, vexhip_
     if ((grid->x_last + 1) % PL_ROWS != 0 || grid->x_last + 1 < rows) return 0;
     if (!plane_geometry(dev, ny, nz, grid->hot_class, out)) return 0;
     out->table_pitch = grid->pitch;
+    out->flat = grid->flat;
     out->x_last = grid->x_last; out->usable = 1;
     return 0;
 }
@@ -748,6 +760,8 @@ int vexhip_sell8_plane_plan(int dev, void *stream, const int32_t *deltas, int nd
     // lines, about one workgroup per CU.  The time also depends on where x and y lie relative to each other (0.378 - 0.41 ms for
     // the same kernel, r04_plane_offsets.json; the copy kernel and the march product do not show it).
     if (!plane_geometry(dev, ny, nz, hot, out)) return 0;
+    out->flat = 1;
+    for (int d : table) if (std::llabs((long long)d) == PL_ROWS) out->flat = 0;
     out->x_last = x_last; out->usable = 1;
     return 0;
 }

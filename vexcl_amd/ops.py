@@ -440,7 +440,7 @@ class SpMat:
                       if info.march.usable else None)              # not None: apply() runs the march product
         self.plane = ({"lines_per_plane": int(info.plane.lines_per_plane), "planes": int(info.plane.planes), "depth": int(info.plane.depth),
                        "hot_block": int(info.plane.hot_block), "tile": int(info.plane.tile), "store_policy": int(info.plane.store_policy), "x_last": int(info.plane.x_last),
-                       "table_pitch": int(info.plane.table_pitch)}
+                       "table_pitch": int(info.plane.table_pitch), "flat": int(info.plane.flat)}
                       if info.plane.usable else None)              # not None: apply() runs the plane product (fp64: plane.hip; fp32: plane32.hip)
         g = info.grid
         self.grid = ({"nx": int(g.nx), "lines_per_plane": int(g.lines_per_plane), "planes": int(g.planes), "depth": int(g.depth),
