@@ -646,7 +646,7 @@ def test_wide_value_coded_slices_share_a_dictionary(T, oracle, built_lib):
         m = len(ptr) - 1
         A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
         assert A.storage == "sell8v" and int(A.info.ell_width) == 27, (A.storage, A.reason)
-        assert A.dictionary_blocks > 0 and A.product == "sell8v_kernel", (A.dictionary_blocks, A.product, A.reason)
+        assert A.dictionary_blocks > 0 and A.product == "sell8v_runs_kernel", (A.dictionary_blocks, A.product, A.reason)
         x = oracle.random_f64(21, m); y0 = oracle.random_f64(22, m)
         y = T.up(np.full(m, np.nan)); A.apply(T.up(x), y)
         assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x))
@@ -665,6 +665,47 @@ def test_wide_value_coded_slices_share_a_dictionary(T, oracle, built_lib):
         xi = x.copy(); xi[0] = np.inf; xi[m - 1] = np.nan
         y = T.up(np.full(m, np.nan)); A.apply(T.up(xi), y)
         assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, xi), equal_nan=True)
+        # round 6, the runs product (sell8.hip sell8v_runs_kernel: entries decoded once per distinct slice -- masks and a value per wave
+        # and column --, a request per triple of consecutive diagonals): y = alpha A x + beta z in the same pass, and the float matrix
+        xd, zd = T.up(x), T.up(y0.copy())
+        want = oracle.spmv_csr(ptr, col, val, x)
+        for z, zh in ((zd, y0), (xd, x)):
+            ya = T.torch.empty_like(xd)
+            A.apply_axpby(xd, ya, -0.75, z, 2.5)
+            assert np.array_equal(ya.cpu().numpy(), 2.5 * zh + (-0.75) * want)
+        f32 = np.float32
+        F = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val.astype(f32)))
+        assert F.product == "sell8v_runs_kernel", (F.product, F.reason)
+        yf = T.up(np.full(m, np.nan, dtype=f32)); F.apply(T.up(x.astype(f32)), yf)
+        assert np.array_equal(yf.cpu().numpy(), oracle.spmv_csr(ptr, col, val.astype(f32), x.astype(f32)))
+        # a value that is not finite: its column keeps the codes' path (Inf times the +0.0 of an absent entry would be NaN)
+        vi = val.copy(); vi[vi == 26.0] = np.inf
+        I = T.ops.SpMat(T.up(ptr), T.up(col), T.up(vi))
+        y = T.up(np.full(m, np.nan)); I.apply(T.up(x), y)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, vi, x), equal_nan=True)
+    # 19 points (no corners: triples and single columns mixed), natural boundaries (rows of 8 .. 19 entries: columns of mixed diagonals),
+    # values that differ from row to row inside a column (two alternating coefficients: no single value per column)
+    g = 48
+    N = g ** 3
+    idx = np.arange(N, dtype=np.int64)
+    i, j, k = idx % g, (idx // g) % g, idx // (g * g)
+    offs = [(dx, dy, dz) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if abs(dx) + abs(dy) + abs(dz) <= 2]
+    assert len(offs) == 19
+    for alternating in (False, True):
+        has = np.stack([(i + dx >= 0) & (i + dx < g) & (j + dy >= 0) & (j + dy < g) & (k + dz >= 0) & (k + dz < g) for dx, dy, dz in offs], axis=1)
+        cols = idx[:, None] + np.array([dz * g * g + dy * g + dx for dx, dy, dz in offs], dtype=np.int64)[None, :]
+        vals = np.where(np.array([o == (0, 0, 0) for o in offs])[None, :], 18.0, -1.0 - 0.5 * np.array([abs(dx) + abs(dy) + abs(dz) for dx, dy, dz in offs], dtype=np.float64)[None, :]) * np.ones((N, 1))
+        if alternating:
+            vals = vals * np.where((idx % 3 == 0)[:, None], 1.0, 0.5)
+        ptr = np.zeros(N + 1, dtype=np.int64); ptr[1:] = np.cumsum(has.sum(axis=1))
+        ptr, col, val = ptr.astype(np.int32), cols[has].astype(np.int32), vals[has]
+        A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
+        assert A.storage == "sell8v" and int(A.info.ell_width) == 19 and A.dictionary_blocks > 0, (A.storage, A.reason)
+        x = oracle.random_f64(77, N); y0 = oracle.random_f64(78, N)
+        y = T.up(np.full(N, np.nan)); A.apply(T.up(x), y)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x)), alternating
+        y = T.up(y0.copy()); A.apply(T.up(x), y, 1.5, True)
+        assert np.array_equal(y.cpu().numpy(), oracle.spmv_csr(ptr, col, val, x, y=y0.copy(), alpha=1.5, append=True)), alternating
 
 
 def test_product_with_a_vector_added_is_bit_identical(T, oracle, built_lib):

@@ -1,4 +1,5 @@
-// Round 6 experiment, NOT part of the library (never compiled by csrc/Makefile): "runs of three diagonals" for value-coded slices wider
+// Round 6 experiment, NOT part of the library (never compiled by csrc/Makefile; the form that WAS kept -- entries decoded at set-up -- is
+// sell8v_runs_kernel in csrc/sell8.hip): "runs of three diagonals" for value-coded slices wider
 // than nine columns (27-point stencils) in its LAST form -- triples found once per distinct slice at set-up (sell8v_runs_plan), the
 // product persistent with the codes of a dictionary block kept in registers across the slices that share it.  Four forms were measured,
 // all bit-identical (tests/test_gpu_spmv.py), none kept (profiles/r06_runs_of_three.md):

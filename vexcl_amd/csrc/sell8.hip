@@ -19,6 +19,7 @@
 #include "traversal.hpp"
 #include "pairing.hpp"
 #include "halo.hpp"
+#include "lanes.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -413,6 +414,173 @@ void sell8v_kernel(long long n, long long nslices, V alpha, int append, int ell_
                 const int sh = 8 * ((j & 1) * 2 + q);
                 const unsigned code = (cword >> sh) & 255u;
                 if (code < S8_FIRST_PAD) sum[q] += s_value[(vword >> sh) & 255u] * x[i + q + s_delta[code]];
+            }
+        }
+    }
+    if (csr_ptr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (i + q < n)
+                for (int j = csr_ptr[i + q], e = csr_ptr[i + q + 1]; j < e; ++j) sum[q] += csr_val[j] * x[csr_col[j]];
+    }
+    store_pair<V>(n, i, alpha, append, sum, y, trav);
+}
+
+// ---------------------------------------------------------------------------
+// RUNS of three diagonals, decoded at set-up (round 6): value-coded slices wider than nine columns whose distinct slices live in the
+// dictionary -- 19- and 27-point stencils, 9-point operators in 2-D, dense bands.
+// Four forms that only cut the REQUESTS of such a product (a 27-point row holds nine triples d-1, d, d+1: one 16-byte request and two DPP
+// shifts serve a lane's six elements of x) left its time where it was (profiles/r06_runs_of_three.md): the product is bound by what it
+// does per ENTRY of its two-byte codes -- extract, test for padding, read the value table, select, multiply: ~10 instructions, 3 456
+// entries per wave and slice.  So the entries are decoded ONCE per distinct slice, at set-up (sell8v_runs_plan_kernel): for every wave of
+// a dictionary block and every ELL column, which lanes hold an entry in their first / second row (two 64-bit masks) and -- where all of
+// them carry the same value, as the rows of a constant-coefficient stencil do -- that value; for every aligned group of three columns,
+// whether each sits on ONE diagonal and the three are consecutive.  The product reads these with scalar loads: a FAST group costs one
+// request for x (+ the wave's two edge elements), and per entry a select of x by the mask and the multiply-add with a scalar value --
+// what the grid storage's walk does with its hot class.  Groups that are not fast (the first columns of a wave that holds boundary
+// rows, values that differ within a column, the first / last waves of the matrix) take the codes' path of the any-width kernel.
+// Sums in column order; an absent entry adds (value) * (+0.0) = +-0.0, which leaves a sum that started at +0.0 bit for bit (the
+// pair kernels below argue the same way): bit-identical to the CSR loop.
+constexpr int RUNS_GROUPS = 11;                          // groups of three columns: ELL widths up to 33
+constexpr int RUNS_HEAD = 12;                            // ints: mask of the fast groups, then every group's centre diagonal
+constexpr int RUNS_STRIDE = RUNS_HEAD + 6 * 3 * RUNS_GROUPS;   // + per column {mask of first rows, mask of second rows, value}: 8 bytes each
+
+template <typename V>
+__global__ __launch_bounds__(256)
+void sell8v_runs_plan_kernel(const char *__restrict__ pool, int w, const int *__restrict__ deltas, const V *__restrict__ values, int *__restrict__ desc, int *__restrict__ total)
+{
+    __shared__ int s_delta[256];
+    __shared__ V s_value[256];
+    s_delta[threadIdx.x] = deltas[threadIdx.x];
+    s_value[threadIdx.x] = values[threadIdx.x];
+    __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wp = (w + 1) / 2;
+    const unsigned *cw = reinterpret_cast<const unsigned *>(pool + (long long)blockIdx.x * ((long long)wp * 2048)) + t;
+    const unsigned *vw = cw + wp * 256;
+    int *out = desc + ((long long)blockIdx.x * 4 + wave) * RUNS_STRIDE;
+    unsigned mask = 0;
+    for (int k = 0; k < RUNS_GROUPS; ++k) {
+        int dg[3]; bool ok = true;
+        for (int u = 0; u < 3; ++u) {
+            const int j = 3 * k + u;
+            unsigned long long m0 = 0, m1 = 0, vbits = 0;
+            dg[u] = INT_MIN;
+            if (j < w) {
+                const unsigned word = cw[(j >> 1) * 256] >> (16 * (j & 1)), vword = vw[(j >> 1) * 256] >> (16 * (j & 1));
+                const unsigned c0 = word & 255u, c1 = (word >> 8) & 255u, v0 = vword & 255u, v1 = (vword >> 8) & 255u;
+                const bool e0 = c0 < S8_FIRST_PAD, e1 = c1 < S8_FIRST_PAD;
+                m0 = __builtin_amdgcn_ballot_w64(e0); m1 = __builtin_amdgcn_ballot_w64(e1);
+                const unsigned long long any = m0 | m1;
+                if (any) {
+                    const int first = __builtin_ctzll(any);
+                    const unsigned cu = (unsigned)__shfl((int)(e0 ? c0 : c1), first, 64), vu = (unsigned)__shfl((int)(e0 ? v0 : v1), first, 64);
+                    const bool one_diagonal = !__builtin_amdgcn_ballot_w64((e0 && c0 != cu) || (e1 && c1 != cu));
+                    const bool one_value = !__builtin_amdgcn_ballot_w64((e0 && v0 != vu) || (e1 && v1 != vu));
+                    const V val = s_value[vu];
+                    // (a value that is not finite times the +0.0 of an absent entry would be NaN: such a column keeps the codes' path)
+                    if (one_diagonal && one_value && val - val == V(0)) {
+                        dg[u] = s_delta[cu];
+                        __builtin_memcpy(&vbits, &val, sizeof(V));
+                    }
+                }
+            }
+            ok = ok && dg[u] != INT_MIN;
+            if (lane == 0) {
+                int *col = out + RUNS_HEAD + 6 * j;
+                col[0] = (int)(unsigned)m0; col[1] = (int)(unsigned)(m0 >> 32); col[2] = (int)(unsigned)m1; col[3] = (int)(unsigned)(m1 >> 32);
+                col[4] = (int)(unsigned)vbits; col[5] = (int)(unsigned)(vbits >> 32);
+            }
+        }
+        ok = ok && (long long)dg[1] == (long long)dg[0] + 1 && (long long)dg[2] == (long long)dg[0] + 2;
+        if (ok) mask |= 1u << k;
+        if (lane == 0) out[1 + k] = ok ? dg[1] : 0;
+    }
+    if (lane == 0) { out[0] = (int)mask; if (mask) atomicAdd(total, __popc(mask)); }
+}
+
+// +0.0 outside `lanes` (an absent entry must not see what x holds there -- Inf, NaN -- and contributes +-0.0)
+__device__ __forceinline__ double zero_outside(double v, unsigned long long lanes) {
+    unsigned lo, hi;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"((unsigned)__double2loint(v)), "s"(lanes));
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"((unsigned)__double2hiint(v)), "s"(lanes));
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ float zero_outside(float v, unsigned long long lanes) { return keep_lanes(v, lanes); }
+
+template <typename V>
+__global__ __launch_bounds__(256)
+void sell8v_runs_kernel(long long n, long long nslices, V alpha, int append, int w,
+        const char *__restrict__ pool, const int *__restrict__ deltas, const V *__restrict__ values,
+        const int *__restrict__ csr_ptr, const int *__restrict__ csr_col, const V *__restrict__ csr_val,
+        const V *__restrict__ x, V *__restrict__ y, trav_dev trav, const int *__restrict__ blocks, const int *__restrict__ desc, long long x_last)
+{
+    constexpr int G = RUNS_GROUPS;
+    typedef typename vec2<V>::type V2;
+    __shared__ int s_delta[256];
+    __shared__ V s_value[256];
+    s_delta[threadIdx.x] = deltas[threadIdx.x];
+    s_value[threadIdx.x] = values[threadIdx.x];
+    __syncthreads();
+
+    const long long s = traversal_block(trav, nslices);
+    if (s < 0) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const long long i = s * S8_ROWS + 2 * t;
+    const long long r_lo = s * S8_ROWS + 128 * wave, r_hi = r_lo + 127;         // the wave's rows
+    const int wp = (w + 1) / 2;
+    const long long sb = (long long)__builtin_amdgcn_readfirstlane(blocks[s]);
+    const unsigned *cw = reinterpret_cast<const unsigned *>(pool + sb * ((long long)wp * 2048)) + t;
+    const unsigned *vw = cw + wp * 256;
+    const int *dw = desc + (sb * 4 + wave) * RUNS_STRIDE;                         // uniform: scalar loads
+    unsigned tmask = (unsigned)__builtin_amdgcn_readfirstlane(dw[0]);
+
+    // every fast group's elements of x, requested before anything is used
+    V2 Pk[G];
+    V Ek[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        if ((tmask >> k) & 1u) {                                                       // uniform
+            const long long dc = (long long)__builtin_amdgcn_readfirstlane(dw[1 + k]);
+            if (r_lo + dc - 1 >= 0 && r_hi + dc + 1 <= x_last) {
+                __builtin_memcpy(&Pk[k], x + (i + dc), sizeof(V2));                   // (4-byte alignment is enough for the wide load)
+                Ek[k] = x[lane == 63 ? i + dc + 2 : r_lo + dc - 1];
+            } else tmask &= ~(1u << k);                                                // the first / last waves of the matrix: the codes' path
+        }
+    }
+
+    V sum[2] = {V(0), V(0)};
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        if (3 * k >= w) continue;                                                      // uniform
+        if ((tmask >> k) & 1u) {                                                       // uniform
+            const V2 P = Pk[k]; const V E = Ek[k];
+            const V xs[3][2] = {{shift_from_lower_lane(P.y, E), P.x},                  // diagonal dc - 1: x[i + dc - 1], x[i + dc]
+                                {P.x, P.y},                                            // diagonal dc
+                                {P.y, shift_from_upper_lane(P.x, E)}};                 // diagonal dc + 1: x[i + dc + 1], x[i + dc + 2]
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int *col = dw + RUNS_HEAD + 6 * (3 * k + u);
+                const unsigned long long m0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(col[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(col[0]);
+                const unsigned long long m1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(col[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(col[2]);
+                V a;
+                if constexpr (sizeof(V) == 8) a = __hiloint2double(__builtin_amdgcn_readfirstlane(col[5]), __builtin_amdgcn_readfirstlane(col[4]));
+                else a = __int_as_float(__builtin_amdgcn_readfirstlane(col[4]));
+                // (a variant of the group without the selects, for waves whose lanes hold all six entries, was slower: 0.255 -> 0.313 ms at 320^3)
+                sum[0] += a * zero_outside(xs[u][0], m0);
+                sum[1] += a * zero_outside(xs[u][1], m1);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int j = 3 * k + u;
+                if (j >= w) continue;                                                  // uniform
+                const int sh = 16 * (j & 1);
+                const unsigned cword = cw[(j >> 1) * 256], vword = vw[(j >> 1) * 256];
+                const unsigned c0 = (cword >> sh) & 255u, c1 = (cword >> (sh + 8)) & 255u;
+                if (c0 < S8_FIRST_PAD) sum[0] += s_value[(vword >> sh) & 255u] * x[i + s_delta[c0]];
+                if (c1 < S8_FIRST_PAD) sum[1] += s_value[(vword >> (sh + 8)) & 255u] * x[i + 1 + s_delta[c1]];
             }
         }
     }
@@ -1849,6 +2017,59 @@ int sell8_analyze(int dev, void *stream, int64_t n, const P *ptr, const int32_t 
 int sell8_apply_halo(int dev, hipStream_t s, long long own_rows, double alpha, int append, int w, bool vcoded, const void *buf, const void *pool,
         const int *blocks, const int *deltas, const double *values, const double *x, double *y, halo_dev H)
 { return sell8_apply_halo_impl<double>(dev, s, own_rows, alpha, append, w, vcoded, buf, pool, blocks, deltas, values, x, y, H); }
+
+// ---- runs of three diagonals (above): the plan of a dictionary's blocks, and the product (spmat.hip) ----
+// desc_out: device array of nblocks x 4 waves x RUNS_STRIDE ints (hipFree), NULL when no wave of any block holds a fast group
+template <typename V>
+static int sell8v_runs_plan_impl(int dev, void *stream, const void *pool, int64_t nblocks, int64_t w, const int *deltas, const V *values, int **desc_out)
+{
+    VEXHIP_REQUIRE(desc_out, "NULL output");
+    *desc_out = nullptr;
+    if (!pool || !deltas || !values || nblocks < 1 || w < 10 || w > 3 * RUNS_GROUPS) return 0;
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    int *desc = nullptr;
+    const size_t ints = (size_t)nblocks * 4 * RUNS_STRIDE;
+    VEXHIP_TRY(hipMalloc(reinterpret_cast<void **>(&desc), sizeof(int) * (ints + 1)));
+    int *total = desc + ints;
+    hipError_t e = hipMemsetAsync(desc, 0, sizeof(int) * (ints + 1), s);
+    if (e == hipSuccess) { sell8v_runs_plan_kernel<V><<<(unsigned)nblocks, 256, 0, s>>>(static_cast<const char *>(pool), (int)w, deltas, values, desc, total); e = hipGetLastError(); }
+    int found = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&found, total, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess || found == 0) { (void)hipFree(desc); return e == hipSuccess ? 0 : check(e, __FILE__, __LINE__); }
+    *desc_out = desc;
+    return 0;
+}
+int sell8v_runs_plan(int dev, void *stream, const void *pool, int64_t nblocks, int64_t w, const int *deltas, const double *values, int **desc_out)
+{ return sell8v_runs_plan_impl<double>(dev, stream, pool, nblocks, w, deltas, values, desc_out); }
+int sell8v_runs_plan(int dev, void *stream, const void *pool, int64_t nblocks, int64_t w, const int *deltas, const float *values, int **desc_out)
+{ return sell8v_runs_plan_impl<float>(dev, stream, pool, nblocks, w, deltas, values, desc_out); }
+
+template <typename V>
+static int sell8v_runs_apply_impl(int dev, void *stream, int64_t n, V alpha, int append, int64_t w, const void *pool, const int *blocks,
+        const int *deltas, const V *values, const int *cp, const int *cc, const V *cv, const V *x, V *y, const vexhip_traversal *tr, const int *desc, long long x_last)
+{
+    VEXHIP_REQUIRE(n >= 0 && w >= 10 && w <= 3 * RUNS_GROUPS && pool && blocks && deltas && values && desc && x_last >= 0, "bad arguments of the runs product");
+    if (n == 0) return 0;
+    VEXHIP_REQUIRE(x && y, "NULL vector");
+    VEXHIP_SET_DEVICE(dev);
+    hipStream_t s = as_stream(stream);
+    const long long ns = (n + S8_ROWS - 1) / S8_ROWS;
+    long long grid = 0;
+    trav_dev t8 = make_traversal(tr, ns, &grid);
+    VEXHIP_REQUIRE(grid < (1ll << 31), "matrix too large for one launch");
+    t8 = with_addend(t8);
+    sell8v_runs_kernel<V><<<(unsigned)grid, 256, 0, s>>>(n, ns, alpha, append, (int)w, static_cast<const char *>(pool), deltas, values, cp, cc, cv, x, y, t8, blocks, desc, x_last);
+    VEXHIP_LAUNCH_CHECK();
+    return 0;
+}
+int sell8v_runs_apply(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *pool, const int *blocks, const int *deltas, const double *values,
+        const int *cp, const int *cc, const double *cv, const double *x, double *y, const vexhip_traversal *tr, const int *desc, long long x_last)
+{ return sell8v_runs_apply_impl<double>(dev, stream, n, alpha, append, w, pool, blocks, deltas, values, cp, cc, cv, x, y, tr, desc, x_last); }
+int sell8v_runs_apply(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *pool, const int *blocks, const int *deltas, const float *values,
+        const int *cp, const int *cc, const float *cv, const float *x, float *y, const vexhip_traversal *tr, const int *desc, long long x_last)
+{ return sell8v_runs_apply_impl<float>(dev, stream, n, alpha, append, w, pool, blocks, deltas, values, cp, cc, cv, x, y, tr, desc, x_last); }
 
 
 // ---- 64-bit row pointers (a device may hold 2^31 entries or more; columns stay 32-bit): internal entry points used by

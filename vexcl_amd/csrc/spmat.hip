@@ -65,6 +65,12 @@ int grid32_apply_axpby(int dev, void *stream, int64_t n, float alpha, int zm, co
         const float *x, float *y, const vexhip_grid *g);
 int grid_apply_halo(int dev, hipStream_t s, int64_t n_ext, double alpha, int append, const double *values, const double *x, double *y,
         const vexhip_grid *g, halo_dev H);
+int sell8v_runs_plan(int dev, void *stream, const void *pool, int64_t nblocks, int64_t w, const int *deltas, const double *values, int **desc_out);
+int sell8v_runs_plan(int dev, void *stream, const void *pool, int64_t nblocks, int64_t w, const int *deltas, const float *values, int **desc_out);
+int sell8v_runs_apply(int dev, void *stream, int64_t n, double alpha, int append, int64_t w, const void *pool, const int *blocks, const int *deltas, const double *values,
+        const int *cp, const int *cc, const double *cv, const double *x, double *y, const vexhip_traversal *tr, const int *desc, long long x_last);
+int sell8v_runs_apply(int dev, void *stream, int64_t n, float alpha, int append, int64_t w, const void *pool, const int *blocks, const int *deltas, const float *values,
+        const int *cp, const int *cc, const float *cv, const float *x, float *y, const vexhip_traversal *tr, const int *desc, long long x_last);
 int sell8_apply_halo(int dev, hipStream_t s, long long own_rows, double alpha, int append, int w, bool vcoded, const void *buf, const void *pool,
         const int *blocks, const int *deltas, const double *values, const double *x, double *y, halo_dev H);
 int plane32_apply_halo(int dev, hipStream_t s, int64_t n_ext, float alpha, int append, int64_t w, const void *pool, const int32_t *blocks,
@@ -77,6 +83,8 @@ struct spmat {
     int value_type = VEXHIP_F64;
     int format = VEXHIP_SPMAT_CSR;
     int64_t n = 0, nnz = 0, ell_w = 0, tail = 0;
+    int64_t ell_max_col = -1;                                      // SELL8V: the largest column of the ELL part (or columns the caller vouched for): how far x reaches
+    int *runs = nullptr;                                           // wide value-coded slices in a dictionary, decoded per wave and column (sell8.hip sell8v_runs_plan)
     void *sell = nullptr; int64_t sell_bytes = 0;
     // slice dictionary (sell8.hip): the codes of slice s are block blocks[s] of `pool` (dict_blocks distinct code blocks of
     // code_bytes each).  SELL8V: the slices are nothing but codes -- `sell` is freed; SELL8: `sell` keeps the values.
@@ -105,6 +113,7 @@ void release(spmat *A) {
     (void)hipSetDevice(A->dev);
     if (A->sell) (void)hipFree(A->sell);
     if (A->blocks) (void)hipFree(A->blocks);
+    if (A->runs) (void)hipFree(A->runs);
     if (A->pool) (void)hipFree(A->pool);
     if (A->deltas) (void)hipFree(A->deltas);
     if (A->values) (void)hipFree(A->values);
@@ -145,6 +154,7 @@ inline product_choice select_product(const spmat *A, const void *x, const void *
             if (A->grid.usable && (g_sell8_variant == 0 || A->direct) && !A->tail)
                 return f64 ? product_choice{P_GRID64, "sell8_grid_kernel", A->plane.usable ? "plane plan, but x or y is not 16-byte aligned: the grid product addresses by element" : "grid plan (lines of any length)"}
                            : product_choice{P_GRID32, "sell8_grid_f32_kernel", "grid plan (lines of any length), float"};
+            if (A->blocks && A->runs && A->ell_max_col >= 0 && g_sell8_variant == 0) return {P_MARCH, "sell8v_runs_kernel", "slice dictionary; entries decoded once per distinct slice, runs of three consecutive diagonals share a request"};
             if (A->blocks) return {P_MARCH, A->march.usable ? "sell8_march_kernel" : (A->ell_w <= 8 ? "sell8_pair_kernel" : "sell8v_kernel"), A->march.usable ? "slice dictionary + march plan" : "slice dictionary, no march plan: the codes of the distinct slices from the pool"};
             return {P_PAIR_CODES, A->ell_w <= 8 ? "sell8_pair_kernel" : "sell8v_kernel", "value codes, one code block per slice"};
         case VEXHIP_SPMAT_SELL8:
@@ -254,6 +264,11 @@ int make_dictionary(spmat *A, void *stream, int flags, int64_t code_bytes, bool 
         if (e != hipSuccess) return check(e, __FILE__, __LINE__);
         A->dict_blocks = nb; A->code_bytes = code_bytes;
         if (whole_slice) { (void)hipFree(A->sell); A->sell = nullptr; A->sell_bytes = 0; }
+        if (whole_slice && A->ell_w > 9 && g_sell8_variant == 0) {            // 19- / 27-point rows: decoded once per distinct slice (sell8.hip, runs of three diagonals)
+            int rc2 = A->value_type == VEXHIP_F64 ? sell8v_runs_plan(A->dev, stream, A->pool, nb, A->ell_w, A->deltas, (const double *)A->values, &A->runs)
+                                                  : sell8v_runs_plan(A->dev, stream, A->pool, nb, A->ell_w, A->deltas, (const float *)A->values, &A->runs);
+            if (rc2) return rc2;
+        }
         if (whole_slice && A->ell_w <= 8 && !(flags & VEXHIP_SPMAT_NO_MARCH)) {
             const int vb = A->value_type == VEXHIP_F64 ? 8 : 4;
             if (int rc2 = vexhip_sell8_march_plan(A->dev, stream, A->deltas, A->ndeltas, A->blocks, ns, vb,
@@ -409,6 +424,7 @@ int build(spmat *A, void *stream, int64_t n, const P *ptr, const int32_t *col, c
             VEXHIP_TRY(hipMalloc(&A->sell, (size_t)A->sell_bytes));
             trace.mark("allocate slices");
             if (int rc = S::v_fill(dev, stream, n, ptr, col, val, w, A->deltas, nd, (const V *)A->values, nv, A->sell, &A->trav)) return rc;
+            A->ell_max_col = std::max<int64_t>(vexhip_sell8_last_fill_max_col(), min_cols - 1);
             trace.mark("fill");
             if (int rc = make_dictionary(A, stream, flags, A->sell_bytes / ((n + 511) / 512), true)) return rc;
             trace.mark("dictionary + plans");
@@ -503,7 +519,10 @@ int apply(const spmat *A, void *stream, V alpha, int append, const V *x, V *y)
         case P_GRID32:
             if constexpr (std::is_same<V, float>::value) return vexhip_spmv_sell8v_grid_f32(A->dev, stream, A->n, alpha, append, (const float *)A->values, x, y, &A->grid);
             break;
-        case P_MARCH: return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
+        case P_MARCH:
+            if (A->runs && A->ell_max_col >= 0 && g_sell8_variant == 0)
+                return sell8v_runs_apply(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, (const V *)A->values, cp, A->csr_col, (const V *)A->csr_val, x, y, &A->trav, A->runs, A->ell_max_col);
+            return F::mul_vd(A->dev, stream, A->n, alpha, append, A->ell_w, A->pool, A->blocks, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav, &A->march);
         case P_PAIR_CODES: return F::mul_v(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, A->values, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case P_PAIR_DICT_VALUES: return F::mul_dd(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->pool, A->blocks, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
         case P_PAIR_VALUES: return F::mul_d(A->dev, stream, A->n, alpha, append, A->ell_w, A->sell, A->deltas, cp, A->csr_col, A->csr_val, x, y, &A->trav);
