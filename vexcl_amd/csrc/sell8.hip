@@ -486,6 +486,7 @@ void sell8v_runs_plan_kernel(const char *__restrict__ pool, int w, const int *__
                 }
             }
             ok = ok && dg[u] != INT_MIN;
+            if (lane == 0 && (m0 | m1)) atomicAdd(total + 1, 1);                       // columns that hold entries at all
             if (lane == 0) {
                 int *col = out + RUNS_HEAD + 6 * j;
                 col[0] = (int)(unsigned)m0; col[1] = (int)(unsigned)(m0 >> 32); col[2] = (int)(unsigned)m1; col[3] = (int)(unsigned)(m1 >> 32);
@@ -496,7 +497,7 @@ void sell8v_runs_plan_kernel(const char *__restrict__ pool, int w, const int *__
         if (ok) mask |= 1u << k;
         if (lane == 0) out[1 + k] = ok ? dg[1] : 0;
     }
-    if (lane == 0) { out[0] = (int)mask; if (mask) atomicAdd(total, __popc(mask)); }
+    if (lane == 0) { out[0] = (int)mask; if (mask) atomicAdd(total, 3 * __popc(mask)); }      // columns in fast groups
 }
 
 // +0.0 outside `lanes` (an absent entry must not see what x holds there -- Inf, NaN -- and contributes +-0.0)
@@ -2030,14 +2031,18 @@ static int sell8v_runs_plan_impl(int dev, void *stream, const void *pool, int64_
     hipStream_t s = as_stream(stream);
     int *desc = nullptr;
     const size_t ints = (size_t)nblocks * 4 * RUNS_STRIDE;
-    VEXHIP_TRY(hipMalloc(reinterpret_cast<void **>(&desc), sizeof(int) * (ints + 1)));
-    int *total = desc + ints;
-    hipError_t e = hipMemsetAsync(desc, 0, sizeof(int) * (ints + 1), s);
+    VEXHIP_TRY(hipMalloc(reinterpret_cast<void **>(&desc), sizeof(int) * (ints + 2)));
+    int *total = desc + ints;                                                          // {columns in fast groups, columns that hold entries} over all waves of all blocks
+    hipError_t e = hipMemsetAsync(desc, 0, sizeof(int) * (ints + 2), s);
     if (e == hipSuccess) { sell8v_runs_plan_kernel<V><<<(unsigned)nblocks, 256, 0, s>>>(static_cast<const char *>(pool), (int)w, deltas, values, desc, total); e = hipGetLastError(); }
-    int found = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&found, total, sizeof(int), hipMemcpyDeviceToHost, s);
+    int found[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(found, total, sizeof(found), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess || found == 0) { (void)hipFree(desc); return e == hipSuccess ? 0 : check(e, __FILE__, __LINE__); }
+    // Worth it where most columns are fast: the codes' path of this kernel takes its columns one at a time (the any-width kernel eight at a
+    // time).  A 19-point row -- five triples and four single columns, the triples at columns 1, 5, 8, 11, 15: not aligned -- is slower through
+    // it (320^3: 0.478 ms against 0.339) and keeps the any-width kernel; a form with triples at any column and single fast columns (a state
+    // per column instead of straight-line groups) lost on BOTH (0.458 and 0.470 ms, profiles/r06_runs_of_three.md).
+    if (e != hipSuccess || found[0] * 4 < found[1] * 3) { (void)hipFree(desc); return e == hipSuccess ? 0 : check(e, __FILE__, __LINE__); }
     *desc_out = desc;
     return 0;
 }
