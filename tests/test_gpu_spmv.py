@@ -618,12 +618,13 @@ def test_storage_by_grid_line_holds_the_matrix(T, oracle, built_lib):
         os.environ.pop("VEXHIP_PLANE_FORCE", None)
 
 
-def _stencil27_const(g):
-    """constant-coefficient 27-point operator on g^3, identity rows on the boundary, columns ascending"""
-    N = g ** 3
+def _stencil27_const(g, gz=None):
+    """constant-coefficient 27-point operator on g x g x gz (g^3 by default), identity rows on the boundary, columns ascending"""
+    gz = g if gz is None else gz
+    N = g * g * gz
     idx = np.arange(N, dtype=np.int64)
     i, j, k = idx % g, (idx // g) % g, idx // (g * g)
-    inner = (i > 0) & (i < g - 1) & (j > 0) & (j < g - 1) & (k > 0) & (k < g - 1)
+    inner = (i > 0) & (i < g - 1) & (j > 0) & (j < g - 1) & (k > 0) & (k < gz - 1)
     ptr = np.zeros(N + 1, dtype=np.int64); ptr[1:] = np.cumsum(np.where(inner, 27, 1))
     col = np.empty(ptr[-1], dtype=np.int32); val = np.empty(ptr[-1], dtype=np.float64)
     b = ptr[:-1][inner]; e = 0
@@ -641,8 +642,8 @@ def test_wide_value_coded_slices_share_a_dictionary(T, oracle, built_lib):
     """Round 6: value-coded SELL-512 slices WIDER than eight columns (a constant-coefficient 27-point operator: 27 diagonals, a handful of
     values) are pooled in the slice dictionary too -- 28 KiB of codes per distinct slice instead of 54 bytes per row (320^3: 1.06 -> 0.52 ms with the eight-column trips of the any-width kernel,
     profiles/r06_widen_probe.json).  Product, '+=', the multi-vector product: bit for bit the CSR loop."""
-    for g in (64, 40):
-        ptr, col, val = _stencil27_const(g)
+    for g, gz in ((64, None), (40, None), (48, 47), (40, 83)):          # (48 x 48 x 47, 40 x 40 x 83: a ragged last slice)
+        ptr, col, val = _stencil27_const(g, gz)
         m = len(ptr) - 1
         A = T.ops.SpMat(T.up(ptr), T.up(col), T.up(val))
         assert A.storage == "sell8v" and int(A.info.ell_width) == 27, (A.storage, A.reason)
