@@ -363,6 +363,10 @@ int vexhip_sell8_grid_release(int dev, vexhip_grid *grid);
  * for a matrix of n rows (the same test the product runs before every launch).  Both exist so that the plan of EVERY line length
  * can be checked where there is no GPU (tests/test_capi_exports.py).                                                            */
 int vexhip_sell8_grid_geometry(int cus, int64_t nx, int64_t lines_per_plane, int64_t planes, vexhip_grid *out);
+/* Round 6: the virtual grid line (in points) a matrix with the diagonals {0, +-1, +-row_length} -- a 5-point operator on a 2-D grid -- is
+ * stored by: 512 where an even number >= 4 of them make a row, else the longest even divisor of row_length in [128, min(1024,
+ * row_length / 10)], else 0 (such a matrix keeps the SELL-512 products).  Host arithmetic only, like _grid_geometry.                */
+int64_t vexhip_sell8_grid_virtual_line(int64_t row_length);
 int vexhip_sell8_grid_check(const vexhip_grid *grid, int64_t n);
 int vexhip_spmv_sell8v_grid_f64(int dev, void *stream, int64_t n, double alpha, int append, const double *values,
         const double *x, double *y, const vexhip_grid *grid);

@@ -123,6 +123,44 @@ def test_grid_plan_of_every_line_length_is_one_the_product_accepts(built_lib):
     assert not refused, refused[:10]
 
 
+def test_virtual_lines_of_two_dimensional_rows(built_lib):
+    """Round 6 (grid.hip grid_diagonals / vexhip_sell8_grid_virtual_line): a matrix {0, +-1, +-W} is stored by virtual grid lines -- 512 points
+    where an even number (>= 4) of them make a row, else the longest even divisor of W in [128, min(1024, W / 10)], else none.  Host
+    arithmetic only: the rule for every row length up to 40 000 against its statement, the cases the GPU tests and the bench rows rest on,
+    and that the plan of every such grid (lines per row = W / line, a few thousand rows) is one the product accepts."""
+    from vexcl_amd import _capi
+    L = _capi.lib()
+    def rule(W):
+        if W < 16:
+            return 0
+        if W % 512 == 0 and (W // 512) % 2 == 0 and W // 512 >= 4:
+            return 512
+        for d in range(min(1024, W // 10), 127, -1):
+            if W % d == 0 and d % 2 == 0:
+                return d
+        return 0
+    lines = {}
+    for W in list(range(1, 40001)) + [65536, 100000, 1 << 20, (1 << 30) + 2]:
+        nx = L.sell8_grid_virtual_line(W)
+        assert nx == (rule(W) if W <= (1 << 30) else 0), (W, nx)
+        if nx:
+            assert W % nx == 0 and nx % 2 == 0 and 128 <= nx <= 1024 and (nx == 512 or W // nx >= 10), (W, nx)
+            lines[W] = nx
+    assert [lines.get(W, 0) for W in (12000, 10000, 9000, 7000, 16384, 2000, 1400, 5632, 1536, 9999, 1000, 96)] == [1000, 1000, 900, 700, 512, 200, 140, 512, 128, 0, 0, 0]
+    refused = []
+    for W, nx in list(lines.items())[::7]:
+        for rows in (4, 3000):
+            g = _capi.Grid()
+            L.sell8_grid_geometry(256, nx, W // nx, rows, ctypes.byref(g))
+            if g.depth == 0:
+                continue
+            try:
+                L.sell8_grid_check(ctypes.byref(g), W * rows)
+            except _capi.Error:
+                refused.append((W, nx, rows))
+    assert not refused, refused[:10]
+
+
 def test_long_grid_lines_get_one_segment_and_enough_walks_to_balance_the_cus(built_lib):
     """Round 5 (grid.hip grid_geometry_with): lines of 513 .. 1024 points are ONE segment (workgroups of 5 .. 8 waves), and a
     cube of such lines -- 1.25 .. 2 tiles per CU and plane -- is cut into walks so that every CU sees at least six workgroups

@@ -184,6 +184,7 @@ _PROTOS = {
     "vexhip_sell8_grid_plan": (None, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_i64, ctypes.POINTER(Grid)]),
     "vexhip_sell8_grid_release": (None, [c_int, ctypes.POINTER(Grid)]),
     "vexhip_sell8_grid_geometry": (None, [c_int, c_i64, c_i64, c_i64, ctypes.POINTER(Grid)]),
+    "vexhip_sell8_grid_virtual_line": (c_i64, [c_i64]),
     "vexhip_sell8_plane_geometry": (None, [c_int, c_i64, c_i64, ctypes.POINTER(Plane)]),
     "vexhip_sell8_plane_f32_depth": (c_i64, [c_int, c_i64, c_i64]),
     "vexhip_sell8_grid_check": (None, [ctypes.POINTER(Grid), c_i64]),

@@ -913,6 +913,20 @@ void grid_fill_plan(vexhip_grid *out, long long nx, long long ny, long long nz, 
     out->flat = 0; out->reserved = 0;
 }
 
+} // namespace
+} // namespace vexhip
+/* the virtual grid line a 2-D row of `row_length` points is cut into (vexhip.h): host arithmetic only */
+extern "C" int64_t vexhip_sell8_grid_virtual_line(int64_t W)
+{
+    if (W < 16 || W > (1ll << 30)) return 0;
+    if (W % 512 == 0 && (W / 512) % 2 == 0 && W / 512 >= 4) return 512;
+    for (long long d = std::min<long long>(1024, W / 10); d >= 128; --d)
+        if (W % d == 0 && d % 2 == 0) return d;
+    return 0;
+}
+namespace vexhip {
+namespace {
+
 // the diagonals: {0, +-1, +-nx, +-P} with 1 < nx < P, P a multiple of nx (a subset that names both); false: not a grid matrix
 bool grid_diagonals(const std::vector<int> &table, long long rows, long long *nx_out, long long *far_out)
 {
@@ -927,20 +941,18 @@ bool grid_diagonals(const std::vector<int> &table, long long rows, long long *nx
         // (spmat/ccsr.hpp:55-113).  Taken where 512-point lines fit (an even number of them, four or more): the plane product.
         const long long W = mags[1];
         if (W < 16 || rows % W != 0 || W > (1ll << 30)) return false;
-        long long nx = 0;
-        if (W % 512 == 0 && (W / 512) % 2 == 0 && W / 512 >= 4) nx = 512;
-        // Round 6: any other row length -- the walk of a FLAT plan (vexhip_grid.flat) no longer requests the lines above and below a
-        // tile, which is what kept these rows behind the pair product in round 5 (below).  Virtual lines of the longest even divisor of
-        // W up to 1024 points, ten or more of them per row (the first and the last line of a row are classes of their own, so are the
-        // lines of the first and the last row: the hot class must keep three lines in four).  VEXHIP_GRID_2D_LINE = points per virtual
-        // line (a divisor of W), 0: as in round 5.
-        if (nx == 0) {
-            long long want = -1;
-            if (const char *e = env(ENV_VEXHIP_GRID_2D_LINE)) want = std::atoll(e);
-            if (want > 0) { if (W % want == 0 && want >= 8) nx = want; }
-            else if (want < 0)
-                for (long long d = std::min<long long>(1024, W / 10); d >= 128; --d)
-                    if (W % d == 0 && d % 2 == 0) { nx = d; break; }
+        // Virtual lines: 512 points where an even number (>= 4) of them make a row (the plane product); round 6: any other row length -- the
+        // walk of a FLAT plan (vexhip_grid.flat) no longer requests the lines above and below a tile, which is what kept these rows behind
+        // the pair product in round 5 (below) -- the longest even divisor of W up to 1024 points, ten or more of them per row (the first and
+        // the last line of a row are classes of their own, so are the lines of the first and the last row: the hot class must keep three
+        // lines in four).  vexhip_sell8_grid_virtual_line is this rule by itself; VEXHIP_GRID_2D_LINE = points per virtual line (a
+        // divisor of W) overrides the second part, 0: as in round 5.
+        long long nx = vexhip_sell8_grid_virtual_line(W);
+        if (nx != 512) {
+            if (const char *e = env(ENV_VEXHIP_GRID_2D_LINE)) {
+                const long long want = std::atoll(e);
+                nx = (want > 0 && W % want == 0 && want >= 8) ? want : (want == 0 ? 0 : nx);
+            }
         }
         // (other row lengths walked along a divisor of W -- 10000^2 as 20 lines of 500 points, 12000 x 9000, 7000 x 20000 -- ran level
         //  with the pair product of the SELL-512 storage or behind it, 0.528 / 0.462 / 0.656 ms against 0.493 / 0.467 / 0.678: few
