@@ -20,6 +20,8 @@ renumbered to their rank in the sorted ghost set (hybrid_ell.inl:132-136);
 sorted by global column and owners hold contiguous column ranges, the ghost
 buffer is the concatenation, in rank order, of what each owner sends.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -97,6 +99,44 @@ class DistSpMat:
         self._strip = (ptr, col, val) if keep_strip else None
         self._ext = None
         # ---- split into local / remote parts (setup; not on the timed path)
+        # On the GPU (round 6): the library's own split (csrc/split.hip, vexhip_csr_split_*: what vexcl/spmat.hpp's set-up calls) -- local
+        # part, remote part as a row-subset CSR with its columns renumbered to their rank in the sorted ghost set, the ghost set itself.
+        # (Until then torch's boolean-mask indexing / unique / bincount did it: correct, several GB of temporaries, and with FOUR
+        # processes sharing one GPU its rocPRIM partition stalled -- tools/r06_n4_probe.py.)
+        if (dev.type == "cuda" and kernels is None and ptr.dtype == torch.int32 and col.dtype == torch.int32
+                and val.dtype in (torch.float64, torch.float32) and os.environ.get("VEXCL_AMD_TORCH_SPLIT") != "1"):
+            self._split_native(ptr, col, val, c0, c1, local_fmt)
+            ghosts = self.ghosts
+        else:
+            ghosts = self._split_torch(ptr, col, val, c0, c1, local_fmt)
+        self._plan_exchange(ghosts, c0, val, dev)
+
+    def _split_native(self, ptr, col, val, c0, c1, local_fmt):
+        import ctypes
+        from . import _capi
+        L = _capi.lib()
+        dev = val.device
+        d = dev.index or 0
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        ptr, col, val = ptr.contiguous(), col.contiguous(), val.contiguous()
+        sizes = (ctypes.c_int64 * 4)()
+        L.csr_split_sizes_i32(d, stream, self.rows, p(ptr), p(col), c0, c1, sizes)
+        nloc, nrem, nrows = int(sizes[0]), int(sizes[1]), int(sizes[2])
+        i32 = dict(dtype=torch.int32, device=dev)
+        lptr = torch.empty(self.rows + 1, **i32); lcol = torch.empty(max(nloc, 1), **i32); lval = torch.empty(max(nloc, 1), dtype=val.dtype, device=dev)
+        rrows = torch.empty(max(nrows, 1), **i32); rptr = torch.empty(nrows + 1, **i32)
+        rcol = torch.empty(max(nrem, 1), **i32); rval = torch.empty(max(nrem, 1), dtype=val.dtype, device=dev); gh = torch.empty(max(nrem, 1), **i32)
+        split = L.csr_split_f64_i32 if val.dtype == torch.float64 else L.csr_split_f32_i32
+        split(d, stream, self.rows, p(ptr), p(col), p(val), c0, c1, sizes, p(lptr), p(lcol), p(lval), p(rrows), p(rptr), p(rcol), p(rval), p(gh))
+        torch.cuda.current_stream(dev).synchronize()
+        nghost = int(sizes[3])
+        self.ghosts = gh[:nghost].to(torch.int64)                  # sorted global ids
+        self.loc = self.k.make_matrix(lptr, lcol[:nloc], lval[:nloc], self.local_cols, local_fmt) if nloc else None
+        self.rem = self.k.make_remote(rrows[:nrows], rptr, rcol[:nrem], rval[:nrem]) if nghost else None
+
+    def _split_torch(self, ptr, col, val, c0, c1, local_fmt):
+        dev = val.device
         is_loc = (col >= c0) & (col < c1)
         rem_mask = ~is_loc
         ghosts = torch.unique(col[rem_mask].to(torch.int64))            # sorted global ids
@@ -126,7 +166,9 @@ class DistSpMat:
         else:
             self.rem = None
         del row_of, is_loc, rem_mask
+        return ghosts
 
+    def _plan_exchange(self, ghosts, c0, val, dev):
         # ---- exchange plan: who needs which of my columns
         self.recv_counts = [0] * self.world         # from each owner, in ghost order
         self.send_counts = [0] * self.world
